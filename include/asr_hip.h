@@ -1,0 +1,188 @@
+/*
+ * asr_hip.h -- C ABI of libasr_hip.so: MI355X (gfx950) kernels for the
+ * BLSTM / VGG-BLSTM -> CTC / attention training + decode hot path of
+ * hirofumi0810/tensorflow_end2end_speech_recognition.
+ *
+ * The reference is 100 % Python over TensorFlow 1.x; it has no FFI of its own.
+ * The boundary below therefore stands in for the TensorFlow op call sites the
+ * hot path dispatches to.  Each entry point cites the
+ * reference call site it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer, including workspaces (no allocation and no
+ *     synchronisation inside a call; everything is enqueued on `stream`);
+ *   - row-major, contiguous unless a leading dimension (ld*) is given;
+ *   - returns 0 on success, a negative asr_status otherwise;
+ *     asr_last_error_string() explains the last failure on that handle;
+ *   - one handle per GPU per process; calls on one handle are not thread-safe.
+ *   - `dtype` selects the MFMA operand type of the matmul-shaped work:
+ *     ASR_F32 = exact fp32 (v_mfma_f32_16x16x4_f32), ASR_BF16 = bf16 operands
+ *     with fp32 accumulation (v_mfma_f32_16x16x32_bf16).  Gate math, cell
+ *     state, CTC recursions, reductions and optimizer state are always fp32.
+ */
+#ifndef ASR_HIP_H_
+#define ASR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct asr_handle asr_handle;
+typedef void* asr_stream; /* hipStream_t */
+
+typedef enum {
+  ASR_OK = 0,
+  ASR_ERR_INVALID_ARG = -1,
+  ASR_ERR_UNSUPPORTED = -2,
+  ASR_ERR_HIP = -3,
+  ASR_ERR_WORKSPACE = -4
+} asr_status;
+
+typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype;
+
+/* tf.train.*Optimizer table of models/model_base.py:12-20 */
+typedef enum {
+  ASR_OPT_SGD = 0, ASR_OPT_MOMENTUM = 1, ASR_OPT_NESTEROV = 2, ASR_OPT_ADAGRAD = 3,
+  ASR_OPT_ADADELTA = 4, ASR_OPT_RMSPROP = 5, ASR_OPT_ADAM = 6
+} asr_optimizer;
+
+/* ---- lifetime ------------------------------------------------------------ */
+int asr_abi_version(void);
+int asr_create(asr_handle** out, int device);
+int asr_destroy(asr_handle* h);
+const char* asr_last_error_string(asr_handle* h);
+/* number of CUs / device name (for bench reporting) */
+int asr_device_info(asr_handle* h, int* num_cu, char* name, int name_len);
+
+/* ---- layout / elementwise ----------------------------------------------- */
+/* [B,T,D] fp32 batch-major -> [T,B,D] time-major in `dtype`
+ * (tf.transpose(inputs,[1,0,2]) at models/encoders/core/blstm.py:277-279). */
+int asr_bt_to_tb(asr_handle* h, int dtype, const float* in_btd, void* out_tbd,
+                 int B, int T, int D, asr_stream s);
+/* fp32 -> dtype cast / dtype -> fp32 of n elements (weight copies for the MFMA path) */
+int asr_cast_from_f32(asr_handle* h, int dtype, const float* in, void* out, size_t n, asr_stream s);
+int asr_cast_to_f32(asr_handle* h, int dtype, const void* in, float* out, size_t n, asr_stream s);
+/* out[i] = in[i] * mask[i] (DropoutWrapper(output_keep_prob), blstm.py:308-311;
+ * mask already holds 0 or 1/keep_prob).  in/out in `dtype`, mask fp32. */
+int asr_apply_mask(asr_handle* h, int dtype, const void* in, const float* mask, void* out,
+                   size_t n, asr_stream s);
+/* Bernoulli(keep_prob)/keep_prob mask from a counter-based generator (seed, offset) */
+int asr_dropout_mask(asr_handle* h, float* mask, size_t n, float keep_prob,
+                     uint64_t seed, uint64_t offset, asr_stream s);
+/* out[N] = sum over rows of a[M,N] (bias gradients); a in `dtype`, out fp32 */
+int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N, int lda,
+               float* out, asr_stream s);
+
+/* ---- GEMM (input projections, output FC, all backward contractions) ------ *
+ * C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ C if accumulate)
+ * transA=0: A is [M,K] with lda; transA=1: A is stored [K,M] with lda.  Same for B.
+ * A, B in `dtype`; C in `out_dtype`; bias fp32 or NULL.
+ * Replaces fully_connected / the [x,h]W product of LSTMBlockCell hoisted over T
+ * (models/ctc/ctc.py:198-233, models/encoders/core/blstm.py:286-320). */
+int asr_gemm(asr_handle* h, int dtype, int out_dtype, int transA, int transB,
+             int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+             void* C, int ldc, const float* bias, int accumulate, asr_stream s);
+
+/* ---- LSTM recurrence ------------------------------------------------------ *
+ * One layer, `ndir` directions (1 = LSTMEncoder, 2 = BLSTMEncoder), all T steps:
+ * tf.contrib.rnn.LSTMBlockCell(forget_bias, clip_cell, use_peephole) under
+ * tf.nn.(bidirectional_)dynamic_rnn(sequence_length) --
+ * models/encoders/core/blstm.py:286-323, lstm.py:253-285.
+ *
+ * Pack the recurrent weights W_h = kernel[Din:Din+H, :] ([H,4H] fp32, ld = 4H,
+ * gate column blocks i, ci, f, o) of one direction into MFMA fragment order.
+ *   fwd pack: B operand of  h[16,H] x W_h[H,4H]
+ *   bwd pack: B operand of dG[16,4H] x W_h^T[4H,H]
+ * Each packed buffer holds H*4H elements of `dtype`. */
+int asr_lstm_pack_wh(asr_handle* h, int dtype, const float* wh, int H,
+                     void* packed_fwd, void* packed_bwd, asr_stream s);
+
+/* Forward.  xproj[T,B,ndir*4H] fp32 = x*W_x + b (from asr_gemm) is overwritten IN
+ * PLACE with the post-activation gates (i, ci, f, o) needed by backward.
+ * wh_packed: ndir fwd-packed buffers back to back.  peep: [ndir][3][H] fp32
+ * (w_i_diag, w_f_diag, w_o_diag) or NULL (use_peephole=False).
+ * hout[T,B,ndir*H] in `dtype`: cell outputs, zero for t >= seq_len[b];
+ * cs[T,B,ndir*H] fp32: cell state per frame (after clipping);
+ * c_final/h_final [ndir][B][H] fp32 (may be NULL): state at the last valid step.
+ * cell_clip <= 0 disables clipping.  B must be a multiple of 16 (pad with
+ * seq_len 0 rows); H a multiple of 16. */
+int asr_lstm_fwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
+                 float* xproj_gates, const void* wh_packed, const float* peep,
+                 const int32_t* seq_len, float forget_bias, float cell_clip,
+                 void* hout, float* cs, float* c_final, float* h_final, asr_stream s);
+
+/* Backward through time.  dhout[T,B,ndir*H] fp32: gradient w.r.t. hout (already
+ * multiplied by the dropout mask if any).  d_c_final/d_h_final [ndir][B][H] or NULL.
+ * gates/cs from forward.  wh_packed_bwd: ndir bwd-packed buffers.
+ * dgates[T,B,ndir*4H] in `dtype`: gradient w.r.t. the pre-activations (zero at
+ * padded frames) -- feeds the dW_x, dW_h, db, dx GEMMs.
+ * dpeep [ndir][3][H] fp32 (may be NULL): peephole gradients (overwritten);
+ * dpeep_workspace: (B/16)*ndir*3*H floats (per batch-tile partials, reduced in a fixed
+ * order so the result is run-to-run deterministic); required iff dpeep != NULL. */
+int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
+                 const float* dhout, const float* gates, const float* cs,
+                 const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,
+                 const float* d_c_final, const float* d_h_final,
+                 void* dgates, float* dpeep, float* dpeep_workspace, asr_stream s);
+
+/* ---- CTC ------------------------------------------------------------------ *
+ * tf.nn.ctc_loss(labels, logits, seq_len, preprocess_collapse_repeated=False,
+ * ctc_merge_repeated=True, time_major=True) -- models/ctc/ctc.py:289-297,
+ * models/attention/joint_ctc_attention.py:308-316.  blank = C-1.
+ * logits[T,B,C] fp32; labels_flat: concatenated label ids (int32), label_offsets[B+1];
+ * loss[B] fp32; grad[T,B,C] fp32 = d loss[b] / d logits * grad_scale (pass 1/B to get the
+ * gradient of the batch mean of ctc.py:298); zero for t >= seq_len[b].
+ * Infeasible utterances give loss 0 and grad 0 (ignore_longer_outputs_than_inputs=True);
+ * their count is written to *num_infeasible (device int32, may be NULL).
+ * workspace: asr_ctc_workspace_bytes(T,B,max label length). */
+size_t asr_ctc_workspace_bytes(int T, int B, int max_label_len);
+int asr_ctc_loss(asr_handle* h, const float* logits, int T, int B, int C,
+                 const int32_t* labels_flat, const int32_t* label_offsets,
+                 const int32_t* seq_len, int max_label_len, float grad_scale,
+                 float* loss, float* grad, int32_t* num_infeasible,
+                 void* workspace, size_t workspace_bytes, asr_stream s);
+
+/* tf.nn.ctc_greedy_decoder(merge_repeated=True) -- models/ctc/ctc.py:341-342 and
+ * models/ctc/decoders/greedy_decoder.py:19-50.  logits[T,B,C]; out_labels[B,T] int32
+ * padded with -1; out_len[B]. */
+int asr_ctc_greedy_decode(asr_handle* h, const float* logits, int T, int B, int C,
+                          const int32_t* seq_len, int blank,
+                          int32_t* out_labels, int32_t* out_len, asr_stream s);
+
+/* row softmax: CTC.posteriors (models/ctc/ctc.py:354-380) */
+int asr_softmax_rows(asr_handle* h, const float* in, float* out, int rows, int C, asr_stream s);
+
+/* ---- gradient clipping + optimizers -------------------------------------- *
+ * Multi-tensor over one flat fp32 parameter buffer; tensor i is
+ * [offsets[i], offsets[i+1]).  tf.clip_by_norm per variable
+ * (models/model_base.py:148-152): g *= clip / max(||g||_2, clip). */
+/* Norms are reduced in fixed 4096-element chunks (deterministic).  asr_clip_plan (host
+ * helper) fills chunk_start_host[num_tensors+1] from HOST offsets; upload it once.
+ * partial_ws: chunk_start[num_tensors] (= total_chunks) floats of device scratch. */
+int asr_clip_plan(asr_handle* h, const int64_t* offsets_host, int num_tensors,
+                  int64_t* chunk_start_host);
+int asr_clip_by_norm_multi(asr_handle* h, float* grads, const int64_t* offsets,
+                           const int64_t* chunk_start, int num_tensors, int64_t total_chunks,
+                           float clip_norm, float* partial_ws, asr_stream s);
+/* weight decay term of ctc.py:280-286: grads += wd * params on tensors with decay_mask[i]!=0;
+ * l2_out (device fp32, may be NULL) receives wd * sum(0.5*||p||^2). */
+int asr_weight_decay(asr_handle* h, float* grads, const float* params, const int64_t* offsets,
+                     const uint8_t* decay_mask, int num_tensors, float wd, float* l2_out,
+                     asr_stream s);
+/* One optimizer step over n fp32 parameters with TF1 default hyper-parameters
+ * (models/model_base.py:68-95).  slot0/slot1: optimizer state
+ * (momentum / accumulators / m,v), `step` = 1-based step count (Adam bias correction). */
+int asr_optimizer_step(asr_handle* h, int optimizer, float* params, const float* grads,
+                       float* slot0, float* slot1, size_t n, float lr, int64_t step,
+                       asr_stream s);
+/* p[i] = (a[i] + b[i]) * scale helpers for the tower mean of utils/training/multi_gpu.py:39-40 */
+int asr_scale(asr_handle* h, float* x, size_t n, float scale, asr_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H_ */

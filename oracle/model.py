@@ -1,0 +1,101 @@
+"""Oracle (test infrastructure, PARITY UNPINNED -- see oracle/__init__.py): the CTC
+model of the reference end to end on the CPU.
+
+Follows models/ctc/ctc.py:175-323: encoder (oracle.lstm) -> reshape [T*B, 2H] ->
+output FC (weights [2H,C], biases) -> logits [T,B,C] -> tf.nn.ctc_loss -> batch mean
+(+ weight_decay * sum l2_loss(non-bias vars), ctc.py:280-286).  Gradients of every
+variable come from torch autograd through the restated forward; the CTC gradient is
+the explicit alpha-beta formula of oracle.ctc plugged in as a custom Function.
+"""
+import numpy as np
+import torch
+
+from . import ctc as octc
+from . import lstm as olstm
+
+
+class _CTCLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels_list, seq_len):
+        loss, grad = octc.ctc_loss_batch(logits.detach().cpu().numpy().astype(np.float64),
+                                         labels_list, seq_len)
+        ctx.save_for_backward(torch.from_numpy(grad).to(logits.dtype))
+        return torch.from_numpy(loss).to(logits.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g.view(1, -1, 1), None, None
+
+
+def ctc_loss(logits_tbc, labels_list, seq_len):
+    return _CTCLossFn.apply(logits_tbc, labels_list, np.asarray(seq_len))
+
+
+def params_from_state_dict(sd, num_layers, ndir=2, dtype=torch.float64, requires_grad=True, prefix=''):
+    """{TF variable name -> array} -> oracle layer dicts.  Names: SURVEY.md Appendix C."""
+    def t(name):
+        v = torch.as_tensor(np.asarray(sd[name].detach().cpu() if torch.is_tensor(sd[name]) else sd[name]),
+                            dtype=dtype).clone()
+        v.requires_grad_(requires_grad)
+        return v
+    layers = []
+    for i in range(1, num_layers + 1):
+        dirs = []
+        for d in (['fw', 'bw'] if ndir == 2 else ['fw']):
+            if ndir == 2:
+                base = '%sblstm_hidden%d/%s/lstm_cell' % (prefix, i, d)
+            else:
+                base = '%smulti_lstm/multi_rnn_cell/cell_%d/lstm_cell' % (prefix, i - 1)
+            p = dict(w=t(base + '/kernel'), b=t(base + '/bias'), _base=base)
+            if base + '/w_i_diag' in sd:
+                p.update(wci=t(base + '/w_i_diag'), wcf=t(base + '/w_f_diag'), wco=t(base + '/w_o_diag'))
+                p['_peep'] = True
+            else:
+                H = p['b'].shape[0] // 4
+                z = torch.zeros(H, dtype=dtype)
+                p.update(wci=z, wcf=z, wco=z)
+                p['_peep'] = False
+            dirs.append(p)
+        layers.append(tuple(dirs) if ndir == 2 else dirs[0])
+    return layers
+
+
+def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, cell_clip=0.0,
+                      weight_decay=0.0, drop_masks=None, dtype=torch.float64, temperature=1.0):
+    """Returns dict(total_loss, ctc_losses [B], logits [T,B,C], grads {name: array})."""
+    layers = params_from_state_dict(sd, num_layers, ndir, dtype)
+    w_out = torch.as_tensor(np.asarray(sd['output/weights'].detach().cpu() if torch.is_tensor(sd['output/weights']) else sd['output/weights']), dtype=dtype).clone().requires_grad_(True)
+    b_out = torch.as_tensor(np.asarray(sd['output/biases'].detach().cpu() if torch.is_tensor(sd['output/biases']) else sd['output/biases']), dtype=dtype).clone().requires_grad_(True)
+    x = torch.as_tensor(np.asarray(inputs_btd), dtype=dtype)
+    sl = torch.as_tensor(np.asarray(seq_len), dtype=torch.long)
+    peep = layers[0][0]['_peep'] if ndir == 2 else layers[0]['_peep']
+    kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=peep)
+    if ndir == 2:
+        enc, final = olstm.blstm_encoder(x, sl, layers, drop_masks, **kw)
+    else:
+        enc, final = olstm.lstm_encoder(x, sl, layers, drop_masks, **kw)
+    T, B, E = enc.shape
+    logits = (enc.reshape(T * B, E) @ w_out + b_out).reshape(T, B, -1)
+    losses = ctc_loss(logits / temperature, labels_list, seq_len)
+    total = losses.mean()
+    named = {}
+    for li, layer in enumerate(layers):
+        for p in (layer if ndir == 2 else (layer,)):
+            base = p['_base']
+            named[base + '/kernel'] = p['w']
+            named[base + '/bias'] = p['b']
+            if p['_peep']:
+                named[base + '/w_i_diag'] = p['wci']
+                named[base + '/w_f_diag'] = p['wcf']
+                named[base + '/w_o_diag'] = p['wco']
+    named['output/weights'] = w_out
+    named['output/biases'] = b_out
+    if weight_decay > 0:
+        l2 = sum(0.5 * (v ** 2).sum() for n, v in named.items() if 'bias' not in n.lower())
+        total = total + weight_decay * l2
+    total.backward()
+    grads = {n: v.grad.detach().numpy().copy() for n, v in named.items()}
+    return dict(total_loss=float(total.detach()), ctc_losses=losses.detach().numpy(),
+                logits=logits.detach().numpy(), grads=grads, enc=enc.detach().numpy(),
+                final=final)

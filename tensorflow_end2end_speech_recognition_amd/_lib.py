@@ -1,0 +1,116 @@
+"""ctypes binding of libasr_hip.so (include/asr_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails this
+module raises.  torch is used only to own device memory / streams.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libasr_hip.so')
+
+ASR_F32, ASR_BF16 = 0, 1
+OPTIMIZER_IDS = {'sgd': 0, 'momentum': 1, 'nestrov': 2, 'adagrad': 3, 'adadelta': 4,
+                 'rmsprop': 5, 'adam': 6}
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_i64, _u64 = C.c_int64, C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/asr_hip.h declaration by declaration
+SIGNATURES = {
+    'asr_abi_version': (_i, []),
+    'asr_create': (_i, [C.POINTER(_vp), _i]),
+    'asr_destroy': (_i, [_vp]),
+    'asr_last_error_string': (C.c_char_p, [_vp]),
+    'asr_device_info': (_i, [_vp, C.POINTER(_i), C.c_char_p, _i]),
+    'asr_bt_to_tb': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'asr_cast_from_f32': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
+    'asr_cast_to_f32': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
+    'asr_apply_mask': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    'asr_dropout_mask': (_i, [_vp, _vp, _sz, _f, _u64, _u64, _vp]),
+    'asr_colsum': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    'asr_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    'asr_lstm_pack_wh': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    'asr_lstm_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'asr_lstm_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                          _vp, _vp]),
+    'asr_ctc_workspace_bytes': (_sz, [_i, _i, _i]),
+    'asr_ctc_loss': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'asr_ctc_greedy_decode': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    'asr_softmax_rows': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'asr_clip_plan': (_i, [_vp, _vp, _i, _vp]),
+    'asr_clip_by_norm_multi': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _f, _vp, _vp]),
+    'asr_weight_decay': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
+    'asr_optimizer_step': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _f, _i64, _vp]),
+    'asr_scale': (_i, [_vp, _vp, _sz, _f, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libasr_hip.so and type every entry point.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libasr_hip.so not found at %s -- build it with '
+            '`python -m tensorflow_end2end_speech_recognition_amd.build` '
+            '(there is no CPU fallback for the HIP path)' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class AsrError(RuntimeError):
+    pass
+
+
+class Handle(object):
+    """One per process per GPU (asr_create/asr_destroy)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.asr_create(C.byref(h), int(device))
+        if rc != 0:
+            raise AsrError('asr_create(device=%d) failed with %d: no usable MI355X/HIP device -- '
+                           'the HIP path has no CPU fallback' % (device, rc))
+        self.h = h
+        self.device = device
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.asr_last_error_string(self.h)
+            msg = msg.decode() if msg else ''
+            if rc == -1:
+                raise ValueError('%s: %s' % (what, msg))
+            raise AsrError('%s failed (%d): %s' % (what, rc, msg))
+
+    def info(self):
+        n = _i(0)
+        buf = C.create_string_buffer(128)
+        self.check(self.lib.asr_device_info(self.h, C.byref(n), buf, 128), 'asr_device_info')
+        return n.value, buf.value.decode()
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self.lib.asr_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+_handles = {}
+
+
+def handle(device=0):
+    if device not in _handles:
+        _handles[device] = Handle(device)
+    return _handles[device]

@@ -1,0 +1,65 @@
+"""Build libasr_hip.so (gfx950) in-tree with hipcc.
+
+    python -m tensorflow_end2end_speech_recognition_amd.build [--force]
+
+Each csrc/*.hip is compiled to an object in parallel and linked into
+tensorflow_end2end_speech_recognition_amd/libasr_hip.so.  hipcc cross-compiles
+without a GPU, so this runs in the build container; the .so travels to the GPU box.
+"""
+import concurrent.futures
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
+LIB = os.path.join(PKG, 'libasr_hip.so')
+ARCH = 'gfx950'
+FLAGS = ['--offload-arch=%s' % ARCH, '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, headers, force):
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+    if force or _stale(obj, [src] + headers):
+        cmd = [_hipcc()] + FLAGS + ['-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (src, r.stderr[-4000:]))
+    return obj
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    headers = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + \
+        sorted(glob.glob(os.path.join(PKG, '..', 'include', '*.h')))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, headers, force), srcs))
+    if force or _stale(LIB, objs):
+        cmd = [_hipcc(), '--offload-arch=%s' % ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s' % r.stderr[-4000:])
+    if verbose:
+        print('built %s (%d objects)' % (LIB, len(objs)))
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

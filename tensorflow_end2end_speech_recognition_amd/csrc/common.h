@@ -1,0 +1,71 @@
+// Shared helpers for the gfx950 kernels of libasr_hip.so.  CDNA4 only: wave = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/asr_hip.h"
+
+struct asr_handle {
+  int device;
+  int num_cu;
+  char name[128];
+  char err[512];
+};
+
+#define ASR_FAIL(h, code, ...)                                  \
+  do {                                                          \
+    if (h) snprintf((h)->err, sizeof((h)->err), __VA_ARGS__);   \
+    return (code);                                              \
+  } while (0)
+
+#define ASR_CHECK_LAUNCH(h, what)                                                   \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) ASR_FAIL(h, ASR_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;  // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;   // MFMA 16x16 C/D fragment
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+  static __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
+};
+
+// Gate nonlinearities.  Precise libm forms (expf/tanhf, <= 1-2 ulp): the fp32 path
+// is the parity path (loss within 1e-4 relative of the oracle).
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int asr_dtype_ok(int dt) { return dt == ASR_F32 || dt == ASR_BF16; }
+static inline size_t asr_dtype_size(int dt) { return dt == ASR_BF16 ? 2 : 4; }

@@ -1,0 +1,393 @@
+// CTC loss (alpha/beta DP + gradient), greedy decode, row softmax for gfx950.
+//
+// Replaces tf.nn.ctc_loss (CPU-only kernel in TF1 -> a device->host->device hop every
+// step in the reference: models/ctc/ctc.py:289-297, joint_ctc_attention.py:308-316),
+// tf.nn.ctc_greedy_decoder (ctc.py:341-342 == models/ctc/decoders/greedy_decoder.py:19-50)
+// and tf.nn.softmax in CTC.posteriors (ctc.py:354-380).  blank = C-1.
+//
+// These are HBM/latency-bound passes over logits[T,B,C]; nothing here is GEMM-shaped:
+//   1. row_lse:      one wave per (t,b) row, ln sum exp           (1 read of logits)
+//   2. alpha_beta:   one workgroup per utterance, 4 waves run the alpha recursion while 4
+//                    run beta; previous row in LDS (double buffered), one barrier per frame,
+//                    the emission ln y_t(l'_s) of the NEXT frame is fetched before the barrier
+//   3. grad:         one wave per (t,b): posterior occupations gamma_t(s) =
+//                    exp(alpha+beta-ln y-ln p) are summed per class in a fixed order
+//                    (blank by a wave tree reduction, labels by rank rounds) so the result
+//                    is deterministic; writes softmax - occupation   (1 read + 1 write)
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr float NEG_INF = -INFINITY;
+
+__device__ __forceinline__ float lse2(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == NEG_INF) return NEG_INF;
+  return m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  const float m = fmaxf(fmaxf(a, b), c);
+  if (m == NEG_INF) return NEG_INF;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// ---- 1. row log-sum-exp ---------------------------------------------------
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ x, int rows, int C,
+                                                      float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = x + (size_t)row * C;
+  float m = NEG_INF;
+  for (int k = lane; k < C; k += 64) m = fmaxf(m, p[k]);
+  m = wave_reduce_max(m);
+  float s = 0.f;
+  for (int k = lane; k < C; k += 64) s += expf(p[k] - m);
+  s = wave_reduce_sum(s);
+  if (lane == 0) lse[row] = m + logf(s);
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = x + (size_t)row * C;
+  float m = NEG_INF;
+  for (int k = lane; k < C; k += 64) m = fmaxf(m, p[k]);
+  m = wave_reduce_max(m);
+  float s = 0.f;
+  for (int k = lane; k < C; k += 64) s += expf(p[k] - m);
+  s = wave_reduce_sum(s);
+  const float inv = 1.f / s;
+  for (int k = lane; k < C; k += 64) y[(size_t)row * C + k] = expf(p[k] - m) * inv;
+}
+
+// ---- 2. alpha / beta recursions --------------------------------------------
+// workspace per utterance: alpha[T][SW], beta[T][SW] (SW = 2*Lmax+1), rank[Lmax], ll
+constexpr int AB_THREADS = 512;  // waves 0-3 alpha, 4-7 beta
+constexpr int AB_HALF = 256;
+constexpr int MAX_NS = 8;        // S <= 2048
+
+__global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
+    const float* __restrict__ logits, const float* __restrict__ lse, int T, int B, int C,
+    const int32_t* __restrict__ labels_flat, const int32_t* __restrict__ label_offsets,
+    const int32_t* __restrict__ seq_len, int SW, float* __restrict__ alpha_ws,
+    float* __restrict__ beta_ws, int32_t* __restrict__ rank_ws, float* __restrict__ ll_ws,
+    float* __restrict__ loss, int32_t* __restrict__ num_infeasible) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rowbuf = reinterpret_cast<float*>(smem);  // [2 (alpha/beta)][2 (ping/pong)][SW]
+  const int b = blockIdx.x;
+  const int blank = C - 1;
+  const int lo = label_offsets[b];
+  const int L = label_offsets[b + 1] - lo;
+  const int S = 2 * L + 1;
+  const int Tb = min(seq_len[b], T);
+  const int half = threadIdx.x / AB_HALF;  // 0 alpha, 1 beta
+  const int tid = threadIdx.x % AB_HALF;
+  const int32_t* lab = labels_flat + lo;
+  float* ws = (half == 0 ? alpha_ws : beta_ws) + (size_t)b * T * SW;
+  float* buf = rowbuf + half * 2 * SW;
+
+  // rank of each label among equal earlier labels (fixed summation order in the grad kernel)
+  for (int i = threadIdx.x; i < L; i += AB_THREADS) {
+    const int li = lab[i];
+    int r = 0;
+    for (int k = 0; k < i; ++k) r += (lab[k] == li);
+    rank_ws[(size_t)b * ((SW - 1) / 2) + i] = r;
+  }
+  if (Tb <= 0 || L > (SW - 1) / 2) {
+    if (threadIdx.x == 0) {
+      loss[b] = 0.f;
+      ll_ws[b] = NEG_INF;
+      if (num_infeasible && Tb > 0) atomicAdd(num_infeasible, 1);
+    }
+    return;
+  }
+
+  // per-thread extended-label info for s = tid + n*256
+  int ext[MAX_NS];
+  bool skp[MAX_NS];  // alpha: may come from s-2 ; beta: may go to s+2
+#pragma unroll
+  for (int n = 0; n < MAX_NS; ++n) {
+    const int s = tid + n * AB_HALF;
+    ext[n] = blank; skp[n] = false;
+    if (s < S) {
+      ext[n] = (s & 1) ? lab[s >> 1] : blank;
+      if (half == 0) skp[n] = (s & 1) && s >= 2 && lab[s >> 1] != lab[(s >> 1) - 1];
+      else skp[n] = (s & 1) && s + 2 < S && lab[s >> 1] != lab[(s >> 1) + 1];
+    }
+  }
+  const int t0 = half == 0 ? 0 : Tb - 1;
+  const int dt = half == 0 ? 1 : -1;
+  // emissions of the first frame
+  float lp[MAX_NS];
+  {
+    const float* row = logits + ((size_t)t0 * B + b) * C;
+    const float z = lse[(size_t)t0 * B + b];
+#pragma unroll
+    for (int n = 0; n < MAX_NS; ++n) {
+      const int s = tid + n * AB_HALF;
+      lp[n] = (s < S) ? row[ext[n]] - z : NEG_INF;
+    }
+  }
+  // init row
+#pragma unroll
+  for (int n = 0; n < MAX_NS; ++n) {
+    const int s = tid + n * AB_HALF;
+    if (s < S) {
+      float v = NEG_INF;
+      if (half == 0) { if (s <= 1) v = lp[n]; }
+      else { if (s >= S - 2) v = lp[n]; }
+      buf[s] = v;
+      ws[(size_t)t0 * SW + s] = v;
+    }
+  }
+  __syncthreads();
+  for (int step = 1; step < Tb; ++step) {
+    const int t = t0 + dt * step;
+    const float* prev = buf + ((step - 1) & 1) * SW;
+    float* cur = buf + (step & 1) * SW;
+    {
+      const float* row = logits + ((size_t)t * B + b) * C;
+      const float z = lse[(size_t)t * B + b];
+#pragma unroll
+      for (int n = 0; n < MAX_NS; ++n) {
+        const int s = tid + n * AB_HALF;
+        if (s < S) lp[n] = row[ext[n]] - z;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < MAX_NS; ++n) {
+      const int s = tid + n * AB_HALF;
+      if (s < S) {
+        float a0 = prev[s], a1, a2;
+        if (half == 0) {
+          a1 = s >= 1 ? prev[s - 1] : NEG_INF;
+          a2 = skp[n] ? prev[s - 2] : NEG_INF;
+        } else {
+          a1 = s + 1 < S ? prev[s + 1] : NEG_INF;
+          a2 = skp[n] ? prev[s + 2] : NEG_INF;
+        }
+        const float v = lse3(a0, a1, a2) + lp[n];
+        cur[s] = v;
+        ws[(size_t)t * SW + s] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {  // alpha half, thread 0
+    const float* last = buf + ((Tb - 1) & 1) * SW;
+    const float ll = lse2(last[S - 1], S >= 2 ? last[S - 2] : NEG_INF);
+    const bool ok = ll > NEG_INF;
+    loss[b] = ok ? -ll : 0.f;
+    ll_ws[b] = ok ? ll : NEG_INF;
+    if (!ok && num_infeasible) atomicAdd(num_infeasible, 1);
+  }
+}
+
+// ---- 3. gradient -------------------------------------------------------------
+__global__ __launch_bounds__(256) void ctc_grad_kernel(
+    const float* __restrict__ logits, const float* __restrict__ lse, int T, int B, int C,
+    const int32_t* __restrict__ labels_flat, const int32_t* __restrict__ label_offsets,
+    const int32_t* __restrict__ seq_len, int SW, const float* __restrict__ alpha_ws,
+    const float* __restrict__ beta_ws, const int32_t* __restrict__ rank_ws,
+    const float* __restrict__ ll_ws, float grad_scale, float* __restrict__ grad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* acc = reinterpret_cast<float*>(smem) + (size_t)wave * (C + SW);  // [C] occupation per class
+  float* gam = acc + C;                                                    // [SW]
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= T) return;
+  float* g = grad + ((size_t)t * B + b) * C;
+  const int Tb = min(seq_len[b], T);
+  const float ll = ll_ws[b];
+  if (t >= Tb || !(ll > NEG_INF)) {
+    for (int k = lane; k < C; k += 64) g[k] = 0.f;
+    return;
+  }
+  const int lo = label_offsets[b];
+  const int L = label_offsets[b + 1] - lo;
+  const int S = 2 * L + 1;
+  const int blank = C - 1;
+  const int32_t* lab = labels_flat + lo;
+  const float* row = logits + ((size_t)t * B + b) * C;
+  const float z = lse[(size_t)t * B + b];
+  const float* al = alpha_ws + ((size_t)b * T + t) * SW;
+  const float* be = beta_ws + ((size_t)b * T + t) * SW;
+
+  for (int k = lane; k < C; k += 64) acc[k] = 0.f;
+  float blank_sum = 0.f;
+  int maxrank = 0;
+  for (int s = lane; s < S; s += 64) {
+    const int e = (s & 1) ? lab[s >> 1] : blank;
+    const float lpv = row[e] - z;
+    const float v = al[s] + be[s] - lpv - ll;   // ln gamma_t(s); -inf/NaN-safe below
+    const float gm = (al[s] > NEG_INF && be[s] > NEG_INF) ? expf(v) : 0.f;
+    gam[s] = gm;
+    if (!(s & 1)) blank_sum += gm;
+    else maxrank = max(maxrank, rank_ws[(size_t)b * ((SW - 1) / 2) + (s >> 1)]);
+  }
+  blank_sum = wave_reduce_sum(blank_sum);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxrank = max(maxrank, __shfl_xor(maxrank, o, 64));
+  // labels: round r adds the r-th occurrence of every class -> no two lanes touch one class
+  for (int r = 0; r <= maxrank; ++r) {
+    for (int i = lane; i < L; i += 64) {
+      if (rank_ws[(size_t)b * ((SW - 1) / 2) + i] == r) acc[lab[i]] += gam[2 * i + 1];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int k = lane; k < C; k += 64) {
+    const float occ = (k == blank) ? (acc[k] + blank_sum) : acc[k];
+    g[k] = (expf(row[k] - z) - occ) * grad_scale;
+  }
+}
+
+// ---- greedy decode -------------------------------------------------------------
+__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ logits, int T,
+                                                         int B, int C,
+                                                         const int32_t* __restrict__ seq_len,
+                                                         int blank, int32_t* __restrict__ out_labels,
+                                                         int32_t* __restrict__ out_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* am = reinterpret_cast<int32_t*>(smem);  // [T] per-frame argmax
+  __shared__ int32_t wsum[4];
+  __shared__ int32_t carry;
+  const int b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Tb = min(max(seq_len[b], 0), T);
+  for (int t = wave; t < Tb; t += 4) {
+    const float* row = logits + ((size_t)t * B + b) * C;
+    float best = NEG_INF;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < C; k += 64) {
+      const float v = row[k];
+      if (v > best || (v == best && k < bi)) { best = v; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) am[t] = (bi == 0x7fffffff) ? 0 : bi;
+  }
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  // ordered compaction, 256 frames per pass
+  for (int base = 0; base < Tb; base += 256) {
+    const int t = base + threadIdx.x;
+    int keep = 0, a = 0;
+    if (t < Tb) {
+      a = am[t];
+      keep = (a != blank) && (t == 0 || a != am[t - 1]);
+    }
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (keep) out_labels[(size_t)b * T + off + before] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  const int n = carry;
+  for (int i = n + threadIdx.x; i < T; i += 256) out_labels[(size_t)b * T + i] = -1;
+  if (threadIdx.x == 0) out_len[b] = n;
+}
+
+struct CtcWs {
+  size_t lse, alpha, beta, rank, ll, total;
+};
+inline CtcWs ctc_ws_layout(int T, int B, int Lmax) {
+  const size_t SW = 2 * (size_t)Lmax + 1;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  CtcWs w;
+  size_t o = 0;
+  w.lse = o;   o += al((size_t)T * B * 4);
+  w.alpha = o; o += al((size_t)B * T * SW * 4);
+  w.beta = o;  o += al((size_t)B * T * SW * 4);
+  w.rank = o;  o += al((size_t)B * (Lmax > 0 ? Lmax : 1) * 4);
+  w.ll = o;    o += al((size_t)B * 4);
+  w.total = o;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t asr_ctc_workspace_bytes(int T, int B, int max_label_len) {
+  if (T < 0 || B < 0 || max_label_len < 0) return 0;
+  return ctc_ws_layout(T, B, max_label_len).total;
+}
+
+extern "C" int asr_ctc_loss(asr_handle* h, const float* logits, int T, int B, int C,
+                            const int32_t* labels_flat, const int32_t* label_offsets,
+                            const int32_t* seq_len, int max_label_len, float grad_scale, float* loss,
+                            float* grad, int32_t* num_infeasible, void* workspace,
+                            size_t workspace_bytes, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!logits || !label_offsets || !seq_len || !loss || T <= 0 || B <= 0 || C < 2 ||
+      max_label_len < 0 || (max_label_len > 0 && !labels_flat))
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_ctc_loss: bad args T=%d B=%d C=%d Lmax=%d", T, B, C, max_label_len);
+  const int SW = 2 * max_label_len + 1;
+  if (SW > MAX_NS * AB_HALF)
+    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_loss: label length %d > %d", max_label_len, (MAX_NS * AB_HALF - 1) / 2);
+  const CtcWs w = ctc_ws_layout(T, B, max_label_len);
+  if (!workspace || workspace_bytes < w.total)
+    ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_ctc_loss: workspace %zu < %zu bytes", workspace_bytes, w.total);
+  char* ws = (char*)workspace;
+  float* lse = (float*)(ws + w.lse);
+  float* alpha = (float*)(ws + w.alpha);
+  float* beta = (float*)(ws + w.beta);
+  int32_t* rank = (int32_t*)(ws + w.rank);
+  float* ll = (float*)(ws + w.ll);
+  hipStream_t st = (hipStream_t)s;
+  if (num_infeasible) (void)hipMemsetAsync(num_infeasible, 0, sizeof(int32_t), st);
+  const int rows = T * B;
+  hipLaunchKernelGGL(row_lse_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, rows, C, lse);
+  ASR_CHECK_LAUNCH(h, "asr_ctc_loss(row_lse)");
+  const size_t lds_ab = (size_t)4 * SW * sizeof(float);
+  hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3(B), dim3(AB_THREADS), lds_ab, st, logits, lse, T, B, C,
+                     labels_flat, label_offsets, seq_len, SW, alpha, beta, rank, ll, loss, num_infeasible);
+  ASR_CHECK_LAUNCH(h, "asr_ctc_loss(alpha_beta)");
+  if (grad) {
+    const size_t lds_g = (size_t)4 * (C + SW) * sizeof(float);
+    if (lds_g > 160 * 1024)
+      ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_loss: C=%d, Lmax=%d need %zu B of LDS", C, max_label_len, lds_g);
+    (void)hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g);
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3((T + 3) / 4, B), dim3(256), lds_g, st, logits, lse, T, B, C,
+                       labels_flat, label_offsets, seq_len, SW, alpha, beta, rank, ll, grad_scale, grad);
+    ASR_CHECK_LAUNCH(h, "asr_ctc_loss(grad)");
+  }
+  return ASR_OK;
+}
+
+extern "C" int asr_ctc_greedy_decode(asr_handle* h, const float* logits, int T, int B, int C,
+                                     const int32_t* seq_len, int blank, int32_t* out_labels,
+                                     int32_t* out_len, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!logits || !seq_len || !out_labels || !out_len || T <= 0 || B <= 0 || C < 1)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_ctc_greedy_decode: bad args T=%d B=%d C=%d", T, B, C);
+  const size_t lds = (size_t)T * sizeof(int32_t);
+  if (lds > 150 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_greedy_decode: T=%d too long", T);
+  (void)hipFuncSetAttribute((const void*)ctc_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, logits, T, B, C, seq_len,
+                     blank, out_labels, out_len);
+  ASR_CHECK_LAUNCH(h, "asr_ctc_greedy_decode");
+  return ASR_OK;
+}
+
+extern "C" int asr_softmax_rows(asr_handle* h, const float* in, float* out, int rows, int C,
+                                asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!in || !out || rows < 0 || C < 1) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_softmax_rows: bad args");
+  if (rows == 0) return ASR_OK;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, in, out, rows, C);
+  ASR_CHECK_LAUNCH(h, "asr_softmax_rows");
+  return ASR_OK;
+}

@@ -1,0 +1,390 @@
+// Handle lifetime + the HBM-bound elementwise passes of the training step:
+// layout change, casts, dropout masks, bias (column) sums, per-variable clip_by_norm,
+// weight decay and the seven TF1 optimizers of models/model_base.py:12-20.
+// All are grid-stride, 16 B per lane where the layout allows (cdna guide G13).
+#include "common.h"
+#include <math.h>
+
+extern "C" int asr_abi_version(void) { return 1; }
+
+extern "C" int asr_create(asr_handle** out, int device) {
+  if (!out) return ASR_ERR_INVALID_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return ASR_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return ASR_ERR_HIP;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) return ASR_ERR_HIP;
+  asr_handle* h = new asr_handle();
+  h->device = device;
+  h->num_cu = p.multiProcessorCount;
+  snprintf(h->name, sizeof(h->name), "%s (%s)", p.name, p.gcnArchName);
+  h->err[0] = 0;
+  *out = h;
+  return ASR_OK;
+}
+extern "C" int asr_destroy(asr_handle* h) {
+  delete h;
+  return ASR_OK;
+}
+extern "C" const char* asr_last_error_string(asr_handle* h) { return h ? h->err : "null handle"; }
+extern "C" int asr_device_info(asr_handle* h, int* num_cu, char* name, int name_len) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (num_cu) *num_cu = h->num_cu;
+  if (name && name_len > 0) snprintf(name, name_len, "%s", h->name);
+  return ASR_OK;
+}
+
+namespace {
+
+inline int grid_for(size_t n, int per_thread = 1) {
+  size_t blocks = (n + 256 * (size_t)per_thread - 1) / (256 * (size_t)per_thread);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  return (int)blocks;
+}
+
+// [B,T,D] -> [T,B,D]: one row of D per wave-slice, rows of the OUTPUT enumerated in order
+template <typename T>
+__global__ void bt_to_tb_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int T_, int D) {
+  const size_t total = (size_t)B * T_ * D;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int dd = i % D;
+    const size_t r = i / D;
+    const int b = r % B;
+    const size_t t = r / B;
+    out[i] = Elem<T>::from_f32(in[((size_t)b * T_ + t) * D + dd]);
+  }
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = Elem<T>::from_f32(in[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = Elem<T>::to_f32(in[i]);
+}
+template <typename T>
+__global__ void apply_mask_kernel(const T* __restrict__ in, const float* __restrict__ mask,
+                                  T* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = Elem<T>::from_f32(Elem<T>::to_f32(in[i]) * mask[i]);
+}
+
+// Philox4x32-10 (Salmon et al. 2011): counter-based, one call gives 4 uniforms
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float keep, uint64_t seed,
+                                    uint64_t offset) {
+  const float inv = 1.f / keep;
+  const size_t n4 = (n + 3) / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t ctr = offset + i;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t e = i * 4 + j;
+      if (e < n) {
+        const float u = (c[j] >> 8) * (1.0f / 16777216.0f);  // [0,1)
+        mask[e] = (u < keep) ? inv : 0.f;
+      }
+    }
+  }
+}
+
+// column sums: block (64 cols x 4 row-groups); fixed order -> deterministic
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, int M, int N, int lda,
+                                                     float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rgp = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < N)
+    for (int m = rgp; m < M; m += 4) s += Elem<T>::to_f32(a[(size_t)m * lda + col]);
+  part[rgp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rgp == 0 && col < N) out[col] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+// ---- per-tensor L2 norms (two-stage, deterministic) + clip ----
+constexpr int NORM_CHUNK = 4096;  // elements per partial
+__global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restrict__ g,
+                                                            const int64_t* __restrict__ offsets,
+                                                            const int64_t* __restrict__ chunk_start,
+                                                            int num_tensors, float* __restrict__ partial) {
+  // blockIdx.x = global chunk id; find its tensor by binary search on chunk_start
+  __shared__ float red[4];
+  const int64_t cid = blockIdx.x;
+  int lo = 0, hi = num_tensors - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (chunk_start[mid] <= cid) lo = mid; else hi = mid - 1;
+  }
+  const int64_t beg = offsets[lo] + (cid - chunk_start[lo]) * NORM_CHUNK;
+  const int64_t end = min(beg + (int64_t)NORM_CHUNK, offsets[lo + 1]);
+  float s = 0.f;
+  for (int64_t i = beg + threadIdx.x; i < end; i += 256) { const float v = g[i]; s += v * v; }
+  s = wave_reduce_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[cid] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void clip_scale_kernel(float* __restrict__ g, const int64_t* __restrict__ offsets,
+                                  const int64_t* __restrict__ chunk_start, int num_tensors,
+                                  const float* __restrict__ partial, float clip) {
+  const int64_t cid = blockIdx.x;
+  int lo = 0, hi = num_tensors - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (chunk_start[mid] <= cid) lo = mid; else hi = mid - 1;
+  }
+  // every block of a tensor recomputes the same ordered sum of that tensor's partials
+  float ss = 0.f;
+  for (int64_t c = chunk_start[lo]; c < chunk_start[lo + 1]; ++c) ss += partial[c];
+  const float norm = sqrtf(ss);
+  const float scale = clip / fmaxf(norm, clip);  // tf.clip_by_norm: t * clip / max(||t||, clip)
+  if (scale == 1.f) return;
+  const int64_t beg = offsets[lo] + (cid - chunk_start[lo]) * NORM_CHUNK;
+  const int64_t end = min(beg + (int64_t)NORM_CHUNK, offsets[lo + 1]);
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) g[i] *= scale;
+}
+
+__global__ void weight_decay_kernel(float* __restrict__ g, const float* __restrict__ p,
+                                    const int64_t* __restrict__ offsets,
+                                    const uint8_t* __restrict__ decay_mask, int num_tensors, float wd) {
+  const int t = blockIdx.y;
+  if (!decay_mask[t]) return;
+  const int64_t beg = offsets[t], end = offsets[t + 1];
+  for (int64_t i = beg + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < end;
+       i += (int64_t)gridDim.x * blockDim.x)
+    g[i] += wd * p[i];
+}
+__global__ __launch_bounds__(256) void l2_loss_kernel(const float* __restrict__ p,
+                                                      const int64_t* __restrict__ offsets,
+                                                      const uint8_t* __restrict__ decay_mask,
+                                                      int num_tensors, float wd, float* __restrict__ out) {
+  // single block, fixed order: sum_t mask_t * 0.5*||p_t||^2 * wd
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int t = 0; t < num_tensors; ++t) {
+    if (!decay_mask[t]) continue;
+    for (int64_t i = offsets[t] + threadIdx.x; i < offsets[t + 1]; i += 256) { const float v = p[i]; s += v * v; }
+  }
+  s = wave_reduce_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = 0.5f * wd * (red[0] + red[1] + red[2] + red[3]);
+}
+
+// TF1 optimizer update rules with default hyper-parameters
+template <int OPT>
+__global__ void optimizer_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                 float* __restrict__ s0, float* __restrict__ s1, size_t n, float lr,
+                                 float adam_lr_t) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i];
+    if (OPT == ASR_OPT_SGD) {
+      pi -= lr * gi;
+    } else if (OPT == ASR_OPT_MOMENTUM) {
+      const float a = 0.9f * s0[i] + gi;
+      s0[i] = a;
+      pi -= lr * a;
+    } else if (OPT == ASR_OPT_NESTEROV) {
+      const float a = 0.9f * s0[i] + gi;
+      s0[i] = a;
+      pi -= lr * gi + lr * 0.9f * a;
+    } else if (OPT == ASR_OPT_ADAGRAD) {
+      const float a = s0[i] + gi * gi;  // slot initialised to 0.1 by the host
+      s0[i] = a;
+      pi -= lr * gi / sqrtf(a);
+    } else if (OPT == ASR_OPT_ADADELTA) {
+      const float rho = 0.95f, eps = 1e-8f;
+      const float a = rho * s0[i] + (1.f - rho) * gi * gi;
+      const float upd = sqrtf(s1[i] + eps) / sqrtf(a + eps) * gi;
+      s0[i] = a;
+      s1[i] = rho * s1[i] + (1.f - rho) * upd * upd;
+      pi -= lr * upd;
+    } else if (OPT == ASR_OPT_RMSPROP) {
+      const float decay = 0.9f, eps = 1e-10f;
+      const float ms = decay * s0[i] + (1.f - decay) * gi * gi;  // slot initialised to 1 by the host
+      s0[i] = ms;
+      const float mom = 0.f * s1[i] + lr * gi / sqrtf(ms + eps);
+      s1[i] = mom;
+      pi -= mom;
+    } else if (OPT == ASR_OPT_ADAM) {
+      const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+      const float m = b1 * s0[i] + (1.f - b1) * gi;
+      const float v = b2 * s1[i] + (1.f - b2) * gi * gi;
+      s0[i] = m; s1[i] = v;
+      pi -= adam_lr_t * m / (sqrtf(v) + eps);
+    }
+    p[i] = pi;
+  }
+}
+
+__global__ void scale_kernel(float* __restrict__ x, size_t n, float sc) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    x[i] *= sc;
+}
+
+}  // namespace
+
+#define ASR_NEED(cond, ...) do { if (!(cond)) ASR_FAIL(h, ASR_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
+
+extern "C" int asr_bt_to_tb(asr_handle* h, int dtype, const float* in, void* out, int B, int T, int D,
+                            asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(asr_dtype_ok(dtype) && in && out && B >= 0 && T >= 0 && D >= 0, "asr_bt_to_tb: bad args");
+  const size_t n = (size_t)B * T * D;
+  if (!n) return ASR_OK;
+  if (dtype == ASR_F32) hipLaunchKernelGGL(bt_to_tb_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, in, (float*)out, B, T, D);
+  else hipLaunchKernelGGL(bt_to_tb_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, in, (bf16_t*)out, B, T, D);
+  ASR_CHECK_LAUNCH(h, "asr_bt_to_tb");
+  return ASR_OK;
+}
+extern "C" int asr_cast_from_f32(asr_handle* h, int dtype, const float* in, void* out, size_t n, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(asr_dtype_ok(dtype) && in && out, "asr_cast_from_f32: bad args");
+  if (!n) return ASR_OK;
+  if (dtype == ASR_F32) hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, in, (float*)out, n);
+  else hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, in, (bf16_t*)out, n);
+  ASR_CHECK_LAUNCH(h, "asr_cast_from_f32");
+  return ASR_OK;
+}
+extern "C" int asr_cast_to_f32(asr_handle* h, int dtype, const void* in, float* out, size_t n, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(asr_dtype_ok(dtype) && in && out, "asr_cast_to_f32: bad args");
+  if (!n) return ASR_OK;
+  if (dtype == ASR_F32) hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, (const float*)in, out, n);
+  else hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, out, n);
+  ASR_CHECK_LAUNCH(h, "asr_cast_to_f32");
+  return ASR_OK;
+}
+extern "C" int asr_apply_mask(asr_handle* h, int dtype, const void* in, const float* mask, void* out, size_t n, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(asr_dtype_ok(dtype) && in && mask && out, "asr_apply_mask: bad args");
+  if (!n) return ASR_OK;
+  if (dtype == ASR_F32) hipLaunchKernelGGL(apply_mask_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, (const float*)in, mask, (float*)out, n);
+  else hipLaunchKernelGGL(apply_mask_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, mask, (bf16_t*)out, n);
+  ASR_CHECK_LAUNCH(h, "asr_apply_mask");
+  return ASR_OK;
+}
+extern "C" int asr_dropout_mask(asr_handle* h, float* mask, size_t n, float keep_prob, uint64_t seed, uint64_t offset, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(mask && keep_prob > 0.f && keep_prob <= 1.f, "asr_dropout_mask: keep_prob must be in (0,1]");
+  if (!n) return ASR_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)s, mask, n, keep_prob, seed, offset);
+  ASR_CHECK_LAUNCH(h, "asr_dropout_mask");
+  return ASR_OK;
+}
+extern "C" int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N, int lda, float* out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(asr_dtype_ok(dtype) && a && out && M >= 0 && N > 0 && lda >= N, "asr_colsum: bad args");
+  if (dtype == ASR_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)s, (const float*)a, M, N, lda, out);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, M, N, lda, out);
+  ASR_CHECK_LAUNCH(h, "asr_colsum");
+  return ASR_OK;
+}
+
+extern "C" int asr_clip_plan(asr_handle* h, const int64_t* offsets_host, int num_tensors,
+                             int64_t* chunk_start_host) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(offsets_host && chunk_start_host && num_tensors >= 0, "asr_clip_plan: bad args");
+  int64_t c = 0;
+  for (int t = 0; t < num_tensors; ++t) {
+    chunk_start_host[t] = c;
+    c += (offsets_host[t + 1] - offsets_host[t] + NORM_CHUNK - 1) / NORM_CHUNK;
+  }
+  chunk_start_host[num_tensors] = c;
+  return ASR_OK;
+}
+extern "C" int asr_clip_by_norm_multi(asr_handle* h, float* grads, const int64_t* offsets,
+                                      const int64_t* chunk_start, int num_tensors, int64_t total_chunks,
+                                      float clip_norm, float* partial_ws, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(grads && offsets && chunk_start && partial_ws && num_tensors >= 0 && clip_norm > 0.f,
+           "asr_clip_by_norm_multi: bad args (clip_norm must be > 0)");
+  if (num_tensors == 0 || total_chunks == 0) return ASR_OK;
+  hipLaunchKernelGGL(sqsum_partial_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)s, grads,
+                     offsets, chunk_start, num_tensors, partial_ws);
+  ASR_CHECK_LAUNCH(h, "asr_clip_by_norm_multi(sqsum)");
+  hipLaunchKernelGGL(clip_scale_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)s, grads,
+                     offsets, chunk_start, num_tensors, partial_ws, clip_norm);
+  ASR_CHECK_LAUNCH(h, "asr_clip_by_norm_multi(scale)");
+  return ASR_OK;
+}
+extern "C" int asr_weight_decay(asr_handle* h, float* grads, const float* params, const int64_t* offsets,
+                                const uint8_t* decay_mask, int num_tensors, float wd, float* l2_out,
+                                asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(params && offsets && decay_mask && num_tensors >= 0 && wd >= 0.f, "asr_weight_decay: bad args");
+  if (num_tensors == 0) return ASR_OK;
+  if (grads) {
+    hipLaunchKernelGGL(weight_decay_kernel, dim3(64, num_tensors), dim3(256), 0, (hipStream_t)s, grads, params,
+                       offsets, decay_mask, num_tensors, wd);
+    ASR_CHECK_LAUNCH(h, "asr_weight_decay");
+  }
+  if (l2_out) {
+    hipLaunchKernelGGL(l2_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, params, offsets, decay_mask,
+                       num_tensors, wd, l2_out);
+    ASR_CHECK_LAUNCH(h, "asr_weight_decay(l2)");
+  }
+  return ASR_OK;
+}
+extern "C" int asr_optimizer_step(asr_handle* h, int optimizer, float* params, const float* grads,
+                                  float* slot0, float* slot1, size_t n, float lr, int64_t step,
+                                  asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(params && grads, "asr_optimizer_step: null params/grads");
+  if (!n) return ASR_OK;
+  const int needs0 = optimizer != ASR_OPT_SGD;
+  const int needs1 = optimizer == ASR_OPT_ADADELTA || optimizer == ASR_OPT_RMSPROP || optimizer == ASR_OPT_ADAM;
+  ASR_NEED(!needs0 || slot0, "asr_optimizer_step: optimizer %d needs slot0", optimizer);
+  ASR_NEED(!needs1 || slot1, "asr_optimizer_step: optimizer %d needs slot1", optimizer);
+  float adam_lr_t = lr;
+  if (optimizer == ASR_OPT_ADAM) {
+    ASR_NEED(step >= 1, "asr_optimizer_step: adam needs step >= 1");
+    adam_lr_t = (float)(lr * sqrt(1.0 - pow(0.999, (double)step)) / (1.0 - pow(0.9, (double)step)));
+  }
+  const dim3 g(grid_for(n)), b(256);
+  hipStream_t st = (hipStream_t)s;
+  switch (optimizer) {
+#define ASR_OPT_CASE(O) case O: hipLaunchKernelGGL(optimizer_kernel<O>, g, b, 0, st, params, grads, slot0, slot1, n, lr, adam_lr_t); break
+    ASR_OPT_CASE(ASR_OPT_SGD);
+    ASR_OPT_CASE(ASR_OPT_MOMENTUM);
+    ASR_OPT_CASE(ASR_OPT_NESTEROV);
+    ASR_OPT_CASE(ASR_OPT_ADAGRAD);
+    ASR_OPT_CASE(ASR_OPT_ADADELTA);
+    ASR_OPT_CASE(ASR_OPT_RMSPROP);
+    ASR_OPT_CASE(ASR_OPT_ADAM);
+#undef ASR_OPT_CASE
+    default: ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_optimizer_step: unknown optimizer %d", optimizer);
+  }
+  ASR_CHECK_LAUNCH(h, "asr_optimizer_step");
+  return ASR_OK;
+}
+extern "C" int asr_scale(asr_handle* h, float* x, size_t n, float scale, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(x, "asr_scale: null");
+  if (!n) return ASR_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, x, n, scale);
+  ASR_CHECK_LAUNCH(h, "asr_scale");
+  return ASR_OK;
+}

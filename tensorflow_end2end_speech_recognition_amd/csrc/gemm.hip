@@ -1,0 +1,255 @@
+// LDS-tiled MFMA GEMM for gfx950:  C[M,N] = op(A) * op(B) (+bias) (+C).
+//   fp32 operands -> v_mfma_f32_16x16x4_f32   (exact fp32, the parity path)
+//   bf16 operands -> v_mfma_f32_16x16x32_bf16 (fp32 accumulate)
+// Used for every contraction that is not on the serial recurrence: the LSTM input
+// projections x*W_x hoisted over all T (models/encoders/core/blstm.py:286-320), the
+// bottleneck/output FC (models/ctc/ctc.py:198-233) and all dW / dX products of backward.
+//
+// Tile BM x BN x 128 bytes-of-K, 256 threads = 4 waves in a 2x2 grid, each wave owns a
+// (BM/2)x(BN/2) block of 16x16 MFMA tiles.  Both operands are staged K-contiguous in
+// LDS (As[m][k], Bs[n][k], row padded by 16 B so the 16 rows of a fragment read hit
+// distinct banks); global loads are 16 B per lane along whichever dimension is
+// contiguous in memory, register-staged so the next tile's loads fly during the MFMAs.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct GT;
+template <> struct GT<float> {
+  static constexpr int BK = 32;   // 128 B of K per row
+  static constexpr int VEC = 4;   // elements per 16 B
+};
+template <> struct GT<bf16_t> {
+  static constexpr int BK = 64;
+  static constexpr int VEC = 8;
+};
+
+template <typename T> struct Vec16 { T v[GT<T>::VEC]; } __attribute__((aligned(16)));
+
+template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+template <typename TO> __device__ __forceinline__ float load_out(const TO* p);
+template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+
+// Stage one operand tile [ROWS x BK] (logical: row r, reduction index k) into registers.
+// KCONT: memory is k-contiguous (elem(r,k) = p[r*ld + k]); else r-contiguous (p[k*ld + r]).
+template <typename T, int ROWS, bool KCONT>
+struct TileLoader {
+  static constexpr int BK = GT<T>::BK, VEC = GT<T>::VEC;
+  static constexpr int NVEC = ROWS * BK / VEC;
+  static constexpr int PER_THREAD = NVEC / 256;
+  static_assert(NVEC % 256 == 0, "tile must divide over 256 threads");
+  Vec16<T> reg[PER_THREAD];
+
+  __device__ __forceinline__ void load(const T* __restrict__ p, int ld, int r0, int k0, int R,
+                                       int K, bool aligned) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int v = tid + i * 256;
+      int r, k;
+      size_t off;
+      int nr, nk;  // extent of the vector in r and k
+      if (KCONT) {
+        r = v / (BK / VEC); k = (v % (BK / VEC)) * VEC;
+        off = (size_t)(r0 + r) * ld + (k0 + k);
+        nr = 1; nk = VEC;
+      } else {
+        k = v / (ROWS / VEC); r = (v % (ROWS / VEC)) * VEC;
+        off = (size_t)(k0 + k) * ld + (r0 + r);
+        nr = VEC; nk = 1;
+      }
+      const bool full = (r0 + r + nr <= R) && (k0 + k + nk <= K);
+      if (full && aligned) {
+        reg[i] = *reinterpret_cast<const Vec16<T>*>(p + off);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const int rr = r0 + r + (KCONT ? 0 : j), kk = k0 + k + (KCONT ? j : 0);
+          T val = T(0);
+          if (rr < R && kk < K) val = p[KCONT ? ((size_t)rr * ld + kk) : ((size_t)kk * ld + rr)];
+          reg[i].v[j] = val;
+        }
+      }
+    }
+  }
+  // LDS image: s[r][k], row stride LDS_LD elements
+  __device__ __forceinline__ void store(T* s, int lds_ld) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int v = tid + i * 256;
+      if (KCONT) {
+        const int r = v / (BK / VEC), k = (v % (BK / VEC)) * VEC;
+        *reinterpret_cast<Vec16<T>*>(s + r * lds_ld + k) = reg[i];
+      } else {
+        const int k = v / (ROWS / VEC), r = (v % (ROWS / VEC)) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[(r + j) * lds_ld + k] = reg[i].v[j];
+      }
+    }
+  }
+};
+
+template <typename T, typename TO, int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T* __restrict__ A,
+                                                   int lda, const T* __restrict__ B, int ldb,
+                                                   TO* __restrict__ C, int ldc,
+                                                   const float* __restrict__ bias, int accumulate,
+                                                   int a_aligned, int b_aligned) {
+  constexpr int BK = GT<T>::BK, VEC = GT<T>::VEC;
+  constexpr int LDS_LD = BK + VEC;  // +16 B pad
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* As = reinterpret_cast<T*>(smem);
+  T* Bs = As + BM * LDS_LD;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // A tile: rows = m. memory k-contiguous iff !TA.  B tile: rows = n. k-contiguous iff TB.
+  TileLoader<T, BM, !TA> la;
+  TileLoader<T, BN, TB> lb;
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (K + BK - 1) / BK;
+  la.load(A, lda, m0, 0, M, K, a_aligned);
+  lb.load(B, ldb, n0, 0, N, K, b_aligned);
+  la.store(As, LDS_LD);
+  lb.store(Bs, LDS_LD);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) {
+      la.load(A, lda, m0, (kt + 1) * BK, M, K, a_aligned);
+      lb.load(B, ldb, n0, (kt + 1) * BK, N, K, b_aligned);
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8_t a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * WM + i * 16 + fr) * LDS_LD + ks * 32 + fq * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WN + j * 16 + fr) * LDS_LD + ks * 32 + fq * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[(wm * WM + i * 16 + fr) * LDS_LD + ks * 4 + fq];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[(wn * WN + j * 16 + fr) * LDS_LD + ks * 4 + fq];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      la.store(As, LDS_LD);
+      lb.store(Bs, LDS_LD);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D fragment = col lane&15, row (lane>>4)*4 + r
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + (lane & 15);
+      if (n >= N) continue;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+        if (m >= M) continue;
+        TO* cp = C + (size_t)m * ldc + n;
+        float v = acc[i][j][r] + bv;
+        if (accumulate) v += load_out<TO>(cp);
+        store_out<TO>(cp, v);
+      }
+    }
+}
+
+template <typename T, typename TO, int BM, int BN>
+int launch_layout(int transA, int transB, dim3 grid, size_t lds, hipStream_t st, int M, int N, int K,
+                  const T* A, int lda, const T* B, int ldb, TO* C, int ldc, const float* bias,
+                  int accumulate, int aa, int ba) {
+#define ASR_GEMM_LAUNCH(TA_, TB_)                                                             \
+  hipLaunchKernelGGL((gemm_kernel<T, TO, BM, BN, TA_, TB_>), grid, dim3(256), lds, st, M, N, K, A, \
+                     lda, B, ldb, C, ldc, bias, accumulate, aa, ba)
+  if (!transA && !transB) ASR_GEMM_LAUNCH(false, false);
+  else if (!transA && transB) ASR_GEMM_LAUNCH(false, true);
+  else if (transA && !transB) ASR_GEMM_LAUNCH(true, false);
+  else ASR_GEMM_LAUNCH(true, true);
+#undef ASR_GEMM_LAUNCH
+  return 0;
+}
+
+template <typename T, typename TO>
+int launch_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
+                int ldb, void* C, int ldc, const float* bias, int accumulate, hipStream_t st) {
+  constexpr int VEC = GT<T>::VEC, BK = GT<T>::BK;
+  const int aa = (((uintptr_t)A) % 16 == 0) && (lda % VEC == 0);
+  const int ba = (((uintptr_t)B) % 16 == 0) && (ldb % VEC == 0);
+  // big tiles only when they still fill the 256 CUs
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles128 >= 512) {
+    dim3 grid((N + 127) / 128, (M + 127) / 128);
+    size_t lds = (size_t)(128 + 128) * (BK + VEC) * sizeof(T);
+    return launch_layout<T, TO, 128, 128>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda,
+                                          (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba);
+  }
+  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  size_t lds = (size_t)(64 + 64) * (BK + VEC) * sizeof(T);
+  return launch_layout<T, TO, 64, 64>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda,
+                                      (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba);
+}
+
+}  // namespace
+
+extern "C" int asr_gemm(asr_handle* h, int dtype, int out_dtype, int transA, int transB, int M,
+                        int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                        int ldc, const float* bias, int accumulate, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!asr_dtype_ok(dtype) || !asr_dtype_ok(out_dtype))
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_gemm: bad dtype %d/%d", dtype, out_dtype);
+  if (M < 0 || N < 0 || K < 0 || !A || !B || !C)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_gemm: bad shape/pointer M=%d N=%d K=%d", M, N, K);
+  if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)",
+             lda, ldb, ldc);
+  if (M == 0 || N == 0) return ASR_OK;
+  hipStream_t st = (hipStream_t)s;
+  if (dtype == ASR_F32 && out_dtype == ASR_F32)
+    launch_gemm<float, float>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+  else if (dtype == ASR_F32 && out_dtype == ASR_BF16)
+    launch_gemm<float, bf16_t>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+  else if (dtype == ASR_BF16 && out_dtype == ASR_F32)
+    launch_gemm<bf16_t, float>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+  else
+    launch_gemm<bf16_t, bf16_t>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+  ASR_CHECK_LAUNCH(h, "asr_gemm");
+  return ASR_OK;
+}

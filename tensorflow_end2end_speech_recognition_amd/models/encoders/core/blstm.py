@@ -1,0 +1,123 @@
+"""Bidirectional LSTM encoder on the HIP recurrence kernels.
+
+Mirror of models/encoders/core/blstm.py:13-121 (class BLSTMEncoder, same
+constructor arguments and __call__(inputs, inputs_seq_len, keep_prob,
+is_training) -> (outputs, final_state)).  Every lstm_impl the reference offers
+('BasicLSTMCell', 'LSTMCell', 'LSTMBlockCell', 'LSTMBlockFusedCell',
+'CudnnLSTM'; blstm.py:83-121) computes the same cell; here they all map onto
+the one fused kernel ('BasicLSTMCell' = no peephole / no clip, blstm.py:124-190).
+num_proj is dropped exactly as the reference drops it unless lstm_impl ==
+'LSTMCell' (blstm.py:49-52); a projection layer is not implemented -> ValueError.
+"""
+import numpy as np
+import torch
+
+from .... import ops
+from ...._lib import ASR_F32
+from ....utils.parameter import ParamStore
+from .rnn_util import LSTMLayer, declare_lstm_vars
+
+LSTM_IMPLS = ('BasicLSTMCell', 'LSTMCell', 'LSTMBlockCell', 'LSTMBlockFusedCell', 'CudnnLSTM')
+
+
+class _RecurrentEncoderBase(object):
+    ndir = 2
+    scope_fmt = 'blstm_hidden%d'
+
+    def __init__(self, num_units, num_proj, num_layers, lstm_impl, use_peephole, parameter_init,
+                 clip_activation, time_major=True, name='lstm_encoder', dtype=ASR_F32, seed=0):
+        assert num_proj != 0
+        if lstm_impl not in LSTM_IMPLS:
+            raise IndexError('lstm_impl is "BasicLSTMCell" or "LSTMCell" or "LSTMBlockCell" or '
+                             '"LSTMBlockFusedCell" or "CudnnLSTM".')
+        self.num_units = num_units
+        self.num_proj = num_proj if lstm_impl == 'LSTMCell' else None
+        if self.num_proj is not None:
+            raise ValueError('LSTMCell projection layers (num_proj) are not implemented on the HIP path')
+        self.num_layers = num_layers
+        self.lstm_impl = lstm_impl
+        self.use_peephole = bool(use_peephole) and lstm_impl != 'BasicLSTMCell'
+        self.parameter_init = parameter_init
+        self.clip_activation = None if lstm_impl == 'BasicLSTMCell' else clip_activation
+        self.time_major = time_major
+        self.name = name
+        self.dtype = ops.dtype_id(dtype)
+        self.seed = seed
+        self.layers = None
+        self.store = None
+        self.scope_prefix = ''
+
+    # variables are created at graph-build time in the reference; here when the input size is known
+    def build(self, store, input_dim, rng, scope_prefix=''):
+        self.store = store
+        self.scope_prefix = scope_prefix
+        self.layers = []
+        din = input_dim
+        H = self.num_units
+        for i in range(1, self.num_layers + 1):
+            bases = self._declare(store, i, din, rng)
+            self.layers.append(LSTMLayer(store, bases, din, H, self.use_peephole, 1.0,
+                                         self.clip_activation))
+            din = self.ndir * H
+        self.output_dim = self.ndir * H
+        return self.output_dim
+
+    def _declare(self, store, i, din, rng):
+        scope = self.scope_prefix + (self.scope_fmt % i)
+        return declare_lstm_vars(store, scope, din, self.num_units, self.ndir, self.use_peephole,
+                                 self.parameter_init, rng)
+
+    def _ensure_built(self, inputs):
+        if self.layers is None:
+            store = ParamStore(inputs.device)
+            self.build(store, inputs.shape[-1], np.random.RandomState(self.seed))
+            store.finalize()
+
+    def __call__(self, inputs, inputs_seq_len, keep_prob, is_training, drop_masks=None, rng_state=None):
+        """inputs [B,T,input_size] fp32 (cuda); inputs_seq_len [B] int32.
+        Returns outputs [T,B,ndir*H] if time_major else [B,T,ndir*H] (fp32) and final_state of
+        the last layer: ((c_fw,h_fw),(c_bw,h_bw)) for the bidirectional encoder."""
+        self._ensure_built(inputs)
+        B, T, _ = inputs.shape
+        self.pad_b = (-B) % 16
+        if self.pad_b:  # the kernel tiles 16 utterances; pad with zero-length rows
+            inputs = torch.cat([inputs, inputs.new_zeros(self.pad_b, T, inputs.shape[2])], 0)
+            inputs_seq_len = torch.cat([inputs_seq_len, inputs_seq_len.new_zeros(self.pad_b)], 0)
+        self.batch = B
+        seq_len = inputs_seq_len.to(torch.int32).contiguous()
+        x = ops.bt_to_tb(inputs.contiguous(), self.dtype)       # blstm.py:277-279
+        final = None
+        for li, layer in enumerate(self.layers):
+            dm = drop_masks[li] if drop_masks is not None else None
+            rs = None
+            if rng_state is not None:
+                rs = (rng_state[0], rng_state[1] + li * (1 << 32))
+            x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, rs, dm)
+        self.seq_len_padded = seq_len
+        out = ops.cast_to_f32(x) if x.dtype != torch.float32 else x
+        self._out_tm = out
+        self._out_op = x   # same values in the MFMA operand dtype
+        cf, hf = final
+        final_state = tuple((cf[d, :B], hf[d, :B]) for d in range(self.ndir))
+        if self.ndir == 1:
+            final_state = final_state[0]
+        out_user = out[:, :B]
+        if not self.time_major:
+            out_user = out_user.transpose(0, 1)
+        return out_user, final_state
+
+    def backward(self, d_outputs, d_final=None):
+        """d_outputs: gradient w.r.t. the TIME-MAJOR padded-batch outputs [T,Bpad,ndir*H] fp32."""
+        dx = d_outputs
+        for li in reversed(range(len(self.layers))):
+            dcf = dhf = None
+            if d_final is not None and li == len(self.layers) - 1:
+                dcf, dhf = d_final
+            dx = self.layers[li].backward(dx.contiguous(), dcf, dhf, need_dx=(li > 0))
+        return dx
+
+
+class BLSTMEncoder(_RecurrentEncoderBase):
+    """models/encoders/core/blstm.py:13 BLSTMEncoder."""
+    ndir = 2
+    scope_fmt = 'blstm_hidden%d'

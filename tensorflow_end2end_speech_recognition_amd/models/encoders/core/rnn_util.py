@@ -1,0 +1,135 @@
+"""Host driver of one (bi)directional LSTM layer on the HIP kernels.
+
+Stands in for the per-layer body of lstmblockcell() in the reference
+(models/encoders/core/blstm.py:281-323 / lstm.py:250-285):
+LSTMBlockCell(forget_bias=1.0, clip_cell, use_peephole) fw (+ bw) under
+DropoutWrapper(output_keep_prob) and (bidirectional_)dynamic_rnn(sequence_length).
+
+Dataflow per layer (all device-side, one stream):
+  forward : xproj = x W_x + b          one MFMA GEMM per direction over all T
+            pack W_h -> fragments      (weights changed last step)
+            lstm_fwd                   the serial recurrence kernel
+            (dropout: mask on the emitted output only)
+  backward: lstm_bwd                   BPTT -> dgates (pre-activation grads)
+            dW_x = x^T dG, dW_h = h_prev^T dG, db = colsum(dG), dx = dG W_x^T   MFMA GEMMs
+Variable names follow TF 1.3:
+  <scope>/{fw,bw}/lstm_cell/{kernel,bias,w_i_diag,w_f_diag,w_o_diag}
+"""
+import numpy as np
+import torch
+
+from .... import ops
+from ...._lib import ASR_BF16, ASR_F32
+
+DIRS = ('fw', 'bw')
+
+
+def declare_lstm_vars(store, scope, din, H, ndir, use_peephole, parameter_init, rng, cell_scope=None):
+    """uniform(+-parameter_init) kernel and peepholes (variable_scope initializer,
+    blstm.py:283-284), zero bias (LSTMBlockCell default)."""
+    names = []
+    for d in range(ndir):
+        base = '%s/%s/lstm_cell' % (scope, DIRS[d]) if cell_scope is None else cell_scope
+        u = lambda *s: rng.uniform(-parameter_init, parameter_init, size=s)
+        store.declare(base + '/kernel', (din + H, 4 * H), u(din + H, 4 * H))
+        store.declare(base + '/bias', (4 * H,), np.zeros(4 * H))
+        if use_peephole:
+            store.declare(base + '/w_i_diag', (H,), u(H))
+            store.declare(base + '/w_f_diag', (H,), u(H))
+            store.declare(base + '/w_o_diag', (H,), u(H))
+        names.append(base)
+    return names
+
+
+class LSTMLayer(object):
+    def __init__(self, store, bases, din, H, use_peephole, forget_bias=1.0, cell_clip=None):
+        self.store = store
+        self.bases = bases
+        self.ndir = len(bases)
+        self.din, self.H = din, H
+        self.use_peephole = use_peephole
+        self.forget_bias = forget_bias
+        self.cell_clip = cell_clip
+        self.ctx = None
+
+    def _peep(self):
+        if not self.use_peephole:
+            return None
+        st = self.store
+        return torch.stack([torch.stack([st[b + '/w_i_diag'], st[b + '/w_f_diag'], st[b + '/w_o_diag']])
+                            for b in self.bases]).contiguous()
+
+    def forward(self, x, seq_len, dtype, keep_prob=1.0, is_training=True, rng_state=None,
+                drop_mask=None, save=True):
+        """x [T,B,din] in `dtype`; returns (out [T,B,ndir*H] in dtype, (c_final, h_final))."""
+        st = self.store
+        sh = st.shadow(dtype)
+        T, B, din = x.shape
+        H, ndir = self.H, self.ndir
+        x2d = x.view(T * B, din)
+        xproj = torch.empty((T, B, ndir * 4 * H), dtype=torch.float32, device=x.device)
+        xp2d = xproj.view(T * B, ndir * 4 * H)
+        wdt = torch.bfloat16 if dtype == ASR_BF16 else torch.float32
+        whf = torch.empty((ndir, H * 4 * H), dtype=wdt, device=x.device)
+        whb = torch.empty((ndir, H * 4 * H), dtype=wdt, device=x.device)
+        for d, base in enumerate(self.bases):
+            wx = sh[base + '/kernel'][:din]
+            ops.gemm(x2d, wx, bias=st[base + '/bias'], out=xp2d[:, d * 4 * H:(d + 1) * 4 * H])
+            h = ops._h(x)
+            h.check(h.lib.asr_lstm_pack_wh(h.h, dtype, ops._p(st[base + '/kernel'][din:]), H,
+                                           ops._p(whf[d]), ops._p(whb[d]), ops._s()), 'asr_lstm_pack_wh')
+        peep = self._peep()
+        hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, seq_len, H, ndir, dtype,
+                                        self.forget_bias, self.cell_clip or 0.0)
+        out = hout
+        mask = None
+        if is_training and (drop_mask is not None or keep_prob < 1.0):
+            if drop_mask is None:
+                seed, offset = rng_state
+                mask = ops.dropout_mask(hout.shape, keep_prob, seed, offset, x.device)
+            else:
+                mask = drop_mask
+            out = ops.apply_mask(hout, mask)
+        if save:
+            self.ctx = dict(x=x, gates=xproj, cs=cs, hout=hout, whb=whb, peep=peep, seq_len=seq_len,
+                            dtype=dtype, mask=mask)
+        return out, (cf, hf)
+
+    def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True):
+        """dout [T,B,ndir*H] fp32 -> dx [T,B,din] fp32 (or None).  Fills store.grad."""
+        c = self.ctx
+        st = self.store
+        dtype = c['dtype']
+        sh = st.shadow(dtype)
+        x, hout = c['x'], c['hout']
+        T, B, din = x.shape
+        H, ndir = self.H, self.ndir
+        if c['mask'] is not None:
+            dout = ops.apply_mask(dout, c['mask'])
+        dgates, dpeep = ops.lstm_bwd(dout, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H,
+                                     ndir, dtype, d_c_final, d_h_final, want_dpeep=self.use_peephole)
+        x2d = x.view(T * B, din)
+        h2d = hout.view(T * B, ndir * H)
+        dg2d = dgates.view(T * B, ndir * 4 * H)
+        dx = torch.empty((T, B, din), dtype=torch.float32, device=x.device) if need_dx else None
+        for d, base in enumerate(self.bases):
+            dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
+            gk = st.g(base + '/kernel')
+            ops.gemm(x2d, dg, transA=True, out=gk[:din], out_dtype=ASR_F32)
+            if T > 1:
+                if d == 0:   # forward direction: h_prev(t) = h(t-1)
+                    ops.gemm(h2d[:(T - 1) * B, d * H:(d + 1) * H], dg[B:], transA=True, out=gk[din:])
+                else:        # backward direction: h_prev(t) = h(t+1) (zero beyond len-1)
+                    ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=gk[din:])
+            else:
+                gk[din:].zero_()
+            ops.colsum(dg, out=st.g(base + '/bias'))
+            if self.use_peephole:
+                st.g(base + '/w_i_diag').copy_(dpeep[d, 0])
+                st.g(base + '/w_f_diag').copy_(dpeep[d, 1])
+                st.g(base + '/w_o_diag').copy_(dpeep[d, 2])
+            if need_dx:
+                ops.gemm(dg, sh[base + '/kernel'][:din], transB=True, out=dx.view(T * B, din),
+                         accumulate=(d > 0))
+        self.ctx = None
+        return dx

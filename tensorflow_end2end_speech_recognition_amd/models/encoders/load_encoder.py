@@ -1,0 +1,26 @@
+"""Select & load encoder -- mirror of models/encoders/load_encoder.py:26-57.
+
+The registry is the reference's plugin point: an encoder is a class with
+__call__(inputs, inputs_seq_len, keep_prob, is_training) -> (outputs, final_state).
+Keys outside the north-star hot path (gru, cnn_zhang, vgg_wang, multitask_*,
+pyramid_blstm, cldnn_wang, student_*) are not built: asking for
+them raises the same ValueError as an unknown key."""
+from .core.blstm import BLSTMEncoder
+from .core.lstm import LSTMEncoder
+
+ENCODERS = {
+    "blstm": BLSTMEncoder,
+    "lstm": LSTMEncoder,
+}
+
+
+def register(encoder_type, cls):
+    ENCODERS[encoder_type] = cls
+
+
+def load(encoder_type):
+    if encoder_type not in ENCODERS.keys():
+        raise ValueError(
+            "encoder_type should be one of [%s], you provided %s." %
+            (", ".join(ENCODERS), encoder_type))
+    return ENCODERS[encoder_type]

@@ -1,0 +1,275 @@
+"""Thin torch-tensor front end of the C ABI (include/asr_hip.h).
+
+torch owns device memory and the stream; every function below hands raw device
+pointers + shapes to libasr_hip.so.  No arithmetic happens in torch here and
+there is no CPU fallback: non-CUDA tensors raise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ASR_BF16, ASR_F32
+
+TORCH_DTYPE = {ASR_F32: torch.float32, ASR_BF16: torch.bfloat16}
+
+
+def dtype_id(dtype):
+    if dtype in (ASR_F32, 'f32', 'fp32', 'float32', torch.float32):
+        return ASR_F32
+    if dtype in (ASR_BF16, 'bf16', 'bfloat16', torch.bfloat16):
+        return ASR_BF16
+    raise ValueError('dtype must be f32 or bf16, got %r' % (dtype,))
+
+
+def _h(t):
+    if not t.is_cuda:
+        raise RuntimeError('HIP path needs a CUDA(ROCm) tensor; there is no CPU fallback')
+    return _lib.handle(t.device.index or 0)
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError('tensor must be contiguous')
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name):
+    if t.dtype != dtype:
+        raise ValueError('%s must be %s, got %s' % (name, dtype, t.dtype))
+
+
+# ---------------------------------------------------------------- layout / casts
+def bt_to_tb(x_btd, dtype=ASR_F32):
+    h = _h(x_btd)
+    _chk(x_btd, torch.float32, 'inputs')
+    B, T, D = x_btd.shape
+    out = torch.empty((T, B, D), dtype=TORCH_DTYPE[dtype], device=x_btd.device)
+    h.check(h.lib.asr_bt_to_tb(h.h, dtype, _p(x_btd), _p(out), B, T, D, _s()), 'asr_bt_to_tb')
+    return out
+
+
+def cast_from_f32(x, dtype, out=None):
+    h = _h(x)
+    _chk(x, torch.float32, 'x')
+    if out is None:
+        out = torch.empty(x.shape, dtype=TORCH_DTYPE[dtype], device=x.device)
+    h.check(h.lib.asr_cast_from_f32(h.h, dtype, _p(x), _p(out), x.numel(), _s()), 'asr_cast_from_f32')
+    return out
+
+
+def cast_to_f32(x, out=None):
+    h = _h(x)
+    dt = dtype_id(x.dtype)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    h.check(h.lib.asr_cast_to_f32(h.h, dt, _p(x), _p(out), x.numel(), _s()), 'asr_cast_to_f32')
+    return out
+
+
+def apply_mask(x, mask, out=None):
+    h = _h(x)
+    dt = dtype_id(x.dtype)
+    _chk(mask, torch.float32, 'mask')
+    if out is None:
+        out = torch.empty_like(x)
+    h.check(h.lib.asr_apply_mask(h.h, dt, _p(x), _p(mask), _p(out), x.numel(), _s()), 'asr_apply_mask')
+    return out
+
+
+def dropout_mask(shape, keep_prob, seed, offset, device):
+    mask = torch.empty(shape, dtype=torch.float32, device=device)
+    h = _h(mask)
+    h.check(h.lib.asr_dropout_mask(h.h, _p(mask), mask.numel(), float(keep_prob), int(seed),
+                                   int(offset), _s()), 'asr_dropout_mask')
+    return mask
+
+
+def colsum(a, out=None):
+    """sum over rows of a [M,N] (last-dim contiguous 2-D view) -> fp32 [N]."""
+    h = _h(a)
+    dt = dtype_id(a.dtype)
+    M, N = a.shape
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=a.device)
+    h.check(h.lib.asr_colsum(h.h, dt, _p(a), M, N, a.stride(0), _p(out), _s()), 'asr_colsum')
+    return out
+
+
+# ---------------------------------------------------------------- GEMM
+def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, accumulate=False):
+    """C = op(A) @ op(B) (+bias) (+C).  A, B 2-D, same dtype (f32 or bf16), row stride = ld."""
+    h = _h(A)
+    dt = dtype_id(A.dtype)
+    if B.dtype != A.dtype:
+        raise ValueError('gemm: A and B dtypes differ')
+    for t, n in ((A, 'A'), (B, 'B')):
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError('gemm: %s must be 2-D with unit inner stride' % n)
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    Kb, N = (B.shape[1], B.shape[0]) if transB else (B.shape[0], B.shape[1])
+    if K != Kb:
+        raise ValueError('gemm: inner dimensions differ (%d vs %d)' % (K, Kb))
+    odt = dt if out_dtype is None else dtype_id(out_dtype)
+    if out is None:
+        out = torch.empty((M, N), dtype=TORCH_DTYPE[odt], device=A.device)
+    else:
+        odt = dtype_id(out.dtype)
+        if out.shape != (M, N) or out.stride(1) != 1:
+            raise ValueError('gemm: bad out shape %s' % (tuple(out.shape),))
+    if bias is not None:
+        _chk(bias, torch.float32, 'bias')
+    h.check(h.lib.asr_gemm(h.h, dt, odt, int(transA), int(transB), M, N, K,
+                           C.c_void_p(A.data_ptr()), A.stride(0), C.c_void_p(B.data_ptr()), B.stride(0),
+                           C.c_void_p(out.data_ptr()), out.stride(0), _p(bias), int(accumulate), _s()),
+            'asr_gemm')
+    return out
+
+
+# ---------------------------------------------------------------- LSTM
+def lstm_pack_wh(wh, dtype):
+    """wh [H,4H] fp32 -> (fwd-packed, bwd-packed) in `dtype`."""
+    h = _h(wh)
+    _chk(wh, torch.float32, 'wh')
+    H = wh.shape[0]
+    if wh.shape != (H, 4 * H):
+        raise ValueError('wh must be [H,4H]')
+    pf = torch.empty((H * 4 * H,), dtype=TORCH_DTYPE[dtype], device=wh.device)
+    pb = torch.empty_like(pf)
+    h.check(h.lib.asr_lstm_pack_wh(h.h, dtype, _p(wh), H, _p(pf), _p(pb), _s()), 'asr_lstm_pack_wh')
+    return pf, pb
+
+
+def lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, cell_clip=0.0,
+             want_final=True):
+    """xproj [T,B,ndir*4H] fp32 (overwritten with the gates).  Returns hout, cs, c_final, h_final."""
+    h = _h(xproj)
+    _chk(xproj, torch.float32, 'xproj')
+    _chk(seq_len, torch.int32, 'seq_len')
+    T, B, G = xproj.shape
+    if G != ndir * 4 * H:
+        raise ValueError('xproj last dim %d != ndir*4H' % G)
+    dev = xproj.device
+    hout = torch.empty((T, B, ndir * H), dtype=TORCH_DTYPE[dtype], device=dev)
+    cs = torch.empty((T, B, ndir * H), dtype=torch.float32, device=dev)
+    cf = torch.empty((ndir, B, H), dtype=torch.float32, device=dev) if want_final else None
+    hf = torch.empty((ndir, B, H), dtype=torch.float32, device=dev) if want_final else None
+    h.check(h.lib.asr_lstm_fwd(h.h, dtype, T, B, H, ndir, _p(xproj), _p(wh_packed), _p(peep),
+                               _p(seq_len), float(forget_bias), float(cell_clip or 0.0), _p(hout),
+                               _p(cs), _p(cf), _p(hf), _s()), 'asr_lstm_fwd')
+    return hout, cs, cf, hf
+
+
+def lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c_final=None,
+             d_h_final=None, want_dpeep=True):
+    h = _h(dhout)
+    _chk(dhout, torch.float32, 'dhout')
+    T, B, _ = dhout.shape
+    dev = dhout.device
+    dgates = torch.empty((T, B, ndir * 4 * H), dtype=TORCH_DTYPE[dtype], device=dev)
+    dpeep = ws = None
+    if want_dpeep:
+        dpeep = torch.empty((ndir, 3, H), dtype=torch.float32, device=dev)
+        ws = torch.empty(((B // 16) * ndir * 3 * H,), dtype=torch.float32, device=dev)
+    h.check(h.lib.asr_lstm_bwd(h.h, dtype, T, B, H, ndir, _p(dhout), _p(gates), _p(cs),
+                               _p(wh_packed_bwd), _p(peep), _p(seq_len), _p(d_c_final), _p(d_h_final),
+                               _p(dgates), _p(dpeep), _p(ws), _s()), 'asr_lstm_bwd')
+    return dgates, dpeep
+
+
+# ---------------------------------------------------------------- CTC
+def ctc_loss(logits, labels_flat, label_offsets, seq_len, max_label_len, grad_scale=1.0,
+             want_grad=True):
+    """logits [T,B,C] fp32; returns (loss [B], grad [T,B,C] or None, num_infeasible [1] int32)."""
+    h = _h(logits)
+    _chk(logits, torch.float32, 'logits')
+    _chk(labels_flat, torch.int32, 'labels_flat')
+    _chk(label_offsets, torch.int32, 'label_offsets')
+    _chk(seq_len, torch.int32, 'seq_len')
+    T, B, Cc = logits.shape
+    dev = logits.device
+    nbytes = h.lib.asr_ctc_workspace_bytes(T, B, int(max_label_len))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    grad = torch.empty_like(logits) if want_grad else None
+    ninf = torch.zeros((1,), dtype=torch.int32, device=dev)
+    h.check(h.lib.asr_ctc_loss(h.h, _p(logits), T, B, Cc, _p(labels_flat), _p(label_offsets),
+                               _p(seq_len), int(max_label_len), float(grad_scale), _p(loss), _p(grad),
+                               _p(ninf), _p(ws), nbytes, _s()), 'asr_ctc_loss')
+    return loss, grad, ninf
+
+
+def ctc_greedy_decode(logits, seq_len, blank=None):
+    h = _h(logits)
+    _chk(logits, torch.float32, 'logits')
+    _chk(seq_len, torch.int32, 'seq_len')
+    T, B, Cc = logits.shape
+    if blank is None:
+        blank = Cc - 1
+    out = torch.empty((B, T), dtype=torch.int32, device=logits.device)
+    n = torch.empty((B,), dtype=torch.int32, device=logits.device)
+    h.check(h.lib.asr_ctc_greedy_decode(h.h, _p(logits), T, B, Cc, _p(seq_len), int(blank), _p(out),
+                                        _p(n), _s()), 'asr_ctc_greedy_decode')
+    return out, n
+
+
+def softmax_rows(x2d):
+    h = _h(x2d)
+    _chk(x2d, torch.float32, 'x')
+    out = torch.empty_like(x2d)
+    h.check(h.lib.asr_softmax_rows(h.h, _p(x2d), _p(out), x2d.shape[0], x2d.shape[1], _s()),
+            'asr_softmax_rows')
+    return out
+
+
+# ---------------------------------------------------------------- clip / decay / optimizers
+class ClipPlan(object):
+    """Device-side description of a flat fp32 parameter buffer split into tensors."""
+
+    def __init__(self, offsets_host, device):
+        off = np.asarray(offsets_host, dtype=np.int64)
+        self.num_tensors = len(off) - 1
+        cs = np.zeros(self.num_tensors + 1, dtype=np.int64)
+        lib = _lib.load()
+        hd = _lib.handle(device.index or 0)
+        hd.check(lib.asr_clip_plan(hd.h, off.ctypes.data_as(C.c_void_p), self.num_tensors,
+                                   cs.ctypes.data_as(C.c_void_p)), 'asr_clip_plan')
+        self.total_chunks = int(cs[-1])
+        self.offsets = torch.from_numpy(off).to(device)
+        self.chunk_start = torch.from_numpy(cs).to(device)
+        self.partial = torch.empty((max(self.total_chunks, 1),), dtype=torch.float32, device=device)
+
+
+def clip_by_norm_multi(flat_grads, plan, clip_norm):
+    h = _h(flat_grads)
+    _chk(flat_grads, torch.float32, 'grads')
+    h.check(h.lib.asr_clip_by_norm_multi(h.h, _p(flat_grads), _p(plan.offsets), _p(plan.chunk_start),
+                                         plan.num_tensors, plan.total_chunks, float(clip_norm),
+                                         _p(plan.partial), _s()), 'asr_clip_by_norm_multi')
+
+
+def weight_decay(flat_grads, flat_params, plan, decay_mask, wd, l2_out=None):
+    h = _h(flat_params)
+    h.check(h.lib.asr_weight_decay(h.h, _p(flat_grads), _p(flat_params), _p(plan.offsets),
+                                   _p(decay_mask), plan.num_tensors, float(wd), _p(l2_out), _s()),
+            'asr_weight_decay')
+
+
+def optimizer_step(opt_id, params, grads, slot0, slot1, lr, step):
+    h = _h(params)
+    h.check(h.lib.asr_optimizer_step(h.h, int(opt_id), _p(params), _p(grads), _p(slot0), _p(slot1),
+                                     params.numel(), float(lr), int(step), _s()), 'asr_optimizer_step')
+
+
+def scale_(x, s):
+    h = _h(x)
+    _chk(x, torch.float32, 'x')
+    h.check(h.lib.asr_scale(h.h, _p(x), x.numel(), float(s), _s()), 'asr_scale')
+    return x

@@ -1,0 +1,370 @@
+"""GPU parity tests: every HIP op through the C ABI vs the CPU oracle on the same seeded
+inputs.  Tolerances: fp32 path 1e-4 relative (north_star), bf16 path documented looser."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc as octc
+from oracle import decoders as odec
+from oracle import lstm as olstm
+from oracle import optim as oopt
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _ops():
+    from tensorflow_end2end_speech_recognition_amd import ops
+    return ops
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('M,N,K', [(64, 64, 32), (130, 70, 45), (1, 62, 512), (257, 1024, 120),
+                                   (700, 130, 1000), (16, 16, 4), (3000, 2048, 120)])
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_f32(cuda, M, N, K, ta, tb):
+    ops = _ops()
+    rng = np.random.RandomState(M + N + K + ta * 2 + tb)
+    A = rng.randn(*((K, M) if ta else (M, K))).astype(np.float32)
+    B = rng.randn(*((N, K) if tb else (K, N))).astype(np.float32)
+    bias = rng.randn(N).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64) + bias
+    out = ops.gemm(torch.tensor(A, device=cuda), torch.tensor(B, device=cuda), bool(ta), bool(tb),
+                   bias=torch.tensor(bias, device=cuda))
+    assert _rel(out.cpu().numpy(), ref) < 2e-6
+    # accumulate + strided C view
+    big = torch.ones((M, N + 8), dtype=torch.float32, device=cuda)
+    ops.gemm(torch.tensor(A, device=cuda), torch.tensor(B, device=cuda), bool(ta), bool(tb),
+             out=big[:, 4:4 + N], accumulate=True)
+    assert _rel(big[:, 4:4 + N].cpu().numpy(), ref - bias + 1.0) < 2e-6
+    assert float(big[:, :4].min()) == 1.0 and float(big[:, 4 + N:].max()) == 1.0
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 64, 64), (130, 70, 45), (257, 1024, 120), (3000, 2048, 512)])
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16(cuda, M, N, K, ta, tb):
+    ops = _ops()
+    rng = np.random.RandomState(M + N + K)
+    A = torch.tensor(rng.randn(*((K, M) if ta else (M, K))), dtype=torch.bfloat16)
+    B = torch.tensor(rng.randn(*((N, K) if tb else (K, N))), dtype=torch.bfloat16)
+    Af, Bf = A.double().numpy(), B.double().numpy()
+    ref = (Af.T if ta else Af) @ (Bf.T if tb else Bf)
+    out = ops.gemm(A.to(cuda), B.to(cuda), bool(ta), bool(tb), out_dtype='f32')
+    # inputs are exactly representable; only fp32 accumulation order differs
+    assert _rel(out.cpu().numpy(), ref) < 1e-5
+
+
+def test_gemm_bad_args(cuda):
+    ops = _ops()
+    with pytest.raises(ValueError):
+        ops.gemm(torch.zeros(4, 5, device=cuda), torch.zeros(6, 4, device=cuda))
+
+
+# --------------------------------------------------------------------------- LSTM
+def _lstm_case(rng, T, B, D, H, ndir, lens, init=0.3):
+    x = rng.randn(B, T, D)
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    ps = [olstm.init_lstm_params(rng, D, H, init=init) for _ in range(ndir)]
+    for p in ps:
+        p['b'] = torch.tensor(rng.uniform(-init, init, 4 * H))
+    return x, ps
+
+
+def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfinal=None):
+    ops = _ops()
+    from tensorflow_end2end_speech_recognition_amd._lib import ASR_BF16, ASR_F32
+    dt = ASR_BF16 if dtype == 'bf16' else ASR_F32
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    B, T, D = x.shape
+    xd = ops.bt_to_tb(torch.tensor(x, dtype=torch.float32, device=cuda), dt)
+    xproj = torch.empty((T, B, ndir * 4 * H), dtype=torch.float32, device=cuda)
+    whf = torch.empty((ndir, 4 * H * H), dtype=tdt, device=cuda)
+    whb = torch.empty_like(whf)
+    for d, p in enumerate(ps):
+        w = torch.tensor(p['w'].numpy(), dtype=torch.float32, device=cuda)
+        wx = w[:D].to(tdt).contiguous()
+        ops.gemm(xd.view(T * B, D), wx, bias=torch.tensor(p['b'].numpy(), dtype=torch.float32, device=cuda),
+                 out=xproj.view(T * B, -1)[:, d * 4 * H:(d + 1) * 4 * H])
+        pf, pb = ops.lstm_pack_wh(w[D:].contiguous(), dt)
+        whf[d].copy_(pf)
+        whb[d].copy_(pb)
+    peep = torch.tensor(np.stack([np.stack([p['wci'].numpy(), p['wcf'].numpy(), p['wco'].numpy()]) for p in ps]),
+                        dtype=torch.float32, device=cuda)
+    sl = torch.tensor(lens, dtype=torch.int32, device=cuda)
+    hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, sl, H, ndir, dt, 1.0, cell_clip)
+    res = dict(hout=hout.float().cpu().numpy(), cs=cs.cpu().numpy(), cf=cf.cpu().numpy(), hf=hf.cpu().numpy())
+    if dout is not None:
+        dcf = dhf = None
+        if dfinal is not None:
+            dcf = torch.tensor(dfinal[0], dtype=torch.float32, device=cuda)
+            dhf = torch.tensor(dfinal[1], dtype=torch.float32, device=cuda)
+        dg, dpeep = ops.lstm_bwd(torch.tensor(dout, dtype=torch.float32, device=cuda), xproj, cs, whb, peep, sl,
+                                 H, ndir, dt, dcf, dhf)
+        res['dgates'] = dg.float().cpu().numpy()
+        res['dpeep'] = dpeep.cpu().numpy()
+    return res
+
+
+def _oracle_layer(x, ps, lens, ndir, cell_clip, dout=None, dfinal=None):
+    xt = torch.tensor(x).transpose(0, 1).contiguous().requires_grad_(True)
+    sl = torch.tensor(lens, dtype=torch.long)
+    for p in ps:
+        for k in ('w', 'b', 'wci', 'wcf', 'wco'):
+            p[k] = p[k].detach().clone().requires_grad_(True)
+    kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=True)
+    outs, fins = [], []
+    for d, p in enumerate(ps):
+        o, f = olstm.dynamic_rnn(xt, sl, p, reverse=(d == 1), **kw)
+        outs.append(o)
+        fins.append(f)
+    out = torch.cat(outs, 2)
+    res = dict(hout=out.detach().numpy(), cf=np.stack([f[0].detach().numpy() for f in fins]),
+               hf=np.stack([f[1].detach().numpy() for f in fins]))
+    if dout is not None:
+        obj = (out * torch.tensor(dout)).sum()
+        if dfinal is not None:
+            for d in range(ndir):
+                obj = obj + (fins[d][0] * torch.tensor(dfinal[0][d])).sum() + (fins[d][1] * torch.tensor(dfinal[1][d])).sum()
+        obj.backward()
+        res['dx'] = xt.grad.numpy()
+        res['dw'] = [p['w'].grad.numpy() for p in ps]
+        res['db'] = [p['b'].grad.numpy() for p in ps]
+        res['dpeep'] = np.stack([np.stack([p['wci'].grad.numpy(), p['wcf'].grad.numpy(), p['wco'].grad.numpy()]) for p in ps])
+    return res
+
+
+LSTM_SHAPES = [(12, 16, 24, 64, 2), (37, 32, 120, 128, 2), (20, 16, 40, 256, 2), (9, 16, 12, 64, 1),
+               (15, 16, 30, 192, 2)]
+
+
+@pytest.mark.parametrize('T,B,D,H,ndir', LSTM_SHAPES)
+def test_lstm_fwd_f32(cuda, T, B, D, H, ndir):
+    rng = np.random.RandomState(T * 7 + H)
+    lens = rng.randint(1, T + 1, size=B)
+    lens[0] = T
+    lens[-1] = 0 if B > 16 else lens[-1]
+    x, ps = _lstm_case(rng, T, B, D, H, ndir, lens)
+    got = _run_hip_layer(cuda, x, ps, lens, H, ndir, 'f32', 0.0)
+    ref = _oracle_layer(x, ps, lens, ndir, 0.0)
+    assert np.abs(got['hout'] - ref['hout']).max() < 2e-5
+    assert np.abs(got['cf'] - ref['cf']).max() < 5e-5
+    assert np.abs(got['hf'] - ref['hf']).max() < 2e-5
+    for b in range(B):   # padded frames exactly zero
+        assert np.abs(got['hout'][lens[b]:, b]).max() == 0 if lens[b] < T else True
+
+
+def test_lstm_fwd_cell_clip(cuda):
+    rng = np.random.RandomState(5)
+    T, B, D, H = 14, 16, 20, 64
+    lens = rng.randint(3, T + 1, size=B)
+    x, ps = _lstm_case(rng, T, B, D, H, 2, lens, init=1.5)
+    got = _run_hip_layer(cuda, x * 3, ps, lens, H, 2, 'f32', 0.5)
+    ref = _oracle_layer(x * 3, ps, lens, 2, 0.5)
+    assert np.abs(got['cs']).max() <= 0.5 + 1e-6 and np.abs(got['cs']).max() > 0.49   # clip active
+    assert np.abs(got['hout'] - ref['hout']).max() < 5e-5
+
+
+@pytest.mark.parametrize('T,B,D,H,ndir', LSTM_SHAPES)
+def test_lstm_bwd_f32(cuda, T, B, D, H, ndir):
+    rng = np.random.RandomState(T * 11 + H)
+    lens = rng.randint(1, T + 1, size=B)
+    lens[0] = T
+    x, ps = _lstm_case(rng, T, B, D, H, ndir, lens)
+    dout = rng.randn(T, B, ndir * H)
+    dfinal = (rng.randn(ndir, B, H) * 0.5, rng.randn(ndir, B, H) * 0.5)
+    got = _run_hip_layer(cuda, x, ps, lens, H, ndir, 'f32', 0.0, dout, dfinal)
+    ref = _oracle_layer(x, ps, lens, ndir, 0.0, dout, dfinal)
+    # rebuild the parameter/input gradients from dgates exactly as the host driver does
+    dg = got['dgates'].astype(np.float64)                     # [T,B,ndir*4H]
+    xt = np.transpose(x, (1, 0, 2))
+    hout = got['hout'].astype(np.float64)
+    dx = np.zeros_like(xt)
+    for d, p in enumerate(ps):
+        g = dg[:, :, d * 4 * H:(d + 1) * 4 * H].reshape(T * B, 4 * H)
+        w = p['w'].detach().numpy()
+        dwx = xt.reshape(T * B, D).T @ g
+        hp = np.zeros((T, B, H))
+        if d == 0:
+            hp[1:] = hout[:-1, :, :H]
+        else:
+            hp[:-1] = hout[1:, :, H:2 * H]
+        dwh = hp.reshape(T * B, H).T @ g
+        dx += (g @ w[:D].T).reshape(T, B, D)
+        assert _rel(np.concatenate([dwx, dwh], 0), ref['dw'][d]) < 1e-4
+        assert _rel(g.sum(0), ref['db'][d]) < 1e-4
+    assert _rel(dx, ref['dx']) < 1e-4
+    assert _rel(got['dpeep'], ref['dpeep']) < 1e-4
+    for b in range(B):
+        if lens[b] < T:
+            assert np.abs(got['dgates'][lens[b]:, b]).max() == 0
+
+
+@pytest.mark.parametrize('T,B,D,H,ndir', [(20, 16, 40, 256, 2), (11, 16, 24, 512, 2), (13, 32, 24, 320, 1)])
+def test_lstm_bf16_and_wide(cuda, T, B, D, H, ndir):
+    """bf16 operand path (and the 8-wave H=512 / odd H=320 instantiations): outputs within
+    bf16 rounding of the fp64 oracle (tolerance 3e-2 abs on O(1) activations)."""
+    rng = np.random.RandomState(H + T)
+    lens = rng.randint(1, T + 1, size=B)
+    lens[0] = T
+    x, ps = _lstm_case(rng, T, B, D, H, ndir, lens, init=0.1)
+    dout = rng.randn(T, B, ndir * H)
+    ref = _oracle_layer(x, ps, lens, ndir, 0.0, dout)
+    for dtype, tol in (('f32', 1e-4), ('bf16', 3e-2)):
+        got = _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, 0.0, dout)
+        assert np.abs(got['hout'] - ref['hout']).max() < tol
+        assert _rel(got['dpeep'], ref['dpeep']) < (1e-4 if dtype == 'f32' else 5e-2)
+
+
+# --------------------------------------------------------------------------- CTC
+def _ctc_case(rng, T, B, C, lmax, scale=2.0):
+    logits = (rng.randn(T, B, C) * scale).astype(np.float32)
+    sl = rng.randint(max(1, T // 3), T + 1, size=B).astype(np.int32)
+    sl[0] = T
+    labs = []
+    for b in range(B):
+        L = rng.randint(0, min(lmax, sl[b] // 2) + 1)
+        labs.append([int(v) for v in rng.randint(0, C - 1, size=L)])
+    return logits, sl, labs
+
+
+def _flat(labs):
+    flat = np.asarray(sum(labs, []) or [0], dtype=np.int32)
+    off = np.zeros(len(labs) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(l) for l in labs])
+    return flat, off
+
+
+@pytest.mark.parametrize('T,B,C,lmax', [(30, 4, 6, 8), (120, 16, 40, 30), (300, 16, 62, 75), (50, 3, 29, 20),
+                                         (64, 2, 700, 25), (400, 2, 29, 150)])
+def test_ctc_loss_and_grad(cuda, T, B, C, lmax):
+    ops = _ops()
+    rng = np.random.RandomState(T + C)
+    logits, sl, labs = _ctc_case(rng, T, B, C, lmax)
+    labs[0] = labs[0][:2] + labs[0][:2] if len(labs[0]) >= 2 else labs[0]   # force repeats
+    flat, off = _flat(labs)
+    ref_loss, ref_grad = octc.ctc_loss_batch(logits.astype(np.float64), labs, sl)
+    loss, grad, ninf = ops.ctc_loss(torch.tensor(logits, device=cuda), torch.tensor(flat, device=cuda),
+                                    torch.tensor(off, device=cuda), torch.tensor(sl, device=cuda),
+                                    max(len(l) for l in labs), grad_scale=1.0)
+    assert np.abs(loss.cpu().numpy() - ref_loss).max() / max(ref_loss.max(), 1) < 1e-5
+    assert np.abs(grad.cpu().numpy() - ref_grad).max() < 2e-5
+    assert int(ninf.item()) == 0
+
+
+def test_ctc_edge_cases(cuda):
+    """empty label rows, T == exact minimum, infeasible rows (-> 0 loss/grad), seq_len 0."""
+    ops = _ops()
+    rng = np.random.RandomState(0)
+    T, B, C = 12, 5, 7
+    logits = rng.randn(T, B, C).astype(np.float32)
+    sl = np.array([12, 5, 3, 0, 7], dtype=np.int32)
+    labs = [[], [1, 1, 1], [2, 2], [3], [0, 1, 2, 3, 4, 5, 0]]   # row1 needs exactly 5; row2 needs 3 has 3
+    labs[2] = [2, 2, 2]                                          # needs 5 > 3 -> infeasible
+    flat, off = _flat(labs)
+    ref_loss, ref_grad = octc.ctc_loss_batch(logits.astype(np.float64), labs, sl)
+    loss, grad, ninf = ops.ctc_loss(torch.tensor(logits, device=cuda), torch.tensor(flat, device=cuda),
+                                    torch.tensor(off, device=cuda), torch.tensor(sl, device=cuda), 7, 1.0)
+    assert np.abs(loss.cpu().numpy() - ref_loss).max() < 1e-4
+    assert np.abs(grad.cpu().numpy() - ref_grad).max() < 2e-5
+    assert loss[2].item() == 0 and float(grad[:, 2].abs().max()) == 0 and int(ninf.item()) == 1
+    assert loss[3].item() == 0 and float(grad[:, 3].abs().max()) == 0
+    # deterministic
+    loss2, grad2, _ = ops.ctc_loss(torch.tensor(logits, device=cuda), torch.tensor(flat, device=cuda),
+                                   torch.tensor(off, device=cuda), torch.tensor(sl, device=cuda), 7, 1.0)
+    assert torch.equal(grad, grad2) and torch.equal(loss, loss2)
+
+
+def test_greedy_decode_bit_exact(cuda):
+    ops = _ops()
+    g = np.load(os.path.join(GOLD, 'decoders_v1.npz'))
+    for i in range(int(g['num_cases'])):
+        probs, sl = g['c%d_probs' % i], g['c%d_seq_len' % i]
+        C = probs.shape[2]
+        logits = np.log(probs).astype(np.float32).transpose(1, 0, 2).copy()     # [T,1,C]
+        lab, n = ops.ctc_greedy_decode(torch.tensor(logits, device=cuda), torch.tensor(sl, device=cuda))
+        ref = odec.greedy_decode(logits.transpose(1, 0, 2), sl, C - 1)[0]        # same fp32 values
+        assert lab[0, :int(n[0])].cpu().tolist() == ref
+        assert lab[0, int(n[0]):].cpu().tolist() == [-1] * (logits.shape[0] - int(n[0]))
+    rng = np.random.RandomState(1)
+    T, B, C = 700, 16, 62
+    logits = rng.randn(T, B, C).astype(np.float32)
+    logits[:, :, C - 1] += 2.0
+    logits[5:9] = logits[4]           # runs of identical frames (ties on repeats)
+    logits[20, :, 3] = logits[20, :, 7] = 50.0    # exact tie -> lowest index wins
+    sl = rng.randint(0, T + 1, size=B).astype(np.int32)
+    sl[0], sl[1] = T, 0
+    lab, n = ops.ctc_greedy_decode(torch.tensor(logits, device=cuda), torch.tensor(sl, device=cuda))
+    ref = odec.greedy_decode(logits.transpose(1, 0, 2), sl, C - 1)
+    for b in range(B):
+        assert lab[b, :int(n[b])].cpu().tolist() == ref[b]
+
+
+def test_softmax_rows(cuda):
+    ops = _ops()
+    x = torch.randn(100, 62, device=cuda) * 3
+    assert torch.allclose(ops.softmax_rows(x), torch.softmax(x, 1), atol=1e-6)
+
+
+# --------------------------------------------------------------------------- clip + optimizers
+def test_clip_decay_optimizers(cuda):
+    ops = _ops()
+    from tensorflow_end2end_speech_recognition_amd._lib import OPTIMIZER_IDS
+    rng = np.random.RandomState(0)
+    sizes = [5000, 16, 12288, 48, 1]
+    offs = np.concatenate([[0], np.cumsum([(s + 15) // 16 * 16 for s in sizes])]).astype(np.int64)
+    n = int(offs[-1])
+    g = np.zeros(n, np.float32)
+    p = np.zeros(n, np.float32)
+    for i, s in enumerate(sizes):
+        g[offs[i]:offs[i] + s] = rng.randn(s) * (10 if i % 2 == 0 else 0.001)
+        p[offs[i]:offs[i] + s] = rng.randn(s)
+    plan = ops.ClipPlan(offs, cuda)
+    gd = torch.tensor(g, device=cuda)
+    ops.clip_by_norm_multi(gd, plan, 5.0)
+    ref = g.copy()
+    for i, s in enumerate(sizes):
+        ref[offs[i]:offs[i] + s] = oopt.clip_by_norm(g[offs[i]:offs[i] + s], 5.0)
+    assert np.abs(gd.cpu().numpy() - ref).max() < 1e-5
+    mask = torch.tensor([1, 0, 1, 0, 1], dtype=torch.uint8, device=cuda)
+    pd = torch.tensor(p, device=cuda)
+    l2 = torch.zeros((), device=cuda)
+    g2 = torch.tensor(ref, device=cuda)
+    ops.weight_decay(g2, pd, plan, mask, 0.01, l2_out=l2)
+    exp = ref.copy()
+    tot = 0.0
+    for i, s in enumerate(sizes):
+        if i % 2 == 0:
+            exp[offs[i]:offs[i] + s] += 0.01 * p[offs[i]:offs[i] + s]
+            tot += 0.5 * (p[offs[i]:offs[i] + s].astype(np.float64) ** 2).sum()
+    assert np.abs(g2.cpu().numpy() - exp).max() < 1e-6
+    assert abs(l2.item() - 0.01 * tot) / (0.01 * tot) < 1e-5
+    for name, oid in OPTIMIZER_IDS.items():
+        pr = p.astype(np.float64)
+        s0, s1 = oopt.init_slots(name, pr)
+        pdv = torch.tensor(p, device=cuda)
+        d0 = torch.tensor(s0.astype(np.float32), device=cuda)
+        d1 = torch.tensor(s1.astype(np.float32), device=cuda)
+        for t in range(1, 4):
+            gt = (rng.randn(n) * 0.1).astype(np.float32)
+            pr, s0, s1 = oopt.step(name, pr, gt.astype(np.float64), s0, s1, 0.01, t)
+            ops.optimizer_step(oid, pdv, torch.tensor(gt, device=cuda), d0, d1, 0.01, t)
+        assert np.abs(pdv.cpu().numpy() - pr).max() < 2e-5, name
+
+
+def test_dropout_mask(cuda):
+    ops = _ops()
+    m = ops.dropout_mask((1000, 257), 0.8, seed=7, offset=0, device=cuda)
+    vals = torch.unique(m).cpu().tolist()
+    assert len(vals) == 2 and vals[0] == 0 and abs(vals[1] - 1.25) < 1e-6
+    assert abs((m > 0).float().mean().item() - 0.8) < 0.01
+    m2 = ops.dropout_mask((1000, 257), 0.8, seed=7, offset=0, device=cuda)
+    m3 = ops.dropout_mask((1000, 257), 0.8, seed=8, offset=0, device=cuda)
+    assert torch.equal(m, m2) and not torch.equal(m, m3)

@@ -1,0 +1,175 @@
+"""CPU: pin the oracle against the reference's own golden vectors and independent
+second implementations (torch.nn.LSTM, torch ctc_loss, finite differences)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc as octc
+from oracle import decoders as odec
+from oracle import lstm as olstm
+from oracle import model as omodel
+from oracle import optim as oopt
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_decoders_match_reference_golden():
+    g = np.load(os.path.join(GOLD, 'decoders_v1.npz'))
+    n = int(g['num_cases'])
+    assert n >= 20
+    for i in range(n):
+        probs, sl = g['c%d_probs' % i], g['c%d_seq_len' % i]
+        C = probs.shape[2]
+        lp = np.log(probs)
+        assert odec.greedy_decode(lp, sl, C - 1)[0] == list(g['c%d_greedy' % i])
+        for w in g['c%d_widths' % i]:
+            hyp, score = odec.beam_search_decode(lp, sl, C - 1, int(w))
+            assert hyp[0] == list(g['c%d_beam%d' % (i, w)]), (i, w)
+            assert abs(score[0] - float(g['c%d_beam%d_score' % (i, w)])) < 1e-9
+
+
+def _mk_lstm(D, H, seed=0):
+    rng = np.random.RandomState(seed)
+    return rng, olstm.init_lstm_params(rng, D, H), olstm.init_lstm_params(rng, D, H)
+
+
+def test_lstm_matches_torch_nn_lstm_without_peepholes():
+    B, T, D, H = 4, 11, 6, 5
+    rng, p_fw, p_bw = _mk_lstm(D, H)
+    for p in (p_fw, p_bw):
+        for k in ('wci', 'wcf', 'wco'):
+            p[k].zero_()
+        p['b'] = torch.tensor(rng.uniform(-.1, .1, 4 * H))
+    x = torch.tensor(rng.randn(B, T, D))
+    sl = torch.tensor([11, 7, 4, 1])
+    out, fin = olstm.blstm_layer(x.transpose(0, 1), sl, p_fw, p_bw)
+    m = torch.nn.LSTM(D, H, bidirectional=True).double()
+
+    def load(p, sfx):
+        def reorder(mat):  # i,g,f,o -> torch i,f,g,o
+            i, g, f, o = mat[:, :H], mat[:, H:2 * H], mat[:, 2 * H:3 * H], mat[:, 3 * H:]
+            return torch.cat([i, f, g, o], 1)
+        wr = reorder(p['w'])
+        fb = torch.cat([torch.zeros(2 * H), torch.ones(H), torch.zeros(H)]).double()
+        br = reorder((p['b'] + fb).unsqueeze(0))[0]
+        getattr(m, 'weight_ih_l0' + sfx).data = wr[:D].t().contiguous()
+        getattr(m, 'weight_hh_l0' + sfx).data = wr[D:].t().contiguous()
+        getattr(m, 'bias_ih_l0' + sfx).data = br
+        getattr(m, 'bias_hh_l0' + sfx).data.zero_()
+    load(p_fw, '')
+    load(p_bw, '_reverse')
+    pk = torch.nn.utils.rnn.pack_padded_sequence(x.transpose(0, 1), sl, enforce_sorted=True)
+    o, (hn, cn) = m(pk)
+    o, _ = torch.nn.utils.rnn.pad_packed_sequence(o, total_length=T)
+    assert (o - out).abs().max() < 1e-12
+    assert (hn[0] - fin[0][1]).abs().max() < 1e-12 and (cn[1] - fin[1][0]).abs().max() < 1e-12
+
+
+def test_lstm_peephole_cell_equations():
+    """models/recurrent/layers/lstm.py:142-170 written out by hand for one step."""
+    rng = np.random.RandomState(3)
+    D, H, B = 3, 2, 2
+    p = olstm.init_lstm_params(rng, D, H, init=0.5)
+    x, c0, h0 = (torch.tensor(rng.randn(B, n)) for n in (D, H, H))
+    c1, h1 = olstm.lstm_block_cell(x, c0, h0, p['w'], p['b'], p['wci'], p['wcf'], p['wco'], 1.0, 0.3)
+    z = np.concatenate([x.numpy(), h0.numpy()], 1) @ p['w'].numpy() + p['b'].numpy()
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    i, g, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
+    c = sig(f + 1.0 + p['wcf'].numpy() * c0.numpy()) * c0.numpy() + \
+        sig(i + p['wci'].numpy() * c0.numpy()) * np.tanh(g)
+    c = np.clip(c, -0.3, 0.3)
+    h = sig(o + p['wco'].numpy() * c) * np.tanh(c)
+    assert np.abs(c1.numpy() - c).max() < 1e-12 and np.abs(h1.numpy() - h).max() < 1e-12
+
+
+def test_padded_frames_are_zero_and_state_carried():
+    rng, p_fw, p_bw = _mk_lstm(4, 3, 1)
+    x = torch.tensor(rng.randn(2, 6, 4))
+    sl = torch.tensor([6, 2])
+    out, fin = olstm.blstm_layer(x.transpose(0, 1), sl, p_fw, p_bw)
+    assert out[2:, 1].abs().max() == 0
+    # fw final state of the short utterance == its output at its last valid frame
+    assert torch.allclose(fin[0][1][1], out[1, 1, :3])
+    assert torch.allclose(fin[1][1][1], out[0, 1, 3:])
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_ctc_matches_torch(seed):
+    rng = np.random.RandomState(seed)
+    T, B, C = 25, 5, 6
+    logits = rng.randn(T, B, C) * 2
+    sl = np.array([25, 20, 9, 13, 3])
+    labs = [[0, 1, 1, 2], [3, 3, 3], [], [4, 0, 4, 0, 1], [2, 2]]   # last one: needs 3 frames, feasible
+    loss, grad = octc.ctc_loss_batch(logits, labs, sl)
+    lt = torch.tensor(logits, requires_grad=True)
+    tl = torch.nn.functional.ctc_loss(lt.log_softmax(2), torch.tensor(sum(labs, []), dtype=torch.long),
+                                      torch.tensor(sl), torch.tensor([len(l) for l in labs]),
+                                      blank=C - 1, reduction='none', zero_infinity=True)
+    tl.sum().backward()
+    assert np.abs(loss - tl.detach().numpy()).max() < 1e-10
+    assert np.abs(grad - lt.grad.numpy()).max() < 1e-10
+    assert np.abs(grad[sl[2]:, 2]).max() == 0
+
+
+def test_ctc_infeasible_is_zero():
+    rng = np.random.RandomState(0)
+    logits = rng.randn(4, 1, 5)
+    loss, grad = octc.ctc_loss_batch(logits, [[1, 1, 1]], np.array([4]))   # needs 5 frames
+    assert loss[0] == 0 and np.abs(grad).max() == 0
+    with pytest.raises(ValueError):
+        octc.ctc_loss_batch(logits, [[1, 1, 1]], np.array([4]), ignore_longer=False)
+
+
+def test_ctc_model_gradient_finite_difference():
+    rng = np.random.RandomState(0)
+    B, T, D, H, C, L = 3, 8, 6, 4, 5, 2
+    sd = {}
+    for i in range(1, L + 1):
+        din = D if i == 1 else 2 * H
+        for d in ('fw', 'bw'):
+            p = olstm.init_lstm_params(rng, din, H, init=0.3)
+            base = 'blstm_hidden%d/%s/lstm_cell' % (i, d)
+            sd[base + '/kernel'] = p['w'].numpy()
+            sd[base + '/bias'] = p['b'].numpy()
+            sd[base + '/w_i_diag'], sd[base + '/w_f_diag'], sd[base + '/w_o_diag'] = \
+                p['wci'].numpy(), p['wcf'].numpy(), p['wco'].numpy()
+    sd['output/weights'] = rng.randn(2 * H, C) * .3
+    sd['output/biases'] = np.zeros(C)
+    x = rng.randn(B, T, D)
+    sl = np.array([8, 5, 7])
+    labs = [[0, 1], [2], [3, 3, 1]]
+    r = omodel.ctc_model_forward(sd, x, labs, sl, L, weight_decay=1e-3)
+    for k, idx in [('blstm_hidden1/bw/lstm_cell/kernel', (1, 2)), ('blstm_hidden2/fw/lstm_cell/w_o_diag', (1,)),
+                   ('blstm_hidden1/fw/lstm_cell/w_f_diag', (0,)), ('output/weights', (3, 1)),
+                   ('blstm_hidden2/bw/lstm_cell/bias', (5,))]:
+        eps = 1e-6
+        sd2 = {a: np.array(b, dtype=np.float64).copy() for a, b in sd.items()}
+        sd2[k][idx] += eps
+        r2 = omodel.ctc_model_forward(sd2, x, labs, sl, L, weight_decay=1e-3)
+        fd = (r2['total_loss'] - r['total_loss']) / eps
+        assert abs(fd - r['grads'][k][idx]) < 1e-5 * max(1, abs(fd)), k
+
+
+def test_optimizers_against_torch():
+    rng = np.random.RandomState(0)
+    p0 = rng.randn(50)
+    gs = [rng.randn(50) for _ in range(5)]
+    cases = {'sgd': lambda p: torch.optim.SGD([p], lr=0.1),
+             'momentum': lambda p: torch.optim.SGD([p], lr=0.1, momentum=0.9),
+             'adagrad': lambda p: torch.optim.Adagrad([p], lr=0.1, initial_accumulator_value=0.1, eps=0)}
+    for name, mk in cases.items():
+        p = p0.copy()
+        s0, s1 = oopt.init_slots(name, p)
+        tp = torch.tensor(p0.copy(), requires_grad=True)
+        opt = mk(tp)
+        for t, g in enumerate(gs, 1):
+            p, s0, s1 = oopt.step(name, p, g, s0, s1, 0.1, t)
+            tp.grad = torch.tensor(g)
+            opt.step()
+        assert np.abs(p - tp.detach().numpy()).max() < 1e-10, name
+    # clip_by_norm
+    g = rng.randn(10)
+    assert abs(np.linalg.norm(oopt.clip_by_norm(g, 0.5)) - 0.5) < 1e-12
+    assert np.allclose(oopt.clip_by_norm(g, 100.0), g)
