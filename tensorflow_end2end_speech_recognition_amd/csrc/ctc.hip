@@ -31,10 +31,24 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
   if (m == NEG_INF) return NEG_INF;
   return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
+// The alpha/beta recursions run in fp64: for T of several hundred frames the log-domain values
+// reach -1e3 and fp32 (what TF's CPU kernel uses) leaves ~1e-3 absolute error in the
+// posteriors.  The DP is latency-bound, MI355X has full-rate fp64 VALU, so this costs little.
+constexpr double DNEG_INF = -INFINITY;
+__device__ __forceinline__ double dlse2(double a, double b) {
+  const double m = fmax(a, b);
+  if (m == DNEG_INF) return DNEG_INF;
+  return m + log(exp(a - m) + exp(b - m));
+}
+__device__ __forceinline__ double dlse3(double a, double b, double c) {
+  const double m = fmax(fmax(a, b), c);
+  if (m == DNEG_INF) return DNEG_INF;
+  return m + log(exp(a - m) + exp(b - m) + exp(c - m));
+}
 
 // ---- 1. row log-sum-exp ---------------------------------------------------
 __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ x, int rows, int C,
-                                                      float* __restrict__ lse) {
+                                                      double* __restrict__ lse) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -42,10 +56,11 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
   float m = NEG_INF;
   for (int k = lane; k < C; k += 64) m = fmaxf(m, p[k]);
   m = wave_reduce_max(m);
-  float s = 0.f;
-  for (int k = lane; k < C; k += 64) s += expf(p[k] - m);
-  s = wave_reduce_sum(s);
-  if (lane == 0) lse[row] = m + logf(s);
+  double s = 0.0;
+  for (int k = lane; k < C; k += 64) s += exp((double)p[k] - (double)m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) lse[row] = (double)m + log(s);
 }
 
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x,
@@ -71,13 +86,13 @@ constexpr int AB_HALF = 256;
 constexpr int MAX_NS = 8;        // S <= 2048
 
 __global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
-    const float* __restrict__ logits, const float* __restrict__ lse, int T, int B, int C,
+    const float* __restrict__ logits, const double* __restrict__ lse, int T, int B, int C,
     const int32_t* __restrict__ labels_flat, const int32_t* __restrict__ label_offsets,
-    const int32_t* __restrict__ seq_len, int SW, float* __restrict__ alpha_ws,
-    float* __restrict__ beta_ws, int32_t* __restrict__ rank_ws, float* __restrict__ ll_ws,
+    const int32_t* __restrict__ seq_len, int SW, double* __restrict__ alpha_ws,
+    double* __restrict__ beta_ws, int32_t* __restrict__ rank_ws, double* __restrict__ ll_ws,
     float* __restrict__ loss, int32_t* __restrict__ num_infeasible) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* rowbuf = reinterpret_cast<float*>(smem);  // [2 (alpha/beta)][2 (ping/pong)][SW]
+  double* rowbuf = reinterpret_cast<double*>(smem);  // [2 (alpha/beta)][2 (ping/pong)][SW]
   const int b = blockIdx.x;
   const int blank = C - 1;
   const int lo = label_offsets[b];
@@ -87,8 +102,8 @@ __global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
   const int half = threadIdx.x / AB_HALF;  // 0 alpha, 1 beta
   const int tid = threadIdx.x % AB_HALF;
   const int32_t* lab = labels_flat + lo;
-  float* ws = (half == 0 ? alpha_ws : beta_ws) + (size_t)b * T * SW;
-  float* buf = rowbuf + half * 2 * SW;
+  double* ws = (half == 0 ? alpha_ws : beta_ws) + (size_t)b * T * SW;
+  double* buf = rowbuf + half * 2 * SW;
 
   // rank of each label among equal earlier labels (fixed summation order in the grad kernel)
   for (int i = threadIdx.x; i < L; i += AB_THREADS) {
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
   if (Tb <= 0 || L > (SW - 1) / 2) {
     if (threadIdx.x == 0) {
       loss[b] = 0.f;
-      ll_ws[b] = NEG_INF;
+      ll_ws[b] = DNEG_INF;
       if (num_infeasible && Tb > 0) atomicAdd(num_infeasible, 1);
     }
     return;
@@ -122,14 +137,14 @@ __global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
   const int t0 = half == 0 ? 0 : Tb - 1;
   const int dt = half == 0 ? 1 : -1;
   // emissions of the first frame
-  float lp[MAX_NS];
+  double lp[MAX_NS];
   {
     const float* row = logits + ((size_t)t0 * B + b) * C;
-    const float z = lse[(size_t)t0 * B + b];
+    const double z = lse[(size_t)t0 * B + b];
 #pragma unroll
     for (int n = 0; n < MAX_NS; ++n) {
       const int s = tid + n * AB_HALF;
-      lp[n] = (s < S) ? row[ext[n]] - z : NEG_INF;
+      lp[n] = (s < S) ? (double)row[ext[n]] - z : DNEG_INF;
     }
   }
   // init row
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
   for (int n = 0; n < MAX_NS; ++n) {
     const int s = tid + n * AB_HALF;
     if (s < S) {
-      float v = NEG_INF;
+      double v = DNEG_INF;
       if (half == 0) { if (s <= 1) v = lp[n]; }
       else { if (s >= S - 2) v = lp[n]; }
       buf[s] = v;
@@ -147,30 +162,30 @@ __global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
   __syncthreads();
   for (int step = 1; step < Tb; ++step) {
     const int t = t0 + dt * step;
-    const float* prev = buf + ((step - 1) & 1) * SW;
-    float* cur = buf + (step & 1) * SW;
+    const double* prev = buf + ((step - 1) & 1) * SW;
+    double* cur = buf + (step & 1) * SW;
     {
       const float* row = logits + ((size_t)t * B + b) * C;
-      const float z = lse[(size_t)t * B + b];
+      const double z = lse[(size_t)t * B + b];
 #pragma unroll
       for (int n = 0; n < MAX_NS; ++n) {
         const int s = tid + n * AB_HALF;
-        if (s < S) lp[n] = row[ext[n]] - z;
+        if (s < S) lp[n] = (double)row[ext[n]] - z;
       }
     }
 #pragma unroll
     for (int n = 0; n < MAX_NS; ++n) {
       const int s = tid + n * AB_HALF;
       if (s < S) {
-        float a0 = prev[s], a1, a2;
+        double a0 = prev[s], a1, a2;
         if (half == 0) {
-          a1 = s >= 1 ? prev[s - 1] : NEG_INF;
-          a2 = skp[n] ? prev[s - 2] : NEG_INF;
+          a1 = s >= 1 ? prev[s - 1] : DNEG_INF;
+          a2 = skp[n] ? prev[s - 2] : DNEG_INF;
         } else {
-          a1 = s + 1 < S ? prev[s + 1] : NEG_INF;
-          a2 = skp[n] ? prev[s + 2] : NEG_INF;
+          a1 = s + 1 < S ? prev[s + 1] : DNEG_INF;
+          a2 = skp[n] ? prev[s + 2] : DNEG_INF;
         }
-        const float v = lse3(a0, a1, a2) + lp[n];
+        const double v = dlse3(a0, a1, a2) + lp[n];
         cur[s] = v;
         ws[(size_t)t * SW + s] = v;
       }
@@ -178,22 +193,22 @@ __global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
     __syncthreads();
   }
   if (threadIdx.x == 0) {  // alpha half, thread 0
-    const float* last = buf + ((Tb - 1) & 1) * SW;
-    const float ll = lse2(last[S - 1], S >= 2 ? last[S - 2] : NEG_INF);
-    const bool ok = ll > NEG_INF;
-    loss[b] = ok ? -ll : 0.f;
-    ll_ws[b] = ok ? ll : NEG_INF;
+    const double* last = buf + ((Tb - 1) & 1) * SW;
+    const double ll = dlse2(last[S - 1], S >= 2 ? last[S - 2] : DNEG_INF);
+    const bool ok = ll > DNEG_INF;
+    loss[b] = ok ? (float)(-ll) : 0.f;
+    ll_ws[b] = ok ? ll : DNEG_INF;
     if (!ok && num_infeasible) atomicAdd(num_infeasible, 1);
   }
 }
 
 // ---- 3. gradient -------------------------------------------------------------
 __global__ __launch_bounds__(256) void ctc_grad_kernel(
-    const float* __restrict__ logits, const float* __restrict__ lse, int T, int B, int C,
+    const float* __restrict__ logits, const double* __restrict__ lse, int T, int B, int C,
     const int32_t* __restrict__ labels_flat, const int32_t* __restrict__ label_offsets,
-    const int32_t* __restrict__ seq_len, int SW, const float* __restrict__ alpha_ws,
-    const float* __restrict__ beta_ws, const int32_t* __restrict__ rank_ws,
-    const float* __restrict__ ll_ws, float grad_scale, float* __restrict__ grad) {
+    const int32_t* __restrict__ seq_len, int SW, const double* __restrict__ alpha_ws,
+    const double* __restrict__ beta_ws, const int32_t* __restrict__ rank_ws,
+    const double* __restrict__ ll_ws, float grad_scale, float* __restrict__ grad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* acc = reinterpret_cast<float*>(smem) + (size_t)wave * (C + SW);  // [C] occupation per class
@@ -203,8 +218,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
   if (t >= T) return;
   float* g = grad + ((size_t)t * B + b) * C;
   const int Tb = min(seq_len[b], T);
-  const float ll = ll_ws[b];
-  if (t >= Tb || !(ll > NEG_INF)) {
+  const double ll = ll_ws[b];
+  if (t >= Tb || !(ll > DNEG_INF)) {
     for (int k = lane; k < C; k += 64) g[k] = 0.f;
     return;
   }
@@ -214,18 +229,18 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
   const int blank = C - 1;
   const int32_t* lab = labels_flat + lo;
   const float* row = logits + ((size_t)t * B + b) * C;
-  const float z = lse[(size_t)t * B + b];
-  const float* al = alpha_ws + ((size_t)b * T + t) * SW;
-  const float* be = beta_ws + ((size_t)b * T + t) * SW;
+  const double z = lse[(size_t)t * B + b];
+  const double* al = alpha_ws + ((size_t)b * T + t) * SW;
+  const double* be = beta_ws + ((size_t)b * T + t) * SW;
 
   for (int k = lane; k < C; k += 64) acc[k] = 0.f;
   float blank_sum = 0.f;
   int maxrank = 0;
   for (int s = lane; s < S; s += 64) {
     const int e = (s & 1) ? lab[s >> 1] : blank;
-    const float lpv = row[e] - z;
-    const float v = al[s] + be[s] - lpv - ll;   // ln gamma_t(s); -inf/NaN-safe below
-    const float gm = (al[s] > NEG_INF && be[s] > NEG_INF) ? expf(v) : 0.f;
+    const double lpv = (double)row[e] - z;
+    const double v = al[s] + be[s] - lpv - ll;   // ln gamma_t(s); -inf/NaN-safe below
+    const float gm = (al[s] > DNEG_INF && be[s] > DNEG_INF) ? (float)exp(v) : 0.f;
     gam[s] = gm;
     if (!(s & 1)) blank_sum += gm;
     else maxrank = max(maxrank, rank_ws[(size_t)b * ((SW - 1) / 2) + (s >> 1)]);
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
   }
   for (int k = lane; k < C; k += 64) {
     const float occ = (k == blank) ? (acc[k] + blank_sum) : acc[k];
-    g[k] = (expf(row[k] - z) - occ) * grad_scale;
+    g[k] = ((float)exp((double)row[k] - z) - occ) * grad_scale;
   }
 }
 
@@ -309,11 +324,11 @@ inline CtcWs ctc_ws_layout(int T, int B, int Lmax) {
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   CtcWs w;
   size_t o = 0;
-  w.lse = o;   o += al((size_t)T * B * 4);
-  w.alpha = o; o += al((size_t)B * T * SW * 4);
-  w.beta = o;  o += al((size_t)B * T * SW * 4);
+  w.lse = o;   o += al((size_t)T * B * 8);
+  w.alpha = o; o += al((size_t)B * T * SW * 8);
+  w.beta = o;  o += al((size_t)B * T * SW * 8);
   w.rank = o;  o += al((size_t)B * (Lmax > 0 ? Lmax : 1) * 4);
-  w.ll = o;    o += al((size_t)B * 4);
+  w.ll = o;    o += al((size_t)B * 8);
   w.total = o;
   return w;
 }
@@ -341,17 +356,17 @@ extern "C" int asr_ctc_loss(asr_handle* h, const float* logits, int T, int B, in
   if (!workspace || workspace_bytes < w.total)
     ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_ctc_loss: workspace %zu < %zu bytes", workspace_bytes, w.total);
   char* ws = (char*)workspace;
-  float* lse = (float*)(ws + w.lse);
-  float* alpha = (float*)(ws + w.alpha);
-  float* beta = (float*)(ws + w.beta);
+  double* lse = (double*)(ws + w.lse);
+  double* alpha = (double*)(ws + w.alpha);
+  double* beta = (double*)(ws + w.beta);
   int32_t* rank = (int32_t*)(ws + w.rank);
-  float* ll = (float*)(ws + w.ll);
+  double* ll = (double*)(ws + w.ll);
   hipStream_t st = (hipStream_t)s;
   if (num_infeasible) (void)hipMemsetAsync(num_infeasible, 0, sizeof(int32_t), st);
   const int rows = T * B;
   hipLaunchKernelGGL(row_lse_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, rows, C, lse);
   ASR_CHECK_LAUNCH(h, "asr_ctc_loss(row_lse)");
-  const size_t lds_ab = (size_t)4 * SW * sizeof(float);
+  const size_t lds_ab = (size_t)4 * SW * sizeof(double);
   hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3(B), dim3(AB_THREADS), lds_ab, st, logits, lse, T, B, C,
                      labels_flat, label_offsets, seq_len, SW, alpha, beta, rank, ll, loss, num_infeasible);
   ASR_CHECK_LAUNCH(h, "asr_ctc_loss(alpha_beta)");

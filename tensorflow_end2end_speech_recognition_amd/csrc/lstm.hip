@@ -10,16 +10,18 @@
 //   len-1 .. 0 (reverse_sequence semantics).
 //
 // Mapping (MI355X-first, not a port of TF's per-step op):
-//   * one workgroup (4 waves) per (direction, 16-utterance batch tile) runs ALL T steps;
+//   * one workgroup (up to 16 waves = 4 per SIMD) per (direction, 16-utterance batch tile)
+//     runs ALL T steps;
 //     the 16 utterances are the M dimension of a 16x16 MFMA tile, so a lane of the C/D
 //     fragment permanently owns (utterance b = (lane>>4)*4+r, unit j = ub*16+(lane&15)):
 //     c, h, the peepholes and the four gate pre-activations of that (b,j) never leave
 //     its registers -> the gate math needs no cross-lane traffic.
-//   * wave w owns unit blocks ub = w, w+4, ...; for each it accumulates the four gate
+//   * wave w owns unit blocks ub = w, w+NW, ...; for each it accumulates the four gate
 //     tiles (i, ci, f, o) so one lane ends a step with all four gates of its (b,j).
 //   * h_{t-1} (16 x H) lives in LDS (double buffered, one barrier per step) as the MFMA
 //     A operand; W_h is pre-packed in B-fragment order so every wave-load is one
-//     contiguous 1 KiB (bf16) / 1 KiB (4 k-steps of fp32) line, streamed from L2 each step.
+//     contiguous 1 KiB line; as many k-chunks as fit are parked in LDS for the whole
+//     launch, the rest is streamed from L2 each step.
 //   * x W_x + b for step s+1 is prefetched into registers while step s computes; the
 //     same buffer is overwritten in place with the post-activation gates for BPTT.
 #include "common.h"
@@ -84,9 +86,45 @@ template <typename T> struct Frag;
 template <> struct Frag<float> { typedef f32x4_t type; };
 template <> struct Frag<bf16_t> { typedef bf16x8_t type; };
 
+// ---------------------------------------------------------------- gate math
+// v_exp_f32 / v_rcp_f32 forms (1 ulp each): a sigmoid is 4 VALU ops instead of the ~25 of
+// expf + IEEE division.  The recurrence is VALU-issue/latency bound, so this
+// and the wave count below are what set the step time, not HBM or the MFMA pipe.
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+}
+
+// waves per workgroup: the largest divisor of H/16 (unit blocks) that is <= 16, so that every
+// wave owns NUB = H/(16*NW) unit blocks and the CU runs up to 4 waves per SIMD.
+constexpr int pick_nw(int H) {
+  int nb = H / 16, best = 1;
+  for (int w = 1; w <= 16; ++w)
+    if (nb % w == 0) best = w;
+  return best;
+}
+// k-chunks of every (unit block, gate) tile of W_h parked in LDS for the whole launch
+// (the rest is streamed from L2 every step); sized to leave room for the h / dG buffers.
+template <typename T> constexpr int fwd_ksl(int H) {
+  const int tiles = (H / 16) * 4, ks = H / LT<T>::KV;
+  const long hbuf = 2L * 16 * (H + LT<T>::PAD) * (long)sizeof(T);
+  long k = (150L * 1024 - hbuf) / (tiles * 1024L);
+  if (k < 0) k = 0;
+  if (k > ks) k = ks;
+  return (int)(k & ~1L);   // even: keeps the streamed loop's trip count a multiple of its unroll
+}
+template <typename T> constexpr int bwd_ksl(int H, bool db) {
+  const int tiles = H / 16, ks = 4 * H / LT<T>::KV;
+  const long gbuf = (db ? 2L : 1L) * 16 * (4 * H + LT<T>::PAD) * (long)sizeof(T);
+  long k = (150L * 1024 - gbuf) / (tiles * 1024L);
+  if (k < 0) k = 0;
+  if (k > ks) k = ks;
+  return (int)(k & ~1L);   // even: keeps the streamed loop's trip count a multiple of its unroll
+}
+
 // ---------------------------------------------------------------- forward
-template <typename T, int H, int NW, bool PF>
-__global__ __launch_bounds__(NW * 64, NW / 4) void lstm_fwd_kernel(
+template <typename T, int H, int NW, int KSL, bool PF>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(
     int T_, int B_, int ndir, float* __restrict__ xg, const T* __restrict__ whp,
     const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
     float cell_clip, T* __restrict__ hout, float* __restrict__ cs, float* __restrict__ c_final,
@@ -94,15 +132,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void lstm_fwd_kernel(
   constexpr int NUB = H / (16 * NW);
   constexpr int KV = LT<T>::KV, KS = H / KV;
   constexpr int LDH = H + LT<T>::PAD;
+  constexpr int E = 16 / (int)sizeof(T);
   typedef typename Frag<T>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* hs = reinterpret_cast<T*>(smem);  // [2][16][LDH]
+  T* hs = reinterpret_cast<T*>(smem);                       // [2][16][LDH]
+  T* wl = hs + 2 * 16 * LDH;                                // [tile][KSL][64][E]  (LDS-resident W_h)
 
   const int d = blockIdx.y, b0 = blockIdx.x * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, rg = lane >> 4;
   const bool rev = (d == 1);
   const int G4 = ndir * 4 * H, G1 = ndir * H;
+  const T* wp = whp + (size_t)d * H * 4 * H;
 
   int len[4];
   int tmax = 0;
@@ -122,96 +163,115 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void lstm_fwd_kernel(
     for (int r = 0; r < 4; ++r) c[u][r] = hr[u][r] = 0.f;
   }
   for (int i = threadIdx.x; i < 2 * 16 * LDH; i += NW * 64) hs[i] = T(0);
+  // park the first KSL k-chunks of every tile in LDS (fragment order, 16 B per lane)
+  if (KSL > 0) {
+    constexpr int NT = (H / 16) * 4;
+    for (int f = threadIdx.x; f < NT * KSL * 64; f += NW * 64) {
+      const int l = f & 63, fk = (f >> 6) % KSL, tile = (f >> 6) / KSL;
+      const frag_t v = *reinterpret_cast<const frag_t*>(wp + (((size_t)tile * KS + fk) * 64 + l) * E);
+      *reinterpret_cast<frag_t*>(wl + (size_t)f * E) = v;
+    }
+  }
   __syncthreads();
 
-  const T* wp = whp + (size_t)d * H * 4 * H;
-
-  // prefetch registers for x W_x + b of the coming step
-  // (PF = false for H >= 512: 16xH (b,j) pairs x {4 acc, 4 prefetch, c, h} would not fit the
-  // 512 KB register file of one CU; there the loads are issued just before the MFMA chain.)
+  // x W_x + b of the coming step, prefetched while the current step computes
   float xn[NUB][4][4];
   auto prefetch = [&](int s) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool act = s < len[r];
-      const int t = rev ? len[r] - 1 - s : s;
-      const float* row = xg + ((size_t)(act ? t : 0) * B_ + b0 + rg * 4 + r) * G4 + d * 4 * H;
+      const int t = act ? (rev ? len[r] - 1 - s : s) : 0;
+      const float* row = xg + ((size_t)t * B_ + b0 + rg * 4 + r) * G4 + d * 4 * H + wave * 16 + col;
 #pragma unroll
       for (int u = 0; u < NUB; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          xn[u][q][r] = act ? row[q * H + (wave + NW * u) * 16 + col] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const float v = row[q * H + NW * 16 * u];     // padded frames hold finite junk: harmless
+          xn[u][q][r] = act ? v : 0.f;
+        }
     }
   };
   if (PF && tmax > 0) prefetch(0);
 
-  for (int s = 0; s < T_; ++s) {
-    if (s < tmax) {
-      const T* hcur = hs + (s & 1) * 16 * LDH;
-      T* hnxt = hs + ((s + 1) & 1) * 16 * LDH;
-      f32x4_t acc[NUB][4];
-      if (!PF) prefetch(s);
+  for (int s = 0; s < tmax; ++s) {
+    const T* hcur = hs + (s & 1) * 16 * LDH;
+    T* hnxt = hs + ((s + 1) & 1) * 16 * LDH;
+    f32x4_t acc[NUB][4];
+    if (!PF) prefetch(s);
+#pragma unroll
+    for (int u = 0; u < NUB; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u][q][r] = xn[u][q][r];
+    if (PF && s + 1 < tmax) prefetch(s + 1);
+
+    // LDS-resident k-chunks
+#pragma unroll
+    for (int ks = 0; ks < KSL; ++ks) {
+      const frag_t a = *reinterpret_cast<const frag_t*>(hcur + col * LDH + ks * KV + rg * E);
 #pragma unroll
       for (int u = 0; u < NUB; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[u][q][r] = xn[u][q][r];
-      if (PF && s + 1 < tmax) prefetch(s + 1);
-
+        for (int q = 0; q < 4; ++q) {
+          const int tile = (wave + NW * u) * 4 + q;
+          const frag_t b = *reinterpret_cast<const frag_t*>(wl + (((size_t)tile * KSL + ks) * 64 + lane) * E);
+          acc[u][q] = mma_chunk(a, b, acc[u][q]);
+        }
+    }
+    // k-chunks streamed from L2 (limited unroll: each chunk keeps 4*NUB 16-B loads in flight)
 #pragma unroll 2
-      for (int ks = 0; ks < KS; ++ks) {
-        const frag_t a = *reinterpret_cast<const frag_t*>(hcur + col * LDH + ks * KV + rg * (16 / (int)sizeof(T)));
+    for (int ks = KSL; ks < KS; ++ks) {
+      const frag_t a = *reinterpret_cast<const frag_t*>(hcur + col * LDH + ks * KV + rg * E);
 #pragma unroll
-        for (int u = 0; u < NUB; ++u)
+      for (int u = 0; u < NUB; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const size_t fi = ((size_t)((wave + NW * u) * 4 + q) * KS + ks) * 64 + lane;
-            const frag_t b = *reinterpret_cast<const frag_t*>(wp + fi * (16 / sizeof(T)));
-            acc[u][q] = mma_chunk(a, b, acc[u][q]);
-          }
-      }
+        for (int q = 0; q < 4; ++q) {
+          const int tile = (wave + NW * u) * 4 + q;
+          const frag_t b = *reinterpret_cast<const frag_t*>(wp + (((size_t)tile * KS + ks) * 64 + lane) * E);
+          acc[u][q] = mma_chunk(a, b, acc[u][q]);
+        }
+    }
 
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int brow = rg * 4 + r;
+      const bool act = s < len[r];
+      const int t = act ? (rev ? len[r] - 1 - s : s) : s;   // inactive: frame s is a padded frame
+      const size_t rowi = (size_t)t * B_ + b0 + brow;
+      float* gp = xg + rowi * G4 + d * 4 * H + wave * 16 + col;
+      float* cp_ = cs + rowi * G1 + d * H + wave * 16 + col;
+      T* hp = hout + rowi * G1 + d * H + wave * 16 + col;
 #pragma unroll
       for (int u = 0; u < NUB; ++u) {
-        const int j = (wave + NW * u) * 16 + col;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int brow = rg * 4 + r, b = b0 + brow;
-          const bool act = s < len[r];
-          const float cp = c[u][r];
-          const float ig = sigmoidf_(acc[u][0][r] + wci[u] * cp);
-          const float gg = tanhf_(acc[u][1][r]);
-          const float fg = sigmoidf_(acc[u][2][r] + forget_bias + wcf[u] * cp);
-          float cn = gg * ig + cp * fg;
-          if (cell_clip > 0.f) cn = fminf(fmaxf(cn, -cell_clip), cell_clip);
-          const float og = sigmoidf_(acc[u][3][r] + wco[u] * cn);
-          const float hn = tanhf_(cn) * og;
-          if (act) {
-            const int t = rev ? len[r] - 1 - s : s;
-            const size_t rowi = (size_t)t * B_ + b;
-            float* gp = xg + rowi * G4 + d * 4 * H + j;
-            gp[0] = ig; gp[H] = gg; gp[2 * H] = fg; gp[3 * H] = og;
-            cs[rowi * G1 + d * H + j] = cn;
-            hout[rowi * G1 + d * H + j] = Elem<T>::from_f32(hn);
-            c[u][r] = cn;
-            hr[u][r] = hn;
-          } else {
-            // frame s is a padded frame of utterance b in either direction
-            hout[((size_t)s * B_ + b) * G1 + d * H + j] = T(0);
-          }
-          hnxt[brow * LDH + j] = Elem<T>::from_f32(hr[u][r]);
+        const float cprev = c[u][r];
+        const float ig = fsig(acc[u][0][r] + wci[u] * cprev);
+        const float gg = ftanh(acc[u][1][r]);
+        const float fg = fsig(acc[u][2][r] + forget_bias + wcf[u] * cprev);
+        float cn = gg * ig + cprev * fg;
+        if (cell_clip > 0.f) cn = fminf(fmaxf(cn, -cell_clip), cell_clip);
+        const float og = fsig(acc[u][3][r] + wco[u] * cn);
+        const float hn = ftanh(cn) * og;
+        c[u][r] = act ? cn : cprev;
+        hr[u][r] = act ? hn : hr[u][r];
+        const int o = NW * 16 * u;
+        if (act) {
+          gp[o] = ig; gp[H + o] = gg; gp[2 * H + o] = fg; gp[3 * H + o] = og;
+          cp_[o] = cn;
         }
+        hp[o] = Elem<T>::from_f32(act ? hn : 0.f);
+        hnxt[brow * LDH + (wave + NW * u) * 16 + col] = Elem<T>::from_f32(hr[u][r]);
       }
-      __syncthreads();
-    } else {
-#pragma unroll
-      for (int u = 0; u < NUB; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          hout[((size_t)s * B_ + b0 + rg * 4 + r) * G1 + d * H + (wave + NW * u) * 16 + col] = T(0);
     }
+    __syncthreads();
   }
+  // zero-fill the common padded tail [tmax, T)
+  for (int s = tmax; s < T_; ++s)
+#pragma unroll
+    for (int u = 0; u < NUB; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        hout[((size_t)s * B_ + b0 + rg * 4 + r) * G1 + d * H + (wave + NW * u) * 16 + col] = T(0);
 #pragma unroll
   for (int u = 0; u < NUB; ++u)
 #pragma unroll
@@ -227,8 +287,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void lstm_fwd_kernel(
 //   do = dh*tanh(c)*o(1-o);  dc = dc_rec + dh*o*(1-tanh(c)^2) + do*wco
 //   dci = dc*i*(1-ci^2); di = dc*ci*i(1-i); df = dc*c_prev*f(1-f)
 //   dc_prev = dc*f + di*wci + df*wcf;  dh_prev = [di dci df do] W_h^T
-template <typename T, int H, bool DB, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void lstm_bwd_kernel(
+template <typename T, int H, bool DB, int NW, int KSL>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(
     int T_, int B_, int ndir, const float* __restrict__ dhout, const float* __restrict__ gates,
     const float* __restrict__ cs, const T* __restrict__ whpb, const float* __restrict__ peep,
     const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
@@ -236,15 +296,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void lstm_bwd_kernel(
   constexpr int NUB = H / (16 * NW);
   constexpr int KV = LT<T>::KV, KS = 4 * H / KV;
   constexpr int LDG = 4 * H + LT<T>::PAD;
+  constexpr int E = 16 / (int)sizeof(T);
   typedef typename Frag<T>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* dgs = reinterpret_cast<T*>(smem);  // [DB?2:1][16][LDG]
+  T* dgs = reinterpret_cast<T*>(smem);                      // [DB?2:1][16][LDG]
+  T* wl = dgs + (DB ? 2 : 1) * 16 * LDG;                    // [ub][KSL][64][E]
 
   const int d = blockIdx.y, b0 = blockIdx.x * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, rg = lane >> 4;
   const bool rev = (d == 1);
   const int G4 = ndir * 4 * H, G1 = ndir * H;
+  const T* wp = whpb + (size_t)d * H * 4 * H;
 
   int len[4];
   int tmax = 0;
@@ -269,9 +332,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void lstm_bwd_kernel(
       dcr[u][r] = d_c_final ? d_c_final[o] : 0.f;
     }
   }
-  const T* wp = whpb + (size_t)d * H * 4 * H;
+  if (KSL > 0) {
+    constexpr int NT = H / 16;
+    for (int f = threadIdx.x; f < NT * KSL * 64; f += NW * 64) {
+      const int l = f & 63, fk = (f >> 6) % KSL, tile = (f >> 6) / KSL;
+      const frag_t v = *reinterpret_cast<const frag_t*>(wp + (((size_t)tile * KS + fk) * 64 + l) * E);
+      *reinterpret_cast<frag_t*>(wl + (size_t)f * E) = v;
+    }
+  }
 
-  // zero-fill the padded tail frames [tmax, T)
+  // zero-fill the common padded tail frames [tmax, T)
   for (int s = T_ - 1; s >= tmax; --s)
 #pragma unroll
     for (int u = 0; u < NUB; ++u)
@@ -280,31 +350,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void lstm_bwd_kernel(
         T* gp = dgates + ((size_t)s * B_ + b0 + rg * 4 + r) * G4 + d * 4 * H + (wave + NW * u) * 16 + col;
         gp[0] = T(0); gp[H] = T(0); gp[2 * H] = T(0); gp[3 * H] = T(0);
       }
+  __syncthreads();
 
   for (int s = tmax - 1; s >= 0; --s) {
     T* dcur = dgs + (DB ? (s & 1) : 0) * 16 * LDG;
-    // ---- loads that do not depend on the recurrence (issued before the MFMA chain)
-    float gi[NUB][4], gg[NUB][4], gf[NUB][4], go[NUB][4], cc[NUB][4], cp[NUB][4], dho[NUB][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool act = s < len[r];
-      const int t = rev ? len[r] - 1 - s : s;
-      const int tp = rev ? t + 1 : t - 1;
-      const size_t rowi = (size_t)(act ? t : 0) * B_ + b0 + rg * 4 + r;
-      const size_t rowp = (size_t)((act && s > 0) ? tp : 0) * B_ + b0 + rg * 4 + r;
-#pragma unroll
-      for (int u = 0; u < NUB; ++u) {
-        const int j = (wave + NW * u) * 16 + col;
-        const float* gp = gates + rowi * G4 + d * 4 * H + j;
-        gi[u][r] = act ? gp[0] : 0.f;
-        gg[u][r] = act ? gp[H] : 0.f;
-        gf[u][r] = act ? gp[2 * H] : 0.f;
-        go[u][r] = act ? gp[3 * H] : 0.f;
-        cc[u][r] = act ? cs[rowi * G1 + d * H + j] : 0.f;
-        cp[u][r] = (act && s > 0) ? cs[rowp * G1 + d * H + j] : 0.f;
-        dho[u][r] = act ? dhout[rowi * G1 + d * H + j] : 0.f;
-      }
-    }
     // ---- dh_rec of this step = dG(step s+1) W_h^T, carried through inactive rows
     if (s != tmax - 1) {
       const T* dprev = dgs + (DB ? ((s + 1) & 1) : 0) * 16 * LDG;
@@ -312,14 +361,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void lstm_bwd_kernel(
 #pragma unroll
       for (int u = 0; u < NUB; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[u][r] = dhr[u][r];  // holds carry (inactive) or 0 (active)
-#pragma unroll 2
-      for (int ks = 0; ks < KS; ++ks) {
-        const frag_t a = *reinterpret_cast<const frag_t*>(dprev + col * LDG + ks * KV + rg * (16 / (int)sizeof(T)));
+        for (int r = 0; r < 4; ++r) acc[u][r] = dhr[u][r];  // carry (inactive) or 0 (active)
+#pragma unroll
+      for (int ks = 0; ks < KSL; ++ks) {
+        const frag_t a = *reinterpret_cast<const frag_t*>(dprev + col * LDG + ks * KV + rg * E);
 #pragma unroll
         for (int u = 0; u < NUB; ++u) {
-          const size_t fi = ((size_t)(wave + NW * u) * KS + ks) * 64 + lane;
-          const frag_t b = *reinterpret_cast<const frag_t*>(wp + fi * (16 / sizeof(T)));
+          const int tile = wave + NW * u;
+          const frag_t b = *reinterpret_cast<const frag_t*>(wl + (((size_t)tile * KSL + ks) * 64 + lane) * E);
+          acc[u] = mma_chunk(a, b, acc[u]);
+        }
+      }
+#pragma unroll 2
+      for (int ks = KSL; ks < KS; ++ks) {
+        const frag_t a = *reinterpret_cast<const frag_t*>(dprev + col * LDG + ks * KV + rg * E);
+#pragma unroll
+        for (int u = 0; u < NUB; ++u) {
+          const int tile = wave + NW * u;
+          const frag_t b = *reinterpret_cast<const frag_t*>(wp + (((size_t)tile * KS + ks) * 64 + lane) * E);
           acc[u] = mma_chunk(a, b, acc[u]);
         }
       }
@@ -329,41 +388,62 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void lstm_bwd_kernel(
         for (int r = 0; r < 4; ++r) dhr[u][r] = acc[u][r];
       if (!DB) __syncthreads();  // all reads of dgs done before it is overwritten
     }
-    // ---- gate gradients
+    // ---- loads that do not depend on the recurrence (after the MFMA chain: with 4 waves/SIMD other waves cover
+    //      the latency, and the two phases do not add up their register pressure)
+    float gi[NUB][4], gg[NUB][4], gf[NUB][4], go[NUB][4], cc[NUB][4], cp[NUB][4], dho[NUB][4];
 #pragma unroll
-    for (int u = 0; u < NUB; ++u) {
-      const int j = (wave + NW * u) * 16 + col;
+    for (int r = 0; r < 4; ++r) {
+      const bool act = s < len[r];
+      const int t = act ? (rev ? len[r] - 1 - s : s) : 0;
+      const bool hasp = act && s > 0;
+      const int tp = hasp ? (rev ? t + 1 : t - 1) : 0;
+      const size_t rowi = (size_t)t * B_ + b0 + rg * 4 + r;
+      const size_t rowp = (size_t)tp * B_ + b0 + rg * 4 + r;
+      const float* gp = gates + rowi * G4 + d * 4 * H + wave * 16 + col;
+      const float* cq = cs + rowi * G1 + d * H + wave * 16 + col;
+      const float* cpq = cs + rowp * G1 + d * H + wave * 16 + col;
+      const float* dq = dhout + rowi * G1 + d * H + wave * 16 + col;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int brow = rg * 4 + r, b = b0 + brow;
-        const bool act = s < len[r];
-        T* ls = dcur + brow * LDG + j;
-        if (act) {
-          const int t = rev ? len[r] - 1 - s : s;
-          const float dh = dho[u][r] + dhr[u][r];
-          const float tc = tanhf_(cc[u][r]);
-          const float o = go[u][r], i = gi[u][r], g = gg[u][r], f = gf[u][r];
-          const float d_o = dh * tc * o * (1.f - o);
-          const float dc = dcr[u][r] + dh * o * (1.f - tc * tc) + d_o * wco[u];
-          const float d_g = dc * i * (1.f - g * g);
-          const float d_i = dc * g * i * (1.f - i);
-          const float d_f = dc * cp[u][r] * f * (1.f - f);
-          dcr[u][r] = dc * f + d_i * wci[u] + d_f * wcf[u];
-          dhr[u][r] = 0.f;  // the MFMA of the next iteration supplies dh_prev
-          pwi[u] += d_i * cp[u][r];
-          pwf[u] += d_f * cp[u][r];
-          pwo[u] += d_o * cc[u][r];
-          const T ti = Elem<T>::from_f32(d_i), tg = Elem<T>::from_f32(d_g),
-                  tf = Elem<T>::from_f32(d_f), to = Elem<T>::from_f32(d_o);
-          T* gp = dgates + ((size_t)t * B_ + b) * G4 + d * 4 * H + j;
-          gp[0] = ti; gp[H] = tg; gp[2 * H] = tf; gp[3 * H] = to;
-          ls[0] = ti; ls[H] = tg; ls[2 * H] = tf; ls[3 * H] = to;
-        } else {
-          // padded frame s: zero gradient; (dh, dc) carried unchanged
-          T* gp = dgates + ((size_t)s * B_ + b) * G4 + d * 4 * H + j;
-          gp[0] = T(0); gp[H] = T(0); gp[2 * H] = T(0); gp[3 * H] = T(0);
-          ls[0] = T(0); ls[H] = T(0); ls[2 * H] = T(0); ls[3 * H] = T(0);
-        }
+      for (int u = 0; u < NUB; ++u) {
+        const int o = NW * 16 * u;
+        gi[u][r] = gp[o];
+        gg[u][r] = gp[H + o];
+        gf[u][r] = gp[2 * H + o];
+        go[u][r] = gp[3 * H + o];
+        cc[u][r] = cq[o];
+        const float cpv = cpq[o];
+        cp[u][r] = hasp ? cpv : 0.f;
+        dho[u][r] = dq[o];
+      }
+    }
+    // ---- gate gradients (predicated, no divergent control flow)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int brow = rg * 4 + r;
+      const bool act = s < len[r];
+      const int t = act ? (rev ? len[r] - 1 - s : s) : s;    // inactive: frame s is padded -> zeros
+      T* gp = dgates + ((size_t)t * B_ + b0 + brow) * G4 + d * 4 * H + wave * 16 + col;
+      T* ls = dcur + brow * LDG + wave * 16 + col;
+#pragma unroll
+      for (int u = 0; u < NUB; ++u) {
+        const float dh = dho[u][r] + dhr[u][r];
+        const float tc = ftanh(cc[u][r]);
+        const float o = go[u][r], i = gi[u][r], g = gg[u][r], f = gf[u][r];
+        const float d_o = dh * tc * o * (1.f - o);
+        const float dc = dcr[u][r] + dh * o * (1.f - tc * tc) + d_o * wco[u];
+        const float d_g = dc * i * (1.f - g * g);
+        const float d_i = dc * g * i * (1.f - i);
+        const float d_f = dc * cp[u][r] * f * (1.f - f);
+        dcr[u][r] = act ? (dc * f + d_i * wci[u] + d_f * wcf[u]) : dcr[u][r];
+        dhr[u][r] = act ? 0.f : dhr[u][r];   // active: the next MFMA supplies dh_prev
+        pwi[u] += act ? d_i * cp[u][r] : 0.f;
+        pwf[u] += act ? d_f * cp[u][r] : 0.f;
+        pwo[u] += act ? d_o * cc[u][r] : 0.f;
+        const T ti = Elem<T>::from_f32(act ? d_i : 0.f), tg = Elem<T>::from_f32(act ? d_g : 0.f),
+                tf = Elem<T>::from_f32(act ? d_f : 0.f), to = Elem<T>::from_f32(act ? d_o : 0.f);
+        const int oo = NW * 16 * u;
+        gp[oo] = ti; gp[H + oo] = tg; gp[2 * H + oo] = tf; gp[3 * H + oo] = to;
+        ls[oo] = ti; ls[H + oo] = tg; ls[2 * H + oo] = tf; ls[3 * H + oo] = to;
       }
     }
     __syncthreads();
@@ -399,9 +479,11 @@ template <typename T, int H>
 int launch_fwd(int T_, int B, int ndir, float* xg, const void* whp, const float* peep,
                const int32_t* seq_len, float fb, float clip, void* hout, float* cs, float* cf,
                float* hf, hipStream_t st) {
-  const size_t lds = (size_t)2 * 16 * (H + LT<T>::PAD) * sizeof(T);
-  constexpr int NW = (H >= 512) ? 8 : 4;
-  auto k = lstm_fwd_kernel<T, H, NW, (H < 512)>;
+  constexpr int NW = pick_nw(H);
+  constexpr int KSL = fwd_ksl<T>(H);
+  const size_t lds = (size_t)2 * 16 * (H + LT<T>::PAD) * sizeof(T) + (size_t)(H / 16) * 4 * KSL * 1024;
+  constexpr bool PF = (H / (16 * NW)) * NW <= 16;   // prefetch x W_x only when 128 VGPRs/wave can hold it
+  auto k = lstm_fwd_kernel<T, H, NW, KSL, PF>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(B / 16, ndir), dim3(NW * 64), lds, st, T_, B, ndir, xg, (const T*)whp, peep,
                      seq_len, fb, clip, (T*)hout, cs, cf, hf);
@@ -413,10 +495,11 @@ int launch_bwd(int T_, int B, int ndir, const float* dhout, const float* gates, 
                const void* whpb, const float* peep, const int32_t* seq_len, const float* dcf,
                const float* dhf, void* dgates, float* dpeep_part, hipStream_t st) {
   constexpr size_t one = (size_t)16 * (4 * H + LT<T>::PAD) * sizeof(T);
-  constexpr bool DB = (2 * one <= 150 * 1024);
-  const size_t lds = DB ? 2 * one : one;
-  constexpr int NW = (H >= 512) ? 8 : 4;
-  auto k = lstm_bwd_kernel<T, H, DB, NW>;
+  constexpr bool DB = (2 * one <= 72 * 1024);
+  constexpr int NW = pick_nw(H);
+  constexpr int KSL = bwd_ksl<T>(H, DB);
+  const size_t lds = (DB ? 2 * one : one) + (size_t)(H / 16) * KSL * 1024;
+  auto k = lstm_bwd_kernel<T, H, DB, NW, KSL>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(B / 16, ndir), dim3(NW * 64), lds, st, T_, B, ndir, dhout, gates, cs,
                      (const T*)whpb, peep, seq_len, dcf, dhf, (T*)dgates, dpeep_part);

@@ -97,9 +97,12 @@ def colsum(a, out=None):
     h = _h(a)
     dt = dtype_id(a.dtype)
     M, N = a.shape
+    if a.stride(1) != 1:
+        raise ValueError('colsum: inner stride must be 1')
     if out is None:
         out = torch.empty((N,), dtype=torch.float32, device=a.device)
-    h.check(h.lib.asr_colsum(h.h, dt, _p(a), M, N, a.stride(0), _p(out), _s()), 'asr_colsum')
+    h.check(h.lib.asr_colsum(h.h, dt, C.c_void_p(a.data_ptr()), M, N, a.stride(0), _p(out), _s()),
+            'asr_colsum')
     return out
 
 

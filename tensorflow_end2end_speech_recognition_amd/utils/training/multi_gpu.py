@@ -1,0 +1,64 @@
+"""Synchronous data-parallel gradient averaging -- the MI355X form of
+utils/training/multi_gpu.py:13-48 (average_gradients) + the tower loop of
+examples/librispeech/training/train_ctc.py:82-147.
+
+Reference: ONE process, N in-graph towers; per tower compute_gradients and per-variable
+clip_by_norm (train_ctc.py:112-117), then per variable stack the N tower gradients and
+reduce_mean (multi_gpu.py:32-40), one apply_gradients.
+Here: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI); every rank
+holds an identical replica, clips locally, then ONE all-reduce(sum) over the flat fp32
+gradient buffer of the ParamStore (a single contiguous bucket: 28 MB for the 5x256 BLSTM)
+followed by a 1/N scale -- the same mean over towers; every rank then applies the identical
+optimizer step, so replicas stay bit-identical without a broadcast after step 0.
+"""
+import torch
+import torch.distributed as dist
+
+from ... import ops
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def broadcast_parameters(store, src=0):
+    """Make replicas identical once, before the first step."""
+    if is_distributed():
+        dist.broadcast(store.flat, src=src)
+        store.mark_dirty()
+
+
+def average_gradients(store_or_tower_grads):
+    """ParamStore -> in-place mean of store.grad over all ranks.
+    (A list of per-tower gradient lists, the reference's calling convention, is averaged
+    on the host side of whatever device the tensors live on.)"""
+    if isinstance(store_or_tower_grads, (list, tuple)):
+        out = []
+        for grads in zip(*store_or_tower_grads):
+            gs = [g for g in grads if g is not None]          # multi_gpu.py:30-36 skips None
+            out.append(torch.stack(gs, 0).mean(0) if gs else None)
+        return out
+    store = store_or_tower_grads
+    if is_distributed():
+        dist.all_reduce(store.grad, op=dist.ReduceOp.SUM)
+        n = dist.get_world_size()
+        if store.grad.is_cuda:
+            ops.scale_(store.grad, 1.0 / n)
+        else:
+            store.grad.mul_(1.0 / n)
+    return store.grad
+
+
+def average_scalar(x):
+    """loss / LER are tower-averaged too (train_ctc.py:136-139)."""
+    if is_distributed():
+        t = x.detach().clone().float()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t / dist.get_world_size()
+    return x
+
+
+def split_batch(arrays, num_gpu):
+    """utils/dataset/ctc.py:171-182: np.array_split of every batch tensor along axis 0."""
+    import numpy as np
+    return [np.array_split(a, num_gpu, axis=0) for a in arrays]

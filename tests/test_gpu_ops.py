@@ -89,14 +89,14 @@ def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfin
     whf = torch.empty((ndir, 4 * H * H), dtype=tdt, device=cuda)
     whb = torch.empty_like(whf)
     for d, p in enumerate(ps):
-        w = torch.tensor(p['w'].numpy(), dtype=torch.float32, device=cuda)
+        w = torch.tensor(p['w'].detach().numpy(), dtype=torch.float32, device=cuda)
         wx = w[:D].to(tdt).contiguous()
-        ops.gemm(xd.view(T * B, D), wx, bias=torch.tensor(p['b'].numpy(), dtype=torch.float32, device=cuda),
+        ops.gemm(xd.view(T * B, D), wx, bias=torch.tensor(p['b'].detach().numpy(), dtype=torch.float32, device=cuda),
                  out=xproj.view(T * B, -1)[:, d * 4 * H:(d + 1) * 4 * H])
         pf, pb = ops.lstm_pack_wh(w[D:].contiguous(), dt)
         whf[d].copy_(pf)
         whb[d].copy_(pb)
-    peep = torch.tensor(np.stack([np.stack([p['wci'].numpy(), p['wcf'].numpy(), p['wco'].numpy()]) for p in ps]),
+    peep = torch.tensor(np.stack([np.stack([p['wci'].detach().numpy(), p['wcf'].detach().numpy(), p['wco'].detach().numpy()]) for p in ps]),
                         dtype=torch.float32, device=cuda)
     sl = torch.tensor(lens, dtype=torch.int32, device=cuda)
     hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, sl, H, ndir, dt, 1.0, cell_clip)
