@@ -93,41 +93,54 @@ int asr_gemm(asr_handle* h, int dtype, int out_dtype, int transA, int transB,
  * tf.nn.(bidirectional_)dynamic_rnn(sequence_length) --
  * models/encoders/core/blstm.py:286-323, lstm.py:253-285.
  *
- * Pack the recurrent weights W_h = kernel[Din:Din+H, :] ([H,4H] fp32, ld = 4H,
- * gate column blocks i, ci, f, o) of one direction into MFMA fragment order.
- *   fwd pack: B operand of  h[16,H] x W_h[H,4H]
- *   bwd pack: B operand of dG[16,4H] x W_h^T[4H,H]
- * Each packed buffer holds H*4H elements of `dtype`. */
-int asr_lstm_pack_wh(asr_handle* h, int dtype, const float* wh, int H,
-                     void* packed_fwd, void* packed_bwd, asr_stream s);
+ * Gate layout.  The TF variable `kernel` [Din+H, 4H] has gate-major columns q*H + j
+ * (q = i, ci, f, o).  The device-side activation tensors keep the four gates of a unit
+ * INTERLEAVED (column j*4 + q) so that the recurrence kernels move one 16-byte (fp32) or
+ * 8-byte (bf16) quadruple per (utterance, unit) pair:
+ *     xproj / gates / dgates : [T, B, ndir, H, 4]
+ *
+ * asr_lstm_prep_weights: once per (layer, direction) per step, from kernel/bias (fp32):
+ *   wx_il   [Din, 4H] `dtype`  W_x with interleaved columns (B operand of the hoisted GEMM)
+ *   bias_il [4H] fp32          bias, interleaved
+ *   packed_fwd / packed_bwd    W_h = kernel[Din:] in MFMA B-fragment order for
+ *                              h[16,H] x W_h  and  dG[16,4H] x W_h^T   (H*4H `dtype` each) */
+int asr_lstm_prep_weights(asr_handle* h, int dtype, const float* kernel, const float* bias,
+                          int Din, int H, void* wx_il, float* bias_il,
+                          void* packed_fwd, void* packed_bwd, asr_stream s);
+/* [rows, 4H] fp32 with interleaved columns -> gate-major columns (dW after the GEMMs) */
+int asr_gate_deinterleave(asr_handle* h, const float* in, int ld_in, float* out, int ld_out,
+                          int rows, int H, asr_stream s);
 
-/* Forward.  xproj[T,B,ndir*4H] fp32 = x*W_x + b (from asr_gemm) is overwritten IN
- * PLACE with the post-activation gates (i, ci, f, o) needed by backward.
+/* Forward.  xproj[T,B,ndir,H,4] fp32 = x*wx_il + bias_il (from asr_gemm).
  * wh_packed: ndir fwd-packed buffers back to back.  peep: [ndir][3][H] fp32
  * (w_i_diag, w_f_diag, w_o_diag) or NULL (use_peephole=False).
- * hout[T,B,ndir*H] in `dtype`: cell outputs, zero for t >= seq_len[b];
+ * gates[T,B,ndir,H,4] `dtype`: post-activation i, ci, f, o (valid frames only);
+ * hout[T,B,ndir*H] `dtype`: cell outputs, zero for t >= seq_len[b];
  * cs[T,B,ndir*H] fp32: cell state per frame (after clipping);
  * c_final/h_final [ndir][B][H] fp32 (may be NULL): state at the last valid step.
  * cell_clip <= 0 disables clipping.  B must be a multiple of 16 (pad with
- * seq_len 0 rows); H a multiple of 16. */
+ * seq_len 0 rows); H in {64,128,192,256,320,512}. */
 int asr_lstm_fwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
-                 float* xproj_gates, const void* wh_packed, const float* peep,
+                 const float* xproj, const void* wh_packed, const float* peep,
                  const int32_t* seq_len, float forget_bias, float cell_clip,
-                 void* hout, float* cs, float* c_final, float* h_final, asr_stream s);
+                 void* gates, void* hout, float* cs, float* c_final, float* h_final,
+                 asr_stream s);
 
 /* Backward through time.  dhout[T,B,ndir*H] fp32: gradient w.r.t. hout (already
  * multiplied by the dropout mask if any).  d_c_final/d_h_final [ndir][B][H] or NULL.
  * gates/cs from forward.  wh_packed_bwd: ndir bwd-packed buffers.
- * dgates[T,B,ndir*4H] in `dtype`: gradient w.r.t. the pre-activations (zero at
- * padded frames) -- feeds the dW_x, dW_h, db, dx GEMMs.
- * dpeep [ndir][3][H] fp32 (may be NULL): peephole gradients (overwritten);
- * dpeep_workspace: (B/16)*ndir*3*H floats (per batch-tile partials, reduced in a fixed
- * order so the result is run-to-run deterministic); required iff dpeep != NULL. */
+ * dgates[T,B,ndir,H,4] in `dtype`: gradient w.r.t. the pre-activations (interleaved, zero
+ * at padded frames) -- feeds the dW_x, dW_h, dx GEMMs.
+ * dpeep_dbias [ndir][7][H] fp32 (may be NULL; overwritten): rows 0-2 = gradients of the
+ * peepholes (w_i_diag, w_f_diag, w_o_diag), rows 3-6 = gradient of the bias, i.e. the column
+ * sums of dgates per gate block (i, ci, f, o) -- accumulated in registers during BPTT.
+ * dpeep_workspace: (B/16)*ndir*7*H floats (per batch-tile partials, reduced in a fixed
+ * order so the result is run-to-run deterministic); required iff dpeep_dbias != NULL. */
 int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
-                 const float* dhout, const float* gates, const float* cs,
+                 const float* dhout, const void* gates, const float* cs,
                  const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,
                  const float* d_c_final, const float* d_h_final,
-                 void* dgates, float* dpeep, float* dpeep_workspace, asr_stream s);
+                 void* dgates, float* dpeep_dbias, float* dpeep_workspace, asr_stream s);
 
 /* ---- CTC ------------------------------------------------------------------ *
  * tf.nn.ctc_loss(labels, logits, seq_len, preprocess_collapse_repeated=False,

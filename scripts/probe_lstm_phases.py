@@ -1,0 +1,27 @@
+import sys, os, ctypes
+os.environ['ASR_LSTM_DBG'] = '1'
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from bench import make_batch
+from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+from tensorflow_end2end_speech_recognition_amd import _lib
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dev = torch.device('cuda:0')
+x, sl, labels, dense = make_batch(1, 16, 120, 62, 100, 778)
+m = CTC('blstm', 120, H, 1, 61, dtype='bf16', seed=0)
+xd = torch.tensor(x, device=dev); sld = torch.tensor(sl, device=dev)
+for it in range(2):
+    loss, _ = m.compute_loss(xd, dense, sld, keep_prob=1.0, is_training=False)
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = (ctypes.c_ulonglong * 256)()
+lib.asr_debug_lstm_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
+print('rc', lib.asr_debug_lstm_cycles(buf, 256))
+a = np.array(list(buf), dtype=np.float64).reshape(2, 16, 8)
+names = ['top', 'lds_mfma', 'stream_mfma', 'gate', 'barrier']
+for d in range(2):
+    steps = a[d, 0, 5]
+    print('dir', d, 'steps', steps)
+    for w in (0, 1, 4, 8, 15):
+        print('  wave %2d: ' % w + '  '.join('%s %.0f' % (n, a[d, w, k] / max(steps, 1)) for k, n in enumerate(names)),
+              ' total/step %.0f' % (a[d, w, :5].sum() / max(steps, 1)))

@@ -11,6 +11,10 @@ struct asr_handle {
   int num_cu;
   char name[128];
   char err[512];
+  // device scratch owned by the handle (allocated once in asr_create, never in a hot call):
+  // split-K slabs of asr_gemm.  Calls on one handle are single-stream by contract.
+  void* scratch;
+  size_t scratch_bytes;
 };
 
 #define ASR_FAIL(h, code, ...)                                  \

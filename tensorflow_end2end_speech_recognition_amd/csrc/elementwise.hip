@@ -19,10 +19,17 @@ extern "C" int asr_create(asr_handle** out, int device) {
   h->num_cu = p.multiProcessorCount;
   snprintf(h->name, sizeof(h->name), "%s (%s)", p.name, p.gcnArchName);
   h->err[0] = 0;
+  h->scratch = nullptr;
+  h->scratch_bytes = (size_t)128 << 20;
+  if (hipMalloc(&h->scratch, h->scratch_bytes) != hipSuccess) {
+    delete h;
+    return ASR_ERR_HIP;
+  }
   *out = h;
   return ASR_OK;
 }
 extern "C" int asr_destroy(asr_handle* h) {
+  if (h && h->scratch) (void)hipFree(h->scratch);
   delete h;
   return ASR_OK;
 }
@@ -107,19 +114,30 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float ke
   }
 }
 
-// column sums: block (64 cols x 4 row-groups); fixed order -> deterministic
+// column sums, two deterministic stages: grid (col blocks, row blocks) -> partial[rb][N] -> out[N]
+constexpr int COLSUM_ROWS = 512;
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, int M, int N, int lda,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ partial) {
   __shared__ float part[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rgp = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
   float s = 0.f;
   if (col < N)
-    for (int m = rgp; m < M; m += 4) s += Elem<T>::to_f32(a[(size_t)m * lda + col]);
+    for (int m = r0 + rgp; m < r1; m += 4) s += Elem<T>::to_f32(a[(size_t)m * lda + col]);
   part[rgp][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rgp == 0 && col < N) out[col] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+  if (rgp == 0 && col < N)
+    partial[(size_t)blockIdx.y * N + col] =
+        part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int RB, int N, float* __restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float s = 0.f;
+  for (int r = 0; r < RB; ++r) s += partial[(size_t)r * N + col];
+  out[col] = s;
 }
 
 // ---- per-tensor L2 norms (two-stage, deterministic) + clip ----
@@ -297,8 +315,13 @@ extern "C" int asr_dropout_mask(asr_handle* h, float* mask, size_t n, float keep
 extern "C" int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N, int lda, float* out, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ASR_NEED(asr_dtype_ok(dtype) && a && out && M >= 0 && N > 0 && lda >= N, "asr_colsum: bad args");
-  if (dtype == ASR_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)s, (const float*)a, M, N, lda, out);
-  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, M, N, lda, out);
+  const int RB = (M + COLSUM_ROWS - 1) / COLSUM_ROWS > 0 ? (M + COLSUM_ROWS - 1) / COLSUM_ROWS : 1;
+  if ((size_t)RB * N * sizeof(float) > h->scratch_bytes) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_colsum: scratch too small");
+  float* partial = (float*)h->scratch;
+  const dim3 grid((N + 63) / 64, RB);
+  if (dtype == ASR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)a, M, N, lda, partial);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, M, N, lda, partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, partial, RB, N, out);
   ASR_CHECK_LAUNCH(h, "asr_colsum");
   return ASR_OK;
 }

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
                                                    int lda, const T* __restrict__ B, int ldb,
                                                    TO* __restrict__ C, int ldc,
                                                    const float* __restrict__ bias, int accumulate,
-                                                   int a_aligned, int b_aligned) {
+                                                   int a_aligned, int b_aligned, int kchunk,
+                                                   float* __restrict__ partial) {
   constexpr int BK = GT<T>::BK, VEC = GT<T>::VEC;
   constexpr int LDS_LD = BK + VEC;  // +16 B pad
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
@@ -120,17 +121,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nkt = (K + BK - 1) / BK;
-  la.load(A, lda, m0, 0, M, K, a_aligned);
-  lb.load(B, ldb, n0, 0, N, K, b_aligned);
+  // split-K: blockIdx.z owns the reduction range [kbeg, kend)
+  const int kbeg = blockIdx.z * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  la.load(A, lda, m0, kbeg, M, kend, a_aligned);
+  lb.load(B, ldb, n0, kbeg, N, kend, b_aligned);
   la.store(As, LDS_LD);
   lb.store(Bs, LDS_LD);
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) {
-      la.load(A, lda, m0, (kt + 1) * BK, M, K, a_aligned);
-      lb.load(B, ldb, n0, (kt + 1) * BK, N, K, b_aligned);
+      la.load(A, lda, m0, kbeg + (kt + 1) * BK, M, kend, a_aligned);
+      lb.load(B, ldb, n0, kbeg + (kt + 1) * BK, N, kend, b_aligned);
     }
     const int fr = lane & 15, fq = lane >> 4;
     if constexpr (sizeof(T) == 2) {
@@ -184,6 +188,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
         if (m >= M) continue;
+        if (partial) {  // split-K partial slab [z][M][N]; bias / accumulate applied by the reducer
+          partial[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];
+          continue;
+        }
         TO* cp = C + (size_t)m * ldc + n;
         float v = acc[i][j][r] + bv;
         if (accumulate) v += load_out<TO>(cp);
@@ -192,13 +200,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
     }
 }
 
+// fixed-order sum of the split-K slabs -> deterministic
+template <typename TO>
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
+                                     TO* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                     int accumulate) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int m = i / N, n = i % N;
+    float v = bias ? bias[n] : 0.f;
+    for (int z = 0; z < S; ++z) v += partial[(size_t)z * total + i];
+    TO* cp = C + (size_t)m * ldc + n;
+    if (accumulate) v += load_out<TO>(cp);
+    store_out<TO>(cp, v);
+  }
+}
+
 template <typename T, typename TO, int BM, int BN>
 int launch_layout(int transA, int transB, dim3 grid, size_t lds, hipStream_t st, int M, int N, int K,
                   const T* A, int lda, const T* B, int ldb, TO* C, int ldc, const float* bias,
-                  int accumulate, int aa, int ba) {
+                  int accumulate, int aa, int ba, int kchunk, float* partial) {
 #define ASR_GEMM_LAUNCH(TA_, TB_)                                                             \
   hipLaunchKernelGGL((gemm_kernel<T, TO, BM, BN, TA_, TB_>), grid, dim3(256), lds, st, M, N, K, A, \
-                     lda, B, ldb, C, ldc, bias, accumulate, aa, ba)
+                     lda, B, ldb, C, ldc, bias, accumulate, aa, ba, kchunk, partial)
   if (!transA && !transB) ASR_GEMM_LAUNCH(false, false);
   else if (!transA && transB) ASR_GEMM_LAUNCH(false, true);
   else if (transA && !transB) ASR_GEMM_LAUNCH(true, false);
@@ -208,8 +233,9 @@ int launch_layout(int transA, int transB, dim3 grid, size_t lds, hipStream_t st,
 }
 
 template <typename T, typename TO>
-int launch_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
-                int ldb, void* C, int ldc, const float* bias, int accumulate, hipStream_t st) {
+int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, const void* A, int lda,
+                const void* B, int ldb, void* C, int ldc, const float* bias, int accumulate,
+                hipStream_t st) {
   constexpr int VEC = GT<T>::VEC, BK = GT<T>::BK;
   const int aa = (((uintptr_t)A) % 16 == 0) && (lda % VEC == 0);
   const int ba = (((uintptr_t)B) % 16 == 0) && (ldb % VEC == 0);
@@ -219,12 +245,39 @@ int launch_gemm(int transA, int transB, int M, int N, int K, const void* A, int 
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     size_t lds = (size_t)(128 + 128) * (BK + VEC) * sizeof(T);
     return launch_layout<T, TO, 128, 128>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda,
-                                          (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba);
+                                          (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba, K, nullptr);
   }
-  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+  // small output, long reduction (the dW = X^T dG products: K = T*B): split K over blockIdx.z so
+  // the launch has >= ~2 workgroups per CU; slabs go to the handle's scratch and are summed in
+  // a fixed order (deterministic, unlike fp32 atomics).
+  int S = 1;
+  if (tiles64 < 256 && K >= 16 * BK) {
+    S = (int)((512 + tiles64 - 1) / tiles64);
+    const int maxS = K / (4 * BK);
+    if (S > maxS) S = maxS;
+    if (S > 64) S = 64;
+    while (S > 1 && (size_t)S * M * N * sizeof(float) > h->scratch_bytes) --S;
+  }
   size_t lds = (size_t)(64 + 64) * (BK + VEC) * sizeof(T);
-  return launch_layout<T, TO, 64, 64>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda,
-                                      (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba);
+  if (S <= 1) {
+    dim3 grid((N + 63) / 64, (M + 63) / 64);
+    return launch_layout<T, TO, 64, 64>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda,
+                                        (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba, K, nullptr);
+  }
+  int kchunk = (K + S - 1) / S;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  S = (K + kchunk - 1) / kchunk;
+  dim3 grid((N + 63) / 64, (M + 63) / 64, S);
+  float* partial = (float*)h->scratch;
+  launch_layout<T, TO, 64, 64>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda, (const T*)B, ldb,
+                               (TO*)C, ldc, nullptr, 0, aa, ba, kchunk, partial);
+  const size_t total = (size_t)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(blocks), dim3(256), 0, st, partial, S, M, N, (TO*)C, ldc,
+                     bias, accumulate);
+  return 0;
 }
 
 }  // namespace
@@ -243,13 +296,13 @@ extern "C" int asr_gemm(asr_handle* h, int dtype, int out_dtype, int transA, int
   if (M == 0 || N == 0) return ASR_OK;
   hipStream_t st = (hipStream_t)s;
   if (dtype == ASR_F32 && out_dtype == ASR_F32)
-    launch_gemm<float, float>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+    launch_gemm<float, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
   else if (dtype == ASR_F32 && out_dtype == ASR_BF16)
-    launch_gemm<float, bf16_t>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+    launch_gemm<float, bf16_t>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
   else if (dtype == ASR_BF16 && out_dtype == ASR_F32)
-    launch_gemm<bf16_t, float>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+    launch_gemm<bf16_t, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
   else
-    launch_gemm<bf16_t, bf16_t>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+    launch_gemm<bf16_t, bf16_t>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
   ASR_CHECK_LAUNCH(h, "asr_gemm");
   return ASR_OK;
 }

@@ -72,15 +72,17 @@ class LSTMLayer(object):
         wdt = torch.bfloat16 if dtype == ASR_BF16 else torch.float32
         whf = torch.empty((ndir, H * 4 * H), dtype=wdt, device=x.device)
         whb = torch.empty((ndir, H * 4 * H), dtype=wdt, device=x.device)
+        wx_il = []
         for d, base in enumerate(self.bases):
-            wx = sh[base + '/kernel'][:din]
-            ops.gemm(x2d, wx, bias=st[base + '/bias'], out=xp2d[:, d * 4 * H:(d + 1) * 4 * H])
-            h = ops._h(x)
-            h.check(h.lib.asr_lstm_pack_wh(h.h, dtype, ops._p(st[base + '/kernel'][din:]), H,
-                                           ops._p(whf[d]), ops._p(whb[d]), ops._s()), 'asr_lstm_pack_wh')
+            w = ops.lstm_prep_weights(st[base + '/kernel'], st[base + '/bias'], din, H, dtype,
+                                      out=dict(wx_il=torch.empty((din, 4 * H), dtype=wdt, device=x.device),
+                                               bias_il=torch.empty((4 * H,), dtype=torch.float32, device=x.device),
+                                               pf=whf[d], pb=whb[d]))
+            wx_il.append(w['wx_il'])
+            ops.gemm(x2d, w['wx_il'], bias=w['bias_il'], out=xp2d[:, d * 4 * H:(d + 1) * 4 * H])
         peep = self._peep()
-        hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, seq_len, H, ndir, dtype,
-                                        self.forget_bias, self.cell_clip or 0.0)
+        gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, seq_len, H, ndir, dtype,
+                                               self.forget_bias, self.cell_clip or 0.0)
         out = hout
         mask = None
         if is_training and (drop_mask is not None or keep_prob < 1.0):
@@ -91,8 +93,8 @@ class LSTMLayer(object):
                 mask = drop_mask
             out = ops.apply_mask(hout, mask)
         if save:
-            self.ctx = dict(x=x, gates=xproj, cs=cs, hout=hout, whb=whb, peep=peep, seq_len=seq_len,
-                            dtype=dtype, mask=mask)
+            self.ctx = dict(x=x, gates=gates, cs=cs, hout=hout, whb=whb, peep=peep, seq_len=seq_len,
+                            dtype=dtype, mask=mask, wx_il=wx_il)
         return out, (cf, hf)
 
     def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True):
@@ -107,29 +109,29 @@ class LSTMLayer(object):
         if c['mask'] is not None:
             dout = ops.apply_mask(dout, c['mask'])
         dgates, dpeep = ops.lstm_bwd(dout, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H,
-                                     ndir, dtype, d_c_final, d_h_final, want_dpeep=self.use_peephole)
+                                     ndir, dtype, d_c_final, d_h_final, want_dpeep=True)
         x2d = x.view(T * B, din)
         h2d = hout.view(T * B, ndir * H)
         dg2d = dgates.view(T * B, ndir * 4 * H)
         dx = torch.empty((T, B, din), dtype=torch.float32, device=x.device) if need_dx else None
+        dw_il = torch.empty((din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved columns
         for d, base in enumerate(self.bases):
             dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
-            gk = st.g(base + '/kernel')
-            ops.gemm(x2d, dg, transA=True, out=gk[:din], out_dtype=ASR_F32)
+            ops.gemm(x2d, dg, transA=True, out=dw_il[:din])
             if T > 1:
                 if d == 0:   # forward direction: h_prev(t) = h(t-1)
-                    ops.gemm(h2d[:(T - 1) * B, d * H:(d + 1) * H], dg[B:], transA=True, out=gk[din:])
+                    ops.gemm(h2d[:(T - 1) * B, d * H:(d + 1) * H], dg[B:], transA=True, out=dw_il[din:])
                 else:        # backward direction: h_prev(t) = h(t+1) (zero beyond len-1)
-                    ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=gk[din:])
+                    ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=dw_il[din:])
             else:
-                gk[din:].zero_()
-            ops.colsum(dg, out=st.g(base + '/bias'))
+                dw_il[din:].zero_()
+            ops.gate_deinterleave(dw_il, st.g(base + '/kernel'), H)
+            st.g(base + '/bias').copy_(dpeep[d, 3:7].reshape(-1))   # bias grad accumulated inside BPTT
             if self.use_peephole:
                 st.g(base + '/w_i_diag').copy_(dpeep[d, 0])
                 st.g(base + '/w_f_diag').copy_(dpeep[d, 1])
                 st.g(base + '/w_o_diag').copy_(dpeep[d, 2])
             if need_dx:
-                ops.gemm(dg, sh[base + '/kernel'][:din], transB=True, out=dx.view(T * B, din),
-                         accumulate=(d > 0))
+                ops.gemm(dg, c['wx_il'][d], transB=True, out=dx.view(T * B, din), accumulate=(d > 0))
         self.ctx = None
         return dx

@@ -137,22 +137,38 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, 
 
 
 # ---------------------------------------------------------------- LSTM
-def lstm_pack_wh(wh, dtype):
-    """wh [H,4H] fp32 -> (fwd-packed, bwd-packed) in `dtype`."""
-    h = _h(wh)
-    _chk(wh, torch.float32, 'wh')
-    H = wh.shape[0]
-    if wh.shape != (H, 4 * H):
-        raise ValueError('wh must be [H,4H]')
-    pf = torch.empty((H * 4 * H,), dtype=TORCH_DTYPE[dtype], device=wh.device)
-    pb = torch.empty_like(pf)
-    h.check(h.lib.asr_lstm_pack_wh(h.h, dtype, _p(wh), H, _p(pf), _p(pb), _s()), 'asr_lstm_pack_wh')
-    return pf, pb
+def lstm_prep_weights(kernel, bias, din, H, dtype, out=None):
+    """kernel [Din+H,4H] fp32 (TF layout), bias [4H] -> dict(wx_il [Din,4H] dtype, bias_il [4H] fp32,
+    pf, pb packed W_h fragments)."""
+    h = _h(kernel)
+    _chk(kernel, torch.float32, 'kernel')
+    if kernel.shape != (din + H, 4 * H):
+        raise ValueError('kernel must be [Din+H,4H]')
+    dev, tdt = kernel.device, TORCH_DTYPE[dtype]
+    if out is None:
+        out = dict(wx_il=torch.empty((din, 4 * H), dtype=tdt, device=dev),
+                   bias_il=torch.empty((4 * H,), dtype=torch.float32, device=dev),
+                   pf=torch.empty((H * 4 * H,), dtype=tdt, device=dev),
+                   pb=torch.empty((H * 4 * H,), dtype=tdt, device=dev))
+    h.check(h.lib.asr_lstm_prep_weights(h.h, dtype, _p(kernel), _p(bias), din, H, _p(out['wx_il']),
+                                        _p(out['bias_il']), _p(out['pf']), _p(out['pb']), _s()),
+            'asr_lstm_prep_weights')
+    return out
+
+
+def gate_deinterleave(src, dst, H):
+    """src [R,4H] fp32 interleaved columns -> dst [R,4H] gate-major (row strides honoured)."""
+    h = _h(src)
+    h.check(h.lib.asr_gate_deinterleave(h.h, C.c_void_p(src.data_ptr()), src.stride(0),
+                                        C.c_void_p(dst.data_ptr()), dst.stride(0), src.shape[0], H, _s()),
+            'asr_gate_deinterleave')
+    return dst
 
 
 def lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, cell_clip=0.0,
              want_final=True):
-    """xproj [T,B,ndir*4H] fp32 (overwritten with the gates).  Returns hout, cs, c_final, h_final."""
+    """xproj [T,B,ndir*4H] fp32 (interleaved gate layout [T,B,ndir,H,4]).
+    Returns gates, hout, cs, c_final, h_final."""
     h = _h(xproj)
     _chk(xproj, torch.float32, 'xproj')
     _chk(seq_len, torch.int32, 'seq_len')
@@ -160,14 +176,15 @@ def lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, c
     if G != ndir * 4 * H:
         raise ValueError('xproj last dim %d != ndir*4H' % G)
     dev = xproj.device
+    gates = torch.empty((T, B, ndir * 4 * H), dtype=TORCH_DTYPE[dtype], device=dev)
     hout = torch.empty((T, B, ndir * H), dtype=TORCH_DTYPE[dtype], device=dev)
     cs = torch.empty((T, B, ndir * H), dtype=torch.float32, device=dev)
     cf = torch.empty((ndir, B, H), dtype=torch.float32, device=dev) if want_final else None
     hf = torch.empty((ndir, B, H), dtype=torch.float32, device=dev) if want_final else None
     h.check(h.lib.asr_lstm_fwd(h.h, dtype, T, B, H, ndir, _p(xproj), _p(wh_packed), _p(peep),
-                               _p(seq_len), float(forget_bias), float(cell_clip or 0.0), _p(hout),
-                               _p(cs), _p(cf), _p(hf), _s()), 'asr_lstm_fwd')
-    return hout, cs, cf, hf
+                               _p(seq_len), float(forget_bias), float(cell_clip or 0.0), _p(gates),
+                               _p(hout), _p(cs), _p(cf), _p(hf), _s()), 'asr_lstm_fwd')
+    return gates, hout, cs, cf, hf
 
 
 def lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c_final=None,
@@ -179,8 +196,8 @@ def lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c
     dgates = torch.empty((T, B, ndir * 4 * H), dtype=TORCH_DTYPE[dtype], device=dev)
     dpeep = ws = None
     if want_dpeep:
-        dpeep = torch.empty((ndir, 3, H), dtype=torch.float32, device=dev)
-        ws = torch.empty(((B // 16) * ndir * 3 * H,), dtype=torch.float32, device=dev)
+        dpeep = torch.empty((ndir, 7, H), dtype=torch.float32, device=dev)   # 3 peephole + 4 bias rows
+        ws = torch.empty(((B // 16) * ndir * 7 * H,), dtype=torch.float32, device=dev)
     h.check(h.lib.asr_lstm_bwd(h.h, dtype, T, B, H, ndir, _p(dhout), _p(gates), _p(cs),
                                _p(wh_packed_bwd), _p(peep), _p(seq_len), _p(d_c_final), _p(d_h_final),
                                _p(dgates), _p(dpeep), _p(ws), _s()), 'asr_lstm_bwd')

@@ -27,7 +27,7 @@ def _rel(a, b):
 
 # --------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (130, 70, 45), (1, 62, 512), (257, 1024, 120),
-                                   (700, 130, 1000), (16, 16, 4), (3000, 2048, 120)])
+                                   (700, 130, 1000), (16, 16, 4), (3000, 2048, 120), (120, 1024, 5000)])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_f32(cuda, M, N, K, ta, tb):
     ops = _ops()
@@ -47,7 +47,8 @@ def test_gemm_f32(cuda, M, N, K, ta, tb):
     assert float(big[:, :4].min()) == 1.0 and float(big[:, 4 + N:].max()) == 1.0
 
 
-@pytest.mark.parametrize('M,N,K', [(64, 64, 64), (130, 70, 45), (257, 1024, 120), (3000, 2048, 512)])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 64), (130, 70, 45), (257, 1024, 120), (3000, 2048, 512),
+                                   (256, 1024, 12448)])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_bf16(cuda, M, N, K, ta, tb):
     ops = _ops()
@@ -89,26 +90,27 @@ def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfin
     whf = torch.empty((ndir, 4 * H * H), dtype=tdt, device=cuda)
     whb = torch.empty_like(whf)
     for d, p in enumerate(ps):
-        w = torch.tensor(p['w'].detach().numpy(), dtype=torch.float32, device=cuda)
-        wx = w[:D].to(tdt).contiguous()
-        ops.gemm(xd.view(T * B, D), wx, bias=torch.tensor(p['b'].detach().numpy(), dtype=torch.float32, device=cuda),
+        kernel = torch.tensor(p['w'].detach().numpy(), dtype=torch.float32, device=cuda)
+        bias = torch.tensor(p['b'].detach().numpy(), dtype=torch.float32, device=cuda)
+        w = ops.lstm_prep_weights(kernel, bias, D, H, dt)
+        ops.gemm(xd.view(T * B, D), w['wx_il'], bias=w['bias_il'],
                  out=xproj.view(T * B, -1)[:, d * 4 * H:(d + 1) * 4 * H])
-        pf, pb = ops.lstm_pack_wh(w[D:].contiguous(), dt)
-        whf[d].copy_(pf)
-        whb[d].copy_(pb)
+        whf[d].copy_(w['pf'])
+        whb[d].copy_(w['pb'])
     peep = torch.tensor(np.stack([np.stack([p['wci'].detach().numpy(), p['wcf'].detach().numpy(), p['wco'].detach().numpy()]) for p in ps]),
                         dtype=torch.float32, device=cuda)
     sl = torch.tensor(lens, dtype=torch.int32, device=cuda)
-    hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, sl, H, ndir, dt, 1.0, cell_clip)
+    gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, sl, H, ndir, dt, 1.0, cell_clip)
     res = dict(hout=hout.float().cpu().numpy(), cs=cs.cpu().numpy(), cf=cf.cpu().numpy(), hf=hf.cpu().numpy())
     if dout is not None:
         dcf = dhf = None
         if dfinal is not None:
             dcf = torch.tensor(dfinal[0], dtype=torch.float32, device=cuda)
             dhf = torch.tensor(dfinal[1], dtype=torch.float32, device=cuda)
-        dg, dpeep = ops.lstm_bwd(torch.tensor(dout, dtype=torch.float32, device=cuda), xproj, cs, whb, peep, sl,
+        dg, dpeep = ops.lstm_bwd(torch.tensor(dout, dtype=torch.float32, device=cuda), gates, cs, whb, peep, sl,
                                  H, ndir, dt, dcf, dhf)
-        res['dgates'] = dg.float().cpu().numpy()
+        # device layout [T,B,ndir,H,4] (gates interleaved) -> gate-major [T,B,ndir*4H] for the checks
+        res['dgates'] = dg.float().view(T, B, ndir, H, 4).permute(0, 1, 2, 4, 3).reshape(T, B, ndir * 4 * H).cpu().numpy()
         res['dpeep'] = dpeep.cpu().numpy()
     return res
 
@@ -200,8 +202,9 @@ def test_lstm_bwd_f32(cuda, T, B, D, H, ndir):
         dx += (g @ w[:D].T).reshape(T, B, D)
         assert _rel(np.concatenate([dwx, dwh], 0), ref['dw'][d]) < 1e-4
         assert _rel(g.sum(0), ref['db'][d]) < 1e-4
+        assert _rel(got['dpeep'][d, 3:7].reshape(-1), ref['db'][d]) < 1e-4
     assert _rel(dx, ref['dx']) < 1e-4
-    assert _rel(got['dpeep'], ref['dpeep']) < 1e-4
+    assert _rel(got['dpeep'][:, :3], ref['dpeep']) < 1e-4
     for b in range(B):
         if lens[b] < T:
             assert np.abs(got['dgates'][lens[b]:, b]).max() == 0
@@ -220,7 +223,7 @@ def test_lstm_bf16_and_wide(cuda, T, B, D, H, ndir):
     for dtype, tol in (('f32', 1e-4), ('bf16', 3e-2)):
         got = _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, 0.0, dout)
         assert np.abs(got['hout'] - ref['hout']).max() < tol
-        assert _rel(got['dpeep'], ref['dpeep']) < (1e-4 if dtype == 'f32' else 5e-2)
+        assert _rel(got['dpeep'][:, :3], ref['dpeep']) < (1e-4 if dtype == 'f32' else 5e-2)
 
 
 # --------------------------------------------------------------------------- CTC
