@@ -99,6 +99,9 @@ def main():
     ap.add_argument('--keep-prob', type=float, default=0.8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=1)
+    ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--cpu-tmax', type=int, default=256,
+                    help='CPU baseline sample: the same batch truncated to its first N frames')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -173,9 +176,13 @@ def main():
         dom = max(('lstm_fwd', 'lstm_bwd', 'gemm', 'ctc_loss'), key=lambda n: ks.get(n, {}).get('total_ms', 0))
         s_act = 2 if args.dtype == 'bf16' else 4
         # algorithmic HBM bytes per launch of the recurrence kernels (DESIGN.md "Kernels"):
-        #   fwd: read x W_x+b 16H, write gates 16H + c 4H + h s*H        per valid frame per direction
-        #   bwd: read gates 16H + c 4H + dh 4H, write dgates s*4H         per valid frame per direction
-        per_frame = {'lstm_fwd': 36 * H + s_act * H, 'lstm_bwd': 24 * H + s_act * 4 * H}
+        #   fwd: read x W_x+b 16H, write gates s*4H + c 4H + h s*H             per valid frame per direction
+        #   bwd: read gates s*4H + c 4H + dh 4H, write dgates s*4H              per valid frame per direction
+        per_frame = {'lstm_fwd': 20 * H + 5 * s_act * H, 'lstm_bwd': 8 * H + 8 * s_act * H}
+        # measured HBM bytes per launch for THIS default workload (profiles/r01_pmc_hbm.md:
+        # 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, gfx950 correction applied); null otherwise
+        default_cfg = (args.units, args.layers, args.batch, args.tmax, args.dtype) == (256, 5, 16, 778, 'bf16')
+        measured_traffic = {'lstm_bwd': 100.1e6, 'lstm_fwd': 102.8e6}
         flops_frame = 2 * 4 * H * H   # recurrent h W_h (fwd) / dG W_h^T (bwd), per frame per direction
         roof = None
         if dom in per_frame:
@@ -184,7 +191,8 @@ def main():
             dur = ks[dom]['avg_us'] * 1e-6
             ach = bytes_launch / dur / 1e9
             roof = dict(kernel=dom, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=ach / HBM_PEAK_GBS, traffic=None, avg_launch_us=ks[dom]['avg_us'],
+                        frac=ach / HBM_PEAK_GBS, traffic=(measured_traffic[dom] if default_cfg else None),
+                        avg_launch_us=ks[dom]['avg_us'],
                         algorithmic_bytes_per_launch=bytes_launch,
                         mfma_tflops=frames * 2 * flops_frame / dur / 1e12,
                         mfma_frac=frames * 2 * flops_frame / dur / 1e12 /
@@ -195,13 +203,21 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import fast_cpu
             sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
-            ncores = os.cpu_count() or 1
+            ncores = min(os.cpu_count() or 1, args.cpu_threads)
+            # bounded sample (10-30 s of CPU work): the same utterances cut to their first cpu_tmax frames
+            # (per-frame cost of the recurrence does not depend on T), labels cut to stay feasible
+            tcut = args.cpu_tmax
+            sl_c = np.minimum(seq_len, tcut)
+            x_c = x[:, :int(sl_c.max())].copy()
+            lab_c = [l[:max(1, int(n) // 8)] for l, n in zip(labels, sl_c)]
             cm = fast_cpu.CpuBLSTMCTC(sd, L, cell_clip=50.0, clip_grad_norm=5.0, threads=ncores)
-            t_cpu = fast_cpu.time_train_steps(cm, x, labels, seq_len, steps=args.cpu_steps, warmup=0)
-            cpu = dict(value=frames / t_cpu, unit='frames/s', cores=ncores, kind='port',
-                       sample='%d full training step(s) of the same %d-utterance batch (%d valid frames), '
-                              'torch-CPU fp32 restatement of the TF1 path (oracle/fast_cpu.py)'
-                              % (args.cpu_steps, args.batch, frames),
+            t_cpu = fast_cpu.time_train_steps(cm, x_c, lab_c, sl_c, steps=args.cpu_steps, warmup=0)
+            cframes = int(sl_c.sum())
+            cpu = dict(value=cframes / t_cpu, unit='frames/s', cores=ncores, kind='port',
+                       sample='%d training step(s) of the same %d-utterance batch truncated to its first %d '
+                              'frames (%d valid frames), torch-CPU fp32 restatement of the TF1 path '
+                              '(oracle/fast_cpu.py), %d threads of a %d-core host'
+                              % (args.cpu_steps, args.batch, tcut, cframes, ncores, os.cpu_count() or 1),
                        seconds_per_step=t_cpu)
         out = dict(metric='acoustic frames/sec (train), TIMIT-shaped BLSTM-CTC', value=value, unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -253,14 +253,20 @@ def softmax_rows(x2d):
 class ClipPlan(object):
     """Device-side description of a flat fp32 parameter buffer split into tensors."""
 
+    NORM_CHUNK = 4096   # == NORM_CHUNK in csrc/elementwise.hip (asr_clip_plan computes the same table)
+
     def __init__(self, offsets_host, device):
         off = np.asarray(offsets_host, dtype=np.int64)
         self.num_tensors = len(off) - 1
         cs = np.zeros(self.num_tensors + 1, dtype=np.int64)
-        lib = _lib.load()
-        hd = _lib.handle(device.index or 0)
-        hd.check(lib.asr_clip_plan(hd.h, off.ctypes.data_as(C.c_void_p), self.num_tensors,
-                                   cs.ctypes.data_as(C.c_void_p)), 'asr_clip_plan')
+        device = torch.device(device)
+        if device.type == 'cuda':
+            lib = _lib.load()
+            hd = _lib.handle(device.index or 0)
+            hd.check(lib.asr_clip_plan(hd.h, off.ctypes.data_as(C.c_void_p), self.num_tensors,
+                                       cs.ctypes.data_as(C.c_void_p)), 'asr_clip_plan')
+        else:   # host-only bookkeeping (CPU tests of the data-parallel logic); kernels still need a GPU
+            cs[1:] = np.cumsum((np.diff(off) + self.NORM_CHUNK - 1) // self.NORM_CHUNK)
         self.total_chunks = int(cs[-1])
         self.offsets = torch.from_numpy(off).to(device)
         self.chunk_start = torch.from_numpy(cs).to(device)

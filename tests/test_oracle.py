@@ -173,3 +173,33 @@ def test_optimizers_against_torch():
     g = rng.randn(10)
     assert abs(np.linalg.norm(oopt.clip_by_norm(g, 0.5)) - 0.5) < 1e-12
     assert np.allclose(oopt.clip_by_norm(g, 100.0), g)
+
+
+def test_fast_cpu_port_matches_oracle():
+    """oracle/fast_cpu.py (the cpu_baseline 'port' of bench.py) == the fp64 oracle."""
+    from oracle import fast_cpu
+    rng = np.random.RandomState(0)
+    B, T, D, H, C, L = 4, 12, 6, 8, 5, 2
+    sd = {}
+    for i in range(1, L + 1):
+        din = D if i == 1 else 2 * H
+        for d in ('fw', 'bw'):
+            p = olstm.init_lstm_params(rng, din, H)
+            base = 'blstm_hidden%d/%s/lstm_cell' % (i, d)
+            sd[base + '/kernel'], sd[base + '/bias'] = p['w'].numpy(), p['b'].numpy()
+            sd[base + '/w_i_diag'], sd[base + '/w_f_diag'], sd[base + '/w_o_diag'] = \
+                p['wci'].numpy(), p['wcf'].numpy(), p['wco'].numpy()
+    sd['output/weights'] = rng.randn(2 * H, C) * .1
+    sd['output/biases'] = np.zeros(C)
+    x = rng.randn(B, T, D)
+    sl = np.array([12, 7, 9, 3])
+    labs = [[0, 1], [2], [3, 3, 1], [0]]
+    for b in range(B):
+        x[b, sl[b]:] = 0
+    r = omodel.ctc_model_forward(sd, x, labs, sl, L, cell_clip=50.)
+    m = fast_cpu.CpuBLSTMCTC(sd, L, cell_clip=50.)
+    loss, _ = m.loss(x, labs, sl)
+    loss.backward()
+    assert abs(float(loss.detach()) - r['total_loss']) < 1e-5
+    assert max(np.abs(m.params[k].grad.numpy() - r['grads'][k]).max() for k in sd) < 1e-5
+    assert np.isfinite(m.train_step(x, labs, sl))
