@@ -166,6 +166,17 @@ int asr_ctc_greedy_decode(asr_handle* h, const float* logits, int T, int B, int 
                           const int32_t* seq_len, int blank,
                           int32_t* out_labels, int32_t* out_len, asr_stream s);
 
+/* Prefix beam search -- models/ctc/decoders/beam_search_decoder.py:53-152
+ * (also stands in for tf.nn.ctc_beam_search_decoder, models/ctc/ctc.py:344-346).
+ * logits[T,B,C] fp32 (log-softmax is taken inside); out_labels[B,T] padded -1;
+ * out_len[B]; out_score[B] = -log p of the best prefix (float64).
+ * beam_width <= 128.  Scores are fp64, ties are broken like the reference's stable sort. */
+size_t asr_ctc_beam_workspace_bytes(int T, int B, int C, int beam_width);
+int asr_ctc_beam_decode(asr_handle* h, const float* logits, int T, int B, int C,
+                        const int32_t* seq_len, int blank, int beam_width,
+                        int32_t* out_labels, int32_t* out_len, double* out_score,
+                        void* workspace, size_t workspace_bytes, asr_stream s);
+
 /* row softmax: CTC.posteriors (models/ctc/ctc.py:354-380) */
 int asr_softmax_rows(asr_handle* h, const float* in, float* out, int rows, int C, asr_stream s);
 

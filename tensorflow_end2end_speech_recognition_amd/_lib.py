@@ -38,6 +38,8 @@ SIGNATURES = {
     'asr_ctc_workspace_bytes': (_sz, [_i, _i, _i]),
     'asr_ctc_loss': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'asr_ctc_greedy_decode': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    'asr_ctc_beam_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'asr_ctc_beam_decode': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'asr_softmax_rows': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'asr_clip_plan': (_i, [_vp, _vp, _i, _vp]),
     'asr_clip_by_norm_multi': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _f, _vp, _vp]),

@@ -240,6 +240,26 @@ def ctc_greedy_decode(logits, seq_len, blank=None):
     return out, n
 
 
+def ctc_beam_decode(logits, seq_len, beam_width, blank=None):
+    """Prefix beam search.  logits [T,B,C] fp32 -> (labels [B,T] int32 padded -1, lengths [B],
+    scores [B] float64 = -log p of the best prefix)."""
+    h = _h(logits)
+    _chk(logits, torch.float32, 'logits')
+    _chk(seq_len, torch.int32, 'seq_len')
+    T, B, Cc = logits.shape
+    if blank is None:
+        blank = Cc - 1
+    dev = logits.device
+    nbytes = h.lib.asr_ctc_beam_workspace_bytes(T, B, Cc, int(beam_width))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, T), dtype=torch.int32, device=dev)
+    n = torch.empty((B,), dtype=torch.int32, device=dev)
+    score = torch.empty((B,), dtype=torch.float64, device=dev)
+    h.check(h.lib.asr_ctc_beam_decode(h.h, _p(logits), T, B, Cc, _p(seq_len), int(blank), int(beam_width),
+                                      _p(out), _p(n), _p(score), _p(ws), nbytes, _s()), 'asr_ctc_beam_decode')
+    return out, n, score
+
+
 def softmax_rows(x2d):
     h = _h(x2d)
     _chk(x2d, torch.float32, 'x')

@@ -310,6 +310,60 @@ def test_greedy_decode_bit_exact(cuda):
         assert lab[b, :int(n[b])].cpu().tolist() == ref[b]
 
 
+def test_beam_search_matches_reference_golden(cuda):
+    """Every golden case of the reference's numpy BeamSearchDecoder (beam widths 1..20): labels
+    bit-exact, -log score within 1e-5 (the kernel consumes fp32 logits = log of the golden fp64
+    posteriors; the search itself is fp64)."""
+    ops = _ops()
+    g = np.load(os.path.join(GOLD, 'decoders_v1.npz'))
+    checked = 0
+    for i in range(int(g['num_cases'])):
+        probs, sl = g['c%d_probs' % i], g['c%d_seq_len' % i]
+        C = probs.shape[2]
+        logits = np.log(probs).astype(np.float32).transpose(1, 0, 2).copy()     # [T,1,C]
+        for w in g['c%d_widths' % i]:
+            lab, n, score = ops.ctc_beam_decode(torch.tensor(logits, device=cuda), torch.tensor(sl, device=cuda), int(w))
+            ref = list(g['c%d_beam%d' % (i, w)])
+            assert lab[0, :int(n[0])].cpu().tolist() == ref, (i, int(w))
+            assert abs(score[0].item() - float(g['c%d_beam%d_score' % (i, w)])) < 1e-5 * max(1, abs(score[0].item()))
+            checked += 1
+    assert checked >= 40
+
+
+def test_decoder_classes_reference_signature(cuda):
+    """GreedyDecoder / BeamSearchDecoder called like the reference's numpy classes (probs [B,T,C])."""
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.decoders.greedy_decoder import GreedyDecoder
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.decoders.beam_search_decoder import BeamSearchDecoder
+    g = np.load(os.path.join(GOLD, 'decoders_v1.npz'))
+    for i in (0, 5, 8, 17):
+        probs, sl = g['c%d_probs' % i], g['c%d_seq_len' % i]
+        C = probs.shape[2]
+        assert GreedyDecoder(blank_index=C - 1)(probs, sl)[0] == list(g['c%d_greedy' % i])
+        w = int(g['c%d_widths' % i][-1])
+        hyp, score = BeamSearchDecoder(space_index=-1, blank_index=C - 1)(probs, sl, beam_width=w)
+        assert hyp[0] == list(g['c%d_beam%d' % (i, w)])
+
+
+def test_beam_search_batch_vs_oracle(cuda):
+    """A ragged batch at TIMIT shape (C=62, beam 20) and a wide-vocabulary case against the oracle."""
+    ops = _ops()
+    rng = np.random.RandomState(3)
+    for (T, B, C, W, sharp) in [(60, 6, 62, 20, 3.0), (30, 3, 300, 10, 4.0), (25, 2, 29, 100, 2.0)]:
+        logits = (rng.randn(T, B, C) * sharp).astype(np.float32)
+        logits[:, :, C - 1] += sharp
+        for t in range(1, T):
+            if rng.rand() < 0.3:
+                logits[t] = logits[t - 1]
+        sl = rng.randint(1, T + 1, size=B).astype(np.int32)
+        sl[0] = T
+        lab, n, score = ops.ctc_beam_decode(torch.tensor(logits, device=cuda), torch.tensor(sl, device=cuda), W)
+        lp = octc.log_softmax(logits.astype(np.float64).transpose(1, 0, 2))
+        ref, rs = odec.beam_search_decode(lp, sl, C - 1, W)
+        for b in range(B):
+            assert lab[b, :int(n[b])].cpu().tolist() == ref[b], (T, C, W, b)
+            assert abs(score[b].item() - rs[b]) < 1e-7 * max(1, abs(rs[b]))
+
+
 def test_softmax_rows(cuda):
     ops = _ops()
     x = torch.randn(100, 62, device=cuda) * 3
