@@ -142,6 +142,11 @@ int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
                  const float* d_c_final, const float* d_h_final,
                  void* dgates, float* dpeep_dbias, float* dpeep_workspace, asr_stream s);
 
+/* The bf16 H=256 recurrence runs as a cluster of 4 workgroups per direction that hand their
+ * slices of h / dh to each other inside the launch (bounded spins).  This synchronises the device
+ * and reports a hand-off timeout (never expected; ASR_ERR_HIP) -- call at a sync point. */
+int asr_check_async_errors(asr_handle* h, unsigned* flags_out);
+
 /* ---- CTC ------------------------------------------------------------------ *
  * tf.nn.ctc_loss(labels, logits, seq_len, preprocess_collapse_repeated=False,
  * ctc_merge_repeated=True, time_major=True) -- models/ctc/ctc.py:289-297,

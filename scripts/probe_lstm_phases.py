@@ -25,3 +25,15 @@ for d in range(2):
     for w in (0, 1, 4, 8, 15):
         print('  wave %2d: ' % w + '  '.join('%s %.0f' % (n, a[d, w, k] / max(steps, 1)) for k, n in enumerate(names)),
               ' total/step %.0f' % (a[d, w, :5].sum() / max(steps, 1)))
+
+if H == 256:
+    buf2 = (ctypes.c_ulonglong * 256)()
+    lib.asr_debug_cluster_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    if lib.asr_debug_cluster_cycles(buf2, 256) == 0:
+        a = np.array(list(buf2), dtype=np.float64).reshape(2, 4, 4, 8)
+        names = ['mfma', 'gate+publish', 'gather', 'barrier']
+        for d in range(2):
+            for g in range(4):
+                steps = a[d, g, 0, 5]
+                print('cluster dir', d, 'cu', g, ' '.join('%s %.0f' % (n, a[d, g, 0, k] / max(steps, 1)) for k, n in enumerate(names)),
+                      'total/step %.0f' % (a[d, g, 0, :4].sum() / max(steps, 1)))

@@ -71,5 +71,16 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
   return v;
 }
 
+// top ASR_XCH_BYTES of the scratch: granule exchange + error word of the multi-CU LSTM kernels
+static constexpr size_t ASR_XCH_BYTES = (size_t)16 << 20;
+bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* xproj,
+                         const void* whp, const float* peep, const int32_t* seq_len, float fb,
+                         float clip, void* gates, void* hout, float* cs, float* cf, float* hf,
+                         hipStream_t st);
+bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* dhout,
+                         const void* gates, const float* cs, const void* whpb, const float* peep,
+                         const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
+                         float* dpeep_part, hipStream_t st);
+
 static inline int asr_dtype_ok(int dt) { return dt == ASR_F32 || dt == ASR_BF16; }
 static inline size_t asr_dtype_size(int dt) { return dt == ASR_BF16 ? 2 : 4; }

@@ -25,6 +25,7 @@ extern "C" int asr_create(asr_handle** out, int device) {
     delete h;
     return ASR_ERR_HIP;
   }
+  (void)hipMemset((char*)h->scratch + h->scratch_bytes - ASR_XCH_BYTES, 0, ASR_XCH_BYTES);
   *out = h;
   return ASR_OK;
 }
@@ -316,7 +317,7 @@ extern "C" int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N,
   if (!h) return ASR_ERR_INVALID_ARG;
   ASR_NEED(asr_dtype_ok(dtype) && a && out && M >= 0 && N > 0 && lda >= N, "asr_colsum: bad args");
   const int RB = (M + COLSUM_ROWS - 1) / COLSUM_ROWS > 0 ? (M + COLSUM_ROWS - 1) / COLSUM_ROWS : 1;
-  if ((size_t)RB * N * sizeof(float) > h->scratch_bytes) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_colsum: scratch too small");
+  if ((size_t)RB * N * sizeof(float) > h->scratch_bytes - ASR_XCH_BYTES) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_colsum: scratch too small");
   float* partial = (float*)h->scratch;
   const dim3 grid((N + 63) / 64, RB);
   if (dtype == ASR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)a, M, N, lda, partial);

@@ -257,7 +257,7 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
     const int maxS = K / (4 * BK);
     if (S > maxS) S = maxS;
     if (S > 64) S = 64;
-    while (S > 1 && (size_t)S * M * N * sizeof(float) > h->scratch_bytes) --S;
+    while (S > 1 && (size_t)S * M * N * sizeof(float) > h->scratch_bytes - ASR_XCH_BYTES) --S;
   }
   size_t lds = (size_t)(64 + 64) * (BK + VEC) * sizeof(T);
   if (S <= 1) {

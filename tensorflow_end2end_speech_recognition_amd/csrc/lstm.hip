@@ -731,6 +731,12 @@ extern "C" int asr_lstm_fwd(asr_handle* h, int dtype, int T, int B, int H, int n
     ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_lstm_fwd: T*B*ndir*H exceeds 32-bit element offsets");
   if (T == 0) return ASR_OK;
   hipStream_t st = (hipStream_t)s;
+  // multi-CU form (W_h slices LDS-resident, per-step h all-gather between 4 CUs): lstm_cluster.hip
+  if (dtype == ASR_BF16 && asr_cluster_fwd_try(h, T, B, H, ndir, xproj, wh_packed, peep, seq_len, forget_bias,
+                                               cell_clip, gates, hout, cs, c_final, h_final, st)) {
+    ASR_CHECK_LAUNCH(h, "asr_lstm_fwd(cluster)");
+    return ASR_OK;
+  }
   if (dtype == ASR_F32) {
     ASR_H_DISPATCH(H, T, (launch_fwd<float, HH>(T, B, ndir, xproj, wh_packed, peep, seq_len, forget_bias,
                                                 cell_clip, gates, hout, cs, c_final, h_final, st)));
@@ -761,6 +767,11 @@ extern "C" int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int n
     return ASR_OK;
   }
   float* part = dpeep ? dpeep_workspace : nullptr;
+  bool launched = false;
+  if (dtype == ASR_BF16 && asr_cluster_bwd_try(h, T, B, H, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len,
+                                               d_c_final, d_h_final, dgates, part, st)) {
+    launched = true;
+  } else
   if (dtype == ASR_F32) {
     ASR_H_DISPATCH(H, T, (launch_bwd<float, HH>(T, B, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len,
                                                 d_c_final, d_h_final, dgates, part, st)));

@@ -1,0 +1,497 @@
+// LSTM recurrence, multi-CU form: the hidden units of one direction are split over a CLUSTER of
+// G = H/64 workgroups (one per CU), so that each CU's slice of W_h is resident in its LDS for the
+// whole launch and nothing is re-streamed from L2 per step.
+//
+// Why (measured): the single-CU kernels of lstm.hip spend 4.2-6.6k of their
+// 10.6k cycles/step pulling the 384-448 KB of W_h that does not fit on chip through the one CU's
+// L2 port (58 B/clk).  With G CUs the slice is H x 4*64 bf16 = 128 KB (H = 256) -> LDS.
+// The price is one all-gather of h (forward) / one reduce-scatter of dh (backward) per step
+// between the G CUs.  It is done with the placement-independent hand-off of
+// cdna_hip_programming.md G16 "R2": the data IS the flag -- 8-byte {tag = step+1, payload}
+// granules written with ONE relaxed agent-scope atomic store and polled with relaxed agent-scope
+// atomic loads; no fence, no separate flag, correct for any workgroup->XCD placement.
+// Slots are double-buffered by step parity (a producer can only reach step s+1 after every
+// consumer has consumed step s-1, see the comment at the poll).  Every spin is bounded: on
+// timeout the workgroup raises the error word and keeps going (garbage, but no hang).
+//
+// Same semantics / data layouts as lstm.hip (gates interleaved [T,B,dir,H,4], etc.).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned long long u64;
+typedef __attribute__((ext_vector_type(4))) __bf16 cbf16x4_t;
+
+constexpr int HS = 64;                 // units per CU
+constexpr int CW = HS / 16;            // waves per workgroup (one 16-unit block each)
+constexpr int CT = CW * 64;            // threads
+constexpr unsigned SPIN_LIMIT = 4000000u;
+
+__device__ __forceinline__ float cfsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float cftanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+  return __builtin_bit_cast(unsigned, (bf2){(__bf16)lo, (__bf16)hi});
+}
+__device__ __forceinline__ void gstore(u64* p, unsigned epoch, unsigned payload) {
+  __hip_atomic_store(p, ((u64)epoch << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gload(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ unsigned long long* g_cdbg = nullptr;   // debug phase timers (env ASR_LSTM_DBG=1)
+
+// ---------------------------------------------------------------- forward
+// grid (G, ndir, B/16); block CT.  xch: [ntile][ndir][2 parity][G][16][HS/2] granules.
+template <int H>
+__global__ __launch_bounds__(CT, 1) void lstm_fwd_cluster_kernel(
+    int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const bf16_t* __restrict__ whp,
+    const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
+    float cell_clip, cbf16x4_t* __restrict__ gates, bf16_t* __restrict__ hout, float* __restrict__ cs,
+    float* __restrict__ c_final, float* __restrict__ h_final, u64* __restrict__ xch,
+    unsigned* __restrict__ err) {
+  constexpr int G = H / HS;
+  constexpr int KS = H / 32;                 // k-chunks (16x16x32 MFMA)
+  constexpr int LDH = H + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* hs = reinterpret_cast<bf16_t*>(smem);            // [2][16][LDH]
+
+  const int g = blockIdx.x, d = blockIdx.y, b0 = blockIdx.z * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rg = lane >> 4;
+  const bool rev = (d == 1);
+  const bf16_t* wp = whp + (size_t)d * H * 4 * H;
+  const int ub = g * CW + wave;                            // global unit block of this wave
+  const unsigned jw = ub * 16 + col;                       // global unit of this lane
+
+  int len[4];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) len[r] = seq_len[b0 + rg * 4 + r];
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  float c[4], hr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = hr[r] = 0.f;
+  const float wci = peep ? peep[(d * 3 + 0) * H + jw] : 0.f;
+  const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
+  const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
+
+  for (int i = threadIdx.x; i < 2 * 16 * LDH; i += CT) hs[i] = 0;
+  // this wave's 4 gate tiles of W_h, all k-chunks: 32 fragments = 128 VGPRs, REGISTER-resident for
+  // the whole launch (one wave per SIMD owns the full 512-entry register file)
+  bf16x8_t wreg[4][KS];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wreg[q][ks] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)(ub * 4 + q) * KS + ks) * 64 + lane) * 8);
+  __syncthreads();
+
+  auto row_off = [&](int t, int brow) -> unsigned {
+    return ((unsigned)(t * B_ + b0 + brow) * ndir + d) * H + jw;
+  };
+  f32x4_t acc[4];
+  auto load_x = [&](int s) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = s < len[r];
+      const int t = act ? (rev ? len[r] - 1 - s : s) : 0;
+      const f32x4_t v = xg[row_off(t, rg * 4 + r)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q][r] = v[q];
+    }
+  };
+  if (tmax > 0) load_x(0);
+
+  u64* xbase = xch + ((size_t)(blockIdx.z * ndir + d) * 2) * G * 16 * (HS / 2);
+  bool timed_out = false;
+  unsigned long long* dbg = g_cdbg;
+  unsigned long long ph[4] = {0, 0, 0, 0};
+#define CDBG_T() (dbg ? (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime()) : 0ull)
+
+  for (int s = 0; s < tmax; ++s) {
+    const unsigned long long t0 = CDBG_T();
+    const bf16_t* hcur = hs + (s & 1) * 16 * LDH;
+    bf16_t* hnxt = hs + ((s + 1) & 1) * 16 * LDH;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(hcur + col * LDH + ks * 32 + rg * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wreg[q][ks], acc[q], 0, 0, 0);
+    }
+    if (dbg) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[q]));
+    }
+    const unsigned long long t1 = CDBG_T();
+    const unsigned epoch = (unsigned)s + 1u;
+    u64* xw = xbase + ((size_t)(s & 1) * G + g) * 16 * (HS / 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int brow = rg * 4 + r;
+      const bool act = s < len[r];
+      const int t = act ? (rev ? len[r] - 1 - s : s) : s;
+      const unsigned o = row_off(t, brow);
+      const float cprev = c[r];
+      const float ig = cfsig(acc[0][r] + wci * cprev);
+      const float gg = cftanh(acc[1][r]);
+      const float fg = cfsig(acc[2][r] + forget_bias + wcf * cprev);
+      float cn = gg * ig + cprev * fg;
+      if (cell_clip > 0.f) cn = fminf(fmaxf(cn, -cell_clip), cell_clip);
+      const float og = cfsig(acc[3][r] + wco * cn);
+      const float hn = cftanh(cn) * og;
+      c[r] = act ? cn : cprev;
+      hr[r] = act ? hn : hr[r];
+      if (act) {
+        gates[o] = (cbf16x4_t){(__bf16)ig, (__bf16)gg, (__bf16)fg, (__bf16)og};
+        cs[o] = cn;
+      }
+      hout[o] = __builtin_bit_cast(bf16_t, (__bf16)(act ? hn : 0.f));
+      // publish (h_j, h_j+1) of this row as one granule from the even lane; own slice also to LDS
+      const float hnb = __shfl_xor(hr[r], 1, 64);
+      const unsigned pk = pack_bf16x2(hr[r], hnb);
+      if (!(col & 1)) {
+        gstore(xw + brow * (HS / 2) + ((wave * 16 + col) >> 1), epoch, pk);
+        *reinterpret_cast<unsigned*>(hnxt + brow * LDH + jw) = pk;
+      }
+    }
+    if (s + 1 < tmax) load_x(s + 1);
+    const unsigned long long t2 = CDBG_T();
+    // gather the other G-1 slices of h_s.  Slot reuse is safe: a CU writes step s+2 into this
+    // parity only after it has consumed every step-s+1 slice, which the others publish only after
+    // they consumed step s.
+    {
+      constexpr int NG = (G - 1) * 16 * (HS / 2) / CT;     // granules per thread (6 for H = 256)
+      static_assert((G - 1) * 16 * (HS / 2) % CT == 0, "foreign granules must divide over the threads");
+      const u64* src[NG];
+      u64 v[NG];
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {                        // all loads in flight at once
+        const int i = threadIdx.x + k * CT;
+        const int gi = i / (16 * (HS / 2));
+        const int gsrc = gi + (gi >= g ? 1 : 0);
+        src[k] = xbase + ((size_t)(s & 1) * G + gsrc) * 16 * (HS / 2) + i % (16 * (HS / 2));
+        v[k] = gload(src[k]);
+      }
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) ok = ok && ((unsigned)(v[k] >> 32) == epoch);
+        if (ok) break;
+        if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+#pragma unroll
+        for (int k = 0; k < NG; ++k)
+          if ((unsigned)(v[k] >> 32) != epoch) v[k] = gload(src[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        const int i = threadIdx.x + k * CT;
+        const int gi = i / (16 * (HS / 2));
+        const int gsrc = gi + (gi >= g ? 1 : 0);
+        const int gran = i % (16 * (HS / 2));
+        const int row = gran / (HS / 2), pair = gran % (HS / 2);
+        *reinterpret_cast<unsigned*>(hnxt + row * LDH + gsrc * HS + pair * 2) = (unsigned)v[k];
+      }
+    }
+    const unsigned long long t3 = CDBG_T();
+    __syncthreads();
+    if (dbg) {
+      const unsigned long long t4 = CDBG_T();
+      ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
+    }
+  }
+  if (dbg && lane == 0 && blockIdx.z == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dbg[((size_t)(d * G + g) * CW + wave) * 8 + k] = ph[k];
+    dbg[((size_t)(d * G + g) * CW + wave) * 8 + 5] = tmax;
+  }
+  if (timed_out) atomicOr(err, 1u);
+  // zero-fill the common padded tail [tmax, T)
+  for (int s = tmax; s < T_; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hout[row_off(s, rg * 4 + r)] = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const size_t o = ((size_t)d * B_ + b0 + rg * 4 + r) * H + jw;
+    if (c_final) c_final[o] = c[r];
+    if (h_final) h_final[o] = hr[r];
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// K-partition: CU g owns the gate gradients of its 64 units (k' = unit*4+q in its slice) and the
+// rows k' of W_h^T; each step it multiplies its dG slice by W_h^T[k' slice, all H] -> a partial
+// dh_prev for ALL units, keeps the part for its own units and publishes the rest; the partials
+// for its own units from the other CUs are gathered at the next step (reduce-scatter).
+// xch: [ntile][ndir][2 parity][G dst][G src][16][HS] granules (fp32 payload).
+template <int H>
+__global__ __launch_bounds__(CT, 1) void lstm_bwd_cluster_kernel(
+    int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
+    const float* __restrict__ cs, const bf16_t* __restrict__ whpb, const float* __restrict__ peep,
+    const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
+    const float* __restrict__ d_h_final, cbf16x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
+    u64* __restrict__ xch, unsigned* __restrict__ err) {
+  constexpr int G = H / HS;
+  constexpr int KC = 4 * HS / 32;            // k-chunks of this CU's slice (8)
+  constexpr int KSF = 4 * H / 32;            // k-chunks of the full packing
+  constexpr int NT = H / 16;                 // output tiles (all units)
+  constexpr int LDG = 4 * HS + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* dgs = reinterpret_cast<bf16_t*>(smem);           // [16][LDG]   own dG slice (A operand)
+  float* own = reinterpret_cast<float*>(dgs + 16 * LDG);   // [CW][16][16] own-unit partials hand-over
+
+  const int g = blockIdx.x, d = blockIdx.y, b0 = blockIdx.z * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rg = lane >> 4;
+  const bool rev = (d == 1);
+  const bf16_t* wp = whpb + (size_t)d * H * 4 * H;
+  const int ub = g * CW + wave;
+  const unsigned jw = ub * 16 + col;
+
+  int len[4];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) len[r] = seq_len[b0 + rg * 4 + r];
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  auto row_off = [&](int t, int brow) -> unsigned {
+    return ((unsigned)(t * B_ + b0 + brow) * ndir + d) * H + jw;
+  };
+  auto frame = [&](int s, int r) -> int { return rev ? len[r] - 1 - s : s; };
+
+  const float wci = peep ? peep[(d * 3 + 0) * H + jw] : 0.f;
+  const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
+  const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
+  float dhr[4], dcr[4], cc[4];
+  float sums[7] = {0, 0, 0, 0, 0, 0, 0};     // dwci, dwcf, dwco, db_i, db_g, db_f, db_o
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const size_t o = ((size_t)d * B_ + b0 + rg * 4 + r) * H + jw;
+    dhr[r] = d_h_final ? d_h_final[o] : 0.f;
+    dcr[r] = d_c_final ? d_c_final[o] : 0.f;
+    const bool a0 = tmax > 0 && tmax - 1 < len[r];
+    cc[r] = a0 ? cs[row_off(frame(tmax - 1, r), rg * 4 + r)] : 0.f;
+  }
+  // W_h^T rows of this CU's k' slice (global chunks g*KC .. g*KC+KC-1) for the NT/CW = 4 output tiles
+  // this wave computes (nt = wave, wave+CW, ...): 32 fragments = 128 VGPRs, register-resident
+  bf16x8_t wreg[NT / CW][KC];
+#pragma unroll
+  for (int i = 0; i < NT / CW; ++i)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+      wreg[i][kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)(wave + i * CW) * KSF + g * KC + kc) * 64 + lane) * 8);
+  const cbf16x4_t gzero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+  for (int s = T_ - 1; s >= tmax; --s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dgates[row_off(s, rg * 4 + r)] = gzero;
+  __syncthreads();
+
+  u64* xbase = xch + ((size_t)(blockIdx.z * ndir + d) * 2) * G * G * 16 * HS;
+  bool timed_out = false;
+
+  for (int s = tmax - 1; s >= 0; --s) {
+    const unsigned epoch = (unsigned)(tmax - s);           // 1, 2, ... (never 0)
+    // ---- 1. dh_rec(own units) += partials the other CUs published at the previous iteration
+    if (s != tmax - 1) {
+      const int par = (s + 1) & 1;
+      const u64* src[4][G - 1];
+      u64 v[4][G - 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int gi = 0; gi < G - 1; ++gi) {                 // all 12 loads in flight at once
+          const int gsrc = gi + (gi >= g ? 1 : 0);
+          src[r][gi] = xbase + (((size_t)par * G + g) * G + gsrc) * 16 * HS + (rg * 4 + r) * HS + wave * 16 + col;
+          v[r][gi] = gload(src[r][gi]);
+        }
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int gi = 0; gi < G - 1; ++gi) ok = ok && ((unsigned)(v[r][gi] >> 32) == epoch - 1u);
+        if (ok) break;
+        if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int gi = 0; gi < G - 1; ++gi)
+            if ((unsigned)(v[r][gi] >> 32) != epoch - 1u) v[r][gi] = gload(src[r][gi]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float add = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < G - 1; ++gi) add += __uint_as_float((unsigned)v[r][gi]);   // fixed order
+        dhr[r] += add;
+      }
+    }
+    // ---- 2. gate gradients of the own units
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int brow = rg * 4 + r;
+      const bool act = s < len[r];
+      const bool hasp = act && s > 0;
+      const bool ldp = (s > 0) && (s - 1 < len[r]);
+      const unsigned offn = row_off(ldp ? frame(s - 1, r) : 0, brow);
+      const unsigned off = act ? row_off(frame(s, r), brow) : row_off(s, brow);
+      const unsigned offl = act ? off : offn;
+      const cbf16x4_t gv = gates[offl];
+      const float i = (float)gv[0], gq = (float)gv[1], f = (float)gv[2], oo = (float)gv[3];
+      const float cpv = cs[offn];
+      const float cprev = hasp ? cpv : 0.f;
+      const float dho = dhout[offl];
+      const float cur = cc[r];
+      const float dh = dho + dhr[r];
+      const float tc = cftanh(cur);
+      const float d_o = dh * tc * oo * (1.f - oo);
+      const float dc = dcr[r] + dh * oo * (1.f - tc * tc) + d_o * wco;
+      const float d_g = dc * i * (1.f - gq * gq);
+      const float d_i = dc * gq * i * (1.f - i);
+      const float d_f = dc * cprev * f * (1.f - f);
+      dcr[r] = act ? (dc * f + d_i * wci + d_f * wcf) : dcr[r];
+      dhr[r] = act ? 0.f : dhr[r];
+      const float zi = act ? d_i : 0.f, zg = act ? d_g : 0.f, zf = act ? d_f : 0.f, zo = act ? d_o : 0.f;
+      sums[0] += zi * cprev; sums[1] += zf * cprev; sums[2] += zo * cur;
+      sums[3] += zi; sums[4] += zg; sums[5] += zf; sums[6] += zo;
+      cc[r] = ldp ? cpv : 0.f;
+      const cbf16x4_t pk = {(__bf16)zi, (__bf16)zg, (__bf16)zf, (__bf16)zo};
+      dgates[off] = pk;
+      *reinterpret_cast<cbf16x4_t*>(dgs + brow * LDG + (wave * 16 + col) * 4) = pk;
+    }
+    __syncthreads();
+    // ---- 3. partial dh_prev for ALL units from the own dG slice; own part kept, rest published
+    if (s > 0) {
+      const int par = s & 1;
+#pragma unroll
+      for (int i = 0; i < NT / CW; ++i) {                  // 4 output tiles per wave
+        const int nt = wave + i * CW;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(dgs + col * LDG + kc * 32 + rg * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wreg[i][kc], acc, 0, 0, 0);
+        }
+        const int gdst = nt / CW, lw = nt % CW;            // tile nt belongs to CU gdst, its wave lw
+        if (gdst == g) {
+          // own units: tile nt == g*CW + lw is owned by wave lw -> hand over through LDS below
+#pragma unroll
+          for (int r = 0; r < 4; ++r) own[(lw * 16 + rg * 4 + r) * 16 + col] = acc[r];
+        } else {
+          u64* dst = xbase + (((size_t)par * G + gdst) * G + g) * 16 * HS;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            gstore(dst + (rg * 4 + r) * HS + lw * 16 + col, epoch, __float_as_uint(acc[r]));
+        }
+      }
+      __syncthreads();
+      // own part: wave `wave` picks up tile (g*CW + wave)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dhr[r] += own[(wave * 16 + rg * 4 + r) * 16 + col];
+    }
+  }
+  if (timed_out) atomicOr(err, 2u);
+  if (dpeep_part) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      sums[k] += __shfl_xor(sums[k], 16, 64);
+      sums[k] += __shfl_xor(sums[k], 32, 64);
+    }
+    if (rg == 0) {
+      float* p = dpeep_part + ((size_t)blockIdx.z * ndir + d) * 7 * H;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) p[k * H + jw] = sums[k];
+    }
+  }
+}
+
+static unsigned long long* g_cdbg_host = nullptr;
+static void cdbg_setup() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const char* e = getenv("ASR_LSTM_DBG");
+  if (!(e && e[0] == '1')) return;
+  (void)hipMalloc(&g_cdbg_host, 256 * sizeof(unsigned long long));
+  (void)hipMemset(g_cdbg_host, 0, 256 * sizeof(unsigned long long));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cdbg), &g_cdbg_host, sizeof(g_cdbg_host));
+}
+static bool cluster_enabled() {
+  static const bool on = [] { const char* e = getenv("ASR_LSTM_CLUSTER"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+}  // namespace
+
+static constexpr size_t XCH_BYTES = ASR_XCH_BYTES;
+
+bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* xproj,
+                         const void* whp, const float* peep, const int32_t* seq_len, float fb,
+                         float clip, void* gates, void* hout, float* cs, float* cf, float* hf,
+                         hipStream_t st) {
+  if (!cluster_enabled() || H != 256) return false;
+  cdbg_setup();
+  constexpr int HH = 256, G = HH / HS;
+  const size_t need = (size_t)(B / 16) * ndir * 2 * G * 16 * (HS / 2) * sizeof(u64);
+  if (need + 256 > XCH_BYTES || h->scratch_bytes < XCH_BYTES) return false;
+  char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+  u64* xch = (u64*)(base + 256);
+  unsigned* err = (unsigned*)base;
+  (void)hipMemsetAsync(xch, 0, need, st);                  // tags must not survive from a previous launch
+  const size_t lds = (size_t)2 * 16 * (HH + 8) * 2;
+  auto k = lstm_fwd_cluster_kernel<HH>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(G, ndir, B / 16), dim3(CT), lds, st, T, B, ndir, (const f32x4_t*)xproj,
+                     (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates, (bf16_t*)hout, cs, cf, hf,
+                     xch, err);
+  return true;
+}
+
+bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* dhout,
+                         const void* gates, const float* cs, const void* whpb, const float* peep,
+                         const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
+                         float* dpeep_part, hipStream_t st) {
+  if (!cluster_enabled() || H != 256) return false;
+  constexpr int HH = 256, G = HH / HS;
+  const size_t need = (size_t)(B / 16) * ndir * 2 * G * G * 16 * HS * sizeof(u64);
+  if (need + 256 > XCH_BYTES || h->scratch_bytes < XCH_BYTES) return false;
+  char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+  u64* xch = (u64*)(base + 256);
+  unsigned* err = (unsigned*)base;
+  (void)hipMemsetAsync(xch, 0, need, st);
+  const size_t lds = (size_t)16 * (4 * HS + 8) * 2 + (size_t)CW * 16 * 16 * 4;
+  auto k = lstm_bwd_cluster_kernel<HH>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(G, ndir, B / 16), dim3(CT), lds, st, T, B, ndir, dhout, (const cbf16x4_t*)gates, cs,
+                     (const bf16_t*)whpb, peep, seq_len, dcf, dhf, (cbf16x4_t*)dgates, dpeep_part, xch, err);
+  return true;
+}
+
+extern "C" int asr_debug_cluster_cycles(unsigned long long* out, int n) {
+  if (!g_cdbg_host || n > 256) return -1;
+  return hipMemcpy(out, g_cdbg_host, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+
+// Synchronises the device and returns the sticky error word of the cluster kernels
+// (bit 0: forward hand-off timed out, bit 1: backward); 0 = fine.
+extern "C" int asr_check_async_errors(asr_handle* h, unsigned* flags_out) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  unsigned v = 0;
+  char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(&v, base, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+    ASR_FAIL(h, ASR_ERR_HIP, "asr_check_async_errors: device error");
+  if (flags_out) *flags_out = v;
+  if (v) ASR_FAIL(h, ASR_ERR_HIP, "LSTM cluster hand-off timed out (flags 0x%x)", v);
+  return ASR_OK;
+}

@@ -204,6 +204,14 @@ def lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c
     return dgates, dpeep
 
 
+def check_async_errors(device=0):
+    """Device sync + sticky error word of the multi-CU LSTM kernels (raises on a hand-off timeout)."""
+    h = _lib.handle(device)
+    flags = C.c_uint(0)
+    h.check(h.lib.asr_check_async_errors(h.h, C.byref(flags)), 'asr_check_async_errors')
+    return flags.value
+
+
 # ---------------------------------------------------------------- CTC
 def ctc_loss(logits, labels_flat, label_offsets, seq_len, max_label_len, grad_scale=1.0,
              want_grad=True):
