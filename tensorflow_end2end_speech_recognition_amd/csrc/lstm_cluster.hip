@@ -96,15 +96,15 @@ __global__ __launch_bounds__(CT, 1) void lstm_fwd_cluster_kernel(
   auto row_off = [&](int t, int brow) -> unsigned {
     return ((unsigned)(t * B_ + b0 + brow) * ndir + d) * H + jw;
   };
-  f32x4_t acc[4];
+  // x W_x + b of the next step is prefetched into its own registers (xn) at the end of a step and
+  // only copied into the accumulators after the barrier, so no wait sits on the critical path
+  f32x4_t xn[4];
   auto load_x = [&](int s) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool act = s < len[r];
       const int t = act ? (rev ? len[r] - 1 - s : s) : 0;
-      const f32x4_t v = xg[row_off(t, rg * 4 + r)];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q][r] = v[q];
+      xn[r] = xg[row_off(t, rg * 4 + r)];
     }
   };
   if (tmax > 0) load_x(0);
@@ -119,6 +119,12 @@ __global__ __launch_bounds__(CT, 1) void lstm_fwd_cluster_kernel(
     const unsigned long long t0 = CDBG_T();
     const bf16_t* hcur = hs + (s & 1) * 16 * LDH;
     bf16_t* hnxt = hs + ((s + 1) & 1) * 16 * LDH;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] = xn[r][q];
+    if (s + 1 < tmax) load_x(s + 1);                       // lands during this step's MFMA + gate math
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(hcur + col * LDH + ks * 32 + rg * 8);
@@ -132,28 +138,40 @@ __global__ __launch_bounds__(CT, 1) void lstm_fwd_cluster_kernel(
     const unsigned long long t1 = CDBG_T();
     const unsigned epoch = (unsigned)s + 1u;
     u64* xw = xbase + ((size_t)(s & 1) * G + g) * 16 * (HS / 2);
+    // gate math, written stage-wise over the 4 rows so the independent chains interleave
+    bool act[4];
+    unsigned off[4];
+    float ig[4], gg[4], fg[4], og[4], cn[4], hn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      act[r] = s < len[r];
+      const int t = act[r] ? (rev ? len[r] - 1 - s : s) : s;
+      off[r] = row_off(t, rg * 4 + r);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ig[r] = cfsig(acc[0][r] + wci * c[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gg[r] = cftanh(acc[1][r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fg[r] = cfsig(acc[2][r] + forget_bias + wcf * c[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cn[r] = gg[r] * ig[r] + c[r] * fg[r];
+      if (cell_clip > 0.f) cn[r] = fminf(fmaxf(cn[r], -cell_clip), cell_clip);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) og[r] = cfsig(acc[3][r] + wco * cn[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hn[r] = cftanh(cn[r]) * og[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      c[r] = act[r] ? cn[r] : c[r];
+      hr[r] = act[r] ? hn[r] : hr[r];
+    }
+    // publish (h_j, h_j+1) of each row as one granule from the even lane; own slice also to LDS
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int brow = rg * 4 + r;
-      const bool act = s < len[r];
-      const int t = act ? (rev ? len[r] - 1 - s : s) : s;
-      const unsigned o = row_off(t, brow);
-      const float cprev = c[r];
-      const float ig = cfsig(acc[0][r] + wci * cprev);
-      const float gg = cftanh(acc[1][r]);
-      const float fg = cfsig(acc[2][r] + forget_bias + wcf * cprev);
-      float cn = gg * ig + cprev * fg;
-      if (cell_clip > 0.f) cn = fminf(fmaxf(cn, -cell_clip), cell_clip);
-      const float og = cfsig(acc[3][r] + wco * cn);
-      const float hn = cftanh(cn) * og;
-      c[r] = act ? cn : cprev;
-      hr[r] = act ? hn : hr[r];
-      if (act) {
-        gates[o] = (cbf16x4_t){(__bf16)ig, (__bf16)gg, (__bf16)fg, (__bf16)og};
-        cs[o] = cn;
-      }
-      hout[o] = __builtin_bit_cast(bf16_t, (__bf16)(act ? hn : 0.f));
-      // publish (h_j, h_j+1) of this row as one granule from the even lane; own slice also to LDS
       const float hnb = __shfl_xor(hr[r], 1, 64);
       const unsigned pk = pack_bf16x2(hr[r], hnb);
       if (!(col & 1)) {
@@ -161,7 +179,15 @@ __global__ __launch_bounds__(CT, 1) void lstm_fwd_cluster_kernel(
         *reinterpret_cast<unsigned*>(hnxt + brow * LDH + jw) = pk;
       }
     }
-    if (s + 1 < tmax) load_x(s + 1);
+    // saved activations (off the critical path: nothing waits on these stores)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (act[r]) {
+        gates[off[r]] = (cbf16x4_t){(__bf16)ig[r], (__bf16)gg[r], (__bf16)fg[r], (__bf16)og[r]};
+        cs[off[r]] = cn[r];
+      }
+      hout[off[r]] = __builtin_bit_cast(bf16_t, (__bf16)(act[r] ? hn[r] : 0.f));
+    }
     const unsigned long long t2 = CDBG_T();
     // gather the other G-1 slices of h_s.  Slot reuse is safe: a CU writes step s+2 into this
     // parity only after it has consumed every step-s+1 slice, which the others publish only after
@@ -296,6 +322,27 @@ __global__ __launch_bounds__(CT, 1) void lstm_bwd_cluster_kernel(
 
   u64* xbase = xch + ((size_t)(blockIdx.z * ndir + d) * 2) * G * G * 16 * HS;
   bool timed_out = false;
+  // saved activations of iteration s, fetched one iteration ahead: gates, c(s-1), dh, and the
+  // offset the gate gradient is written to (padded frame s for inactive rows -> zeros)
+  cbf16x4_t pg[4];
+  float pcp[4], pdh[4];
+  unsigned poff[4];
+  auto prefetch = [&](int s) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int brow = rg * 4 + r;
+      const bool act = s < len[r];
+      const bool ldp = (s > 0) && (s - 1 < len[r]);
+      const unsigned offn = row_off(ldp ? frame(s - 1, r) : 0, brow);
+      const unsigned off = act ? row_off(frame(s, r), brow) : row_off(s, brow);
+      const unsigned offl = act ? off : offn;
+      pg[r] = gates[offl];
+      pcp[r] = cs[offn];
+      pdh[r] = dhout[offl];
+      poff[r] = off;
+    }
+  };
+  if (tmax > 0) prefetch(tmax - 1);
 
   for (int s = tmax - 1; s >= 0; --s) {
     const unsigned epoch = (unsigned)(tmax - s);           // 1, 2, ... (never 0)
@@ -335,39 +382,46 @@ __global__ __launch_bounds__(CT, 1) void lstm_bwd_cluster_kernel(
         dhr[r] += add;
       }
     }
-    // ---- 2. gate gradients of the own units
+    // ---- 2. gate gradients of the own units (inputs were prefetched one iteration ahead)
+    {
+      bool act[4], hasp[4];
+      float gi[4], gq[4], gf[4], go[4], cprev[4], cur[4], dh[4], tc[4], d_o[4], dc[4], d_g[4], d_i[4], d_f[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int brow = rg * 4 + r;
-      const bool act = s < len[r];
-      const bool hasp = act && s > 0;
-      const bool ldp = (s > 0) && (s - 1 < len[r]);
-      const unsigned offn = row_off(ldp ? frame(s - 1, r) : 0, brow);
-      const unsigned off = act ? row_off(frame(s, r), brow) : row_off(s, brow);
-      const unsigned offl = act ? off : offn;
-      const cbf16x4_t gv = gates[offl];
-      const float i = (float)gv[0], gq = (float)gv[1], f = (float)gv[2], oo = (float)gv[3];
-      const float cpv = cs[offn];
-      const float cprev = hasp ? cpv : 0.f;
-      const float dho = dhout[offl];
-      const float cur = cc[r];
-      const float dh = dho + dhr[r];
-      const float tc = cftanh(cur);
-      const float d_o = dh * tc * oo * (1.f - oo);
-      const float dc = dcr[r] + dh * oo * (1.f - tc * tc) + d_o * wco;
-      const float d_g = dc * i * (1.f - gq * gq);
-      const float d_i = dc * gq * i * (1.f - i);
-      const float d_f = dc * cprev * f * (1.f - f);
-      dcr[r] = act ? (dc * f + d_i * wci + d_f * wcf) : dcr[r];
-      dhr[r] = act ? 0.f : dhr[r];
-      const float zi = act ? d_i : 0.f, zg = act ? d_g : 0.f, zf = act ? d_f : 0.f, zo = act ? d_o : 0.f;
-      sums[0] += zi * cprev; sums[1] += zf * cprev; sums[2] += zo * cur;
-      sums[3] += zi; sums[4] += zg; sums[5] += zf; sums[6] += zo;
-      cc[r] = ldp ? cpv : 0.f;
-      const cbf16x4_t pk = {(__bf16)zi, (__bf16)zg, (__bf16)zf, (__bf16)zo};
-      dgates[off] = pk;
-      *reinterpret_cast<cbf16x4_t*>(dgs + brow * LDG + (wave * 16 + col) * 4) = pk;
+      for (int r = 0; r < 4; ++r) {
+        act[r] = s < len[r];
+        hasp[r] = act[r] && s > 0;
+        gi[r] = (float)pg[r][0]; gq[r] = (float)pg[r][1]; gf[r] = (float)pg[r][2]; go[r] = (float)pg[r][3];
+        cprev[r] = hasp[r] ? pcp[r] : 0.f;
+        cur[r] = cc[r];
+        dh[r] = pdh[r] + dhr[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tc[r] = cftanh(cur[r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d_o[r] = dh[r] * tc[r] * go[r] * (1.f - go[r]);
+        dc[r] = dcr[r] + dh[r] * go[r] * (1.f - tc[r] * tc[r]) + d_o[r] * wco;
+        d_g[r] = dc[r] * gi[r] * (1.f - gq[r] * gq[r]);
+        d_i[r] = dc[r] * gq[r] * gi[r] * (1.f - gi[r]);
+        d_f[r] = dc[r] * cprev[r] * gf[r] * (1.f - gf[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int brow = rg * 4 + r;
+        dcr[r] = act[r] ? (dc[r] * gf[r] + d_i[r] * wci + d_f[r] * wcf) : dcr[r];
+        dhr[r] = act[r] ? 0.f : dhr[r];
+        const float zi = act[r] ? d_i[r] : 0.f, zg = act[r] ? d_g[r] : 0.f, zf = act[r] ? d_f[r] : 0.f,
+                    zo = act[r] ? d_o[r] : 0.f;
+        sums[0] += zi * cprev[r]; sums[1] += zf * cprev[r]; sums[2] += zo * cur[r];
+        sums[3] += zi; sums[4] += zg; sums[5] += zf; sums[6] += zo;
+        const bool ldp = (s > 0) && (s - 1 < len[r]);
+        cc[r] = ldp ? pcp[r] : 0.f;
+        const cbf16x4_t pk = {(__bf16)zi, (__bf16)zg, (__bf16)zf, (__bf16)zo};
+        *reinterpret_cast<cbf16x4_t*>(dgs + brow * LDG + (wave * 16 + col) * 4) = pk;
+        dgates[poff[r]] = pk;
+      }
     }
+    if (s > 0) prefetch(s - 1);
     __syncthreads();
     // ---- 3. partial dh_prev for ALL units from the own dG slice; own part kept, rest published
     if (s > 0) {
