@@ -185,6 +185,58 @@ int asr_ctc_beam_decode(asr_handle* h, const float* logits, int T, int B, int C,
 /* row softmax: CTC.posteriors (models/ctc/ctc.py:354-380) */
 int asr_softmax_rows(asr_handle* h, const float* in, float* out, int rows, int C, asr_stream s);
 
+/* ---- attention decoder (models/attention/...) -------------------------------- *
+ * Encoder outputs and keys are TIME-MAJOR: enc[T,B,E], keys[T,B,A]; per-utterance vectors [B,*].
+ *
+ * One LSTMBlockCell step of the decoder RNN (attention_seq2seq.py:352-371): pre[B,4U] fp32 =
+ * [x,h]W + b with TF gate-major columns (i, ci, f, o); peep [3][U] or NULL.  live[B] (1/0):
+ * rows already finished keep their state (dynamic_decode impute_finished,
+ * decoders/dynamic_decoder.py:171-193).  Outputs: gates[B,4U] post-activation, c_raw/h_raw = new
+ * cell/output before the finished-carry, c_out/h_out = carried state. */
+int asr_lstm_cell_fwd(asr_handle* h, const float* pre, const float* c_prev, const float* h_prev,
+                      const float* peep, const float* live, int B, int U, float forget_bias,
+                      float cell_clip, float* gates, float* c_raw, float* c_out, float* h_out,
+                      float* h_raw, asr_stream s);
+/* dh_use: gradient on the cell output of live rows; dc_next/dh_next: gradient on the carried state.
+ * dpre[B,4U]; dc_prev; dh_prev_carry (pass-through part, add (dpre W^T)[h] for live rows);
+ * dpeep_rows[B][3][U] per-row peephole gradient terms (sum over rows/steps on the caller side). */
+int asr_lstm_cell_bwd(asr_handle* h, const float* dh_use, const float* dc_next, const float* dh_next,
+                      const float* gates, const float* c_raw, const float* c_prev, const float* peep,
+                      const float* live, int B, int U, float* dpre, float* dc_prev,
+                      float* dh_prev_carry, float* dpeep_rows, asr_stream s);
+/* Attention energies (attention_layer.py:115-347).  mode 0 (bahdanau_content / location / hybrid):
+ * energy[b,t] = sum_a v[a] * tanh(keys[t,b,a] + qz[b,a])   (keys NULL for 'location');
+ * mode 1 (dot_product / luong_dot / luong_general): energy[b,t] = sum_a keys[t,b,a] * qz[b,a].
+ * qz = W_query s (+ W_filter bias where the type has location features). */
+int asr_att_energy_fwd(asr_handle* h, const float* keys, const float* qz, const float* v, int T,
+                       int B, int A, int mode, float* energy, asr_stream s);
+/* dkeys[T,B,A] += (may be NULL); dqz[B,A] = ; dv_rows[B,A] = per-utterance v gradient (may be NULL) */
+int asr_att_energy_bwd(asr_handle* h, const float* denergy, const float* keys, const float* qz,
+                       const float* v, int T, int B, int A, int mode, float* dkeys, float* dqz,
+                       float* dv_rows, asr_stream s);
+/* energy*mask + (1-mask)*float32.min, * sharpening, softmax over t, context = sum_t alpha enc
+ * (attention_layer.py:75-111).  alpha[B,T], ctx[B,E]. */
+int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* seq_len,
+                            float sharpening, const float* enc, int T, int B, int E, float* alpha,
+                            float* ctx, asr_stream s);
+/* denergy[B,T] = ; denc[T,B,E] += alpha * dctx */
+int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const float* alpha,
+                            const int32_t* seq_len, float sharpening, const float* enc, int T,
+                            int B, int E, float* denergy, float* denc, asr_stream s);
+int asr_tanh_fwd(asr_handle* h, const float* x, float* y, size_t n, asr_stream s);
+int asr_tanh_bwd(asr_handle* h, const float* dy, const float* y, float* dx, size_t n, asr_stream s);
+/* tf.nn.embedding_lookup (attention_seq2seq.py:439) and its gradient (deterministic) */
+int asr_embedding_gather(asr_handle* h, const float* W, const int32_t* ids, int rows, int E,
+                         float* out, asr_stream s);
+int asr_embedding_scatter(asr_handle* h, const float* dout, const int32_t* ids, int rows, int E,
+                          int vocab, float* dW, asr_stream s);
+/* sparse softmax cross-entropy per row of logits[rows,C] (+eps), weighted (sequence_loss,
+ * attention_seq2seq.py:625-637): row_loss[r] = w[r]*xent; dlogits = (softmax-onehot)*w*dscale */
+int asr_seq_xent(asr_handle* h, const float* logits, const int32_t* targets, const float* weights,
+                 int rows, int C, float eps, float dscale, float* row_loss, float* dlogits,
+                 asr_stream s);
+int asr_argmax_rows(asr_handle* h, const float* x, int rows, int C, int32_t* out, asr_stream s);
+
 /* ---- gradient clipping + optimizers -------------------------------------- *
  * Multi-tensor over one flat fp32 parameter buffer; tensor i is
  * [offsets[i], offsets[i+1]).  tf.clip_by_norm per variable

@@ -1,0 +1,221 @@
+"""Oracle (test infrastructure, PARITY UNPINNED -- TF1 absent, see oracle/__init__.py): CPU
+restatement of the attention encoder-decoder and the joint CTC-attention model.
+
+Follows
+  * models/attention/attention_seq2seq.py:193-277 (_build), :413-509 (_decode_train /
+    _decode_infer), :579-664 (compute_loss: logits/temperature, +1e-10, sequence_loss masked
+    by labels_seq_len-1 over labels[:,1:])
+  * models/attention/decoders/attention_layer.py:45-113 (mask with float32.min, sharpening,
+    softmax, context) and :115-347 (energies)
+  * models/attention/decoders/attention_decoder.py:142-295 (initialize: first input
+    [emb(<SOS>); zeros], step: cell -> attention -> tanh(FC_nobias([cell_out; ctx])) ->
+    output FC -> next input [emb(next); ctx]), dynamic_decoder.py:148-197 (impute_finished)
+  * models/attention/bridge.py:128-151 (flatten final (c,h) fw+bw -> FC -> split (c0,h0))
+  * models/attention/joint_ctc_attention.py:182-346 ((1-lambda)*xent + lambda*mean ctc on a
+    'ctc_output' FC over the encoder outputs; the [B*T,C] -> [T,B,C] reshape bug Q2 is NOT
+    reproduced: the intended transpose is used)
+Reference quirk Q1 IS reproduced because it is what the reference graph
+computes: the "previous attention weights" fed to location / hybrid attention are always the
+zeros tensor of initialize(), so the location features reduce to the W_filter bias.
+"""
+import numpy as np
+import torch
+
+from . import lstm as olstm
+from .model import ctc_loss as _ctc_loss
+
+F32_MIN = float(np.finfo(np.float32).min)
+ADDITIVE = ('bahdanau_content', 'location', 'hybrid')
+DOT = ('dot_product', 'luong_dot', 'luong_general')
+
+
+def attention_step(p, att_type, enc_bt, keys, s, seq_len, sharpening=1.0):
+    """enc_bt [B,T,2H]; keys [B,T,A] or None; s [B,U] -> (alpha [B,T], ctx [B,2H])."""
+    B, T, _ = enc_bt.shape
+    if att_type in ADDITIVE:
+        z = (s @ p['W_query/weights']).unsqueeze(1)                       # [B,1,A]
+        if att_type in ('bahdanau_content', 'hybrid'):
+            z = z + keys
+        if att_type in ('location', 'hybrid'):
+            z = z + p['W_filter/biases']          # conv(zeros) @ W_filter + b  (quirk Q1)
+        if att_type == 'location':
+            z = z.expand(B, T, z.shape[2])
+        energy = (p['v_a'] * torch.tanh(z)).sum(2)
+    elif att_type == 'dot_product':
+        energy = (keys @ (s @ p['W_query/weights']).unsqueeze(2)).squeeze(2)
+    elif att_type == 'luong_dot':
+        energy = (enc_bt @ s.unsqueeze(2)).squeeze(2)
+    elif att_type == 'luong_general':
+        energy = (keys @ s.unsqueeze(2)).squeeze(2)
+    else:
+        raise NotImplementedError(att_type)
+    mask = (torch.arange(T).unsqueeze(0) < seq_len.unsqueeze(1)).to(enc_bt.dtype)
+    energy = energy * mask + (1.0 - mask) * F32_MIN
+    energy = energy * sharpening
+    alpha = torch.softmax(energy, dim=1)
+    ctx = (alpha.unsqueeze(2) * enc_bt).sum(1)
+    return alpha, ctx
+
+
+def compute_keys(p, att_type, enc_bt):
+    if att_type in ('bahdanau_content', 'hybrid'):
+        return enc_bt @ p['W_keys/weights'] + p['W_keys/biases']
+    if att_type in ('dot_product', 'luong_general'):
+        return enc_bt @ p['W_keys/weights']
+    return None
+
+
+def decoder_params(sd, dtype=torch.float64, requires_grad=True):
+    pre = 'attention_decoder/decoder/'
+    out = {}
+    for k, v in sd.items():
+        if k.startswith(pre) or k.startswith('output_embedding/') or k.startswith('bridge/') \
+                or k.startswith('ctc_output/'):
+            t = torch.as_tensor(np.asarray(v.detach().cpu() if torch.is_tensor(v) else v), dtype=dtype).clone()
+            t.requires_grad_(requires_grad)
+            out[k] = t
+    return out
+
+
+def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_len, enc_layers,
+                            att_type, clip_enc=0.0, clip_dec=0.0, sharpening=1.0, temperature=1.0,
+                            drop_emb=None, drop_dec=None, ctc_labels=None, lambda_weight=None,
+                            dtype=torch.float64):
+    """Teacher-forced forward + loss + all parameter gradients.
+    labels [B, Lmax] int (<SOS> y <EOS>, padded with eos); returns dict(loss, logits [B,To,C],
+    alphas, grads, ...)."""
+    from .model import params_from_state_dict
+    layers = params_from_state_dict(sd, enc_layers, 2, dtype, prefix='encoder/')
+    P = decoder_params(sd, dtype)
+    D = 'attention_decoder/decoder/'
+    A = D + 'attention_layer/'
+    ap = {k[len(A):]: v for k, v in P.items() if k.startswith(A)}
+    x = torch.as_tensor(np.asarray(inputs_btd), dtype=dtype)
+    sl = torch.as_tensor(np.asarray(inputs_seq_len), dtype=torch.long)
+    lsl = torch.as_tensor(np.asarray(labels_seq_len), dtype=torch.long)
+    lab = torch.as_tensor(np.asarray(labels), dtype=torch.long)
+    peep = layers[0][0]['_peep']
+    enc_tm, final = olstm.blstm_encoder(x, sl, layers, None, forget_bias=1.0, cell_clip=clip_enc,
+                                        use_peephole=peep)
+    enc = enc_tm.transpose(0, 1)                                          # [B,T,2H]
+    B, T, E2 = enc.shape
+    # bridge: flatten (c_fw, h_fw, c_bw, h_bw) -> FC -> (c0, h0)
+    (c_fw, h_fw), (c_bw, h_bw) = final
+    bi = torch.cat([c_fw, h_fw, c_bw, h_bw], dim=1)
+    init = bi @ P['bridge/fully_connected/weights'] + P['bridge/fully_connected/biases']
+    U = init.shape[1] // 2
+    c, h = init[:, :U], init[:, U:]
+    emb_w = P['output_embedding/W_embedding']
+    emb = emb_w[lab]                                                      # [B,Lmax,E]
+    if drop_emb is not None:
+        emb = emb * torch.as_tensor(drop_emb, dtype=dtype)
+    To = int(lsl.max()) - 1
+    keys = compute_keys(ap, att_type, enc)
+    cell = dict(w=P[D + 'lstm_cell/kernel'], b=P[D + 'lstm_cell/bias'])
+    has_peep = (D + 'lstm_cell/w_i_diag') in P
+    z = torch.zeros(U, dtype=dtype)
+    wci, wcf, wco = (P[D + 'lstm_cell/w_i_diag'], P[D + 'lstm_cell/w_f_diag'], P[D + 'lstm_cell/w_o_diag']) \
+        if has_peep else (z, z, z)
+    ctx = x.new_zeros(B, E2)
+    logits_steps, alphas, ids = [], [], []
+    for k in range(To):
+        fin_prev = (k >= (lsl - 1)).to(dtype).unsqueeze(1)               # finished BEFORE this step
+        inp_emb = emb[:, k] if k == 0 else emb[:, k] * (1.0 - fin_prev_in)
+        inp = torch.cat([inp_emb, ctx], dim=1)
+        cn, hn = olstm.lstm_block_cell(inp, c, h, cell['w'], cell['b'], wci, wcf, wco, 1.0, clip_dec, has_peep)
+        cell_out = hn if drop_dec is None else hn * torch.as_tensor(drop_dec[k], dtype=dtype)
+        alpha, ctx_k = attention_step(ap, att_type, enc, keys, cell_out, sl, sharpening)
+        av = torch.tanh(torch.cat([cell_out, ctx_k], dim=1) @ P[D + 'attentional_vector/weights'])
+        lg = av @ P[D + 'output_layer/weights'] + P[D + 'output_layer/biases']
+        live = 1.0 - fin_prev                                             # impute_finished
+        logits_steps.append(lg * live)
+        alphas.append(alpha * live)
+        ids.append(torch.argmax(lg, dim=1) * live.squeeze(1).long())
+        c = live * cn + fin_prev * c
+        h = live * hn + fin_prev * h
+        ctx = ctx_k * live                     # outputs (incl. context) are zeroed once finished
+        # TrainingHelper.next_inputs: zeros once time+1 >= sequence_length
+        fin_prev_in = ((k + 1) >= (lsl - 1)).to(dtype).unsqueeze(1)
+    logits = torch.stack(logits_steps, dim=1) / temperature               # [B,To,C]
+    lg = logits + 1e-10
+    targets = lab[:, 1:To + 1]
+    w = (torch.arange(To).unsqueeze(0) < (lsl - 1).unsqueeze(1)).to(dtype)
+    xent = torch.nn.functional.cross_entropy(lg.reshape(B * To, -1), targets.reshape(-1), reduction='none')
+    seq_loss = (xent.view(B, To) * w).sum() / (w.sum() + 1e-12)
+    out = dict(logits=logits.detach().numpy(), alphas=torch.stack(alphas, 1).detach().numpy(),
+               predicted_ids=torch.stack(ids, 1).numpy(), sequence_loss=float(seq_loss.detach()))
+    total = seq_loss
+    if lambda_weight is not None:
+        ctc_lg = (enc_tm.reshape(T * B, E2) @ P['ctc_output/weights'] + P['ctc_output/biases']).reshape(T, B, -1)
+        ctc_losses = _ctc_loss(ctc_lg, ctc_labels, np.asarray(inputs_seq_len))
+        total = (1.0 - lambda_weight) * seq_loss + lambda_weight * ctc_losses.mean()
+        out['ctc_logits'] = ctc_lg.detach().numpy()
+        out['ctc_losses'] = ctc_losses.detach().numpy()
+    total.backward()
+    grads = {}
+    for name, t in P.items():
+        grads[name] = t.grad.detach().numpy().copy() if t.grad is not None else np.zeros(tuple(t.shape))
+    for layer in layers:
+        for p in layer:
+            base = p['_base']
+            grads[base + '/kernel'] = p['w'].grad.numpy().copy()
+            grads[base + '/bias'] = p['b'].grad.numpy().copy()
+            if p['_peep']:
+                grads[base + '/w_i_diag'] = p['wci'].grad.numpy().copy()
+                grads[base + '/w_f_diag'] = p['wcf'].grad.numpy().copy()
+                grads[base + '/w_o_diag'] = p['wco'].grad.numpy().copy()
+    out.update(total_loss=float(total.detach()), grads=grads, enc=enc.detach().numpy())
+    return out
+
+
+def attention_model_infer(sd, inputs_btd, inputs_seq_len, enc_layers, att_type, sos, eos, max_len,
+                          clip_enc=0.0, clip_dec=0.0, sharpening=1.0, dtype=torch.float64):
+    """GreedyEmbeddingHelper decode (attention_seq2seq.py:462-509): returns predicted ids [B, <=max_len]."""
+    from .model import params_from_state_dict
+    with torch.no_grad():
+        layers = params_from_state_dict(sd, enc_layers, 2, dtype, requires_grad=False, prefix='encoder/')
+        P = decoder_params(sd, dtype, requires_grad=False)
+        D = 'attention_decoder/decoder/'
+        A = D + 'attention_layer/'
+        ap = {k[len(A):]: v for k, v in P.items() if k.startswith(A)}
+        x = torch.as_tensor(np.asarray(inputs_btd), dtype=dtype)
+        sl = torch.as_tensor(np.asarray(inputs_seq_len), dtype=torch.long)
+        peep = layers[0][0]['_peep']
+        enc_tm, final = olstm.blstm_encoder(x, sl, layers, None, forget_bias=1.0, cell_clip=clip_enc,
+                                            use_peephole=peep)
+        enc = enc_tm.transpose(0, 1)
+        B = enc.shape[0]
+        (c_fw, h_fw), (c_bw, h_bw) = final
+        init = torch.cat([c_fw, h_fw, c_bw, h_bw], 1) @ P['bridge/fully_connected/weights'] + \
+            P['bridge/fully_connected/biases']
+        U = init.shape[1] // 2
+        c, h = init[:, :U], init[:, U:]
+        emb_w = P['output_embedding/W_embedding']
+        keys = compute_keys(ap, att_type, enc)
+        has_peep = (D + 'lstm_cell/w_i_diag') in P
+        z = torch.zeros(U, dtype=dtype)
+        wci, wcf, wco = (P[D + 'lstm_cell/w_i_diag'], P[D + 'lstm_cell/w_f_diag'], P[D + 'lstm_cell/w_o_diag']) \
+            if has_peep else (z, z, z)
+        ctx = x.new_zeros(B, enc.shape[2])
+        tok = torch.full((B,), sos, dtype=torch.long)
+        finished = torch.zeros(B, dtype=torch.bool)
+        out = []
+        for k in range(max_len):
+            inp = torch.cat([emb_w[tok], ctx], 1)
+            cn, hn = olstm.lstm_block_cell(inp, c, h, P[D + 'lstm_cell/kernel'], P[D + 'lstm_cell/bias'],
+                                           wci, wcf, wco, 1.0, clip_dec, has_peep)
+            alpha, ctx_k = attention_step(ap, att_type, enc, keys, hn, sl, sharpening)
+            av = torch.tanh(torch.cat([hn, ctx_k], 1) @ P[D + 'attentional_vector/weights'])
+            lg = av @ P[D + 'output_layer/weights'] + P[D + 'output_layer/biases']
+            sample = torch.argmax(lg, 1)
+            live = ~finished
+            out.append(torch.where(live, sample, torch.zeros_like(sample)))
+            lf = live.to(dtype).unsqueeze(1)
+            c = lf * cn + (1 - lf) * c
+            h = lf * hn + (1 - lf) * h
+            ctx = ctx_k * lf
+            finished = finished | (sample == eos)
+            tok = torch.where(finished, torch.full_like(tok, sos), sample)
+            if bool(finished.all()):
+                break
+        return torch.stack(out, 1).numpy()

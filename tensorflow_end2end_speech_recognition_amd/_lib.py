@@ -42,6 +42,18 @@ SIGNATURES = {
     'asr_ctc_beam_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'asr_ctc_beam_decode': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'asr_softmax_rows': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'asr_lstm_cell_fwd': (_i, [_vp] * 6 + [_i, _i, _f, _f] + [_vp] * 6),
+    'asr_lstm_cell_bwd': (_i, [_vp] * 9 + [_i, _i] + [_vp] * 5),
+    'asr_att_energy_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'asr_att_energy_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'asr_att_softmax_ctx_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'asr_att_softmax_ctx_bwd': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'asr_tanh_fwd': (_i, [_vp, _vp, _vp, _sz, _vp]),
+    'asr_tanh_bwd': (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    'asr_embedding_gather': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    'asr_embedding_scatter': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'asr_seq_xent': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
+    'asr_argmax_rows': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     'asr_clip_plan': (_i, [_vp, _vp, _i, _vp]),
     'asr_clip_by_norm_multi': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _f, _vp, _vp]),
     'asr_weight_decay': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),

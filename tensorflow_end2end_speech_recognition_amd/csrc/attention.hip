@@ -1,0 +1,470 @@
+// Attention decoder kernels for gfx950 (rows a11-a15 of SURVEY.md section 8).
+//
+// Stand in for the per-step TF ops of the reference's decoder loop:
+//   * LSTMBlockCell step of the decoder RNN           models/attention/attention_seq2seq.py:352-371
+//   * AttentionLayer: energies, mask, sharpening, softmax, context
+//                                                      models/attention/decoders/attention_layer.py:45-347
+//   * tanh of the attentional vector, embedding lookup, masked sequence cross-entropy
+//                                                      attention_decoder.py:189-209, attention_seq2seq.py:433-447,625-637
+// Encoder outputs stay TIME-MAJOR [T,B,E] (what the encoder kernels write); keys [T,B,A] likewise.
+// Everything here is HBM/latency-bound: per decoder step the energy pass reads keys once
+// (B*T*A*4 B) and the context pass reads the encoder outputs once (B*T*E*4 B).  The GEMM-shaped
+// parts (keys, query, cell input projection, attentional vector, output layer and all their
+// gradients) run on asr_gemm, batched over all decoder steps wherever the recurrence allows.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float sigf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- decoder LSTM cell, one step.  pre[B,4U] gate-major (i, ci, f, o) = [x,h]W + b.
+// live[b] = 0 -> the row is finished: state copied through (dynamic_decode impute_finished).
+__global__ void cell_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ c_prev,
+                                const float* __restrict__ h_prev, const float* __restrict__ peep,
+                                const float* __restrict__ live, int B, int U, float fb, float clip,
+                                float* __restrict__ gates, float* __restrict__ c_raw,
+                                float* __restrict__ c_out, float* __restrict__ h_out,
+                                float* __restrict__ h_raw) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * U) return;
+  const int b = idx / U, j = idx % U;
+  const float* p = pre + (size_t)b * 4 * U;
+  const float cp = c_prev[idx];
+  const float wci = peep ? peep[j] : 0.f, wcf = peep ? peep[U + j] : 0.f, wco = peep ? peep[2 * U + j] : 0.f;
+  const float i = sigf(p[j] + wci * cp);
+  const float g = tanhf(p[U + j]);
+  const float f = sigf(p[2 * U + j] + fb + wcf * cp);
+  float cn = g * i + cp * f;
+  if (clip > 0.f) cn = fminf(fmaxf(cn, -clip), clip);
+  const float o = sigf(p[3 * U + j] + wco * cn);
+  const float hn = tanhf(cn) * o;
+  float* gp = gates + (size_t)b * 4 * U;
+  gp[j] = i; gp[U + j] = g; gp[2 * U + j] = f; gp[3 * U + j] = o;
+  c_raw[idx] = cn;
+  h_raw[idx] = hn;
+  const float lv = live[b];
+  c_out[idx] = lv > 0.f ? cn : cp;
+  h_out[idx] = lv > 0.f ? hn : h_prev[idx];
+}
+
+// dh_raw: gradient w.r.t. the cell output h_new of LIVE rows (already includes everything that
+// consumed it); dc_next / dh_next: gradient w.r.t. the carried state (c_out, h_out).
+__global__ void cell_bwd_kernel(const float* __restrict__ dh_out_use, const float* __restrict__ dc_next,
+                                const float* __restrict__ dh_next, const float* __restrict__ gates,
+                                const float* __restrict__ c_raw, const float* __restrict__ c_prev,
+                                const float* __restrict__ peep, const float* __restrict__ live, int B, int U,
+                                float* __restrict__ dpre, float* __restrict__ dc_prev,
+                                float* __restrict__ dh_prev_carry, float* __restrict__ dpeep_rows) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * U) return;
+  const int b = idx / U, j = idx % U;
+  const float lv = live[b];
+  float* dp = dpre + (size_t)b * 4 * U;
+  if (!(lv > 0.f)) {   // finished row: state passes through, no parameter gradient
+    dp[j] = 0.f; dp[U + j] = 0.f; dp[2 * U + j] = 0.f; dp[3 * U + j] = 0.f;
+    dc_prev[idx] = dc_next[idx];
+    dh_prev_carry[idx] = dh_next[idx];
+    if (dpeep_rows) { dpeep_rows[(size_t)b * 3 * U + j] = 0.f; dpeep_rows[(size_t)b * 3 * U + U + j] = 0.f; dpeep_rows[(size_t)b * 3 * U + 2 * U + j] = 0.f; }
+    return;
+  }
+  const float* gp = gates + (size_t)b * 4 * U;
+  const float i = gp[j], g = gp[U + j], f = gp[2 * U + j], o = gp[3 * U + j];
+  const float wci = peep ? peep[j] : 0.f, wcf = peep ? peep[U + j] : 0.f, wco = peep ? peep[2 * U + j] : 0.f;
+  const float c = c_raw[idx], cp = c_prev[idx];
+  const float dh = dh_out_use[idx] + dh_next[idx];
+  const float tc = tanhf(c);
+  const float d_o = dh * tc * o * (1.f - o);
+  const float dc = dc_next[idx] + dh * o * (1.f - tc * tc) + d_o * wco;
+  const float d_g = dc * i * (1.f - g * g);
+  const float d_i = dc * g * i * (1.f - i);
+  const float d_f = dc * cp * f * (1.f - f);
+  dp[j] = d_i; dp[U + j] = d_g; dp[2 * U + j] = d_f; dp[3 * U + j] = d_o;
+  dc_prev[idx] = dc * f + d_i * wci + d_f * wcf;
+  dh_prev_carry[idx] = 0.f;   // h_prev enters only through the input projection (dpre W^T)
+  if (dpeep_rows) {
+    dpeep_rows[(size_t)b * 3 * U + j] = d_i * cp;
+    dpeep_rows[(size_t)b * 3 * U + U + j] = d_f * cp;
+    dpeep_rows[(size_t)b * 3 * U + 2 * U + j] = d_o * c;
+  }
+}
+
+// ---- energies.  keys[T,B,A] (may be null), qz[B,A].  mode 0: sum_a v_a tanh(useK*K + qz);
+// mode 1: sum_a K*qz.  One block per utterance, 4 waves stride over t, lanes over a.
+__global__ __launch_bounds__(256) void att_energy_fwd_kernel(const float* __restrict__ keys,
+                                                             const float* __restrict__ qz,
+                                                             const float* __restrict__ v, int T, int B,
+                                                             int A, int mode, float* __restrict__ energy) {
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* q = qz + (size_t)b * A;
+  for (int t = wave; t < T; t += 4) {
+    const float* k = keys ? keys + ((size_t)t * B + b) * A : nullptr;
+    float s = 0.f;
+    for (int a = lane; a < A; a += 64) {
+      if (mode == 0) s += v[a] * tanhf((k ? k[a] : 0.f) + q[a]);
+      else s += k[a] * q[a];
+    }
+    s = wave_reduce_sum(s);
+    if (lane == 0) energy[(size_t)b * T + t] = s;
+  }
+}
+
+// dkeys[T,B,A] += dZ ; dqz[B,A] = sum_t dZ ; dv_rows[B,A] = sum_t denergy*tanh(Z)
+__global__ __launch_bounds__(256) void att_energy_bwd_kernel(const float* __restrict__ denergy,
+                                                             const float* __restrict__ keys,
+                                                             const float* __restrict__ qz,
+                                                             const float* __restrict__ v, int T, int B,
+                                                             int A, int mode, float* __restrict__ dkeys,
+                                                             float* __restrict__ dqz,
+                                                             float* __restrict__ dv_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* acc = reinterpret_cast<float*>(smem);   // [4 waves][2][A]
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* q = qz + (size_t)b * A;
+  for (int a = lane; a < 2 * A; a += 64) acc[wave * 2 * A + a] = 0.f;
+  for (int t = wave; t < T; t += 4) {
+    const float de = denergy[(size_t)b * T + t];
+    const size_t off = ((size_t)t * B + b) * A;
+    for (int a = lane; a < A; a += 64) {
+      if (mode == 0) {
+        const float th = tanhf((keys ? keys[off + a] : 0.f) + q[a]);
+        const float dz = de * v[a] * (1.f - th * th);
+        if (dkeys) dkeys[off + a] += dz;
+        acc[wave * 2 * A + a] += dz;
+        acc[wave * 2 * A + A + a] += de * th;
+      } else {
+        const float kv = keys[off + a];
+        if (dkeys) dkeys[off + a] += de * q[a];
+        acc[wave * 2 * A + a] += de * kv;
+      }
+    }
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < A; a += 256) {
+    dqz[(size_t)b * A + a] = acc[a] + acc[2 * A + a] + acc[4 * A + a] + acc[6 * A + a];
+    if (dv_rows) dv_rows[(size_t)b * A + a] = acc[A + a] + acc[3 * A + a] + acc[5 * A + a] + acc[7 * A + a];
+  }
+}
+
+// ---- masked softmax over t + context.  energy[B,T] -> alpha[B,T], ctx[B,E] = sum_t alpha enc[t,b,:]
+// mask: e*m + (1-m)*FLT_MIN(lowest), then *sharpening (attention_layer.py:76-89).
+__global__ __launch_bounds__(256) void att_softmax_ctx_fwd_kernel(const float* __restrict__ energy,
+                                                                  const int32_t* __restrict__ seq_len,
+                                                                  float sharp, const float* __restrict__ enc,
+                                                                  int T, int B, int E,
+                                                                  float* __restrict__ alpha,
+                                                                  float* __restrict__ ctx) {
+  __shared__ float red[4];
+  __shared__ float s_max, s_inv;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* al = reinterpret_cast<float*>(smem);   // [T]
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int len = min(max(seq_len[b], 0), T);
+  const float lowest = -3.402823466e+38f;
+  float m = -INFINITY;
+  for (int t = tid; t < T; t += 256) {
+    // float32.min * sharpening overflows to -inf for sharpening > 1 (reference quirk Q13); clamp so a
+    // fully masked row (batch padding, len = 0) still yields finite, uniform weights
+    const float e = fmaxf((t < len ? energy[(size_t)b * T + t] : lowest) * sharp, lowest);
+    al[t] = e;
+    m = fmaxf(m, e);
+  }
+  m = wave_reduce_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (tid == 0) s_max = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  const float mx = s_max;
+  float s = 0.f;
+  for (int t = tid; t < T; t += 256) {
+    const float p = expf(al[t] - mx);
+    al[t] = p;
+    s += p;
+  }
+  s = wave_reduce_sum(s);
+  __syncthreads();
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) s_inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+  const float inv = s_inv;
+  for (int t = tid; t < T; t += 256) {
+    const float a = al[t] * inv;
+    al[t] = a;
+    alpha[(size_t)b * T + t] = a;
+  }
+  __syncthreads();
+  for (int e0 = tid; e0 < E; e0 += 256) {
+    float c = 0.f;
+    for (int t = 0; t < len; ++t) c += al[t] * enc[((size_t)t * B + b) * E + e0];
+    if (len == 0)   // all-masked row: uniform weights over T zero frames
+      for (int t = 0; t < T; ++t) c += al[t] * enc[((size_t)t * B + b) * E + e0];
+    ctx[(size_t)b * E + e0] = c;
+  }
+}
+
+// dctx[B,E], dalpha_in[B,T] (may be null) -> denergy[B,T]; denc[t,b,:] += alpha*dctx
+__global__ __launch_bounds__(256) void att_softmax_ctx_bwd_kernel(const float* __restrict__ dctx,
+                                                                  const float* __restrict__ alpha,
+                                                                  const int32_t* __restrict__ seq_len,
+                                                                  float sharp, const float* __restrict__ enc,
+                                                                  int T, int B, int E,
+                                                                  float* __restrict__ denergy,
+                                                                  float* __restrict__ denc) {
+  __shared__ float red[4];
+  __shared__ float s_dot;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* da = reinterpret_cast<float*>(smem);   // [T]
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int len = min(max(seq_len[b], 0), T);
+  const float* dc = dctx + (size_t)b * E;
+  // dalpha_t = enc[t,b,:] . dctx   (one wave per t)
+  for (int t = wave; t < len; t += 4) {
+    const float* er = enc + ((size_t)t * B + b) * E;
+    float s = 0.f;
+    for (int e0 = lane; e0 < E; e0 += 64) s += er[e0] * dc[e0];
+    s = wave_reduce_sum(s);
+    if (lane == 0) da[t] = s;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int t = tid; t < len; t += 256) dot += alpha[(size_t)b * T + t] * da[t];
+  dot = wave_reduce_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  if (tid == 0) s_dot = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  const float dsum = s_dot;
+  for (int t = tid; t < T; t += 256) {
+    float de = 0.f;
+    if (t < len) de = sharp * alpha[(size_t)b * T + t] * (da[t] - dsum);
+    denergy[(size_t)b * T + t] = de;
+  }
+  for (int t = wave; t < len; t += 4) {
+    const float a = alpha[(size_t)b * T + t];
+    float* dr = denc + ((size_t)t * B + b) * E;
+    for (int e0 = lane; e0 < E; e0 += 64) dr[e0] += a * dc[e0];
+  }
+}
+
+__global__ void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = tanhf(x[i]);
+}
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                float* __restrict__ dx, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+
+// out[r,:] = W[ids[r],:]
+__global__ void emb_gather_kernel(const float* __restrict__ W, const int32_t* __restrict__ ids, int R, int E,
+                                  float* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)R * E; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = W[(size_t)ids[i / E] * E + i % E];
+}
+// dW[v,:] = sum_{r: ids[r]==v} dout[r,:]   (one block per vocabulary row, fixed order: deterministic)
+__global__ __launch_bounds__(256) void emb_scatter_kernel(const float* __restrict__ dout,
+                                                          const int32_t* __restrict__ ids, int R, int E,
+                                                          float* __restrict__ dW) {
+  const int v = blockIdx.x;
+  for (int e0 = threadIdx.x; e0 < E; e0 += 256) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r)
+      if (ids[r] == v) s += dout[(size_t)r * E + e0];
+    dW[(size_t)v * E + e0] = s;
+  }
+}
+
+// masked sequence cross-entropy: rows = B*To; per-row loss*w and dlogits = (softmax-onehot)*w*scale
+__global__ __launch_bounds__(256) void seq_xent_kernel(const float* __restrict__ logits,
+                                                       const int32_t* __restrict__ targets,
+                                                       const float* __restrict__ weights, int rows, int Cc,
+                                                       float eps, float dscale, float* __restrict__ row_loss,
+                                                       float* __restrict__ dlogits) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = logits + (size_t)row * Cc;
+  const float w = weights[row];
+  if (w == 0.f) {   // masked position: exact zero (never 0 * NaN)
+    if (lane == 0) row_loss[row] = 0.f;
+    if (dlogits)
+      for (int k = lane; k < Cc; k += 64) dlogits[(size_t)row * Cc + k] = 0.f;
+    return;
+  }
+  float m = -INFINITY;
+  for (int k = lane; k < Cc; k += 64) m = fmaxf(m, p[k] + eps);
+  m = wave_reduce_max(m);
+  float s = 0.f;
+  for (int k = lane; k < Cc; k += 64) s += expf(p[k] + eps - m);
+  s = wave_reduce_sum(s);
+  const float lse = m + logf(s);
+  const int tg = targets[row];
+  if (lane == 0) row_loss[row] = w * (lse - (p[tg] + eps));
+  if (dlogits) {
+    const float sc = w * dscale;
+    for (int k = lane; k < Cc; k += 64)
+      dlogits[(size_t)row * Cc + k] = (expf(p[k] + eps - lse) - (k == tg ? 1.f : 0.f)) * sc;
+  }
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int rows, int Cc,
+                                                          int32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = x + (size_t)row * Cc;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int k = lane; k < Cc; k += 64) {
+    const float v = p[k];
+    if (v > best || (v == best && k < bi)) { best = v; bi = k; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+inline int gridn(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+}  // namespace
+
+#define ATT_NEED(cond, ...) do { if (!(cond)) ASR_FAIL(h, ASR_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
+
+extern "C" int asr_lstm_cell_fwd(asr_handle* h, const float* pre, const float* c_prev, const float* h_prev,
+                                 const float* peep, const float* live, int B, int U, float forget_bias,
+                                 float cell_clip, float* gates, float* c_raw, float* c_out, float* h_out,
+                                 float* h_raw, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(pre && c_prev && h_prev && live && gates && c_raw && c_out && h_out && h_raw && B > 0 && U > 0,
+           "asr_lstm_cell_fwd: bad args");
+  hipLaunchKernelGGL(cell_fwd_kernel, dim3((B * U + 255) / 256), dim3(256), 0, (hipStream_t)s, pre, c_prev, h_prev,
+                     peep, live, B, U, forget_bias, cell_clip, gates, c_raw, c_out, h_out, h_raw);
+  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_fwd");
+  return ASR_OK;
+}
+
+extern "C" int asr_lstm_cell_bwd(asr_handle* h, const float* dh_use, const float* dc_next, const float* dh_next,
+                                 const float* gates, const float* c_raw, const float* c_prev, const float* peep,
+                                 const float* live, int B, int U, float* dpre, float* dc_prev,
+                                 float* dh_prev_carry, float* dpeep_rows, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(dh_use && dc_next && dh_next && gates && c_raw && c_prev && live && dpre && dc_prev && dh_prev_carry &&
+               B > 0 && U > 0, "asr_lstm_cell_bwd: bad args");
+  hipLaunchKernelGGL(cell_bwd_kernel, dim3((B * U + 255) / 256), dim3(256), 0, (hipStream_t)s, dh_use, dc_next,
+                     dh_next, gates, c_raw, c_prev, peep, live, B, U, dpre, dc_prev, dh_prev_carry, dpeep_rows);
+  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_bwd");
+  return ASR_OK;
+}
+
+extern "C" int asr_att_energy_fwd(asr_handle* h, const float* keys, const float* qz, const float* v, int T,
+                                  int B, int A, int mode, float* energy, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(qz && energy && T > 0 && B > 0 && A > 0 && (mode == 0 ? v != nullptr : keys != nullptr),
+           "asr_att_energy_fwd: bad args");
+  hipLaunchKernelGGL(att_energy_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, keys, qz, v, T, B, A, mode, energy);
+  ASR_CHECK_LAUNCH(h, "asr_att_energy_fwd");
+  return ASR_OK;
+}
+
+extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const float* keys, const float* qz,
+                                  const float* v, int T, int B, int A, int mode, float* dkeys, float* dqz,
+                                  float* dv_rows, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(denergy && qz && dqz && T > 0 && B > 0 && A > 0, "asr_att_energy_bwd: bad args");
+  const size_t lds = (size_t)8 * A * sizeof(float);
+  hipLaunchKernelGGL(att_energy_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, denergy, keys, qz, v, T, B, A,
+                     mode, dkeys, dqz, dv_rows);
+  ASR_CHECK_LAUNCH(h, "asr_att_energy_bwd");
+  return ASR_OK;
+}
+
+extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* seq_len,
+                                       float sharpening, const float* enc, int T, int B, int E, float* alpha,
+                                       float* ctx, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(energy && seq_len && enc && alpha && ctx && T > 0 && B > 0 && E > 0, "asr_att_softmax_ctx_fwd: bad args");
+  const size_t lds = (size_t)T * sizeof(float);
+  if (lds > 64 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_softmax_ctx_fwd: T=%d too long", T);
+  hipLaunchKernelGGL(att_softmax_ctx_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, energy, seq_len, sharpening,
+                     enc, T, B, E, alpha, ctx);
+  ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_fwd");
+  return ASR_OK;
+}
+
+extern "C" int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const float* alpha,
+                                       const int32_t* seq_len, float sharpening, const float* enc, int T,
+                                       int B, int E, float* denergy, float* denc, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(dctx && alpha && seq_len && enc && denergy && denc && T > 0 && B > 0 && E > 0,
+           "asr_att_softmax_ctx_bwd: bad args");
+  const size_t lds = (size_t)T * sizeof(float);
+  if (lds > 64 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_softmax_ctx_bwd: T=%d too long", T);
+  hipLaunchKernelGGL(att_softmax_ctx_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, dctx, alpha, seq_len,
+                     sharpening, enc, T, B, E, denergy, denc);
+  ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_bwd");
+  return ASR_OK;
+}
+
+extern "C" int asr_tanh_fwd(asr_handle* h, const float* x, float* y, size_t n, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(x && y, "asr_tanh_fwd: null");
+  if (!n) return ASR_OK;
+  hipLaunchKernelGGL(tanh_fwd_kernel, dim3(gridn(n)), dim3(256), 0, (hipStream_t)s, x, y, n);
+  ASR_CHECK_LAUNCH(h, "asr_tanh_fwd");
+  return ASR_OK;
+}
+extern "C" int asr_tanh_bwd(asr_handle* h, const float* dy, const float* y, float* dx, size_t n, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(dy && y && dx, "asr_tanh_bwd: null");
+  if (!n) return ASR_OK;
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(gridn(n)), dim3(256), 0, (hipStream_t)s, dy, y, dx, n);
+  ASR_CHECK_LAUNCH(h, "asr_tanh_bwd");
+  return ASR_OK;
+}
+extern "C" int asr_embedding_gather(asr_handle* h, const float* W, const int32_t* ids, int rows, int E,
+                                    float* out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(W && ids && out && rows >= 0 && E > 0, "asr_embedding_gather: bad args");
+  if (!rows) return ASR_OK;
+  hipLaunchKernelGGL(emb_gather_kernel, dim3(gridn((size_t)rows * E)), dim3(256), 0, (hipStream_t)s, W, ids, rows, E, out);
+  ASR_CHECK_LAUNCH(h, "asr_embedding_gather");
+  return ASR_OK;
+}
+extern "C" int asr_embedding_scatter(asr_handle* h, const float* dout, const int32_t* ids, int rows, int E,
+                                     int vocab, float* dW, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(dout && ids && dW && rows >= 0 && E > 0 && vocab > 0, "asr_embedding_scatter: bad args");
+  hipLaunchKernelGGL(emb_scatter_kernel, dim3(vocab), dim3(256), 0, (hipStream_t)s, dout, ids, rows, E, dW);
+  ASR_CHECK_LAUNCH(h, "asr_embedding_scatter");
+  return ASR_OK;
+}
+extern "C" int asr_seq_xent(asr_handle* h, const float* logits, const int32_t* targets, const float* weights,
+                            int rows, int C, float eps, float dscale, float* row_loss, float* dlogits,
+                            asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(logits && targets && weights && row_loss && rows >= 0 && C > 0, "asr_seq_xent: bad args");
+  if (!rows) return ASR_OK;
+  hipLaunchKernelGGL(seq_xent_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, targets, weights,
+                     rows, C, eps, dscale, row_loss, dlogits);
+  ASR_CHECK_LAUNCH(h, "asr_seq_xent");
+  return ASR_OK;
+}
+extern "C" int asr_argmax_rows(asr_handle* h, const float* x, int rows, int C, int32_t* out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(x && out && rows >= 0 && C > 0, "asr_argmax_rows: bad args");
+  if (!rows) return ASR_OK;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, x, rows, C, out);
+  ASR_CHECK_LAUNCH(h, "asr_argmax_rows");
+  return ASR_OK;
+}

@@ -1,0 +1,470 @@
+"""Attention-based encoder-decoder -- mirror of models/attention/attention_seq2seq.py:25-725
+(class AttentionSeq2Seq) on the HIP path.
+
+Same constructor arguments and methods: create_placeholders, compute_loss(inputs, labels,
+inputs_seq_len, labels_seq_len, keep_prob_encoder, keep_prob_decoder, keep_prob_embedding) ->
+(total_loss, logits [B,T_out,C+2], decoder_outputs_train, decoder_outputs_infer), train
+(ModelBase), decode(train, infer) -> (ids_train, ids_infer), compute_ler.
+
+Graph restated (eager): BLSTM encoder -> InitialStateBridge (bridge.py:128-151) -> teacher-forced
+AttentionDecoder loop (attention_decoder.py:256-295, dynamic_decoder.py:148-197) -> masked
+sequence loss (:625-637).  The recurrence (cell + attention) runs step by step; everything that
+does not feed back (attentional vector, output layer, all weight gradients) is batched over the
+decoder steps in single GEMMs.
+
+Reference quirk Q1 is reproduced (it IS the reference graph): location / hybrid attention see a
+zero "previous alpha", so their location features reduce to the W_filter bias; `filter` and
+W_filter/weights therefore receive zero gradient, W_keys of 'location' too (Q6).
+"""
+import numpy as np
+import torch
+
+from ... import ops
+from ..._lib import ASR_F32
+from ...utils.evaluation.edit_distance import compute_ler as _ler
+from ...utils.parameter import ParamStore
+from ..ctc.ctc import Placeholder, truncated_normal
+from ..encoders.load_encoder import load as load_encoder
+from ..model_base import ModelBase
+from .decoders import attention_layer as AL
+
+D = 'attention_decoder/decoder/'
+AT = D + 'attention_layer/'
+
+
+class AttentionDecoderOutput(object):
+    """namedtuple stand-in of attention_decoder.py:19-26."""
+
+    def __init__(self, logits=None, predicted_ids=None, decoder_output=None, attention_weights=None,
+                 context_vector=None, lazy=None):
+        self.logits, self._ids = logits, predicted_ids
+        self.decoder_output, self.attention_weights, self.context_vector = \
+            decoder_output, attention_weights, context_vector
+        self._lazy = lazy
+
+    @property
+    def predicted_ids(self):
+        if self._ids is None and self._lazy is not None:
+            self._ids = self._lazy()          # the INFER decoder only runs when its output is fetched
+        return self._ids
+
+
+class AttentionSeq2Seq(ModelBase):
+
+    def __init__(self, input_size, encoder_type, encoder_num_units, encoder_num_layers, encoder_num_proj,
+                 attention_type, attention_dim, decoder_type, decoder_num_units, decoder_num_layers,
+                 embedding_dim, num_classes, sos_index, eos_index, max_decode_length,
+                 lstm_impl='LSTMBlockCell', use_peephole=True, splice=1, parameter_init=0.1,
+                 clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50,
+                 weight_decay=0.0, time_major=True, sharpening_factor=1.0, logits_temperature=1.0,
+                 sigmoid_smoothing=False, name='attention', dtype='f32', device='cuda:0', seed=0,
+                 _extra_vars=None):
+        super(AttentionSeq2Seq, self).__init__()
+        assert input_size % 3 == 0, 'input_size must be divisible by 3 (+ delta, double delta features).'
+        assert splice % 2 == 1, 'splice must be the odd number'
+        assert clip_grad_norm > 0, 'clip_grad_norm must be larger than 0.'
+        assert weight_decay >= 0, 'weight_decay must not be a negative value.'
+        AL.check_attention_type(attention_type)
+        if decoder_type != 'lstm':
+            raise TypeError('decoder_type is "lstm" or "gru".') if decoder_type != 'gru' else \
+                NotImplementedError('GRU decoder (crashes in the reference too, attention_seq2seq.py:364-365)')
+        if sigmoid_smoothing:
+            raise NotImplementedError('sigmoid_smoothing is not built on the HIP path yet')
+        if encoder_type not in ('blstm',):
+            raise NotImplementedError
+        self.input_size, self.splice = input_size, splice
+        self.encoder_type = encoder_type
+        self.encoder_num_units, self.encoder_num_proj = encoder_num_units, encoder_num_proj
+        self.encoder_num_layers = encoder_num_layers
+        self.lstm_impl, self.use_peephole = lstm_impl, use_peephole
+        self.attention_type, self.attention_dim = attention_type, attention_dim
+        self.sharpening_factor, self.sigmoid_smoothing = sharpening_factor, sigmoid_smoothing
+        self.decoder_type, self.decoder_num_units = decoder_type, decoder_num_units
+        self.decdoder_num_layers = decoder_num_layers
+        self.embedding_dim = embedding_dim
+        self.num_classes = num_classes + 2
+        self.sos_index, self.eos_index = sos_index, eos_index
+        self.max_decode_length = max_decode_length
+        self.logits_temperature = logits_temperature
+        self.use_beam_search = False
+        self.parameter_init = parameter_init
+        self.clip_grad_norm = clip_grad_norm
+        self.clip_activation_encoder = clip_activation_encoder
+        self.clip_activation_decoder = clip_activation_decoder
+        self.weight_decay = weight_decay
+        self.time_major = time_major
+        self.name = name
+        self.summaries_train, self.summaries_dev = [], []
+        self.inputs_pl_list, self.labels_pl_list = [], []
+        self.inputs_seq_len_pl_list, self.labels_seq_len_pl_list = [], []
+        self.keep_prob_encoder_pl_list, self.keep_prob_decoder_pl_list = [], []
+        self.keep_prob_embedding_pl_list = []
+        self.labels_st_true_pl_list, self.labels_st_pred_pl_list = [], []
+        self.dtype = ops.dtype_id(dtype)
+        self.device = torch.device(device)
+        self.seed = seed
+        self._calls = 0
+
+        rng = np.random.RandomState(seed)
+        st = self.store = ParamStore(self.device)
+        self.encoder = load_encoder(encoder_type)(
+            num_units=encoder_num_units, num_proj=None, num_layers=encoder_num_layers, lstm_impl=lstm_impl,
+            use_peephole=use_peephole, parameter_init=parameter_init, clip_activation=clip_activation_encoder,
+            time_major=True, dtype=self.dtype)
+        E2 = self.enc_dim = self.encoder.build(st, input_size * splice, rng, scope_prefix='encoder/')
+        H, U, A, Em, C2 = encoder_num_units, decoder_num_units, attention_dim, embedding_dim, self.num_classes
+        u = lambda *s: rng.uniform(-parameter_init, parameter_init, size=s)
+        tn = lambda *s: truncated_normal(rng, parameter_init, s)
+        st.declare('output_embedding/W_embedding', (C2, Em), u(C2, Em))
+        st.declare('bridge/fully_connected/weights', (4 * H, 2 * U), tn(4 * H, 2 * U))
+        st.declare('bridge/fully_connected/biases', (2 * U,), np.zeros(2 * U))
+        self.dec_in_dim = Em + E2 + U
+        st.declare(D + 'lstm_cell/kernel', (self.dec_in_dim, 4 * U), u(self.dec_in_dim, 4 * U))
+        st.declare(D + 'lstm_cell/bias', (4 * U,), np.zeros(4 * U))
+        if use_peephole:
+            for n in ('w_i_diag', 'w_f_diag', 'w_o_diag'):
+                st.declare(D + 'lstm_cell/' + n, (U,), u(U))
+        at = attention_type
+        self.att_mode = 0 if at in AL.ADDITIVE else 1
+        if at == 'luong_dot' and E2 != U:
+            raise ValueError('encoder_num_units and decoder_num_units must be the same size.')
+        self.key_dim = {'luong_dot': E2, 'luong_general': U}.get(at, A)
+        if at in AL.HAS_QUERY_FC:
+            st.declare(AT + 'W_query/weights', (U, A), tn(U, A))
+        if at in AL.HAS_KEYS_FC:
+            st.declare(AT + 'W_keys/weights', (E2, self.key_dim), tn(E2, self.key_dim))
+            if at not in ('dot_product', 'luong_general'):
+                st.declare(AT + 'W_keys/biases', (A,), np.zeros(A))
+        if at in AL.HAS_FILTER:
+            taps = 201 if at == 'location' else 200
+            st.declare(AT + 'filter', (taps, 1, 10),
+                       truncated_normal(rng, 0.1 if at == 'location' else parameter_init, (taps, 1, 10)))
+            st.declare(AT + 'W_filter/weights', (10, A), tn(10, A))
+            st.declare(AT + 'W_filter/biases', (A,), np.zeros(A))
+        if at in AL.ADDITIVE:
+            lim = np.sqrt(3.0 / A)      # tf.get_variable default (glorot_uniform) for a [A] vector
+            st.declare(AT + 'v_a', (A,), rng.uniform(-lim, lim, size=(A,)))
+        st.declare(D + 'attentional_vector/weights', (U + E2, U), tn(U + E2, U))
+        st.declare(D + 'output_layer/weights', (U, C2), tn(U, C2))
+        st.declare(D + 'output_layer/biases', (C2,), np.zeros(C2))
+        for name_, shape, init in (_extra_vars(rng, E2) if _extra_vars else []):
+            st.declare(name_, shape, init)
+        st.finalize()
+        self._tape = None
+
+    # ------------------------------------------------------------------ helpers
+    def create_placeholders(self):
+        for lst, nm in ((self.inputs_pl_list, 'input'), (self.labels_pl_list, 'labels'),
+                        (self.inputs_seq_len_pl_list, 'inputs_seq_len'),
+                        (self.labels_seq_len_pl_list, 'labels_seq_len'),
+                        (self.keep_prob_encoder_pl_list, 'keep_prob_encoder'),
+                        (self.keep_prob_decoder_pl_list, 'keep_prob_decoder'),
+                        (self.keep_prob_embedding_pl_list, 'keep_prob_embedding')):
+            lst.append(Placeholder(nm))
+
+    def _peep(self):
+        st = self.store
+        if not self.use_peephole:
+            return None
+        return torch.stack([st[D + 'lstm_cell/w_i_diag'], st[D + 'lstm_cell/w_f_diag'],
+                            st[D + 'lstm_cell/w_o_diag']]).contiguous()
+
+    def _encode(self, inputs, inputs_seq_len, keep_prob_encoder, is_training):
+        rs = None
+        if is_training and float(keep_prob_encoder) < 1.0:
+            self._calls += 1
+            rs = (self.seed, self._calls << 40)
+        _, final = self.encoder(inputs, inputs_seq_len, float(keep_prob_encoder), is_training, rng_state=rs)
+        enc = self.encoder._out_tm.contiguous()            # [T,Bp,E2] fp32, time-major
+        lay = self.encoder.layers[-1]
+        return enc, self.encoder.seq_len_padded
+
+    def _keys(self, enc):
+        st, at = self.store, self.attention_type
+        T, Bp, E2 = enc.shape
+        if at in AL.USES_KEYS:
+            b = st[AT + 'W_keys/biases'] if (AT + 'W_keys/biases') in st.views else None
+            return ops.gemm(enc.view(T * Bp, E2), st[AT + 'W_keys/weights'], bias=b).view(T, Bp, self.key_dim)
+        if at == 'luong_dot':
+            return enc
+        return None                                          # 'location': keys unused (Q6)
+
+    def _query(self, s):
+        st, at = self.store, self.attention_type
+        if at in AL.HAS_QUERY_FC:
+            b = st[AT + 'W_filter/biases'] if at in AL.HAS_FILTER else None
+            return ops.gemm(s, st[AT + 'W_query/weights'], bias=b)
+        return s                                             # luong_*: the decoder state itself
+
+    def _bridge(self, final_c, final_h, B):
+        """final_c/final_h [2,Bp,H] -> (bi [Bp,4H], c0, h0)."""
+        bi = torch.cat([final_c[0], final_h[0], final_c[1], final_h[1]], dim=1).contiguous()
+        st = self.store
+        init = ops.gemm(bi, st['bridge/fully_connected/weights'], bias=st['bridge/fully_connected/biases'])
+        U = self.decoder_num_units
+        return bi, init[:, :U].contiguous(), init[:, U:].contiguous()
+
+    # ------------------------------------------------------------------ forward
+    def compute_loss(self, inputs, labels, inputs_seq_len, labels_seq_len, keep_prob_encoder,
+                     keep_prob_decoder, keep_prob_embedding, scope=None, is_training=True, **joint):
+        dev, st = self.device, self.store
+        inputs = torch.as_tensor(inputs, dtype=torch.float32, device=dev)
+        isl = torch.as_tensor(inputs_seq_len, dtype=torch.int32, device=dev)
+        labels_np = np.asarray(labels.cpu() if torch.is_tensor(labels) else labels).astype(np.int64)
+        lsl_np = np.asarray(labels_seq_len.cpu() if torch.is_tensor(labels_seq_len) else labels_seq_len).astype(np.int64)
+        B = inputs.shape[0]
+        enc, seq_p = self._encode(inputs, isl, keep_prob_encoder, is_training)
+        T, Bp, E2 = enc.shape
+        U, Em, C2 = self.decoder_num_units, self.embedding_dim, self.num_classes
+        To = int(lsl_np.max()) - 1
+        Lmax = labels_np.shape[1]
+        # host-side step tables: ids fed at step k, targets, live mask, loss weights  ([To,Bp])
+        ids_in = np.full((To, Bp), self.eos_index, dtype=np.int32)
+        tgt = np.zeros((To, Bp), dtype=np.int32)
+        live = np.zeros((To, Bp), dtype=np.float32)
+        ids_in[:, :B] = labels_np[:, :To].T
+        tgt[:, :B] = labels_np[:, 1:To + 1].T
+        live[:, :B] = (np.arange(To)[:, None] < (lsl_np - 1)[None, :]).astype(np.float32)
+        ids_d = torch.from_numpy(ids_in).to(dev)
+        tgt_d = torch.from_numpy(tgt).to(dev)
+        live_d = torch.from_numpy(live).to(dev)
+        emb = ops.embedding_gather(st['output_embedding/W_embedding'], ids_d.view(-1)).view(To, Bp, Em)
+        emb_mask = None
+        if is_training and float(keep_prob_embedding) < 1.0:
+            self._calls += 1
+            emb_mask = ops.dropout_mask(emb.shape, keep_prob_embedding, self.seed + 1, self._calls << 40, dev)
+            emb = ops.apply_mask(emb, emb_mask)
+        cf, hf = self.encoder._final_ch
+        bi, c, h = self._bridge(cf, hf, B)
+        keys = self._keys(enc)
+        peep = self._peep()
+        Din = self.dec_in_dim
+        dec_in = torch.empty((To, Bp, Din), dtype=torch.float32, device=dev)
+        av_in = torch.empty((To, Bp, U + E2), dtype=torch.float32, device=dev)
+        ctx = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
+        W_cell, b_cell = st[D + 'lstm_cell/kernel'], st[D + 'lstm_cell/bias']
+        v = st[AT + 'v_a'] if self.att_mode == 0 else None
+        saved = []
+        use_ddrop = is_training and float(keep_prob_decoder) < 1.0
+        for k in range(To):
+            dec_in[k, :, :Em].copy_(emb[k])
+            dec_in[k, :, Em:Em + E2].copy_(ctx)
+            dec_in[k, :, Em + E2:].copy_(h)
+            pre = ops.gemm(dec_in[k], W_cell, bias=b_cell)
+            gates, c_raw, c_new, h_new, h_raw = ops.lstm_cell_fwd(pre, c, h, peep, live_d[k], 1.0,
+                                                                  self.clip_activation_decoder or 0.0)
+            cell_out, dmask = h_raw, None
+            if use_ddrop:
+                self._calls += 1
+                dmask = ops.dropout_mask(h_raw.shape, keep_prob_decoder, self.seed + 2, self._calls << 40, dev)
+                cell_out = ops.apply_mask(h_raw, dmask)
+            qz = self._query(cell_out)
+            energy = ops.att_energy_fwd(keys, qz, v, T, self.att_mode)
+            alpha, ctx_k = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc)
+            av_in[k, :, :U].copy_(cell_out)
+            av_in[k, :, U:].copy_(ctx_k)
+            saved.append(dict(gates=gates, c_raw=c_raw, c_prev=c, qz=qz, alpha=alpha, dmask=dmask))
+            c, h, ctx = c_new, h_new, ctx_k
+        av = ops.tanh_fwd(ops.gemm(av_in.view(To * Bp, U + E2), st[D + 'attentional_vector/weights']))
+        logits2d = ops.gemm(av, st[D + 'output_layer/weights'], bias=st[D + 'output_layer/biases'])
+        logits2d = ops.apply_mask(logits2d, live_d.view(-1, 1).expand(To * Bp, C2).contiguous())  # impute_finished
+        inv_t = 1.0 / float(self.logits_temperature)
+        lt = ops.scale_(logits2d.clone(), inv_t) if self.logits_temperature != 1.0 else logits2d
+        wsum = float(live.sum())
+        lam = joint.get('lambda_weight')
+        seq_scale = (1.0 - lam) if lam is not None else 1.0
+        row_loss, dlogits = ops.seq_xent(lt, tgt_d.view(-1), live_d.view(-1), 1e-10,
+                                         seq_scale * inv_t / (wsum + 1e-12), want_grad=is_training)
+        seq_loss = row_loss.sum() / (wsum + 1e-12)
+        total = seq_loss
+        ctc_logits = None
+        ctc_tape = None
+        if lam is not None:
+            ctc_logits, ctc_mean, ctc_tape = self._ctc_head(enc, seq_p, joint['ctc_labels'], B, lam, is_training)
+            total = (1.0 - lam) * seq_loss + lam * ctc_mean
+        if self.weight_decay > 0:
+            l2 = torch.zeros((), dtype=torch.float32, device=dev)
+            ops.weight_decay(None, st.flat, st.plan, st.decay_mask, self.weight_decay, l2_out=l2)
+            total = total + l2
+        self.sequence_loss = seq_loss
+        logits_bm = logits2d.view(To, Bp, C2)[:, :B].transpose(0, 1)        # [B,To,C2] (batch-major)
+        ids_train = ops.argmax_rows(logits2d).view(To, Bp)[:, :B].t()
+        # dynamic_decode(impute_finished=True): every emitted field is zero once a row has finished
+        lv = live_d[:, :B].t().unsqueeze(2)                                  # [B,To,1]
+        alphas = torch.stack([s['alpha'] for s in saved], 0)[:, :B].transpose(0, 1) * lv
+        out_train = AttentionDecoderOutput(logits=logits_bm, predicted_ids=ids_train * live_d[:, :B].t().int(),
+                                           decoder_output=av.view(To, Bp, U)[:, :B].transpose(0, 1) * lv,
+                                           attention_weights=alphas,
+                                           context_vector=av_in[:, :B, U:].transpose(0, 1) * lv)
+        inf_args = (inputs, isl)
+        out_infer = AttentionDecoderOutput(lazy=lambda: self._decode_infer(*inf_args))
+        if is_training:
+            self._tape = dict(B=B, To=To, enc=enc, seq_p=seq_p, keys=keys, dec_in=dec_in, av_in=av_in, av=av,
+                              saved=saved, dlogits=dlogits, ids=ids_d, emb_mask=emb_mask, live=live_d, bi=bi,
+                              peep=peep, ctc=ctc_tape)
+        else:
+            self._tape = None
+        total._asr_model = self
+        if lam is not None:
+            return total, logits_bm, ctc_logits, out_train, out_infer
+        return total, logits_bm, out_train, out_infer
+
+    def _ctc_head(self, *a, **k):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ backward
+    def _backward(self):
+        if self._tape is None:
+            raise RuntimeError('train()/compute_gradients() needs a preceding compute_loss(is_training=True)')
+        tp, st, dev = self._tape, self.store, self.device
+        enc, seq_p, keys, dec_in, av_in, av = tp['enc'], tp['seq_p'], tp['keys'], tp['dec_in'], tp['av_in'], tp['av']
+        saved, To, live = tp['saved'], tp['To'], tp['live']
+        T, Bp, E2 = enc.shape
+        U, Em, C2, A = self.decoder_num_units, self.embedding_dim, self.num_classes, self.key_dim
+        at = self.attention_type
+        st.grad.zero_()
+        # ---- output layer + attentional vector, all steps at once
+        dlogits = tp['dlogits']
+        W_out, W_av = st[D + 'output_layer/weights'], st[D + 'attentional_vector/weights']
+        ops.gemm(av, dlogits, transA=True, out=st.g(D + 'output_layer/weights'))
+        ops.colsum(dlogits, out=st.g(D + 'output_layer/biases'))
+        dav_pre = ops.tanh_bwd(ops.gemm(dlogits, W_out, transB=True), av)
+        ops.gemm(av_in.view(To * Bp, U + E2), dav_pre, transA=True, out=st.g(D + 'attentional_vector/weights'))
+        dav_in = ops.gemm(dav_pre, W_av, transB=True).view(To, Bp, U + E2)
+        # ---- the recurrence, backwards
+        denc = torch.zeros_like(enc)
+        dkeys = None
+        if at in AL.USES_KEYS:
+            dkeys = torch.zeros_like(keys)
+        elif at == 'luong_dot':
+            dkeys = denc
+        dpre_all = torch.empty((To, Bp, 4 * U), dtype=torch.float32, device=dev)
+        dqz_all = torch.empty((To, Bp, saved[0]['qz'].shape[1]), dtype=torch.float32, device=dev)
+        dv_all = torch.empty_like(dqz_all) if self.att_mode == 0 else None
+        dpeep_all = torch.empty((To, Bp, 3 * U), dtype=torch.float32, device=dev) if self.use_peephole else None
+        cell_out_all = av_in[:, :, :U]
+        W_cell = st[D + 'lstm_cell/kernel']
+        dc_next = torch.zeros((Bp, U), dtype=torch.float32, device=dev)
+        dh_next = torch.zeros((Bp, U), dtype=torch.float32, device=dev)
+        dctx_in = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
+        v = st[AT + 'v_a'] if self.att_mode == 0 else None
+        for k in range(To - 1, -1, -1):
+            s = saved[k]
+            dctx = (dav_in[k, :, U:] + dctx_in).contiguous()
+            denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, enc, denc)
+            dqz, dv_rows = ops.att_energy_bwd(denergy, keys, s['qz'], v, self.att_mode, dkeys=dkeys,
+                                              want_dv=self.att_mode == 0)
+            dqz_all[k].copy_(dqz)
+            if dv_rows is not None:
+                dv_all[k].copy_(dv_rows)
+            dcell = dav_in[k, :, :U].contiguous()
+            if at in AL.HAS_QUERY_FC:
+                ops.gemm(dqz, st[AT + 'W_query/weights'], transB=True, out=dcell, accumulate=True)
+            else:
+                dcell = dcell + dqz
+            if s['dmask'] is not None:
+                dcell = ops.apply_mask(dcell, s['dmask'])
+            dpre, dc_prev, dh_carry, dpeep_rows = ops.lstm_cell_bwd(dcell, dc_next, dh_next, s['gates'], s['c_raw'],
+                                                                    s['c_prev'], tp['peep'], live[k],
+                                                                    want_dpeep=self.use_peephole)
+            dpre_all[k].copy_(dpre)
+            if dpeep_rows is not None:
+                dpeep_all[k].copy_(dpeep_rows.view(Bp, 3 * U))
+            d_in = ops.gemm(dpre, W_cell, transB=True)                      # [Bp, Em+E2+U]
+            dec_in_grad_emb = d_in[:, :Em]
+            if k == To - 1:
+                demb_all = torch.empty((To, Bp, Em), dtype=torch.float32, device=dev)
+            demb_all[k].copy_(dec_in_grad_emb)
+            dctx_in = d_in[:, Em:Em + E2].contiguous()
+            dh_next = dh_carry + d_in[:, Em + E2:]
+            dc_next = dc_prev
+        # ---- weight gradients of everything inside the loop, batched over the steps
+        ops.gemm(dec_in.view(To * Bp, -1), dpre_all.view(To * Bp, 4 * U), transA=True, out=st.g(D + 'lstm_cell/kernel'))
+        ops.colsum(dpre_all.view(To * Bp, 4 * U), out=st.g(D + 'lstm_cell/bias'))
+        if self.use_peephole:
+            dp = ops.colsum(dpeep_all.view(To * Bp, 3 * U))
+            st.g(D + 'lstm_cell/w_i_diag').copy_(dp[:U])
+            st.g(D + 'lstm_cell/w_f_diag').copy_(dp[U:2 * U])
+            st.g(D + 'lstm_cell/w_o_diag').copy_(dp[2 * U:])
+        dq2d = dqz_all.view(To * Bp, -1)
+        if at in AL.HAS_QUERY_FC:
+            ops.gemm(cell_out_all.reshape(To * Bp, U), dq2d, transA=True, out=st.g(AT + 'W_query/weights'))
+        if at in AL.HAS_FILTER:
+            ops.colsum(dq2d, out=st.g(AT + 'W_filter/biases'))
+        if self.att_mode == 0:
+            ops.colsum(dv_all.view(To * Bp, -1), out=st.g(AT + 'v_a'))
+        if at in AL.USES_KEYS:
+            dk2d = dkeys.view(T * Bp, -1)
+            ops.gemm(enc.view(T * Bp, E2), dk2d, transA=True, out=st.g(AT + 'W_keys/weights'))
+            if (AT + 'W_keys/biases') in st.views:
+                ops.colsum(dk2d, out=st.g(AT + 'W_keys/biases'))
+            ops.gemm(dk2d, st[AT + 'W_keys/weights'], transB=True, out=denc.view(T * Bp, E2), accumulate=True)
+        # embedding
+        if tp['emb_mask'] is not None:
+            demb_all = ops.apply_mask(demb_all, tp['emb_mask'])
+        ops.embedding_scatter(demb_all.view(To * Bp, Em), tp['ids'].view(-1), C2, st.g('output_embedding/W_embedding'))
+        # bridge
+        dinit = torch.cat([dc_next, dh_next], dim=1).contiguous()
+        ops.gemm(tp['bi'], dinit, transA=True, out=st.g('bridge/fully_connected/weights'))
+        ops.colsum(dinit, out=st.g('bridge/fully_connected/biases'))
+        dbi = ops.gemm(dinit, st['bridge/fully_connected/weights'], transB=True)
+        H = self.encoder_num_units
+        dcf = torch.stack([dbi[:, :H], dbi[:, 2 * H:3 * H]]).contiguous()
+        dhf = torch.stack([dbi[:, H:2 * H], dbi[:, 3 * H:]]).contiguous()
+        if tp['ctc'] is not None:
+            self._ctc_head_backward(tp['ctc'], enc, denc)
+        self.encoder.backward(denc, d_final=(dcf, dhf))
+        if self.weight_decay > 0:
+            ops.weight_decay(st.grad, st.flat, st.plan, st.decay_mask, self.weight_decay)
+        self._tape = None
+
+    def _ctc_head_backward(self, *a):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ inference
+    def _decode_infer(self, inputs, isl):
+        """GreedyEmbeddingHelper loop (attention_seq2seq.py:462-509), at most max_decode_length steps."""
+        st, dev = self.store, self.device
+        B = inputs.shape[0]
+        enc, seq_p = self._encode(inputs, isl, 1.0, False)
+        T, Bp, E2 = enc.shape
+        U, Em = self.decoder_num_units, self.embedding_dim
+        cf, hf = self.encoder._final_ch
+        _, c, h = self._bridge(cf, hf, B)
+        keys, peep = self._keys(enc), self._peep()
+        ctx = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
+        tok = torch.full((Bp,), self.sos_index, dtype=torch.int32, device=dev)
+        live = torch.ones((Bp,), dtype=torch.float32, device=dev)
+        live[B:] = 0
+        v = st[AT + 'v_a'] if self.att_mode == 0 else None
+        dec_in = torch.empty((Bp, self.dec_in_dim), dtype=torch.float32, device=dev)
+        av_in = torch.empty((Bp, U + E2), dtype=torch.float32, device=dev)
+        out = []
+        for k in range(self.max_decode_length):
+            dec_in[:, :Em].copy_(ops.embedding_gather(st['output_embedding/W_embedding'], tok))
+            dec_in[:, Em:Em + E2].copy_(ctx)
+            dec_in[:, Em + E2:].copy_(h)
+            pre = ops.gemm(dec_in, st[D + 'lstm_cell/kernel'], bias=st[D + 'lstm_cell/bias'])
+            _, _, c, h, h_raw = ops.lstm_cell_fwd(pre, c, h, peep, live, 1.0, self.clip_activation_decoder or 0.0)
+            energy = ops.att_energy_fwd(keys, self._query(h_raw), v, T, self.att_mode)
+            _, ctx = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc)
+            av_in[:, :U].copy_(h_raw)
+            av_in[:, U:].copy_(ctx)
+            av = ops.tanh_fwd(ops.gemm(av_in, st[D + 'attentional_vector/weights']))
+            lg = ops.gemm(av, st[D + 'output_layer/weights'], bias=st[D + 'output_layer/biases'])
+            sample = ops.argmax_rows(lg)
+            out.append((sample * live.int())[:B])
+            live = live * (sample != self.eos_index).float()
+            tok = sample
+            if float(live[:B].sum()) == 0:
+                break
+        return torch.stack(out, 1)
+
+    def decode(self, decoder_outputs_train, decoder_outputs_infer):
+        """attention_seq2seq.py:666-701."""
+        return decoder_outputs_train.predicted_ids, decoder_outputs_infer.predicted_ids
+
+    def compute_ler(self, labels_true, labels_pred):
+        """mean normalised edit distance between two lists of label sequences
+        (tf.edit_distance(labels_pred, labels_true, normalize=True), :703-725)."""
+        return _ler(labels_pred, labels_true)

@@ -1,0 +1,79 @@
+"""Joint CTC-attention model -- mirror of models/attention/joint_ctc_attention.py:15-346
+(class JointCTCAttention): an extra 'ctc_output' FC on the encoder outputs and
+loss = (1 - lambda_weight) * sequence_loss + lambda_weight * mean(ctc_loss)   (:296-318).
+
+ctc num_classes = num_classes + 1 (blank = last).  ignore_longer_outputs_than_inputs=False in the
+reference (:315): an utterance without a valid alignment raises ValueError here too.
+Quirk Q2 (the [B*T,C] -> [T,B,C] reshape of batch-major logits, :190-226) is NOT reproduced: the
+encoder outputs are kept time-major, which is the intended computation.
+"""
+import numpy as np
+import torch
+
+from ... import ops
+from ...utils.io.labels.sparsetensor import dense_to_flat, sparse_to_flat
+from ..ctc.ctc import CTC, truncated_normal
+from .attention_seq2seq import AttentionSeq2Seq
+
+
+class JointCTCAttention(AttentionSeq2Seq):
+
+    def __init__(self, input_size, encoder_type, encoder_num_units, encoder_num_layers, encoder_num_proj,
+                 attention_type, attention_dim, decoder_type, decoder_num_units, decoder_num_layers,
+                 embedding_dim, lambda_weight, num_classes, sos_index, eos_index, max_decode_length,
+                 lstm_impl='LSTMBlockCell', use_peephole=True, splice=1, parameter_init=0.1,
+                 clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50,
+                 weight_decay=0.0, time_major=True, sharpening_factor=1.0, logits_temperature=1.0,
+                 name='joint_ctc_attention', **kw):
+        assert 0 <= lambda_weight <= 1, 'lambda_weight must be in [0, 1]'
+        self.lambda_weight = float(lambda_weight)
+        self.ctc_num_classes = num_classes + 1
+        init = parameter_init
+
+        def extra(rng, enc_dim):
+            return [('ctc_output/weights', (enc_dim, num_classes + 1), truncated_normal(rng, init, (enc_dim, num_classes + 1))),
+                    ('ctc_output/biases', (num_classes + 1,), np.zeros(num_classes + 1))]
+        super(JointCTCAttention, self).__init__(
+            input_size=input_size, encoder_type=encoder_type, encoder_num_units=encoder_num_units,
+            encoder_num_layers=encoder_num_layers, encoder_num_proj=encoder_num_proj,
+            attention_type=attention_type, attention_dim=attention_dim, decoder_type=decoder_type,
+            decoder_num_units=decoder_num_units, decoder_num_layers=decoder_num_layers,
+            embedding_dim=embedding_dim, num_classes=num_classes, sos_index=sos_index, eos_index=eos_index,
+            max_decode_length=max_decode_length, lstm_impl=lstm_impl, use_peephole=use_peephole, splice=splice,
+            parameter_init=parameter_init, clip_grad_norm=clip_grad_norm,
+            clip_activation_encoder=clip_activation_encoder, clip_activation_decoder=clip_activation_decoder,
+            weight_decay=weight_decay, time_major=time_major, sharpening_factor=sharpening_factor,
+            logits_temperature=logits_temperature, name=name, _extra_vars=extra, **kw)
+
+    def compute_loss(self, inputs, labels, ctc_labels, inputs_seq_len, labels_seq_len, keep_prob_encoder,
+                     keep_prob_decoder, keep_prob_embedding, scope=None, is_training=True):
+        """:237-346.  Returns (total_loss, logits, ctc_logits [T,B,C+1], dec_out_train, dec_out_infer)."""
+        return super(JointCTCAttention, self).compute_loss(
+            inputs, labels, inputs_seq_len, labels_seq_len, keep_prob_encoder, keep_prob_decoder,
+            keep_prob_embedding, scope=scope, is_training=is_training, lambda_weight=self.lambda_weight,
+            ctc_labels=ctc_labels)
+
+    def _ctc_head(self, enc, seq_p, ctc_labels, B, lam, is_training):
+        st, dev = self.store, self.device
+        T, Bp, E2 = enc.shape
+        Cc = self.ctc_num_classes
+        logits = ops.gemm(enc.view(T * Bp, E2), st['ctc_output/weights'], bias=st['ctc_output/biases']).view(T, Bp, Cc)
+        flat, offsets, max_len = CTC._labels_to_flat(ctc_labels, B)
+        if Bp > B:
+            offsets = np.concatenate([offsets, np.full(Bp - B, offsets[-1], dtype=np.int32)])
+        flat_d = torch.from_numpy(np.ascontiguousarray(flat if len(flat) else np.zeros(1, np.int32))).to(dev)
+        off_d = torch.from_numpy(np.ascontiguousarray(offsets)).to(dev)
+        losses, grad, ninf = ops.ctc_loss(logits, flat_d, off_d, seq_p, max_len, grad_scale=lam / B,
+                                          want_grad=is_training)
+        if int(ninf.item()) > 0:      # ignore_longer_outputs_than_inputs=False
+            raise ValueError('Not enough time for target transition sequence (%d utterance(s))' % int(ninf.item()))
+        self.ctc_losses = losses[:B]
+        return logits[:, :B], losses[:B].mean(), dict(dlogits=grad)
+
+    def _ctc_head_backward(self, tape, enc, denc):
+        st = self.store
+        T, Bp, E2 = enc.shape
+        dl = tape['dlogits'].view(T * Bp, -1)
+        ops.gemm(enc.view(T * Bp, E2), dl, transA=True, out=st.g('ctc_output/weights'))
+        ops.colsum(dl, out=st.g('ctc_output/biases'))
+        ops.gemm(dl, st['ctc_output/weights'], transB=True, out=denc.view(T * Bp, E2), accumulate=True)

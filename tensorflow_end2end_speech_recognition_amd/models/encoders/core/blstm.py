@@ -98,6 +98,7 @@ class _RecurrentEncoderBase(object):
         self._out_tm = out
         self._out_op = x   # same values in the MFMA operand dtype
         cf, hf = final
+        self._final_ch = (cf, hf)          # [ndir,Bp,H] each (the attention bridge consumes these)
         final_state = tuple((cf[d, :B], hf[d, :B]) for d in range(self.ndir))
         if self.ndir == 1:
             final_state = final_state[0]

@@ -277,6 +277,124 @@ def softmax_rows(x2d):
     return out
 
 
+# ---------------------------------------------------------------- attention decoder
+def _f32(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def lstm_cell_fwd(pre, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.0):
+    h = _h(pre)
+    B, U4 = pre.shape
+    U = U4 // 4
+    dev = pre.device
+    gates, c_raw, c_out, h_out, h_raw = _f32((B, U4), dev), _f32((B, U), dev), _f32((B, U), dev), \
+        _f32((B, U), dev), _f32((B, U), dev)
+    h.check(h.lib.asr_lstm_cell_fwd(h.h, _p(pre), _p(c_prev), _p(h_prev), _p(peep), _p(live), B, U,
+                                    float(forget_bias), float(cell_clip or 0.0), _p(gates), _p(c_raw), _p(c_out),
+                                    _p(h_out), _p(h_raw), _s()), 'asr_lstm_cell_fwd')
+    return gates, c_raw, c_out, h_out, h_raw
+
+
+def lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True):
+    h = _h(dh_use)
+    B, U = dh_use.shape
+    dev = dh_use.device
+    dpre, dc_prev, dh_carry = _f32((B, 4 * U), dev), _f32((B, U), dev), _f32((B, U), dev)
+    dpeep = _f32((B, 3, U), dev) if want_dpeep else None
+    h.check(h.lib.asr_lstm_cell_bwd(h.h, _p(dh_use), _p(dc_next), _p(dh_next), _p(gates), _p(c_raw), _p(c_prev),
+                                    _p(peep), _p(live), B, U, _p(dpre), _p(dc_prev), _p(dh_carry), _p(dpeep), _s()),
+            'asr_lstm_cell_bwd')
+    return dpre, dc_prev, dh_carry, dpeep
+
+
+def att_energy_fwd(keys, qz, v, T, mode):
+    h = _h(qz)
+    B, A = qz.shape
+    energy = _f32((B, T), qz.device)
+    h.check(h.lib.asr_att_energy_fwd(h.h, _p(keys), _p(qz), _p(v), T, B, A, int(mode), _p(energy), _s()),
+            'asr_att_energy_fwd')
+    return energy
+
+
+def att_energy_bwd(denergy, keys, qz, v, mode, dkeys=None, want_dv=True):
+    h = _h(qz)
+    B, A = qz.shape
+    T = denergy.shape[1]
+    dqz = _f32((B, A), qz.device)
+    dv = _f32((B, A), qz.device) if want_dv else None
+    h.check(h.lib.asr_att_energy_bwd(h.h, _p(denergy), _p(keys), _p(qz), _p(v), T, B, A, int(mode), _p(dkeys),
+                                     _p(dqz), _p(dv), _s()), 'asr_att_energy_bwd')
+    return dqz, dv
+
+
+def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc):
+    h = _h(energy)
+    B, T = energy.shape
+    E = enc.shape[2]
+    alpha, ctx = _f32((B, T), energy.device), _f32((B, E), energy.device)
+    h.check(h.lib.asr_att_softmax_ctx_fwd(h.h, _p(energy), _p(seq_len), float(sharpening), _p(enc), T, B, E,
+                                          _p(alpha), _p(ctx), _s()), 'asr_att_softmax_ctx_fwd')
+    return alpha, ctx
+
+
+def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc):
+    h = _h(dctx)
+    B, T = alpha.shape
+    E = enc.shape[2]
+    denergy = _f32((B, T), dctx.device)
+    h.check(h.lib.asr_att_softmax_ctx_bwd(h.h, _p(dctx), _p(alpha), _p(seq_len), float(sharpening), _p(enc), T, B, E,
+                                          _p(denergy), _p(denc), _s()), 'asr_att_softmax_ctx_bwd')
+    return denergy
+
+
+def tanh_fwd(x):
+    h = _h(x)
+    y = torch.empty_like(x)
+    h.check(h.lib.asr_tanh_fwd(h.h, _p(x), _p(y), x.numel(), _s()), 'asr_tanh_fwd')
+    return y
+
+
+def tanh_bwd(dy, y):
+    h = _h(dy)
+    dx = torch.empty_like(dy)
+    h.check(h.lib.asr_tanh_bwd(h.h, _p(dy), _p(y), _p(dx), dy.numel(), _s()), 'asr_tanh_bwd')
+    return dx
+
+
+def embedding_gather(W, ids):
+    h = _h(W)
+    _chk(ids, torch.int32, 'ids')
+    out = _f32(tuple(ids.shape) + (W.shape[1],), W.device)
+    h.check(h.lib.asr_embedding_gather(h.h, _p(W), _p(ids), ids.numel(), W.shape[1], _p(out), _s()),
+            'asr_embedding_gather')
+    return out
+
+
+def embedding_scatter(dout, ids, vocab, out):
+    h = _h(dout)
+    E = dout.shape[-1]
+    h.check(h.lib.asr_embedding_scatter(h.h, _p(dout), _p(ids), ids.numel(), E, int(vocab), _p(out), _s()),
+            'asr_embedding_scatter')
+    return out
+
+
+def seq_xent(logits2d, targets, weights, eps, dscale, want_grad=True):
+    h = _h(logits2d)
+    rows, Cc = logits2d.shape
+    row_loss = _f32((rows,), logits2d.device)
+    dl = torch.empty_like(logits2d) if want_grad else None
+    h.check(h.lib.asr_seq_xent(h.h, _p(logits2d), _p(targets), _p(weights), rows, Cc, float(eps), float(dscale),
+                               _p(row_loss), _p(dl), _s()), 'asr_seq_xent')
+    return row_loss, dl
+
+
+def argmax_rows(x2d):
+    h = _h(x2d)
+    out = torch.empty((x2d.shape[0],), dtype=torch.int32, device=x2d.device)
+    h.check(h.lib.asr_argmax_rows(h.h, _p(x2d), x2d.shape[0], x2d.shape[1], _p(out), _s()), 'asr_argmax_rows')
+    return out
+
+
 # ---------------------------------------------------------------- clip / decay / optimizers
 class ClipPlan(object):
     """Device-side description of a flat fp32 parameter buffer split into tensors."""
