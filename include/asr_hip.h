@@ -87,6 +87,31 @@ int asr_gemm(asr_handle* h, int dtype, int out_dtype, int transA, int transB,
              int M, int N, int K, const void* A, int lda, const void* B, int ldb,
              void* C, int ldc, const float* bias, int accumulate, asr_stream s);
 
+/* asr_gemm with a fused epilogue activation: act 0 = none, 1 = ReLU (conv_layer /
+ * fully_connected(activation_fn=relu): models/encoders/core/cnn_util.py:78-84, vgg_blstm.py:165-173) */
+int asr_gemm_act(asr_handle* h, int dtype, int out_dtype, int transA, int transB,
+                 int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                 void* C, int ldc, const float* bias, int accumulate, int act, asr_stream s);
+
+/* ---- VGG front-end (models/encoders/core/vgg_blstm.py:107-177) --------------- *
+ * Images are NHWC: [N = B*T frames, H = channels(40), W = splice*stack, C].
+ * 3x3 SAME convolution = asr_im2col3x3 (patches[m, tap*Cin+ci], row stride ldp >= 9*Cin,
+ * m = (n*H+h)*W+w) followed by asr_gemm_act(patches, weight[9*Cin, Cout], bias, relu);
+ * backward: dW = patches^T dpre, dpatches = dpre W^T, asr_col2im3x3 gathers dpatches back. */
+int asr_im2col3x3(asr_handle* h, int dtype, const void* in, int N, int H, int W, int Cin, int ldp,
+                  void* patches, asr_stream s);
+int asr_col2im3x3(asr_handle* h, const float* dpatches, int N, int H, int W, int Cin, int ldp,
+                  float* din, asr_stream s);
+/* tf.nn.max_pool 2x2 stride 2 SAME (cnn_util.py:13-28): out [N, ceil(H/2), ceil(W/2), C];
+ * argmax (uint8, 0..3 = position in the window) drives the backward pass. */
+int asr_maxpool2x2_fwd(asr_handle* h, int dtype, const void* in, int N, int H, int W, int C,
+                       void* out, uint8_t* argmax, asr_stream s);
+int asr_maxpool2x2_bwd(asr_handle* h, const float* dout, const uint8_t* argmax, int N, int H, int W,
+                       int C, float* din, asr_stream s);
+/* dpre = dout * (out > 0) (* mask if given), written in `dtype` (ReLU + dropout backward) */
+int asr_relu_bwd(asr_handle* h, int dtype, const float* dout, const void* out, const float* mask,
+                 size_t n, void* dpre, asr_stream s);
+
 /* ---- LSTM recurrence ------------------------------------------------------ *
  * One layer, `ndir` directions (1 = LSTMEncoder, 2 = BLSTMEncoder), all T steps:
  * tf.contrib.rnn.LSTMBlockCell(forget_bias, clip_cell, use_peephole) under

@@ -62,13 +62,21 @@ def params_from_state_dict(sd, num_layers, ndir=2, dtype=torch.float64, requires
 
 
 def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, cell_clip=0.0,
-                      weight_decay=0.0, drop_masks=None, dtype=torch.float64, temperature=1.0):
+                      weight_decay=0.0, drop_masks=None, dtype=torch.float64, temperature=1.0, vgg=None):
     """Returns dict(total_loss, ctc_losses [B], logits [T,B,C], grads {name: array})."""
     layers = params_from_state_dict(sd, num_layers, ndir, dtype)
     w_out = torch.as_tensor(np.asarray(sd['output/weights'].detach().cpu() if torch.is_tensor(sd['output/weights']) else sd['output/weights']), dtype=dtype).clone().requires_grad_(True)
     b_out = torch.as_tensor(np.asarray(sd['output/biases'].detach().cpu() if torch.is_tensor(sd['output/biases']) else sd['output/biases']), dtype=dtype).clone().requires_grad_(True)
     x = torch.as_tensor(np.asarray(inputs_btd), dtype=dtype)
     sl = torch.as_tensor(np.asarray(seq_len), dtype=torch.long)
+    vgg_params = {}
+    if vgg is not None:      # VGG front-end (models/encoders/core/vgg_blstm.py:107-177): vgg = (F, W)
+        from . import vgg as ovgg
+        for k in sd:
+            if k.startswith('VGG') or k.startswith('bridge/'):
+                vgg_params[k] = torch.as_tensor(np.asarray(sd[k].detach().cpu() if torch.is_tensor(sd[k]) else sd[k]), dtype=dtype).clone().requires_grad_(True)
+        x = ovgg.vgg_frontend(x, vgg_params, vgg[0], vgg[1])
+        # frames past seq_len feed the LSTM but are masked there, exactly as in the reference
     peep = layers[0][0]['_peep'] if ndir == 2 else layers[0]['_peep']
     kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=peep)
     if ndir == 2:
@@ -91,6 +99,7 @@ def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, 
                 named[base + '/w_o_diag'] = p['wco']
     named['output/weights'] = w_out
     named['output/biases'] = b_out
+    named.update(vgg_params)
     if weight_decay > 0:
         l2 = sum(0.5 * (v ** 2).sum() for n, v in named.items() if 'bias' not in n.lower())
         total = total + weight_decay * l2

@@ -30,6 +30,12 @@ SIGNATURES = {
     'asr_dropout_mask': (_i, [_vp, _vp, _sz, _f, _u64, _u64, _vp]),
     'asr_colsum': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     'asr_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    'asr_gemm_act': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    'asr_im2col3x3': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'asr_col2im3x3': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'asr_maxpool2x2_fwd': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'asr_maxpool2x2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'asr_relu_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     'asr_lstm_prep_weights': (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_gate_deinterleave': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     'asr_lstm_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

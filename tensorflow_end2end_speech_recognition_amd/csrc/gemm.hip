@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
                                                    TO* __restrict__ C, int ldc,
                                                    const float* __restrict__ bias, int accumulate,
                                                    int a_aligned, int b_aligned, int kchunk,
-                                                   float* __restrict__ partial) {
+                                                   float* __restrict__ partial, int act) {
   constexpr int BK = GT<T>::BK, VEC = GT<T>::VEC;
   constexpr int LDS_LD = BK + VEC;  // +16 B pad
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
         TO* cp = C + (size_t)m * ldc + n;
         float v = acc[i][j][r] + bv;
         if (accumulate) v += load_out<TO>(cp);
+        if (act == 1) v = fmaxf(v, 0.f);   // fused ReLU (conv_layer / bridge FC, cnn_util.py:78-84)
         store_out<TO>(cp, v);
       }
     }
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
 template <typename TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
                                      TO* __restrict__ C, int ldc, const float* __restrict__ bias,
-                                     int accumulate) {
+                                     int accumulate, int act) {
   const size_t total = (size_t)M * N;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -213,6 +214,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, i
     for (int z = 0; z < S; ++z) v += partial[(size_t)z * total + i];
     TO* cp = C + (size_t)m * ldc + n;
     if (accumulate) v += load_out<TO>(cp);
+    if (act == 1) v = fmaxf(v, 0.f);
     store_out<TO>(cp, v);
   }
 }
@@ -220,10 +222,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, i
 template <typename T, typename TO, int BM, int BN>
 int launch_layout(int transA, int transB, dim3 grid, size_t lds, hipStream_t st, int M, int N, int K,
                   const T* A, int lda, const T* B, int ldb, TO* C, int ldc, const float* bias,
-                  int accumulate, int aa, int ba, int kchunk, float* partial) {
+                  int accumulate, int aa, int ba, int kchunk, float* partial, int act) {
 #define ASR_GEMM_LAUNCH(TA_, TB_)                                                             \
   hipLaunchKernelGGL((gemm_kernel<T, TO, BM, BN, TA_, TB_>), grid, dim3(256), lds, st, M, N, K, A, \
-                     lda, B, ldb, C, ldc, bias, accumulate, aa, ba, kchunk, partial)
+                     lda, B, ldb, C, ldc, bias, accumulate, aa, ba, kchunk, partial, act)
   if (!transA && !transB) ASR_GEMM_LAUNCH(false, false);
   else if (!transA && transB) ASR_GEMM_LAUNCH(false, true);
   else if (transA && !transB) ASR_GEMM_LAUNCH(true, false);
@@ -235,7 +237,7 @@ int launch_layout(int transA, int transB, dim3 grid, size_t lds, hipStream_t st,
 template <typename T, typename TO>
 int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, const void* A, int lda,
                 const void* B, int ldb, void* C, int ldc, const float* bias, int accumulate,
-                hipStream_t st) {
+                hipStream_t st, int act) {
   constexpr int VEC = GT<T>::VEC, BK = GT<T>::BK;
   const int aa = (((uintptr_t)A) % 16 == 0) && (lda % VEC == 0);
   const int ba = (((uintptr_t)B) % 16 == 0) && (ldb % VEC == 0);
@@ -245,7 +247,7 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     size_t lds = (size_t)(128 + 128) * (BK + VEC) * sizeof(T);
     return launch_layout<T, TO, 128, 128>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda,
-                                          (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba, K, nullptr);
+                                          (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba, K, nullptr, act);
   }
   const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
   // small output, long reduction (the dW = X^T dG products: K = T*B): split K over blockIdx.z so
@@ -263,7 +265,7 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
   if (S <= 1) {
     dim3 grid((N + 63) / 64, (M + 63) / 64);
     return launch_layout<T, TO, 64, 64>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda,
-                                        (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba, K, nullptr);
+                                        (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba, K, nullptr, act);
   }
   int kchunk = (K + S - 1) / S;
   kchunk = (kchunk + BK - 1) / BK * BK;
@@ -271,23 +273,32 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
   dim3 grid((N + 63) / 64, (M + 63) / 64, S);
   float* partial = (float*)h->scratch;
   launch_layout<T, TO, 64, 64>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda, (const T*)B, ldb,
-                               (TO*)C, ldc, nullptr, 0, aa, ba, kchunk, partial);
+                               (TO*)C, ldc, nullptr, 0, aa, ba, kchunk, partial, 0);
   const size_t total = (size_t)M * N;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(blocks), dim3(256), 0, st, partial, S, M, N, (TO*)C, ldc,
-                     bias, accumulate);
+                     bias, accumulate, act);
   return 0;
 }
 
 }  // namespace
 
+extern "C" int asr_gemm_act(asr_handle* h, int dtype, int out_dtype, int transA, int transB, int M,
+                            int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                            int ldc, const float* bias, int accumulate, int act, asr_stream s);
 extern "C" int asr_gemm(asr_handle* h, int dtype, int out_dtype, int transA, int transB, int M,
                         int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                         int ldc, const float* bias, int accumulate, asr_stream s) {
+  return asr_gemm_act(h, dtype, out_dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 0, s);
+}
+extern "C" int asr_gemm_act(asr_handle* h, int dtype, int out_dtype, int transA, int transB, int M,
+                            int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                            int ldc, const float* bias, int accumulate, int act, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   if (!asr_dtype_ok(dtype) || !asr_dtype_ok(out_dtype))
     ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_gemm: bad dtype %d/%d", dtype, out_dtype);
+  if (act != 0 && act != 1) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_gemm_act: act must be 0 (none) or 1 (relu)");
   if (M < 0 || N < 0 || K < 0 || !A || !B || !C)
     ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_gemm: bad shape/pointer M=%d N=%d K=%d", M, N, K);
   if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N)
@@ -296,13 +307,13 @@ extern "C" int asr_gemm(asr_handle* h, int dtype, int out_dtype, int transA, int
   if (M == 0 || N == 0) return ASR_OK;
   hipStream_t st = (hipStream_t)s;
   if (dtype == ASR_F32 && out_dtype == ASR_F32)
-    launch_gemm<float, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+    launch_gemm<float, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act);
   else if (dtype == ASR_F32 && out_dtype == ASR_BF16)
-    launch_gemm<float, bf16_t>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+    launch_gemm<float, bf16_t>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act);
   else if (dtype == ASR_BF16 && out_dtype == ASR_F32)
-    launch_gemm<bf16_t, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+    launch_gemm<bf16_t, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act);
   else
-    launch_gemm<bf16_t, bf16_t>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st);
+    launch_gemm<bf16_t, bf16_t>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act);
   ASR_CHECK_LAUNCH(h, "asr_gemm");
   return ASR_OK;
 }

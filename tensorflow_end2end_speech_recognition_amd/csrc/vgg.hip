@@ -1,0 +1,168 @@
+// VGG front-end helpers for gfx950 (row a5): the per-frame convolution stack of
+// models/encoders/core/vgg_blstm.py:107-177 over windows [F=channels(40), W=splice*stack, 3] NHWC
+// (layout of utils/io/inputs/splicing.py:60-73), conv_layer / max_pool of cnn_util.py:13-84:
+//   conv3x3 SAME + bias + relu (x4), max_pool 2x2/2 SAME (x2), flatten, bridge FC 256 + relu.
+//
+// Round-1 form: the 3x3 SAME convolutions run as  im2col (this file)  ->  asr_gemm with a fused
+// bias+ReLU epilogue (MFMA)  -- chunked over frames so the patch matrix stays a bounded scratch.
+// (An implicit-GEMM A-operand gather that never materialises the patches is the planned upgrade;
+// DESIGN.md.)  Everything in this file is HBM-bound data movement.
+#include "common.h"
+
+namespace {
+
+// patches[m, tap*Cin + ci] = in[n, h+dh, w+dw, ci] (0 outside); m = (n*H + h)*W + w; row stride ldp
+template <typename T>
+__global__ void im2col3x3_kernel(const T* __restrict__ in, int N, int H, int W, int Cin, int ldp,
+                                 T* __restrict__ patches) {
+  const size_t total = (size_t)N * H * W * 9 * Cin;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int ci = idx % Cin;
+    const int tap = (idx / Cin) % 9;
+    const size_t m = idx / ((size_t)9 * Cin);
+    const int w = m % W, h = (m / W) % H;
+    const size_t n = m / ((size_t)W * H);
+    const int hs = h + tap / 3 - 1, ws = w + tap % 3 - 1;
+    T v = T(0);
+    if (hs >= 0 && hs < H && ws >= 0 && ws < W) v = in[((n * H + hs) * W + ws) * Cin + ci];
+    patches[m * ldp + tap * Cin + ci] = v;
+  }
+}
+
+// din[n,h,w,ci] = sum_taps dpatches[pixel(h-dh, w-dw), tap*Cin+ci]   (gather: no atomics)
+__global__ void col2im3x3_kernel(const float* __restrict__ dpatches, int N, int H, int W, int Cin, int ldp,
+                                 float* __restrict__ din) {
+  const size_t total = (size_t)N * H * W * Cin;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int ci = idx % Cin;
+    const size_t m = idx / Cin;
+    const int w = m % W, h = (m / W) % H;
+    const size_t n = m / ((size_t)W * H);
+    float s = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hd = h - (tap / 3 - 1), wd = w - (tap % 3 - 1);
+      if (hd >= 0 && hd < H && wd >= 0 && wd < W)
+        s += dpatches[((n * H + hd) * W + wd) * ldp + tap * Cin + ci];
+    }
+    din[idx] = s;
+  }
+}
+
+// max_pool 2x2 stride 2 SAME (cnn_util.py:13-28): Ho = ceil(H/2); padding goes AFTER (-inf)
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ in, int N, int H, int W, int C, T* __restrict__ out,
+                                   uint8_t* __restrict__ arg) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const size_t total = (size_t)N * Ho * Wo * C;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = idx % C;
+    const int wo = (idx / C) % Wo, ho = (idx / ((size_t)C * Wo)) % Ho;
+    const size_t n = idx / ((size_t)C * Wo * Ho);
+    float best = -INFINITY;
+    int bi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int h = 2 * ho + (k >> 1), w = 2 * wo + (k & 1);
+      if (h < H && w < W) {
+        const float v = Elem<T>::to_f32(in[((n * H + h) * W + w) * C + c]);
+        if (v > best) { best = v; bi = k; }
+      }
+    }
+    out[idx] = Elem<T>::from_f32(best);
+    arg[idx] = (uint8_t)bi;
+  }
+}
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ arg, int N, int H,
+                                   int W, int C, float* __restrict__ din) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const size_t total = (size_t)N * H * W * C;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = idx % C;
+    const int w = (idx / C) % W, h = (idx / ((size_t)C * W)) % H;
+    const size_t n = idx / ((size_t)C * W * H);
+    const size_t o = ((n * Ho + h / 2) * Wo + w / 2) * C + c;
+    const int k = ((h & 1) << 1) | (w & 1);
+    din[idx] = (arg[o] == k) ? dout[o] : 0.f;
+  }
+}
+
+// dpre = dout * (out > 0) (* mask), written in the MFMA operand dtype
+template <typename T>
+__global__ void relu_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ out,
+                                const float* __restrict__ mask, size_t n, T* __restrict__ dpre) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float g = dout[i];
+    if (mask) g *= mask[i];
+    dpre[i] = Elem<T>::from_f32(Elem<T>::to_f32(out[i]) > 0.f ? g : 0.f);
+  }
+}
+
+inline int gridv(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 4096) b = 4096;
+  return (int)b;
+}
+
+}  // namespace
+
+#define VGG_NEED(cond, ...) do { if (!(cond)) ASR_FAIL(h, ASR_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
+
+extern "C" int asr_im2col3x3(asr_handle* h, int dtype, const void* in, int N, int H, int W, int Cin, int ldp,
+                             void* patches, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(asr_dtype_ok(dtype) && in && patches && N >= 0 && H > 0 && W > 0 && Cin > 0 && ldp >= 9 * Cin,
+           "asr_im2col3x3: bad args");
+  const size_t total = (size_t)N * H * W * 9 * Cin;
+  if (!total) return ASR_OK;
+  if (dtype == ASR_F32) hipLaunchKernelGGL(im2col3x3_kernel<float>, dim3(gridv(total)), dim3(256), 0, (hipStream_t)s, (const float*)in, N, H, W, Cin, ldp, (float*)patches);
+  else hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, dim3(gridv(total)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, N, H, W, Cin, ldp, (bf16_t*)patches);
+  ASR_CHECK_LAUNCH(h, "asr_im2col3x3");
+  return ASR_OK;
+}
+extern "C" int asr_col2im3x3(asr_handle* h, const float* dpatches, int N, int H, int W, int Cin, int ldp,
+                             float* din, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(dpatches && din && N >= 0 && H > 0 && W > 0 && Cin > 0 && ldp >= 9 * Cin, "asr_col2im3x3: bad args");
+  const size_t total = (size_t)N * H * W * Cin;
+  if (!total) return ASR_OK;
+  hipLaunchKernelGGL(col2im3x3_kernel, dim3(gridv(total)), dim3(256), 0, (hipStream_t)s, dpatches, N, H, W, Cin, ldp, din);
+  ASR_CHECK_LAUNCH(h, "asr_col2im3x3");
+  return ASR_OK;
+}
+extern "C" int asr_maxpool2x2_fwd(asr_handle* h, int dtype, const void* in, int N, int H, int W, int C, void* out,
+                                  uint8_t* argmax, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(asr_dtype_ok(dtype) && in && out && argmax && N >= 0 && H > 0 && W > 0 && C > 0, "asr_maxpool2x2_fwd: bad args");
+  const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
+  if (!total) return ASR_OK;
+  if (dtype == ASR_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(gridv(total)), dim3(256), 0, (hipStream_t)s, (const float*)in, N, H, W, C, (float*)out, argmax);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(gridv(total)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, N, H, W, C, (bf16_t*)out, argmax);
+  ASR_CHECK_LAUNCH(h, "asr_maxpool2x2_fwd");
+  return ASR_OK;
+}
+extern "C" int asr_maxpool2x2_bwd(asr_handle* h, const float* dout, const uint8_t* argmax, int N, int H, int W,
+                                  int C, float* din, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(dout && argmax && din && N >= 0 && H > 0 && W > 0 && C > 0, "asr_maxpool2x2_bwd: bad args");
+  const size_t total = (size_t)N * H * W * C;
+  if (!total) return ASR_OK;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gridv(total)), dim3(256), 0, (hipStream_t)s, dout, argmax, N, H, W, C, din);
+  ASR_CHECK_LAUNCH(h, "asr_maxpool2x2_bwd");
+  return ASR_OK;
+}
+extern "C" int asr_relu_bwd(asr_handle* h, int dtype, const float* dout, const void* out, const float* mask,
+                            size_t n, void* dpre, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(asr_dtype_ok(dtype) && dout && out && dpre, "asr_relu_bwd: bad args");
+  if (!n) return ASR_OK;
+  if (dtype == ASR_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(gridv(n)), dim3(256), 0, (hipStream_t)s, dout, (const float*)out, mask, n, (float*)dpre);
+  else hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(gridv(n)), dim3(256), 0, (hipStream_t)s, dout, (const bf16_t*)out, mask, n, (bf16_t*)dpre);
+  ASR_CHECK_LAUNCH(h, "asr_relu_bwd");
+  return ASR_OK;
+}

@@ -107,14 +107,15 @@ class _RecurrentEncoderBase(object):
             out_user = out_user.transpose(0, 1)
         return out_user, final_state
 
-    def backward(self, d_outputs, d_final=None):
-        """d_outputs: gradient w.r.t. the TIME-MAJOR padded-batch outputs [T,Bpad,ndir*H] fp32."""
+    def backward(self, d_outputs, d_final=None, need_input_grad=False):
+        """d_outputs: gradient w.r.t. the TIME-MAJOR padded-batch outputs [T,Bpad,ndir*H] fp32.
+        Returns the gradient w.r.t. the (time-major) encoder input if need_input_grad."""
         dx = d_outputs
         for li in reversed(range(len(self.layers))):
             dcf = dhf = None
             if d_final is not None and li == len(self.layers) - 1:
                 dcf, dhf = d_final
-            dx = self.layers[li].backward(dx.contiguous(), dcf, dhf, need_dx=(li > 0))
+            dx = self.layers[li].backward(dx.contiguous(), dcf, dhf, need_dx=(li > 0 or need_input_grad))
         return dx
 
 

@@ -1,0 +1,214 @@
+"""VGG + (bidirectional) LSTM encoder -- mirror of models/encoders/core/vgg_blstm.py:17-220
+(class VGGBLSTMEncoder; vgg_lstm.py is the same front-end over the unidirectional stack).
+
+__call__(inputs [B,T,num_channels*(splice*num_stack)*3], inputs_seq_len, keep_prob, is_training):
+reshape to [B*T, num_channels, splice*num_stack, 3] (:108-110), VGG1: conv3x3(3->64)+relu+dropout,
+conv3x3(64->64)+relu, max_pool 2x2 SAME, dropout (:113-134); VGG2: 64->128, 128->128, pool,
+dropouts (:136-157); flatten; bridge FC -> 256 relu + dropout (:165-174); then the same LSTM stack
+as BLSTMEncoder (:182-218).  Variables: VGG{1,2}/conv{1,2}/{weight,bias} (tf.Variable in
+cnn_util.py:66-69), bridge/{weights,biases}.
+
+Round-1 execution: convolution = asr_im2col3x3 + MFMA GEMM with fused bias+ReLU, chunked over
+frames (CHUNK_FRAMES) so the patch matrix is a bounded scratch; backward recomputes the patches.
+"""
+import numpy as np
+import torch
+
+from .... import ops
+from ...._lib import ASR_BF16, ASR_F32
+from ....utils.parameter import ParamStore
+from .blstm import BLSTMEncoder
+from .lstm import LSTMEncoder
+
+CONVS = [('VGG1/conv1', 3, 64), ('VGG1/conv2', 64, 64), ('VGG2/conv1', 64, 128), ('VGG2/conv2', 128, 128)]
+CHUNK_FRAMES = 4096
+
+
+def _trunc_normal(rng, std, shape):
+    x = rng.normal(0.0, std, size=shape)
+    bad = np.abs(x) > 2 * std
+    while bad.any():
+        x[bad] = rng.normal(0.0, std, size=int(bad.sum()))
+        bad = np.abs(x) > 2 * std
+    return x
+
+
+class _VGGFrontEnd(object):
+    """conv/pool/bridge part; owns no LSTM."""
+
+    def __init__(self, input_size, splice, num_stack, parameter_init, dtype):
+        assert input_size % 3 == 0
+        self.F = input_size // 3
+        self.W = splice * num_stack
+        self.parameter_init = parameter_init
+        self.dtype = dtype
+        self.out_dim = 256
+        self.prefix = ''
+
+    def build(self, store, rng, prefix=''):
+        self.store, self.prefix = store, prefix
+        for name, cin, cout in CONVS:
+            store.declare(prefix + name + '/weight', (3, 3, cin, cout), _trunc_normal(rng, self.parameter_init, (3, 3, cin, cout)))
+            store.declare(prefix + name + '/bias', (cout,), np.zeros(cout))
+        H2, W2 = (self.F + 1) // 2, (self.W + 1) // 2
+        H4, W4 = (H2 + 1) // 2, (W2 + 1) // 2
+        self.flat = H4 * W4 * 128
+        store.declare(prefix + 'bridge/weights', (self.flat, 256), _trunc_normal(rng, self.parameter_init, (self.flat, 256)))
+        store.declare(prefix + 'bridge/biases', (256,), np.zeros(256))
+
+    # one conv layer on a chunk: x [n,H,W,Cin] (operand dtype) -> relu(conv + b) same dtype
+    def _conv_fwd(self, x, name, cin, cout, sh):
+        n, H, W, _ = x.shape
+        ldp = (9 * cin + 7) // 8 * 8                     # 16-B aligned rows for the GEMM loader
+        patches = ops.im2col3x3(x, ldp)
+        w2d = sh[self.prefix + name + '/weight'].view(9 * cin, cout)
+        return ops.gemm(patches[:, :9 * cin], w2d, bias=self.store[self.prefix + name + '/bias'], relu=True)
+
+    def forward(self, x_btd, keep_prob, is_training, rng_state=None):
+        """x [B,T,F*W*3] fp32 cuda -> [B,T,256] fp32; keeps what backward needs."""
+        st = self.store
+        sh = st.shadow(self.dtype)
+        B, T, Dd = x_btd.shape
+        assert Dd == self.F * self.W * 3
+        N = B * T
+        tdt = torch.bfloat16 if self.dtype == ASR_BF16 else torch.float32
+        x0 = ops.cast_from_f32(x_btd.reshape(N, self.F, self.W, 3).contiguous(), self.dtype) \
+            if self.dtype == ASR_BF16 else x_btd.reshape(N, self.F, self.W, 3).contiguous()
+        drop = is_training and keep_prob < 1.0
+        self.ctx = dict(N=N, B=B, T=T, x0=x0, acts=[], masks={}, args=[])
+        self._drop_i = 0
+
+        def dropout(t, key):
+            if not drop:
+                return t
+            seed, off = rng_state
+            self._drop_i += 1
+            m = ops.dropout_mask(t.shape, keep_prob, seed + 7, off + (self._drop_i << 32), t.device)
+            self.ctx['masks'][key] = m
+            return ops.apply_mask(t, m)
+        a1 = self._layer(x0, CONVS[0], sh)
+        a1d = dropout(a1, 'a1')
+        a2 = self._layer(a1d, CONVS[1], sh)
+        p1, arg1 = ops.maxpool2x2_fwd(a2)
+        p1d = dropout(p1, 'p1')
+        a3 = self._layer(p1d, CONVS[2], sh)
+        a3d = dropout(a3, 'a3')
+        a4 = self._layer(a3d, CONVS[3], sh)
+        p2, arg2 = ops.maxpool2x2_fwd(a4)
+        p2d = dropout(p2, 'p2')
+        flat = p2d.reshape(N, self.flat)
+        br = ops.gemm(flat, sh[self.prefix + 'bridge/weights'], bias=st[self.prefix + 'bridge/biases'], relu=True)
+        brd = dropout(br, 'br')
+        self.ctx.update(a1=a1, a1d=a1d, a2=a2, arg1=arg1, p1d=p1d, a3=a3, a3d=a3d, a4=a4, arg2=arg2, p2d=p2d,
+                        flat=flat, br=br)
+        out = ops.cast_to_f32(brd) if brd.dtype != torch.float32 else brd
+        return out.view(B, T, 256)
+
+    def _layer(self, x, conv, sh):
+        name, cin, cout = conv
+        N, H, W, _ = x.shape
+        out = torch.empty((N, H, W, cout), dtype=x.dtype, device=x.device)
+        for c0 in range(0, N, CHUNK_FRAMES):
+            xc = x[c0:c0 + CHUNK_FRAMES]
+            out[c0:c0 + CHUNK_FRAMES] = self._conv_fwd(xc, name, cin, cout, sh).view(xc.shape[0], H, W, cout)
+        return out
+
+    # conv backward on the full batch, chunked: dout fp32 [N,H,W,Cout] -> din fp32 [N,H,W,Cin]; fills dW, db
+    def _conv_bwd(self, dout, out, mask, x_in, conv, sh, need_dx=True):
+        name, cin, cout = conv
+        st = self.store
+        N, H, W, _ = out.shape
+        gw = st.g(self.prefix + name + '/weight').view(9 * cin, cout)
+        gb = st.g(self.prefix + name + '/bias')
+        w2d = sh[self.prefix + name + '/weight'].view(9 * cin, cout)
+        ldp = (9 * cin + 7) // 8 * 8
+        din = torch.empty((N, H, W, cin), dtype=torch.float32, device=dout.device) if need_dx else None
+        gb_acc = torch.zeros_like(gb)
+        for ci, c0 in enumerate(range(0, N, CHUNK_FRAMES)):
+            sl = slice(c0, c0 + CHUNK_FRAMES)
+            n = out[sl].shape[0]
+            dpre = ops.relu_bwd(dout[sl].contiguous(), out[sl].contiguous(),
+                                mask[sl].contiguous() if mask is not None else None).view(n * H * W, cout)
+            patches = ops.im2col3x3(x_in[sl].contiguous(), ldp)
+            ops.gemm(patches[:, :9 * cin], dpre, transA=True, out=gw, accumulate=(ci > 0))
+            gb_acc += ops.colsum(dpre)
+            if need_dx:
+                dpat = ops.gemm(dpre, w2d, transB=True, out_dtype=ASR_F32)
+                din[sl] = ops.col2im3x3(dpat, n, H, W, cin)
+        gb.copy_(gb_acc)
+        return din
+
+    def backward(self, dout_btd):
+        """dout [B,T,256] fp32 (gradient w.r.t. the front-end output)."""
+        c, st = self.ctx, self.store
+        sh = st.shadow(self.dtype)
+        N = c['N']
+        m = c['masks']
+        d = dout_btd.reshape(N, 256).contiguous()
+        dpre = ops.relu_bwd(d, c['br'], m.get('br'))
+        ops.gemm(c['flat'], dpre, transA=True, out=st.g(self.prefix + 'bridge/weights'))
+        ops.colsum(dpre, out=st.g(self.prefix + 'bridge/biases'))
+        dflat = ops.gemm(dpre, sh[self.prefix + 'bridge/weights'], transB=True, out_dtype=ASR_F32)
+        H2, W2 = (self.F + 1) // 2, (self.W + 1) // 2
+        H4, W4 = (H2 + 1) // 2, (W2 + 1) // 2
+        dp2 = dflat.view(N, H4, W4, 128)
+        if 'p2' in m:
+            dp2 = ops.apply_mask(dp2.contiguous(), m['p2'])
+        da4 = ops.maxpool2x2_bwd(dp2.contiguous(), c['arg2'], H2, W2)
+        da3d = self._conv_bwd(da4, c['a4'], None, c['a3d'], CONVS[3], sh)
+        dp1d = self._conv_bwd(da3d, c['a3'], m.get('a3'), c['p1d'], CONVS[2], sh)
+        if 'p1' in m:
+            dp1d = ops.apply_mask(dp1d, m['p1'])
+        da2 = ops.maxpool2x2_bwd(dp1d, c['arg1'], self.F, self.W)
+        da1d = self._conv_bwd(da2, c['a2'], None, c['a1d'], CONVS[1], sh)
+        self._conv_bwd(da1d, c['a1'], m.get('a1'), c['x0'], CONVS[0], sh, need_dx=False)
+        self.ctx = None
+
+
+class _VGGRecurrentMixin(object):
+    """VGG front-end + the recurrent stack of the base class."""
+
+    def _vgg_init(self, input_size, splice, num_stack, parameter_init, dtype):
+        self.front = _VGGFrontEnd(input_size, splice, num_stack, parameter_init, ops.dtype_id(dtype))
+        self.input_size, self.splice, self.num_stack = input_size, splice, num_stack
+
+    def build(self, store, input_dim, rng, scope_prefix=''):
+        assert input_dim == self.front.F * self.front.W * 3
+        self.front.build(store, rng, scope_prefix)
+        return super(_VGGRecurrentMixin, self).build(store, 256, rng, scope_prefix)
+
+    def __call__(self, inputs, inputs_seq_len, keep_prob, is_training, drop_masks=None, rng_state=None):
+        if self.layers is None:
+            store = ParamStore(inputs.device)
+            self.build(store, inputs.shape[-1], np.random.RandomState(self.seed))
+            store.finalize()
+        x = self.front.forward(inputs.contiguous(), float(keep_prob), is_training,
+                               rng_state or (self.seed, 1 << 50))
+        return super(_VGGRecurrentMixin, self).__call__(x, inputs_seq_len, keep_prob, is_training, drop_masks,
+                                                        rng_state)
+
+    def backward(self, d_outputs, d_final=None):
+        dx = super(_VGGRecurrentMixin, self).backward(d_outputs, d_final, need_input_grad=True)   # [T,Bp,256]
+        B = self.batch
+        self.front.backward(dx[:, :B].transpose(0, 1).contiguous())
+        return None
+
+
+class VGGBLSTMEncoder(_VGGRecurrentMixin, BLSTMEncoder):
+    """models/encoders/core/vgg_blstm.py:17 VGGBLSTMEncoder."""
+
+    def __init__(self, input_size, splice, num_stack, num_units, num_proj, num_layers, lstm_impl, use_peephole,
+                 parameter_init, clip_activation, time_major=False, name='vgg_blstm_encoder', dtype=ASR_F32, seed=0):
+        BLSTMEncoder.__init__(self, num_units, num_proj, num_layers, lstm_impl, use_peephole, parameter_init,
+                              clip_activation, time_major, name, dtype, seed)
+        self._vgg_init(input_size, splice, num_stack, parameter_init, dtype)
+
+
+class VGGLSTMEncoder(_VGGRecurrentMixin, LSTMEncoder):
+    """models/encoders/core/vgg_lstm.py VGGLSTMEncoder (same front-end, unidirectional stack)."""
+
+    def __init__(self, input_size, splice, num_stack, num_units, num_proj, num_layers, lstm_impl, use_peephole,
+                 parameter_init, clip_activation, time_major=False, name='vgg_lstm_encoder', dtype=ASR_F32, seed=0):
+        LSTMEncoder.__init__(self, num_units, num_proj, num_layers, lstm_impl, use_peephole, parameter_init,
+                             clip_activation, time_major, name, dtype, seed)
+        self._vgg_init(input_size, splice, num_stack, parameter_init, dtype)

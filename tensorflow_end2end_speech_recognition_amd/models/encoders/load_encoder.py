@@ -7,10 +7,13 @@ pyramid_blstm, cldnn_wang, student_*) are not built
 them raises the same ValueError as an unknown key."""
 from .core.blstm import BLSTMEncoder
 from .core.lstm import LSTMEncoder
+from .core.vgg_blstm import VGGBLSTMEncoder, VGGLSTMEncoder
 
 ENCODERS = {
     "blstm": BLSTMEncoder,
     "lstm": LSTMEncoder,
+    "vgg_blstm": VGGBLSTMEncoder,
+    "vgg_lstm": VGGLSTMEncoder,
 }
 
 

@@ -107,7 +107,7 @@ def colsum(a, out=None):
 
 
 # ---------------------------------------------------------------- GEMM
-def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, accumulate=False):
+def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, accumulate=False, relu=False):
     """C = op(A) @ op(B) (+bias) (+C).  A, B 2-D, same dtype (f32 or bf16), row stride = ld."""
     h = _h(A)
     dt = dtype_id(A.dtype)
@@ -129,11 +129,58 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, 
             raise ValueError('gemm: bad out shape %s' % (tuple(out.shape),))
     if bias is not None:
         _chk(bias, torch.float32, 'bias')
-    h.check(h.lib.asr_gemm(h.h, dt, odt, int(transA), int(transB), M, N, K,
-                           C.c_void_p(A.data_ptr()), A.stride(0), C.c_void_p(B.data_ptr()), B.stride(0),
-                           C.c_void_p(out.data_ptr()), out.stride(0), _p(bias), int(accumulate), _s()),
-            'asr_gemm')
+    h.check(h.lib.asr_gemm_act(h.h, dt, odt, int(transA), int(transB), M, N, K,
+                               C.c_void_p(A.data_ptr()), A.stride(0), C.c_void_p(B.data_ptr()), B.stride(0),
+                               C.c_void_p(out.data_ptr()), out.stride(0), _p(bias), int(accumulate),
+                               1 if relu else 0, _s()), 'asr_gemm')
     return out
+
+
+# ---------------------------------------------------------------- VGG front-end
+def im2col3x3(x_nhwc, ldp=None, out=None):
+    h = _h(x_nhwc)
+    dt = dtype_id(x_nhwc.dtype)
+    N, H, W, Cin = x_nhwc.shape
+    ldp = ldp or 9 * Cin
+    if out is None:
+        out = torch.zeros((N * H * W, ldp), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    h.check(h.lib.asr_im2col3x3(h.h, dt, _p(x_nhwc), N, H, W, Cin, ldp, _p(out), _s()), 'asr_im2col3x3')
+    return out
+
+
+def col2im3x3(dpatches, N, H, W, Cin):
+    h = _h(dpatches)
+    _chk(dpatches, torch.float32, 'dpatches')
+    din = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dpatches.device)
+    h.check(h.lib.asr_col2im3x3(h.h, _p(dpatches), N, H, W, Cin, dpatches.stride(0), _p(din), _s()), 'asr_col2im3x3')
+    return din
+
+
+def maxpool2x2_fwd(x_nhwc):
+    h = _h(x_nhwc)
+    dt = dtype_id(x_nhwc.dtype)
+    N, H, W, Cc = x_nhwc.shape
+    out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, Cc), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    arg = torch.empty(out.shape, dtype=torch.uint8, device=x_nhwc.device)
+    h.check(h.lib.asr_maxpool2x2_fwd(h.h, dt, _p(x_nhwc), N, H, W, Cc, _p(out), _p(arg), _s()), 'asr_maxpool2x2_fwd')
+    return out, arg
+
+
+def maxpool2x2_bwd(dout, arg, H, W):
+    h = _h(dout)
+    N, _, _, Cc = dout.shape
+    din = torch.empty((N, H, W, Cc), dtype=torch.float32, device=dout.device)
+    h.check(h.lib.asr_maxpool2x2_bwd(h.h, _p(dout), _p(arg), N, H, W, Cc, _p(din), _s()), 'asr_maxpool2x2_bwd')
+    return din
+
+
+def relu_bwd(dout, out, mask=None):
+    """dout fp32, out in the operand dtype -> dpre (operand dtype) = dout * (out>0) (* mask)."""
+    h = _h(dout)
+    dt = dtype_id(out.dtype)
+    dpre = torch.empty_like(out)
+    h.check(h.lib.asr_relu_bwd(h.h, dt, _p(dout), _p(out), _p(mask), out.numel(), _p(dpre), _s()), 'asr_relu_bwd')
+    return dpre
 
 
 # ---------------------------------------------------------------- LSTM

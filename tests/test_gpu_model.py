@@ -108,3 +108,38 @@ def test_dropout_path_runs_and_masks(cuda):
     l3, _ = model.compute_loss(x, dense, sl, keep_prob=0.5, is_training=False)   # eval: no dropout
     assert abs(l1.item() - l2.item()) > 1e-4
     assert np.isfinite(l3.item())
+
+
+def test_vgg_blstm_ctc_parity(cuda):
+    """VGG front-end + BLSTM + CTC (BASELINE config C topology, small): loss and every gradient vs the oracle."""
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    rng = np.random.RandomState(2)
+    B, T, F, W, H, L, C = 3, 9, 8, 5, 64, 1, 7          # input_size = 3F = 24, splice 5
+    D = F * W * 3
+    x, sl, labs, dense = _batch(rng, B, T, D, C, lo=4)
+    model = CTC(encoder_type='vgg_blstm', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
+                parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='f32', seed=4)
+    sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+    # non-zero biases so that the bias paths are exercised
+    for k in sd:
+        if k.endswith('/bias') or k.endswith('/biases'):
+            sd[k] = (rng.randn(*sd[k].shape) * 0.05).astype(np.float32)
+    model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    ref = omodel.ctc_model_forward(sd, x, labs, sl, L, ndir=2, cell_clip=50.0, vgg=(F, W))
+    loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-4
+    assert np.abs(logits.cpu().numpy() - ref['logits']).max() < 2e-4
+    opt = model._set_optimizer('sgd', 0.1)
+    for g, name in opt.compute_gradients(loss, model=model):
+        r = ref['grads'][name]
+        err = np.abs(g.cpu().numpy() - r).max()
+        assert err < 2e-3 * max(np.abs(r).max(), 1e-3) + 1e-7, (name, err, np.abs(r).max())
+    # dropout path + bf16 operands run and train
+    m2 = CTC(encoder_type='vgg_blstm', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
+             clip_grad_norm=5.0, clip_activation=50, dtype='bf16', seed=4)
+    l0 = None
+    for it in range(25):
+        l, _ = m2.compute_loss(x, dense, sl, keep_prob=0.9)
+        m2.train(l, 'adam', 2e-3)
+        l0 = l.item() if l0 is None else l0
+    assert l.item() < 0.8 * l0
