@@ -1,0 +1,64 @@
+"""CPU: host data formats on either side of the path pinned to
+golden vectors produced by the reference's own functions (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_splice_and_stack_match_reference_golden():
+    from tensorflow_end2end_speech_recognition_amd.utils.io.inputs.splicing import do_splice
+    from tensorflow_end2end_speech_recognition_amd.utils.io.inputs.frame_stacking import stack_frame
+    g = np.load(os.path.join(GOLD, 'splice_v1.npz'))
+    for i in range(int(g['num_splice'])):
+        splice, num_stack = g['s%d_cfg' % i]
+        y = do_splice(g['s%d_in' % i], splice=int(splice), batch_size=2, num_stack=int(num_stack))
+        assert y.shape == g['s%d_out' % i].shape
+        assert np.array_equal(y, g['s%d_out' % i]), i
+    for i in range(int(g['num_stack'])):
+        num_stack, num_skip = g['f%d_cfg' % i]
+        y = stack_frame(np.array([g['f%d_in' % i]]), int(num_stack), int(num_skip))
+        assert np.array_equal(np.asarray(y[0], dtype=np.float64), g['f%d_out' % i]), i
+    # the reference's in-file self test (splicing.py:76-88)
+    assert do_splice(np.zeros((3, 100, 15)), splice=11, batch_size=3).shape == (3, 100, 165)
+
+
+def test_dataset_iterator_contract():
+    from tensorflow_end2end_speech_recognition_amd.utils.dataset.ctc import DatasetBase
+    rng = np.random.RandomState(0)
+
+    class DS(DatasetBase):
+        def __init__(self, num_gpu):
+            super(DS, self).__init__()
+            self.input_paths = [rng.randn(rng.randint(5, 30), 6) for _ in range(23)]
+            self.label_paths = [rng.randint(0, 5, size=rng.randint(1, 3)) for _ in range(23)]
+            self.batch_size, self.splice, self.num_stack, self.num_skip = 4 * num_gpu, 3, 2, 2
+            self.shuffle, self.sort_utt, self.sort_stop_epoch = False, True, 2
+            self.num_gpu, self.is_test, self.max_epoch = num_gpu, False, 2
+            self.rest = set(range(len(self.input_paths)))
+    for num_gpu in (1, 2):
+        ds = DS(num_gpu)
+        n = 0
+        for (inputs, labels, seq_len, names), new_epoch in ds:
+            assert len(inputs) == num_gpu
+            for gi in range(num_gpu):
+                x, l, s = inputs[gi], labels[gi], seq_len[gi]
+                assert x.dtype == np.float32 and x.shape[2] == 6 * 2 * 3
+                assert x.shape[1] == inputs[0].shape[1]                      # global max T across shards
+                for b in range(len(s)):
+                    assert np.all(x[b, s[b]:] == 0)
+                    assert s[b] >= (l[b] != -1).sum()                       # input length >= label length
+            n += sum(len(s) for s in seq_len)
+        assert n == 2 * 23 and ds.epoch == 2
+
+
+def test_lr_controller():
+    from tensorflow_end2end_speech_recognition_amd.utils.training.learning_rate_controller import Controller
+    c = Controller(1e-3, decay_start_epoch=2, decay_rate=0.5, decay_patient_epoch=1, lower_better=True)
+    lr = 1e-3
+    got = []
+    for ep, v in enumerate([0.9, 0.8, 0.85, 0.86, 0.7, 0.71, 0.72], 1):
+        lr = c.decay_lr(lr, ep, v)
+        got.append(lr)
+    assert got == [1e-3, 1e-3, 1e-3, 5e-4, 5e-4, 5e-4, 2.5e-4]
