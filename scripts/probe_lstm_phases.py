@@ -36,4 +36,4 @@ if H == 256:
             for g in range(4):
                 steps = a[d, g, 0, 5]
                 print('cluster dir', d, 'cu', g, ' '.join('%s %.0f' % (n, a[d, g, 0, k] / max(steps, 1)) for k, n in enumerate(names)),
-                      'total/step %.0f' % (a[d, g, 0, :4].sum() / max(steps, 1)))
+                      'total/step %.0f' % (a[d, g, 0, :4].sum() / max(steps, 1)), 'fast|loadRTT', a[d, g, 0, 6] if a[d, g, 0, 6] < 2 else a[d, g, 0, 6] / max(steps, 1), 'xcc|storeAck', a[d, g, 0, 7] if a[d, g, 0, 7] < 16 else a[d, g, 0, 7] / max(steps, 1), 'repolls/step %.2f' % (a[d, g, 0, 4] / max(steps, 1)))

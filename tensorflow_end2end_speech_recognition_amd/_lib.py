@@ -132,7 +132,10 @@ class Handle(object):
 _handles = {}
 
 
-def handle(device=0):
-    if device not in _handles:
-        _handles[device] = Handle(device)
-    return _handles[device]
+def handle(device=0, lane=0):
+    """lane 0 = the main launch stream's handle; lane 1 = a second handle (own split-K scratch)
+    for work issued on the side stream (ops.side_lane), so concurrent GEMMs never share scratch."""
+    key = (device, lane)
+    if key not in _handles:
+        _handles[key] = Handle(device)
+    return _handles[key]

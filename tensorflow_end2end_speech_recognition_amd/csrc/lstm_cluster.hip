@@ -17,6 +17,7 @@
 // Same semantics / data layouts as lstm.hip (gates interleaved [T,B,dir,H,4], etc.).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -251,6 +252,320 @@ __global__ __launch_bounds__(CT, 1) void lstm_fwd_cluster_kernel(
   }
 }
 
+// ---------------------------------------------------------------- forward, 8 waves
+// Same cluster / exchange as above with TWO waves per SIMD: the 4-wave form spends ~2.2k of its
+// 5.2k cycles/step in the gate math of 4 (row, unit) pairs per lane with nothing to hide the
+// v_exp/v_rcp latency chains behind.  Here a wave owns 8 units: tile 0 = columns [i x 8 | ci x 8],
+// tile 1 = [f x 8 | o x 8]; after the MFMAs lanes n and n^8 swap halves over DPP row_ror:8 so each
+// lane ends up with all four gates of TWO (row, unit) pairs; the second wave of the SIMD fills
+// the other's stalls.  LDS A-fragment reads double (8 waves x 8 KB) but hide behind the MFMAs.
+constexpr int CT8 = 512;
+
+__device__ __forceinline__ float dpp_ror8(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_xor1(float v) {   // quad_perm [1,0,3,2]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+
+// ---------------------------------------------------------------- cluster placement
+// Cluster c = tile * ndir + dir.  Block b of the 1-D grid: XCD slot x = b % 8, q = b / 8,
+// member g = q % G, round = q / G, cluster c = round * 8 + x.  grid = 8 * G * ceil(nclusters / 8).
+struct ClusterId { int c, g, d, tile; bool valid; };
+template <int G>
+__device__ __forceinline__ ClusterId cluster_id(int ndir, int ntiles) {
+  const int b = blockIdx.x, x = b & 7, q = b >> 3;
+  ClusterId r;
+  r.g = q % G;
+  r.c = (q / G) * 8 + x;
+  r.valid = r.c < ndir * ntiles;
+  r.d = r.c % ndir;
+  r.tile = r.c / ndir;
+  return r;
+}
+static inline unsigned cluster_grid(int G, int nclusters) { return 8u * G * ((nclusters + 7) / 8); }
+
+constexpr int XHDR = 16;                  // header granules per cluster (XCC ids of the members)
+constexpr unsigned XCC_EPOCH = 0x80000001u;
+
+// Every member publishes the XCC (= XCD) id it runs on with the placement-independent granule
+// protocol and reads all G of them: true iff the whole cluster shares one XCD, hence one L2.
+// Same inputs -> same answer on every member.
+template <int G>
+__device__ __forceinline__ bool same_xcd(u64* hdr, int g, bool& timed_out) {
+  const unsigned mine = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu;   // HW_REG_XCC_ID[3:0]
+  if (threadIdx.x == 0) gstore(hdr + g, XCC_EPOCH, mine);
+  bool same = true;
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    u64 v = gload(hdr + i);
+    unsigned spins = 0;
+    while ((unsigned)(v >> 32) != XCC_EPOCH) {
+      if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+      v = gload(hdr + i);
+    }
+    same = same && ((unsigned)v == mine);
+  }
+  return same;
+}
+// Granule publish.  Same-XCD cluster: a PLAIN 8-byte store stays in the shared L2, where the
+// consumers' L1-bypassing (sc1) polls find it after ~an L2 round trip; an sc1 store would drop the
+// line from L2 and make every poll a fabric round trip (MI355X_MICROARCH.md, store-flavour row).
+// Otherwise: the write-through agent-scope store, correct for any placement.
+__device__ __forceinline__ void gpublish(u64* p, unsigned epoch, unsigned payload, bool fast) {
+  const u64 v = ((u64)epoch << 32) | payload;
+  if (fast) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store, no wait
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// masked DPP: lanes whose bank (lane & 15) >> 2 is in `BANKS` take `src` of lane (i + 8) % 16 of
+// their row, the others keep `old` -- the halves swap without any v_cndmask
+template <int BANKS>
+__device__ __forceinline__ float dpp_ror8_into(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, src), 0x128, 0xF, BANKS, false));
+}
+
+// The kernel is instruction-issue bound (a wave issues ~1 instruction per 4 cycles; measured
+// 435 instructions/step -> 3.5k cycles), so the step body is written for instruction count:
+// exchange-buffer parity is a compile-time constant (loop unrolled by two), every address is an
+// incrementally advanced register, the phase timers (DBG) are a template parameter, nothing in
+// the loop is exec-masked.
+template <int H, bool DBG>
+__global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
+    int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const bf16_t* __restrict__ whp,
+    const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
+    float cell_clip, cbf16x4_t* __restrict__ gates, bf16_t* __restrict__ hout, float* __restrict__ cs,
+    float* __restrict__ c_final, float* __restrict__ h_final, u64* __restrict__ xch,
+    unsigned* __restrict__ err, int force_wt) {
+  constexpr int G = H / HS;
+  constexpr int KS = H / 32;
+  constexpr int LDH = H + 8;
+  constexpr int SLICE = 16 * (HS / 2);                     // granules one CU publishes per step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* hs = reinterpret_cast<bf16_t*>(smem);            // [2][16][LDH]
+
+  // 1-D grid laid out so that the G workgroups of a cluster get block ids congruent mod 8: the
+  // dispatcher is observed to put block b on XCD b % 8, so a cluster shares ONE L2 (speed only:
+  // the placement is verified below and the exchange falls back to write-through stores)
+  const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
+  if (!cid.valid) return;
+  const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rg = lane >> 4;
+  const bool lo = col < 8, odd = (col & 1) != 0;
+  const bool rev = (d == 1);
+  const bf16_t* wp = whp + (size_t)d * H * 4 * H;
+  const int ul = wave * 8 + (col & 7);                     // unit inside this CU's slice
+  const unsigned jw = g * HS + ul;                         // global unit of this lane
+  const int rbase = rg * 4 + (lo ? 0 : 2);                 // first of this lane's two batch rows
+
+  int len[2];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) len[r] = seq_len[b0 + rbase + r];
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  float c[2] = {0.f, 0.f}, hr[2] = {0.f, 0.f};
+  const float wci = peep ? peep[(d * 3 + 0) * H + jw] : 0.f;
+  const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
+  const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
+
+  for (int i = threadIdx.x; i < 2 * 16 * LDH; i += CT8) hs[i] = 0;
+  // B fragments straight out of the standard forward packing (tile = (unit/16)*4 + gate, column
+  // unit%16): this lane's column of tile p is (gate p*2 + (col>>3), unit jw)
+  bf16x8_t wreg[2][KS];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int tile = (jw >> 4) * 4 + p * 2 + (col >> 3);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wreg[p][ks] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)tile * KS + ks) * 64 + rg * 16 + (jw & 15)) * 8);
+  }
+
+  u64* xhdr = xch + (size_t)cid.c * (XHDR + 2 * G * SLICE);
+  u64* xbase = xhdr + XHDR;                                // [2 parity][G][8 waves][16 rows][4]
+  bool timed_out = false;
+  const bool colocated = same_xcd<G>(xhdr, g, timed_out);
+  const bool fast = colocated && !force_wt;                // same decision on every member
+  __syncthreads();
+
+  // element offsets into the [T,B,ndir,H] arrays: os = frame s (padded rows write their zeros
+  // there), oa = frame of the running step of an active row (s or len-1-s); both just advance
+  const unsigned stride = (unsigned)B_ * ndir * H;
+  const unsigned dstep = rev ? 0u - stride : stride;
+  unsigned oa[2], os[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    os[r] = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+    oa[r] = os[r] + (rev ? (unsigned)max(len[r] - 1, 0) * stride : 0u);
+  }
+  // per-lane exchange addresses (both parities): publish slot, the three foreign slices this
+  // wave polls (wave w polls the granules wave w of the peers publishes), LDS staging targets
+  const int prow = rbase + (odd ? 1 : 0);
+  u64* pub[2];
+  const u64* src[2][G - 1];
+  unsigned ldst[G - 1];                                    // byte offset inside one h buffer
+#pragma unroll
+  for (int P = 0; P < 2; ++P) {
+    pub[P] = xbase + ((size_t)P * G + g) * SLICE + wave * 64 + prow * 4 + ((col & 7) >> 1);
+#pragma unroll
+    for (int k = 0; k < G - 1; ++k) {
+      const int gsrc = k + (k >= g ? 1 : 0);
+      src[P][k] = xbase + ((size_t)P * G + gsrc) * SLICE + wave * 64 + lane;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < G - 1; ++k) {
+    const int gsrc = k + (k >= g ? 1 : 0);
+    ldst[k] = (unsigned)(((lane >> 2) & 15) * LDH + gsrc * HS + (wave * 4 + (lane & 3)) * 2) * 2u;
+  }
+  const unsigned lown = (unsigned)(prow * LDH + g * HS + (ul & ~1)) * 2u;
+  const unsigned lrd = (unsigned)(col * LDH + rg * 8) * 2u;
+
+  f32x4_t xn[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) xn[r] = xg[(0 < len[r]) ? oa[r] : os[r]];
+
+  unsigned long long* dbg = g_cdbg;
+  unsigned long long ph[4] = {0, 0, 0, 0};
+  unsigned nspin = 0;
+#define C8_T() (DBG ? (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime()) : 0ull)
+
+  auto step = [&](int s, auto PAR) {
+    constexpr int P = decltype(PAR)::value;                // parity of step s
+    const unsigned long long t0 = C8_T();
+    const char* hcur = smem + P * 16 * LDH * 2;
+    char* hnxt = smem + (1 - P) * 16 * LDH * 2;
+    const f32x4_t x0 = xn[0], x1 = xn[1];
+    if (s + 1 < tmax) {                                    // lands during this step's MFMA + gate math
+#pragma unroll
+      for (int r = 0; r < 2; ++r) xn[r] = xg[(s + 1 < len[r]) ? oa[r] + dstep : os[r] + stride];
+    }
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + ks * 64);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wreg[0][ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wreg[1][ks], acc1, 0, 0, 0);
+    }
+    if (DBG) { asm volatile("" : "+v"(acc0)); asm volatile("" : "+v"(acc1)); }
+    const unsigned long long t1 = C8_T();
+    // lanes n / n^8 swap halves: lo lanes (banks 0,1) keep rows 0,1 (own i,f + the partner's ci,o),
+    // hi lanes (banks 2,3) rows 2,3 (own ci,o + the partner's i,f)
+    float pi[2], pq[2], pf[2], po[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      pi[r] = dpp_ror8_into<0xC>(acc0[r], acc0[2 + r]);    // hi lanes <- partner's i of rows 2,3
+      pq[r] = dpp_ror8_into<0x3>(acc0[2 + r], acc0[r]);    // lo lanes <- partner's ci of rows 0,1
+      pf[r] = dpp_ror8_into<0xC>(acc1[r], acc1[2 + r]);
+      po[r] = dpp_ror8_into<0x3>(acc1[2 + r], acc1[r]);
+    }
+    const unsigned epoch = (unsigned)s + 1u;
+    bool act[2];
+    float ig[2], gg[2], fg[2], og[2], cn[2], hn[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) act[r] = s < len[r];
+    const f32x4_t xr[2] = {x0, x1};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) ig[r] = cfsig(pi[r] + xr[r][0] + wci * c[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) gg[r] = cftanh(pq[r] + xr[r][1]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) fg[r] = cfsig(pf[r] + xr[r][2] + forget_bias + wcf * c[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      cn[r] = gg[r] * ig[r] + c[r] * fg[r];
+      if (cell_clip > 0.f) cn[r] = fminf(fmaxf(cn[r], -cell_clip), cell_clip);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) og[r] = cfsig(po[r] + xr[r][3] + wco * cn[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) hn[r] = cftanh(cn[r]) * og[r];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      c[r] = act[r] ? cn[r] : c[r];
+      hr[r] = act[r] ? hn[r] : hr[r];
+    }
+    // publish: even lanes the (unit, unit+1) granule of row 0, odd lanes (unit-1, unit) of row 1
+    const float nb = dpp_xor1(odd ? hr[0] : hr[1]);
+    const unsigned pk = odd ? pack_bf16x2(nb, hr[1]) : pack_bf16x2(hr[0], nb);
+    gpublish(pub[P], epoch, pk, fast);
+    *reinterpret_cast<unsigned*>(hnxt + lown) = pk;
+    // saved activations; rows past their length write frame s of the padding (hout: zeros,
+    // gates / cs: never read there), so nothing is predicated
+    unsigned off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) off[r] = act[r] ? oa[r] : os[r];
+    {
+      const bool pact = odd ? act[1] : act[0];
+      const unsigned poff = (odd ? off[1] : off[0]) - (odd ? 1u : 0u);
+      *reinterpret_cast<unsigned*>(hout + poff) = pact ? pk : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      gates[off[r]] = (cbf16x4_t){(__bf16)ig[r], (__bf16)gg[r], (__bf16)fg[r], (__bf16)og[r]};
+      cs[off[r]] = cn[r];
+      oa[r] += dstep;
+      os[r] += stride;
+    }
+    const unsigned long long t2 = C8_T();
+    {
+      u64 v[G - 1];
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k) v[k] = gload(src[P][k]);
+      unsigned spins = 0;
+      for (;;) {                                           // wave-uniform loop: no exec masking
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) ok = ok && ((unsigned)(v[k] >> 32) == epoch);
+        if (__all(ok)) break;
+        if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) v[k] = gload(src[P][k]);
+      }
+      if (DBG) nspin += spins;
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k) *reinterpret_cast<unsigned*>(hnxt + ldst[k]) = (unsigned)v[k];
+    }
+    const unsigned long long t3 = C8_T();
+    __syncthreads();
+    if (DBG) {
+      const unsigned long long t4 = C8_T();
+      ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
+    }
+  };
+  int s = 0;
+  for (; s + 1 < tmax; s += 2) {
+    step(s, std::integral_constant<int, 0>{});
+    step(s + 1, std::integral_constant<int, 1>{});
+  }
+  if (s < tmax) step(s, std::integral_constant<int, 0>{});
+#undef C8_T
+
+  if (DBG && dbg && lane == 0 && cid.tile == 0 && wave < CW) {
+    unsigned long long* o = dbg + ((size_t)(d * G + g) * CW + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = ph[k];
+    o[4] = nspin;
+    o[5] = tmax;
+    o[6] = fast ? 1 : 0;
+    o[7] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu;
+  }
+  if (timed_out) atomicOr(err, 1u);
+  // zero-fill the common padded tail [tmax, T): os already points at frame tmax
+  for (int t = tmax; t < T_; ++t)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { hout[os[r]] = 0; os[r] += stride; }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const size_t o = ((size_t)d * B_ + b0 + rbase + r) * H + jw;
+    if (c_final) c_final[o] = c[r];
+    if (h_final) h_final[o] = hr[r];
+  }
+}
+
 // ---------------------------------------------------------------- backward
 // K-partition: CU g owns the gate gradients of its 64 units (k' = unit*4+q in its slice) and the
 // rows k' of W_h^T; each step it multiplies its dG slice by W_h^T[k' slice, all H] -> a partial
@@ -480,6 +795,15 @@ static void cdbg_setup() {
   (void)hipMemset(g_cdbg_host, 0, 256 * sizeof(unsigned long long));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cdbg), &g_cdbg_host, sizeof(g_cdbg_host));
 }
+static int cluster_waves() {   // ASR_LSTM_CW=4 selects the one-wave-per-SIMD forms
+  static const int w = [] { const char* e = getenv("ASR_LSTM_CW"); return (e && e[0] == '4') ? 4 : 8; }();
+  return w;
+}
+static int g_dflags = -1;
+static int dbg_flags() {   // bit 4 (16): force the placement-independent write-through exchange
+  if (g_dflags < 0) { const char* e = getenv("ASR_LSTM_DFLAGS"); g_dflags = e ? atoi(e) : 0; }
+  return g_dflags;
+}
 static bool cluster_enabled() {
   static const bool on = [] { const char* e = getenv("ASR_LSTM_CLUSTER"); return !(e && e[0] == '0'); }();
   return on;
@@ -501,10 +825,20 @@ bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
   u64* xch = (u64*)(base + 256);
   unsigned* err = (unsigned*)base;
-  (void)hipMemsetAsync(xch, 0, need, st);                  // tags must not survive from a previous launch
   const size_t lds = (size_t)2 * 16 * (HH + 8) * 2;
+  if (cluster_waves() == 8 && (size_t)T * B * ndir * HH < (1ull << 31)) {
+    const int ncl = (B / 16) * ndir;
+    const size_t need8 = (size_t)ncl * (XHDR + 2 * G * 16 * (HS / 2)) * sizeof(u64);
+    if (need8 + 256 > XCH_BYTES) return false;
+    (void)hipMemsetAsync(xch, 0, need8, st);
+    auto k = g_cdbg_host ? lstm_fwd_cluster8_kernel<HH, true> : lstm_fwd_cluster8_kernel<HH, false>;
+    hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8), lds, st, T, B, ndir, (const f32x4_t*)xproj,
+                       (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates, (bf16_t*)hout, cs, cf,
+                       hf, xch, err, (dbg_flags() & 16) ? 1 : 0);
+    return true;
+  }
+  (void)hipMemsetAsync(xch, 0, need, st);                  // tags must not survive from a previous launch
   auto k = lstm_fwd_cluster_kernel<HH>;
-  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(G, ndir, B / 16), dim3(CT), lds, st, T, B, ndir, (const f32x4_t*)xproj,
                      (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates, (bf16_t*)hout, cs, cf, hf,
                      xch, err);
@@ -531,6 +865,7 @@ bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
   return true;
 }
 
+extern "C" int asr_debug_set_lstm_flags(int flags) { g_dflags = flags; return 0; }
 extern "C" int asr_debug_cluster_cycles(unsigned long long* out, int n) {
   if (!g_cdbg_host || n > 256) return -1;
   return hipMemcpy(out, g_cdbg_host, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;

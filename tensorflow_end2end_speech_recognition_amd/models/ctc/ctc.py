@@ -173,8 +173,11 @@ class CTC(ModelBase):
         flat, offsets, max_len = self._labels_to_flat(labels, B)
         if Bp > B:
             offsets = np.concatenate([offsets, np.full(Bp - B, offsets[-1], dtype=np.int32)])
-        flat_d = torch.from_numpy(np.ascontiguousarray(flat if len(flat) else np.zeros(1, np.int32))).to(dev)
-        off_d = torch.from_numpy(np.ascontiguousarray(offsets)).to(dev)
+        # pinned staging + async copy: a pageable H2D would block the host until the whole forward
+        # has drained and leave the GPU idle while the CTC launches are issued
+        flat_d = torch.from_numpy(np.ascontiguousarray(flat if len(flat) else np.zeros(1, np.int32))) \
+            .pin_memory().to(dev, non_blocking=True)
+        off_d = torch.from_numpy(np.ascontiguousarray(offsets)).pin_memory().to(dev, non_blocking=True)
         ctc_in = logits
         inv_temp = 1.0 / float(softmax_temperature)
         if softmax_temperature != 1:
@@ -206,9 +209,10 @@ class CTC(ModelBase):
         sh = st.shadow(self.dtype)
         dl2d = dlogits.view(T * Bp, C)
         dl_op = ops.cast_from_f32(dl2d, ASR_BF16) if self.dtype == ASR_BF16 else dl2d
-        ops.gemm(x_op.view(T * Bp, E), dl_op, transA=True, out=st.g('output/weights'))
-        ops.colsum(dl2d, out=st.g('output/biases'))
         denc = ops.gemm(dl_op, sh['output/weights'], transB=True, out_dtype=ASR_F32)
+        with ops.side_lane(dlogits.device, keep=(x_op, dl_op, dl2d)):   # joined by encoder.backward
+            ops.gemm(x_op.view(T * Bp, E), dl_op, transA=True, out=st.g('output/weights'))
+            ops.colsum(dl2d, out=st.g('output/biases'))
         self.encoder.backward(denc.view(T, Bp, E))
         if self.weight_decay > 0:
             ops.weight_decay(st.grad, st.flat, st.plan, st.decay_mask, self.weight_decay)

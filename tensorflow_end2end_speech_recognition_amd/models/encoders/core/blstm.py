@@ -116,6 +116,7 @@ class _RecurrentEncoderBase(object):
             if d_final is not None and li == len(self.layers) - 1:
                 dcf, dhf = d_final
             dx = self.layers[li].backward(dx.contiguous(), dcf, dhf, need_dx=(li > 0 or need_input_grad))
+        ops.join_side(d_outputs.device)      # weight-gradient GEMMs issued on the side stream
         return dx
 
 

@@ -114,24 +114,29 @@ class LSTMLayer(object):
         h2d = hout.view(T * B, ndir * H)
         dg2d = dgates.view(T * B, ndir * 4 * H)
         dx = torch.empty((T, B, din), dtype=torch.float32, device=x.device) if need_dx else None
-        dw_il = torch.empty((din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved columns
-        for d, base in enumerate(self.bases):
-            dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
-            ops.gemm(x2d, dg, transA=True, out=dw_il[:din])
-            if T > 1:
-                if d == 0:   # forward direction: h_prev(t) = h(t-1)
-                    ops.gemm(h2d[:(T - 1) * B, d * H:(d + 1) * H], dg[B:], transA=True, out=dw_il[din:])
-                else:        # backward direction: h_prev(t) = h(t+1) (zero beyond len-1)
-                    ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=dw_il[din:])
-            else:
-                dw_il[din:].zero_()
-            ops.gate_deinterleave(dw_il, st.g(base + '/kernel'), H)
-            st.g(base + '/bias').copy_(dpeep[d, 3:7].reshape(-1))   # bias grad accumulated inside BPTT
-            if self.use_peephole:
-                st.g(base + '/w_i_diag').copy_(dpeep[d, 0])
-                st.g(base + '/w_f_diag').copy_(dpeep[d, 1])
-                st.g(base + '/w_o_diag').copy_(dpeep[d, 2])
-            if need_dx:
-                ops.gemm(dg, c['wx_il'][d], transB=True, out=dx.view(T * B, din), accumulate=(d > 0))
+        if need_dx:   # the only result the layer below waits for: main stream, first
+            for d in range(ndir):
+                ops.gemm(dg2d[:, d * 4 * H:(d + 1) * 4 * H], c['wx_il'][d], transB=True,
+                         out=dx.view(T * B, din), accumulate=(d > 0))
+        # weight gradients: side stream, concurrent with the BPTT kernel of the layer below
+        # (joined in the model's backward before clipping)
+        dw_il = torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols
+        with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il)):
+            for d, base in enumerate(self.bases):
+                dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
+                ops.gemm(x2d, dg, transA=True, out=dw_il[d, :din])
+                if T > 1:
+                    if d == 0:   # forward direction: h_prev(t) = h(t-1)
+                        ops.gemm(h2d[:(T - 1) * B, d * H:(d + 1) * H], dg[B:], transA=True, out=dw_il[d, din:])
+                    else:        # backward direction: h_prev(t) = h(t+1) (zero beyond len-1)
+                        ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=dw_il[d, din:])
+                else:
+                    dw_il[d, din:].zero_()
+                ops.gate_deinterleave(dw_il[d], st.g(base + '/kernel'), H)
+                st.g(base + '/bias').copy_(dpeep[d, 3:7].reshape(-1))   # bias grad accumulated inside BPTT
+                if self.use_peephole:
+                    st.g(base + '/w_i_diag').copy_(dpeep[d, 0])
+                    st.g(base + '/w_f_diag').copy_(dpeep[d, 1])
+                    st.g(base + '/w_o_diag').copy_(dpeep[d, 2])
         self.ctx = None
         return dx

@@ -23,10 +23,55 @@ def dtype_id(dtype):
     raise ValueError('dtype must be f32 or bf16, got %r' % (dtype,))
 
 
+_lane = 0            # 0: main stream / handle, 1: side stream / second handle (side_lane)
+_side = {}           # device index -> dict(stream, keep)
+
+
 def _h(t):
     if not t.is_cuda:
         raise RuntimeError('HIP path needs a CUDA(ROCm) tensor; there is no CPU fallback')
-    return _lib.handle(t.device.index or 0)
+    return _lib.handle(t.device.index or 0, _lane)
+
+
+class side_lane(object):
+    """Issue the enclosed launches on a second HIP stream (with its own handle, i.e. its own
+    split-K scratch) ordered after everything already on the main stream.  Used for work
+    nothing downstream waits on until the optimizer (weight-gradient GEMMs), so it overlaps
+    with the next layer's BPTT kernel, which only occupies a handful of CUs.
+    `keep`: tensors the side work reads/writes -- held until join_side() so the caching
+    allocator cannot hand their memory to later main-stream allocations."""
+
+    def __init__(self, device, keep=()):
+        self.dev = device.index or 0
+        self.keep = list(keep)
+
+    def __enter__(self):
+        global _lane
+        st = _side.get(self.dev)
+        if st is None:
+            st = _side[self.dev] = dict(stream=torch.cuda.Stream(device=self.dev), keep=[])
+        st['keep'].extend(self.keep)
+        st['stream'].wait_stream(torch.cuda.current_stream(self.dev))
+        self._ctx = torch.cuda.stream(st['stream'])
+        self._ctx.__enter__()
+        self._prev = _lane
+        _lane = 1
+        return self
+
+    def __exit__(self, *exc):
+        global _lane
+        _lane = self._prev
+        self._ctx.__exit__(*exc)
+        return False
+
+
+def join_side(device):
+    """Main stream waits for all side-lane work; releases the tensors held for it."""
+    st = _side.get(device.index or 0)
+    if st is None:
+        return
+    torch.cuda.current_stream(device.index or 0).wait_stream(st['stream'])
+    st['keep'] = []
 
 
 def _s():
