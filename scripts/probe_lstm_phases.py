@@ -27,13 +27,19 @@ for d in range(2):
               ' total/step %.0f' % (a[d, w, :5].sum() / max(steps, 1)))
 
 if H == 256:
-    buf2 = (ctypes.c_ulonglong * 256)()
+    buf2 = (ctypes.c_ulonglong * 1280)()
     lib.asr_debug_cluster_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    if lib.asr_debug_cluster_cycles(buf2, 256) == 0:
-        a = np.array(list(buf2), dtype=np.float64).reshape(2, 4, 4, 8)
-        names = ['mfma', 'gate+publish', 'gather', 'barrier']
-        for d in range(2):
-            for g in range(4):
-                steps = a[d, g, 0, 5]
-                print('cluster dir', d, 'cu', g, ' '.join('%s %.0f' % (n, a[d, g, 0, k] / max(steps, 1)) for k, n in enumerate(names)),
-                      'total/step %.0f' % (a[d, g, 0, :4].sum() / max(steps, 1)), 'fast|loadRTT', a[d, g, 0, 6] if a[d, g, 0, 6] < 2 else a[d, g, 0, 6] / max(steps, 1), 'xcc|storeAck', a[d, g, 0, 7] if a[d, g, 0, 7] < 16 else a[d, g, 0, 7] / max(steps, 1), 'repolls/step %.2f' % (a[d, g, 0, 4] / max(steps, 1)))
+    if lib.asr_debug_cluster_cycles(buf2, 1280) == 0:
+        allv = np.array(list(buf2), dtype=np.float64)
+        for label, a in (('fwd', allv[256:768].reshape(2, 4, 8, 8)), ('bwd', allv[768:1280].reshape(2, 4, 8, 8))):
+            names = ['p0', 'p1', 'p2', 'p3']
+            for d in range(2):
+                for g in (0, 1):
+                    for w in range(8):
+                        steps = a[d, g, w, 5]
+                        if steps == 0:
+                            continue
+                        print('cluster8', label, 'dir', d, 'cu', g, 'wave', w,
+                              ' '.join('%s %.0f' % (n, a[d, g, w, k] / steps) for k, n in enumerate(names)),
+                              'total/step %.0f' % (a[d, g, w, :4].sum() / steps), 'fast', a[d, g, w, 6], 'xcc', a[d, g, w, 7],
+                              'repolls/step %.2f' % (a[d, g, w, 4] / steps))

@@ -252,6 +252,14 @@ __global__ __launch_bounds__(CT, 1) void lstm_fwd_cluster_kernel(
   }
 }
 
+// 16-byte exchange store of self-tagged words.  Same-XCD cluster: plain store (stays in the shared
+// L2); otherwise sc1 (write-through), as the agent-scope atomics lower to.  Inline asm pins the store
+// in program order (a plain C++ store could legally sink below the spin loop that follows).
+__device__ __forceinline__ void xstore16(f32x4_t* p, f32x4_t v, bool fast) {
+  if (fast) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 // ---------------------------------------------------------------- forward, 8 waves
 // Same cluster / exchange as above with TWO waves per SIMD: the 4-wave form spends ~2.2k of its
 // 5.2k cycles/step in the gate math of 4 (row, unit) pairs per lane with nothing to hide the
@@ -444,11 +452,16 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
       for (int r = 0; r < 2; ++r) xn[r] = xg[(s + 1 < len[r]) ? oa[r] + dstep : os[r] + stride];
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // all A fragments in flight at once (left alone the scheduler recycles ONE register and
+    // exposes the LDS latency KS times: 870 cycles for 16 MFMAs)
+    bf16x8_t afr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + ks * 64);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + ks * 64);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wreg[0][ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wreg[1][ks], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[0][ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[1][ks], acc1, 0, 0, 0);
     }
     if (DBG) { asm volatile("" : "+v"(acc0)); asm volatile("" : "+v"(acc1)); }
     const unsigned long long t1 = C8_T();
@@ -544,8 +557,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   if (s < tmax) step(s, std::integral_constant<int, 0>{});
 #undef C8_T
 
-  if (DBG && dbg && lane == 0 && cid.tile == 0 && wave < CW) {
-    unsigned long long* o = dbg + ((size_t)(d * G + g) * CW + wave) * 8;
+  if (DBG && dbg && lane == 0 && cid.tile == 0) {
+    unsigned long long* o = dbg + 256 + ((size_t)(d * G + g) * 8 + wave) * 8;   // [256, 768): 8-wave kernels
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = ph[k];
     o[4] = nspin;
@@ -784,6 +797,308 @@ __global__ __launch_bounds__(CT, 1) void lstm_bwd_cluster_kernel(
   }
 }
 
+// ---------------------------------------------------------------- backward, 8 waves
+// Same partition as lstm_bwd_cluster_kernel (CU g owns the gate gradients of its 64 units and the
+// matching rows of W_h^T; partial dh_prev for all units, reduce-scatter to the owners), rebuilt
+// around what bounds these kernels (instruction issue + the cross-CU hop):
+//  * a thread owns TWO (row, unit) pairs in the MFMA C layout: wave w = (hh = w >> 2, wt = w & 3),
+//    lane (col, rg) -> unit wt*16 + col of the slice, rows rg*4 + hh*2 + {0,1};
+//  * the own-unit tile wt is computed by BOTH waves wt and wt+4 (8 extra MFMAs per wave), so the
+//    own partial is already in the right registers: no LDS hand-over, ONE barrier per step;
+//  * foreign tiles (12 per CU) are spread 2/1 over the waves of each SIMD and published with one
+//    16-byte store per lane: 4 rows of one unit, every fp32 word carrying the step's parity tag in
+//    its mantissa LSB (the data is the flag, per word, so any store width is tear-proof);
+//  * everything that does not depend on dh (tanh(c), the gate-derivative factors) is computed
+//    while the polls for the peers' partials are in flight.
+// xch per cluster: header + [2 parity][G dst][G src][4 tiles][64 lanes][4 words].
+template <int H, bool DBG>
+__global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
+    int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
+    const float* __restrict__ cs, const bf16_t* __restrict__ whpb, const float* __restrict__ peep,
+    const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
+    const float* __restrict__ d_h_final, cbf16x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
+    u64* __restrict__ xch, unsigned* __restrict__ err, int force_wt) {
+  constexpr int G = H / HS;
+  constexpr int KC = 4 * HS / 32;            // k-chunks of this CU's slice (8)
+  constexpr int KSF = 4 * H / 32;            // k-chunks of the full packing
+  constexpr int LDG = 4 * HS + 8;
+  constexpr size_t CL_U64 = XHDR + (size_t)2 * G * G * 4 * 64 * 2;   // u64 words per cluster
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // smem: [2][16][LDG] bf16 -- the own dG slice (MFMA A operand), double-buffered by iteration
+  // parity so that ONE barrier per step orders writers and readers
+  constexpr int DGB = 16 * LDG * 2;                        // bytes per buffer
+
+  const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
+  if (!cid.valid) return;
+  const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, rg = lane >> 4;
+  const int hh = wave >> 2, wt = wave & 3;
+  const bool rev = (d == 1);
+  const bf16_t* wp = whpb + (size_t)d * H * 4 * H;
+  const int ul = wt * 16 + col;
+  const unsigned jw = g * HS + ul;
+  const int rbase = rg * 4 + hh * 2;
+
+  int len[2];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) len[r] = seq_len[b0 + rbase + r];
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  const float wci = peep ? peep[(d * 3 + 0) * H + jw] : 0.f;
+  const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
+  const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
+
+  // element offsets: os = frame s, oa = frame of step s for an active row (s or len-1-s)
+  const unsigned stride = (unsigned)B_ * ndir * H;
+  const unsigned dstep = rev ? stride : 0u - stride;      // oa moves with decreasing s
+  unsigned oa[2], os[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned base = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+    os[r] = base + (unsigned)(tmax - 1) * stride;
+    oa[r] = base + (unsigned)(rev ? len[r] - tmax : tmax - 1) * stride;
+  }
+  // zero the gate gradients of the common padded tail [tmax, T)
+  {
+    const cbf16x4_t gzero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    for (int t = tmax; t < T_; ++t)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) dgates[os[r] + (unsigned)(t - tmax + 1) * stride] = gzero;
+  }
+
+  float dhr[2], dcr[2], cc[2];
+  float sums[7] = {0, 0, 0, 0, 0, 0, 0};     // dwci, dwcf, dwco, db_i, db_g, db_f, db_o
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const size_t o = ((size_t)d * B_ + b0 + rbase + r) * H + jw;
+    dhr[r] = d_h_final ? d_h_final[o] : 0.f;
+    dcr[r] = d_c_final ? d_c_final[o] : 0.f;
+    cc[r] = (tmax > 0 && tmax - 1 < len[r]) ? cs[oa[r]] : 0.f;
+  }
+  // W_h^T fragments: own tile (4g + wt), foreign tile f0 = wave, and (waves 0-3) f1 = 8 + wave.
+  // foreign index f in [0,12): destination CU = (f >> 2) skipping g, tile inside it = f & 3
+  auto ftile = [&](int f) { const int q = f >> 2; return ((q + (q >= g ? 1 : 0)) << 2) | (f & 3); };
+  const int nt_own = g * 4 + wt, nt_f0 = ftile(wave), nt_f1 = ftile(8 + wt);
+  bf16x8_t wo[KC], w0[KC], w1[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    wo[kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_own * KSF + g * KC + kc) * 64 + lane) * 8);
+    w0[kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_f0 * KSF + g * KC + kc) * 64 + lane) * 8);
+    w1[kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_f1 * KSF + g * KC + kc) * 64 + lane) * 8);
+  }
+
+  u64* xhdr = xch + (size_t)cid.c * CL_U64;
+  bool timed_out = false;
+  const bool fast = same_xcd<G>(xhdr, g, timed_out) && !force_wt;
+  f32x4_t* xs = reinterpret_cast<f32x4_t*>(xhdr + XHDR);   // [2][G dst][G src][4][64] x 16 B
+  auto slot = [&](int par, int dst, int src_, int tile) -> f32x4_t* {
+    return xs + ((((size_t)par * G + dst) * G + src_) * 4 + tile) * 64 + lane;
+  };
+  f32x4_t* pub0[2];
+  f32x4_t* pub1[2];
+  const u64* pol[2][G - 1];
+#pragma unroll
+  for (int P = 0; P < 2; ++P) {
+    pub0[P] = slot(P, nt_f0 >> 2, g, nt_f0 & 3);
+    pub1[P] = slot(P, nt_f1 >> 2, g, nt_f1 & 3);
+#pragma unroll
+    for (int k = 0; k < G - 1; ++k)
+      pol[P][k] = reinterpret_cast<const u64*>(slot(P, g, k + (k >= g ? 1 : 0), wt)) + hh;
+  }
+  const unsigned lwr = (unsigned)(rbase * LDG + ul * 4) * 2u;        // own dG rows -> LDS (bytes)
+  const unsigned lrd = (unsigned)(col * LDG + rg * 8) * 2u;          // A fragment reads
+
+  // saved activations of iteration s, fetched one iteration ahead
+  cbf16x4_t pg[2];
+  float pcp[2], pdh[2];
+  auto prefetch = [&](int s_) {                            // oa/os already hold iteration s_
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const bool act = s_ < len[r];
+      const bool ldp = (s_ > 0) && (s_ - 1 < len[r]);
+      const unsigned offl = act ? oa[r] : os[r];
+      const unsigned offn = ldp ? oa[r] + dstep : os[r];
+      pg[r] = gates[offl];
+      pcp[r] = cs[offn];
+      pdh[r] = dhout[offl];
+    }
+  };
+  if (tmax > 0) prefetch(tmax - 1);
+  __syncthreads();
+
+  unsigned long long* dbg = g_cdbg;
+  unsigned long long ph[4] = {0, 0, 0, 0};
+  unsigned nspin = 0;
+#define C8_T() (DBG ? (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime()) : 0ull)
+
+  auto step = [&](int s, auto PAR) {
+    constexpr int P = decltype(PAR)::value;                // parity of THIS iteration's publish
+    const int it = tmax - 1 - s;                           // 0, 1, ...
+    const unsigned long long t0 = C8_T();
+    // ---- 1. polls for the partials the peers published at the previous iteration (parity 1-P)
+    u64 pv[G - 1];
+    if (it > 0) {
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k) pv[k] = gload(pol[1 - P][k]);
+    }
+    // ---- 2. everything that does not need dh
+    bool act[2], ldp[2];
+    float gi[2], gq[2], gf[2], go[2], cprev[2], a_o[2], b_c[2], c_g[2], c_i[2], c_f[2];
+    unsigned off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      act[r] = s < len[r];
+      ldp[r] = (s > 0) && (s - 1 < len[r]);
+      off[r] = act[r] ? oa[r] : os[r];
+      gi[r] = (float)pg[r][0]; gq[r] = (float)pg[r][1]; gf[r] = (float)pg[r][2]; go[r] = (float)pg[r][3];
+      cprev[r] = (act[r] && s > 0) ? pcp[r] : 0.f;
+    }
+    float tc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) tc[r] = cftanh(cc[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      a_o[r] = tc[r] * go[r] * (1.f - go[r]);
+      b_c[r] = go[r] * (1.f - tc[r] * tc[r]);
+      c_g[r] = gi[r] * (1.f - gq[r] * gq[r]);
+      c_i[r] = gq[r] * gi[r] * (1.f - gi[r]);
+      c_f[r] = cprev[r] * gf[r] * (1.f - gf[r]);
+    }
+    const float pdh0 = pdh[0], pdh1 = pdh[1], pcp0 = pcp[0], pcp1 = pcp[1];
+    const float cur0 = cc[0], cur1 = cc[1];
+    // next iteration's inputs (independent of everything below)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { oa[r] += dstep; os[r] -= stride; }
+    if (s > 0) prefetch(s - 1);
+    // ---- 3. finish the polls: every word must carry the previous iteration's tag
+    if (it > 0) {
+      const unsigned want = (((unsigned)(it - 1) >> 1) + 1u) & 1u;
+      const u64 wmask = 0x0000000100000001ull, wtag = want ? wmask : 0ull;
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) ok = ok && ((pv[k] & wmask) == wtag);
+        if (__all(ok)) break;
+        if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) pv[k] = gload(pol[1 - P][k]);
+      }
+      if (DBG) nspin += spins;
+      float add0 = 0.f, add1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k) {                     // fixed order
+        add0 += __uint_as_float((unsigned)pv[k] & ~1u);
+        add1 += __uint_as_float((unsigned)(pv[k] >> 32) & ~1u);
+      }
+      dhr[0] += add0;
+      dhr[1] += add1;
+    }
+    const unsigned long long t1 = C8_T();
+    // ---- 4. gate gradients of the own pairs
+    const float pdhv[2] = {pdh0, pdh1}, pcpv[2] = {pcp0, pcp1}, curv[2] = {cur0, cur1};
+    float zi[2], zg[2], zf[2], zo[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float dh = pdhv[r] + dhr[r];
+      const float d_o = dh * a_o[r];
+      const float dc = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float d_g = dc * c_g[r], d_i = dc * c_i[r], d_f = dc * c_f[r];
+      dcr[r] = act[r] ? (dc * gf[r] + d_i * wci + d_f * wcf) : dcr[r];
+      dhr[r] = act[r] ? 0.f : dhr[r];
+      zi[r] = act[r] ? d_i : 0.f; zg[r] = act[r] ? d_g : 0.f;
+      zf[r] = act[r] ? d_f : 0.f; zo[r] = act[r] ? d_o : 0.f;
+      cc[r] = ldp[r] ? pcpv[r] : 0.f;
+      const cbf16x4_t pk = {(__bf16)zi[r], (__bf16)zg[r], (__bf16)zf[r], (__bf16)zo[r]};
+      *reinterpret_cast<cbf16x4_t*>(smem + P * DGB + lwr + r * LDG * 2) = pk;
+      dgates[off[r]] = pk;
+    }
+    const unsigned long long t2 = C8_T();
+    __syncthreads();
+    // peephole / bias gradient sums: off the critical path, behind the barrier
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      sums[0] += zi[r] * cprev[r]; sums[1] += zf[r] * cprev[r]; sums[2] += zo[r] * curv[r];
+      sums[3] += zi[r]; sums[4] += zg[r]; sums[5] += zf[r]; sums[6] += zo[r];
+    }
+    // ---- 5. partial dh_prev from the own dG slice; own tile stays, foreign tiles are published
+    if (s > 0) {
+      bf16x8_t afr[KC];
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) afr[kc] = *reinterpret_cast<const bf16x8_t*>(smem + P * DGB + lrd + kc * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned tag = (((unsigned)it >> 1) + 1u) & 1u;
+      auto tagged = [&](const f32x4_t& a) {
+        f32x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __uint_as_float((__float_as_uint(a[i]) & ~1u) | tag);
+        return o;
+      };
+      f32x4_t a0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], w0[kc], a0, 0, 0, 0);
+      xstore16(pub0[P], tagged(a0), fast);
+      if (wave < 4) {
+        f32x4_t a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], w1[kc], a1, 0, 0, 0);
+        xstore16(pub1[P], tagged(a1), fast);
+      }
+      f32x4_t ao = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wo[kc], ao, 0, 0, 0);
+      dhr[0] += hh ? ao[2] : ao[0];
+      dhr[1] += hh ? ao[3] : ao[1];
+    }
+    const unsigned long long t3 = C8_T();
+    if (DBG) { ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; }
+  };
+  (void)dbg;
+  // parity of iteration `it` is it & 1; iterations come in pairs from it = 0
+  int s = tmax - 1;
+  for (; s >= 1; s -= 2) {
+    step(s, std::integral_constant<int, 0>{});
+    step(s - 1, std::integral_constant<int, 1>{});
+  }
+  if (s == 0) step(0, std::integral_constant<int, 0>{});
+#undef C8_T
+
+  if (DBG && dbg && lane == 0 && cid.tile == 0) {
+    unsigned long long* o = dbg + 768 + ((size_t)(d * G + g) * 8 + wave) * 8;   // [768, 1280)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = ph[k];
+    o[4] = nspin;
+    o[5] = tmax;
+    o[6] = fast ? 1 : 0;
+    o[7] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu;
+  }
+  if (timed_out) atomicOr(err, 2u);
+  if (dpeep_part) {
+    // reduce over the 4 row groups of the wave, then over the two waves (hh) that share a unit
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      sums[k] += __shfl_xor(sums[k], 16, 64);
+      sums[k] += __shfl_xor(sums[k], 32, 64);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);           // [7][HS]
+    if (hh == 1 && rg == 0) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) red[k * HS + ul] = sums[k];
+    }
+    __syncthreads();
+    if (hh == 0 && rg == 0) {
+      float* p = dpeep_part + ((size_t)cid.tile * ndir + d) * 7 * H;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) p[k * H + jw] = sums[k] + red[k * HS + ul];
+    }
+  }
+}
+
 static unsigned long long* g_cdbg_host = nullptr;
 static void cdbg_setup() {
   static bool done = false;
@@ -791,8 +1106,8 @@ static void cdbg_setup() {
   done = true;
   const char* e = getenv("ASR_LSTM_DBG");
   if (!(e && e[0] == '1')) return;
-  (void)hipMalloc(&g_cdbg_host, 256 * sizeof(unsigned long long));
-  (void)hipMemset(g_cdbg_host, 0, 256 * sizeof(unsigned long long));
+  (void)hipMalloc(&g_cdbg_host, 1280 * sizeof(unsigned long long));
+  (void)hipMemset(g_cdbg_host, 0, 1280 * sizeof(unsigned long long));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cdbg), &g_cdbg_host, sizeof(g_cdbg_host));
 }
 static int cluster_waves() {   // ASR_LSTM_CW=4 selects the one-wave-per-SIMD forms
@@ -850,12 +1165,27 @@ bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
                          const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
                          float* dpeep_part, hipStream_t st) {
   if (!cluster_enabled() || H != 256) return false;
+  cdbg_setup();
   constexpr int HH = 256, G = HH / HS;
-  const size_t need = (size_t)(B / 16) * ndir * 2 * G * G * 16 * HS * sizeof(u64);
-  if (need + 256 > XCH_BYTES || h->scratch_bytes < XCH_BYTES) return false;
+  if (h->scratch_bytes < XCH_BYTES) return false;
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
   u64* xch = (u64*)(base + 256);
   unsigned* err = (unsigned*)base;
+  if (cluster_waves() == 8 && (size_t)T * B * ndir * HH < (1ull << 31)) {
+    const int ncl = (B / 16) * ndir;
+    const size_t need8 = (size_t)ncl * (XHDR + (size_t)2 * G * G * 4 * 64 * 2) * sizeof(u64);
+    if (need8 + 256 <= XCH_BYTES) {
+      (void)hipMemsetAsync(xch, 0, need8, st);             // tags must not survive from a previous launch
+      const size_t lds = (size_t)2 * 16 * (4 * HS + 8) * 2;
+      auto k = g_cdbg_host ? lstm_bwd_cluster8_kernel<HH, true> : lstm_bwd_cluster8_kernel<HH, false>;
+      hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8), lds, st, T, B, ndir, dhout,
+                         (const cbf16x4_t*)gates, cs, (const bf16_t*)whpb, peep, seq_len, dcf, dhf,
+                         (cbf16x4_t*)dgates, dpeep_part, xch, err, (dbg_flags() & 16) ? 1 : 0);
+      return true;
+    }
+  }
+  const size_t need = (size_t)(B / 16) * ndir * 2 * G * G * 16 * HS * sizeof(u64);
+  if (need + 256 > XCH_BYTES) return false;
   (void)hipMemsetAsync(xch, 0, need, st);
   const size_t lds = (size_t)16 * (4 * HS + 8) * 2 + (size_t)CW * 16 * 16 * 4;
   auto k = lstm_bwd_cluster_kernel<HH>;
@@ -867,7 +1197,7 @@ bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
 
 extern "C" int asr_debug_set_lstm_flags(int flags) { g_dflags = flags; return 0; }
 extern "C" int asr_debug_cluster_cycles(unsigned long long* out, int n) {
-  if (!g_cdbg_host || n > 256) return -1;
+  if (!g_cdbg_host || n > 1280) return -1;
   return hipMemcpy(out, g_cdbg_host, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 
