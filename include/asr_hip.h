@@ -63,6 +63,12 @@ int asr_device_info(asr_handle* h, int* num_cu, char* name, int name_len);
  * (tf.transpose(inputs,[1,0,2]) at models/encoders/core/blstm.py:277-279). */
 int asr_bt_to_tb(asr_handle* h, int dtype, const float* in_btd, void* out_tbd,
                  int B, int T, int D, asr_stream s);
+/* out[c*ld_out + r] = in[r*ld_in + c] for an [rows, cols] matrix in `dtype` (LDS-tiled, both
+ * sides coalesced).  The MFMA GEMM wants both operands reduction-contiguous; the k-major ones
+ * (W_x as stored by TF: [Din, 4H], models/encoders/core/blstm.py:286-320 via LSTMBlockCell's
+ * kernel) are transposed once per step instead of through bank-conflicting LDS scatter stores. */
+int asr_transpose2d(asr_handle* h, int dtype, const void* in, int rows, int cols, int ld_in,
+                    void* out, int ld_out, asr_stream s);
 /* fp32 -> dtype cast / dtype -> fp32 of n elements (weight copies for the MFMA path) */
 int asr_cast_from_f32(asr_handle* h, int dtype, const float* in, void* out, size_t n, asr_stream s);
 int asr_cast_to_f32(asr_handle* h, int dtype, const void* in, float* out, size_t n, asr_stream s);

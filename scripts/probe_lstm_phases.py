@@ -41,5 +41,5 @@ if H == 256:
                             continue
                         print('cluster8', label, 'dir', d, 'cu', g, 'wave', w,
                               ' '.join('%s %.0f' % (n, a[d, g, w, k] / steps) for k, n in enumerate(names)),
-                              'total/step %.0f' % (a[d, g, w, :4].sum() / steps), 'fast', a[d, g, w, 6], 'xcc', a[d, g, w, 7],
+                              'total/step %.0f' % (a[d, g, w, :4].sum() / steps), 'fast', a[d, g, w, 6], 'x7/step %.0f' % (a[d, g, w, 7] / steps),
                               'repolls/step %.2f' % (a[d, g, w, 4] / steps))

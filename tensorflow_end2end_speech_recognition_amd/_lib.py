@@ -24,6 +24,7 @@ SIGNATURES = {
     'asr_last_error_string': (C.c_char_p, [_vp]),
     'asr_device_info': (_i, [_vp, C.POINTER(_i), C.c_char_p, _i]),
     'asr_bt_to_tb': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'asr_transpose2d': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
     'asr_cast_from_f32': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     'asr_cast_to_f32': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     'asr_apply_mask': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -267,6 +267,36 @@ __global__ void scale_kernel(float* __restrict__ x, size_t n, float sc) {
 
 #define ASR_NEED(cond, ...) do { if (!(cond)) ASR_FAIL(h, ASR_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
 
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const T* __restrict__ in, int rows, int cols, int ld_in,
+                                                          T* __restrict__ out, int ld_out) {
+  __shared__ T tile[64][64 + 2];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(size_t)(r0 + i) * ld_in + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4)
+    if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * ld_out + r0 + tx] = tile[tx][i];
+}
+
+extern "C" int asr_transpose2d(asr_handle* h, int dtype, const void* in, int rows, int cols, int ld_in,
+                               void* out, int ld_out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(asr_dtype_ok(dtype) && in && out && rows >= 0 && cols >= 0 && ld_in >= cols && ld_out >= rows,
+           "asr_transpose2d: bad args");
+  if (rows == 0 || cols == 0) return ASR_OK;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL(transpose2d_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)in, rows, cols,
+                       ld_in, (float*)out, ld_out);
+  else
+    hipLaunchKernelGGL(transpose2d_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, rows, cols,
+                       ld_in, (bf16_t*)out, ld_out);
+  ASR_CHECK_LAUNCH(h, "asr_transpose2d");
+  return ASR_OK;
+}
+
 extern "C" int asr_bt_to_tb(asr_handle* h, int dtype, const float* in, void* out, int B, int T, int D,
                             asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;

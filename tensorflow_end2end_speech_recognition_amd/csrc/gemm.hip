@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
                                                    TO* __restrict__ C, int ldc,
                                                    const float* __restrict__ bias, int accumulate,
                                                    int a_aligned, int b_aligned, int kchunk,
-                                                   float* __restrict__ partial, int act) {
+                                                   float* __restrict__ partial, int act, int c_vec) {
   constexpr int BK = GT<T>::BK, VEC = GT<T>::VEC;
   constexpr int LDS_LD = BK + VEC;  // +16 B pad
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
   const int kbeg = blockIdx.z * kchunk;
   const int kend = min(K, kbeg + kchunk);
   const int nkt = (kend - kbeg + BK - 1) / BK;
+  // LDS is double-buffered: tile kt+1 is stored into the other buffer while nobody reads it, so
+  // one barrier per k-tile orders everything (writers of buffer b at kt+1 have passed the
+  // barrier of kt, which every reader of b reached only after finishing tile kt-1).
+  constexpr int STAGE = (BM + BN) * LDS_LD;
   la.load(A, lda, m0, kbeg, M, kend, a_aligned);
   lb.load(B, ldb, n0, kbeg, N, kend, b_aligned);
   la.store(As, LDS_LD);
@@ -132,6 +136,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
+    const T* Ac = As + (kt & 1) * STAGE;
+    const T* Bc = Bs + (kt & 1) * STAGE;
     if (kt + 1 < nkt) {
       la.load(A, lda, m0, kbeg + (kt + 1) * BK, M, kend, a_aligned);
       lb.load(B, ldb, n0, kbeg + (kt + 1) * BK, N, kend, b_aligned);
@@ -143,62 +149,246 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
         bf16x8_t a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          a[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * WM + i * 16 + fr) * LDS_LD + ks * 32 + fq * 8);
+          a[i] = *reinterpret_cast<const bf16x8_t*>(Ac + (wm * WM + i * 16 + fr) * LDS_LD + ks * 32 + fq * 8);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WN + j * 16 + fr) * LDS_LD + ks * 32 + fq * 8);
+          b[j] = *reinterpret_cast<const bf16x8_t*>(Bc + (wn * WN + j * 16 + fr) * LDS_LD + ks * 32 + fq * 8);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
       }
     } else {
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
         float a[TM], b[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[(wm * WM + i * 16 + fr) * LDS_LD + ks * 4 + fq];
+        for (int i = 0; i < TM; ++i) a[i] = Ac[(wm * WM + i * 16 + fr) * LDS_LD + ks * 4 + fq];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Bs[(wn * WN + j * 16 + fr) * LDS_LD + ks * 4 + fq];
+        for (int j = 0; j < TN; ++j) b[j] = Bc[(wn * WN + j * 16 + fr) * LDS_LD + ks * 4 + fq];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);
       }
     }
-    __syncthreads();
     if (kt + 1 < nkt) {
-      la.store(As, LDS_LD);
-      lb.store(Bs, LDS_LD);
-      __syncthreads();
+      la.store(As + ((kt + 1) & 1) * STAGE, LDS_LD);
+      lb.store(Bs + ((kt + 1) & 1) * STAGE, LDS_LD);
     }
+    __syncthreads();
   }
 
-  // epilogue: C/D fragment = col lane&15, row (lane>>4)*4 + r
+  // epilogue.  The MFMAs above take (B fragment, A fragment), i.e. they produce the TRANSPOSED
+  // tile: a lane holds C[m = lane&15][n = (lane>>4)*4 + 0..3] -- four consecutive columns of one
+  // row -> one 16-byte (fp32) / 8-byte (bf16) store per tile instead of four scalar ones (the
+  // scalar-store epilogue was store-issue bound and as long as the K loop at K = 512).
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WN + j * 16 + (lane & 15);
-      if (n >= N) continue;
-      const float bv = bias ? bias[n] : 0.f;
+      const int m = m0 + wm * WM + i * 16 + (lane & 15);
+      const int nb = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+      if (m >= M || nb >= N) continue;
+      const bool full = nb + 3 < N;
+      if (partial) {  // split-K partial slab [z][M][N]; bias / accumulate applied by the reducer
+        float* pp = partial + ((size_t)blockIdx.z * M + m) * N + nb;
+        if (full && (N & 3) == 0) *reinterpret_cast<f32x4_t*>(pp) = acc[i][j];
+        else
+          for (int r = 0; r < 4 && nb + r < N; ++r) pp[r] = acc[i][j][r];
+        continue;
+      }
+      TO* cp = C + (size_t)m * ldc + nb;
+      float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-        if (m >= M) continue;
-        if (partial) {  // split-K partial slab [z][M][N]; bias / accumulate applied by the reducer
-          partial[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];
-          continue;
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ((bias && nb + r < N) ? bias[nb + r] : 0.f);
+      if (full && c_vec) {
+        if constexpr (sizeof(TO) == 4) {
+          if (accumulate) {
+            const f32x4_t o = *reinterpret_cast<const f32x4_t*>(cp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += o[r];
+          }
+          if (act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+        } else {
+          typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+          if (accumulate) {
+            const us4_t o = *reinterpret_cast<const us4_t*>(cp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bf16_to_f32(o[r]);
+          }
+          if (act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          *reinterpret_cast<us4_t*>(cp) = (us4_t){f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
         }
-        TO* cp = C + (size_t)m * ldc + n;
-        float v = acc[i][j][r] + bv;
-        if (accumulate) v += load_out<TO>(cp);
-        if (act == 1) v = fmaxf(v, 0.f);   // fused ReLU (conv_layer / bridge FC, cnn_util.py:78-84)
-        store_out<TO>(cp, v);
+      } else {
+        for (int r = 0; r < 4 && nb + r < N; ++r) {
+          float w = v[r];
+          if (accumulate) w += load_out<TO>(cp + r);
+          if (act == 1) w = fmaxf(w, 0.f);
+          store_out<TO>(cp + r, w);
+        }
       }
     }
+}
+
+// ---------------------------------------------------------------- lean NT kernel (bf16)
+// C[M,N] = A[M,K] * Bt[N,K]^T (+bias)(+C)(relu): both operands reduction-contiguous, K % 64 == 0,
+// N % 128 == 0, 16-byte aligned rows.  This is the shape of every GEMM on the critical path of
+// the BLSTM step (x W_x with W_x pre-transposed, dG W_x^T).  No bounds code in the loop: rows of
+// the last M tile are clamped for the loads and masked at the store.  128x128x64 tiles, register
+// staged global->LDS with the next tile's loads in flight during the MFMAs, double-buffered LDS
+// (one barrier per k-tile), transposed accumulators (16-byte stores).  Tiles are mapped to blocks
+// so that the N-tiles sharing an A row-panel run on ONE XCD (block b lands on XCD b % 8): the
+// panel is then fetched into one L2 instead of eight.
+template <typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
+                                                           int lda, const bf16_t* __restrict__ Bt, int ldb,
+                                                           TO* __restrict__ C, int ldc,
+                                                           const float* __restrict__ bias, int accumulate,
+                                                           int act) {
+  constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
+  constexpr int STAGE = (BM + BN) * LD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* S = reinterpret_cast<bf16_t*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN, ntm = (M + BM - 1) / BM, total = ntn * ntm;
+  int t = blockIdx.x;
+  if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);   // XCD x gets a contiguous run of tiles
+  const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+
+  // 4 A vectors + 4 B vectors of 16 B per thread per k-tile: vector v -> row v>>3, k-offset (v&7)*8
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+  unsigned so[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int v = tid + i * 256, r = v >> 3, kv = (v & 7) * 8;
+    pa[i] = A + (size_t)min(m0 + r, M - 1) * lda + kv;
+    pb[i] = Bt + (size_t)(n0 + r) * ldb + kv;
+    so[i] = (unsigned)(r * LD + kv);
+  }
+  bf16x8_t ra[4], rb[4];
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const bf16x8_t*>(pa[i]);
+      rb[i] = *reinterpret_cast<const bf16x8_t*>(pb[i]);
+      pa[i] += BK;
+      pb[i] += BK;
+    }
+  };
+  auto sstore = [&](bf16_t* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<bf16x8_t*>(st + so[i]) = ra[i];
+      *reinterpret_cast<bf16x8_t*>(st + BM * LD + so[i]) = rb[i];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / BK;
+  gload();
+  sstore(S);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  const unsigned aoff = (unsigned)((wm * 64 + fr) * LD + fq * 8);
+  const unsigned boff = (unsigned)(BM * LD + (wn * 64 + fr) * LD + fq * 8);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bf16_t* cur = S + (kt & 1) * STAGE;
+    if (kt + 1 < nkt) gload();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(cur + aoff + i * 16 * LD + ks * 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(cur + boff + j * 16 * LD + ks * 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) sstore(S + ((kt + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+  // lane holds C[m = fr][n = fq*4 .. +3] of each 16x16 tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + wn * 64 + j * 16 + fq * 4;
+      TO* cp = C + (size_t)m * ldc + nb;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      if (bias) {
+        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+      }
+      if constexpr (sizeof(TO) == 4) {
+        if (accumulate) {
+          const f32x4_t o = *reinterpret_cast<const f32x4_t*>(cp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += o[r];
+        }
+        if (act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+      } else {
+        typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+        if (accumulate) {
+          const us4_t o = *reinterpret_cast<const us4_t*>(cp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bf16_to_f32(o[r]);
+        }
+        if (act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        *reinterpret_cast<us4_t*>(cp) = (us4_t){f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+      }
+    }
+  }
+}
+
+template <typename TO>
+bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
+                      int ldb, void* C, int ldc, const float* bias, int accumulate, hipStream_t st, int act) {
+  if (transA || !transB || K % 64 != 0 || N % 128 != 0 || M < 1024) return false;
+  if (lda % 8 != 0 || ldb % 8 != 0 || ((uintptr_t)A) % 16 != 0 || ((uintptr_t)B) % 16 != 0) return false;
+  if (ldc % 4 != 0 || ((uintptr_t)C) % (4 * sizeof(TO)) != 0 || (bias && ((uintptr_t)bias) % 16 != 0)) return false;
+  const size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * sizeof(bf16_t);
+  static bool attr_done = false;
+  if (!attr_done) {
+    attr_done = true;
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  const int total = (N / 128) * ((M + 127) / 128);
+  hipLaunchKernelGGL(gemm_nt_bf16_kernel<TO>, dim3(total), dim3(256), lds, st, M, N, K, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, (TO*)C, ldc, bias, accumulate, act);
+  return true;
 }
 
 // fixed-order sum of the split-K slabs -> deterministic
@@ -223,9 +413,11 @@ template <typename T, typename TO, int BM, int BN>
 int launch_layout(int transA, int transB, dim3 grid, size_t lds, hipStream_t st, int M, int N, int K,
                   const T* A, int lda, const T* B, int ldb, TO* C, int ldc, const float* bias,
                   int accumulate, int aa, int ba, int kchunk, float* partial, int act) {
+  // 4-column vector stores need the row starts of C aligned to 4 elements
+  const int c_vec = (((uintptr_t)C) % (4 * sizeof(TO)) == 0) && (ldc % 4 == 0);
 #define ASR_GEMM_LAUNCH(TA_, TB_)                                                             \
   hipLaunchKernelGGL((gemm_kernel<T, TO, BM, BN, TA_, TB_>), grid, dim3(256), lds, st, M, N, K, A, \
-                     lda, B, ldb, C, ldc, bias, accumulate, aa, ba, kchunk, partial, act)
+                     lda, B, ldb, C, ldc, bias, accumulate, aa, ba, kchunk, partial, act, c_vec)
   if (!transA && !transB) ASR_GEMM_LAUNCH(false, false);
   else if (!transA && transB) ASR_GEMM_LAUNCH(false, true);
   else if (transA && !transB) ASR_GEMM_LAUNCH(true, false);
@@ -239,13 +431,24 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
                 const void* B, int ldb, void* C, int ldc, const float* bias, int accumulate,
                 hipStream_t st, int act) {
   constexpr int VEC = GT<T>::VEC, BK = GT<T>::BK;
+  if constexpr (sizeof(T) == 2) {
+    if (try_gemm_nt_bf16<TO>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act)) return 0;
+  }
   const int aa = (((uintptr_t)A) % 16 == 0) && (lda % VEC == 0);
   const int ba = (((uintptr_t)B) % 16 == 0) && (ldb % VEC == 0);
   // big tiles only when they still fill the 256 CUs
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (tiles128 >= 512) {
+  if (tiles128 >= 320) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
-    size_t lds = (size_t)(128 + 128) * (BK + VEC) * sizeof(T);
+    size_t lds = (size_t)2 * (128 + 128) * (BK + VEC) * sizeof(T);
+    static bool attr_done = false;   // 72 KB of dynamic LDS needs the opt-in
+    if (!attr_done) {
+      attr_done = true;
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<T, TO, 128, 128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<T, TO, 128, 128, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<T, TO, 128, 128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<T, TO, 128, 128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     return launch_layout<T, TO, 128, 128>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda,
                                           (const T*)B, ldb, (TO*)C, ldc, bias, accumulate, aa, ba, K, nullptr, act);
   }
@@ -261,7 +464,7 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
     if (S > 64) S = 64;
     while (S > 1 && (size_t)S * M * N * sizeof(float) > h->scratch_bytes - ASR_XCH_BYTES) --S;
   }
-  size_t lds = (size_t)(64 + 64) * (BK + VEC) * sizeof(T);
+  size_t lds = (size_t)2 * (64 + 64) * (BK + VEC) * sizeof(T);
   if (S <= 1) {
     dim3 grid((N + 63) / 64, (M + 63) / 64);
     return launch_layout<T, TO, 64, 64>(transA, transB, grid, lds, st, M, N, K, (const T*)A, lda,

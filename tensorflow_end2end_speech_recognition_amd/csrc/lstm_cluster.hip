@@ -438,6 +438,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
 
   unsigned long long* dbg = g_cdbg;
   unsigned long long ph[4] = {0, 0, 0, 0};
+  unsigned long long ph4 = 0;
   unsigned nspin = 0;
 #define C8_T() (DBG ? (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime()) : 0ull)
 
@@ -458,6 +459,11 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + ks * 64);
     __builtin_amdgcn_sched_barrier(0);
+    if (DBG) {                                             // sub-phase: A fragments landed
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(afr[ks]));
+      ph4 += C8_T() - t0;
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[0][ks], acc0, 0, 0, 0);
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
     o[4] = nspin;
     o[5] = tmax;
     o[6] = fast ? 1 : 0;
-    o[7] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu;
+    o[7] = ph4;
   }
   if (timed_out) atomicOr(err, 1u);
   // zero-fill the common padded tail [tmax, T): os already points at frame tmax

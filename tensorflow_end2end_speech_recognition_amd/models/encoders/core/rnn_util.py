@@ -79,7 +79,9 @@ class LSTMLayer(object):
                                                bias_il=torch.empty((4 * H,), dtype=torch.float32, device=x.device),
                                                pf=whf[d], pb=whb[d]))
             wx_il.append(w['wx_il'])
-            ops.gemm(x2d, w['wx_il'], bias=w['bias_il'], out=xp2d[:, d * 4 * H:(d + 1) * 4 * H])
+            # W_x is k-major ([Din, 4H]); the GEMM's fast path wants it reduction-contiguous
+            ops.gemm(x2d, ops.transpose2d(w['wx_il']), transB=True, bias=w['bias_il'],
+                     out=xp2d[:, d * 4 * H:(d + 1) * 4 * H])
         peep = self._peep()
         gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, seq_len, H, ndir, dtype,
                                                self.forget_bias, self.cell_clip or 0.0)

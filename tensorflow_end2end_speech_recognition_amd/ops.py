@@ -101,6 +101,20 @@ def bt_to_tb(x_btd, dtype=ASR_F32):
     return out
 
 
+def transpose2d(x, out=None):
+    """out[c, r] = x[r, c] for a 2-D tensor with unit inner stride."""
+    h = _h(x)
+    dt = dtype_id(x.dtype)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError('transpose2d: 2-D tensor with unit inner stride expected')
+    R, Cc = x.shape
+    if out is None:
+        out = torch.empty((Cc, R), dtype=x.dtype, device=x.device)
+    h.check(h.lib.asr_transpose2d(h.h, dt, C.c_void_p(x.data_ptr()), R, Cc, x.stride(0),
+                                  C.c_void_p(out.data_ptr()), out.stride(0), _s()), 'asr_transpose2d')
+    return out
+
+
 def cast_from_f32(x, dtype, out=None):
     h = _h(x)
     _chk(x, torch.float32, 'x')

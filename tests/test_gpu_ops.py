@@ -25,6 +25,16 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(1, 1), (63, 65), (120, 1024), (512, 1024), (130, 70)])
+def test_transpose2d(cuda, dtype, shape):
+    x = torch.randn(shape[0], shape[1] + 3, device=cuda).to(dtype)[:, :shape[1]]   # strided rows
+    y = _ops().transpose2d(x)
+    assert y.shape == (shape[1], shape[0])
+    assert torch.equal(y, x.t().contiguous())
+
+
 # --------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (130, 70, 45), (1, 62, 512), (257, 1024, 120),
                                    (700, 130, 1000), (16, 16, 4), (3000, 2048, 120), (120, 1024, 5000)])
