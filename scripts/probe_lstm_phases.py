@@ -11,7 +11,8 @@ x, sl, labels, dense = make_batch(1, 16, 120, 62, 100, 778)
 m = CTC('blstm', 120, H, 1, 61, dtype='bf16', seed=0)
 xd = torch.tensor(x, device=dev); sld = torch.tensor(sl, device=dev)
 for it in range(2):
-    loss, _ = m.compute_loss(xd, dense, sld, keep_prob=1.0, is_training=False)
+    loss, _ = m.compute_loss(xd, dense, sld, keep_prob=1.0, is_training=True)
+    m.train(loss, 'sgd', 0.0)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 256)()

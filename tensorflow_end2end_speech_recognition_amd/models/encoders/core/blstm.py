@@ -87,12 +87,25 @@ class _RecurrentEncoderBase(object):
         seq_len = inputs_seq_len.to(torch.int32).contiguous()
         x = ops.bt_to_tb(inputs.contiguous(), self.dtype)       # blstm.py:277-279
         final = None
-        for li, layer in enumerate(self.layers):
+        Tt, Bp = x.shape[0], x.shape[1]
+
+        def prep(li):
             dm = drop_masks[li] if drop_masks is not None else None
             rs = None
             if rng_state is not None:
                 rs = (rng_state[0], rng_state[1] + li * (1 << 32))
-            x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, rs, dm)
+            return self.layers[li].prepare(x.device, self.dtype, Tt, Bp, keep_prob, is_training, rs, dm)
+
+        nxt = prep(0)
+        for li, layer in enumerate(self.layers):
+            cur = nxt
+            if li + 1 < len(self.layers):
+                # weight images + dropout mask of the next layer: side stream, under this layer's
+                # recurrence kernel (which only occupies a handful of CUs)
+                with ops.side_lane(x.device):
+                    nxt = prep(li + 1)
+            x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, prep=cur)
+            ops.join_side(x.device)
         self.seq_len_padded = seq_len
         out = ops.cast_to_f32(x) if x.dtype != torch.float32 else x
         self._out_tm = out

@@ -59,44 +59,56 @@ class LSTMLayer(object):
         return torch.stack([torch.stack([st[b + '/w_i_diag'], st[b + '/w_f_diag'], st[b + '/w_o_diag']])
                             for b in self.bases]).contiguous()
 
-    def forward(self, x, seq_len, dtype, keep_prob=1.0, is_training=True, rng_state=None,
-                drop_mask=None, save=True):
-        """x [T,B,din] in `dtype`; returns (out [T,B,ndir*H] in dtype, (c_final, h_final))."""
+    def prepare(self, device, dtype, T, B, keep_prob=1.0, is_training=True, rng_state=None, drop_mask=None):
+        """Everything of a layer's forward that does not depend on its input: operand-dtype weight
+        images (W_x transposed for the GEMM's fast path, W_h in MFMA fragment order for both
+        passes), the peephole block and the dropout mask.  The encoder issues this for layer l+1
+        on the side stream while layer l's recurrence runs."""
         st = self.store
-        sh = st.shadow(dtype)
-        T, B, din = x.shape
-        H, ndir = self.H, self.ndir
-        x2d = x.view(T * B, din)
-        xproj = torch.empty((T, B, ndir * 4 * H), dtype=torch.float32, device=x.device)
-        xp2d = xproj.view(T * B, ndir * 4 * H)
+        H, ndir, din = self.H, self.ndir, self.din
         wdt = torch.bfloat16 if dtype == ASR_BF16 else torch.float32
-        whf = torch.empty((ndir, H * 4 * H), dtype=wdt, device=x.device)
-        whb = torch.empty((ndir, H * 4 * H), dtype=wdt, device=x.device)
+        whf = torch.empty((ndir, H * 4 * H), dtype=wdt, device=device)
+        whb = torch.empty((ndir, H * 4 * H), dtype=wdt, device=device)
+        wxT = torch.empty((ndir * 4 * H, din), dtype=wdt, device=device)      # both directions stacked
+        bias = torch.empty((ndir * 4 * H,), dtype=torch.float32, device=device)
         wx_il = []
         for d, base in enumerate(self.bases):
             w = ops.lstm_prep_weights(st[base + '/kernel'], st[base + '/bias'], din, H, dtype,
-                                      out=dict(wx_il=torch.empty((din, 4 * H), dtype=wdt, device=x.device),
-                                               bias_il=torch.empty((4 * H,), dtype=torch.float32, device=x.device),
+                                      out=dict(wx_il=torch.empty((din, 4 * H), dtype=wdt, device=device),
+                                               bias_il=bias[d * 4 * H:(d + 1) * 4 * H],
                                                pf=whf[d], pb=whb[d]))
             wx_il.append(w['wx_il'])
             # W_x is k-major ([Din, 4H]); the GEMM's fast path wants it reduction-contiguous
-            ops.gemm(x2d, ops.transpose2d(w['wx_il']), transB=True, bias=w['bias_il'],
-                     out=xp2d[:, d * 4 * H:(d + 1) * 4 * H])
-        peep = self._peep()
-        gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, seq_len, H, ndir, dtype,
-                                               self.forget_bias, self.cell_clip or 0.0)
-        out = hout
+            ops.transpose2d(w['wx_il'], out=wxT[d * 4 * H:(d + 1) * 4 * H])
         mask = None
         if is_training and (drop_mask is not None or keep_prob < 1.0):
             if drop_mask is None:
                 seed, offset = rng_state
-                mask = ops.dropout_mask(hout.shape, keep_prob, seed, offset, x.device)
+                mask = ops.dropout_mask((T, B, ndir * H), keep_prob, seed, offset, device)
             else:
                 mask = drop_mask
+        return dict(whf=whf, whb=whb, wxT=wxT, bias=bias, wx_il=wx_il, peep=self._peep(), mask=mask)
+
+    def forward(self, x, seq_len, dtype, keep_prob=1.0, is_training=True, rng_state=None,
+                drop_mask=None, save=True, prep=None):
+        """x [T,B,din] in `dtype`; returns (out [T,B,ndir*H] in dtype, (c_final, h_final))."""
+        T, B, din = x.shape
+        H, ndir = self.H, self.ndir
+        if prep is None:
+            prep = self.prepare(x.device, dtype, T, B, keep_prob, is_training, rng_state, drop_mask)
+        xproj = torch.empty((T, B, ndir * 4 * H), dtype=torch.float32, device=x.device)
+        # x W_x + b for both directions in ONE GEMM (N = ndir*4H), written in the interleaved layout
+        ops.gemm(x.view(T * B, din), prep['wxT'], transB=True, bias=prep['bias'],
+                 out=xproj.view(T * B, ndir * 4 * H))
+        gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, prep['whf'], prep['peep'], seq_len, H, ndir, dtype,
+                                               self.forget_bias, self.cell_clip or 0.0)
+        out = hout
+        mask = prep['mask']
+        if mask is not None:
             out = ops.apply_mask(hout, mask)
         if save:
-            self.ctx = dict(x=x, gates=gates, cs=cs, hout=hout, whb=whb, peep=peep, seq_len=seq_len,
-                            dtype=dtype, mask=mask, wx_il=wx_il)
+            self.ctx = dict(x=x, gates=gates, cs=cs, hout=hout, whb=prep['whb'], peep=prep['peep'],
+                            seq_len=seq_len, dtype=dtype, mask=mask, wx_il=prep['wx_il'])
         return out, (cf, hf)
 
     def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True):
