@@ -181,10 +181,11 @@ def main():
         #   fwd: read x W_x+b 16H, write gates s*4H + c 4H + h s*H             per valid frame per direction
         #   bwd: read gates s*4H + c 4H + dh 4H, write dgates s*4H              per valid frame per direction
         per_frame = {'lstm_fwd': 20 * H + 5 * s_act * H, 'lstm_bwd': 8 * H + 8 * s_act * H}
-        # measured HBM bytes per launch for THIS default workload (profiles/r01_pmc_hbm.md:
-        # 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, gfx950 correction applied); null otherwise
+        # measured HBM bytes per launch for THIS default workload (profiles/r01b_pmc_hbm.md:
+        # 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, gfx950 correction applied; includes the
+        # per-step cross-CU exchange of the cluster kernels); null otherwise
         default_cfg = (args.units, args.layers, args.batch, args.tmax, args.dtype) == (256, 5, 16, 778, 'bf16')
-        measured_traffic = {'lstm_bwd': 100.1e6, 'lstm_fwd': 102.8e6}
+        measured_traffic = {'lstm_bwd': 144.5e6, 'lstm_fwd': 180.1e6}
         flops_frame = 2 * 4 * H * H   # recurrent h W_h (fwd) / dG W_h^T (bwd), per frame per direction
         roof = None
         if dom in per_frame:
@@ -199,8 +200,9 @@ def main():
                         mfma_tflops=frames * 2 * flops_frame / dur / 1e12,
                         mfma_frac=frames * 2 * flops_frame / dur / 1e12 /
                         (MFMA_BF16_PEAK_TF if args.dtype == 'bf16' else MFMA_F32_PEAK_TF),
-                        note='serial recurrence: latency-bound on the h->h dependency chain, neither '
-                             'roofline is approached by construction (SURVEY.md section 8d)')
+                        note='serial recurrence over T frames on one 16-utterance MFMA tile per direction: '
+                             'bound by the per-step chain (LDS operand reads, gate math issue, one cross-CU '
+                             'L2 hop), not by HBM or MFMA throughput (DESIGN.md section 4)')
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import fast_cpu
