@@ -236,6 +236,37 @@ def test_lstm_bf16_and_wide(cuda, T, B, D, H, ndir):
         assert _rel(got['dpeep'][:, :3], ref['dpeep']) < (1e-4 if dtype == 'f32' else 5e-2)
 
 
+def test_lstm_cluster_exchange_paths(cuda):
+    """The multi-CU recurrence (bf16, H=256) must give bit-identical results whether the cluster's
+    per-step exchange uses same-XCD plain stores or the placement-independent write-through form
+    (forced with the debug flag), and no hand-off may time out."""
+    import ctypes
+    from tensorflow_end2end_speech_recognition_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    lib.asr_debug_set_lstm_flags.argtypes = [ctypes.c_int]
+    rng = np.random.RandomState(7)
+    T, B, D, H, ndir = 61, 32, 40, 256, 2
+    lens = rng.randint(1, T + 1, size=B)
+    lens[0], lens[5] = T, 1
+    x, ps = _lstm_case(rng, T, B, D, H, ndir, lens, init=0.1)
+    dout = rng.randn(T, B, ndir * H)
+    res = []
+    try:
+        for flags in (0, 16):
+            lib.asr_debug_set_lstm_flags(flags)
+            res.append(_run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', 50.0, dout))
+            assert ops.check_async_errors(0) == 0
+    finally:
+        lib.asr_debug_set_lstm_flags(0)
+    for k in ('hout', 'cf', 'hf', 'dgates', 'dpeep'):
+        assert np.array_equal(res[0][k], res[1][k]), k
+    for b in range(B):   # saved cell states are only defined on valid frames
+        assert np.array_equal(res[0]['cs'][:lens[b], b], res[1]['cs'][:lens[b], b])
+    ref = _oracle_layer(x, ps, lens, ndir, 50.0, dout)
+    assert np.abs(res[0]['hout'] - ref['hout']).max() < 3e-2
+
+
 # --------------------------------------------------------------------------- CTC
 def _ctc_case(rng, T, B, C, lmax, scale=2.0):
     logits = (rng.randn(T, B, C) * scale).astype(np.float32)
