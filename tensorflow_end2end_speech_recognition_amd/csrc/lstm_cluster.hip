@@ -207,6 +207,7 @@ __global__ __launch_bounds__(CT, 1) void lstm_fwd_cluster_kernel(
         v[k] = gload(src[k]);
       }
       unsigned spins = 0;
+#pragma unroll 1
       for (;;) {
         bool ok = true;
 #pragma unroll
@@ -255,9 +256,15 @@ __global__ __launch_bounds__(CT, 1) void lstm_fwd_cluster_kernel(
 // 16-byte exchange store of self-tagged words.  Same-XCD cluster: plain store (stays in the shared
 // L2); otherwise sc1 (write-through), as the agent-scope atomics lower to.  Inline asm pins the store
 // in program order (a plain C++ store could legally sink below the spin loop that follows).
-__device__ __forceinline__ void xstore16(f32x4_t* p, f32x4_t v, bool fast) {
-  if (fast) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ void xstore16(f32x4_t* ubase, unsigned voff, f32x4_t v, bool fast) {
+  // uniform base in SGPRs + 32-bit per-lane byte offset: no 64-bit pointer registers per slot
+  if (fast) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(ubase) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(ubase) : "memory");
+}
+// uniform base + per-lane element offset (lets the backend use the SGPR-base addressing mode)
+template <typename T>
+__device__ __forceinline__ T* uoff(T* ubase, unsigned elem) {
+  return ubase + elem;   // plain pointer arithmetic: an integer round trip would demote it to a flat pointer
 }
 
 // ---------------------------------------------------------------- forward, 8 waves
@@ -418,18 +425,10 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   // per-lane exchange addresses (both parities): publish slot, the three foreign slices this
   // wave polls (wave w polls the granules wave w of the peers publishes), LDS staging targets
   const int prow = rbase + (odd ? 1 : 0);
-  u64* pub[2];
-  const u64* src[2][G - 1];
+  const unsigned pofs = (unsigned)(wave * 64 + prow * 4 + ((col & 7) >> 1));   // publish slot in the slice
+  const unsigned lofs = threadIdx.x;                                           // polled granule in a slice
   unsigned ldst[G - 1];                                    // byte offset inside one h buffer
-#pragma unroll
-  for (int P = 0; P < 2; ++P) {
-    pub[P] = xbase + ((size_t)P * G + g) * SLICE + wave * 64 + prow * 4 + ((col & 7) >> 1);
-#pragma unroll
-    for (int k = 0; k < G - 1; ++k) {
-      const int gsrc = k + (k >= g ? 1 : 0);
-      src[P][k] = xbase + ((size_t)P * G + gsrc) * SLICE + wave * 64 + lane;
-    }
-  }
+  auto slice = [&](int P, int gg) -> u64* { return xbase + ((size_t)P * G + gg) * SLICE; };   // uniform
 #pragma unroll
   for (int k = 0; k < G - 1; ++k) {
     const int gsrc = k + (k >= g ? 1 : 0);
@@ -460,21 +459,24 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
       for (int r = 0; r < 2; ++r) xn[r] = xg[(s + 1 < len[r]) ? oa[r] + dstep : os[r] + stride];
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // all A fragments in flight at once (left alone the scheduler recycles ONE register and
-    // exposes the LDS latency KS times: 870 cycles for 16 MFMAs)
-    bf16x8_t afr[KS];
+    // 8 A fragments in flight at once (left alone the scheduler recycles ONE register and exposes
+    // the LDS latency KS times: 870 cycles for 16 MFMAs); H = 512 takes two such batches
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + ks * 64);
-    __builtin_amdgcn_sched_barrier(0);
-    if (DBG) {                                             // sub-phase: A fragments landed
+    for (int kb = 0; kb < KS; kb += 8) {
+      bf16x8_t afr[8];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(afr[ks]));
-      ph4 += C8_T() - t0;
-    }
+      for (int ks = 0; ks < 8; ++ks) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + (kb + ks) * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG && kb == 0) {                                // sub-phase: first A fragments landed
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[0][ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[1][ks], acc1, 0, 0, 0);
+        for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(afr[ks]));
+        ph4 += C8_T() - t0;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[0][kb + ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[1][kb + ks], acc1, 0, 0, 0);
+      }
     }
     if (DBG) { asm volatile("" : "+v"(acc0)); asm volatile("" : "+v"(acc1)); }
     const unsigned long long t1 = C8_T();
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
     // publish: even lanes the (unit, unit+1) granule of row 0, odd lanes (unit-1, unit) of row 1
     const float nb = dpp_xor1(odd ? hr[0] : hr[1]);
     const unsigned pk = odd ? pack_bf16x2(nb, hr[1]) : pack_bf16x2(hr[0], nb);
-    gpublish(pub[P], epoch, pk, fast);
+    gpublish(uoff(slice(P, g), pofs), epoch, pk, fast);
     *reinterpret_cast<unsigned*>(hnxt + lown) = pk;
     // saved activations; rows past their length write frame s of the padding (hout: zeros,
     // gates / cs: never read there), so nothing is predicated
@@ -540,8 +542,9 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
     {
       u64 v[G - 1];
 #pragma unroll
-      for (int k = 0; k < G - 1; ++k) v[k] = gload(src[P][k]);
+      for (int k = 0; k < G - 1; ++k) v[k] = gload(uoff(slice(P, k + (k >= g ? 1 : 0)), lofs));
       unsigned spins = 0;
+#pragma unroll 1
       for (;;) {                                           // wave-uniform loop: no exec masking
         bool ok = true;
 #pragma unroll
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
         if (__all(ok)) break;
         if (++spins > SPIN_LIMIT) { timed_out = true; break; }
 #pragma unroll
-        for (int k = 0; k < G - 1; ++k) v[k] = gload(src[P][k]);
+        for (int k = 0; k < G - 1; ++k) v[k] = gload(uoff(slice(P, k + (k >= g ? 1 : 0)), lofs));
       }
       if (DBG) nspin += spins;
 #pragma unroll
@@ -570,8 +573,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   if (s < tmax) step(s, std::integral_constant<int, 0>{});
 #undef C8_T
 
-  if (DBG && dbg && lane == 0 && cid.tile == 0) {
-    unsigned long long* o = dbg + 256 + ((size_t)(d * G + g) * 8 + wave) * 8;   // [256, 768): 8-wave kernels
+  if (DBG && dbg && lane == 0 && cid.tile == 0 && g < 4) {
+    unsigned long long* o = dbg + 256 + ((size_t)(d * 4 + g) * 8 + wave) * 8;   // [256, 768): 8-wave kernels
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = ph[k];
     o[4] = nspin;
@@ -701,6 +704,7 @@ __global__ __launch_bounds__(CT, 1) void lstm_bwd_cluster_kernel(
           v[r][gi] = gload(src[r][gi]);
         }
       unsigned spins = 0;
+#pragma unroll 1
       for (;;) {
         bool ok = true;
 #pragma unroll
@@ -892,36 +896,34 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
     dcr[r] = d_c_final ? d_c_final[o] : 0.f;
     cc[r] = (tmax > 0 && tmax - 1 < len[r]) ? cs[oa[r]] : 0.f;
   }
-  // W_h^T fragments: own tile (4g + wt), foreign tile f0 = wave, and (waves 0-3) f1 = 8 + wave.
-  // foreign index f in [0,12): destination CU = (f >> 2) skipping g, tile inside it = f & 3
+  // W_h^T fragments: own tile (4g + wt) and this wave's foreign tiles f = wave, 8 + wave, ...
+  // foreign index f in [0, 4(G-1)): destination CU = (f >> 2) skipping g, tile inside it = f & 3
+  constexpr int NFT = 4 * (G - 1);                         // foreign tiles per CU (12 / 28)
+  constexpr int NF = (NFT + 7) / 8;                        // per wave: waves < NFT - 8(NF-1) carry NF, the rest NF-1
   auto ftile = [&](int f) { const int q = f >> 2; return ((q + (q >= g ? 1 : 0)) << 2) | (f & 3); };
-  const int nt_own = g * 4 + wt, nt_f0 = ftile(wave), nt_f1 = ftile(8 + wt);
-  bf16x8_t wo[KC], w0[KC], w1[KC];
+  const int nt_own = g * 4 + wt;
+  const bool last_f = wave < NFT - 8 * (NF - 1);           // does this wave carry the NF-th foreign tile?
+  int nt_f[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) nt_f[i] = ftile((i < NF - 1 || last_f) ? wave + 8 * i : wave);
+  bf16x8_t wo[KC], wf[NF][KC];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
     wo[kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_own * KSF + g * KC + kc) * 64 + lane) * 8);
-    w0[kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_f0 * KSF + g * KC + kc) * 64 + lane) * 8);
-    w1[kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_f1 * KSF + g * KC + kc) * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+      wf[i][kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_f[i] * KSF + g * KC + kc) * 64 + lane) * 8);
   }
 
   u64* xhdr = xch + (size_t)cid.c * CL_U64;
   bool timed_out = false;
   const bool fast = same_xcd<G>(xhdr, g, timed_out) && !force_wt;
   f32x4_t* xs = reinterpret_cast<f32x4_t*>(xhdr + XHDR);   // [2][G dst][G src][4][64] x 16 B
-  auto slot = [&](int par, int dst, int src_, int tile) -> f32x4_t* {
-    return xs + ((((size_t)par * G + dst) * G + src_) * 4 + tile) * 64 + lane;
+  auto uslot = [&](int par, int dst, int src_, int tile) -> f32x4_t* {       // uniform part of a slot
+    return xs + ((((size_t)par * G + dst) * G + src_) * 4 + tile) * 64;
   };
-  f32x4_t* pub0[2];
-  f32x4_t* pub1[2];
-  const u64* pol[2][G - 1];
-#pragma unroll
-  for (int P = 0; P < 2; ++P) {
-    pub0[P] = slot(P, nt_f0 >> 2, g, nt_f0 & 3);
-    pub1[P] = slot(P, nt_f1 >> 2, g, nt_f1 & 3);
-#pragma unroll
-    for (int k = 0; k < G - 1; ++k)
-      pol[P][k] = reinterpret_cast<const u64*>(slot(P, g, k + (k >= g ? 1 : 0), wt)) + hh;
-  }
+  const unsigned voff16 = (unsigned)lane * 16u;            // byte offset of this lane's 16-byte word group
+  const unsigned pofs = (unsigned)lane * 2u + hh;          // u64 index of this lane's two rows in a slot
   // own dG rows -> LDS (bytes); rows rbase, rbase+1 are in the same swizzle class (rbase is even)
   const unsigned lwr[2] = {((unsigned)(rbase * LDG + ul * 4) * 2u) ^ lds_swz(rbase),
                            ((unsigned)((rbase + 1) * LDG + ul * 4) * 2u) ^ lds_swz(rbase + 1)};
@@ -958,7 +960,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
     u64 pv[G - 1];
     if (it > 0) {
 #pragma unroll
-      for (int k = 0; k < G - 1; ++k) pv[k] = gload(pol[1 - P][k]);
+      for (int k = 0; k < G - 1; ++k)
+        pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
     }
     // ---- 2. everything that does not need dh
     bool act[2], ldp[2];
@@ -994,6 +997,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
       const unsigned want = (((unsigned)(it - 1) >> 1) + 1u) & 1u;
       const u64 wmask = 0x0000000100000001ull, wtag = want ? wmask : 0ull;
       unsigned spins = 0;
+#pragma unroll 1
       for (;;) {
         bool ok = true;
 #pragma unroll
@@ -1001,7 +1005,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
         if (__all(ok)) break;
         if (++spins > SPIN_LIMIT) { timed_out = true; break; }
 #pragma unroll
-        for (int k = 0; k < G - 1; ++k) pv[k] = gload(pol[1 - P][k]);
+        for (int k = 0; k < G - 1; ++k)
+          pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
       }
       if (DBG) nspin += spins;
       float add0 = 0.f, add1 = 0.f;
@@ -1053,15 +1058,14 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
         for (int i = 0; i < 4; ++i) o[i] = __uint_as_float((__float_as_uint(a[i]) & ~1u) | tag);
         return o;
       };
-      f32x4_t a0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], w0[kc], a0, 0, 0, 0);
-      xstore16(pub0[P], tagged(a0), fast);
-      if (wave < 4) {
-        f32x4_t a1 = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < NF; ++i) {
+        if (i < NF - 1 || last_f) {                        // wave-uniform
+          f32x4_t af = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], w1[kc], a1, 0, 0, 0);
-        xstore16(pub1[P], tagged(a1), fast);
+          for (int kc = 0; kc < KC; ++kc) af = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[i][kc], af, 0, 0, 0);
+          xstore16(uslot(P, nt_f[i] >> 2, g, nt_f[i] & 3), voff16, tagged(af), fast);
+        }
       }
       f32x4_t ao = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1082,8 +1086,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
   if (s == 0) step(0, std::integral_constant<int, 0>{});
 #undef C8_T
 
-  if (DBG && dbg && lane == 0 && cid.tile == 0) {
-    unsigned long long* o = dbg + 768 + ((size_t)(d * G + g) * 8 + wave) * 8;   // [768, 1280)
+  if (DBG && dbg && lane == 0 && cid.tile == 0 && g < 4) {
+    unsigned long long* o = dbg + 768 + ((size_t)(d * 4 + g) * 8 + wave) * 8;   // [768, 1280)
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = ph[k];
     o[4] = nspin;
@@ -1147,8 +1151,23 @@ bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
                          const void* whp, const float* peep, const int32_t* seq_len, float fb,
                          float clip, void* gates, void* hout, float* cs, float* cf, float* hf,
                          hipStream_t st) {
-  if (!cluster_enabled() || H != 256) return false;
+  if (!cluster_enabled() || (H != 256 && H != 512)) return false;
   cdbg_setup();
+  if (H == 512) {   // 8 CUs per direction, 8-wave kernels only
+    constexpr int H5 = 512, G5 = H5 / HS;
+    const int ncl = (B / 16) * ndir;
+    const size_t need5 = (size_t)ncl * (XHDR + 2 * G5 * 16 * (HS / 2)) * sizeof(u64);
+    if (cluster_waves() != 8 || (size_t)T * B * ndir * H5 >= (1ull << 31) || h->scratch_bytes < XCH_BYTES ||
+        need5 + 256 > XCH_BYTES || ((ncl + 7) / 8) * G5 > 32)
+      return false;
+    char* base5 = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+    (void)hipMemsetAsync(base5 + 256, 0, need5, st);
+    auto k5 = g_cdbg_host ? lstm_fwd_cluster8_kernel<H5, true> : lstm_fwd_cluster8_kernel<H5, false>;
+    hipLaunchKernelGGL(k5, dim3(cluster_grid(G5, ncl)), dim3(CT8), (size_t)2 * 16 * (H5 + 8) * 2, st, T, B, ndir,
+                       (const f32x4_t*)xproj, (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates,
+                       (bf16_t*)hout, cs, cf, hf, (u64*)(base5 + 256), (unsigned*)base5, (dbg_flags() & 16) ? 1 : 0);
+    return true;
+  }
   constexpr int HH = 256, G = HH / HS;
   const size_t need = (size_t)(B / 16) * ndir * 2 * G * 16 * (HS / 2) * sizeof(u64);
   if (need + 256 > XCH_BYTES || h->scratch_bytes < XCH_BYTES) return false;
@@ -1179,10 +1198,26 @@ bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
                          const void* gates, const float* cs, const void* whpb, const float* peep,
                          const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
                          float* dpeep_part, hipStream_t st) {
-  if (!cluster_enabled() || H != 256) return false;
+  if (!cluster_enabled() || (H != 256 && H != 512)) return false;
   cdbg_setup();
-  constexpr int HH = 256, G = HH / HS;
   if (h->scratch_bytes < XCH_BYTES) return false;
+  if (H == 512) {
+    constexpr int H5 = 512, G5 = H5 / HS;
+    const int ncl = (B / 16) * ndir;
+    const size_t need5 = (size_t)ncl * (XHDR + (size_t)2 * G5 * G5 * 4 * 64 * 2) * sizeof(u64);
+    if (cluster_waves() != 8 || (size_t)T * B * ndir * H5 >= (1ull << 31) || need5 + 256 > XCH_BYTES ||
+        ((ncl + 7) / 8) * G5 > 32)
+      return false;
+    char* base5 = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+    (void)hipMemsetAsync(base5 + 256, 0, need5, st);
+    auto k5 = g_cdbg_host ? lstm_bwd_cluster8_kernel<H5, true> : lstm_bwd_cluster8_kernel<H5, false>;
+    hipLaunchKernelGGL(k5, dim3(cluster_grid(G5, ncl)), dim3(CT8), (size_t)2 * 16 * (4 * HS + 8) * 2, st, T, B, ndir,
+                       dhout, (const cbf16x4_t*)gates, cs, (const bf16_t*)whpb, peep, seq_len, dcf, dhf,
+                       (cbf16x4_t*)dgates, dpeep_part, (u64*)(base5 + 256), (unsigned*)base5,
+                       (dbg_flags() & 16) ? 1 : 0);
+    return true;
+  }
+  constexpr int HH = 256, G = HH / HS;
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
   u64* xch = (u64*)(base + 256);
   unsigned* err = (unsigned*)base;
