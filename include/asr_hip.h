@@ -250,7 +250,9 @@ int asr_att_energy_bwd(asr_handle* h, const float* denergy, const float* keys, c
 int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* seq_len,
                             float sharpening, const float* enc, int T, int B, int E, float* alpha,
                             float* ctx, asr_stream s);
-/* denergy[B,T] = ; denc[T,B,E] += alpha * dctx */
+/* denergy[B,T] = ; denc[T,B,E] += alpha * dctx.  denc may be NULL: a decoder loop then keeps alpha and
+ * dctx of every step and forms d_enc = sum_steps alpha (x) dctx with ONE GEMM per utterance at the end
+ * instead of a read-modify-write of the whole [T,B,E] tensor per step. */
 int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const float* alpha,
                             const int32_t* seq_len, float sharpening, const float* enc, int T,
                             int B, int E, float* denergy, float* denc, asr_stream s);

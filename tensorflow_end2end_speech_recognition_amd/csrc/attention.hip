@@ -89,15 +89,21 @@ __global__ void cell_bwd_kernel(const float* __restrict__ dh_out_use, const floa
   }
 }
 
-// ---- energies.  keys[T,B,A] (may be null), qz[B,A].  mode 0: sum_a v_a tanh(useK*K + qz);
-// mode 1: sum_a K*qz.  One block per utterance, 4 waves stride over t, lanes over a.
+// ---- attention scoring / context.  All of these stream [T,B,*] tensors once per decoder step, so
+// they are HBM-bound and laid out for that: grid = (frame chunks, utterances) -> hundreds of
+// workgroups instead of one per utterance, float4 rows, per-chunk partial sums reduced in a fixed
+// order (deterministic) through the handle's scratch.
+constexpr int ATT_CH = 64;                      // frames per workgroup
+
+// energies.  keys[T,B,A] (may be null), qz[B,A].  mode 0: sum_a v_a tanh(useK*K + qz); mode 1: sum_a K*qz.
 __global__ __launch_bounds__(256) void att_energy_fwd_kernel(const float* __restrict__ keys,
                                                              const float* __restrict__ qz,
                                                              const float* __restrict__ v, int T, int B,
                                                              int A, int mode, float* __restrict__ energy) {
-  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(T, t0 + ATT_CH);
   const float* q = qz + (size_t)b * A;
-  for (int t = wave; t < T; t += 4) {
+  for (int t = t0 + wave; t < t1; t += 4) {
     const float* k = keys ? keys + ((size_t)t * B + b) * A : nullptr;
     float s = 0.f;
     for (int a = lane; a < A; a += 64) {
@@ -109,20 +115,20 @@ __global__ __launch_bounds__(256) void att_energy_fwd_kernel(const float* __rest
   }
 }
 
-// dkeys[T,B,A] += dZ ; dqz[B,A] = sum_t dZ ; dv_rows[B,A] = sum_t denergy*tanh(Z)
+// dkeys[T,B,A] += dZ ; per-chunk partials part[ch][b][2][A] = (sum_t dZ, sum_t denergy*tanh(Z))
 __global__ __launch_bounds__(256) void att_energy_bwd_kernel(const float* __restrict__ denergy,
                                                              const float* __restrict__ keys,
                                                              const float* __restrict__ qz,
                                                              const float* __restrict__ v, int T, int B,
                                                              int A, int mode, float* __restrict__ dkeys,
-                                                             float* __restrict__ dqz,
-                                                             float* __restrict__ dv_rows) {
+                                                             float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* acc = reinterpret_cast<float*>(smem);   // [4 waves][2][A]
-  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(T, t0 + ATT_CH);
   const float* q = qz + (size_t)b * A;
   for (int a = lane; a < 2 * A; a += 64) acc[wave * 2 * A + a] = 0.f;
-  for (int t = wave; t < T; t += 4) {
+  for (int t = t0 + wave; t < t1; t += 4) {
     const float de = denergy[(size_t)b * T + t];
     const size_t off = ((size_t)t * B + b) * A;
     for (int a = lane; a < A; a += 64) {
@@ -140,20 +146,31 @@ __global__ __launch_bounds__(256) void att_energy_bwd_kernel(const float* __rest
     }
   }
   __syncthreads();
-  for (int a = threadIdx.x; a < A; a += 256) {
-    dqz[(size_t)b * A + a] = acc[a] + acc[2 * A + a] + acc[4 * A + a] + acc[6 * A + a];
-    if (dv_rows) dv_rows[(size_t)b * A + a] = acc[A + a] + acc[3 * A + a] + acc[5 * A + a] + acc[7 * A + a];
+  float* o = part + ((size_t)blockIdx.x * B + b) * 2 * A;
+  for (int a = threadIdx.x; a < 2 * A; a += 256)
+    o[a] = (acc[a] + acc[2 * A + a]) + (acc[4 * A + a] + acc[6 * A + a]);
+}
+// dqz[b,a] / dv_rows[b,a] = fixed-order sum of the chunk partials
+__global__ void att_energy_bwd_reduce_kernel(const float* __restrict__ part, int nch, int B, int A,
+                                             float* __restrict__ dqz, float* __restrict__ dv_rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * A) return;
+  const int b = i / A, a = i % A;
+  float s0 = 0.f, s1 = 0.f;
+  for (int c = 0; c < nch; ++c) {
+    const float* o = part + ((size_t)c * B + b) * 2 * A;
+    s0 += o[a];
+    s1 += o[A + a];
   }
+  dqz[i] = s0;
+  if (dv_rows) dv_rows[i] = s1;
 }
 
-// ---- masked softmax over t + context.  energy[B,T] -> alpha[B,T], ctx[B,E] = sum_t alpha enc[t,b,:]
+// masked softmax over t.  energy[B,T] -> alpha[B,T].
 // mask: e*m + (1-m)*FLT_MIN(lowest), then *sharpening (attention_layer.py:76-89).
-__global__ __launch_bounds__(256) void att_softmax_ctx_fwd_kernel(const float* __restrict__ energy,
-                                                                  const int32_t* __restrict__ seq_len,
-                                                                  float sharp, const float* __restrict__ enc,
-                                                                  int T, int B, int E,
-                                                                  float* __restrict__ alpha,
-                                                                  float* __restrict__ ctx) {
+__global__ __launch_bounds__(256) void att_softmax_kernel(const float* __restrict__ energy,
+                                                          const int32_t* __restrict__ seq_len, float sharp,
+                                                          int T, float* __restrict__ alpha) {
   __shared__ float red[4];
   __shared__ float s_max, s_inv;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -188,47 +205,88 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_fwd_kernel(const float* _
   if (tid == 0) s_inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
   __syncthreads();
   const float inv = s_inv;
-  for (int t = tid; t < T; t += 256) {
-    const float a = al[t] * inv;
-    al[t] = a;
-    alpha[(size_t)b * T + t] = a;
-  }
-  __syncthreads();
-  for (int e0 = tid; e0 < E; e0 += 256) {
-    float c = 0.f;
-    for (int t = 0; t < len; ++t) c += al[t] * enc[((size_t)t * B + b) * E + e0];
-    if (len == 0)   // all-masked row: uniform weights over T zero frames
-      for (int t = 0; t < T; ++t) c += al[t] * enc[((size_t)t * B + b) * E + e0];
-    ctx[(size_t)b * E + e0] = c;
-  }
+  for (int t = tid; t < T; t += 256) alpha[(size_t)b * T + t] = al[t] * inv;
 }
 
-// dctx[B,E], dalpha_in[B,T] (may be null) -> denergy[B,T]; denc[t,b,:] += alpha*dctx
-__global__ __launch_bounds__(256) void att_softmax_ctx_bwd_kernel(const float* __restrict__ dctx,
-                                                                  const float* __restrict__ alpha,
-                                                                  const int32_t* __restrict__ seq_len,
-                                                                  float sharp, const float* __restrict__ enc,
-                                                                  int T, int B, int E,
-                                                                  float* __restrict__ denergy,
-                                                                  float* __restrict__ denc) {
-  __shared__ float red[4];
-  __shared__ float s_dot;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* da = reinterpret_cast<float*>(smem);   // [T]
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// partial context of one frame chunk: part[ch][b][E] = sum_{t in chunk, t < len*} alpha[b,t] enc[t,b,:]
+// (len* = len, or T for an all-masked row whose weights are uniform over T zero frames)
+__global__ __launch_bounds__(256) void att_ctx_partial_kernel(const float* __restrict__ alpha,
+                                                              const int32_t* __restrict__ seq_len,
+                                                              const float* __restrict__ enc, int T, int B,
+                                                              int E, float* __restrict__ part) {
+  __shared__ float al[ATT_CH];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int t0 = blockIdx.x * ATT_CH;
+  int len = min(max(seq_len[b], 0), T);
+  if (len == 0) len = T;
+  const int n = max(0, min(ATT_CH, len - t0));
+  if (tid < n) al[tid] = alpha[(size_t)b * T + t0 + tid];
+  __syncthreads();
+  float* o = part + ((size_t)blockIdx.x * B + b) * E;
+  const size_t rs = (size_t)B * E;
+  if ((E & 3) == 0) {
+    for (int e4 = tid; e4 < E / 4; e4 += 256) {
+      const float* p = enc + ((size_t)t0 * B + b) * E + e4 * 4;
+      f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < n; ++i) {
+        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(p + i * rs);
+        const float w = al[i];
+        c[0] += w * x[0]; c[1] += w * x[1]; c[2] += w * x[2]; c[3] += w * x[3];
+      }
+      *reinterpret_cast<f32x4_t*>(o + e4 * 4) = c;
+    }
+  } else {
+    for (int e0 = tid; e0 < E; e0 += 256) {
+      float c = 0.f;
+      for (int i = 0; i < n; ++i) c += al[i] * enc[((size_t)(t0 + i) * B + b) * E + e0];
+      o[e0] = c;
+    }
+  }
+}
+__global__ void att_ctx_reduce_kernel(const float* __restrict__ part, int nch, int BE, float* __restrict__ ctx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BE) return;
+  float c = 0.f;
+  for (int k = 0; k < nch; ++k) c += part[(size_t)k * BE + i];   // fixed order
+  ctx[i] = c;
+}
+
+// dalpha[b,t] = enc[t,b,:] . dctx[b,:]  for t < len (one wave per frame, float4 lanes)
+__global__ __launch_bounds__(256) void att_dalpha_kernel(const float* __restrict__ dctx,
+                                                         const int32_t* __restrict__ seq_len,
+                                                         const float* __restrict__ enc, int T, int B, int E,
+                                                         float* __restrict__ da) {
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int len = min(max(seq_len[b], 0), T);
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(len, t0 + ATT_CH);
   const float* dc = dctx + (size_t)b * E;
-  // dalpha_t = enc[t,b,:] . dctx   (one wave per t)
-  for (int t = wave; t < len; t += 4) {
+  for (int t = t0 + wave; t < t1; t += 4) {
     const float* er = enc + ((size_t)t * B + b) * E;
     float s = 0.f;
-    for (int e0 = lane; e0 < E; e0 += 64) s += er[e0] * dc[e0];
+    if ((E & 3) == 0) {
+      for (int e4 = lane; e4 < E / 4; e4 += 64) {
+        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(er + e4 * 4);
+        const f32x4_t d = *reinterpret_cast<const f32x4_t*>(dc + e4 * 4);
+        s += x[0] * d[0] + x[1] * d[1] + x[2] * d[2] + x[3] * d[3];
+      }
+    } else {
+      for (int e0 = lane; e0 < E; e0 += 64) s += er[e0] * dc[e0];
+    }
     s = wave_reduce_sum(s);
-    if (lane == 0) da[t] = s;
+    if (lane == 0) da[(size_t)b * T + t] = s;
   }
-  __syncthreads();
+}
+// denergy[b,t] = sharp * alpha * (dalpha - sum_t alpha dalpha)   (zero past len)
+__global__ __launch_bounds__(256) void att_softmax_bwd_kernel(const float* __restrict__ da,
+                                                              const float* __restrict__ alpha,
+                                                              const int32_t* __restrict__ seq_len, float sharp,
+                                                              int T, float* __restrict__ denergy) {
+  __shared__ float red[4];
+  __shared__ float s_dot;
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int len = min(max(seq_len[b], 0), T);
   float dot = 0.f;
-  for (int t = tid; t < len; t += 256) dot += alpha[(size_t)b * T + t] * da[t];
+  for (int t = tid; t < len; t += 256) dot += alpha[(size_t)b * T + t] * da[(size_t)b * T + t];
   dot = wave_reduce_sum(dot);
   if (lane == 0) red[wave] = dot;
   __syncthreads();
@@ -237,10 +295,20 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_bwd_kernel(const float* _
   const float dsum = s_dot;
   for (int t = tid; t < T; t += 256) {
     float de = 0.f;
-    if (t < len) de = sharp * alpha[(size_t)b * T + t] * (da[t] - dsum);
+    if (t < len) de = sharp * alpha[(size_t)b * T + t] * (da[(size_t)b * T + t] - dsum);
     denergy[(size_t)b * T + t] = de;
   }
-  for (int t = wave; t < len; t += 4) {
+}
+// denc[t,b,:] += alpha[b,t] * dctx[b,:]  (per-step form; the model defers this to one GEMM per utterance)
+__global__ __launch_bounds__(256) void att_denc_kernel(const float* __restrict__ dctx,
+                                                       const float* __restrict__ alpha,
+                                                       const int32_t* __restrict__ seq_len, int T, int B, int E,
+                                                       float* __restrict__ denc) {
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int len = min(max(seq_len[b], 0), T);
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(len, t0 + ATT_CH);
+  const float* dc = dctx + (size_t)b * E;
+  for (int t = t0 + wave; t < t1; t += 4) {
     const float a = alpha[(size_t)b * T + t];
     float* dr = denc + ((size_t)t * B + b) * E;
     for (int e0 = lane; e0 < E; e0 += 64) dr[e0] += a * dc[e0];
@@ -372,9 +440,14 @@ extern "C" int asr_att_energy_fwd(asr_handle* h, const float* keys, const float*
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(qz && energy && T > 0 && B > 0 && A > 0 && (mode == 0 ? v != nullptr : keys != nullptr),
            "asr_att_energy_fwd: bad args");
-  hipLaunchKernelGGL(att_energy_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, keys, qz, v, T, B, A, mode, energy);
+  hipLaunchKernelGGL(att_energy_fwd_kernel, dim3((T + ATT_CH - 1) / ATT_CH, B), dim3(256), 0, (hipStream_t)s, keys, qz,
+                     v, T, B, A, mode, energy);
   ASR_CHECK_LAUNCH(h, "asr_att_energy_fwd");
   return ASR_OK;
+}
+
+static inline float* att_scratch(asr_handle* h, size_t bytes) {
+  return (bytes <= h->scratch_bytes - ASR_XCH_BYTES) ? (float*)h->scratch : nullptr;
 }
 
 extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const float* keys, const float* qz,
@@ -382,9 +455,14 @@ extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const flo
                                   float* dv_rows, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(denergy && qz && dqz && T > 0 && B > 0 && A > 0, "asr_att_energy_bwd: bad args");
+  const int nch = (T + ATT_CH - 1) / ATT_CH;
+  float* part = att_scratch(h, (size_t)nch * B * 2 * A * sizeof(float));
+  if (!part) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_energy_bwd: scratch too small");
   const size_t lds = (size_t)8 * A * sizeof(float);
-  hipLaunchKernelGGL(att_energy_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, denergy, keys, qz, v, T, B, A,
-                     mode, dkeys, dqz, dv_rows);
+  hipLaunchKernelGGL(att_energy_bwd_kernel, dim3(nch, B), dim3(256), lds, (hipStream_t)s, denergy, keys, qz, v, T, B,
+                     A, mode, dkeys, part);
+  hipLaunchKernelGGL(att_energy_bwd_reduce_kernel, dim3((B * A + 255) / 256), dim3(256), 0, (hipStream_t)s, part, nch,
+                     B, A, dqz, dv_rows);
   ASR_CHECK_LAUNCH(h, "asr_att_energy_bwd");
   return ASR_OK;
 }
@@ -396,8 +474,14 @@ extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const
   ATT_NEED(energy && seq_len && enc && alpha && ctx && T > 0 && B > 0 && E > 0, "asr_att_softmax_ctx_fwd: bad args");
   const size_t lds = (size_t)T * sizeof(float);
   if (lds > 64 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_softmax_ctx_fwd: T=%d too long", T);
-  hipLaunchKernelGGL(att_softmax_ctx_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, energy, seq_len, sharpening,
-                     enc, T, B, E, alpha, ctx);
+  const int nch = (T + ATT_CH - 1) / ATT_CH;
+  float* part = att_scratch(h, (size_t)nch * B * E * sizeof(float));
+  if (!part) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_softmax_ctx_fwd: scratch too small");
+  hipLaunchKernelGGL(att_softmax_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, energy, seq_len, sharpening, T, alpha);
+  hipLaunchKernelGGL(att_ctx_partial_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)s, alpha, seq_len, enc, T, B, E,
+                     part);
+  hipLaunchKernelGGL(att_ctx_reduce_kernel, dim3((B * E + 255) / 256), dim3(256), 0, (hipStream_t)s, part, nch, B * E,
+                     ctx);
   ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_fwd");
   return ASR_OK;
 }
@@ -406,12 +490,16 @@ extern "C" int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const f
                                        const int32_t* seq_len, float sharpening, const float* enc, int T,
                                        int B, int E, float* denergy, float* denc, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
-  ATT_NEED(dctx && alpha && seq_len && enc && denergy && denc && T > 0 && B > 0 && E > 0,
+  ATT_NEED(dctx && alpha && seq_len && enc && denergy && T > 0 && B > 0 && E > 0,
            "asr_att_softmax_ctx_bwd: bad args");
-  const size_t lds = (size_t)T * sizeof(float);
-  if (lds > 64 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_softmax_ctx_bwd: T=%d too long", T);
-  hipLaunchKernelGGL(att_softmax_ctx_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, dctx, alpha, seq_len,
-                     sharpening, enc, T, B, E, denergy, denc);
+  const int nch = (T + ATT_CH - 1) / ATT_CH;
+  float* da = att_scratch(h, (size_t)B * T * sizeof(float));
+  if (!da) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_softmax_ctx_bwd: scratch too small");
+  hipLaunchKernelGGL(att_dalpha_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, seq_len, enc, T, B, E, da);
+  hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, da, alpha, seq_len, sharpening, T,
+                     denergy);
+  if (denc)   // NULL: the caller accumulates d_enc = sum_steps alpha (x) dctx itself (one GEMM per utterance)
+    hipLaunchKernelGGL(att_denc_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, alpha, seq_len, T, B, E, denc);
   ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_bwd");
   return ASR_OK;
 }

@@ -245,6 +245,7 @@ class AttentionSeq2Seq(ModelBase):
         W_cell, b_cell = st[D + 'lstm_cell/kernel'], st[D + 'lstm_cell/bias']
         v = st[AT + 'v_a'] if self.att_mode == 0 else None
         saved = []
+        alpha_all = torch.empty((To, Bp, T), dtype=torch.float32, device=dev)   # one slab: d_enc GEMMs read it strided
         use_ddrop = is_training and float(keep_prob_decoder) < 1.0
         for k in range(To):
             dec_in[k, :, :Em].copy_(emb[k])
@@ -260,7 +261,7 @@ class AttentionSeq2Seq(ModelBase):
                 cell_out = ops.apply_mask(h_raw, dmask)
             qz = self._query(cell_out)
             energy = ops.att_energy_fwd(keys, qz, v, T, self.att_mode)
-            alpha, ctx_k = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc)
+            alpha, ctx_k = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc, alpha_out=alpha_all[k])
             av_in[k, :, :U].copy_(cell_out)
             av_in[k, :, U:].copy_(ctx_k)
             saved.append(dict(gates=gates, c_raw=c_raw, c_prev=c, qz=qz, alpha=alpha, dmask=dmask))
@@ -291,7 +292,7 @@ class AttentionSeq2Seq(ModelBase):
         ids_train = ops.argmax_rows(logits2d).view(To, Bp)[:, :B].t()
         # dynamic_decode(impute_finished=True): every emitted field is zero once a row has finished
         lv = live_d[:, :B].t().unsqueeze(2)                                  # [B,To,1]
-        alphas = torch.stack([s['alpha'] for s in saved], 0)[:, :B].transpose(0, 1) * lv
+        alphas = alpha_all[:, :B].transpose(0, 1) * lv
         out_train = AttentionDecoderOutput(logits=logits_bm, predicted_ids=ids_train * live_d[:, :B].t().int(),
                                            decoder_output=av.view(To, Bp, U)[:, :B].transpose(0, 1) * lv,
                                            attention_weights=alphas,
@@ -301,7 +302,7 @@ class AttentionSeq2Seq(ModelBase):
         if is_training:
             self._tape = dict(B=B, To=To, enc=enc, seq_p=seq_p, keys=keys, dec_in=dec_in, av_in=av_in, av=av,
                               saved=saved, dlogits=dlogits, ids=ids_d, emb_mask=emb_mask, live=live_d, bi=bi,
-                              peep=peep, ctc=ctc_tape)
+                              peep=peep, ctc=ctc_tape, alpha_all=alpha_all)
         else:
             self._tape = None
         total._asr_model = self
@@ -348,10 +349,14 @@ class AttentionSeq2Seq(ModelBase):
         dh_next = torch.zeros((Bp, U), dtype=torch.float32, device=dev)
         dctx_in = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
         v = st[AT + 'v_a'] if self.att_mode == 0 else None
+        dctx_all = torch.empty((To, Bp, E2), dtype=torch.float32, device=dev)
         for k in range(To - 1, -1, -1):
             s = saved[k]
-            dctx = (dav_in[k, :, U:] + dctx_in).contiguous()
-            denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, enc, denc)
+            dctx = dctx_all[k]
+            torch.add(dav_in[k, :, U:], dctx_in, out=dctx)
+            # d_enc += alpha (x) dctx is NOT done per step (a read-modify-write of [T,B,2H] each time):
+            # alpha and dctx of all steps are kept and contracted once per utterance below
+            denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, enc, None)
             dqz, dv_rows = ops.att_energy_bwd(denergy, keys, s['qz'], v, self.att_mode, dkeys=dkeys,
                                               want_dv=self.att_mode == 0)
             dqz_all[k].copy_(dqz)
@@ -378,6 +383,10 @@ class AttentionSeq2Seq(ModelBase):
             dctx_in = d_in[:, Em:Em + E2].contiguous()
             dh_next = dh_carry + d_in[:, Em + E2:]
             dc_next = dc_prev
+        # ---- d_enc[:, b, :] += alpha_b^T [T, To] . dctx_b [To, 2H]   (context path of all steps at once)
+        alpha_all = tp['alpha_all']
+        for b in range(tp['B']):
+            ops.gemm(alpha_all[:, b, :], dctx_all[:, b, :], transA=True, out=denc[:, b, :], accumulate=True)
         # ---- weight gradients of everything inside the loop, batched over the steps
         ops.gemm(dec_in.view(To * Bp, -1), dpre_all.view(To * Bp, 4 * U), transA=True, out=st.g(D + 'lstm_cell/kernel'))
         ops.colsum(dpre_all.view(To * Bp, 4 * U), out=st.g(D + 'lstm_cell/bias'))

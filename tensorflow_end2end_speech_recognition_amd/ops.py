@@ -433,17 +433,19 @@ def att_energy_bwd(denergy, keys, qz, v, mode, dkeys=None, want_dv=True):
     return dqz, dv
 
 
-def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc):
+def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None):
     h = _h(energy)
     B, T = energy.shape
     E = enc.shape[2]
-    alpha, ctx = _f32((B, T), energy.device), _f32((B, E), energy.device)
+    alpha = alpha_out if alpha_out is not None else _f32((B, T), energy.device)
+    ctx = _f32((B, E), energy.device)
     h.check(h.lib.asr_att_softmax_ctx_fwd(h.h, _p(energy), _p(seq_len), float(sharpening), _p(enc), T, B, E,
                                           _p(alpha), _p(ctx), _s()), 'asr_att_softmax_ctx_fwd')
     return alpha, ctx
 
 
-def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc):
+def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None):
+    """denc None: only denergy is produced; the caller accumulates d_enc = sum_steps alpha (x) dctx itself."""
     h = _h(dctx)
     B, T = alpha.shape
     E = enc.shape[2]
