@@ -24,6 +24,13 @@
 //   4. exact top-W by a byte-wise radix select over the 12-byte composite key
 //      (orderable fp64 total, ~insertion index)  -> ties resolved as the reference's stable sort,
 //   5. winners ranked (W^2 compares) into the next beam, new trie nodes appended.
+// Exact class pruning (step 2b): an extension (entry j, class c) can only reach the top W if fewer
+// than W classes c' != last_j have a strictly larger log-probability (each of those gives a distinct
+// candidate of the same parent with a larger total), so only the classes at or above the (W+1)-th
+// largest log-probability of the frame (minus a margin far above fp64 rounding, so "larger" survives
+// the addition) are enumerated: W*(W+1) candidates instead of W*C (10 k vs 339 k for C = 3387, W = 100).
+// Merged pairs are handled in the stay candidates and do not depend on the pruning; insertion
+// indices still use the real class id, so the reference's tie order is unchanged.
 // HBM/latency-bound integer+fp64 work; nothing here is GEMM-shaped.
 #include "common.h"
 #include <math.h>
@@ -49,6 +56,10 @@ __device__ __forceinline__ unsigned long long okey(double x) {
   unsigned long long u = (unsigned long long)__double_as_longlong(x);
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
+__device__ __forceinline__ double unokey(unsigned long long k) {
+  const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)u);
+}
 __device__ __forceinline__ unsigned long long hmix(unsigned long long h, int c) {
   unsigned long long x = h * 0x9E3779B97F4A7C15ull + (unsigned long long)(c + 1);
   x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 29;
@@ -72,6 +83,12 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
     int32_t* __restrict__ out_labels, int32_t* __restrict__ out_len, double* __restrict__ out_score) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lp = reinterpret_cast<double*>(smem);      // [C]
+  int* kc = reinterpret_cast<int*>(lp + C);          // [C] kept classes of the frame, ascending
+  int* kpos = kc + C;                                // [C] position of a class in kc, -1 if pruned
+  __shared__ double s_L[BEAM_MAX];                   // logsumexp(p_b, p_nb) of each beam entry
+  __shared__ unsigned wcnt[BEAM_THREADS / 64];
+  __shared__ int s_K;
+  __shared__ double s_thr;
   __shared__ Entry beam[BEAM_MAX];
   __shared__ Entry nbeam[BEAM_MAX];
   __shared__ double s_pb[BEAM_MAX], s_pnb[BEAM_MAX];  // stay candidates
@@ -162,29 +179,84 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
       s_idx[tid] = ~first;
     }
     __syncthreads();
-    // ---- 3. extension totals (p_b = -inf, so total = p_nb contribution)
-    for (int e = tid; e < nb * C; e += BEAM_THREADS) {
-      const int j = e / C, c = e % C;
-      double v = DNEG;
-      if (c != blank) {
-        const Entry p = beam[j];
-        v = (c == p.last) ? p.pb + lp[c] : lse2d(p.pb, p.pnb) + lp[c];
+    // ---- 2b. classes that can still reach the top W (see the header): threshold = (W+1)-th largest
+    //      non-blank log-probability, found with a byte-wise radix select over the frame's C values
+    if (tid < nb) s_L[tid] = lse2d(beam[tid].pb, beam[tid].pnb);
+    const int R = W + 1;
+    if (C - 1 > 4 * R) {   // small vocabularies: the select + compaction passes cost more than they prune
+      if (tid == 0) { sel_key = 0; sel_remaining = (unsigned)R; }
+      __syncthreads();
+      for (int byte = 7; byte >= 0; --byte) {
+        hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long pk = sel_key;
+        const int sh = (byte + 1) * 8;
+        for (int c = tid; c < C; c += BEAM_THREADS) {
+          if (c == blank) continue;
+          const unsigned long long k = okey(lp[c]);
+          if (sh >= 64 || (k >> sh) == (pk >> sh)) atomicAdd(&hist[(unsigned)((k >> (byte * 8)) & 0xff)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned rem = sel_remaining;
+          int dgt = 255;
+          for (; dgt > 0; --dgt) {
+            if (hist[dgt] >= rem) break;
+            rem -= hist[dgt];
+          }
+          sel_remaining = rem;
+          sel_key |= ((unsigned long long)dgt) << (byte * 8);
+        }
+        __syncthreads();
       }
-      tot[e] = v;
+      if (tid == 0) {
+        const double th = unokey(sel_key);
+        s_thr = th - 1e-9 * (1.0 + fabs(th));
+      }
+    } else if (tid == 0) {
+      s_thr = DNEG;
     }
     __syncthreads();
-    if (tid < nb && s_parent[tid] >= 0 && beam[tid].last != blank)   // merged pairs are not new prefixes
-      tot[(size_t)s_parent[tid] * C + beam[tid].last] = NAN;          // NaN = excluded marker
+    {   // ordered compaction of the kept classes
+      const double thr = s_thr;
+      int base = 0;
+      for (int c0 = 0; c0 < C; c0 += BEAM_THREADS) {
+        const int c = c0 + tid;
+        const bool keep = c < C && c != blank && lp[c] >= thr;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wcnt[wave] = (unsigned)__popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += (int)wcnt[w];
+        const int pos = off + (int)__popcll(bal & ((1ull << lane) - 1ull));
+        if (c < C) kpos[c] = keep ? pos : -1;
+        if (keep) kc[pos] = c;
+        base += (int)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+        __syncthreads();
+      }
+      if (tid == 0) s_K = base;
+    }
     __syncthreads();
-    // ---- 4. exact top-W over nb stay + nb*(C) extension candidates (excluded ones skipped)
-    const int M = nb + nb * C;
+    const int K = s_K;
+    // ---- 3. extension totals over the kept classes (p_b = -inf, so total = p_nb contribution)
+    for (int e = tid; e < nb * K; e += BEAM_THREADS) {
+      const int j = e / K, c = kc[e % K];
+      tot[e] = ((c == beam[j].last) ? beam[j].pb : s_L[j]) + lp[c];
+    }
+    __syncthreads();
+    if (tid < nb && s_parent[tid] >= 0 && beam[tid].last != blank) {   // merged pairs are not new prefixes
+      const int kp = kpos[beam[tid].last];
+      if (kp >= 0) tot[(size_t)s_parent[tid] * K + kp] = NAN;           // NaN = excluded marker
+    }
+    __syncthreads();
+    // ---- 4. exact top-W over nb stay + nb*K extension candidates (excluded ones skipped)
+    const int M = nb + nb * K;
     auto cand = [&](int id, unsigned long long& key, unsigned& nidx) -> bool {
       if (id < nb) { key = s_key[id]; nidx = s_idx[id]; return true; }
       const int e = id - nb;
       const double v = tot[e];
       if (v != v) return false;
-      const int j = e / C, c = e % C;
-      if (c == blank) return false;
+      const int j = e / K, c = kc[e % K];
       key = okey(v);
       nidx = ~((unsigned)c * (2u * W) + 2u * j);
       return true;
@@ -266,7 +338,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
         ne = beam[id];
         ne.pb = s_pb[id]; ne.pnb = s_pnb[id];
       } else {
-        const int e = id - nb, j = e / C, c = e % C;
+        const int e = id - nb, j = e / K, c = kc[e % K];
         const Entry p = beam[j];
         ne.pb = DNEG; ne.pnb = tot[e];
         ne.phash = p.hash; ne.hash = hmix(p.hash, c);
@@ -332,7 +404,7 @@ extern "C" int asr_ctc_beam_decode(asr_handle* h, const float* logits, int T, in
   const BeamWs w = beam_ws_layout(T, B, C, beam_width);
   if (!workspace || workspace_bytes < w.total)
     ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_ctc_beam_decode: workspace %zu < %zu bytes", workspace_bytes, w.total);
-  const size_t lds = (size_t)C * sizeof(double);
+  const size_t lds = (size_t)C * (sizeof(double) + 2 * sizeof(int));
   if (lds > 96 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_beam_decode: C=%d too large for LDS", C);
   (void)hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   char* ws = (char*)workspace;
