@@ -391,6 +391,126 @@ bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A
   return true;
 }
 
+// ---------------------------------------------------------------- lean TN kernel (bf16)
+// C[M,N] = A^T B with A [K,M] and B [K,N] both REDUCTION-MAJOR (row = one k): the weight-gradient
+// products X^T dG with K = T*B.  The MFMA fragments want 8 consecutive k per lane, so the tiles are
+// transposed on their way into LDS: a thread loads the 16-byte vectors (8 consecutive m) of two
+// adjacent k rows and writes eight 32-bit (k, k+1) pairs into the [m][k] image.  Sixteen lanes
+// cover 256 contiguous bytes of a k row (coalesced); the LDS image is XOR-swizzled in 16-byte
+// units by (m >> 3) & 7 so those sixteen lanes (rows 8 apart = same bank without it) spread over
+// the banks, and a fragment's 16 bytes stay contiguous.  Split-K over blockIdx.z into fp32 slabs
+// (summed in a fixed order by splitk_reduce_kernel), 128x128x64 tiles, double-buffered LDS.
+// Requires M % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0, 16-byte aligned bases.
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
+                                                           int lda, const bf16_t* __restrict__ Bm, int ldb,
+                                                           int kchunk, float* __restrict__ partial) {
+  constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
+  constexpr int STAGE = (BM + BN) * LD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* S = reinterpret_cast<bf16_t*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+
+  // two (k-pair, m-vector) items per operand per thread: item q -> mvec = q & 15, kp = q >> 4
+  const int mvec = tid & 15;
+  const int kp0 = tid >> 4;                                // second item: kp0 + 16
+  const bool a_ok = m0 + mvec * 8 + 8 <= M, b_ok = n0 + mvec * 8 + 8 <= N;
+  const bf16_t* pa = A + (size_t)(kbeg + 2 * kp0) * lda + m0 + mvec * 8;
+  const bf16_t* pb = Bm + (size_t)(kbeg + 2 * kp0) * ldb + n0 + mvec * 8;
+  const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8_t ra[2][2], rb[2][2];                             // [item][k parity]
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = kbeg + kt * BK + 2 * (kp0 + 16 * it) + h;
+        const size_t ro = (size_t)(kt * BK + 32 * it + h);
+        ra[it][h] = (a_ok && k < kend) ? *reinterpret_cast<const bf16x8_t*>(pa + ro * lda) : zero;
+        rb[it][h] = (b_ok && k < kend) ? *reinterpret_cast<const bf16x8_t*>(pb + ro * ldb) : zero;
+      }
+  };
+  // [m][k] image; the 16-byte unit index INSIDE a row (k >> 3, 0..7) is XORed with (m >> 3) & 7
+  // (== mvec & 7 for the rows this thread writes); rows keep their 144-byte stride
+  const unsigned sw = (unsigned)(mvec & 7);
+  auto sstore = [&](bf16_t* st) {
+    char* base = reinterpret_cast<char*>(st);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const unsigned k2 = (unsigned)(2 * (kp0 + 16 * it));                 // even k of the pair
+      const unsigned inrow = (((k2 >> 3) ^ sw) << 4) + (k2 & 7u) * 2u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned off = (unsigned)(mvec * 8 + j) * LD * 2u + inrow;
+        // elements are (signed) shorts holding raw bf16 bits: no sign extension into the high half
+        *reinterpret_cast<unsigned*>(base + off) =
+            (unsigned)(unsigned short)ra[it][0][j] | ((unsigned)(unsigned short)ra[it][1][j] << 16);
+        *reinterpret_cast<unsigned*>(base + BM * LD * 2 + off) =
+            (unsigned)(unsigned short)rb[it][0][j] | ((unsigned)(unsigned short)rb[it][1][j] << 16);
+      }
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (nkt > 0) {
+    gload(0);
+    sstore(S);
+  }
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  unsigned arow[4], brow[4], au[4], bu[4];                 // row byte offset / swizzled unit of k-block fq
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned ra_ = (unsigned)(wm * 64 + i * 16 + fr), rb_ = (unsigned)(wn * 64 + i * 16 + fr);
+    arow[i] = ra_ * LD * 2u;
+    brow[i] = (unsigned)BM * LD * 2u + rb_ * LD * 2u;
+    au[i] = (unsigned)fq ^ ((ra_ >> 3) & 7u);
+    bu[i] = (unsigned)fq ^ ((rb_ >> 3) & 7u);
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* cur = reinterpret_cast<const char*>(S + (kt & 1) * STAGE);
+    if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[4], b[4];
+      // k-block of this lane = ks*4 + fq; (ks*4 + fq) ^ sw == (fq ^ sw) ^ (ks*4)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(cur + arow[i] + ((au[i] ^ (unsigned)(ks * 4)) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(cur + brow[j] + ((bu[j] ^ (unsigned)(ks * 4)) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) sstore(S + ((kt + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+  // slab [z][M][N]; lane holds C[m = fr][n = fq*4 .. +3] of each 16x16 tile
+  float* slab = partial + (size_t)blockIdx.z * M * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + wn * 64 + j * 16 + fq * 4;
+      if (nb >= N) continue;                               // N % 8 == 0: a 4-group is all in or all out
+      *reinterpret_cast<f32x4_t*>(slab + (size_t)m * N + nb) = acc[i][j];
+    }
+  }
+}
+
 // fixed-order sum of the split-K slabs -> deterministic
 template <typename TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
@@ -433,6 +553,36 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
   constexpr int VEC = GT<T>::VEC, BK = GT<T>::BK;
   if constexpr (sizeof(T) == 2) {
     if (try_gemm_nt_bf16<TO>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act)) return 0;
+    // reduction-major operands (X^T dG): lean TN kernel, always through split-K slabs
+    if (transA && !transB && K >= 2048 && M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+        ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0) {
+      const int tm = (M + 127) / 128, tn = (N + 127) / 128;
+      int S = (1024 + tm * tn - 1) / (tm * tn);            // aim at ~4 workgroups per CU
+      const int maxS = (K + 255) / 256;
+      if (S > maxS) S = maxS;
+      if (S > 256) S = 256;
+      while (S > 1 && (size_t)S * M * N * sizeof(float) > h->scratch_bytes - ASR_XCH_BYTES) --S;
+      if ((size_t)S * M * N * sizeof(float) <= h->scratch_bytes - ASR_XCH_BYTES) {
+        int kchunk = (K + S - 1) / S;
+        kchunk = (kchunk + 63) / 64 * 64;
+        S = (K + kchunk - 1) / kchunk;
+        const size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * sizeof(bf16_t);
+        static bool attr_done = false;
+        if (!attr_done) {
+          attr_done = true;
+          (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        float* partial = (float*)h->scratch;
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tn, tm, S), dim3(256), lds, st, M, N, K, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, kchunk, partial);
+        const size_t total = (size_t)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(blocks), dim3(256), 0, st, partial, S, M, N, (TO*)C, ldc,
+                           bias, accumulate, act);
+        return 0;
+      }
+    }
   }
   const int aa = (((uintptr_t)A) % 16 == 0) && (lda % VEC == 0);
   const int ba = (((uintptr_t)B) % 16 == 0) && (ldb % VEC == 0);

@@ -58,7 +58,7 @@ def test_gemm_f32(cuda, M, N, K, ta, tb):
 
 
 @pytest.mark.parametrize('M,N,K', [(64, 64, 64), (130, 70, 45), (257, 1024, 120), (3000, 2048, 512),
-                                   (256, 1024, 12448)])
+                                   (256, 1024, 12448), (120, 1024, 12448), (512, 2040, 5001), (1024, 64, 3000)])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_bf16(cuda, M, N, K, ta, tb):
     ops = _ops()
@@ -180,7 +180,9 @@ def test_lstm_fwd_cell_clip(cuda):
     x, ps = _lstm_case(rng, T, B, D, H, 2, lens, init=1.5)
     got = _run_hip_layer(cuda, x * 3, ps, lens, H, 2, 'f32', 0.5)
     ref = _oracle_layer(x * 3, ps, lens, 2, 0.5)
-    assert np.abs(got['cs']).max() <= 0.5 + 1e-6 and np.abs(got['cs']).max() > 0.49   # clip active
+    # saved cell states are only defined on valid frames (the padding is never written)
+    cmax = max(np.abs(got['cs'][:lens[b], b]).max() for b in range(B))
+    assert cmax <= 0.5 + 1e-6 and cmax > 0.49   # clip active
     assert np.abs(got['hout'] - ref['hout']).max() < 5e-5
 
 
