@@ -108,6 +108,23 @@ int asr_im2col3x3(asr_handle* h, int dtype, const void* in, int N, int H, int W,
                   void* patches, asr_stream s);
 int asr_col2im3x3(asr_handle* h, const float* dpatches, int N, int H, int W, int Cin, int ldp,
                   float* din, asr_stream s);
+/* Implicit-GEMM form of the same 3x3 SAME convolution for bf16 operands (no patch matrix: a 64-wide
+ * k-tile is one tap x 64 input channels, read straight from the NHWC image; conv_layer of
+ * models/encoders/core/cnn_util.py:14-84, VGG blocks of vgg_blstm.py:113-157).
+ *   prep:  from the HWIO fp32 master [3,3,Cin,Cout]: wt_fwd[Cout][9*Cin] and the flipped-tap image
+ *          wt_bwd[Cin][9*Cout] (both bf16, reduction-contiguous);
+ *   fwd:   out[N,H,W,Cout] bf16 = relu?(conv(x) + bias)             (Cin, Cout multiples of 64);
+ *   bwd_data:   dx[N,H,W,Cin] fp32 = conv of dy (bf16) with wt_bwd;
+ *   bwd_weight: dw[9*Cin, Cout] fp32 (+= if accumulate) = sum over pixels of x(shifted) (x) dy,
+ *               deterministic split-K over the pixels through the handle scratch. */
+int asr_conv3x3_prep_weights(asr_handle* h, const float* w_hwio, int Cin, int Cout, void* wt_fwd,
+                             void* wt_bwd, asr_stream s);
+int asr_conv3x3_fwd(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* wt_fwd,
+                    const float* bias, int Cout, int relu, void* out, asr_stream s);
+int asr_conv3x3_bwd_data(asr_handle* h, const void* dy, int N, int H, int W, int Cout,
+                         const void* wt_bwd, int Cin, float* dx, asr_stream s);
+int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* dy, int N, int H, int W,
+                           int Cin, int Cout, float* dw, int accumulate, asr_stream s);
 /* tf.nn.max_pool 2x2 stride 2 SAME (cnn_util.py:13-28): out [N, ceil(H/2), ceil(W/2), C];
  * argmax (uint8, 0..3 = position in the window) drives the backward pass. */
 int asr_maxpool2x2_fwd(asr_handle* h, int dtype, const void* in, int N, int H, int W, int C,

@@ -32,6 +32,10 @@ SIGNATURES = {
     'asr_colsum': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     'asr_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'asr_gemm_act': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    'asr_conv3x3_prep_weights': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'asr_conv3x3_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    'asr_conv3x3_bwd_data': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'asr_conv3x3_bwd_weight': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'asr_im2col3x3': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_col2im3x3': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_maxpool2x2_fwd': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -511,6 +511,269 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int M, int N, int K, 
   }
 }
 
+// ---------------------------------------------------------------- implicit-GEMM 3x3 convolution (bf16)
+// out[p, co] = act(sum_{tap, ci} x[p + s_tap, ci] * Wt[co][tap*Cin + ci] + bias[co]),  SAME padding,
+// x NHWC [Nimg, H, W, Cin], p = flat pixel index, s_tap = (tap/3 - 1, tap%3 - 1).
+// This is gemm_nt_bf16_kernel with the A tile gathered straight from the image: a 64-wide k-tile is
+// (one tap, 64 consecutive input channels) = 128 contiguous bytes of the shifted pixel, zero when the
+// shifted pixel falls off the frame -- no im2col patch matrix (9x the activation bytes) is ever written.
+// The data gradient is the same kernel on dOut with the flipped-tap weight image (conv3x3_prep_kernel).
+// Requires Cin % 64 == 0; BN in {64, 128} = Cout tile.
+template <typename TO, int BN>
+__global__ __launch_bounds__(256) void conv3x3_nt_bf16_kernel(int Mpix, int H, int W, int Cin, int Cout,
+                                                              const bf16_t* __restrict__ X,
+                                                              const bf16_t* __restrict__ Wt,
+                                                              TO* __restrict__ Out, const float* __restrict__ bias,
+                                                              int act) {
+  constexpr int BM = 128, BK = 64, LD = BK + 8;
+  constexpr int STAGE = (BM + BN) * LD;
+  constexpr int WN = BN / 2, TN = WN / 16;
+  constexpr int NB = BN * 8 / 256;                         // B vectors per thread per k-tile (4 / 2)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* S = reinterpret_cast<bf16_t*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = Cout / BN;
+  const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+  const int K = 9 * Cin, nkt = K / BK, kpt = Cin / BK;     // k-tiles per tap
+  const int HW = H * W;
+
+  // A: 4 vectors per thread: pixel row r = v >> 3 (tile-local), channel offset (v & 7) * 8
+  int py[4], px[4];
+  const bf16_t* pa[4];
+  unsigned so[4];
+  bool mok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int v = tid + i * 256, r = v >> 3, kv = (v & 7) * 8;
+    const int m = m0 + r;
+    mok[i] = m < Mpix;
+    const int mm = mok[i] ? m : 0;
+    const int rem = mm % HW;
+    py[i] = rem / W;
+    px[i] = rem % W;
+    pa[i] = X + (size_t)mm * Cin + kv;
+    so[i] = (unsigned)(r * LD + kv);
+  }
+  const bf16_t* pb[NB];
+  unsigned sob[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int v = tid + i * 256, r = v >> 3, kv = (v & 7) * 8;
+    pb[i] = Wt + (size_t)(n0 + r) * K + kv;
+    sob[i] = (unsigned)(BM * LD + r * LD + kv);
+  }
+  const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8_t ra[4], rb[NB];
+  auto gload = [&](int kt) {
+    const int tap = kt / kpt, ci0 = (kt - tap * kpt) * BK;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const ptrdiff_t sh = ((ptrdiff_t)dy * W + dx) * Cin + ci0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = mok[i] && (unsigned)(py[i] + dy) < (unsigned)H && (unsigned)(px[i] + dx) < (unsigned)W;
+      ra[i] = ok ? *reinterpret_cast<const bf16x8_t*>(pa[i] + sh) : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const bf16x8_t*>(pb[i] + (size_t)kt * BK);
+  };
+  auto sstore = [&](bf16_t* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16x8_t*>(st + so[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<bf16x8_t*>(st + sob[i]) = rb[i];
+  };
+
+  f32x4_t acc[4][TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  sstore(S);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  const unsigned aoff = (unsigned)((wm * 64 + fr) * LD + fq * 8);
+  const unsigned boff = (unsigned)(BM * LD + (wn * WN + fr) * LD + fq * 8);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bf16_t* cur = S + (kt & 1) * STAGE;
+    if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[4], b[TN];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(cur + aoff + i * 16 * LD + ks * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(cur + boff + j * 16 * LD + ks * 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) sstore(S + ((kt + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= Mpix) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + wn * WN + j * 16 + fq * 4;
+      TO* cp = Out + (size_t)m * Cout + nb;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      if (bias) {
+        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+      }
+      if (act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+      } else {
+        typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+        *reinterpret_cast<us4_t*>(cp) = (us4_t){f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+      }
+    }
+  }
+}
+
+// weight images for the two implicit GEMMs from the HWIO fp32 master [9][Cin][Cout]:
+//   wf[co][tap*Cin + ci] = w[tap][ci][co]          (forward:   B^T of x * W)
+//   wb[ci][tap*Cout + co] = w[8 - tap][ci][co]     (data grad: B^T of dOut * flipped W)
+__global__ void conv3x3_prep_kernel(const float* __restrict__ w, int Cin, int Cout, bf16_t* __restrict__ wf,
+                                    bf16_t* __restrict__ wb) {
+  const size_t total = (size_t)9 * Cin * Cout;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = i % Cout, ci = (i / Cout) % Cin, tap = i / ((size_t)Cin * Cout);
+    const bf16_t v = f32_to_bf16(w[i]);
+    wf[(size_t)co * 9 * Cin + (size_t)tap * Cin + ci] = v;
+    wb[(size_t)ci * 9 * Cout + (size_t)(8 - tap) * Cout + co] = v;
+  }
+}
+
+// Weight gradient: dW[tap*Cin + ci][co] = sum_p x[p + s_tap, ci] * dOut[p, co].  gemm_tn_bf16_kernel with the
+// A operand (reduction index = pixel, column = (tap, ci)) gathered from the image; B = dOut is plain.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_tn_kernel(int Mpix, int H, int W, int Cin, int Cout,
+                                                               const bf16_t* __restrict__ X,
+                                                               const bf16_t* __restrict__ dY, int kchunk,
+                                                               float* __restrict__ partial) {
+  constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
+  constexpr int STAGE = (BM + BN) * LD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* S = reinterpret_cast<bf16_t*>(smem);
+  const int M = 9 * Cin, N = Cout, K = Mpix, HW = H * W;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+
+  const int mvec = tid & 15;
+  const int kp0 = tid >> 4;
+  const int mcol = m0 + mvec * 8;                          // first of this thread's 8 virtual columns
+  const bool a_ok = mcol + 8 <= M, b_ok = n0 + mvec * 8 + 8 <= N;
+  const int tap = a_ok ? mcol / Cin : 0, ci = a_ok ? mcol - tap * Cin : 0;
+  const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+  const ptrdiff_t sh = ((ptrdiff_t)dy * W + dx) * Cin + ci;
+  const float invW = 1.0f / (float)W;
+  const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8_t ra[2][2], rb[2][2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int p = kbeg + kt * BK + 2 * (kp0 + 16 * it) + h;              // pixel = reduction index
+        const bool kin = p < kend;
+        const int pp = kin ? p : 0;
+        const int rem = pp % HW;
+        const int y = (int)(((float)rem + 0.5f) * invW), x = rem - y * W;    // exact for rem < 2^22
+        const bool ok = a_ok && kin && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+        ra[it][h] = ok ? *reinterpret_cast<const bf16x8_t*>(X + (ptrdiff_t)((size_t)pp * Cin) + sh) : zero;
+        rb[it][h] = (b_ok && kin) ? *reinterpret_cast<const bf16x8_t*>(dY + (size_t)pp * Cout + n0 + mvec * 8) : zero;
+      }
+  };
+  const unsigned sw = (unsigned)(mvec & 7);
+  auto sstore = [&](bf16_t* st) {
+    char* base = reinterpret_cast<char*>(st);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const unsigned k2 = (unsigned)(2 * (kp0 + 16 * it));
+      const unsigned inrow = (((k2 >> 3) ^ sw) << 4) + (k2 & 7u) * 2u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned off = (unsigned)(mvec * 8 + j) * LD * 2u + inrow;
+        *reinterpret_cast<unsigned*>(base + off) =
+            (unsigned)(unsigned short)ra[it][0][j] | ((unsigned)(unsigned short)ra[it][1][j] << 16);
+        *reinterpret_cast<unsigned*>(base + BM * LD * 2 + off) =
+            (unsigned)(unsigned short)rb[it][0][j] | ((unsigned)(unsigned short)rb[it][1][j] << 16);
+      }
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  if (nkt > 0) {
+    gload(0);
+    sstore(S);
+  }
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  unsigned arow[4], brow[4], au[4], bu[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned ra_ = (unsigned)(wm * 64 + i * 16 + fr), rb_ = (unsigned)(wn * 64 + i * 16 + fr);
+    arow[i] = ra_ * LD * 2u;
+    brow[i] = (unsigned)BM * LD * 2u + rb_ * LD * 2u;
+    au[i] = (unsigned)fq ^ ((ra_ >> 3) & 7u);
+    bu[i] = (unsigned)fq ^ ((rb_ >> 3) & 7u);
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* cur = reinterpret_cast<const char*>(S + (kt & 1) * STAGE);
+    if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(cur + arow[i] + ((au[i] ^ (unsigned)(ks * 4)) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(cur + brow[j] + ((bu[j] ^ (unsigned)(ks * 4)) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) sstore(S + ((kt + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+  float* slab = partial + (size_t)blockIdx.z * M * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + wn * 64 + j * 16 + fq * 4;
+      if (nb >= N) continue;
+      *reinterpret_cast<f32x4_t*>(slab + (size_t)m * N + nb) = acc[i][j];
+    }
+  }
+}
+
 // fixed-order sum of the split-K slabs -> deterministic
 template <typename TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
@@ -668,5 +931,100 @@ extern "C" int asr_gemm_act(asr_handle* h, int dtype, int out_dtype, int transA,
   else
     launch_gemm<bf16_t, bf16_t>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act);
   ASR_CHECK_LAUNCH(h, "asr_gemm");
+  return ASR_OK;
+}
+
+// ---------------------------------------------------------------- implicit-GEMM conv entry points
+extern "C" int asr_conv3x3_prep_weights(asr_handle* h, const float* w_hwio, int Cin, int Cout, void* wt_fwd,
+                                        void* wt_bwd, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!w_hwio || !wt_fwd || !wt_bwd || Cin < 1 || Cout < 1)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_prep_weights: bad args");
+  const size_t total = (size_t)9 * Cin * Cout;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(conv3x3_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w_hwio, Cin, Cout,
+                     (bf16_t*)wt_fwd, (bf16_t*)wt_bwd);
+  ASR_CHECK_LAUNCH(h, "asr_conv3x3_prep_weights");
+  return ASR_OK;
+}
+
+template <typename TO>
+static int conv3x3_launch(asr_handle* h, const void* x, int Nimg, int H, int W, int Cin, const void* wt,
+                          const float* bias, int Cout, int act, void* out, hipStream_t st) {
+  const long long mp = (long long)Nimg * H * W;
+  if (mp <= 0 || mp >= (1ll << 31)) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3: %lld pixels", mp);
+  const int Mpix = (int)mp;
+  const int tm = (Mpix + 127) / 128;
+  if (Cout % 128 == 0) {
+    const size_t lds = (size_t)2 * (128 + 128) * 72 * sizeof(bf16_t);
+    auto k = conv3x3_nt_bf16_kernel<TO, 128>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)tm * (Cout / 128)), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
+                       (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, bias, act);
+  } else {
+    const size_t lds = (size_t)2 * (128 + 64) * 72 * sizeof(bf16_t);
+    auto k = conv3x3_nt_bf16_kernel<TO, 64>;
+    hipLaunchKernelGGL(k, dim3((unsigned)tm * (Cout / 64)), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
+                       (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, bias, act);
+  }
+  ASR_CHECK_LAUNCH(h, "asr_conv3x3");
+  return ASR_OK;
+}
+
+extern "C" int asr_conv3x3_fwd(asr_handle* h, const void* x, int Nimg, int H, int W, int Cin, const void* wt_fwd,
+                               const float* bias, int Cout, int relu, void* out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!x || !wt_fwd || !out || Nimg < 1 || H < 1 || W < 1)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_fwd: bad args");
+  if (Cin % 64 != 0 || Cout % 64 != 0)
+    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_fwd: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);
+  return conv3x3_launch<bf16_t>(h, x, Nimg, H, W, Cin, wt_fwd, bias, Cout, relu ? 1 : 0, out, (hipStream_t)s);
+}
+
+extern "C" int asr_conv3x3_bwd_data(asr_handle* h, const void* dy, int Nimg, int H, int W, int Cout,
+                                    const void* wt_bwd, int Cin, float* dx, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!dy || !wt_bwd || !dx || Nimg < 1 || H < 1 || W < 1)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_bwd_data: bad args");
+  if (Cin % 64 != 0 || Cout % 64 != 0)
+    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_bwd_data: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);
+  // the data gradient is a convolution of dOut (Cout channels) with the flipped-tap image -> Cin channels
+  return conv3x3_launch<float>(h, dy, Nimg, H, W, Cout, wt_bwd, nullptr, Cin, 0, dx, (hipStream_t)s);
+}
+
+extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* dy, int Nimg, int H, int W,
+                                      int Cin, int Cout, float* dw, int accumulate, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!x || !dy || !dw || Nimg < 1 || H < 1 || W < 1)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_bwd_weight: bad args");
+  if (Cin % 8 != 0 || Cout % 8 != 0)
+    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_bwd_weight: Cin=%d, Cout=%d must be multiples of 8", Cin, Cout);
+  const long long mp = (long long)Nimg * H * W;
+  if (mp >= (1ll << 31)) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_bwd_weight: %lld pixels", mp);
+  const int Mpix = (int)mp, M = 9 * Cin, N = Cout;
+  const int tm = (M + 127) / 128, tn = (N + 127) / 128;
+  int S = (2048 + tm * tn - 1) / (tm * tn);
+  const int maxS = (Mpix + 511) / 512;
+  if (S > maxS) S = maxS;
+  if (S > 512) S = 512;
+  while (S > 1 && (size_t)S * M * N * sizeof(float) > h->scratch_bytes - ASR_XCH_BYTES) --S;
+  if ((size_t)S * M * N * sizeof(float) > h->scratch_bytes - ASR_XCH_BYTES)
+    ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_conv3x3_bwd_weight: scratch too small");
+  int kchunk = (Mpix + S - 1) / S;
+  kchunk = (kchunk + 63) / 64 * 64;
+  S = (Mpix + kchunk - 1) / kchunk;
+  const size_t lds = (size_t)2 * (128 + 128) * 72 * sizeof(bf16_t);
+  (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  float* partial = (float*)h->scratch;
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(conv3x3_wgrad_tn_kernel, dim3(tn, tm, S), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
+                     (const bf16_t*)x, (const bf16_t*)dy, kchunk, partial);
+  const size_t total = (size_t)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, partial, S, M, N, dw, N, nullptr,
+                     accumulate, 0);
+  ASR_CHECK_LAUNCH(h, "asr_conv3x3_bwd_weight");
   return ASR_OK;
 }

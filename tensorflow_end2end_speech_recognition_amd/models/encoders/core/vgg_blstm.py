@@ -8,7 +8,9 @@ dropouts (:136-157); flatten; bridge FC -> 256 relu + dropout (:165-174); then t
 as BLSTMEncoder (:182-218).  Variables: VGG{1,2}/conv{1,2}/{weight,bias} (tf.Variable in
 cnn_util.py:66-69), bridge/{weights,biases}.
 
-Round-1 execution: convolution = asr_im2col3x3 + MFMA GEMM with fused bias+ReLU, chunked over
+Execution: bf16 layers with Cin % 64 == 0 (3 of the 4 convolutions, 98 % of the FLOPs) run as
+implicit GEMMs (asr_conv3x3_fwd / _bwd_data / _bwd_weight: no patch matrix); the 3-channel first
+layer and the fp32 parity path use asr_im2col3x3 + MFMA GEMM with fused bias+ReLU, chunked over
 frames (CHUNK_FRAMES) so the patch matrix is a bounded scratch; backward recomputes the patches.
 """
 import numpy as np
@@ -104,8 +106,23 @@ class _VGGFrontEnd(object):
         out = ops.cast_to_f32(brd) if brd.dtype != torch.float32 else brd
         return out.view(B, T, 256)
 
+    def _implicit(self, cin, cout):
+        import os
+        if os.environ.get('ASR_VGG_IMPLICIT', '1') == '0':      # A-B switch: im2col + GEMM everywhere
+            return False
+        return self.dtype == ASR_BF16 and cin % 64 == 0 and cout % 64 == 0
+
+    def _conv_images(self, name):
+        """bf16 weight images of the implicit GEMMs (forward / flipped-tap), built once per step."""
+        cache = self.ctx.setdefault('wimg', {})
+        if name not in cache:
+            cache[name] = ops.conv3x3_prep_weights(self.store[self.prefix + name + '/weight'])
+        return cache[name]
+
     def _layer(self, x, conv, sh):
         name, cin, cout = conv
+        if self._implicit(cin, cout):
+            return ops.conv3x3_fwd(x, self._conv_images(name)[0], self.store[self.prefix + name + '/bias'], relu=True)
         N, H, W, _ = x.shape
         out = torch.empty((N, H, W, cout), dtype=x.dtype, device=x.device)
         for c0 in range(0, N, CHUNK_FRAMES):
@@ -120,6 +137,11 @@ class _VGGFrontEnd(object):
         N, H, W, _ = out.shape
         gw = st.g(self.prefix + name + '/weight').view(9 * cin, cout)
         gb = st.g(self.prefix + name + '/bias')
+        if self._implicit(cin, cout):
+            dpre = ops.relu_bwd(dout.contiguous(), out, mask)                  # [N,H,W,cout] bf16
+            ops.conv3x3_bwd_weight(x_in, dpre, gw)
+            ops.colsum(dpre.view(N * H * W, cout), out=gb)
+            return ops.conv3x3_bwd_data(dpre, self._conv_images(name)[1]) if need_dx else None
         w2d = sh[self.prefix + name + '/weight'].view(9 * cin, cout)
         ldp = (9 * cin + 7) // 8 * 8
         din = torch.empty((N, H, W, cin), dtype=torch.float32, device=dout.device) if need_dx else None

@@ -196,6 +196,52 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, 
 
 
 # ---------------------------------------------------------------- VGG front-end
+def conv3x3_prep_weights(w_hwio):
+    """fp32 [3,3,Cin,Cout] -> (wt_fwd bf16 [Cout, 9*Cin], wt_bwd bf16 [Cin, 9*Cout])."""
+    h = _h(w_hwio)
+    _chk(w_hwio, torch.float32, 'w')
+    _, _, Cin, Cout = w_hwio.shape
+    wf = torch.empty((Cout, 9 * Cin), dtype=torch.bfloat16, device=w_hwio.device)
+    wb = torch.empty((Cin, 9 * Cout), dtype=torch.bfloat16, device=w_hwio.device)
+    h.check(h.lib.asr_conv3x3_prep_weights(h.h, _p(w_hwio.contiguous()), Cin, Cout, _p(wf), _p(wb), _s()),
+            'asr_conv3x3_prep_weights')
+    return wf, wb
+
+
+def conv3x3_fwd(x_nhwc, wt_fwd, bias, relu=True):
+    h = _h(x_nhwc)
+    _chk(x_nhwc, torch.bfloat16, 'x')
+    N, H, W, Cin = x_nhwc.shape
+    Cout = wt_fwd.shape[0]
+    out = torch.empty((N, H, W, Cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    h.check(h.lib.asr_conv3x3_fwd(h.h, _p(x_nhwc), N, H, W, Cin, _p(wt_fwd), _p(bias), Cout, 1 if relu else 0,
+                                  _p(out), _s()), 'asr_conv3x3_fwd')
+    return out
+
+
+def conv3x3_bwd_data(dy_nhwc, wt_bwd):
+    h = _h(dy_nhwc)
+    _chk(dy_nhwc, torch.bfloat16, 'dy')
+    N, H, W, Cout = dy_nhwc.shape
+    Cin = wt_bwd.shape[0]
+    dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy_nhwc.device)
+    h.check(h.lib.asr_conv3x3_bwd_data(h.h, _p(dy_nhwc), N, H, W, Cout, _p(wt_bwd), Cin, _p(dx), _s()),
+            'asr_conv3x3_bwd_data')
+    return dx
+
+
+def conv3x3_bwd_weight(x_nhwc, dy_nhwc, dw, accumulate=False):
+    """dw: fp32 [9*Cin, Cout] view of the HWIO gradient."""
+    h = _h(x_nhwc)
+    _chk(x_nhwc, torch.bfloat16, 'x')
+    _chk(dy_nhwc, torch.bfloat16, 'dy')
+    N, H, W, Cin = x_nhwc.shape
+    Cout = dy_nhwc.shape[3]
+    h.check(h.lib.asr_conv3x3_bwd_weight(h.h, _p(x_nhwc), _p(dy_nhwc), N, H, W, Cin, Cout, _p(dw),
+                                         int(accumulate), _s()), 'asr_conv3x3_bwd_weight')
+    return dw
+
+
 def im2col3x3(x_nhwc, ldp=None, out=None):
     h = _h(x_nhwc)
     dt = dtype_id(x_nhwc.dtype)

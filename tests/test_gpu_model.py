@@ -134,6 +134,27 @@ def test_vgg_blstm_ctc_parity(cuda):
         r = ref['grads'][name]
         err = np.abs(g.cpu().numpy() - r).max()
         assert err < 2e-3 * max(np.abs(r).max(), 1e-3) + 1e-7, (name, err, np.abs(r).max())
+    # bf16 operands: the implicit-GEMM convolutions against the im2col + GEMM form (same bf16 operands, so
+    # the two agree far inside bf16 rounding) and, loosely, against the fp64 oracle
+    import os
+    grads = {}
+    for mode in ('1', '0'):
+        os.environ['ASR_VGG_IMPLICIT'] = mode
+        try:
+            m3 = CTC(encoder_type='vgg_blstm', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
+                     parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='bf16', seed=4)
+            m3.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+            l3, _ = m3.compute_loss(x, dense, sl, keep_prob=1.0)
+            assert abs(l3.item() - ref['total_loss']) / abs(ref['total_loss']) < 2e-2
+            opt3 = m3._set_optimizer('sgd', 0.1)
+            grads[mode] = {name: g.cpu().numpy().copy() for g, name in opt3.compute_gradients(l3, model=m3)}
+        finally:
+            os.environ.pop('ASR_VGG_IMPLICIT', None)
+    for name, g in grads['1'].items():
+        if 'VGG' in name or 'bridge' in name:
+            r = ref['grads'][name]
+            assert np.abs(g - grads['0'][name]).max() < 1e-2 * np.abs(r).max(), name
+            assert np.abs(g - r).max() < 0.25 * np.abs(r).max(), name
     # dropout path + bf16 operands run and train
     m2 = CTC(encoder_type='vgg_blstm', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
              clip_grad_norm=5.0, clip_activation=50, dtype='bf16', seed=4)

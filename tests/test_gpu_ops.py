@@ -35,6 +35,36 @@ def test_transpose2d(cuda, dtype, shape):
     assert torch.equal(y, x.t().contiguous())
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(5, 7, 5, 64, 64), (3, 40, 11, 64, 128), (70, 6, 3, 128, 128), (2, 1, 1, 64, 64)])
+def test_conv3x3_implicit_gemm(cuda, N, H, W, Cin, Cout):
+    """Implicit-GEMM 3x3 SAME convolution (forward, data gradient, weight gradient) against
+    torch.nn.functional.conv2d in fp64 on the same bf16-rounded operands."""
+    ops = _ops()
+    rng = np.random.RandomState(N + H + Cin)
+    x = torch.tensor(rng.randn(N, H, W, Cin), dtype=torch.bfloat16)
+    w = torch.tensor(rng.randn(3, 3, Cin, Cout) * 0.05, dtype=torch.float32)
+    b = torch.tensor(rng.randn(Cout), dtype=torch.float32)
+    dy = torch.tensor(rng.randn(N, H, W, Cout), dtype=torch.bfloat16)
+    wf, wb = ops.conv3x3_prep_weights(w.to(cuda))
+    wq = wf.float().cpu().view(Cout, 3, 3, Cin).permute(1, 2, 3, 0).double()        # the bf16-rounded weights, HWIO
+    assert torch.equal(wb.cpu(), wq.flip(0, 1).permute(2, 0, 1, 3).reshape(Cin, 9 * Cout).to(torch.bfloat16))
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)                           # NCHW
+    wr = wq.permute(3, 2, 0, 1).clone().requires_grad_(True)                           # OIHW
+    yr = torch.nn.functional.conv2d(xr, wr, b.double(), padding=1)
+    out = ops.conv3x3_fwd(x.to(cuda), wf, b.to(cuda), relu=True)
+    ref = torch.relu(yr).permute(0, 2, 3, 1).detach().numpy()
+    assert np.abs(out.float().cpu().numpy() - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
+    (yr * dy.double().permute(0, 3, 1, 2)).sum().backward()
+    dx = ops.conv3x3_bwd_data(dy.to(cuda), wb)
+    assert _rel(dx.cpu().numpy(), xr.grad.permute(0, 2, 3, 1).numpy()) < 1e-5
+    dw = torch.zeros(9 * Cin, Cout, device=cuda)
+    ops.conv3x3_bwd_weight(x.to(cuda), dy.to(cuda), dw)
+    refw = wr.grad.permute(2, 3, 1, 0).reshape(9 * Cin, Cout).numpy()
+    assert _rel(dw.cpu().numpy(), refw) < 1e-5
+    ops.conv3x3_bwd_weight(x.to(cuda), dy.to(cuda), dw, accumulate=True)
+    assert _rel(dw.cpu().numpy(), 2 * refw) < 1e-5
+
+
 # --------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (130, 70, 45), (1, 62, 512), (257, 1024, 120),
                                    (700, 130, 1000), (16, 16, 4), (3000, 2048, 120), (120, 1024, 5000)])
