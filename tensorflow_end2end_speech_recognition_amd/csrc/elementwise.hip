@@ -346,12 +346,24 @@ extern "C" int asr_dropout_mask(asr_handle* h, float* mask, size_t n, float keep
 extern "C" int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N, int lda, float* out, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ASR_NEED(asr_dtype_ok(dtype) && a && out && M >= 0 && N > 0 && lda >= N, "asr_colsum: bad args");
-  const int RB = (M + COLSUM_ROWS - 1) / COLSUM_ROWS > 0 ? (M + COLSUM_ROWS - 1) / COLSUM_ROWS : 1;
-  if ((size_t)RB * N * sizeof(float) > h->scratch_bytes - ASR_XCH_BYTES) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_colsum: scratch too small");
+  int RB = (M + COLSUM_ROWS - 1) / COLSUM_ROWS > 0 ? (M + COLSUM_ROWS - 1) / COLSUM_ROWS : 1;
+  // partial[RB][N], then (for tall inputs) the partials themselves are reduced 512 rows at a time, ping-pong
+  // inside the scratch, until few enough remain for the one-thread-per-column final pass
+  const size_t need = ((size_t)RB + (size_t)(RB + COLSUM_ROWS - 1) / COLSUM_ROWS + 1) * N * sizeof(float);
+  if (need > h->scratch_bytes - ASR_XCH_BYTES) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_colsum: scratch too small");
   float* partial = (float*)h->scratch;
-  const dim3 grid((N + 63) / 64, RB);
-  if (dtype == ASR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)a, M, N, lda, partial);
-  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, M, N, lda, partial);
+  {
+    const dim3 grid((N + 63) / 64, RB);
+    if (dtype == ASR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)a, M, N, lda, partial);
+    else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, M, N, lda, partial);
+  }
+  float* other = partial + (size_t)RB * N;
+  while (RB > 64) {
+    const int RB2 = (RB + COLSUM_ROWS - 1) / COLSUM_ROWS;
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64, RB2), dim3(256), 0, (hipStream_t)s, partial, RB, N, N, other);
+    float* t = partial; partial = other; other = t;
+    RB = RB2;
+  }
   hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, partial, RB, N, out);
   ASR_CHECK_LAUNCH(h, "asr_colsum");
   return ASR_OK;
