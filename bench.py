@@ -163,6 +163,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     final_loss = float(loss.item())
+    handoff_flags = ops.check_async_errors(local_rank)    # sticky error word of the multi-CU recurrence kernels
 
     tot_frames = torch.tensor([float(frames)], device=dev)
     el = torch.tensor([elapsed], device=dev)
@@ -233,7 +234,8 @@ def main():
                                            1 - args.keep_prob),
                                global_batch=args.batch * world, frames_per_step=total_frames,
                                parallelism='dp%d' % world),
-                   final_loss=final_loss, kernels=ks, roofline=roof, cpu_baseline=cpu)
+                   final_loss=final_loss, cluster_handoff_flags=handoff_flags, kernels=ks, roofline=roof,
+                   cpu_baseline=cpu)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
