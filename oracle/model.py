@@ -62,7 +62,8 @@ def params_from_state_dict(sd, num_layers, ndir=2, dtype=torch.float64, requires
 
 
 def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, cell_clip=0.0,
-                      weight_decay=0.0, drop_masks=None, dtype=torch.float64, temperature=1.0, vgg=None):
+                      weight_decay=0.0, drop_masks=None, dtype=torch.float64, temperature=1.0, vgg=None,
+                      bottleneck=False):
     """Returns dict(total_loss, ctc_losses [B], logits [T,B,C], grads {name: array})."""
     layers = params_from_state_dict(sd, num_layers, ndir, dtype)
     w_out = torch.as_tensor(np.asarray(sd['output/weights'].detach().cpu() if torch.is_tensor(sd['output/weights']) else sd['output/weights']), dtype=dtype).clone().requires_grad_(True)
@@ -84,7 +85,14 @@ def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, 
     else:
         enc, final = olstm.lstm_encoder(x, sl, layers, drop_masks, **kw)
     T, B, E = enc.shape
-    logits = (enc.reshape(T * B, E) @ w_out + b_out).reshape(T, B, -1)
+    head_in = enc.reshape(T * B, E)
+    bn_params = {}
+    if bottleneck:   # models/ctc/ctc.py:201-216: fully_connected(relu) under scope 'bottleneck'
+        for k in ('bottleneck/weights', 'bottleneck/biases'):
+            bn_params[k] = torch.as_tensor(np.asarray(sd[k].detach().cpu() if torch.is_tensor(sd[k]) else sd[k]),
+                                           dtype=dtype).clone().requires_grad_(True)
+        head_in = torch.relu(head_in @ bn_params['bottleneck/weights'] + bn_params['bottleneck/biases'])
+    logits = (head_in @ w_out + b_out).reshape(T, B, -1)
     losses = ctc_loss(logits / temperature, labels_list, seq_len)
     total = losses.mean()
     named = {}
@@ -100,6 +108,7 @@ def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, 
     named['output/weights'] = w_out
     named['output/biases'] = b_out
     named.update(vgg_params)
+    named.update(bn_params)
     if weight_decay > 0:
         l2 = sum(0.5 * (v ** 2).sum() for n, v in named.items() if 'bias' not in n.lower())
         total = total + weight_decay * l2

@@ -92,8 +92,7 @@ class CTC(ModelBase):
         self._dropout_calls = 0
         self.seed = seed
 
-        if bottleneck_dim not in (None, 0):
-            raise NotImplementedError('bottleneck layer is not built on the HIP path yet')
+        self.bottleneck_dim = int(bottleneck_dim) if bottleneck_dim not in (None, 0) else None
 
         if encoder_type in ['blstm', 'lstm']:
             self.encoder = load(encoder_type)(
@@ -114,6 +113,11 @@ class CTC(ModelBase):
         rng = np.random.RandomState(seed)
         self.store = ParamStore(self.device)
         enc_dim = self.encoder.build(self.store, input_size * num_stack * splice, rng)
+        if self.bottleneck_dim:   # ctc.py:201-216: FC(relu) named by its variable scope, then dropout
+            self.store.declare('bottleneck/weights', (enc_dim, self.bottleneck_dim),
+                               truncated_normal(rng, parameter_init, (enc_dim, self.bottleneck_dim)))
+            self.store.declare('bottleneck/biases', (self.bottleneck_dim,), np.zeros(self.bottleneck_dim))
+            enc_dim = self.bottleneck_dim
         self.store.declare('output/weights', (enc_dim, self.num_classes),
                            truncated_normal(rng, parameter_init, (enc_dim, self.num_classes)))
         self.store.declare('output/biases', (self.num_classes,), np.zeros(self.num_classes))
@@ -133,6 +137,19 @@ class CTC(ModelBase):
         T, Bp, E = enc.shape
         x_op = self._enc_operand()
         sh = self.store.shadow(self.dtype)
+        self._bn = None
+        if self.bottleneck_dim:
+            # bottleneck FC + ReLU (+ dropout on the hidden-output connection), ctc.py:201-216
+            h = ops.gemm(x_op.view(T * Bp, E), sh['bottleneck/weights'], bias=self.store['bottleneck/biases'],
+                         relu=True)
+            mask = None
+            hd = h
+            if rng_state is not None:
+                mask = ops.dropout_mask(h.shape, float(keep_prob), rng_state[0] + 11, rng_state[1], enc.device)
+                hd = ops.apply_mask(h, mask)
+            self._bn = dict(x=x_op, h=h, hd=hd, mask=mask)
+            x_op, E = hd.view(T, Bp, self.bottleneck_dim), self.bottleneck_dim
+        self._head_in = x_op
         logits = torch.empty((T, Bp, self.num_classes), dtype=torch.float32, device=enc.device)
         ops.gemm(x_op.view(T * Bp, E), sh['output/weights'], bias=self.store['output/biases'],
                  out=logits.view(T * Bp, self.num_classes))
@@ -204,7 +221,7 @@ class CTC(ModelBase):
         tape, st = self._tape, self.store
         dlogits = tape['dlogits']
         T, Bp, C = dlogits.shape
-        x_op = self._enc_operand()
+        x_op = self._head_in                             # what the output FC consumed
         E = x_op.shape[2]
         sh = st.shadow(self.dtype)
         dl2d = dlogits.view(T * Bp, C)
@@ -213,6 +230,16 @@ class CTC(ModelBase):
         with ops.side_lane(dlogits.device, keep=(x_op, dl_op, dl2d)):   # joined by encoder.backward
             ops.gemm(x_op.view(T * Bp, E), dl_op, transA=True, out=st.g('output/weights'))
             ops.colsum(dl2d, out=st.g('output/biases'))
+        if self._bn is not None:
+            bn = self._bn
+            dpre = ops.relu_bwd(denc, bn['h'], bn['mask'])                  # operand dtype
+            xe = bn['x']
+            Ee = xe.shape[2]
+            ops.gemm(xe.view(T * Bp, Ee), dpre, transA=True, out=st.g('bottleneck/weights'))
+            ops.colsum(dpre, out=st.g('bottleneck/biases'))
+            denc = ops.gemm(dpre, sh['bottleneck/weights'], transB=True, out_dtype=ASR_F32)
+            E = Ee
+            self._bn = None
         self.encoder.backward(denc.view(T, Bp, E))
         if self.weight_decay > 0:
             ops.weight_decay(st.grad, st.flat, st.plan, st.decay_mask, self.weight_decay)
