@@ -47,6 +47,9 @@ def attention_step(p, att_type, enc_bt, keys, s, seq_len, sharpening=1.0):
         energy = (enc_bt @ s.unsqueeze(2)).squeeze(2)
     elif att_type == 'luong_general':
         energy = (keys @ s.unsqueeze(2)).squeeze(2)
+    elif att_type == 'luong_concat':      # attention_layer.py:314-345, as written there: FC over the concatenation
+        cat = torch.cat([enc_bt, s.unsqueeze(1).expand(B, T, s.shape[1])], 2)
+        energy = (p['v_a'] * torch.tanh(cat @ p['W_concat/weights'])).sum(2)
     else:
         raise NotImplementedError(att_type)
     mask = (torch.arange(T).unsqueeze(0) < seq_len.unsqueeze(1)).to(enc_bt.dtype)

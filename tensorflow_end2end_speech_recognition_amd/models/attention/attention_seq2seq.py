@@ -129,7 +129,9 @@ class AttentionSeq2Seq(ModelBase):
         if at == 'luong_dot' and E2 != U:
             raise ValueError('encoder_num_units and decoder_num_units must be the same size.')
         self.key_dim = {'luong_dot': E2, 'luong_general': U}.get(at, A)
-        if at in AL.HAS_QUERY_FC:
+        if at == 'luong_concat':
+            st.declare(AT + 'W_concat/weights', (E2 + U, A), tn(E2 + U, A))
+        elif at in AL.HAS_QUERY_FC:
             st.declare(AT + 'W_query/weights', (U, A), tn(U, A))
         if at in AL.HAS_KEYS_FC:
             st.declare(AT + 'W_keys/weights', (E2, self.key_dim), tn(E2, self.key_dim))
@@ -169,6 +171,21 @@ class AttentionSeq2Seq(ModelBase):
         return torch.stack([st[D + 'lstm_cell/w_i_diag'], st[D + 'lstm_cell/w_f_diag'],
                             st[D + 'lstm_cell/w_o_diag']]).contiguous()
 
+    # key / query projection matrices (and their gradient views); luong_concat slices W_concat
+    def _wk(self, grad=False):
+        st = self.store
+        get = st.g if grad else st.__getitem__
+        if self.attention_type == 'luong_concat':
+            return get(AT + 'W_concat/weights')[:2 * self.encoder_num_units]
+        return get(AT + 'W_keys/weights')
+
+    def _wq(self, grad=False):
+        st = self.store
+        get = st.g if grad else st.__getitem__
+        if self.attention_type == 'luong_concat':
+            return get(AT + 'W_concat/weights')[2 * self.encoder_num_units:]
+        return get(AT + 'W_query/weights')
+
     def _encode(self, inputs, inputs_seq_len, keep_prob_encoder, is_training):
         rs = None
         if is_training and float(keep_prob_encoder) < 1.0:
@@ -184,7 +201,7 @@ class AttentionSeq2Seq(ModelBase):
         T, Bp, E2 = enc.shape
         if at in AL.USES_KEYS:
             b = st[AT + 'W_keys/biases'] if (AT + 'W_keys/biases') in st.views else None
-            return ops.gemm(enc.view(T * Bp, E2), st[AT + 'W_keys/weights'], bias=b).view(T, Bp, self.key_dim)
+            return ops.gemm(enc.view(T * Bp, E2), self._wk(), bias=b).view(T, Bp, self.key_dim)
         if at == 'luong_dot':
             return enc
         return None                                          # 'location': keys unused (Q6)
@@ -193,7 +210,7 @@ class AttentionSeq2Seq(ModelBase):
         st, at = self.store, self.attention_type
         if at in AL.HAS_QUERY_FC:
             b = st[AT + 'W_filter/biases'] if at in AL.HAS_FILTER else None
-            return ops.gemm(s, st[AT + 'W_query/weights'], bias=b)
+            return ops.gemm(s, self._wq(), bias=b)
         return s                                             # luong_*: the decoder state itself
 
     def _bridge(self, final_c, final_h, B):
@@ -364,7 +381,7 @@ class AttentionSeq2Seq(ModelBase):
                 dv_all[k].copy_(dv_rows)
             dcell = dav_in[k, :, :U].contiguous()
             if at in AL.HAS_QUERY_FC:
-                ops.gemm(dqz, st[AT + 'W_query/weights'], transB=True, out=dcell, accumulate=True)
+                ops.gemm(dqz, self._wq(), transB=True, out=dcell, accumulate=True)
             else:
                 dcell = dcell + dqz
             if s['dmask'] is not None:
@@ -397,17 +414,17 @@ class AttentionSeq2Seq(ModelBase):
             st.g(D + 'lstm_cell/w_o_diag').copy_(dp[2 * U:])
         dq2d = dqz_all.view(To * Bp, -1)
         if at in AL.HAS_QUERY_FC:
-            ops.gemm(cell_out_all.reshape(To * Bp, U), dq2d, transA=True, out=st.g(AT + 'W_query/weights'))
+            ops.gemm(cell_out_all.reshape(To * Bp, U), dq2d, transA=True, out=self._wq(grad=True))
         if at in AL.HAS_FILTER:
             ops.colsum(dq2d, out=st.g(AT + 'W_filter/biases'))
         if self.att_mode == 0:
             ops.colsum(dv_all.view(To * Bp, -1), out=st.g(AT + 'v_a'))
         if at in AL.USES_KEYS:
             dk2d = dkeys.view(T * Bp, -1)
-            ops.gemm(enc.view(T * Bp, E2), dk2d, transA=True, out=st.g(AT + 'W_keys/weights'))
+            ops.gemm(enc.view(T * Bp, E2), dk2d, transA=True, out=self._wk(grad=True))
             if (AT + 'W_keys/biases') in st.views:
                 ops.colsum(dk2d, out=st.g(AT + 'W_keys/biases'))
-            ops.gemm(dk2d, st[AT + 'W_keys/weights'], transB=True, out=denc.view(T * Bp, E2), accumulate=True)
+            ops.gemm(dk2d, self._wk(), transB=True, out=denc.view(T * Bp, E2), accumulate=True)
         # embedding
         if tp['emb_mask'] is not None:
             demb_all = ops.apply_mask(demb_all, tp['emb_mask'])

@@ -8,11 +8,13 @@ ATTENTION_TYPE = [
     'luong_dot', 'scaled_luong_dot', 'luong_general', 'luong_concat',
     'baidu_attetion']
 
-ADDITIVE = ('bahdanau_content', 'location', 'hybrid')      # energy = sum_a v_a tanh(.)
+ADDITIVE = ('bahdanau_content', 'location', 'hybrid', 'luong_concat')      # energy = sum_a v_a tanh(.)
 DOT = ('dot_product', 'luong_dot', 'luong_general')        # energy = keys . query
 HAS_KEYS_FC = ('bahdanau_content', 'location', 'hybrid', 'dot_product', 'luong_general')
-USES_KEYS = ('bahdanau_content', 'hybrid', 'dot_product', 'luong_general')
-HAS_QUERY_FC = ('bahdanau_content', 'location', 'hybrid', 'dot_product')
+USES_KEYS = ('bahdanau_content', 'hybrid', 'dot_product', 'luong_general', 'luong_concat')
+HAS_QUERY_FC = ('bahdanau_content', 'location', 'hybrid', 'dot_product', 'luong_concat')
+# luong_concat (:314-345): ONE bias-free FC W_concat over [h_enc; h_dec]; its first 2H rows act as the key
+# projection and its last U rows as the query projection (tanh(W [a;b]) == tanh(W_a a + W_b b))
 HAS_FILTER = ('location', 'hybrid')
 
 
@@ -23,5 +25,3 @@ def check_attention_type(attention_type):
             (", ".join(ATTENTION_TYPE), attention_type))
     if attention_type in ('normed_bahdanau_content', 'scaled_luong_dot', 'baidu_attetion'):
         raise NotImplementedError      # as the reference (:188-189, :267-268, :287-288)
-    if attention_type == 'luong_concat':
-        raise NotImplementedError('luong_concat is not built on the HIP path yet')

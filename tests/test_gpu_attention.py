@@ -37,7 +37,8 @@ def _mk(cls, att, D, H, L, U, A, Em, C, **kw):
                clip_activation_encoder=50, clip_activation_decoder=50, dtype='f32', seed=5, **kw)
 
 
-@pytest.mark.parametrize('att', ['bahdanau_content', 'location', 'hybrid', 'dot_product', 'luong_dot', 'luong_general'])
+@pytest.mark.parametrize('att', ['bahdanau_content', 'location', 'hybrid', 'dot_product', 'luong_dot', 'luong_general',
+                                 'luong_concat'])
 def test_attention_model_parity(cuda, att):
     from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
     rng = np.random.RandomState(11)
