@@ -98,7 +98,7 @@ def main():
     ap.add_argument('--tmax', type=int, default=778)
     ap.add_argument('--keep-prob', type=float, default=0.8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=1)
+    ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=16)
     ap.add_argument('--cpu-tmax', type=int, default=256,
                     help='CPU baseline sample: the same batch truncated to its first N frames')
