@@ -87,7 +87,9 @@ class LSTMLayer(object):
                 mask = ops.dropout_mask((T, B, ndir * H), keep_prob, seed, offset, device)
             else:
                 mask = drop_mask
-        return dict(whf=whf, whb=whb, wxT=wxT, bias=bias, wx_il=wx_il, peep=self._peep(), mask=mask)
+        # [Din, ndir*4H]: dx = dG [T*B, ndir*4H] . wx_cat^T is then ONE GEMM over both directions
+        wx_cat = torch.cat(wx_il, dim=1) if ndir > 1 else wx_il[0]
+        return dict(whf=whf, whb=whb, wxT=wxT, bias=bias, wx_cat=wx_cat, peep=self._peep(), mask=mask)
 
     def forward(self, x, seq_len, dtype, keep_prob=1.0, is_training=True, rng_state=None,
                 drop_mask=None, save=True, prep=None):
@@ -108,7 +110,7 @@ class LSTMLayer(object):
             out = ops.apply_mask(hout, mask)
         if save:
             self.ctx = dict(x=x, gates=gates, cs=cs, hout=hout, whb=prep['whb'], peep=prep['peep'],
-                            seq_len=seq_len, dtype=dtype, mask=mask, wx_il=prep['wx_il'])
+                            seq_len=seq_len, dtype=dtype, mask=mask, wx_cat=prep['wx_cat'])
         return out, (cf, hf)
 
     def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True):
@@ -129,9 +131,7 @@ class LSTMLayer(object):
         dg2d = dgates.view(T * B, ndir * 4 * H)
         dx = torch.empty((T, B, din), dtype=torch.float32, device=x.device) if need_dx else None
         if need_dx:   # the only result the layer below waits for: main stream, first
-            for d in range(ndir):
-                ops.gemm(dg2d[:, d * 4 * H:(d + 1) * 4 * H], c['wx_il'][d], transB=True,
-                         out=dx.view(T * B, din), accumulate=(d > 0))
+            ops.gemm(dg2d, c['wx_cat'], transB=True, out=dx.view(T * B, din))
         # weight gradients: side stream, concurrent with the BPTT kernel of the layer below
         # (joined in the model's backward before clipping)
         dw_il = torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols
