@@ -1058,6 +1058,9 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
         for (int i = 0; i < 4; ++i) o[i] = __uint_as_float((__float_as_uint(a[i]) & ~1u) | tag);
         return o;
       };
+      // the tiles other CUs wait for go first; while they issue, this wave outranks its SIMD sibling's
+      // own-tile MFMAs (nobody waits for those before the next step's gate math)
+      __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         if (i < NF - 1 || last_f) {                        // wave-uniform
@@ -1067,6 +1070,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
           xstore16(uslot(P, nt_f[i] >> 2, g, nt_f[i] & 3), voff16, tagged(af), fast);
         }
       }
+      __builtin_amdgcn_s_setprio(0);
       f32x4_t ao = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wo[kc], ao, 0, 0, 0);
