@@ -27,7 +27,7 @@ for d in range(2):
         print('  wave %2d: ' % w + '  '.join('%s %.0f' % (n, a[d, w, k] / max(steps, 1)) for k, n in enumerate(names)),
               ' total/step %.0f' % (a[d, w, :5].sum() / max(steps, 1)))
 
-if H == 256:
+if H in (256, 512):
     buf2 = (ctypes.c_ulonglong * 1280)()
     lib.asr_debug_cluster_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
     if lib.asr_debug_cluster_cycles(buf2, 1280) == 0:

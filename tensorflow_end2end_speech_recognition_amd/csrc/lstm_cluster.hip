@@ -899,21 +899,35 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
   // W_h^T fragments: own tile (4g + wt) and this wave's foreign tiles f = wave, 8 + wave, ...
   // foreign index f in [0, 4(G-1)): destination CU = (f >> 2) skipping g, tile inside it = f & 3
   constexpr int NFT = 4 * (G - 1);                         // foreign tiles per CU (12 / 28)
-  constexpr int NF = (NFT + 7) / 8;                        // per wave: waves < NFT - 8(NF-1) carry NF, the rest NF-1
+  // G = 4: every wave also computes its own-unit tile (both row-half waves redundantly: no hand-over, one
+  //        barrier per step) next to NF = 2 / 1 foreign tiles.
+  // G = 8: that would be 5 tiles x 32 fragment registers per wave and spills (measured: 8 k of the 10 k
+  //        cycles per step); instead the 4 own + 28 foreign tiles are dealt 4 per wave, the own tile is
+  //        computed once by the hh = 0 wave, which hands rows 2,3 to its hh = 1 partner through LDS (a
+  //        second barrier per step, cheap next to 32 MFMAs per wave).
+  constexpr bool OWN_ONCE = (G == 8);
+  constexpr int NF = OWN_ONCE ? 4 : (NFT + 7) / 8;         // fragment sets per wave (last one: see below)
   auto ftile = [&](int f) { const int q = f >> 2; return ((q + (q >= g ? 1 : 0)) << 2) | (f & 3); };
   const int nt_own = g * 4 + wt;
-  const bool last_f = wave < NFT - 8 * (NF - 1);           // does this wave carry the NF-th foreign tile?
+  // OWN_ONCE: slot NF-1 is the own tile on hh = 0 waves and foreign tile 24 + wt on hh = 1 waves
+  const bool last_f = OWN_ONCE ? (hh == 1) : (wave < NFT - 8 * (NF - 1));
   int nt_f[NF];
 #pragma unroll
-  for (int i = 0; i < NF; ++i) nt_f[i] = ftile((i < NF - 1 || last_f) ? wave + 8 * i : wave);
-  bf16x8_t wo[KC], wf[NF][KC];
+  for (int i = 0; i < NF; ++i) {
+    if (OWN_ONCE) nt_f[i] = (i < NF - 1) ? ftile(wave + 8 * i) : (hh == 1 ? ftile(24 + wt) : nt_own);
+    else nt_f[i] = ftile((i < NF - 1 || last_f) ? wave + 8 * i : wave);
+  }
+  bf16x8_t wo[OWN_ONCE ? 1 : KC], wf[NF][KC];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    wo[kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_own * KSF + g * KC + kc) * 64 + lane) * 8);
+    if (!OWN_ONCE)
+      wo[kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_own * KSF + g * KC + kc) * 64 + lane) * 8);
 #pragma unroll
     for (int i = 0; i < NF; ++i)
       wf[i][kc] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)nt_f[i] * KSF + g * KC + kc) * 64 + lane) * 8);
   }
+  // OWN_ONCE hand-over buffer behind the two dG images: [2 parity][4 tiles][64 lanes] x (row 2, row 3)
+  float* ownx = reinterpret_cast<float*>(smem + 2 * DGB);
 
   u64* xhdr = xch + (size_t)cid.c * CL_U64;
   bool timed_out = false;
@@ -1063,7 +1077,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
       __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
-        if (i < NF - 1 || last_f) {                        // wave-uniform
+        if (OWN_ONCE ? (i < NF - 1 || last_f) : (i < NF - 1 || last_f)) {      // wave-uniform: a foreign tile
           f32x4_t af = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kc = 0; kc < KC; ++kc) af = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[i][kc], af, 0, 0, 0);
@@ -1071,11 +1085,32 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
         }
       }
       __builtin_amdgcn_s_setprio(0);
-      f32x4_t ao = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (OWN_ONCE) {
+        if (hh == 0) {                                     // own tile, once: rows 0,1 stay, rows 2,3 -> partner
+          f32x4_t ao = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wo[kc], ao, 0, 0, 0);
-      dhr[0] += hh ? ao[2] : ao[0];
-      dhr[1] += hh ? ao[3] : ao[1];
+          for (int kc = 0; kc < KC; ++kc) ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[NF - 1][kc], ao, 0, 0, 0);
+          dhr[0] += ao[0];
+          dhr[1] += ao[1];
+          float* o = ownx + ((P * 4 + wt) * 64 + lane) * 2;
+          o[0] = ao[2];
+          o[1] = ao[3];
+        }
+      } else {
+        f32x4_t ao = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wo[kc], ao, 0, 0, 0);
+        dhr[0] += hh ? ao[2] : ao[0];
+        dhr[1] += hh ? ao[3] : ao[1];
+      }
+    }
+    if constexpr (OWN_ONCE) {
+      __syncthreads();                                     // hand-over visible before the partner's next step
+      if (s > 0 && hh == 1) {
+        const float* o = ownx + ((P * 4 + wt) * 64 + lane) * 2;
+        dhr[0] += o[0];
+        dhr[1] += o[1];
+      }
     }
     const unsigned long long t3 = C8_T();
     if (DBG) { ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; }
@@ -1215,8 +1250,8 @@ bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
     char* base5 = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
     (void)hipMemsetAsync(base5 + 256, 0, need5, st);
     auto k5 = g_cdbg_host ? lstm_bwd_cluster8_kernel<H5, true> : lstm_bwd_cluster8_kernel<H5, false>;
-    hipLaunchKernelGGL(k5, dim3(cluster_grid(G5, ncl)), dim3(CT8), (size_t)2 * 16 * (4 * HS + 8) * 2, st, T, B, ndir,
-                       dhout, (const cbf16x4_t*)gates, cs, (const bf16_t*)whpb, peep, seq_len, dcf, dhf,
+    hipLaunchKernelGGL(k5, dim3(cluster_grid(G5, ncl)), dim3(CT8), (size_t)2 * 16 * (4 * HS + 8) * 2 + 2 * 4 * 64 * 8, st, T,
+                       B, ndir, dhout, (const cbf16x4_t*)gates, cs, (const bf16_t*)whpb, peep, seq_len, dcf, dhf,
                        (cbf16x4_t*)dgates, dpeep_part, (u64*)(base5 + 256), (unsigned*)base5,
                        (dbg_flags() & 16) ? 1 : 0);
     return true;
