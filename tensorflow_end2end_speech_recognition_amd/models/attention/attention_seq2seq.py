@@ -264,8 +264,12 @@ class AttentionSeq2Seq(ModelBase):
         saved = []
         alpha_all = torch.empty((To, Bp, T), dtype=torch.float32, device=dev)   # one slab: d_enc GEMMs read it strided
         use_ddrop = is_training and float(keep_prob_decoder) < 1.0
+        dec_in[:, :, :Em].copy_(emb.view(To, Bp, Em))          # the embedded inputs of all steps at once
+        dmask_all = None
+        if use_ddrop:                                            # one launch for the masks of every step
+            self._calls += 1
+            dmask_all = ops.dropout_mask((To, Bp, U), keep_prob_decoder, self.seed + 2, self._calls << 40, dev)
         for k in range(To):
-            dec_in[k, :, :Em].copy_(emb[k])
             dec_in[k, :, Em:Em + E2].copy_(ctx)
             dec_in[k, :, Em + E2:].copy_(h)
             pre = ops.gemm(dec_in[k], W_cell, bias=b_cell)
@@ -273,8 +277,7 @@ class AttentionSeq2Seq(ModelBase):
                                                                   self.clip_activation_decoder or 0.0)
             cell_out, dmask = h_raw, None
             if use_ddrop:
-                self._calls += 1
-                dmask = ops.dropout_mask(h_raw.shape, keep_prob_decoder, self.seed + 2, self._calls << 40, dev)
+                dmask = dmask_all[k]
                 cell_out = ops.apply_mask(h_raw, dmask)
             qz = self._query(cell_out)
             energy = ops.att_energy_fwd(keys, qz, v, T, self.att_mode)
