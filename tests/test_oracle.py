@@ -152,6 +152,55 @@ def test_ctc_model_gradient_finite_difference():
         assert abs(fd - r['grads'][k][idx]) < 1e-5 * max(1, abs(fd)), k
 
 
+def test_ctc_model_bottleneck_gradient_finite_difference():
+    """bottleneck FC + ReLU (models/ctc/ctc.py:201-216) in the oracle: analytic vs finite differences."""
+    rng = np.random.RandomState(1)
+    B, T, D, H, C, BN = 2, 6, 5, 3, 4, 7
+    sd = {}
+    for d in ('fw', 'bw'):
+        p = olstm.init_lstm_params(rng, D, H, init=0.3)
+        base = 'blstm_hidden1/%s/lstm_cell' % d
+        sd[base + '/kernel'], sd[base + '/bias'] = p['w'].numpy(), p['b'].numpy()
+        sd[base + '/w_i_diag'], sd[base + '/w_f_diag'], sd[base + '/w_o_diag'] = \
+            p['wci'].numpy(), p['wcf'].numpy(), p['wco'].numpy()
+    sd['bottleneck/weights'] = rng.randn(2 * H, BN) * .5
+    sd['bottleneck/biases'] = rng.randn(BN) * .1
+    sd['output/weights'] = rng.randn(BN, C) * .3
+    sd['output/biases'] = np.zeros(C)
+    x, sl, labs = rng.randn(B, T, D), np.array([6, 4]), [[0, 1], [2]]
+    r = omodel.ctc_model_forward(sd, x, labs, sl, 1, bottleneck=True)
+    assert r['logits'].shape == (T, B, C)
+    for k, idx in [('bottleneck/weights', (2, 3)), ('bottleneck/biases', (1,)), ('output/weights', (4, 2)),
+                   ('blstm_hidden1/fw/lstm_cell/kernel', (0, 1))]:
+        eps = 1e-6
+        sd2 = {a: np.array(b, dtype=np.float64).copy() for a, b in sd.items()}
+        sd2[k][idx] += eps
+        fd = (omodel.ctc_model_forward(sd2, x, labs, sl, 1, bottleneck=True)['total_loss'] - r['total_loss']) / eps
+        assert abs(fd - r['grads'][k][idx]) < 1e-5 * max(1, abs(fd)), k
+
+
+def test_luong_concat_energy_is_the_fc_over_the_concatenation():
+    """attention_layer.py:314-345: energy = v_a . tanh(W_concat [h_enc; h_dec]); the device path runs it as
+    the key half and the query half of W_concat -- check the oracle states the reference form and that the
+    two forms agree."""
+    import torch
+    from oracle import attention as oatt
+    rng = np.random.RandomState(2)
+    B, T, E2, U, A = 3, 5, 6, 4, 7
+    enc = torch.tensor(rng.randn(B, T, E2))
+    s = torch.tensor(rng.randn(B, U))
+    p = {'W_concat/weights': torch.tensor(rng.randn(E2 + U, A)), 'v_a': torch.tensor(rng.randn(A))}
+    sl = torch.tensor([5, 3, 4])
+    alpha, ctx = oatt.attention_step(p, 'luong_concat', enc, None, s, sl)
+    W = p['W_concat/weights']
+    e = (p['v_a'] * torch.tanh(enc @ W[:E2] + (s @ W[E2:]).unsqueeze(1))).sum(2)
+    mask = (torch.arange(T).unsqueeze(0) < sl.unsqueeze(1))
+    ref = torch.softmax(torch.where(mask, e, torch.tensor(float(np.finfo(np.float32).min), dtype=e.dtype)), dim=1)
+    assert torch.allclose(alpha, ref, atol=1e-12)
+    assert torch.allclose(ctx, (ref.unsqueeze(2) * enc).sum(1), atol=1e-12)
+    assert float(alpha[1, 3:].abs().max()) == 0.0          # masked frames get exactly zero weight
+
+
 def test_optimizers_against_torch():
     rng = np.random.RandomState(0)
     p0 = rng.randn(50)
