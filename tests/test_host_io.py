@@ -3,6 +3,7 @@ golden vectors produced by the reference's own functions (tests/golden/make_gold
 import os
 
 import numpy as np
+import pytest
 
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
@@ -62,3 +63,45 @@ def test_lr_controller():
         lr = c.decay_lr(lr, ep, v)
         got.append(lr)
     assert got == [1e-3, 1e-3, 1e-3, 5e-4, 5e-4, 5e-4, 2.5e-4]
+
+
+def test_saver_roundtrip(tmp_path):
+    """Saver.save / get_checkpoint_state / restore with the recipes' call shape (train_ctc.py:220-223,
+    eval_ctc.py:74-86): TF variable names, `model.ckpt-<epoch>` prefixes, `checkpoint` index file."""
+    import torch
+    from tensorflow_end2end_speech_recognition_amd.utils.parameter import ParamStore
+    from tensorflow_end2end_speech_recognition_amd.models.model_base import Optimizer
+    from tensorflow_end2end_speech_recognition_amd.utils.training.checkpoint import Saver, get_checkpoint_state
+
+    class M(object):
+        pass
+    rng = np.random.RandomState(0)
+    m = M()
+    m.store = ParamStore(torch.device('cpu'))
+    m.store.declare('blstm_hidden1/fw/lstm_cell/kernel', (7, 12), rng.randn(7, 12))
+    m.store.declare('output/biases', (5,), rng.randn(5))
+    m.store.finalize()
+    m.optimizer = Optimizer('adam', 1e-3, m.store)
+    m.optimizer.slot0.normal_()
+    m.optimizer.global_step = 17
+    assert get_checkpoint_state(str(tmp_path)) is None
+    saver = Saver(max_to_keep=None)
+    p1 = saver.save(m, os.path.join(str(tmp_path), 'model.ckpt'), global_step=3)
+    assert p1.endswith('model.ckpt-3') and os.path.isfile(p1 + '.npz')
+    want = {k: v.clone() for k, v in m.store.state_dict().items()}
+    slot = m.optimizer.slot0.clone()
+    m.store.flat.zero_()
+    m.optimizer.slot0.zero_()
+    m.optimizer.global_step = 0
+    saver.save(m, os.path.join(str(tmp_path), 'model.ckpt'), global_step=4)
+    ck = get_checkpoint_state(str(tmp_path))
+    assert ck.model_checkpoint_path.endswith('model.ckpt-4') and len(ck.all_model_checkpoint_paths) == 2
+    best = '/'.join(ck.model_checkpoint_path.split('/')[:-1]) + '/model.ckpt-' + str(3)     # eval_ctc.py:84-85
+    saver.restore(m, best)
+    for k, v in want.items():
+        assert torch.equal(m.store[k], v)
+    assert torch.equal(m.optimizer.slot0, slot) and m.optimizer.global_step == 17
+    with np.load(best + '.npz') as z:
+        assert z['blstm_hidden1/fw/lstm_cell/kernel'].shape == (7, 12)
+    with pytest.raises(ValueError):
+        saver.restore(m, os.path.join(str(tmp_path), 'model.ckpt-9'))
