@@ -197,3 +197,24 @@ def test_vgg_blstm_ctc_parity(cuda):
         m2.train(l, 'adam', 2e-3)
         l0 = l.item() if l0 is None else l0
     assert l.item() < 0.8 * l0
+
+
+def test_end_to_end_recipe_on_synthetic_corpus(cuda, tmp_path):
+    """examples/synthetic/train_ctc.py: dataset iterator -> compute_loss/train -> decoder/compute_ler -> LR
+    controller -> Saver, i.e. the call sequence of the reference's train_ctc.py, learns the synthetic corpus and
+    its best checkpoint restores into a fresh model."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('synth_train_ctc', os.path.join(root, 'examples', 'synthetic', 'train_ctc.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(['--epochs', '5', '--save_path', str(tmp_path), '--units', '256'])
+    hist = out['history']
+    assert len(hist) == 5 and out['best'] < 0.35 and out['best'] < 0.6 * hist[0], hist
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    from tensorflow_end2end_speech_recognition_amd.utils.training.checkpoint import Saver
+    fresh = CTC(encoder_type='blstm', input_size=24, num_units=256, num_layers=2, num_classes=12, clip_grad_norm=5.0,
+                clip_activation=50, dtype='bf16', seed=99)
+    Saver().restore(fresh, out['checkpoint'])
+    assert abs(mod.evaluate(fresh, out['dev']) - out['best']) < 1e-6
