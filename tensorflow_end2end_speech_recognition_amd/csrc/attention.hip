@@ -208,11 +208,23 @@ __global__ __launch_bounds__(256) void att_softmax_kernel(const float* __restric
   for (int t = tid; t < T; t += 256) alpha[(size_t)b * T + t] = al[t] * inv;
 }
 
+// encoder rows are read either as fp32 or from the bf16 operand copy the encoder already keeps (half the bytes
+// of the two per-step streams over [T,B,2H])
+__device__ __forceinline__ f32x4_t enc_ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ f32x4_t enc_ld4(const bf16_t* p) {
+  typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+  const us4_t v = *reinterpret_cast<const us4_t*>(p);
+  return (f32x4_t){bf16_to_f32(v[0]), bf16_to_f32(v[1]), bf16_to_f32(v[2]), bf16_to_f32(v[3])};
+}
+__device__ __forceinline__ float enc_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float enc_ld1(const bf16_t* p) { return bf16_to_f32(*p); }
+
 // partial context of one frame chunk: part[ch][b][E] = sum_{t in chunk, t < len*} alpha[b,t] enc[t,b,:]
 // (len* = len, or T for an all-masked row whose weights are uniform over T zero frames)
+template <typename TE>
 __global__ __launch_bounds__(256) void att_ctx_partial_kernel(const float* __restrict__ alpha,
                                                               const int32_t* __restrict__ seq_len,
-                                                              const float* __restrict__ enc, int T, int B,
+                                                              const TE* __restrict__ enc, int T, int B,
                                                               int E, float* __restrict__ part) {
   __shared__ float al[ATT_CH];
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -226,10 +238,10 @@ __global__ __launch_bounds__(256) void att_ctx_partial_kernel(const float* __res
   const size_t rs = (size_t)B * E;
   if ((E & 3) == 0) {
     for (int e4 = tid; e4 < E / 4; e4 += 256) {
-      const float* p = enc + ((size_t)t0 * B + b) * E + e4 * 4;
+      const TE* p = enc + ((size_t)t0 * B + b) * E + e4 * 4;
       f32x4_t c = {0.f, 0.f, 0.f, 0.f};
       for (int i = 0; i < n; ++i) {
-        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(p + i * rs);
+        const f32x4_t x = enc_ld4(p + i * rs);
         const float w = al[i];
         c[0] += w * x[0]; c[1] += w * x[1]; c[2] += w * x[2]; c[3] += w * x[3];
       }
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void att_ctx_partial_kernel(const float* __res
   } else {
     for (int e0 = tid; e0 < E; e0 += 256) {
       float c = 0.f;
-      for (int i = 0; i < n; ++i) c += al[i] * enc[((size_t)(t0 + i) * B + b) * E + e0];
+      for (int i = 0; i < n; ++i) c += al[i] * enc_ld1(enc + ((size_t)(t0 + i) * B + b) * E + e0);
       o[e0] = c;
     }
   }
@@ -252,25 +264,26 @@ __global__ void att_ctx_reduce_kernel(const float* __restrict__ part, int nch, i
 }
 
 // dalpha[b,t] = enc[t,b,:] . dctx[b,:]  for t < len (one wave per frame, float4 lanes)
+template <typename TE>
 __global__ __launch_bounds__(256) void att_dalpha_kernel(const float* __restrict__ dctx,
                                                          const int32_t* __restrict__ seq_len,
-                                                         const float* __restrict__ enc, int T, int B, int E,
+                                                         const TE* __restrict__ enc, int T, int B, int E,
                                                          float* __restrict__ da) {
   const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int len = min(max(seq_len[b], 0), T);
   const int t0 = blockIdx.x * ATT_CH, t1 = min(len, t0 + ATT_CH);
   const float* dc = dctx + (size_t)b * E;
   for (int t = t0 + wave; t < t1; t += 4) {
-    const float* er = enc + ((size_t)t * B + b) * E;
+    const TE* er = enc + ((size_t)t * B + b) * E;
     float s = 0.f;
     if ((E & 3) == 0) {
       for (int e4 = lane; e4 < E / 4; e4 += 64) {
-        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(er + e4 * 4);
+        const f32x4_t x = enc_ld4(er + e4 * 4);
         const f32x4_t d = *reinterpret_cast<const f32x4_t*>(dc + e4 * 4);
         s += x[0] * d[0] + x[1] * d[1] + x[2] * d[2] + x[3] * d[3];
       }
     } else {
-      for (int e0 = lane; e0 < E; e0 += 64) s += er[e0] * dc[e0];
+      for (int e0 = lane; e0 < E; e0 += 64) s += enc_ld1(er + e0) * dc[e0];
     }
     s = wave_reduce_sum(s);
     if (lane == 0) da[(size_t)b * T + t] = s;
@@ -468,18 +481,23 @@ extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const flo
 }
 
 extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* seq_len,
-                                       float sharpening, const float* enc, int T, int B, int E, float* alpha,
-                                       float* ctx, asr_stream s) {
+                                       float sharpening, const void* enc, int enc_dtype, int T, int B, int E,
+                                       float* alpha, float* ctx, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
-  ATT_NEED(energy && seq_len && enc && alpha && ctx && T > 0 && B > 0 && E > 0, "asr_att_softmax_ctx_fwd: bad args");
+  ATT_NEED(energy && seq_len && enc && alpha && ctx && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype),
+           "asr_att_softmax_ctx_fwd: bad args");
   const size_t lds = (size_t)T * sizeof(float);
   if (lds > 64 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_softmax_ctx_fwd: T=%d too long", T);
   const int nch = (T + ATT_CH - 1) / ATT_CH;
   float* part = att_scratch(h, (size_t)nch * B * E * sizeof(float));
   if (!part) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_softmax_ctx_fwd: scratch too small");
   hipLaunchKernelGGL(att_softmax_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, energy, seq_len, sharpening, T, alpha);
-  hipLaunchKernelGGL(att_ctx_partial_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)s, alpha, seq_len, enc, T, B, E,
-                     part);
+  if (enc_dtype == ASR_F32)
+    hipLaunchKernelGGL(att_ctx_partial_kernel<float>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, alpha, seq_len,
+                       (const float*)enc, T, B, E, part);
+  else
+    hipLaunchKernelGGL(att_ctx_partial_kernel<bf16_t>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, alpha, seq_len,
+                       (const bf16_t*)enc, T, B, E, part);
   hipLaunchKernelGGL(att_ctx_reduce_kernel, dim3((B * E + 255) / 256), dim3(256), 0, (hipStream_t)s, part, nch, B * E,
                      ctx);
   ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_fwd");
@@ -487,15 +505,20 @@ extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const
 }
 
 extern "C" int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const float* alpha,
-                                       const int32_t* seq_len, float sharpening, const float* enc, int T,
-                                       int B, int E, float* denergy, float* denc, asr_stream s) {
+                                       const int32_t* seq_len, float sharpening, const void* enc, int enc_dtype,
+                                       int T, int B, int E, float* denergy, float* denc, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
-  ATT_NEED(dctx && alpha && seq_len && enc && denergy && T > 0 && B > 0 && E > 0,
+  ATT_NEED(dctx && alpha && seq_len && enc && denergy && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype),
            "asr_att_softmax_ctx_bwd: bad args");
   const int nch = (T + ATT_CH - 1) / ATT_CH;
   float* da = att_scratch(h, (size_t)B * T * sizeof(float));
   if (!da) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_softmax_ctx_bwd: scratch too small");
-  hipLaunchKernelGGL(att_dalpha_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, seq_len, enc, T, B, E, da);
+  if (enc_dtype == ASR_F32)
+    hipLaunchKernelGGL(att_dalpha_kernel<float>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, seq_len,
+                       (const float*)enc, T, B, E, da);
+  else
+    hipLaunchKernelGGL(att_dalpha_kernel<bf16_t>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, seq_len,
+                       (const bf16_t*)enc, T, B, E, da);
   hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, da, alpha, seq_len, sharpening, T,
                      denergy);
   if (denc)   // NULL: the caller accumulates d_enc = sum_steps alpha (x) dctx itself (one GEMM per utterance)

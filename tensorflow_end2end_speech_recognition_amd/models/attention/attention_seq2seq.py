@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from ... import ops
-from ..._lib import ASR_F32
+from ..._lib import ASR_BF16, ASR_F32
 from ...utils.evaluation.edit_distance import compute_ler as _ler
 from ...utils.parameter import ParamStore
 from ..ctc.ctc import Placeholder, truncated_normal
@@ -254,6 +254,9 @@ class AttentionSeq2Seq(ModelBase):
         cf, hf = self.encoder._final_ch
         bi, c, h = self._bridge(cf, hf, B)
         keys = self._keys(enc)
+        # what the per-step context / d-alpha kernels stream: the bf16 operand copy the encoder keeps (same
+        # values as enc, half the bytes) for bf16-operand models, enc itself otherwise
+        enc_att = self.encoder._out_op.contiguous() if self.dtype == ASR_BF16 else enc
         peep = self._peep()
         Din = self.dec_in_dim
         dec_in = torch.empty((To, Bp, Din), dtype=torch.float32, device=dev)
@@ -281,7 +284,8 @@ class AttentionSeq2Seq(ModelBase):
                 cell_out = ops.apply_mask(h_raw, dmask)
             qz = self._query(cell_out)
             energy = ops.att_energy_fwd(keys, qz, v, T, self.att_mode)
-            alpha, ctx_k = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc, alpha_out=alpha_all[k])
+            alpha, ctx_k = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc_att,
+                                                   alpha_out=alpha_all[k])
             av_in[k, :, :U].copy_(cell_out)
             av_in[k, :, U:].copy_(ctx_k)
             saved.append(dict(gates=gates, c_raw=c_raw, c_prev=c, qz=qz, alpha=alpha, dmask=dmask))
@@ -322,7 +326,7 @@ class AttentionSeq2Seq(ModelBase):
         if is_training:
             self._tape = dict(B=B, To=To, enc=enc, seq_p=seq_p, keys=keys, dec_in=dec_in, av_in=av_in, av=av,
                               saved=saved, dlogits=dlogits, ids=ids_d, emb_mask=emb_mask, live=live_d, bi=bi,
-                              peep=peep, ctc=ctc_tape, alpha_all=alpha_all)
+                              peep=peep, ctc=ctc_tape, alpha_all=alpha_all, enc_att=enc_att)
         else:
             self._tape = None
         total._asr_model = self
@@ -376,7 +380,7 @@ class AttentionSeq2Seq(ModelBase):
             torch.add(dav_in[k, :, U:], dctx_in, out=dctx)
             # d_enc += alpha (x) dctx is NOT done per step (a read-modify-write of [T,B,2H] each time):
             # alpha and dctx of all steps are kept and contracted once per utterance below
-            denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, enc, None)
+            denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, tp['enc_att'], None)
             dqz, dv_rows = ops.att_energy_bwd(denergy, keys, s['qz'], v, self.att_mode, dkeys=dkeys,
                                               want_dv=self.att_mode == 0)
             dqz_all[k].copy_(dqz)

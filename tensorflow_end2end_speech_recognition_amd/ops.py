@@ -485,8 +485,9 @@ def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None):
     E = enc.shape[2]
     alpha = alpha_out if alpha_out is not None else _f32((B, T), energy.device)
     ctx = _f32((B, E), energy.device)
-    h.check(h.lib.asr_att_softmax_ctx_fwd(h.h, _p(energy), _p(seq_len), float(sharpening), _p(enc), T, B, E,
-                                          _p(alpha), _p(ctx), _s()), 'asr_att_softmax_ctx_fwd')
+    h.check(h.lib.asr_att_softmax_ctx_fwd(h.h, _p(energy), _p(seq_len), float(sharpening), _p(enc),
+                                          dtype_id(enc.dtype), T, B, E, _p(alpha), _p(ctx), _s()),
+            'asr_att_softmax_ctx_fwd')
     return alpha, ctx
 
 
@@ -496,8 +497,9 @@ def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None):
     B, T = alpha.shape
     E = enc.shape[2]
     denergy = _f32((B, T), dctx.device)
-    h.check(h.lib.asr_att_softmax_ctx_bwd(h.h, _p(dctx), _p(alpha), _p(seq_len), float(sharpening), _p(enc), T, B, E,
-                                          _p(denergy), _p(denc), _s()), 'asr_att_softmax_ctx_bwd')
+    h.check(h.lib.asr_att_softmax_ctx_bwd(h.h, _p(dctx), _p(alpha), _p(seq_len), float(sharpening), _p(enc),
+                                          dtype_id(enc.dtype), T, B, E, _p(denergy), _p(denc), _s()),
+            'asr_att_softmax_ctx_bwd')
     return denergy
 
 

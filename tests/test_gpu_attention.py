@@ -96,3 +96,29 @@ def test_joint_ctc_attention_parity_and_training(cuda):
         first = loss.item() if first is None else first
         last = loss.item()
     assert last < 0.6 * first, (first, last)
+
+
+def test_attention_bf16_operands(cuda):
+    """bf16-operand model (encoder MFMA operands, per-step context / d-alpha streams over the bf16 encoder
+    copy): loss within bf16 rounding of the fp64 oracle, and it trains."""
+    from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
+    rng = np.random.RandomState(8)
+    B, T, D, H, L, U, A, Em, C = 6, 20, 12, 64, 2, 64, 32, 8, 7
+    x, sl, labels, lsl, _ = _batch(rng, B, T, D, C)
+    for att in ('bahdanau_content', 'luong_dot'):
+        kw = dict(input_size=D, encoder_type='blstm', encoder_num_units=H, encoder_num_layers=L, encoder_num_proj=None,
+                  attention_type=att, attention_dim=A, decoder_type='lstm', decoder_num_units=2 * H if att == 'luong_dot' else U,
+                  decoder_num_layers=1, embedding_dim=Em, num_classes=C, sos_index=C, eos_index=C + 1,
+                  max_decode_length=12, parameter_init=0.1, clip_grad_norm=5.0, clip_activation_encoder=50,
+                  clip_activation_decoder=50, seed=5)
+        model = AttentionSeq2Seq(dtype='bf16', **kw)
+        sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+        ref = oatt.attention_model_forward(sd, x, labels, sl, lsl, L, att, clip_enc=50.0, clip_dec=50.0)
+        loss, *_ = model.compute_loss(x, labels, sl, lsl, 1.0, 1.0, 1.0)
+        assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 3e-2, att
+        first = None
+        for step in range(30):
+            loss, *_ = model.compute_loss(x, labels, sl, lsl, 0.9, 0.9, 0.9)
+            model.train(loss, 'adam', 3e-3)
+            first = loss.item() if first is None else first
+        assert loss.item() < 0.7 * first, att
