@@ -26,3 +26,58 @@ def compute_ler(hyps, refs):
         d = levenshtein(h, r)
         vals.append(d / len(r) if len(r) > 0 else (0.0 if d == 0 else float('inf')))
     return float(np.mean(vals)) if vals else 0.0
+
+
+# ---- utils/evaluation/edit_distance.py:35-109: PER / CER / WER on host sequences.  The reference calls
+# python-Levenshtein's `distance` (unit-cost edit distance); `levenshtein` above is that function.
+def compute_per(ref, hyp, normalize=True):
+    """Phone error rate between two lists of phone strings; divided by len(ref) (:35-56)."""
+    per = levenshtein(list(ref), list(hyp))
+    return per / len(ref) if normalize else per
+
+
+def compute_cer(str_pred, str_true, normalize=True):
+    """Character error rate between two strings without spaces; divided by len(str_true) (:59-71)."""
+    cer = levenshtein(list(str_pred), list(str_true))
+    return cer / len(list(str_true)) if normalize else cer
+
+
+def _wer_table(ref, hyp):
+    d = np.zeros((len(ref) + 1, len(hyp) + 1), dtype=np.int64)
+    d[0, :] = np.arange(len(hyp) + 1)
+    d[:, 0] = np.arange(len(ref) + 1)
+    for i in range(1, len(ref) + 1):
+        for j in range(1, len(hyp) + 1):
+            if ref[i - 1] == hyp[j - 1]:
+                d[i, j] = d[i - 1, j - 1]
+            else:
+                d[i, j] = min(d[i - 1, j - 1], d[i, j - 1], d[i - 1, j]) + 1
+    return d
+
+
+def compute_wer(ref, hyp, normalize=True):
+    """Word error rate between two word lists; divided by len(ref) (:74-109)."""
+    wer = _wer_table(ref, hyp)[len(ref), len(hyp)]
+    return wer / len(ref) if normalize else wer
+
+
+def wer_align(ref, hyp):
+    """(substitutions, insertions, deletions) of one optimal alignment, back-traced with the reference's
+    preference order match > insertion > substitution > deletion (:112-280; the aligned print-out is not
+    reproduced)."""
+    d = _wer_table(ref, hyp)
+    x, y = len(ref), len(hyp)
+    sub = ins = dele = 0
+    while x > 0 or y > 0:
+        if x > 0 and y > 0 and d[x, y] == d[x - 1, y - 1] and ref[x - 1] == hyp[y - 1]:
+            x, y = x - 1, y - 1
+        elif y > 0 and d[x, y] == d[x, y - 1] + 1:
+            ins += 1
+            y -= 1
+        elif x > 0 and y > 0 and d[x, y] == d[x - 1, y - 1] + 1:
+            sub += 1
+            x, y = x - 1, y - 1
+        else:
+            dele += 1
+            x -= 1
+    return sub, ins, dele

@@ -15,6 +15,7 @@ Produces
     float64 under both old (value-based) and NEP-50 numpy promotion rules.
   splice_v1.npz   : inputs/outputs of utils/io/inputs/splicing.py do_splice and
       utils/io/inputs/frame_stacking.py stack_frame.
+  labels_v1.json  : outputs of the label maps (utils/io/labels/*.py), Map2phone39 and compute_wer.
 """
 import os
 import sys
@@ -102,8 +103,68 @@ def make_splice():
     print('splice_v1.npz: %d splice + %d stack cases' % (n, m))
 
 
+def make_labels():
+    """Outputs of the reference's label / scoring utilities (utils/io/labels/{phone,character,word}.py,
+    examples/timit/metrics/mapping.py Map2phone39, utils/evaluation/edit_distance.py compute_wer) run on its
+    own mapping files (examples/timit/metrics/mapping_files/*.txt).  Only OUTPUTS are stored.
+    python-Levenshtein and TensorFlow are not installed here, so the module is imported with empty stubs for
+    both and only compute_wer (pure numpy) is recorded."""
+    import json
+    sys.path.insert(0, REF)
+    sys.modules.setdefault('Levenshtein', types.ModuleType('Levenshtein'))
+    sys.modules.setdefault('tensorflow', types.ModuleType('tensorflow'))   # only compute_edit_distance uses it
+    from utils.io.labels.phone import Phone2idx, Idx2phone
+    from utils.io.labels.character import Char2idx, Idx2char
+    from utils.io.labels.word import Idx2word
+    from utils.evaluation.edit_distance import compute_wer
+    sys.path.insert(0, os.path.join(REF, 'examples', 'timit', 'metrics'))
+    from mapping import Map2phone39
+    mf = os.path.join(REF, 'examples', 'timit', 'metrics', 'mapping_files')
+    rng = np.random.RandomState(77)
+    out = {}
+    for lt, n in (('phone61', 61), ('phone48', 48), ('phone39', 39)):
+        i2p = Idx2phone(os.path.join(mf, lt + '.txt'))
+        table = i2p(np.arange(n)).split(' ')
+        out[lt + '_table'] = table                                   # idx -> phone (what the map file says)
+        p2i = Phone2idx(os.path.join(mf, lt + '.txt'))
+        seqs = [rng.randint(0, n, size=rng.randint(1, 15)).tolist() + [-1] * rng.randint(0, 3) for _ in range(6)]
+        out[lt + '_idx2phone'] = [[s_, i2p(np.array(s_))] for s_ in seqs]
+        out[lt + '_phone2idx'] = [[table[i] for i in s_ if i >= 0] for s_ in seqs], \
+            [p2i([table[i] for i in s_ if i >= 0]).tolist() for s_ in seqs]
+        m39 = Map2phone39(lt, os.path.join(mf, 'phone2phone.txt'))
+        out[lt + '_to39_table'] = [[ph, m39([ph])] for ph in table]  # per-phone folding ([] = dropped)
+        out[lt + '_to39_seq'] = [[[table[i] for i in s_ if i >= 0], m39([table[i] for i in s_ if i >= 0])] for s_ in seqs]
+    for name, kw in (('character', {}), ('character_capital_divide', dict(capital_divide=True, space_mark='_'))):
+        path = os.path.join(mf, name + '.txt')
+        rows = [l.strip().split() for l in open(path) if l.strip()]
+        chars = [r[0] for r in rows]
+        out[name + '_table'] = [[r[0], int(r[1])] for r in rows]
+        i2c = Idx2char(path, **kw)
+        seqs = [rng.randint(0, len(chars), size=rng.randint(1, 20)).tolist() + [-1] * rng.randint(0, 3) for _ in range(8)]
+        out[name + '_idx2char'] = [[s_, i2c(np.array(s_))] for s_ in seqs]
+        strs = [''.join(chars[i] for i in s_ if i >= 0) for s_ in seqs]
+        singles = [c for c in chars if len(c) == 1]
+        strs = [''.join(ch for ch in st if ch in singles) or singles[0] for st in strs]
+        c2i = Char2idx(path)
+        out[name + '_char2idx'] = [[st, [int(v) for v in c2i(st)]] for st in strs]
+        if any(len(c) == 2 for c in chars):
+            c2d = Char2idx(path, double_letter=True)
+            out[name + '_char2idx_double'] = [[st, [int(v) for v in c2d(st)]] for st in strs]
+    words = ['w%d' % i for i in range(12)]
+    wl = []
+    for _ in range(12):
+        a = [words[i] for i in rng.randint(0, 12, size=rng.randint(1, 9))]
+        b = [w for w in a if rng.rand() > 0.2] + [words[i] for i in rng.randint(0, 12, size=rng.randint(0, 3))]
+        wl.append([a, b, float(compute_wer(ref=a, hyp=b, normalize=True)), int(compute_wer(ref=a, hyp=b, normalize=False))])
+    out['compute_wer'] = wl
+    with open(os.path.join(HERE, 'labels_v1.json'), 'w') as f:
+        json.dump(out, f)
+    print('labels_v1.json written')
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('needs %s (build container only)' % REF)
     make_decoders()
     make_splice()
+    make_labels()

@@ -105,3 +105,139 @@ def test_saver_roundtrip(tmp_path):
         assert z['blstm_hidden1/fw/lstm_cell/kernel'].shape == (7, 12)
     with pytest.raises(ValueError):
         saver.restore(m, os.path.join(str(tmp_path), 'model.ckpt-9'))
+
+
+def _golden_labels():
+    import json
+    return json.load(open(os.path.join(GOLD, 'labels_v1.json')))
+
+
+def _write_map(path, table):
+    with open(path, 'w') as f:
+        for tok, idx in table:
+            f.write('%s  %d\n' % (tok, idx))
+
+
+def test_label_maps_match_reference_golden(tmp_path):
+    """Phone2idx / Idx2phone / Char2idx / Idx2char (utils/io/labels/*.py) against outputs of the reference's own
+    classes on its mapping files (tests/golden/labels_v1.json)."""
+    from tensorflow_end2end_speech_recognition_amd.utils.io.labels.phone import Phone2idx, Idx2phone
+    from tensorflow_end2end_speech_recognition_amd.utils.io.labels.character import Char2idx, Idx2char
+    g = _golden_labels()
+    for lt in ('phone61', 'phone48', 'phone39'):
+        path = str(tmp_path / (lt + '.txt'))
+        _write_map(path, [(p, i) for i, p in enumerate(g[lt + '_table'])])
+        i2p, p2i = Idx2phone(path), Phone2idx(path)
+        for seq, want in g[lt + '_idx2phone']:
+            assert i2p(np.array(seq)) == want
+        for phones, want in zip(*g[lt + '_phone2idx']):
+            assert p2i(list(phones)).tolist() == want
+    for name, kw in (('character', {}), ('character_capital_divide', dict(capital_divide=True, space_mark='_'))):
+        path = str(tmp_path / (name + '.txt'))
+        _write_map(path, g[name + '_table'])
+        i2c = Idx2char(path, **kw)
+        for seq, want in g[name + '_idx2char']:
+            assert i2c(np.array(seq)) == want
+        c2i = Char2idx(path)
+        for st, want in g[name + '_char2idx']:
+            assert [int(v) for v in c2i(st)] == want
+        if (name + '_char2idx_double') in g:
+            c2d = Char2idx(path, double_letter=True)
+            for st, want in g[name + '_char2idx_double']:
+                assert [int(v) for v in c2d(st)] == want
+
+
+def test_phone_folding_and_error_rates_match_reference_golden():
+    """Map2phone39's built-in Lee & Hon table phone by phone against the reference's class on its
+    phone2phone.txt; compute_wer against the reference's numpy implementation; PER / CER / wer_align
+    consistency with the unit-cost edit distance."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from examples.timit.metrics.mapping import Map2phone39
+    from tensorflow_end2end_speech_recognition_amd.utils.evaluation import edit_distance as ed
+    g = _golden_labels()
+    for lt in ('phone61', 'phone48', 'phone39'):
+        m = Map2phone39(lt)
+        for ph, want in g[lt + '_to39_table']:
+            assert m([ph]) == want, (lt, ph)
+        for seq, want in g[lt + '_to39_seq']:
+            assert m(list(seq)) == want
+    for ref, hyp, wer, dist in g['compute_wer']:
+        assert abs(ed.compute_wer(ref=ref, hyp=hyp, normalize=True) - wer) < 1e-12
+        assert int(ed.compute_wer(ref=ref, hyp=hyp, normalize=False)) == dist == ed.levenshtein(ref, hyp)
+        s, i, d = ed.wer_align(ref, hyp)
+        assert s + i + d == dist and len(ref) - d + i == len(hyp)
+    assert ed.compute_per(['a', 'b', 'c', 'd'], ['a', 'x', 'd'], normalize=True) == 2 / 4
+    assert ed.compute_cer('kitten', 'sitting', normalize=False) == 3
+    assert abs(ed.compute_cer('kitten', 'sitting') - 3 / 7) < 1e-12
+
+
+class _FakeDataset(object):
+    """Two batches of two utterances; yields (data, is_new_epoch) like the reference's DatasetBase."""
+
+    def __init__(self, batches, label_type, padded_value=-1):
+        self.batches, self.label_type, self.padded_value, self.batch_size = batches, label_type, padded_value, 2
+
+    def reset(self):
+        pass
+
+    def __len__(self):
+        return sum(b[0][0].shape[0] for b in self.batches)
+
+    def __iter__(self):
+        for i, b in enumerate(self.batches):
+            yield b, i == len(self.batches) - 1
+
+
+class _FakeModel(object):
+    """Stands in for models.ctc.CTC: the 'logits' are the label rows to return, decoding is the identity."""
+
+    def compute_loss(self, inputs, labels, seq_len, keep_prob=1.0, is_training=False):
+        return None, inputs
+
+    def decoder(self, logits, seq_len, beam_width=1):
+        from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import list2sparsetensor
+        return list2sparsetensor(np.asarray(logits)[:, :, 0].astype(np.int64), padded_value=-1)
+
+
+def test_eval_loops_on_fake_model(tmp_path):
+    """do_eval_per / do_eval_cer (examples/timit/metrics/ctc.py) end to end on CPU with a stand-in model: the
+    index->string maps, 61->39 folding, punctuation stripping and the PER/CER/WER means."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from examples.timit.metrics.ctc import do_eval_per, do_eval_cer
+    from tensorflow_end2end_speech_recognition_amd.utils.evaluation import edit_distance as ed
+    g = _golden_labels()
+    for lt in ('phone61', 'phone39'):
+        _write_map(str(tmp_path / (lt + '.txt')), [(p, i) for i, p in enumerate(g[lt + '_table'])])
+    _write_map(str(tmp_path / 'character.txt'), g['character_table'])
+    t61 = g['phone61_table']
+
+    def rows(*seqs):
+        L = max(len(q) for q in seqs)
+        return np.array([list(q) + [-1] * (L - len(q)) for q in seqs], dtype=np.int32)
+
+    def batch(hyp, true):
+        return ([hyp[:, :, None].astype(np.float32)], [true], [np.full(len(hyp), hyp.shape[1], np.int32)], [None])
+
+    ix = dict((p, i) for i, p in enumerate(t61))
+    # utterance 0: identical; 1: 'ao' vs 'aa' fold to the same phone -> 0; 2: one substitution over 3; 3: closure dropped by folding
+    hyp = [[ix['sil'] if 'sil' in ix else ix['h#'], ix['aa'], ix['b']], [ix['ao'], ix['d']], [ix['iy'], ix['k'], ix['s']],
+           [ix['aa'], ix['q'], ix['t']]]
+    tru = [hyp[0], [ix['aa'], ix['d']], [ix['iy'], ix['g'], ix['s']], [ix['aa'], ix['t']]]
+    ds = _FakeDataset([batch(rows(*hyp[:2]), rows(*tru[:2])), batch(rows(*hyp[2:]), rows(*tru[2:]))], 'phone61')
+    per = do_eval_per(None, None, None, _FakeModel(), ds, 'phone61', map_dir=str(tmp_path))
+    assert abs(per - (0 + 0 + 1 / 3 + 0) / 4) < 1e-12
+    cmap = dict(g['character_table'])
+    enc = lambda st: [cmap[c] for c in st]
+    hyp_s, tru_s = ['the_cat', 'a__dog', "it's_fine", 'one_two'], ['the_cat', 'a_dig', 'its_fine', 'one_too_x']
+    ds = _FakeDataset([batch(rows(*map(enc, hyp_s[:2])), rows(*map(enc, tru_s[:2]))),
+                       batch(rows(*map(enc, hyp_s[2:])), rows(*map(enc, tru_s[2:])))], 'character')
+    cer, wer = do_eval_cer(None, None, _FakeModel(), ds, 'character', map_dir=str(tmp_path))
+    want_cer = (0 + 1 / 4 + 0 + ed.levenshtein('onetwo', 'onetoox') / 7) / 4
+    want_wer = (0 + 1 / 2 + 0 + 2 / 3) / 4
+    assert abs(cer - want_cer) < 1e-12 and abs(wer - want_wer) < 1e-12
