@@ -264,16 +264,19 @@ int asr_att_energy_bwd(asr_handle* h, const float* denergy, const float* keys, c
                        float* dv_rows, asr_stream s);
 /* energy*mask + (1-mask)*float32.min, * sharpening, softmax over t, context = sum_t alpha enc
  * (attention_layer.py:75-111).  alpha[B,T], ctx[B,E].  enc[T,B,E] in `enc_dtype`: a bf16-operand model passes
- * the bf16 copy of the encoder output it already keeps, halving the two per-step streams over enc. */
+ * the bf16 copy of the encoder output it already keeps, halving the two per-step streams over enc.
+ * sigmoid_norm NULL: softmax.  Non-NULL ([B], written): `sigmoid_smoothing` (attention_layer.py:92-96),
+ * alpha = sigmoid(e) / sum_t sigmoid(e), and sigmoid_norm[b] = that sum -- hand it back to the backward. */
 int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* seq_len,
                             float sharpening, const void* enc, int enc_dtype, int T, int B, int E,
-                            float* alpha, float* ctx, asr_stream s);
+                            float* alpha, float* ctx, float* sigmoid_norm, asr_stream s);
 /* denergy[B,T] = ; denc[T,B,E] += alpha * dctx.  denc may be NULL: a decoder loop then keeps alpha and
  * dctx of every step and forms d_enc = sum_steps alpha (x) dctx with ONE GEMM per utterance at the end
  * instead of a read-modify-write of the whole [T,B,E] tensor per step. */
 int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const float* alpha,
                             const int32_t* seq_len, float sharpening, const void* enc, int enc_dtype,
-                            int T, int B, int E, float* denergy, float* denc, asr_stream s);
+                            int T, int B, int E, float* denergy, float* denc,
+                            const float* sigmoid_norm, asr_stream s);
 int asr_tanh_fwd(asr_handle* h, const float* x, float* y, size_t n, asr_stream s);
 int asr_tanh_bwd(asr_handle* h, const float* dy, const float* y, float* dx, size_t n, asr_stream s);
 /* tf.nn.embedding_lookup (attention_seq2seq.py:439) and its gradient (deterministic) */

@@ -29,8 +29,9 @@ ADDITIVE = ('bahdanau_content', 'location', 'hybrid')
 DOT = ('dot_product', 'luong_dot', 'luong_general')
 
 
-def attention_step(p, att_type, enc_bt, keys, s, seq_len, sharpening=1.0):
-    """enc_bt [B,T,2H]; keys [B,T,A] or None; s [B,U] -> (alpha [B,T], ctx [B,2H])."""
+def attention_step(p, att_type, enc_bt, keys, s, seq_len, sharpening=1.0, sigmoid_smoothing=False):
+    """enc_bt [B,T,2H]; keys [B,T,A] or None; s [B,U] -> (alpha [B,T], ctx [B,2H]).
+    sigmoid_smoothing: attention_layer.py:92-96, sigmoid(e) / sum_t sigmoid(e) instead of the softmax."""
     B, T, _ = enc_bt.shape
     if att_type in ADDITIVE:
         z = (s @ p['W_query/weights']).unsqueeze(1)                       # [B,1,A]
@@ -55,7 +56,11 @@ def attention_step(p, att_type, enc_bt, keys, s, seq_len, sharpening=1.0):
     mask = (torch.arange(T).unsqueeze(0) < seq_len.unsqueeze(1)).to(enc_bt.dtype)
     energy = energy * mask + (1.0 - mask) * F32_MIN
     energy = energy * sharpening
-    alpha = torch.softmax(energy, dim=1)
+    if sigmoid_smoothing:
+        sg = torch.sigmoid(energy)
+        alpha = sg / sg.sum(dim=1, keepdim=True)
+    else:
+        alpha = torch.softmax(energy, dim=1)
     ctx = (alpha.unsqueeze(2) * enc_bt).sum(1)
     return alpha, ctx
 
@@ -83,7 +88,7 @@ def decoder_params(sd, dtype=torch.float64, requires_grad=True):
 def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_len, enc_layers,
                             att_type, clip_enc=0.0, clip_dec=0.0, sharpening=1.0, temperature=1.0,
                             drop_emb=None, drop_dec=None, ctc_labels=None, lambda_weight=None,
-                            dtype=torch.float64):
+                            dtype=torch.float64, sigmoid_smoothing=False):
     """Teacher-forced forward + loss + all parameter gradients.
     labels [B, Lmax] int (<SOS> y <EOS>, padded with eos); returns dict(loss, logits [B,To,C],
     alphas, grads, ...)."""
@@ -127,7 +132,7 @@ def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_l
         inp = torch.cat([inp_emb, ctx], dim=1)
         cn, hn = olstm.lstm_block_cell(inp, c, h, cell['w'], cell['b'], wci, wcf, wco, 1.0, clip_dec, has_peep)
         cell_out = hn if drop_dec is None else hn * torch.as_tensor(drop_dec[k], dtype=dtype)
-        alpha, ctx_k = attention_step(ap, att_type, enc, keys, cell_out, sl, sharpening)
+        alpha, ctx_k = attention_step(ap, att_type, enc, keys, cell_out, sl, sharpening, sigmoid_smoothing)
         av = torch.tanh(torch.cat([cell_out, ctx_k], dim=1) @ P[D + 'attentional_vector/weights'])
         lg = av @ P[D + 'output_layer/weights'] + P[D + 'output_layer/biases']
         live = 1.0 - fin_prev                                             # impute_finished
@@ -172,7 +177,8 @@ def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_l
 
 
 def attention_model_infer(sd, inputs_btd, inputs_seq_len, enc_layers, att_type, sos, eos, max_len,
-                          clip_enc=0.0, clip_dec=0.0, sharpening=1.0, dtype=torch.float64):
+                          clip_enc=0.0, clip_dec=0.0, sharpening=1.0, dtype=torch.float64,
+                          sigmoid_smoothing=False):
     """GreedyEmbeddingHelper decode (attention_seq2seq.py:462-509): returns predicted ids [B, <=max_len]."""
     from .model import params_from_state_dict
     with torch.no_grad():
@@ -207,7 +213,7 @@ def attention_model_infer(sd, inputs_btd, inputs_seq_len, enc_layers, att_type, 
             inp = torch.cat([emb_w[tok], ctx], 1)
             cn, hn = olstm.lstm_block_cell(inp, c, h, P[D + 'lstm_cell/kernel'], P[D + 'lstm_cell/bias'],
                                            wci, wcf, wco, 1.0, clip_dec, has_peep)
-            alpha, ctx_k = attention_step(ap, att_type, enc, keys, hn, sl, sharpening)
+            alpha, ctx_k = attention_step(ap, att_type, enc, keys, hn, sl, sharpening, sigmoid_smoothing)
             av = torch.tanh(torch.cat([hn, ctx_k], 1) @ P[D + 'attentional_vector/weights'])
             lg = av @ P[D + 'output_layer/weights'] + P[D + 'output_layer/biases']
             sample = torch.argmax(lg, 1)

@@ -57,8 +57,8 @@ SIGNATURES = {
     'asr_lstm_cell_bwd': (_i, [_vp] * 9 + [_i, _i] + [_vp] * 5),
     'asr_att_energy_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'asr_att_energy_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    'asr_att_softmax_ctx_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    'asr_att_softmax_ctx_bwd': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'asr_att_softmax_ctx_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'asr_att_softmax_ctx_bwd': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'asr_tanh_fwd': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'asr_tanh_bwd': (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     'asr_embedding_gather': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

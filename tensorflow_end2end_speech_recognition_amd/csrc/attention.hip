@@ -168,9 +168,12 @@ __global__ void att_energy_bwd_reduce_kernel(const float* __restrict__ part, int
 
 // masked softmax over t.  energy[B,T] -> alpha[B,T].
 // mask: e*m + (1-m)*FLT_MIN(lowest), then *sharpening (attention_layer.py:76-89).
+// norm != NULL selects the reference's sigmoid smoothing (attention_layer.py:92-96): alpha = sigmoid(e) / sum_t
+// sigmoid(e); norm[b] receives the sum, which the backward needs (d sigmoid = s (1 - s), s = alpha * sum).
 __global__ __launch_bounds__(256) void att_softmax_kernel(const float* __restrict__ energy,
                                                           const int32_t* __restrict__ seq_len, float sharp,
-                                                          int T, float* __restrict__ alpha) {
+                                                          int T, float* __restrict__ alpha,
+                                                          float* __restrict__ norm) {
   __shared__ float red[4];
   __shared__ float s_max, s_inv;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,6 +181,28 @@ __global__ __launch_bounds__(256) void att_softmax_kernel(const float* __restric
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int len = min(max(seq_len[b], 0), T);
   const float lowest = -3.402823466e+38f;
+  if (norm) {
+    float sg = 0.f;
+    for (int t = tid; t < T; t += 256) {
+      const float e = fmaxf((t < len ? energy[(size_t)b * T + t] : lowest) * sharp, lowest);
+      const float p = 1.f / (1.f + expf(-e));          // masked frames: exp(+3.4e38) = inf -> exactly 0
+      al[t] = p;
+      sg += p;
+    }
+    sg = wave_reduce_sum(sg);
+    if (lane == 0) red[wave] = sg;
+    __syncthreads();
+    if (tid == 0) {
+      const float tot = red[0] + red[1] + red[2] + red[3];
+      norm[b] = tot;
+      s_inv = tot > 0.f ? 1.f / tot : 0.f;
+    }
+    __syncthreads();
+    const float inv = s_inv;
+    // an all-masked row (batch padding) is 0/0 in the reference; uniform weights here, like the softmax branch
+    for (int t = tid; t < T; t += 256) alpha[(size_t)b * T + t] = inv > 0.f ? al[t] * inv : 1.f / (float)T;
+    return;
+  }
   float m = -INFINITY;
   for (int t = tid; t < T; t += 256) {
     // float32.min * sharpening overflows to -inf for sharpening > 1 (reference quirk Q13); clamp so a
@@ -293,7 +318,8 @@ __global__ __launch_bounds__(256) void att_dalpha_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void att_softmax_bwd_kernel(const float* __restrict__ da,
                                                               const float* __restrict__ alpha,
                                                               const int32_t* __restrict__ seq_len, float sharp,
-                                                              int T, float* __restrict__ denergy) {
+                                                              int T, float* __restrict__ denergy,
+                                                              const float* __restrict__ norm) {
   __shared__ float red[4];
   __shared__ float s_dot;
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -308,7 +334,11 @@ __global__ __launch_bounds__(256) void att_softmax_bwd_kernel(const float* __res
   const float dsum = s_dot;
   for (int t = tid; t < T; t += 256) {
     float de = 0.f;
-    if (t < len) de = sharp * alpha[(size_t)b * T + t] * (da[(size_t)b * T + t] - dsum);
+    if (t < len) {
+      const float a = alpha[(size_t)b * T + t];
+      de = sharp * a * (da[(size_t)b * T + t] - dsum);
+      if (norm) de *= 1.f - a * norm[b];               // sigmoid smoothing: s (1 - s) / sum, s = a * sum
+    }
     denergy[(size_t)b * T + t] = de;
   }
 }
@@ -482,7 +512,7 @@ extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const flo
 
 extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* seq_len,
                                        float sharpening, const void* enc, int enc_dtype, int T, int B, int E,
-                                       float* alpha, float* ctx, asr_stream s) {
+                                       float* alpha, float* ctx, float* sigmoid_norm, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(energy && seq_len && enc && alpha && ctx && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype),
            "asr_att_softmax_ctx_fwd: bad args");
@@ -491,7 +521,8 @@ extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const
   const int nch = (T + ATT_CH - 1) / ATT_CH;
   float* part = att_scratch(h, (size_t)nch * B * E * sizeof(float));
   if (!part) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_softmax_ctx_fwd: scratch too small");
-  hipLaunchKernelGGL(att_softmax_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, energy, seq_len, sharpening, T, alpha);
+  hipLaunchKernelGGL(att_softmax_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, energy, seq_len, sharpening, T, alpha,
+                     sigmoid_norm);
   if (enc_dtype == ASR_F32)
     hipLaunchKernelGGL(att_ctx_partial_kernel<float>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, alpha, seq_len,
                        (const float*)enc, T, B, E, part);
@@ -506,7 +537,8 @@ extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const
 
 extern "C" int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const float* alpha,
                                        const int32_t* seq_len, float sharpening, const void* enc, int enc_dtype,
-                                       int T, int B, int E, float* denergy, float* denc, asr_stream s) {
+                                       int T, int B, int E, float* denergy, float* denc,
+                                       const float* sigmoid_norm, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(dctx && alpha && seq_len && enc && denergy && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype),
            "asr_att_softmax_ctx_bwd: bad args");
@@ -520,7 +552,7 @@ extern "C" int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const f
     hipLaunchKernelGGL(att_dalpha_kernel<bf16_t>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, seq_len,
                        (const bf16_t*)enc, T, B, E, da);
   hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, da, alpha, seq_len, sharpening, T,
-                     denergy);
+                     denergy, sigmoid_norm);
   if (denc)   // NULL: the caller accumulates d_enc = sum_steps alpha (x) dctx itself (one GEMM per utterance)
     hipLaunchKernelGGL(att_denc_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, alpha, seq_len, T, B, E, denc);
   ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_bwd");

@@ -68,8 +68,6 @@ class AttentionSeq2Seq(ModelBase):
         if decoder_type != 'lstm':
             raise TypeError('decoder_type is "lstm" or "gru".') if decoder_type != 'gru' else \
                 NotImplementedError('GRU decoder (crashes in the reference too, attention_seq2seq.py:364-365)')
-        if sigmoid_smoothing:
-            raise NotImplementedError('sigmoid_smoothing is not built on the HIP path yet')
         if encoder_type not in ('blstm',):
             raise NotImplementedError
         self.input_size, self.splice = input_size, splice
@@ -272,6 +270,8 @@ class AttentionSeq2Seq(ModelBase):
         if use_ddrop:                                            # one launch for the masks of every step
             self._calls += 1
             dmask_all = ops.dropout_mask((To, Bp, U), keep_prob_decoder, self.seed + 2, self._calls << 40, dev)
+        # sigmoid smoothing (attention_layer.py:92-96): the per-step normaliser is kept for the backward
+        snorm_all = torch.empty((To, Bp), dtype=torch.float32, device=dev) if self.sigmoid_smoothing else None
         for k in range(To):
             dec_in[k, :, Em:Em + E2].copy_(ctx)
             dec_in[k, :, Em + E2:].copy_(h)
@@ -285,10 +285,12 @@ class AttentionSeq2Seq(ModelBase):
             qz = self._query(cell_out)
             energy = ops.att_energy_fwd(keys, qz, v, T, self.att_mode)
             alpha, ctx_k = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc_att,
-                                                   alpha_out=alpha_all[k])
+                                                   alpha_out=alpha_all[k],
+                                                   sigmoid_norm=snorm_all[k] if snorm_all is not None else None)
             av_in[k, :, :U].copy_(cell_out)
             av_in[k, :, U:].copy_(ctx_k)
-            saved.append(dict(gates=gates, c_raw=c_raw, c_prev=c, qz=qz, alpha=alpha, dmask=dmask))
+            saved.append(dict(gates=gates, c_raw=c_raw, c_prev=c, qz=qz, alpha=alpha, dmask=dmask,
+                              snorm=snorm_all[k] if snorm_all is not None else None))
             c, h, ctx = c_new, h_new, ctx_k
         av = ops.tanh_fwd(ops.gemm(av_in.view(To * Bp, U + E2), st[D + 'attentional_vector/weights']))
         logits2d = ops.gemm(av, st[D + 'output_layer/weights'], bias=st[D + 'output_layer/biases'])
@@ -380,7 +382,8 @@ class AttentionSeq2Seq(ModelBase):
             torch.add(dav_in[k, :, U:], dctx_in, out=dctx)
             # d_enc += alpha (x) dctx is NOT done per step (a read-modify-write of [T,B,2H] each time):
             # alpha and dctx of all steps are kept and contracted once per utterance below
-            denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, tp['enc_att'], None)
+            denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, tp['enc_att'], None,
+                                              sigmoid_norm=s['snorm'])
             dqz, dv_rows = ops.att_energy_bwd(denergy, keys, s['qz'], v, self.att_mode, dkeys=dkeys,
                                               want_dv=self.att_mode == 0)
             dqz_all[k].copy_(dqz)
@@ -473,6 +476,7 @@ class AttentionSeq2Seq(ModelBase):
         dec_in = torch.empty((Bp, self.dec_in_dim), dtype=torch.float32, device=dev)
         av_in = torch.empty((Bp, U + E2), dtype=torch.float32, device=dev)
         out = []
+        snorm = torch.empty((Bp,), dtype=torch.float32, device=dev) if self.sigmoid_smoothing else None
         for k in range(self.max_decode_length):
             dec_in[:, :Em].copy_(ops.embedding_gather(st['output_embedding/W_embedding'], tok))
             dec_in[:, Em:Em + E2].copy_(ctx)
@@ -480,7 +484,7 @@ class AttentionSeq2Seq(ModelBase):
             pre = ops.gemm(dec_in, st[D + 'lstm_cell/kernel'], bias=st[D + 'lstm_cell/bias'])
             _, _, c, h, h_raw = ops.lstm_cell_fwd(pre, c, h, peep, live, 1.0, self.clip_activation_decoder or 0.0)
             energy = ops.att_energy_fwd(keys, self._query(h_raw), v, T, self.att_mode)
-            _, ctx = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc)
+            _, ctx = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc, sigmoid_norm=snorm)
             av_in[:, :U].copy_(h_raw)
             av_in[:, U:].copy_(ctx)
             av = ops.tanh_fwd(ops.gemm(av_in, st[D + 'attentional_vector/weights']))

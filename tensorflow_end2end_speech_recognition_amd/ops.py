@@ -479,26 +479,33 @@ def att_energy_bwd(denergy, keys, qz, v, mode, dkeys=None, want_dv=True):
     return dqz, dv
 
 
-def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None):
+def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmoid_norm=None):
+    """sigmoid_norm: None = softmax; a [B] fp32 tensor = sigmoid smoothing (receives sum_t sigmoid(e))."""
     h = _h(energy)
     B, T = energy.shape
     E = enc.shape[2]
     alpha = alpha_out if alpha_out is not None else _f32((B, T), energy.device)
     ctx = _f32((B, E), energy.device)
+    if sigmoid_norm is not None and (sigmoid_norm.dtype != torch.float32 or sigmoid_norm.numel() != B):
+        raise ValueError('sigmoid_norm must be fp32 [B]')
     h.check(h.lib.asr_att_softmax_ctx_fwd(h.h, _p(energy), _p(seq_len), float(sharpening), _p(enc),
-                                          dtype_id(enc.dtype), T, B, E, _p(alpha), _p(ctx), _s()),
+                                          dtype_id(enc.dtype), T, B, E, _p(alpha), _p(ctx), _p(sigmoid_norm), _s()),
             'asr_att_softmax_ctx_fwd')
     return alpha, ctx
 
 
-def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None):
-    """denc None: only denergy is produced; the caller accumulates d_enc = sum_steps alpha (x) dctx itself."""
+def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmoid_norm=None):
+    """denc None: only denergy is produced; the caller accumulates d_enc = sum_steps alpha (x) dctx itself.
+    sigmoid_norm: the tensor the forward filled (sigmoid smoothing), or None (softmax)."""
     h = _h(dctx)
     B, T = alpha.shape
     E = enc.shape[2]
     denergy = _f32((B, T), dctx.device)
+    if sigmoid_norm is not None and (sigmoid_norm.dtype != torch.float32 or sigmoid_norm.numel() != B):
+        raise ValueError('sigmoid_norm must be fp32 [B]')
     h.check(h.lib.asr_att_softmax_ctx_bwd(h.h, _p(dctx), _p(alpha), _p(seq_len), float(sharpening), _p(enc),
-                                          dtype_id(enc.dtype), T, B, E, _p(denergy), _p(denc), _s()),
+                                          dtype_id(enc.dtype), T, B, E, _p(denergy), _p(denc), _p(sigmoid_norm),
+                                          _s()),
             'asr_att_softmax_ctx_bwd')
     return denergy
 

@@ -252,3 +252,22 @@ def test_fast_cpu_port_matches_oracle():
     assert abs(float(loss.detach()) - r['total_loss']) < 1e-5
     assert max(np.abs(m.params[k].grad.numpy() - r['grads'][k]).max() for k in sd) < 1e-5
     assert np.isfinite(m.train_step(x, labs, sl))
+
+
+def test_sigmoid_smoothing_backward_formula():
+    """The closed form att_softmax_bwd_kernel uses for sigmoid smoothing,
+    de = k * alpha * (1 - alpha * S) * (da - sum_j alpha_j da_j), S = sum_t sigmoid(k e_t),
+    against autograd through the oracle's normalisation (oracle/attention.py attention_step)."""
+    import torch
+    rng = np.random.RandomState(4)
+    B, T, k = 3, 11, 1.7
+    e = torch.tensor(rng.randn(B, T) * 2.0, dtype=torch.float64, requires_grad=True)
+    da = torch.tensor(rng.randn(B, T), dtype=torch.float64)
+    sg = torch.sigmoid(e * k)
+    S = sg.sum(1, keepdim=True)
+    alpha = sg / S
+    (alpha * da).sum().backward()
+    a = alpha.detach()
+    dot = (a * da).sum(1, keepdim=True)
+    closed = k * a * (1.0 - a * S.detach()) * (da - dot)
+    assert (closed - e.grad).abs().max().item() < 1e-12
