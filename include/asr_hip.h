@@ -63,6 +63,18 @@ int asr_device_info(asr_handle* h, int* num_cu, char* name, int name_len);
  * (tf.transpose(inputs,[1,0,2]) at models/encoders/core/blstm.py:277-279). */
 int asr_bt_to_tb(asr_handle* h, int dtype, const float* in_btd, void* out_tbd,
                  int B, int T, int D, asr_stream s);
+/* Batch assembly on the device.  Frame stacking / skipping of a zero-padded batch
+ * x[B,T,F] (utils/io/inputs/frame_stacking.py:14-85): out[B, ceil(T/num_skip), F*num_stack], output frame k
+ * = input frames k*num_skip .. +num_stack-1 side by side, zero where they run past the utterance;
+ * out_len[b] = ceil(seq_len[b]/num_skip) (may be NULL).  num_stack < num_skip is an error as in the
+ * reference (:30-31). */
+int asr_stack_frames(asr_handle* h, const float* x, const int32_t* seq_len, int B, int T, int F,
+                     int num_stack, int num_skip, float* out, int32_t* out_len, asr_stream s);
+/* Context splicing per utterance over its own seq_len[b] frames (utils/io/inputs/splicing.py:9-73 as coded:
+ * frames t-splice .. t-1 with first/last-frame replication, output laid out [channels][splice*num_stack][3]);
+ * x[B,T,D], D = channels*3*num_stack; out[B,T,D*splice], zero for t >= seq_len[b]. */
+int asr_splice(asr_handle* h, const float* x, const int32_t* seq_len, int B, int T, int D, int splice,
+               int num_stack, float* out, asr_stream s);
 /* out[c*ld_out + r] = in[r*ld_in + c] for an [rows, cols] matrix in `dtype` (LDS-tiled, both
  * sides coalesced).  The MFMA GEMM wants both operands reduction-contiguous; the k-major ones
  * (W_x as stored by TF: [Din, 4H], models/encoders/core/blstm.py:286-320 via LSTMBlockCell's

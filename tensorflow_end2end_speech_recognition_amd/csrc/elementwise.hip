@@ -297,6 +297,91 @@ extern "C" int asr_transpose2d(asr_handle* h, int dtype, const void* in, int row
   return ASR_OK;
 }
 
+namespace {
+// Frame stacking / skipping on the padded batch (utils/io/inputs/frame_stacking.py:14-85): output frame k of
+// utterance b holds input frames k*skip .. k*skip+stack-1 side by side; slots past the utterance's last frame
+// (and whole frames past ceil(len/skip)) are zero.
+__global__ void stack_frames_kernel(const float* __restrict__ x, const int32_t* __restrict__ seq_len, int B, int T,
+                                    int F, int num_stack, int num_skip, int Tn, float* __restrict__ out,
+                                    int32_t* __restrict__ out_len) {
+  const size_t row = (size_t)F * num_stack;
+  const size_t n = (size_t)B * Tn * row;
+  const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (out_len && gid < (size_t)B) {
+    const int len = min(max(seq_len[gid], 0), T);
+    out_len[gid] = (len + num_skip - 1) / num_skip;
+  }
+  for (size_t i = gid; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % row);
+    const size_t bk = i / row;
+    const int k = (int)(bk % Tn), b = (int)(bk / Tn);
+    const int len = min(max(seq_len[b], 0), T);
+    const int src = k * num_skip + col / F;
+    out[i] = src < len ? x[((size_t)b * T + src) * F + col % F] : 0.f;
+  }
+}
+
+// Context splicing (utils/io/inputs/splicing.py:9-73, behaviour of the code, quirk Q9): per utterance, over its
+// own len frames, frame t takes frames t-splice .. t-1 with the edge rules of :42-57; an input frame
+// [C*3*num_stack] is read as (C, 3, num_stack) and the result is laid out [C][splice*num_stack][3].
+// The reference writes slots i .. i+num_stack-1 for i = 0 .. splice-1 in order, so slot j keeps the write of
+// i = min(j, splice-1) and slots j >= splice-1+num_stack stay zero.
+__global__ void splice_kernel(const float* __restrict__ x, const int32_t* __restrict__ seq_len, int B, int T, int D,
+                              int splice, int num_stack, float* __restrict__ out) {
+  const int C = D / (3 * num_stack);
+  const int SJ = splice * num_stack;
+  const size_t row = (size_t)C * SJ * 3;
+  const size_t n = (size_t)B * T * row;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % row);
+    const size_t bt = i / row;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const int len = min(max(seq_len[b], 0), T);
+    const int k3 = col % 3, j = (col / 3) % SJ, c = col / (3 * SJ);
+    const int is = min(j, splice - 1), sidx = j - is;
+    float v = 0.f;
+    if (t < len && sidx < num_stack) {
+      int src = t + is - splice;
+      const bool left = t <= splice - 1 && is < splice - t;
+      if (left) src = 0;
+      else if (len - splice <= t && src > len - 1) src = len - 1;
+      v = x[((size_t)b * T + src) * D + (size_t)c * 3 * num_stack + k3 * num_stack + sidx];
+    }
+    out[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int asr_stack_frames(asr_handle* h, const float* x, const int32_t* seq_len, int B, int T, int F,
+                                int num_stack, int num_skip, float* out, int32_t* out_len, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(x && seq_len && out && B >= 0 && T >= 0 && F > 0 && num_stack >= 1 && num_skip >= 1,
+           "asr_stack_frames: bad args");
+  // frame_stacking.py:30-31 raises ValueError for num_stack < num_skip
+  ASR_NEED(num_stack >= num_skip, "asr_stack_frames: num_skip must not exceed num_stack");
+  const int Tn = (T + num_skip - 1) / num_skip;
+  const size_t n = (size_t)B * Tn * F * num_stack;
+  if (!n) return ASR_OK;
+  hipLaunchKernelGGL(stack_frames_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, x, seq_len, B, T, F,
+                     num_stack, num_skip, Tn, out, out_len);
+  ASR_CHECK_LAUNCH(h, "asr_stack_frames");
+  return ASR_OK;
+}
+
+extern "C" int asr_splice(asr_handle* h, const float* x, const int32_t* seq_len, int B, int T, int D, int splice,
+                          int num_stack, float* out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(x && seq_len && out && B >= 0 && T >= 0 && D > 0 && splice >= 1 && num_stack >= 1,
+           "asr_splice: bad args");
+  ASR_NEED(D % (3 * num_stack) == 0, "asr_splice: frame width %d is not channels*3*num_stack", D);
+  const size_t n = (size_t)B * T * D * splice;
+  if (!n) return ASR_OK;
+  hipLaunchKernelGGL(splice_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, x, seq_len, B, T, D, splice,
+                     num_stack, out);
+  ASR_CHECK_LAUNCH(h, "asr_splice");
+  return ASR_OK;
+}
+
 extern "C" int asr_bt_to_tb(asr_handle* h, int dtype, const float* in, void* out, int B, int T, int D,
                             asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;

@@ -101,6 +101,36 @@ def bt_to_tb(x_btd, dtype=ASR_F32):
     return out
 
 
+def stack_frames(x_btf, seq_len, num_stack, num_skip):
+    """Zero-padded batch [B,T,F] fp32 + seq_len [B] int32 -> ([B, ceil(T/num_skip), F*num_stack], new seq_len)."""
+    h = _h(x_btf)
+    _chk(x_btf, torch.float32, 'inputs')
+    _chk(seq_len, torch.int32, 'seq_len')
+    if num_stack < num_skip:
+        raise ValueError('num_skip must be less than num_stack.')
+    B, T, F = x_btf.shape
+    Tn = (T + num_skip - 1) // num_skip
+    out = torch.empty((B, Tn, F * num_stack), dtype=torch.float32, device=x_btf.device)
+    out_len = torch.empty((B,), dtype=torch.int32, device=x_btf.device)
+    h.check(h.lib.asr_stack_frames(h.h, _p(x_btf), _p(seq_len), B, T, F, int(num_stack), int(num_skip), _p(out),
+                                   _p(out_len), _s()), 'asr_stack_frames')
+    return out, out_len
+
+
+def splice(x_btd, seq_len, splice, num_stack=1):
+    """Zero-padded batch [B,T,D] fp32 -> [B,T,D*splice], spliced per utterance over its own seq_len frames."""
+    h = _h(x_btd)
+    _chk(x_btd, torch.float32, 'inputs')
+    _chk(seq_len, torch.int32, 'seq_len')
+    B, T, D = x_btd.shape
+    if D % (3 * num_stack) != 0:
+        raise ValueError('frame width must be channels*3*num_stack')
+    out = torch.empty((B, T, D * splice), dtype=torch.float32, device=x_btd.device)
+    h.check(h.lib.asr_splice(h.h, _p(x_btd), _p(seq_len), B, T, D, int(splice), int(num_stack), _p(out), _s()),
+            'asr_splice')
+    return out
+
+
 def transpose2d(x, out=None):
     """out[c, r] = x[r, c] for a 2-D tensor with unit inner stride."""
     h = _h(x)

@@ -74,10 +74,15 @@ class DatasetBase(Base):
             self.input_size = input_list[0].shape[1]
             if self.num_stack is not None and self.num_skip is not None:
                 self.input_size *= self.num_stack
-        input_list = stack_frame(input_list, self.num_stack, self.num_skip, progressbar=False)
+        device_assembly = getattr(self, 'device_assembly', False)
+        if not device_assembly:
+            input_list = stack_frame(input_list, self.num_stack, self.num_skip, progressbar=False)
         max_frame_num = max(map(lambda x: x.shape[0], input_list))
         max_seq_len = max(map(len, label_list))
-        inputs = np.zeros((len(data_indices), max_frame_num, self.input_size * self.splice), dtype=np.float32)
+        # device_assembly: yield the raw padded features; utils/io/inputs/device.py assemble() stacks and
+        # splices them on the GPU (same result, no Python loop over utterances x splice)
+        width = input_list[0].shape[1] if device_assembly else self.input_size * self.splice
+        inputs = np.zeros((len(data_indices), max_frame_num, width), dtype=np.float32)
         labels = np.array([[self.padded_value] * max_seq_len] * len(data_indices))
         inputs_seq_len = np.zeros((len(data_indices),), dtype=np.int32)
         input_names = [basename(p).split('.')[0] if isinstance(p, str) else str(i)
@@ -85,8 +90,9 @@ class DatasetBase(Base):
         for i_batch in range(len(data_indices)):
             data_i = np.asarray(input_list[i_batch], dtype=np.float64)
             frame_num, input_size = data_i.shape
-            data_i = do_splice(data_i.reshape(1, frame_num, input_size), splice=self.splice, batch_size=1,
-                               num_stack=self.num_stack).reshape(frame_num, -1)
+            if not device_assembly:
+                data_i = do_splice(data_i.reshape(1, frame_num, input_size), splice=self.splice, batch_size=1,
+                                   num_stack=self.num_stack).reshape(frame_num, -1)
             inputs[i_batch, :frame_num, :] = data_i
             if self.is_test:
                 labels[i_batch, 0] = label_list[i_batch]

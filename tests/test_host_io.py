@@ -241,3 +241,31 @@ def test_eval_loops_on_fake_model(tmp_path):
     want_cer = (0 + 1 / 4 + 0 + ed.levenshtein('onetwo', 'onetoox') / 7) / 4
     want_wer = (0 + 1 / 2 + 0 + 2 / 3) / 4
     assert abs(cer - want_cer) < 1e-12 and abs(wer - want_wer) < 1e-12
+
+
+def test_dataset_device_assembly_yields_raw_features():
+    """device_assembly=True: the iterator hands over the raw zero-padded features and raw frame counts (the
+    stacking / splicing then runs in utils/io/inputs/device.py assemble(), GPU test test_device_batch_assembly);
+    sampling order and labels are the host path's."""
+    from tensorflow_end2end_speech_recognition_amd.utils.dataset.ctc import DatasetBase
+    feats = [np.random.RandomState(i).randn(5 + 3 * i, 6) for i in range(7)]
+    labs = [np.arange(1 + i % 3) for i in range(7)]
+
+    class DS(DatasetBase):
+        def __init__(self, device_assembly):
+            super(DS, self).__init__()
+            self.input_paths, self.label_paths = feats, labs
+            self.batch_size, self.splice, self.num_stack, self.num_skip = 3, 3, 2, 2
+            self.shuffle, self.sort_utt, self.sort_stop_epoch = False, False, None
+            self.num_gpu, self.is_test, self.max_epoch = 1, False, 1
+            self.rest = set(range(len(feats)))
+            self.device_assembly = device_assembly
+    host, dev = DS(False), DS(True)
+    for ((xh, lh, sh, nh), _), ((xd, ld, sd, nd), _) in zip(host, dev):
+        assert np.array_equal(lh, ld) and list(nh[0]) == list(nd[0])
+        ids = [int(n) for n in nd[0]]
+        assert xd.shape[-1] == 6 and xh.shape[-1] == 6 * 2 * 3
+        for r, i in enumerate(ids):
+            T = feats[i].shape[0]
+            assert sd[0][r] == T and sh[0][r] == -(-T // 2)
+            assert np.array_equal(xd[0][r, :T], feats[i].astype(np.float32)) and not xd[0][r, T:].any()
