@@ -117,3 +117,56 @@ def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, 
     return dict(total_loss=float(total.detach()), ctc_losses=losses.detach().numpy(),
                 logits=logits.detach().numpy(), grads=grads, enc=enc.detach().numpy(),
                 final=final)
+
+
+def multitask_ctc_model_forward(sd, inputs_btd, labels_main, labels_sub, seq_len, num_layers_main, num_layers_sub,
+                                main_task_weight, ndir=2, cell_clip=0.0, weight_decay=0.0, bottleneck=False,
+                                dtype=torch.float64):
+    """models/ctc/multitask_ctc.py:100-312: one encoder, the sub head ('output_sub') on the outputs of layer
+    num_layers_sub (models/encoders/core/blstm.py:326-328), the main head ('output_main', behind 'bottleneck' if
+    present) on the top layer; total = w * mean CTC(main) + (1 - w) * mean CTC(sub) (+ weight decay).
+    For ndir == 1 the caller passes num_layers_sub = num_layers_main (the list alias of lstm.py:271-272).
+    Returns dict(total_loss, ctc_losses_main, ctc_losses_sub, logits_main, logits_sub, grads)."""
+    def t(name):
+        v = sd[name]
+        return torch.as_tensor(np.asarray(v.detach().cpu() if torch.is_tensor(v) else v), dtype=dtype).clone() \
+            .requires_grad_(True)
+    layers = params_from_state_dict(sd, num_layers_main, ndir, dtype)
+    x = torch.as_tensor(np.asarray(inputs_btd), dtype=dtype)
+    sl = torch.as_tensor(np.asarray(seq_len), dtype=torch.long)
+    peep = layers[0][0]['_peep'] if ndir == 2 else layers[0]['_peep']
+    kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=peep)
+    run = olstm.blstm_encoder if ndir == 2 else olstm.lstm_encoder
+    enc, _ = run(x, sl, layers, None, **kw)
+    # the lower layers evaluated again with the SAME parameter tensors: identical values, and autograd adds the
+    # two paths' gradients exactly as the shared graph of the reference does
+    enc_sub, _ = run(x, sl, layers[:num_layers_sub], None, **kw)
+    T, B, E = enc.shape
+    heads = {k: t(k) for k in ('output_main/weights', 'output_main/biases', 'output_sub/weights',
+                               'output_sub/biases')}
+    head_in = enc.reshape(T * B, E)
+    if bottleneck:
+        heads['bottleneck/weights'], heads['bottleneck/biases'] = t('bottleneck/weights'), t('bottleneck/biases')
+        head_in = torch.relu(head_in @ heads['bottleneck/weights'] + heads['bottleneck/biases'])
+    logits_main = (head_in @ heads['output_main/weights'] + heads['output_main/biases']).reshape(T, B, -1)
+    logits_sub = (enc_sub.reshape(T * B, E) @ heads['output_sub/weights'] + heads['output_sub/biases']) \
+        .reshape(T, B, -1)
+    lm = ctc_loss(logits_main, labels_main, seq_len)
+    ls = ctc_loss(logits_sub, labels_sub, seq_len)
+    total = main_task_weight * lm.mean() + (1.0 - main_task_weight) * ls.mean()
+    named = {}
+    for layer in layers:
+        for p in (layer if ndir == 2 else (layer,)):
+            base = p['_base']
+            named[base + '/kernel'], named[base + '/bias'] = p['w'], p['b']
+            if p['_peep']:
+                named[base + '/w_i_diag'], named[base + '/w_f_diag'], named[base + '/w_o_diag'] = \
+                    p['wci'], p['wcf'], p['wco']
+    named.update(heads)
+    if weight_decay > 0:
+        total = total + weight_decay * sum(0.5 * (v ** 2).sum() for n, v in named.items() if 'bias' not in n.lower())
+    total.backward()
+    grads = {n: v.grad.detach().numpy().copy() for n, v in named.items()}
+    return dict(total_loss=float(total.detach()), ctc_losses_main=lm.detach().numpy(),
+                ctc_losses_sub=ls.detach().numpy(), logits_main=logits_main.detach().numpy(),
+                logits_sub=logits_sub.detach().numpy(), grads=grads)

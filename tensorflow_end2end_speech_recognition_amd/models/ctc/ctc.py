@@ -49,6 +49,7 @@ class CTC(ModelBase):
     Extra keyword arguments of the HIP build (not in the reference): `dtype` ('f32' exact
     fp32 MFMA path | 'bf16' operands with fp32 accumulate), `device`, `seed`.
     """
+    head_scope = 'output'      # variable scope of the output FC (ctc.py:216-224)
 
     def __init__(self, encoder_type, input_size, num_units, num_layers, num_classes,
                  lstm_impl='LSTMBlockCell', use_peephole=True, splice=1, num_stack=1,
@@ -94,35 +95,43 @@ class CTC(ModelBase):
 
         self.bottleneck_dim = int(bottleneck_dim) if bottleneck_dim not in (None, 0) else None
 
+        self.encoder = self._create_encoder(encoder_type, input_size, splice, num_stack, num_units, num_layers,
+                                            lstm_impl, use_peephole, parameter_init, clip_activation)
+
+        # variables: encoder, then the output head(s) (ctc.py:216-224)
+        rng = np.random.RandomState(seed)
+        self.store = ParamStore(self.device)
+        enc_dim = self.encoder.build(self.store, input_size * num_stack * splice, rng)
+        self._declare_heads(rng, enc_dim, parameter_init)
+        self.store.finalize()
+        self._tape = None
+
+    def _create_encoder(self, encoder_type, input_size, splice, num_stack, num_units, num_layers, lstm_impl,
+                        use_peephole, parameter_init, clip_activation):
+        """ctc.py:124-170: constructor keywords differ per encoder family."""
         if encoder_type in ['blstm', 'lstm']:
-            self.encoder = load(encoder_type)(
+            return load(encoder_type)(
                 num_units=num_units, num_proj=self.num_proj, num_layers=num_layers,
                 lstm_impl=lstm_impl, use_peephole=use_peephole, parameter_init=parameter_init,
                 clip_activation=clip_activation, time_major=True, dtype=self.dtype)
-        elif encoder_type in ['vgg_blstm', 'vgg_lstm']:
-            self.encoder = load(encoder_type)(
+        if encoder_type in ['vgg_blstm', 'vgg_lstm']:
+            return load(encoder_type)(
                 input_size=input_size, splice=splice, num_stack=num_stack, num_units=num_units,
                 num_proj=self.num_proj, num_layers=num_layers, lstm_impl=lstm_impl,
                 use_peephole=use_peephole, parameter_init=parameter_init,
                 clip_activation=clip_activation, time_major=True, dtype=self.dtype)
-        else:
-            load(encoder_type)  # ValueError for unknown keys, as load_encoder.py:53-56
-            raise NotImplementedError
+        load(encoder_type)  # ValueError for unknown keys, as load_encoder.py:53-56
+        raise NotImplementedError
 
-        # variables: encoder, then output/{weights,biases} (ctc.py:216-224)
-        rng = np.random.RandomState(seed)
-        self.store = ParamStore(self.device)
-        enc_dim = self.encoder.build(self.store, input_size * num_stack * splice, rng)
+    def _declare_heads(self, rng, enc_dim, parameter_init):
         if self.bottleneck_dim:   # ctc.py:201-216: FC(relu) named by its variable scope, then dropout
             self.store.declare('bottleneck/weights', (enc_dim, self.bottleneck_dim),
                                truncated_normal(rng, parameter_init, (enc_dim, self.bottleneck_dim)))
             self.store.declare('bottleneck/biases', (self.bottleneck_dim,), np.zeros(self.bottleneck_dim))
             enc_dim = self.bottleneck_dim
-        self.store.declare('output/weights', (enc_dim, self.num_classes),
+        self.store.declare(self.head_scope + '/weights', (enc_dim, self.num_classes),
                            truncated_normal(rng, parameter_init, (enc_dim, self.num_classes)))
-        self.store.declare('output/biases', (self.num_classes,), np.zeros(self.num_classes))
-        self.store.finalize()
-        self._tape = None
+        self.store.declare(self.head_scope + '/biases', (self.num_classes,), np.zeros(self.num_classes))
 
     # ------------------------------------------------------------------ graph pieces
     def _build(self, inputs, inputs_seq_len, keep_prob, is_training):
@@ -151,7 +160,7 @@ class CTC(ModelBase):
             x_op, E = hd.view(T, Bp, self.bottleneck_dim), self.bottleneck_dim
         self._head_in = x_op
         logits = torch.empty((T, Bp, self.num_classes), dtype=torch.float32, device=enc.device)
-        ops.gemm(x_op.view(T * Bp, E), sh['output/weights'], bias=self.store['output/biases'],
+        ops.gemm(x_op.view(T * Bp, E), sh[self.head_scope + '/weights'], bias=self.store[self.head_scope + '/biases'],
                  out=logits.view(T * Bp, self.num_classes))
         return logits
 
@@ -226,10 +235,10 @@ class CTC(ModelBase):
         sh = st.shadow(self.dtype)
         dl2d = dlogits.view(T * Bp, C)
         dl_op = ops.cast_from_f32(dl2d, ASR_BF16) if self.dtype == ASR_BF16 else dl2d
-        denc = ops.gemm(dl_op, sh['output/weights'], transB=True, out_dtype=ASR_F32)
+        denc = ops.gemm(dl_op, sh[self.head_scope + '/weights'], transB=True, out_dtype=ASR_F32)
         with ops.side_lane(dlogits.device, keep=(x_op, dl_op, dl2d)):   # joined by encoder.backward
-            ops.gemm(x_op.view(T * Bp, E), dl_op, transA=True, out=st.g('output/weights'))
-            ops.colsum(dl2d, out=st.g('output/biases'))
+            ops.gemm(x_op.view(T * Bp, E), dl_op, transA=True, out=st.g(self.head_scope + '/weights'))
+            ops.colsum(dl2d, out=st.g(self.head_scope + '/biases'))
         if self._bn is not None:
             bn = self._bn
             dpre = ops.relu_bwd(denc, bn['h'], bn['mask'])                  # operand dtype
@@ -240,10 +249,14 @@ class CTC(ModelBase):
             denc = ops.gemm(dpre, sh['bottleneck/weights'], transB=True, out_dtype=ASR_F32)
             E = Ee
             self._bn = None
-        self.encoder.backward(denc.view(T, Bp, E))
+        self.encoder.backward(denc.view(T, Bp, E), **self._encoder_backward_extra())
         if self.weight_decay > 0:
             ops.weight_decay(st.grad, st.flat, st.plan, st.decay_mask, self.weight_decay)
         self._tape = None
+
+    def _encoder_backward_extra(self):
+        """Further gradients entering the encoder (the sub-task head of MultitaskCTC)."""
+        return {}
 
     # ------------------------------------------------------------------ decode / eval
     def decoder(self, logits, inputs_seq_len, beam_width=1):

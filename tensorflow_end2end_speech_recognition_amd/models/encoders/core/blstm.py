@@ -46,6 +46,7 @@ class _RecurrentEncoderBase(object):
         self.layers = None
         self.store = None
         self.scope_prefix = ''
+        self.num_layers_sub = None     # multitask encoders: the layer whose output also feeds the sub-task head
 
     # variables are created at graph-build time in the reference; here when the input size is known
     def build(self, store, input_dim, rng, scope_prefix=''):
@@ -106,6 +107,9 @@ class _RecurrentEncoderBase(object):
                     nxt = prep(li + 1)
             x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, prep=cur)
             ops.join_side(x.device)
+            if self.num_layers_sub is not None and li + 1 == self.num_layers_sub:
+                # blstm.py:326-328: outputs_sub IS the tensor the next layer consumes (after the dropout wrapper)
+                self._out_sub_op, self._final_sub_ch = x, final
         self.seq_len_padded = seq_len
         out = ops.cast_to_f32(x) if x.dtype != torch.float32 else x
         self._out_tm = out
@@ -120,11 +124,14 @@ class _RecurrentEncoderBase(object):
             out_user = out_user.transpose(0, 1)
         return out_user, final_state
 
-    def backward(self, d_outputs, d_final=None, need_input_grad=False):
+    def backward(self, d_outputs, d_final=None, need_input_grad=False, d_outputs_sub=None):
         """d_outputs: gradient w.r.t. the TIME-MAJOR padded-batch outputs [T,Bpad,ndir*H] fp32.
+        d_outputs_sub (multitask encoders): gradient w.r.t. the sub-task outputs, joined where they branch off.
         Returns the gradient w.r.t. the (time-major) encoder input if need_input_grad."""
         dx = d_outputs
         for li in reversed(range(len(self.layers))):
+            if d_outputs_sub is not None and li == self.num_layers_sub - 1:
+                dx = torch.add(dx, d_outputs_sub)
             dcf = dhf = None
             if d_final is not None and li == len(self.layers) - 1:
                 dcf, dhf = d_final
