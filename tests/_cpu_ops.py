@@ -1,0 +1,450 @@
+"""TEST INFRASTRUCTURE ONLY: a torch-CPU stand-in for the C-ABI front end (package `ops`), so that the HOST logic
+above the kernels -- layer wiring, gradient plumbing, head / loss composition, clip + optimizer sequencing -- runs
+in the `-m "not gpu"` suite.  install(monkeypatch) swaps the functions of the `ops` module for the duration of one
+test; the product never imports this file and `ops` itself still refuses non-CUDA tensors.
+
+The stand-ins are built from the oracle (oracle/lstm.py, oracle/ctc.py, oracle/optim.py) and plain torch; they are
+self-consistent rather than layout-identical to the kernels: the "packed" recurrent weights are W_h as stored, the
+"interleaved" gate layout is the plain i, ci, f, o column order, and the saved-activation tensor of lstm_fwd carries
+the autograd graph that lstm_bwd differentiates.  Kernel numerics are NOT tested here -- that is what the GPU
+parity tests are for."""
+import numpy as np
+import torch
+
+from oracle import ctc as octc
+from oracle import decoders as odec
+from oracle import lstm as olstm
+from oracle import optim as oopt
+
+F64 = torch.float64
+
+
+class _NullLane(object):
+    def __init__(self, device, keep=()):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _bt_to_tb(x_btd, dtype=0):
+    return x_btd.transpose(0, 1).contiguous()
+
+
+def _transpose2d(x, out=None):
+    y = x.t().contiguous()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def _cast_from_f32(x, dtype, out=None):
+    if out is not None:
+        out.copy_(x)
+        return out
+    return x.clone()
+
+
+def _cast_to_f32(x, out=None):
+    y = x.float()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def _apply_mask(x, mask, out=None):
+    y = x * mask.to(x.dtype).view(x.shape) if mask.numel() == x.numel() else x * mask
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def _dropout_mask(shape, keep_prob, seed, offset, device):
+    g = torch.Generator().manual_seed((int(seed) * 1000003 + int(offset)) % (2 ** 63 - 1))
+    return (torch.rand(shape, generator=g) < keep_prob).float() / float(keep_prob)
+
+
+def _colsum(a, out=None):
+    y = a.double().sum(0).float()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def _gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, accumulate=False, relu=False):
+    if A.dim() != 2 or B.dim() != 2 or A.stride(1) != 1 or B.stride(1) != 1:
+        raise ValueError('gemm: operands must be 2-D with unit inner stride')
+    a = A.double().t() if transA else A.double()
+    b = B.double().t() if transB else B.double()
+    if a.shape[1] != b.shape[0]:
+        raise ValueError('gemm: inner dimensions differ (%d vs %d)' % (a.shape[1], b.shape[0]))
+    y = a @ b
+    if bias is not None:
+        y = y + bias.double()
+    if accumulate:
+        y = y + out.double()
+    if relu:
+        y = torch.relu(y)
+    if out is not None:
+        if tuple(out.shape) != tuple(y.shape) or out.stride(1) != 1:
+            raise ValueError('gemm: bad out shape %s' % (tuple(out.shape),))
+        out.copy_(y)
+        return out
+    return y.float()
+
+
+def _relu_bwd(dout, out, mask=None):
+    y = dout * (out > 0).to(dout.dtype)
+    if mask is not None:
+        y = y * mask.view(y.shape)
+    return y
+
+
+def _lstm_prep_weights(kernel, bias, din, H, dtype, out=None):
+    if kernel.shape != (din + H, 4 * H):
+        raise ValueError('kernel must be [Din+H,4H]')
+    if out is None:
+        out = dict(wx_il=torch.empty((din, 4 * H)), bias_il=torch.empty((4 * H,)),
+                   pf=torch.empty((H * 4 * H,)), pb=torch.empty((H * 4 * H,)))
+    out['wx_il'].copy_(kernel[:din])
+    out['bias_il'].copy_(bias)
+    out['pf'].copy_(kernel[din:].reshape(-1))
+    out['pb'].copy_(kernel[din:].reshape(-1))
+    return out
+
+
+def _gate_deinterleave(src, dst, H):
+    dst.copy_(src)
+    return dst
+
+
+def _lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, cell_clip=0.0, want_final=True):
+    T, B, G = xproj.shape
+    if G != ndir * 4 * H:
+        raise ValueError('xproj last dim %d != ndir*4H' % G)
+    sl = seq_len.long()
+    eye = torch.eye(4 * H, dtype=F64)
+    runs, outs, cfs, hfs = [], [], [], []
+    for d in range(ndir):
+        xp = xproj[:, :, d * 4 * H:(d + 1) * 4 * H].double().clone().requires_grad_(True)
+        wh = wh_packed[d].view(H, 4 * H).double()
+        if peep is not None:
+            pp = peep[d].double().clone().requires_grad_(True)
+            wci, wcf, wco = pp[0], pp[1], pp[2]
+        else:
+            pp = None
+            wci = wcf = wco = torch.zeros(H, dtype=F64)
+        p = dict(w=torch.cat([eye, wh], 0), b=torch.zeros(4 * H, dtype=F64), wci=wci, wcf=wcf, wco=wco)
+        out, (cf, hf) = olstm.dynamic_rnn(xp, sl, p, reverse=(d == 1), forget_bias=forget_bias,
+                                          cell_clip=cell_clip, use_peephole=peep is not None)
+        runs.append(dict(xp=xp, pp=pp, out=out, cf=cf, hf=hf))
+        outs.append(out.detach())
+        cfs.append(cf.detach())
+        hfs.append(hf.detach())
+    gates = torch.zeros((T, B, ndir * 4 * H))
+    gates._runs = runs                       # the graph lstm_bwd differentiates (stand-in for the saved gates)
+    hout = torch.cat(outs, 2).float().contiguous()
+    cs = torch.zeros((T, B, ndir * H))
+    return gates, hout, cs, torch.stack(cfs).float(), torch.stack(hfs).float()
+
+
+def _lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c_final=None, d_h_final=None,
+              want_dpeep=True):
+    T, B, _ = dhout.shape
+    dgates = torch.zeros((T, B, ndir * 4 * H))
+    dpeep = torch.zeros((ndir, 7, H)) if want_dpeep else None
+    for d, r in enumerate(gates._runs):
+        outs = [r['out'], r['cf'], r['hf']]
+        gos = [dhout[:, :, d * H:(d + 1) * H].double(),
+               d_c_final[d].double() if d_c_final is not None else torch.zeros_like(r['cf']),
+               d_h_final[d].double() if d_h_final is not None else torch.zeros_like(r['hf'])]
+        ins = [r['xp']] + ([r['pp']] if r['pp'] is not None else [])
+        gr = torch.autograd.grad(outs, ins, grad_outputs=gos, allow_unused=True)
+        dxp = gr[0]
+        dgates[:, :, d * 4 * H:(d + 1) * 4 * H] = dxp.float()
+        if want_dpeep:
+            if r['pp'] is not None and gr[1] is not None:
+                dpeep[d, 0:3] = gr[1].float()
+            dpeep[d, 3:7] = dxp.sum((0, 1)).view(4, H).float()
+    return dgates, dpeep
+
+
+def _labels_list(labels_flat, label_offsets, B):
+    flat = labels_flat.cpu().numpy()
+    off = label_offsets.cpu().numpy()
+    return [[int(v) for v in flat[off[b]:off[b + 1]]] for b in range(B)]
+
+
+def _ctc_loss(logits, labels_flat, label_offsets, seq_len, max_label_len, grad_scale=1.0, want_grad=True):
+    T, B, Cc = logits.shape
+    labs = _labels_list(labels_flat, label_offsets, B)
+    sl = seq_len.cpu().numpy()
+    loss = np.zeros(B)
+    grad = np.zeros((T, B, Cc))
+    ninf = 0
+    x = logits.double().numpy()
+    for b in range(B):
+        n = int(sl[b])
+        if n == 0 and len(labs[b]) == 0:
+            continue                                  # batch-padding row
+        l, g, ok = octc.ctc_loss_single(x[:n, b], labs[b])
+        if not ok:
+            ninf += 1
+            continue                                  # ignore_longer_outputs_than_inputs=True: loss 0, grad 0
+        loss[b] = l
+        grad[:n, b] = g
+    g = torch.from_numpy(grad * grad_scale).float() if want_grad else None
+    return torch.from_numpy(loss).float(), g, torch.tensor([ninf], dtype=torch.int32)
+
+
+def _ctc_greedy_decode(logits, seq_len, blank=None):
+    T, B, Cc = logits.shape
+    blank = Cc - 1 if blank is None else blank
+    lp = torch.log_softmax(logits.double(), 2).transpose(0, 1).numpy()
+    out = torch.full((B, T), -1, dtype=torch.int32)
+    n = torch.zeros((B,), dtype=torch.int32)
+    for b in range(B):
+        hyp = odec.greedy_decode(lp[b:b + 1], [int(seq_len[b])], blank)[0]
+        n[b] = len(hyp)
+        out[b, :len(hyp)] = torch.tensor([int(v) for v in hyp], dtype=torch.int32)
+    return out, n
+
+
+def _softmax_rows(x2d):
+    return torch.softmax(x2d.double(), 1).float()
+
+
+def _clip_by_norm_multi(flat_grads, plan, clip_norm):
+    off = plan.offsets.cpu().numpy()
+    g = flat_grads.numpy()
+    for i in range(plan.num_tensors):
+        g[off[i]:off[i + 1]] = oopt.clip_by_norm(g[off[i]:off[i + 1]], clip_norm)
+
+
+def _weight_decay(flat_grads, flat_params, plan, decay_mask, wd, l2_out=None):
+    off = plan.offsets.cpu().numpy()
+    m = decay_mask.cpu().numpy()
+    tot = 0.0
+    for i in range(plan.num_tensors):
+        if not m[i]:
+            continue
+        p = flat_params[off[i]:off[i + 1]]
+        tot += 0.5 * float((p.double() ** 2).sum())
+        if flat_grads is not None:
+            flat_grads[off[i]:off[i + 1]] += wd * p
+    if l2_out is not None:
+        l2_out.fill_(wd * tot)
+
+
+_OPT_NAMES = None
+
+
+def _optimizer_step(opt_id, params, grads, slot0, slot1, lr, step):
+    from tensorflow_end2end_speech_recognition_amd._lib import OPTIMIZER_IDS
+    name = [k for k, v in OPTIMIZER_IDS.items() if v == opt_id][0]
+    z = np.zeros(params.numel(), dtype=np.float64)
+    s0 = slot0.double().numpy() if slot0 is not None else z
+    s1 = slot1.double().numpy() if slot1 is not None else z
+    p, s0, s1 = oopt.step(name, params.double().numpy(), grads.double().numpy(), s0, s1, lr, step)
+    params.copy_(torch.from_numpy(np.asarray(p)).float())
+    if slot0 is not None:
+        slot0.copy_(torch.from_numpy(np.asarray(s0)).float())
+    if slot1 is not None:
+        slot1.copy_(torch.from_numpy(np.asarray(s1)).float())
+
+
+def _scale_(x, s):
+    x.mul_(s)
+    return x
+
+
+# ---------------------------------------------------------------- attention decoder stand-ins
+def _lstm_cell_fwd(pre, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.0):
+    """csrc/attention.hip cell_fwd_kernel: gate-major columns i, ci, f, o; finished rows keep their state."""
+    B, U4 = pre.shape
+    U = U4 // 4
+    p, cp = pre.double(), c_prev.double()
+    z = torch.zeros(U, dtype=F64)
+    wci, wcf, wco = (peep.double().view(3, U) if peep is not None else (z, z, z))
+    i = torch.sigmoid(p[:, :U] + wci * cp)
+    g = torch.tanh(p[:, U:2 * U])
+    f = torch.sigmoid(p[:, 2 * U:3 * U] + forget_bias + wcf * cp)
+    cn = g * i + cp * f
+    if cell_clip and cell_clip > 0:
+        cn = cn.clamp(-cell_clip, cell_clip)
+    o = torch.sigmoid(p[:, 3 * U:] + wco * cn)
+    hn = torch.tanh(cn) * o
+    lv = (live.double() > 0).view(B, 1)
+    gates = torch.cat([i, g, f, o], 1).float()
+    return gates, cn.float(), torch.where(lv, cn, cp).float(), torch.where(lv, hn, h_prev.double()).float(), hn.float()
+
+
+def _lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True):
+    B, U = dh_use.shape
+    gt = gates.double()
+    i, g, f, o = gt[:, :U], gt[:, U:2 * U], gt[:, 2 * U:3 * U], gt[:, 3 * U:]
+    z = torch.zeros(U, dtype=F64)
+    wci, wcf, wco = (peep.double().view(3, U) if peep is not None else (z, z, z))
+    c, cp = c_raw.double(), c_prev.double()
+    lv = (live.double() > 0).view(B, 1)
+    dh = dh_use.double() + dh_next.double()
+    tc = torch.tanh(c)
+    d_o = dh * tc * o * (1 - o)
+    dc = dc_next.double() + dh * o * (1 - tc * tc) + d_o * wco          # the clip is straight-through
+    d_g = dc * i * (1 - g * g)
+    d_i = dc * g * i * (1 - i)
+    d_f = dc * cp * f * (1 - f)
+    zero = torch.zeros_like(dc)
+    dpre = torch.where(lv, torch.cat([d_i, d_g, d_f, d_o], 1), torch.zeros(B, 4 * U, dtype=F64))
+    dc_prev = torch.where(lv, dc * f + d_i * wci + d_f * wcf, dc_next.double())
+    dh_carry = torch.where(lv, zero, dh_next.double())
+    dpeep = None
+    if want_dpeep:
+        dpeep = torch.stack([torch.where(lv, d_i * cp, zero), torch.where(lv, d_f * cp, zero),
+                             torch.where(lv, d_o * c, zero)], 1).float()
+    return dpre.float(), dc_prev.float(), dh_carry.float(), dpeep
+
+
+def _att_energy_fwd(keys, qz, v, T, mode):
+    """keys [T,B,A] or None, qz [B,A] -> energy [B,T]."""
+    q = qz.double().unsqueeze(0)                                           # [1,B,A]
+    if mode == 0:
+        zz = (keys.double() if keys is not None else 0.0) + q
+        if keys is None:
+            zz = zz.expand(T, *zz.shape[1:])
+        e = (v.double() * torch.tanh(zz)).sum(2)
+    else:
+        e = (keys.double() * q).sum(2)
+    return e.t().contiguous().float()
+
+
+def _att_energy_bwd(denergy, keys, qz, v, mode, dkeys=None, want_dv=True):
+    B, A = qz.shape
+    T = denergy.shape[1]
+    de = denergy.double().t().unsqueeze(2)                                 # [T,B,1]
+    q = qz.double().unsqueeze(0)
+    dv = None
+    if mode == 0:
+        zz = (keys.double() if keys is not None else 0.0) + q
+        if keys is None:
+            zz = zz.expand(T, B, A)
+        th = torch.tanh(zz)
+        dz = de * v.double() * (1 - th * th)
+        if dkeys is not None:
+            dkeys += dz.float()
+        dqz = dz.sum(0)
+        if want_dv:
+            dv = (de * th).sum(0).float()
+    else:
+        if dkeys is not None:
+            dkeys += (de * q).float()
+        dqz = (de * keys.double()).sum(0)
+        if want_dv:
+            dv = torch.zeros(B, A)
+    return dqz.float(), dv
+
+
+_F32_LOWEST = float(np.finfo(np.float32).min)
+
+
+def _att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmoid_norm=None):
+    B, T = energy.shape
+    mask = torch.arange(T).unsqueeze(0) < seq_len.long().clamp(0, T).unsqueeze(1)
+    e = torch.where(mask, energy.double(), torch.full_like(energy, _F32_LOWEST, dtype=F64)) * sharpening
+    e = e.clamp(min=_F32_LOWEST)
+    if sigmoid_norm is not None:
+        sg = torch.sigmoid(e) * mask
+        tot = sg.sum(1, keepdim=True)
+        sigmoid_norm.copy_(tot.view(-1).float())
+        alpha = torch.where(tot > 0, sg / tot.clamp(min=1e-300), torch.full_like(sg, 1.0 / T))
+    else:
+        alpha = torch.softmax(e, 1)
+    ctx = torch.einsum('bt,tbe->be', alpha * (mask | (seq_len.long() == 0).unsqueeze(1)), enc.double())
+    if alpha_out is not None:
+        alpha_out.copy_(alpha.float())
+        alpha = alpha_out
+    else:
+        alpha = alpha.float()
+    return alpha, ctx.float()
+
+
+def _att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmoid_norm=None):
+    B, T = alpha.shape
+    mask = (torch.arange(T).unsqueeze(0) < seq_len.long().clamp(0, T).unsqueeze(1)).double()
+    a = alpha.double()
+    da = torch.einsum('be,tbe->bt', dctx.double(), enc.double()) * mask
+    dot = (a * da * mask).sum(1, keepdim=True)
+    de = sharpening * a * (da - dot) * mask
+    if sigmoid_norm is not None:
+        de = de * (1 - a * sigmoid_norm.double().view(B, 1))
+    if denc is not None:
+        denc += torch.einsum('bt,be->tbe', a * mask, dctx.double()).float()
+    return de.float()
+
+
+def _tanh_fwd(x):
+    return torch.tanh(x.double()).float()
+
+
+def _tanh_bwd(dy, y):
+    return (dy.double() * (1 - y.double() ** 2)).float()
+
+
+def _embedding_gather(W, ids):
+    return W[ids.long()].contiguous()
+
+
+def _embedding_scatter(dout, ids, vocab, out):
+    out.zero_()
+    out.index_add_(0, ids.long().view(-1), dout.reshape(-1, dout.shape[-1]))
+    return out
+
+
+def _seq_xent(logits2d, targets, weights, eps, dscale, want_grad=True):
+    x = logits2d.double() + eps
+    lse = torch.logsumexp(x, 1)
+    w = weights.double()
+    tg = targets.long()
+    row_loss = w * (lse - x.gather(1, tg.view(-1, 1)).view(-1))
+    dl = None
+    if want_grad:
+        dl = torch.exp(x - lse.view(-1, 1))
+        dl[torch.arange(x.shape[0]), tg] -= 1.0
+        dl = (dl * (w * dscale).view(-1, 1)).float()
+    return row_loss.float(), dl
+
+
+def _argmax_rows(x2d):
+    return torch.argmax(x2d, 1).to(torch.int32)
+
+
+STAND_INS = dict(
+    side_lane=_NullLane, join_side=lambda device: None, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
+    cast_from_f32=_cast_from_f32, cast_to_f32=_cast_to_f32, apply_mask=_apply_mask, dropout_mask=_dropout_mask,
+    colsum=_colsum, gemm=_gemm, relu_bwd=_relu_bwd, lstm_prep_weights=_lstm_prep_weights,
+    gate_deinterleave=_gate_deinterleave, lstm_fwd=_lstm_fwd, lstm_bwd=_lstm_bwd, ctc_loss=_ctc_loss,
+    ctc_greedy_decode=_ctc_greedy_decode, softmax_rows=_softmax_rows, clip_by_norm_multi=_clip_by_norm_multi,
+    weight_decay=_weight_decay, optimizer_step=_optimizer_step, scale_=_scale_,
+    lstm_cell_fwd=_lstm_cell_fwd, lstm_cell_bwd=_lstm_cell_bwd, att_energy_fwd=_att_energy_fwd,
+    att_energy_bwd=_att_energy_bwd, att_softmax_ctx_fwd=_att_softmax_ctx_fwd,
+    att_softmax_ctx_bwd=_att_softmax_ctx_bwd, tanh_fwd=_tanh_fwd, tanh_bwd=_tanh_bwd,
+    embedding_gather=_embedding_gather, embedding_scatter=_embedding_scatter, seq_xent=_seq_xent,
+    argmax_rows=_argmax_rows,
+)
+
+
+def install(monkeypatch):
+    """Swap the kernel front end for the CPU stand-ins for one test; pinned staging buffers become plain ones."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    for name, fn in STAND_INS.items():
+        assert hasattr(ops, name), name
+        monkeypatch.setattr(ops, name, fn)
+    monkeypatch.setattr(torch.Tensor, 'pin_memory', lambda self, *a, **k: self)
+    return ops

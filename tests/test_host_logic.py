@@ -1,0 +1,208 @@
+"""Host logic above the kernels, on the CPU: the models are run with the kernel front end (`ops`) swapped for the
+torch/oracle stand-ins of tests/_cpu_ops.py, and compared with the oracle's end-to-end models.  What this pins is
+the Python side -- which tensors are fed to which GEMM, how weight / bias / peephole gradients are assembled from
+the BPTT output, the head and loss composition, the clip -> optimizer sequence -- not kernel numerics (GPU tests)."""
+import numpy as np
+import pytest
+import torch
+
+import _cpu_ops
+from oracle import model as omodel
+from oracle import optim as oopt
+
+
+def _batch(rng, B, T, D, C, div=4):
+    x = rng.randn(B, T, D).astype(np.float32)
+    sl = rng.randint(max(2, T // 2), T + 1, size=B).astype(np.int32)
+    sl[0] = T
+    labs = []
+    for b in range(B):
+        x[b, sl[b]:] = 0
+        labs.append([int(v) for v in rng.randint(0, C, size=max(1, sl[b] // div))])
+    dense = np.full((B, max(len(l) for l in labs)), -1, dtype=np.int64)
+    for b, l in enumerate(labs):
+        dense[b, :len(l)] = l
+    return x, sl, labs, dense
+
+
+def _check_grads(opt, loss, model, ref, tol=1e-4):
+    seen = set()
+    for g, name in opt.compute_gradients(loss, model=model):
+        r = ref['grads'][name]
+        seen.add(name)
+        err = np.abs(g.numpy() - r).max()
+        assert err < tol * max(np.abs(r).max(), 1e-3) + 1e-7, (name, err, np.abs(r).max())
+    assert seen == set(ref['grads'])
+
+
+@pytest.mark.parametrize('enc,L,bn,wd', [('blstm', 2, None, 0.0), ('lstm', 2, None, 0.0), ('blstm', 1, 12, 1e-3)])
+def test_ctc_model_host_logic(monkeypatch, enc, L, bn, wd):
+    _cpu_ops.install(monkeypatch)
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    rng = np.random.RandomState(5)
+    B, T, D, H, C = 5, 11, 6, 8, 6                    # B is padded to 16 utterances inside the encoder
+    x, sl, labs, dense = _batch(rng, B, T, D, C)
+    model = CTC(encoder_type=enc, input_size=D, num_units=H, num_layers=L, num_classes=C, parameter_init=0.1,
+                clip_grad_norm=0.05, clip_activation=50, bottleneck_dim=bn, weight_decay=wd, dtype='f32', seed=3,
+                device='cpu')
+    sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    for k in sd:
+        if k.endswith('/bias') or k.endswith('/biases'):
+            sd[k] = (rng.randn(*sd[k].shape) * 0.05).astype(np.float32)
+    model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    ref = omodel.ctc_model_forward(sd, x, labs, sl, L, ndir=2 if enc == 'blstm' else 1, cell_clip=50.0,
+                                   weight_decay=wd, bottleneck=bn is not None)
+    loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-5
+    assert np.abs(logits.numpy() - ref['logits']).max() < 1e-5
+    opt = model._set_optimizer('sgd', 0.1)
+    _check_grads(opt, loss, model, ref)
+    # one full training step: per-variable clip, then the update (model_base.py:97-152)
+    before = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    loss, _ = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    model.train(loss, 'momentum', 0.1)
+    after = model.store.state_dict()
+    for name, r in ref['grads'].items():
+        want = before[name] - 0.1 * oopt.clip_by_norm(r, 0.05)          # first momentum step: v = g
+        assert np.abs(after[name].numpy() - want).max() < 1e-5, name
+    # decode / LER plumbing
+    dec = model.decoder(logits, sl, beam_width=1)
+    from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import list2sparsetensor
+    assert 0.0 <= model.compute_ler(dec, list2sparsetensor(dense, -1))
+
+
+@pytest.mark.parametrize('enc,Lm,Ls,bn', [('multitask_blstm', 3, 2, None), ('multitask_blstm', 2, 2, 10),
+                                          ('multitask_blstm', 3, 1, None), ('multitask_lstm', 3, 1, None)])
+def test_multitask_ctc_host_logic(monkeypatch, enc, Lm, Ls, bn):
+    """The second head and the join of its gradient inside the encoder stack (models/ctc/multitask_ctc.py,
+    models/encoders/core/multitask_blstm.py) against the oracle's multitask model."""
+    _cpu_ops.install(monkeypatch)
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.multitask_ctc import MultitaskCTC
+    from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import list2sparsetensor
+    rng = np.random.RandomState(17)
+    B, T, D, H, Cm, Cs, w = 4, 10, 6, 8, 7, 3, 0.7
+    x, sl, labs_m, dense_m = _batch(rng, B, T, D, Cm)
+    labs_s = [[int(v) for v in rng.randint(0, Cs, size=max(1, int(sl[b]) // 5))] for b in range(B)]
+    dense_s = np.full((B, max(len(l) for l in labs_s)), -1, dtype=np.int64)
+    for b, l in enumerate(labs_s):
+        dense_s[b, :len(l)] = l
+    model = MultitaskCTC(encoder_type=enc, input_size=D, num_units=H, num_layers_main=Lm, num_layers_sub=Ls,
+                         num_classes_main=Cm, num_classes_sub=Cs, main_task_weight=w, parameter_init=0.1,
+                         clip_grad_norm=5.0, clip_activation=50, bottleneck_dim=bn, dtype='f32', seed=9, device='cpu')
+    ndir = 2 if enc == 'multitask_blstm' else 1
+    sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    for k in sd:
+        if k.endswith('/biases'):
+            sd[k] = (rng.randn(*sd[k].shape) * 0.05).astype(np.float32)
+    model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    ref = omodel.multitask_ctc_model_forward(sd, x, labs_m, labs_s, sl, Lm, Ls if ndir == 2 else Lm, w, ndir=ndir,
+                                             cell_clip=50.0, bottleneck=bn is not None)
+    loss, lg_m, lg_s = model.compute_loss(x, dense_m, list2sparsetensor(dense_s, -1), sl, keep_prob=1.0)
+    assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-5
+    assert np.abs(lg_m.numpy() - ref['logits_main']).max() < 1e-5
+    assert np.abs(lg_s.numpy() - ref['logits_sub']).max() < 1e-5
+    assert np.abs(model.ctc_losses_sub.numpy() - ref['ctc_losses_sub']).max() < 1e-4
+    _check_grads(model._set_optimizer('sgd', 0.1), loss, model, ref)
+    # dropout path runs, trains, decodes and scores both tasks
+    first = last = None
+    for it in range(6):
+        l, lm_, ls_ = model.compute_loss(x, dense_m, dense_s, sl, keep_prob=0.9)
+        model.train(l, 'adam', 1e-2)
+        first = l.item() if first is None else first
+        last = l.item()
+    assert last < first
+    dm, ds = model.decoder(lm_, ls_, sl, beam_width=1)
+    ler_m, ler_s = model.compute_ler(dm, ds, list2sparsetensor(dense_m, -1), list2sparsetensor(dense_s, -1))
+    assert 0.0 <= ler_m and 0.0 <= ler_s
+    pm, ps = model.posteriors(lm_, ls_)
+    assert pm.shape == (B * T, Cm + 1) and ps.shape == (B * T, Cs + 1)
+
+
+def _att_batch(rng, B, T, D, C):
+    x = rng.randn(B, T, D).astype(np.float32)
+    sl = rng.randint(max(2, T // 2), T + 1, size=B).astype(np.int32)
+    sl[0] = T
+    lens = rng.randint(1, 5, size=B)
+    lens[0] = 4
+    Lmax = int(lens.max()) + 2
+    sos, eos = C, C + 1
+    labels = np.full((B, Lmax), eos, dtype=np.int64)
+    ctc_labels = np.full((B, int(lens.max())), -1, dtype=np.int64)
+    for b in range(B):
+        x[b, sl[b]:] = 0
+        y = rng.randint(0, C, size=lens[b])
+        labels[b, 0] = sos
+        labels[b, 1:1 + lens[b]] = y
+        ctc_labels[b, :lens[b]] = y
+    return x, sl, labels, lens + 2, ctc_labels
+
+
+def _mk_att(cls, att, D, H, L, U, A, Em, C, **kw):
+    return cls(input_size=D, encoder_type='blstm', encoder_num_units=H, encoder_num_layers=L,
+               encoder_num_proj=None, attention_type=att, attention_dim=A, decoder_type='lstm',
+               decoder_num_units=U, decoder_num_layers=1, embedding_dim=Em, num_classes=C, sos_index=C,
+               eos_index=C + 1, max_decode_length=8, parameter_init=0.1, clip_grad_norm=5.0,
+               clip_activation_encoder=50, clip_activation_decoder=50, dtype='f32', seed=5, device='cpu', **kw)
+
+
+@pytest.mark.parametrize('att,sig', [('bahdanau_content', False), ('location', False), ('hybrid', False),
+                                     ('dot_product', False), ('luong_dot', False), ('luong_general', False),
+                                     ('luong_concat', False), ('bahdanau_content', True), ('luong_dot', True)])
+def test_attention_model_host_logic(monkeypatch, att, sig):
+    """Decoder loop, bridge, per-type query / key wiring, deferred d_enc, sigmoid-smoothing plumbing
+    (models/attention/attention_seq2seq.py) against the oracle's attention model."""
+    _cpu_ops.install(monkeypatch)
+    from oracle import attention as oatt
+    from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
+    rng = np.random.RandomState(11)
+    B, T, D, H, L, A, Em, C = 3, 9, 6, 8, 1, 10, 4, 6
+    U = 2 * H if att == 'luong_dot' else 12
+    x, sl, labels, lsl, _ = _att_batch(rng, B, T, D, C)
+    model = _mk_att(AttentionSeq2Seq, att, D, H, L, U, A, Em, C, sharpening_factor=1.5, logits_temperature=2.0,
+                    sigmoid_smoothing=sig)
+    sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    ref = oatt.attention_model_forward(sd, x, labels, sl, lsl, L, att, clip_enc=50.0, clip_dec=50.0, sharpening=1.5,
+                                       temperature=2.0, sigmoid_smoothing=sig)
+    loss, logits, out_train, out_infer = model.compute_loss(x, labels, sl, lsl, 1.0, 1.0, 1.0)
+    assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-5
+    assert np.abs(out_train.attention_weights.numpy() - ref['alphas']).max() < 1e-5
+    assert np.array_equal(out_train.predicted_ids.numpy(), ref['predicted_ids'])
+    opt = model._set_optimizer('adam', 1e-3)
+    for g, name in opt.compute_gradients(loss, model=model):
+        r = ref['grads'][name]
+        err = np.abs(g.numpy() - r).max()
+        assert err < 1e-4 * max(np.abs(r).max(), 1e-3) + 1e-7, (name, err, np.abs(r).max())
+    ref_ids = oatt.attention_model_infer(sd, x, sl, L, att, C, C + 1, 8, clip_enc=50.0, clip_dec=50.0, sharpening=1.5,
+                                         sigmoid_smoothing=sig)
+    assert np.array_equal(out_infer.predicted_ids.numpy(), ref_ids)
+
+
+def test_joint_ctc_attention_host_logic(monkeypatch):
+    _cpu_ops.install(monkeypatch)
+    from oracle import attention as oatt
+    from tensorflow_end2end_speech_recognition_amd.models.attention.joint_ctc_attention import JointCTCAttention
+    from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import list2sparsetensor
+    rng = np.random.RandomState(3)
+    B, T, D, H, L, U, A, Em, C = 4, 10, 6, 8, 2, 12, 10, 4, 5
+    x, sl, labels, lsl, ctc_labels = _att_batch(rng, B, T, D, C)
+    model = _mk_att(JointCTCAttention, 'bahdanau_content', D, H, L, U, A, Em, C, lambda_weight=0.5)
+    sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    ctc_list = [[int(v) for v in row if v >= 0] for row in ctc_labels]
+    ref = oatt.attention_model_forward(sd, x, labels, sl, lsl, L, 'bahdanau_content', clip_enc=50.0, clip_dec=50.0,
+                                       ctc_labels=ctc_list, lambda_weight=0.5)
+    loss, logits, ctc_logits, otr, oinf = model.compute_loss(x, labels, list2sparsetensor(ctc_labels, -1), sl, lsl,
+                                                             1.0, 1.0, 1.0)
+    assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-5
+    assert np.abs(ctc_logits.numpy() - ref['ctc_logits']).max() < 1e-5
+    opt = model._set_optimizer('adam', 1e-3)
+    for g, name in opt.compute_gradients(loss, model=model):
+        r = ref['grads'][name]
+        err = np.abs(g.numpy() - r).max()
+        assert err < 1e-4 * max(np.abs(r).max(), 1e-3) + 1e-7, (name, err)
+    first = last = None
+    for step in range(5):                                 # dropout paths + optimizer sequencing run
+        loss, *_ = model.compute_loss(x, labels, ctc_labels, sl, lsl, 0.9, 0.9, 0.9)
+        model.train(loss, 'adam', 5e-3)
+        first = loss.item() if first is None else first
+        last = loss.item()
+    assert last < first
