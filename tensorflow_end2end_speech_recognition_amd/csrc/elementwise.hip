@@ -350,6 +350,53 @@ __global__ void splice_kernel(const float* __restrict__ x, const int32_t* __rest
     out[i] = v;
   }
 }
+
+// Same result, laid out for the write stream that dominates (the output is splice x the input): the column ->
+// (window slot, offset inside the source frame) map is identical for every frame, so a workgroup builds it once
+// in LDS (the only integer divisions) and then emits SPLICE_FPB frames as 16-byte stores, four gathers each.
+constexpr int SPLICE_FPB = 8;
+__global__ __launch_bounds__(256) void splice_rows_kernel(const float* __restrict__ x,
+                                                          const int32_t* __restrict__ seq_len, int B, int T, int D,
+                                                          int splice, int num_stack, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char splice_smem[];
+  uint32_t* tab = reinterpret_cast<uint32_t*>(splice_smem);       // [row]: slot << 24 | offset, ~0 = stays zero
+  const int C = D / (3 * num_stack);
+  const int SJ = splice * num_stack;
+  const int row = C * SJ * 3;
+  for (int col = threadIdx.x; col < row; col += 256) {
+    const int k3 = col % 3, j = (col / 3) % SJ, c = col / (3 * SJ);
+    const int is = min(j, splice - 1), sidx = j - is;
+    tab[col] = sidx < num_stack ? ((uint32_t)is << 24) | (uint32_t)(c * 3 * num_stack + k3 * num_stack + sidx)
+                                : 0xffffffffu;
+  }
+  __syncthreads();
+  const size_t nf = (size_t)B * T;
+  const size_t f0 = (size_t)blockIdx.x * SPLICE_FPB;
+  for (size_t f = f0; f < f0 + SPLICE_FPB && f < nf; ++f) {
+    const int b = (int)(f / T), t = (int)(f % T);
+    const int len = min(max(seq_len[b], 0), T);
+    const float* xb = x + (size_t)b * T * D;
+    float* o = out + f * row;
+    const bool live = t < len;
+    for (int c4 = threadIdx.x * 4; c4 < row; c4 += 1024) {
+      const uint4 u = *reinterpret_cast<const uint4*>(tab + c4);
+      const uint32_t uu[4] = {u.x, u.y, u.z, u.w};
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = 0.f;
+        if (live && uu[e] != 0xffffffffu) {
+          const int is = (int)(uu[e] >> 24);
+          int src = t + is - splice;
+          if (t <= splice - 1 && is < splice - t) src = 0;
+          else if (len - splice <= t && src > len - 1) src = len - 1;
+          v[e] = xb[(size_t)src * D + (uu[e] & 0xffffffu)];
+        }
+      }
+      *reinterpret_cast<float4*>(o + c4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
 }  // namespace
 
 extern "C" int asr_stack_frames(asr_handle* h, const float* x, const int32_t* seq_len, int B, int T, int F,
@@ -376,8 +423,16 @@ extern "C" int asr_splice(asr_handle* h, const float* x, const int32_t* seq_len,
   ASR_NEED(D % (3 * num_stack) == 0, "asr_splice: frame width %d is not channels*3*num_stack", D);
   const size_t n = (size_t)B * T * D * splice;
   if (!n) return ASR_OK;
-  hipLaunchKernelGGL(splice_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, x, seq_len, B, T, D, splice,
-                     num_stack, out);
+  const size_t row = (size_t)D * splice;
+  if (row % 4 == 0 && row * sizeof(uint32_t) <= 48 * 1024 && splice < 256 && D < (1 << 24) &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const size_t nblk = ((size_t)B * T + SPLICE_FPB - 1) / SPLICE_FPB;
+    hipLaunchKernelGGL(splice_rows_kernel, dim3((unsigned)nblk), dim3(256), row * sizeof(uint32_t), (hipStream_t)s, x,
+                       seq_len, B, T, D, splice, num_stack, out);
+  } else {
+    hipLaunchKernelGGL(splice_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, x, seq_len, B, T, D, splice,
+                       num_stack, out);
+  }
   ASR_CHECK_LAUNCH(h, "asr_splice");
   return ASR_OK;
 }

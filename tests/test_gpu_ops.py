@@ -509,6 +509,10 @@ def test_dropout_mask(cuda):
     (29, 1, 2, 2, 5),       # both; D = 3*num_stack per channel
     (6, 2, 3, 2, 11),       # utterances shorter than the splice window
     (1, 1, 1, 1, 3),        # single frame
+    (33, 4, 1, 1, 11),      # row width % 4 == 0: the LDS-table / 16-byte-store kernel
+    (50, 40, 1, 1, 11),     # the VGG recipe's real frame: 40 channels x 3, splice 11
+    (29, 4, 2, 2, 5),       # vector kernel with stacked frames
+    (5, 4, 3, 3, 11),       # vector kernel, utterances shorter than the window, slots that stay zero
 ])
 def test_device_batch_assembly(cuda, T, F, num_stack, num_skip, splice):
     """asr_stack_frames + asr_splice through utils/io/inputs/device.py assemble(): bit-exact against the host
