@@ -1,0 +1,57 @@
+"""Dataset for the CTC model on TIMIT -- mirror of examples/timit/data/load_dataset_ctc.py:18-96.
+
+Directory layout of the reference's feature extraction: <root>/inputs/<data_type>/{frame_num.pickle, <utt>.npy}
+and <root>/labels/<data_type>/<label_type>/<utt>.npy.  The reference hard-codes two site paths (:66-67); here the
+root comes from the `dataset_root` argument or $TIMIT_DATASET_ROOT, then those two paths."""
+import os
+import pickle
+from os.path import isfile, join
+
+import numpy as np
+
+from tensorflow_end2end_speech_recognition_amd.utils.dataset.ctc import DatasetBase
+
+DEFAULT_ROOTS = ['/data/inaguma/timit', '/n/sd8/inaguma/corpus/timit/dataset']
+
+
+class Dataset(DatasetBase):
+
+    def __init__(self, data_type, label_type, batch_size, max_epoch=None, splice=1, num_stack=1, num_skip=1,
+                 shuffle=False, sort_utt=False, sort_stop_epoch=None, progressbar=False, dataset_root=None,
+                 device_assembly=False):
+        super(Dataset, self).__init__()
+        self.is_test = data_type == 'test'
+        self.data_type, self.label_type = data_type, label_type
+        self.batch_size, self.max_epoch = batch_size, max_epoch
+        self.splice, self.num_stack, self.num_skip = splice, num_stack, num_skip
+        self.shuffle, self.sort_utt, self.sort_stop_epoch = shuffle, sort_utt, sort_stop_epoch
+        self.progressbar = progressbar
+        self.num_gpu = 1
+        self.device_assembly = device_assembly
+        roots = [r for r in [dataset_root, os.environ.get('TIMIT_DATASET_ROOT')] if r] + DEFAULT_ROOTS
+        for root in roots:
+            input_path = join(root, 'inputs', data_type)
+            if isfile(join(input_path, 'frame_num.pickle')):
+                break
+        else:
+            raise IOError('frame_num.pickle not found under any of %s (inputs/%s/)' % (roots, data_type))
+        label_path = join(root, 'labels', data_type, label_type)
+        with open(join(input_path, 'frame_num.pickle'), 'rb') as f:
+            self.frame_num_dict = pickle.load(f)
+        # sorted by utterance name, or by frame count when sort_utt (:83-85)
+        axis = 1 if sort_utt else 0
+        input_paths, label_paths = [], []
+        for input_name, frame_num in sorted(self.frame_num_dict.items(), key=lambda x: x[axis]):
+            input_paths.append(join(input_path, input_name + '.npy'))
+            label_paths.append(join(label_path, input_name + '.npy'))
+        self.input_paths = np.array(input_paths)
+        self.label_paths = np.array(label_paths)
+        self.rest = set(range(len(self.input_paths)))
+
+    def _load(self, paths, indices):
+        # test-set labels are stored as strings (phones / transcript), everything else as arrays
+        out = []
+        for p in (paths[i] for i in indices):
+            a = np.load(p, allow_pickle=True)
+            out.append(a.item() if a.ndim == 0 else a)           # a stored string comes back as a 0-d array
+        return out

@@ -274,3 +274,37 @@ def test_end_to_end_recipe_on_synthetic_corpus(cuda, tmp_path):
                 clip_activation=50, dtype='bf16', seed=99)
     Saver().restore(fresh, out['checkpoint'])
     assert abs(mod.evaluate(fresh, out['dev']) - out['best']) < 1e-6
+
+
+def test_timit_recipe_on_generated_corpus(cuda, tmp_path):
+    """examples/timit/training/train_ctc.py + evaluation/eval_ctc.py on the HIP path (bf16 operands): the run
+    trains to a dev PER far below the start, writes the reference's run-directory files, and the evaluation script
+    reproduces the test PER from the checkpoint.  (The same flow runs on CPU stand-ins in tests/test_host_logic.py.)"""
+    import os
+    import sys
+    import yaml
+    from _corpus import make_timit_like
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from examples.timit.training import train_ctc
+    from examples.timit.evaluation import eval_ctc
+    corpus = str(tmp_path / 'corpus')
+    make_timit_like(corpus, np.random.RandomState(0), n_train=64, n_dev=8, n_test=6, feat=12)
+    with open(os.path.join(root, 'examples/timit/config/ctc/blstm_ctc_phone61.yml')) as f:
+        cfg = yaml.safe_load(f)
+    cfg['param'].update(input_size=12, num_units=64, num_layers=2, batch_size=16, num_epoch=10, eval_start_epoch=1,
+                        print_step=4, optimizer='adam', learning_rate=0.01, dropout=0.1, decay_start_epoch=5,
+                        dtype='bf16', dataset_root=corpus, sort_stop_epoch=2)
+    cfg_path = str(tmp_path / 'cfg.yml')
+    with open(cfg_path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    res = train_ctc.main(cfg_path, str(tmp_path / 'runs'))
+    run = res['save_path']
+    for name in ('config.yml', 'train.log', 'complete.txt', 'loss.csv', 'ler.csv', 'checkpoint'):
+        assert os.path.isfile(os.path.join(run, name)), name
+    assert len(res['ler_dev']) == 10 and min(res['ler_dev']) < 0.5, res['ler_dev']
+    per = eval_ctc.main([run, '--beam_width', '1'])
+    assert abs(per - res['ler_test']) < 1e-9
+    per_beam = eval_ctc.main([run, '--beam_width', '8'])
+    assert 0.0 <= per_beam < 2.0

@@ -2,6 +2,9 @@
 torch/oracle stand-ins of tests/_cpu_ops.py, and compared with the oracle's end-to-end models.  What this pins is
 the Python side -- which tensors are fed to which GEMM, how weight / bias / peephole gradients are assembled from
 the BPTT output, the head and loss composition, the clip -> optimizer sequence -- not kernel numerics (GPU tests)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -206,3 +209,51 @@ def test_joint_ctc_attention_host_logic(monkeypatch):
         first = loss.item() if first is None else first
         last = loss.item()
     assert last < first
+
+
+from _corpus import make_timit_like as _make_timit_like          # noqa: E402
+
+
+def test_timit_recipe_end_to_end_on_cpu_stand_ins(monkeypatch, tmp_path):
+    """examples/timit/training/train_ctc.py + evaluation/eval_ctc.py on a generated corpus in the reference's
+    directory layout: dataset -> train -> print_step logging -> per-epoch PER on 39 phones -> checkpoint on a new
+    best -> test-set PER -> LR controller -> run-directory bookkeeping; then the evaluation script restores the
+    checkpoint and reproduces the test PER."""
+    import os
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    _cpu_ops.install(monkeypatch)
+    from examples.timit.training import train_ctc
+    from examples.timit.evaluation import eval_ctc
+    corpus = str(tmp_path / 'corpus')
+    _make_timit_like(corpus, np.random.RandomState(0))
+    with open(os.path.join(root, 'examples/timit/config/ctc/blstm_ctc_phone61.yml')) as f:
+        cfg = yaml.safe_load(f)
+    cfg['param'].update(input_size=6, num_units=8, num_layers=1, batch_size=8, num_epoch=14, eval_start_epoch=1,
+                        print_step=5, optimizer='adam', learning_rate=0.05, dropout=0.0, weight_decay=0,
+                        decay_start_epoch=2, dtype='f32', device='cpu', dataset_root=corpus, sort_stop_epoch=2)
+    cfg_path = str(tmp_path / 'cfg.yml')
+    with open(cfg_path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    res = train_ctc.main(cfg_path, str(tmp_path / 'runs'))
+    run = res['save_path']
+    assert run.endswith(os.path.join('ctc', 'phone61', 'blstm_ctc_8_1_adam_lr0.05'))
+    for name in ('config.yml', 'train.log', 'complete.txt', 'loss.csv', 'ler.csv', 'checkpoint',
+                 os.path.join('mapping_files', 'phone2phone.txt')):
+        assert os.path.isfile(os.path.join(run, name)), name
+    assert len(res['ler_dev']) == 14 and res['checkpoints'] and res['ler_test'] is not None
+    assert all(0.0 <= v for v in res['ler_dev']) and min(res['ler_dev']) < 0.5
+    log = open(os.path.join(run, 'train.log')).read()
+    assert 'Total 12 variables' in log and '-----EPOCH:14' in log and 'PER:' in log and 'Model saved in file' in log
+    # a second run never reuses the directory
+    cfg['param']['num_epoch'] = 1
+    with open(cfg_path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    res2 = train_ctc.main(cfg_path, str(tmp_path / 'runs'))
+    assert res2['save_path'] == run + '_1'
+    # evaluation script: latest checkpoint of the first run == its last best epoch
+    per = eval_ctc.main([run, '--beam_width', '1', '--device', 'cpu'])
+    assert abs(per - res['ler_test']) < 1e-9
