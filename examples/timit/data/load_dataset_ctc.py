@@ -47,11 +47,3 @@ class Dataset(DatasetBase):
         self.input_paths = np.array(input_paths)
         self.label_paths = np.array(label_paths)
         self.rest = set(range(len(self.input_paths)))
-
-    def _load(self, paths, indices):
-        # test-set labels are stored as strings (phones / transcript), everything else as arrays
-        out = []
-        for p in (paths[i] for i in indices):
-            a = np.load(p, allow_pickle=True)
-            out.append(a.item() if a.ndim == 0 else a)           # a stored string comes back as a 0-d array
-        return out

@@ -16,6 +16,8 @@ Produces
   splice_v1.npz   : inputs/outputs of utils/io/inputs/splicing.py do_splice and
       utils/io/inputs/frame_stacking.py stack_frame.
   labels_v1.json  : outputs of the label maps (utils/io/labels/*.py), Map2phone39 and compute_wer.
+  datasets_v1.npz : every batch the reference's four DatasetBase iterators (utils/dataset/*.py) yield on a small
+      generated corpus (numpy < 1.24 ragged-array semantics restored by a shim, see _OldNumpy).
 """
 import os
 import sys
@@ -162,9 +164,122 @@ def make_labels():
     print('labels_v1.json written')
 
 
+class _OldNumpy(types.ModuleType):
+    """numpy as the reference saw it (< 1.24): np.array() of a ragged list gives an object array instead of raising.
+    Injected as `np` into the reference's dataset modules only."""
+
+    def __init__(self):
+        super(_OldNumpy, self).__init__('numpy_compat')
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    def array(self, obj, *a, **k):
+        try:
+            return np.array(obj, *a, **k)
+        except ValueError:
+            seq = list(obj)
+            out = np.empty(len(seq), dtype=object)
+            for i, v in enumerate(seq):
+                out[i] = v
+            return out
+
+
+def make_datasets():
+    """Batches produced by the reference's OWN iterators (utils/dataset/{ctc,attention,joint_ctc_attention,
+    multitask_ctc}.py DatasetBase.__next__) on a small generated corpus of .npy files, with `random` seeded, for
+    every sampling mode (sorted window / shuffle / sequential), splice + stacking, 1 and 2 GPUs and the test-set
+    (string label) path.  Stored: the corpus itself and, per configuration, every array of every batch."""
+    import random
+    import tempfile
+    sys.path.insert(0, REF)
+    import utils.io.inputs.frame_stacking as fs
+    import utils.dataset.ctc as dctc
+    import utils.dataset.attention as datt
+    import utils.dataset.joint_ctc_attention as djoint
+    import utils.dataset.multitask_ctc as dmulti
+    shim = _OldNumpy()
+    for m in (fs, dctc, datt, djoint, dmulti):
+        m.np = shim
+    rng = np.random.RandomState(42)
+    tmp = tempfile.mkdtemp()
+    N = 11
+    feats = [rng.randn(rng.randint(4, 15), 6).astype(np.float32) for _ in range(N)]
+    labs = [rng.randint(0, 9, size=rng.randint(1, 5)).astype(np.int32) for _ in range(N)]
+    subs = [rng.randint(0, 4, size=rng.randint(1, 4)).astype(np.int32) for _ in range(N)]
+    strs = [' '.join('p%d' % v for v in l) for l in labs]
+    order = np.argsort([f.shape[0] for f in feats], kind='stable')        # subclasses list utterances by length
+    paths = dict(inp=[], lab=[], sub=[], txt=[])
+    for rank, i in enumerate(order):
+        for key, arr in (('inp', feats[i]), ('lab', labs[i]), ('sub', subs[i]), ('txt', np.array(strs[i]))):
+            pth = os.path.join(tmp, '%s_%02d.npy' % (key, rank))
+            np.save(pth, arr)
+            paths[key].append(pth)
+    out = dict(corpus_order=order)
+    for i in range(N):
+        out['feat_%d' % i], out['lab_%d' % i], out['sub_%d' % i] = feats[i], labs[i], subs[i]
+    out['strs'] = np.array(strs)
+    eos_sos = {'<': 9, '>': 10}
+
+    def make(cls, kind, cfg):
+        class DS(cls):
+            def __init__(self):
+                super(DS, self).__init__()
+                self.map_dict = dict(eos_sos)
+                self.input_paths = np.array(paths['inp'])
+                lab_key = 'txt' if cfg['is_test'] else 'lab'
+                if kind == 'multitask':
+                    self.label_main_paths = np.array(paths[lab_key])
+                    self.label_sub_paths = np.array(paths['sub'])
+                else:
+                    self.label_paths = np.array(paths[lab_key])
+                self.batch_size = cfg['batch_size'] * cfg['num_gpu']
+                self.splice, self.num_stack, self.num_skip = cfg['splice'], cfg['num_stack'], cfg['num_skip']
+                self.shuffle, self.sort_utt, self.sort_stop_epoch = cfg['shuffle'], cfg['sort_utt'], cfg['sort_stop']
+                self.num_gpu, self.is_test, self.max_epoch = cfg['num_gpu'], cfg['is_test'], cfg['max_epoch']
+                self.progressbar = False
+                self.rest = set(range(N))
+        return DS()
+
+    cfgs = [
+        dict(batch_size=3, num_gpu=1, splice=1, num_stack=1, num_skip=1, shuffle=False, sort_utt=True, sort_stop=1,
+             is_test=False, max_epoch=3),
+        dict(batch_size=4, num_gpu=1, splice=3, num_stack=2, num_skip=2, shuffle=True, sort_utt=False, sort_stop=None,
+             is_test=False, max_epoch=2),
+        dict(batch_size=2, num_gpu=2, splice=1, num_stack=3, num_skip=3, shuffle=False, sort_utt=False, sort_stop=None,
+             is_test=False, max_epoch=2),
+        dict(batch_size=1, num_gpu=1, splice=1, num_stack=1, num_skip=1, shuffle=False, sort_utt=False, sort_stop=None,
+             is_test=True, max_epoch=1),
+    ]
+    kinds = [('ctc', dctc.DatasetBase), ('attention', datt.DatasetBase), ('joint', djoint.DatasetBase),
+             ('multitask', dmulti.DatasetBase)]
+    import json
+    meta = []
+    warnings.simplefilter('ignore')
+    for kind, cls in kinds:
+        for ci, cfg in enumerate(cfgs):
+            random.seed(100 + ci)
+            ds = make(cls, kind, cfg)
+            nb = 0
+            for data, is_new_epoch in ds:
+                for fi, field in enumerate(data):
+                    for gi in range(cfg['num_gpu']):
+                        a = np.asarray(field[gi])
+                        if a.dtype == object or a.dtype.kind in 'US':
+                            a = np.array([str(v) for v in a.ravel()]).reshape(a.shape)
+                        out['%s_c%d_b%d_f%d_g%d' % (kind, ci, nb, fi, gi)] = a
+                out['%s_c%d_b%d_new' % (kind, ci, nb)] = np.array(bool(is_new_epoch))
+                nb += 1
+            meta.append(dict(kind=kind, cfg=ci, num_batches=nb, num_fields=len(data), epoch=int(ds.epoch)))
+    out['meta'] = np.array(json.dumps(dict(cfgs=cfgs, runs=meta, sos=9, eos=10)))
+    np.savez_compressed(os.path.join(HERE, 'datasets_v1.npz'), **out)
+    print('datasets_v1.npz:', len(meta), 'runs,', sum(m['num_batches'] for m in meta), 'batches')
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('needs %s (build container only)' % REF)
     make_decoders()
     make_splice()
     make_labels()
+    make_datasets()

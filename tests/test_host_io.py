@@ -269,3 +269,94 @@ def test_dataset_device_assembly_yields_raw_features():
             T = feats[i].shape[0]
             assert sd[0][r] == T and sh[0][r] == -(-T // 2)
             assert np.array_equal(xd[0][r, :T], feats[i].astype(np.float32)) and not xd[0][r, T:].any()
+
+
+def test_generated_mapping_files_match_reference_tables(tmp_path):
+    """examples/timit/metrics/mapping_files.py writes the token tables instead of shipping the reference's files;
+    every generated table equals the one read from the reference's own mapping file (labels_v1.json), and
+    Map2phone39 on the generated phone2phone.txt folds like the reference's class on its file."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from examples.timit.metrics.mapping_files import write_mapping_files
+    from examples.timit.metrics.mapping import Map2phone39
+    g = _golden_labels()
+    d = write_mapping_files(str(tmp_path / 'maps'))
+    for lt in ('phone61', 'phone48', 'phone39'):
+        rows = [l.split() for l in open(os.path.join(d, lt + '.txt'))]
+        assert [r[0] for r in rows] == g[lt + '_table'] and [int(r[1]) for r in rows] == list(range(len(rows)))
+    for name in ('character', 'character_capital_divide'):
+        rows = [l.split() for l in open(os.path.join(d, name + '.txt'))]
+        assert [[r[0], int(r[1])] for r in rows] == g[name + '_table']
+    for lt in ('phone61', 'phone48'):
+        m = Map2phone39(lt, os.path.join(d, 'phone2phone.txt'))
+        for ph, want in g[lt + '_to39_table']:
+            assert m([ph]) == want
+
+
+@pytest.mark.parametrize('kind', ['ctc', 'attention', 'joint', 'multitask'])
+def test_dataset_iterators_match_reference_batches(tmp_path, kind):
+    """utils/dataset/{ctc,attention,joint_ctc_attention,multitask_ctc}.py: every array of every batch equals what
+    the reference's own DatasetBase.__next__ produced on the same corpus with the same `random` seed
+    (tests/golden/datasets_v1.npz: sorted-window / shuffle / sequential sampling, splice + stacking, 2-GPU split,
+    string labels of the test set)."""
+    import importlib
+    import json
+    import random
+    z = np.load(os.path.join(GOLD, 'datasets_v1.npz'), allow_pickle=False)
+    meta = json.loads(str(z['meta']))
+    order = z['corpus_order']
+    N = len(order)
+    strs = z['strs']
+    paths = dict(inp=[], lab=[], sub=[], txt=[])
+    for rank, i in enumerate(order):
+        for key, arr in (('inp', z['feat_%d' % i]), ('lab', z['lab_%d' % i]), ('sub', z['sub_%d' % i]),
+                         ('txt', np.array(str(strs[i])))):
+            pth = str(tmp_path / ('%s_%02d.npy' % (key, rank)))
+            np.save(pth, arr)
+            paths[key].append(pth)
+    mod = importlib.import_module('tensorflow_end2end_speech_recognition_amd.utils.dataset.' +
+                                  dict(ctc='ctc', attention='attention', joint='joint_ctc_attention',
+                                       multitask='multitask_ctc')[kind])
+
+    def make(cfg):
+        class DS(mod.DatasetBase):
+            def __init__(self):
+                super(DS, self).__init__()
+                self.map_dict = {'<': meta['sos'], '>': meta['eos']}
+                self.input_paths = np.array(paths['inp'])
+                lab_key = 'txt' if cfg['is_test'] else 'lab'
+                if kind == 'multitask':
+                    self.label_main_paths = np.array(paths[lab_key])
+                    self.label_sub_paths = np.array(paths['sub'])
+                else:
+                    self.label_paths = np.array(paths[lab_key])
+                self.batch_size = cfg['batch_size'] * cfg['num_gpu']
+                self.splice, self.num_stack, self.num_skip = cfg['splice'], cfg['num_stack'], cfg['num_skip']
+                self.shuffle, self.sort_utt, self.sort_stop_epoch = cfg['shuffle'], cfg['sort_utt'], cfg['sort_stop']
+                self.num_gpu, self.is_test, self.max_epoch = cfg['num_gpu'], cfg['is_test'], cfg['max_epoch']
+                self.rest = set(range(N))
+        return DS()
+
+    runs = [r for r in meta['runs'] if r['kind'] == kind]
+    assert len(runs) == len(meta['cfgs'])
+    for run in runs:
+        cfg = meta['cfgs'][run['cfg']]
+        random.seed(100 + run['cfg'])
+        ds = make(cfg)
+        nb = 0
+        for data, is_new_epoch in ds:
+            assert len(data) == run['num_fields']
+            assert bool(z['%s_c%d_b%d_new' % (kind, run['cfg'], nb)]) == bool(is_new_epoch)
+            for fi, field in enumerate(data):
+                assert len(field) == cfg['num_gpu']
+                for gi in range(cfg['num_gpu']):
+                    want = z['%s_c%d_b%d_f%d_g%d' % (kind, run['cfg'], nb, fi, gi)]
+                    got = np.asarray(field[gi])
+                    if want.dtype.kind in 'US':
+                        got = np.array([str(v) for v in got.ravel()]).reshape(got.shape)
+                    assert got.shape == want.shape, (run, nb, fi, got.shape, want.shape)
+                    assert np.array_equal(got, want), (run, nb, fi)
+            nb += 1
+        assert nb == run['num_batches'] and ds.epoch == run['epoch']
