@@ -16,6 +16,8 @@ Produces
   splice_v1.npz   : inputs/outputs of utils/io/inputs/splicing.py do_splice and
       utils/io/inputs/frame_stacking.py stack_frame.
   labels_v1.json  : outputs of the label maps (utils/io/labels/*.py), Map2phone39 and compute_wer.
+  controller_v1.json : learning-rate trajectories of utils/training/learning_rate_controller.py Controller.
+  sparsetensor_v1.json : list2sparsetensor / sparsetensor2list of utils/io/labels/sparsetensor.py.
   datasets_v1.npz : every batch the reference's four DatasetBase iterators (utils/dataset/*.py) yield on a small
       generated corpus (numpy < 1.24 ragged-array semantics restored by a shim, see _OldNumpy).
 """
@@ -164,6 +166,62 @@ def make_labels():
     print('labels_v1.json written')
 
 
+def make_controller():
+    """Learning-rate trajectories of the reference's utils/training/learning_rate_controller.py Controller on seeded
+    score sequences (both directions, patience 0-3, different start epochs)."""
+    import json
+    sys.path.insert(0, REF)
+    from utils.training.learning_rate_controller import Controller
+    rng = np.random.RandomState(7)
+    runs = []
+    for lower_better in (True, False):
+        for patient in (0, 1, 2, 3):
+            for start in (1, 3, 6):
+                vals = np.round(np.abs(np.cumsum(rng.randn(25) * 0.05) + (0.8 if lower_better else 0.3)), 4).tolist()
+                c = Controller(learning_rate_init=1e-3, decay_start_epoch=start, decay_rate=0.5 + 0.1 * patient,
+                               decay_patient_epoch=patient, lower_better=lower_better,
+                               worst_value=1 if lower_better else 0)
+                lr, traj = 1e-3, []
+                for ep, v in enumerate(vals, 1):
+                    lr = c.decay_lr(learning_rate=lr, epoch=ep, value=v)
+                    traj.append(lr)
+                runs.append(dict(lower_better=lower_better, patient=patient, start=start, rate=0.5 + 0.1 * patient,
+                                 worst=1 if lower_better else 0, values=vals, lrs=traj))
+    with open(os.path.join(HERE, 'controller_v1.json'), 'w') as f:
+        json.dump(runs, f)
+    print('controller_v1.json:', len(runs), 'runs')
+
+
+def make_sparsetensor():
+    """utils/io/labels/sparsetensor.py list2sparsetensor / sparsetensor2list (tensorflow stubbed: only
+    tf.SparseTensorValue is touched, in an isinstance check) on seeded padded label batches."""
+    import json
+    sys.path.insert(0, REF)
+    if 'tensorflow' not in sys.modules:
+        tf = types.ModuleType('tensorflow')
+        tf.SparseTensorValue = type('SparseTensorValue', (), {})
+        sys.modules['tensorflow'] = tf
+    elif not hasattr(sys.modules['tensorflow'], 'SparseTensorValue'):
+        sys.modules['tensorflow'].SparseTensorValue = type('SparseTensorValue', (), {})
+    from utils.io.labels.sparsetensor import list2sparsetensor, sparsetensor2list
+    rng = np.random.RandomState(3)
+    cases = []
+    for B in (1, 2, 5, 16):
+        for rep in range(3):
+            lens = rng.randint(1, 9, size=B)
+            dense = np.full((B, int(lens.max()) + rep), -1, dtype=np.int64)
+            for b in range(B):
+                dense[b, :lens[b]] = rng.randint(0, 40, size=lens[b])
+            st = list2sparsetensor(dense, padded_value=-1)
+            back = sparsetensor2list(st, B)
+            cases.append(dict(dense=dense.tolist(), indices=st[0].tolist(), values=st[1].tolist(),
+                              values_dtype=str(st[1].dtype), shape=st[2].tolist(),
+                              back=[np.asarray(r).tolist() for r in back]))
+    with open(os.path.join(HERE, 'sparsetensor_v1.json'), 'w') as f:
+        json.dump(cases, f)
+    print('sparsetensor_v1.json:', len(cases), 'cases')
+
+
 class _OldNumpy(types.ModuleType):
     """numpy as the reference saw it (< 1.24): np.array() of a ragged list gives an object array instead of raising.
     Injected as `np` into the reference's dataset modules only."""
@@ -283,3 +341,5 @@ if __name__ == '__main__':
     make_splice()
     make_labels()
     make_datasets()
+    make_controller()
+    make_sparsetensor()

@@ -65,6 +65,34 @@ def test_lr_controller():
     assert got == [1e-3, 1e-3, 1e-3, 5e-4, 5e-4, 5e-4, 2.5e-4]
 
 
+def test_lr_controller_matches_reference_trajectories():
+    """24 learning-rate trajectories recorded from the reference's own Controller (controller_v1.json)."""
+    import json
+    from tensorflow_end2end_speech_recognition_amd.utils.training.learning_rate_controller import Controller
+    for run in json.load(open(os.path.join(GOLD, 'controller_v1.json'))):
+        c = Controller(learning_rate_init=1e-3, decay_start_epoch=run['start'], decay_rate=run['rate'],
+                       decay_patient_epoch=run['patient'], lower_better=run['lower_better'], worst_value=run['worst'])
+        lr, got = 1e-3, []
+        for ep, v in enumerate(run['values'], 1):
+            lr = c.decay_lr(learning_rate=lr, epoch=ep, value=v)
+            got.append(lr)
+        assert got == run['lrs'], run
+
+
+def test_sparsetensor_helpers_match_reference():
+    """list2sparsetensor / sparsetensor2list against outputs of the reference's own functions
+    (sparsetensor_v1.json), incl. the batch_size == 1 reshape and the value dtype."""
+    import json
+    from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import list2sparsetensor, sparsetensor2list
+    for c in json.load(open(os.path.join(GOLD, 'sparsetensor_v1.json'))):
+        dense = np.asarray(c['dense'], dtype=np.int64)
+        st = list2sparsetensor(dense, padded_value=-1)
+        assert st[0].tolist() == c['indices'] and st[1].tolist() == c['values'] and st[2].tolist() == c['shape']
+        assert str(st[1].dtype) == c['values_dtype'] and st[0].dtype == np.int64 and st[2].dtype == np.int64
+        back = sparsetensor2list(st, len(dense))
+        assert [np.asarray(r).tolist() for r in back] == c['back']
+
+
 def test_saver_roundtrip(tmp_path):
     """Saver.save / get_checkpoint_state / restore with the recipes' call shape (train_ctc.py:220-223,
     eval_ctc.py:74-86): TF variable names, `model.ckpt-<epoch>` prefixes, `checkpoint` index file."""
