@@ -1,0 +1,101 @@
+"""CER / WER evaluation loops of the Librispeech recipe -- mirror of examples/librispeech/metrics/ctc.py:20-145
+(do_eval_cer) and :277-380 (do_eval_wer) for the eager model.  `session` / `decode_ops` are accepted for call
+compatibility and ignored; every shard of a batch ([num_gpu][B,...], as the iterator yields them) is decoded on the
+model's device in turn.  Scoring as there: only apostrophes are stripped (:100-101), '_' separates words."""
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from tensorflow_end2end_speech_recognition_amd.utils.io.labels.character import Idx2char              # noqa: E402
+from tensorflow_end2end_speech_recognition_amd.utils.io.labels.word import Idx2word                    # noqa: E402
+from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import sparsetensor2list  # noqa: E402
+from tensorflow_end2end_speech_recognition_amd.utils.evaluation.edit_distance import compute_cer, compute_wer  # noqa: E402
+
+
+def _decode_shards(model, inputs, inputs_seq_len, beam_width):
+    """-> per shard, the list of decoded index arrays."""
+    out = []
+    for x, sl in zip(inputs, inputs_seq_len):
+        B = len(x)
+        if B == 0:
+            out.append([])
+            continue
+        _, logits = model.compute_loss(x, np.zeros((B, 1), dtype=np.int64), sl, keep_prob=1.0, is_training=False)
+        dec = model.decoder(logits, sl, beam_width=beam_width)
+        out.append([np.asarray(h, dtype=np.int64) for h in sparsetensor2list(dec, B)])
+    return out
+
+
+def do_eval_cer(session, decode_ops, model, dataset, label_type, is_test=False, eval_batch_size=None,
+                progressbar=False, is_multitask=False, map_dir=None, beam_width=1):
+    """-> (mean CER, mean WER)."""
+    map_dir = map_dir or '../metrics/mapping_files'
+    batch_size_original = dataset.batch_size
+    dataset.reset()
+    if eval_batch_size is not None:
+        dataset.batch_size = eval_batch_size
+    if label_type == 'character':
+        idx2char = Idx2char(os.path.join(map_dir, 'character.txt'))
+    elif label_type == 'character_capital_divide':
+        idx2char = Idx2char(os.path.join(map_dir, 'character_capital_divide.txt'), capital_divide=True, space_mark='_')
+    else:
+        raise TypeError
+    cer_sum = wer_sum = 0.0
+    for data, is_new_epoch in dataset:
+        if is_multitask:
+            inputs, _, labels_true, inputs_seq_len, _ = data
+        else:
+            inputs, labels_true, inputs_seq_len, _ = data
+        for i_device, hyps in enumerate(_decode_shards(model, inputs, inputs_seq_len, beam_width)):
+            for b in range(len(hyps)):
+                if is_test:
+                    str_true = labels_true[i_device][b][0]
+                else:
+                    str_true = idx2char(labels_true[i_device][b], padded_value=dataset.padded_value)
+                str_pred = re.sub(r'[_]+', '_', idx2char(hyps[b]))
+                str_true = re.sub(r'[\']+', '', str_true)
+                str_pred = re.sub(r'[\']+', '', str_pred)
+                wer_sum += compute_wer(ref=str_true.split('_'), hyp=str_pred.split('_'), normalize=True)
+                cer_sum += compute_cer(str_pred=re.sub(r'[_]+', '', str_pred), str_true=re.sub(r'[_]+', '', str_true),
+                                       normalize=True)
+        if is_new_epoch:
+            break
+    if eval_batch_size is not None:
+        dataset.batch_size = batch_size_original
+    return cer_sum / len(dataset), wer_sum / len(dataset)
+
+
+def do_eval_wer(session, decode_ops, model, dataset, train_data_size, is_test=False, eval_batch_size=None,
+                progressbar=False, is_multitask=False, map_dir=None, beam_width=1):
+    """Word-level targets (:277-380): mean WER over the set."""
+    map_dir = map_dir or '../metrics/mapping_files'
+    batch_size_original = dataset.batch_size
+    dataset.reset()
+    if eval_batch_size is not None:
+        dataset.batch_size = eval_batch_size
+    idx2word = Idx2word(os.path.join(map_dir, 'word_' + train_data_size + '.txt'))
+    wer_sum = 0.0
+    for data, is_new_epoch in dataset:
+        if is_multitask:
+            inputs, labels_true, _, inputs_seq_len, _ = data
+        else:
+            inputs, labels_true, inputs_seq_len, _ = data
+        for i_device, hyps in enumerate(_decode_shards(model, inputs, inputs_seq_len, beam_width)):
+            for b in range(len(hyps)):
+                if is_test:
+                    str_true = labels_true[i_device][b][0]
+                else:
+                    str_true = '_'.join(idx2word(labels_true[i_device][b]))
+                str_pred = '_'.join(idx2word(hyps[b]))
+                wer_sum += compute_wer(ref=str_true.split('_'), hyp=str_pred.split('_'), normalize=True)
+        if is_new_epoch:
+            break
+    if eval_batch_size is not None:
+        dataset.batch_size = batch_size_original
+    return wer_sum / len(dataset)

@@ -42,6 +42,9 @@ class DatasetBase(Base):
             batch_size = self.batch_size
         if self.is_new_epoch:
             self.is_new_epoch = False
+        # the reference draws from the global `random`; a dataset may carry its own generator (`self.rng`, a
+        # random.Random) so that data-parallel ranks keep sampling the same global batches whatever else runs
+        rnd = getattr(self, 'rng', None) or random
         if self.sort_utt:
             if len(self.rest) > batch_size:
                 data_indices = sorted(list(self.rest))[:batch_size]
@@ -54,17 +57,17 @@ class DatasetBase(Base):
                 if self.epoch == self.sort_stop_epoch:
                     self.sort_utt = False
                     self.shuffle = True
-            random.shuffle(data_indices)
+            rnd.shuffle(data_indices)
         elif self.shuffle:
             if len(self.rest) > batch_size:
-                data_indices = random.sample(list(self.rest), batch_size)
+                data_indices = rnd.sample(list(self.rest), batch_size)
                 self.rest -= set(data_indices)
             else:
                 data_indices = list(self.rest)
                 self.reset()
                 self.is_new_epoch = True
                 self.epoch += 1
-                random.shuffle(data_indices)
+                rnd.shuffle(data_indices)
         else:
             if len(self.rest) > batch_size:
                 data_indices = sorted(list(self.rest))[:batch_size]

@@ -62,3 +62,44 @@ def split_batch(arrays, num_gpu):
     """utils/dataset/ctc.py:171-182: np.array_split of every batch tensor along axis 0."""
     import numpy as np
     return [np.array_split(a, num_gpu, axis=0) for a in arrays]
+
+
+def init_process_group(device):
+    """One process per GPU: join the job `python -m torch.distributed.run` started (RANK / WORLD_SIZE / MASTER_* in
+    the environment).  RCCL ("nccl") for a GPU device, gloo for a CPU one (tests).  Returns (rank, world)."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        device = torch.device(device)
+        if device.type == 'cuda':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+    return rank, world
+
+
+def tower_step(model, optimizer, inputs, labels, inputs_seq_len, keep_prob, learning_rate=None):
+    """One synchronous data-parallel step of THIS rank's tower -- the body of the tower loop of
+    examples/librispeech/training/train_ctc.py:82-147 plus its apply_gradients:
+    compute_loss -> compute_gradients -> per-variable clip_by_norm (:116, before the mean) -> mean over towers
+    (utils/training/multi_gpu.py:13-48) -> the identical optimizer update on every rank.
+    A rank whose shard of the global batch is empty (np.array_split of a short last batch; the reference does not
+    guard this) contributes zero gradients and loss 0 -- it must still take part in the collective.
+    Returns (loss averaged over towers, this tower's logits or None)."""
+    B = len(inputs)
+    logits = None
+    if B > 0:
+        loss, logits = model.compute_loss(inputs, labels, inputs_seq_len, keep_prob)
+        gv = optimizer.compute_gradients(loss, model=model)
+        if model.clip_grad_norm is not None:
+            model._clip_gradients(gv)
+        loss = loss.detach()
+    else:
+        model.store.grad.zero_()
+        loss = torch.zeros((), dtype=torch.float32, device=model.store.flat.device)
+    average_gradients(model.store)
+    optimizer.apply_gradients(None, learning_rate=learning_rate)
+    return average_scalar(loss), logits

@@ -33,3 +33,34 @@ def make_timit_like(root, rng, n_train=24, n_dev=6, n_test=4, feat=6):
             frame_num[name] = x.shape[0]
         with open(os.path.join(root, 'inputs', data_type, 'frame_num.pickle'), 'wb') as f:
             pickle.dump(frame_num, f)
+
+
+def make_librispeech_like(root, rng, n_train=12, n_other=4, feat=6, size='train100h'):
+    """<root>/inputs/<size>/<data_type>/{frame_num.pickle, <speaker>/<utt>.npy} and the matching labels tree
+    (character indices; the two test sets store the transcript as a string), as the Librispeech recipe reads them.
+    Every character owns a feature vector held for 2 frames."""
+    import pickle
+    from examples.timit.metrics.mapping_files import character_tables
+    chars = character_tables()['character']
+    protos = rng.randn(len(chars), feat).astype(np.float32) * 1.5
+    words = ['the', 'cat', 'sat', 'on', 'a', 'mat', 'dog', 'ran']
+    for data_type, n in (('train', n_train), ('dev_clean', n_other), ('dev_other', n_other), ('test_clean', n_other),
+                         ('test_other', n_other)):
+        inp = os.path.join(root, 'inputs', size, data_type)
+        lab = os.path.join(root, 'labels', size, data_type, 'character')
+        frame_num = {}
+        for i in range(n):
+            speaker = str(100 + i % 3)
+            os.makedirs(os.path.join(inp, speaker), exist_ok=True)
+            os.makedirs(os.path.join(lab, speaker), exist_ok=True)
+            text = '_'.join(words[j] for j in rng.randint(0, len(words), size=rng.randint(1, 4)))
+            idx = [chars.index(c) for c in text]
+            x = np.concatenate([np.repeat(protos[c][None], 2, 0) for c in idx], 0)
+            x = (x + 0.1 * rng.randn(*x.shape)).astype(np.float32)
+            name = '%s-%d-%04d' % (speaker, 7, i)
+            np.save(os.path.join(inp, speaker, name + '.npy'), x)
+            np.save(os.path.join(lab, speaker, name + '.npy'),
+                    np.array(text) if 'test' in data_type else np.asarray(idx, dtype=np.int32))
+            frame_num[name] = x.shape[0]
+        with open(os.path.join(inp, 'frame_num.pickle'), 'wb') as f:
+            pickle.dump(frame_num, f)

@@ -440,11 +440,19 @@ STAND_INS = dict(
 )
 
 
-def install(monkeypatch):
-    """Swap the kernel front end for the CPU stand-ins for one test; pinned staging buffers become plain ones."""
+def install(monkeypatch=None):
+    """Swap the kernel front end for the CPU stand-ins for one test (monkeypatch fixture), or for the life of a
+    spawned worker process (monkeypatch=None); pinned staging buffers become plain ones."""
     from tensorflow_end2end_speech_recognition_amd import ops
     for name, fn in STAND_INS.items():
         assert hasattr(ops, name), name
-        monkeypatch.setattr(ops, name, fn)
-    monkeypatch.setattr(torch.Tensor, 'pin_memory', lambda self, *a, **k: self)
+        if monkeypatch is not None:
+            monkeypatch.setattr(ops, name, fn)
+        else:
+            setattr(ops, name, fn)
+    pin = lambda self, *a, **k: self
+    if monkeypatch is not None:
+        monkeypatch.setattr(torch.Tensor, 'pin_memory', pin)
+    else:
+        torch.Tensor.pin_memory = pin
     return ops

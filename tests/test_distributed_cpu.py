@@ -86,3 +86,97 @@ def test_split_batch_rule():
     t1 = [torch.full((2, 2), 3.0), None, torch.full((3,), 4.0)]
     avg = average_gradients([t0, t1])
     assert torch.equal(avg[0], torch.full((2, 2), 2.0)) and avg[1] is None and torch.equal(avg[2], torch.full((3,), 3.0))
+
+
+def _recipe_worker(rank, world, port, cfg_path, save_path, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import _cpu_ops
+    _cpu_ops.install()                       # CPU stand-ins of the kernel front end for this worker process
+    from examples.librispeech.training import train_ctc
+    res = train_ctc.main(cfg_path, save_path)
+    q.put((rank, res['model'].store.flat.clone().numpy(), res['steps'], res['save_path'],
+           [float(v) for v in res['metric_dev']], res['checkpoints']))
+    dist.destroy_process_group()
+
+
+def test_librispeech_recipe_data_parallel_world2(tmp_path):
+    """examples/librispeech/training/train_ctc.py under two gloo ranks (kernel front end = CPU stand-ins):
+    replicas stay bit-identical, rank 0 owns the run directory, and the parameters after the run equal the
+    reference's tower loop (train_ctc.py:82-147) replayed with the oracle on the same global batches: per-tower
+    gradient -> per-variable clip -> mean over towers -> one Adam update."""
+    import sys
+    import random
+    import yaml
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (here, root):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from _corpus import make_librispeech_like
+    from oracle import model as omodel
+    corpus = str(tmp_path / 'corpus')
+    make_librispeech_like(corpus, np.random.RandomState(1), n_train=13)   # 6 + 6 + 1: unequal and EMPTY shards
+    with open(os.path.join(root, 'examples/librispeech/config/ctc/blstm_ctc_character_100h.yml')) as f:
+        cfg = yaml.safe_load(f)
+    P = cfg['param']
+    P.update(input_size=6, num_stack=1, num_skip=1, num_units=8, num_layers=1, batch_size=3, num_epoch=2,
+             eval_start_epoch=1, print_step=4, learning_rate=0.02, dropout=0.0, weight_decay=1e-3, clip_grad_norm=0.5,
+             dtype='f32', device='cpu', dataset_root=corpus, sort_stop_epoch=1, seed=4)
+    cfg_path = str(tmp_path / 'cfg.yml')
+    with open(cfg_path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_recipe_worker, args=(r, world, port, cfg_path, str(tmp_path / 'runs'), q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, flat0, steps0, run0, metric0, ckpt0), (_, flat1, steps1, run1, metric1, ckpt1) = res
+    assert np.array_equal(flat0, flat1) and steps0 == steps1 == 6          # 13 utterances -> batches of 6, 6, 1 per epoch, 2 epochs
+    assert run0 == run1 and len(metric0) == 2 and metric1 == []           # only rank 0 evaluates
+    for name in ('config.yml', 'train.log', 'complete.txt', 'loss_ler.csv'):
+        assert os.path.isfile(os.path.join(run0, name)), name
+    log = open(os.path.join(run0, 'train.log')).read()
+    assert 'CER (clean)' in log and '-----EPOCH:2' in log and 'Step 6' in log
+
+    # replay: the reference's tower loop with the oracle
+    from examples.librispeech.data.load_dataset_ctc import Dataset
+    from examples.librispeech.training.train_ctc import build_model
+    from oracle import optim as oopt
+    model = build_model(dict(P), 'cpu')                                    # same seed -> same initial parameters
+    sd = {k: v.numpy().astype(np.float64) for k, v in model.store.state_dict().items()}
+    train = Dataset(data_type='train', train_data_size='train100h', label_type='character', batch_size=3,
+                    max_epoch=2, sort_utt=True, sort_stop_epoch=1, num_gpu=world, dataset_root=corpus)
+    train.rng = random.Random(4)
+    slots = {n: oopt.init_slots('adam', v) for n, v in sd.items()}
+    for step, ((inputs, labels, seq_len, _), _new) in enumerate(train, 1):
+        towers = []
+        for g in range(world):
+            if len(inputs[g]) == 0:      # empty shard: the rank contributes zeros to the tower mean (the guard of
+                towers.append([np.zeros_like(sd[n]) for n in sd])       # multi_gpu.tower_step; TF would fail here)
+                continue
+            labs = [[int(v) for v in row if v >= 0] for row in labels[g]]
+            ref = omodel.ctc_model_forward(sd, inputs[g], labs, seq_len[g], 1, ndir=2, cell_clip=50.0,
+                                           weight_decay=1e-3)
+            towers.append([oopt.clip_by_norm(ref['grads'][n], 0.5) for n in sd])
+        avg = oopt.average_gradients(towers)
+        for n, g in zip(list(sd), avg):
+            sd[n], s0, s1 = oopt.step('adam', sd[n], g, slots[n][0], slots[n][1], 0.02, step)
+            slots[n] = (s0, s1)
+    assert step == 6
+    got = dict(zip(model.store.names, [None] * len(model.store.names)))
+    model.store.flat.copy_(torch.from_numpy(flat0))
+    for n in model.store.names:
+        err = np.abs(model.store[n].numpy() - sd[n]).max()
+        assert err < 2e-5, (n, err)

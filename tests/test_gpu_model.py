@@ -308,3 +308,33 @@ def test_timit_recipe_on_generated_corpus(cuda, tmp_path):
     assert abs(per - res['ler_test']) < 1e-9
     per_beam = eval_ctc.main([run, '--beam_width', '8'])
     assert 0.0 <= per_beam < 2.0
+
+
+def test_librispeech_recipe_single_rank(cuda, tmp_path):
+    """examples/librispeech/training/train_ctc.py with one rank on the HIP path (the N-rank form of the same driver
+    runs under gloo with CPU stand-ins in tests/test_distributed_cpu.py): trains, evaluates CER/WER on both dev
+    sets, checkpoints."""
+    import os
+    import sys
+    import yaml
+    from _corpus import make_librispeech_like
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from examples.librispeech.training import train_ctc
+    corpus = str(tmp_path / 'corpus')
+    make_librispeech_like(corpus, np.random.RandomState(1), n_train=48, n_other=6, feat=12)
+    with open(os.path.join(root, 'examples/librispeech/config/ctc/blstm_ctc_character_100h.yml')) as f:
+        cfg = yaml.safe_load(f)
+    cfg['param'].update(input_size=12, num_stack=1, num_skip=1, num_units=64, num_layers=2, batch_size=16, num_epoch=8,
+                        eval_start_epoch=1, print_step=3, learning_rate=0.01, dropout=0.1, dataset_root=corpus,
+                        sort_stop_epoch=2, decay_start_epoch=4)
+    cfg_path = str(tmp_path / 'cfg.yml')
+    with open(cfg_path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    res = train_ctc.main(cfg_path, str(tmp_path / 'runs'))
+    assert res['world'] == 1 and res['steps'] == 24 and len(res['metric_dev']) == 8
+    assert min(res['metric_dev']) < 0.6 * res['metric_dev'][0], res['metric_dev']
+    assert res['checkpoints'] and res['test'] is not None
+    for name in ('config.yml', 'train.log', 'complete.txt', 'loss_ler.csv', 'checkpoint'):
+        assert os.path.isfile(os.path.join(res['save_path'], name)), name
