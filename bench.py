@@ -86,8 +86,8 @@ class KernelTimer(object):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--units', type=int, default=256)
     ap.add_argument('--layers', type=int, default=5)

@@ -3,15 +3,9 @@
 Directory layout of the reference's feature extraction: <root>/inputs/<data_type>/{frame_num.pickle, <utt>.npy}
 and <root>/labels/<data_type>/<label_type>/<utt>.npy.  The reference hard-codes two site paths (:66-67); here the
 root comes from the `dataset_root` argument or $TIMIT_DATASET_ROOT, then those two paths."""
-import os
-import pickle
-from os.path import isfile, join
-
-import numpy as np
-
 from tensorflow_end2end_speech_recognition_amd.utils.dataset.ctc import DatasetBase
 
-DEFAULT_ROOTS = ['/data/inaguma/timit', '/n/sd8/inaguma/corpus/timit/dataset']
+from ._paths import utterance_paths
 
 
 class Dataset(DatasetBase):
@@ -28,22 +22,6 @@ class Dataset(DatasetBase):
         self.progressbar = progressbar
         self.num_gpu = 1
         self.device_assembly = device_assembly
-        roots = [r for r in [dataset_root, os.environ.get('TIMIT_DATASET_ROOT')] if r] + DEFAULT_ROOTS
-        for root in roots:
-            input_path = join(root, 'inputs', data_type)
-            if isfile(join(input_path, 'frame_num.pickle')):
-                break
-        else:
-            raise IOError('frame_num.pickle not found under any of %s (inputs/%s/)' % (roots, data_type))
-        label_path = join(root, 'labels', data_type, label_type)
-        with open(join(input_path, 'frame_num.pickle'), 'rb') as f:
-            self.frame_num_dict = pickle.load(f)
-        # sorted by utterance name, or by frame count when sort_utt (:83-85)
-        axis = 1 if sort_utt else 0
-        input_paths, label_paths = [], []
-        for input_name, frame_num in sorted(self.frame_num_dict.items(), key=lambda x: x[axis]):
-            input_paths.append(join(input_path, input_name + '.npy'))
-            label_paths.append(join(label_path, input_name + '.npy'))
-        self.input_paths = np.array(input_paths)
-        self.label_paths = np.array(label_paths)
+        self.input_paths, (self.label_paths,), self.frame_num_dict = utterance_paths(
+            data_type, [label_type], sort_utt, dataset_root)
         self.rest = set(range(len(self.input_paths)))

@@ -1,5 +1,6 @@
 """The token <-> index tables of examples/timit/metrics/mapping_files/*.txt, generated instead of shipped:
-the three phone sets are the sorted columns of the Lee & Hon folding table (mapping.py _FOLD), the character
+the three phone sets are the sorted columns of the Lee & Hon folding table (mapping.py _FOLD) followed by
+'<' and '>', the character
 sets are '_' / A-Z + a-z (+ doubled letters) + ' < >.  write_mapping_files(dir) produces phone61.txt, phone48.txt,
 phone39.txt, phone2phone.txt, character.txt, character_capital_divide.txt in the reference's `<token>  <index>`
 form; tests/test_host_io.py pins them to the tables read from the reference's own files
@@ -34,6 +35,8 @@ def write_mapping_files(map_dir):
     os.makedirs(map_dir, exist_ok=True)
     tables = dict(phone_tables())
     tables.update(character_tables())
+    for name in ('phone61', 'phone48', 'phone39'):
+        tables[name] = tables[name] + ['<', '>']          # <SOS> / <EOS> of the attention models close every phone file
     for name, toks in tables.items():
         with open(os.path.join(map_dir, name + '.txt'), 'w') as f:
             for i, t in enumerate(toks):

@@ -497,6 +497,14 @@ class AttentionSeq2Seq(ModelBase):
                 break
         return torch.stack(out, 1)
 
+    def infer(self, inputs, inputs_seq_len):
+        """Greedy inference ids [B, <= max_decode_length] (numpy) for a batch of features -- what running the
+        reference's `decode_op_infer` with a feed_dict of inputs / inputs_seq_len / keep_prob = 1 returns
+        (examples/timit/metrics/attention.py:80-86)."""
+        inputs = torch.as_tensor(inputs, dtype=torch.float32, device=self.device)
+        isl = torch.as_tensor(inputs_seq_len, dtype=torch.int32, device=self.device)
+        return self._decode_infer(inputs, isl).cpu().numpy()
+
     def decode(self, decoder_outputs_train, decoder_outputs_infer):
         """attention_seq2seq.py:666-701."""
         return decoder_outputs_train.predicted_ids, decoder_outputs_infer.predicted_ids

@@ -4,20 +4,27 @@ import os
 import numpy as np
 
 
-def make_timit_like(root, rng, n_train=24, n_dev=6, n_test=4, feat=6):
-    """A corpus in the directory layout the TIMIT recipe reads (examples/timit/data/load_dataset_ctc.py): every
-    phone owns a feature vector held for 2-3 frames."""
+def make_timit_like(root, rng, n_train=24, n_dev=6, n_test=4, feat=6, multitask=False):
+    """A corpus in the directory layout the TIMIT recipes read (examples/timit/data/load_dataset_*.py): every
+    phone owns a feature vector held for 2-3 frames.  labels/<set>/phone61 (index arrays; the test set is scored on
+    labels/test/phone39, stored as a string) and labels/<set>/character (one letter per phone, '_' for silence; the
+    test transcript is a string).  multitask=True stores the test set's phone39 labels as index arrays, which is
+    what the multitask recipe's sub task reads."""
     import pickle
-    from examples.timit.metrics.mapping_files import phone_tables
+    from examples.timit.metrics.mapping_files import phone_tables, character_tables
     from examples.timit.metrics.mapping import Map2phone39
-    p61 = phone_tables()['phone61']
-    use = [p61.index(p) for p in ('aa', 'b', 'iy', 'k', 's', 'h#', 'ao', 'tcl', 't')]
+    tables = phone_tables()
+    p61, p39 = tables['phone61'], tables['phone39']
+    chars = character_tables()['character']
+    letter = {'aa': 'a', 'b': 'b', 'iy': 'i', 'k': 'k', 's': 's', 'h#': '_', 'ao': 'o', 'tcl': '', 't': 't'}
+    use = [p61.index(p) for p in letter]
     protos = rng.randn(61, feat).astype(np.float32) * 1.5
     to39 = Map2phone39('phone61')
     for data_type, n in (('train', n_train), ('dev', n_dev), ('test', n_test)):
         os.makedirs(os.path.join(root, 'inputs', data_type))
         lt = 'phone39' if data_type == 'test' else 'phone61'
         os.makedirs(os.path.join(root, 'labels', data_type, lt))
+        os.makedirs(os.path.join(root, 'labels', data_type, 'character'))
         frame_num = {}
         for i in range(n):
             lab = [use[j] for j in rng.randint(0, len(use), size=rng.randint(3, 6))]
@@ -25,11 +32,17 @@ def make_timit_like(root, rng, n_train=24, n_dev=6, n_test=4, feat=6):
             x = (x + 0.1 * rng.randn(*x.shape)).astype(np.float32)
             name = '%s_utt%02d' % (data_type, i)
             np.save(os.path.join(root, 'inputs', data_type, name + '.npy'), x)
-            if data_type == 'test':       # the test set stores the 39-phone transcript as a string
+            text = ''.join(letter[p61[c]] for c in lab).strip('_') or 'a'
+            if data_type == 'test':       # the test set stores transcripts as strings
+                ph39 = to39([p61[c] for c in lab])
                 np.save(os.path.join(root, 'labels', data_type, lt, name + '.npy'),
-                        np.array(' '.join(to39([p61[c] for c in lab]))))
+                        np.asarray([p39.index(p) for p in ph39], dtype=np.int32) if multitask
+                        else np.array(' '.join(ph39)))
+                np.save(os.path.join(root, 'labels', data_type, 'character', name + '.npy'), np.array(text))
             else:
                 np.save(os.path.join(root, 'labels', data_type, lt, name + '.npy'), np.asarray(lab, dtype=np.int32))
+                np.save(os.path.join(root, 'labels', data_type, 'character', name + '.npy'),
+                        np.asarray([chars.index(c) for c in text], dtype=np.int32))
             frame_num[name] = x.shape[0]
         with open(os.path.join(root, 'inputs', data_type, 'frame_num.pickle'), 'wb') as f:
             pickle.dump(frame_num, f)

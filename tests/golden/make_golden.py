@@ -130,6 +130,7 @@ def make_labels():
         i2p = Idx2phone(os.path.join(mf, lt + '.txt'))
         table = i2p(np.arange(n)).split(' ')
         out[lt + '_table'] = table                                   # idx -> phone (what the map file says)
+        out[lt + '_file_tokens'] = [l.split()[0] for l in open(os.path.join(mf, lt + '.txt')) if l.strip()]
         p2i = Phone2idx(os.path.join(mf, lt + '.txt'))
         seqs = [rng.randint(0, n, size=rng.randint(1, 15)).tolist() + [-1] * rng.randint(0, 3) for _ in range(6)]
         out[lt + '_idx2phone'] = [[s_, i2p(np.array(s_))] for s_ in seqs]

@@ -313,7 +313,8 @@ def test_generated_mapping_files_match_reference_tables(tmp_path):
     d = write_mapping_files(str(tmp_path / 'maps'))
     for lt in ('phone61', 'phone48', 'phone39'):
         rows = [l.split() for l in open(os.path.join(d, lt + '.txt'))]
-        assert [r[0] for r in rows] == g[lt + '_table'] and [int(r[1]) for r in rows] == list(range(len(rows)))
+        assert [r[0] for r in rows] == g[lt + '_file_tokens'] == g[lt + '_table'] + ['<', '>']
+        assert [int(r[1]) for r in rows] == list(range(len(rows)))
     for name in ('character', 'character_capital_divide'):
         rows = [l.split() for l in open(os.path.join(d, name + '.txt'))]
         assert [[r[0], int(r[1])] for r in rows] == g[name + '_table']

@@ -257,3 +257,50 @@ def test_timit_recipe_end_to_end_on_cpu_stand_ins(monkeypatch, tmp_path):
     # evaluation script: latest checkpoint of the first run == its last best epoch
     per = eval_ctc.main([run, '--beam_width', '1', '--device', 'cpu'])
     assert abs(per - res['ler_test']) < 1e-9
+
+
+def _recipe_cfg(root, rel, tmp_path, **upd):
+    import yaml
+    with open(os.path.join(root, rel)) as f:
+        cfg = yaml.safe_load(f)
+    cfg['param'].update(upd)
+    path = str(tmp_path / ('cfg_%s' % os.path.basename(rel)))
+    with open(path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    return path
+
+
+@pytest.mark.parametrize('family', ['attention', 'joint', 'multitask'])
+def test_timit_attention_joint_multitask_recipes_on_cpu_stand_ins(monkeypatch, tmp_path, family):
+    """examples/timit/training/train_{attention,joint_ctc_attention,multitask_ctc}.py on a generated corpus: the
+    family-specific dataset, loss call, inference-decoder monitoring and PER / CER evaluation, through the shared
+    loop (checkpoint on a new best, test evaluation, run-directory files)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    _cpu_ops.install(monkeypatch)
+    corpus = str(tmp_path / 'corpus')
+    _make_timit_like(corpus, np.random.RandomState(0), n_train=16, n_dev=4, n_test=3, multitask=family == 'multitask')
+    common = dict(input_size=6, batch_size=8, num_epoch=3, eval_start_epoch=1, print_step=2, optimizer='adam',
+                  learning_rate=0.02, weight_decay=0, decay_start_epoch=2, dtype='f32', device='cpu',
+                  dataset_root=corpus, sort_stop_epoch=2)
+    if family == 'multitask':
+        from examples.timit.training import train_multitask_ctc as drv
+        cfg = _recipe_cfg(root, 'examples/timit/config/ctc/multitask_blstm_ctc_char_phone61.yml', tmp_path,
+                          num_units=8, num_layers_main=2, num_layers_sub=1, dropout=0.0, **common)
+    else:
+        from examples.timit.training import train_attention, train_joint_ctc_attention
+        drv = train_attention if family == 'attention' else train_joint_ctc_attention
+        cfg = _recipe_cfg(root, 'examples/timit/config/attention/blstm_attention_phone61.yml', tmp_path,
+                          encoder_num_units=8, encoder_num_layers=1, attention_dim=6, decoder_num_units=8,
+                          embedding_dim=4, max_decode_length=10, dropout_encoder=0.0, dropout_decoder=0.1,
+                          dropout_embedding=0.1, **common)
+    res = drv.main(cfg, str(tmp_path / 'runs'))
+    run = res['save_path']
+    assert res['steps'] == 6 and len(res['ler_dev']) == 3 and all(v >= 0 for v in res['ler_dev'])
+    for name in ('config.yml', 'train.log', 'complete.txt', 'loss_ler.csv', os.path.join('mapping_files', 'phone61.txt')):
+        assert os.path.isfile(os.path.join(run, name)), name
+    log = open(os.path.join(run, 'train.log')).read()
+    assert '-----EPOCH:3' in log and 'Step 6' in log and ('PER' in log or 'CER' in log)
+    if res['checkpoints']:
+        assert res['ler_test'] is not None and os.path.isfile(os.path.join(run, 'checkpoint'))
