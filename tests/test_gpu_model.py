@@ -338,3 +338,50 @@ def test_librispeech_recipe_single_rank(cuda, tmp_path):
     assert res['checkpoints'] and res['test'] is not None
     for name in ('config.yml', 'train.log', 'complete.txt', 'loss_ler.csv', 'checkpoint'):
         assert os.path.isfile(os.path.join(res['save_path'], name)), name
+
+
+def test_rccl_collectives_on_the_parameter_store(cuda):
+    """The RCCL calls of the data-parallel step (utils/training/multi_gpu.py: init with device_id, broadcast of the
+    flat parameter buffer, all-reduce + scale of the flat gradient buffer, scalar mean) issued for real on the GPU.
+    The box has one GPU, so the group has one rank: this checks API use, dtypes, contiguity and stream ordering
+    against the HIP kernels around them -- the N-rank arithmetic is covered by the gloo tests."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    try:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=cuda)
+    except Exception as e:                                   # no RCCL in this environment: nothing to check
+        pytest.skip('RCCL process group could not be created: %r' % (e,))
+    try:
+        rng = np.random.RandomState(0)
+        B, T, D, H, C = 16, 20, 12, 64, 7
+        x, sl, labs, dense = _batch(rng, B, T, D, C)
+        model = CTC('blstm', D, H, 1, C, clip_grad_norm=5.0, clip_activation=50, dtype='bf16', seed=1)
+        before = model.store.flat.clone()
+        dist.broadcast(model.store.flat, src=0)
+        assert torch.equal(before, model.store.flat)
+        opt = model._set_optimizer('adam', 1e-3)
+        loss, _ = model.compute_loss(x, dense, sl, keep_prob=1.0)
+        gv = opt.compute_gradients(loss, model=model)
+        model._clip_gradients(gv)
+        g = model.store.grad.clone()
+        dist.all_reduce(model.store.grad, op=dist.ReduceOp.SUM)         # what average_gradients issues for N > 1
+        assert torch.equal(g, model.store.grad)
+        t = multi_gpu.average_scalar(loss.detach())
+        assert abs(float(t) - float(loss)) < 1e-6
+        opt.apply_gradients(gv)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.isfinite(model.store.flat).all()
+    finally:
+        dist.destroy_process_group()
