@@ -201,7 +201,7 @@ def main(config_path, model_save_path, log_to_file=True):
         if log_to_file:
             sys.stdout.close()
             sys.stdout = stdout
-    result['save_path'] = model.save_path
+    result.update(save_path=model.save_path, model=model)
     return result
 
 

@@ -74,7 +74,7 @@ def main(config_path, model_save_path, log_to_file=True):
     model.save_path = new_run_directory(join(model_save_path, 'joint_ctc_attention', params['label_type'], model.name),
                                         config_path)
     result = run_with_log(lambda: do_train(model, params), model.save_path, log_to_file)
-    result['save_path'] = model.save_path
+    result.update(save_path=model.save_path, model=model)
     return result
 
 

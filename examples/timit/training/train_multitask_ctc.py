@@ -91,7 +91,7 @@ def main(config_path, model_save_path, log_to_file=True):
         join(model_save_path, 'ctc', params['label_type_main'] + '_' + params['label_type_sub'], model.name),
         config_path)
     result = run_with_log(lambda: do_train(model, params), model.save_path, log_to_file)
-    result['save_path'] = model.save_path
+    result.update(save_path=model.save_path, model=model)
     return result
 
 

@@ -150,6 +150,19 @@ def test_librispeech_recipe_data_parallel_world2(tmp_path):
     log = open(os.path.join(run0, 'train.log')).read()
     assert 'CER (clean)' in log and '-----EPOCH:2' in log and 'Step 6' in log
 
+    # the evaluation script restores rank 0's checkpoint (kernel front end = stand-ins in this process too)
+    import pytest
+    mpatch = pytest.MonkeyPatch()
+    try:
+        import _cpu_ops
+        _cpu_ops.install(mpatch)
+        from examples.librispeech.evaluation import eval_ctc
+        if ckpt0:
+            ev = eval_ctc.main([run0, '--beam_width', '1', '--device', 'cpu'])
+            assert set(ev) == {'test_clean', 'test_other'} and all(0.0 <= v for v in ev.values())
+    finally:
+        mpatch.undo()
+
     # replay: the reference's tower loop with the oracle
     from examples.librispeech.data.load_dataset_ctc import Dataset
     from examples.librispeech.training.train_ctc import build_model

@@ -304,3 +304,20 @@ def test_timit_attention_joint_multitask_recipes_on_cpu_stand_ins(monkeypatch, t
     assert '-----EPOCH:3' in log and 'Step 6' in log and ('PER' in log or 'CER' in log)
     if res['checkpoints']:
         assert res['ler_test'] is not None and os.path.isfile(os.path.join(run, 'checkpoint'))
+    if family != 'multitask':
+        # the evaluation script: rebuild the model from the run's config.yml, restore a checkpoint of the trained
+        # parameters, score the test set -- must equal scoring the trained model object directly
+        from examples.timit.evaluation import eval_attention
+        from examples.timit.metrics.attention import do_eval_per
+        from examples.timit.training.train_attention import make_datasets
+        from tensorflow_end2end_speech_recognition_amd.utils.training.checkpoint import Saver
+        model = res['model']
+        Saver().save(model, os.path.join(run, 'model.ckpt'), global_step=99)
+        map_dir = os.path.join(run, 'mapping_files')
+        params = dict(label_type='phone61', splice=1, num_stack=1, num_skip=1, batch_size=8, num_epoch=1,
+                      sort_stop_epoch=1, dataset_root=corpus)
+        test_data = make_datasets(drv.Dataset, params, map_dir)[2]
+        want = do_eval_per(None, None, None, model, test_data, 'phone61', is_test=True, eval_batch_size=1,
+                           map_dir=map_dir, is_jointctcatt=family == 'joint')
+        got = eval_attention.main([run, '--device', 'cpu'] + (['--joint'] if family == 'joint' else []))
+        assert abs(got - want) < 1e-9
