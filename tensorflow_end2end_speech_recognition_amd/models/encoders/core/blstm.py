@@ -9,6 +9,8 @@ the one fused kernel ('BasicLSTMCell' = no peephole / no clip, blstm.py:124-190)
 num_proj is dropped exactly as the reference drops it unless lstm_impl ==
 'LSTMCell' (blstm.py:49-52); a projection layer is not implemented -> ValueError.
 """
+import collections
+
 import numpy as np
 import torch
 
@@ -16,6 +18,9 @@ from .... import ops
 from ...._lib import ASR_F32
 from ....utils.parameter import ParamStore
 from .rnn_util import LSTMLayer, declare_lstm_vars
+
+# tf.contrib.rnn.LSTMStateTuple: what the reference's encoders hand back as final state (.c, .h)
+LSTMStateTuple = collections.namedtuple('LSTMStateTuple', ('c', 'h'))
 
 LSTM_IMPLS = ('BasicLSTMCell', 'LSTMCell', 'LSTMBlockCell', 'LSTMBlockFusedCell', 'CudnnLSTM')
 
@@ -90,6 +95,11 @@ class _RecurrentEncoderBase(object):
         final = None
         Tt, Bp = x.shape[0], x.shape[1]
 
+        if rng_state is None and drop_masks is None and is_training and keep_prob is not None and keep_prob < 1.0:
+            # an encoder used on its own (the models pass their own state): a fresh dropout stream per call
+            self._dropout_calls = getattr(self, '_dropout_calls', 0) + 1
+            rng_state = (self.seed, self._dropout_calls << 40)
+
         def prep(li):
             dm = drop_masks[li] if drop_masks is not None else None
             rs = None
@@ -98,6 +108,7 @@ class _RecurrentEncoderBase(object):
             return self.layers[li].prepare(x.device, self.dtype, Tt, Bp, keep_prob, is_training, rs, dm)
 
         nxt = prep(0)
+        finals = []
         for li, layer in enumerate(self.layers):
             cur = nxt
             if li + 1 < len(self.layers):
@@ -107,6 +118,7 @@ class _RecurrentEncoderBase(object):
                     nxt = prep(li + 1)
             x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, prep=cur)
             ops.join_side(x.device)
+            finals.append(final)
             if self.num_layers_sub is not None and li + 1 == self.num_layers_sub:
                 # blstm.py:326-328: outputs_sub IS the tensor the next layer consumes (after the dropout wrapper)
                 self._out_sub_op, self._final_sub_ch = x, final
@@ -116,13 +128,22 @@ class _RecurrentEncoderBase(object):
         self._out_op = x   # same values in the MFMA operand dtype
         cf, hf = final
         self._final_ch = (cf, hf)          # [ndir,Bp,H] each (the attention bridge consumes these)
-        final_state = tuple((cf[d, :B], hf[d, :B]) for d in range(self.ndir))
-        if self.ndir == 1:
-            final_state = final_state[0]
+        self._finals = finals
+        final_state = self._state_tuple(finals, len(finals))
         out_user = out[:, :B]
         if not self.time_major:
             out_user = out_user.transpose(0, 1)
         return out_user, final_state
+
+    def _state_tuple(self, finals, upto):
+        """The reference's final_state: bidirectional_dynamic_rnn of the LAST layer -> (LSTMStateTuple fw,
+        LSTMStateTuple bw) (blstm.py:313-323); MultiRNNCell under one dynamic_rnn -> one LSTMStateTuple per layer
+        (lstm.py:275-284).  `upto`: number of layers the (sub-)stack has."""
+        B = self.batch
+        if self.ndir == 2:
+            cf, hf = finals[upto - 1]
+            return tuple(LSTMStateTuple(cf[d, :B], hf[d, :B]) for d in range(2))
+        return tuple(LSTMStateTuple(cf[0, :B], hf[0, :B]) for cf, hf in finals[:upto])
 
     def backward(self, d_outputs, d_final=None, need_input_grad=False, d_outputs_sub=None):
         """d_outputs: gradient w.r.t. the TIME-MAJOR padded-batch outputs [T,Bpad,ndir*H] fp32.

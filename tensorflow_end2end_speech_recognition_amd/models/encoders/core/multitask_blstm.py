@@ -27,10 +27,7 @@ class _MultitaskMixin(object):
         B = self.batch
         sub = self._out_sub_op
         self._out_sub_tm = ops.cast_to_f32(sub) if sub.dtype != torch.float32 else sub
-        cf, hf = self._final_sub_ch
-        final_sub = tuple((cf[d, :B], hf[d, :B]) for d in range(self.ndir))
-        if self.ndir == 1:
-            final_sub = final_sub[0]
+        final_sub = self._state_tuple(self._finals, self.num_layers_sub)
         out_sub = self._out_sub_tm[:, :B]
         if not self.time_major:
             out_sub = out_sub.transpose(0, 1)

@@ -238,6 +238,8 @@ def test_timit_recipe_end_to_end_on_cpu_stand_ins(monkeypatch, tmp_path):
     cfg_path = str(tmp_path / 'cfg.yml')
     with open(cfg_path, 'w') as f:
         yaml.safe_dump(cfg, f)
+    import random
+    random.seed(0)                    # the iterators draw from the global generator, as the reference's do
     res = train_ctc.main(cfg_path, str(tmp_path / 'runs'))
     run = res['save_path']
     assert run.endswith(os.path.join('ctc', 'phone61', 'blstm_ctc_8_1_adam_lr0.05'))
@@ -321,3 +323,93 @@ def test_timit_attention_joint_multitask_recipes_on_cpu_stand_ins(monkeypatch, t
                            map_dir=map_dir, is_jointctcatt=family == 'joint')
         got = eval_attention.main([run, '--device', 'cpu'] + (['--joint'] if family == 'joint' else []))
         assert abs(got - want) < 1e-9
+
+
+@pytest.mark.parametrize('encoder_type', ['blstm', 'lstm', 'multitask_blstm', 'multitask_lstm'])
+def test_encoder_shape_table(monkeypatch, encoder_type):
+    """The reference's own encoder test (models/test/test_encoder.py:258-314): for every lstm_impl and both
+    time_major settings, outputs are (B, T, ndir*H) -- (T, B, ndir*H) when time_major -- and the final state is
+    (LSTMStateTuple fw, LSTMStateTuple bw) of the last layer, or one LSTMStateTuple per layer for the
+    unidirectional stack, each (B, H); the multitask encoders add the sub-task outputs / state."""
+    _cpu_ops.install(monkeypatch)
+    from tensorflow_end2end_speech_recognition_amd.models.encoders.load_encoder import load
+    from tensorflow_end2end_speech_recognition_amd.models.encoders.core.blstm import LSTM_IMPLS
+    rng = np.random.RandomState(0)
+    B, T, D, H, L = 3, 7, 6, 8, 3
+    x = torch.tensor(rng.randn(B, T, D).astype(np.float32))
+    sl = torch.tensor([7, 5, 2], dtype=torch.int32)
+    bidir = 'blstm' in encoder_type
+    multi = encoder_type.startswith('multitask')
+    for lstm_impl in LSTM_IMPLS:
+        for time_major in (True, False):
+            kw = dict(num_units=H, num_proj=None, lstm_impl=lstm_impl, use_peephole=True, parameter_init=0.1,
+                      clip_activation=50, time_major=time_major)
+            if multi:
+                kw.update(num_layers_main=L, num_layers_sub=2)
+            else:
+                kw.update(num_layers=L)
+            enc = load(encoder_type)(**kw)
+            res = enc(x, sl, 0.9, True)
+            outs, final = res[0], res[1]
+            want = (T, B, H * (2 if bidir else 1)) if time_major else (B, T, H * (2 if bidir else 1))
+            assert tuple(outs.shape) == want
+            assert len(final) == (2 if bidir else L)
+            for st in final:
+                assert tuple(st.c.shape) == (B, H) and tuple(st.h.shape) == (B, H)
+            if multi:
+                outs_sub, final_sub = res[2], res[3]
+                assert tuple(outs_sub.shape) == want
+                assert len(final_sub) == (2 if bidir else L)          # lstm.py:271-272: the sub stack is the full stack
+                for st in final_sub:
+                    assert tuple(st.c.shape) == (B, H) and tuple(st.h.shape) == (B, H)
+            # frames past an utterance's length are zero
+            o = outs if not time_major else outs.transpose(0, 1)
+            assert float(o[2, 2:].abs().max()) == 0.0 and float(o[1, 5:].abs().max()) == 0.0
+
+
+def test_overfit_one_utterance_like_the_reference_model_tests(monkeypatch):
+    """models/test/test_ctc.py:170-233 and test_attention.py:107-226: one utterance repeated B times, train until
+    the label error rate of the decode drops below 0.1 (the reference's only pass criterion; it allows 1000 steps).
+    CTC (greedy decode) and attention (inference decoder) on the CPU stand-ins."""
+    _cpu_ops.install(monkeypatch)
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
+    from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import list2sparsetensor
+    rng = np.random.RandomState(0)
+    B, T, D, C = 2, 24, 6, 8
+    x = np.repeat(rng.randn(1, T, D).astype(np.float32), B, 0)
+    sl = np.array([T] * B, np.int32)
+    lab = rng.randint(0, C, size=6)
+    st = list2sparsetensor(np.repeat(lab[None], B, 0), -1)
+    model = CTC('blstm', D, 16, 1, C, parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='f32',
+                device='cpu', seed=1)
+    ler = 1.0
+    for step in range(1000):
+        loss, logits = model.compute_loss(x, st, sl, 1.0)
+        model.train(loss, 'adam', 1e-2)
+        if (step + 1) % 10 == 0:
+            ler = model.compute_ler(model.decoder(logits, sl, 1), st)
+            if ler < 0.1:
+                break
+    assert ler < 0.1, (step, ler)
+
+    labels = np.concatenate([[C], lab, [C + 1]])[None].repeat(B, 0)
+    lsl = np.array([len(lab) + 2] * B)
+    att = AttentionSeq2Seq(input_size=D, encoder_type='blstm', encoder_num_units=16, encoder_num_layers=1,
+                           encoder_num_proj=None, attention_type='bahdanau_content', attention_dim=8,
+                           decoder_type='lstm', decoder_num_units=16, decoder_num_layers=1, embedding_dim=6,
+                           num_classes=C, sos_index=C, eos_index=C + 1, max_decode_length=12, parameter_init=0.1,
+                           clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50, dtype='f32',
+                           device='cpu', seed=1)
+    ler = 1.0
+    for step in range(1000):
+        loss, _, out_train, out_infer = att.compute_loss(x, labels, sl, lsl, 1.0, 1.0, 1.0)
+        att.train(loss, 'adam', 1e-2)
+        if (step + 1) % 10 == 0:
+            ids = np.asarray(out_infer.predicted_ids)
+            pred = [[int(v) for v in row[:list(row).index(C + 1)]] if (C + 1) in row else [int(v) for v in row]
+                    for row in ids]
+            ler = att.compute_ler([list(lab)] * B, pred)
+            if ler < 0.1:
+                break
+    assert ler < 0.1, (step, ler)
