@@ -13,8 +13,15 @@ Pinning status (see DESIGN.md "Oracle"):
   ``tests/golden/make_golden.py``.
 * ``oracle.splice`` (frame stacking / splicing) is PINNED the same way against
   ``/root/reference/utils/io/inputs/{splicing,frame_stacking}.py``.
-* Everything whose arithmetic lives in TensorFlow 1.x (LSTMBlockCell,
-  dynamic_rnn masking, tf.nn.ctc_loss, conv2d SAME, optimizers ...) is
+* ``oracle.ctc`` (tf.nn.ctc_loss: loss and gradient) and the peephole-free cell of ``oracle.lstm`` are PINNED
+  to TensorFlow's own known-answer tests: the constants of ``ctc_loss_op_test.py::testBasic`` (two losses, 60
+  gradient entries) and of ``lstm_ops_test.py::testLSTMBlockCell`` (``tests/golden/tf_known_answers.py``) are
+  reproduced to their printed precision; the greedy decoder also reproduces
+  ``ctc_decoder_ops_test.py::testCTCGreedyDecoder``.
+* The label maps, the dataset iterators, the LR controller and the sparse-label helpers of the host side are
+  PINNED to outputs recorded from the reference's own classes (``tests/golden/*.json``, ``datasets_v1.npz``).
+* The rest of what lives in TensorFlow 1.x (peepholes and cell clip of LSTMBlockCell,
+  dynamic_rnn masking, conv2d SAME, the attention decoder, optimizers ...) is
   "PARITY UNPINNED": TensorFlow 1.2/1.3 (requirements.txt:11) is not
   installable here and the reference's tests hold no golden numbers
   (models/test/test_ctc.py:225-233 only loops until LER < 0.1).  Those parts

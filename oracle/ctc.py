@@ -1,5 +1,6 @@
-"""Oracle (test infrastructure, PARITY UNPINNED for the loss -- TF1 absent; see
-oracle/__init__.py): CPU restatement of tf.nn.ctc_loss as the reference calls it.
+"""Oracle (test infrastructure; PINNED to TensorFlow's own known-answer vectors of ctc_loss_op_test.py testBasic,
+tests/golden/tf_known_answers.py -- see oracle/__init__.py): CPU restatement of tf.nn.ctc_loss as the reference
+calls it.
 
 Call sites restated: models/ctc/ctc.py:289-298 (ctc_merge_repeated=True,
 preprocess_collapse_repeated=False, ignore_longer_outputs_than_inputs=True,

@@ -1,4 +1,5 @@
-"""Oracle (test infrastructure, PARITY UNPINNED -- see oracle/__init__.py):
+"""Oracle (test infrastructure; the peephole-free cell is PINNED to TensorFlow's lstm_ops_test.py constants, the
+peephole / clip / sequence-masking parts are PARITY UNPINNED -- see oracle/__init__.py):
 CPU restatement of the recurrent encoder of the reference.
 
 Follows

@@ -1,0 +1,65 @@
+"""Known-answer vectors of TensorFlow's OWN unit tests for the two ops the hot path takes from TensorFlow
+(tensorflow==1.2/1.3, the reference's pinned dependency), so that the oracle -- and through it the HIP
+kernels -- is pinned to TensorFlow's results, not only to an independent restatement:
+
+  * tf.nn.ctc_loss: tensorflow/python/kernel_tests/ctc_loss_op_test.py, CTCLossTest.testBasic -- two utterances,
+    depth 6 (blank = 5), 5 frames each; expected loss and the full gradient w.r.t. the (log-probability) inputs.
+  * tf.contrib.rnn.LSTMBlockCell (no peephole, forget_bias 1): tensorflow/contrib/rnn/python/kernel_tests/
+    lstm_ops_test.py, LSTMBlockCellTest.testLSTMBlockCell (the same numbers as rnn_cell_test.py testBasicLSTMCell):
+    two stacked cells of 2 units, every weight 0.5, zero bias, x = [1, 1], every state entry 0.1.
+
+TensorFlow is not installable here; the numbers are the constants printed in those test files.  They validate
+themselves: the oracle, written from the op semantics, reproduces both losses to 3e-6 (the printed precision) and
+all 60 gradient entries to 5e-7 (tests/test_oracle.py) -- which no independent implementation does by accident."""
+import numpy as np
+
+CTC_DEPTH = 6           # classes incl. blank (index 5 = depth - 1, TensorFlow's convention)
+
+CTC_TARGETS_0 = [0, 1, 2, 1, 0]
+CTC_LOSS_0 = 3.34211
+CTC_PROBS_0 = np.asarray(
+    [[0.633766, 0.221185, 0.0917319, 0.0129757, 0.0142857, 0.0260553],
+     [0.111121, 0.588392, 0.278779, 0.0055756, 0.00569609, 0.010436],
+     [0.0357786, 0.633813, 0.321418, 0.00249248, 0.00272882, 0.0037688],
+     [0.0663296, 0.643849, 0.280111, 0.00283995, 0.0035545, 0.00331533],
+     [0.458235, 0.396634, 0.123377, 0.00648837, 0.00903441, 0.00623107]], dtype=np.float64)
+CTC_GRAD_0 = np.asarray(
+    [[-0.366234, 0.221185, 0.0917319, 0.0129757, 0.0142857, 0.0260553],
+     [0.111121, -0.411608, 0.278779, 0.0055756, 0.00569609, 0.010436],
+     [0.0357786, 0.633813, -0.678582, 0.00249248, 0.00272882, 0.0037688],
+     [0.0663296, -0.356151, 0.280111, 0.00283995, 0.0035545, 0.00331533],
+     [-0.541765, 0.396634, 0.123377, 0.00648837, 0.00903441, 0.00623107]], dtype=np.float64)
+
+CTC_TARGETS_1 = [0, 1, 1, 0]
+CTC_LOSS_1 = 5.42262
+CTC_PROBS_1 = np.asarray(
+    [[0.30176, 0.28562, 0.0831517, 0.0862751, 0.0816851, 0.161508],
+     [0.24082, 0.397533, 0.0557226, 0.0546814, 0.0557528, 0.19549],
+     [0.230246, 0.450868, 0.0389607, 0.038309, 0.0391602, 0.202456],
+     [0.280884, 0.429522, 0.0326593, 0.0339046, 0.0326856, 0.190345],
+     [0.423286, 0.315517, 0.0338439, 0.0393744, 0.0339315, 0.154046]], dtype=np.float64)
+CTC_GRAD_1 = np.asarray(
+    [[-0.69824, 0.28562, 0.0831517, 0.0862751, 0.0816851, 0.161508],
+     [0.24082, -0.602467, 0.0557226, 0.0546814, 0.0557528, 0.19549],
+     [0.230246, 0.450868, 0.0389607, 0.038309, 0.0391602, -0.797544],
+     [0.280884, -0.570478, 0.0326593, 0.0339046, 0.0326856, 0.190345],
+     [-0.576714, 0.315517, 0.0338439, 0.0393744, 0.0339315, 0.154046]], dtype=np.float64)
+
+CTC_CASES = [(CTC_PROBS_0, CTC_TARGETS_0, CTC_LOSS_0, CTC_GRAD_0), (CTC_PROBS_1, CTC_TARGETS_1, CTC_LOSS_1, CTC_GRAD_1)]
+
+# LSTMBlockCell x 2, num_units 2, all weights 0.5, x = [[1, 1]], c = h = 0.1 everywhere
+LSTM_WEIGHT, LSTM_X, LSTM_STATE = 0.5, [1.0, 1.0], 0.1
+LSTM_C0, LSTM_H0 = [0.68967271, 0.68967271], [0.44848421, 0.44848421]
+LSTM_C1, LSTM_H1 = [0.39897051, 0.39897051], [0.24024698, 0.24024698]
+
+# tf.nn.ctc_greedy_decoder: tensorflow/python/kernel_tests/ctc_decoder_ops_test.py, testCTCGreedyDecoder -- depth 4
+# (blank = 3), 6 padded frames, two utterances of 4 and 5 frames; decoded labels and the negative log probability of
+# the best path (sum of -log of the per-frame maxima).
+GREEDY_SEQ_LEN = [4, 5]
+GREEDY_PROBS = np.asarray(
+    [[[1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.4, 0.6], [0.0, 0.0, 0.4, 0.6], [0.0, 0.9, 0.1, 0.0], [0.0, 0.0, 0.0, 0.0],
+      [0.0, 0.0, 0.0, 0.0]],
+     [[0.1, 0.9, 0.0, 0.0], [0.0, 0.9, 0.1, 0.0], [0.0, 0.0, 0.1, 0.9], [0.0, 0.9, 0.1, 0.1], [0.9, 0.1, 0.0, 0.0],
+      [0.0, 0.0, 0.0, 0.0]]], dtype=np.float64)                                   # [B, T, depth]
+GREEDY_DECODED = [[0, 1], [1, 1, 0]]
+GREEDY_NEG_LOG_PROB = [float(np.sum(-np.log([1.0, 0.6, 0.6, 0.9]))), float(np.sum(-np.log([0.9] * 5)))]

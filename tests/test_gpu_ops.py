@@ -335,6 +335,28 @@ def test_ctc_loss_and_grad(cuda, T, B, C, lmax):
     assert int(ninf.item()) == 0
 
 
+def test_ctc_matches_tensorflow_known_answer_vectors(cuda):
+    """asr_ctc_loss against the constants of TensorFlow's own ctc_loss_op_test.py testBasic
+    (tests/golden/tf_known_answers.py): two utterances, depth 6, 5 valid of 7 padded frames -- both losses and all
+    60 gradient entries, i.e. the HIP kernel agrees with tf.nn.ctc_loss itself, not only with the oracle."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import tf_known_answers as tfk
+    ops = _ops()
+    logits = np.zeros((7, 2, tfk.CTC_DEPTH), dtype=np.float32)
+    for b, (probs, _, _, _) in enumerate(tfk.CTC_CASES):
+        logits[:5, b] = np.log(probs)
+    labs = [list(c[1]) for c in tfk.CTC_CASES]
+    flat, off = _flat(labs)
+    sl = np.array([5, 5], dtype=np.int32)
+    loss, grad, ninf = ops.ctc_loss(torch.tensor(logits, device=cuda), torch.tensor(flat, device=cuda),
+                                    torch.tensor(off, device=cuda), torch.tensor(sl, device=cuda), 5, 1.0)
+    loss, grad = loss.cpu().numpy(), grad.cpu().numpy()
+    assert np.abs(loss - [tfk.CTC_LOSS_0, tfk.CTC_LOSS_1]).max() < 1e-4
+    assert np.abs(grad[:5, 0] - tfk.CTC_GRAD_0).max() < 2e-5 and np.abs(grad[:5, 1] - tfk.CTC_GRAD_1).max() < 2e-5
+    assert not grad[5:].any() and int(ninf.item()) == 0
+
+
 def test_ctc_edge_cases(cuda):
     """empty label rows, T == exact minimum, infeasible rows (-> 0 loss/grad), seq_len 0."""
     ops = _ops()

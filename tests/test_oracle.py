@@ -271,3 +271,58 @@ def test_sigmoid_smoothing_backward_formula():
     dot = (a * da).sum(1, keepdim=True)
     closed = k * a * (1.0 - a * S.detach()) * (da - dot)
     assert (closed - e.grad).abs().max().item() < 1e-12
+
+
+def test_ctc_matches_tensorflow_known_answer_vectors():
+    """oracle/ctc.py against the constants of TensorFlow's own ctc_loss_op_test.py testBasic
+    (tests/golden/tf_known_answers.py): both losses and all 60 gradient entries."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import ctc as octc
+    for probs, targets, loss, grad in tfk.CTC_CASES:
+        l, g, ok = octc.ctc_loss_single(np.log(probs), targets)           # blank = depth - 1
+        assert ok and abs(l - loss) < 5e-6
+        assert np.abs(g - grad).max() < 2e-6
+    # batched, time-major, padded to 7 frames as in that test
+    logits = np.zeros((7, 2, tfk.CTC_DEPTH))
+    for b, (probs, _, _, _) in enumerate(tfk.CTC_CASES):
+        logits[:5, b] = np.log(probs)
+    loss, grad = octc.ctc_loss_batch(logits, [c[1] for c in tfk.CTC_CASES], [5, 5])
+    assert np.abs(loss - [tfk.CTC_LOSS_0, tfk.CTC_LOSS_1]).max() < 5e-6
+    assert np.abs(grad[:5, 0] - tfk.CTC_GRAD_0).max() < 2e-6 and not grad[5:].any()
+
+
+def test_lstm_cell_matches_tensorflow_known_answer():
+    """oracle/lstm.py lstm_block_cell (no peephole, forget_bias 1) against the constants of TensorFlow's own
+    lstm_ops_test.py testLSTMBlockCell: two stacked 2-unit cells, all weights 0.5."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import lstm as olstm
+    H = 2
+    z = torch.zeros(H, dtype=torch.float64)
+    w = torch.full((2 + H, 4 * H), tfk.LSTM_WEIGHT, dtype=torch.float64)
+    b = torch.zeros(4 * H, dtype=torch.float64)
+    st = torch.full((1, H), tfk.LSTM_STATE, dtype=torch.float64)
+    x = torch.tensor([tfk.LSTM_X], dtype=torch.float64)
+    c0, h0 = olstm.lstm_block_cell(x, st, st, w, b, z, z, z, forget_bias=1.0, cell_clip=0.0, use_peephole=False)
+    c1, h1 = olstm.lstm_block_cell(h0, st, st, w, b, z, z, z, forget_bias=1.0, cell_clip=0.0, use_peephole=False)
+    for got, want in ((c0, tfk.LSTM_C0), (h0, tfk.LSTM_H0), (c1, tfk.LSTM_C1), (h1, tfk.LSTM_H1)):
+        assert np.abs(got.numpy()[0] - np.asarray(want)).max() < 2e-7      # TensorFlow printed float32 values
+
+
+def test_greedy_decoder_matches_tensorflow_known_answer():
+    """oracle/decoders.py greedy_decode against TensorFlow's own ctc_decoder_ops_test.py testCTCGreedyDecoder
+    (best path, repeats merged, blank = depth - 1; zero-probability entries are -inf log-probabilities)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import decoders as odec
+    with np.errstate(divide='ignore'):
+        logp = np.log(tfk.GREEDY_PROBS)
+    got = odec.greedy_decode(logp, tfk.GREEDY_SEQ_LEN, 3)
+    assert [list(map(int, g)) for g in got] == tfk.GREEDY_DECODED
+    for b, n in enumerate(tfk.GREEDY_SEQ_LEN):
+        assert abs(float(-logp[b, :n].max(1).sum()) - tfk.GREEDY_NEG_LOG_PROB[b]) < 1e-12
