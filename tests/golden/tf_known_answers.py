@@ -63,3 +63,14 @@ GREEDY_PROBS = np.asarray(
       [0.0, 0.0, 0.0, 0.0]]], dtype=np.float64)                                   # [B, T, depth]
 GREEDY_DECODED = [[0, 1], [1, 1, 0]]
 GREEDY_NEG_LOG_PROB = [float(np.sum(-np.log([1.0, 0.6, 0.6, 0.9]))), float(np.sum(-np.log([0.9] * 5)))]
+
+# tf.train.AdagradOptimizer: tensorflow/python/training/adagrad_test.py, doTestBasic -- learning rate 3.0,
+# initial_accumulator_value 0.1, constant gradients, 3 steps.
+ADAGRAD_LR, ADAGRAD_STEPS = 3.0, 3
+ADAGRAD_VAR0, ADAGRAD_GRAD0, ADAGRAD_OUT0 = [1.0, 2.0], [0.1, 0.1], [-1.6026098728179932, -0.6026098728179932]
+ADAGRAD_VAR1, ADAGRAD_GRAD1, ADAGRAD_OUT1 = [3.0, 4.0], [0.01, 0.01], [2.715679168701172, 3.715679168701172]
+
+# tf.clip_by_norm: tensorflow/python/kernel_tests/clip_ops_test.py, testClipByNormClipped / NotClipped
+CLIP_X = [[-3.0, 0.0, 0.0], [4.0, 0.0, 0.0]]
+CLIP_NORM_CLIPPED, CLIP_ANS_CLIPPED = 4.0, [[-2.4, 0.0, 0.0], [3.2, 0.0, 0.0]]
+CLIP_NORM_NOT_CLIPPED = 6.0

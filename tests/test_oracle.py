@@ -326,3 +326,30 @@ def test_greedy_decoder_matches_tensorflow_known_answer():
     assert [list(map(int, g)) for g in got] == tfk.GREEDY_DECODED
     for b, n in enumerate(tfk.GREEDY_SEQ_LEN):
         assert abs(float(-logp[b, :n].max(1).sum()) - tfk.GREEDY_NEG_LOG_PROB[b]) < 1e-12
+
+
+def test_adagrad_matches_tensorflow_known_answer():
+    """oracle/optim.py 'adagrad' (accumulator starts at 0.1, TF1 default) against the constants of TensorFlow's
+    own adagrad_test.py doTestBasic: three steps at learning rate 3.0."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import optim as oopt
+    for var, grad, want in ((tfk.ADAGRAD_VAR0, tfk.ADAGRAD_GRAD0, tfk.ADAGRAD_OUT0),
+                            (tfk.ADAGRAD_VAR1, tfk.ADAGRAD_GRAD1, tfk.ADAGRAD_OUT1)):
+        p, g = np.asarray(var, dtype=np.float64), np.asarray(grad, dtype=np.float64)
+        s0, s1 = oopt.init_slots('adagrad', p)
+        for t in range(1, tfk.ADAGRAD_STEPS + 1):
+            p, s0, s1 = oopt.step('adagrad', p, g, s0, s1, tfk.ADAGRAD_LR, t)
+        assert np.abs(p - want).max() < 5e-7          # TensorFlow's constants are float32 results
+
+
+def test_clip_by_norm_matches_tensorflow_known_answer():
+    """oracle/optim.py clip_by_norm against TensorFlow's clip_ops_test.py testClipByNormClipped / NotClipped."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import optim as oopt
+    x = np.asarray(tfk.CLIP_X)
+    assert np.abs(oopt.clip_by_norm(x, tfk.CLIP_NORM_CLIPPED) - np.asarray(tfk.CLIP_ANS_CLIPPED)).max() < 1e-12
+    assert np.array_equal(oopt.clip_by_norm(x, tfk.CLIP_NORM_NOT_CLIPPED), x)
