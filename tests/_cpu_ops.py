@@ -425,6 +425,47 @@ def _argmax_rows(x2d):
     return torch.argmax(x2d, 1).to(torch.int32)
 
 
+# ---------------------------------------------------------------- VGG front-end stand-ins (im2col form)
+def _im2col3x3(x_nhwc, ldp=None, out=None):
+    """patches[(n*H+h)*W+w, tap*Cin+ci], tap = kh*3+kw, zero padding (SAME)."""
+    N, H, W, Cin = x_nhwc.shape
+    ldp = ldp or 9 * Cin
+    xp = torch.nn.functional.pad(x_nhwc.permute(0, 3, 1, 2), (1, 1, 1, 1))          # [N,Cin,H+2,W+2]
+    cols = [xp[:, :, kh:kh + H, kw:kw + W].permute(0, 2, 3, 1).reshape(N * H * W, Cin)
+            for kh in range(3) for kw in range(3)]
+    pat = torch.zeros((N * H * W, ldp), dtype=x_nhwc.dtype)
+    pat[:, :9 * Cin] = torch.cat(cols, 1)
+    return pat
+
+
+def _col2im3x3(dpatches, N, H, W, Cin):
+    dp = dpatches[:, :9 * Cin].reshape(N, H, W, 9, Cin).double()
+    din = torch.zeros((N, H + 2, W + 2, Cin), dtype=F64)
+    for kh in range(3):
+        for kw in range(3):
+            din[:, kh:kh + H, kw:kw + W] += dp[:, :, :, kh * 3 + kw]
+    return din[:, 1:H + 1, 1:W + 1].float().contiguous()
+
+
+def _maxpool2x2_fwd(x_nhwc):
+    """2x2 stride 2 SAME: odd edges are padded at the bottom / right (never selected)."""
+    N, H, W, Cc = x_nhwc.shape
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    xp = torch.full((N, 2 * Ho, 2 * Wo, Cc), float('-inf'), dtype=x_nhwc.dtype)
+    xp[:, :H, :W] = x_nhwc
+    win = xp.view(N, Ho, 2, Wo, 2, Cc).permute(0, 1, 3, 5, 2, 4).reshape(N, Ho, Wo, Cc, 4)
+    out, arg = win.max(dim=4)
+    return out.contiguous(), arg.to(torch.uint8)
+
+
+def _maxpool2x2_bwd(dout, arg, H, W):
+    N, Ho, Wo, Cc = dout.shape
+    g = torch.zeros((N, Ho, Wo, Cc, 4))
+    g.scatter_(4, arg.long().unsqueeze(4), dout.unsqueeze(4))
+    g = g.view(N, Ho, Wo, Cc, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * Ho, 2 * Wo, Cc)
+    return g[:, :H, :W].contiguous()
+
+
 STAND_INS = dict(
     side_lane=_NullLane, join_side=lambda device: None, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
     cast_from_f32=_cast_from_f32, cast_to_f32=_cast_to_f32, apply_mask=_apply_mask, dropout_mask=_dropout_mask,
@@ -436,7 +477,8 @@ STAND_INS = dict(
     att_energy_bwd=_att_energy_bwd, att_softmax_ctx_fwd=_att_softmax_ctx_fwd,
     att_softmax_ctx_bwd=_att_softmax_ctx_bwd, tanh_fwd=_tanh_fwd, tanh_bwd=_tanh_bwd,
     embedding_gather=_embedding_gather, embedding_scatter=_embedding_scatter, seq_xent=_seq_xent,
-    argmax_rows=_argmax_rows,
+    argmax_rows=_argmax_rows, im2col3x3=_im2col3x3, col2im3x3=_col2im3x3, maxpool2x2_fwd=_maxpool2x2_fwd,
+    maxpool2x2_bwd=_maxpool2x2_bwd,
 )
 
 

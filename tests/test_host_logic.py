@@ -413,3 +413,37 @@ def test_overfit_one_utterance_like_the_reference_model_tests(monkeypatch):
             if ler < 0.1:
                 break
     assert ler < 0.1, (step, ler)
+
+
+@pytest.mark.parametrize('enc', ['vgg_blstm', 'vgg_lstm'])
+def test_vgg_front_end_host_logic(monkeypatch, enc):
+    """VGG front-end + recurrent stack + CTC (models/encoders/core/vgg_blstm.py): valid-frame packing of the padded
+    batch, the im2col form of the four convolutions, pooling with odd edges, the bridge, and every gradient, against
+    the oracle's VGG model (oracle/vgg.py)."""
+    _cpu_ops.install(monkeypatch)
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    rng = np.random.RandomState(2)
+    B, T, F, W, H, C = 3, 7, 5, 3, 8, 5               # 5 x 3 images: both pooling stages see an odd edge
+    D = F * W * 3
+    x, sl, labs, dense = _batch(rng, B, T, D, C, div=3)
+    model = CTC(encoder_type=enc, input_size=3 * F, splice=W, num_units=H, num_layers=1, num_classes=C,
+                parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='f32', seed=4, device='cpu')
+    sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    for k in sd:
+        if k.endswith('/bias') or k.endswith('/biases'):
+            sd[k] = (rng.randn(*sd[k].shape) * 0.05).astype(np.float32)
+    model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    ref = omodel.ctc_model_forward(sd, x, labs, sl, 1, ndir=2 if enc == 'vgg_blstm' else 1, cell_clip=50.0, vgg=(F, W))
+    loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-5
+    valid = np.arange(T)[:, None] < sl[None, :]
+    assert np.abs((logits.numpy() - ref['logits'])[valid]).max() < 1e-4
+    _check_grads(model._set_optimizer('sgd', 0.1), loss, model, ref, tol=2e-4)
+    # dropout path runs and trains
+    first = last = None
+    for it in range(4):
+        l, _ = model.compute_loss(x, dense, sl, keep_prob=0.8)
+        model.train(l, 'adam', 5e-3)
+        first = l.item() if first is None else first
+        last = l.item()
+    assert np.isfinite(last)
