@@ -103,3 +103,22 @@ def tower_step(model, optimizer, inputs, labels, inputs_seq_len, keep_prob, lear
     average_gradients(model.store)
     optimizer.apply_gradients(None, learning_rate=learning_rate)
     return average_scalar(loss), logits
+
+
+def tower_step_with(model, optimizer, loss_fn, learning_rate=None):
+    """tower_step for any model family: `loss_fn()` runs this rank's forward and returns the loss tensor of
+    compute_loss (or None when the rank's shard of the global batch is empty); the rest is the tower loop of
+    examples/csj/training/train_attention.py:90-150 -- gradients, per-variable clip on the tower, mean over towers,
+    identical update.  Returns the loss averaged over towers."""
+    loss = loss_fn()
+    if loss is not None:
+        gv = optimizer.compute_gradients(loss, model=model)
+        if model.clip_grad_norm is not None:
+            model._clip_gradients(gv)
+        loss = loss.detach()
+    else:
+        model.store.grad.zero_()
+        loss = torch.zeros((), dtype=torch.float32, device=model.store.flat.device)
+    average_gradients(model.store)
+    optimizer.apply_gradients(None, learning_rate=learning_rate)
+    return average_scalar(loss)

@@ -193,3 +193,104 @@ def test_librispeech_recipe_data_parallel_world2(tmp_path):
     for n in model.store.names:
         err = np.abs(model.store[n].numpy() - sd[n]).max()
         assert err < 2e-5, (n, err)
+
+
+def _joint_worker(rank, world, port, cfg_path, save_path, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import _cpu_ops
+    _cpu_ops.install()
+    from examples.librispeech.training import train_joint_ctc_attention as drv
+    res = drv.main(cfg_path, save_path)
+    q.put((rank, res['model'].store.flat.clone().numpy(), res['steps'], res['save_path'], res['losses'],
+           [float(v) for v in res['metric_dev']]))
+    dist.destroy_process_group()
+
+
+def test_joint_ctc_attention_recipe_data_parallel_world2(tmp_path):
+    """BASELINE configs[3] in small: examples/librispeech/training/train_joint_ctc_attention.py under two gloo ranks
+    (kernel front end = CPU stand-ins), location attention + lambda-weighted CTC head.  Replicas stay bit-identical
+    and the parameters after the run equal the tower loop replayed with the oracle's joint model on the same global
+    batches (unequal and empty shards included): per-tower gradient -> per-variable clip -> tower mean -> Adam."""
+    import random
+    import sys
+    import yaml
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (here, root):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from _corpus import make_librispeech_like
+    from oracle import attention as oatt
+    corpus = str(tmp_path / 'corpus')
+    make_librispeech_like(corpus, np.random.RandomState(1), n_train=13, size='train960h')
+    with open(os.path.join(root, 'examples/librispeech/config/attention/blstm_joint_ctc_attention_location_960h.yml')) as f:
+        cfg = yaml.safe_load(f)
+    P = cfg['param']
+    P.update(input_size=6, num_stack=1, num_skip=1, encoder_num_units=8, encoder_num_layers=1, attention_dim=6,
+             decoder_num_units=8, embedding_dim=4, max_decode_length=12, batch_size=3, num_epoch=1, eval_start_epoch=1,
+             print_step=2, learning_rate=0.02, dropout_encoder=0.0, dropout_decoder=0.0, dropout_embedding=0.0,
+             weight_decay=0, clip_grad_norm=0.5, dtype='f32', device='cpu', dataset_root=corpus, sort_stop_epoch=1,
+             seed=4)
+    cfg_path = str(tmp_path / 'cfg.yml')
+    with open(cfg_path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_joint_worker, args=(r, world, port, cfg_path, str(tmp_path / 'runs'), q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, flat0, steps0, run0, losses0, metric0), (_, flat1, steps1, run1, losses1, metric1) = res
+    assert np.array_equal(flat0, flat1) and steps0 == steps1 == 3 and run0 == run1
+    assert losses0 == losses1 and len(metric0) == 1 and metric1 == []
+    for name in ('config.yml', 'train.log', 'complete.txt'):
+        assert os.path.isfile(os.path.join(run0, name)), name
+
+    from examples.librispeech.data.load_dataset_joint_ctc_attention import Dataset
+    from examples.timit.training.train_attention import model_kwargs
+    from tensorflow_end2end_speech_recognition_amd.models.attention.joint_ctc_attention import JointCTCAttention
+    from oracle import optim as oopt
+    params = dict(P, num_classes=28)
+    model = JointCTCAttention(lambda_weight=P['lambda_weight'], seed=4, **model_kwargs(params))
+    sd = {k: v.numpy().astype(np.float64) for k, v in model.store.state_dict().items()}
+    train = Dataset(data_type='train', train_data_size='train960h', label_type='character', batch_size=3,
+                    map_file_path=os.path.join(run0, 'mapping_files', 'character.txt'), max_epoch=1, sort_utt=True,
+                    sort_stop_epoch=1, num_gpu=world, dataset_root=corpus)
+    train.rng = random.Random(4)
+    slots = {n: oopt.init_slots('adam', v) for n, v in sd.items()}
+    tower_means = []
+    for step, ((inputs, att, ctc, seq_len, att_len, _), _new) in enumerate(train, 1):
+        towers, losses = [], []
+        for g in range(world):
+            if len(inputs[g]) == 0:
+                towers.append([np.zeros_like(sd[n]) for n in sd])
+                losses.append(0.0)
+                continue
+            ctc_list = [[int(v) for v in row if v >= 0] for row in ctc[g]]
+            ref = oatt.attention_model_forward(sd, inputs[g], att[g], seq_len[g], att_len[g], 1, 'location',
+                                               clip_enc=50.0, clip_dec=50.0, ctc_labels=ctc_list,
+                                               lambda_weight=P['lambda_weight'])
+            towers.append([oopt.clip_by_norm(ref['grads'][n], 0.5) for n in sd])
+            losses.append(ref['total_loss'])
+        tower_means.append(float(np.mean(losses)))
+        avg = oopt.average_gradients(towers)
+        for n, g_ in zip(list(sd), avg):
+            sd[n], s0, s1 = oopt.step('adam', sd[n], g_, slots[n][0], slots[n][1], 0.02, step)
+            slots[n] = (s0, s1)
+    assert step == 3
+    assert np.abs(np.asarray(losses0) - np.asarray(tower_means)).max() < 1e-4       # loss = mean over towers
+    model.store.flat.copy_(torch.from_numpy(flat0))
+    for n in model.store.names:
+        err = np.abs(model.store[n].numpy() - sd[n]).max()
+        assert err < 5e-5, (n, err)
