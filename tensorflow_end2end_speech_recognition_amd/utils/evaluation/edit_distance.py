@@ -81,3 +81,20 @@ def wer_align(ref, hyp):
             dele += 1
             x -= 1
     return sub, ins, dele
+
+
+def compute_edit_distance(session, labels_true_st, labels_pred_st):
+    """Per-utterance normalised edit distance of two sparse label batches ([indices, values, dense_shape] triples),
+    what the reference's compute_edit_distance (edit_distance.py:15-32) gets from tf.edit_distance(normalize=True):
+    distance / len(truth).  `session` is accepted for call compatibility and ignored."""
+    import numpy as np
+    from ..io.labels.sparsetensor import sparse_to_flat
+    B = int(np.asarray(labels_true_st[2])[0])
+    tv, to, _ = sparse_to_flat(labels_true_st, B)
+    pv, po, _ = sparse_to_flat(labels_pred_st, B)
+    out = np.zeros(B, dtype=np.float64)
+    for b in range(B):
+        truth, hyp = tv[to[b]:to[b + 1]], pv[po[b]:po[b + 1]]
+        d = levenshtein(list(truth), list(hyp))
+        out[b] = d / len(truth) if len(truth) else (float('inf') if d else 0.0)   # tf: inf for an empty truth
+    return out

@@ -389,3 +389,32 @@ def test_dataset_iterators_match_reference_batches(tmp_path, kind):
                     assert np.array_equal(got, want), (run, nb, fi)
             nb += 1
         assert nb == run['num_batches'] and ds.epoch == run['epoch']
+
+
+def test_small_host_utilities(tmp_path, capsys):
+    """utils/directory.py, measure_time_func.py, progressbar.py, training/plot.py and compute_edit_distance: the
+    reference's helper calls keep working."""
+    from tensorflow_end2end_speech_recognition_amd.utils.directory import mkdir, mkdir_join
+    from tensorflow_end2end_speech_recognition_amd.utils.measure_time_func import measure_time
+    from tensorflow_end2end_speech_recognition_amd.utils.progressbar import wrap_iterator, wrap_generator
+    from tensorflow_end2end_speech_recognition_amd.utils.training.plot import plot_loss, plot_ler
+    from tensorflow_end2end_speech_recognition_amd.utils.evaluation.edit_distance import compute_edit_distance
+    from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import list2sparsetensor
+    root = str(tmp_path / 'runs')
+    assert mkdir(root) == root and os.path.isdir(root) and mkdir(None) is None and mkdir_join(None, 'a') is None
+    p = mkdir_join(root, 'ctc', 'phone61', 'model.ckpt')
+    assert p == os.path.join(root, 'ctc', 'phone61', 'model.ckpt') and os.path.isdir(os.path.dirname(p))
+    assert not os.path.exists(p)                                    # a dotted component is a file name
+
+    @measure_time
+    def f(a, b=1):
+        return a + b
+    assert f(2, b=3) == 5 and 'Takes' in capsys.readouterr().out
+    assert list(wrap_iterator(range(3), False)) == [0, 1, 2] and list(wrap_generator(iter([1, 2]), False, 2)) == [1, 2]
+    plot_loss([3.0, 2.0], [3.5, 2.5], [10, 20], root)
+    plot_ler([0.9, 0.5], [0.95, 0.6], [10, 20], 'phone61', root)
+    assert open(os.path.join(root, 'loss.csv')).read().splitlines()[1] == '10,3.000000,3.500000'
+    assert open(os.path.join(root, 'ler.csv')).read().splitlines()[2] == '20,0.500000,0.600000'
+    true = list2sparsetensor(np.array([[1, 2, 3, -1], [4, 4, 5, 6]]), -1)
+    pred = list2sparsetensor(np.array([[1, 3, -1, -1], [4, 4, 5, 6]]), -1)
+    assert np.allclose(compute_edit_distance(None, true, pred), [1 / 3, 0.0])
