@@ -74,6 +74,12 @@ def make_librispeech_like(root, rng, n_train=12, n_other=4, feat=6, size='train1
             np.save(os.path.join(inp, speaker, name + '.npy'), x)
             np.save(os.path.join(lab, speaker, name + '.npy'),
                     np.array(text) if 'test' in data_type else np.asarray(idx, dtype=np.int32))
+            # word-level targets of the same transcript (label type word_freq10; index = position in `words`)
+            wdir = os.path.join(root, 'labels', size, data_type, 'word_freq10', speaker)
+            os.makedirs(wdir, exist_ok=True)
+            widx = [words.index(w) for w in text.split('_')]
+            np.save(os.path.join(wdir, name + '.npy'),
+                    np.array(text) if 'test' in data_type else np.asarray(widx, dtype=np.int32))
             frame_num[name] = x.shape[0]
         with open(os.path.join(inp, 'frame_num.pickle'), 'wb') as f:
             pickle.dump(frame_num, f)
