@@ -259,6 +259,10 @@ def test_timit_recipe_end_to_end_on_cpu_stand_ins(monkeypatch, tmp_path):
     # evaluation script: latest checkpoint of the first run == its last best epoch
     per = eval_ctc.main([run, '--beam_width', '1', '--device', 'cpu'])
     assert abs(per - res['ler_test']) < 1e-9
+    # visualization script: Ref / Hyp pairs of the test set
+    from examples.timit.visualization import decode_ctc
+    pairs = decode_ctc.main([run, '--beam_width', '1', '--device', 'cpu'])
+    assert len(pairs) == 4 and all(isinstance(r, str) and isinstance(h, str) for _, r, h in pairs)
 
 
 def _recipe_cfg(root, rel, tmp_path, **upd):
@@ -306,6 +310,12 @@ def test_timit_attention_joint_multitask_recipes_on_cpu_stand_ins(monkeypatch, t
     assert '-----EPOCH:3' in log and 'Step 6' in log and ('PER' in log or 'CER' in log)
     if res['checkpoints']:
         assert res['ler_test'] is not None and os.path.isfile(os.path.join(run, 'checkpoint'))
+    if family == 'multitask':
+        from examples.timit.evaluation import eval_multitask_ctc
+        from tensorflow_end2end_speech_recognition_amd.utils.training.checkpoint import Saver
+        Saver().save(res['model'], os.path.join(run, 'model.ckpt'), global_step=99)
+        cer, wer, per = eval_multitask_ctc.main([run, '--beam_width', '1', '--device', 'cpu'])
+        assert cer >= 0 and wer >= 0 and per >= 0
     if family != 'multitask':
         # the evaluation script: rebuild the model from the run's config.yml, restore a checkpoint of the trained
         # parameters, score the test set -- must equal scoring the trained model object directly
