@@ -19,4 +19,4 @@ golden:           ## regenerate tests/golden/* from the reference's own code (ne
 	cd /tmp && $(PY) $(CURDIR)/tests/golden/make_golden.py
 
 clean:
-	rm -f tensorflow_end2end_speech_recognition_amd/libasr_hip.so tensorflow_end2end_speech_recognition_amd/csrc/*.o
+	rm -rf tensorflow_end2end_speech_recognition_amd/libasr_hip.so tensorflow_end2end_speech_recognition_amd/csrc/_obj
