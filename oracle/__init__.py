@@ -17,7 +17,9 @@ Pinning status (see DESIGN.md "Oracle"):
   to TensorFlow's own known-answer tests: the constants of ``ctc_loss_op_test.py::testBasic`` (two losses, 60
   gradient entries) and of ``lstm_ops_test.py::testLSTMBlockCell`` (``tests/golden/tf_known_answers.py``) are
   reproduced to their printed precision; the greedy decoder also reproduces
-  ``ctc_decoder_ops_test.py::testCTCGreedyDecoder``.
+  ``ctc_decoder_ops_test.py::testCTCGreedyDecoder``; the convolution layout / SAME-pool padding conventions of
+  ``oracle.vgg``, Adagrad and clip_by_norm of ``oracle.optim`` reproduce the constants of TensorFlow's
+  conv_ops / pooling_ops / adagrad / clip_ops tests.
 * The label maps, the dataset iterators, the LR controller and the sparse-label helpers of the host side are
   PINNED to outputs recorded from the reference's own classes (``tests/golden/*.json``, ``datasets_v1.npz``).
 * The rest of what lives in TensorFlow 1.x (peepholes and cell clip of LSTMBlockCell,

@@ -74,3 +74,13 @@ ADAGRAD_VAR1, ADAGRAD_GRAD1, ADAGRAD_OUT1 = [3.0, 4.0], [0.01, 0.01], [2.7156791
 CLIP_X = [[-3.0, 0.0, 0.0], [4.0, 0.0, 0.0]]
 CLIP_NORM_CLIPPED, CLIP_ANS_CLIPPED = 4.0, [[-2.4, 0.0, 0.0], [3.2, 0.0, 0.0]]
 CLIP_NORM_NOT_CLIPPED = 6.0
+
+# tf.nn.conv2d (NHWC input, HWIO filter): tensorflow/python/kernel_tests/conv_ops_test.py, testConv2D2x2Filter and
+# testConv2D1x2Filter -- input [1,2,3,3] and filter filled with 1, 2, 3, ... in row-major order, stride 1, VALID.
+CONV_IN_SHAPE = (1, 2, 3, 3)
+CONV_2X2_FILTER_SHAPE, CONV_2X2_OUT = (2, 2, 3, 3), [2271.0, 2367.0, 2463.0, 2901.0, 3033.0, 3165.0]
+CONV_1X2_FILTER_SHAPE, CONV_1X2_OUT = (1, 2, 3, 3), [231.0, 252.0, 273.0, 384.0, 423.0, 462.0, 690.0, 765.0, 840.0,
+                                                     843.0, 936.0, 1029.0]
+# tf.nn.max_pool 2x2 stride 2 SAME on an odd width: tensorflow/python/kernel_tests/pooling_ops_test.py,
+# testMaxPoolSamePadding -- input [1,2,3,3] = 1..18: the extra column is padded AFTER.
+POOL_SAME_OUT = [13.0, 14.0, 15.0, 16.0, 17.0, 18.0]

@@ -353,3 +353,29 @@ def test_clip_by_norm_matches_tensorflow_known_answer():
     x = np.asarray(tfk.CLIP_X)
     assert np.abs(oopt.clip_by_norm(x, tfk.CLIP_NORM_CLIPPED) - np.asarray(tfk.CLIP_ANS_CLIPPED)).max() < 1e-12
     assert np.array_equal(oopt.clip_by_norm(x, tfk.CLIP_NORM_NOT_CLIPPED), x)
+
+
+def test_conv_and_pool_conventions_match_tensorflow_known_answers():
+    """oracle/vgg.py: the NHWC / HWIO -> NCHW / OIHW permutes of its convolutions and the pad-AFTER rule of its SAME
+    max-pool, against the constants of TensorFlow's conv_ops_test.py (testConv2D2x2Filter, testConv2D1x2Filter) and
+    pooling_ops_test.py (testMaxPoolSamePadding)."""
+    import sys
+    import torch
+    import torch.nn.functional as Fn
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import vgg as ovgg
+    n_in = int(np.prod(tfk.CONV_IN_SHAPE))
+    x = torch.arange(1, n_in + 1, dtype=torch.float64).reshape(tfk.CONV_IN_SHAPE)            # NHWC
+    for fshape, want in ((tfk.CONV_2X2_FILTER_SHAPE, tfk.CONV_2X2_OUT), (tfk.CONV_1X2_FILTER_SHAPE, tfk.CONV_1X2_OUT)):
+        w = torch.arange(1, int(np.prod(fshape)) + 1, dtype=torch.float64).reshape(fshape)   # HWIO
+        y = Fn.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1))                          # the oracle's permutes
+        assert y.permute(0, 2, 3, 1).reshape(-1).tolist() == want
+    # ... and oracle._conv is exactly that expression with SAME padding 1, bias and ReLU
+    rng = np.random.RandomState(0)
+    xi = torch.tensor(rng.randn(2, 3, 5, 4))
+    w3, b3 = torch.tensor(rng.randn(3, 3, 3, 6)), torch.tensor(rng.randn(6))
+    want = torch.relu(Fn.conv2d(Fn.pad(xi, (1, 1, 1, 1)), w3.permute(3, 2, 0, 1)) + b3.view(1, -1, 1, 1))
+    assert (ovgg._conv(xi, w3, b3) - want).abs().max().item() < 1e-12
+    pooled = ovgg._pool_same(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).reshape(-1).tolist()
+    assert pooled == tfk.POOL_SAME_OUT
