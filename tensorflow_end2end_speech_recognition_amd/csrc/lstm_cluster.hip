@@ -352,7 +352,11 @@ __device__ __forceinline__ float dpp_ror8_into(float old, float src) {
 // exchange-buffer parity is a compile-time constant (loop unrolled by two), every address is an
 // incrementally advanced register, the phase timers (DBG) are a template parameter, nothing in
 // the loop is exec-masked.
-template <int H, bool DBG>
+// EARLY (experimental, ASR_LSTM_DFLAGS bit 5, off by default): the k-chunks of this CU's OWN slice of h -- which
+// never leave the CU -- are multiplied for step s+1 right after they are written, i.e. before the wave starts polling
+// for the peers' slices, so that part of the LDS-read + MFMA phase runs under the L2 hop.  The chunk order in the
+// registers is rotated by the CU index so that the own chunks are always register chunks 0 .. KO-1.
+template <int H, bool DBG, bool EARLY = false>
 __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
     int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const bf16_t* __restrict__ whp,
     const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
@@ -363,6 +367,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   constexpr int KS = H / 32;
   constexpr int LDH = H + 8;
   constexpr int SLICE = 16 * (HS / 2);                     // granules one CU publishes per step
+  constexpr int KO = HS / 32;                              // k-chunks of one CU's own slice
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* hs = reinterpret_cast<bf16_t*>(smem);            // [2][16][LDH]
 
@@ -401,8 +406,14 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   for (int p = 0; p < 2; ++p) {
     const int tile = (jw >> 4) * 4 + p * 2 + (col >> 3);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      wreg[p][ks] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)tile * KS + ks) * 64 + rg * 16 + (jw & 15)) * 8);
+    for (int ks = 0; ks < KS; ++ks) {
+      if constexpr (EARLY) {
+        const int kk = (ks + g * KO) & (KS - 1);           // register chunk ks holds k-chunk kk
+        wreg[p][ks] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)tile * KS + kk) * 64 + rg * 16 + (jw & 15)) * 8);
+      } else {
+        wreg[p][ks] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)tile * KS + ks) * 64 + rg * 16 + (jw & 15)) * 8);
+      }
+    }
   }
 
   u64* xhdr = xch + (size_t)cid.c * (XHDR + 2 * G * SLICE);
@@ -441,6 +452,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   f32x4_t xn[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) xn[r] = xg[(0 < len[r]) ? oa[r] : os[r]];
+  f32x4_t accn0 = {0.f, 0.f, 0.f, 0.f}, accn1 = {0.f, 0.f, 0.f, 0.f};   // EARLY: own-slice part of the next step
 
   unsigned long long* dbg = g_cdbg;
   unsigned long long ph[4] = {0, 0, 0, 0};
@@ -459,13 +471,20 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
       for (int r = 0; r < 2; ++r) xn[r] = xg[(s + 1 < len[r]) ? oa[r] + dstep : os[r] + stride];
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EARLY) { acc0 = accn0; acc1 = accn1; }    // own-slice chunks: done at the end of the last step
     // 8 A fragments in flight at once (left alone the scheduler recycles ONE register and exposes
     // the LDS latency KS times: 870 cycles for 16 MFMAs); H = 512 takes two such batches
 #pragma unroll
     for (int kb = 0; kb < KS; kb += 8) {
       bf16x8_t afr[8];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + (kb + ks) * 64);
+      for (int ks = 0; ks < 8; ++ks) {
+        if constexpr (EARLY) {
+          if (kb + ks >= KO) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + ((kb + ks + g * KO) & (KS - 1)) * 64);
+        } else {
+          afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + (kb + ks) * 64);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (DBG && kb == 0) {                                // sub-phase: first A fragments landed
 #pragma unroll
@@ -474,6 +493,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
+        if (EARLY && kb + ks < KO) continue;
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[0][kb + ks], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[1][kb + ks], acc1, 0, 0, 0);
       }
@@ -539,6 +559,21 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
       os[r] += stride;
     }
     const unsigned long long t2 = C8_T();
+    if constexpr (EARLY) {
+      if (s + 1 < tmax) {                                  // block-uniform
+        __syncthreads();                                   // the CU's own slice of h(s) is complete in hnxt
+        bf16x8_t ao[KO];
+#pragma unroll
+        for (int k = 0; k < KO; ++k) ao[k] = *reinterpret_cast<const bf16x8_t*>(hnxt + lrd + ((k + g * KO) & (KS - 1)) * 64);
+        accn0 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        accn1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KO; ++k) {
+          accn0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[k], wreg[0][k], accn0, 0, 0, 0);
+          accn1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[k], wreg[1][k], accn1, 0, 0, 0);
+        }
+      }
+    }
     {
       u64 v[G - 1];
 #pragma unroll
@@ -1173,7 +1208,7 @@ static int cluster_waves() {   // ASR_LSTM_CW=4 selects the one-wave-per-SIMD fo
   return w;
 }
 static int g_dflags = -1;
-static int dbg_flags() {   // bit 4 (16): force the placement-independent write-through exchange
+static int dbg_flags() {   // bit 4 (16): force the placement-independent write-through exchange; bit 5 (32): EARLY forward
   if (g_dflags < 0) { const char* e = getenv("ASR_LSTM_DFLAGS"); g_dflags = e ? atoi(e) : 0; }
   return g_dflags;
 }
@@ -1201,7 +1236,8 @@ bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
       return false;
     char* base5 = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
     (void)hipMemsetAsync(base5 + 256, 0, need5, st);
-    auto k5 = g_cdbg_host ? lstm_fwd_cluster8_kernel<H5, true> : lstm_fwd_cluster8_kernel<H5, false>;
+    auto k5 = g_cdbg_host ? lstm_fwd_cluster8_kernel<H5, true>
+                          : ((dbg_flags() & 32) ? lstm_fwd_cluster8_kernel<H5, false, true> : lstm_fwd_cluster8_kernel<H5, false>);
     hipLaunchKernelGGL(k5, dim3(cluster_grid(G5, ncl)), dim3(CT8), (size_t)2 * 16 * (H5 + 8) * 2, st, T, B, ndir,
                        (const f32x4_t*)xproj, (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates,
                        (bf16_t*)hout, cs, cf, hf, (u64*)(base5 + 256), (unsigned*)base5, (dbg_flags() & 16) ? 1 : 0);
@@ -1219,7 +1255,8 @@ bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
     const size_t need8 = (size_t)ncl * (XHDR + 2 * G * 16 * (HS / 2)) * sizeof(u64);
     if (need8 + 256 > XCH_BYTES) return false;
     (void)hipMemsetAsync(xch, 0, need8, st);
-    auto k = g_cdbg_host ? lstm_fwd_cluster8_kernel<HH, true> : lstm_fwd_cluster8_kernel<HH, false>;
+    auto k = g_cdbg_host ? lstm_fwd_cluster8_kernel<HH, true>
+                         : ((dbg_flags() & 32) ? lstm_fwd_cluster8_kernel<HH, false, true> : lstm_fwd_cluster8_kernel<HH, false>);
     hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8), lds, st, T, B, ndir, (const f32x4_t*)xproj,
                        (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates, (bf16_t*)hout, cs, cf,
                        hf, xch, err, (dbg_flags() & 16) ? 1 : 0);
