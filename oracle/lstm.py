@@ -60,8 +60,17 @@ def reverse_sequence(x_tm, seq_len):
     return x_tm[src, torch.arange(B).unsqueeze(0)]
 
 
+def ste_round(x, fn):
+    """Straight-through rounding of a torch tensor: value fn(x), gradient of the identity."""
+    return x + (fn(x.detach()) - x.detach())
+
+
+def bf16_round_t(x):
+    return x.to(torch.float32).to(torch.bfloat16).to(x.dtype)
+
+
 def dynamic_rnn(x_tm, seq_len, p, reverse=False, drop_mask=None,
-                forget_bias=1.0, cell_clip=0.0, use_peephole=True):
+                forget_bias=1.0, cell_clip=0.0, use_peephole=True, h_round=None):
     """tf.nn.dynamic_rnn(time_major=True, sequence_length) over one direction.
 
     x_tm [T,B,Din]; seq_len LongTensor [B]; p = dict(w,b,wci,wcf,wco).
@@ -69,6 +78,8 @@ def dynamic_rnn(x_tm, seq_len, p, reverse=False, drop_mask=None,
     (reverse_sequence on the valid prefix, outputs reversed back).
     drop_mask [T,B,H] (already scaled by 1/keep_prob, indexed by FRAME) multiplies
     the emitted output only.  Returns out [T,B,H], (c_final, h_final).
+    h_round (tests of the bf16-operand device path): rounding applied, straight-through, to the h
+    that is fed back through W_h and emitted (the device keeps c and the final h unrounded).
     """
     T, B, _ = x_tm.shape
     H = p['b'].shape[0] // 4
@@ -76,14 +87,17 @@ def dynamic_rnn(x_tm, seq_len, p, reverse=False, drop_mask=None,
         x_tm = reverse_sequence(x_tm, seq_len)
     c = x_tm.new_zeros(B, H)
     h = x_tm.new_zeros(B, H)
+    h_fb = h
     outs = []
     for s in range(T):
         active = (s < seq_len).to(x_tm.dtype).unsqueeze(1)
-        c_new, h_new = lstm_block_cell(x_tm[s], c, h, p['w'], p['b'], p['wci'], p['wcf'],
+        c_new, h_new = lstm_block_cell(x_tm[s], c, h_fb, p['w'], p['b'], p['wci'], p['wcf'],
                                        p['wco'], forget_bias, cell_clip, use_peephole)
         c = active * c_new + (1 - active) * c
         h = active * h_new + (1 - active) * h
-        outs.append(h_new * active)
+        h_emit = h_new if h_round is None else ste_round(h_new, h_round)
+        h_fb = h if h_round is None else active * h_emit + (1 - active) * h_fb
+        outs.append(h_emit * active)
     out = torch.stack(outs, dim=0)
     if reverse:
         out = reverse_sequence(out, seq_len)
@@ -132,3 +146,139 @@ def init_lstm_params(rng, din, H, init=0.1, dtype=torch.float64):
     u = lambda *s: torch.tensor(rng.uniform(-init, init, size=s), dtype=dtype)
     return dict(w=u(din + H, 4 * H), b=torch.zeros(4 * H, dtype=dtype),
                 wci=u(H), wcf=u(H), wco=u(H))
+
+
+# --------------------------------------------------------------------------------------------------
+# Second, independent restatement (numpy, explicit BPTT -- no autograd) of ONE direction of a layer,
+# with optional rounding of the MFMA operands.  Two uses (tests only):
+#   * round_fn=None: fp64 hand-derived forward + backward of the same LSTMBlockCell / dynamic_rnn
+#     semantics as above (peepholes, forget bias, straight-through cell clip, sequence_length masking,
+#     reverse_sequence) -- checked against the autograd path in tests/test_oracle.py, so the two
+#     statements of the peephole / clip / masking rules pin each other;
+#   * round_fn=bf16_round: the rounding points of the bf16-operand device kernels (csrc/lstm_cluster.hip,
+#     csrc/lstm.hip) are reproduced -- x, W_x, W_h, the fed-back / emitted h, the saved gate
+#     activations and the gate gradients entering dG.W_h^T are bf16, everything else fp64 -- so the
+#     device results can be held to ~1e-3 instead of "within bf16 noise of the fp64 oracle".
+def bf16_round(a):
+    """float array -> nearest-even bfloat16 -> float64 (numpy in, numpy out)."""
+    import numpy as np
+    t = torch.as_tensor(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float64)
+    return t.numpy()
+
+
+def _sig(x):
+    import numpy as np
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def layer_forward_np(x_tm, lens, p, reverse=False, forget_bias=1.0, cell_clip=0.0, use_peephole=True,
+                     round_fn=None):
+    """x_tm [T,B,Din] float64 numpy (already rounded by the caller if round_fn is used);
+    p: dict of numpy arrays w [Din+H,4H] (columns i|ci|f|o), b, wci, wcf, wco.
+    Returns dict: gates [T,B,4,H] (post-activation i, ci, f, o stored at the FRAME they belong to;
+    rounded if round_fn), cs [T,B,H], hout [T,B,H] (zero past len; rounded), c_final, h_final
+    (h_final unrounded fp32-like: the device keeps the final h in fp32)."""
+    import numpy as np
+    rnd = round_fn if round_fn is not None else (lambda a: a)
+    T, B, Din = x_tm.shape
+    H = p['b'].shape[0] // 4
+    w = rnd(p['w'])
+    wx, wh = w[:Din], w[Din:]
+    wci, wcf, wco = (p['wci'], p['wcf'], p['wco']) if use_peephole else (0.0, 0.0, 0.0)
+    lens = np.asarray(lens)
+    xproj = x_tm.reshape(T * B, Din) @ wx + p['b']
+    xproj = xproj.reshape(T, B, 4 * H)
+    gates = np.zeros((T, B, 4, H))
+    cs = np.zeros((T, B, H))
+    hout = np.zeros((T, B, H))
+    c = np.zeros((B, H))
+    h = np.zeros((B, H))          # unrounded running h (the device's fp32 register copy)
+    hb = np.zeros((B, H))         # what is fed back through W_h (rounded)
+    rows = np.arange(B)
+    for s in range(int(lens.max()) if B else 0):
+        act = s < lens
+        fr = np.where(act, (lens - 1 - s) if reverse else s, 0)
+        pre = xproj[fr, rows] + hb @ wh
+        i = _sig(pre[:, :H] + wci * c)
+        g = np.tanh(pre[:, H:2 * H])
+        f = _sig(pre[:, 2 * H:3 * H] + forget_bias + wcf * c)
+        cn = g * i + c * f
+        if cell_clip and cell_clip > 0:
+            cn = np.clip(cn, -cell_clip, cell_clip)
+        o = _sig(pre[:, 3 * H:] + wco * cn)
+        hn = np.tanh(cn) * o
+        a = act[:, None]
+        c = np.where(a, cn, c)
+        h = np.where(a, hn, h)
+        hb = np.where(a, rnd(hn), hb)
+        ra, fa = rows[act], fr[act]
+        gates[fa, ra] = rnd(np.stack([i, g, f, o], 1))[act]
+        cs[fa, ra] = cn[act]
+        hout[fa, ra] = rnd(hn)[act]
+    return dict(gates=gates, cs=cs, hout=hout, c_final=c, h_final=h, xproj=xproj)
+
+
+def layer_backward_np(dout, gates, cs, lens, p, reverse=False, use_peephole=True, d_c_final=None,
+                      d_h_final=None, round_fn=None):
+    """Explicit BPTT of layer_forward_np (LSTMBlockCellGrad semantics: cell clip straight-through).
+    dout [T,B,H] gradient w.r.t. the emitted outputs; gates/cs as saved by the forward (by frame).
+    Returns dict: dgates [T,B,4,H] (pre-activation gradients i, ci, f, o by frame, zero past len; rounded
+    if round_fn), dpeep [3,H] (wci, wcf, wco), db [4H]."""
+    import numpy as np
+    rnd = round_fn if round_fn is not None else (lambda a: a)
+    T, B, H = dout.shape
+    Din = p['w'].shape[0] - H
+    wh = rnd(p['w'])[Din:]                                  # [H,4H]
+    wci, wcf, wco = (p['wci'], p['wcf'], p['wco']) if use_peephole else (0.0, 0.0, 0.0)
+    lens = np.asarray(lens)
+    dgates = np.zeros((T, B, 4, H))
+    dpeep = np.zeros((3, H))
+    dh_rec = np.zeros((B, H)) if d_h_final is None else np.array(d_h_final, dtype=np.float64)
+    dc_car = np.zeros((B, H)) if d_c_final is None else np.array(d_c_final, dtype=np.float64)
+    rows = np.arange(B)
+    for s in range((int(lens.max()) if B else 0) - 1, -1, -1):
+        act = s < lens
+        fr = np.where(act, (lens - 1 - s) if reverse else s, 0)
+        hasp = act & (s > 0)
+        frp = np.where(hasp, (lens - s) if reverse else s - 1, 0)
+        gt = gates[fr, rows]
+        i, g, f, o = gt[:, 0], gt[:, 1], gt[:, 2], gt[:, 3]
+        c = cs[fr, rows]
+        cprev = np.where(hasp[:, None], cs[frp, rows], 0.0)
+        dh = dout[fr, rows] + dh_rec
+        tc = np.tanh(c)
+        d_o = dh * tc * o * (1 - o)
+        dc = dc_car + dh * o * (1 - tc * tc) + d_o * wco
+        d_g = dc * i * (1 - g * g)
+        d_i = dc * g * i * (1 - i)
+        d_f = dc * cprev * f * (1 - f)
+        a = act[:, None]
+        dG = np.where(a[:, :, None], np.stack([d_i, d_g, d_f, d_o], 1), 0.0)    # [B,4,H]
+        dpeep[0] += (dG[:, 0] * cprev).sum(0)
+        dpeep[1] += (dG[:, 2] * cprev).sum(0)
+        dpeep[2] += (dG[:, 3] * c * a).sum(0)
+        dGr = rnd(dG)
+        ra, fa = rows[act], fr[act]
+        dgates[fa, ra] = dGr[act]
+        dc_car = np.where(a, dc * f + d_i * wci + d_f * wcf, dc_car)
+        dh_rec = np.where(a, dGr.reshape(B, 4 * H) @ wh.T, dh_rec)
+    db = dgates.sum((0, 1)).reshape(4 * H)
+    return dict(dgates=dgates, dpeep=dpeep, db=db)
+
+
+def layer_param_grads_np(x_tm, hout, dgates, lens, p, reverse=False, round_fn=None):
+    """dW [Din+H,4H], dx [T,B,Din] from the gate gradients, as the host driver forms them
+    (models/encoders/core/rnn_util.py): dW_x = x^T dG, dW_h = h_prev^T dG, dx = dG W_x^T."""
+    import numpy as np
+    rnd = round_fn if round_fn is not None else (lambda a: a)
+    T, B, Din = x_tm.shape
+    H = hout.shape[2]
+    dg = dgates.reshape(T * B, 4 * H)
+    hp = np.zeros_like(hout)
+    if reverse:
+        hp[:-1] = hout[1:]
+    else:
+        hp[1:] = hout[:-1]
+    dw = np.concatenate([x_tm.reshape(T * B, Din).T @ dg, hp.reshape(T * B, H).T @ dg], 0)
+    dx = (dg @ rnd(p['w'])[:Din].T).reshape(T, B, Din)
+    return dw, dx

@@ -63,8 +63,18 @@ def params_from_state_dict(sd, num_layers, ndir=2, dtype=torch.float64, requires
 
 def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, cell_clip=0.0,
                       weight_decay=0.0, drop_masks=None, dtype=torch.float64, temperature=1.0, vgg=None,
-                      bottleneck=False):
-    """Returns dict(total_loss, ctc_losses [B], logits [T,B,C], grads {name: array})."""
+                      bottleneck=False, operand_round=None):
+    """Returns dict(total_loss, ctc_losses [B], logits [T,B,C], grads {name: array}).
+    operand_round (e.g. oracle.lstm.bf16_round_t): reproduces the rounding points of the bf16-operand device path in
+    the forward -- inputs, LSTM kernels, output weights and every emitted / fed-back h are rounded (straight-through),
+    state, biases, peepholes and all accumulation stay in `dtype`."""
+    if operand_round is not None:
+        sd = dict(sd)
+        for k in list(sd):
+            if k.endswith('/kernel') or k == 'output/weights':
+                v = sd[k].detach().cpu() if torch.is_tensor(sd[k]) else torch.as_tensor(np.asarray(sd[k]))
+                sd[k] = operand_round(v.to(torch.float64)).numpy()
+        inputs_btd = operand_round(torch.as_tensor(np.asarray(inputs_btd), dtype=torch.float64)).numpy()
     layers = params_from_state_dict(sd, num_layers, ndir, dtype)
     w_out = torch.as_tensor(np.asarray(sd['output/weights'].detach().cpu() if torch.is_tensor(sd['output/weights']) else sd['output/weights']), dtype=dtype).clone().requires_grad_(True)
     b_out = torch.as_tensor(np.asarray(sd['output/biases'].detach().cpu() if torch.is_tensor(sd['output/biases']) else sd['output/biases']), dtype=dtype).clone().requires_grad_(True)
@@ -80,6 +90,8 @@ def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, 
         # frames past seq_len feed the LSTM but are masked there, exactly as in the reference
     peep = layers[0][0]['_peep'] if ndir == 2 else layers[0]['_peep']
     kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=peep)
+    if operand_round is not None:
+        kw['h_round'] = operand_round
     if ndir == 2:
         enc, final = olstm.blstm_encoder(x, sl, layers, drop_masks, **kw)
     else:

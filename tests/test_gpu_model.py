@@ -415,3 +415,56 @@ def test_overfit_one_utterance_to_low_ler(cuda, dtype):
             if ler < 0.1:
                 break
     assert ler < 0.1, (step, ler)
+
+
+def test_cfgB_bf16_model_parity_at_the_benchmarked_shape(cuda):
+    """BASELINE configs[1] exactly as bench.py times it (TIMIT-61, 5x256 BLSTM-CTC, bf16 operands, B = 16, D = 120,
+    C = 62, seq_len ~ U{100..778}; same seeded batch and the same constructor arguments as bench.py) against the oracle
+    evaluated on the bf16-rounded operands (inputs, LSTM kernels, output weights, every emitted / fed-back h rounded,
+    straight-through; state and accumulation fp64): mean loss, per-utterance losses, logits, EVERY parameter
+    gradient, and the greedy labels (as a label error rate against the oracle's decode: one flipped argmax anywhere
+    in 6.4k frames changes a label, so this is a rate, not bit-exactness -- bit-exact decode is asserted on the fp32
+    path).  Runs the multi-CU cluster kernels for 778 steps; the hand-off error word must stay 0.
+    Reference: models/ctc/ctc.py:175-323, models/encoders/core/blstm.py:258-332."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_batch
+    from oracle import lstm as olstm
+    from tensorflow_end2end_speech_recognition_amd import ops
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import sparsetensor2list
+    from tensorflow_end2end_speech_recognition_amd.utils.evaluation.edit_distance import compute_ler
+    B, D, H, L, C = 16, 120, 256, 5, 62
+    x, sl, labs, dense = make_batch(1, B, D, C, 100, 778)
+    model = CTC('blstm', D, H, L, C - 1, parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='bf16',
+                device='cuda:0', seed=0)
+    sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+    loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    opt = model._set_optimizer('rmsprop', 1e-3)
+    gv = opt.compute_gradients(loss, model=model)
+    assert ops.check_async_errors(0) == 0
+    ref = omodel.ctc_model_forward(sd, x, labs, sl, L, cell_clip=50.0, operand_round=olstm.bf16_round_t)
+    rel = abs(loss.item() - ref['total_loss']) / abs(ref['total_loss'])
+    per_utt = np.abs(model.ctc_losses.cpu().numpy() - ref['ctc_losses']).max() / ref['ctc_losses'].max()
+    lg = logits.cpu().numpy()
+    valid = (np.arange(lg.shape[0])[:, None] < sl[None, :])
+    elog = np.abs(lg - ref['logits'])[valid]
+    report = ['loss %.6f vs oracle %.6f  rel %.2e   per-utterance rel %.2e   logits max abs %.2e mean abs %.2e'
+              % (loss.item(), ref['total_loss'], rel, per_utt, elog.max(), elog.mean())]
+    worst = 0.0
+    for g, name in gv:
+        r = ref['grads'][name]
+        e = np.abs(g.cpu().numpy() - r).max() / max(np.abs(r).max(), 1e-12)
+        report.append('%-44s rel-to-max %.2e' % (name, e))
+        worst = max(worst, e)
+    hyp = [list(h) for h in sparsetensor2list(model.decoder(logits, sl, beam_width=1), B)]
+    ref_hyp = odec.greedy_decode(np.transpose(ref['logits'], (1, 0, 2)), sl, C - 1)
+    ler = compute_ler(hyp, ref_hyp)
+    report.append('greedy decode vs oracle decode: label error rate %.4f (%d of %d utterances identical)'
+                  % (ler, sum(h == r for h, r in zip(hyp, ref_hyp)), B))
+    print('\n' + '\n'.join(report))
+    assert rel < 2e-3 and per_utt < 2e-3, report[0]
+    assert elog.max() < 5e-2 and elog.mean() < 2e-3, report[0]
+    assert worst < 2e-2, '\n'.join(report)
+    assert ler < 0.02, report[-1]

@@ -142,6 +142,8 @@ def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfin
     sl = torch.tensor(lens, dtype=torch.int32, device=cuda)
     gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, whf, peep, sl, H, ndir, dt, 1.0, cell_clip)
     res = dict(hout=hout.float().cpu().numpy(), cs=cs.cpu().numpy(), cf=cf.cpu().numpy(), hf=hf.cpu().numpy())
+    # saved activations, device layout [T,B,ndir,H,4] -> [ndir][T,B,4,H]
+    res['gates'] = gates.float().view(T, B, ndir, H, 4).permute(2, 0, 1, 4, 3).contiguous().cpu().numpy()
     if dout is not None:
         dcf = dhf = None
         if dfinal is not None:
@@ -297,6 +299,104 @@ def test_lstm_cluster_exchange_paths(cuda):
         assert np.array_equal(res[0]['cs'][:lens[b], b], res[1]['cs'][:lens[b], b])
     ref = _oracle_layer(x, ps, lens, ndir, 50.0, dout)
     assert np.abs(res[0]['hout'] - ref['hout']).max() < 3e-2
+
+
+def _err_stats(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    d = np.abs(got - ref)
+    return d.max() / max(np.abs(ref).max(), 1e-30), d.mean() / max(np.abs(ref).mean(), 1e-30)
+
+
+# (H, B, T, cell_clip): the shapes bench.py times (cfg B: H=256, B=16, T<=778) and the cfg C/D width
+HEADLINE_LSTM = [(256, 16, 778, 50.0), (256, 32, 300, 1.0), (512, 16, 300, 50.0), (512, 32, 778, 50.0)]
+
+
+@pytest.mark.parametrize('H,B,T,clip', HEADLINE_LSTM)
+def test_lstm_cluster_bf16_gradient_parity_headline_shapes(cuda, H, B, T, clip):
+    """The multi-CU bf16 recurrence kernels (lstm_{fwd,bwd}_cluster8_kernel<256|512>, what bench.py times) against the
+    oracle evaluated ON THE SAME bf16-rounded operands (oracle.lstm.layer_*_np with round_fn=bf16_round reproduces the
+    kernels' rounding points: x, W, fed-back / emitted h, saved gates, dG entering dG.W_h^T), at the headline shapes:
+    ragged lengths up to T = 778 (the double-buffered tag/parity exchange runs for the full sequence), ndir = 2,
+    gradients entering through the outputs AND the final states.  Compared: hout, cs, c/h_final, saved gates, dgates,
+    dW_x, dW_h, db, dx, dpeep.  What remains between device and oracle is fp32-vs-fp64 arithmetic plus the rare
+    element whose fp32 value sits on a bf16 rounding boundary and rounds the other way (1 bf16 ulp = 2^-8 relative on
+    that element): max-norm tolerances are therefore a few bf16 ulps of the largest entry, the mean error is held
+    ~100x tighter than the bf16 step.
+    Reference semantics: models/encoders/core/blstm.py:286-323."""
+    ops = _ops()
+    ndir, D = 2, 48
+    rng = np.random.RandomState(H + B + T)
+    lens = rng.randint(T // 3, T + 1, size=B)
+    lens[0], lens[3] = T, 1
+    if B > 16:
+        lens[17], lens[20] = 0, T
+    x = olstm.bf16_round(rng.randn(B, T, D))
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    ps = [olstm.init_lstm_params(rng, D, H, init=0.1) for _ in range(ndir)]
+    for p in ps:
+        p['b'] = torch.tensor(rng.uniform(-0.1, 0.1, 4 * H))
+    dout = rng.randn(T, B, ndir * H)
+    dfinal = (rng.randn(ndir, B, H) * 0.5, rng.randn(ndir, B, H) * 0.5)
+    got = _run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', clip, dout, dfinal)
+    assert ops.check_async_errors(0) == 0
+    xt = np.ascontiguousarray(np.transpose(x, (1, 0, 2)))
+    R = olstm.bf16_round
+    valid = (np.arange(T)[:, None] < lens[None, :])                   # [T,B]
+    checks = []                                                       # (what, measured, bound)
+
+    def chk(what, val, bound):
+        checks.append((what, float(val), bound))
+
+    for d in range(ndir):
+        pn = {k: v.detach().numpy() for k, v in ps[d].items()}
+        rev = d == 1
+        tag = 'bw ' if rev else 'fw '
+        f = olstm.layer_forward_np(xt, lens, pn, rev, 1.0, clip, True, round_fn=R)
+        if clip < 10:
+            assert np.abs(f['cs']).max() == clip                      # the clip is exercised
+        sl = slice(d * H, (d + 1) * H)
+        # ---- forward
+        e = np.abs(got['hout'][:, :, sl] - f['hout'])
+        chk(tag + 'hout max abs', e.max(), 2 ** -7)
+        chk(tag + 'hout mean abs', e.mean(), 2e-5)
+        assert np.abs(got['hout'][:, :, sl][~valid]).max() == 0     # padded frames exactly zero
+        ecs = np.abs(got['cs'][:, :, sl] - f['cs'])[valid]
+        chk(tag + 'cs max abs / max|cs|', ecs.max() / max(1.0, np.abs(f['cs']).max()), 2e-2)
+        chk(tag + 'cs mean abs', ecs.mean(), 1e-4)
+        eg = np.abs(got['gates'][d] - f['gates'])[valid]
+        chk(tag + 'gates max abs', eg.max(), 2 ** -6)
+        chk(tag + 'gates mean abs', eg.mean(), 5e-5)
+        chk(tag + 'c_final max abs', np.abs(got['cf'][d] - f['c_final']).max(), 2e-2)
+        chk(tag + 'h_final max abs', np.abs(got['hf'][d] - f['h_final']).max(), 5e-3)
+        # ---- backward kernel in isolation: explicit BPTT fed with the DEVICE's saved activations
+        dg_dev = got['dgates'][:, :, d * 4 * H:(d + 1) * 4 * H].reshape(T, B, 4, H)
+        bwd = olstm.layer_backward_np(dout[:, :, sl], got['gates'][d], got['cs'][:, :, sl], lens, pn, rev, True,
+                                      dfinal[0][d], dfinal[1][d], round_fn=R)
+        mx, mean = _err_stats(dg_dev, bwd['dgates'])
+        chk(tag + 'dgates|device activations max rel', mx, 4e-3)
+        chk(tag + 'dgates|device activations mean rel', mean, 1e-3)
+        assert np.abs(dg_dev[~valid]).max() == 0
+        chk(tag + 'dpeep|device activations', _rel(got['dpeep'][d, :3], bwd['dpeep']), 2e-3)
+        chk(tag + 'db|device activations', _rel(got['dpeep'][d, 3:7].reshape(-1), bwd['db']), 2e-3)
+        # ---- whole chain against the oracle's own forward (device never consulted)
+        full = olstm.layer_backward_np(dout[:, :, sl], f['gates'], f['cs'], lens, pn, rev, True,
+                                       dfinal[0][d], dfinal[1][d], round_fn=R)
+        mx, mean = _err_stats(dg_dev, full['dgates'])
+        chk(tag + 'dgates max rel', mx, 2e-2)
+        chk(tag + 'dgates mean rel', mean, 3e-3)
+        chk(tag + 'dpeep', _rel(got['dpeep'][d, :3], full['dpeep']), 5e-3)
+        chk(tag + 'db', _rel(got['dpeep'][d, 3:7].reshape(-1), full['db']), 5e-3)
+        # weight / input gradients as the host driver forms them from dgates (x^T dG, h_prev^T dG, dG W_x^T)
+        dw_ref, dx_ref = olstm.layer_param_grads_np(xt, f['hout'], full['dgates'], lens, pn, rev, round_fn=R)
+        dw_dev, dx_dev = olstm.layer_param_grads_np(xt, got['hout'][:, :, sl].astype(np.float64), dg_dev.astype(np.float64),
+                                                    lens, pn, rev, round_fn=R)
+        chk(tag + 'dW_x', _rel(dw_dev[:D], dw_ref[:D]), 3e-3)
+        chk(tag + 'dW_h', _rel(dw_dev[D:], dw_ref[D:]), 3e-3)
+        chk(tag + 'dx', _rel(dx_dev, dx_ref), 1e-2)
+    table = '\n'.join('%-44s %.3e  (bound %.1e)%s' % (w, v, bnd, '' if v <= bnd else '   <-- FAIL') for w, v, bnd in checks)
+    print('\nH=%d B=%d T=%d clip=%g\n%s' % (H, B, T, clip, table))
+    assert all(v <= bnd for _, v, bnd in checks), table
 
 
 # --------------------------------------------------------------------------- CTC

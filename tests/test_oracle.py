@@ -379,3 +379,48 @@ def test_conv_and_pool_conventions_match_tensorflow_known_answers():
     assert (ovgg._conv(xi, w3, b3) - want).abs().max().item() < 1e-12
     pooled = ovgg._pool_same(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).reshape(-1).tolist()
     assert pooled == tfk.POOL_SAME_OUT
+
+
+@pytest.mark.parametrize('reverse', [False, True])
+@pytest.mark.parametrize('clip,peep', [(0.0, True), (0.6, True), (0.6, False)])
+def test_lstm_explicit_bptt_matches_autograd(reverse, clip, peep):
+    """Second implementation of the peephole / cell-clip / sequence_length rules: the numpy forward +
+    hand-derived BPTT (oracle.lstm.layer_*_np, LSTMBlockCellGrad form with the straight-through clip)
+    against the torch-autograd statement, ragged lengths incl. 0 and 1, gradients entering through
+    the outputs and the final (c, h)."""
+    rng = np.random.RandomState(3 + int(reverse))
+    T, B, D, H = 11, 6, 5, 8
+    lens = np.array([11, 3, 1, 0, 7, 11])
+    x = rng.randn(B, T, D) * 2
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    p = olstm.init_lstm_params(rng, D, H, 0.5)
+    p['b'] = torch.tensor(rng.randn(4 * H) * 0.3)
+    pt = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xt = torch.tensor(x).transpose(0, 1).contiguous().requires_grad_(True)
+    out, (cf, hf) = olstm.dynamic_rnn(xt, torch.tensor(lens), pt, reverse=reverse, cell_clip=clip, use_peephole=peep)
+    dout, dcf, dhf = rng.randn(T, B, H), rng.randn(B, H), rng.randn(B, H)
+    ((out * torch.tensor(dout)).sum() + (cf * torch.tensor(dcf)).sum() + (hf * torch.tensor(dhf)).sum()).backward()
+    pn = {k: v.numpy() for k, v in p.items()}
+    f = olstm.layer_forward_np(xt.detach().numpy(), lens, pn, reverse, 1.0, clip, peep)
+    if clip:
+        assert np.abs(f['cs']).max() == clip      # the clip is active in this case
+    assert np.abs(f['hout'] - out.detach().numpy()).max() < 1e-13
+    assert np.abs(f['c_final'] - cf.detach().numpy()).max() < 1e-13
+    assert np.abs(f['h_final'] - hf.detach().numpy()).max() < 1e-13
+    bw = olstm.layer_backward_np(dout, f['gates'], f['cs'], lens, pn, reverse, peep, dcf, dhf)
+    dw, dx = olstm.layer_param_grads_np(xt.detach().numpy(), f['hout'], bw['dgates'], lens, pn, reverse)
+    assert np.abs(dw - pt['w'].grad.numpy()).max() < 1e-12
+    assert np.abs(dx - xt.grad.numpy()).max() < 1e-12
+    assert np.abs(bw['db'] - pt['b'].grad.numpy()).max() < 1e-12
+    if peep:
+        for k, n in enumerate(('wci', 'wcf', 'wco')):
+            assert np.abs(bw['dpeep'][k] - pt[n].grad.numpy()).max() < 1e-12
+    # the rounded variants of the two statements agree with each other as well (bf16 operand points)
+    xr = olstm.bf16_round(xt.detach().numpy())
+    pr = {k: v.clone() for k, v in p.items()}
+    pr['w'] = olstm.bf16_round_t(pr['w'])
+    o2, _ = olstm.dynamic_rnn(torch.tensor(xr), torch.tensor(lens), pr, reverse=reverse, cell_clip=clip,
+                              use_peephole=peep, h_round=olstm.bf16_round_t)
+    f2 = olstm.layer_forward_np(xr, lens, pn, reverse, 1.0, clip, peep, round_fn=olstm.bf16_round)
+    assert np.abs(f2['hout'] - o2.numpy()).max() < 1e-12
