@@ -206,6 +206,16 @@ int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
  * slices of h / dh to each other inside the launch (bounded spins).  This synchronises the device
  * and reports a hand-off timeout (never expected; ASR_ERR_HIP) -- call at a sync point. */
 int asr_check_async_errors(asr_handle* h, unsigned* flags_out);
+/* Non-blocking form for training loops: enqueues ONE 4-byte device->host copy of the sticky error word on `s` into
+ * host_flags (pinned host memory owned by the caller; valid once work on `s` up to here has completed) -- the Python
+ * front end arms it after every optimizer step and inspects the previous step's word (ops.ErrorWatch), so a timed-out
+ * hand-off raises within one step instead of silently training on garbage. */
+int asr_peek_async_errors(asr_handle* h, unsigned* host_flags, asr_stream s);
+/* Resets the sticky error word (after it has been reported). */
+int asr_clear_async_errors(asr_handle* h, asr_stream s);
+/* Debug / test switches of the cluster kernels (process-wide, same bits as the environment variable ASR_LSTM_DFLAGS):
+ * 16 = force the placement-independent write-through exchange, 64 = TEST ONLY, make every hand-off time out. */
+int asr_debug_set_lstm_flags(int flags);
 
 /* ---- CTC ------------------------------------------------------------------ *
  * tf.nn.ctc_loss(labels, logits, seq_len, preprocess_collapse_repeated=False,

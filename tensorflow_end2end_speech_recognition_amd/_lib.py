@@ -47,6 +47,9 @@ SIGNATURES = {
     'asr_lstm_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp]),
     'asr_check_async_errors': (_i, [_vp, C.POINTER(C.c_uint)]),
+    'asr_peek_async_errors': (_i, [_vp, _vp, _vp]),
+    'asr_clear_async_errors': (_i, [_vp, _vp]),
+    'asr_debug_set_lstm_flags': (_i, [_i]),
     'asr_ctc_workspace_bytes': (_sz, [_i, _i, _i]),
     'asr_ctc_loss': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'asr_ctc_greedy_decode': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),

@@ -48,6 +48,9 @@ class Optimizer(object):
         st = self.store
         ops.optimizer_step(self.opt_id, st.flat, st.grad, self.slot0, self.slot1, lr, self.global_step)
         st.mark_dirty()
+        if st.flat.is_cuda:
+            # hand-off timeouts of the multi-CU recurrence kernels must not train on silently (raises AsrError)
+            ops.watch_async_errors(st.flat.device)
         return self.global_step
 
     def state_dict(self):

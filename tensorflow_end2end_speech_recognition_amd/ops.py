@@ -387,11 +387,68 @@ def lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c
 
 
 def check_async_errors(device=0):
-    """Device sync + sticky error word of the multi-CU LSTM kernels (raises on a hand-off timeout)."""
+    """Device sync + sticky error word of the multi-CU LSTM kernels (raises on a hand-off timeout).
+    The blocking form: call at sync points (evaluation, checkpoint, end of an epoch)."""
     h = _lib.handle(device)
     flags = C.c_uint(0)
-    h.check(h.lib.asr_check_async_errors(h.h, C.byref(flags)), 'asr_check_async_errors')
+    rc = h.lib.asr_check_async_errors(h.h, C.byref(flags))
+    if flags.value:
+        h.lib.asr_clear_async_errors(h.h, _s())     # sticky until reported once
+    h.check(rc, 'asr_check_async_errors')
     return flags.value
+
+
+class ErrorWatch(object):
+    """Non-blocking watch on the sticky error word of the cluster recurrence kernels.
+
+    poll() is called once per optimizer step (models/model_base.py Optimizer.apply_gradients): it enqueues a 4-byte
+    device->host copy of the word behind the step's kernels and inspects the copy armed DEPTH polls earlier (its event
+    has long completed, so the host never stalls in steady state).  A hand-off timeout therefore raises AsrError at
+    most DEPTH steps after it happened instead of silently corrupting the weights."""
+    DEPTH = 3
+
+    def __init__(self, device):
+        self.dev = device
+        self.host = torch.zeros(self.DEPTH, dtype=torch.int32).pin_memory()
+        self.events = [None] * self.DEPTH
+        self.i = 0
+
+    def poll(self):
+        slot = self.i % self.DEPTH
+        ev = self.events[slot]
+        if ev is not None:
+            ev.synchronize()
+            flags = int(self.host[slot])
+            if flags:
+                h = _lib.handle(self.dev)
+                h.lib.asr_clear_async_errors(h.h, _s())
+                self.events = [None] * self.DEPTH
+                raise _lib.AsrError('LSTM cluster hand-off timed out (flags 0x%x): the recurrent state of a recent '
+                                    'step is garbage -- restore the last checkpoint' % flags)
+        h = _lib.handle(self.dev)
+        h.check(h.lib.asr_peek_async_errors(h.h, C.c_void_p(self.host.data_ptr() + 4 * slot), _s()),
+                'asr_peek_async_errors')
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[slot] = ev
+        self.i += 1
+
+
+_watches = {}
+
+
+def watch_async_errors(device):
+    """One ErrorWatch per device; see ErrorWatch.poll."""
+    dev = device.index or 0 if isinstance(device, torch.device) else int(device)
+    w = _watches.get(dev)
+    if w is None:
+        w = _watches[dev] = ErrorWatch(dev)
+    w.poll()
+
+
+def debug_set_lstm_flags(flags):
+    """ASR_LSTM_DFLAGS at run time (tests): 16 = write-through exchange, 64 = force hand-off timeouts."""
+    _lib.load().asr_debug_set_lstm_flags(int(flags))
 
 
 # ---------------------------------------------------------------- CTC

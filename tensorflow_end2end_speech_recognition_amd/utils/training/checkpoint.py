@@ -67,6 +67,10 @@ class Saver(object):
         `sess` may be the model itself (there is no session); returns the checkpoint prefix."""
         model = model if model is not None else sess
         prefix = save_path if global_step is None else '%s-%d' % (save_path, int(global_step))
+        if model.store.flat.is_cuda:
+            # a checkpoint is a sync point anyway: never persist weights trained through a timed-out hand-off
+            from ... import ops
+            ops.check_async_errors(model.store.flat.device.index or 0)
         arrays = {n: v.detach().cpu().numpy() for n, v in model.store.state_dict().items()}
         opt = getattr(model, 'optimizer', None)
         if opt is not None:
@@ -97,7 +101,8 @@ class Saver(object):
         return prefix
 
     def restore(self, sess, save_path, model=None):
-        """Loads the variables (and, when the model already has a matching optimizer, its slots)."""
+        """Loads the variables and the optimizer state (slots, global_step); an optimizer the model has not created yet
+        is built from the checkpoint's record."""
         model = model if model is not None else sess
         path = self._file(save_path)
         if not os.path.isfile(path):
@@ -109,10 +114,21 @@ class Saver(object):
                 raise ValueError('checkpoint %s lacks variables: %s' % (path, ', '.join(missing[:5])))
             model.store.load_state_dict({n: torch.from_numpy(np.asarray(z[n], dtype=np.float32)) for n in names})
             opt = getattr(model, 'optimizer', None)
-            if opt is not None and (_OPT + 'name') in z.files and str(z[_OPT + 'name']) == opt.name:
-                opt.global_step = int(z[_OPT + 'global_step'])
-                for k in ('slot0', 'slot1'):
-                    t = getattr(opt, k)
-                    if t is not None and (_OPT + k) in z.files:
-                        t.copy_(torch.from_numpy(z[_OPT + k]).to(t.device))
+            if (_OPT + 'name') in z.files:
+                saved = str(z[_OPT + 'name'])
+                if opt is None and hasattr(model, '_set_optimizer'):
+                    # the recipes create the optimizer lazily inside train(): build it now so that a
+                    # restore-then-train resume continues the saved slots / Adam step (train() adopts it,
+                    # only the learning rate is replaced)
+                    opt = model.optimizer = model._set_optimizer(saved, 0.0)
+                if opt is not None and saved == opt.name:
+                    opt.global_step = int(z[_OPT + 'global_step'])
+                    for k in ('slot0', 'slot1'):
+                        t = getattr(opt, k)
+                        if t is not None and (_OPT + k) in z.files:
+                            t.copy_(torch.from_numpy(z[_OPT + k]).to(t.device))
+                elif opt is not None:
+                    import warnings
+                    warnings.warn('checkpoint %s holds %s optimizer state but the model uses %s: slots and '
+                                  'global_step restart from their initial values' % (path, saved, opt.name))
         return model

@@ -12,6 +12,22 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _bounded_cpu_threads():
+    """The oracle's per-time-step loops do thousands of tiny matmuls: on a 256-core GPU-box host an unbounded
+    BLAS / torch thread pool spends its time waking threads (measured: 9.5 s vs 0.6 s for one 300-step layer)."""
+    import torch
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    try:
+        from threadpoolctl import threadpool_limits
+        ctl = threadpool_limits(limits=4, user_api='blas')
+    except Exception:       # threadpoolctl absent: run unbounded
+        ctl = None
+    yield
+    if ctl is not None:
+        ctl.restore_original_limits()
+
+
 @pytest.fixture(scope='session')
 def cuda():
     import torch

@@ -131,6 +131,23 @@ def test_saver_roundtrip(tmp_path):
     assert torch.equal(m.optimizer.slot0, slot) and m.optimizer.global_step == 17
     with np.load(best + '.npz') as z:
         assert z['blstm_hidden1/fw/lstm_cell/kernel'].shape == (7, 12)
+    # resume into a model whose optimizer does not exist yet (the recipes create it lazily inside train()):
+    # restore builds it from the checkpoint's record, so Adam's moments and bias-correction step continue
+    from tensorflow_end2end_speech_recognition_amd.models.model_base import ModelBase
+    fresh = ModelBase()
+    fresh.store = ParamStore(torch.device('cpu'))
+    fresh.store.declare('blstm_hidden1/fw/lstm_cell/kernel', (7, 12), np.zeros((7, 12)))
+    fresh.store.declare('output/biases', (5,), np.zeros(5))
+    fresh.store.finalize()
+    assert fresh.optimizer is None
+    saver.restore(fresh, best)
+    assert fresh.optimizer is not None and fresh.optimizer.name == 'adam' and fresh.optimizer.global_step == 17
+    assert torch.equal(fresh.optimizer.slot0, slot)
+    other = ModelBase()
+    other.store = fresh.store
+    other.optimizer = Optimizer('rmsprop', 1e-3, other.store)
+    with pytest.warns(UserWarning):
+        saver.restore(other, best)
     with pytest.raises(ValueError):
         saver.restore(m, os.path.join(str(tmp_path), 'model.ckpt-9'))
 
