@@ -56,15 +56,19 @@ def _direction(x_tm, seq_len, p, reverse, clip):
 
 
 class CpuBLSTMCTC(object):
-    def __init__(self, state_dict, num_layers, cell_clip=0.0, clip_grad_norm=None, threads=None):
+    def __init__(self, state_dict, num_layers, cell_clip=0.0, clip_grad_norm=None, threads=None,
+                 optimizer='momentum'):
         if threads:
             torch.set_num_threads(threads)
+        assert optimizer in ('momentum', 'rmsprop')
+        self.optimizer = optimizer
         self.L = num_layers
         self.clip = cell_clip
         self.clip_grad_norm = clip_grad_norm
         self.params = {k: torch.tensor(np.asarray(v), dtype=torch.float32).requires_grad_(True)
                        for k, v in state_dict.items()}
         self.mom = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.rms = {k: torch.ones_like(v) for k, v in self.params.items()}    # TF1 RMSProp: rms slot starts at 1
 
     def _layer_params(self, i, d):
         base = 'blstm_hidden%d/%s/lstm_cell' % (i, d)
@@ -90,7 +94,7 @@ class CpuBLSTMCTC(object):
         return losses.mean(), logits
 
     def train_step(self, x_btd, labels_list, seq_len, lr=1e-3):
-        """fwd + bwd + per-variable clip + momentum(0.9) update; returns loss value."""
+        """fwd + bwd + per-variable clip + update (momentum 0.9 or rmsprop); returns loss value."""
         for p in self.params.values():
             p.grad = None
         loss, _ = self.loss(x_btd, labels_list, seq_len)
@@ -101,8 +105,12 @@ class CpuBLSTMCTC(object):
                 if self.clip_grad_norm:
                     n = g.norm()
                     g = g * (self.clip_grad_norm / torch.clamp(n, min=self.clip_grad_norm))
-                self.mom[k].mul_(0.9).add_(g)
-                p.sub_(lr * self.mom[k])
+                if self.optimizer == 'rmsprop':   # tf.train.RMSPropOptimizer(decay 0.9, momentum 0, eps 1e-10)
+                    self.rms[k].mul_(0.9).addcmul_(g, g, value=0.1)
+                    p.sub_(lr * g / torch.sqrt(self.rms[k] + 1e-10))
+                else:
+                    self.mom[k].mul_(0.9).add_(g)
+                    p.sub_(lr * self.mom[k])
         return float(loss.detach())
 
 

@@ -63,7 +63,7 @@ def params_from_state_dict(sd, num_layers, ndir=2, dtype=torch.float64, requires
 
 def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, cell_clip=0.0,
                       weight_decay=0.0, drop_masks=None, dtype=torch.float64, temperature=1.0, vgg=None,
-                      bottleneck=False, operand_round=None):
+                      bottleneck=False, operand_round=None, want_grads=True):
     """Returns dict(total_loss, ctc_losses [B], logits [T,B,C], grads {name: array}).
     operand_round (e.g. oracle.lstm.bf16_round_t): reproduces the rounding points of the bf16-operand device path in
     the forward -- inputs, LSTM kernels, output weights and every emitted / fed-back h are rounded (straight-through),
@@ -124,8 +124,10 @@ def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, 
     if weight_decay > 0:
         l2 = sum(0.5 * (v ** 2).sum() for n, v in named.items() if 'bias' not in n.lower())
         total = total + weight_decay * l2
-    total.backward()
-    grads = {n: v.grad.detach().numpy().copy() for n, v in named.items()}
+    grads = None
+    if want_grads:
+        total.backward()
+        grads = {n: v.grad.detach().numpy().copy() for n, v in named.items()}
     return dict(total_loss=float(total.detach()), ctc_losses=losses.detach().numpy(),
                 logits=logits.detach().numpy(), grads=grads, enc=enc.detach().numpy(),
                 final=final)

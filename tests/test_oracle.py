@@ -252,6 +252,14 @@ def test_fast_cpu_port_matches_oracle():
     assert abs(float(loss.detach()) - r['total_loss']) < 1e-5
     assert max(np.abs(m.params[k].grad.numpy() - r['grads'][k]).max() for k in sd) < 1e-5
     assert np.isfinite(m.train_step(x, labs, sl))
+    # the rmsprop variant bench.py times: one step == oracle.optim on the clipped oracle gradients
+    m2 = fast_cpu.CpuBLSTMCTC(sd, L, cell_clip=50., clip_grad_norm=5.0, optimizer='rmsprop')
+    m2.train_step(x, labs, sl, lr=1e-3)
+    for k in sd:
+        g = oopt.clip_by_norm(r['grads'][k], 5.0)
+        s0, s1 = oopt.init_slots('rmsprop', np.asarray(sd[k], np.float64))
+        want, _, _ = oopt.step('rmsprop', np.asarray(sd[k], np.float64), g, s0, s1, 1e-3, 1)
+        assert np.abs(m2.params[k].detach().numpy() - want).max() < 1e-5, k
 
 
 def test_sigmoid_smoothing_backward_formula():
