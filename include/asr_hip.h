@@ -10,8 +10,12 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host;
- *   - the caller owns every buffer, including workspaces (no allocation and no
- *     synchronisation inside a call; everything is enqueued on `stream`);
+ *   - the caller owns every tensor and every per-call workspace argument (asr_*_workspace_bytes);
+ *     the handle owns ONE scratch arena, allocated once by asr_create / asr_create_ex and reported by
+ *     asr_scratch_bytes: deterministic split-K slabs and chunk partials of the calls that say so, and
+ *     (its top 16 MiB) the exchange slots + error word of the multi-CU recurrence kernels.  A call
+ *     that needs more than the arena holds returns ASR_ERR_WORKSPACE -- create the handle larger.
+ *     No allocation and no synchronisation inside any call; everything is enqueued on `stream`;
  *   - row-major, contiguous unless a leading dimension (ld*) is given;
  *   - returns 0 on success, a negative asr_status otherwise;
  *     asr_last_error_string() explains the last failure on that handle;
@@ -52,7 +56,9 @@ typedef enum {
 
 /* ---- lifetime ------------------------------------------------------------ */
 int asr_abi_version(void);
-int asr_create(asr_handle** out, int device);
+int asr_create(asr_handle** out, int device);                        /* 128 MiB scratch arena */
+int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes); /* >= 32 MiB */
+size_t asr_scratch_bytes(asr_handle* h);
 int asr_destroy(asr_handle* h);
 const char* asr_last_error_string(asr_handle* h);
 /* number of CUs / device name (for bench reporting) */
@@ -298,7 +304,30 @@ int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* s
 int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const float* alpha,
                             const int32_t* seq_len, float sharpening, const void* enc, int enc_dtype,
                             int T, int B, int E, float* denergy, float* denc,
-                            const float* sigmoid_norm, asr_stream s);
+                            const float* sigmoid_norm, const float* dalpha_extra, asr_stream s);
+/* dalpha_extra [B,T] (may be NULL): a further gradient w.r.t. alpha, added before the softmax gradient -- with
+ * carried location features the NEXT decoder step's conv1d hands one back (asr_att_loc_energy_bwd).
+ *
+ * Location / hybrid attention with the previous step's weights carried (attention_layer.py:191-265; the recurrence
+ * the reference wrote down -- its graph feeds zeros at every step, SURVEY Appendix A Q1, which stays the default of
+ * the Python model: prev_alpha='zeros' | 'carry'):
+ *   f = tf.nn.conv1d(alpha_prev[B,T,1], filter[taps,1,10], stride 1, 'SAME')    taps = 201 (location) / 200 (hybrid),
+ *       zero padding (taps-1)/2 frames before, the rest after; cross-correlation
+ *   energy[b,t] = sum_a v[a] tanh( keys[t,b,a] + qz[b,a] + (f W_filter)[b,t,a] )     keys NULL for 'location';
+ *       qz = W_query s + b_filter as for asr_att_energy_fwd.
+ * filt [taps,10] (the [taps,1,10] variable), wfil [10,A] (W_filter/weights). */
+int asr_att_loc_energy_fwd(asr_handle* h, const float* alpha_prev, const float* filt, const float* wfil,
+                           const float* keys, const float* qz, const float* v, int T, int B, int A, int taps,
+                           float* energy, asr_stream s);
+/* Gradients of the above for one decoder step.  dkeys[T,B,A] += (may be NULL); dqz[B,A], dv_rows[B,A] written;
+ * dwfil_rows[B,10,A] and dfilt_rows[B,taps,10]: per-utterance gradients of W_filter/weights and filter, overwritten
+ * when accumulate == 0 and added to otherwise (a decoder loop accumulates over its steps and sums over B once);
+ * dalpha_prev[B,T] written: gradient w.r.t. the previous step's weights (-> dalpha_extra of that step).
+ * Partials go through the handle scratch in a fixed order: run-to-run deterministic. */
+int asr_att_loc_energy_bwd(asr_handle* h, const float* denergy, const float* alpha_prev, const float* filt,
+                           const float* wfil, const float* keys, const float* qz, const float* v, int T, int B,
+                           int A, int taps, float* dkeys, float* dqz, float* dv_rows, float* dwfil_rows,
+                           float* dfilt_rows, float* dalpha_prev, int accumulate, asr_stream s);
 int asr_tanh_fwd(asr_handle* h, const float* x, float* y, size_t n, asr_stream s);
 int asr_tanh_bwd(asr_handle* h, const float* dy, const float* y, float* dx, size_t n, asr_stream s);
 /* tf.nn.embedding_lookup (attention_seq2seq.py:439) and its gradient (deterministic) */

@@ -14,9 +14,11 @@ Follows
   * models/attention/joint_ctc_attention.py:182-346 ((1-lambda)*xent + lambda*mean ctc on a
     'ctc_output' FC over the encoder outputs; the [B*T,C] -> [T,B,C] reshape bug Q2 is NOT
     reproduced: the intended transpose is used)
-Reference quirk Q1 IS reproduced because it is what the reference graph
+Reference quirk Q1 is reproduced by default because it is what the reference graph
 computes: the "previous attention weights" fed to location / hybrid attention are always the
-zeros tensor of initialize(), so the location features reduce to the W_filter bias.
+zeros tensor of initialize(), so the location features reduce to the W_filter bias.  prev_alpha='carry'
+selects the recurrence the code was written to express (attention_layer.py:191-265): the previous step's
+weights through conv1d([201|200, 1, 10], SAME) -> W_filter.
 """
 import numpy as np
 import torch
@@ -29,17 +31,37 @@ ADDITIVE = ('bahdanau_content', 'location', 'hybrid')
 DOT = ('dot_product', 'luong_dot', 'luong_general')
 
 
-def attention_step(p, att_type, enc_bt, keys, s, seq_len, sharpening=1.0, sigmoid_smoothing=False):
+def location_features(p, prev_alpha):
+    """attention_layer.py:200-221 / :239-257: f = tf.nn.conv1d(alpha_{i-1} [B,T,1], filter [taps,1,10], stride 1,
+    'SAME') -> fully_connected(10 -> A, bias).  SAME with an even kernel (hybrid: 200 taps) pads
+    (taps-1)//2 = 99 frames before and 100 after (SURVEY Appendix B); 201 taps (location): 100 / 100.
+    prev_alpha [B,T] -> [B,T,A]."""
+    filt = p['filter']                                                    # [taps,1,10]
+    taps = filt.shape[0]
+    before = (taps - 1) // 2
+    a = torch.nn.functional.pad(prev_alpha.unsqueeze(1), (before, taps - 1 - before))      # [B,1,T+taps-1]
+    f = torch.nn.functional.conv1d(a, filt.permute(2, 1, 0))             # cross-correlation, like tf.nn.conv1d
+    return f.transpose(1, 2) @ p['W_filter/weights'] + p['W_filter/biases']
+
+
+def attention_step(p, att_type, enc_bt, keys, s, seq_len, sharpening=1.0, sigmoid_smoothing=False,
+                   prev_alpha=None):
     """enc_bt [B,T,2H]; keys [B,T,A] or None; s [B,U] -> (alpha [B,T], ctx [B,2H]).
-    sigmoid_smoothing: attention_layer.py:92-96, sigmoid(e) / sum_t sigmoid(e) instead of the softmax."""
+    sigmoid_smoothing: attention_layer.py:92-96, sigmoid(e) / sum_t sigmoid(e) instead of the softmax.
+    prev_alpha: None = the reference's EFFECTIVE graph (quirk Q1: the location features see the zeros of
+    initialize() at every step, i.e. reduce to the W_filter bias); a [B,T] tensor = the INTENDED recurrence,
+    the previous step's attention weights go through conv1d -> W_filter (model switch prev_alpha='carry')."""
     B, T, _ = enc_bt.shape
     if att_type in ADDITIVE:
         z = (s @ p['W_query/weights']).unsqueeze(1)                       # [B,1,A]
         if att_type in ('bahdanau_content', 'hybrid'):
             z = z + keys
         if att_type in ('location', 'hybrid'):
-            z = z + p['W_filter/biases']          # conv(zeros) @ W_filter + b  (quirk Q1)
-        if att_type == 'location':
+            if prev_alpha is None:
+                z = z + p['W_filter/biases']      # conv(zeros) @ W_filter + b  (quirk Q1)
+            else:
+                z = z + location_features(p, prev_alpha)
+        if att_type == 'location' and z.shape[1] == 1:
             z = z.expand(B, T, z.shape[2])
         energy = (p['v_a'] * torch.tanh(z)).sum(2)
     elif att_type == 'dot_product':
@@ -88,8 +110,9 @@ def decoder_params(sd, dtype=torch.float64, requires_grad=True):
 def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_len, enc_layers,
                             att_type, clip_enc=0.0, clip_dec=0.0, sharpening=1.0, temperature=1.0,
                             drop_emb=None, drop_dec=None, ctc_labels=None, lambda_weight=None,
-                            dtype=torch.float64, sigmoid_smoothing=False):
+                            dtype=torch.float64, sigmoid_smoothing=False, prev_alpha='zeros'):
     """Teacher-forced forward + loss + all parameter gradients.
+    prev_alpha: 'zeros' (reference's effective graph, Q1) | 'carry' (previous step's weights feed location / hybrid).
     labels [B, Lmax] int (<SOS> y <EOS>, padded with eos); returns dict(loss, logits [B,To,C],
     alphas, grads, ...)."""
     from .model import params_from_state_dict
@@ -126,13 +149,17 @@ def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_l
         if has_peep else (z, z, z)
     ctx = x.new_zeros(B, E2)
     logits_steps, alphas, ids = [], [], []
+    carry = prev_alpha == 'carry' and att_type in ('location', 'hybrid')
+    a_prev = x.new_zeros(B, T) if carry else None             # AttentionDecoder.initialize(): zeros
     for k in range(To):
         fin_prev = (k >= (lsl - 1)).to(dtype).unsqueeze(1)               # finished BEFORE this step
         inp_emb = emb[:, k] if k == 0 else emb[:, k] * (1.0 - fin_prev_in)
         inp = torch.cat([inp_emb, ctx], dim=1)
         cn, hn = olstm.lstm_block_cell(inp, c, h, cell['w'], cell['b'], wci, wcf, wco, 1.0, clip_dec, has_peep)
         cell_out = hn if drop_dec is None else hn * torch.as_tensor(drop_dec[k], dtype=dtype)
-        alpha, ctx_k = attention_step(ap, att_type, enc, keys, cell_out, sl, sharpening, sigmoid_smoothing)
+        alpha, ctx_k = attention_step(ap, att_type, enc, keys, cell_out, sl, sharpening, sigmoid_smoothing, a_prev)
+        if carry:
+            a_prev = alpha
         av = torch.tanh(torch.cat([cell_out, ctx_k], dim=1) @ P[D + 'attentional_vector/weights'])
         lg = av @ P[D + 'output_layer/weights'] + P[D + 'output_layer/biases']
         live = 1.0 - fin_prev                                             # impute_finished
@@ -178,7 +205,7 @@ def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_l
 
 def attention_model_infer(sd, inputs_btd, inputs_seq_len, enc_layers, att_type, sos, eos, max_len,
                           clip_enc=0.0, clip_dec=0.0, sharpening=1.0, dtype=torch.float64,
-                          sigmoid_smoothing=False):
+                          sigmoid_smoothing=False, prev_alpha='zeros'):
     """GreedyEmbeddingHelper decode (attention_seq2seq.py:462-509): returns predicted ids [B, <=max_len]."""
     from .model import params_from_state_dict
     with torch.no_grad():
@@ -209,11 +236,15 @@ def attention_model_infer(sd, inputs_btd, inputs_seq_len, enc_layers, att_type, 
         tok = torch.full((B,), sos, dtype=torch.long)
         finished = torch.zeros(B, dtype=torch.bool)
         out = []
+        carry = prev_alpha == 'carry' and att_type in ('location', 'hybrid')
+        a_prev = x.new_zeros(B, enc.shape[1]) if carry else None
         for k in range(max_len):
             inp = torch.cat([emb_w[tok], ctx], 1)
             cn, hn = olstm.lstm_block_cell(inp, c, h, P[D + 'lstm_cell/kernel'], P[D + 'lstm_cell/bias'],
                                            wci, wcf, wco, 1.0, clip_dec, has_peep)
-            alpha, ctx_k = attention_step(ap, att_type, enc, keys, hn, sl, sharpening, sigmoid_smoothing)
+            alpha, ctx_k = attention_step(ap, att_type, enc, keys, hn, sl, sharpening, sigmoid_smoothing, a_prev)
+            if carry:
+                a_prev = alpha
             av = torch.tanh(torch.cat([hn, ctx_k], 1) @ P[D + 'attentional_vector/weights'])
             lg = av @ P[D + 'output_layer/weights'] + P[D + 'output_layer/biases']
             sample = torch.argmax(lg, 1)

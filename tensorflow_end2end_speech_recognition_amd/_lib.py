@@ -20,6 +20,8 @@ _i64, _u64 = C.c_int64, C.c_uint64
 SIGNATURES = {
     'asr_abi_version': (_i, []),
     'asr_create': (_i, [C.POINTER(_vp), _i]),
+    'asr_create_ex': (_i, [C.POINTER(_vp), _i, _sz]),
+    'asr_scratch_bytes': (_sz, [_vp]),
     'asr_destroy': (_i, [_vp]),
     'asr_last_error_string': (C.c_char_p, [_vp]),
     'asr_device_info': (_i, [_vp, C.POINTER(_i), C.c_char_p, _i]),
@@ -63,7 +65,9 @@ SIGNATURES = {
     'asr_att_energy_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'asr_att_energy_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'asr_att_softmax_ctx_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    'asr_att_softmax_ctx_bwd': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'asr_att_softmax_ctx_bwd': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'asr_att_loc_energy_fwd': (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp, _vp]),
+    'asr_att_loc_energy_bwd': (_i, [_vp] * 8 + [_i, _i, _i, _i] + [_vp] * 6 + [_i, _vp]),
     'asr_tanh_fwd': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'asr_tanh_bwd': (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     'asr_embedding_gather': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -315,16 +315,21 @@ __global__ __launch_bounds__(256) void att_dalpha_kernel(const float* __restrict
   }
 }
 // denergy[b,t] = sharp * alpha * (dalpha - sum_t alpha dalpha)   (zero past len)
-__global__ __launch_bounds__(256) void att_softmax_bwd_kernel(const float* __restrict__ da,
+// dalpha_extra (may be NULL): a further gradient w.r.t. alpha -- the location features of the NEXT decoder step
+// (carried-alpha location / hybrid attention)
+__global__ __launch_bounds__(256) void att_softmax_bwd_kernel(float* __restrict__ da,
                                                               const float* __restrict__ alpha,
                                                               const int32_t* __restrict__ seq_len, float sharp,
                                                               int T, float* __restrict__ denergy,
-                                                              const float* __restrict__ norm) {
+                                                              const float* __restrict__ norm,
+                                                              const float* __restrict__ dalpha_extra) {
   __shared__ float red[4];
   __shared__ float s_dot;
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int len = min(max(seq_len[b], 0), T);
   float dot = 0.f;
+  if (dalpha_extra)      // each thread revisits exactly the elements it updates here
+    for (int t = tid; t < len; t += 256) da[(size_t)b * T + t] += dalpha_extra[(size_t)b * T + t];
   for (int t = tid; t < len; t += 256) dot += alpha[(size_t)b * T + t] * da[(size_t)b * T + t];
   dot = wave_reduce_sum(dot);
   if (lane == 0) red[wave] = dot;
@@ -356,6 +361,198 @@ __global__ __launch_bounds__(256) void att_denc_kernel(const float* __restrict__
     float* dr = denc + ((size_t)t * B + b) * E;
     for (int e0 = lane; e0 < E; e0 += 64) dr[e0] += a * dc[e0];
   }
+}
+
+// ---- location / hybrid attention with the CARRIED previous weights (attention_layer.py:191-265) -------------------
+// f[b,t,c] = sum_j alpha_prev[b, t + j - P] F[j,c]   (tf.nn.conv1d(alpha [B,T,1], filter [taps,1,10], 'SAME'):
+//            cross-correlation, P = (taps-1)/2 zero frames before, taps-1-P after; taps = 201 location / 200 hybrid)
+// z[b,t,a] = (keys[t,b,a]) + qz[b,a] + sum_c f[b,t,c] W_filter[c,a]      (qz carries W_query s + b_filter)
+// energy[b,t] = sum_a v_a tanh(z)
+// The [T,B,A] location term is never materialised: a workgroup owns 64 frames of one utterance, stages the
+// alpha window (64 + taps - 1 values), the filter (8 KB) and W_filter (5 KB) in LDS, forms its 64 x 10 features
+// there and folds them into the energy pass that streams the keys once.
+constexpr int LOC_C = 10;                       // feature channels of the reference's filter
+
+__device__ __forceinline__ void loc_stage(const float* __restrict__ alpha_prev_b, const float* __restrict__ filt,
+                                          int T, int taps, int t0, float* aw, float* fl, float* ff) {
+  const int P = (taps - 1) / 2;
+  for (int i = threadIdx.x; i < ATT_CH + taps - 1; i += 256) {
+    const int u = t0 + i - P;
+    aw[i] = (u >= 0 && u < T) ? alpha_prev_b[u] : 0.f;
+  }
+  for (int i = threadIdx.x; i < taps * LOC_C; i += 256) fl[i] = filt[i];
+  __syncthreads();
+  for (int o = threadIdx.x; o < ATT_CH * LOC_C; o += 256) {
+    const int i = o / LOC_C, c = o % LOC_C;
+    float s = 0.f;
+    for (int j = 0; j < taps; ++j) s += aw[i + j] * fl[j * LOC_C + c];
+    ff[o] = s;
+  }
+}
+static inline size_t loc_lds_floats(int taps, int A) {   // aw | filter | features | W_filter
+  return (size_t)(ATT_CH + taps - 1) + (size_t)taps * LOC_C + (size_t)ATT_CH * LOC_C + (size_t)LOC_C * A;
+}
+
+__global__ __launch_bounds__(256) void att_loc_energy_fwd_kernel(
+    const float* __restrict__ alpha_prev, const float* __restrict__ filt, const float* __restrict__ wfil,
+    const float* __restrict__ keys, const float* __restrict__ qz, const float* __restrict__ v, int T, int B, int A,
+    int taps, float* __restrict__ energy) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* aw = reinterpret_cast<float*>(smem);
+  float* fl = aw + (ATT_CH + taps - 1);
+  float* ff = fl + taps * LOC_C;
+  float* ws = ff + ATT_CH * LOC_C;
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(T, t0 + ATT_CH);
+  for (int i = threadIdx.x; i < LOC_C * A; i += 256) ws[i] = wfil[i];
+  loc_stage(alpha_prev + (size_t)b * T, filt, T, taps, t0, aw, fl, ff);
+  __syncthreads();
+  const float* q = qz + (size_t)b * A;
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const float* k = keys ? keys + ((size_t)t * B + b) * A : nullptr;
+    const float* f = ff + (t - t0) * LOC_C;
+    float s = 0.f;
+    for (int a = lane; a < A; a += 64) {
+      float z = (k ? k[a] : 0.f) + q[a];
+#pragma unroll
+      for (int c = 0; c < LOC_C; ++c) z += f[c] * ws[c * A + a];
+      s += v[a] * tanhf(z);
+    }
+    s = wave_reduce_sum(s);
+    if (lane == 0) energy[(size_t)b * T + t] = s;
+  }
+}
+
+// Backward, pass A: dZ -> dkeys (+=), per-chunk partials part[ch][b][(2 + LOC_C) * A] = (sum_t dZ, sum_t de tanh(z),
+// sum_t f[t,c] dZ[t,a]) and the feature gradients dfeat[b,t,c] = sum_a dZ[t,a] W_filter[c,a] for pass B.
+__global__ __launch_bounds__(256) void att_loc_energy_bwd_kernel(
+    const float* __restrict__ denergy, const float* __restrict__ alpha_prev, const float* __restrict__ filt,
+    const float* __restrict__ wfil, const float* __restrict__ keys, const float* __restrict__ qz,
+    const float* __restrict__ v, int T, int B, int A, int taps, float* __restrict__ dkeys, float* __restrict__ part,
+    float* __restrict__ dfeat) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* aw = reinterpret_cast<float*>(smem);
+  float* fl = aw + (ATT_CH + taps - 1);
+  float* ff = fl + taps * LOC_C;
+  float* ws = ff + ATT_CH * LOC_C;
+  float* acc = ws + LOC_C * A;                   // [4 waves][(2 + LOC_C) * A]
+  const int NP = (2 + LOC_C) * A;
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(T, t0 + ATT_CH);
+  for (int i = threadIdx.x; i < LOC_C * A; i += 256) ws[i] = wfil[i];
+  for (int i = threadIdx.x; i < 4 * NP; i += 256) acc[i] = 0.f;
+  loc_stage(alpha_prev + (size_t)b * T, filt, T, taps, t0, aw, fl, ff);
+  __syncthreads();
+  const float* q = qz + (size_t)b * A;
+  float* my = acc + wave * NP;
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const float de = denergy[(size_t)b * T + t];
+    const size_t off = ((size_t)t * B + b) * A;
+    const float* f = ff + (t - t0) * LOC_C;
+    float df[LOC_C];
+#pragma unroll
+    for (int c = 0; c < LOC_C; ++c) df[c] = 0.f;
+    for (int a = lane; a < A; a += 64) {
+      float z = (keys ? keys[off + a] : 0.f) + q[a];
+#pragma unroll
+      for (int c = 0; c < LOC_C; ++c) z += f[c] * ws[c * A + a];
+      const float th = tanhf(z);
+      const float dz = de * v[a] * (1.f - th * th);
+      if (dkeys) dkeys[off + a] += dz;
+      my[a] += dz;
+      my[A + a] += de * th;
+#pragma unroll
+      for (int c = 0; c < LOC_C; ++c) {
+        my[(2 + c) * A + a] += f[c] * dz;
+        df[c] += dz * ws[c * A + a];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < LOC_C; ++c) df[c] = wave_reduce_sum(df[c]);
+    if (lane < LOC_C) {
+      float mine = 0.f;
+#pragma unroll
+      for (int c = 0; c < LOC_C; ++c) mine = (lane == c) ? df[c] : mine;
+      dfeat[((size_t)b * T + t) * LOC_C + lane] = mine;
+    }
+  }
+  __syncthreads();
+  float* o = part + ((size_t)blockIdx.x * B + b) * NP;
+  for (int i = threadIdx.x; i < NP; i += 256) o[i] = (acc[i] + acc[NP + i]) + (acc[2 * NP + i] + acc[3 * NP + i]);
+}
+// dqz, dv_rows [B,A] and dwfil_rows [B,LOC_C,A] (+= when `accumulate`): fixed-order sums of the chunk partials
+__global__ void att_loc_bwd_reduce_kernel(const float* __restrict__ part, int nch, int B, int A,
+                                          float* __restrict__ dqz, float* __restrict__ dv_rows,
+                                          float* __restrict__ dwfil_rows, int accumulate) {
+  const int NP = (2 + LOC_C) * A;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * NP) return;
+  const int b = i / NP, r = i % NP;
+  float s = 0.f;
+  for (int c = 0; c < nch; ++c) s += part[((size_t)c * B + b) * NP + r];
+  if (r < A) dqz[(size_t)b * A + r] = s;
+  else if (r < 2 * A) { if (dv_rows) dv_rows[(size_t)b * A + r - A] = s; }
+  else {
+    float* o = dwfil_rows + (size_t)b * LOC_C * A + (r - 2 * A);
+    *o = accumulate ? *o + s : s;
+  }
+}
+// Backward, pass B: gradients through the convolution.
+//   dalpha_prev[b,u] = sum_j sum_c dfeat[b, u - j + P, c] F[j,c]
+//   dfilt partial of the chunk: sum_{t in chunk} alpha_prev[b, t + j - P] dfeat[b,t,c]  -> fpart[ch][b][taps*LOC_C]
+__global__ __launch_bounds__(256) void att_loc_conv_bwd_kernel(
+    const float* __restrict__ dfeat, const float* __restrict__ alpha_prev, const float* __restrict__ filt, int T,
+    int B, int taps, float* __restrict__ dalpha_prev, float* __restrict__ fpart) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int W = ATT_CH + taps - 1;
+  float* aw = reinterpret_cast<float*>(smem);   // alpha window  [W]
+  float* fl = aw + W;                             // filter        [taps*LOC_C]
+  float* dw = fl + taps * LOC_C;                  // dfeat window  [W*LOC_C]: frames t0 + P - (taps-1) ...
+  const int P = (taps - 1) / 2;
+  const int b = blockIdx.y, t0 = blockIdx.x * ATT_CH, n = min(ATT_CH, T - t0);
+  for (int i = threadIdx.x; i < W; i += 256) {
+    const int u = t0 + i - P;
+    aw[i] = (u >= 0 && u < T) ? alpha_prev[(size_t)b * T + u] : 0.f;
+  }
+  for (int i = threadIdx.x; i < taps * LOC_C; i += 256) fl[i] = filt[i];
+  const int tb = t0 + P - (taps - 1);
+  for (int i = threadIdx.x; i < W * LOC_C; i += 256) {
+    const int t = tb + i / LOC_C;
+    dw[i] = (t >= 0 && t < T) ? dfeat[((size_t)b * T + t) * LOC_C + i % LOC_C] : 0.f;
+  }
+  __syncthreads();
+  // dalpha: 4 lanes per output frame, each a quarter of the taps, combined with two DPP-free shuffles
+  {
+    const int i = threadIdx.x >> 2, r = threadIdx.x & 3;
+    float s = 0.f;
+    for (int j = r; j < taps; j += 4) {
+      const float* d = dw + (i + (taps - 1) - j) * LOC_C;
+      const float* f = fl + j * LOC_C;
+#pragma unroll
+      for (int c = 0; c < LOC_C; ++c) s += d[c] * f[c];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (r == 0 && i < n) dalpha_prev[(size_t)b * T + t0 + i] = s;
+  }
+  // dfilt partial: this chunk's own dfeat rows sit at window rows (taps-1-P) + i
+  float* o = fpart + ((size_t)blockIdx.x * B + b) * taps * LOC_C;
+  const int own = (taps - 1) - P;
+  for (int q = threadIdx.x; q < taps * LOC_C; q += 256) {
+    const int j = q / LOC_C, c = q % LOC_C;
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += aw[i + j] * dw[(own + i) * LOC_C + c];
+    o[q] = s;
+  }
+}
+__global__ void att_loc_filt_reduce_kernel(const float* __restrict__ fpart, int nch, int B, int n,
+                                           float* __restrict__ dfilt_rows, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n) return;
+  const int b = i / n, r = i % n;
+  float s = 0.f;
+  for (int c = 0; c < nch; ++c) s += fpart[((size_t)c * B + b) * n + r];
+  dfilt_rows[i] = accumulate ? dfilt_rows[i] + s : s;
 }
 
 __global__ void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
@@ -510,6 +707,51 @@ extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const flo
   return ASR_OK;
 }
 
+extern "C" int asr_att_loc_energy_fwd(asr_handle* h, const float* alpha_prev, const float* filt, const float* wfil,
+                                      const float* keys, const float* qz, const float* v, int T, int B, int A,
+                                      int taps, float* energy, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(alpha_prev && filt && wfil && qz && v && energy && T > 0 && B > 0 && A > 0 && taps > 0,
+           "asr_att_loc_energy_fwd: bad args");
+  const size_t lds = loc_lds_floats(taps, A) * sizeof(float);
+  if (lds > 64 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_loc_energy_fwd: taps=%d / A=%d need %zu B of LDS", taps, A, lds);
+  hipLaunchKernelGGL(att_loc_energy_fwd_kernel, dim3((T + ATT_CH - 1) / ATT_CH, B), dim3(256), lds, (hipStream_t)s,
+                     alpha_prev, filt, wfil, keys, qz, v, T, B, A, taps, energy);
+  ASR_CHECK_LAUNCH(h, "asr_att_loc_energy_fwd");
+  return ASR_OK;
+}
+
+extern "C" int asr_att_loc_energy_bwd(asr_handle* h, const float* denergy, const float* alpha_prev,
+                                      const float* filt, const float* wfil, const float* keys, const float* qz,
+                                      const float* v, int T, int B, int A, int taps, float* dkeys, float* dqz,
+                                      float* dv_rows, float* dwfil_rows, float* dfilt_rows, float* dalpha_prev,
+                                      int accumulate, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(denergy && alpha_prev && filt && wfil && qz && v && dqz && dwfil_rows && dfilt_rows && dalpha_prev &&
+               T > 0 && B > 0 && A > 0 && taps > 0, "asr_att_loc_energy_bwd: bad args");
+  const int nch = (T + ATT_CH - 1) / ATT_CH;
+  const size_t NP = (size_t)(2 + LOC_C) * A;
+  const size_t n_part = (size_t)nch * B * NP, n_feat = (size_t)B * T * LOC_C, n_fp = (size_t)nch * B * taps * LOC_C;
+  float* part = att_scratch(h, (n_part + n_feat + n_fp) * sizeof(float));
+  if (!part) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_loc_energy_bwd: scratch too small");
+  float* dfeat = part + n_part;
+  float* fpart = dfeat + n_feat;
+  const size_t ldsA = (loc_lds_floats(taps, A) + 4 * NP) * sizeof(float);
+  const size_t ldsB = ((size_t)(ATT_CH + taps - 1) * (1 + LOC_C) + (size_t)taps * LOC_C) * sizeof(float);
+  if (ldsA > 64 * 1024 || ldsB > 64 * 1024)
+    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_loc_energy_bwd: taps=%d / A=%d need %zu / %zu B of LDS", taps, A, ldsA, ldsB);
+  hipLaunchKernelGGL(att_loc_energy_bwd_kernel, dim3(nch, B), dim3(256), ldsA, (hipStream_t)s, denergy, alpha_prev, filt,
+                     wfil, keys, qz, v, T, B, A, taps, dkeys, part, dfeat);
+  hipLaunchKernelGGL(att_loc_bwd_reduce_kernel, dim3((unsigned)((B * NP + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                     part, nch, B, A, dqz, dv_rows, dwfil_rows, accumulate);
+  hipLaunchKernelGGL(att_loc_conv_bwd_kernel, dim3(nch, B), dim3(256), ldsB, (hipStream_t)s, dfeat, alpha_prev, filt, T,
+                     B, taps, dalpha_prev, fpart);
+  hipLaunchKernelGGL(att_loc_filt_reduce_kernel, dim3((B * taps * LOC_C + 255) / 256), dim3(256), 0, (hipStream_t)s,
+                     fpart, nch, B, taps * LOC_C, dfilt_rows, accumulate);
+  ASR_CHECK_LAUNCH(h, "asr_att_loc_energy_bwd");
+  return ASR_OK;
+}
+
 extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* seq_len,
                                        float sharpening, const void* enc, int enc_dtype, int T, int B, int E,
                                        float* alpha, float* ctx, float* sigmoid_norm, asr_stream s) {
@@ -538,7 +780,7 @@ extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const
 extern "C" int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const float* alpha,
                                        const int32_t* seq_len, float sharpening, const void* enc, int enc_dtype,
                                        int T, int B, int E, float* denergy, float* denc,
-                                       const float* sigmoid_norm, asr_stream s) {
+                                       const float* sigmoid_norm, const float* dalpha_extra, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(dctx && alpha && seq_len && enc && denergy && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype),
            "asr_att_softmax_ctx_bwd: bad args");
@@ -552,7 +794,7 @@ extern "C" int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const f
     hipLaunchKernelGGL(att_dalpha_kernel<bf16_t>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, seq_len,
                        (const bf16_t*)enc, T, B, E, da);
   hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, da, alpha, seq_len, sharpening, T,
-                     denergy, sigmoid_norm);
+                     denergy, sigmoid_norm, dalpha_extra);
   if (denc)   // NULL: the caller accumulates d_enc = sum_steps alpha (x) dctx itself (one GEMM per utterance)
     hipLaunchKernelGGL(att_denc_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, alpha, seq_len, T, B, E, denc);
   ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_bwd");

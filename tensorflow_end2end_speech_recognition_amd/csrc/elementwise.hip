@@ -7,8 +7,11 @@
 
 extern "C" int asr_abi_version(void) { return 1; }
 
-extern "C" int asr_create(asr_handle** out, int device) {
-  if (!out) return ASR_ERR_INVALID_ARG;
+extern "C" int asr_create(asr_handle** out, int device) { return asr_create_ex(out, device, (size_t)128 << 20); }
+extern "C" size_t asr_scratch_bytes(asr_handle* h) { return h ? h->scratch_bytes : 0; }
+
+extern "C" int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes) {
+  if (!out || scratch_bytes < ((size_t)32 << 20)) return ASR_ERR_INVALID_ARG;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return ASR_ERR_HIP;
   if (hipSetDevice(device) != hipSuccess) return ASR_ERR_HIP;
@@ -20,7 +23,7 @@ extern "C" int asr_create(asr_handle** out, int device) {
   snprintf(h->name, sizeof(h->name), "%s (%s)", p.name, p.gcnArchName);
   h->err[0] = 0;
   h->scratch = nullptr;
-  h->scratch_bytes = (size_t)128 << 20;
+  h->scratch_bytes = scratch_bytes;
   if (hipMalloc(&h->scratch, h->scratch_bytes) != hipSuccess) {
     delete h;
     return ASR_ERR_HIP;

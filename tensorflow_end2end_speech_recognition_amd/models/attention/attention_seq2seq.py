@@ -12,9 +12,13 @@ sequence loss (:625-637).  The recurrence (cell + attention) runs step by step; 
 does not feed back (attentional vector, output layer, all weight gradients) is batched over the
 decoder steps in single GEMMs.
 
-Reference quirk Q1 is reproduced (it IS the reference graph): location / hybrid attention see a
+Reference quirk Q1 is reproduced by default (it IS the reference graph): location / hybrid attention see a
 zero "previous alpha", so their location features reduce to the W_filter bias; `filter` and
 W_filter/weights therefore receive zero gradient, W_keys of 'location' too (Q6).
+`prev_alpha='carry'` (an extension keyword, default 'zeros') runs the recurrence attention_layer.py:191-265 was
+written to express: the previous step's weights go through conv1d([201|200,1,10], SAME) -> W_filter inside the
+energy kernel (csrc/attention.hip asr_att_loc_energy_*), with gradients into `filter`, W_filter and, through the
+previous step's softmax, everything upstream.
 """
 import numpy as np
 import torch
@@ -58,13 +62,17 @@ class AttentionSeq2Seq(ModelBase):
                  clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50,
                  weight_decay=0.0, time_major=True, sharpening_factor=1.0, logits_temperature=1.0,
                  sigmoid_smoothing=False, name='attention', dtype='f32', device='cuda:0', seed=0,
-                 _extra_vars=None):
+                 _extra_vars=None, prev_alpha='zeros'):
         super(AttentionSeq2Seq, self).__init__()
         assert input_size % 3 == 0, 'input_size must be divisible by 3 (+ delta, double delta features).'
         assert splice % 2 == 1, 'splice must be the odd number'
         assert clip_grad_norm > 0, 'clip_grad_norm must be larger than 0.'
         assert weight_decay >= 0, 'weight_decay must not be a negative value.'
         AL.check_attention_type(attention_type)
+        if prev_alpha not in ('zeros', 'carry'):
+            raise ValueError("prev_alpha is 'zeros' (the reference's effective graph) or 'carry'")
+        # carried weights only exist for the two types that have location features
+        self.carry_alpha = prev_alpha == 'carry' and attention_type in AL.HAS_FILTER
         if decoder_type != 'lstm':
             raise TypeError('decoder_type is "lstm" or "gru".') if decoder_type != 'gru' else \
                 NotImplementedError('GRU decoder (crashes in the reference too, attention_seq2seq.py:364-365)')
@@ -272,6 +280,7 @@ class AttentionSeq2Seq(ModelBase):
             dmask_all = ops.dropout_mask((To, Bp, U), keep_prob_decoder, self.seed + 2, self._calls << 40, dev)
         # sigmoid smoothing (attention_layer.py:92-96): the per-step normaliser is kept for the backward
         snorm_all = torch.empty((To, Bp), dtype=torch.float32, device=dev) if self.sigmoid_smoothing else None
+        alpha_zero = torch.zeros((Bp, T), dtype=torch.float32, device=dev) if self.carry_alpha else None
         for k in range(To):
             dec_in[k, :, Em:Em + E2].copy_(ctx)
             dec_in[k, :, Em + E2:].copy_(h)
@@ -283,7 +292,11 @@ class AttentionSeq2Seq(ModelBase):
                 dmask = dmask_all[k]
                 cell_out = ops.apply_mask(h_raw, dmask)
             qz = self._query(cell_out)
-            energy = ops.att_energy_fwd(keys, qz, v, T, self.att_mode)
+            if self.carry_alpha:     # previous weights (zeros at step 0, attention_decoder.py:163-164) -> conv -> W_filter
+                energy = ops.att_loc_energy_fwd(alpha_all[k - 1] if k > 0 else alpha_zero, st[AT + 'filter'],
+                                                st[AT + 'W_filter/weights'], keys, qz, v, T)
+            else:
+                energy = ops.att_energy_fwd(keys, qz, v, T, self.att_mode)
             alpha, ctx_k = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc_att,
                                                    alpha_out=alpha_all[k],
                                                    sigmoid_norm=snorm_all[k] if snorm_all is not None else None)
@@ -376,6 +389,12 @@ class AttentionSeq2Seq(ModelBase):
         dctx_in = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
         v = st[AT + 'v_a'] if self.att_mode == 0 else None
         dctx_all = torch.empty((To, Bp, E2), dtype=torch.float32, device=dev)
+        dalpha_next = None                     # carried location features: d loss / d alpha_k from step k+1's conv
+        if self.carry_alpha:
+            filt, wfil = st[AT + 'filter'], st[AT + 'W_filter/weights']
+            dwfil_rows = torch.empty((Bp,) + tuple(wfil.shape), dtype=torch.float32, device=dev)
+            dfilt_rows = torch.empty((Bp, filt.shape[0], filt.shape[2]), dtype=torch.float32, device=dev)
+            alpha_zero = torch.zeros((Bp, T), dtype=torch.float32, device=dev)
         for k in range(To - 1, -1, -1):
             s = saved[k]
             dctx = dctx_all[k]
@@ -383,9 +402,14 @@ class AttentionSeq2Seq(ModelBase):
             # d_enc += alpha (x) dctx is NOT done per step (a read-modify-write of [T,B,2H] each time):
             # alpha and dctx of all steps are kept and contracted once per utterance below
             denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, tp['enc_att'], None,
-                                              sigmoid_norm=s['snorm'])
-            dqz, dv_rows = ops.att_energy_bwd(denergy, keys, s['qz'], v, self.att_mode, dkeys=dkeys,
-                                              want_dv=self.att_mode == 0)
+                                              sigmoid_norm=s['snorm'], dalpha_extra=dalpha_next)
+            if self.carry_alpha:
+                dqz, dv_rows, dalpha_next = ops.att_loc_energy_bwd(
+                    denergy, tp['alpha_all'][k - 1] if k > 0 else alpha_zero, filt, wfil, keys, s['qz'], v,
+                    dwfil_rows, dfilt_rows, accumulate=(k != To - 1), dkeys=dkeys)
+            else:
+                dqz, dv_rows = ops.att_energy_bwd(denergy, keys, s['qz'], v, self.att_mode, dkeys=dkeys,
+                                                  want_dv=self.att_mode == 0)
             dqz_all[k].copy_(dqz)
             if dv_rows is not None:
                 dv_all[k].copy_(dv_rows)
@@ -427,6 +451,9 @@ class AttentionSeq2Seq(ModelBase):
             ops.gemm(cell_out_all.reshape(To * Bp, U), dq2d, transA=True, out=self._wq(grad=True))
         if at in AL.HAS_FILTER:
             ops.colsum(dq2d, out=st.g(AT + 'W_filter/biases'))
+            if self.carry_alpha:       # per-utterance sums over the steps -> sum over the batch
+                ops.colsum(dwfil_rows.view(Bp, -1), out=st.g(AT + 'W_filter/weights').view(-1))
+                ops.colsum(dfilt_rows.view(Bp, -1), out=st.g(AT + 'filter').view(-1))
         if self.att_mode == 0:
             ops.colsum(dv_all.view(To * Bp, -1), out=st.g(AT + 'v_a'))
         if at in AL.USES_KEYS:
@@ -477,14 +504,19 @@ class AttentionSeq2Seq(ModelBase):
         av_in = torch.empty((Bp, U + E2), dtype=torch.float32, device=dev)
         out = []
         snorm = torch.empty((Bp,), dtype=torch.float32, device=dev) if self.sigmoid_smoothing else None
+        a_prev = torch.zeros((Bp, T), dtype=torch.float32, device=dev) if self.carry_alpha else None
         for k in range(self.max_decode_length):
             dec_in[:, :Em].copy_(ops.embedding_gather(st['output_embedding/W_embedding'], tok))
             dec_in[:, Em:Em + E2].copy_(ctx)
             dec_in[:, Em + E2:].copy_(h)
             pre = ops.gemm(dec_in, st[D + 'lstm_cell/kernel'], bias=st[D + 'lstm_cell/bias'])
             _, _, c, h, h_raw = ops.lstm_cell_fwd(pre, c, h, peep, live, 1.0, self.clip_activation_decoder or 0.0)
-            energy = ops.att_energy_fwd(keys, self._query(h_raw), v, T, self.att_mode)
-            _, ctx = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc, sigmoid_norm=snorm)
+            if self.carry_alpha:
+                energy = ops.att_loc_energy_fwd(a_prev, st[AT + 'filter'], st[AT + 'W_filter/weights'], keys,
+                                                self._query(h_raw), v, T)
+            else:
+                energy = ops.att_energy_fwd(keys, self._query(h_raw), v, T, self.att_mode)
+            a_prev, ctx = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc, sigmoid_norm=snorm)
             av_in[:, :U].copy_(h_raw)
             av_in[:, U:].copy_(ctx)
             av = ops.tanh_fwd(ops.gemm(av_in, st[D + 'attentional_vector/weights']))

@@ -581,9 +581,36 @@ def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmoi
     return alpha, ctx
 
 
-def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmoid_norm=None):
+def att_loc_energy_fwd(alpha_prev, filt, wfil, keys, qz, v, T):
+    """Location / hybrid energies with the previous step's weights carried through conv1d -> W_filter
+    (attention_layer.py:191-265).  alpha_prev [B,T]; filt [taps,1,10]; wfil [10,A]; keys [T,B,A] or None."""
+    h = _h(qz)
+    B, A = qz.shape
+    taps = filt.shape[0]
+    energy = _f32((B, T), qz.device)
+    h.check(h.lib.asr_att_loc_energy_fwd(h.h, _p(alpha_prev), _p(filt), _p(wfil), _p(keys), _p(qz), _p(v), T, B, A,
+                                         taps, _p(energy), _s()), 'asr_att_loc_energy_fwd')
+    return energy
+
+
+def att_loc_energy_bwd(denergy, alpha_prev, filt, wfil, keys, qz, v, dwfil_rows, dfilt_rows, accumulate, dkeys=None):
+    """-> (dqz [B,A], dv_rows [B,A], dalpha_prev [B,T]); dwfil_rows [B,10,A] / dfilt_rows [B,taps,10] are
+    overwritten (accumulate False) or added to (True); dkeys += in place when given."""
+    h = _h(qz)
+    B, A = qz.shape
+    T = denergy.shape[1]
+    taps = filt.shape[0]
+    dqz, dv, dap = _f32((B, A), qz.device), _f32((B, A), qz.device), _f32((B, T), qz.device)
+    h.check(h.lib.asr_att_loc_energy_bwd(h.h, _p(denergy), _p(alpha_prev), _p(filt), _p(wfil), _p(keys), _p(qz), _p(v),
+                                         T, B, A, taps, _p(dkeys), _p(dqz), _p(dv), _p(dwfil_rows), _p(dfilt_rows),
+                                         _p(dap), 1 if accumulate else 0, _s()), 'asr_att_loc_energy_bwd')
+    return dqz, dv, dap
+
+
+def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmoid_norm=None, dalpha_extra=None):
     """denc None: only denergy is produced; the caller accumulates d_enc = sum_steps alpha (x) dctx itself.
-    sigmoid_norm: the tensor the forward filled (sigmoid smoothing), or None (softmax)."""
+    sigmoid_norm: the tensor the forward filled (sigmoid smoothing), or None (softmax).
+    dalpha_extra [B,T]: gradient w.r.t. alpha from the next step's carried location features, or None."""
     h = _h(dctx)
     B, T = alpha.shape
     E = enc.shape[2]
@@ -592,7 +619,7 @@ def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmoi
         raise ValueError('sigmoid_norm must be fp32 [B]')
     h.check(h.lib.asr_att_softmax_ctx_bwd(h.h, _p(dctx), _p(alpha), _p(seq_len), float(sharpening), _p(enc),
                                           dtype_id(enc.dtype), T, B, E, _p(denergy), _p(denc), _p(sigmoid_norm),
-                                          _s()),
+                                          _p(dalpha_extra), _s()),
             'asr_att_softmax_ctx_bwd')
     return denergy
 

@@ -375,11 +375,51 @@ def _att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmo
     return alpha, ctx.float()
 
 
-def _att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmoid_norm=None):
+def _loc_energy(alpha_prev, filt, wfil, keys, qz, v, T):
+    """torch statement of asr_att_loc_energy_fwd (all float64, differentiable)."""
+    taps = filt.shape[0]
+    before = (taps - 1) // 2
+    a = torch.nn.functional.pad(alpha_prev.unsqueeze(1), (before, taps - 1 - before))
+    f = torch.nn.functional.conv1d(a, filt.reshape(taps, 1, -1).permute(2, 1, 0)).transpose(1, 2)    # [B,T,10]
+    z = qz.unsqueeze(1) + f @ wfil
+    if keys is not None:
+        z = z + keys.transpose(0, 1)
+    return (v * torch.tanh(z)).sum(2)
+
+
+def _att_loc_energy_fwd(alpha_prev, filt, wfil, keys, qz, v, T):
+    return _loc_energy(alpha_prev.double(), filt.double(), wfil.double(), None if keys is None else keys.double(),
+                       qz.double(), v.double(), T).float()
+
+
+def _att_loc_energy_bwd(denergy, alpha_prev, filt, wfil, keys, qz, v, dwfil_rows, dfilt_rows, accumulate, dkeys=None):
+    B, A = qz.shape
+    T = denergy.shape[1]
+    dqz, dv, dap = torch.zeros(B, A), torch.zeros(B, A), torch.zeros(B, T)
+    for b in range(B):     # per utterance, as the device op reports its row gradients
+        leaves = [t.double().clone().requires_grad_(True) for t in
+                  (alpha_prev[b:b + 1], filt, wfil, qz[b:b + 1], v)]
+        k = None if keys is None else keys[:, b:b + 1].double().clone().requires_grad_(True)
+        e = _loc_energy(leaves[0], leaves[1], leaves[2], k, leaves[3], leaves[4], T)
+        (e * denergy[b:b + 1].double()).sum().backward()
+        dap[b] = leaves[0].grad[0].float()
+        dfr, dwr = leaves[1].grad.reshape(dfilt_rows[b].shape).float(), leaves[2].grad.float()
+        dfilt_rows[b] = dfilt_rows[b] + dfr if accumulate else dfr
+        dwfil_rows[b] = dwfil_rows[b] + dwr if accumulate else dwr
+        dqz[b] = leaves[3].grad[0].float()
+        dv[b] = leaves[4].grad.float()
+        if dkeys is not None and k is not None:
+            dkeys[:, b:b + 1] += k.grad.float()
+    return dqz, dv, dap
+
+
+def _att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmoid_norm=None, dalpha_extra=None):
     B, T = alpha.shape
     mask = (torch.arange(T).unsqueeze(0) < seq_len.long().clamp(0, T).unsqueeze(1)).double()
     a = alpha.double()
     da = torch.einsum('be,tbe->bt', dctx.double(), enc.double()) * mask
+    if dalpha_extra is not None:
+        da = da + dalpha_extra.double() * mask
     dot = (a * da * mask).sum(1, keepdim=True)
     de = sharpening * a * (da - dot) * mask
     if sigmoid_norm is not None:
@@ -476,6 +516,7 @@ STAND_INS = dict(
     lstm_cell_fwd=_lstm_cell_fwd, lstm_cell_bwd=_lstm_cell_bwd, att_energy_fwd=_att_energy_fwd,
     att_energy_bwd=_att_energy_bwd, att_softmax_ctx_fwd=_att_softmax_ctx_fwd,
     att_softmax_ctx_bwd=_att_softmax_ctx_bwd, tanh_fwd=_tanh_fwd, tanh_bwd=_tanh_bwd,
+    att_loc_energy_fwd=_att_loc_energy_fwd, att_loc_energy_bwd=_att_loc_energy_bwd,
     embedding_gather=_embedding_gather, embedding_scatter=_embedding_scatter, seq_xent=_seq_xent,
     argmax_rows=_argmax_rows, im2col3x3=_im2col3x3, col2im3x3=_col2im3x3, maxpool2x2_fwd=_maxpool2x2_fwd,
     maxpool2x2_bwd=_maxpool2x2_bwd,

@@ -148,12 +148,17 @@ def _mk_att(cls, att, D, H, L, U, A, Em, C, **kw):
                clip_activation_encoder=50, clip_activation_decoder=50, dtype='f32', seed=5, device='cpu', **kw)
 
 
-@pytest.mark.parametrize('att,sig', [('bahdanau_content', False), ('location', False), ('hybrid', False),
-                                     ('dot_product', False), ('luong_dot', False), ('luong_general', False),
-                                     ('luong_concat', False), ('bahdanau_content', True), ('luong_dot', True)])
-def test_attention_model_host_logic(monkeypatch, att, sig):
+@pytest.mark.parametrize('att,sig,prev', [
+    ('bahdanau_content', False, 'zeros'), ('location', False, 'zeros'), ('hybrid', False, 'zeros'),
+    ('dot_product', False, 'zeros'), ('luong_dot', False, 'zeros'), ('luong_general', False, 'zeros'),
+    ('luong_concat', False, 'zeros'), ('bahdanau_content', True, 'zeros'), ('luong_dot', True, 'zeros'),
+    ('location', False, 'carry'), ('hybrid', False, 'carry'), ('hybrid', True, 'carry'),
+    ('bahdanau_content', False, 'carry')])
+def test_attention_model_host_logic(monkeypatch, att, sig, prev):
     """Decoder loop, bridge, per-type query / key wiring, deferred d_enc, sigmoid-smoothing plumbing
-    (models/attention/attention_seq2seq.py) against the oracle's attention model."""
+    (models/attention/attention_seq2seq.py) against the oracle's attention model.  prev='carry': the previous
+    step's weights feed the location features (conv1d -> W_filter) and gradients flow back through them into
+    `filter`, W_filter/weights and the earlier steps (a no-op for types without location features)."""
     _cpu_ops.install(monkeypatch)
     from oracle import attention as oatt
     from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
@@ -162,10 +167,13 @@ def test_attention_model_host_logic(monkeypatch, att, sig):
     U = 2 * H if att == 'luong_dot' else 12
     x, sl, labels, lsl, _ = _att_batch(rng, B, T, D, C)
     model = _mk_att(AttentionSeq2Seq, att, D, H, L, U, A, Em, C, sharpening_factor=1.5, logits_temperature=2.0,
-                    sigmoid_smoothing=sig)
+                    sigmoid_smoothing=sig, prev_alpha=prev)
     sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
     ref = oatt.attention_model_forward(sd, x, labels, sl, lsl, L, att, clip_enc=50.0, clip_dec=50.0, sharpening=1.5,
-                                       temperature=2.0, sigmoid_smoothing=sig)
+                                       temperature=2.0, sigmoid_smoothing=sig, prev_alpha=prev)
+    if prev == 'carry' and att in ('location', 'hybrid'):   # the location path is live: its variables get gradient
+        A_ = 'attention_decoder/decoder/attention_layer/'
+        assert np.abs(ref['grads'][A_ + 'filter']).max() > 0 and np.abs(ref['grads'][A_ + 'W_filter/weights']).max() > 0
     loss, logits, out_train, out_infer = model.compute_loss(x, labels, sl, lsl, 1.0, 1.0, 1.0)
     assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-5
     assert np.abs(out_train.attention_weights.numpy() - ref['alphas']).max() < 1e-5
@@ -176,7 +184,7 @@ def test_attention_model_host_logic(monkeypatch, att, sig):
         err = np.abs(g.numpy() - r).max()
         assert err < 1e-4 * max(np.abs(r).max(), 1e-3) + 1e-7, (name, err, np.abs(r).max())
     ref_ids = oatt.attention_model_infer(sd, x, sl, L, att, C, C + 1, 8, clip_enc=50.0, clip_dec=50.0, sharpening=1.5,
-                                         sigmoid_smoothing=sig)
+                                         sigmoid_smoothing=sig, prev_alpha=prev)
     assert np.array_equal(out_infer.predicted_ids.numpy(), ref_ids)
 
 
