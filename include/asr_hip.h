@@ -368,6 +368,22 @@ int asr_optimizer_step(asr_handle* h, int optimizer, float* params, const float*
 /* p[i] = (a[i] + b[i]) * scale helpers for the tower mean of utils/training/multi_gpu.py:39-40 */
 int asr_scale(asr_handle* h, float* x, size_t n, float scale, asr_stream s);
 
+/* ---- data-parallel collective (RCCL over xGMI) ------------------------------------------------ *
+ * The tower mean of utils/training/multi_gpu.py:13-48 (average_gradients: per variable, stack the N towers'
+ * already-clipped gradients and reduce_mean) and its caller examples/librispeech/training/train_ctc.py:112-147, as
+ * ONE all-reduce(sum) over the flat fp32 gradient buffer + x 1/world -- one process per GPU.  librccl.so is opened
+ * with dlopen (asr_comm_set_library names it; default: the loader's librccl.so.1) so that a host that already has
+ * one loaded (PyTorch) shares the instance.  Bootstrap as for NCCL: rank 0 calls asr_comm_unique_id (128 bytes,
+ * host memory), the host program hands the bytes to every rank, every rank calls asr_comm_init. */
+typedef struct asr_comm asr_comm;
+int asr_comm_set_library(const char* path);
+int asr_comm_unique_id(void* id128_host);
+int asr_comm_init(asr_comm** out, asr_handle* h, int rank, int world, const void* id128_host);
+int asr_comm_destroy(asr_comm* c);
+int asr_comm_info(asr_comm* c, int* rank, int* world);
+/* buf[0..n) <- mean over ranks, in place, asynchronous on `s`; every rank calls it with the same n. */
+int asr_allreduce_mean(asr_comm* c, float* buf, size_t n, asr_stream s);
+
 #ifdef __cplusplus
 }
 #endif

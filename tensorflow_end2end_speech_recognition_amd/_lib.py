@@ -79,6 +79,12 @@ SIGNATURES = {
     'asr_weight_decay': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     'asr_optimizer_step': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _f, _i64, _vp]),
     'asr_scale': (_i, [_vp, _vp, _sz, _f, _vp]),
+    'asr_comm_set_library': (_i, [C.c_char_p]),
+    'asr_comm_unique_id': (_i, [_vp]),
+    'asr_comm_init': (_i, [C.POINTER(_vp), _vp, _i, _i, _vp]),
+    'asr_comm_destroy': (_i, [_vp]),
+    'asr_comm_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    'asr_allreduce_mean': (_i, [_vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -52,7 +52,7 @@ def build(force=False, verbose=True):
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, headers, force), srcs))
     if force or _stale(LIB, objs):
-        cmd = [_hipcc(), '--offload-arch=%s' % ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [_hipcc(), '--offload-arch=%s' % ARCH, '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s' % r.stderr[-4000:])

@@ -722,3 +722,55 @@ def scale_(x, s):
     _chk(x, torch.float32, 'x')
     h.check(h.lib.asr_scale(h.h, _p(x), x.numel(), float(s), _s()), 'asr_scale')
     return x
+
+
+# ---------------------------------------------------------------- data-parallel collective (RCCL through the C ABI)
+class NativeComm(object):
+    """asr_comm_* : one RCCL communicator per process / GPU, created from a 128-byte unique id that rank 0 generates
+    (NativeComm.unique_id()) and the host program distributes.  allreduce_mean works in place on a flat fp32 cuda
+    tensor, asynchronously on the current stream."""
+
+    @staticmethod
+    def _bind_library():
+        import os
+        lib = _lib.load()
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        if os.path.exists(path):        # share the instance PyTorch has loaded
+            lib.asr_comm_set_library(path.encode())
+        return lib
+
+    @staticmethod
+    def unique_id():
+        lib = NativeComm._bind_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.asr_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.AsrError('asr_comm_unique_id failed (%d)' % rc)
+        return bytes(buf.raw)
+
+    def __init__(self, device, rank, world, unique_id):
+        self._bind_library()
+        self.h = _lib.handle(device)
+        self.rank, self.world = int(rank), int(world)
+        c = C.c_void_p()
+        idbuf = C.create_string_buffer(bytes(unique_id), 128)
+        self.h.check(self.h.lib.asr_comm_init(C.byref(c), self.h.h, self.rank, self.world, idbuf), 'asr_comm_init')
+        self.c = c
+
+    def allreduce_mean(self, flat):
+        _chk(flat, torch.float32, 'buffer')
+        if not flat.is_cuda or not flat.is_contiguous():
+            raise ValueError('allreduce_mean: contiguous cuda tensor expected')
+        self.h.check(self.h.lib.asr_allreduce_mean(self.c, _p(flat), flat.numel(), _s()), 'asr_allreduce_mean')
+        return flat
+
+    def close(self):
+        if getattr(self, 'c', None):
+            self.h.lib.asr_comm_destroy(self.c)
+            self.c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -28,6 +28,45 @@ def broadcast_parameters(store, src=0):
         store.mark_dirty()
 
 
+_native_comm = {}      # device index -> ops.NativeComm, or False after a failed bootstrap
+
+
+def native_comm(device):
+    """The RCCL communicator of the C ABI (asr_comm_init / asr_allreduce_mean) for this rank's GPU, created on first
+    use: rank 0 draws the unique id, torch.distributed (already up for the launcher's rendezvous) carries the 128
+    bytes to the other ranks.  Returns None when not distributed, on a CPU device, when ASR_DP_COLLECTIVE=torch, or
+    when the bootstrap failed (warned once; the torch.distributed all-reduce -- the same RCCL -- is used instead)."""
+    import os
+    import warnings
+    device = torch.device(device)
+    if device.type != 'cuda' or not is_distributed() or os.environ.get('ASR_DP_COLLECTIVE', '') == 'torch':
+        return None
+    key = device.index or 0
+    if key not in _native_comm:
+        rank, world = dist.get_rank(), dist.get_world_size()
+        comm, err = None, None
+        try:
+            box = [ops.NativeComm.unique_id() if rank == 0 else None]
+        except Exception as e:      # keep the collective below matched on every rank
+            box, err = [None], e
+        dist.broadcast_object_list(box, src=0)
+        ok = torch.zeros(1, dtype=torch.int32, device=device)
+        if box[0] is not None:
+            try:
+                comm = ops.NativeComm(key, rank, world, box[0])
+                ok += 1
+            except Exception as e:
+                err = e
+        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+        if int(ok.item()) != world:      # all or nothing: a partial communicator would deadlock the first all-reduce
+            if comm is not None:
+                comm.close()
+            comm = False
+            warnings.warn('native RCCL communicator not available (%s); using torch.distributed all_reduce' % (err,))
+        _native_comm[key] = comm
+    return _native_comm[key] or None
+
+
 def average_gradients(store_or_tower_grads):
     """ParamStore -> in-place mean of store.grad over all ranks.
     (A list of per-tower gradient lists, the reference's calling convention, is averaged
@@ -39,7 +78,10 @@ def average_gradients(store_or_tower_grads):
             out.append(torch.stack(gs, 0).mean(0) if gs else None)
         return out
     store = store_or_tower_grads
-    if is_distributed():
+    comm = native_comm(store.grad.device) if store.grad.is_cuda else None
+    if comm is not None:
+        comm.allreduce_mean(store.grad)         # RCCL through the C ABI: all-reduce(sum) + x 1/N on this stream
+    elif is_distributed():
         dist.all_reduce(store.grad, op=dist.ReduceOp.SUM)
         n = dist.get_world_size()
         if store.grad.is_cuda:
@@ -74,10 +116,14 @@ def init_process_group(device):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         device = torch.device(device)
+        # rank 0 alone evaluates dev / test sets at epoch ends while the others wait in a collective
+        # (examples/librispeech/training/train_ctc.py): far longer than the default 10-minute watchdog
+        import datetime
+        timeout = datetime.timedelta(hours=float(os.environ.get('ASR_DIST_TIMEOUT_HOURS', '6')))
         if device.type == 'cuda':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device, timeout=timeout)
         else:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+            dist.init_process_group('gloo', rank=rank, world_size=world, timeout=timeout)
     return rank, world
 
 

@@ -391,6 +391,64 @@ def test_rccl_collectives_on_the_parameter_store(cuda):
         dist.destroy_process_group()
 
 
+def test_native_rccl_allreduce_mean_one_rank(cuda):
+    """asr_comm_unique_id / asr_comm_init / asr_allreduce_mean (the collective of the C ABI, RCCL opened with dlopen)
+    with a one-rank communicator on the box's single GPU: library binding, id bootstrap, in-place all-reduce on the
+    launch stream ordered against HIP kernels before and after it; value unchanged for world = 1."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    comm = ops.NativeComm(0, 0, 1, ops.NativeComm.unique_id())
+    x = torch.arange(1, 100004, dtype=torch.float32, device=cuda)        # odd length: scalar tail of the scale kernel
+    y = ops.scale_(x.clone(), 3.0)
+    comm.allreduce_mean(y)
+    y = ops.scale_(y, 0.5)
+    assert torch.equal(y.cpu(), (x * 3.0 * 0.5).cpu())
+    comm.close()
+
+
+def _rccl_world2_worker(rank, port, out):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
+                      LOCAL_RANK=str(rank))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    from tensorflow_end2end_speech_recognition_amd.utils.parameter import ParamStore
+    from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    multi_gpu.init_process_group(dev)
+    st = ParamStore(dev)
+    st.declare('w', (1000, 37), np.zeros((1000, 37)))
+    st.finalize()
+    st.grad.copy_(torch.arange(st.grad.numel(), dtype=torch.float32, device=dev) * (rank + 1))
+    assert multi_gpu.native_comm(dev) is not None
+    multi_gpu.average_gradients(st)
+    want = torch.arange(st.grad.numel(), dtype=torch.float32) * 1.5
+    out.put((rank, bool(torch.equal(st.grad.cpu(), want))))
+    dist.destroy_process_group()
+
+
+def test_native_rccl_allreduce_mean_world2(cuda):
+    """Two ranks on two GPUs over xGMI through the C ABI communicator (skipped on a 1-GPU box: the driver's
+    multi-GPU node is where this runs)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_world2_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_overfit_one_utterance_to_low_ler(cuda, dtype):
     """The reference's own model test (models/test/test_ctc.py:170-233): one utterance repeated B = 4 times, adam,
