@@ -116,12 +116,14 @@ __global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
   double* ws = (half == 0 ? alpha_ws : beta_ws) + (size_t)b * T * SW;
   double* buf = rowbuf + half * 2 * SW;
 
-  // rank of each label among equal earlier labels (fixed summation order in the grad kernel)
+  // rank of each label among equal earlier labels (fixed summation order in the grad kernel) and the position of
+  // the first label of its class (where the grad kernel accumulates that class), packed rank | first << 16
   for (int i = threadIdx.x; i < L; i += AB_THREADS) {
     const int li = lab[i];
-    int r = 0;
-    for (int k = 0; k < i; ++k) r += (lab[k] == li);
-    rank_ws[(size_t)b * ((SW - 1) / 2) + i] = r;
+    int r = 0, first = i;
+    for (int k = i - 1; k >= 0; --k)
+      if (lab[k] == li) { ++r; first = k; }
+    rank_ws[(size_t)b * ((SW - 1) / 2) + i] = r | (first << 16);
   }
   if (Tb <= 0 || L > (SW - 1) / 2) {
     if (threadIdx.x == 0) {
@@ -243,8 +245,13 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const double* __restrict__ ll_ws, float grad_scale, float* __restrict__ grad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* acc = reinterpret_cast<float*>(smem) + (size_t)wave * (C + SW);  // [C] occupation per class
-  float* gam = acc + C;                                                    // [SW]
+  // Per wave: gam[SW] (state occupations), acc[(SW-1)/2] (occupation of a class, kept at the position of its FIRST
+  // label) and a C-bit membership map of the label classes.  Nothing is sized by C x 4 bytes, so word-level
+  // vocabularies (C = 18-27 k classes, examples/librispeech) fit: 4 x (SW + Lmax + C/32) words of LDS.
+  const int LW = (SW - 1) / 2, BW = (C + 31) / 32;
+  float* gam = reinterpret_cast<float*>(smem) + (size_t)wave * (SW + LW + BW);
+  float* acc = gam + SW;
+  unsigned* bits = reinterpret_cast<unsigned*>(acc + LW);
   const int b = blockIdx.y;
   const int t = blockIdx.x * 4 + wave;
   if (t >= T) return;
@@ -260,12 +267,14 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
   const int S = 2 * L + 1;
   const int blank = C - 1;
   const int32_t* lab = labels_flat + lo;
+  const int32_t* rk = rank_ws + (size_t)b * LW;
   const float* row = logits + ((size_t)t * B + b) * C;
   const double z = lse[(size_t)t * B + b];
   const double* al = alpha_ws + ((size_t)b * T + t) * SW;
   const double* be = beta_ws + ((size_t)b * T + t) * SW;
 
-  for (int k = lane; k < C; k += 64) acc[k] = 0.f;
+  for (int k = lane; k < BW; k += 64) bits[k] = 0u;
+  for (int i = lane; i < L; i += 64) acc[i] = 0.f;
   float blank_sum = 0.f;
   int maxrank = 0;
   for (int s = lane; s < S; s += 64) {
@@ -275,21 +284,34 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float gm = (al[s] > DNEG_INF && be[s] > DNEG_INF) ? (float)exp(v) : 0.f;
     gam[s] = gm;
     if (!(s & 1)) blank_sum += gm;
-    else maxrank = max(maxrank, rank_ws[(size_t)b * ((SW - 1) / 2) + (s >> 1)]);
+    else maxrank = max(maxrank, rk[s >> 1] & 0xffff);
   }
   blank_sum = wave_reduce_sum(blank_sum);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) maxrank = max(maxrank, __shfl_xor(maxrank, o, 64));
-  // labels: round r adds the r-th occurrence of every class -> no two lanes touch one class
+  __builtin_amdgcn_wave_barrier();
+  // labels: round r adds the r-th occurrence of every class to the slot of its first occurrence -> no two lanes
+  // touch one slot in a round, and the summation order is fixed (deterministic)
   for (int r = 0; r <= maxrank; ++r) {
     for (int i = lane; i < L; i += 64) {
-      if (rank_ws[(size_t)b * ((SW - 1) / 2) + i] == r) acc[lab[i]] += gam[2 * i + 1];
+      const int pk = rk[i];
+      if ((pk & 0xffff) == r) {
+        acc[pk >> 16] += gam[2 * i + 1];
+        if (r == 0) atomicOr(&bits[lab[i] >> 5], 1u << (lab[i] & 31));
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
+  // classes that are not labels (and not blank): softmax only; every address below is written exactly once
   for (int k = lane; k < C; k += 64) {
-    const float occ = (k == blank) ? (acc[k] + blank_sum) : acc[k];
-    g[k] = ((float)exp((double)row[k] - z) - occ) * grad_scale;
+    if (k == blank) g[k] = ((float)exp((double)row[k] - z) - blank_sum) * grad_scale;
+    else if (!((bits[k >> 5] >> (k & 31)) & 1u)) g[k] = (float)exp((double)row[k] - z) * grad_scale;
+  }
+  for (int i = lane; i < L; i += 64) {
+    if ((rk[i] & 0xffff) == 0) {
+      const int k = lab[i];
+      g[k] = ((float)exp((double)row[k] - z) - acc[i]) * grad_scale;
+    }
   }
 }
 
@@ -412,7 +434,7 @@ extern "C" int asr_ctc_loss(asr_handle* h, const float* logits, int T, int B, in
   }
   ASR_CHECK_LAUNCH(h, "asr_ctc_loss(alpha_beta)");
   if (grad) {
-    const size_t lds_g = (size_t)4 * (C + SW) * sizeof(float);
+    const size_t lds_g = (size_t)4 * (SW + (SW - 1) / 2 + (C + 31) / 32) * sizeof(float);
     if (lds_g > 160 * 1024)
       ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_loss: C=%d, Lmax=%d need %zu B of LDS", C, max_label_len, lds_g);
     (void)hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g);

@@ -259,10 +259,16 @@ class CTC(ModelBase):
         return {}
 
     # ------------------------------------------------------------------ decode / eval
-    def decoder(self, logits, inputs_seq_len, beam_width=1):
+    def decoder(self, logits, inputs_seq_len, beam_width=1, merge_repeated=True):
         """ctc.py:325-352.  Returns the decoded labels as the SparseTensor triple
         [indices int64 [n,2], values int32 [n], dense_shape int64 [2]] (host numpy), i.e. what
-        sess.run(decode_op) hands to sparsetensor2list in the reference."""
+        sess.run(decode_op) hands to sparsetensor2list in the reference.
+        merge_repeated (beam_width > 1 only; extension keyword): the reference calls
+        tf.nn.ctc_beam_search_decoder(logits, seq_len, beam_width=...) with TensorFlow's default
+        merge_repeated=True (ctc.py:344-346), under which consecutive equal labels of the OUTPUT beam are collapsed to
+        their first occurrence -- 'a a' can never be emitted.  True (default) reproduces that
+        call; False returns the prefix beam search result as it is, the semantics of the reference's numpy
+        BeamSearchDecoder (models/ctc/decoders/beam_search_decoder.py) the device search is pinned to."""
         assert isinstance(beam_width, int), "beam_width must be integer."
         assert beam_width >= 1, "beam_width must be >= 1"
         logits = logits.contiguous()
@@ -272,6 +278,15 @@ class CTC(ModelBase):
         else:
             lab, n, _ = ops.ctc_beam_decode(logits, seq, beam_width=beam_width)
         lab, n = lab.cpu().numpy(), n.cpu().numpy()
+        if beam_width > 1 and merge_repeated:
+            lab, n = lab.copy(), n.copy()
+            for b in range(lab.shape[0]):
+                row = lab[b, :int(n[b])]
+                keep = np.ones(len(row), dtype=bool)
+                keep[1:] = row[1:] != row[:-1]
+                kept = row[keep]
+                lab[b, :len(kept)] = kept
+                n[b] = len(kept)
         indices, values = [], []
         for b in range(lab.shape[0]):
             for i in range(int(n[b])):

@@ -135,10 +135,11 @@ class MultitaskCTC(CTC):
         return dict(d_outputs_sub=dsub.view(T, Bp, E))
 
     # ------------------------------------------------------------------ decode / eval
-    def decoder(self, logits_main, logits_sub, inputs_seq_len, beam_width=1):
-        """:314-347 -> (decode_op_main, decode_op_sub), each the SparseTensor triple."""
+    def decoder(self, logits_main, logits_sub, inputs_seq_len, beam_width=1, merge_repeated=True):
+        """:314-347 -> (decode_op_main, decode_op_sub), each the SparseTensor triple (merge_repeated: see CTC.decoder)."""
         dec = super(MultitaskCTC, self).decoder
-        return dec(logits_main, inputs_seq_len, beam_width), dec(logits_sub, inputs_seq_len, beam_width)
+        return (dec(logits_main, inputs_seq_len, beam_width, merge_repeated),
+                dec(logits_sub, inputs_seq_len, beam_width, merge_repeated))
 
     def posteriors(self, logits_main, logits_sub):
         """:349-372: softmax over classes on the batch-major flattenings."""

@@ -83,18 +83,29 @@ def wer_align(ref, hyp):
     return sub, ins, dele
 
 
-def compute_edit_distance(session, labels_true_st, labels_pred_st):
-    """Per-utterance normalised edit distance of two sparse label batches ([indices, values, dense_shape] triples),
-    what the reference's compute_edit_distance (edit_distance.py:15-32) gets from tf.edit_distance(normalize=True):
-    distance / len(truth).  `session` is accepted for call compatibility and ignored."""
+def tf_edit_distance(hypothesis_st, truth_st, normalize=True):
+    """tf.edit_distance(hypothesis, truth, normalize) on two [indices, values, dense_shape] triples: per batch row the
+    Levenshtein distance, divided by len(truth) when normalize (inf for an empty truth against a non-empty hypothesis,
+    0 when both are empty) -- the cases of the op's documentation are pinned in tests/test_host_io.py."""
     import numpy as np
     from ..io.labels.sparsetensor import sparse_to_flat
-    B = int(np.asarray(labels_true_st[2])[0])
-    tv, to, _ = sparse_to_flat(labels_true_st, B)
-    pv, po, _ = sparse_to_flat(labels_pred_st, B)
+    B = int(np.asarray(truth_st[2])[0])
+    hv, ho, _ = sparse_to_flat(hypothesis_st, B)
+    tv, to, _ = sparse_to_flat(truth_st, B)
     out = np.zeros(B, dtype=np.float64)
     for b in range(B):
-        truth, hyp = tv[to[b]:to[b + 1]], pv[po[b]:po[b + 1]]
-        d = levenshtein(list(truth), list(hyp))
-        out[b] = d / len(truth) if len(truth) else (float('inf') if d else 0.0)   # tf: inf for an empty truth
+        hyp, truth = hv[ho[b]:ho[b + 1]], tv[to[b]:to[b + 1]]
+        d = levenshtein(list(hyp), list(truth))
+        out[b] = float(d) if not normalize else (d / len(truth) if len(truth) else (float('inf') if d else 0.0))
     return out
+
+
+def compute_edit_distance(session, labels_true_st, labels_pred_st):
+    """What the reference's compute_edit_distance (utils/evaluation/edit_distance.py:15-32) returns -- including its
+    argument swap: it builds `labels_pred_pl` from labels_TRUE_st and `labels_true_pl` from labels_PRED_st and calls
+    tf.edit_distance(labels_pred_pl, labels_true_pl, normalize=True), so the transcript is passed as the hypothesis
+    and the PREDICTION as the truth the distance is divided by: distance / len(prediction), not / len(transcript)
+    (the Levenshtein distance itself is symmetric).  `session` is accepted for call compatibility and ignored.
+    CTC.compute_ler (models/ctc/ctc.py:391) calls tf.edit_distance(decode_op, labels) directly and does divide by the
+    transcript length -- compute_ler above."""
+    return tf_edit_distance(labels_true_st, labels_pred_st, normalize=True)

@@ -54,9 +54,12 @@ def test_ctc_model_loss_grads_and_step(cuda, enc, B, T, D, H, L, C):
     assert [list(h) for h in hyp] == ref_hyp
     ler = model.compute_ler(dec, list2sparsetensor(dense, -1))
     assert 0 <= ler
-    dec_b = model.decoder(logits, sl, beam_width=4)       # device prefix beam search
+    dec_b = model.decoder(logits, sl, beam_width=4, merge_repeated=False)       # device prefix beam search
     ref_b, _ = odec.beam_search_decode(__import__('oracle.ctc', fromlist=['x']).log_softmax(np.transpose(ref['logits'], (1, 0, 2))), sl, C, 4)
     assert [list(h) for h in sparsetensor2list(dec_b, B)] == ref_b
+    # default = the reference's call, tf.nn.ctc_beam_search_decoder(merge_repeated=True): repeats of the output collapse
+    dec_m = [list(h) for h in sparsetensor2list(model.decoder(logits, sl, beam_width=4), B)]
+    assert dec_m == [[v for i, v in enumerate(h) if i == 0 or v != h[i - 1]] for h in ref_b]
     # gradients (before clipping)
     opt = model._set_optimizer('momentum', 0.01)
     gv = opt.compute_gradients(loss, model=model)

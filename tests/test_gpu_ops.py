@@ -454,13 +454,19 @@ def _flat(labs):
     return flat, off
 
 
+# the last three: cfg E (CSJ kanji, C = 3386, labels up to ~166 at T = 1000) and the word-level vocabularies of
+# examples/librispeech/training/train_ctc.py (18 641 / 26 642 classes + blank) -- the gradient kernel keeps a C-bit
+# membership map, never a per-class accumulator, in LDS
 @pytest.mark.parametrize('T,B,C,lmax', [(30, 4, 6, 8), (120, 16, 40, 30), (300, 16, 62, 75), (50, 3, 29, 20),
-                                         (64, 2, 700, 25), (400, 2, 29, 150)])
+                                         (64, 2, 700, 25), (400, 2, 29, 150), (200, 3, 3386, 60), (500, 2, 3386, 166),
+                                         (40, 3, 26643, 12)])
 def test_ctc_loss_and_grad(cuda, T, B, C, lmax):
     ops = _ops()
     rng = np.random.RandomState(T + C)
     logits, sl, labs = _ctc_case(rng, T, B, C, lmax)
     labs[0] = labs[0][:2] + labs[0][:2] if len(labs[0]) >= 2 else labs[0]   # force repeats
+    if len(labs[-1]) >= 3:
+        labs[-1][2] = labs[-1][0]                                            # a non-adjacent repeat of a class
     flat, off = _flat(labs)
     ref_loss, ref_grad = octc.ctc_loss_batch(logits.astype(np.float64), labs, sl)
     loss, grad, ninf = ops.ctc_loss(torch.tensor(logits, device=cuda), torch.tensor(flat, device=cuda),
