@@ -1,0 +1,43 @@
+"""Seeded posteriors at BASELINE cfg E scale (CSJ kanji: C = 3385 + blank ... here 3387 as the attention
+vocabulary of SURVEY 8a) shared by the golden generator (make_golden_cfge.py, runs the REFERENCE's
+BeamSearchDecoder on them) and by the GPU parity test (which feeds log(probs) as fp32 logits to the HIP kernel).
+numpy.random.RandomState is a frozen stream, so the inputs need not be stored: the golden file keeps a SHA-256
+of the fp32 log-posteriors and the test checks it before comparing labels."""
+import hashlib
+
+import numpy as np
+
+# name -> (seed, T, C, beam_width, sharpness, grid)   grid > 0: logits rounded to multiples of 1/grid, so many
+# classes tie EXACTLY inside a frame (equal logits -> equal softmax outputs): the class-pruning threshold of the
+# kernel and the stable-sort tie rule of the reference (beam_search_decoder.py:143-146) are both exercised.
+CASES = {
+    'peaky_w20': (41, 200, 3387, 20, 4.0, 0),
+    'peaky_w100': (42, 200, 3387, 100, 4.0, 0),
+    'ties_w20': (43, 120, 3387, 20, 2.0, 2),
+    'ties_w100': (44, 80, 3387, 100, 2.0, 2),
+    'flat_w100': (45, 40, 3387, 100, 0.5, 0),
+}
+
+
+def posteriors(name):
+    seed, T, C, W, sharp, grid = CASES[name]
+    rng = np.random.RandomState(seed)
+    logits = rng.randn(1, T, C) * sharp
+    if grid:
+        logits = np.round(logits * grid) / grid
+    logits[0, :, C - 1] += sharp * (0.5 + rng.rand())            # blank frequent, like a trained CTC model
+    for t in range(1, T):
+        if rng.rand() < 0.35:                                     # repeated frames: the merge rule matters
+            logits[0, t] = logits[0, t - 1]
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    probs = (e / e.sum(-1, keepdims=True)).astype(np.float64)
+    return probs, np.array([T], dtype=np.int32), W
+
+
+def fp32_logits(probs):
+    """[1,T,C] float64 posteriors -> [T,1,C] fp32 log-posteriors (what the HIP decoder consumes)."""
+    return np.ascontiguousarray(np.log(probs).astype(np.float32).transpose(1, 0, 2))
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
