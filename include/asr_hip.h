@@ -69,6 +69,10 @@ int asr_device_info(asr_handle* h, int* num_cu, char* name, int name_len);
  * (tf.transpose(inputs,[1,0,2]) at models/encoders/core/blstm.py:277-279). */
 int asr_bt_to_tb(asr_handle* h, int dtype, const float* in_btd, void* out_tbd,
                  int B, int T, int D, asr_stream s);
+/* same with output rows of ld_out >= D elements, columns D..ld_out-1 zero (the first layer's reduction width padded
+ * to the GEMM's k tile, e.g. 120 -> 128) */
+int asr_bt_to_tb_ld(asr_handle* h, int dtype, const float* in_btd, void* out_tbd,
+                    int B, int T, int D, int ld_out, asr_stream s);
 /* Batch assembly on the device.  Frame stacking / skipping of a zero-padded batch
  * x[B,T,F] (utils/io/inputs/frame_stacking.py:14-85): out[B, ceil(T/num_skip), F*num_stack], output frame k
  * = input frames k*num_skip .. +num_stack-1 side by side, zero where they run past the utterance;
@@ -173,6 +177,22 @@ int asr_relu_bwd(asr_handle* h, int dtype, const float* dout, const void* out, c
 int asr_lstm_prep_weights(asr_handle* h, int dtype, const float* kernel, const float* bias,
                           int Din, int H, void* wx_il, float* bias_il,
                           void* packed_fwd, void* packed_bwd, asr_stream s);
+/* asr_lstm_prep_layer: the same images for ALL directions of a layer in one launch, in the form the layer's GEMMs
+ * consume (no transposes / concatenations afterwards).  vars[ndir*5] (host array of device pointers), per direction:
+ * {kernel [Din+H,4H], bias [4H], w_i_diag, w_f_diag, w_o_diag [H]} -- the five tf.get_variable()s of one
+ * LSTMBlockCell (blstm.py:287-305; SURVEY App. C names); the peephole pointers may be NULL iff peep_out is NULL.
+ *   wxT     [ndir*4H, ldk] `dtype`  W_x^T, interleaved rows, directions stacked, columns Din..ldk-1 zero
+ *                                   (xproj = x [T*B, ldk] . wxT^T: one GEMM for both directions)
+ *   wx_cat  [Din, ndir*4H] `dtype`  W_x, interleaved columns, directions side by side (dx = dG . wx_cat^T)
+ *   bias_cat[ndir*4H] fp32, packed_fwd / packed_bwd [ndir][H*4H] `dtype`, peep_out [ndir][3][H] fp32 */
+int asr_lstm_prep_layer(asr_handle* h, int dtype, int ndir, const float* const* vars, int Din, int ldk, int H,
+                        void* wxT, void* wx_cat, float* bias_cat, void* packed_fwd, void* packed_bwd,
+                        float* peep_out, asr_stream s);
+/* asr_lstm_grad_finish: the way back for one layer's gradients, one launch.  dw_il [ndir][rows = Din+H][4H] fp32 with
+ * interleaved columns (output of the weight-gradient GEMMs) and dpeep_dbias [ndir][7][H] (asr_lstm_bwd) are written
+ * to grads[ndir*5] = the gradient buffers of the same five variables, in TF's layouts (kernel gate-major). */
+int asr_lstm_grad_finish(asr_handle* h, int ndir, float* const* grads, int rows, int H, const float* dw_il,
+                         const float* dpeep_dbias, int has_peep, asr_stream s);
 /* [rows, 4H] fp32 with interleaved columns -> gate-major columns (dW after the GEMMs) */
 int asr_gate_deinterleave(asr_handle* h, const float* in, int ld_in, float* out, int ld_out,
                           int rows, int H, asr_stream s);
@@ -222,6 +242,10 @@ int asr_clear_async_errors(asr_handle* h, asr_stream s);
 /* Debug / test switches of the cluster kernels (process-wide, same bits as the environment variable ASR_LSTM_DFLAGS):
  * 16 = force the placement-independent write-through exchange, 64 = TEST ONLY, make every hand-off time out. */
 int asr_debug_set_lstm_flags(int flags);
+
+/* Debug: records, per workgroup of a probe grid launched on `s`, {XCC id, HW_ID register} into out[2*nblocks]
+ * (device memory); every workgroup stays resident for spin_cycles so that the grid spreads over the CUs. */
+int asr_debug_placement(asr_handle* h, unsigned* out, int nblocks, int spin_cycles, asr_stream s);
 
 /* ---- CTC ------------------------------------------------------------------ *
  * tf.nn.ctc_loss(labels, logits, seq_len, preprocess_collapse_repeated=False,

@@ -1,7 +1,8 @@
 #!/bin/bash
-# round-2 GPU call 3 (re-entry): full GPU suite, driver-settings bench, kernel trace -> profiles/
+# full GPU suite, driver-settings bench (20 steps / 5 warm-up), default bench, kernel trace + one-step timeline
+# usage: bash scripts/r02_gpu_suite_bench_trace.sh [outdir under gpurun_out/]
 set -u
-OUT=gpurun_out/r02_c3
+OUT=${1:-gpurun_out/r02_c5}
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $OUT/gpu_tests.log 2>&1
 echo "gpu tests rc=$? $(tail -1 $OUT/gpu_tests.log)"
@@ -9,9 +10,9 @@ timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/be
 echo "bench20 rc=$?"
 timeout 300 python bench.py --no-cpu-baseline --no-parity --no-cfgA > $OUT/bench100.json 2> $OUT/bench100.err
 echo "bench100 rc=$?"
-python - <<'PY'
-import json, glob
-for p in sorted(glob.glob('gpurun_out/r02_c3/bench*.json')):
+OUT=$OUT python - <<'PY'
+import json, glob, os
+for p in sorted(glob.glob(os.environ['OUT'] + '/bench*.json')):
     try:
         d = json.load(open(p)); k = d['kernels']
         print('%s: %.0f frames/s %.3f ms/step (median %.3f, host issue %.2f) fwd %.1f bwd %.1f ctc %.1f handoff %s' % (p, d['value'], d['ms_per_step'],

@@ -26,6 +26,7 @@ SIGNATURES = {
     'asr_last_error_string': (C.c_char_p, [_vp]),
     'asr_device_info': (_i, [_vp, C.POINTER(_i), C.c_char_p, _i]),
     'asr_bt_to_tb': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'asr_bt_to_tb_ld': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'asr_transpose2d': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
     'asr_cast_from_f32': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     'asr_cast_to_f32': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
@@ -44,6 +45,8 @@ SIGNATURES = {
     'asr_maxpool2x2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'asr_relu_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     'asr_lstm_prep_weights': (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'asr_lstm_prep_layer': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'asr_lstm_grad_finish': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     'asr_gate_deinterleave': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     'asr_lstm_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'asr_lstm_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -52,6 +55,7 @@ SIGNATURES = {
     'asr_peek_async_errors': (_i, [_vp, _vp, _vp]),
     'asr_clear_async_errors': (_i, [_vp, _vp]),
     'asr_debug_set_lstm_flags': (_i, [_i]),
+    'asr_debug_placement': (_i, [_vp, _vp, _i, _i, _vp]),
     'asr_ctc_workspace_bytes': (_sz, [_i, _i, _i]),
     'asr_ctc_loss': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'asr_ctc_greedy_decode': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),

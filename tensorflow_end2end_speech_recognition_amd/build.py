@@ -18,6 +18,10 @@ OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libasr_hip.so')
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=%s' % ARCH, '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value']
+# ctc.hip: the SLP vectoriser pairs the per-state multiplies of the single-wave recursion into v_pk_mul_f32 and then
+# re-packs freshly loaded emission registers right behind their global_load (s_waitcnt vmcnt(0) every frame: the whole
+# memory latency on the serial chain); without it the loads stay 8 frames ahead of their use
+FILE_FLAGS = {'ctc.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -37,7 +41,7 @@ def _stale(target, deps):
 def _compile(src, headers, force):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
     if force or _stale(obj, [src] + headers):
-        cmd = [_hipcc()] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (src, r.stderr[-4000:]))

@@ -15,6 +15,10 @@ struct asr_handle {
   // split-K slabs of asr_gemm.  Calls on one handle are single-stream by contract.
   void* scratch;
   size_t scratch_bytes;
+  // exchange areas of the multi-CU LSTM kernels (lstm_cluster.hip): bytes of each area that hold stale tags, and the
+  // area the next launch runs on
+  size_t xch_dirty[2];
+  int xch_next;
 };
 
 #define ASR_FAIL(h, code, ...)                                  \

@@ -6,12 +6,14 @@
 // and tf.nn.softmax in CTC.posteriors (ctc.py:354-380).  blank = C-1.
 //
 // These are HBM/latency-bound passes over logits[T,B,C]; nothing here is GEMM-shaped:
-//   1. row_lse:      one wave per (t,b) row, ln sum exp           (1 read of logits)
-//   2. alpha_beta:   one workgroup per utterance, 4 waves run the alpha recursion while 4
-//                    run beta; previous row in LDS (double buffered), one barrier per frame,
-//                    the emission ln y_t(l'_s) of the NEXT frame is fetched before the barrier
+//   1. row_lse:      one wave per (t,b) row: ln sum exp, and the emission probabilities of the row along the
+//                    utterance's blank-extended label sequence (yext)          (1 read of logits)
+//   2. alpha_beta:   ONE WAVE per recursion (alpha and beta of an utterance in two single-wave workgroups), LINEAR
+//                    domain with a private exponent per state ({fp32 mantissa, int32 exponent}: the range of the
+//                    log domain without its exp / log), K consecutive states per lane in registers, lane-boundary
+//                    values over wave_shr / wave_shl DPP: no transcendental, no LDS, no barrier on the per-frame chain
 //   3. grad:         one wave per (t,b): posterior occupations gamma_t(s) =
-//                    exp(alpha+beta-ln y-ln p) are summed per class in a fixed order
+//                    alpha beta / (y p) are summed per class in a fixed order
 //                    (blank by a wave tree reduction, labels by rank rounds) so the result
 //                    is deterministic; writes softmax - occupation   (1 read + 1 write)
 #include "common.h"
@@ -21,44 +23,25 @@ namespace {
 
 constexpr float NEG_INF = -INFINITY;
 
-__device__ __forceinline__ float lse2(float a, float b) {
-  const float m = fmaxf(a, b);
-  if (m == NEG_INF) return NEG_INF;
-  return m + logf(expf(a - m) + expf(b - m));
-}
-__device__ __forceinline__ float lse3(float a, float b, float c) {
-  const float m = fmaxf(fmaxf(a, b), c);
-  if (m == NEG_INF) return NEG_INF;
-  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
-}
-// The alpha/beta recursions run in fp64: for T of several hundred frames the log-domain values
-// reach -1e3 and fp32 (what TF's CPU kernel uses) leaves ~1e-3 absolute error in the
-// posteriors.  The DP is latency-bound, MI355X has full-rate fp64 VALU, so this costs little.
 constexpr double DNEG_INF = -INFINITY;
-__device__ __forceinline__ double dlse2(double a, double b) {
-  const double m = fmax(a, b);
-  if (m == DNEG_INF) return DNEG_INF;
-  return m + log(exp(a - m) + exp(b - m));
-}
-__device__ __forceinline__ double dlse3(double a, double b, double c) {
-  const double m = fmax(fmax(a, b), c);
-  if (m == DNEG_INF) return DNEG_INF;
-  return m + log(exp(a - m) + exp(b - m) + exp(c - m));
-}
 
-// Recursion form: the running maximum and the result stay fp64; only the three differences
-// (<= 0) go through the fp32 v_exp / v_log units.  Per-frame error ~1e-7 absolute in the log
-// domain (vs 6e-5 when alpha itself is fp32), ~30 instructions instead of ~400 of fp64 libm.
-__device__ __forceinline__ double dlse3_mixed(double a, double b, double c) {
-  const double m = fmax(fmax(a, b), c);
-  if (m == DNEG_INF) return DNEG_INF;
-  const float e = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
-  return m + (double)__logf(e);
-}
+// ---- 1. row log-sum-exp + emissions of the extended label sequence ----------
+// One wave per (t,b) row: lse[row] = ln sum_k exp(x_k) (fp64), then -- when yext is given -- the emission
+// probabilities of the row's utterance along its blank-extended label sequence l' (s even: blank, s odd: label s>>1),
+//   yext[b][t][s] = {m, e}: y_t(l'_s) = exp(x[l'_s] - lse) = m * 2^e, m in [0.5, 1] fp32, e int32   for s < S,
+//   {0, ME_ZERO} for S <= s < SP  (SP = 64 * K, K states per lane of kernel 2)
+// i.e. already in the form the recursion multiplies with.  This is the only thing the serial kernel reads per frame:
+// contiguous, prefetchable, no gather and no exp on the chain.  yrev holds the same rows in reversed time order
+// (row Tb-1-t): the beta recursion then walks memory forwards exactly like alpha, and the two share one loop body.
+constexpr int ME_ZERO = -(1 << 24);      // exponent of the value 0 (any real exponent stays above -126 * T)
+struct __attribute__((aligned(8))) MantExp { float m; int e; };
 
-// ---- 1. row log-sum-exp ---------------------------------------------------
 __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ x, int rows, int C,
-                                                      double* __restrict__ lse) {
+                                                      double* __restrict__ lse, int T, int B,
+                                                      const int32_t* __restrict__ labels_flat,
+                                                      const int32_t* __restrict__ label_offsets,
+                                                      const int32_t* __restrict__ seq_len, int SP,
+                                                      MantExp* __restrict__ yext, MantExp* __restrict__ yrev) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -70,7 +53,32 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
   for (int k = lane; k < C; k += 64) s += exp((double)p[k] - (double)m);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) lse[row] = (double)m + log(s);
+  const double z = (double)m + log(s);
+  if (lane == 0) lse[row] = z;
+  if (!yext) return;
+  const int t = row / B, b = row - t * B;
+  const int Tb = min(seq_len[b], T);
+  if (t >= Tb) return;                                    // frames past the utterance are never read
+  const int lo = label_offsets[b];
+  const int S = 2 * (label_offsets[b + 1] - lo) + 1;
+  const int32_t* lab = labels_flat + lo;
+  MantExp* out = yext + ((size_t)b * T + t) * SP;
+  MantExp* outr = yrev + ((size_t)b * T + (Tb - 1 - t)) * SP;   // the same frame where the beta recursion reads it
+  const int blank = C - 1;
+  for (int st = lane; st < SP; st += 64) {
+    MantExp v = {0.f, ME_ZERO};
+    if (st < S) {
+      const int cls = (st & 1) ? lab[st >> 1] : blank;
+      const double l2 = ((double)p[cls] - z) * 1.4426950408889634074;      // log2 y  (<= 0)
+      if (l2 > -1.0e7) {                                                    // a logit of -inf: y = 0
+        const double fl = floor(l2);
+        v.e = (int)fl + 1;
+        v.m = (float)exp2(l2 - fl - 1.0);                                   // 2^[-1, 0) = [0.5, 1)
+      }
+    }
+    out[st] = v;
+    outr[st] = v;
+  }
 }
 
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x,
@@ -90,148 +98,176 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 }
 
 // ---- 2. alpha / beta recursions --------------------------------------------
-// workspace per utterance: alpha[T][SW], beta[T][SW] (SW = 2*Lmax+1), rank[Lmax], ll
-constexpr int AB_THREADS = 512;  // waves 0-3 alpha, 4-7 beta
-constexpr int AB_HALF = 256;
-constexpr int MAX_NS = 8;        // S <= 2048
+// ONE WAVE per recursion (grid = 2 x B workgroups of 64 threads: alpha of utterance b, beta of utterance b), in the
+// LINEAR domain:
+//   alpha_t(s) = (alpha_{t-1}(s) + alpha_{t-1}(s-1) + [skip] alpha_{t-1}(s-2)) * y_t(l'_s)
+// with every state carried as {m, e} = m * 2^e (fp32 mantissa in [0.5, 1], private int32 exponent; 0 = {0, ME_ZERO}).
+// That is the range of the log domain (the states of one frame of a peaked model differ by far more than fp64's
+// 2^2046: a state that is negligible now can carry the whole likelihood a hundred frames later) without its cost:
+// the sum aligns the three terms to their largest exponent (v_max3, 3 v_sub, 3 v_ldexp), the product adds exponents,
+// v_frexp_* renormalises -- ~16 full-rate instructions per state and frame, no exp / log.  (The log-domain form this
+// replaces spent ~1.1k cycles per frame in three exp + one log behind an LDS round trip and a 512-thread barrier.)
+// Lane i owns the K consecutive states K*i .. K*i+K-1 in registers; the two states that cross a lane boundary move
+// with wave_shr:1 / wave_shl:1 DPP -- no LDS, no barrier.  The recursion is started from a virtual frame
+// (alpha_{-1} = indicator of state 0, beta_T = indicator of state S-1), which yields the usual initial rows.
+// Emissions come from yext (kernel 1) through a register ring D frames deep; the main loop body is D frames of
+// straight-line code (static ring registers, exact s_waitcnt counts), the < D remaining frames run from the ring.
+// Per-frame precision: ~4 roundings of 2^-24 -> ~1e-5 relative on p(l|x) after 1000 frames, i.e. ~1e-8 relative on
+// the loss; -ln p = -(ln(m1 2^(e1-E) + m2 2^(e2-E)) + E ln 2) over the two final states, in fp64.
+__device__ __forceinline__ float dpp_shift_f(float v, bool right) {
+  return __builtin_bit_cast(float, right ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false)
+                                         : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ int dpp_shift_e(int v, bool right) {   // the lane without a source gets the exponent of 0
+  return right ? __builtin_amdgcn_update_dpp(ME_ZERO, v, 0x138, 0xF, 0xF, false)
+               : __builtin_amdgcn_update_dpp(ME_ZERO, v, 0x130, 0xF, 0xF, false);
+}
 
-template <int NS>
-__global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
-    const float* __restrict__ logits, const double* __restrict__ lse, int T, int B, int C,
+// ybase / ws: rows in RECURSION order (step 0, 1, ...): for beta that is reversed time (row i = frame Tb-1-i).
+template <int K, int D, bool BETA>
+__device__ __forceinline__ void ctc_recursion(const MantExp* __restrict__ ybase, MantExp* __restrict__ ws, int Tb,
+                                              int S, int lane, const int32_t* __restrict__ lab, float (&am)[K],
+                                              int (&ae)[K]) {
+  constexpr int SP = 64 * K;
+  // exponent offset of the skip term: 0 where the transition s-2 -> s (beta: s+2 -> s) exists, else "times 0"
+  int skoff[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int s = K * lane + k;
+    bool ok = false;
+    if ((s & 1) && s < S) {
+      if (!BETA) ok = s >= 3 && lab[s >> 1] != lab[(s >> 1) - 1];
+      else ok = s + 2 < S && lab[s >> 1] != lab[(s >> 1) + 1];
+    }
+    skoff[k] = ok ? 0 : ME_ZERO;
+  }
+  // virtual start frame
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int s = K * lane + k;
+    const bool on = BETA ? (s == S - 1) : (s == 0);
+    am[k] = on ? 0.5f : 0.f;
+    ae[k] = on ? 1 : ME_ZERO;
+  }
+  float rm[D][K];
+  int re[D][K];
+  auto fetch = [&](int slot, int step) {                   // emissions of recursion step `step` (clamped: no branch)
+    const MantExp* src = ybase + (size_t)min(step, Tb - 1) * SP;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const MantExp v = src[k]; rm[slot][k] = v.m; re[slot][k] = v.e; }
+  };
+  auto frame = [&](int slot, int step) {
+    float nm[K];
+    int ne[K];
+    const float p1m = dpp_shift_f(BETA ? am[0] : am[K - 1], !BETA), p2m = dpp_shift_f(BETA ? am[1] : am[K - 2], !BETA);
+    const int p1e = dpp_shift_e(BETA ? ae[0] : ae[K - 1], !BETA), p2e = dpp_shift_e(BETA ? ae[1] : ae[K - 2], !BETA);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float m1, m2;
+      int e1, e2;
+      if (!BETA) {
+        m1 = k >= 1 ? am[k - 1] : p1m;  e1 = k >= 1 ? ae[k - 1] : p1e;
+        m2 = k >= 2 ? am[k - 2] : (k == 1 ? p1m : p2m);  e2 = k >= 2 ? ae[k - 2] : (k == 1 ? p1e : p2e);
+      } else {
+        m1 = k + 1 < K ? am[k + 1] : p1m;  e1 = k + 1 < K ? ae[k + 1] : p1e;
+        m2 = k + 2 < K ? am[k + 2] : (k + 2 == K ? p1m : p2m);  e2 = k + 2 < K ? ae[k + 2] : (k + 2 == K ? p1e : p2e);
+      }
+      e2 += skoff[k];
+      const int E = max(max(ae[k], e1), e2);
+      const float sum = ldexpf(am[k], ae[k] - E) + ldexpf(m1, e1 - E) + ldexpf(m2, e2 - E);
+      const float pr = sum * rm[slot][k];
+      nm[k] = __builtin_amdgcn_frexp_mantf(pr);
+      ne[k] = pr > 0.f ? E + re[slot][k] + __builtin_amdgcn_frexp_expf(pr) : ME_ZERO;
+    }
+    MantExp* dst = ws + (size_t)step * SP;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      am[k] = nm[k];
+      ae[k] = ne[k];
+      dst[k] = (MantExp){nm[k], ne[k]};
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < D; ++j) fetch(j, j);
+  int base = 0;
+  for (; base + D <= Tb; base += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      frame(j, base + j);
+      fetch(j, base + j + D);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (base + j < Tb) frame(j, base + j);                 // wave-uniform; slot j holds frame base + j
+}
+
+template <int K, int D>
+__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(
+    const MantExp* __restrict__ yext, const MantExp* __restrict__ yrev, int T, int B, int C,
     const int32_t* __restrict__ labels_flat, const int32_t* __restrict__ label_offsets,
-    const int32_t* __restrict__ seq_len, int SW, double* __restrict__ alpha_ws,
-    double* __restrict__ beta_ws, int32_t* __restrict__ rank_ws, double* __restrict__ ll_ws,
-    float* __restrict__ loss, int32_t* __restrict__ num_infeasible) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* rowbuf = reinterpret_cast<double*>(smem);  // [2 (alpha/beta)][2 (ping/pong)][SW]
-  const int b = blockIdx.x;
-  const int blank = C - 1;
+    const int32_t* __restrict__ seq_len, int Lcap, MantExp* __restrict__ alpha_ws, MantExp* __restrict__ beta_ws, int32_t* __restrict__ rank_ws,
+    double* __restrict__ ll_ws, float* __restrict__ loss, int32_t* __restrict__ num_infeasible) {
+  constexpr int SP = 64 * K;
+  const int b = blockIdx.x >> 1;
+  const bool is_beta = blockIdx.x & 1;
+  const int lane = threadIdx.x;
   const int lo = label_offsets[b];
   const int L = label_offsets[b + 1] - lo;
   const int S = 2 * L + 1;
   const int Tb = min(seq_len[b], T);
-  const int half = threadIdx.x / AB_HALF;  // 0 alpha, 1 beta
-  const int tid = threadIdx.x % AB_HALF;
   const int32_t* lab = labels_flat + lo;
-  double* ws = (half == 0 ? alpha_ws : beta_ws) + (size_t)b * T * SW;
-  double* buf = rowbuf + half * 2 * SW;
 
-  // rank of each label among equal earlier labels (fixed summation order in the grad kernel) and the position of
-  // the first label of its class (where the grad kernel accumulates that class), packed rank | first << 16
-  for (int i = threadIdx.x; i < L; i += AB_THREADS) {
-    const int li = lab[i];
-    int r = 0, first = i;
-    for (int k = i - 1; k >= 0; --k)
-      if (lab[k] == li) { ++r; first = k; }
-    rank_ws[(size_t)b * ((SW - 1) / 2) + i] = r | (first << 16);
+  if (!is_beta) {
+    // rank of each label among equal earlier labels (fixed summation order in the grad kernel) and the position of
+    // the first label of its class (where the grad kernel accumulates that class), packed rank | first << 16
+    for (int i = lane; i < L && i < Lcap; i += 64) {
+      const int li = lab[i];
+      int r = 0, first = i;
+      for (int k = i - 1; k >= 0; --k)
+        if (lab[k] == li) { ++r; first = k; }
+      rank_ws[(size_t)b * (Lcap > 0 ? Lcap : 1) + i] = r | (first << 16);
+    }
   }
-  if (Tb <= 0 || L > (SW - 1) / 2) {
-    if (threadIdx.x == 0) {
+  if (Tb <= 0 || L > Lcap || S > SP) {
+    if (!is_beta && lane == 0) {
       loss[b] = 0.f;
       ll_ws[b] = DNEG_INF;
       if (num_infeasible && Tb > 0) atomicAdd(num_infeasible, 1);
     }
     return;
   }
-
-  // per-thread extended-label info for s = tid + n*256
-  int ext[NS];
-  bool skp[NS];  // alpha: may come from s-2 ; beta: may go to s+2
-#pragma unroll
-  for (int n = 0; n < NS; ++n) {
-    const int s = tid + n * AB_HALF;
-    ext[n] = blank; skp[n] = false;
-    if (s < S) {
-      ext[n] = (s & 1) ? lab[s >> 1] : blank;
-      if (half == 0) skp[n] = (s & 1) && s >= 2 && lab[s >> 1] != lab[(s >> 1) - 1];
-      else skp[n] = (s & 1) && s + 2 < S && lab[s >> 1] != lab[(s >> 1) + 1];
-    }
+  const MantExp* ybase = (is_beta ? yrev : yext) + (size_t)b * T * SP + K * lane;
+  float am[K];
+  int ae[K];
+  if (is_beta) {
+    ctc_recursion<K, D, true>(ybase, beta_ws + (size_t)b * T * SP + K * lane, Tb, S, lane, lab, am, ae);
+    return;
   }
-  const int t0 = half == 0 ? 0 : Tb - 1;
-  const int dt = half == 0 ? 1 : -1;
-  // emissions of the first frame
-  double lp[NS];
-  {
-    const float* row = logits + ((size_t)t0 * B + b) * C;
-    const double z = lse[(size_t)t0 * B + b];
+  ctc_recursion<K, D, false>(ybase, alpha_ws + (size_t)b * T * SP + K * lane, Tb, S, lane, lab, am, ae);
+  // p = alpha_T(S-1) + alpha_T(S-2): the two states live in lanes (S-1)/K and (S-2)/K
+  float m1 = 0.f, m2 = 0.f;
+  int e1 = ME_ZERO, e2 = ME_ZERO;
 #pragma unroll
-    for (int n = 0; n < NS; ++n) {
-      const int s = tid + n * AB_HALF;
-      lp[n] = (s < S) ? (double)row[ext[n]] - z : DNEG_INF;
-    }
+  for (int k = 0; k < K; ++k) {
+    const int s = K * lane + k;
+    if (s == S - 1) { m1 = am[k]; e1 = ae[k]; }
+    if (s == S - 2) { m2 = am[k]; e2 = ae[k]; }
   }
-  // init row
 #pragma unroll
-  for (int n = 0; n < NS; ++n) {
-    const int s = tid + n * AB_HALF;
-    if (s < S) {
-      double v = DNEG_INF;
-      if (half == 0) { if (s <= 1) v = lp[n]; }
-      else { if (s >= S - 2) v = lp[n]; }
-      buf[s] = v;
-      ws[(size_t)t0 * SW + s] = v;
-    }
+  for (int o = 32; o > 0; o >>= 1) {                       // every lane but the owners holds {0, ME_ZERO}
+    const float om1 = __shfl_xor(m1, o, 64), om2 = __shfl_xor(m2, o, 64);
+    const int oe1 = __shfl_xor(e1, o, 64), oe2 = __shfl_xor(e2, o, 64);
+    if (oe1 > e1) { m1 = om1; e1 = oe1; }
+    if (oe2 > e2) { m2 = om2; e2 = oe2; }
   }
-  __syncthreads();
-  // emissions of the next frame are requested BEFORE this frame's recursion and converted after it
-  const size_t rstride = (size_t)B * C;
-  const float* row = logits + ((size_t)t0 * B + b) * C;
-  const double* zp = lse + (size_t)t0 * B + b;
-  for (int step = 1; step < Tb; ++step) {
-    const int t = t0 + dt * step;
-    const double* prev = buf + ((step - 1) & 1) * SW;
-    double* cur = buf + (step & 1) * SW;
-    // lp currently holds frame t's emissions (loaded one iteration ahead, or below for step 1)
-    if (step == 1) {
-      row += dt * (ptrdiff_t)rstride; zp += dt * (ptrdiff_t)B;
-      const double z = *zp;
-#pragma unroll
-      for (int n = 0; n < NS; ++n) {
-        const int s = tid + n * AB_HALF;
-        if (s < S) lp[n] = (double)row[ext[n]] - z;
-      }
-    }
-    float nf[NS];
-    double nz = 0.0;
-    const bool more = step + 1 < Tb;
-    if (more) {
-      row += dt * (ptrdiff_t)rstride; zp += dt * (ptrdiff_t)B;
-      nz = *zp;
-#pragma unroll
-      for (int n = 0; n < NS; ++n) {
-        const int s = tid + n * AB_HALF;
-        nf[n] = (s < S) ? row[ext[n]] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < NS; ++n) {
-      const int s = tid + n * AB_HALF;
-      if (s < S) {
-        double a0 = prev[s], a1, a2;
-        if (half == 0) {
-          a1 = s >= 1 ? prev[s - 1] : DNEG_INF;
-          a2 = skp[n] ? prev[s - 2] : DNEG_INF;
-        } else {
-          a1 = s + 1 < S ? prev[s + 1] : DNEG_INF;
-          a2 = skp[n] ? prev[s + 2] : DNEG_INF;
-        }
-        const double v = dlse3_mixed(a0, a1, a2) + lp[n];
-        cur[s] = v;
-        ws[(size_t)t * SW + s] = v;
-      }
-    }
-    if (more) {
-#pragma unroll
-      for (int n = 0; n < NS; ++n) lp[n] = (double)nf[n] - nz;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {  // alpha half, thread 0
-    const double* last = buf + ((Tb - 1) & 1) * SW;
-    const double ll = dlse2(last[S - 1], S >= 2 ? last[S - 2] : DNEG_INF);
-    const bool ok = ll > DNEG_INF;
+  if (lane == 0) {
+    const int E = max(e1, e2);
+    const bool ok = E > ME_ZERO;
+    double ll = DNEG_INF;
+    if (ok) ll = log(ldexp((double)m1, e1 - E) + ldexp((double)m2, e2 - E)) + (double)E * 0.6931471805599453094;
     loss[b] = ok ? (float)(-ll) : 0.f;
-    ll_ws[b] = ok ? ll : DNEG_INF;
+    ll_ws[b] = ll;
     if (!ok && num_infeasible) atomicAdd(num_infeasible, 1);
   }
 }
@@ -240,9 +276,10 @@ __global__ __launch_bounds__(AB_THREADS) void ctc_alpha_beta_kernel(
 __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ logits, const double* __restrict__ lse, int T, int B, int C,
     const int32_t* __restrict__ labels_flat, const int32_t* __restrict__ label_offsets,
-    const int32_t* __restrict__ seq_len, int SW, const double* __restrict__ alpha_ws,
-    const double* __restrict__ beta_ws, const int32_t* __restrict__ rank_ws,
-    const double* __restrict__ ll_ws, float grad_scale, float* __restrict__ grad) {
+    const int32_t* __restrict__ seq_len, int SW, int SP, const MantExp* __restrict__ yext,
+    const MantExp* __restrict__ alpha_ws, const MantExp* __restrict__ beta_ws,
+    const int32_t* __restrict__ rank_ws, const double* __restrict__ ll_ws, float grad_scale,
+    float* __restrict__ grad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // Per wave: gam[SW] (state occupations), acc[(SW-1)/2] (occupation of a class, kept at the position of its FIRST
@@ -267,21 +304,24 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
   const int S = 2 * L + 1;
   const int blank = C - 1;
   const int32_t* lab = labels_flat + lo;
-  const int32_t* rk = rank_ws + (size_t)b * LW;
+  const int32_t* rk = rank_ws + (size_t)b * (LW > 0 ? LW : 1);
   const float* row = logits + ((size_t)t * B + b) * C;
   const double z = lse[(size_t)t * B + b];
-  const double* al = alpha_ws + ((size_t)b * T + t) * SW;
-  const double* be = beta_ws + ((size_t)b * T + t) * SW;
+  const MantExp* al = alpha_ws + ((size_t)b * T + t) * SP;
+  const MantExp* be = beta_ws + ((size_t)b * T + (Tb - 1 - t)) * SP;   // stored in recursion order
+  const MantExp* ye = yext + ((size_t)b * T + t) * SP;
 
   for (int k = lane; k < BW; k += 64) bits[k] = 0u;
   for (int i = lane; i < L; i += 64) acc[i] = 0.f;
   float blank_sum = 0.f;
   int maxrank = 0;
   for (int s = lane; s < S; s += 64) {
-    const int e = (s & 1) ? lab[s >> 1] : blank;
-    const double lpv = (double)row[e] - z;
-    const double v = al[s] + be[s] - lpv - ll;   // ln gamma_t(s); -inf/NaN-safe below
-    const float gm = (al[s] > DNEG_INF && be[s] > DNEG_INF) ? (float)exp(v) : 0.f;
+    // gamma_t(s) = alpha_t(s) beta_t(s) / (y_t(s) p): mantissas in fp64, exponents as integers, ln p = ll
+    const MantExp av = al[s], bv = be[s], yv = ye[s];
+    float gm = 0.f;
+    if (av.m > 0.f && bv.m > 0.f)
+      gm = (float)((double)av.m * (double)bv.m / (double)yv.m *
+                   exp((double)(av.e + bv.e - yv.e) * 0.6931471805599453094 - ll));
     gam[s] = gm;
     if (!(s & 1)) blank_sum += gm;
     else maxrank = max(maxrank, rk[s >> 1] & 0xffff);
@@ -370,17 +410,29 @@ __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict
   if (threadIdx.x == 0) out_len[b] = n;
 }
 
+// states per lane of the recursion kernel for an extended label sequence of SW = 2 Lmax + 1 states (0: too long)
+inline int ctc_states_per_lane(int SW) {
+  const int ks[5] = {3, 6, 12, 24, 32};
+  for (int i = 0; i < 5; ++i)
+    if (64 * ks[i] >= SW) return ks[i];
+  return 0;
+}
 struct CtcWs {
-  size_t lse, alpha, beta, rank, ll, total;
+  size_t lse, yext, yrev, alpha, beta, rank, ll, total;
+  int K;
 };
 inline CtcWs ctc_ws_layout(int T, int B, int Lmax) {
-  const size_t SW = 2 * (size_t)Lmax + 1;
+  const int SW = 2 * Lmax + 1;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   CtcWs w;
+  w.K = ctc_states_per_lane(SW);
+  const size_t SP = 64 * (size_t)(w.K ? w.K : 32);
   size_t o = 0;
   w.lse = o;   o += al((size_t)T * B * 8);
-  w.alpha = o; o += al((size_t)B * T * SW * 8);
-  w.beta = o;  o += al((size_t)B * T * SW * 8);
+  w.yext = o;  o += al((size_t)B * T * SP * sizeof(MantExp));
+  w.yrev = o;  o += al((size_t)B * T * SP * sizeof(MantExp));
+  w.alpha = o; o += al((size_t)B * T * SP * sizeof(MantExp));
+  w.beta = o;  o += al((size_t)B * T * SP * sizeof(MantExp));
   w.rank = o;  o += al((size_t)B * (Lmax > 0 ? Lmax : 1) * 4);
   w.ll = o;    o += al((size_t)B * 8);
   w.total = o;
@@ -404,32 +456,36 @@ extern "C" int asr_ctc_loss(asr_handle* h, const float* logits, int T, int B, in
       max_label_len < 0 || (max_label_len > 0 && !labels_flat))
     ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_ctc_loss: bad args T=%d B=%d C=%d Lmax=%d", T, B, C, max_label_len);
   const int SW = 2 * max_label_len + 1;
-  if (SW > MAX_NS * AB_HALF)
-    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_loss: label length %d > %d", max_label_len, (MAX_NS * AB_HALF - 1) / 2);
   const CtcWs w = ctc_ws_layout(T, B, max_label_len);
+  if (!w.K) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_loss: label length %d > %d", max_label_len, (64 * 32 - 1) / 2);
   if (!workspace || workspace_bytes < w.total)
     ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_ctc_loss: workspace %zu < %zu bytes", workspace_bytes, w.total);
   char* ws = (char*)workspace;
   double* lse = (double*)(ws + w.lse);
-  double* alpha = (double*)(ws + w.alpha);
-  double* beta = (double*)(ws + w.beta);
+  MantExp* yext = (MantExp*)(ws + w.yext);
+  MantExp* yrev = (MantExp*)(ws + w.yrev);
+  MantExp* alpha = (MantExp*)(ws + w.alpha);
+  MantExp* beta = (MantExp*)(ws + w.beta);
   int32_t* rank = (int32_t*)(ws + w.rank);
   double* ll = (double*)(ws + w.ll);
   hipStream_t st = (hipStream_t)s;
   if (num_infeasible) (void)hipMemsetAsync(num_infeasible, 0, sizeof(int32_t), st);
   const int rows = T * B;
-  hipLaunchKernelGGL(row_lse_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, rows, C, lse);
+  const int SP = 64 * w.K;
+  hipLaunchKernelGGL(row_lse_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, rows, C, lse, T, B, labels_flat,
+                     label_offsets, seq_len, SP, yext, yrev);
   ASR_CHECK_LAUNCH(h, "asr_ctc_loss(row_lse)");
-  const size_t lds_ab = (size_t)4 * SW * sizeof(double);
   {
-    const int ns = (SW + AB_HALF - 1) / AB_HALF;
-#define ASR_AB(NSV)                                                                                    \
-  hipLaunchKernelGGL(ctc_alpha_beta_kernel<NSV>, dim3(B), dim3(AB_THREADS), lds_ab, st, logits, lse, T, B, \
-                     C, labels_flat, label_offsets, seq_len, SW, alpha, beta, rank, ll, loss, num_infeasible)
-    if (ns <= 1) ASR_AB(1);
-    else if (ns <= 2) ASR_AB(2);
-    else if (ns <= 4) ASR_AB(4);
-    else ASR_AB(8);
+#define ASR_AB(KV, DV)                                                                                   \
+  hipLaunchKernelGGL((ctc_alpha_beta_kernel<KV, DV>), dim3(2 * B), dim3(64), 0, st, yext, yrev, T, B, C, labels_flat, \
+                     label_offsets, seq_len, max_label_len, alpha, beta, rank, ll, loss, num_infeasible)
+    switch (w.K) {
+      case 3: ASR_AB(3, 8); break;
+      case 6: ASR_AB(6, 4); break;
+      case 12: ASR_AB(12, 2); break;
+      case 24: ASR_AB(24, 2); break;
+      default: ASR_AB(32, 2); break;
+    }
 #undef ASR_AB
   }
   ASR_CHECK_LAUNCH(h, "asr_ctc_loss(alpha_beta)");
@@ -439,7 +495,7 @@ extern "C" int asr_ctc_loss(asr_handle* h, const float* logits, int T, int B, in
       ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_loss: C=%d, Lmax=%d need %zu B of LDS", C, max_label_len, lds_g);
     (void)hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g);
     hipLaunchKernelGGL(ctc_grad_kernel, dim3((T + 3) / 4, B), dim3(256), lds_g, st, logits, lse, T, B, C,
-                       labels_flat, label_offsets, seq_len, SW, alpha, beta, rank, ll, grad_scale, grad);
+                       labels_flat, label_offsets, seq_len, SW, SP, yext, alpha, beta, rank, ll, grad_scale, grad);
     ASR_CHECK_LAUNCH(h, "asr_ctc_loss(grad)");
   }
   return ASR_OK;

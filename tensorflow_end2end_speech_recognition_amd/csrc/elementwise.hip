@@ -24,6 +24,8 @@ extern "C" int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes)
   h->err[0] = 0;
   h->scratch = nullptr;
   h->scratch_bytes = scratch_bytes;
+  h->xch_dirty[0] = h->xch_dirty[1] = 0;
+  h->xch_next = 0;
   if (hipMalloc(&h->scratch, h->scratch_bytes) != hipSuccess) {
     delete h;
     return ASR_ERR_HIP;
@@ -45,6 +47,29 @@ extern "C" int asr_device_info(asr_handle* h, int* num_cu, char* name, int name_
   return ASR_OK;
 }
 
+// ---- placement probe ----------------------------------------------------------------------------
+// Records where the workgroups of a grid run ({XCC id, HW_ID} per block).  Used to establish that (i) block b of a
+// 1-D grid lands on XCD b % 8 (what the cluster kernels' layout relies on for speed, never for correctness) and
+// (ii) queue CU masks (hipExtStreamCreateWithCUMask) are NOT honoured on this stack: a masked stream's grid still
+// spreads over all 8 XCDs / 256 CUs (profiles/r02_cumask_probe.json), so side work cannot be fenced off that way.
+namespace {
+__global__ void placement_kernel(unsigned* out, int spin) {
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu;      // HW_REG_XCC_ID[3:0]
+    out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);         // HW_REG_HW_ID
+  }
+  // keep the workgroup resident for a while so that a grid spreads over CUs instead of reusing the first one
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while ((long long)(__builtin_amdgcn_s_memtime() - t0) < spin) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+extern "C" int asr_debug_placement(asr_handle* h, unsigned* out, int nblocks, int spin_cycles, asr_stream s) {
+  if (!h || !out || nblocks < 1) return ASR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(placement_kernel, dim3(nblocks), dim3(64), 0, (hipStream_t)s, out, spin_cycles);
+  ASR_CHECK_LAUNCH(h, "placement_kernel");
+  return ASR_OK;
+}
+
 namespace {
 
 inline int grid_for(size_t n, int per_thread = 1) {
@@ -56,15 +81,15 @@ inline int grid_for(size_t n, int per_thread = 1) {
 
 // [B,T,D] -> [T,B,D]: one row of D per wave-slice, rows of the OUTPUT enumerated in order
 template <typename T>
-__global__ void bt_to_tb_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int T_, int D) {
-  const size_t total = (size_t)B * T_ * D;
+__global__ void bt_to_tb_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int T_, int D, int ld) {
+  const size_t total = (size_t)B * T_ * ld;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    const int dd = i % D;
-    const size_t r = i / D;
+    const int dd = i % ld;
+    const size_t r = i / ld;
     const int b = r % B;
     const size_t t = r / B;
-    out[i] = Elem<T>::from_f32(in[((size_t)b * T_ + t) * D + dd]);
+    out[i] = dd < D ? Elem<T>::from_f32(in[((size_t)b * T_ + t) * D + dd]) : Elem<T>::from_f32(0.f);
   }
 }
 
@@ -440,16 +465,19 @@ extern "C" int asr_splice(asr_handle* h, const float* x, const int32_t* seq_len,
   return ASR_OK;
 }
 
-extern "C" int asr_bt_to_tb(asr_handle* h, int dtype, const float* in, void* out, int B, int T, int D,
-                            asr_stream s) {
+extern "C" int asr_bt_to_tb_ld(asr_handle* h, int dtype, const float* in, void* out, int B, int T, int D, int ld_out,
+                               asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
-  ASR_NEED(asr_dtype_ok(dtype) && in && out && B >= 0 && T >= 0 && D >= 0, "asr_bt_to_tb: bad args");
-  const size_t n = (size_t)B * T * D;
+  ASR_NEED(asr_dtype_ok(dtype) && in && out && B >= 0 && T >= 0 && D >= 0 && ld_out >= D, "asr_bt_to_tb: bad args");
+  const size_t n = (size_t)B * T * ld_out;
   if (!n) return ASR_OK;
-  if (dtype == ASR_F32) hipLaunchKernelGGL(bt_to_tb_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, in, (float*)out, B, T, D);
-  else hipLaunchKernelGGL(bt_to_tb_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, in, (bf16_t*)out, B, T, D);
+  if (dtype == ASR_F32) hipLaunchKernelGGL(bt_to_tb_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, in, (float*)out, B, T, D, ld_out);
+  else hipLaunchKernelGGL(bt_to_tb_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, in, (bf16_t*)out, B, T, D, ld_out);
   ASR_CHECK_LAUNCH(h, "asr_bt_to_tb");
   return ASR_OK;
+}
+extern "C" int asr_bt_to_tb(asr_handle* h, int dtype, const float* in, void* out, int B, int T, int D, asr_stream s) {
+  return asr_bt_to_tb_ld(h, dtype, in, out, B, T, D, D, s);
 }
 extern "C" int asr_cast_from_f32(asr_handle* h, int dtype, const float* in, void* out, size_t n, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;

@@ -120,6 +120,109 @@ __global__ void deinterleave_cols_kernel(const float* __restrict__ in, int ld_in
   }
 }
 
+// Everything a layer's launches consume that depends only on its variables, for BOTH directions in one pass (the
+// per-direction prep_weights + transpose + concatenations it replaces were ~9 launches per layer and step):
+//   wxT    [ndir*4H, ldk]      T   W_x^T with interleaved rows j*4+q, directions stacked, k padded with zeros to ldk
+//                                  (both operands of the hoisted GEMM x W_x reduction-contiguous)
+//   wx_cat [Din, ndir*4H]      T   W_x with interleaved columns, directions side by side (dx = dG wx_cat^T: one GEMM)
+//   bias   [ndir*4H]         f32   interleaved
+//   pf, pb [ndir][H*4H]        T   the two MFMA packings of W_h (see prep_weights_kernel)
+//   peep   [ndir][3][H]      f32   w_i_diag, w_f_diag, w_o_diag (only if the layer has peepholes)
+struct PrepVars { const float* kernel[2]; const float* bias[2]; const float* peep[2][3]; };
+template <typename T>
+__global__ void prep_layer_kernel(PrepVars v, int ndir, int Din, int ldk, int H, T* __restrict__ wxT,
+                                  T* __restrict__ wx_cat, float* __restrict__ bias_cat, T* __restrict__ pf,
+                                  T* __restrict__ pb, float* __restrict__ peep_out) {
+  constexpr int KV = LT<T>::KV;
+  constexpr int E = 16 / sizeof(T);
+  const int G = 4 * H;
+  const size_t n_t = (size_t)G * ldk, n_wx = (size_t)Din * G, n_wh = (size_t)H * G;
+  const size_t n_peep = peep_out ? (size_t)3 * H : 0;
+  const size_t per_dir = n_t + n_wx + n_wh + G + n_peep;
+  for (size_t gidx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; gidx < per_dir * ndir;
+       gidx += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(gidx / per_dir);
+    size_t idx = gidx - (size_t)d * per_dir;
+    const float* kernel = v.kernel[d];
+    const float* wh = kernel + n_wx;
+    if (idx < n_t) {                                       // wxT: row cp = j*4+q, column r (k), coalesced writes
+      const int cp = (int)(idx / ldk), r = (int)(idx % ldk);
+      const float w = r < Din ? kernel[(size_t)r * G + (cp & 3) * H + (cp >> 2)] : 0.f;
+      wxT[((size_t)d * G + cp) * ldk + r] = Elem<T>::from_f32(w);
+      continue;
+    }
+    idx -= n_t;
+    if (idx < n_wx) {
+      const int r = (int)(idx / G), cp = (int)(idx % G);
+      wx_cat[(size_t)r * ndir * G + (size_t)d * G + cp] = Elem<T>::from_f32(kernel[(size_t)r * G + (cp & 3) * H + (cp >> 2)]);
+      continue;
+    }
+    idx -= n_wx;
+    if (idx < n_wh) {
+      const size_t i2 = idx;
+      const int e = i2 % E;
+      const int lane = (i2 / E) % 64;
+      const size_t frag = i2 / (E * 64);
+      const int n = lane & 15, rg = lane >> 4;
+      const int kin = rg * E + e;
+      {
+        const int KS = H / KV;
+        const int ks = frag % KS;
+        const int tile = frag / KS;
+        const int q = tile & 3, ub = tile >> 2;
+        const int k = ks * KV + kin;
+        pf[(size_t)d * n_wh + i2] = Elem<T>::from_f32(wh[(size_t)k * G + q * H + ub * 16 + n]);
+      }
+      {
+        const int KS = G / KV;
+        const int ks = frag % KS;
+        const int ub = frag / KS;
+        const int kp = ks * KV + kin;
+        pb[(size_t)d * n_wh + i2] = Elem<T>::from_f32(wh[(size_t)(ub * 16 + n) * G + (kp & 3) * H + (kp >> 2)]);
+      }
+      continue;
+    }
+    idx -= n_wh;
+    if (idx < (size_t)G) {
+      const int cp = (int)idx;
+      bias_cat[(size_t)d * G + cp] = v.bias[d][(cp & 3) * H + (cp >> 2)];
+      continue;
+    }
+    idx -= G;
+    peep_out[(size_t)d * 3 * H + idx] = v.peep[d][idx / H][idx % H];
+  }
+}
+
+// The inverse trip for the gradients of one layer (both directions, one launch): dW [ndir][Din+H][4H] with interleaved
+// columns (what the weight-gradient GEMMs write) -> kernel gradient in TF's gate-major layout; rows 3..6 of
+// dpeep [ndir][7][H] (bias gradient by gate, accumulated inside the BPTT kernel) -> bias gradient; rows 0..2 -> the
+// three peephole gradients.
+struct GradVars { float* kernel[2]; float* bias[2]; float* peep[2][3]; };
+__global__ void grad_finish_kernel(GradVars v, int ndir, int R, int H, const float* __restrict__ dw_il,
+                                   const float* __restrict__ dpeep, int has_peep) {
+  const int G = 4 * H;
+  const size_t n_w = (size_t)R * G;
+  const size_t per_dir = n_w + G + (has_peep ? (size_t)3 * H : 0);
+  for (size_t gidx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; gidx < per_dir * ndir;
+       gidx += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(gidx / per_dir);
+    size_t idx = gidx - (size_t)d * per_dir;
+    if (idx < n_w) {
+      const int r = (int)(idx / G), c = (int)(idx % G);    // c = q*H + j (output, coalesced)
+      const int q = c / H, j = c % H;
+      v.kernel[d][idx] = dw_il[(size_t)d * n_w + (size_t)r * G + j * 4 + q];
+      continue;
+    }
+    idx -= n_w;
+    if (idx < (size_t)G) {
+      v.bias[d][idx] = dpeep[((size_t)d * 7 + 3) * H + idx];
+      continue;
+    }
+    idx -= G;
+    v.peep[d][idx / H][idx % H] = dpeep[(size_t)d * 7 * H + idx];
+  }
+}
+
 // one k-chunk of MFMA work: acc += A(16 x KV) * B(KV x 16)
 __device__ __forceinline__ f32x4_t mma_chunk(const bf16x8_t& a, const bf16x8_t& b, f32x4_t acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
@@ -719,6 +822,57 @@ extern "C" int asr_gate_deinterleave(asr_handle* h, const float* in, int ld_in, 
   return ASR_OK;
 }
 
+extern "C" int asr_lstm_prep_layer(asr_handle* h, int dtype, int ndir, const float* const* vars, int Din, int ldk,
+                                   int H, void* wxT, void* wx_cat, float* bias_cat, void* packed_fwd,
+                                   void* packed_bwd, float* peep_out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!asr_dtype_ok(dtype) || (ndir != 1 && ndir != 2) || !vars || !wxT || !wx_cat || !bias_cat || !packed_fwd ||
+      !packed_bwd || Din <= 0 || ldk < Din || H <= 0 || H % 64)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_prep_layer: bad args (H=%d must be a multiple of 64, ldk=%d >= Din=%d)", H, ldk, Din);
+  PrepVars v;
+  memset(&v, 0, sizeof(v));
+  for (int d = 0; d < ndir; ++d) {
+    v.kernel[d] = vars[d * 5 + 0];
+    v.bias[d] = vars[d * 5 + 1];
+    for (int k = 0; k < 3; ++k) v.peep[d][k] = vars[d * 5 + 2 + k];
+    if (!v.kernel[d] || !v.bias[d]) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_prep_layer: kernel / bias of direction %d missing", d);
+    if (peep_out && (!v.peep[d][0] || !v.peep[d][1] || !v.peep[d][2]))
+      ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_prep_layer: peep_out given but a peephole vector of direction %d is missing", d);
+  }
+  const size_t total = (size_t)ndir * ((size_t)4 * H * ldk + (size_t)(Din + H + 1) * 4 * H + (peep_out ? 3 * H : 0));
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL(prep_layer_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, v, ndir, Din, ldk, H,
+                       (float*)wxT, (float*)wx_cat, bias_cat, (float*)packed_fwd, (float*)packed_bwd, peep_out);
+  else
+    hipLaunchKernelGGL(prep_layer_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, v, ndir, Din, ldk, H,
+                       (bf16_t*)wxT, (bf16_t*)wx_cat, bias_cat, (bf16_t*)packed_fwd, (bf16_t*)packed_bwd, peep_out);
+  ASR_CHECK_LAUNCH(h, "asr_lstm_prep_layer");
+  return ASR_OK;
+}
+
+extern "C" int asr_lstm_grad_finish(asr_handle* h, int ndir, float* const* grads, int rows, int H,
+                                    const float* dw_il, const float* dpeep_dbias, int has_peep, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if ((ndir != 1 && ndir != 2) || !grads || !dw_il || !dpeep_dbias || rows <= 0 || H <= 0)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_grad_finish: bad args");
+  GradVars v;
+  memset(&v, 0, sizeof(v));
+  for (int d = 0; d < ndir; ++d) {
+    v.kernel[d] = grads[d * 5 + 0];
+    v.bias[d] = grads[d * 5 + 1];
+    for (int k = 0; k < 3; ++k) v.peep[d][k] = grads[d * 5 + 2 + k];
+    if (!v.kernel[d] || !v.bias[d] || (has_peep && (!v.peep[d][0] || !v.peep[d][1] || !v.peep[d][2])))
+      ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_grad_finish: a gradient pointer of direction %d is missing", d);
+  }
+  const size_t total = (size_t)ndir * ((size_t)(rows + 1) * 4 * H + (has_peep ? 3 * H : 0));
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, v, ndir, rows, H, dw_il,
+                     dpeep_dbias, has_peep);
+  ASR_CHECK_LAUNCH(h, "asr_lstm_grad_finish");
+  return ASR_OK;
+}
+
 extern "C" int asr_lstm_fwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
                             const float* xproj, const void* wh_packed, const float* peep,
                             const int32_t* seq_len, float forget_bias, float cell_clip, void* gates,
@@ -766,7 +920,9 @@ extern "C" int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int n
     if (dpeep) (void)hipMemsetAsync(dpeep, 0, sizeof(float) * ndir * 7 * H, st);
     return ASR_OK;
   }
-  float* part = dpeep ? dpeep_workspace : nullptr;
+  // one 16-utterance tile: the tile partials [tile][ndir][7][H] ARE the result, no reduction launch
+  const bool single_tile = (B == 16);
+  float* part = dpeep ? (single_tile ? dpeep : dpeep_workspace) : nullptr;
   bool launched = false;
   if (dtype == ASR_BF16 && asr_cluster_bwd_try(h, T, B, H, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len,
                                                d_c_final, d_h_final, dgates, part, st)) {
@@ -780,7 +936,7 @@ extern "C" int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int n
                                                  d_c_final, d_h_final, dgates, part, st)));
   }
   ASR_CHECK_LAUNCH(h, "asr_lstm_bwd");
-  if (dpeep) {
+  if (dpeep && !single_tile) {
     const int n = ndir * 7 * H;
     hipLaunchKernelGGL(reduce_tiles_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, B / 16, n, dpeep);
     ASR_CHECK_LAUNCH(h, "asr_lstm_bwd(reduce)");

@@ -58,6 +58,15 @@ __device__ __forceinline__ T* uoff(T* ubase, unsigned elem) {
   return ubase + elem;   // plain pointer arithmetic: an integer round trip would demote it to a flat pointer
 }
 
+// The exchange area is double-buffered ACROSS launches: launch n runs on area n % 2 and, as its first act, zeroes the
+// part of the other area the previous launch dirtied (all workgroups of the grid help: < 3 stores per thread), so the
+// next launch finds clean tags without a memset launch in front of every recurrence kernel (10 per training step,
+// each ~6 us on the critical path).  The host side tracks the dirty extent of both areas (asr_handle::xch_dirty).
+__device__ __forceinline__ void zero_next_area(u64* __restrict__ znext, unsigned zwords) {
+  const unsigned nthreads = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < zwords; i += nthreads) znext[i] = 0;
+}
+
 // ---------------------------------------------------------------- forward, 8 waves
 // Same cluster / exchange as above with TWO waves per SIMD: the 4-wave form spends ~2.2k of its
 // 5.2k cycles/step in the gate math of 4 (row, unit) pairs per lane with nothing to hide the
@@ -153,7 +162,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
     const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
     float cell_clip, cbf16x4_t* __restrict__ gates, bf16_t* __restrict__ hout, float* __restrict__ cs,
     float* __restrict__ c_final, float* __restrict__ h_final, u64* __restrict__ xch,
-    unsigned* __restrict__ err, int kflags) {
+    unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+  zero_next_area(znext, zwords);
   constexpr int G = H / HS;
   constexpr int KS = H / 32;
   constexpr int LDH = H + 8;
@@ -447,7 +457,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
     const float* __restrict__ cs, const bf16_t* __restrict__ whpb, const float* __restrict__ peep,
     const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
     const float* __restrict__ d_h_final, cbf16x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
-    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags) {
+    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+  zero_next_area(znext, zwords);
   constexpr int G = H / HS;
   constexpr int KC = 4 * HS / 32;            // k-chunks of this CU's slice (8)
   constexpr int KSF = 4 * H / 32;            // k-chunks of the full packing
@@ -801,6 +812,28 @@ static bool cluster_enabled() {
 }  // namespace
 
 static constexpr size_t XCH_BYTES = ASR_XCH_BYTES;
+static constexpr size_t XCH_HALF = ((XCH_BYTES - 256) / 2) & ~(size_t)255;   // one of the two exchange areas
+
+// The area this launch runs on (clean by construction; the memset is the fallback for a handle whose bookkeeping was
+// reset) and the stretch of the other one it has to zero for its successor (zero_next_area).
+struct XchAreas { u64* area; u64* znext; unsigned zwords; };
+static XchAreas xch_take(asr_handle* h, char* base, size_t need, hipStream_t st) {
+  const int a = h->xch_next & 1, o = a ^ 1;
+  char* area = base + 256 + (size_t)a * XCH_HALF;
+  char* other = base + 256 + (size_t)o * XCH_HALF;
+  if (h->xch_dirty[a]) {
+    (void)hipMemsetAsync(area, 0, h->xch_dirty[a], st);
+    h->xch_dirty[a] = 0;
+  }
+  XchAreas x;
+  x.area = (u64*)area;
+  x.znext = (u64*)other;
+  x.zwords = (unsigned)(h->xch_dirty[o] / sizeof(u64));
+  h->xch_dirty[o] = 0;
+  h->xch_dirty[a] = (need + 7) & ~(size_t)7;
+  h->xch_next = o;
+  return x;
+}
 
 template <int H>
 static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const float* xproj, const void* whp,
@@ -809,11 +842,11 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   constexpr int G = H / HS;
   const int ncl = (B / 16) * ndir;
   const size_t need = (size_t)ncl * (XHDR + 2 * G * 16 * (HS / 2)) * sizeof(u64);
-  if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need + 256 > XCH_BYTES ||
+  if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
       (int)cluster_grid(G, ncl) > h->num_cu)   // every member must be resident at once: 1 workgroup per CU
     return false;
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
-  (void)hipMemsetAsync(base + 256, 0, need, st);           // tags must not survive from a previous launch
+  const XchAreas xa = xch_take(h, base, need, st);
   // EARLY (own-slice k-chunks multiplied under the L2 hop): measured at H = 256 (round 2, cfg B): 970 -> 938 us per
   // launch; default there.  ASR_LSTM_DFLAGS bit 5 (32) inverts the default for A/B measurements.
   const bool early = (H == 256) != ((dbg_flags() & 32) != 0);
@@ -821,7 +854,7 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
                        : (early ? lstm_fwd_cluster8_kernel<H, false, true> : lstm_fwd_cluster8_kernel<H, false, false>);
   hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8), (size_t)2 * 16 * (H + 8) * 2, st, T, B, ndir,
                      (const f32x4_t*)xproj, (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates,
-                     (bf16_t*)hout, cs, cf, hf, (u64*)(base + 256), (unsigned*)base, kernel_flags());
+                     (bf16_t*)hout, cs, cf, hf, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
   return true;
 }
 
@@ -843,17 +876,17 @@ static bool cluster_bwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   constexpr int G = H / HS;
   const int ncl = (B / 16) * ndir;
   const size_t need = (size_t)ncl * (XHDR + (size_t)2 * G * G * 4 * 64 * 2) * sizeof(u64);
-  if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need + 256 > XCH_BYTES ||
+  if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
       (int)cluster_grid(G, ncl) > h->num_cu)   // every member must be resident at once: 1 workgroup per CU
     return false;
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
-  (void)hipMemsetAsync(base + 256, 0, need, st);           // tags must not survive from a previous launch
+  const XchAreas xa = xch_take(h, base, need, st);
   // two dG images; the H = 512 form adds the own-tile hand-over buffer behind them
   const size_t lds = (size_t)2 * 16 * (4 * HS + 8) * 2 + (G == 8 ? 2 * 4 * 64 * 8 : 0);
   auto k = g_cdbg_host ? lstm_bwd_cluster8_kernel<H, true> : lstm_bwd_cluster8_kernel<H, false>;
   hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8), lds, st, T, B, ndir, dhout,
                      (const cbf16x4_t*)gates, cs, (const bf16_t*)whpb, peep, seq_len, dcf, dhf,
-                     (cbf16x4_t*)dgates, dpeep_part, (u64*)(base + 256), (unsigned*)base, kernel_flags());
+                     (cbf16x4_t*)dgates, dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
   return true;
 }
 

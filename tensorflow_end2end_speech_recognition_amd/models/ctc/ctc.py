@@ -140,12 +140,16 @@ class CTC(ModelBase):
         if is_training and keep_prob is not None and float(keep_prob) < 1.0:
             self._dropout_calls += 1
             rng_state = (self.seed, self._dropout_calls << 40)
+        # operand-dtype shadow of the variables the heads multiply with: refreshed on the side stream, ahead of the
+        # encoder's weight images (whose per-layer events the main stream waits on, so it is complete by then)
+        with ops.side_lane(inputs.device):
+            sh = self.store.shadow(self.dtype)
+        self.encoder.want_f32_outputs = False            # the heads consume the operand copy
         self.encoder(inputs, inputs_seq_len, float(keep_prob) if keep_prob is not None else 1.0,
                      is_training, rng_state=rng_state)
-        enc = self.encoder._out_tm                       # [T,Bp,E] fp32
-        T, Bp, E = enc.shape
-        x_op = self._enc_operand()
-        sh = self.store.shadow(self.dtype)
+        x_op = self._enc_operand()                       # [T,Bp,E]
+        T, Bp, E = x_op.shape
+        enc = x_op
         self._bn = None
         if self.bottleneck_dim:
             # bottleneck FC + ReLU (+ dropout on the hidden-output connection), ctc.py:201-216
@@ -194,16 +198,17 @@ class CTC(ModelBase):
         inputs = torch.as_tensor(inputs, dtype=torch.float32, device=dev)
         inputs_seq_len = torch.as_tensor(inputs_seq_len, dtype=torch.int32, device=dev)
         B = inputs.shape[0]
-        logits = self._build(inputs, inputs_seq_len, keep_prob, is_training)
-        T, Bp, C = logits.shape
         flat, offsets, max_len = self._labels_to_flat(labels, B)
+        Bp = B + (-B) % 16                               # the encoder pads the batch to whole 16-utterance tiles
         if Bp > B:
             offsets = np.concatenate([offsets, np.full(Bp - B, offsets[-1], dtype=np.int32)])
-        # pinned staging + async copy: a pageable H2D would block the host until the whole forward
-        # has drained and leave the GPU idle while the CTC launches are issued
+        # labels go up FIRST (pinned staging + async copy), i.e. before the forward is enqueued: behind it they
+        # would sit on the critical path between the output FC and the CTC kernels
         flat_d = torch.from_numpy(np.ascontiguousarray(flat if len(flat) else np.zeros(1, np.int32))) \
             .pin_memory().to(dev, non_blocking=True)
         off_d = torch.from_numpy(np.ascontiguousarray(offsets)).pin_memory().to(dev, non_blocking=True)
+        logits = self._build(inputs, inputs_seq_len, keep_prob, is_training)
+        T, Bp, C = logits.shape
         ctc_in = logits
         inv_temp = 1.0 / float(softmax_temperature)
         if softmax_temperature != 1:

@@ -52,6 +52,7 @@ class _RecurrentEncoderBase(object):
         self.store = None
         self.scope_prefix = ''
         self.num_layers_sub = None     # multitask encoders: the layer whose output also feeds the sub-task head
+        self.want_f32_outputs = True   # False: __call__ returns the operand-dtype outputs (no fp32 copy is made)
 
     # variables are created at graph-build time in the reference; here when the input size is known
     def build(self, store, input_dim, rng, scope_prefix=''):
@@ -91,9 +92,10 @@ class _RecurrentEncoderBase(object):
             inputs_seq_len = torch.cat([inputs_seq_len, inputs_seq_len.new_zeros(self.pad_b)], 0)
         self.batch = B
         seq_len = inputs_seq_len.to(torch.int32).contiguous()
-        x = ops.bt_to_tb(inputs.contiguous(), self.dtype)       # blstm.py:277-279
-        final = None
-        Tt, Bp = x.shape[0], x.shape[1]
+        Tt, Bp = T, inputs.shape[0]
+        D = inputs.shape[2]
+        # the lean GEMM wants a reduction width that is a multiple of its k tile: pad the first layer's rows
+        ldk0 = (D + 63) // 64 * 64 if self.dtype != ASR_F32 else D
 
         if rng_state is None and drop_masks is None and is_training and keep_prob is not None and keep_prob < 1.0:
             # an encoder used on its own (the models pass their own state): a fresh dropout stream per call
@@ -105,27 +107,31 @@ class _RecurrentEncoderBase(object):
             rs = None
             if rng_state is not None:
                 rs = (rng_state[0], rng_state[1] + li * (1 << 32))
-            return self.layers[li].prepare(x.device, self.dtype, Tt, Bp, keep_prob, is_training, rs, dm)
+            return self.layers[li].prepare(inputs.device, self.dtype, Tt, Bp, keep_prob, is_training, rs, dm,
+                                           ldk=ldk0 if li == 0 else None)
 
-        nxt = prep(0)
+        # weight images + dropout masks of EVERY layer: side stream, in layer order, one event per layer; the
+        # first layer's (~10 us) run beside the input transpose, the others under the first recurrence kernel
+        preps, ready = [], []
+        with ops.side_lane(inputs.device):
+            for li in range(len(self.layers)):
+                preps.append(prep(li))
+                ready.append(ops.stream_event())
+        x = ops.bt_to_tb(inputs.contiguous(), self.dtype, ld=ldk0)       # blstm.py:277-279
+        final = None
         finals = []
         for li, layer in enumerate(self.layers):
-            cur = nxt
-            if li + 1 < len(self.layers):
-                # weight images + dropout mask of the next layer: side stream, under this layer's
-                # recurrence kernel (which only occupies a handful of CUs)
-                with ops.side_lane(x.device):
-                    nxt = prep(li + 1)
-            x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, prep=cur)
-            ops.join_side(x.device)
+            ops.wait_event(ready[li])
+            x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, prep=preps[li])
             finals.append(final)
             if self.num_layers_sub is not None and li + 1 == self.num_layers_sub:
                 # blstm.py:326-328: outputs_sub IS the tensor the next layer consumes (after the dropout wrapper)
                 self._out_sub_op, self._final_sub_ch = x, final
         self.seq_len_padded = seq_len
-        out = ops.cast_to_f32(x) if x.dtype != torch.float32 else x
+        self._out_op = x   # time-major padded-batch outputs in the MFMA operand dtype
+        # the fp32 copy the reference's callers receive; models that only consume the operand copy switch it off
+        out = ops.cast_to_f32(x) if (x.dtype != torch.float32 and self.want_f32_outputs) else x
         self._out_tm = out
-        self._out_op = x   # same values in the MFMA operand dtype
         cf, hf = final
         self._final_ch = (cf, hf)          # [ndir,Bp,H] each (the attention bridge consumes these)
         self._finals = finals

@@ -52,55 +52,45 @@ class LSTMLayer(object):
         self.cell_clip = cell_clip
         self.ctx = None
 
-    def _peep(self):
-        if not self.use_peephole:
-            return None
-        st = self.store
-        return torch.stack([torch.stack([st[b + '/w_i_diag'], st[b + '/w_f_diag'], st[b + '/w_o_diag']])
-                            for b in self.bases]).contiguous()
+    def _vars(self, view):
+        """Per direction (kernel, bias, w_i_diag, w_f_diag, w_o_diag) through `view` (store[...] or store.g)."""
+        rows = []
+        for b in self.bases:
+            row = [view(b + '/kernel'), view(b + '/bias')]
+            row += [view(b + '/w_i_diag'), view(b + '/w_f_diag'), view(b + '/w_o_diag')] if self.use_peephole \
+                else [None, None, None]
+            rows.append(tuple(row))
+        return rows
 
-    def prepare(self, device, dtype, T, B, keep_prob=1.0, is_training=True, rng_state=None, drop_mask=None):
+    def prepare(self, device, dtype, T, B, keep_prob=1.0, is_training=True, rng_state=None, drop_mask=None,
+                ldk=None):
         """Everything of a layer's forward that does not depend on its input: operand-dtype weight
-        images (W_x transposed for the GEMM's fast path, W_h in MFMA fragment order for both
-        passes), the peephole block and the dropout mask.  The encoder issues this for layer l+1
-        on the side stream while layer l's recurrence runs."""
-        st = self.store
-        H, ndir, din = self.H, self.ndir, self.din
-        wdt = torch.bfloat16 if dtype == ASR_BF16 else torch.float32
-        whf = torch.empty((ndir, H * 4 * H), dtype=wdt, device=device)
-        whb = torch.empty((ndir, H * 4 * H), dtype=wdt, device=device)
-        wxT = torch.empty((ndir * 4 * H, din), dtype=wdt, device=device)      # both directions stacked
-        bias = torch.empty((ndir * 4 * H,), dtype=torch.float32, device=device)
-        wx_il = []
-        for d, base in enumerate(self.bases):
-            w = ops.lstm_prep_weights(st[base + '/kernel'], st[base + '/bias'], din, H, dtype,
-                                      out=dict(wx_il=torch.empty((din, 4 * H), dtype=wdt, device=device),
-                                               bias_il=bias[d * 4 * H:(d + 1) * 4 * H],
-                                               pf=whf[d], pb=whb[d]))
-            wx_il.append(w['wx_il'])
-            # W_x is k-major ([Din, 4H]); the GEMM's fast path wants it reduction-contiguous
-            ops.transpose2d(w['wx_il'], out=wxT[d * 4 * H:(d + 1) * 4 * H])
+        images (W_x transposed + zero-padded to the input's row width `ldk` for the GEMM's fast path, W_x
+        with both directions side by side for dx, W_h in MFMA fragment order for both passes, the
+        peephole block: ONE launch) and the dropout mask.  The encoder issues this for every layer on
+        the side stream at the start of the step, under the first recurrence kernels."""
+        w = ops.lstm_prep_layer(self._vars(self.store.__getitem__), self.din, self.H, dtype, ldk=ldk)
         mask = None
         if is_training and (drop_mask is not None or keep_prob < 1.0):
             if drop_mask is None:
                 seed, offset = rng_state
-                mask = ops.dropout_mask((T, B, ndir * H), keep_prob, seed, offset, device)
+                mask = ops.dropout_mask((T, B, self.ndir * self.H), keep_prob, seed, offset, device)
             else:
                 mask = drop_mask
-        # [Din, ndir*4H]: dx = dG [T*B, ndir*4H] . wx_cat^T is then ONE GEMM over both directions
-        wx_cat = torch.cat(wx_il, dim=1) if ndir > 1 else wx_il[0]
-        return dict(whf=whf, whb=whb, wxT=wxT, bias=bias, wx_cat=wx_cat, peep=self._peep(), mask=mask)
+        w['mask'] = mask
+        return w
 
     def forward(self, x, seq_len, dtype, keep_prob=1.0, is_training=True, rng_state=None,
                 drop_mask=None, save=True, prep=None):
-        """x [T,B,din] in `dtype`; returns (out [T,B,ndir*H] in dtype, (c_final, h_final))."""
-        T, B, din = x.shape
+        """x [T,B,ldk] in `dtype` (ldk >= din: columns din.. are zero padding); returns
+        (out [T,B,ndir*H] in dtype, (c_final, h_final))."""
+        T, B, ldk = x.shape
         H, ndir = self.H, self.ndir
         if prep is None:
-            prep = self.prepare(x.device, dtype, T, B, keep_prob, is_training, rng_state, drop_mask)
+            prep = self.prepare(x.device, dtype, T, B, keep_prob, is_training, rng_state, drop_mask, ldk=ldk)
         xproj = torch.empty((T, B, ndir * 4 * H), dtype=torch.float32, device=x.device)
         # x W_x + b for both directions in ONE GEMM (N = ndir*4H), written in the interleaved layout
-        ops.gemm(x.view(T * B, din), prep['wxT'], transB=True, bias=prep['bias'],
+        ops.gemm(x.view(T * B, ldk), prep['wxT'], transB=True, bias=prep['bias'],
                  out=xproj.view(T * B, ndir * 4 * H))
         gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, prep['whf'], prep['peep'], seq_len, H, ndir, dtype,
                                                self.forget_bias, self.cell_clip or 0.0)
@@ -118,25 +108,25 @@ class LSTMLayer(object):
         c = self.ctx
         st = self.store
         dtype = c['dtype']
-        sh = st.shadow(dtype)
         x, hout = c['x'], c['hout']
-        T, B, din = x.shape
-        H, ndir = self.H, self.ndir
+        T, B, ldk = x.shape
+        din, H, ndir = self.din, self.H, self.ndir
         if c['mask'] is not None:
             dout = ops.apply_mask(dout, c['mask'])
         dgates, dpeep = ops.lstm_bwd(dout, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H,
                                      ndir, dtype, d_c_final, d_h_final, want_dpeep=True)
-        x2d = x.view(T * B, din)
+        x2d = x.view(T * B, ldk)[:, :din]
         h2d = hout.view(T * B, ndir * H)
         dg2d = dgates.view(T * B, ndir * 4 * H)
         dx = torch.empty((T, B, din), dtype=torch.float32, device=x.device) if need_dx else None
         if need_dx:   # the only result the layer below waits for: main stream, first
             ops.gemm(dg2d, c['wx_cat'], transB=True, out=dx.view(T * B, din))
-        # weight gradients: side stream, concurrent with the BPTT kernel of the layer below
-        # (joined in the model's backward before clipping)
+        # weight gradients: side streams (one per direction), concurrent with the BPTT kernel of the layer
+        # below (joined in the model's backward before clipping)
         dw_il = torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols
-        with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il)):
-            for d, base in enumerate(self.bases):
+        done = []
+        for d in range(ndir):
+            with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il), lane=1 + d):
                 dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
                 ops.gemm(x2d, dg, transA=True, out=dw_il[d, :din])
                 if T > 1:
@@ -146,11 +136,13 @@ class LSTMLayer(object):
                         ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=dw_il[d, din:])
                 else:
                     dw_il[d, din:].zero_()
-                ops.gate_deinterleave(dw_il[d], st.g(base + '/kernel'), H)
-                st.g(base + '/bias').copy_(dpeep[d, 3:7].reshape(-1))   # bias grad accumulated inside BPTT
-                if self.use_peephole:
-                    st.g(base + '/w_i_diag').copy_(dpeep[d, 0])
-                    st.g(base + '/w_f_diag').copy_(dpeep[d, 1])
-                    st.g(base + '/w_o_diag').copy_(dpeep[d, 2])
+                if d > 0:
+                    done.append(ops.stream_event())
+        with ops.side_lane(x.device, lane=1):
+            for ev in done:
+                ops.wait_event(ev)
+            # interleaved columns -> TF's gate-major kernel gradient; bias / peephole gradients (accumulated
+            # inside the BPTT kernel) to their variables: one launch for the layer
+            ops.lstm_grad_finish(self._vars(st.g), dw_il, dpeep, H)
         self.ctx = None
         return dx

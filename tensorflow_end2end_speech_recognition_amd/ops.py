@@ -5,6 +5,7 @@ pointers + shapes to libasr_hip.so.  No arithmetic happens in torch here and
 there is no CPU fallback: non-CUDA tensors raise.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -33,29 +34,41 @@ def _h(t):
     return _lib.handle(t.device.index or 0, _lane)
 
 
+def debug_placement(nblocks, stream=None, spin_cycles=200000, device=0):
+    """[nblocks, 2] int32 (XCC id, HW_ID) of a probe grid launched on `stream` (default: current)."""
+    h = _lib.handle(device, 0)
+    out = torch.zeros((nblocks, 2), dtype=torch.int32, device='cuda:%d' % device)
+    sp = C.c_void_p(stream.cuda_stream) if stream is not None else _s()
+    h.check(h.lib.asr_debug_placement(h.h, _p(out), nblocks, spin_cycles, sp), 'asr_debug_placement')
+    return out
+
+
 class side_lane(object):
-    """Issue the enclosed launches on a second HIP stream (with its own handle, i.e. its own
+    """Issue the enclosed launches on a side HIP stream (with its own handle, i.e. its own
     split-K scratch) ordered after everything already on the main stream.  Used for work
-    nothing downstream waits on until the optimizer (weight-gradient GEMMs), so it overlaps
-    with the next layer's BPTT kernel, which only occupies a handful of CUs.
+    nothing downstream waits on until later (weight images of the layers ahead, weight-gradient
+    GEMMs), so it overlaps with the recurrence kernels, which only occupy a handful of CUs.
+    `lane` 1, 2, ...: independent side streams (the two directions of a layer's weight gradients
+    run side by side on lanes 1 and 2).
     `keep`: tensors the side work reads/writes -- held until join_side() so the caching
     allocator cannot hand their memory to later main-stream allocations."""
 
-    def __init__(self, device, keep=()):
+    def __init__(self, device, keep=(), lane=1):
         self.dev = device.index or 0
         self.keep = list(keep)
+        self.lane = int(lane)
 
     def __enter__(self):
         global _lane
-        st = _side.get(self.dev)
+        st = _side.get((self.dev, self.lane))
         if st is None:
-            st = _side[self.dev] = dict(stream=torch.cuda.Stream(device=self.dev), keep=[])
+            st = _side[(self.dev, self.lane)] = dict(stream=torch.cuda.Stream(device=self.dev), keep=[])
         st['keep'].extend(self.keep)
         st['stream'].wait_stream(torch.cuda.current_stream(self.dev))
         self._ctx = torch.cuda.stream(st['stream'])
         self._ctx.__enter__()
         self._prev = _lane
-        _lane = 1
+        _lane = self.lane
         return self
 
     def __exit__(self, *exc):
@@ -67,11 +80,25 @@ class side_lane(object):
 
 def join_side(device):
     """Main stream waits for all side-lane work; releases the tensors held for it."""
-    st = _side.get(device.index or 0)
-    if st is None:
-        return
-    torch.cuda.current_stream(device.index or 0).wait_stream(st['stream'])
-    st['keep'] = []
+    dev = device.index or 0
+    for (d, lane), st in _side.items():
+        if d != dev:
+            continue
+        torch.cuda.current_stream(dev).wait_stream(st['stream'])
+        st['keep'] = []
+
+
+def stream_event():
+    """Event recorded on the CURRENT stream (inside a side_lane block: on that lane).  wait_event(ev) makes the
+    then-current stream wait for exactly this point instead of for everything on the other stream."""
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
+
+
+def wait_event(ev):
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
 
 
 def _s():
@@ -92,12 +119,15 @@ def _chk(t, dtype, name):
 
 
 # ---------------------------------------------------------------- layout / casts
-def bt_to_tb(x_btd, dtype=ASR_F32):
+def bt_to_tb(x_btd, dtype=ASR_F32, ld=None):
+    """[B,T,D] fp32 -> [T,B,ld] in `dtype`; columns D..ld-1 (ld defaults to D) are zero -- the reduction width the
+    lean GEMM wants (a multiple of 64) when D is not one."""
     h = _h(x_btd)
     _chk(x_btd, torch.float32, 'inputs')
     B, T, D = x_btd.shape
-    out = torch.empty((T, B, D), dtype=TORCH_DTYPE[dtype], device=x_btd.device)
-    h.check(h.lib.asr_bt_to_tb(h.h, dtype, _p(x_btd), _p(out), B, T, D, _s()), 'asr_bt_to_tb')
+    ld = D if ld is None else int(ld)
+    out = torch.empty((T, B, ld), dtype=TORCH_DTYPE[dtype], device=x_btd.device)
+    h.check(h.lib.asr_bt_to_tb_ld(h.h, dtype, _p(x_btd), _p(out), B, T, D, ld, _s()), 'asr_bt_to_tb')
     return out
 
 
@@ -347,6 +377,51 @@ def gate_deinterleave(src, dst, H):
     return dst
 
 
+def _ptr_table(rows):
+    """ndir x 5 device pointers (kernel, bias, w_i_diag, w_f_diag, w_o_diag per direction) as a C array."""
+    flat = []
+    for r in rows:
+        r = list(r) + [None] * (5 - len(r))
+        flat.extend(t.data_ptr() if t is not None else None for t in r)
+    return (C.c_void_p * len(flat))(*flat)
+
+
+def lstm_prep_layer(variables, din, H, dtype, ldk=None):
+    """variables: per direction (kernel [Din+H,4H], bias [4H], w_i_diag, w_f_diag, w_o_diag [H] or None) fp32 views.
+    One launch -> dict(wxT [ndir*4H, ldk], wx_cat [Din, ndir*4H], bias [ndir*4H] fp32, whf / whb [ndir, H*4H] packed
+    W_h, peep [ndir,3,H] fp32 or None) in the operand dtype (include/asr_hip.h asr_lstm_prep_layer)."""
+    k0 = variables[0][0]
+    h = _h(k0)
+    ndir = len(variables)
+    ldk = din if ldk is None else int(ldk)
+    for v in variables:
+        _chk(v[0], torch.float32, 'kernel')
+        if v[0].shape != (din + H, 4 * H):
+            raise ValueError('kernel must be [Din+H,4H]')
+    has_peep = len(variables[0]) >= 5 and variables[0][2] is not None
+    dev, tdt = k0.device, TORCH_DTYPE[dtype]
+    out = dict(wxT=torch.empty((ndir * 4 * H, ldk), dtype=tdt, device=dev),
+               wx_cat=torch.empty((din, ndir * 4 * H), dtype=tdt, device=dev),
+               bias=torch.empty((ndir * 4 * H,), dtype=torch.float32, device=dev),
+               whf=torch.empty((ndir, H * 4 * H), dtype=tdt, device=dev),
+               whb=torch.empty((ndir, H * 4 * H), dtype=tdt, device=dev),
+               peep=torch.empty((ndir, 3, H), dtype=torch.float32, device=dev) if has_peep else None)
+    h.check(h.lib.asr_lstm_prep_layer(h.h, dtype, ndir, _ptr_table(variables), din, ldk, H, _p(out['wxT']),
+                                      _p(out['wx_cat']), _p(out['bias']), _p(out['whf']), _p(out['whb']),
+                                      _p(out['peep']), _s()), 'asr_lstm_prep_layer')
+    return out
+
+
+def lstm_grad_finish(grads, dw_il, dpeep, H):
+    """dw_il [ndir, Din+H, 4H] fp32 (interleaved columns) + dpeep [ndir,7,H] -> the gradient views `grads`
+    (per direction: kernel, bias, w_i_diag, w_f_diag, w_o_diag or None), TF layouts, one launch."""
+    h = _h(dw_il)
+    ndir, rows, _ = dw_il.shape
+    has_peep = len(grads[0]) >= 5 and grads[0][2] is not None
+    h.check(h.lib.asr_lstm_grad_finish(h.h, ndir, _ptr_table(grads), rows, H, _p(dw_il), _p(dpeep),
+                                       1 if has_peep else 0, _s()), 'asr_lstm_grad_finish')
+
+
 def lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, cell_clip=0.0,
              want_final=True):
     """xproj [T,B,ndir*4H] fp32 (interleaved gate layout [T,B,ndir,H,4]).
@@ -466,7 +541,7 @@ def ctc_loss(logits, labels_flat, label_offsets, seq_len, max_label_len, grad_sc
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     loss = torch.empty((B,), dtype=torch.float32, device=dev)
     grad = torch.empty_like(logits) if want_grad else None
-    ninf = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ninf = torch.empty((1,), dtype=torch.int32, device=dev)     # zeroed by the call
     h.check(h.lib.asr_ctc_loss(h.h, _p(logits), T, B, Cc, _p(labels_flat), _p(label_offsets),
                                _p(seq_len), int(max_label_len), float(grad_scale), _p(loss), _p(grad),
                                _p(ninf), _p(ws), nbytes, _s()), 'asr_ctc_loss')

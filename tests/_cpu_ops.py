@@ -20,7 +20,7 @@ F64 = torch.float64
 
 
 class _NullLane(object):
-    def __init__(self, device, keep=()):
+    def __init__(self, device, keep=(), lane=1):
         pass
 
     def __enter__(self):
@@ -30,8 +30,11 @@ class _NullLane(object):
         return False
 
 
-def _bt_to_tb(x_btd, dtype=0):
-    return x_btd.transpose(0, 1).contiguous()
+def _bt_to_tb(x_btd, dtype=0, ld=None):
+    y = x_btd.transpose(0, 1).contiguous()
+    if ld is not None and ld > y.shape[2]:
+        y = torch.cat([y, y.new_zeros(y.shape[0], y.shape[1], ld - y.shape[2])], 2)
+    return y
 
 
 def _transpose2d(x, out=None):
@@ -118,6 +121,30 @@ def _lstm_prep_weights(kernel, bias, din, H, dtype, out=None):
     out['pf'].copy_(kernel[din:].reshape(-1))
     out['pb'].copy_(kernel[din:].reshape(-1))
     return out
+
+
+def _lstm_prep_layer(variables, din, H, dtype, ldk=None):
+    ldk = din if ldk is None else ldk
+    for v in variables:
+        if v[0].shape != (din + H, 4 * H):
+            raise ValueError('kernel must be [Din+H,4H]')
+    pad = lambda w: torch.cat([w, w.new_zeros(w.shape[0], ldk - din)], 1) if ldk > din else w
+    has_peep = len(variables[0]) >= 5 and variables[0][2] is not None
+    return dict(wxT=torch.cat([pad(v[0][:din].t()) for v in variables], 0).contiguous(),
+                wx_cat=torch.cat([v[0][:din] for v in variables], 1).contiguous(),
+                bias=torch.cat([v[1] for v in variables]).clone(),
+                whf=torch.stack([v[0][din:].reshape(-1) for v in variables]).clone(),
+                whb=torch.stack([v[0][din:].reshape(-1) for v in variables]).clone(),
+                peep=torch.stack([torch.stack([v[2], v[3], v[4]]) for v in variables]) if has_peep else None)
+
+
+def _lstm_grad_finish(grads, dw_il, dpeep, H):
+    for d, g in enumerate(grads):
+        g[0].copy_(dw_il[d])
+        g[1].copy_(dpeep[d, 3:7].reshape(-1))
+        if len(g) >= 5 and g[2] is not None:
+            for k in range(3):
+                g[2 + k].copy_(dpeep[d, k])
 
 
 def _gate_deinterleave(src, dst, H):
@@ -507,7 +534,8 @@ def _maxpool2x2_bwd(dout, arg, H, W):
 
 
 STAND_INS = dict(
-    side_lane=_NullLane, join_side=lambda device: None, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
+    side_lane=_NullLane, join_side=lambda device: None, stream_event=lambda: None, wait_event=lambda ev: None,
+    lstm_prep_layer=_lstm_prep_layer, lstm_grad_finish=_lstm_grad_finish, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
     cast_from_f32=_cast_from_f32, cast_to_f32=_cast_to_f32, apply_mask=_apply_mask, dropout_mask=_dropout_mask,
     colsum=_colsum, gemm=_gemm, relu_bwd=_relu_bwd, lstm_prep_weights=_lstm_prep_weights,
     gate_deinterleave=_gate_deinterleave, lstm_fwd=_lstm_fwd, lstm_bwd=_lstm_bwd, ctc_loss=_ctc_loss,

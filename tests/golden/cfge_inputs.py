@@ -30,7 +30,12 @@ def posteriors(name):
         if rng.rand() < 0.35:                                     # repeated frames: the merge rule matters
             logits[0, t] = logits[0, t - 1]
     e = np.exp(logits - logits.max(-1, keepdims=True))
-    probs = (e / e.sum(-1, keepdims=True)).astype(np.float64)
+    logp32 = np.log(e / e.sum(-1, keepdims=True)).astype(np.float32)
+    # The reference takes np.log(probs) in float64, the device decoder takes fp32 log-posteriors.  At this vocabulary
+    # size neighbouring classes are closer than an fp32 ulp of their log-probability, so both sides must see the SAME
+    # numbers for the ranking to be comparable: the posteriors handed to the reference are exp(fp32 log-posterior) in
+    # float64 (their log reproduces the fp32 value to 1e-16; rows sum to 1 within 1e-7, which the reference never checks)
+    probs = np.exp(logp32.astype(np.float64))
     return probs, np.array([T], dtype=np.int32), W
 
 

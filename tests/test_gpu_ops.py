@@ -435,6 +435,62 @@ def test_lstm_cluster_bf16_gradient_parity_headline_shapes(cuda, H, B, T, clip):
     assert all(v <= bnd for _, v, bnd in checks), table
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('din,H,ndir,peep,ldk', [(120, 256, 2, True, 128), (512, 256, 2, True, 512),
+                                                 (40, 64, 1, False, 40), (24, 128, 2, False, 64)])
+def test_lstm_prep_layer_and_grad_finish_match_the_per_direction_ops(cuda, dtype, din, H, ndir, peep, ldk):
+    """asr_lstm_prep_layer (all weight images of a layer, one launch) against asr_lstm_prep_weights + asr_transpose2d +
+    concatenation, bit for bit; asr_lstm_grad_finish against asr_gate_deinterleave + copies."""
+    ops = _ops()
+    from tensorflow_end2end_speech_recognition_amd._lib import ASR_BF16, ASR_F32
+    dt = ASR_BF16 if dtype == 'bf16' else ASR_F32
+    g = torch.Generator(device='cpu').manual_seed(din + H)
+    mk = lambda *s: torch.randn(*s, generator=g).to(cuda)
+    variables = []
+    for d in range(ndir):
+        row = [mk(din + H, 4 * H), mk(4 * H)] + ([mk(H), mk(H), mk(H)] if peep else [None, None, None])
+        variables.append(tuple(row))
+    w = ops.lstm_prep_layer(variables, din, H, dt, ldk=ldk)
+    for d, v in enumerate(variables):
+        old = ops.lstm_prep_weights(v[0], v[1], din, H, dt)
+        G = 4 * H
+        assert torch.equal(w['wx_cat'][:, d * G:(d + 1) * G], old['wx_il'])
+        assert torch.equal(w['wxT'][d * G:(d + 1) * G, :din], ops.transpose2d(old['wx_il']))
+        assert not w['wxT'][d * G:(d + 1) * G, din:].float().abs().sum().item()
+        assert torch.equal(w['bias'][d * G:(d + 1) * G], old['bias_il'])
+        assert torch.equal(w['whf'][d], old['pf']) and torch.equal(w['whb'][d], old['pb'])
+        if peep:
+            assert torch.equal(w['peep'][d], torch.stack(v[2:5]))
+    assert (w['peep'] is None) == (not peep)
+    # the way back
+    dw_il = mk(ndir, din + H, 4 * H)
+    dpeep = mk(ndir, 7, H)
+    grads = []
+    for d in range(ndir):
+        row = [torch.zeros(din + H, 4 * H, device=cuda), torch.zeros(4 * H, device=cuda)]
+        row += [torch.zeros(H, device=cuda) for _ in range(3)] if peep else [None, None, None]
+        grads.append(tuple(row))
+    ops.lstm_grad_finish(grads, dw_il, dpeep, H)
+    for d in range(ndir):
+        ref = ops.gate_deinterleave(dw_il[d], torch.zeros(din + H, 4 * H, device=cuda), H)
+        assert torch.equal(grads[d][0], ref)
+        assert torch.equal(grads[d][1], dpeep[d, 3:7].reshape(-1))
+        if peep:
+            for k in range(3):
+                assert torch.equal(grads[d][2 + k], dpeep[d, k])
+
+
+def test_bt_to_tb_padded_rows(cuda):
+    ops = _ops()
+    from tensorflow_end2end_speech_recognition_amd._lib import ASR_BF16, ASR_F32
+    x = torch.randn(5, 7, 120, device=cuda)
+    for dt, tdt in ((ASR_F32, torch.float32), (ASR_BF16, torch.bfloat16)):
+        y = ops.bt_to_tb(x, dt, ld=128)
+        assert y.shape == (7, 5, 128) and y.dtype == tdt
+        assert torch.equal(y[:, :, :120], x.transpose(0, 1).to(tdt)) and not y[:, :, 120:].float().abs().sum().item()
+        assert torch.equal(ops.bt_to_tb(x, dt), x.transpose(0, 1).to(tdt).contiguous())
+
+
 # --------------------------------------------------------------------------- CTC
 def _ctc_case(rng, T, B, C, lmax, scale=2.0):
     logits = (rng.randn(T, B, C) * scale).astype(np.float32)
@@ -459,12 +515,17 @@ def _flat(labs):
 # membership map, never a per-class accumulator, in LDS
 @pytest.mark.parametrize('T,B,C,lmax', [(30, 4, 6, 8), (120, 16, 40, 30), (300, 16, 62, 75), (50, 3, 29, 20),
                                          (64, 2, 700, 25), (400, 2, 29, 150), (200, 3, 3386, 60), (500, 2, 3386, 166),
-                                         (40, 3, 26643, 12)])
+                                         (40, 3, 26643, 12),
+                                         # extended label sequences of 2L+1 = 401 / 1101 / 1901 states: 12, 24 and 32
+                                         # states per lane of the single-wave recursion (3 and 6 are covered above)
+                                         (700, 2, 29, 200), (1300, 2, 29, 550), (2000, 1, 12, 950)])
 def test_ctc_loss_and_grad(cuda, T, B, C, lmax):
     ops = _ops()
     rng = np.random.RandomState(T + C)
     logits, sl, labs = _ctc_case(rng, T, B, C, lmax)
     labs[0] = labs[0][:2] + labs[0][:2] if len(labs[0]) >= 2 else labs[0]   # force repeats
+    if lmax >= 200:   # the long-label cases: one utterance really has lmax labels (sl[0] == T leaves room for repeats)
+        labs[0] = [int(v) for v in rng.randint(0, C - 1, size=lmax)]
     if len(labs[-1]) >= 3:
         labs[-1][2] = labs[-1][0]                                            # a non-adjacent repeat of a class
     flat, off = _flat(labs)
@@ -475,6 +536,35 @@ def test_ctc_loss_and_grad(cuda, T, B, C, lmax):
     assert np.abs(loss.cpu().numpy() - ref_loss).max() / max(ref_loss.max(), 1) < 1e-5
     assert np.abs(grad.cpu().numpy() - ref_grad).max() < 2e-5
     assert int(ninf.item()) == 0
+
+
+def test_ctc_peaked_posteriors_and_long_utterances(cuda):
+    """The scaled linear-domain recursion over inputs where log-domain and linear-domain arithmetic differ most:
+    near one-hot posteriors (logit gaps of 60: most emission probabilities sit at the 2^-126 floor), a long utterance
+    whose likelihood is ~e^-2500 (far below fp64's smallest power of two without the per-8-frames renormalisation)
+    and an utterance whose correct path runs through improbable frames."""
+    ops = _ops()
+    rng = np.random.RandomState(5)
+    T, B, C = 1500, 3, 30
+    logits = (rng.randn(T, B, C) * 1.5).astype(np.float32)
+    labs = [[int(v) for v in rng.randint(0, C - 1, size=n)] for n in (180, 40, 75)]
+    sl = np.array([T, 600, 900], dtype=np.int32)
+    # utterance 1: peaked posteriors along a valid alignment (7 frames per label, blanks in between)
+    for t in range(600):
+        k = labs[1][min(t // 15, len(labs[1]) - 1)] if (t // 7) % 2 == 0 else C - 1
+        logits[t, 1, :] = -30.0
+        logits[t, 1, k] = 30.0
+    logits[300:330, 1, :] = rng.randn(30, C).astype(np.float32)      # a stretch the model is unsure about
+    # utterance 2: every label is improbable at every frame (gap 25 to the blank)
+    logits[:, 2, C - 1] += 25.0
+    flat, off = _flat(labs)
+    ref_loss, ref_grad = octc.ctc_loss_batch(logits.astype(np.float64), labs, sl)
+    assert ref_loss[0] > 1000 and ref_loss[2] > 1000
+    loss, grad, ninf = ops.ctc_loss(torch.tensor(logits, device=cuda), torch.tensor(flat, device=cuda),
+                                    torch.tensor(off, device=cuda), torch.tensor(sl, device=cuda), 180, 1.0)
+    assert int(ninf.item()) == 0
+    assert np.abs(loss.cpu().numpy() - ref_loss).max() / ref_loss.max() < 1e-5
+    assert np.abs(grad.cpu().numpy() - ref_grad).max() < 2e-5
 
 
 def test_ctc_matches_tensorflow_known_answer_vectors(cuda):
@@ -565,6 +655,30 @@ def test_beam_search_matches_reference_golden(cuda):
             assert abs(score[0].item() - float(g['c%d_beam%d_score' % (i, w)])) < 1e-5 * max(1, abs(score[0].item()))
             checked += 1
     assert checked >= 40
+
+
+def test_beam_search_cfgE_scale_matches_reference_golden(cuda):
+    """BASELINE cfg E scale (C = 3387 classes, beam 20 and 100): labels bit-exact against the outputs of the
+    REFERENCE'S OWN BeamSearchDecoder (tests/golden/decoders_cfge_v1.json, generated by make_golden_cfge.py in the
+    build container; the seeded inputs are regenerated here and checked by digest).  Includes posteriors on a coarse
+    grid (many exact ties at the class-pruning threshold) and nearly flat posteriors (no class is prunable)."""
+    import json
+    import sys
+    sys.path.insert(0, GOLD)
+    import cfge_inputs
+    ops = _ops()
+    gold = json.load(open(os.path.join(GOLD, 'decoders_cfge_v1.json')))
+    assert len(gold) >= 4
+    for name, g in sorted(gold.items()):
+        probs, sl, W = cfge_inputs.posteriors(name)
+        logits = cfge_inputs.fp32_logits(probs)
+        assert cfge_inputs.digest(logits) == g['logits_sha256'], name
+        assert W == g['beam_width'] and probs.shape[2] == g['C']
+        lab, n, score = ops.ctc_beam_decode(torch.tensor(logits, device=cuda), torch.tensor(sl, device=cuda), W)
+        assert lab[0, :int(n[0])].cpu().tolist() == g['labels'], name
+        assert abs(score[0].item() - g['score']) < 1e-5 * max(1.0, abs(g['score'])), name
+        glab, gn = ops.ctc_greedy_decode(torch.tensor(logits, device=cuda), torch.tensor(sl, device=cuda))
+        assert glab[0, :int(gn[0])].cpu().tolist() == g['greedy'], name
 
 
 def test_decoder_classes_reference_signature(cuda):
