@@ -61,6 +61,11 @@ int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes); /* >= 32 
 size_t asr_scratch_bytes(asr_handle* h);
 int asr_destroy(asr_handle* h);
 const char* asr_last_error_string(asr_handle* h);
+/* Handles used for SIDE-stream work (weight-gradient GEMMs issued beside a recurrence kernel): the lean reduction-major
+ * GEMM and its split-K reduction leave the first n XCDs (0 <= n <= 6) to the recurrence clusters, which sit on XCD
+ * 0 .. (B/16)*ndir-1 and whose per-step hand-off goes through those XCDs' L2 (workgroup b of a 1-D grid runs on XCD
+ * b % 8; workgroups that land on a skipped XCD retire at once).  Results are identical for every n. */
+int asr_set_xcd_skip(asr_handle* h, int n);
 /* number of CUs / device name (for bench reporting) */
 int asr_device_info(asr_handle* h, int* num_cu, char* name, int name_len);
 
@@ -120,6 +125,13 @@ int asr_gemm(asr_handle* h, int dtype, int out_dtype, int transA, int transB,
 int asr_gemm_act(asr_handle* h, int dtype, int out_dtype, int transA, int transB,
                  int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                  void* C, int ldc, const float* bias, int accumulate, int act, asr_stream s);
+/* asr_gemm_act with fp32 output and an elementwise multiplier mul [M, N] (row stride ldmul, fp32) applied last:
+ * C = act(op(A) op(B) + bias [+ C]) * mul.  The gradient of a layer input that went through a DropoutWrapper
+ * (blstm.py:308-311: dx = dG W_x^T, then times the keep mask of the layer below) in one pass; same bits as
+ * asr_gemm_act followed by asr_apply_mask. */
+int asr_gemm_mul(asr_handle* h, int dtype, int transA, int transB, int M, int N, int K,
+                 const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                 const float* bias, int accumulate, int act, const float* mul, int ldmul, asr_stream s);
 
 /* ---- VGG front-end (models/encoders/core/vgg_blstm.py:107-177) --------------- *
  * Images are NHWC: [N = B*T frames, H = channels(40), W = splice*stack, C].

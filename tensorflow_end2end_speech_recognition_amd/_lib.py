@@ -23,6 +23,7 @@ SIGNATURES = {
     'asr_create_ex': (_i, [C.POINTER(_vp), _i, _sz]),
     'asr_scratch_bytes': (_sz, [_vp]),
     'asr_destroy': (_i, [_vp]),
+    'asr_set_xcd_skip': (_i, [_vp, _i]),
     'asr_last_error_string': (C.c_char_p, [_vp]),
     'asr_device_info': (_i, [_vp, C.POINTER(_i), C.c_char_p, _i]),
     'asr_bt_to_tb': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
@@ -35,6 +36,7 @@ SIGNATURES = {
     'asr_colsum': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     'asr_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'asr_gemm_act': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    'asr_gemm_mul': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     'asr_conv3x3_prep_weights': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     'asr_conv3x3_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     'asr_conv3x3_bwd_data': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),

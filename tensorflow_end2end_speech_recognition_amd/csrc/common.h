@@ -19,6 +19,8 @@ struct asr_handle {
   // area the next launch runs on
   size_t xch_dirty[2];
   int xch_next;
+  // side-stream handles: number of leading XCDs the lean weight-gradient GEMM leaves to the recurrence clusters
+  int xcd_skip;
 };
 
 #define ASR_FAIL(h, code, ...)                                  \

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
                                                            int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                            TO* __restrict__ C, int ldc,
                                                            const float* __restrict__ bias, int accumulate,
-                                                           int act) {
+                                                           int act, const float* __restrict__ mul, int ldm) {
   constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
   constexpr int STAGE = (BM + BN) * LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -355,6 +355,11 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
+        if (mul) {                                         // e.g. the dropout mask of the tensor this gradient is of
+          const f32x4_t mv = *reinterpret_cast<const f32x4_t*>(mul + (size_t)m * ldm + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= mv[r];
+        }
         *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
       } else {
         typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
@@ -375,8 +380,10 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
 
 template <typename TO>
 bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
-                      int ldb, void* C, int ldc, const float* bias, int accumulate, hipStream_t st, int act) {
+                      int ldb, void* C, int ldc, const float* bias, int accumulate, hipStream_t st, int act,
+                      const float* mul, int ldm) {
   if (transA || !transB || K % 64 != 0 || N % 128 != 0 || M < 1024) return false;
+  if (mul && (sizeof(TO) != 4 || ldm % 4 != 0 || ((uintptr_t)mul) % 16 != 0)) return false;
   if (lda % 8 != 0 || ldb % 8 != 0 || ((uintptr_t)A) % 16 != 0 || ((uintptr_t)B) % 16 != 0) return false;
   if (ldc % 4 != 0 || ((uintptr_t)C) % (4 * sizeof(TO)) != 0 || (bias && ((uintptr_t)bias) % 16 != 0)) return false;
   const size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * sizeof(bf16_t);
@@ -387,8 +394,21 @@ bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A
   }
   const int total = (N / 128) * ((M + 127) / 128);
   hipLaunchKernelGGL(gemm_nt_bf16_kernel<TO>, dim3(total), dim3(256), lds, st, M, N, K, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, (TO*)C, ldc, bias, accumulate, act);
+                     (const bf16_t*)B, ldb, (TO*)C, ldc, bias, accumulate, act, mul, ldm);
   return true;
+}
+
+// Workgroup b of a 1-D grid runs on XCD b % 8 (asr_debug_placement).  Side-stream kernels leave the first `skip` XCDs
+// -- where the recurrence clusters live -- alone: their workgroups there retire at once and the work is dealt over
+// the others.  Returns the dense work index of this workgroup, -1 for a workgroup that has nothing to do.
+__device__ __forceinline__ int xcd_work_index(int skip) {
+  const int b = blockIdx.x, x = b & 7;
+  if (x < skip) return -1;
+  return (b >> 3) * (8 - skip) + (x - skip);
+}
+static inline unsigned xcd_grid(long work, int skip) {     // workgroups to launch for `work` work items
+  const long per = 8 - skip;
+  return (unsigned)((work + per - 1) / per * 8);
 }
 
 // ---------------------------------------------------------------- lean TN kernel (bf16)
@@ -403,16 +423,21 @@ bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A
 // Requires M % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0, 16-byte aligned bases.
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
                                                            int lda, const bf16_t* __restrict__ Bm, int ldb,
-                                                           int kchunk, float* __restrict__ partial) {
+                                                           int kchunk, float* __restrict__ partial, int tn, int tm,
+                                                           int nslab, int xcd_skip) {
   constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
   constexpr int STAGE = (BM + BN) * LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* S = reinterpret_cast<bf16_t*>(smem);
 
+  // 1-D grid; workgroup b runs on XCD b % 8 and the first xcd_skip XCDs are left to the recurrence clusters
+  const int widx = xcd_work_index(xcd_skip);
+  if (widx < 0 || widx >= tn * tm * nslab) return;
+  const int bx = widx % tn, by = (widx / tn) % tm, bz = widx / (tn * tm);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * kchunk, kend = min(K, kbeg + kchunk);
   const int nkt = (kend - kbeg + BK - 1) / BK;
 
   // two (k-pair, m-vector) items per operand per thread: item q -> mvec = q & 15, kp = q >> 4
@@ -497,7 +522,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int M, int N, int K, 
     __syncthreads();
   }
   // slab [z][M][N]; lane holds C[m = fr][n = fq*4 .. +3] of each 16x16 tile
-  float* slab = partial + (size_t)blockIdx.z * M * N;
+  float* slab = partial + (size_t)bz * M * N;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + fr;
@@ -778,10 +803,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tn_kernel(int Mpix, int H, 
 template <typename TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
                                      TO* __restrict__ C, int ldc, const float* __restrict__ bias,
-                                     int accumulate, int act) {
+                                     int accumulate, int act, int xcd_skip) {
   const size_t total = (size_t)M * N;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
+  const int widx = xcd_work_index(xcd_skip);
+  if (widx < 0) return;
+  const size_t nwork = (size_t)(gridDim.x >> 3) * (8 - xcd_skip) + max(0, (int)(gridDim.x & 7) - xcd_skip);
+  for (size_t i = widx * (size_t)blockDim.x + threadIdx.x; i < total; i += nwork * blockDim.x) {
     const int m = i / N, n = i % N;
     float v = bias ? bias[n] : 0.f;
     for (int z = 0; z < S; ++z) v += partial[(size_t)z * total + i];
@@ -812,15 +839,18 @@ int launch_layout(int transA, int transB, dim3 grid, size_t lds, hipStream_t st,
 template <typename T, typename TO>
 int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, const void* A, int lda,
                 const void* B, int ldb, void* C, int ldc, const float* bias, int accumulate,
-                hipStream_t st, int act) {
+                hipStream_t st, int act, const float* mul = nullptr, int ldm = 0, bool* mul_done = nullptr) {
   constexpr int VEC = GT<T>::VEC, BK = GT<T>::BK;
   if constexpr (sizeof(T) == 2) {
-    if (try_gemm_nt_bf16<TO>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act)) return 0;
+    if (try_gemm_nt_bf16<TO>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act, mul, ldm)) {
+      if (mul_done) *mul_done = true;
+      return 0;
+    }
     // reduction-major operands (X^T dG): lean TN kernel, always through split-K slabs
     if (transA && !transB && K >= 2048 && M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
         ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0) {
       const int tm = (M + 127) / 128, tn = (N + 127) / 128;
-      int S = (1024 + tm * tn - 1) / (tm * tn);            // aim at ~4 workgroups per CU
+      int S = (512 + tm * tn - 1) / (tm * tn);             // aim at ~2 workgroups per CU (what its LDS allows)
       const int maxS = (K + 255) / 256;
       if (S > maxS) S = maxS;
       if (S > 256) S = 256;
@@ -836,13 +866,14 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
           (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
         float* partial = (float*)h->scratch;
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tn, tm, S), dim3(256), lds, st, M, N, K, (const bf16_t*)A, lda,
-                           (const bf16_t*)B, ldb, kchunk, partial);
+        const int skip = h->xcd_skip;
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(xcd_grid((long)tn * tm * S, skip)), dim3(256), lds, st, M, N, K,
+                           (const bf16_t*)A, lda, (const bf16_t*)B, ldb, kchunk, partial, tn, tm, S, skip);
         const size_t total = (size_t)M * N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(blocks), dim3(256), 0, st, partial, S, M, N, (TO*)C, ldc,
-                           bias, accumulate, act);
+        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(xcd_grid(blocks, skip)), dim3(256), 0, st, partial, S, M, N,
+                           (TO*)C, ldc, bias, accumulate, act, skip);
         return 0;
       }
     }
@@ -894,7 +925,7 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(blocks), dim3(256), 0, st, partial, S, M, N, (TO*)C, ldc,
-                     bias, accumulate, act);
+                     bias, accumulate, act, 0);
   return 0;
 }
 
@@ -931,6 +962,45 @@ extern "C" int asr_gemm_act(asr_handle* h, int dtype, int out_dtype, int transA,
   else
     launch_gemm<bf16_t, bf16_t>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act);
   ASR_CHECK_LAUNCH(h, "asr_gemm");
+  return ASR_OK;
+}
+
+namespace {
+__global__ void mul_rows_kernel(float* __restrict__ C, int ldc, const float* __restrict__ mul, int ldm, int M, int N) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / N, n = i % N;
+    C[m * ldc + n] *= mul[m * ldm + n];
+  }
+}
+}  // namespace
+
+// C = (op(A) op(B) + bias [+ C]) [relu] * mul, mul [M, N] fp32 with row stride ldmul: the multiplier is applied in the
+// epilogue of the lean NT kernel (no second pass over C); other shapes run the plain GEMM and one multiply pass.
+extern "C" int asr_gemm_mul(asr_handle* h, int dtype, int transA, int transB, int M, int N, int K, const void* A,
+                            int lda, const void* B, int ldb, float* C, int ldc, const float* bias, int accumulate,
+                            int act, const float* mul, int ldmul, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!mul) return asr_gemm_act(h, dtype, ASR_F32, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, act, s);
+  if (!asr_dtype_ok(dtype) || (act != 0 && act != 1) || M < 0 || N < 0 || K < 0 || !A || !B || !C ||
+      lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N || ldmul < N)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_gemm_mul: bad args M=%d N=%d K=%d lda=%d ldb=%d ldc=%d ldmul=%d", M, N, K, lda,
+             ldb, ldc, ldmul);
+  if (M == 0 || N == 0) return ASR_OK;
+  hipStream_t st = (hipStream_t)s;
+  bool fused = false;
+  if (dtype == ASR_F32)
+    launch_gemm<float, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act, mul, ldmul, &fused);
+  else
+    launch_gemm<bf16_t, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act, mul, ldmul, &fused);
+  ASR_CHECK_LAUNCH(h, "asr_gemm_mul");
+  if (!fused) {
+    const size_t total = (size_t)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mul_rows_kernel, dim3(blocks), dim3(256), 0, st, C, ldc, mul, ldmul, M, N);
+    ASR_CHECK_LAUNCH(h, "asr_gemm_mul(multiply)");
+  }
   return ASR_OK;
 }
 
@@ -1024,7 +1094,7 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, partial, S, M, N, dw, N, nullptr,
-                     accumulate, 0);
+                     accumulate, 0, 0);
   ASR_CHECK_LAUNCH(h, "asr_conv3x3_bwd_weight");
   return ASR_OK;
 }

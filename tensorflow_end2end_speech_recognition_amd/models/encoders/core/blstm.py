@@ -156,13 +156,21 @@ class _RecurrentEncoderBase(object):
         d_outputs_sub (multitask encoders): gradient w.r.t. the sub-task outputs, joined where they branch off.
         Returns the gradient w.r.t. the (time-major) encoder input if need_input_grad."""
         dx = d_outputs
+        masked = False
         for li in reversed(range(len(self.layers))):
             if d_outputs_sub is not None and li == self.num_layers_sub - 1:
                 dx = torch.add(dx, d_outputs_sub)
             dcf = dhf = None
             if d_final is not None and li == len(self.layers) - 1:
                 dcf, dhf = d_final
-            dx = self.layers[li].backward(dx.contiguous(), dcf, dhf, need_dx=(li > 0 or need_input_grad))
+            # the dropout mask of the layer below is folded into this layer's dx GEMM (no separate pass over dx
+            # between two BPTT kernels) -- unless another gradient joins dx before that layer's mask applies
+            below = self.layers[li - 1].ctx['mask'] if li > 0 else None
+            if d_outputs_sub is not None and li - 1 == self.num_layers_sub - 1:
+                below = None
+            dx = self.layers[li].backward(dx.contiguous(), dcf, dhf, need_dx=(li > 0 or need_input_grad),
+                                          dout_masked=masked, dx_mask=below)
+            masked = below is not None
         ops.join_side(d_outputs.device)      # weight-gradient GEMMs issued on the side stream
         return dx
 

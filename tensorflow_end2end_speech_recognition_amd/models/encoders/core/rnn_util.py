@@ -22,6 +22,9 @@ from .... import ops
 from ...._lib import ASR_BF16, ASR_F32
 
 DIRS = ('fw', 'bw')
+# side streams the weight-gradient GEMMs of a layer are spread over: one per direction (one lane for both measures the
+# same step time, 12.39 ms, but leaves a longer tail after the last BPTT kernel)
+DW_LANES = 2
 
 
 def declare_lstm_vars(store, scope, din, H, ndir, use_peephole, parameter_init, rng, cell_scope=None):
@@ -103,15 +106,18 @@ class LSTMLayer(object):
                             seq_len=seq_len, dtype=dtype, mask=mask, wx_cat=prep['wx_cat'])
         return out, (cf, hf)
 
-    def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True):
-        """dout [T,B,ndir*H] fp32 -> dx [T,B,din] fp32 (or None).  Fills store.grad."""
+    def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True, dout_masked=False, dx_mask=None):
+        """dout [T,B,ndir*H] fp32 -> dx [T,B,din] fp32 (or None).  Fills store.grad.
+        dout_masked: the caller has already multiplied dout with this layer's dropout mask.
+        dx_mask: dropout mask [T,B,din] of the layer BELOW: dx comes back already multiplied with it (in the epilogue
+        of the dx GEMM), i.e. ready to be passed to that layer's backward with dout_masked=True."""
         c = self.ctx
         st = self.store
         dtype = c['dtype']
         x, hout = c['x'], c['hout']
         T, B, ldk = x.shape
         din, H, ndir = self.din, self.H, self.ndir
-        if c['mask'] is not None:
+        if c['mask'] is not None and not dout_masked:
             dout = ops.apply_mask(dout, c['mask'])
         dgates, dpeep = ops.lstm_bwd(dout, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H,
                                      ndir, dtype, d_c_final, d_h_final, want_dpeep=True)
@@ -120,13 +126,14 @@ class LSTMLayer(object):
         dg2d = dgates.view(T * B, ndir * 4 * H)
         dx = torch.empty((T, B, din), dtype=torch.float32, device=x.device) if need_dx else None
         if need_dx:   # the only result the layer below waits for: main stream, first
-            ops.gemm(dg2d, c['wx_cat'], transB=True, out=dx.view(T * B, din))
+            ops.gemm(dg2d, c['wx_cat'], transB=True, out=dx.view(T * B, din),
+                     mul=dx_mask.view(T * B, din) if dx_mask is not None else None)
         # weight gradients: side streams (one per direction), concurrent with the BPTT kernel of the layer
         # below (joined in the model's backward before clipping)
         dw_il = torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols
         done = []
         for d in range(ndir):
-            with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il), lane=1 + d):
+            with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il), lane=1 + (d % DW_LANES)):
                 dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
                 ops.gemm(x2d, dg, transA=True, out=dw_il[d, :din])
                 if T > 1:
@@ -136,7 +143,7 @@ class LSTMLayer(object):
                         ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=dw_il[d, din:])
                 else:
                     dw_il[d, din:].zero_()
-                if d > 0:
+                if d % DW_LANES > 0:
                     done.append(ops.stream_event())
         with ops.side_lane(x.device, lane=1):
             for ev in done:

@@ -78,6 +78,19 @@ class side_lane(object):
         return False
 
 
+def set_side_xcd_skip(device, n):
+    """The side lanes' reduction-major GEMMs leave the first n XCDs alone (asr_set_xcd_skip).  An experiment knob, off
+    by default: keeping the weight-gradient GEMMs off the recurrence clusters' XCDs (their L2s carry the per-step
+    hand-off) was measured on the headline step -- BPTT launch 1321 us (n = 0), 1314 us (n = 2), 1362 us (n = 4) -- so
+    whatever stretches the recurrence beside the side GEMMs (1.19 ms alone) is not L2 sharing."""
+    dev = device.index or 0
+    for lane in (1, 2):
+        h = _lib.handle(dev, lane)
+        if getattr(h, '_xcd_skip', None) != n:
+            h.check(h.lib.asr_set_xcd_skip(h.h, int(n)), 'asr_set_xcd_skip')
+            h._xcd_skip = n
+
+
 def join_side(device):
     """Main stream waits for all side-lane work; releases the tensors held for it."""
     dev = device.index or 0
@@ -226,7 +239,8 @@ def colsum(a, out=None):
 
 
 # ---------------------------------------------------------------- GEMM
-def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, accumulate=False, relu=False):
+def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, accumulate=False, relu=False,
+         mul=None):
     """C = op(A) @ op(B) (+bias) (+C).  A, B 2-D, same dtype (f32 or bf16), row stride = ld."""
     h = _h(A)
     dt = dtype_id(A.dtype)
@@ -248,6 +262,15 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, 
             raise ValueError('gemm: bad out shape %s' % (tuple(out.shape),))
     if bias is not None:
         _chk(bias, torch.float32, 'bias')
+    if mul is not None:   # fp32 output times an elementwise fp32 multiplier [M,N] (a dropout mask), in the epilogue
+        _chk(mul, torch.float32, 'mul')
+        if odt != ASR_F32 or mul.dim() != 2 or mul.shape != (M, N) or mul.stride(1) != 1:
+            raise ValueError('gemm: mul needs an fp32 output and an fp32 [M,N] multiplier')
+        h.check(h.lib.asr_gemm_mul(h.h, dt, int(transA), int(transB), M, N, K,
+                                   C.c_void_p(A.data_ptr()), A.stride(0), C.c_void_p(B.data_ptr()), B.stride(0),
+                                   C.c_void_p(out.data_ptr()), out.stride(0), _p(bias), int(accumulate),
+                                   1 if relu else 0, C.c_void_p(mul.data_ptr()), mul.stride(0), _s()), 'asr_gemm_mul')
+        return out
     h.check(h.lib.asr_gemm_act(h.h, dt, odt, int(transA), int(transB), M, N, K,
                                C.c_void_p(A.data_ptr()), A.stride(0), C.c_void_p(B.data_ptr()), B.stride(0),
                                C.c_void_p(out.data_ptr()), out.stride(0), _p(bias), int(accumulate),

@@ -102,6 +102,47 @@ def test_gemm_bf16(cuda, M, N, K, ta, tb):
     assert _rel(out.cpu().numpy(), ref) < 1e-5
 
 
+@pytest.mark.parametrize('M,N,K,dt', [(12448, 512, 2048, 'bf16'), (1500, 256, 128, 'bf16'), (130, 70, 45, 'bf16'),
+                                        (257, 64, 120, 'f32')])
+def test_gemm_with_multiplier_epilogue(cuda, M, N, K, dt):
+    """asr_gemm_mul (the dropout mask of the layer below folded into the dx GEMM): bit-identical to the GEMM followed
+    by asr_apply_mask, on the lean NT kernel (fused epilogue) and on the shapes that take the generic kernel + one
+    multiply pass."""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(M + N)
+    tdt = torch.bfloat16 if dt == 'bf16' else torch.float32
+    A = torch.randn(M, K, generator=g).to(cuda).to(tdt)
+    Bt = torch.randn(N, K, generator=g).to(cuda).to(tdt)
+    mask = (torch.rand(M, N, generator=g) < 0.8).float().to(cuda) / 0.8
+    plain = ops.gemm(A, Bt, transB=True, out_dtype='f32')
+    fused = ops.gemm(A, Bt, transB=True, out_dtype='f32', mul=mask)
+    assert torch.equal(fused, ops.apply_mask(plain, mask))
+    with pytest.raises(ValueError):
+        ops.gemm(A, Bt, transB=True, out_dtype='f32', mul=mask[:, :N - 1])
+
+
+def test_gemm_tn_xcd_skip_is_result_neutral(cuda):
+    """The side lanes' reduction-major GEMM with the first n XCDs left alone (asr_set_xcd_skip): bit-identical to n = 0
+    for every n, including shapes whose tile count is not a multiple of the XCDs in use."""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    for (K, M, N) in [(12448, 512, 1024), (4096, 120, 1024), (3000, 256, 1032)]:
+        A = torch.randn(K, M, generator=g).to(cuda).to(torch.bfloat16)
+        B = torch.randn(K, N, generator=g).to(cuda).to(torch.bfloat16)
+        outs = []
+        for n in (0, 2, 4, 6):
+            ops.set_side_xcd_skip(A.device, n)
+            with ops.side_lane(A.device):
+                outs.append(ops.gemm(A, B, transA=True, out_dtype='f32'))
+            ops.join_side(A.device)
+        ops.set_side_xcd_skip(A.device, 0)
+        torch.cuda.synchronize()
+        ref = A.float().t() @ B.float()
+        assert (outs[0] - ref).abs().max() < 2e-3 * ref.abs().max()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+
+
 def test_gemm_bad_args(cuda):
     ops = _ops()
     with pytest.raises(ValueError):
