@@ -66,12 +66,13 @@ def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, 
                       bottleneck=False, operand_round=None, want_grads=True):
     """Returns dict(total_loss, ctc_losses [B], logits [T,B,C], grads {name: array}).
     operand_round (e.g. oracle.lstm.bf16_round_t): reproduces the rounding points of the bf16-operand device path in
-    the forward -- inputs, LSTM kernels, output weights and every emitted / fed-back h are rounded (straight-through),
+    the forward -- inputs, LSTM kernels, output weights, VGG filters / activations / bridge and every emitted / fed-back
+    h are rounded (straight-through),
     state, biases, peepholes and all accumulation stay in `dtype`."""
     if operand_round is not None:
         sd = dict(sd)
         for k in list(sd):
-            if k.endswith('/kernel') or k == 'output/weights':
+            if k.endswith('/kernel') or k == 'output/weights' or k.endswith('/weight') or k == 'bridge/weights':
                 v = sd[k].detach().cpu() if torch.is_tensor(sd[k]) else torch.as_tensor(np.asarray(sd[k]))
                 sd[k] = operand_round(v.to(torch.float64)).numpy()
         inputs_btd = operand_round(torch.as_tensor(np.asarray(inputs_btd), dtype=torch.float64)).numpy()
@@ -86,7 +87,7 @@ def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, 
         for k in sd:
             if k.startswith('VGG') or k.startswith('bridge/'):
                 vgg_params[k] = torch.as_tensor(np.asarray(sd[k].detach().cpu() if torch.is_tensor(sd[k]) else sd[k]), dtype=dtype).clone().requires_grad_(True)
-        x = ovgg.vgg_frontend(x, vgg_params, vgg[0], vgg[1])
+        x = ovgg.vgg_frontend(x, vgg_params, vgg[0], vgg[1], act_round=operand_round)
         # frames past seq_len feed the LSTM but are masked there, exactly as in the reference
     peep = layers[0][0]['_peep'] if ndir == 2 else layers[0]['_peep']
     kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=peep)

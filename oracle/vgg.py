@@ -20,16 +20,21 @@ def _pool_same(x):
     return Fn.max_pool2d(x, 2, 2)
 
 
-def vgg_frontend(x_btd, P, F, W):
-    """x [B,T,F*W*3] -> [B,T,256].  P: dict of torch tensors with the reference variable names."""
+def vgg_frontend(x_btd, P, F, W, act_round=None):
+    """x [B,T,F*W*3] -> [B,T,256].  P: dict of torch tensors with the reference variable names.
+    act_round (tests of the bf16-operand device path): rounding applied, straight-through, to every activation
+    the device stores in the operand dtype (the four ReLU outputs and the bridge output; pooling is exact on
+    rounded values).  The caller rounds the inputs and the weights."""
+    from .lstm import ste_round
+    r = (lambda t: t) if act_round is None else (lambda t: ste_round(t, act_round))
     B, T, _ = x_btd.shape
     x = x_btd.reshape(B * T, F, W, 3).permute(0, 3, 1, 2)
-    x = _conv(x, P['VGG1/conv1/weight'], P['VGG1/conv1/bias'])
-    x = _conv(x, P['VGG1/conv2/weight'], P['VGG1/conv2/bias'])
+    x = r(_conv(x, P['VGG1/conv1/weight'], P['VGG1/conv1/bias']))
+    x = r(_conv(x, P['VGG1/conv2/weight'], P['VGG1/conv2/bias']))
     x = _pool_same(x)
-    x = _conv(x, P['VGG2/conv1/weight'], P['VGG2/conv1/bias'])
-    x = _conv(x, P['VGG2/conv2/weight'], P['VGG2/conv2/bias'])
+    x = r(_conv(x, P['VGG2/conv1/weight'], P['VGG2/conv1/bias']))
+    x = r(_conv(x, P['VGG2/conv2/weight'], P['VGG2/conv2/bias']))
     x = _pool_same(x)
     x = x.permute(0, 2, 3, 1).reshape(B * T, -1)          # NHWC flatten (vgg_blstm.py:160-161)
-    x = Fn.relu(x @ P['bridge/weights'] + P['bridge/biases'])
+    x = r(Fn.relu(x @ P['bridge/weights'] + P['bridge/biases']))
     return x.reshape(B, T, -1)

@@ -227,7 +227,7 @@ def test_vgg_blstm_ctc_parity(cuda):
         err = np.abs(g.cpu().numpy() - r).max()
         assert err < 2e-3 * max(np.abs(r).max(), 1e-3) + 1e-7, (name, err, np.abs(r).max())
     # bf16 operands: the implicit-GEMM convolutions against the im2col + GEMM form (same bf16 operands, so
-    # the two agree far inside bf16 rounding) and, loosely, against the fp64 oracle
+    # the two agree far inside bf16 rounding) and against the oracle evaluated on the bf16-rounded operands
     import os
     grads = {}
     for mode in ('1', '0'):
@@ -242,11 +242,14 @@ def test_vgg_blstm_ctc_parity(cuda):
             grads[mode] = {name: g.cpu().numpy().copy() for g, name in opt3.compute_gradients(l3, model=m3)}
         finally:
             os.environ.pop('ASR_VGG_IMPLICIT', None)
+    from oracle import lstm as olstm
+    ref16 = omodel.ctc_model_forward(sd, x, labs, sl, L, ndir=2, cell_clip=50.0, vgg=(F, W),
+                                     operand_round=olstm.bf16_round_t)     # the device path's rounding points
     for name, g in grads['1'].items():
         if 'VGG' in name or 'bridge' in name:
-            r = ref['grads'][name]
+            r = ref16['grads'][name]
             assert np.abs(g - grads['0'][name]).max() < 1e-2 * np.abs(r).max(), name
-            assert np.abs(g - r).max() < 0.25 * np.abs(r).max(), name
+            assert np.abs(g - r).max() < 2e-2 * np.abs(r).max(), (name, np.abs(g - r).max() / np.abs(r).max())
     # dropout path + bf16 operands run and train
     m2 = CTC(encoder_type='vgg_blstm', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
              clip_grad_norm=5.0, clip_activation=50, dtype='bf16', seed=4)
@@ -256,6 +259,54 @@ def test_vgg_blstm_ctc_parity(cuda):
         m2.train(l, 'adam', 2e-3)
         l0 = l.item() if l0 is None else l0
     assert l.item() < 0.8 * l0
+
+
+def test_vgg_blstm_bf16_parity_at_the_cfgC_image_size(cuda):
+    """BASELINE configs[2] front-end at its own image size (40 mel bins x splice 11 x {static, delta, delta-delta}, the
+    implicit-GEMM convolutions with 64 / 128 channels on MFMA) + one 512-unit BLSTM layer (the 8-CU cluster kernels)
+    + CTC, bf16 operands, on three ragged utterances -- against the oracle evaluated with the device path's rounding
+    points (inputs, filters, bridge / LSTM / output weights, every stored activation and every emitted h rounded to
+    bf16, straight-through; biases, state and all accumulation fp64): loss, logits and EVERY gradient.
+    Reference: models/encoders/core/vgg_blstm.py:107-177, cnn_util.py:13-84."""
+    from oracle import lstm as olstm
+    from tensorflow_end2end_speech_recognition_amd import ops
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    rng = np.random.RandomState(12)
+    B, T, F, W, H, L, C = 3, 14, 40, 11, 512, 1, 28
+    D = F * W * 3
+    x, sl, labs, dense = _batch(rng, B, T, D, C, lo=6)
+    model = CTC(encoder_type='vgg_blstm', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
+                parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='bf16', seed=7)
+    sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+    for k in sd:      # non-zero biases so that the bias paths are exercised
+        if k.endswith('/bias') or k.endswith('/biases'):
+            sd[k] = (rng.randn(*sd[k].shape) * 0.05).astype(np.float32)
+    model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    opt = model._set_optimizer('sgd', 0.1)
+    gv = opt.compute_gradients(loss, model=model)
+    assert ops.check_async_errors(0) == 0
+    ref = omodel.ctc_model_forward(sd, x, labs, sl, L, ndir=2, cell_clip=50.0, vgg=(F, W),
+                                   operand_round=olstm.bf16_round_t)
+    rel = abs(loss.item() - ref['total_loss']) / abs(ref['total_loss'])
+    lg = logits.cpu().numpy()
+    valid = (np.arange(lg.shape[0])[:, None] < sl[None, :])
+    elog = np.abs(lg - ref['logits'])[valid]
+    report = ['loss %.6f vs oracle %.6f  rel %.2e   logits max abs %.2e (max |logit| %.2f)'
+              % (loss.item(), ref['total_loss'], rel, elog.max(), np.abs(ref['logits']).max())]
+    worst = 0.0
+    for g, name in gv:
+        r = ref['grads'][name]
+        e = np.abs(g.cpu().numpy() - r).max() / max(np.abs(r).max(), 1e-12)
+        report.append('%-44s rel-to-max %.2e' % (name, e))
+        worst = max(worst, e)
+    print('\n' + '\n'.join(report))
+    # measured on MI355X: loss rel 6e-5, logits 1.9e-2 abs (|logit| <= 3.4), gradients 0.7e-2 .. 1.5e-2 of their max:
+    # a stored bf16 activation whose fp32-accumulated value lies near a rounding boundary lands one bf16 step (2^-8)
+    # away from the fp64-accumulated oracle's, the same bound as the cfg-B test below
+    assert rel < 2e-3, report[0]
+    assert elog.max() < 2e-2 * max(1.0, np.abs(ref['logits']).max()), report[0]
+    assert worst < 2e-2, '\n'.join(report)
 
 
 def test_end_to_end_recipe_on_synthetic_corpus(cuda, tmp_path):
