@@ -166,10 +166,10 @@ def run_workload(args, wl, dev, world, rank, local_rank, want_parity, want_h2d):
 
     def step(xin):
         loss, logits = model.compute_loss(xin, dense, sld, keep_prob=wl['keep_prob'])
-        gv = opt.compute_gradients(loss, model=model)
-        model._clip_gradients(gv)                       # clip per tower BEFORE averaging
-        multi_gpu.average_gradients(model.store)        # RCCL all-reduce / N
-        opt.apply_gradients(gv)
+        # gradients -> per-variable clip on the tower (BEFORE averaging) -> mean over towers: per encoder layer on a
+        # communication stream under the BPTT of the layers below when N > 1 (multi_gpu.BucketedAverager)
+        multi_gpu.clip_and_average(model, opt, loss)
+        opt.apply_gradients(None)
         return loss
 
     def fence():

@@ -52,6 +52,7 @@ class _RecurrentEncoderBase(object):
         self.store = None
         self.scope_prefix = ''
         self.num_layers_sub = None     # multitask encoders: the layer whose output also feeds the sub-task head
+        self.grad_ready_hook = None    # callable(layer_index, LSTMLayer) fired from backward() per finished layer
         self.want_f32_outputs = True   # False: __call__ returns the operand-dtype outputs (no fp32 copy is made)
 
     # variables are created at graph-build time in the reference; here when the input size is known
@@ -171,6 +172,8 @@ class _RecurrentEncoderBase(object):
             dx = self.layers[li].backward(dx.contiguous(), dcf, dhf, need_dx=(li > 0 or need_input_grad),
                                           dout_masked=masked, dx_mask=below)
             masked = below is not None
+            if self.grad_ready_hook is not None:      # data-parallel step: this layer's gradients are on their way
+                self.grad_ready_hook(li, self.layers[li])
         ops.join_side(d_outputs.device)      # weight-gradient GEMMs issued on the side stream
         return dx
 

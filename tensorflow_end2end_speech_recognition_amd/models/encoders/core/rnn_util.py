@@ -54,6 +54,7 @@ class LSTMLayer(object):
         self.forget_bias = forget_bias
         self.cell_clip = cell_clip
         self.ctx = None
+        self.grad_event = None
 
     def _vars(self, view):
         """Per direction (kernel, bias, w_i_diag, w_f_diag, w_o_diag) through `view` (store[...] or store.g)."""
@@ -151,5 +152,17 @@ class LSTMLayer(object):
             # interleaved columns -> TF's gate-major kernel gradient; bias / peephole gradients (accumulated
             # inside the BPTT kernel) to their variables: one launch for the layer
             ops.lstm_grad_finish(self._vars(st.g), dw_il, dpeep, H)
+            # every gradient of this layer is complete at this point of side lane 1 (the data-parallel step hangs
+            # the layer's clip + all-reduce on it while the layers below are still in their BPTT)
+            self.grad_event = ops.stream_event()
         self.ctx = None
         return dx
+
+    def var_names(self):
+        """This layer's variables, in declaration order (one contiguous run of the ParamStore)."""
+        names = []
+        for b in self.bases:
+            names += [b + '/kernel', b + '/bias']
+            if self.use_peephole:
+                names += [b + '/w_i_diag', b + '/w_f_diag', b + '/w_o_diag']
+        return names

@@ -78,6 +78,18 @@ class ParamStore(object):
     def g(self, name):
         return self.gviews[name]
 
+    def bucket(self, first, last):
+        """Contiguous run of variables [first .. last] (declaration order) as a bucket of the flat buffers:
+        dict(start, end, grad = view of the flat gradient buffer, plan = ClipPlan of the run).  Used by the
+        data-parallel step to clip + all-reduce a layer's gradients as soon as they are complete."""
+        i0, i1 = self._index[first], self._index[last]
+        if i1 < i0:
+            raise ValueError('bucket: %s is declared after %s' % (first, last))
+        off = self.offsets_host[i0:i1 + 2] - self.offsets_host[i0]
+        start, end = int(self.offsets_host[i0]), int(self.offsets_host[i1 + 1])
+        return dict(start=start, end=end, names=self.names[i0:i1 + 1], grad=self.grad[start:end],
+                    plan=ops.ClipPlan(off, self.flat.device))
+
     def num_params(self):
         return int(sum(int(np.prod(s[1])) if len(s[1]) else 1 for s in self._specs))
 

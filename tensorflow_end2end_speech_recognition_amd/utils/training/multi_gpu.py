@@ -6,10 +6,12 @@ Reference: ONE process, N in-graph towers; per tower compute_gradients and per-v
 clip_by_norm (train_ctc.py:112-117), then per variable stack the N tower gradients and
 reduce_mean (multi_gpu.py:32-40), one apply_gradients.
 Here: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI); every rank
-holds an identical replica, clips locally, then ONE all-reduce(sum) over the flat fp32
-gradient buffer of the ParamStore (a single contiguous bucket: 28 MB for the 5x256 BLSTM)
-followed by a 1/N scale -- the same mean over towers; every rank then applies the identical
-optimizer step, so replicas stay bit-identical without a broadcast after step 0.
+holds an identical replica, clips locally, then all-reduces(sum) the flat fp32 gradient buffer
+of the ParamStore and scales by 1/N -- the same mean over towers -- per encoder layer on a
+communication stream while the layers below are still in their BPTT (BucketedAverager), or as
+ONE bucket (average_gradients: 28 MB for the 5x256 BLSTM) where that does not apply; every rank
+then applies the identical optimizer step, so replicas stay bit-identical without a broadcast
+after step 0.
 """
 import torch
 import torch.distributed as dist
@@ -91,6 +93,153 @@ def average_gradients(store_or_tower_grads):
     return store.grad
 
 
+def _allreduce_mean_(t):
+    """In-place mean over ranks of a contiguous fp32 tensor (view of the flat gradient buffer), on the current stream."""
+    comm = native_comm(t.device) if t.is_cuda else None
+    if comm is not None:
+        comm.allreduce_mean(t)
+    elif is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        n = dist.get_world_size()
+        if t.is_cuda:
+            ops.scale_(t, 1.0 / n)
+        else:
+            t.mul_(1.0 / n)
+    return t
+
+
+class BucketedAverager(object):
+    """The tower mean of average_gradients, per LAYER and overlapped with the backward pass.
+
+    The gradients of recurrent layer l are complete as soon as its weight-gradient GEMMs have run (side lane 1,
+    LSTMLayer.grad_event) -- long before the BPTT kernels of the layers below have finished, and those leave ~240 of
+    the 256 CUs and all of xGMI idle.  So the layer's bucket (its contiguous run of the flat gradient buffer: 2.6 MB at
+    5x256, 21 MB at 5x512) is clipped per variable (train_ctc.py:116: clip BEFORE the mean) and all-reduced on a
+    communication stream right then, top layer first; what is not an encoder layer (heads, VGG front-end, attention
+    decoder) forms the remaining bucket(s), reduced after the backward pass.  Same arithmetic as the single-bucket
+    path (clip_by_norm is per variable, the mean is elementwise), same collective order on every rank.
+    Not used with weight decay (its gradient term is added over the whole buffer after the backward pass)."""
+
+    def __init__(self, model):
+        self.model = model
+        st = model.store
+        enc = getattr(model, 'encoder', None)
+        self.enc = enc if hasattr(enc, 'grad_ready_hook') else None
+        layers = list(getattr(self.enc, 'layers', None) or [])
+        self.layers = layers
+        self.buckets = []
+        self.ok = bool(layers) and not float(getattr(model, 'weight_decay', 0.0) or 0.0) > 0.0
+        covered = []
+        if self.ok:
+            for layer in layers:
+                names = layer.var_names()
+                idx = [st._index[n] for n in names]
+                if idx != list(range(idx[0], idx[0] + len(idx))):
+                    self.ok = False                       # not one contiguous run: keep the single bucket
+                    break
+                b = st.bucket(names[0], names[-1])
+                self.buckets.append(b)
+                covered.append((idx[0], idx[-1]))
+        self.rest = []
+        if self.ok:
+            taken = set()
+            for a, b in covered:
+                taken.update(range(a, b + 1))
+            run = []
+            for i, n in enumerate(st.names + [None]):
+                if n is not None and i not in taken:
+                    run.append(n)
+                elif run:
+                    self.rest.append(st.bucket(run[0], run[-1]))
+                    run = []
+        self.comm_stream = None
+        self._seen = set()
+
+    def enabled(self):
+        return self.ok and (is_distributed() or bool(getattr(self, 'force', False)))
+
+    def _reduce(self, bucket):
+        clip = self.model.clip_grad_norm
+        if clip is not None:
+            ops.clip_by_norm_multi(bucket['grad'], bucket['plan'], float(clip))
+        _allreduce_mean_(bucket['grad'])
+
+    def _comm(self):
+        dev = self.model.store.flat.device
+        if dev.type != 'cuda':
+            return None
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=dev)
+        return self.comm_stream
+
+    def begin(self):
+        self._seen = set()
+        if self.enc is not None:
+            self.enc.grad_ready_hook = self.layer_ready
+
+    def layer_ready(self, li, layer):
+        """Hook of encoder.backward(): layer li's gradient GEMMs have been issued."""
+        self._seen.add(li)
+        cs = self._comm()
+        if cs is None:
+            self._reduce(self.buckets[li])
+            return
+        with torch.cuda.stream(cs):
+            ops.wait_event(layer.grad_event)
+            self._reduce(self.buckets[li])
+
+    def finish(self):
+        """After the backward pass (or for a rank with an empty shard, whose gradients are zero): the layers the hook
+        has not seen -- same order as the backward pass issues them -- then the remaining buckets; the launch stream
+        then waits for the communication stream."""
+        if self.enc is not None:
+            self.enc.grad_ready_hook = None
+        cs = self._comm()
+        if cs is not None:
+            cs.wait_stream(torch.cuda.current_stream(cs.device))
+        ctx = torch.cuda.stream(cs) if cs is not None else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            for li in reversed(range(len(self.buckets))):
+                if li not in self._seen:
+                    self._reduce(self.buckets[li])
+            for b in self.rest:
+                self._reduce(b)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        if cs is not None:
+            torch.cuda.current_stream(cs.device).wait_stream(cs)
+
+
+def averager_for(model):
+    a = getattr(model, '_dp_averager', None)
+    if a is None or a.model.store is not model.store:
+        a = model._dp_averager = BucketedAverager(model)
+    return a
+
+
+def clip_and_average(model, optimizer, loss):
+    """compute_gradients -> per-variable clip -> mean over towers for this rank's tower (loss None: empty shard)."""
+    avg = averager_for(model)
+    if avg.enabled():
+        avg.begin()
+        if loss is not None:
+            optimizer.compute_gradients(loss, model=model)     # fires layer_ready per finished layer
+        else:
+            model.store.grad.zero_()
+        avg.finish()
+        return
+    if loss is not None:
+        gv = optimizer.compute_gradients(loss, model=model)
+        if model.clip_grad_norm is not None:
+            model._clip_gradients(gv)
+    else:
+        model.store.grad.zero_()
+    average_gradients(model.store)
+
+
 def average_scalar(x):
     """loss / LER are tower-averaged too (train_ctc.py:136-139)."""
     if is_distributed():
@@ -137,16 +286,11 @@ def tower_step(model, optimizer, inputs, labels, inputs_seq_len, keep_prob, lear
     Returns (loss averaged over towers, this tower's logits or None)."""
     B = len(inputs)
     logits = None
+    loss = None
     if B > 0:
         loss, logits = model.compute_loss(inputs, labels, inputs_seq_len, keep_prob)
-        gv = optimizer.compute_gradients(loss, model=model)
-        if model.clip_grad_norm is not None:
-            model._clip_gradients(gv)
-        loss = loss.detach()
-    else:
-        model.store.grad.zero_()
-        loss = torch.zeros((), dtype=torch.float32, device=model.store.flat.device)
-    average_gradients(model.store)
+    clip_and_average(model, optimizer, loss)
+    loss = loss.detach() if loss is not None else torch.zeros((), dtype=torch.float32, device=model.store.flat.device)
     optimizer.apply_gradients(None, learning_rate=learning_rate)
     return average_scalar(loss), logits
 
@@ -157,14 +301,7 @@ def tower_step_with(model, optimizer, loss_fn, learning_rate=None):
     examples/csj/training/train_attention.py:90-150 -- gradients, per-variable clip on the tower, mean over towers,
     identical update.  Returns the loss averaged over towers."""
     loss = loss_fn()
-    if loss is not None:
-        gv = optimizer.compute_gradients(loss, model=model)
-        if model.clip_grad_norm is not None:
-            model._clip_gradients(gv)
-        loss = loss.detach()
-    else:
-        model.store.grad.zero_()
-        loss = torch.zeros((), dtype=torch.float32, device=model.store.flat.device)
-    average_gradients(model.store)
+    clip_and_average(model, optimizer, loss)
+    loss = loss.detach() if loss is not None else torch.zeros((), dtype=torch.float32, device=model.store.flat.device)
     optimizer.apply_gradients(None, learning_rate=learning_rate)
     return average_scalar(loss)

@@ -445,6 +445,38 @@ def test_rccl_collectives_on_the_parameter_store(cuda):
         dist.destroy_process_group()
 
 
+def test_bucketed_gradient_averaging_on_the_communication_stream(cuda):
+    """multi_gpu.BucketedAverager on the device: per-layer clip (+ collective) on a communication stream hung on the
+    layers' gradient events while the BPTT kernels of the layers below run, the rest after the backward pass -- the
+    clipped gradient buffer must equal the single-bucket path bit for bit, for the fp32 single-CU kernels and for the
+    bf16 cluster kernels (one rank: the tower mean is the identity; the N-rank arithmetic is covered by the gloo
+    tests, the collective itself by the RCCL tests below)."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu
+    rng = np.random.RandomState(4)
+    for dtype, H, L in (('f32', 64, 3), ('bf16', 256, 3)):
+        B, T, D, C = 16, 60, 24, 9
+        x, sl, labs, dense = _batch(rng, B, T, D, C)
+        model = CTC('blstm', D, H, L, C, parameter_init=0.3, clip_grad_norm=0.01, clip_activation=50, dtype=dtype, seed=2)
+        opt = model._set_optimizer('sgd', 0.1)
+        loss, _ = model.compute_loss(x, dense, sl, keep_prob=0.9)
+        gv = opt.compute_gradients(loss, model=model)
+        model._clip_gradients(gv)
+        want = model.store.grad.clone()
+        model._dropout_calls -= 1                       # replay the same dropout masks
+        avg = multi_gpu.averager_for(model)
+        assert avg.ok and len(avg.buckets) == L
+        avg.force = True
+        loss2, _ = model.compute_loss(x, dense, sl, keep_prob=0.9)
+        multi_gpu.clip_and_average(model, opt, loss2)
+        torch.cuda.synchronize()
+        assert abs(loss2.item() - loss.item()) == 0.0
+        assert torch.equal(model.store.grad, want), dtype
+        opt.apply_gradients(None)
+        assert ops.check_async_errors(0) == 0
+
+
 def test_native_rccl_allreduce_mean_one_rank(cuda):
     """asr_comm_unique_id / asr_comm_init / asr_allreduce_mean (the collective of the C ABI, RCCL opened with dlopen)
     with a one-rank communicator on the box's single GPU: library binding, id bootstrap, in-place all-reduce on the

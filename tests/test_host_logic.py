@@ -74,6 +74,48 @@ def test_ctc_model_host_logic(monkeypatch, enc, L, bn, wd):
     assert 0.0 <= model.compute_ler(dec, list2sparsetensor(dense, -1))
 
 
+@pytest.mark.parametrize('enc,L,bn', [('blstm', 3, None), ('lstm', 2, 12)])
+def test_bucketed_gradient_averaging_is_the_single_bucket_arithmetic(monkeypatch, enc, L, bn):
+    """utils/training/multi_gpu.BucketedAverager (clip + tower mean per encoder layer as soon as the layer's gradients
+    are issued, the rest after the backward pass): its buckets partition the flat gradient buffer, the hook fires for
+    every layer top-down, and the clipped gradients equal those of the single-bucket path bit for bit (one rank: the
+    mean is the identity; N ranks are covered by the gloo tests of the recipes, which run this path)."""
+    _cpu_ops.install(monkeypatch)
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu
+    rng = np.random.RandomState(8)
+    B, T, D, H, C = 4, 9, 6, 8, 5
+    x, sl, labs, dense = _batch(rng, B, T, D, C)
+    model = CTC(encoder_type=enc, input_size=D, num_units=H, num_layers=L, num_classes=C, parameter_init=0.3,
+                clip_grad_norm=0.02, clip_activation=50, bottleneck_dim=bn, dtype='f32', seed=3, device='cpu')
+    opt = model._set_optimizer('sgd', 0.1)
+    loss, _ = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    gv = opt.compute_gradients(loss, model=model)
+    model._clip_gradients(gv)
+    want = model.store.grad.clone()
+    avg = multi_gpu.averager_for(model)
+    assert avg.ok and len(avg.buckets) == L
+    spans = sorted((b['start'], b['end']) for b in avg.buckets + avg.rest)
+    assert spans[0][0] == 0 and spans[-1][1] == model.store.total
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    order = []
+    orig = avg.layer_ready
+    monkeypatch.setattr(avg, 'layer_ready', lambda li, layer: (order.append(li), orig(li, layer)))
+    avg.force = True
+    loss, _ = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    multi_gpu.clip_and_average(model, opt, loss)
+    assert order == list(reversed(range(L)))
+    assert torch.equal(model.store.grad, want)
+    assert model.encoder.grad_ready_hook is None
+    # a rank with an empty shard: zero gradients through the same sequence of buckets
+    multi_gpu.clip_and_average(model, opt, None)
+    assert float(model.store.grad.abs().sum()) == 0.0
+    # weight decay adds its gradient term over the whole buffer after the backward pass: single bucket
+    m2 = CTC(encoder_type=enc, input_size=D, num_units=H, num_layers=L, num_classes=C, weight_decay=1e-3,
+             dtype='f32', seed=3, device='cpu')
+    assert not multi_gpu.averager_for(m2).ok
+
+
 @pytest.mark.parametrize('enc,Lm,Ls,bn', [('multitask_blstm', 3, 2, None), ('multitask_blstm', 2, 2, 10),
                                           ('multitask_blstm', 3, 1, None), ('multitask_lstm', 3, 1, None)])
 def test_multitask_ctc_host_logic(monkeypatch, enc, Lm, Ls, bn):
