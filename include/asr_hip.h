@@ -142,6 +142,14 @@ int asr_im2col3x3(asr_handle* h, int dtype, const void* in, int N, int H, int W,
                   void* patches, asr_stream s);
 int asr_col2im3x3(asr_handle* h, const float* dpatches, int N, int H, int W, int Cin, int ldp,
                   float* din, asr_stream s);
+/* General SAME convolution (NHWC x HWIO, any kernel / stride) as im2col + asr_gemm: conv_layer of the CLDNN front-end
+ * (models/encoders/core/cldnn_wang.py:141-177: 11x21 stride (3,2), 11x11 stride (1,2), 3x3; cnn_util.py:50-84).
+ * patches [N*Ho*Wo, ldp] (`dtype`), column (ky*kw + kx)*Cin + ci, Ho = ceil(H/sh), Wo = ceil(W/sw), TensorFlow's SAME
+ * padding (the odd cell goes after).  asr_col2im: gradient w.r.t. the input from the gradient of the patches (fp32). */
+int asr_im2col(asr_handle* h, int dtype, const void* in_nhwc, int N, int H, int W, int Cin, int kh, int kw,
+               int sh, int sw, int ldp, void* patches, asr_stream s);
+int asr_col2im(asr_handle* h, const float* dpatches, int N, int H, int W, int Cin, int kh, int kw,
+               int sh, int sw, int ldp, float* din_nhwc, asr_stream s);
 /* Implicit-GEMM form of the same 3x3 SAME convolution for bf16 operands (no patch matrix: a 64-wide
  * k-tile is one tap x 64 input channels, read straight from the NHWC image; conv_layer of
  * models/encoders/core/cnn_util.py:14-84, VGG blocks of vgg_blstm.py:113-157).
@@ -258,6 +266,27 @@ int asr_debug_set_lstm_flags(int flags);
 /* Debug: records, per workgroup of a probe grid launched on `s`, {XCC id, HW_ID register} into out[2*nblocks]
  * (device memory); every workgroup stays resident for spin_cycles so that the grid spreads over the CUs. */
 int asr_debug_placement(asr_handle* h, unsigned* out, int nblocks, int spin_cycles, asr_stream s);
+
+/* ---- GRU recurrence ------------------------------------------------------- *
+ * tf.contrib.rnn.GRUCell under tf.nn.(bidirectional_)dynamic_rnn(sequence_length) -- the reference's GRUEncoder /
+ * BGRUEncoder (models/encoders/core/gru.py:58-76, :126-152).  fp32.  One layer, ndir directions, all steps:
+ *     [r, u] = sigmoid(xg_t + h W_gh),  c = tanh(xc_t + (r * h) W_ch),  h' = u * h + (1 - u) * c
+ * xg [T,B,ndir,2H] = x W_g[:D] + b_g and xc [T,B,ndir,H] = x W_c[:D] + b_c are the caller's hoisted GEMMs;
+ * wgh [ndir][H][2H] / wch [ndir][H][H] the recurrent blocks of the two kernels (row-major), wghT / wchT their
+ * transposes ([ndir][2H][H] / [ndir][H][H]).  tmax = max(seq_len) (host value: the step loop is issued by the host).
+ * Saved for the backward pass, all [T,B,ndir,H] at the frame a row worked on: r, u, c, rh = r * h_prev.
+ * hout [T,B,ndir*H] (zero past seq_len); hstate2: 2*ndir*B*H floats of work space, the final state [ndir,B,H] is
+ * left in its first half.
+ * asr_gru_bwd: dout [T,B,ndir*H] (+ d_h_final [ndir,B,H] or NULL) -> dgate [T,B,ndir,2H] (d r_pre | d u_pre) and
+ * dcand [T,B,ndir,H] (d c_pre), zero where no row is active; the weight / input gradients are GEMMs over them
+ * (dW_g = [x; h_prev]^T dgate, dW_c = [x; rh]^T dcand, dx = dgate W_gx^T + dcand W_cx^T).  work2: 2*ndir*B*H floats. */
+int asr_gru_fwd(asr_handle* h, int T, int B, int H, int ndir, const float* xg, const float* xc,
+                const float* wgh, const float* wch, const int32_t* seq_len, int tmax, float* r, float* u,
+                float* c, float* rh, float* hout, float* hstate2, asr_stream s);
+int asr_gru_bwd(asr_handle* h, int T, int B, int H, int ndir, const float* dout, const float* d_h_final,
+                const float* hout, const float* r, const float* u, const float* c, const float* wghT,
+                const float* wchT, const int32_t* seq_len, int tmax, float* dgate, float* dcand,
+                float* work2, asr_stream s);
 
 /* ---- CTC ------------------------------------------------------------------ *
  * tf.nn.ctc_loss(labels, logits, seq_len, preprocess_collapse_repeated=False,

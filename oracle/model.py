@@ -185,3 +185,93 @@ def multitask_ctc_model_forward(sd, inputs_btd, labels_main, labels_sub, seq_len
     return dict(total_loss=float(total.detach()), ctc_losses_main=lm.detach().numpy(),
                 ctc_losses_sub=ls.detach().numpy(), logits_main=logits_main.detach().numpy(),
                 logits_sub=logits_sub.detach().numpy(), grads=grads)
+
+
+def gru_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, drop_masks=None, want_grads=True,
+                          dtype=torch.float64):
+    """GRU / BGRU encoder (models/encoders/core/gru.py) + output FC + CTC, as CTC(encoder_type='gru' | 'bgru') builds
+    it (models/ctc/ctc.py:150-155, :198-233).  sd: {variable name -> array} with the TF 1.3 names.  Returns
+    dict(total_loss, ctc_losses, logits [T,B,C], grads {name: array}, enc, final)."""
+    from . import gru as ogru
+    named = {}
+
+    def t(name):
+        v = sd[name]
+        v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        named[name] = torch.as_tensor(v, dtype=dtype).clone().requires_grad_(True)
+        return named[name]
+
+    layers = []
+    for i in range(1, num_layers + 1):
+        bases = ['bgru_hidden%d/%s/gru_cell' % (i, d) for d in ('fw', 'bw')] if ndir == 2 else \
+            ['multi_gru/rnn/multi_rnn_cell/cell_%d/gru_cell' % (i - 1)]
+        ps = [dict(wg=t(b + '/gates/kernel'), bg=t(b + '/gates/bias'), wc=t(b + '/candidate/kernel'),
+                   bc=t(b + '/candidate/bias')) for b in bases]
+        layers.append(tuple(ps) if ndir == 2 else ps[0])
+    w_out, b_out = t('output/weights'), t('output/biases')
+    x = torch.as_tensor(np.asarray(inputs_btd), dtype=dtype).transpose(0, 1)
+    sl = torch.as_tensor(np.asarray(seq_len), dtype=torch.long)
+    enc, final = ogru.gru_encoder(x, sl, layers, ndir, drop_masks)
+    T, B, E = enc.shape
+    logits = (enc.reshape(T * B, E) @ w_out + b_out).reshape(T, B, -1)
+    losses = ctc_loss(logits, labels_list, seq_len)
+    total = losses.mean()
+    grads = None
+    if want_grads:
+        total.backward()
+        grads = {n: v.grad.detach().numpy().copy() for n, v in named.items()}
+    return dict(total_loss=float(total.detach()), ctc_losses=losses.detach().numpy(), logits=logits.detach().numpy(),
+                grads=grads, enc=enc.detach().numpy(), final=final)
+
+
+def cldnn_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, F, W, cell_clip=0.0, want_grads=True,
+                            dtype=torch.float64, operand_round=None):
+    """CTC(encoder_type='cldnn_wang'): conv stack -> BLSTM stack -> fc1 relu -> fc2 relu -> output FC -> CTC
+    (models/encoders/core/cldnn_wang.py:134-249, models/ctc/ctc.py:135-147).  No dropout.
+    operand_round: the rounding points of the bf16-operand device path (inputs, every matrix operand, every stored
+    activation and emitted h; straight-through)."""
+    from . import cldnn as ocl
+    named = {}
+    rnd = (lambda v: v) if operand_round is None else (lambda v: olstm.ste_round(v, operand_round))
+    if operand_round is not None:
+        sd = dict(sd)
+        for k in list(sd):
+            if k.endswith('/kernel') or k.endswith('/weights') or k.endswith('/weight'):
+                v = sd[k].detach().cpu() if torch.is_tensor(sd[k]) else torch.as_tensor(np.asarray(sd[k]))
+                sd[k] = operand_round(v.to(torch.float64)).numpy()
+        inputs_btd = operand_round(torch.as_tensor(np.asarray(inputs_btd), dtype=torch.float64)).numpy()
+
+    def t(name):
+        v = sd[name]
+        v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        named[name] = torch.as_tensor(v, dtype=dtype).clone().requires_grad_(True)
+        return named[name]
+
+    P = {n: t(n) for n in sd if n.startswith('CNN')}
+    layers = params_from_state_dict(sd, num_layers, 2, dtype)
+    x = torch.as_tensor(np.asarray(inputs_btd), dtype=dtype)
+    sl = torch.as_tensor(np.asarray(seq_len), dtype=torch.long)
+    feat = ocl.conv_stack(x, P, F, W, act_round=operand_round)              # [B,T,h*w*96] (the LSTM oracle takes batch-major)
+    kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=layers[0][0]['_peep'])
+    if operand_round is not None:
+        kw['h_round'] = operand_round
+    enc, final = olstm.blstm_encoder(feat, sl, layers, None, **kw)
+    T, B, E = enc.shape
+    a1 = rnd(torch.relu(enc.reshape(T * B, E) @ t('fc1/weights') + t('fc1/biases')))
+    a2 = rnd(torch.relu(a1 @ t('fc2/weights') + t('fc2/biases')))
+    logits = (a2 @ t('output/weights') + t('output/biases')).reshape(T, B, -1)
+    losses = ctc_loss(logits, labels_list, seq_len)
+    total = losses.mean()
+    for layer in layers:
+        for p in layer:
+            base = p['_base']
+            named[base + '/kernel'], named[base + '/bias'] = p['w'], p['b']
+            if p['_peep']:
+                named[base + '/w_i_diag'], named[base + '/w_f_diag'], named[base + '/w_o_diag'] = p['wci'], p['wcf'], p['wco']
+    grads = None
+    if want_grads:
+        total.backward()
+        grads = {n: v.grad.detach().numpy().copy() for n, v in named.items()}
+    return dict(total_loss=float(total.detach()), ctc_losses=losses.detach().numpy(), logits=logits.detach().numpy(),
+                grads=grads, enc=a2.detach().numpy().reshape(T, B, -1))
+

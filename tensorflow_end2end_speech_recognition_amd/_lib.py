@@ -43,6 +43,8 @@ SIGNATURES = {
     'asr_conv3x3_bwd_weight': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'asr_im2col3x3': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_col2im3x3': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'asr_im2col': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'asr_col2im': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_maxpool2x2_fwd': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_maxpool2x2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'asr_relu_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
@@ -53,6 +55,8 @@ SIGNATURES = {
     'asr_lstm_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'asr_lstm_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp]),
+    'asr_gru_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'asr_gru_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'asr_check_async_errors': (_i, [_vp, C.POINTER(C.c_uint)]),
     'asr_peek_async_errors': (_i, [_vp, _vp, _vp]),
     'asr_clear_async_errors': (_i, [_vp, _vp]),

@@ -1,0 +1,285 @@
+// GRU recurrence for gfx950: tf.contrib.rnn.GRUCell under tf.nn.(bidirectional_)dynamic_rnn(sequence_length)
+// (models/encoders/core/gru.py:58-76 GRUEncoder, :126-152 BGRUEncoder of the reference):
+//     [r, u] = sigmoid([x, h] W_g + b_g)        W_g [(D+H), 2H], gate columns r | u, b_g initialised to 1
+//     c      = tanh([x, r * h] W_c + b_c)       W_c [(D+H), H]
+//     h'     = u * h + (1 - u) * c              state carried / output zeroed past seq_len
+//
+// The x-parts (x W_gx + b_g, x W_cx + b_c) are hoisted over all T into two GEMMs (asr_gemm), as for the LSTM.  What is
+// left per step is two DEPENDENT small matrix products (h W_gh, then (r*h) W_ch): the reset gate sits between them, so
+// one step is two grid-wide phases.  Each phase is one launch over (16-row tile of utterances) x (16-column tile of
+// units) x direction: the 16 x H slice of h (or r*h) is staged in LDS, every thread owns one (utterance, unit) output
+// and walks K = H with the weight column coalesced across the 16 unit-threads.  fp32 throughout (this encoder is not
+// on a BASELINE configuration; the LSTM path is where the MFMA / multi-CU work went).  Launch-bound: ~2 x 5 us per
+// step forward, 3 launches per step backward.
+//
+// Time indexing as dynamic_rnn: at recurrence step s direction 0 works on frame s, direction 1 on frame len_b-1-s
+// (array_ops.reverse_sequence); rows with s >= len_b keep their state and emit zeros (written to frame s of the
+// padding, as the LSTM kernels do).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float gsig(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// frame a row works on at step s; act = the row is still inside its utterance
+__device__ __forceinline__ int gru_frame(int s, int len, int d, bool& act) {
+  act = s < len;
+  return act ? (d == 1 ? len - 1 - s : s) : s;
+}
+
+// ---- forward phase 1: r, u, r*h -------------------------------------------------------------------------------------
+// grid (2H/16, B/16, ndir), block 256 = 16 rows x 16 columns.  xg [T,B,ndir,2H]; hstate [ndir,B,H] (h of step s-1);
+// wgh [ndir][H][2H]; outputs r, u, rh at the row's frame: [T,B,ndir,H] each.
+__global__ __launch_bounds__(256) void gru_gates_fwd_kernel(int s, int T, int B, int H, int ndir,
+                                                            const float* __restrict__ xg,
+                                                            const float* __restrict__ hstate,
+                                                            const float* __restrict__ wgh,
+                                                            const int32_t* __restrict__ seq_len,
+                                                            float* __restrict__ r_out, float* __restrict__ u_out,
+                                                            float* __restrict__ rh_out) {
+  extern __shared__ float hs[];                            // [16][H + 1]
+  const int d = blockIdx.z, b0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+  const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+  const int LD = H + 1;
+  const float* hsrc = hstate + ((size_t)d * B + b0) * H;
+  for (int i = threadIdx.x; i < 16 * H; i += 256) hs[(i / H) * LD + (i % H)] = hsrc[i];
+  __syncthreads();
+  const int b = b0 + row, j = c0 + col;                    // j in [0, 2H): gate column
+  bool act;
+  const int t = gru_frame(s, min(seq_len[b], T), d, act);
+  if (!act) return;                                        // nothing of an inactive row is read later
+  const float* w = wgh + (size_t)d * H * 2 * H + j;
+  float acc = xg[(((size_t)t * B + b) * ndir + d) * 2 * H + j];
+  const float* hr = hs + row * LD;
+#pragma unroll 8
+  for (int k = 0; k < H; ++k) acc = fmaf(hr[k], w[(size_t)k * 2 * H], acc);
+  const float g = gsig(acc);
+  const size_t o = (((size_t)t * B + b) * ndir + d) * H;
+  if (j < H) {
+    r_out[o + j] = g;
+    rh_out[o + j] = g * hr[j];
+  } else {
+    u_out[o + j - H] = g;
+  }
+}
+
+// ---- forward phase 2: candidate, new state, output ------------------------------------------------------------------
+// grid (H/16, B/16, ndir).  xc [T,B,ndir,H]; rh, u [T,B,ndir,H] (phase 1); wch [ndir][H][H]; hstate -> hnext
+// [ndir,B,H]; c_out [T,B,ndir,H]; hout [T,B,ndir*H] (fw | bw halves, zero for finished rows).
+__global__ __launch_bounds__(256) void gru_cand_fwd_kernel(int s, int T, int B, int H, int ndir,
+                                                           const float* __restrict__ xc,
+                                                           const float* __restrict__ rh,
+                                                           const float* __restrict__ u_in,
+                                                           const float* __restrict__ wch,
+                                                           const float* __restrict__ hstate,
+                                                           const int32_t* __restrict__ seq_len,
+                                                           float* __restrict__ hnext, float* __restrict__ c_out,
+                                                           float* __restrict__ hout) {
+  extern __shared__ float as[];                            // [16][H + 1]: r*h of the 16 rows at their own frames
+  const int d = blockIdx.z, b0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+  const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+  const int LD = H + 1;
+  for (int i = threadIdx.x; i < 16 * H; i += 256) {
+    const int rr = i / H, k = i % H;
+    bool a;
+    const int tt = gru_frame(s, min(seq_len[b0 + rr], T), d, a);
+    as[rr * LD + k] = a ? rh[(((size_t)tt * B + b0 + rr) * ndir + d) * H + k] : 0.f;
+  }
+  __syncthreads();
+  const int b = b0 + row, j = c0 + col;
+  bool act;
+  const int t = gru_frame(s, min(seq_len[b], T), d, act);
+  const size_t so = ((size_t)d * B + b) * H + j;
+  const float hp = hstate[so];
+  const size_t oo = ((size_t)t * B + b) * ndir * H + (size_t)d * H + j;
+  if (!act) {
+    hnext[so] = hp;
+    hout[oo] = 0.f;
+    return;
+  }
+  const size_t o = (((size_t)t * B + b) * ndir + d) * H + j;
+  const float* w = wch + (size_t)d * H * H + j;
+  float acc = xc[o];
+  const float* ar = as + row * LD;
+#pragma unroll 8
+  for (int k = 0; k < H; ++k) acc = fmaf(ar[k], w[(size_t)k * H], acc);
+  const float c = tanhf(acc), u = u_in[o];
+  const float hn = u * hp + (1.f - u) * c;
+  c_out[o] = c;
+  hnext[so] = hn;
+  hout[oo] = hn;
+}
+
+// ---- backward, per step (steps run tmax-1 .. 0) ----------------------------------------------------------------------
+// B1 (elementwise over [ndir,B,H]): dh = dout(frame) + dh_rec;  du_pre, dc_pre to dgc / dcc at the row's frame,
+//    dh_acc = dh * u.   h_prev of step s is hout at the frame of step s-1 (zero for s == 0).
+__global__ void gru_bwd_elem_kernel(int s, int T, int B, int H, int ndir, const float* __restrict__ dout,
+                                    const float* __restrict__ dh_rec, const float* __restrict__ hout,
+                                    const float* __restrict__ u_in, const float* __restrict__ c_in,
+                                    const int32_t* __restrict__ seq_len, float* __restrict__ dgate,
+                                    float* __restrict__ dcand, float* __restrict__ dh_acc) {
+  const size_t n = (size_t)ndir * B * H;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i % H, b = (i / H) % B, d = i / ((size_t)H * B);
+    const int len = min(seq_len[b], T);
+    bool act;
+    const int t = gru_frame(s, len, d, act);
+    const float dr = dh_rec[i];
+    if (!act) { dh_acc[i] = dr; continue; }
+    const size_t o = (((size_t)t * B + b) * ndir + d) * H + j;
+    float hp = 0.f;
+    if (s > 0) {
+      const int tp = d == 1 ? len - s : s - 1;             // frame of step s-1
+      hp = hout[((size_t)tp * B + b) * ndir * H + (size_t)d * H + j];
+    }
+    const float dh = dout[((size_t)t * B + b) * ndir * H + (size_t)d * H + j] + dr;
+    const float u = u_in[o], c = c_in[o];
+    dgate[(((size_t)t * B + b) * ndir + d) * 2 * H + H + j] = dh * (hp - c) * u * (1.f - u);   // d u_pre
+    dcand[o] = dh * (1.f - u) * (1.f - c * c);                                                   // d c_pre
+    dh_acc[i] = dh * u;
+  }
+}
+
+// B2: d(rh)[row][k] = sum_j dc_pre[row][j] W_c[k][j] (wchT [ndir][H j][H k]);  d r_pre -> dgate[..][k],
+//     dh_acc[k] += d(rh) * r.   grid (H/16, B/16, ndir).
+__global__ __launch_bounds__(256) void gru_bwd_reset_kernel(int s, int T, int B, int H, int ndir,
+                                                            const float* __restrict__ dcand,
+                                                            const float* __restrict__ wchT,
+                                                            const float* __restrict__ hout,
+                                                            const float* __restrict__ r_in,
+                                                            const int32_t* __restrict__ seq_len,
+                                                            float* __restrict__ dgate, float* __restrict__ dh_acc) {
+  extern __shared__ float ds[];                            // [16][H + 1]: dc_pre of the rows' frames
+  const int d = blockIdx.z, b0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+  const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+  const int LD = H + 1;
+  for (int i = threadIdx.x; i < 16 * H; i += 256) {
+    const int rr = i / H, k = i % H;
+    bool a;
+    const int tt = gru_frame(s, min(seq_len[b0 + rr], T), d, a);
+    ds[rr * LD + k] = a ? dcand[(((size_t)tt * B + b0 + rr) * ndir + d) * H + k] : 0.f;
+  }
+  __syncthreads();
+  const int b = b0 + row, k = c0 + col;
+  const int len = min(seq_len[b], T);
+  bool act;
+  const int t = gru_frame(s, len, d, act);
+  if (!act) return;
+  const float* w = wchT + (size_t)d * H * H + k;
+  const float* dr = ds + row * LD;
+  float acc = 0.f;
+#pragma unroll 8
+  for (int j = 0; j < H; ++j) acc = fmaf(dr[j], w[(size_t)j * H], acc);
+  float hp = 0.f;
+  if (s > 0) {
+    const int tp = d == 1 ? len - s : s - 1;
+    hp = hout[((size_t)tp * B + b) * ndir * H + (size_t)d * H + k];
+  }
+  const size_t o = (((size_t)t * B + b) * ndir + d) * H + k;
+  const float r = r_in[o];
+  dgate[(((size_t)t * B + b) * ndir + d) * 2 * H + k] = acc * hp * r * (1.f - r);   // d r_pre
+  dh_acc[((size_t)d * B + b) * H + k] += acc * r;
+}
+
+// B3: dh_rec'[row][k] = dh_acc[row][k] + sum_j dgate[row][j] W_g[k][j], j over 2H (wghT [ndir][2H j][H k]).
+__global__ __launch_bounds__(256) void gru_bwd_state_kernel(int s, int T, int B, int H, int ndir,
+                                                            const float* __restrict__ dgate,
+                                                            const float* __restrict__ wghT,
+                                                            const float* __restrict__ dh_acc,
+                                                            const int32_t* __restrict__ seq_len,
+                                                            float* __restrict__ dh_rec) {
+  extern __shared__ float gs[];                            // [16][2H + 1]
+  const int d = blockIdx.z, b0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+  const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+  const int G = 2 * H, LD = G + 1;
+  for (int i = threadIdx.x; i < 16 * G; i += 256) {
+    const int rr = i / G, j = i % G;
+    bool a;
+    const int tt = gru_frame(s, min(seq_len[b0 + rr], T), d, a);
+    gs[rr * LD + j] = a ? dgate[(((size_t)tt * B + b0 + rr) * ndir + d) * G + j] : 0.f;
+  }
+  __syncthreads();
+  const int b = b0 + row, k = c0 + col;
+  const size_t so = ((size_t)d * B + b) * H + k;
+  const float* w = wghT + (size_t)d * G * H + k;
+  const float* gr = gs + row * LD;
+  float acc = dh_acc[so];
+#pragma unroll 8
+  for (int j = 0; j < G; ++j) acc = fmaf(gr[j], w[(size_t)j * H], acc);
+  dh_rec[so] = acc;
+}
+
+}  // namespace
+
+#define GRU_NEED(cond, ...) do { if (!(cond)) ASR_FAIL(h, ASR_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
+
+extern "C" int asr_gru_fwd(asr_handle* h, int T, int B, int H, int ndir, const float* xg, const float* xc,
+                           const float* wgh, const float* wch, const int32_t* seq_len, int tmax, float* r, float* u,
+                           float* c, float* rh, float* hout, float* hstate2, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  GRU_NEED(xg && xc && wgh && wch && seq_len && r && u && c && rh && hout && hstate2 && T >= 0 && B > 0 && B % 16 == 0 &&
+               H > 0 && H % 16 == 0 && (ndir == 1 || ndir == 2) && tmax >= 0 && tmax <= T,
+           "asr_gru_fwd: bad args (B=%d and H=%d must be multiples of 16, ndir=%d)", B, H, ndir);
+  const size_t lds = (size_t)16 * (H + 1) * sizeof(float);
+  if (lds > 160 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_gru_fwd: num_units %d too large", H);
+  hipStream_t st = (hipStream_t)s;
+  (void)hipFuncSetAttribute((const void*)gru_gates_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)gru_cand_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t sn = (size_t)ndir * B * H;
+  float* hs[2] = {hstate2, hstate2 + sn};
+  if (hipMemsetAsync(hs[0], 0, sn * sizeof(float), st) != hipSuccess) ASR_FAIL(h, ASR_ERR_HIP, "asr_gru_fwd: memset");
+  // frames [tmax, T) of the output are beyond every utterance: zero
+  if (T > tmax && hipMemsetAsync(hout + (size_t)tmax * B * ndir * H, 0, (size_t)(T - tmax) * B * ndir * H * sizeof(float), st) != hipSuccess)
+    ASR_FAIL(h, ASR_ERR_HIP, "asr_gru_fwd: memset");
+  for (int step = 0; step < tmax; ++step) {
+    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(2 * H / 16, B / 16, ndir), dim3(256), lds, st, step, T, B, H, ndir, xg,
+                       hs[step & 1], wgh, seq_len, r, u, rh);
+    hipLaunchKernelGGL(gru_cand_fwd_kernel, dim3(H / 16, B / 16, ndir), dim3(256), lds, st, step, T, B, H, ndir, xc, rh,
+                       u, wch, hs[step & 1], seq_len, hs[(step + 1) & 1], c, hout);
+  }
+  ASR_CHECK_LAUNCH(h, "asr_gru_fwd");
+  if ((tmax & 1) && tmax > 0 &&
+      hipMemcpyAsync(hs[0], hs[1], sn * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    ASR_FAIL(h, ASR_ERR_HIP, "asr_gru_fwd: copy of the final state");
+  return ASR_OK;                                           // final state: hstate2[0 .. ndir*B*H)
+}
+
+extern "C" int asr_gru_bwd(asr_handle* h, int T, int B, int H, int ndir, const float* dout, const float* d_h_final,
+                           const float* hout, const float* r, const float* u, const float* c, const float* wghT,
+                           const float* wchT, const int32_t* seq_len, int tmax, float* dgate, float* dcand,
+                           float* work2, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  GRU_NEED(dout && hout && r && u && c && wghT && wchT && seq_len && dgate && dcand && work2 && T >= 0 && B > 0 &&
+               B % 16 == 0 && H > 0 && H % 16 == 0 && (ndir == 1 || ndir == 2) && tmax >= 0 && tmax <= T,
+           "asr_gru_bwd: bad args (B=%d and H=%d must be multiples of 16, ndir=%d)", B, H, ndir);
+  const size_t lds = (size_t)16 * (2 * H + 1) * sizeof(float);
+  if (lds > 160 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_gru_bwd: num_units %d too large", H);
+  hipStream_t st = (hipStream_t)s;
+  (void)hipFuncSetAttribute((const void*)gru_bwd_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)gru_bwd_state_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t sn = (size_t)ndir * B * H;
+  float* dh_rec = work2;
+  float* dh_acc = work2 + sn;
+  // pre-activation gradients of frames no row reaches stay zero (the weight-gradient GEMMs run over all T*B rows)
+  if (hipMemsetAsync(dgate, 0, (size_t)T * B * ndir * 2 * H * sizeof(float), st) != hipSuccess ||
+      hipMemsetAsync(dcand, 0, (size_t)T * B * ndir * H * sizeof(float), st) != hipSuccess)
+    ASR_FAIL(h, ASR_ERR_HIP, "asr_gru_bwd: memset");
+  if (d_h_final) {
+    if (hipMemcpyAsync(dh_rec, d_h_final, sn * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      ASR_FAIL(h, ASR_ERR_HIP, "asr_gru_bwd: copy");
+  } else if (hipMemsetAsync(dh_rec, 0, sn * sizeof(float), st) != hipSuccess) {
+    ASR_FAIL(h, ASR_ERR_HIP, "asr_gru_bwd: memset");
+  }
+  const int eb = (int)((sn + 255) / 256 < 1024 ? (sn + 255) / 256 : 1024);
+  const size_t lds1 = (size_t)16 * (H + 1) * sizeof(float);
+  for (int step = tmax - 1; step >= 0; --step) {
+    hipLaunchKernelGGL(gru_bwd_elem_kernel, dim3(eb), dim3(256), 0, st, step, T, B, H, ndir, dout, dh_rec, hout, u, c,
+                       seq_len, dgate, dcand, dh_acc);
+    hipLaunchKernelGGL(gru_bwd_reset_kernel, dim3(H / 16, B / 16, ndir), dim3(256), lds1, st, step, T, B, H, ndir, dcand,
+                       wchT, hout, r, seq_len, dgate, dh_acc);
+    hipLaunchKernelGGL(gru_bwd_state_kernel, dim3(H / 16, B / 16, ndir), dim3(256), lds, st, step, T, B, H, ndir, dgate,
+                       wghT, dh_acc, seq_len, dh_rec);
+  }
+  ASR_CHECK_LAUNCH(h, "asr_gru_bwd");
+  return ASR_OK;
+}

@@ -255,11 +255,13 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
 
   // xproj rows of the running step, requested TWO steps ahead (slot = step parity): one step (~1.2 us) covers the
   // idle HBM latency but not always the latency beside the side streams' traffic (measured: 945 -> 931 us per launch)
-  f32x4_t xq[2][2];
+  // (H = 512 keeps the one-step queue: the second slot costs 8 VGPRs the 8-CU form does not have -- 4 -> 12 spills)
+  constexpr int XD = (H == 256) ? 2 : 1;
+  f32x4_t xq[XD][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     xq[0][r] = xg[(0 < len[r]) ? oa[r] : os[r]];
-    xq[1][r] = (tmax > 1) ? xg[(1 < len[r]) ? oa[r] + dstep : os[r] + stride] : xq[0][r];
+    if constexpr (XD == 2) xq[1][r] = (tmax > 1) ? xg[(1 < len[r]) ? oa[r] + dstep : os[r] + stride] : xq[0][r];
   }
   f32x4_t accn0 = {0.f, 0.f, 0.f, 0.f}, accn1 = {0.f, 0.f, 0.f, 0.f};   // EARLY: own-slice part of the next step
 
@@ -274,10 +276,11 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
     const unsigned long long t0 = C8_T();
     const char* hcur = smem + P * 16 * LDH * 2;
     char* hnxt = smem + (1 - P) * 16 * LDH * 2;
-    const f32x4_t x0 = xq[P][0], x1 = xq[P][1];
-    if (s + 2 < tmax) {                                    // lands during the next step
+    const f32x4_t x0 = xq[P % XD][0], x1 = xq[P % XD][1];
+    if (s + XD < tmax) {                                   // lands during the next step(s)
 #pragma unroll
-      for (int r = 0; r < 2; ++r) xq[P][r] = xg[(s + 2 < len[r]) ? oa[r] + 2u * dstep : os[r] + 2u * stride];
+      for (int r = 0; r < 2; ++r)
+        xq[P % XD][r] = xg[(s + XD < len[r]) ? oa[r] + (unsigned)XD * dstep : os[r] + (unsigned)XD * stride];
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (EARLY) { acc0 = accn0; acc1 = accn1; }    // own-slice chunks: done at the end of the last step

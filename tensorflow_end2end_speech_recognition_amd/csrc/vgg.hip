@@ -51,6 +51,54 @@ __global__ void col2im3x3_kernel(const float* __restrict__ dpatches, int N, int 
   }
 }
 
+// General SAME convolution as im2col + GEMM (the CLDNN front-end, cldnn_wang.py:141-177: 11x21 stride (3,2),
+// 11x11 stride (1,2), 3x3): patches[p, (ky*kw + kx)*Cin + ci] = in[n, yo*sh + ky - pt, xo*sw + kx - pl, ci] (0 outside),
+// p = (n*Ho + yo)*Wo + xo, Ho = ceil(H/sh), pt = max((Ho-1)*sh + kh - H, 0) / 2 (TF puts the odd cell after).
+struct ConvGeo { int N, H, W, Cin, kh, kw, sh, sw, Ho, Wo, pt, pl; };
+template <typename T>
+__global__ void im2col_kernel(const T* __restrict__ in, ConvGeo g, int ldp, T* __restrict__ patches) {
+  const int K = g.kh * g.kw * g.Cin;
+  const size_t total = (size_t)g.N * g.Ho * g.Wo * K;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int kk = idx % K;
+    const size_t p = idx / K;
+    const int ci = kk % g.Cin, tap = kk / g.Cin, kx = tap % g.kw, ky = tap / g.kw;
+    const int xo = p % g.Wo, yo = (p / g.Wo) % g.Ho;
+    const size_t n = p / ((size_t)g.Wo * g.Ho);
+    const int y = yo * g.sh + ky - g.pt, x = xo * g.sw + kx - g.pl;
+    T v = T(0);
+    if (y >= 0 && y < g.H && x >= 0 && x < g.W) v = in[((n * g.H + y) * g.W + x) * g.Cin + ci];
+    patches[p * ldp + kk] = v;
+  }
+}
+// din[n,y,x,ci] = sum over the (ky,kx) whose output pixel exists of dpatches[...]   (gather: no atomics, fixed order)
+__global__ void col2im_kernel(const float* __restrict__ dpatches, ConvGeo g, int ldp, float* __restrict__ din) {
+  const size_t total = (size_t)g.N * g.H * g.W * g.Cin;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int ci = idx % g.Cin;
+    const size_t m = idx / g.Cin;
+    const int x = m % g.W, y = (m / g.W) % g.H;
+    const size_t n = m / ((size_t)g.W * g.H);
+    float s = 0.f;
+    for (int ky = 0; ky < g.kh; ++ky) {
+      const int yy = y + g.pt - ky;
+      if (yy < 0 || yy % g.sh) continue;
+      const int yo = yy / g.sh;
+      if (yo >= g.Ho) continue;
+      for (int kx = 0; kx < g.kw; ++kx) {
+        const int xx = x + g.pl - kx;
+        if (xx < 0 || xx % g.sw) continue;
+        const int xo = xx / g.sw;
+        if (xo >= g.Wo) continue;
+        s += dpatches[((n * g.Ho + yo) * g.Wo + xo) * ldp + (ky * g.kw + kx) * g.Cin + ci];
+      }
+    }
+    din[idx] = s;
+  }
+}
+
 // max_pool 2x2 stride 2 SAME (cnn_util.py:13-28): Ho = ceil(H/2); padding goes AFTER (-inf)
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ in, int N, int H, int W, int C, T* __restrict__ out,
@@ -166,3 +214,45 @@ extern "C" int asr_relu_bwd(asr_handle* h, int dtype, const float* dout, const v
   ASR_CHECK_LAUNCH(h, "asr_relu_bwd");
   return ASR_OK;
 }
+
+static int conv_geo(asr_handle* h, int N, int H, int W, int Cin, int kh, int kw, int sh, int sw, ConvGeo* g) {
+  if (N < 0 || H < 1 || W < 1 || Cin < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_im2col: bad geometry");
+  g->N = N; g->H = H; g->W = W; g->Cin = Cin; g->kh = kh; g->kw = kw; g->sh = sh; g->sw = sw;
+  g->Ho = (H + sh - 1) / sh;
+  g->Wo = (W + sw - 1) / sw;
+  const int ph = (g->Ho - 1) * sh + kh - H, pw = (g->Wo - 1) * sw + kw - W;
+  g->pt = (ph > 0 ? ph : 0) / 2;
+  g->pl = (pw > 0 ? pw : 0) / 2;
+  return ASR_OK;
+}
+extern "C" int asr_im2col(asr_handle* h, int dtype, const void* in, int N, int H, int W, int Cin, int kh, int kw, int sh,
+                          int sw, int ldp, void* patches, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ConvGeo g;
+  const int rc = conv_geo(h, N, H, W, Cin, kh, kw, sh, sw, &g);
+  if (rc != ASR_OK) return rc;
+  if (!asr_dtype_ok(dtype) || !in || !patches || ldp < kh * kw * Cin) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_im2col: bad args");
+  const size_t total = (size_t)N * g.Ho * g.Wo * kh * kw * Cin;
+  if (!total) return ASR_OK;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == ASR_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)in, g, ldp, (float*)patches);
+  else hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, g, ldp, (bf16_t*)patches);
+  ASR_CHECK_LAUNCH(h, "asr_im2col");
+  return ASR_OK;
+}
+extern "C" int asr_col2im(asr_handle* h, const float* dpatches, int N, int H, int W, int Cin, int kh, int kw, int sh,
+                          int sw, int ldp, float* din, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ConvGeo g;
+  const int rc = conv_geo(h, N, H, W, Cin, kh, kw, sh, sw, &g);
+  if (rc != ASR_OK) return rc;
+  if (!dpatches || !din || ldp < kh * kw * Cin) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_col2im: bad args");
+  const size_t total = (size_t)N * H * W * Cin;
+  if (!total) return ASR_OK;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(col2im_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dpatches, g, ldp, din);
+  ASR_CHECK_LAUNCH(h, "asr_col2im");
+  return ASR_OK;
+}
+

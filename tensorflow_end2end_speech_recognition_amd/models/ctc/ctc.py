@@ -89,6 +89,8 @@ class CTC(ModelBase):
         self.time_major = time_major
         self.name = encoder_type + '_ctc'
         self.dtype = ops.dtype_id(dtype)
+        if encoder_type in ('gru', 'bgru'):
+            self.dtype = ASR_F32                         # the GRU recurrence kernels are fp32: the heads follow
         self.device = torch.device(device)
         self._dropout_calls = 0
         self.seed = seed
@@ -114,12 +116,15 @@ class CTC(ModelBase):
                 num_units=num_units, num_proj=self.num_proj, num_layers=num_layers,
                 lstm_impl=lstm_impl, use_peephole=use_peephole, parameter_init=parameter_init,
                 clip_activation=clip_activation, time_major=True, dtype=self.dtype)
-        if encoder_type in ['vgg_blstm', 'vgg_lstm']:
+        if encoder_type in ['vgg_blstm', 'vgg_lstm', 'cldnn_wang']:
             return load(encoder_type)(
                 input_size=input_size, splice=splice, num_stack=num_stack, num_units=num_units,
                 num_proj=self.num_proj, num_layers=num_layers, lstm_impl=lstm_impl,
                 use_peephole=use_peephole, parameter_init=parameter_init,
                 clip_activation=clip_activation, time_major=True, dtype=self.dtype)
+        if encoder_type in ['bgru', 'gru']:              # ctc.py:150-155
+            return load(encoder_type)(num_units=num_units, num_layers=num_layers, parameter_init=parameter_init,
+                                      time_major=True)
         load(encoder_type)  # ValueError for unknown keys, as load_encoder.py:53-56
         raise NotImplementedError
 

@@ -344,6 +344,34 @@ def col2im3x3(dpatches, N, H, W, Cin):
     return din
 
 
+def conv_out_hw(H, W, sh, sw):
+    return (H + sh - 1) // sh, (W + sw - 1) // sw
+
+
+def im2col(x_nhwc, kh, kw, sh, sw, ldp=None):
+    """[N,H,W,Cin] -> patches [N*Ho*Wo, ldp] of a SAME convolution with any kernel / stride (columns past
+    kh*kw*Cin zero)."""
+    h = _h(x_nhwc)
+    dt = dtype_id(x_nhwc.dtype)
+    N, H, W, Cin = x_nhwc.shape
+    Ho, Wo = conv_out_hw(H, W, sh, sw)
+    K = kh * kw * Cin
+    ldp = ldp or K
+    out = torch.zeros((N * Ho * Wo, ldp), dtype=x_nhwc.dtype, device=x_nhwc.device) if ldp > K else \
+        torch.empty((N * Ho * Wo, ldp), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    h.check(h.lib.asr_im2col(h.h, dt, _p(x_nhwc), N, H, W, Cin, kh, kw, sh, sw, ldp, _p(out), _s()), 'asr_im2col')
+    return out
+
+
+def col2im(dpatches, N, H, W, Cin, kh, kw, sh, sw):
+    h = _h(dpatches)
+    _chk(dpatches, torch.float32, 'dpatches')
+    din = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dpatches.device)
+    h.check(h.lib.asr_col2im(h.h, _p(dpatches), N, H, W, Cin, kh, kw, sh, sw, dpatches.stride(0), _p(din), _s()),
+            'asr_col2im')
+    return din
+
+
 def maxpool2x2_fwd(x_nhwc):
     h = _h(x_nhwc)
     dt = dtype_id(x_nhwc.dtype)
@@ -482,6 +510,40 @@ def lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c
                                _p(wh_packed_bwd), _p(peep), _p(seq_len), _p(d_c_final), _p(d_h_final),
                                _p(dgates), _p(dpeep), _p(ws), _s()), 'asr_lstm_bwd')
     return dgates, dpeep
+
+
+def gru_fwd(xg, xc, wgh, wch, seq_len, tmax, H, ndir):
+    """xg [T,B,ndir*2H], xc [T,B,ndir*H] fp32 (hoisted x-projections + biases); wgh [ndir,H,2H], wch [ndir,H,H].
+    Returns dict(r, u, c, rh [T,B,ndir*H] each, hout [T,B,ndir*H], h_final [ndir,B,H])."""
+    h = _h(xg)
+    _chk(xg, torch.float32, 'xg')
+    _chk(seq_len, torch.int32, 'seq_len')
+    T, B, G = xg.shape
+    if G != ndir * 2 * H or tuple(xc.shape) != (T, B, ndir * H):
+        raise ValueError('gru_fwd: xg / xc shapes do not match ndir, H')
+    dev = xg.device
+    out = {k: torch.empty((T, B, ndir * H), dtype=torch.float32, device=dev) for k in ('r', 'u', 'c', 'rh', 'hout')}
+    hs = torch.empty((2, ndir, B, H), dtype=torch.float32, device=dev)
+    h.check(h.lib.asr_gru_fwd(h.h, T, B, H, ndir, _p(xg), _p(xc), _p(wgh), _p(wch), _p(seq_len), int(tmax),
+                              _p(out['r']), _p(out['u']), _p(out['c']), _p(out['rh']), _p(out['hout']), _p(hs), _s()),
+            'asr_gru_fwd')
+    out['h_final'] = hs[0]
+    return out
+
+
+def gru_bwd(dout, d_h_final, saved, wghT, wchT, seq_len, tmax, H, ndir):
+    """dout [T,B,ndir*H] fp32 -> (dgate [T,B,ndir*2H], dcand [T,B,ndir*H]) pre-activation gradients."""
+    h = _h(dout)
+    _chk(dout, torch.float32, 'dout')
+    T, B, _ = dout.shape
+    dev = dout.device
+    dgate = torch.empty((T, B, ndir * 2 * H), dtype=torch.float32, device=dev)
+    dcand = torch.empty((T, B, ndir * H), dtype=torch.float32, device=dev)
+    work = torch.empty((2, ndir, B, H), dtype=torch.float32, device=dev)
+    h.check(h.lib.asr_gru_bwd(h.h, T, B, H, ndir, _p(dout), _p(d_h_final), _p(saved['hout']), _p(saved['r']),
+                              _p(saved['u']), _p(saved['c']), _p(wghT), _p(wchT), _p(seq_len), int(tmax), _p(dgate),
+                              _p(dcand), _p(work), _s()), 'asr_gru_bwd')
+    return dgate, dcand
 
 
 def check_async_errors(device=0):

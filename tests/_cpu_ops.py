@@ -206,6 +206,62 @@ def _lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_
     return dgates, dpeep
 
 
+def _gru_dir(xg, xc, wgh, wch, sl, reverse):
+    T, B, _ = xg.shape
+    H = wch.shape[0]
+    if reverse:
+        xg, xc = olstm.reverse_sequence(xg, sl), olstm.reverse_sequence(xc, sl)
+    h = xg.new_zeros(B, H)
+    outs, rhs = [], []
+    for t in range(T):
+        act = (t < sl).to(xg.dtype).unsqueeze(1)
+        g = torch.sigmoid(xg[t] + h @ wgh)
+        r, u = g[:, :H], g[:, H:]
+        rh = r * h
+        c = torch.tanh(xc[t] + rh @ wch)
+        hn = u * h + (1 - u) * c
+        outs.append(act * hn)
+        rhs.append(act * rh)
+        h = act * hn + (1 - act) * h
+    out, rhv = torch.stack(outs), torch.stack(rhs)
+    if reverse:
+        out, rhv = olstm.reverse_sequence(out, sl), olstm.reverse_sequence(rhv, sl)
+    return out, rhv, h
+
+
+def _gru_fwd(xg, xc, wgh, wch, seq_len, tmax, H, ndir):
+    T, B, G = xg.shape
+    if G != ndir * 2 * H or tuple(xc.shape) != (T, B, ndir * H):
+        raise ValueError('gru_fwd: xg / xc shapes do not match ndir, H')
+    sl = seq_len.long()
+    runs, outs, rhs, hfs = [], [], [], []
+    for d in range(ndir):
+        a = xg[:, :, d * 2 * H:(d + 1) * 2 * H].double().clone().requires_grad_(True)
+        b = xc[:, :, d * H:(d + 1) * H].double().clone().requires_grad_(True)
+        out, rhv, hf = _gru_dir(a, b, wgh[d].double(), wch[d].double(), sl, d == 1)
+        runs.append(dict(xg=a, xc=b, out=out, hf=hf))
+        outs.append(out.detach())
+        rhs.append(rhv.detach())
+        hfs.append(hf.detach())
+    z = torch.zeros((T, B, ndir * H))
+    hout = torch.cat(outs, 2).float().contiguous()
+    return dict(r=z, u=z.clone(), c=z.clone(), rh=torch.cat(rhs, 2).float().contiguous(), hout=hout,
+                h_final=torch.stack(hfs).float(), _runs=runs)
+
+
+def _gru_bwd(dout, d_h_final, saved, wghT, wchT, seq_len, tmax, H, ndir):
+    T, B, _ = dout.shape
+    dgate = torch.zeros((T, B, ndir * 2 * H))
+    dcand = torch.zeros((T, B, ndir * H))
+    for d, r in enumerate(saved['_runs']):
+        gos = [dout[:, :, d * H:(d + 1) * H].double(),
+               d_h_final[d].double() if d_h_final is not None else torch.zeros_like(r['hf'])]
+        ga, gb = torch.autograd.grad([r['out'], r['hf']], [r['xg'], r['xc']], grad_outputs=gos)
+        dgate[:, :, d * 2 * H:(d + 1) * 2 * H] = ga.float()
+        dcand[:, :, d * H:(d + 1) * H] = gb.float()
+    return dgate, dcand
+
+
 def _labels_list(labels_flat, label_offsets, B):
     flat = labels_flat.cpu().numpy()
     off = label_offsets.cpu().numpy()
@@ -517,6 +573,32 @@ def _col2im3x3(dpatches, N, H, W, Cin):
     return din[:, 1:H + 1, 1:W + 1].float().contiguous()
 
 
+def _conv_geo(H, W, kh, kw, sh, sw):
+    Ho, Wo = (H + sh - 1) // sh, (W + sw - 1) // sw
+    ph, pw = max((Ho - 1) * sh + kh - H, 0), max((Wo - 1) * sw + kw - W, 0)
+    return Ho, Wo, ph // 2, ph - ph // 2, pw // 2, pw - pw // 2
+
+
+def _im2col(x_nhwc, kh, kw, sh, sw, ldp=None):
+    N, H, W, Cin = x_nhwc.shape
+    Ho, Wo, pt, pb, pl, pr = _conv_geo(H, W, kh, kw, sh, sw)
+    xp = torch.nn.functional.pad(x_nhwc.permute(0, 3, 1, 2).double(), (pl, pr, pt, pb))
+    cols = torch.nn.functional.unfold(xp, (kh, kw), stride=(sh, sw))         # [N, Cin*kh*kw, Ho*Wo], (ci, ky, kx) major
+    cols = cols.view(N, Cin, kh * kw, Ho * Wo).permute(0, 3, 2, 1).reshape(N * Ho * Wo, kh * kw * Cin)
+    K = kh * kw * Cin
+    out = torch.zeros((N * Ho * Wo, ldp or K))
+    out[:, :K] = cols.float()
+    return out
+
+
+def _col2im(dpatches, N, H, W, Cin, kh, kw, sh, sw):
+    Ho, Wo, pt, pb, pl, pr = _conv_geo(H, W, kh, kw, sh, sw)
+    K = kh * kw * Cin
+    cols = dpatches[:, :K].double().reshape(N, Ho * Wo, kh * kw, Cin).permute(0, 3, 2, 1).reshape(N, Cin * kh * kw, Ho * Wo)
+    xp = torch.nn.functional.fold(cols, (H + pt + pb, W + pl + pr), (kh, kw), stride=(sh, sw))
+    return xp[:, :, pt:pt + H, pl:pl + W].permute(0, 2, 3, 1).float().contiguous()
+
+
 def _maxpool2x2_fwd(x_nhwc):
     """2x2 stride 2 SAME: odd edges are padded at the bottom / right (never selected)."""
     N, H, W, Cc = x_nhwc.shape
@@ -538,7 +620,7 @@ def _maxpool2x2_bwd(dout, arg, H, W):
 
 STAND_INS = dict(
     side_lane=_NullLane, join_side=lambda device: None, stream_event=lambda: None, wait_event=lambda ev: None,
-    lstm_prep_layer=_lstm_prep_layer, lstm_grad_finish=_lstm_grad_finish, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
+    gru_fwd=_gru_fwd, gru_bwd=_gru_bwd, lstm_prep_layer=_lstm_prep_layer, lstm_grad_finish=_lstm_grad_finish, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
     cast_from_f32=_cast_from_f32, cast_to_f32=_cast_to_f32, apply_mask=_apply_mask, dropout_mask=_dropout_mask,
     colsum=_colsum, gemm=_gemm, relu_bwd=_relu_bwd, lstm_prep_weights=_lstm_prep_weights,
     gate_deinterleave=_gate_deinterleave, lstm_fwd=_lstm_fwd, lstm_bwd=_lstm_bwd, ctc_loss=_ctc_loss,
@@ -550,7 +632,7 @@ STAND_INS = dict(
     att_loc_energy_fwd=_att_loc_energy_fwd, att_loc_energy_bwd=_att_loc_energy_bwd,
     embedding_gather=_embedding_gather, embedding_scatter=_embedding_scatter, seq_xent=_seq_xent,
     argmax_rows=_argmax_rows, im2col3x3=_im2col3x3, col2im3x3=_col2im3x3, maxpool2x2_fwd=_maxpool2x2_fwd,
-    maxpool2x2_bwd=_maxpool2x2_bwd,
+    maxpool2x2_bwd=_maxpool2x2_bwd, im2col=_im2col, col2im=_col2im,
 )
 
 

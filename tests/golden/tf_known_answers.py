@@ -84,3 +84,13 @@ CONV_1X2_FILTER_SHAPE, CONV_1X2_OUT = (1, 2, 3, 3), [231.0, 252.0, 273.0, 384.0,
 # tf.nn.max_pool 2x2 stride 2 SAME on an odd width: tensorflow/python/kernel_tests/pooling_ops_test.py,
 # testMaxPoolSamePadding -- input [1,2,3,3] = 1..18: the extra column is padded AFTER.
 POOL_SAME_OUT = [13.0, 14.0, 15.0, 16.0, 17.0, 18.0]
+
+# tensorflow/contrib/rnn/python/kernel_tests/core_rnn_cell_test.py::testGRUCell (TF 1.x): every kernel entry 0.5
+# (variable_scope initializer), gate bias 1 and candidate bias 0 (the cell's own initializers), h = [0.1, 0.1]:
+#   x = [1, 1]    -> new h = [0.175991, 0.175991]
+#   x = [1, 1, 1] -> new h = [0.156736, 0.156736]
+GRU_CASES = [
+    dict(x=[1.0, 1.0], h=[0.1, 0.1], kernel=0.5, out=[0.175991, 0.175991]),
+    dict(x=[1.0, 1.0, 1.0], h=[0.1, 0.1], kernel=0.5, out=[0.156736, 0.156736]),
+]
+

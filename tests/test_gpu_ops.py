@@ -532,6 +532,36 @@ def test_bt_to_tb_padded_rows(cuda):
         assert torch.equal(ops.bt_to_tb(x, dt), x.transpose(0, 1).to(tdt).contiguous())
 
 
+@pytest.mark.parametrize('N,H,W,Cin,kh,kw,sh,sw', [(5, 40, 11, 3, 11, 21, 3, 2), (4, 14, 6, 32, 11, 11, 1, 2),
+                                                   (3, 14, 3, 32, 3, 3, 1, 1), (2, 7, 5, 3, 11, 21, 3, 2), (3, 9, 8, 4, 2, 4, 2, 3)])
+def test_im2col_col2im_any_kernel_and_stride(cuda, N, H, W, Cin, kh, kw, sh, sw):
+    """asr_im2col / asr_col2im (SAME convolution of any kernel / stride as a GEMM: the CLDNN front-end) against
+    torch's conv2d with TensorFlow's SAME padding made explicit: forward through a GEMM with random filters, input
+    gradient through col2im; bf16 patches are the bf16 rounding of the fp32 ones."""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(N * H + kw)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    wgt = torch.randn(kh, kw, Cin, 6, generator=g)
+    Ho, Wo = ops.conv_out_hw(H, W, sh, sw)
+    ph, pw = max((Ho - 1) * sh + kh - H, 0), max((Wo - 1) * sw + kw - W, 0)
+    xt = x.permute(0, 3, 1, 2).double().clone().requires_grad_(True)
+    xp = torch.nn.functional.pad(xt, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    ref = torch.nn.functional.conv2d(xp, wgt.permute(3, 2, 0, 1).double(), stride=(sh, sw))        # [N,6,Ho,Wo]
+    assert ref.shape[2:] == (Ho, Wo)
+    K = kh * kw * Cin
+    patches = ops.im2col(x.to(cuda), kh, kw, sh, sw, ldp=(K + 7) // 8 * 8)
+    assert patches.shape == (N * Ho * Wo, (K + 7) // 8 * 8) and not patches[:, K:].abs().sum().item()
+    out = patches[:, :K].double().cpu() @ wgt.reshape(K, 6).double()
+    assert (out.view(N, Ho, Wo, 6).permute(0, 3, 1, 2) - ref.detach()).abs().max() < 1e-5
+    pb = ops.im2col(x.to(cuda).to(torch.bfloat16), kh, kw, sh, sw)
+    assert torch.equal(pb, patches[:, :K].to(torch.bfloat16))
+    dout = torch.randn(N * Ho * Wo, 6, generator=g)
+    ref.backward(dout.view(N, Ho, Wo, 6).permute(0, 3, 1, 2).double())
+    dpat = (dout.double() @ wgt.reshape(K, 6).double().t()).float()
+    din = ops.col2im(dpat.to(cuda), N, H, W, Cin, kh, kw, sh, sw)
+    assert (din.cpu().double() - xt.grad.permute(0, 2, 3, 1)).abs().max() < 1e-4
+
+
 # --------------------------------------------------------------------------- CTC
 def _ctc_case(rng, T, B, C, lmax, scale=2.0):
     logits = (rng.randn(T, B, C) * scale).astype(np.float32)

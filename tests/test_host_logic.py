@@ -74,6 +74,85 @@ def test_ctc_model_host_logic(monkeypatch, enc, L, bn, wd):
     assert 0.0 <= model.compute_ler(dec, list2sparsetensor(dense, -1))
 
 
+@pytest.mark.parametrize('enc,L', [('bgru', 2), ('gru', 2), ('bgru', 1)])
+def test_gru_ctc_model_host_logic(monkeypatch, enc, L):
+    """CTC(encoder_type='gru' | 'bgru') (models/ctc/ctc.py:150-155, models/encoders/core/gru.py) on the CPU stand-ins
+    against the oracle's GRU model: loss, logits, every gradient (the hoisted x-projections, the shifted h_prev /
+    same-frame r*h weight-gradient products, bias column sums, dx through both kernels), final states, one step."""
+    _cpu_ops.install(monkeypatch)
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    rng = np.random.RandomState(6)
+    B, T, D, H, C = 5, 10, 6, 16, 6
+    x, sl, labs, dense = _batch(rng, B, T, D, C)
+    ndir = 2 if enc == 'bgru' else 1
+    model = CTC(encoder_type=enc, input_size=D, num_units=H, num_layers=L, num_classes=C, parameter_init=0.3,
+                clip_grad_norm=5.0, dtype='bf16', seed=3, device='cpu')      # dtype request falls back to fp32
+    sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    assert all(np.all(sd[k] == 1.0) for k in sd if k.endswith('gates/bias'))   # GRUCell: gate bias starts at one
+    for k in sd:
+        if k.endswith('/bias') or k.endswith('/biases'):
+            sd[k] = sd[k] + (rng.randn(*sd[k].shape) * 0.05).astype(np.float32)
+    model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    ref = omodel.gru_ctc_model_forward(sd, x, labs, sl, L, ndir=ndir)
+    loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-5
+    assert np.abs(logits.numpy() - ref['logits']).max() < 1e-5
+    fin = model.encoder._finals[-1]
+    want = ref['final'] if ndir == 2 else (ref['final'],)
+    for d in range(ndir):
+        assert np.abs(fin[d, :B].numpy() - want[d].detach().numpy()).max() < 1e-5
+    opt = model._set_optimizer('sgd', 0.1)
+    _check_grads(opt, loss, model, ref)
+    # dropout masks (given explicitly) and one optimizer step
+    masks = [torch.tensor((rng.rand(T, 16, ndir * H) < 0.8) / 0.8, dtype=torch.float32) for _ in range(L)]
+    refd = omodel.gru_ctc_model_forward(sd, x, labs, sl, L, ndir=ndir,
+                                        drop_masks=[m[:, :B].double() for m in masks])
+    model.encoder(torch.tensor(x), torch.tensor(sl), 0.8, True, drop_masks=masks)
+    assert np.abs(model.encoder._out_tm[:, :B].numpy() - refd['enc']).max() < 1e-5
+    loss, _ = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    model.train(loss, 'adam', 1e-2)
+    loss2, _ = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    assert loss2.item() < loss.item()
+
+
+def test_cldnn_ctc_model_host_logic(monkeypatch):
+    """CTC(encoder_type='cldnn_wang') (models/encoders/core/cldnn_wang.py) on the CPU stand-ins against the oracle:
+    the three strided SAME convolutions as im2col + GEMM (chunked over frames), the BLSTM stack on their flattened
+    output, fc1 / fc2, and every gradient back through col2im."""
+    _cpu_ops.install(monkeypatch)
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    from tensorflow_end2end_speech_recognition_amd.models.encoders.core import cldnn_wang
+    monkeypatch.setattr(cldnn_wang, 'CHUNK_FRAMES', 7)              # several chunks, the last one partial
+    rng = np.random.RandomState(9)
+    B, T, F, W, H, L, C = 3, 6, 7, 5, 8, 1, 5
+    D = F * W * 3
+    x, sl, labs, dense = _batch(rng, B, T, D, C, div=3)
+    model = CTC(encoder_type='cldnn_wang', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
+                parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='f32', seed=4, device='cpu')
+    sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    assert sd['CNN1/conv/weight'].shape == (11, 21, 3, 32) and sd['CNN2/conv/weight'].shape == (11, 11, 32, 32)
+    assert sd['CNN3/conv/weight'].shape == (3, 3, 32, 96) and sd['fc1/weights'].shape == (2 * H, 896)
+    assert sd['fc2/weights'].shape == (896, 74) and sd['output/weights'].shape == (74, C + 1)
+    for k in sd:
+        if k.endswith('/bias') or k.endswith('/biases'):
+            sd[k] = (rng.randn(*sd[k].shape) * 0.05 + 0.02).astype(np.float32)
+    model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    ref = omodel.cldnn_ctc_model_forward(sd, x, labs, sl, L, F, W, cell_clip=50.0)
+    loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-5
+    assert np.abs(logits.numpy() - ref['logits']).max() < 1e-5
+    assert np.abs(model.encoder._out_tm[:, :B].numpy() - ref['enc']).max() < 1e-5
+    opt = model._set_optimizer('sgd', 0.1)
+    _check_grads(opt, loss, model, ref)
+    # dropout path runs and a training step lowers the loss
+    l0 = None
+    for it in range(6):
+        l, _ = model.compute_loss(x, dense, sl, keep_prob=0.9)
+        model.train(l, 'adam', 2e-3)
+        l0 = l.item() if l0 is None else l0
+    assert l.item() < l0
+
+
 @pytest.mark.parametrize('enc,L,bn', [('blstm', 3, None), ('lstm', 2, 12)])
 def test_bucketed_gradient_averaging_is_the_single_bucket_arithmetic(monkeypatch, enc, L, bn):
     """utils/training/multi_gpu.BucketedAverager (clip + tower mean per encoder layer as soon as the layer's gradients

@@ -432,3 +432,41 @@ def test_lstm_explicit_bptt_matches_autograd(reverse, clip, peep):
                               use_peephole=peep, h_round=olstm.bf16_round_t)
     f2 = olstm.layer_forward_np(xr, lens, pn, reverse, 1.0, clip, peep, round_fn=olstm.bf16_round)
     assert np.abs(f2['hout'] - o2.numpy()).max() < 1e-12
+
+
+def test_gru_cell_matches_tensorflow_known_answer():
+    """oracle.gru.gru_cell against the constants of TensorFlow's core_rnn_cell_test.py::testGRUCell: pins the GRUCell
+    equations (reset gate before the candidate's matrix product, h' = u h + (1-u) c, gate bias 1, candidate bias 0)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import gru as ogru
+    for case in tfk.GRU_CASES:
+        D, H = len(case['x']), len(case['h'])
+        p = dict(wg=torch.full((D + H, 2 * H), case['kernel'], dtype=torch.float64), bg=torch.ones(2 * H, dtype=torch.float64),
+                 wc=torch.full((D + H, H), case['kernel'], dtype=torch.float64), bc=torch.zeros(H, dtype=torch.float64))
+        out = ogru.gru_cell(torch.tensor([case['x']], dtype=torch.float64), torch.tensor([case['h']], dtype=torch.float64), p)
+        assert np.abs(out.numpy()[0] - np.array(case['out'])).max() < 1e-6
+
+
+def test_gru_dynamic_rnn_masking_and_reverse():
+    """sequence_length handling of the GRU oracle: outputs past the length are zero, the final state is the state at
+    the last valid frame, and the backward direction of an utterance equals the forward direction of its reversal."""
+    from oracle import gru as ogru
+    rng = np.random.RandomState(3)
+    T, B, D, H = 7, 3, 4, 5
+    p = dict(wg=torch.tensor(rng.randn(D + H, 2 * H) * 0.4), bg=torch.tensor(rng.randn(2 * H) * 0.1 + 1),
+             wc=torch.tensor(rng.randn(D + H, H) * 0.4), bc=torch.tensor(rng.randn(H) * 0.1))
+    x = torch.tensor(rng.randn(T, B, D))
+    sl = torch.tensor([7, 4, 2])
+    out, hf = ogru.dynamic_rnn(x, sl, p)
+    for b in range(B):
+        n = int(sl[b])
+        assert float(out[n:, b].abs().sum()) == 0.0
+        assert torch.allclose(hf[b], out[n - 1, b])
+        alone, hfa = ogru.dynamic_rnn(x[:n, b:b + 1], torch.tensor([n]), p)
+        assert torch.allclose(alone[:, 0], out[:n, b], atol=1e-12)
+        rev, hfr = ogru.dynamic_rnn(x[:, b:b + 1], sl[b:b + 1], p, reverse=True)
+        flipped, hff = ogru.dynamic_rnn(torch.flip(x[:n, b:b + 1], [0]), torch.tensor([n]), p)
+        assert torch.allclose(rev[:n, 0], torch.flip(flipped[:, 0], [0]), atol=1e-12) and torch.allclose(hfr, hff, atol=1e-12)
+
