@@ -506,6 +506,42 @@ def test_encoder_shape_table(monkeypatch, encoder_type):
             assert float(o[2, 2:].abs().max()) == 0.0 and float(o[1, 5:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('encoder_type', ['gru', 'bgru', 'cldnn_wang'])
+def test_encoder_shape_table_gru_and_cldnn(monkeypatch, encoder_type):
+    """models/test/test_encoder.py:130-314 for the remaining registry keys: GRU / BGRU outputs (B, T, ndir*H) with one
+    state per layer (MultiRNNCell) / (fw, bw) of the last layer, each (B, H); CLDNN outputs (B, T, 74)."""
+    _cpu_ops.install(monkeypatch)
+    from tensorflow_end2end_speech_recognition_amd.models.encoders.load_encoder import load
+    rng = np.random.RandomState(0)
+    B, T, H, L = 3, 7, 16, 2
+    sl = torch.tensor([7, 5, 2], dtype=torch.int32)
+    for time_major in (True, False):
+        if encoder_type == 'cldnn_wang':
+            F, W = 7, 5
+            x = torch.tensor(rng.randn(B, T, F * W * 3).astype(np.float32))
+            enc = load(encoder_type)(input_size=3 * F, splice=W, num_stack=1, num_units=H, num_proj=None, num_layers=L,
+                                     lstm_impl='LSTMBlockCell', use_peephole=True, parameter_init=0.1,
+                                     clip_activation=50, time_major=time_major)
+            width = 74
+        else:
+            x = torch.tensor(rng.randn(B, T, 6).astype(np.float32))
+            enc = load(encoder_type)(num_units=H, num_layers=L, parameter_init=0.1, time_major=time_major)
+            width = H * (2 if encoder_type == 'bgru' else 1)
+        outs, final = enc(x, sl, 0.9, True)
+        assert tuple(outs.shape) == ((T, B, width) if time_major else (B, T, width))
+        if encoder_type == 'gru':
+            assert len(final) == L and all(tuple(f.shape) == (B, H) for f in final)
+        elif encoder_type == 'bgru':
+            assert len(final) == 2 and all(tuple(f.shape) == (B, H) for f in final)
+        else:
+            assert len(final) == 2 and all(tuple(f.c.shape) == (B, H) for f in final)
+        if encoder_type != 'cldnn_wang':          # the DNN on top of the CLDNN stack maps a zero frame to relu(bias)
+            o = outs if not time_major else outs.transpose(0, 1)
+            assert float(o[2, 2:].abs().max()) == 0.0 and float(o[1, 5:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        load('pyramid_blstm')
+
+
 def test_overfit_one_utterance_like_the_reference_model_tests(monkeypatch):
     """models/test/test_ctc.py:170-233 and test_attention.py:107-226: one utterance repeated B times, train until
     the label error rate of the decode drops below 0.1 (the reference's only pass criterion; it allows 1000 steps).
