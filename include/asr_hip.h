@@ -66,6 +66,11 @@ const char* asr_last_error_string(asr_handle* h);
  * 0 .. (B/16)*ndir-1 and whose per-step hand-off goes through those XCDs' L2 (workgroup b of a 1-D grid runs on XCD
  * b % 8; workgroups that land on a skipped XCD retire at once).  Results are identical for every n. */
 int asr_set_xcd_skip(asr_handle* h, int n);
+/* Workgroups (output tiles x split-K slabs) the lean reduction-major GEMM (X^T dG, K = T*B) aims at on this handle;
+ * 0 = the default (~2 per CU).  Weight-gradient GEMMs issued beside a recurrence kernel are given few (32: no split-K
+ * slabs at all): they have a millisecond to finish and their slab traffic is what slows the recurrence down.  Results
+ * differ only in the summation order of the K slabs (fixed for a given n: run-to-run deterministic). */
+int asr_set_gemm_tn_workgroups(asr_handle* h, int n);
 /* number of CUs / device name (for bench reporting) */
 int asr_device_info(asr_handle* h, int* num_cu, char* name, int name_len);
 

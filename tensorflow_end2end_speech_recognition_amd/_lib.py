@@ -24,6 +24,7 @@ SIGNATURES = {
     'asr_scratch_bytes': (_sz, [_vp]),
     'asr_destroy': (_i, [_vp]),
     'asr_set_xcd_skip': (_i, [_vp, _i]),
+    'asr_set_gemm_tn_workgroups': (_i, [_vp, _i]),
     'asr_last_error_string': (C.c_char_p, [_vp]),
     'asr_device_info': (_i, [_vp, C.POINTER(_i), C.c_char_p, _i]),
     'asr_bt_to_tb': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),

@@ -21,6 +21,8 @@ struct asr_handle {
   int xch_next;
   // side-stream handles: number of leading XCDs the lean weight-gradient GEMM leaves to the recurrence clusters
   int xcd_skip;
+  // workgroups the lean reduction-major GEMM aims at (0 = default 512); see asr_set_gemm_tn_workgroups
+  int tn_wgs;
 };
 
 #define ASR_FAIL(h, code, ...)                                  \

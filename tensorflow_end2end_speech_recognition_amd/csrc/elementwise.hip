@@ -27,6 +27,7 @@ extern "C" int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes)
   h->xch_dirty[0] = h->xch_dirty[1] = 0;
   h->xch_next = 0;
   h->xcd_skip = 0;
+  h->tn_wgs = 0;
   if (hipMalloc(&h->scratch, h->scratch_bytes) != hipSuccess) {
     delete h;
     return ASR_ERR_HIP;
@@ -43,6 +44,11 @@ extern "C" int asr_destroy(asr_handle* h) {
 extern "C" int asr_set_xcd_skip(asr_handle* h, int n) {
   if (!h || n < 0 || n > 6) return ASR_ERR_INVALID_ARG;
   h->xcd_skip = n;
+  return ASR_OK;
+}
+extern "C" int asr_set_gemm_tn_workgroups(asr_handle* h, int n) {
+  if (!h || n < 0) return ASR_ERR_INVALID_ARG;
+  h->tn_wgs = n;
   return ASR_OK;
 }
 extern "C" const char* asr_last_error_string(asr_handle* h) { return h ? h->err : "null handle"; }

@@ -11,6 +11,7 @@
 // distinct banks); global loads are 16 B per lane along whichever dimension is
 // contiguous in memory, register-staged so the next tile's loads fly during the MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -850,7 +851,11 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
     if (transA && !transB && K >= 2048 && M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
         ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0) {
       const int tm = (M + 127) / 128, tn = (N + 127) / 128;
-      int S = (512 + tm * tn - 1) / (tm * tn);             // aim at ~2 workgroups per CU (what its LDS allows)
+      // workgroups (output tiles x split-K slabs) to aim at: ~2 per CU by default; a handle whose GEMMs run BESIDE a
+      // recurrence kernel asks for few (asr_set_gemm_tn_workgroups): the slabs' write + re-read traffic is what stretches
+      // the recurrence (BPTT launch 1340 / 1307 / 1285 / 1256 us with 1024 / 512 / 128 / 32 workgroups per GEMM)
+      const int tn_wgs = h->tn_wgs > 0 ? h->tn_wgs : 512;
+      int S = (tn_wgs + tm * tn - 1) / (tm * tn);
       const int maxS = (K + 255) / 256;
       if (S > maxS) S = maxS;
       if (S > 256) S = 256;

@@ -170,7 +170,7 @@ class _RecurrentEncoderBase(object):
             if d_outputs_sub is not None and li - 1 == self.num_layers_sub - 1:
                 below = None
             dx = self.layers[li].backward(dx.contiguous(), dcf, dhf, need_dx=(li > 0 or need_input_grad),
-                                          dout_masked=masked, dx_mask=below)
+                                          dout_masked=masked, dx_mask=below, background=(li > 0))
             masked = below is not None
             if self.grad_ready_hook is not None:      # data-parallel step: this layer's gradients are on their way
                 self.grad_ready_hook(li, self.layers[li])

@@ -107,11 +107,14 @@ class LSTMLayer(object):
                             seq_len=seq_len, dtype=dtype, mask=mask, wx_cat=prep['wx_cat'])
         return out, (cf, hf)
 
-    def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True, dout_masked=False, dx_mask=None):
+    def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True, dout_masked=False, dx_mask=None,
+                 background=False):
         """dout [T,B,ndir*H] fp32 -> dx [T,B,din] fp32 (or None).  Fills store.grad.
         dout_masked: the caller has already multiplied dout with this layer's dropout mask.
         dx_mask: dropout mask [T,B,din] of the layer BELOW: dx comes back already multiplied with it (in the epilogue
-        of the dx GEMM), i.e. ready to be passed to that layer's backward with dout_masked=True."""
+        of the dx GEMM), i.e. ready to be passed to that layer's backward with dout_masked=True.
+        background: another recurrence kernel follows (the layer below's BPTT): the weight-gradient GEMMs then have a
+        millisecond to finish beside it and run on few workgroups without split-K slabs, whose traffic would slow it."""
         c = self.ctx
         st = self.store
         dtype = c['dtype']
@@ -132,6 +135,7 @@ class LSTMLayer(object):
         # weight gradients: side streams (one per direction), concurrent with the BPTT kernel of the layer
         # below (joined in the model's backward before clipping)
         dw_il = torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols
+        ops.set_side_gemm_workgroups(x.device, 32 if background else 0)
         done = []
         for d in range(ndir):
             with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il), lane=1 + (d % DW_LANES)):

@@ -91,6 +91,17 @@ def set_side_xcd_skip(device, n):
             h._xcd_skip = n
 
 
+def set_side_gemm_workgroups(device, n):
+    """Workgroups the side lanes' reduction-major (weight-gradient) GEMMs aim at (asr_set_gemm_tn_workgroups): 32 for
+    GEMMs that run beside a recurrence kernel, 0 (default, ~2 per CU) for exposed ones."""
+    dev = device.index or 0
+    for lane in (1, 2):
+        h = _lib.handle(dev, lane)
+        if getattr(h, '_tn_wgs', None) != n:
+            h.check(h.lib.asr_set_gemm_tn_workgroups(h.h, int(n)), 'asr_set_gemm_tn_workgroups')
+            h._tn_wgs = n
+
+
 def join_side(device):
     """Main stream waits for all side-lane work; releases the tensors held for it."""
     dev = device.index or 0

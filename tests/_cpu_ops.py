@@ -619,7 +619,7 @@ def _maxpool2x2_bwd(dout, arg, H, W):
 
 
 STAND_INS = dict(
-    side_lane=_NullLane, join_side=lambda device: None, stream_event=lambda: None, wait_event=lambda ev: None,
+    side_lane=_NullLane, join_side=lambda device: None, stream_event=lambda: None, set_side_gemm_workgroups=lambda device, n: None, wait_event=lambda ev: None,
     gru_fwd=_gru_fwd, gru_bwd=_gru_bwd, lstm_prep_layer=_lstm_prep_layer, lstm_grad_finish=_lstm_grad_finish, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
     cast_from_f32=_cast_from_f32, cast_to_f32=_cast_to_f32, apply_mask=_apply_mask, dropout_mask=_dropout_mask,
     colsum=_colsum, gemm=_gemm, relu_bwd=_relu_bwd, lstm_prep_weights=_lstm_prep_weights,
