@@ -412,8 +412,8 @@ __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict
 
 // states per lane of the recursion kernel for an extended label sequence of SW = 2 Lmax + 1 states (0: too long)
 inline int ctc_states_per_lane(int SW) {
-  const int ks[5] = {3, 6, 12, 24, 32};
-  for (int i = 0; i < 5; ++i)
+  const int ks[7] = {3, 6, 8, 12, 16, 24, 32};
+  for (int i = 0; i < 7; ++i)
     if (64 * ks[i] >= SW) return ks[i];
   return 0;
 }
@@ -480,9 +480,11 @@ extern "C" int asr_ctc_loss(asr_handle* h, const float* logits, int T, int B, in
   hipLaunchKernelGGL((ctc_alpha_beta_kernel<KV, DV>), dim3(2 * B), dim3(64), 0, st, yext, yrev, T, B, C, labels_flat, \
                      label_offsets, seq_len, max_label_len, alpha, beta, rank, ll, loss, num_infeasible)
     switch (w.K) {
-      case 3: ASR_AB(3, 8); break;
+      case 3: ASR_AB(3, 8); break;          // D frames of emissions in flight: D * K * 2 ring registers
       case 6: ASR_AB(6, 4); break;
-      case 12: ASR_AB(12, 2); break;
+      case 8: ASR_AB(8, 4); break;
+      case 12: ASR_AB(12, 4); break;
+      case 16: ASR_AB(16, 3); break;
       case 24: ASR_AB(24, 2); break;
       default: ASR_AB(32, 2); break;
     }

@@ -587,9 +587,11 @@ def _flat(labs):
 @pytest.mark.parametrize('T,B,C,lmax', [(30, 4, 6, 8), (120, 16, 40, 30), (300, 16, 62, 75), (50, 3, 29, 20),
                                          (64, 2, 700, 25), (400, 2, 29, 150), (200, 3, 3386, 60), (500, 2, 3386, 166),
                                          (40, 3, 26643, 12),
-                                         # extended label sequences of 2L+1 = 401 / 1101 / 1901 states: 12, 24 and 32
-                                         # states per lane of the single-wave recursion (3 and 6 are covered above)
-                                         (700, 2, 29, 200), (1300, 2, 29, 550), (2000, 1, 12, 950)])
+                                         # extended label sequences of 2L+1 = 401 / 601 / 901 / 1101 / 1901 states:
+                                         # 8, 12, 16, 24 and 32 states per lane of the single-wave recursion (3 and 6
+                                         # are covered above)
+                                         (700, 2, 29, 200), (800, 2, 29, 300), (1100, 2, 29, 450), (1300, 2, 29, 550),
+                                         (2000, 1, 12, 950)])
 def test_ctc_loss_and_grad(cuda, T, B, C, lmax):
     ops = _ops()
     rng = np.random.RandomState(T + C)
