@@ -145,13 +145,16 @@ class CTC(ModelBase):
         if is_training and keep_prob is not None and float(keep_prob) < 1.0:
             self._dropout_calls += 1
             rng_state = (self.seed, self._dropout_calls << 40)
-        # operand-dtype shadow of the variables the heads multiply with: refreshed on the side stream, ahead of the
-        # encoder's weight images (whose per-layer events the main stream waits on, so it is complete by then)
-        with ops.side_lane(inputs.device):
-            sh = self.store.shadow(self.dtype)
+        # operand-dtype shadow of the variables the heads multiply with: refreshed on the encoder's side stream right
+        # after its weight images and before its dropout masks (the main stream waits for the mask events, so it is
+        # complete long before the output FC)
+        if hasattr(self.encoder, 'side_extra'):
+            self.encoder.side_extra = self._refresh_head_shadow
         self.encoder.want_f32_outputs = False            # the heads consume the operand copy
         self.encoder(inputs, inputs_seq_len, float(keep_prob) if keep_prob is not None else 1.0,
                      is_training, rng_state=rng_state)
+        ops.wait_event(getattr(self.encoder, 'side_extra_event', None))
+        sh = self.store.shadow(self.dtype)               # refreshed by side_extra where the encoder offers it
         x_op = self._enc_operand()                       # [T,Bp,E]
         T, Bp, E = x_op.shape
         enc = x_op
@@ -172,6 +175,14 @@ class CTC(ModelBase):
         ops.gemm(x_op.view(T * Bp, E), sh[self.head_scope + '/weights'], bias=self.store[self.head_scope + '/biases'],
                  out=logits.view(T * Bp, self.num_classes))
         return logits
+
+    def _refresh_head_shadow(self):
+        """Operand-dtype copies of the head weights (cast per variable on first use after an update)."""
+        sh = self.store.shadow(self.dtype)
+        if sh is not self.store:
+            for n in self.store.names:
+                if n.endswith('/weights') and not n.startswith(('VGG', 'CNN', 'bridge', 'fc')):
+                    sh[n]
 
     def _enc_operand(self):
         """Encoder output in the MFMA operand dtype (what the output FC consumes)."""

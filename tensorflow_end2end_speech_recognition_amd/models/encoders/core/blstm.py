@@ -53,6 +53,8 @@ class _RecurrentEncoderBase(object):
         self.scope_prefix = ''
         self.num_layers_sub = None     # multitask encoders: the layer whose output also feeds the sub-task head
         self.grad_ready_hook = None    # callable(layer_index, LSTMLayer) fired from backward() per finished layer
+        self.side_extra = None         # callable run on the side stream after the weight images (once per call)
+        self.side_extra_event = None
         self.want_f32_outputs = True   # False: __call__ returns the operand-dtype outputs (no fp32 copy is made)
 
     # variables are created at graph-build time in the reference; here when the input size is known
@@ -103,27 +105,33 @@ class _RecurrentEncoderBase(object):
             self._dropout_calls = getattr(self, '_dropout_calls', 0) + 1
             rng_state = (self.seed, self._dropout_calls << 40)
 
-        def prep(li):
-            dm = drop_masks[li] if drop_masks is not None else None
-            rs = None
-            if rng_state is not None:
-                rs = (rng_state[0], rng_state[1] + li * (1 << 32))
-            return self.layers[li].prepare(inputs.device, self.dtype, Tt, Bp, keep_prob, is_training, rs, dm,
-                                           ldk=ldk0 if li == 0 else None)
+        def rs_of(li):
+            return (rng_state[0], rng_state[1] + li * (1 << 32)) if rng_state is not None else None
 
-        # weight images + dropout masks of EVERY layer: side stream, in layer order, one event per layer; the
-        # first layer's (~10 us) run beside the input transpose, the others under the first recurrence kernel
-        preps, ready = [], []
+        # side stream, in this order: the weight images of every layer (one launch and one event each: the first
+        # layer's GEMM waits for ~10 us of side work, not for the masks), whatever else the model wants refreshed once
+        # per step (side_extra: the operand-dtype shadow of the head weights), then the dropout masks (one event each)
+        preps, ready_w, ready_m = [], [], []
         with ops.side_lane(inputs.device):
-            for li in range(len(self.layers)):
-                preps.append(prep(li))
-                ready.append(ops.stream_event())
+            for li, layer in enumerate(self.layers):
+                preps.append(layer.prepare(inputs.device, self.dtype, Tt, Bp, 1.0, False, None, None,
+                                           ldk=ldk0 if li == 0 else None))
+                ready_w.append(ops.stream_event())
+            self.side_extra_event = None
+            if self.side_extra is not None:
+                self.side_extra()
+                self.side_extra_event = ops.stream_event()   # the caller waits for it before using what it refreshed
+            for li, layer in enumerate(self.layers):
+                dm = drop_masks[li] if drop_masks is not None else None
+                preps[li]['mask'] = layer.make_mask(inputs.device, Tt, Bp, keep_prob, is_training, rs_of(li), dm)
+                ready_m.append(ops.stream_event())
         x = ops.bt_to_tb(inputs.contiguous(), self.dtype, ld=ldk0)       # blstm.py:277-279
         final = None
         finals = []
         for li, layer in enumerate(self.layers):
-            ops.wait_event(ready[li])
-            x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, prep=preps[li])
+            ops.wait_event(ready_w[li])
+            x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, prep=preps[li],
+                                     mask_event=ready_m[li])
             finals.append(final)
             if self.num_layers_sub is not None and li + 1 == self.num_layers_sub:
                 # blstm.py:326-328: outputs_sub IS the tensor the next layer consumes (after the dropout wrapper)

@@ -74,18 +74,20 @@ class LSTMLayer(object):
         peephole block: ONE launch) and the dropout mask.  The encoder issues this for every layer on
         the side stream at the start of the step, under the first recurrence kernels."""
         w = ops.lstm_prep_layer(self._vars(self.store.__getitem__), self.din, self.H, dtype, ldk=ldk)
-        mask = None
-        if is_training and (drop_mask is not None or keep_prob < 1.0):
-            if drop_mask is None:
-                seed, offset = rng_state
-                mask = ops.dropout_mask((T, B, self.ndir * self.H), keep_prob, seed, offset, device)
-            else:
-                mask = drop_mask
-        w['mask'] = mask
+        w['mask'] = self.make_mask(device, T, B, keep_prob, is_training, rng_state, drop_mask)
         return w
 
+    def make_mask(self, device, T, B, keep_prob=1.0, is_training=True, rng_state=None, drop_mask=None):
+        """Dropout mask of the layer's output ([T,B,ndir*H] fp32, 1/keep_prob or 0), or None."""
+        if not (is_training and (drop_mask is not None or keep_prob < 1.0)):
+            return None
+        if drop_mask is not None:
+            return drop_mask
+        seed, offset = rng_state
+        return ops.dropout_mask((T, B, self.ndir * self.H), keep_prob, seed, offset, device)
+
     def forward(self, x, seq_len, dtype, keep_prob=1.0, is_training=True, rng_state=None,
-                drop_mask=None, save=True, prep=None):
+                drop_mask=None, save=True, prep=None, mask_event=None):
         """x [T,B,ldk] in `dtype` (ldk >= din: columns din.. are zero padding); returns
         (out [T,B,ndir*H] in dtype, (c_final, h_final))."""
         T, B, ldk = x.shape
@@ -101,6 +103,7 @@ class LSTMLayer(object):
         out = hout
         mask = prep['mask']
         if mask is not None:
+            ops.wait_event(mask_event)       # the mask was generated on the side stream (None: same stream)
             out = ops.apply_mask(hout, mask)
         if save:
             self.ctx = dict(x=x, gates=gates, cs=cs, hout=hout, whb=prep['whb'], peep=prep['peep'],

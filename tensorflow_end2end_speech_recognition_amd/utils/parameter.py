@@ -96,14 +96,16 @@ class ParamStore(object):
     def mark_dirty(self):
         self._shadow_dirty = True
 
-    # -- bf16 shadow of all weights for the MFMA operand path, refreshed once per step
+    # -- bf16 shadow of the weights for the MFMA operand path: per variable, refreshed on first use after an update
+    # (a step of the 5x256 CTC model touches one shadow variable, the 128 KB output matrix -- casting the whole 28 MB
+    # buffer every step was 42 MB of traffic beside the first recurrence kernel)
     def shadow(self, dtype):
         if dtype != ASR_BF16:
             return self
         if self._shadow is None:
             self._shadow = _Shadow(self)
         if self._shadow_dirty:
-            ops.cast_from_f32(self.flat, ASR_BF16, out=self._shadow.flat)
+            self._shadow.invalidate()
             self._shadow_dirty = False
         return self._shadow
 
@@ -118,14 +120,25 @@ class ParamStore(object):
 
 class _Shadow(object):
     def __init__(self, store):
+        self.store = store
         self.flat = torch.empty(store.total, dtype=torch.bfloat16, device=store.flat.device)
         self.views = {}
+        self.spans = {}
         for name in store.names:
             v = store.views[name]
             st = v.storage_offset()
             self.views[name] = self.flat[st:st + v.numel()].view(v.shape)
+            self.spans[name] = (st, st + v.numel())
+        self.fresh = set()
+
+    def invalidate(self):
+        self.fresh = set()
 
     def __getitem__(self, name):
+        if name not in self.fresh:      # cast this variable on the current stream (its consumers follow on it)
+            a, b = self.spans[name]
+            ops.cast_from_f32(self.store.flat[a:b], ASR_BF16, out=self.flat[a:b])
+            self.fresh.add(name)
         return self.views[name]
 
 
