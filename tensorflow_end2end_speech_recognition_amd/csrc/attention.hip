@@ -584,6 +584,33 @@ __global__ __launch_bounds__(256) void emb_scatter_kernel(const float* __restric
   }
 }
 
+// same, E % 4 == 0 and E <= 1024: a thread owns 4 consecutive embedding columns, the 256 / (E/4) row groups of a block
+// scan interleaved rows and are combined in a fixed order through LDS (deterministic; 16x fewer serial rows per thread
+// at E = 64: 1.8 ms -> ~0.1 ms for the 12.8 k decoder inputs of a cfg-D step)
+__global__ __launch_bounds__(256) void emb_scatter_v4_kernel(const float* __restrict__ dout,
+                                                             const int32_t* __restrict__ ids, int R, int E,
+                                                             float* __restrict__ dW) {
+  extern __shared__ float part[];                          // [groups][E]
+  const int v = blockIdx.x;
+  const int lpr = E >> 2, groups = 256 / lpr;
+  const int g = threadIdx.x / lpr, l = threadIdx.x % lpr;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  if (g < groups) {
+    for (int r = g; r < R; r += groups)
+      if (ids[r] == v) {
+        const f32x4_t d = *reinterpret_cast<const f32x4_t*>(dout + (size_t)r * E + l * 4);
+        acc += d;
+      }
+    *reinterpret_cast<f32x4_t*>(part + (size_t)g * E + l * 4) = acc;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float sum = 0.f;
+    for (int k = 0; k < groups; ++k) sum += part[(size_t)k * E + e];
+    dW[(size_t)v * E + e] = sum;
+  }
+}
+
 // masked sequence cross-entropy: rows = B*To; per-row loss*w and dlogits = (softmax-onehot)*w*scale
 __global__ __launch_bounds__(256) void seq_xent_kernel(const float* __restrict__ logits,
                                                        const int32_t* __restrict__ targets,
@@ -830,7 +857,13 @@ extern "C" int asr_embedding_scatter(asr_handle* h, const float* dout, const int
                                      int vocab, float* dW, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(dout && ids && dW && rows >= 0 && E > 0 && vocab > 0, "asr_embedding_scatter: bad args");
-  hipLaunchKernelGGL(emb_scatter_kernel, dim3(vocab), dim3(256), 0, (hipStream_t)s, dout, ids, rows, E, dW);
+  if (E % 4 == 0 && E <= 1024 && ((uintptr_t)dout) % 16 == 0) {
+    const int groups = 256 / (E / 4);
+    hipLaunchKernelGGL(emb_scatter_v4_kernel, dim3(vocab), dim3(256), (size_t)groups * E * sizeof(float), (hipStream_t)s,
+                       dout, ids, rows, E, dW);
+  } else {
+    hipLaunchKernelGGL(emb_scatter_kernel, dim3(vocab), dim3(256), 0, (hipStream_t)s, dout, ids, rows, E, dW);
+  }
   ASR_CHECK_LAUNCH(h, "asr_embedding_scatter");
   return ASR_OK;
 }

@@ -791,6 +791,23 @@ def test_beam_search_batch_vs_oracle(cuda):
             assert abs(score[b].item() - rs[b]) < 1e-7 * max(1, abs(rs[b]))
 
 
+@pytest.mark.parametrize('rows,E,vocab', [(12832, 64, 30), (300, 8, 12), (77, 20, 9), (500, 1024, 5)])
+def test_embedding_gather_scatter(cuda, rows, E, vocab):
+    """asr_embedding_gather / asr_embedding_scatter (the decoder's input embedding and its gradient) against
+    indexing / index_add; the scatter is deterministic (fixed summation order)."""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(rows + E)
+    W = torch.randn(vocab, E, generator=g).to(cuda)
+    ids = torch.randint(0, vocab, (rows,), generator=g).to(torch.int32).to(cuda)
+    dout = torch.randn(rows, E, generator=g).to(cuda)
+    if rows:
+        assert torch.equal(ops.embedding_gather(W, ids), W[ids.long()])
+    dW = ops.embedding_scatter(dout, ids, vocab, torch.empty(vocab, E, device=cuda))
+    ref = torch.zeros(vocab, E, dtype=torch.float64).index_add_(0, ids.long().cpu(), dout.double().cpu())
+    assert (dW.double().cpu() - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(dW, ops.embedding_scatter(dout, ids, vocab, torch.empty(vocab, E, device=cuda)))
+
+
 def test_softmax_rows(cuda):
     ops = _ops()
     x = torch.randn(100, 62, device=cuda) * 3
