@@ -343,6 +343,17 @@ int asr_lstm_cell_fwd(asr_handle* h, const float* pre, const float* c_prev, cons
                       const float* peep, const float* live, int B, int U, float forget_bias,
                       float cell_clip, float* gates, float* c_raw, float* c_out, float* h_out,
                       float* h_raw, asr_stream s);
+/* The same step with its results also written where the NEXT kernels of the decoder step read them, so that no copy
+ * launch sits between them (attention_decoder.py:142-229: the cell output feeds the attention layer and the
+ * attentional vector, the carried h the next step's cell input):
+ *   cell_out [B,U] (may be NULL) = h_raw * out_mask (out_mask [B,U] fp32 or NULL: DropoutWrapper(output_keep_prob));
+ *   cell_out2 (may be NULL): the same values at cell_out2[b*ld_c2 + j]  (a column block of a wider row-major array);
+ *   h_out2   (may be NULL): h_out at h_out2[b*ld_h2 + j]. */
+int asr_lstm_cell_fwd_ex(asr_handle* h, const float* pre, const float* c_prev, const float* h_prev,
+                         const float* peep, const float* live, int B, int U, float forget_bias,
+                         float cell_clip, float* gates, float* c_raw, float* c_out, float* h_out,
+                         float* h_raw, const float* out_mask, float* cell_out, float* h_out2, int ld_h2,
+                         float* cell_out2, int ld_c2, asr_stream s);
 /* dh_use: gradient on the cell output of live rows; dc_next/dh_next: gradient on the carried state.
  * dpre[B,4U]; dc_prev; dh_prev_carry (pass-through part, add (dpre W^T)[h] for live rows);
  * dpeep_rows[B][3][U] per-row peephole gradient terms (sum over rows/steps on the caller side). */
@@ -368,6 +379,12 @@ int asr_att_energy_bwd(asr_handle* h, const float* denergy, const float* keys, c
 int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* seq_len,
                             float sharpening, const void* enc, int enc_dtype, int T, int B, int E,
                             float* alpha, float* ctx, float* sigmoid_norm, asr_stream s);
+/* the same with the context also written to up to two column blocks of wider row-major arrays
+ * (ctx2[b*ld2 + e], ctx3[b*ld3 + e]; NULL = not wanted): the next step's cell input and the attentional vector's */
+int asr_att_softmax_ctx_fwd_ex(asr_handle* h, const float* energy, const int32_t* seq_len,
+                               float sharpening, const void* enc, int enc_dtype, int T, int B, int E,
+                               float* alpha, float* ctx, float* sigmoid_norm, float* ctx2, int ld2,
+                               float* ctx3, int ld3, asr_stream s);
 /* denergy[B,T] = ; denc[T,B,E] += alpha * dctx.  denc may be NULL: a decoder loop then keeps alpha and
  * dctx of every step and forms d_enc = sum_steps alpha (x) dctx with ONE GEMM per utterance at the end
  * instead of a read-modify-write of the whole [T,B,E] tensor per step. */

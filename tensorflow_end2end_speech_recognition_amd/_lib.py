@@ -70,12 +70,14 @@ SIGNATURES = {
     'asr_ctc_beam_decode': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'asr_softmax_rows': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'asr_lstm_cell_fwd': (_i, [_vp] * 6 + [_i, _i, _f, _f] + [_vp] * 6),
+    'asr_lstm_cell_fwd_ex': (_i, [_vp] * 6 + [_i, _i, _f, _f] + [_vp] * 5 + [_vp, _vp, _vp, _i, _vp, _i, _vp]),
     'asr_lstm_cell_bwd': (_i, [_vp] * 9 + [_i, _i] + [_vp] * 5),
     'asr_stack_frames': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_splice': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_att_energy_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'asr_att_energy_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'asr_att_softmax_ctx_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'asr_att_softmax_ctx_fwd_ex': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     'asr_att_softmax_ctx_bwd': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_att_loc_energy_fwd': (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp, _vp]),
     'asr_att_loc_energy_bwd': (_i, [_vp] * 8 + [_i, _i, _i, _i] + [_vp] * 6 + [_i, _vp]),

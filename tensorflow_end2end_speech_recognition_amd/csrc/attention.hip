@@ -25,7 +25,9 @@ __global__ void cell_fwd_kernel(const float* __restrict__ pre, const float* __re
                                 const float* __restrict__ live, int B, int U, float fb, float clip,
                                 float* __restrict__ gates, float* __restrict__ c_raw,
                                 float* __restrict__ c_out, float* __restrict__ h_out,
-                                float* __restrict__ h_raw) {
+                                float* __restrict__ h_raw, const float* __restrict__ out_mask,
+                                float* __restrict__ cell_out, float* __restrict__ h_out2, int ld_h2,
+                                float* __restrict__ cell_out2, int ld_c2) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * U) return;
   const int b = idx / U, j = idx % U;
@@ -45,7 +47,14 @@ __global__ void cell_fwd_kernel(const float* __restrict__ pre, const float* __re
   h_raw[idx] = hn;
   const float lv = live[b];
   c_out[idx] = lv > 0.f ? cn : cp;
-  h_out[idx] = lv > 0.f ? hn : h_prev[idx];
+  const float ho = lv > 0.f ? hn : h_prev[idx];
+  h_out[idx] = ho;
+  // the same values where their consumers read them (columns of the next step's cell input and of the attentional
+  // vector's input): no copy launches between the step's kernels
+  if (h_out2) h_out2[(size_t)b * ld_h2 + j] = ho;
+  const float co = out_mask ? hn * out_mask[idx] : hn;    // DropoutWrapper(output_keep_prob) on the cell output
+  if (cell_out) cell_out[idx] = co;
+  if (cell_out2) cell_out2[(size_t)b * ld_c2 + j] = co;
 }
 
 // dh_raw: gradient w.r.t. the cell output h_new of LIVE rows (already includes everything that
@@ -280,12 +289,15 @@ __global__ __launch_bounds__(256) void att_ctx_partial_kernel(const float* __res
     }
   }
 }
-__global__ void att_ctx_reduce_kernel(const float* __restrict__ part, int nch, int BE, float* __restrict__ ctx) {
+__global__ void att_ctx_reduce_kernel(const float* __restrict__ part, int nch, int BE, float* __restrict__ ctx, int E,
+                                      float* __restrict__ ctx2, int ld2, float* __restrict__ ctx3, int ld3) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= BE) return;
   float c = 0.f;
   for (int k = 0; k < nch; ++k) c += part[(size_t)k * BE + i];   // fixed order
   ctx[i] = c;
+  if (ctx2) ctx2[(size_t)(i / E) * ld2 + i % E] = c;
+  if (ctx3) ctx3[(size_t)(i / E) * ld3 + i % E] = c;
 }
 
 // dalpha[b,t] = enc[t,b,:] . dctx[b,:]  for t < len (one wave per frame, float4 lanes)
@@ -676,17 +688,26 @@ inline int gridn(size_t n) {
 
 #define ATT_NEED(cond, ...) do { if (!(cond)) ASR_FAIL(h, ASR_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
 
+extern "C" int asr_lstm_cell_fwd_ex(asr_handle* h, const float* pre, const float* c_prev, const float* h_prev,
+                                    const float* peep, const float* live, int B, int U, float forget_bias,
+                                    float cell_clip, float* gates, float* c_raw, float* c_out, float* h_out,
+                                    float* h_raw, const float* out_mask, float* cell_out, float* h_out2, int ld_h2,
+                                    float* cell_out2, int ld_c2, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(pre && c_prev && h_prev && live && gates && c_raw && c_out && h_out && h_raw && B > 0 && U > 0 &&
+               (!h_out2 || ld_h2 >= U) && (!cell_out2 || ld_c2 >= U), "asr_lstm_cell_fwd: bad args");
+  hipLaunchKernelGGL(cell_fwd_kernel, dim3((B * U + 255) / 256), dim3(256), 0, (hipStream_t)s, pre, c_prev, h_prev,
+                     peep, live, B, U, forget_bias, cell_clip, gates, c_raw, c_out, h_out, h_raw, out_mask, cell_out,
+                     h_out2, ld_h2, cell_out2, ld_c2);
+  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_fwd");
+  return ASR_OK;
+}
 extern "C" int asr_lstm_cell_fwd(asr_handle* h, const float* pre, const float* c_prev, const float* h_prev,
                                  const float* peep, const float* live, int B, int U, float forget_bias,
                                  float cell_clip, float* gates, float* c_raw, float* c_out, float* h_out,
                                  float* h_raw, asr_stream s) {
-  if (!h) return ASR_ERR_INVALID_ARG;
-  ATT_NEED(pre && c_prev && h_prev && live && gates && c_raw && c_out && h_out && h_raw && B > 0 && U > 0,
-           "asr_lstm_cell_fwd: bad args");
-  hipLaunchKernelGGL(cell_fwd_kernel, dim3((B * U + 255) / 256), dim3(256), 0, (hipStream_t)s, pre, c_prev, h_prev,
-                     peep, live, B, U, forget_bias, cell_clip, gates, c_raw, c_out, h_out, h_raw);
-  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_fwd");
-  return ASR_OK;
+  return asr_lstm_cell_fwd_ex(h, pre, c_prev, h_prev, peep, live, B, U, forget_bias, cell_clip, gates, c_raw, c_out,
+                              h_out, h_raw, nullptr, nullptr, nullptr, 0, nullptr, 0, s);
 }
 
 extern "C" int asr_lstm_cell_bwd(asr_handle* h, const float* dh_use, const float* dc_next, const float* dh_next,
@@ -779,12 +800,23 @@ extern "C" int asr_att_loc_energy_bwd(asr_handle* h, const float* denergy, const
   return ASR_OK;
 }
 
+extern "C" int asr_att_softmax_ctx_fwd_ex(asr_handle* h, const float* energy, const int32_t* seq_len,
+                                          float sharpening, const void* enc, int enc_dtype, int T, int B, int E,
+                                          float* alpha, float* ctx, float* sigmoid_norm, float* ctx2, int ld2,
+                                          float* ctx3, int ld3, asr_stream s);
 extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const int32_t* seq_len,
                                        float sharpening, const void* enc, int enc_dtype, int T, int B, int E,
                                        float* alpha, float* ctx, float* sigmoid_norm, asr_stream s) {
+  return asr_att_softmax_ctx_fwd_ex(h, energy, seq_len, sharpening, enc, enc_dtype, T, B, E, alpha, ctx, sigmoid_norm,
+                                    nullptr, 0, nullptr, 0, s);
+}
+extern "C" int asr_att_softmax_ctx_fwd_ex(asr_handle* h, const float* energy, const int32_t* seq_len,
+                                          float sharpening, const void* enc, int enc_dtype, int T, int B, int E,
+                                          float* alpha, float* ctx, float* sigmoid_norm, float* ctx2, int ld2,
+                                          float* ctx3, int ld3, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
-  ATT_NEED(energy && seq_len && enc && alpha && ctx && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype),
-           "asr_att_softmax_ctx_fwd: bad args");
+  ATT_NEED(energy && seq_len && enc && alpha && ctx && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype) &&
+               (!ctx2 || ld2 >= E) && (!ctx3 || ld3 >= E), "asr_att_softmax_ctx_fwd: bad args");
   const size_t lds = (size_t)T * sizeof(float);
   if (lds > 64 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_softmax_ctx_fwd: T=%d too long", T);
   const int nch = (T + ATT_CH - 1) / ATT_CH;
@@ -799,7 +831,7 @@ extern "C" int asr_att_softmax_ctx_fwd(asr_handle* h, const float* energy, const
     hipLaunchKernelGGL(att_ctx_partial_kernel<bf16_t>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, alpha, seq_len,
                        (const bf16_t*)enc, T, B, E, part);
   hipLaunchKernelGGL(att_ctx_reduce_kernel, dim3((B * E + 255) / 256), dim3(256), 0, (hipStream_t)s, part, nch, B * E,
-                     ctx);
+                     ctx, E, ctx2, ld2, ctx3, ld3);
   ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_fwd");
   return ASR_OK;
 }

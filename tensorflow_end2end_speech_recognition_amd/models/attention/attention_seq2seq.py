@@ -281,16 +281,19 @@ class AttentionSeq2Seq(ModelBase):
         # sigmoid smoothing (attention_layer.py:92-96): the per-step normaliser is kept for the backward
         snorm_all = torch.empty((To, Bp), dtype=torch.float32, device=dev) if self.sigmoid_smoothing else None
         alpha_zero = torch.zeros((Bp, T), dtype=torch.float32, device=dev) if self.carry_alpha else None
+        dec_in[0, :, Em:Em + E2].copy_(ctx)
+        dec_in[0, :, Em + E2:].copy_(h)
         for k in range(To):
-            dec_in[k, :, Em:Em + E2].copy_(ctx)
-            dec_in[k, :, Em + E2:].copy_(h)
+            # the cell output (after its DropoutWrapper) and the carried h are also written, by the cell kernel itself,
+            # into the column blocks their consumers read: the attentional vector's input of this step and the cell
+            # input of the next one; the context likewise below -- no copy launches inside the step
             pre = ops.gemm(dec_in[k], W_cell, bias=b_cell)
-            gates, c_raw, c_new, h_new, h_raw = ops.lstm_cell_fwd(pre, c, h, peep, live_d[k], 1.0,
-                                                                  self.clip_activation_decoder or 0.0)
-            cell_out, dmask = h_raw, None
-            if use_ddrop:
-                dmask = dmask_all[k]
-                cell_out = ops.apply_mask(h_raw, dmask)
+            dmask = dmask_all[k] if use_ddrop else None
+            nxt = dec_in[k + 1] if k + 1 < To else None
+            gates, c_raw, c_new, h_new, h_raw, cell_out = ops.lstm_cell_fwd(
+                pre, c, h, peep, live_d[k], 1.0, self.clip_activation_decoder or 0.0, out_mask=dmask,
+                want_cell_out=True, h_also=nxt[:, Em + E2:] if nxt is not None else None,
+                cell_out_also=av_in[k, :, :U])
             qz = self._query(cell_out)
             if self.carry_alpha:     # previous weights (zeros at step 0, attention_decoder.py:163-164) -> conv -> W_filter
                 energy = ops.att_loc_energy_fwd(alpha_all[k - 1] if k > 0 else alpha_zero, st[AT + 'filter'],
@@ -299,9 +302,9 @@ class AttentionSeq2Seq(ModelBase):
                 energy = ops.att_energy_fwd(keys, qz, v, T, self.att_mode)
             alpha, ctx_k = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc_att,
                                                    alpha_out=alpha_all[k],
-                                                   sigmoid_norm=snorm_all[k] if snorm_all is not None else None)
-            av_in[k, :, :U].copy_(cell_out)
-            av_in[k, :, U:].copy_(ctx_k)
+                                                   sigmoid_norm=snorm_all[k] if snorm_all is not None else None,
+                                                   ctx_also=(av_in[k, :, U:],
+                                                             nxt[:, Em:Em + E2] if nxt is not None else None))
             saved.append(dict(gates=gates, c_raw=c_raw, c_prev=c, qz=qz, alpha=alpha, dmask=dmask,
                               snorm=snorm_all[k] if snorm_all is not None else None))
             c, h, ctx = c_new, h_new, ctx_k
@@ -370,7 +373,10 @@ class AttentionSeq2Seq(ModelBase):
         ops.colsum(dlogits, out=st.g(D + 'output_layer/biases'))
         dav_pre = ops.tanh_bwd(ops.gemm(dlogits, W_out, transB=True), av)
         ops.gemm(av_in.view(To * Bp, U + E2), dav_pre, transA=True, out=st.g(D + 'attentional_vector/weights'))
-        dav_in = ops.gemm(dav_pre, W_av, transB=True).view(To, Bp, U + E2)
+        # gradient of the attentional vector's inputs, as two contiguous arrays (cell output | context): a step's rows
+        # are then the buffers the loop works in, not slices that have to be copied out first
+        dav_cell = ops.gemm(dav_pre, W_av[:U], transB=True).view(To, Bp, U)
+        dav_ctx = ops.gemm(dav_pre, W_av[U:], transB=True).view(To, Bp, E2)
         # ---- the recurrence, backwards
         denc = torch.zeros_like(enc)
         dkeys = None
@@ -387,6 +393,7 @@ class AttentionSeq2Seq(ModelBase):
         dc_next = torch.zeros((Bp, U), dtype=torch.float32, device=dev)
         dh_next = torch.zeros((Bp, U), dtype=torch.float32, device=dev)
         dctx_in = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
+        d_in_all = torch.empty((To, Bp, Em + E2 + U), dtype=torch.float32, device=dev)   # d loss / d cell input
         v = st[AT + 'v_a'] if self.att_mode == 0 else None
         dctx_all = torch.empty((To, Bp, E2), dtype=torch.float32, device=dev)
         dalpha_next = None                     # carried location features: d loss / d alpha_k from step k+1's conv
@@ -398,7 +405,7 @@ class AttentionSeq2Seq(ModelBase):
         for k in range(To - 1, -1, -1):
             s = saved[k]
             dctx = dctx_all[k]
-            torch.add(dav_in[k, :, U:], dctx_in, out=dctx)
+            torch.add(dav_ctx[k], dctx_in, out=dctx)
             # d_enc += alpha (x) dctx is NOT done per step (a read-modify-write of [T,B,2H] each time):
             # alpha and dctx of all steps are kept and contracted once per utterance below
             denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, tp['enc_att'], None,
@@ -406,34 +413,28 @@ class AttentionSeq2Seq(ModelBase):
             if self.carry_alpha:
                 dqz, dv_rows, dalpha_next = ops.att_loc_energy_bwd(
                     denergy, tp['alpha_all'][k - 1] if k > 0 else alpha_zero, filt, wfil, keys, s['qz'], v,
-                    dwfil_rows, dfilt_rows, accumulate=(k != To - 1), dkeys=dkeys)
+                    dwfil_rows, dfilt_rows, accumulate=(k != To - 1), dkeys=dkeys, dqz_out=dqz_all[k],
+                    dv_out=dv_all[k] if dv_all is not None else None)
             else:
                 dqz, dv_rows = ops.att_energy_bwd(denergy, keys, s['qz'], v, self.att_mode, dkeys=dkeys,
-                                                  want_dv=self.att_mode == 0)
-            dqz_all[k].copy_(dqz)
-            if dv_rows is not None:
-                dv_all[k].copy_(dv_rows)
-            dcell = dav_in[k, :, :U].contiguous()
+                                                  want_dv=self.att_mode == 0, dqz_out=dqz_all[k],
+                                                  dv_out=dv_all[k] if dv_all is not None else None)
+            dcell = dav_cell[k]
             if at in AL.HAS_QUERY_FC:
                 ops.gemm(dqz, self._wq(), transB=True, out=dcell, accumulate=True)
             else:
                 dcell = dcell + dqz
             if s['dmask'] is not None:
                 dcell = ops.apply_mask(dcell, s['dmask'])
-            dpre, dc_prev, dh_carry, dpeep_rows = ops.lstm_cell_bwd(dcell, dc_next, dh_next, s['gates'], s['c_raw'],
-                                                                    s['c_prev'], tp['peep'], live[k],
-                                                                    want_dpeep=self.use_peephole)
-            dpre_all[k].copy_(dpre)
-            if dpeep_rows is not None:
-                dpeep_all[k].copy_(dpeep_rows.view(Bp, 3 * U))
-            d_in = ops.gemm(dpre, W_cell, transB=True)                      # [Bp, Em+E2+U]
-            dec_in_grad_emb = d_in[:, :Em]
-            if k == To - 1:
-                demb_all = torch.empty((To, Bp, Em), dtype=torch.float32, device=dev)
-            demb_all[k].copy_(dec_in_grad_emb)
-            dctx_in = d_in[:, Em:Em + E2].contiguous()
+            dpre, dc_prev, dh_carry, dpeep_rows = ops.lstm_cell_bwd(
+                dcell, dc_next, dh_next, s['gates'], s['c_raw'], s['c_prev'], tp['peep'], live[k],
+                want_dpeep=self.use_peephole, dpre_out=dpre_all[k],
+                dpeep_out=dpeep_all[k] if dpeep_all is not None else None)
+            d_in = ops.gemm(dpre, W_cell, transB=True, out=d_in_all[k])     # [Bp, Em+E2+U]
+            dctx_in = d_in[:, Em:Em + E2]                                   # read in place by the next iteration's add
             dh_next = dh_carry + d_in[:, Em + E2:]
             dc_next = dc_prev
+        demb_all = d_in_all[:, :, :Em].contiguous()
         # ---- d_enc[:, b, :] += alpha_b^T [T, To] . dctx_b [To, 2H]   (context path of all steps at once)
         alpha_all = tp['alpha_all']
         for b in range(tp['B']):

@@ -692,25 +692,47 @@ def _f32(shape, dev):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
-def lstm_cell_fwd(pre, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.0):
+def _col_block(t, B, W, name):
+    """(pointer, row stride) of a [B, W] column block of a row-major array (unit inner stride)."""
+    if t is None:
+        return None, 0
+    if t.dim() != 2 or tuple(t.shape) != (B, W) or t.stride(1) != 1 or t.dtype != torch.float32:
+        raise ValueError('%s must be an fp32 [B,%d] column block with unit inner stride' % (name, W))
+    return C.c_void_p(t.data_ptr()), t.stride(0)
+
+
+def lstm_cell_fwd(pre, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.0, out_mask=None, want_cell_out=False,
+                  h_also=None, cell_out_also=None):
+    """One decoder cell step.  Returns (gates, c_raw, c_out, h_out, h_raw) -- plus cell_out = h_raw * out_mask as a
+    sixth element when want_cell_out.  h_also / cell_out_also: [B,U] column blocks of wider arrays (the next step's
+    cell input, the attentional vector's input) that receive h_out / cell_out as well, inside the same launch."""
     h = _h(pre)
     B, U4 = pre.shape
     U = U4 // 4
     dev = pre.device
     gates, c_raw, c_out, h_out, h_raw = _f32((B, U4), dev), _f32((B, U), dev), _f32((B, U), dev), \
         _f32((B, U), dev), _f32((B, U), dev)
-    h.check(h.lib.asr_lstm_cell_fwd(h.h, _p(pre), _p(c_prev), _p(h_prev), _p(peep), _p(live), B, U,
-                                    float(forget_bias), float(cell_clip or 0.0), _p(gates), _p(c_raw), _p(c_out),
-                                    _p(h_out), _p(h_raw), _s()), 'asr_lstm_cell_fwd')
+    cell_out = _f32((B, U), dev) if want_cell_out else None
+    hp, hld = _col_block(h_also, B, U, 'h_also')
+    cp, cld = _col_block(cell_out_also, B, U, 'cell_out_also')
+    h.check(h.lib.asr_lstm_cell_fwd_ex(h.h, _p(pre), _p(c_prev), _p(h_prev), _p(peep), _p(live), B, U,
+                                       float(forget_bias), float(cell_clip or 0.0), _p(gates), _p(c_raw), _p(c_out),
+                                       _p(h_out), _p(h_raw), _p(out_mask), _p(cell_out), hp, hld, cp, cld, _s()),
+            'asr_lstm_cell_fwd')
+    if want_cell_out:
+        return gates, c_raw, c_out, h_out, h_raw, cell_out
     return gates, c_raw, c_out, h_out, h_raw
 
 
-def lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True):
+def lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True, dpre_out=None,
+                  dpeep_out=None):
+    """dpre_out [B,4U] / dpeep_out [B,3U] (contiguous rows of the caller's per-step arrays): written in place."""
     h = _h(dh_use)
     B, U = dh_use.shape
     dev = dh_use.device
-    dpre, dc_prev, dh_carry = _f32((B, 4 * U), dev), _f32((B, U), dev), _f32((B, U), dev)
-    dpeep = _f32((B, 3, U), dev) if want_dpeep else None
+    dpre = dpre_out if dpre_out is not None else _f32((B, 4 * U), dev)
+    dc_prev, dh_carry = _f32((B, U), dev), _f32((B, U), dev)
+    dpeep = (dpeep_out if dpeep_out is not None else _f32((B, 3, U), dev)) if want_dpeep else None
     h.check(h.lib.asr_lstm_cell_bwd(h.h, _p(dh_use), _p(dc_next), _p(dh_next), _p(gates), _p(c_raw), _p(c_prev),
                                     _p(peep), _p(live), B, U, _p(dpre), _p(dc_prev), _p(dh_carry), _p(dpeep), _s()),
             'asr_lstm_cell_bwd')
@@ -726,19 +748,20 @@ def att_energy_fwd(keys, qz, v, T, mode):
     return energy
 
 
-def att_energy_bwd(denergy, keys, qz, v, mode, dkeys=None, want_dv=True):
+def att_energy_bwd(denergy, keys, qz, v, mode, dkeys=None, want_dv=True, dqz_out=None, dv_out=None):
     h = _h(qz)
     B, A = qz.shape
     T = denergy.shape[1]
-    dqz = _f32((B, A), qz.device)
-    dv = _f32((B, A), qz.device) if want_dv else None
+    dqz = dqz_out if dqz_out is not None else _f32((B, A), qz.device)
+    dv = (dv_out if dv_out is not None else _f32((B, A), qz.device)) if want_dv else None
     h.check(h.lib.asr_att_energy_bwd(h.h, _p(denergy), _p(keys), _p(qz), _p(v), T, B, A, int(mode), _p(dkeys),
                                      _p(dqz), _p(dv), _s()), 'asr_att_energy_bwd')
     return dqz, dv
 
 
-def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmoid_norm=None):
-    """sigmoid_norm: None = softmax; a [B] fp32 tensor = sigmoid smoothing (receives sum_t sigmoid(e))."""
+def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmoid_norm=None, ctx_also=()):
+    """sigmoid_norm: None = softmax; a [B] fp32 tensor = sigmoid smoothing (receives sum_t sigmoid(e)).
+    ctx_also: up to two [B,E] column blocks of wider arrays that receive the context as well (same launch)."""
     h = _h(energy)
     B, T = energy.shape
     E = enc.shape[2]
@@ -746,9 +769,14 @@ def att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmoi
     ctx = _f32((B, E), energy.device)
     if sigmoid_norm is not None and (sigmoid_norm.dtype != torch.float32 or sigmoid_norm.numel() != B):
         raise ValueError('sigmoid_norm must be fp32 [B]')
-    h.check(h.lib.asr_att_softmax_ctx_fwd(h.h, _p(energy), _p(seq_len), float(sharpening), _p(enc),
-                                          dtype_id(enc.dtype), T, B, E, _p(alpha), _p(ctx), _p(sigmoid_norm), _s()),
-            'asr_att_softmax_ctx_fwd')
+    also = [t for t in ctx_also if t is not None]
+    if len(also) > 2:
+        raise ValueError('att_softmax_ctx_fwd: at most two extra destinations')
+    p2, l2 = _col_block(also[0] if len(also) > 0 else None, B, E, 'ctx_also')
+    p3, l3 = _col_block(also[1] if len(also) > 1 else None, B, E, 'ctx_also')
+    h.check(h.lib.asr_att_softmax_ctx_fwd_ex(h.h, _p(energy), _p(seq_len), float(sharpening), _p(enc),
+                                             dtype_id(enc.dtype), T, B, E, _p(alpha), _p(ctx), _p(sigmoid_norm),
+                                             p2, l2, p3, l3, _s()), 'asr_att_softmax_ctx_fwd')
     return alpha, ctx
 
 
@@ -764,14 +792,17 @@ def att_loc_energy_fwd(alpha_prev, filt, wfil, keys, qz, v, T):
     return energy
 
 
-def att_loc_energy_bwd(denergy, alpha_prev, filt, wfil, keys, qz, v, dwfil_rows, dfilt_rows, accumulate, dkeys=None):
+def att_loc_energy_bwd(denergy, alpha_prev, filt, wfil, keys, qz, v, dwfil_rows, dfilt_rows, accumulate, dkeys=None,
+                       dqz_out=None, dv_out=None):
     """-> (dqz [B,A], dv_rows [B,A], dalpha_prev [B,T]); dwfil_rows [B,10,A] / dfilt_rows [B,taps,10] are
     overwritten (accumulate False) or added to (True); dkeys += in place when given."""
     h = _h(qz)
     B, A = qz.shape
     T = denergy.shape[1]
     taps = filt.shape[0]
-    dqz, dv, dap = _f32((B, A), qz.device), _f32((B, A), qz.device), _f32((B, T), qz.device)
+    dqz = dqz_out if dqz_out is not None else _f32((B, A), qz.device)
+    dv = dv_out if dv_out is not None else _f32((B, A), qz.device)
+    dap = _f32((B, T), qz.device)
     h.check(h.lib.asr_att_loc_energy_bwd(h.h, _p(denergy), _p(alpha_prev), _p(filt), _p(wfil), _p(keys), _p(qz), _p(v),
                                          T, B, A, taps, _p(dkeys), _p(dqz), _p(dv), _p(dwfil_rows), _p(dfilt_rows),
                                          _p(dap), 1 if accumulate else 0, _s()), 'asr_att_loc_energy_bwd')

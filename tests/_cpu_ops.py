@@ -352,7 +352,8 @@ def _scale_(x, s):
 
 
 # ---------------------------------------------------------------- attention decoder stand-ins
-def _lstm_cell_fwd(pre, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.0):
+def _lstm_cell_fwd(pre, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.0, out_mask=None, want_cell_out=False,
+                   h_also=None, cell_out_also=None):
     """csrc/attention.hip cell_fwd_kernel: gate-major columns i, ci, f, o; finished rows keep their state."""
     B, U4 = pre.shape
     U = U4 // 4
@@ -369,10 +370,26 @@ def _lstm_cell_fwd(pre, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0
     hn = torch.tanh(cn) * o
     lv = (live.double() > 0).view(B, 1)
     gates = torch.cat([i, g, f, o], 1).float()
-    return gates, cn.float(), torch.where(lv, cn, cp).float(), torch.where(lv, hn, h_prev.double()).float(), hn.float()
+    h_out = torch.where(lv, hn, h_prev.double()).float()
+    cell_out = (hn * out_mask.double()).float() if out_mask is not None else hn.float()
+    if h_also is not None:
+        h_also.copy_(h_out)
+    if cell_out_also is not None:
+        cell_out_also.copy_(cell_out)
+    res = (gates, cn.float(), torch.where(lv, cn, cp).float(), h_out, hn.float())
+    return res + (cell_out,) if want_cell_out else res
 
 
-def _lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True):
+def _into(out, val):
+    """Write a stand-in's result into the caller's buffer when one is given (the kernels' out-parameter form)."""
+    if out is None or val is None:
+        return val
+    out.copy_(val.reshape(out.shape))
+    return out
+
+
+def _lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True, dpre_out=None,
+                   dpeep_out=None):
     B, U = dh_use.shape
     gt = gates.double()
     i, g, f, o = gt[:, :U], gt[:, U:2 * U], gt[:, 2 * U:3 * U], gt[:, 3 * U:]
@@ -395,7 +412,7 @@ def _lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, w
     if want_dpeep:
         dpeep = torch.stack([torch.where(lv, d_i * cp, zero), torch.where(lv, d_f * cp, zero),
                              torch.where(lv, d_o * c, zero)], 1).float()
-    return dpre.float(), dc_prev.float(), dh_carry.float(), dpeep
+    return _into(dpre_out, dpre.float()), dc_prev.float(), dh_carry.float(), _into(dpeep_out, dpeep)
 
 
 def _att_energy_fwd(keys, qz, v, T, mode):
@@ -411,7 +428,7 @@ def _att_energy_fwd(keys, qz, v, T, mode):
     return e.t().contiguous().float()
 
 
-def _att_energy_bwd(denergy, keys, qz, v, mode, dkeys=None, want_dv=True):
+def _att_energy_bwd(denergy, keys, qz, v, mode, dkeys=None, want_dv=True, dqz_out=None, dv_out=None):
     B, A = qz.shape
     T = denergy.shape[1]
     de = denergy.double().t().unsqueeze(2)                                 # [T,B,1]
@@ -434,13 +451,13 @@ def _att_energy_bwd(denergy, keys, qz, v, mode, dkeys=None, want_dv=True):
         dqz = (de * keys.double()).sum(0)
         if want_dv:
             dv = torch.zeros(B, A)
-    return dqz.float(), dv
+    return _into(dqz_out, dqz.float()), _into(dv_out, dv)
 
 
 _F32_LOWEST = float(np.finfo(np.float32).min)
 
 
-def _att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmoid_norm=None):
+def _att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmoid_norm=None, ctx_also=()):
     B, T = energy.shape
     mask = torch.arange(T).unsqueeze(0) < seq_len.long().clamp(0, T).unsqueeze(1)
     e = torch.where(mask, energy.double(), torch.full_like(energy, _F32_LOWEST, dtype=F64)) * sharpening
@@ -458,6 +475,9 @@ def _att_softmax_ctx_fwd(energy, seq_len, sharpening, enc, alpha_out=None, sigmo
         alpha = alpha_out
     else:
         alpha = alpha.float()
+    for t in ctx_also:
+        if t is not None:
+            t.copy_(ctx.float())
     return alpha, ctx.float()
 
 
@@ -478,7 +498,8 @@ def _att_loc_energy_fwd(alpha_prev, filt, wfil, keys, qz, v, T):
                        qz.double(), v.double(), T).float()
 
 
-def _att_loc_energy_bwd(denergy, alpha_prev, filt, wfil, keys, qz, v, dwfil_rows, dfilt_rows, accumulate, dkeys=None):
+def _att_loc_energy_bwd(denergy, alpha_prev, filt, wfil, keys, qz, v, dwfil_rows, dfilt_rows, accumulate, dkeys=None,
+                        dqz_out=None, dv_out=None):
     B, A = qz.shape
     T = denergy.shape[1]
     dqz, dv, dap = torch.zeros(B, A), torch.zeros(B, A), torch.zeros(B, T)
@@ -496,7 +517,7 @@ def _att_loc_energy_bwd(denergy, alpha_prev, filt, wfil, keys, qz, v, dwfil_rows
         dv[b] = leaves[4].grad.float()
         if dkeys is not None and k is not None:
             dkeys[:, b:b + 1] += k.grad.float()
-    return dqz, dv, dap
+    return _into(dqz_out, dqz), _into(dv_out, dv), dap
 
 
 def _att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmoid_norm=None, dalpha_extra=None):
