@@ -415,6 +415,45 @@ int asr_att_loc_energy_bwd(asr_handle* h, const float* denergy, const float* alp
                            const float* wfil, const float* keys, const float* qz, const float* v, int T, int B,
                            int A, int taps, float* dkeys, float* dqz, float* dv_rows, float* dwfil_rows,
                            float* dfilt_rows, float* dalpha_prev, int accumulate, asr_stream s);
+/* ---- the decoder loop, native ----------------------------------------------------------------------------- *
+ * dynamic_decode over a TrainingHelper (decoders/dynamic_decoder.py:68-218, attention_decoder.py:142-229): all To steps
+ * of the attention decoder issued from ONE call -- the per-step sequence cell-input GEMM -> asr_lstm_cell_fwd_ex ->
+ * query GEMM -> asr_att_(loc_)energy_fwd -> asr_att_softmax_ctx_fwd_ex, i.e. exactly the entry points above in the
+ * order a host loop would call them (a Python host spends ~15 us per call, ~9 calls per step, 400 steps: the loop was
+ * host-bound), and the reverse sequence for the gradients.  Every array is the caller's; per-step arrays are [To, ...]
+ * row blocks.  Layouts: dec_in [To,B,Em+E2+U] = embedded input | previous context | previous h (the embedding columns
+ * and row 0 filled by the caller, the rest by the loop), av_in [To,B,U+E2] = cell output (after its dropout mask) |
+ * context; c_all / h_all [To+1,B,U]: carried state BEFORE step k at row k (row 0 = initial state from the bridge). */
+typedef struct asr_att_decoder {
+  int To, B, T, U, Em, E2, A;       /* A: width of keys / qz */
+  int att_mode;                     /* 0 additive (v tanh(keys + qz)), 1 dot */
+  int has_query_fc;                 /* qz = cell_out W_q (+ b_q); 0: qz = cell_out (then A == U) */
+  int carry_alpha, taps;            /* location features of the previous step's weights (asr_att_loc_energy_*) */
+  int enc_dtype;
+  float forget_bias, cell_clip, sharpening;
+  const float *W_cell, *b_cell, *peep;          /* [Em+E2+U,4U], [4U], [3,U] or NULL */
+  const float *W_q, *b_q, *v;                   /* [U,A] (row stride ld_wq) or NULL, [A] or NULL, [A] or NULL */
+  int ld_wq;
+  const float *keys;                            /* [T,B,A] or NULL */
+  const void *enc;                              /* [T,B,E2] in enc_dtype */
+  const int32_t *seq_len;                       /* [B] */
+  const float *filt, *wfil, *alpha_zero;        /* carry_alpha: [taps,1,10], [10,A], zeros [B,T] */
+  const float *live, *dmask;                    /* [To,B]; [To,B,U] or NULL */
+  float *dec_in, *av_in, *alpha_all, *snorm_all;/* snorm_all [To,B] or NULL (sigmoid smoothing) */
+  float *gates_all, *craw_all, *c_all, *h_all, *qz_all;   /* [To,B,4U], [To,B,U], [To+1,B,U] x2, [To,B,A] */
+  float *work;                                  /* forward: B*(4U + U + T + E2) floats; backward: see asr_att_decoder_bwd */
+  /* backward only */
+  const float *dav_cell, *dav_ctx;              /* [To,B,U] (used as work space: overwritten), [To,B,E2] */
+  float *dctx_all, *dpre_all, *dqz_all, *dv_all, *dpeep_all, *d_in_all;   /* [To,B,E2|4U|A|A or NULL|3U or NULL|Em+E2+U] */
+  float *dkeys, *dwfil_rows, *dfilt_rows;       /* [T,B,A] += or NULL; carry_alpha: [B,10,A], [B,taps,10] */
+  float *dc0, *dh0;                             /* [B,U] out: gradient w.r.t. the initial state */
+} asr_att_decoder;
+int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_stream s);
+/* work: B*(5*U + 3*T + E2) floats.  dav_cell is consumed (its rows accumulate the query-path gradient in place). */
+int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_stream s);
+/* out[b, j] = x[b*ldx + j] + y[b*ldy + j], j < W (row blocks of wider arrays; out may alias x) */
+int asr_add_cols(asr_handle* h, const float* x, int ldx, const float* y, int ldy, float* out, int ldo, int B, int W,
+                 asr_stream s);
 int asr_tanh_fwd(asr_handle* h, const float* x, float* y, size_t n, asr_stream s);
 int asr_tanh_bwd(asr_handle* h, const float* dy, const float* y, float* dx, size_t n, asr_stream s);
 /* tf.nn.embedding_lookup (attention_seq2seq.py:439) and its gradient (deterministic) */

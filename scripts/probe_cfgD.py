@@ -21,10 +21,10 @@ for b in range(B):
     y = rng.randint(0, C, size=lens[b])
     labels[b, 0] = sos; labels[b, 1:1 + lens[b]] = y; ctc[b, :lens[b]] = y
 m = JointCTCAttention(input_size=D, encoder_type='blstm', encoder_num_units=512, encoder_num_layers=5,
-                      encoder_num_proj=None, attention_type='location', attention_dim=128, decoder_type='lstm',
+                      encoder_num_proj=None, attention_type=os.environ.get('ATT', 'location'), attention_dim=128, decoder_type='lstm',
                       decoder_num_units=512, decoder_num_layers=1, embedding_dim=64, lambda_weight=0.5,
                       num_classes=C, sos_index=C, eos_index=C + 1, max_decode_length=Lmax, parameter_init=0.1,
-                      clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50, dtype='bf16', seed=5)
+                      clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50, dtype='bf16', seed=5, prev_alpha=os.environ.get('PREV', 'zeros'))
 xd = torch.tensor(x, device=dev)
 for it in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -64,16 +64,21 @@ __global__ void cell_bwd_kernel(const float* __restrict__ dh_out_use, const floa
                                 const float* __restrict__ c_raw, const float* __restrict__ c_prev,
                                 const float* __restrict__ peep, const float* __restrict__ live, int B, int U,
                                 float* __restrict__ dpre, float* __restrict__ dc_prev,
-                                float* __restrict__ dh_prev_carry, float* __restrict__ dpeep_rows) {
+                                float* __restrict__ dh_prev_carry, float* __restrict__ dpeep_rows,
+                                const float* __restrict__ dh_next2, int ld2, const float* __restrict__ use_mask) {
+  // dh_next2 (may be NULL, row stride ld2): a second addend of the carried-h gradient -- inside the decoder loop the
+  // h-columns of the NEXT step's cell-input gradient; use_mask (may be NULL): the DropoutWrapper mask of the cell
+  // output, applied to dh_out_use here instead of by a launch of its own
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * U) return;
   const int b = idx / U, j = idx % U;
   const float lv = live[b];
   float* dp = dpre + (size_t)b * 4 * U;
+  const float dhn = dh_next2 ? dh_next[idx] + dh_next2[(size_t)b * ld2 + j] : dh_next[idx];
   if (!(lv > 0.f)) {   // finished row: state passes through, no parameter gradient
     dp[j] = 0.f; dp[U + j] = 0.f; dp[2 * U + j] = 0.f; dp[3 * U + j] = 0.f;
     dc_prev[idx] = dc_next[idx];
-    dh_prev_carry[idx] = dh_next[idx];
+    dh_prev_carry[idx] = dhn;
     if (dpeep_rows) { dpeep_rows[(size_t)b * 3 * U + j] = 0.f; dpeep_rows[(size_t)b * 3 * U + U + j] = 0.f; dpeep_rows[(size_t)b * 3 * U + 2 * U + j] = 0.f; }
     return;
   }
@@ -81,7 +86,7 @@ __global__ void cell_bwd_kernel(const float* __restrict__ dh_out_use, const floa
   const float i = gp[j], g = gp[U + j], f = gp[2 * U + j], o = gp[3 * U + j];
   const float wci = peep ? peep[j] : 0.f, wcf = peep ? peep[U + j] : 0.f, wco = peep ? peep[2 * U + j] : 0.f;
   const float c = c_raw[idx], cp = c_prev[idx];
-  const float dh = dh_out_use[idx] + dh_next[idx];
+  const float dh = (use_mask ? dh_out_use[idx] * use_mask[idx] : dh_out_use[idx]) + dhn;
   const float tc = tanhf(c);
   const float d_o = dh * tc * o * (1.f - o);
   const float dc = dc_next[idx] + dh * o * (1.f - tc * tc) + d_o * wco;
@@ -108,9 +113,13 @@ constexpr int ATT_CH = 64;                      // frames per workgroup
 __global__ __launch_bounds__(256) void att_energy_fwd_kernel(const float* __restrict__ keys,
                                                              const float* __restrict__ qz,
                                                              const float* __restrict__ v, int T, int B,
-                                                             int A, int mode, float* __restrict__ energy) {
+                                                             int A, int mode, float* __restrict__ energy,
+                                                             const int32_t* __restrict__ seq_len) {
+  // seq_len (may be NULL): frames at or past an utterance's length are masked by the softmax that follows and are
+  // neither computed nor written
   const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t0 = blockIdx.x * ATT_CH, t1 = min(T, t0 + ATT_CH);
+  const int tend = seq_len ? min(max(seq_len[b], 0), T) : T;
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(tend, t0 + ATT_CH);
   const float* q = qz + (size_t)b * A;
   for (int t = t0 + wave; t < t1; t += 4) {
     const float* k = keys ? keys + ((size_t)t * B + b) * A : nullptr;
@@ -130,11 +139,14 @@ __global__ __launch_bounds__(256) void att_energy_bwd_kernel(const float* __rest
                                                              const float* __restrict__ qz,
                                                              const float* __restrict__ v, int T, int B,
                                                              int A, int mode, float* __restrict__ dkeys,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part,
+                                                             const int32_t* __restrict__ seq_len) {
+  // seq_len (may be NULL): denergy is zero at and past an utterance's length, those frames are skipped
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* acc = reinterpret_cast<float*>(smem);   // [4 waves][2][A]
   const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t0 = blockIdx.x * ATT_CH, t1 = min(T, t0 + ATT_CH);
+  const int tend = seq_len ? min(max(seq_len[b], 0), T) : T;
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(tend, t0 + ATT_CH);
   const float* q = qz + (size_t)b * A;
   for (int a = lane; a < 2 * A; a += 64) acc[wave * 2 * A + a] = 0.f;
   for (int t = t0 + wave; t < t1; t += 4) {
@@ -166,6 +178,7 @@ __global__ void att_energy_bwd_reduce_kernel(const float* __restrict__ part, int
   if (i >= B * A) return;
   const int b = i / A, a = i % A;
   float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
   for (int c = 0; c < nch; ++c) {
     const float* o = part + ((size_t)c * B + b) * 2 * A;
     s0 += o[a];
@@ -294,6 +307,7 @@ __global__ void att_ctx_reduce_kernel(const float* __restrict__ part, int nch, i
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= BE) return;
   float c = 0.f;
+#pragma unroll 8
   for (int k = 0; k < nch; ++k) c += part[(size_t)k * BE + i];   // fixed order
   ctx[i] = c;
   if (ctx2) ctx2[(size_t)(i / E) * ld2 + i % E] = c;
@@ -324,6 +338,85 @@ __global__ __launch_bounds__(256) void att_dalpha_kernel(const float* __restrict
     }
     s = wave_reduce_sum(s);
     if (lane == 0) da[(size_t)b * T + t] = s;
+  }
+}
+// The same product for the rows the decoder loop streams every step (E a multiple of 64 sixteen-byte vectors): the
+// lane keeps its slice of dctx in registers, a wave takes FOUR frames per trip and issues their 4 G sixteen-byte loads
+// before the first multiply (the one-frame form above waits for each row in turn and ran at a third of the stream
+// rate of att_ctx_partial_kernel over the same bytes).  dctx = dctx_a (+ dctx_b, row stride ldb): inside the loop the
+// attentional-vector part plus the context columns of the next step's cell-input gradient; the sum is also written
+// to dctx_out (by the first workgroup of each utterance) for the d_enc contraction after the loop.
+template <typename TE> struct EncVec;
+template <> struct EncVec<float> {
+  static constexpr int N = 4;
+  typedef f32x4_t raw_t;
+  static __device__ __forceinline__ void unpack(const raw_t& r, float* o) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = r[i];
+  }
+};
+template <> struct EncVec<bf16_t> {
+  static constexpr int N = 8;
+  typedef bf16x8_t raw_t;
+  static __device__ __forceinline__ void unpack(const raw_t& r, float* o) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32((bf16_t)r[i]);
+  }
+};
+template <typename TE, int G>
+__global__ __launch_bounds__(256) void att_dalpha_vec_kernel(const float* __restrict__ dctx_a,
+                                                             const float* __restrict__ dctx_b, int ldb,
+                                                             float* __restrict__ dctx_out,
+                                                             const int32_t* __restrict__ seq_len,
+                                                             const TE* __restrict__ enc, int T, int B, int E,
+                                                             float* __restrict__ da) {
+  typedef EncVec<TE> V;
+  constexpr int N = V::N;
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int len = min(max(seq_len[b], 0), T);
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(len, t0 + ATT_CH);
+  float d[G][N];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int e0 = (g * 64 + lane) * N;
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+      f32x4_t x = *reinterpret_cast<const f32x4_t*>(dctx_a + (size_t)b * E + e0 + i);
+      if (dctx_b) {
+        const f32x4_t y = *reinterpret_cast<const f32x4_t*>(dctx_b + (size_t)b * ldb + e0 + i);
+        x[0] += y[0]; x[1] += y[1]; x[2] += y[2]; x[3] += y[3];
+      }
+      if (dctx_out && blockIdx.x == 0 && wave == 0) *reinterpret_cast<f32x4_t*>(dctx_out + (size_t)b * E + e0 + i) = x;
+      d[g][i] = x[0]; d[g][i + 1] = x[1]; d[g][i + 2] = x[2]; d[g][i + 3] = x[3];
+    }
+  }
+  for (int tb = t0 + wave * 4; tb < t1; tb += 16) {
+    typename V::raw_t x[4][G];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int t = min(tb + f, t1 - 1);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        x[f][g] = *reinterpret_cast<const typename V::raw_t*>(enc + ((size_t)t * B + b) * E + (g * 64 + lane) * N);
+    }
+    float sum[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      float acc = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float xv[N];
+        V::unpack(x[f][g], xv);
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc += xv[i] * d[g][i];
+      }
+      sum[f] = wave_reduce_sum(acc);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        if (tb + f < t1) da[(size_t)b * T + tb + f] = sum[f];
+    }
   }
 }
 // denergy[b,t] = sharp * alpha * (dalpha - sum_t alpha dalpha)   (zero past len)
@@ -710,37 +803,49 @@ extern "C" int asr_lstm_cell_fwd(asr_handle* h, const float* pre, const float* c
                               h_out, h_raw, nullptr, nullptr, nullptr, 0, nullptr, 0, s);
 }
 
+static int cell_bwd_launch(asr_handle* h, const float* dh_use, const float* dc_next, const float* dh_next,
+                           const float* gates, const float* c_raw, const float* c_prev, const float* peep,
+                           const float* live, int B, int U, float* dpre, float* dc_prev, float* dh_prev_carry,
+                           float* dpeep_rows, const float* dh_next2, int ld2, const float* use_mask, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(dh_use && dc_next && dh_next && gates && c_raw && c_prev && live && dpre && dc_prev && dh_prev_carry &&
+               B > 0 && U > 0 && (!dh_next2 || ld2 >= U), "asr_lstm_cell_bwd: bad args");
+  hipLaunchKernelGGL(cell_bwd_kernel, dim3((B * U + 255) / 256), dim3(256), 0, (hipStream_t)s, dh_use, dc_next,
+                     dh_next, gates, c_raw, c_prev, peep, live, B, U, dpre, dc_prev, dh_prev_carry, dpeep_rows,
+                     dh_next2, ld2, use_mask);
+  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_bwd");
+  return ASR_OK;
+}
 extern "C" int asr_lstm_cell_bwd(asr_handle* h, const float* dh_use, const float* dc_next, const float* dh_next,
                                  const float* gates, const float* c_raw, const float* c_prev, const float* peep,
                                  const float* live, int B, int U, float* dpre, float* dc_prev,
                                  float* dh_prev_carry, float* dpeep_rows, asr_stream s) {
-  if (!h) return ASR_ERR_INVALID_ARG;
-  ATT_NEED(dh_use && dc_next && dh_next && gates && c_raw && c_prev && live && dpre && dc_prev && dh_prev_carry &&
-               B > 0 && U > 0, "asr_lstm_cell_bwd: bad args");
-  hipLaunchKernelGGL(cell_bwd_kernel, dim3((B * U + 255) / 256), dim3(256), 0, (hipStream_t)s, dh_use, dc_next,
-                     dh_next, gates, c_raw, c_prev, peep, live, B, U, dpre, dc_prev, dh_prev_carry, dpeep_rows);
-  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_bwd");
-  return ASR_OK;
+  return cell_bwd_launch(h, dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, B, U, dpre, dc_prev,
+                         dh_prev_carry, dpeep_rows, nullptr, 0, nullptr, s);
 }
 
-extern "C" int asr_att_energy_fwd(asr_handle* h, const float* keys, const float* qz, const float* v, int T,
-                                  int B, int A, int mode, float* energy, asr_stream s) {
+static int energy_fwd_launch(asr_handle* h, const float* keys, const float* qz, const float* v, int T, int B, int A,
+                             int mode, float* energy, const int32_t* seq_len, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(qz && energy && T > 0 && B > 0 && A > 0 && (mode == 0 ? v != nullptr : keys != nullptr),
            "asr_att_energy_fwd: bad args");
   hipLaunchKernelGGL(att_energy_fwd_kernel, dim3((T + ATT_CH - 1) / ATT_CH, B), dim3(256), 0, (hipStream_t)s, keys, qz,
-                     v, T, B, A, mode, energy);
+                     v, T, B, A, mode, energy, seq_len);
   ASR_CHECK_LAUNCH(h, "asr_att_energy_fwd");
   return ASR_OK;
+}
+extern "C" int asr_att_energy_fwd(asr_handle* h, const float* keys, const float* qz, const float* v, int T,
+                                  int B, int A, int mode, float* energy, asr_stream s) {
+  return energy_fwd_launch(h, keys, qz, v, T, B, A, mode, energy, nullptr, s);
 }
 
 static inline float* att_scratch(asr_handle* h, size_t bytes) {
   return (bytes <= h->scratch_bytes - ASR_XCH_BYTES) ? (float*)h->scratch : nullptr;
 }
 
-extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const float* keys, const float* qz,
-                                  const float* v, int T, int B, int A, int mode, float* dkeys, float* dqz,
-                                  float* dv_rows, asr_stream s) {
+static int energy_bwd_launch(asr_handle* h, const float* denergy, const float* keys, const float* qz, const float* v,
+                             int T, int B, int A, int mode, float* dkeys, float* dqz, float* dv_rows,
+                             const int32_t* seq_len, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(denergy && qz && dqz && T > 0 && B > 0 && A > 0, "asr_att_energy_bwd: bad args");
   const int nch = (T + ATT_CH - 1) / ATT_CH;
@@ -748,11 +853,16 @@ extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const flo
   if (!part) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_energy_bwd: scratch too small");
   const size_t lds = (size_t)8 * A * sizeof(float);
   hipLaunchKernelGGL(att_energy_bwd_kernel, dim3(nch, B), dim3(256), lds, (hipStream_t)s, denergy, keys, qz, v, T, B,
-                     A, mode, dkeys, part);
+                     A, mode, dkeys, part, seq_len);
   hipLaunchKernelGGL(att_energy_bwd_reduce_kernel, dim3((B * A + 255) / 256), dim3(256), 0, (hipStream_t)s, part, nch,
                      B, A, dqz, dv_rows);
   ASR_CHECK_LAUNCH(h, "asr_att_energy_bwd");
   return ASR_OK;
+}
+extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const float* keys, const float* qz,
+                                  const float* v, int T, int B, int A, int mode, float* dkeys, float* dqz,
+                                  float* dv_rows, asr_stream s) {
+  return energy_bwd_launch(h, denergy, keys, qz, v, T, B, A, mode, dkeys, dqz, dv_rows, nullptr, s);
 }
 
 extern "C" int asr_att_loc_energy_fwd(asr_handle* h, const float* alpha_prev, const float* filt, const float* wfil,
@@ -836,28 +946,75 @@ extern "C" int asr_att_softmax_ctx_fwd_ex(asr_handle* h, const float* energy, co
   return ASR_OK;
 }
 
+namespace {
+__global__ void add_cols_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
+                                float* __restrict__ out, int ldo, int B, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * W) return;
+  const int b = i / W, j = i % W;
+  out[(size_t)b * ldo + j] = x[(size_t)b * ldx + j] + y[(size_t)b * ldy + j];
+}
+template <typename TE>
+bool dalpha_vec_launch(const float* da_, const float* db_, int ldb, float* dout, const int32_t* seq_len, const TE* enc,
+                       int T, int B, int E, float* da, hipStream_t st) {
+  constexpr int N = EncVec<TE>::N;
+  if (E % (64 * N) != 0 || ((uintptr_t)enc) % 16 != 0 || ((uintptr_t)da_) % 16 != 0 ||
+      (db_ && (((uintptr_t)db_) % 16 != 0 || ldb % 4 != 0)) || (dout && ((uintptr_t)dout) % 16 != 0))
+    return false;
+  const dim3 grid((T + ATT_CH - 1) / ATT_CH, B);
+  switch (E / (64 * N)) {
+    case 1: hipLaunchKernelGGL((att_dalpha_vec_kernel<TE, 1>), grid, dim3(256), 0, st, da_, db_, ldb, dout, seq_len, enc, T, B, E, da); return true;
+    case 2: hipLaunchKernelGGL((att_dalpha_vec_kernel<TE, 2>), grid, dim3(256), 0, st, da_, db_, ldb, dout, seq_len, enc, T, B, E, da); return true;
+    case 4: hipLaunchKernelGGL((att_dalpha_vec_kernel<TE, 4>), grid, dim3(256), 0, st, da_, db_, ldb, dout, seq_len, enc, T, B, E, da); return true;
+    default: return false;
+  }
+}
+}  // namespace
+
+// dctx = dctx_a (+ dctx_b with row stride ldb, may be NULL); the sum goes to dctx_out when that is given
+static int softmax_ctx_bwd_launch(asr_handle* h, const float* dctx_a, const float* dctx_b, int ldb, float* dctx_out,
+                                  const float* alpha, const int32_t* seq_len, float sharpening, const void* enc,
+                                  int enc_dtype, int T, int B, int E, float* denergy, float* denc,
+                                  const float* sigmoid_norm, const float* dalpha_extra, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(dctx_a && alpha && seq_len && enc && denergy && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype) &&
+               (!dctx_b || (dctx_out && ldb >= E)), "asr_att_softmax_ctx_bwd: bad args");
+  hipStream_t st = (hipStream_t)s;
+  const int nch = (T + ATT_CH - 1) / ATT_CH;
+  float* da = att_scratch(h, (size_t)B * T * sizeof(float));
+  if (!da) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_softmax_ctx_bwd: scratch too small");
+  const bool fast = enc_dtype == ASR_F32
+                        ? dalpha_vec_launch<float>(dctx_a, dctx_b, ldb, dctx_out, seq_len, (const float*)enc, T, B, E, da, st)
+                        : dalpha_vec_launch<bf16_t>(dctx_a, dctx_b, ldb, dctx_out, seq_len, (const bf16_t*)enc, T, B, E, da, st);
+  const float* dctx = dctx_a;
+  if (!fast) {
+    if (dctx_b) {
+      hipLaunchKernelGGL(add_cols_kernel, dim3((B * E + 255) / 256), dim3(256), 0, st, dctx_a, E, dctx_b, ldb, dctx_out,
+                         E, B, E);
+      dctx = dctx_out;
+    }
+    if (enc_dtype == ASR_F32)
+      hipLaunchKernelGGL(att_dalpha_kernel<float>, dim3(nch, B), dim3(256), 0, st, dctx, seq_len, (const float*)enc, T,
+                         B, E, da);
+    else
+      hipLaunchKernelGGL(att_dalpha_kernel<bf16_t>, dim3(nch, B), dim3(256), 0, st, dctx, seq_len, (const bf16_t*)enc,
+                         T, B, E, da);
+  } else if (dctx_b) {
+    dctx = dctx_out;
+  }
+  hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(B), dim3(256), 0, st, da, alpha, seq_len, sharpening, T, denergy,
+                     sigmoid_norm, dalpha_extra);
+  if (denc)   // NULL: the caller accumulates d_enc = sum_steps alpha (x) dctx itself (one GEMM per utterance)
+    hipLaunchKernelGGL(att_denc_kernel, dim3(nch, B), dim3(256), 0, st, dctx, alpha, seq_len, T, B, E, denc);
+  ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_bwd");
+  return ASR_OK;
+}
 extern "C" int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const float* alpha,
                                        const int32_t* seq_len, float sharpening, const void* enc, int enc_dtype,
                                        int T, int B, int E, float* denergy, float* denc,
                                        const float* sigmoid_norm, const float* dalpha_extra, asr_stream s) {
-  if (!h) return ASR_ERR_INVALID_ARG;
-  ATT_NEED(dctx && alpha && seq_len && enc && denergy && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype),
-           "asr_att_softmax_ctx_bwd: bad args");
-  const int nch = (T + ATT_CH - 1) / ATT_CH;
-  float* da = att_scratch(h, (size_t)B * T * sizeof(float));
-  if (!da) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_softmax_ctx_bwd: scratch too small");
-  if (enc_dtype == ASR_F32)
-    hipLaunchKernelGGL(att_dalpha_kernel<float>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, seq_len,
-                       (const float*)enc, T, B, E, da);
-  else
-    hipLaunchKernelGGL(att_dalpha_kernel<bf16_t>, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, seq_len,
-                       (const bf16_t*)enc, T, B, E, da);
-  hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, da, alpha, seq_len, sharpening, T,
-                     denergy, sigmoid_norm, dalpha_extra);
-  if (denc)   // NULL: the caller accumulates d_enc = sum_steps alpha (x) dctx itself (one GEMM per utterance)
-    hipLaunchKernelGGL(att_denc_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)s, dctx, alpha, seq_len, T, B, E, denc);
-  ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_bwd");
-  return ASR_OK;
+  return softmax_ctx_bwd_launch(h, dctx, nullptr, 0, nullptr, alpha, seq_len, sharpening, enc, enc_dtype, T, B, E,
+                                denergy, denc, sigmoid_norm, dalpha_extra, s);
 }
 
 extern "C" int asr_tanh_fwd(asr_handle* h, const float* x, float* y, size_t n, asr_stream s) {
@@ -918,3 +1075,138 @@ extern "C" int asr_argmax_rows(asr_handle* h, const float* x, int rows, int C, i
   ASR_CHECK_LAUNCH(h, "asr_argmax_rows");
   return ASR_OK;
 }
+
+// ---------------------------------------------------------------- the decoder loop, native
+extern "C" int asr_add_cols(asr_handle* h, const float* x, int ldx, const float* y, int ldy, float* out, int ldo, int B,
+                            int W, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ATT_NEED(x && y && out && B > 0 && W > 0 && ldx >= W && ldy >= W && ldo >= W, "asr_add_cols: bad args");
+  hipLaunchKernelGGL(add_cols_kernel, dim3((B * W + 255) / 256), dim3(256), 0, (hipStream_t)s, x, ldx, y, ldy, out, ldo,
+                     B, W);
+  ASR_CHECK_LAUNCH(h, "asr_add_cols");
+  return ASR_OK;
+}
+
+#define DEC_TRY(call) do { const int rc_ = (call); if (rc_ != ASR_OK) return rc_; } while (0)
+
+static int dec_check(asr_handle* h, const asr_att_decoder* a, bool bwd) {
+  if (!a || a->To < 1 || a->B < 1 || a->T < 1 || a->U < 1 || a->Em < 0 || a->E2 < 1 || a->A < 1 || !a->W_cell ||
+      !a->b_cell || !a->enc || !a->seq_len || !a->live || !a->dec_in || !a->av_in || !a->alpha_all || !a->gates_all ||
+      !a->craw_all || !a->c_all || !a->h_all || !a->qz_all || !a->work || (a->att_mode != 0 && a->att_mode != 1) ||
+      (a->has_query_fc && !a->W_q) || (!a->has_query_fc && a->A != a->U) || (a->att_mode == 0 && !a->v) ||
+      (a->att_mode == 1 && !a->keys) || (a->carry_alpha && (!a->filt || !a->wfil || !a->alpha_zero || a->taps < 1)))
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_att_decoder: bad arguments");
+  if (bwd && (!a->dav_cell || !a->dav_ctx || !a->dctx_all || !a->dpre_all || !a->dqz_all || !a->d_in_all || !a->dc0 ||
+              !a->dh0 || (a->att_mode == 0 && !a->dv_all) || (a->peep && !a->dpeep_all) ||
+              (a->carry_alpha && (!a->dwfil_rows || !a->dfilt_rows))))
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_att_decoder_bwd: bad arguments");
+  return ASR_OK;
+}
+
+extern "C" int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  DEC_TRY(dec_check(h, a, false));
+  const int B = a->B, U = a->U, T = a->T, E2 = a->E2, Em = a->Em, A = a->A;
+  const int Din = Em + E2 + U, Dav = U + E2;
+  float* pre = a->work;                                    // [B,4U]
+  float* hraw = pre + (size_t)B * 4 * U;                   // [B,U]
+  float* energy = hraw + (size_t)B * U;                    // [B,T]
+  float* ctx = energy + (size_t)B * T;                     // [B,E2]
+  for (int k = 0; k < a->To; ++k) {
+    float* din = a->dec_in + (size_t)k * B * Din;
+    float* dnext = (k + 1 < a->To) ? din + (size_t)B * Din : nullptr;
+    float* av = a->av_in + (size_t)k * B * Dav;
+    float* qz = a->qz_all + (size_t)k * B * A;
+    DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, 4 * U, Din, din, Din, a->W_cell, 4 * U, pre, 4 * U, a->b_cell, 0, 0, s));
+    // the cell output (times its dropout mask) lands in av[:, :U]; without a query FC it IS the query
+    DEC_TRY(asr_lstm_cell_fwd_ex(h, pre, a->c_all + (size_t)k * B * U, a->h_all + (size_t)k * B * U, a->peep,
+                                 a->live + (size_t)k * B, B, U, a->forget_bias, a->cell_clip,
+                                 a->gates_all + (size_t)k * B * 4 * U, a->craw_all + (size_t)k * B * U,
+                                 a->c_all + (size_t)(k + 1) * B * U, a->h_all + (size_t)(k + 1) * B * U, hraw,
+                                 a->dmask ? a->dmask + (size_t)k * B * U : nullptr, a->has_query_fc ? nullptr : qz,
+                                 dnext ? dnext + Em + E2 : nullptr, Din, av, Dav, s));
+    if (a->has_query_fc)
+      DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, A, U, av, Dav, a->W_q, a->ld_wq, qz, A, a->b_q, 0, 0, s));
+    if (a->carry_alpha)
+      DEC_TRY(asr_att_loc_energy_fwd(h, k > 0 ? a->alpha_all + (size_t)(k - 1) * B * T : a->alpha_zero, a->filt, a->wfil,
+                                     a->keys, qz, a->v, T, B, A, a->taps, energy, s));
+    else
+      DEC_TRY(energy_fwd_launch(h, a->keys, qz, a->v, T, B, A, a->att_mode, energy, a->seq_len, s));
+    DEC_TRY(asr_att_softmax_ctx_fwd_ex(h, energy, a->seq_len, a->sharpening, a->enc, a->enc_dtype, T, B, E2,
+                                       a->alpha_all + (size_t)k * B * T, ctx,
+                                       a->snorm_all ? a->snorm_all + (size_t)k * B : nullptr, av + U, Dav,
+                                       dnext ? dnext + Em : nullptr, Din, s));
+  }
+  return ASR_OK;
+}
+
+extern "C" int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  DEC_TRY(dec_check(h, a, true));
+  const int B = a->B, U = a->U, T = a->T, E2 = a->E2, Em = a->Em, A = a->A, To = a->To;
+  const int Din = Em + E2 + U;
+  hipStream_t st = (hipStream_t)s;
+  // work: dc / carried-dh state (two buffers each, ping-pong), denergy, dalpha_prev x2
+  float* dcs[2] = {a->work, a->work + (size_t)B * U};
+  float* dhc[2] = {a->work + (size_t)2 * B * U, a->work + (size_t)3 * B * U};
+  float* dalp[2] = {a->work + (size_t)4 * B * U, a->work + (size_t)4 * B * U + (size_t)B * T};
+  float* denergy = dalp[1] + (size_t)B * T;
+  if (hipMemsetAsync(dcs[0], 0, (size_t)B * U * sizeof(float), st) != hipSuccess ||
+      hipMemsetAsync(dhc[0], 0, (size_t)B * U * sizeof(float), st) != hipSuccess)
+    ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder_bwd: memset");
+  int cur = 0;
+  const float* dalpha_next = nullptr;
+  for (int k = To - 1; k >= 0; --k) {
+    // d loss / d ctx_k = attentional-vector part + the context columns of step k+1's cell-input gradient; the sum is
+    // formed inside the d-alpha kernel (and kept in dctx_all for the d_enc contraction after the loop)
+    float* dctx = a->dctx_all + (size_t)k * B * E2;
+    const float* dav_ctx = a->dav_ctx + (size_t)k * B * E2;
+    const float* d_in_next = (k + 1 < To) ? a->d_in_all + (size_t)(k + 1) * B * Din : nullptr;
+    const float* alpha_k = a->alpha_all + (size_t)k * B * T;
+    const float* qz = a->qz_all + (size_t)k * B * A;
+    float* dqz = a->dqz_all + (size_t)k * B * A;
+    float* dv = a->dv_all ? a->dv_all + (size_t)k * B * A : nullptr;
+    if (d_in_next) {
+      DEC_TRY(softmax_ctx_bwd_launch(h, dav_ctx, d_in_next + Em, Din, dctx, alpha_k, a->seq_len, a->sharpening, a->enc,
+                                     a->enc_dtype, T, B, E2, denergy, nullptr,
+                                     a->snorm_all ? a->snorm_all + (size_t)k * B : nullptr, dalpha_next, s));
+    } else {
+      if (hipMemcpyAsync(dctx, dav_ctx, (size_t)B * E2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder_bwd: copy");
+      DEC_TRY(softmax_ctx_bwd_launch(h, dctx, nullptr, 0, nullptr, alpha_k, a->seq_len, a->sharpening, a->enc,
+                                     a->enc_dtype, T, B, E2, denergy, nullptr,
+                                     a->snorm_all ? a->snorm_all + (size_t)k * B : nullptr, dalpha_next, s));
+    }
+    if (a->carry_alpha) {
+      float* dap = dalp[k & 1];
+      DEC_TRY(asr_att_loc_energy_bwd(h, denergy, k > 0 ? a->alpha_all + (size_t)(k - 1) * B * T : a->alpha_zero, a->filt,
+                                     a->wfil, a->keys, qz, a->v, T, B, A, a->taps, a->dkeys, dqz, dv, a->dwfil_rows,
+                                     a->dfilt_rows, dap, k != To - 1, s));
+      dalpha_next = dap;
+    } else {
+      DEC_TRY(energy_bwd_launch(h, denergy, a->keys, qz, a->v, T, B, A, a->att_mode, a->dkeys, dqz, dv, a->seq_len, s));
+    }
+    float* dcell = const_cast<float*>(a->dav_cell) + (size_t)k * B * U;
+    if (a->has_query_fc)
+      DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 1, B, U, A, dqz, A, a->W_q, a->ld_wq, dcell, U, nullptr, 1, 0, s));
+    else
+      DEC_TRY(asr_add_cols(h, dcell, U, dqz, A, dcell, U, B, U, s));
+    // the cell kernel applies the output dropout mask to dcell and adds the h-columns of step k+1's cell-input
+    // gradient to the carried dh itself
+    float* dpre = a->dpre_all + (size_t)k * B * 4 * U;
+    DEC_TRY(cell_bwd_launch(h, dcell, dcs[cur], dhc[cur], a->gates_all + (size_t)k * B * 4 * U,
+                            a->craw_all + (size_t)k * B * U, a->c_all + (size_t)k * B * U, a->peep,
+                            a->live + (size_t)k * B, B, U, dpre, dcs[cur ^ 1], dhc[cur ^ 1],
+                            a->dpeep_all ? a->dpeep_all + (size_t)k * B * 3 * U : nullptr,
+                            d_in_next ? d_in_next + Em + E2 : nullptr, Din,
+                            a->dmask ? a->dmask + (size_t)k * B * U : nullptr, s));
+    float* d_in = a->d_in_all + (size_t)k * B * Din;
+    DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 1, B, Din, 4 * U, dpre, 4 * U, a->W_cell, 4 * U, d_in, Din, nullptr, 0, 0, s));
+    cur ^= 1;
+  }
+  DEC_TRY(asr_add_cols(h, dhc[cur], U, a->d_in_all + Em + E2, Din, a->dh0, U, B, U, s));
+  if (hipMemcpyAsync(a->dc0, dcs[cur], (size_t)B * U * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder_bwd: copy");
+  return ASR_OK;
+}
+

@@ -412,6 +412,129 @@ static inline unsigned xcd_grid(long work, int skip) {     // workgroups to laun
   return (unsigned)((work + per - 1) / per * 8);
 }
 
+// ---------------------------------------------------------------- skinny fp32 kernel (M <= 32)
+// C[M,N] = A[M,K] op(B) (+bias)(+C)(relu), fp32, M <= 32: the per-step products of the attention decoder (cell input
+// 1600 -> 2048 and back, query 512 <-> 128 at B = 32 utterances, attention_decoder.py:142-229).  They are weight
+// streaming -- 13 MB of W_cell per step against 0.2 GFLOP -- and sit on the decoder's serial chain, so what counts is
+// how many CUs pull on the weights and how many bytes each has in flight.  One workgroup owns 16*NT output columns of
+// ONE 16-row group (grid.y = row groups: the fp32 MFMA rate of the 64..100 column tiles alone is ~7 us per product,
+// so the rows are spread over twice the CUs and B comes out of L2 for the second group); its eight waves split K in
+// 64-element units (interleaved), and a wave issues the loads of its NEXT unit (4 float4 of A, NT x 4 float4 -- or
+// NT x 16 row-segment words -- of B) before the MFMAs of the current one.  TRANSB reads a float4 of a B^T row per
+// lane, the plain form reads full 128-byte lines (NT = 2).  The products are exact fp32 MFMAs (16x16x4) and the eight
+// partial tiles meet in LDS in a fixed order (deterministic).
+// Requires K % 64 == 0, N % (16 NT) == 0, 16-byte aligned rows.
+constexpr int SK_WAVES = 8;
+template <bool TRANSB, int NT>
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_f32_kernel(int M, int N, int K, const float* __restrict__ A,
+                                                                        int lda, const float* __restrict__ Bm, int ldb,
+                                                                        float* __restrict__ C, int ldc,
+                                                                        const float* __restrict__ bias, int accumulate,
+                                                                        int act) {
+  constexpr int TN = 16 * NT;
+  __shared__ float red[SK_WAVES][16][TN + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rg = lane >> 4;
+  const int n0 = blockIdx.x * TN, m0 = blockIdx.y * 16;
+  struct Frag {
+    f32x4_t a[4], b[NT][4];
+    float keep;                 // 1 for a real unit, 0 for a round past the end (A is zeroed at the multiply)
+  };
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float* ap = A + (size_t)min(m0 + col, M - 1) * lda + rg * 4;   // rows past M read a valid row, masked at the store
+  const int units = K / 64;
+  // round r of a wave is the 64-element unit wave + 8r; rounds past the end re-read the last unit with A zeroed, so
+  // every wave runs the same (even) number of rounds and every prefetch below is consumed -- a prefetch whose use sits
+  // behind a branch gets sunk below the multiplies by the compiler, which serialises load and multiply again
+  auto load = [&](int round, Frag& f) {
+    const int unit = wave + round * SK_WAVES;
+    const bool valid = unit < units;
+    const int kb = (valid ? unit : units - 1) * 64;
+    f.keep = valid ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f.a[j] = *reinterpret_cast<const f32x4_t*>(ap + kb + j * 16);     // A[row][kb + 16j + 4rg + e]
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {                                    // B[kb + 16j + 4rg + e][n0 + 16n + col]
+        if (TRANSB) {
+          f.b[n][j] = *reinterpret_cast<const f32x4_t*>(Bm + (size_t)(n0 + n * 16 + col) * ldb + kb + j * 16 + rg * 4);
+        } else {
+          const float* bp = Bm + (size_t)(kb + j * 16 + rg * 4) * ldb + n0 + n * 16 + col;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f.b[n][j][e] = bp[(size_t)e * ldb];
+        }
+      }
+    }
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[j][e] * f.keep, f.b[n][j][e], acc[n], 0, 0, 0);
+  };
+  Frag f0, f1;
+  load(0, f0);
+  if (units <= SK_WAVES) {                  // one round: nothing to overlap
+    mma(f0);
+  } else {
+    const int rounds = ((units + SK_WAVES - 1) / SK_WAVES + 1) & ~1;
+    for (int r = 0; r < rounds; r += 2) {   // the loads of one round are in flight under the MFMAs of the other
+      load(r + 1, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(r + 2, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // lane holds C[m0 + rg*4 + r][n0 + n*16 + col]
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][rg * 4 + r][n * 16 + col] = acc[n][r];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 16 * TN; idx += 64 * SK_WAVES) {
+    const int m = idx / TN, n = idx % TN;
+    if (m0 + m >= M) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) v += red[w][m][n];
+    if (bias) v += bias[n0 + n];
+    float* cp = C + (size_t)(m0 + m) * ldc + n0 + n;
+    if (accumulate) v += *cp;
+    if (act == 1) v = fmaxf(v, 0.f);
+    *cp = v;
+  }
+}
+
+static bool try_gemm_skinny_f32(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
+                                int ldb, void* C, int ldc, const float* bias, int accumulate, hipStream_t st, int act) {
+  if (transA || M < 1 || M > 32 || K % 64 != 0 || N % 16 != 0 || K < 64) return false;
+  if (lda % 4 != 0 || ((uintptr_t)A) % 16 != 0 || ((uintptr_t)B) % 16 != 0) return false;
+  if (transB && ldb % 4 != 0) return false;
+  // full 128-byte lines of a row-major B need 32 columns per workgroup; B^T rows are contiguous in k, so the narrow
+  // tile (twice the workgroups) is used until the launch is wide enough anyway
+  const bool wide = (N % 32 == 0) && (!transB || N >= 32 * 192);
+  const unsigned gy = (unsigned)((M + 15) / 16);
+#define ASR_SKINNY(TB, NT_)                                                                                             \
+  hipLaunchKernelGGL((gemm_skinny_f32_kernel<TB, NT_>), dim3(N / (16 * NT_), gy), dim3(64 * SK_WAVES), 0, st, M, N, K, \
+                     (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, bias, accumulate, act)
+  if (transB) {
+    if (wide) ASR_SKINNY(true, 2); else ASR_SKINNY(true, 1);
+  } else {
+    if (wide) ASR_SKINNY(false, 2); else ASR_SKINNY(false, 1);
+  }
+#undef ASR_SKINNY
+  return true;
+}
+
 // ---------------------------------------------------------------- lean TN kernel (bf16)
 // C[M,N] = A^T B with A [K,M] and B [K,N] both REDUCTION-MAJOR (row = one k): the weight-gradient
 // products X^T dG with K = T*B.  The MFMA fragments want 8 consecutive k per lane, so the tiles are
@@ -842,6 +965,9 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
                 const void* B, int ldb, void* C, int ldc, const float* bias, int accumulate,
                 hipStream_t st, int act, const float* mul = nullptr, int ldm = 0, bool* mul_done = nullptr) {
   constexpr int VEC = GT<T>::VEC, BK = GT<T>::BK;
+  if constexpr (sizeof(T) == 4 && sizeof(TO) == 4) {
+    if (try_gemm_skinny_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act)) return 0;
+  }
   if constexpr (sizeof(T) == 2) {
     if (try_gemm_nt_bf16<TO>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act, mul, ldm)) {
       if (mul_done) *mul_done = true;

@@ -270,7 +270,6 @@ class AttentionSeq2Seq(ModelBase):
         ctx = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
         W_cell, b_cell = st[D + 'lstm_cell/kernel'], st[D + 'lstm_cell/bias']
         v = st[AT + 'v_a'] if self.att_mode == 0 else None
-        saved = []
         alpha_all = torch.empty((To, Bp, T), dtype=torch.float32, device=dev)   # one slab: d_enc GEMMs read it strided
         use_ddrop = is_training and float(keep_prob_decoder) < 1.0
         dec_in[:, :, :Em].copy_(emb.view(To, Bp, Em))          # the embedded inputs of all steps at once
@@ -283,31 +282,28 @@ class AttentionSeq2Seq(ModelBase):
         alpha_zero = torch.zeros((Bp, T), dtype=torch.float32, device=dev) if self.carry_alpha else None
         dec_in[0, :, Em:Em + E2].copy_(ctx)
         dec_in[0, :, Em + E2:].copy_(h)
-        for k in range(To):
-            # the cell output (after its DropoutWrapper) and the carried h are also written, by the cell kernel itself,
-            # into the column blocks their consumers read: the attentional vector's input of this step and the cell
-            # input of the next one; the context likewise below -- no copy launches inside the step
-            pre = ops.gemm(dec_in[k], W_cell, bias=b_cell)
-            dmask = dmask_all[k] if use_ddrop else None
-            nxt = dec_in[k + 1] if k + 1 < To else None
-            gates, c_raw, c_new, h_new, h_raw, cell_out = ops.lstm_cell_fwd(
-                pre, c, h, peep, live_d[k], 1.0, self.clip_activation_decoder or 0.0, out_mask=dmask,
-                want_cell_out=True, h_also=nxt[:, Em + E2:] if nxt is not None else None,
-                cell_out_also=av_in[k, :, :U])
-            qz = self._query(cell_out)
-            if self.carry_alpha:     # previous weights (zeros at step 0, attention_decoder.py:163-164) -> conv -> W_filter
-                energy = ops.att_loc_energy_fwd(alpha_all[k - 1] if k > 0 else alpha_zero, st[AT + 'filter'],
-                                                st[AT + 'W_filter/weights'], keys, qz, v, T)
-            else:
-                energy = ops.att_energy_fwd(keys, qz, v, T, self.att_mode)
-            alpha, ctx_k = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc_att,
-                                                   alpha_out=alpha_all[k],
-                                                   sigmoid_norm=snorm_all[k] if snorm_all is not None else None,
-                                                   ctx_also=(av_in[k, :, U:],
-                                                             nxt[:, Em:Em + E2] if nxt is not None else None))
-            saved.append(dict(gates=gates, c_raw=c_raw, c_prev=c, qz=qz, alpha=alpha, dmask=dmask,
-                              snorm=snorm_all[k] if snorm_all is not None else None))
-            c, h, ctx = c_new, h_new, ctx_k
+        # the To decoder steps (cell-input GEMM -> cell -> query FC -> energies -> softmax + context, each kernel writing
+        # where the next one reads) are issued by ONE native call: a host loop over ~9 launches per step is host-bound
+        A = self.key_dim                                     # width of keys / query (== U for the luong_* types)
+        has_q = self.attention_type in AL.HAS_QUERY_FC
+        c_all = torch.empty((To + 1, Bp, U), dtype=torch.float32, device=dev)
+        h_all = torch.empty((To + 1, Bp, U), dtype=torch.float32, device=dev)
+        c_all[0].copy_(c)
+        h_all[0].copy_(h)
+        loop = dict(To=To, B=Bp, T=T, U=U, Em=Em, E2=E2, A=A, att_mode=self.att_mode, has_query_fc=int(has_q),
+                    carry_alpha=int(self.carry_alpha), taps=int(st[AT + 'filter'].shape[0]) if self.carry_alpha else 0,
+                    enc_dtype=ops.dtype_id(enc_att.dtype), forget_bias=1.0,
+                    cell_clip=float(self.clip_activation_decoder or 0.0), sharpening=float(self.sharpening_factor),
+                    W_cell=W_cell, b_cell=b_cell, peep=peep, W_q=self._wq() if has_q else None,
+                    b_q=st[AT + 'W_filter/biases'] if (has_q and self.attention_type in AL.HAS_FILTER) else None,
+                    v=v, keys=keys, enc=enc_att, seq_len=seq_p,
+                    filt=st[AT + 'filter'] if self.carry_alpha else None,
+                    wfil=st[AT + 'W_filter/weights'] if self.carry_alpha else None, alpha_zero=alpha_zero,
+                    live=live_d, dmask=dmask_all, dec_in=dec_in, av_in=av_in, alpha_all=alpha_all, snorm_all=snorm_all,
+                    gates_all=torch.empty((To, Bp, 4 * U), dtype=torch.float32, device=dev),
+                    craw_all=torch.empty((To, Bp, U), dtype=torch.float32, device=dev), c_all=c_all, h_all=h_all,
+                    qz_all=torch.empty((To, Bp, A), dtype=torch.float32, device=dev))
+        ops.att_decoder_fwd(loop)
         av = ops.tanh_fwd(ops.gemm(av_in.view(To * Bp, U + E2), st[D + 'attentional_vector/weights']))
         logits2d = ops.gemm(av, st[D + 'output_layer/weights'], bias=st[D + 'output_layer/biases'])
         logits2d = ops.apply_mask(logits2d, live_d.view(-1, 1).expand(To * Bp, C2).contiguous())  # impute_finished
@@ -343,7 +339,7 @@ class AttentionSeq2Seq(ModelBase):
         out_infer = AttentionDecoderOutput(lazy=lambda: self._decode_infer(*inf_args))
         if is_training:
             self._tape = dict(B=B, To=To, enc=enc, seq_p=seq_p, keys=keys, dec_in=dec_in, av_in=av_in, av=av,
-                              saved=saved, dlogits=dlogits, ids=ids_d, emb_mask=emb_mask, live=live_d, bi=bi,
+                              loop=loop, dlogits=dlogits, ids=ids_d, emb_mask=emb_mask, live=live_d, bi=bi,
                               peep=peep, ctc=ctc_tape, alpha_all=alpha_all, enc_att=enc_att)
         else:
             self._tape = None
@@ -361,7 +357,7 @@ class AttentionSeq2Seq(ModelBase):
             raise RuntimeError('train()/compute_gradients() needs a preceding compute_loss(is_training=True)')
         tp, st, dev = self._tape, self.store, self.device
         enc, seq_p, keys, dec_in, av_in, av = tp['enc'], tp['seq_p'], tp['keys'], tp['dec_in'], tp['av_in'], tp['av']
-        saved, To, live = tp['saved'], tp['To'], tp['live']
+        loop, To, live = tp['loop'], tp['To'], tp['live']
         T, Bp, E2 = enc.shape
         U, Em, C2, A = self.decoder_num_units, self.embedding_dim, self.num_classes, self.key_dim
         at = self.attention_type
@@ -385,55 +381,27 @@ class AttentionSeq2Seq(ModelBase):
         elif at == 'luong_dot':
             dkeys = denc
         dpre_all = torch.empty((To, Bp, 4 * U), dtype=torch.float32, device=dev)
-        dqz_all = torch.empty((To, Bp, saved[0]['qz'].shape[1]), dtype=torch.float32, device=dev)
+        dqz_all = torch.empty((To, Bp, A), dtype=torch.float32, device=dev)
         dv_all = torch.empty_like(dqz_all) if self.att_mode == 0 else None
         dpeep_all = torch.empty((To, Bp, 3 * U), dtype=torch.float32, device=dev) if self.use_peephole else None
         cell_out_all = av_in[:, :, :U]
-        W_cell = st[D + 'lstm_cell/kernel']
-        dc_next = torch.zeros((Bp, U), dtype=torch.float32, device=dev)
-        dh_next = torch.zeros((Bp, U), dtype=torch.float32, device=dev)
-        dctx_in = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
         d_in_all = torch.empty((To, Bp, Em + E2 + U), dtype=torch.float32, device=dev)   # d loss / d cell input
-        v = st[AT + 'v_a'] if self.att_mode == 0 else None
         dctx_all = torch.empty((To, Bp, E2), dtype=torch.float32, device=dev)
-        dalpha_next = None                     # carried location features: d loss / d alpha_k from step k+1's conv
+        dwfil_rows = dfilt_rows = None
         if self.carry_alpha:
             filt, wfil = st[AT + 'filter'], st[AT + 'W_filter/weights']
             dwfil_rows = torch.empty((Bp,) + tuple(wfil.shape), dtype=torch.float32, device=dev)
             dfilt_rows = torch.empty((Bp, filt.shape[0], filt.shape[2]), dtype=torch.float32, device=dev)
-            alpha_zero = torch.zeros((Bp, T), dtype=torch.float32, device=dev)
-        for k in range(To - 1, -1, -1):
-            s = saved[k]
-            dctx = dctx_all[k]
-            torch.add(dav_ctx[k], dctx_in, out=dctx)
-            # d_enc += alpha (x) dctx is NOT done per step (a read-modify-write of [T,B,2H] each time):
-            # alpha and dctx of all steps are kept and contracted once per utterance below
-            denergy = ops.att_softmax_ctx_bwd(dctx, s['alpha'], seq_p, self.sharpening_factor, tp['enc_att'], None,
-                                              sigmoid_norm=s['snorm'], dalpha_extra=dalpha_next)
-            if self.carry_alpha:
-                dqz, dv_rows, dalpha_next = ops.att_loc_energy_bwd(
-                    denergy, tp['alpha_all'][k - 1] if k > 0 else alpha_zero, filt, wfil, keys, s['qz'], v,
-                    dwfil_rows, dfilt_rows, accumulate=(k != To - 1), dkeys=dkeys, dqz_out=dqz_all[k],
-                    dv_out=dv_all[k] if dv_all is not None else None)
-            else:
-                dqz, dv_rows = ops.att_energy_bwd(denergy, keys, s['qz'], v, self.att_mode, dkeys=dkeys,
-                                                  want_dv=self.att_mode == 0, dqz_out=dqz_all[k],
-                                                  dv_out=dv_all[k] if dv_all is not None else None)
-            dcell = dav_cell[k]
-            if at in AL.HAS_QUERY_FC:
-                ops.gemm(dqz, self._wq(), transB=True, out=dcell, accumulate=True)
-            else:
-                dcell = dcell + dqz
-            if s['dmask'] is not None:
-                dcell = ops.apply_mask(dcell, s['dmask'])
-            dpre, dc_prev, dh_carry, dpeep_rows = ops.lstm_cell_bwd(
-                dcell, dc_next, dh_next, s['gates'], s['c_raw'], s['c_prev'], tp['peep'], live[k],
-                want_dpeep=self.use_peephole, dpre_out=dpre_all[k],
-                dpeep_out=dpeep_all[k] if dpeep_all is not None else None)
-            d_in = ops.gemm(dpre, W_cell, transB=True, out=d_in_all[k])     # [Bp, Em+E2+U]
-            dctx_in = d_in[:, Em:Em + E2]                                   # read in place by the next iteration's add
-            dh_next = dh_carry + d_in[:, Em + E2:]
-            dc_next = dc_prev
+        dc_next = torch.empty((Bp, U), dtype=torch.float32, device=dev)
+        dh_next = torch.empty((Bp, U), dtype=torch.float32, device=dev)
+        # the reverse loop, native as the forward one: per step  d ctx = attentional-vector part + the next step's
+        # cell-input part -> softmax / context backward -> energy backward (d_enc += alpha (x) dctx is NOT done per
+        # step: alpha and dctx of all steps are kept and contracted once per utterance below) -> query FC backward ->
+        # dropout mask -> cell backward -> cell-input GEMM backward; everything lands in the rows of per-step arrays
+        loop.update(dav_cell=dav_cell, dav_ctx=dav_ctx, dctx_all=dctx_all, dpre_all=dpre_all, dqz_all=dqz_all,
+                    dv_all=dv_all, dpeep_all=dpeep_all, d_in_all=d_in_all, dkeys=dkeys, dwfil_rows=dwfil_rows,
+                    dfilt_rows=dfilt_rows, dc0=dc_next, dh0=dh_next)
+        ops.att_decoder_bwd(loop)
         demb_all = d_in_all[:, :, :Em].contiguous()
         # ---- d_enc[:, b, :] += alpha_b^T [T, To] . dctx_b [To, 2H]   (context path of all steps at once)
         alpha_all = tp['alpha_all']

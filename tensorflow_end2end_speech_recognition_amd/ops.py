@@ -826,6 +826,55 @@ def att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmoi
     return denergy
 
 
+class _AttDecoder(C.Structure):
+    """struct asr_att_decoder (include/asr_hip.h), field for field."""
+    _INTS = ['To', 'B', 'T', 'U', 'Em', 'E2', 'A', 'att_mode', 'has_query_fc', 'carry_alpha', 'taps', 'enc_dtype']
+    _FLOATS = ['forget_bias', 'cell_clip', 'sharpening']
+    _PTRS1 = ['W_cell', 'b_cell', 'peep', 'W_q', 'b_q', 'v']
+    _PTRS2 = ['keys', 'enc', 'seq_len', 'filt', 'wfil', 'alpha_zero', 'live', 'dmask', 'dec_in', 'av_in', 'alpha_all',
+              'snorm_all', 'gates_all', 'craw_all', 'c_all', 'h_all', 'qz_all', 'work', 'dav_cell', 'dav_ctx', 'dctx_all',
+              'dpre_all', 'dqz_all', 'dv_all', 'dpeep_all', 'd_in_all', 'dkeys', 'dwfil_rows', 'dfilt_rows', 'dc0', 'dh0']
+    _fields_ = ([(n, C.c_int) for n in _INTS] + [(n, C.c_float) for n in _FLOATS] +
+                [(n, C.c_void_p) for n in _PTRS1] + [('ld_wq', C.c_int)] + [(n, C.c_void_p) for n in _PTRS2])
+
+
+def _att_decoder_struct(a):
+    st = _AttDecoder()
+    for n in _AttDecoder._INTS:
+        setattr(st, n, int(a.get(n, 0) or 0))
+    for n in _AttDecoder._FLOATS:
+        setattr(st, n, float(a.get(n, 0.0) or 0.0))
+    for n in _AttDecoder._PTRS1 + _AttDecoder._PTRS2:
+        t = a.get(n)
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('HIP path needs a CUDA(ROCm) tensor; there is no CPU fallback')
+        if t is not None and n != 'W_q' and not t.is_contiguous():
+            raise ValueError('att_decoder: %s must be contiguous' % n)
+        setattr(st, n, t.data_ptr() if t is not None else None)
+    wq = a.get('W_q')
+    st.ld_wq = int(wq.stride(0)) if wq is not None else 0
+    return st
+
+
+def att_decoder_fwd(a):
+    """All To steps of the attention decoder's forward pass from one call (asr_att_decoder_fwd).  `a`: dict of the
+    struct's fields (ints / floats / cuda tensors or None); the per-step arrays are filled in place."""
+    h = _h(a['dec_in'])
+    if a.get('work') is None:
+        a['work'] = _f32((a['B'] * (5 * a['U'] + a['T'] + a['E2']),), a['dec_in'].device)
+    st = _att_decoder_struct(a)
+    h.check(h.lib.asr_att_decoder_fwd(h.h, C.byref(st), _s()), 'asr_att_decoder_fwd')
+
+
+def att_decoder_bwd(a):
+    """The reverse loop (asr_att_decoder_bwd): fills dctx_all, dpre_all, dqz_all, dv_all, dpeep_all, d_in_all, dc0, dh0
+    (and adds into dkeys / the filter gradients)."""
+    h = _h(a['dec_in'])
+    a['work'] = _f32((a['B'] * (5 * a['U'] + 3 * a['T'] + a['E2']),), a['dec_in'].device)
+    st = _att_decoder_struct(a)
+    h.check(h.lib.asr_att_decoder_bwd(h.h, C.byref(st), _s()), 'asr_att_decoder_bwd')
+
+
 def tanh_fwd(x):
     h = _h(x)
     y = torch.empty_like(x)

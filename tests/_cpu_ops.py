@@ -536,6 +536,76 @@ def _att_softmax_ctx_bwd(dctx, alpha, seq_len, sharpening, enc, denc=None, sigmo
     return de.float()
 
 
+
+def _att_decoder_fwd(a):
+    """asr_att_decoder_fwd: the To steps, each the sequence of stand-ins the native loop issues as kernels."""
+    To, U, Em, E2, T = a['To'], a['U'], a['Em'], a['E2'], a['T']
+    dec_in, av_in, c_all, h_all = a['dec_in'], a['av_in'], a['c_all'], a['h_all']
+    for k in range(To):
+        pre = _gemm(dec_in[k], a['W_cell'], bias=a['b_cell'])
+        nxt = dec_in[k + 1] if k + 1 < To else None
+        dmask = a['dmask'][k] if a.get('dmask') is not None else None
+        gates, c_raw, c_new, h_new, _, cell_out = _lstm_cell_fwd(
+            pre, c_all[k], h_all[k], a.get('peep'), a['live'][k], a['forget_bias'], a['cell_clip'], out_mask=dmask,
+            want_cell_out=True, h_also=nxt[:, Em + E2:] if nxt is not None else None, cell_out_also=av_in[k, :, :U])
+        a['gates_all'][k].copy_(gates)
+        a['craw_all'][k].copy_(c_raw)
+        c_all[k + 1].copy_(c_new)
+        h_all[k + 1].copy_(h_new)
+        qz = _gemm(cell_out, a['W_q'], bias=a.get('b_q')) if a['has_query_fc'] else cell_out
+        a['qz_all'][k].copy_(qz)
+        if a['carry_alpha']:
+            energy = _att_loc_energy_fwd(a['alpha_all'][k - 1] if k > 0 else a['alpha_zero'], a['filt'], a['wfil'],
+                                         a.get('keys'), qz, a['v'], T)
+        else:
+            energy = _att_energy_fwd(a.get('keys'), qz, a.get('v'), T, a['att_mode'])
+        sn = a.get('snorm_all')
+        _att_softmax_ctx_fwd(energy, a['seq_len'], a['sharpening'], a['enc'], alpha_out=a['alpha_all'][k],
+                             sigmoid_norm=sn[k] if sn is not None else None,
+                             ctx_also=(av_in[k, :, U:], nxt[:, Em:Em + E2] if nxt is not None else None))
+
+
+def _att_decoder_bwd(a):
+    """asr_att_decoder_bwd, step for step."""
+    To, B, U, Em, E2 = a['To'], a['B'], a['U'], a['Em'], a['E2']
+    dc_next, dh_next = torch.zeros(B, U), torch.zeros(B, U)
+    dctx_in = torch.zeros(B, E2)
+    dalpha_next = None
+    sn = a.get('snorm_all')
+    for k in range(To - 1, -1, -1):
+        dctx = a['dctx_all'][k]
+        torch.add(a['dav_ctx'][k], dctx_in, out=dctx)
+        denergy = _att_softmax_ctx_bwd(dctx, a['alpha_all'][k], a['seq_len'], a['sharpening'], a['enc'], None,
+                                       sigmoid_norm=sn[k] if sn is not None else None, dalpha_extra=dalpha_next)
+        dv_out = a['dv_all'][k] if a.get('dv_all') is not None else None
+        if a['carry_alpha']:
+            dqz, _, dalpha_next = _att_loc_energy_bwd(
+                denergy, a['alpha_all'][k - 1] if k > 0 else a['alpha_zero'], a['filt'], a['wfil'], a.get('keys'),
+                a['qz_all'][k], a['v'], a['dwfil_rows'], a['dfilt_rows'], accumulate=(k != To - 1),
+                dkeys=a.get('dkeys'), dqz_out=a['dqz_all'][k], dv_out=dv_out)
+        else:
+            dqz, _ = _att_energy_bwd(denergy, a.get('keys'), a['qz_all'][k], a.get('v'), a['att_mode'],
+                                     dkeys=a.get('dkeys'), want_dv=a['att_mode'] == 0, dqz_out=a['dqz_all'][k],
+                                     dv_out=dv_out)
+        dcell = a['dav_cell'][k]
+        if a['has_query_fc']:
+            _gemm(dqz, a['W_q'], transB=True, out=dcell, accumulate=True)
+        else:
+            dcell += dqz
+        if a.get('dmask') is not None:
+            dcell.copy_(_apply_mask(dcell, a['dmask'][k]))
+        dp = a.get('dpeep_all')
+        dpre, dc_prev, dh_carry, _ = _lstm_cell_bwd(
+            dcell, dc_next, dh_next, a['gates_all'][k], a['craw_all'][k], a['c_all'][k], a.get('peep'), a['live'][k],
+            want_dpeep=dp is not None, dpre_out=a['dpre_all'][k], dpeep_out=dp[k] if dp is not None else None)
+        d_in = _gemm(dpre, a['W_cell'], transB=True, out=a['d_in_all'][k])
+        dctx_in = d_in[:, Em:Em + E2]
+        dh_next = dh_carry + d_in[:, Em + E2:]
+        dc_next = dc_prev
+    a['dc0'].copy_(dc_next)
+    a['dh0'].copy_(dh_next)
+
+
 def _tanh_fwd(x):
     return torch.tanh(x.double()).float()
 
@@ -653,7 +723,8 @@ STAND_INS = dict(
     att_loc_energy_fwd=_att_loc_energy_fwd, att_loc_energy_bwd=_att_loc_energy_bwd,
     embedding_gather=_embedding_gather, embedding_scatter=_embedding_scatter, seq_xent=_seq_xent,
     argmax_rows=_argmax_rows, im2col3x3=_im2col3x3, col2im3x3=_col2im3x3, maxpool2x2_fwd=_maxpool2x2_fwd,
-    maxpool2x2_bwd=_maxpool2x2_bwd, im2col=_im2col, col2im=_col2im,
+    maxpool2x2_bwd=_maxpool2x2_bwd, im2col=_im2col, col2im=_col2im, att_decoder_fwd=_att_decoder_fwd,
+    att_decoder_bwd=_att_decoder_bwd,
 )
 
 

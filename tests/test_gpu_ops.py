@@ -67,7 +67,9 @@ def test_conv3x3_implicit_gemm(cuda, N, H, W, Cin, Cout):
 
 # --------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (130, 70, 45), (1, 62, 512), (257, 1024, 120),
-                                   (700, 130, 1000), (16, 16, 4), (3000, 2048, 120), (120, 1024, 5000)])
+                                   (700, 130, 1000), (16, 16, 4), (3000, 2048, 120), (120, 1024, 5000),
+                                   # M <= 32, K % 64 == 0, N % 32 == 0: the skinny kernel of the decoder steps
+                                   (32, 2048, 1600), (32, 1600, 2048), (32, 128, 512), (17, 64, 128), (1, 96, 512)])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_f32(cuda, M, N, K, ta, tb):
     ops = _ops()
