@@ -5,6 +5,14 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from tensorflow_end2end_speech_recognition_amd.models.attention.joint_ctc_attention import JointCTCAttention
 dev = torch.device('cuda:0')
+from tensorflow_end2end_speech_recognition_amd import ops as _ops
+_host = {}
+def _timed(name):
+    fn = getattr(_ops, name)
+    def w(a):
+        t0 = time.perf_counter(); fn(a); _host[name] = (time.perf_counter() - t0) * 1e3
+    setattr(_ops, name, w)
+_timed('att_decoder_fwd'); _timed('att_decoder_bwd')
 rng = np.random.RandomState(3)
 B, D, C = int(os.environ.get('PB', 32)), 240, 28
 tmax = int(os.environ.get('PT', 1600))
@@ -33,4 +41,5 @@ for it in range(3):
     m.train(loss, 'adam', 1e-3)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print('it', it, 'B', B, 'T', T, 'Lmax', Lmax, 'frames', int(sl.sum()), 'fwd %.1f ms  bwd+upd %.1f ms  loss %.3f  -> %.0f frames/s'
-          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, loss.item(), sl.sum() / (t2 - t0)), flush=True)
+          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, loss.item(), sl.sum() / (t2 - t0)),
+          ' host issue of the loops: fwd %.1f ms bwd %.1f ms' % (_host.get('att_decoder_fwd', 0), _host.get('att_decoder_bwd', 0)), flush=True)

@@ -171,21 +171,187 @@ __global__ __launch_bounds__(256) void att_energy_bwd_kernel(const float* __rest
   for (int a = threadIdx.x; a < 2 * A; a += 256)
     o[a] = (acc[a] + acc[2 * A + a]) + (acc[4 * A + a] + acc[6 * A + a]);
 }
-// dqz[b,a] / dv_rows[b,a] = fixed-order sum of the chunk partials
+// dqz[b,a] / dv_rows[b,a] = fixed-order sum of the chunk partials.  One thread per output, the loads of 32 chunks issued
+// before the first add (the kernel is nothing but the latency of those loads)
 __global__ void att_energy_bwd_reduce_kernel(const float* __restrict__ part, int nch, int B, int A,
                                              float* __restrict__ dqz, float* __restrict__ dv_rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * A) return;
-  const int b = i / A, a = i % A;
-  float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-  for (int c = 0; c < nch; ++c) {
-    const float* o = part + ((size_t)c * B + b) * 2 * A;
-    s0 += o[a];
-    s1 += o[A + a];
+  if (i >= B * 2 * A) return;
+  const int b = i / (2 * A), j = i % (2 * A);
+  if (j >= A && !dv_rows) return;
+  const float* p = part + (size_t)b * 2 * A + j;
+  const size_t cs = (size_t)B * 2 * A;
+  float s = 0.f;
+  for (int c0 = 0; c0 < nch; c0 += 32) {
+    float x[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) x[c] = (c0 + c < nch) ? p[(size_t)(c0 + c) * cs] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s += x[c];
   }
-  dqz[i] = s0;
-  if (dv_rows) dv_rows[i] = s1;
+  if (j < A) dqz[(size_t)b * A + j] = s;
+  else dv_rows[(size_t)b * A + j - A] = s;
+}
+
+struct SoftmaxBwdFold {        // see att_energy_bwd_vec_kernel
+  const float* da;             // [B,T] d loss / d alpha  (NULL: not folded)
+  const float* alpha;          // [B,T]
+  const float* dotp;           // [ndot,B] partial sums of alpha . dalpha
+  const float* norm;           // [B] sigmoid-smoothing normaliser or NULL
+  int ndot;
+  float sharp;
+};
+
+// The same two kernels for A % 4 == 0, A <= 512 (every configuration of the reference): a frame is handled by LPF lanes
+// holding float4 slices of qz / v in registers (LPF = 16, 32 or 64 -> 4, 2 or 1 frames per wave and trip), tanh from
+// the hardware exp2 / rcp, the per-frame sum by DPP adds, and -- backward -- the sums over frames in registers instead
+// of read-modify-writes on LDS.  The one-element-per-lane forms above were ALU-bound at ~15 us per launch.
+template <int LPF, int NV>
+__global__ __launch_bounds__(256) void att_energy_fwd_vec_kernel(const float* __restrict__ keys,
+                                                                 const float* __restrict__ qz,
+                                                                 const float* __restrict__ v, int T, int B, int A,
+                                                                 int mode, float* __restrict__ energy,
+                                                                 const int32_t* __restrict__ seq_len) {
+  constexpr int FPW = 64 / LPF;
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / LPF, l = lane % LPF, nvec = A >> 2;
+  const int tend = seq_len ? min(max(seq_len[b], 0), T) : T;
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(tend, t0 + ATT_CH);
+  const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t qv[NV], vv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int a4 = l + i * LPF;
+    qv[i] = a4 < nvec ? *reinterpret_cast<const f32x4_t*>(qz + (size_t)b * A + a4 * 4) : zero;
+    vv[i] = (a4 < nvec && mode == 0) ? *reinterpret_cast<const f32x4_t*>(v + a4 * 4) : zero;
+  }
+  for (int tb = t0 + wave * FPW; tb < t1; tb += 4 * FPW) {
+    const int t = tb + sub;
+    const bool valid = t < t1;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int a4 = l + i * LPF;
+      f32x4_t kv = zero;
+      if (keys && valid && a4 < nvec) kv = *reinterpret_cast<const f32x4_t*>(keys + ((size_t)t * B + b) * A + a4 * 4);
+      if (mode == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += vv[i][e] * fast_tanhf(kv[e] + qv[i][e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += kv[e] * qv[i][e];
+      }
+    }
+    s = group_reduce_sum<LPF>(s);
+    if (l == 0 && valid) energy[(size_t)b * T + t] = s;
+  }
+}
+template <int LPF, int NV>
+__global__ __launch_bounds__(256) void att_energy_bwd_vec_kernel(const float* __restrict__ denergy,
+                                                                 const float* __restrict__ keys,
+                                                                 const float* __restrict__ qz,
+                                                                 const float* __restrict__ v, int T, int B, int A,
+                                                                 int mode, float* __restrict__ dkeys,
+                                                                 float* __restrict__ part,
+                                                                 const int32_t* __restrict__ seq_len, int ech,
+                                                                 SoftmaxBwdFold fold) {
+  // ech: frames per workgroup.  fold.da != NULL: denergy is not read but formed here from the d-alpha values, the
+  // attention weights and the per-chunk partial sums of alpha . dalpha the d-alpha kernel left (the softmax backward
+  // kernel's arithmetic, without its launch)
+  constexpr int FPW = 64 / LPF, AP = NV * LPF * 4;
+  __shared__ float red[4][2][AP];
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / LPF, l = lane % LPF, nvec = A >> 2;
+  const int tend = seq_len ? min(max(seq_len[b], 0), T) : T;
+  const int t0 = blockIdx.x * ech, t1 = min(tend, t0 + ech);
+  float dot = 0.f, nrm = 0.f;
+  if (fold.da) {
+    for (int c = 0; c < fold.ndot; ++c) dot += fold.dotp[(size_t)c * B + b];    // fixed order
+    if (fold.norm) nrm = fold.norm[b];
+  }
+  const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t qv[NV], vv[NV], adq[NV], adv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int a4 = l + i * LPF;
+    qv[i] = a4 < nvec ? *reinterpret_cast<const f32x4_t*>(qz + (size_t)b * A + a4 * 4) : zero;
+    vv[i] = (a4 < nvec && mode == 0) ? *reinterpret_cast<const f32x4_t*>(v + a4 * 4) : zero;
+    adq[i] = zero;
+    adv[i] = zero;
+  }
+  for (int tb = t0 + wave * FPW; tb < t1; tb += 4 * FPW) {
+    const int t = tb + sub;
+    const bool valid = t < t1;
+    float de = 0.f;
+    if (valid) {
+      if (fold.da) {
+        const float al = fold.alpha[(size_t)b * T + t];
+        de = fold.sharp * al * (fold.da[(size_t)b * T + t] - dot);
+        if (fold.norm) de *= 1.f - al * nrm;             // sigmoid smoothing: s (1 - s) / sum, s = alpha * sum
+      } else {
+        de = denergy[(size_t)b * T + t];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int a4 = l + i * LPF;
+      if (!(valid && a4 < nvec)) continue;
+      const size_t off = ((size_t)t * B + b) * A + a4 * 4;
+      const f32x4_t kv = keys ? *reinterpret_cast<const f32x4_t*>(keys + off) : zero;
+      f32x4_t dz;
+      if (mode == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float th = fast_tanhf(kv[e] + qv[i][e]);
+          dz[e] = de * vv[i][e] * (1.f - th * th);
+          adq[i][e] += dz[e];
+          adv[i][e] += de * th;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dz[e] = de * qv[i][e];
+          adq[i][e] += de * kv[e];
+        }
+      }
+      if (dkeys) {
+        f32x4_t* dk = reinterpret_cast<f32x4_t*>(dkeys + off);
+        f32x4_t o = *dk;
+        o[0] += dz[0]; o[1] += dz[1]; o[2] += dz[2]; o[3] += dz[3];
+        *dk = o;
+      }
+    }
+  }
+  // the FPW frame slots of a wave hold the same columns: fold them, then the four waves through LDS (fixed order)
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int o = LPF; o < 64; o <<= 1) {
+        adq[i][e] += __shfl_xor(adq[i][e], o, 64);
+        adv[i][e] += __shfl_xor(adv[i][e], o, 64);
+      }
+    }
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      *reinterpret_cast<f32x4_t*>(&red[wave][0][(l + i * LPF) * 4]) = adq[i];
+      *reinterpret_cast<f32x4_t*>(&red[wave][1][(l + i * LPF) * 4]) = adv[i];
+    }
+  }
+  __syncthreads();
+  float* o = part + ((size_t)blockIdx.x * B + b) * 2 * A;
+  for (int a = threadIdx.x; a < 2 * A; a += 256) {
+    const int w = a >= A, c = a - w * A;
+    o[a] = (red[0][w][c] + red[1][w][c]) + (red[2][w][c] + red[3][w][c]);
+  }
+}
+// 0: not applicable, else LPF * 4 + NV  (A % 4 == 0, A <= 512, 16-byte aligned operands)
+static inline int energy_vec_shape(int A, const void* keys, const void* qz, const void* v, const void* dkeys) {
+  if (A % 4 != 0 || A > 512 || ((uintptr_t)keys | (uintptr_t)qz | (uintptr_t)v | (uintptr_t)dkeys) % 16 != 0) return 0;
+  const int nvec = A / 4;
+  return nvec <= 16 ? 16 * 4 + 1 : nvec <= 32 ? 32 * 4 + 1 : nvec <= 64 ? 64 * 4 + 1 : 64 * 4 + 2;
 }
 
 // masked softmax over t.  energy[B,T] -> alpha[B,T].
@@ -369,7 +535,11 @@ __global__ __launch_bounds__(256) void att_dalpha_vec_kernel(const float* __rest
                                                              float* __restrict__ dctx_out,
                                                              const int32_t* __restrict__ seq_len,
                                                              const TE* __restrict__ enc, int T, int B, int E,
-                                                             float* __restrict__ da) {
+                                                             float* __restrict__ da,
+                                                             const float* __restrict__ alpha,
+                                                             float* __restrict__ dotp) {
+  // dotp (may be NULL): dotp[chunk][b] = sum over the chunk's frames of alpha * dalpha -- what the softmax backward
+  // needs from all of T, handed to the energy backward kernel so that no kernel of its own has to form it
   typedef EncVec<TE> V;
   constexpr int N = V::N;
   const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -390,6 +560,7 @@ __global__ __launch_bounds__(256) void att_dalpha_vec_kernel(const float* __rest
       d[g][i] = x[0]; d[g][i + 1] = x[1]; d[g][i + 2] = x[2]; d[g][i + 3] = x[3];
     }
   }
+  float wdot = 0.f;
   for (int tb = t0 + wave * 4; tb < t1; tb += 16) {
     typename V::raw_t x[4][G];
 #pragma unroll
@@ -415,8 +586,17 @@ __global__ __launch_bounds__(256) void att_dalpha_vec_kernel(const float* __rest
     if (lane == 0) {
 #pragma unroll
       for (int f = 0; f < 4; ++f)
-        if (tb + f < t1) da[(size_t)b * T + tb + f] = sum[f];
+        if (tb + f < t1) {
+          da[(size_t)b * T + tb + f] = sum[f];
+          if (dotp) wdot += alpha[(size_t)b * T + tb + f] * sum[f];
+        }
     }
+  }
+  if (dotp) {
+    __shared__ float wd[4];
+    if (lane == 0) wd[wave] = wdot;
+    __syncthreads();
+    if (threadIdx.x == 0) dotp[(size_t)blockIdx.x * B + b] = (wd[0] + wd[1]) + (wd[2] + wd[3]);
   }
 }
 // denergy[b,t] = sharp * alpha * (dalpha - sum_t alpha dalpha)   (zero past len)
@@ -829,8 +1009,19 @@ static int energy_fwd_launch(asr_handle* h, const float* keys, const float* qz, 
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(qz && energy && T > 0 && B > 0 && A > 0 && (mode == 0 ? v != nullptr : keys != nullptr),
            "asr_att_energy_fwd: bad args");
-  hipLaunchKernelGGL(att_energy_fwd_kernel, dim3((T + ATT_CH - 1) / ATT_CH, B), dim3(256), 0, (hipStream_t)s, keys, qz,
-                     v, T, B, A, mode, energy, seq_len);
+  const dim3 grid((T + ATT_CH - 1) / ATT_CH, B);
+#define ASR_EFWD(L, NV_) \
+  hipLaunchKernelGGL((att_energy_fwd_vec_kernel<L, NV_>), grid, dim3(256), 0, (hipStream_t)s, keys, qz, v, T, B, A, mode, energy, seq_len)
+  switch (energy_vec_shape(A, keys, qz, v, nullptr)) {
+    case 16 * 4 + 1: ASR_EFWD(16, 1); break;
+    case 32 * 4 + 1: ASR_EFWD(32, 1); break;
+    case 64 * 4 + 1: ASR_EFWD(64, 1); break;
+    case 64 * 4 + 2: ASR_EFWD(64, 2); break;
+    default:
+      hipLaunchKernelGGL(att_energy_fwd_kernel, grid, dim3(256), 0, (hipStream_t)s, keys, qz, v, T, B, A, mode, energy,
+                         seq_len);
+  }
+#undef ASR_EFWD
   ASR_CHECK_LAUNCH(h, "asr_att_energy_fwd");
   return ASR_OK;
 }
@@ -845,24 +1036,45 @@ static inline float* att_scratch(asr_handle* h, size_t bytes) {
 
 static int energy_bwd_launch(asr_handle* h, const float* denergy, const float* keys, const float* qz, const float* v,
                              int T, int B, int A, int mode, float* dkeys, float* dqz, float* dv_rows,
-                             const int32_t* seq_len, asr_stream s) {
+                             const int32_t* seq_len, const SoftmaxBwdFold* fold, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
-  ATT_NEED(denergy && qz && dqz && T > 0 && B > 0 && A > 0, "asr_att_energy_bwd: bad args");
-  const int nch = (T + ATT_CH - 1) / ATT_CH;
-  float* part = att_scratch(h, (size_t)nch * B * 2 * A * sizeof(float));
-  if (!part) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_energy_bwd: scratch too small");
+  const int shape = energy_vec_shape(A, keys, qz, v, dkeys);
+  ATT_NEED((denergy || (fold && fold->da && shape)) && qz && dqz && T > 0 && B > 0 && A > 0,
+           "asr_att_energy_bwd: bad args");
+  // frames per workgroup: 64 (measured at T = 1600, A = 128 without keys: 256-frame workgroups -- a 4x shorter
+  // reduction -- run 20 us instead of 7, one wave per SIMD cannot hide the exp / rcp latency)
+  const int ech = ATT_CH;
+  const int nch = (T + ech - 1) / ech;
+  // a folded softmax backward reads d-alpha and the partial dots from the head of the scratch: the partials go behind
+  const size_t skip = (fold && fold->da) ? (((size_t)B * T + (size_t)fold->ndot * B + 3) & ~(size_t)3) : 0;
+  float* base = att_scratch(h, (skip + (size_t)nch * B * 2 * A) * sizeof(float));
+  if (!base) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_energy_bwd: scratch too small");
+  float* part = base + skip;
   const size_t lds = (size_t)8 * A * sizeof(float);
-  hipLaunchKernelGGL(att_energy_bwd_kernel, dim3(nch, B), dim3(256), lds, (hipStream_t)s, denergy, keys, qz, v, T, B,
-                     A, mode, dkeys, part, seq_len);
-  hipLaunchKernelGGL(att_energy_bwd_reduce_kernel, dim3((B * A + 255) / 256), dim3(256), 0, (hipStream_t)s, part, nch,
-                     B, A, dqz, dv_rows);
+  const dim3 grid(nch, B);
+  SoftmaxBwdFold f = {nullptr, nullptr, nullptr, nullptr, 0, 0.f};
+  if (fold && fold->da) f = *fold;
+#define ASR_EBWD(L, NV_) \
+  hipLaunchKernelGGL((att_energy_bwd_vec_kernel<L, NV_>), grid, dim3(256), 0, (hipStream_t)s, denergy, keys, qz, v, T, B, A, mode, dkeys, part, seq_len, ech, f)
+  switch (shape) {
+    case 16 * 4 + 1: ASR_EBWD(16, 1); break;
+    case 32 * 4 + 1: ASR_EBWD(32, 1); break;
+    case 64 * 4 + 1: ASR_EBWD(64, 1); break;
+    case 64 * 4 + 2: ASR_EBWD(64, 2); break;
+    default:
+      hipLaunchKernelGGL(att_energy_bwd_kernel, grid, dim3(256), lds, (hipStream_t)s, denergy, keys, qz, v, T, B, A, mode,
+                         dkeys, part, seq_len);
+  }
+#undef ASR_EBWD
+  hipLaunchKernelGGL(att_energy_bwd_reduce_kernel, dim3((B * 2 * A + 255) / 256), dim3(256), 0, (hipStream_t)s, part,
+                     nch, B, A, dqz, dv_rows);
   ASR_CHECK_LAUNCH(h, "asr_att_energy_bwd");
   return ASR_OK;
 }
 extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const float* keys, const float* qz,
                                   const float* v, int T, int B, int A, int mode, float* dkeys, float* dqz,
                                   float* dv_rows, asr_stream s) {
-  return energy_bwd_launch(h, denergy, keys, qz, v, T, B, A, mode, dkeys, dqz, dv_rows, nullptr, s);
+  return energy_bwd_launch(h, denergy, keys, qz, v, T, B, A, mode, dkeys, dqz, dv_rows, nullptr, nullptr, s);
 }
 
 extern "C" int asr_att_loc_energy_fwd(asr_handle* h, const float* alpha_prev, const float* filt, const float* wfil,
@@ -956,36 +1168,46 @@ __global__ void add_cols_kernel(const float* __restrict__ x, int ldx, const floa
 }
 template <typename TE>
 bool dalpha_vec_launch(const float* da_, const float* db_, int ldb, float* dout, const int32_t* seq_len, const TE* enc,
-                       int T, int B, int E, float* da, hipStream_t st) {
+                       int T, int B, int E, float* da, const float* alpha, float* dotp, hipStream_t st) {
   constexpr int N = EncVec<TE>::N;
   if (E % (64 * N) != 0 || ((uintptr_t)enc) % 16 != 0 || ((uintptr_t)da_) % 16 != 0 ||
       (db_ && (((uintptr_t)db_) % 16 != 0 || ldb % 4 != 0)) || (dout && ((uintptr_t)dout) % 16 != 0))
     return false;
   const dim3 grid((T + ATT_CH - 1) / ATT_CH, B);
+#define ASR_DALPHA(G_) \
+  hipLaunchKernelGGL((att_dalpha_vec_kernel<TE, G_>), grid, dim3(256), 0, st, da_, db_, ldb, dout, seq_len, enc, T, B, E, da, alpha, dotp)
   switch (E / (64 * N)) {
-    case 1: hipLaunchKernelGGL((att_dalpha_vec_kernel<TE, 1>), grid, dim3(256), 0, st, da_, db_, ldb, dout, seq_len, enc, T, B, E, da); return true;
-    case 2: hipLaunchKernelGGL((att_dalpha_vec_kernel<TE, 2>), grid, dim3(256), 0, st, da_, db_, ldb, dout, seq_len, enc, T, B, E, da); return true;
-    case 4: hipLaunchKernelGGL((att_dalpha_vec_kernel<TE, 4>), grid, dim3(256), 0, st, da_, db_, ldb, dout, seq_len, enc, T, B, E, da); return true;
+    case 1: ASR_DALPHA(1); return true;
+    case 2: ASR_DALPHA(2); return true;
+    case 4: ASR_DALPHA(4); return true;
     default: return false;
   }
+#undef ASR_DALPHA
 }
 }  // namespace
 
-// dctx = dctx_a (+ dctx_b with row stride ldb, may be NULL); the sum goes to dctx_out when that is given
+// dctx = dctx_a (+ dctx_b with row stride ldb, may be NULL); the sum goes to dctx_out when that is given.
+// fold (may be NULL): the caller's energy backward can take the softmax backward in (vectorised kernels on both sides,
+// no carried-alpha gradient); when that applies, *fold is filled, denergy is NOT written and no softmax backward
+// kernel is launched -- otherwise fold->da is left NULL and denergy holds the result as usual.
 static int softmax_ctx_bwd_launch(asr_handle* h, const float* dctx_a, const float* dctx_b, int ldb, float* dctx_out,
                                   const float* alpha, const int32_t* seq_len, float sharpening, const void* enc,
                                   int enc_dtype, int T, int B, int E, float* denergy, float* denc,
-                                  const float* sigmoid_norm, const float* dalpha_extra, asr_stream s) {
+                                  const float* sigmoid_norm, const float* dalpha_extra, SoftmaxBwdFold* fold,
+                                  asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(dctx_a && alpha && seq_len && enc && denergy && T > 0 && B > 0 && E > 0 && asr_dtype_ok(enc_dtype) &&
                (!dctx_b || (dctx_out && ldb >= E)), "asr_att_softmax_ctx_bwd: bad args");
   hipStream_t st = (hipStream_t)s;
   const int nch = (T + ATT_CH - 1) / ATT_CH;
-  float* da = att_scratch(h, (size_t)B * T * sizeof(float));
+  float* da = att_scratch(h, ((size_t)B * T + (size_t)nch * B) * sizeof(float));
   if (!da) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_softmax_ctx_bwd: scratch too small");
+  const bool want_fold = fold && !dalpha_extra && !denc;
+  float* dotp = want_fold ? da + (size_t)B * T : nullptr;
+  if (fold) fold->da = nullptr;
   const bool fast = enc_dtype == ASR_F32
-                        ? dalpha_vec_launch<float>(dctx_a, dctx_b, ldb, dctx_out, seq_len, (const float*)enc, T, B, E, da, st)
-                        : dalpha_vec_launch<bf16_t>(dctx_a, dctx_b, ldb, dctx_out, seq_len, (const bf16_t*)enc, T, B, E, da, st);
+                        ? dalpha_vec_launch<float>(dctx_a, dctx_b, ldb, dctx_out, seq_len, (const float*)enc, T, B, E, da, alpha, dotp, st)
+                        : dalpha_vec_launch<bf16_t>(dctx_a, dctx_b, ldb, dctx_out, seq_len, (const bf16_t*)enc, T, B, E, da, alpha, dotp, st);
   const float* dctx = dctx_a;
   if (!fast) {
     if (dctx_b) {
@@ -1002,6 +1224,16 @@ static int softmax_ctx_bwd_launch(asr_handle* h, const float* dctx_a, const floa
   } else if (dctx_b) {
     dctx = dctx_out;
   }
+  if (fast && want_fold) {
+    fold->da = da;
+    fold->alpha = alpha;
+    fold->dotp = dotp;
+    fold->norm = sigmoid_norm;
+    fold->ndot = nch;
+    fold->sharp = sharpening;
+    ASR_CHECK_LAUNCH(h, "asr_att_softmax_ctx_bwd");
+    return ASR_OK;
+  }
   hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(B), dim3(256), 0, st, da, alpha, seq_len, sharpening, T, denergy,
                      sigmoid_norm, dalpha_extra);
   if (denc)   // NULL: the caller accumulates d_enc = sum_steps alpha (x) dctx itself (one GEMM per utterance)
@@ -1014,7 +1246,7 @@ extern "C" int asr_att_softmax_ctx_bwd(asr_handle* h, const float* dctx, const f
                                        int T, int B, int E, float* denergy, float* denc,
                                        const float* sigmoid_norm, const float* dalpha_extra, asr_stream s) {
   return softmax_ctx_bwd_launch(h, dctx, nullptr, 0, nullptr, alpha, seq_len, sharpening, enc, enc_dtype, T, B, E,
-                                denergy, denc, sigmoid_norm, dalpha_extra, s);
+                                denergy, denc, sigmoid_norm, dalpha_extra, nullptr, s);
 }
 
 extern "C" int asr_tanh_fwd(asr_handle* h, const float* x, float* y, size_t n, asr_stream s) {
@@ -1166,16 +1398,18 @@ extern "C" int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_
     const float* qz = a->qz_all + (size_t)k * B * A;
     float* dqz = a->dqz_all + (size_t)k * B * A;
     float* dv = a->dv_all ? a->dv_all + (size_t)k * B * A : nullptr;
+    // the softmax backward is folded into the energy backward when both sides run their vectorised kernels
+    SoftmaxBwdFold fold = {nullptr, nullptr, nullptr, nullptr, 0, 0.f};
+    SoftmaxBwdFold* fp = (!a->carry_alpha && energy_vec_shape(A, a->keys, qz, a->v, a->dkeys)) ? &fold : nullptr;
+    const float* snorm = a->snorm_all ? a->snorm_all + (size_t)k * B : nullptr;
     if (d_in_next) {
       DEC_TRY(softmax_ctx_bwd_launch(h, dav_ctx, d_in_next + Em, Din, dctx, alpha_k, a->seq_len, a->sharpening, a->enc,
-                                     a->enc_dtype, T, B, E2, denergy, nullptr,
-                                     a->snorm_all ? a->snorm_all + (size_t)k * B : nullptr, dalpha_next, s));
+                                     a->enc_dtype, T, B, E2, denergy, nullptr, snorm, dalpha_next, fp, s));
     } else {
       if (hipMemcpyAsync(dctx, dav_ctx, (size_t)B * E2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder_bwd: copy");
       DEC_TRY(softmax_ctx_bwd_launch(h, dctx, nullptr, 0, nullptr, alpha_k, a->seq_len, a->sharpening, a->enc,
-                                     a->enc_dtype, T, B, E2, denergy, nullptr,
-                                     a->snorm_all ? a->snorm_all + (size_t)k * B : nullptr, dalpha_next, s));
+                                     a->enc_dtype, T, B, E2, denergy, nullptr, snorm, dalpha_next, fp, s));
     }
     if (a->carry_alpha) {
       float* dap = dalp[k & 1];
@@ -1184,7 +1418,7 @@ extern "C" int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_
                                      a->dfilt_rows, dap, k != To - 1, s));
       dalpha_next = dap;
     } else {
-      DEC_TRY(energy_bwd_launch(h, denergy, a->keys, qz, a->v, T, B, A, a->att_mode, a->dkeys, dqz, dv, a->seq_len, s));
+      DEC_TRY(energy_bwd_launch(h, denergy, a->keys, qz, a->v, T, B, A, a->att_mode, a->dkeys, dqz, dv, a->seq_len, fp, s));
     }
     float* dcell = const_cast<float*>(a->dav_cell) + (size_t)k * B * U;
     if (a->has_query_fc)

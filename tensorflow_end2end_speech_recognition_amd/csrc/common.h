@@ -79,6 +79,29 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
   return v;
 }
 
+// sum over aligned groups of W lanes (W = 16, 32 or 64), result in every lane of the group.  The steps inside a
+// 16-lane row are DPP modifiers on the add (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8), not LDS permutes.
+template <int CTRL> __device__ __forceinline__ float dpp_mov_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int W> __device__ __forceinline__ float group_reduce_sum(float v) {
+  v += dpp_mov_f32<0xB1>(v);
+  v += dpp_mov_f32<0x4E>(v);
+  v += dpp_mov_f32<0x124>(v);
+  v += dpp_mov_f32<0x128>(v);
+  if (W >= 32) v += __shfl_xor(v, 16, 64);
+  if (W >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// tanh from the hardware exp2 / reciprocal: 1 - 2 / (exp(2x) + 1), absolute error < 2e-7 (each of v_exp_f32 and
+// v_rcp_f32 is good to 1 ulp), saturating correctly at +-1.  For the attention energies -- sum_a v_a tanh(.) over every
+// encoder frame and decoder step, which the libm form (~40 instructions) makes ALU-bound; NOT for the cell
+// nonlinearities, which stay on tanhf_.
+__device__ __forceinline__ float fast_tanhf(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
 // top ASR_XCH_BYTES of the scratch: granule exchange + error word of the multi-CU LSTM kernels
 static constexpr size_t ASR_XCH_BYTES = (size_t)16 << 20;
 bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* xproj,

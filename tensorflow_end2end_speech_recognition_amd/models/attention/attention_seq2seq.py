@@ -238,6 +238,15 @@ class AttentionSeq2Seq(ModelBase):
         B = inputs.shape[0]
         enc, seq_p = self._encode(inputs, isl, keep_prob_encoder, is_training)
         T, Bp, E2 = enc.shape
+        # joint model: the CTC head (logits GEMM, alpha / beta recursions -- one wave per utterance, ~1.6 ms of latency
+        # at T = 1600 -- and the gradient) needs only the encoder output, so it runs on the side lane beside the decoder
+        # loop instead of after it; the main stream waits for it where the two losses meet
+        lam = joint.get('lambda_weight')
+        ctc_pending = ctc_event = None
+        if lam is not None:
+            with ops.side_lane(dev, keep=(enc, seq_p), lane=1):
+                ctc_pending = self._ctc_head_launch(enc, seq_p, joint['ctc_labels'], B, lam, is_training)
+                ctc_event = ops.stream_event()
         U, Em, C2 = self.decoder_num_units, self.embedding_dim, self.num_classes
         To = int(lsl_np.max()) - 1
         Lmax = labels_np.shape[1]
@@ -310,7 +319,6 @@ class AttentionSeq2Seq(ModelBase):
         inv_t = 1.0 / float(self.logits_temperature)
         lt = ops.scale_(logits2d.clone(), inv_t) if self.logits_temperature != 1.0 else logits2d
         wsum = float(live.sum())
-        lam = joint.get('lambda_weight')
         seq_scale = (1.0 - lam) if lam is not None else 1.0
         row_loss, dlogits = ops.seq_xent(lt, tgt_d.view(-1), live_d.view(-1), 1e-10,
                                          seq_scale * inv_t / (wsum + 1e-12), want_grad=is_training)
@@ -319,7 +327,8 @@ class AttentionSeq2Seq(ModelBase):
         ctc_logits = None
         ctc_tape = None
         if lam is not None:
-            ctc_logits, ctc_mean, ctc_tape = self._ctc_head(enc, seq_p, joint['ctc_labels'], B, lam, is_training)
+            ops.wait_event(ctc_event)
+            ctc_logits, ctc_mean, ctc_tape = self._ctc_head_finish(ctc_pending, B)
             total = (1.0 - lam) * seq_loss + lam * ctc_mean
         if self.weight_decay > 0:
             l2 = torch.zeros((), dtype=torch.float32, device=dev)
@@ -348,7 +357,10 @@ class AttentionSeq2Seq(ModelBase):
             return total, logits_bm, ctc_logits, out_train, out_infer
         return total, logits_bm, out_train, out_infer
 
-    def _ctc_head(self, *a, **k):
+    def _ctc_head_launch(self, *a, **k):
+        raise NotImplementedError
+
+    def _ctc_head_finish(self, *a, **k):
         raise NotImplementedError
 
     # ------------------------------------------------------------------ backward
@@ -365,16 +377,28 @@ class AttentionSeq2Seq(ModelBase):
         # ---- output layer + attentional vector, all steps at once
         dlogits = tp['dlogits']
         W_out, W_av = st[D + 'output_layer/weights'], st[D + 'attentional_vector/weights']
-        ops.gemm(av, dlogits, transA=True, out=st.g(D + 'output_layer/weights'))
-        ops.colsum(dlogits, out=st.g(D + 'output_layer/biases'))
         dav_pre = ops.tanh_bwd(ops.gemm(dlogits, W_out, transB=True), av)
-        ops.gemm(av_in.view(To * Bp, U + E2), dav_pre, transA=True, out=st.g(D + 'attentional_vector/weights'))
+        # weight gradients are nobody's input until the optimizer: they go to the side lane (joined by encoder.backward
+        # / the end of this function) and run beside the reverse loop and the encoder's BPTT
+        with ops.side_lane(dev, keep=(av, dlogits, av_in, dav_pre), lane=1):
+            ops.gemm(av, dlogits, transA=True, out=st.g(D + 'output_layer/weights'))
+            ops.colsum(dlogits, out=st.g(D + 'output_layer/biases'))
+            ops.gemm(av_in.view(To * Bp, U + E2), dav_pre, transA=True, out=st.g(D + 'attentional_vector/weights'))
         # gradient of the attentional vector's inputs, as two contiguous arrays (cell output | context): a step's rows
         # are then the buffers the loop works in, not slices that have to be copied out first
         dav_cell = ops.gemm(dav_pre, W_av[:U], transB=True).view(To, Bp, U)
         dav_ctx = ops.gemm(dav_pre, W_av[U:], transB=True).view(To, Bp, E2)
         # ---- the recurrence, backwards
-        denc = torch.zeros_like(enc)
+        # d_enc starts as the CTC head's part (joint model) -- one GEMM that needs nothing from the decoder, issued on
+        # side lane 2 so that it runs beside the reverse loop; the first accumulation into d_enc waits for it
+        ctc_denc_event = None
+        if tp['ctc'] is not None and at != 'luong_dot':
+            denc = torch.empty_like(enc)
+            with ops.side_lane(dev, keep=(enc, denc), lane=2):
+                self._ctc_head_backward(tp['ctc'], enc, denc, accumulate=False)
+                ctc_denc_event = ops.stream_event()
+        else:
+            denc = torch.zeros_like(enc)
         dkeys = None
         if at in AL.USES_KEYS:
             dkeys = torch.zeros_like(keys)
@@ -402,50 +426,58 @@ class AttentionSeq2Seq(ModelBase):
                     dv_all=dv_all, dpeep_all=dpeep_all, d_in_all=d_in_all, dkeys=dkeys, dwfil_rows=dwfil_rows,
                     dfilt_rows=dfilt_rows, dc0=dc_next, dh0=dh_next)
         ops.att_decoder_bwd(loop)
-        demb_all = d_in_all[:, :, :Em].contiguous()
         # ---- d_enc[:, b, :] += alpha_b^T [T, To] . dctx_b [To, 2H]   (context path of all steps at once)
         alpha_all = tp['alpha_all']
+        ops.wait_event(ctc_denc_event)
         for b in range(tp['B']):
             ops.gemm(alpha_all[:, b, :], dctx_all[:, b, :], transA=True, out=denc[:, b, :], accumulate=True)
-        # ---- weight gradients of everything inside the loop, batched over the steps
-        ops.gemm(dec_in.view(To * Bp, -1), dpre_all.view(To * Bp, 4 * U), transA=True, out=st.g(D + 'lstm_cell/kernel'))
-        ops.colsum(dpre_all.view(To * Bp, 4 * U), out=st.g(D + 'lstm_cell/bias'))
-        if self.use_peephole:
-            dp = ops.colsum(dpeep_all.view(To * Bp, 3 * U))
-            st.g(D + 'lstm_cell/w_i_diag').copy_(dp[:U])
-            st.g(D + 'lstm_cell/w_f_diag').copy_(dp[U:2 * U])
-            st.g(D + 'lstm_cell/w_o_diag').copy_(dp[2 * U:])
         dq2d = dqz_all.view(To * Bp, -1)
-        if at in AL.HAS_QUERY_FC:
-            ops.gemm(cell_out_all.reshape(To * Bp, U), dq2d, transA=True, out=self._wq(grad=True))
-        if at in AL.HAS_FILTER:
-            ops.colsum(dq2d, out=st.g(AT + 'W_filter/biases'))
-            if self.carry_alpha:       # per-utterance sums over the steps -> sum over the batch
-                ops.colsum(dwfil_rows.view(Bp, -1), out=st.g(AT + 'W_filter/weights').view(-1))
-                ops.colsum(dfilt_rows.view(Bp, -1), out=st.g(AT + 'filter').view(-1))
-        if self.att_mode == 0:
-            ops.colsum(dv_all.view(To * Bp, -1), out=st.g(AT + 'v_a'))
-        if at in AL.USES_KEYS:
-            dk2d = dkeys.view(T * Bp, -1)
-            ops.gemm(enc.view(T * Bp, E2), dk2d, transA=True, out=self._wk(grad=True))
-            if (AT + 'W_keys/biases') in st.views:
-                ops.colsum(dk2d, out=st.g(AT + 'W_keys/biases'))
+        dk2d = dkeys.view(T * Bp, -1) if at in AL.USES_KEYS else None
+        if dk2d is not None:
             ops.gemm(dk2d, self._wk(), transB=True, out=denc.view(T * Bp, E2), accumulate=True)
-        # embedding
-        if tp['emb_mask'] is not None:
-            demb_all = ops.apply_mask(demb_all, tp['emb_mask'])
-        ops.embedding_scatter(demb_all.view(To * Bp, Em), tp['ids'].view(-1), C2, st.g('output_embedding/W_embedding'))
         # bridge
         dinit = torch.cat([dc_next, dh_next], dim=1).contiguous()
-        ops.gemm(tp['bi'], dinit, transA=True, out=st.g('bridge/fully_connected/weights'))
-        ops.colsum(dinit, out=st.g('bridge/fully_connected/biases'))
         dbi = ops.gemm(dinit, st['bridge/fully_connected/weights'], transB=True)
         H = self.encoder_num_units
         dcf = torch.stack([dbi[:, :H], dbi[:, 2 * H:3 * H]]).contiguous()
         dhf = torch.stack([dbi[:, H:2 * H], dbi[:, 3 * H:]]).contiguous()
-        if tp['ctc'] is not None:
-            self._ctc_head_backward(tp['ctc'], enc, denc)
+        # ---- weight gradients of everything inside the loop, batched over the steps -- on the side lane
+        side_keep = [t for t in (dec_in, dpre_all, dpeep_all, dqz_all, dv_all, dwfil_rows, dfilt_rows, dkeys, enc,
+                                 d_in_all, av_in, dinit, tp['bi'], tp['ids'], tp['emb_mask']) if t is not None]
+        with ops.side_lane(dev, keep=side_keep, lane=1):
+            ops.gemm(dec_in.view(To * Bp, -1), dpre_all.view(To * Bp, 4 * U), transA=True,
+                     out=st.g(D + 'lstm_cell/kernel'))
+            ops.colsum(dpre_all.view(To * Bp, 4 * U), out=st.g(D + 'lstm_cell/bias'))
+            if self.use_peephole:
+                dp = ops.colsum(dpeep_all.view(To * Bp, 3 * U))
+                st.g(D + 'lstm_cell/w_i_diag').copy_(dp[:U])
+                st.g(D + 'lstm_cell/w_f_diag').copy_(dp[U:2 * U])
+                st.g(D + 'lstm_cell/w_o_diag').copy_(dp[2 * U:])
+            if at in AL.HAS_QUERY_FC:
+                ops.gemm(cell_out_all.reshape(To * Bp, U), dq2d, transA=True, out=self._wq(grad=True))
+            if at in AL.HAS_FILTER:
+                ops.colsum(dq2d, out=st.g(AT + 'W_filter/biases'))
+                if self.carry_alpha:       # per-utterance sums over the steps -> sum over the batch
+                    ops.colsum(dwfil_rows.view(Bp, -1), out=st.g(AT + 'W_filter/weights').view(-1))
+                    ops.colsum(dfilt_rows.view(Bp, -1), out=st.g(AT + 'filter').view(-1))
+            if self.att_mode == 0:
+                ops.colsum(dv_all.view(To * Bp, -1), out=st.g(AT + 'v_a'))
+            if dk2d is not None:
+                ops.gemm(enc.view(T * Bp, E2), dk2d, transA=True, out=self._wk(grad=True))
+                if (AT + 'W_keys/biases') in st.views:
+                    ops.colsum(dk2d, out=st.g(AT + 'W_keys/biases'))
+            # embedding
+            demb_all = d_in_all[:, :, :Em].contiguous()
+            if tp['emb_mask'] is not None:
+                demb_all = ops.apply_mask(demb_all, tp['emb_mask'])
+            ops.embedding_scatter(demb_all.view(To * Bp, Em), tp['ids'].view(-1), C2,
+                                  st.g('output_embedding/W_embedding'))
+            ops.gemm(tp['bi'], dinit, transA=True, out=st.g('bridge/fully_connected/weights'))
+            ops.colsum(dinit, out=st.g('bridge/fully_connected/biases'))
+        if tp['ctc'] is not None and ctc_denc_event is None:
+            self._ctc_head_backward(tp['ctc'], enc, denc, accumulate=True)
         self.encoder.backward(denc, d_final=(dcf, dhf))
+        ops.join_side(dev)
         if self.weight_decay > 0:
             ops.weight_decay(st.grad, st.flat, st.plan, st.decay_mask, self.weight_decay)
         self._tape = None

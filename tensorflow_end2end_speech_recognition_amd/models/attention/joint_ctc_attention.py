@@ -53,7 +53,9 @@ class JointCTCAttention(AttentionSeq2Seq):
             keep_prob_embedding, scope=scope, is_training=is_training, lambda_weight=self.lambda_weight,
             ctc_labels=ctc_labels)
 
-    def _ctc_head(self, enc, seq_p, ctc_labels, B, lam, is_training):
+    def _ctc_head_launch(self, enc, seq_p, ctc_labels, B, lam, is_training):
+        """Issue the CTC head (on whatever stream is current -- AttentionSeq2Seq.compute_loss puts it on the side lane);
+        nothing here waits for the device."""
         st, dev = self.store, self.device
         T, Bp, E2 = enc.shape
         Cc = self.ctc_num_classes
@@ -65,15 +67,22 @@ class JointCTCAttention(AttentionSeq2Seq):
         off_d = torch.from_numpy(np.ascontiguousarray(offsets)).to(dev)
         losses, grad, ninf = ops.ctc_loss(logits, flat_d, off_d, seq_p, max_len, grad_scale=lam / B,
                                           want_grad=is_training)
+        return logits, losses, grad, ninf, flat_d, off_d
+
+    def _ctc_head_finish(self, pending, B):
+        logits, losses, grad, ninf = pending[:4]
         if int(ninf.item()) > 0:      # ignore_longer_outputs_than_inputs=False
             raise ValueError('Not enough time for target transition sequence (%d utterance(s))' % int(ninf.item()))
         self.ctc_losses = losses[:B]
         return logits[:, :B], losses[:B].mean(), dict(dlogits=grad)
 
-    def _ctc_head_backward(self, tape, enc, denc):
+    def _ctc_head_backward(self, tape, enc, denc, accumulate=True):
+        """d_enc (+)= dlogits . W^T on the current stream; the head's own weight gradients on side lane 1 (joined by
+        encoder.backward)."""
         st = self.store
         T, Bp, E2 = enc.shape
         dl = tape['dlogits'].view(T * Bp, -1)
-        ops.gemm(enc.view(T * Bp, E2), dl, transA=True, out=st.g('ctc_output/weights'))
-        ops.colsum(dl, out=st.g('ctc_output/biases'))
-        ops.gemm(dl, st['ctc_output/weights'], transB=True, out=denc.view(T * Bp, E2), accumulate=True)
+        ops.gemm(dl, st['ctc_output/weights'], transB=True, out=denc.view(T * Bp, E2), accumulate=accumulate)
+        with ops.side_lane(enc.device, keep=(enc, dl), lane=1):
+            ops.gemm(enc.view(T * Bp, E2), dl, transA=True, out=st.g('ctc_output/weights'))
+            ops.colsum(dl, out=st.g('ctc_output/biases'))
