@@ -840,6 +840,406 @@ __global__ void att_loc_filt_reduce_kernel(const float* __restrict__ fpart, int 
   dfilt_rows[i] = accumulate ? dfilt_rows[i] + s : s;
 }
 
+// ---- the same three passes, MI355X-shaped (A % 4 == 0, A <= 256; the forms above stay as the general fallback and
+// ran at 38 / 116 / 37 us per decoder step at T = 1600, A = 128, 201 taps -- LDS-bound: two LDS reads per multiply-add in
+// the convolutions, twelve LDS read-modify-writes per (frame, column) in the backward):
+//  * the convolution  f[64 x 10] = Toeplitz(alpha window)[64 x taps] . F[taps x 10]  and the filter gradient
+//    dF[taps x 10] = Toeplitz^T[taps x 64] . dfeat[64 x 10]  are exact-fp32 MFMA products (16x16x4) whose A operand is
+//    read straight out of the alpha window in LDS (one ds_read per MFMA and lane);
+//  * the energy passes use the layout of att_energy_*_vec_kernel (LPF lanes x float4 per frame), W_filter in registers,
+//    tanh from exp2 / rcp, and REGISTER accumulators for dq / dv / dW_filter (folded across lanes and waves once);
+//  * only frames below the utterance's length are touched (everything past it is masked by the softmax: alpha, d-energy
+//    and hence every gradient there are zero);
+//  * the two partial-sum reductions are one launch.
+constexpr int LOC_FS = 12;                      // floats per feature / filter row in LDS (16-byte aligned, 10 used)
+
+// dst[i] = src(i), i < n, by the 256 threads of the workgroup, UNR loads in flight per thread before the first LDS write
+// (a plain "load, write" loop is compiled to one global round trip per iteration: ~0.7 us each, 25 of them in pass B)
+template <int UNR, typename F>
+__device__ __forceinline__ void stage_lds(float* dst, int n, F src) {
+  for (int base = 0; base < n; base += 256 * UNR) {
+    float x[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int i = base + u * 256 + (int)threadIdx.x;
+      x[u] = i < n ? src(i) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int i = base + u * 256 + (int)threadIdx.x;
+      if (i < n) dst[i] = x[u];
+    }
+  }
+}
+// ff[i][c] (row stride LOC_FS) = sum_j aw[i + j] F[j][c], i < 64.  aw is zero-padded to 64 + taps16 entries and fl is the
+// filter as [taps16][16] with zero rows / columns past [taps][LOC_C] (taps16 = taps rounded up to 16), so that the loop
+// is straight-line: with bounds checks on the operands the compiler wraps every LDS read in an exec-mask branch
+__device__ __forceinline__ void loc_conv_mfma(const float* aw, const float* fl, int taps16, float* ff) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, kg = lane >> 4;
+  f32x4_t ac[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) ac[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float* arow = aw + wave * 16 + m + kg;
+  const float* brow = fl + kg * 16 + m;
+  for (int k0 = 0; k0 < taps16; k0 += 16) {
+    float a[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = arow[k0 + 4 * u];
+      bv[u] = brow[(k0 + 4 * u) * 16];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ac[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], ac[u], 0, 0, 0);
+  }
+  f32x4_t acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (ac[0][r] + ac[1][r]) + (ac[2][r] + ac[3][r]);
+  if (m < LOC_C) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ff[(wave * 16 + kg * 4 + r) * LOC_FS + m] = acc[r];
+  }
+}
+__device__ __forceinline__ void loc_stage_window(const float* __restrict__ alpha_prev_b, const float* __restrict__ filt,
+                                                 int T, int taps, int t0, float* aw, float* fl) {
+  const int P = (taps - 1) / 2, taps16 = (taps + 15) & ~15;
+  stage_lds<2>(aw, ATT_CH + taps16, [&](int i) {
+    const int u = t0 + i - P;
+    return (i < ATT_CH + taps - 1 && u >= 0 && u < T) ? alpha_prev_b[u] : 0.f;
+  });
+  stage_lds<8>(fl, taps16 * 16, [&](int i) {
+    const int j = i >> 4, c = i & 15;
+    return (j < taps && c < LOC_C) ? filt[j * LOC_C + c] : 0.f;
+  });
+}
+static inline size_t loc_vec_lds_floats(int taps) {      // aw | filter | features
+  const int taps16 = (taps + 15) & ~15;
+  return (size_t)(ATT_CH + taps16) + (size_t)taps16 * 16 + (size_t)ATT_CH * LOC_FS;
+}
+
+template <int LPF, int NV>
+__global__ __launch_bounds__(256) void att_loc_energy_fwd_vec_kernel(
+    const float* __restrict__ alpha_prev, const float* __restrict__ filt, const float* __restrict__ wfil,
+    const float* __restrict__ keys, const float* __restrict__ qz, const float* __restrict__ v, int T, int B, int A,
+    int taps, float* __restrict__ energy, const int32_t* __restrict__ seq_len) {
+  constexpr int FPW = 64 / LPF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int taps16 = (taps + 15) & ~15;
+  float* aw = reinterpret_cast<float*>(smem);
+  float* fl = aw + ATT_CH + taps16;
+  float* ff = fl + taps16 * 16;
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / LPF, l = lane % LPF, nvec = A >> 2;
+  const int tend = seq_len ? min(max(seq_len[b], 0), T) : T;
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(tend, t0 + ATT_CH);
+  if (t0 >= t1) return;                                    // uniform: the whole chunk is masked
+  loc_stage_window(alpha_prev + (size_t)b * T, filt, T, taps, t0, aw, fl);
+  const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t qv[NV], vv[NV], w[NV][LOC_C];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int a4 = l + i * LPF;
+    const bool ok = a4 < nvec;
+    qv[i] = ok ? *reinterpret_cast<const f32x4_t*>(qz + (size_t)b * A + a4 * 4) : zero;
+    vv[i] = ok ? *reinterpret_cast<const f32x4_t*>(v + a4 * 4) : zero;
+#pragma unroll
+    for (int c = 0; c < LOC_C; ++c) w[i][c] = ok ? *reinterpret_cast<const f32x4_t*>(wfil + (size_t)c * A + a4 * 4) : zero;
+  }
+  __syncthreads();
+  loc_conv_mfma(aw, fl, taps16, ff);
+  __syncthreads();
+  for (int tb = t0 + wave * FPW; tb < t1; tb += 4 * FPW) {
+    const int t = tb + sub;
+    const bool valid = t < t1;
+    const float* fr = ff + (valid ? t - t0 : 0) * LOC_FS;
+    const f32x4_t f0 = *reinterpret_cast<const f32x4_t*>(fr), f1 = *reinterpret_cast<const f32x4_t*>(fr + 4),
+                  f2 = *reinterpret_cast<const f32x4_t*>(fr + 8);
+    const float f[LOC_C] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3], f2[0], f2[1]};
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int a4 = l + i * LPF;
+      f32x4_t z = qv[i];
+      if (keys && valid && a4 < nvec) {
+        const f32x4_t kv = *reinterpret_cast<const f32x4_t*>(keys + ((size_t)t * B + b) * A + a4 * 4);
+        z[0] += kv[0]; z[1] += kv[1]; z[2] += kv[2]; z[3] += kv[3];
+      }
+#pragma unroll
+      for (int c = 0; c < LOC_C; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] += f[c] * w[i][c][e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += vv[i][e] * fast_tanhf(z[e]);
+    }
+    s = group_reduce_sum<LPF>(s);
+    if (l == 0 && valid) energy[(size_t)b * T + t] = s;
+  }
+}
+
+// pass A of the backward: part[ch][b][(2 + LOC_C) * A] and dfeat[b,t,c] as att_loc_energy_bwd_kernel
+template <int LPF, int NV>
+__global__ __launch_bounds__(256) void att_loc_energy_bwd_vec_kernel(
+    const float* __restrict__ denergy, const float* __restrict__ alpha_prev, const float* __restrict__ filt,
+    const float* __restrict__ wfil, const float* __restrict__ keys, const float* __restrict__ qz,
+    const float* __restrict__ v, int T, int B, int A, int taps, float* __restrict__ dkeys, float* __restrict__ part,
+    float* __restrict__ dfeat, const int32_t* __restrict__ seq_len) {
+  constexpr int FPW = 64 / LPF, NR = 2 + LOC_C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int taps16 = (taps + 15) & ~15;
+  float* aw = reinterpret_cast<float*>(smem);
+  float* fl = aw + ATT_CH + taps16;
+  float* ff = fl + taps16 * 16;
+  float* red = ff + ATT_CH * LOC_FS;                       // [4 waves][NR * A]
+  const int NP = NR * A;
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / LPF, l = lane % LPF, nvec = A >> 2;
+  const int tend = seq_len ? min(max(seq_len[b], 0), T) : T;
+  const int t0 = blockIdx.x * ATT_CH, t1 = min(tend, t0 + ATT_CH);
+  float* o = part + ((size_t)blockIdx.x * B + b) * NP;
+  if (t0 >= t1) {                                          // uniform: nothing but zero partials
+    for (int i = threadIdx.x; i < NP; i += 256) o[i] = 0.f;
+    return;
+  }
+  loc_stage_window(alpha_prev + (size_t)b * T, filt, T, taps, t0, aw, fl);
+  const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t qv[NV], vv[NV], w[NV][LOC_C], acc[NV][NR];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int a4 = l + i * LPF;
+    const bool ok = a4 < nvec;
+    qv[i] = ok ? *reinterpret_cast<const f32x4_t*>(qz + (size_t)b * A + a4 * 4) : zero;
+    vv[i] = ok ? *reinterpret_cast<const f32x4_t*>(v + a4 * 4) : zero;
+#pragma unroll
+    for (int c = 0; c < LOC_C; ++c) w[i][c] = ok ? *reinterpret_cast<const f32x4_t*>(wfil + (size_t)c * A + a4 * 4) : zero;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[i][r] = zero;
+  }
+  __syncthreads();
+  loc_conv_mfma(aw, fl, taps16, ff);
+  __syncthreads();
+  for (int tb = t0 + wave * FPW; tb < t1; tb += 4 * FPW) {
+    const int t = tb + sub;
+    const bool valid = t < t1;
+    const float de = valid ? denergy[(size_t)b * T + t] : 0.f;
+    const float* fr = ff + (valid ? t - t0 : 0) * LOC_FS;
+    const f32x4_t f0 = *reinterpret_cast<const f32x4_t*>(fr), f1 = *reinterpret_cast<const f32x4_t*>(fr + 4),
+                  f2 = *reinterpret_cast<const f32x4_t*>(fr + 8);
+    const float f[LOC_C] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3], f2[0], f2[1]};
+    float df[LOC_C];
+#pragma unroll
+    for (int c = 0; c < LOC_C; ++c) df[c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int a4 = l + i * LPF;
+      if (!(valid && a4 < nvec)) continue;
+      const size_t off = ((size_t)t * B + b) * A + a4 * 4;
+      f32x4_t z = qv[i];
+      if (keys) {
+        const f32x4_t kv = *reinterpret_cast<const f32x4_t*>(keys + off);
+        z[0] += kv[0]; z[1] += kv[1]; z[2] += kv[2]; z[3] += kv[3];
+      }
+#pragma unroll
+      for (int c = 0; c < LOC_C; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] += f[c] * w[i][c][e];
+      f32x4_t dz;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float th = fast_tanhf(z[e]);
+        dz[e] = de * vv[i][e] * (1.f - th * th);
+        acc[i][0][e] += dz[e];
+        acc[i][1][e] += de * th;
+      }
+#pragma unroll
+      for (int c = 0; c < LOC_C; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[i][2 + c][e] += f[c] * dz[e];
+          df[c] += dz[e] * w[i][c][e];
+        }
+      if (dkeys) {
+        f32x4_t* dk = reinterpret_cast<f32x4_t*>(dkeys + off);
+        f32x4_t x = *dk;
+        x[0] += dz[0]; x[1] += dz[1]; x[2] += dz[2]; x[3] += dz[3];
+        *dk = x;
+      }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int c = 0; c < LOC_C; ++c) {
+      const float tot = group_reduce_sum<LPF>(df[c]);
+      mine = (l == c) ? tot : mine;
+    }
+    if (l < LOC_C && valid) dfeat[((size_t)b * T + t) * LOC_C + l] = mine;
+  }
+  // fold the frame slots of the wave, then the four waves through LDS in a fixed order
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int x = LPF; x < 64; x <<= 1) acc[i][r][e] += __shfl_xor(acc[i][r][e], x, 64);
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int a4 = l + i * LPF;
+      if (a4 < nvec) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) *reinterpret_cast<f32x4_t*>(&red[(size_t)wave * NP + r * A + a4 * 4]) = acc[i][r];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NP; i += 256) o[i] = (red[i] + red[NP + i]) + (red[2 * NP + i] + red[3 * NP + i]);
+}
+
+// pass B: dalpha_prev of the chunk's frames and the chunk's filter-gradient partial (as att_loc_conv_bwd_kernel);
+// dfeat rows at or past the utterance's length are zero and are not read
+__global__ __launch_bounds__(256) void att_loc_conv_bwd_vec_kernel(
+    const float* __restrict__ dfeat, const float* __restrict__ alpha_prev, const float* __restrict__ filt, int T,
+    int B, int taps, float* __restrict__ dalpha_prev, float* __restrict__ fpart, const int32_t* __restrict__ seq_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int W = ATT_CH + taps - 1, taps16 = (taps + 15) & ~15;
+  float* aw = reinterpret_cast<float*>(smem);            // alpha window  [64 + taps16], zero past W
+  float* fl = aw + ATT_CH + taps16;                        // filter        [taps][LOC_FS]
+  float* dw = fl + (size_t)taps * LOC_FS;                  // dfeat window  [W][LOC_FS]: frames t0 + P - (taps-1) ...
+  const int P = (taps - 1) / 2;
+  const int b = blockIdx.y, t0 = blockIdx.x * ATT_CH, n = min(ATT_CH, T - t0);
+  const int len = seq_len ? min(max(seq_len[b], 0), T) : T;
+  const int tb = t0 + P - (taps - 1);
+  float* o = fpart + ((size_t)blockIdx.x * B + b) * taps * LOC_C;
+  if (tb >= len) {                                         // uniform: every dfeat row of the window is zero
+    for (int i = threadIdx.x; i < taps * LOC_C; i += 256) o[i] = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) dalpha_prev[(size_t)b * T + t0 + i] = 0.f;
+    return;
+  }
+  stage_lds<2>(aw, ATT_CH + taps16, [&](int i) {
+    const int u = t0 + i - P;
+    return (i < W && u >= 0 && u < T) ? alpha_prev[(size_t)b * T + u] : 0.f;
+  });
+  stage_lds<10>(fl, taps * LOC_FS, [&](int i) {
+    const int j = i / LOC_FS, c = i % LOC_FS;
+    return c < LOC_C ? filt[j * LOC_C + c] : 0.f;
+  });
+  stage_lds<13>(dw, W * LOC_FS, [&](int i) {
+    const int t = tb + i / LOC_FS, c = i % LOC_FS;
+    return (t >= 0 && t < len && c < LOC_C) ? dfeat[((size_t)b * T + t) * LOC_C + c] : 0.f;
+  });
+  __syncthreads();
+  // dalpha[i] = sum_j dw[i + taps-1 - j] . fl[j]  (rows of LOC_FS floats, pad columns zero on both sides).  A thread
+  // owns FOUR consecutive frames and one sixteenth of the taps: going up one tap slides its four dfeat rows down by
+  // one, so a tap costs one new dfeat row and one filter row (6 ds_read_b128) for 40 multiply-adds; the sixteen tap
+  // slices of a frame group are the sixteen lanes of a DPP row.
+  {
+    const int grp = threadIdx.x >> 4, part = threadIdx.x & 15;          // frames 4 grp .. 4 grp + 3
+    const int per = (taps + 15) / 16, j0 = part * per, j1 = min(taps, j0 + per);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (j0 < j1) {
+      f32x4_t row[4][3];                                                 // dw rows base + r, r = 0..3
+      const int base0 = grp * 4 + (taps - 1) - j0;
+#pragma unroll
+      for (int r = 1; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) row[r][q] = reinterpret_cast<const f32x4_t*>(dw + (size_t)(base0 + r) * LOC_FS)[q];
+      for (int j = j0; j < j1; ++j) {
+        const f32x4_t* d = reinterpret_cast<const f32x4_t*>(dw + (size_t)(grp * 4 + (taps - 1) - j) * LOC_FS);
+        const f32x4_t* f = reinterpret_cast<const f32x4_t*>(fl + (size_t)j * LOC_FS);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) row[0][q] = d[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const f32x4_t y = f[q];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            s[r] += row[r][q][0] * y[0] + row[r][q][1] * y[1] + row[r][q][2] * y[2] + row[r][q][3] * y[3];
+        }
+#pragma unroll
+        for (int r = 3; r > 0; --r)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) row[r][q] = row[r - 1][q];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = group_reduce_sum<16>(s[r]);
+    if (part < 4 && grp * 4 + part < n) {
+      const float mine = part == 0 ? s[0] : part == 1 ? s[1] : part == 2 ? s[2] : s[3];
+      dalpha_prev[(size_t)b * T + t0 + grp * 4 + part] = mine;
+    }
+  }
+  // filter-gradient partial  dF[j][c] = sum_i aw[i + j] dfeat[own + i][c]  as MFMA tiles of 16 taps
+  {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, kg = lane >> 4;
+    const int own = (taps - 1) - P;
+    for (int jt = wave; jt * 16 < taps; jt += 4) {
+      // straight-line operands: rows j >= taps read the zero pad of aw, columns m >= LOC_C read whatever follows in the
+      // dfeat row -- both only reach output rows / columns that are not stored
+      const float* arow = aw + jt * 16 + m + kg;
+      const float* brow = dw + (size_t)(own + kg) * LOC_FS + m;
+      f32x4_t ac[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ac[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i0 = 0; i0 < ATT_CH; i0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          ac[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[i0 + 4 * u], brow[(size_t)(i0 + 4 * u) * LOC_FS], ac[u], 0, 0, 0);
+      }
+      f32x4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = (ac[0][r] + ac[1][r]) + (ac[2][r] + ac[3][r]);
+      if (m < LOC_C) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int jo = jt * 16 + kg * 4 + r;
+          if (jo < taps) o[jo * LOC_C + m] = acc[r];
+        }
+      }
+    }
+  }
+}
+// both reductions of the backward in one launch: outputs [0, B*NP) are dqz / dv_rows / dwfil_rows, the rest dfilt_rows
+__global__ void att_loc_reduce_both_kernel(const float* __restrict__ part, const float* __restrict__ fpart, int nch,
+                                           int B, int A, int nf, float* __restrict__ dqz, float* __restrict__ dv_rows,
+                                           float* __restrict__ dwfil_rows, float* __restrict__ dfilt_rows,
+                                           int accumulate) {
+  const int NP = (2 + LOC_C) * A;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool first = i < B * NP;
+  const int k = first ? i : i - B * NP;
+  if (!first && k >= B * nf) return;
+  const int per = first ? NP : nf;
+  const int b = k / per, r = k % per;
+  const float* p = (first ? part : fpart) + (size_t)b * per + r;
+  const size_t cs = (size_t)B * per;
+  float s = 0.f;
+  for (int c0 = 0; c0 < nch; c0 += 32) {
+    float x[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) x[c] = (c0 + c < nch) ? p[(size_t)(c0 + c) * cs] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s += x[c];
+  }
+  if (!first) {
+    dfilt_rows[k] = accumulate ? dfilt_rows[k] + s : s;
+  } else if (r < A) {
+    dqz[(size_t)b * A + r] = s;
+  } else if (r < 2 * A) {
+    if (dv_rows) dv_rows[(size_t)b * A + r - A] = s;
+  } else {
+    float* o = dwfil_rows + (size_t)b * LOC_C * A + (r - 2 * A);
+    *o = accumulate ? *o + s : s;
+  }
+}
+// 0: the general kernels, else LPF * 4 + NV
+static inline int loc_vec_shape(int A, const void* keys, const void* qz, const void* v, const void* wfil, const void* dkeys) {
+  if (A % 4 != 0 || A > 256 ||
+      ((uintptr_t)keys | (uintptr_t)qz | (uintptr_t)v | (uintptr_t)wfil | (uintptr_t)dkeys) % 16 != 0)
+    return 0;
+  const int nvec = A / 4;
+  return nvec <= 16 ? 16 * 4 + 1 : nvec <= 32 ? 32 * 4 + 1 : 64 * 4 + 1;
+}
+
 __global__ void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     y[i] = tanhf(x[i]);
@@ -1077,25 +1477,41 @@ extern "C" int asr_att_energy_bwd(asr_handle* h, const float* denergy, const flo
   return energy_bwd_launch(h, denergy, keys, qz, v, T, B, A, mode, dkeys, dqz, dv_rows, nullptr, nullptr, s);
 }
 
-extern "C" int asr_att_loc_energy_fwd(asr_handle* h, const float* alpha_prev, const float* filt, const float* wfil,
-                                      const float* keys, const float* qz, const float* v, int T, int B, int A,
-                                      int taps, float* energy, asr_stream s) {
+static int loc_energy_fwd_launch(asr_handle* h, const float* alpha_prev, const float* filt, const float* wfil,
+                                 const float* keys, const float* qz, const float* v, int T, int B, int A, int taps,
+                                 float* energy, const int32_t* seq_len, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(alpha_prev && filt && wfil && qz && v && energy && T > 0 && B > 0 && A > 0 && taps > 0,
            "asr_att_loc_energy_fwd: bad args");
+  const dim3 grid((T + ATT_CH - 1) / ATT_CH, B);
+  const int shape = loc_vec_shape(A, keys, qz, v, wfil, nullptr);
+  const size_t ldsv = loc_vec_lds_floats(taps) * sizeof(float);
+  if (shape && ldsv <= 64 * 1024) {
+#define ASR_LFWD(L) \
+  hipLaunchKernelGGL((att_loc_energy_fwd_vec_kernel<L, 1>), grid, dim3(256), ldsv, (hipStream_t)s, alpha_prev, filt, wfil, keys, qz, v, T, B, A, taps, energy, seq_len)
+    if (shape == 16 * 4 + 1) ASR_LFWD(16); else if (shape == 32 * 4 + 1) ASR_LFWD(32); else ASR_LFWD(64);
+#undef ASR_LFWD
+    ASR_CHECK_LAUNCH(h, "asr_att_loc_energy_fwd");
+    return ASR_OK;
+  }
   const size_t lds = loc_lds_floats(taps, A) * sizeof(float);
   if (lds > 64 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_loc_energy_fwd: taps=%d / A=%d need %zu B of LDS", taps, A, lds);
-  hipLaunchKernelGGL(att_loc_energy_fwd_kernel, dim3((T + ATT_CH - 1) / ATT_CH, B), dim3(256), lds, (hipStream_t)s,
-                     alpha_prev, filt, wfil, keys, qz, v, T, B, A, taps, energy);
+  hipLaunchKernelGGL(att_loc_energy_fwd_kernel, grid, dim3(256), lds, (hipStream_t)s, alpha_prev, filt, wfil, keys, qz, v,
+                     T, B, A, taps, energy);
   ASR_CHECK_LAUNCH(h, "asr_att_loc_energy_fwd");
   return ASR_OK;
 }
+extern "C" int asr_att_loc_energy_fwd(asr_handle* h, const float* alpha_prev, const float* filt, const float* wfil,
+                                      const float* keys, const float* qz, const float* v, int T, int B, int A,
+                                      int taps, float* energy, asr_stream s) {
+  return loc_energy_fwd_launch(h, alpha_prev, filt, wfil, keys, qz, v, T, B, A, taps, energy, nullptr, s);
+}
 
-extern "C" int asr_att_loc_energy_bwd(asr_handle* h, const float* denergy, const float* alpha_prev,
-                                      const float* filt, const float* wfil, const float* keys, const float* qz,
-                                      const float* v, int T, int B, int A, int taps, float* dkeys, float* dqz,
-                                      float* dv_rows, float* dwfil_rows, float* dfilt_rows, float* dalpha_prev,
-                                      int accumulate, asr_stream s) {
+static int loc_energy_bwd_launch(asr_handle* h, const float* denergy, const float* alpha_prev, const float* filt,
+                                 const float* wfil, const float* keys, const float* qz, const float* v, int T, int B,
+                                 int A, int taps, float* dkeys, float* dqz, float* dv_rows, float* dwfil_rows,
+                                 float* dfilt_rows, float* dalpha_prev, int accumulate, const int32_t* seq_len,
+                                 asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(denergy && alpha_prev && filt && wfil && qz && v && dqz && dwfil_rows && dfilt_rows && dalpha_prev &&
                T > 0 && B > 0 && A > 0 && taps > 0, "asr_att_loc_energy_bwd: bad args");
@@ -1106,20 +1522,46 @@ extern "C" int asr_att_loc_energy_bwd(asr_handle* h, const float* denergy, const
   if (!part) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_att_loc_energy_bwd: scratch too small");
   float* dfeat = part + n_part;
   float* fpart = dfeat + n_feat;
+  const dim3 grid(nch, B);
+  const int shape = loc_vec_shape(A, keys, qz, v, wfil, dkeys);
+  const size_t ldsAv = (loc_vec_lds_floats(taps) + 4 * NP) * sizeof(float);
+  const size_t ldsBv = ((size_t)(ATT_CH + ((taps + 15) & ~15)) + (size_t)taps * LOC_FS +
+                        (size_t)(ATT_CH + taps - 1) * LOC_FS + 16) * sizeof(float);
+  if (shape && ldsAv <= 64 * 1024 && ldsBv <= 64 * 1024) {
+#define ASR_LBWD(L) \
+  hipLaunchKernelGGL((att_loc_energy_bwd_vec_kernel<L, 1>), grid, dim3(256), ldsAv, (hipStream_t)s, denergy, alpha_prev, filt, wfil, keys, qz, v, T, B, A, taps, dkeys, part, dfeat, seq_len)
+    if (shape == 16 * 4 + 1) ASR_LBWD(16); else if (shape == 32 * 4 + 1) ASR_LBWD(32); else ASR_LBWD(64);
+#undef ASR_LBWD
+    hipLaunchKernelGGL(att_loc_conv_bwd_vec_kernel, grid, dim3(256), ldsBv, (hipStream_t)s, dfeat, alpha_prev, filt, T, B,
+                       taps, dalpha_prev, fpart, seq_len);
+    const size_t nout = (size_t)B * NP + (size_t)B * taps * LOC_C;
+    hipLaunchKernelGGL(att_loc_reduce_both_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                       part, fpart, nch, B, A, taps * LOC_C, dqz, dv_rows, dwfil_rows, dfilt_rows, accumulate);
+    ASR_CHECK_LAUNCH(h, "asr_att_loc_energy_bwd");
+    return ASR_OK;
+  }
   const size_t ldsA = (loc_lds_floats(taps, A) + 4 * NP) * sizeof(float);
   const size_t ldsB = ((size_t)(ATT_CH + taps - 1) * (1 + LOC_C) + (size_t)taps * LOC_C) * sizeof(float);
   if (ldsA > 64 * 1024 || ldsB > 64 * 1024)
     ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_att_loc_energy_bwd: taps=%d / A=%d need %zu / %zu B of LDS", taps, A, ldsA, ldsB);
-  hipLaunchKernelGGL(att_loc_energy_bwd_kernel, dim3(nch, B), dim3(256), ldsA, (hipStream_t)s, denergy, alpha_prev, filt,
+  hipLaunchKernelGGL(att_loc_energy_bwd_kernel, grid, dim3(256), ldsA, (hipStream_t)s, denergy, alpha_prev, filt,
                      wfil, keys, qz, v, T, B, A, taps, dkeys, part, dfeat);
   hipLaunchKernelGGL(att_loc_bwd_reduce_kernel, dim3((unsigned)((B * NP + 255) / 256)), dim3(256), 0, (hipStream_t)s,
                      part, nch, B, A, dqz, dv_rows, dwfil_rows, accumulate);
-  hipLaunchKernelGGL(att_loc_conv_bwd_kernel, dim3(nch, B), dim3(256), ldsB, (hipStream_t)s, dfeat, alpha_prev, filt, T,
+  hipLaunchKernelGGL(att_loc_conv_bwd_kernel, grid, dim3(256), ldsB, (hipStream_t)s, dfeat, alpha_prev, filt, T,
                      B, taps, dalpha_prev, fpart);
   hipLaunchKernelGGL(att_loc_filt_reduce_kernel, dim3((B * taps * LOC_C + 255) / 256), dim3(256), 0, (hipStream_t)s,
                      fpart, nch, B, taps * LOC_C, dfilt_rows, accumulate);
   ASR_CHECK_LAUNCH(h, "asr_att_loc_energy_bwd");
   return ASR_OK;
+}
+extern "C" int asr_att_loc_energy_bwd(asr_handle* h, const float* denergy, const float* alpha_prev,
+                                      const float* filt, const float* wfil, const float* keys, const float* qz,
+                                      const float* v, int T, int B, int A, int taps, float* dkeys, float* dqz,
+                                      float* dv_rows, float* dwfil_rows, float* dfilt_rows, float* dalpha_prev,
+                                      int accumulate, asr_stream s) {
+  return loc_energy_bwd_launch(h, denergy, alpha_prev, filt, wfil, keys, qz, v, T, B, A, taps, dkeys, dqz, dv_rows,
+                               dwfil_rows, dfilt_rows, dalpha_prev, accumulate, nullptr, s);
 }
 
 extern "C" int asr_att_softmax_ctx_fwd_ex(asr_handle* h, const float* energy, const int32_t* seq_len,
@@ -1360,8 +1802,8 @@ extern "C" int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_
     if (a->has_query_fc)
       DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, A, U, av, Dav, a->W_q, a->ld_wq, qz, A, a->b_q, 0, 0, s));
     if (a->carry_alpha)
-      DEC_TRY(asr_att_loc_energy_fwd(h, k > 0 ? a->alpha_all + (size_t)(k - 1) * B * T : a->alpha_zero, a->filt, a->wfil,
-                                     a->keys, qz, a->v, T, B, A, a->taps, energy, s));
+      DEC_TRY(loc_energy_fwd_launch(h, k > 0 ? a->alpha_all + (size_t)(k - 1) * B * T : a->alpha_zero, a->filt, a->wfil,
+                                    a->keys, qz, a->v, T, B, A, a->taps, energy, a->seq_len, s));
     else
       DEC_TRY(energy_fwd_launch(h, a->keys, qz, a->v, T, B, A, a->att_mode, energy, a->seq_len, s));
     DEC_TRY(asr_att_softmax_ctx_fwd_ex(h, energy, a->seq_len, a->sharpening, a->enc, a->enc_dtype, T, B, E2,
@@ -1413,9 +1855,9 @@ extern "C" int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_
     }
     if (a->carry_alpha) {
       float* dap = dalp[k & 1];
-      DEC_TRY(asr_att_loc_energy_bwd(h, denergy, k > 0 ? a->alpha_all + (size_t)(k - 1) * B * T : a->alpha_zero, a->filt,
-                                     a->wfil, a->keys, qz, a->v, T, B, A, a->taps, a->dkeys, dqz, dv, a->dwfil_rows,
-                                     a->dfilt_rows, dap, k != To - 1, s));
+      DEC_TRY(loc_energy_bwd_launch(h, denergy, k > 0 ? a->alpha_all + (size_t)(k - 1) * B * T : a->alpha_zero, a->filt,
+                                    a->wfil, a->keys, qz, a->v, T, B, A, a->taps, a->dkeys, dqz, dv, a->dwfil_rows,
+                                    a->dfilt_rows, dap, k != To - 1, a->seq_len, s));
       dalpha_next = dap;
     } else {
       DEC_TRY(energy_bwd_launch(h, denergy, a->keys, qz, a->v, T, B, A, a->att_mode, a->dkeys, dqz, dv, a->seq_len, fp, s));

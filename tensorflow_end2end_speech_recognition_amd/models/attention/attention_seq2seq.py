@@ -391,12 +391,12 @@ class AttentionSeq2Seq(ModelBase):
         # ---- the recurrence, backwards
         # d_enc starts as the CTC head's part (joint model) -- one GEMM that needs nothing from the decoder, issued on
         # side lane 2 so that it runs beside the reverse loop; the first accumulation into d_enc waits for it
-        ctc_denc_event = None
+        ctc_denc_event, ctc_denc_done = None, False
         if tp['ctc'] is not None and at != 'luong_dot':
             denc = torch.empty_like(enc)
             with ops.side_lane(dev, keep=(enc, denc), lane=2):
                 self._ctc_head_backward(tp['ctc'], enc, denc, accumulate=False)
-                ctc_denc_event = ops.stream_event()
+                ctc_denc_event, ctc_denc_done = ops.stream_event(), True
         else:
             denc = torch.zeros_like(enc)
         dkeys = None
@@ -474,7 +474,7 @@ class AttentionSeq2Seq(ModelBase):
                                   st.g('output_embedding/W_embedding'))
             ops.gemm(tp['bi'], dinit, transA=True, out=st.g('bridge/fully_connected/weights'))
             ops.colsum(dinit, out=st.g('bridge/fully_connected/biases'))
-        if tp['ctc'] is not None and ctc_denc_event is None:
+        if tp['ctc'] is not None and not ctc_denc_done:
             self._ctc_head_backward(tp['ctc'], enc, denc, accumulate=True)
         self.encoder.backward(denc, d_final=(dcf, dhf))
         ops.join_side(dev)
