@@ -420,7 +420,9 @@ int asr_att_loc_energy_bwd(asr_handle* h, const float* denergy, const float* alp
  * of the attention decoder issued from ONE call -- the per-step sequence cell-input GEMM -> asr_lstm_cell_fwd_ex ->
  * query GEMM -> asr_att_(loc_)energy_fwd -> asr_att_softmax_ctx_fwd_ex, i.e. exactly the entry points above in the
  * order a host loop would call them (a Python host spends ~15 us per call, ~9 calls per step, 400 steps: the loop was
- * host-bound), and the reverse sequence for the gradients.  Every array is the caller's; per-step arrays are [To, ...]
+ * host-bound), and the reverse sequence for the gradients (where adjacent steps of that sequence have a fused kernel --
+ * the dctx add inside the d-alpha kernel, the softmax backward inside the energy backward, mask and carried-dh add
+ * inside the cell backward -- the loop uses it; the arithmetic is that of the separate entry points).  Every array is the caller's; per-step arrays are [To, ...]
  * row blocks.  Layouts: dec_in [To,B,Em+E2+U] = embedded input | previous context | previous h (the embedding columns
  * and row 0 filled by the caller, the rest by the loop), av_in [To,B,U+E2] = cell output (after its dropout mask) |
  * context; c_all / h_all [To+1,B,U]: carried state BEFORE step k at row k (row 0 = initial state from the bridge). */
