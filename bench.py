@@ -331,23 +331,36 @@ def main():
                     help='CPU legs (baseline, oracle parity): the same batch truncated to its first N frames')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: libraries that print banners to file descriptor 1 (RCCL's
+    # version block, gloo's rank messages) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d' % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # dry-run knobs for a box with fewer GPUs than ranks (scripts/r02_dp_dryrun.sh): ASR_BENCH_DEVICE pins every rank to
+    # one device, ASR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU).  Never set by the driver.
+    dev_index = int(os.environ.get('ASR_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('ASR_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = dict(units=args.units, layers=args.layers, classes=args.classes, dtype=args.dtype, batch=args.batch,
               input_size=args.input_size, tmin=args.tmin, tmax=args.tmax, keep_prob=args.keep_prob, seed=1)
-    res = run_workload(args, wl, dev, world, rank, local_rank, want_parity=not args.no_parity, want_h2d=True)
+    res = run_workload(args, wl, dev, world, rank, dev_index, want_parity=not args.no_parity, want_h2d=True)
     agg = aggregate(res, args, world, dev)
     value = agg['total_frames'] * args.steps / agg['elapsed']
 
@@ -383,16 +396,18 @@ def main():
             # BASELINE configs[0]: TIMIT-39, 2x128 BLSTM-CTC, fp32 (exact fp32 MFMA path), B=16, dropout 0.5
             wa = dict(units=128, layers=2, classes=39, dtype='f32', batch=16, input_size=120, tmin=100, tmax=778,
                       keep_prob=0.5, seed=0)
-            ra = run_workload(args, wa, dev, world, rank, local_rank, want_parity=not args.no_parity, want_h2d=False)
+            ra = run_workload(args, wa, dev, world, rank, dev_index, want_parity=not args.no_parity, want_h2d=False)
             out['cfgA'] = dict(workload='TIMIT 39-phone 2x128 BLSTM-CTC fp32, B=16, D=120, C=40, seq_len~U{100..778}, '
                                         'dropout 0.5, rmsprop, train step',
                                value=ra['frames'] * args.steps / ra['elapsed'], unit='frames/s', dtype='f32',
                                ms_per_step=ra['elapsed'] / args.steps * 1e3, step_ms=ra['step_ms'],
                                final_loss=ra['final_loss'], parity=ra.get('parity'), kernels=ra['kernels'],
                                cpu_baseline=None if args.no_cpu_baseline else cpu_baseline(args, wa, ra))
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + '\n').encode())
     if world > 1:
         dist.destroy_process_group()
+    os.close(result_fd)
 
 
 if __name__ == '__main__':
