@@ -537,22 +537,32 @@ static bool try_gemm_skinny_f32(int transA, int transB, int M, int N, int K, con
 
 // ---------------------------------------------------------------- lean TN kernel (bf16)
 // C[M,N] = A^T B with A [K,M] and B [K,N] both REDUCTION-MAJOR (row = one k): the weight-gradient
-// products X^T dG with K = T*B.  The MFMA fragments want 8 consecutive k per lane, so the tiles are
-// transposed on their way into LDS: a thread loads the 16-byte vectors (8 consecutive m) of two
-// adjacent k rows and writes eight 32-bit (k, k+1) pairs into the [m][k] image.  Sixteen lanes
-// cover 256 contiguous bytes of a k row (coalesced); the LDS image is XOR-swizzled in 16-byte
-// units by (m >> 3) & 7 so those sixteen lanes (rows 8 apart = same bank without it) spread over
-// the banks, and a fragment's 16 bytes stay contiguous.  Split-K over blockIdx.z into fp32 slabs
-// (summed in a fixed order by splitk_reduce_kernel), 128x128x64 tiles, double-buffered LDS.
+// products X^T dG with K = T*B.  The MFMA fragments want 8 consecutive k per lane while memory has 8 consecutive m.
+// gfx950 transposes on the LDS READ side: the tiles are copied into LDS as they come (one 16-byte vector = 8 columns
+// of a k row per ds_write_b128), laid out as 16-column subtiles [128/16][64 k][16] so that the 4 x 16 block a
+// 16-lane group needs is 128 contiguous bytes, and a fragment is two ds_read_b64_tr_b16 (k 0-3 and 4-7 of the lane's
+// eight): each lane passes the address of one 8-byte piece of the block and receives its COLUMN.  Subtiles are
+// 2080 bytes apart (2048 + 32) so the sixteen vectors of a k row land in sixteen different bank groups.
+// (The first form of this kernel transposed on the WRITE side -- sixteen 32-bit LDS stores per thread and tile into
+// a swizzled [m][k] image -- and ran the 5 x 512 weight gradients at ~200 TFLOP/s.)
+// Split-K over slabs (summed in a fixed order by splitk_reduce_kernel), 128x128x64 tiles, double-buffered LDS.
 // Requires M % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0, 16-byte aligned bases.
+constexpr int TN_SUB = 2048 + 32;                 // bytes from one 16-column subtile [64 k][16] to the next
+constexpr int TN_OPER = 8 * TN_SUB;               // one operand tile: 128 columns
+constexpr int TN_STAGE = 2 * TN_OPER;             // A tile | B tile
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+__device__ __forceinline__ bf16x8_t tn_frag(const char* p) {
+  typedef __attribute__((address_space(3))) bf16x4_t lds4_t;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t*)(p));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t*)(p + 128));
+  return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
                                                            int lda, const bf16_t* __restrict__ Bm, int ldb,
                                                            int kchunk, float* __restrict__ partial, int tn, int tm,
                                                            int nslab, int xcd_skip) {
-  constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
-  constexpr int STAGE = (BM + BN) * LD;
+  constexpr int BM = 128, BN = 128, BK = 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* S = reinterpret_cast<bf16_t*>(smem);
 
   // 1-D grid; workgroup b runs on XCD b % 8 and the first xcd_skip XCDs are left to the recurrence clusters
   const int widx = xcd_work_index(xcd_skip);
@@ -564,43 +574,29 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int M, int N, int K, 
   const int kbeg = bz * kchunk, kend = min(K, kbeg + kchunk);
   const int nkt = (kend - kbeg + BK - 1) / BK;
 
-  // two (k-pair, m-vector) items per operand per thread: item q -> mvec = q & 15, kp = q >> 4
-  const int mvec = tid & 15;
-  const int kp0 = tid >> 4;                                // second item: kp0 + 16
+  // four (k row, 8-column vector) items per operand per thread: vector mvec = tid & 15 of rows (tid >> 4) + 16 q
+  const int mvec = tid & 15, kr0 = tid >> 4;
   const bool a_ok = m0 + mvec * 8 + 8 <= M, b_ok = n0 + mvec * 8 + 8 <= N;
-  const bf16_t* pa = A + (size_t)(kbeg + 2 * kp0) * lda + m0 + mvec * 8;
-  const bf16_t* pb = Bm + (size_t)(kbeg + 2 * kp0) * ldb + n0 + mvec * 8;
+  const bf16_t* pa = A + (size_t)(kbeg + kr0) * lda + m0 + mvec * 8;
+  const bf16_t* pb = Bm + (size_t)(kbeg + kr0) * ldb + n0 + mvec * 8;
   const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  bf16x8_t ra[2][2], rb[2][2];                             // [item][k parity]
+  bf16x8_t ra[4], rb[4];
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = kbeg + kt * BK + 2 * (kp0 + 16 * it) + h;
-        const size_t ro = (size_t)(kt * BK + 32 * it + h);
-        ra[it][h] = (a_ok && k < kend) ? *reinterpret_cast<const bf16x8_t*>(pa + ro * lda) : zero;
-        rb[it][h] = (b_ok && k < kend) ? *reinterpret_cast<const bf16x8_t*>(pb + ro * ldb) : zero;
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int k = kbeg + kt * BK + kr0 + 16 * q;
+      const size_t ro = (size_t)(kt * BK + 16 * q);
+      ra[q] = (a_ok && k < kend) ? *reinterpret_cast<const bf16x8_t*>(pa + ro * lda) : zero;
+      rb[q] = (b_ok && k < kend) ? *reinterpret_cast<const bf16x8_t*>(pb + ro * ldb) : zero;
+    }
   };
-  // [m][k] image; the 16-byte unit index INSIDE a row (k >> 3, 0..7) is XORed with (m >> 3) & 7
-  // (== mvec & 7 for the rows this thread writes); rows keep their 144-byte stride
-  const unsigned sw = (unsigned)(mvec & 7);
-  auto sstore = [&](bf16_t* st) {
-    char* base = reinterpret_cast<char*>(st);
+  // image: subtile (mvec >> 1), row k (32 bytes), half (mvec & 1)
+  const unsigned wbase = (unsigned)(mvec >> 1) * TN_SUB + (unsigned)kr0 * 32u + (unsigned)(mvec & 1) * 16u;
+  auto sstore = [&](char* st) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const unsigned k2 = (unsigned)(2 * (kp0 + 16 * it));                 // even k of the pair
-      const unsigned inrow = (((k2 >> 3) ^ sw) << 4) + (k2 & 7u) * 2u;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned off = (unsigned)(mvec * 8 + j) * LD * 2u + inrow;
-        // elements are (signed) shorts holding raw bf16 bits: no sign extension into the high half
-        *reinterpret_cast<unsigned*>(base + off) =
-            (unsigned)(unsigned short)ra[it][0][j] | ((unsigned)(unsigned short)ra[it][1][j] << 16);
-        *reinterpret_cast<unsigned*>(base + BM * LD * 2 + off) =
-            (unsigned)(unsigned short)rb[it][0][j] | ((unsigned)(unsigned short)rb[it][1][j] << 16);
-      }
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<bf16x8_t*>(st + wbase + q * 16 * 32) = ra[q];
+      *reinterpret_cast<bf16x8_t*>(st + TN_OPER + wbase + q * 16 * 32) = rb[q];
     }
   };
 
@@ -612,37 +608,36 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int M, int N, int K, 
 
   if (nkt > 0) {
     gload(0);
-    sstore(S);
+    sstore(smem);
   }
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  unsigned arow[4], brow[4], au[4], bu[4];                 // row byte offset / swizzled unit of k-block fq
+  // lane's 8-byte piece of a 16-lane group's [4 k][16 col] block: row (fr >> 2), columns 4 (fr & 3) .. + 3; the
+  // group fq takes k rows 8 fq .. 8 fq + 7 of the 32-row k-block (two reads, 4 rows = 128 bytes apart)
+  const unsigned piece = (unsigned)(8 * fq + (fr >> 2)) * 32u + (unsigned)(fr & 3) * 8u;
+  unsigned aoff[4], boff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const unsigned ra_ = (unsigned)(wm * 64 + i * 16 + fr), rb_ = (unsigned)(wn * 64 + i * 16 + fr);
-    arow[i] = ra_ * LD * 2u;
-    brow[i] = (unsigned)BM * LD * 2u + rb_ * LD * 2u;
-    au[i] = (unsigned)fq ^ ((ra_ >> 3) & 7u);
-    bu[i] = (unsigned)fq ^ ((rb_ >> 3) & 7u);
+    aoff[i] = (unsigned)(wm * 4 + i) * TN_SUB + piece;
+    boff[i] = (unsigned)TN_OPER + (unsigned)(wn * 4 + i) * TN_SUB + piece;
   }
   for (int kt = 0; kt < nkt; ++kt) {
-    const char* cur = reinterpret_cast<const char*>(S + (kt & 1) * STAGE);
+    const char* cur = smem + (kt & 1) * TN_STAGE;
     if (kt + 1 < nkt) gload(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t a[4], b[4];
-      // k-block of this lane = ks*4 + fq; (ks*4 + fq) ^ sw == (fq ^ sw) ^ (ks*4)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(cur + arow[i] + ((au[i] ^ (unsigned)(ks * 4)) << 4));
+      for (int i = 0; i < 4; ++i) a[i] = tn_frag(cur + aoff[i] + ks * 32 * 32);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(cur + brow[j] + ((bu[j] ^ (unsigned)(ks * 4)) << 4));
+      for (int j = 0; j < 4; ++j) b[j] = tn_frag(cur + boff[j] + ks * 32 * 32);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nkt) sstore(S + ((kt + 1) & 1) * STAGE);
+    if (kt + 1 < nkt) sstore(smem + ((kt + 1) & 1) * TN_STAGE);
     __syncthreads();
   }
   // slab [z][M][N]; lane holds C[m = fr][n = fq*4 .. +3] of each 16x16 tile
@@ -990,7 +985,7 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
         int kchunk = (K + S - 1) / S;
         kchunk = (kchunk + 63) / 64 * 64;
         S = (K + kchunk - 1) / kchunk;
-        const size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * sizeof(bf16_t);
+        const size_t lds = (size_t)2 * TN_STAGE;
         static bool attr_done = false;
         if (!attr_done) {
           attr_done = true;
