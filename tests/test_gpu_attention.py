@@ -311,3 +311,83 @@ def test_attention_model_parity_carried_alpha_and_long_inputs(cuda, att, sig, B,
     ref_ids = oatt.attention_model_infer(sd, x, sl, L, att, C, C + 1, 12, clip_enc=50.0, clip_dec=50.0, sharpening=1.5,
                                          sigmoid_smoothing=sig, prev_alpha='carry')
     assert np.array_equal(out_infer.predicted_ids.cpu().numpy(), ref_ids)
+
+
+@pytest.mark.parametrize('case', ['location_zeros_bf16', 'bahdanau_sigmoid_f32', 'location_carry_bf16', 'hybrid_carry_f32',
+                                  'luong_dot_small'])
+def test_native_decoder_loop_against_the_step_by_step_statement(cuda, case):
+    """asr_att_decoder_fwd / _bwd (all To steps from one call, with the fused kernels the loop uses: dctx add inside the
+    4-frame d-alpha kernel, softmax backward folded into the energy backward through partial alpha.dalpha sums, dropout
+    mask and carried-dh add inside the cell backward, length-limited vectorised energy / location kernels with exp2-rcp
+    tanh, skinny MFMA products) against tests/_cpu_ops.py's step-by-step float64 statement of the same loop -- at
+    widths that select those kernels (A = 128 -> 32 lanes x float4 per frame, 2H = 512 bf16 / 256 fp32 -> 16-byte
+    encoder vectors, T = 200 -> four 64-frame chunks), which the small model-level parity tests do not reach.  The last
+    case (A = U = 2H = 64, dot-product scoring without a query FC) takes the general fallbacks instead."""
+    import _cpu_ops as cpu
+    from tensorflow_end2end_speech_recognition_amd import ops
+    cfg = dict(location_zeros_bf16=dict(keys=False, carry=0, sig=False, bf16=True, A=128, E2=512, mode=0, hasq=1, taps=0),
+               bahdanau_sigmoid_f32=dict(keys=True, carry=0, sig=True, bf16=False, A=128, E2=256, mode=0, hasq=1, taps=0),
+               location_carry_bf16=dict(keys=False, carry=1, sig=False, bf16=True, A=128, E2=512, mode=0, hasq=1, taps=201),
+               hybrid_carry_f32=dict(keys=True, carry=1, sig=True, bf16=False, A=32, E2=256, mode=0, hasq=1, taps=200),
+               luong_dot_small=dict(keys=True, carry=0, sig=False, bf16=False, A=64, E2=64, mode=1, hasq=0, taps=0))[case]
+    rng = np.random.RandomState(len(case))
+    B, T, To, Em = 3, 200, 5, 8
+    A, E2 = cfg['A'], cfg['E2']
+    U = A if not cfg['hasq'] else 64
+    Din = Em + E2 + U
+    f = lambda *s, sc=1.0: torch.tensor(rng.randn(*s) * sc, dtype=torch.float32)
+    seq_len = torch.tensor([T, 77, 130], dtype=torch.int32)
+    live = torch.tensor([[1, 1, 1], [1, 1, 1], [1, 0, 1], [1, 0, 1], [1, 0, 0]], dtype=torch.float32)   # [To,B]
+    enc = f(T, B, E2, sc=0.5)
+    enc = enc * (torch.arange(T).view(T, 1, 1) < seq_len.view(1, B, 1))
+    if cfg['bf16']:
+        enc = enc.to(torch.bfloat16)
+    a = dict(To=To, B=B, T=T, U=U, Em=Em, E2=E2, A=A, att_mode=cfg['mode'], has_query_fc=cfg['hasq'],
+             carry_alpha=cfg['carry'], taps=cfg['taps'], enc_dtype=1 if cfg['bf16'] else 0, forget_bias=1.0,
+             cell_clip=3.0, sharpening=1.5,
+             W_cell=f(Din, 4 * U, sc=0.08), b_cell=f(4 * U, sc=0.1), peep=f(3, U, sc=0.1),
+             W_q=f(U, A, sc=0.1) if cfg['hasq'] else None, b_q=f(A, sc=0.1) if (cfg['hasq'] and cfg['carry']) else None,
+             v=f(A, sc=0.5) if cfg['mode'] == 0 else None,
+             keys=(enc.float() if case == 'luong_dot_small' else f(T, B, A, sc=0.5)) if cfg['keys'] else None,
+             enc=enc, seq_len=seq_len,
+             filt=f(cfg['taps'], 1, 10, sc=0.3) if cfg['carry'] else None, wfil=f(10, A, sc=0.3) if cfg['carry'] else None,
+             alpha_zero=torch.zeros(B, T) if cfg['carry'] else None, live=live,
+             dmask=(torch.tensor(rng.rand(To, B, U) < 0.8, dtype=torch.float32) / 0.8),
+             dec_in=f(To, B, Din, sc=0.5), av_in=torch.zeros(To, B, U + E2), alpha_all=torch.zeros(To, B, T),
+             snorm_all=torch.zeros(To, B) if cfg['sig'] else None, gates_all=torch.zeros(To, B, 4 * U),
+             craw_all=torch.zeros(To, B, U), c_all=torch.zeros(To + 1, B, U), h_all=torch.zeros(To + 1, B, U),
+             qz_all=torch.zeros(To, B, A))
+    a['c_all'][0] = f(B, U, sc=0.3)
+    a['h_all'][0] = f(B, U, sc=0.3)
+    a['dec_in'][0, :, Em:Em + E2] = 0.0                      # no context before the first step
+    a['dec_in'][0, :, Em + E2:] = a['h_all'][0]
+    bwd_in = dict(dav_cell=f(To, B, U, sc=0.3), dav_ctx=f(To, B, E2, sc=0.3))
+    bwd_out = dict(dctx_all=(To, B, E2), dpre_all=(To, B, 4 * U), dqz_all=(To, B, A),
+                   dv_all=(To, B, A) if cfg['mode'] == 0 else None, dpeep_all=(To, B, 3 * U), d_in_all=(To, B, Din),
+                   dkeys=(T, B, A) if cfg['keys'] else None, dwfil_rows=(B, 10, A) if cfg['carry'] else None,
+                   dfilt_rows=(B, cfg['taps'], 10) if cfg['carry'] else None, dc0=(B, U), dh0=(B, U))
+
+    def clone_to(dev):
+        d = {k: (v.clone().to(dev) if torch.is_tensor(v) else v) for k, v in a.items()}
+        d.update({k: v.clone().to(dev) for k, v in bwd_in.items()})
+        d.update({k: (torch.zeros(s, device=dev) if s is not None else None) for k, s in bwd_out.items()})
+        return d
+
+    ref, got = clone_to('cpu'), clone_to(cuda)
+    cpu._att_decoder_fwd(ref)
+    ops.att_decoder_fwd(got)
+    # relative to the array's largest entry, with a floor: without keys and without carried location features every frame
+    # has the same energy, so dqz / dv are (sum_t denergy) x const = rounding noise around zero (1e-7) on both sides
+    rel = lambda x, y: float(np.abs(x.cpu().double().numpy() - y.double().numpy()).max() / max(np.abs(y.double().numpy()).max(), 1e-2))
+    for name in ('alpha_all', 'av_in', 'dec_in', 'c_all', 'h_all', 'qz_all', 'gates_all', 'craw_all') + (('snorm_all',) if cfg['sig'] else ()):
+        assert rel(got[name], ref[name]) < 2e-5, (name, rel(got[name], ref[name]))
+    # the backward of both sides starts from the SAME saved forward (the reference's), so the comparison is per kernel
+    for name in ('alpha_all', 'av_in', 'dec_in', 'c_all', 'h_all', 'qz_all', 'gates_all', 'craw_all', 'snorm_all'):
+        if ref.get(name) is not None:
+            got[name].copy_(ref[name].to(cuda))
+    cpu._att_decoder_bwd(ref)
+    ops.att_decoder_bwd(got)
+    for name, shape in bwd_out.items():
+        if shape is not None:
+            assert rel(got[name], ref[name]) < 5e-5, (name, rel(got[name], ref[name]))
+    assert ops.check_async_errors(0) == 0
