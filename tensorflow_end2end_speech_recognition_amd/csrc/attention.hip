@@ -1359,6 +1359,182 @@ inline int gridn(size_t n) {
 
 }  // namespace
 
+namespace {
+// ---- query-FC backward + cell backward of one decoder step, one launch (the reverse loop's third and fourth kernels
+// and the partial-sum reduction before them):
+//   dqz[b,:]  = fixed-order sum over the frame chunks of the energy backward's partials      (also dv_rows)
+//   dcell     = dcell_in + dqz . W_q^T            [B,U]   exact-fp32 MFMA, K = A
+//   cell backward on dcell (cell_bwd_kernel's arithmetic) in the epilogue
+// One workgroup = 16 utterances x 16 units; wave w multiplies the 64-wide slice w of A (A <= 512), its A fragment
+// being the SUM of the chunk partials read straight from the energy kernel's scratch; the tiles meet in LDS in a fixed
+// order.  Column-tile 0 also writes dqz / dv_rows (the weight gradients after the loop need them).
+struct CellBwdArgs {
+  const float *dc_next, *dh_next, *dh_next2, *gates, *c_raw, *c_prev, *peep, *live, *use_mask;
+  float *dpre, *dc_prev, *dh_prev_carry, *dpeep_rows;
+  int ld2;
+};
+// NTL MFMA column tiles (16 NTL units) per workgroup.  Measured on the cfg D shard (A = 128, U = 512, 25 chunks): NTL = 1
+// (34 workgroups x 2 row groups) 54.3 ms for the reverse pass, NTL = 4 (10 x 2) 55.4, the three separate launches 55.0.
+constexpr int DQ_NTL = 1, DQ_CT = 16 * DQ_NTL;
+__global__ __launch_bounds__(512) void att_dq_cell_bwd_kernel(const float* __restrict__ part, int nch, int B, int A, int U,
+                                                              const float* __restrict__ Wq, int ldw,
+                                                              const float* __restrict__ dcell_in,
+                                                              float* __restrict__ dqz_out, float* __restrict__ dv_out,
+                                                              CellBwdArgs c) {
+  // grid.x = U / DQ_CT column blocks + 2 "writer" workgroups (dqz, dv_rows); A / 64 = units in {1, 2, 4, 8}.  Every
+  // column block re-reads the chunk partials of its 16 utterances (the price of not having a reduction launch).
+  __shared__ f32x4_t asum[8][4][64];            // per wave: its share of a slice's chunk sum, in MFMA A-fragment layout
+  __shared__ float red[8][16][DQ_CT + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rg = lane >> 4;
+  const int nblk = U / DQ_CT;
+  const int writer = (int)blockIdx.x - nblk;    // < 0: a column block; 0: writes dqz; 1: writes dv_rows
+  const int n0 = blockIdx.x * DQ_CT, m0 = blockIdx.y * 16;
+  const int units = A / 64, wpu = 8 / units;     // waves per 64-wide slice
+  const int row = min(m0 + col, B - 1);
+  const size_t cs = (size_t)B * 2 * A;
+  if (writer == 1 && !dv_out) return;
+  // wave w: slice u = w / wpu, share si = w % wpu = the chunks si, si + wpu, ... of that slice.  One load phase for the
+  // whole workgroup, the shares meet in LDS and the first wave of each slice adds them in a fixed order.
+  const int u = wave / wpu, si = wave % wpu;
+  const int kb = u * 64 + rg * 4;
+  // everything the multiply and the epilogue read from global memory is requested up front, so that the chunk
+  // partials are the only round trip on the kernel's chain (each of these was one more ~1 us hop behind a barrier)
+  f32x4_t bw[DQ_NTL][4];
+#pragma unroll
+  for (int t = 0; t < DQ_NTL; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bw[t][j] = (writer < 0 && si == 0)
+                     ? *reinterpret_cast<const f32x4_t*>(Wq + (size_t)(n0 + t * 16 + col) * ldw + kb + j * 16)
+                     : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int idx = threadIdx.x;
+  // epilogue: output o = idx + 512 h2 of the [16][DQ_CT] tile
+  constexpr int EPT = (16 * DQ_CT + 511) / 512;
+  float e_dcell[EPT], e_dhn[EPT], e_dcn[EPT], e_g[EPT][4], e_cr[EPT], e_cp[EPT], e_w[EPT][3], e_mask[EPT], e_lv[EPT];
+  if (writer < 0) {
+#pragma unroll
+    for (int h2 = 0; h2 < EPT; ++h2) {
+      const int o = min(idx + 512 * h2, 16 * DQ_CT - 1);
+      const int eb = min(m0 + o / DQ_CT, B - 1), ej = n0 + o % DQ_CT;
+      const size_t bu = (size_t)eb * U + ej;
+      e_lv[h2] = c.live[eb];
+      e_dcell[h2] = dcell_in[bu];
+      e_dhn[h2] = c.dh_next[bu];
+      if (c.dh_next2) e_dhn[h2] += c.dh_next2[(size_t)eb * c.ld2 + ej];
+      e_dcn[h2] = c.dc_next[bu];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e_g[h2][q] = c.gates[(size_t)eb * 4 * U + q * U + ej];
+      e_cr[h2] = c.c_raw[bu];
+      e_cp[h2] = c.c_prev[bu];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) e_w[h2][q] = c.peep ? c.peep[q * U + ej] : 0.f;
+      e_mask[h2] = c.use_mask ? c.use_mask[bu] : 1.f;
+    }
+  }
+  {
+    const float* p = part + (size_t)row * 2 * A + (writer == 1 ? A : 0) + kb;
+    f32x4_t sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int c0 = si; c0 < nch; c0 += 8 * wpu) {
+      f32x4_t x[8][4];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          x[q][j] = (c0 + q * wpu < nch) ? *reinterpret_cast<const f32x4_t*>(p + (size_t)(c0 + q * wpu) * cs + j * 16)
+                                         : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sh[j][0] += x[q][j][0]; sh[j][1] += x[q][j][1]; sh[j][2] += x[q][j][2]; sh[j][3] += x[q][j][3];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asum[wave][j][lane] = sh[j];
+  }
+  __syncthreads();
+  f32x4_t acc[DQ_NTL];
+#pragma unroll
+  for (int t = 0; t < DQ_NTL; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  if (si == 0) {
+    f32x4_t a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4_t t = asum[wave][j][lane];
+      for (int w = 1; w < wpu; ++w) {
+        const f32x4_t y = asum[wave + w][j][lane];
+        t[0] += y[0]; t[1] += y[1]; t[2] += y[2]; t[3] += y[3];
+      }
+      a[j] = t;
+    }
+    if (writer >= 0) {
+      if (m0 + col < B) {
+        float* o = (writer == 1 ? dv_out : dqz_out) + (size_t)row * A + kb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(o + j * 16) = a[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < DQ_NTL; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][e], bw[t][j][e], acc[t], 0, 0, 0);
+    }
+  }
+  if (writer >= 0) return;
+#pragma unroll
+  for (int t = 0; t < DQ_NTL; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][rg * 4 + r][t * 16 + col] = acc[t][r];
+  __syncthreads();
+#pragma unroll
+  for (int h2 = 0; h2 < EPT; ++h2) {
+    const int o = idx + 512 * h2;
+    if (o >= 16 * DQ_CT) continue;
+    const int em = o / DQ_CT, en = o % DQ_CT, b = m0 + em, j = n0 + en;
+    if (b >= B) continue;
+    const size_t bu = (size_t)b * U + j;
+    float dq = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dq += red[w][em][en];
+    const float dcell = e_dcell[h2] + dq;
+    // ---- cell_bwd_kernel's arithmetic on (b, j)
+    float* dp = c.dpre + (size_t)b * 4 * U;
+    if (!(e_lv[h2] > 0.f)) {
+      dp[j] = 0.f; dp[U + j] = 0.f; dp[2 * U + j] = 0.f; dp[3 * U + j] = 0.f;
+      c.dc_prev[bu] = e_dcn[h2];
+      c.dh_prev_carry[bu] = e_dhn[h2];
+      if (c.dpeep_rows) {
+        c.dpeep_rows[(size_t)b * 3 * U + j] = 0.f; c.dpeep_rows[(size_t)b * 3 * U + U + j] = 0.f;
+        c.dpeep_rows[(size_t)b * 3 * U + 2 * U + j] = 0.f;
+      }
+      continue;
+    }
+    const float gi = e_g[h2][0], gg = e_g[h2][1], gf = e_g[h2][2], go = e_g[h2][3];
+    const float dh = dcell * e_mask[h2] + e_dhn[h2];
+    const float tc = tanhf(e_cr[h2]);
+    const float d_o = dh * tc * go * (1.f - go);
+    const float dc = e_dcn[h2] + dh * go * (1.f - tc * tc) + d_o * e_w[h2][2];
+    const float d_g = dc * gi * (1.f - gg * gg);
+    const float d_i = dc * gg * gi * (1.f - gi);
+    const float d_f = dc * e_cp[h2] * gf * (1.f - gf);
+    dp[j] = d_i; dp[U + j] = d_g; dp[2 * U + j] = d_f; dp[3 * U + j] = d_o;
+    c.dc_prev[bu] = dc * gf + d_i * e_w[h2][0] + d_f * e_w[h2][1];
+    c.dh_prev_carry[bu] = 0.f;
+    if (c.dpeep_rows) {
+      c.dpeep_rows[(size_t)b * 3 * U + j] = d_i * e_cp[h2];
+      c.dpeep_rows[(size_t)b * 3 * U + U + j] = d_f * e_cp[h2];
+      c.dpeep_rows[(size_t)b * 3 * U + 2 * U + j] = d_o * e_cr[h2];
+    }
+  }
+}
+}  // namespace
+
 #define ATT_NEED(cond, ...) do { if (!(cond)) ASR_FAIL(h, ASR_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
 
 extern "C" int asr_lstm_cell_fwd_ex(asr_handle* h, const float* pre, const float* c_prev, const float* h_prev,
@@ -1436,7 +1612,10 @@ static inline float* att_scratch(asr_handle* h, size_t bytes) {
 
 static int energy_bwd_launch(asr_handle* h, const float* denergy, const float* keys, const float* qz, const float* v,
                              int T, int B, int A, int mode, float* dkeys, float* dqz, float* dv_rows,
-                             const int32_t* seq_len, const SoftmaxBwdFold* fold, asr_stream s) {
+                             const int32_t* seq_len, const SoftmaxBwdFold* fold, asr_stream s,
+                             const float** part_out = nullptr, int* nch_out = nullptr) {
+  // part_out / nch_out: the caller sums the chunk partials itself (att_dq_cell_bwd_kernel does it on its operand
+  // load) -- no reduction launch here, dqz / dv_rows are not written
   if (!h) return ASR_ERR_INVALID_ARG;
   const int shape = energy_vec_shape(A, keys, qz, v, dkeys);
   ATT_NEED((denergy || (fold && fold->da && shape)) && qz && dqz && T > 0 && B > 0 && A > 0,
@@ -1466,8 +1645,13 @@ static int energy_bwd_launch(asr_handle* h, const float* denergy, const float* k
                          dkeys, part, seq_len);
   }
 #undef ASR_EBWD
-  hipLaunchKernelGGL(att_energy_bwd_reduce_kernel, dim3((B * 2 * A + 255) / 256), dim3(256), 0, (hipStream_t)s, part,
-                     nch, B, A, dqz, dv_rows);
+  if (part_out) {
+    *part_out = part;
+    *nch_out = nch;
+  } else {
+    hipLaunchKernelGGL(att_energy_bwd_reduce_kernel, dim3((B * 2 * A + 255) / 256), dim3(256), 0, (hipStream_t)s, part,
+                       nch, B, A, dqz, dv_rows);
+  }
   ASR_CHECK_LAUNCH(h, "asr_att_energy_bwd");
   return ASR_OK;
 }
@@ -1859,23 +2043,41 @@ extern "C" int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_
                                     a->wfil, a->keys, qz, a->v, T, B, A, a->taps, a->dkeys, dqz, dv, a->dwfil_rows,
                                     a->dfilt_rows, dap, k != To - 1, a->seq_len, s));
       dalpha_next = dap;
-    } else {
-      DEC_TRY(energy_bwd_launch(h, denergy, a->keys, qz, a->v, T, B, A, a->att_mode, a->dkeys, dqz, dv, a->seq_len, fp, s));
     }
     float* dcell = const_cast<float*>(a->dav_cell) + (size_t)k * B * U;
-    if (a->has_query_fc)
-      DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 1, B, U, A, dqz, A, a->W_q, a->ld_wq, dcell, U, nullptr, 1, 0, s));
-    else
-      DEC_TRY(asr_add_cols(h, dcell, U, dqz, A, dcell, U, B, U, s));
-    // the cell kernel applies the output dropout mask to dcell and adds the h-columns of step k+1's cell-input
-    // gradient to the carried dh itself
     float* dpre = a->dpre_all + (size_t)k * B * 4 * U;
-    DEC_TRY(cell_bwd_launch(h, dcell, dcs[cur], dhc[cur], a->gates_all + (size_t)k * B * 4 * U,
-                            a->craw_all + (size_t)k * B * U, a->c_all + (size_t)k * B * U, a->peep,
-                            a->live + (size_t)k * B, B, U, dpre, dcs[cur ^ 1], dhc[cur ^ 1],
-                            a->dpeep_all ? a->dpeep_all + (size_t)k * B * 3 * U : nullptr,
-                            d_in_next ? d_in_next + Em + E2 : nullptr, Din,
-                            a->dmask ? a->dmask + (size_t)k * B * U : nullptr, s));
+    float* dpeep = a->dpeep_all ? a->dpeep_all + (size_t)k * B * 3 * U : nullptr;
+    const float* dh2 = d_in_next ? d_in_next + Em + E2 : nullptr;
+    const float* dmask = a->dmask ? a->dmask + (size_t)k * B * U : nullptr;
+    // query-FC backward + cell backward in ONE launch that also sums the energy backward's chunk partials, when the
+    // shapes allow (a query FC over A = 64 / 128 / 256 / 512 columns, U % 16 == 0, 16-byte aligned rows, no carried alpha)
+    const bool fused_q = !a->carry_alpha && a->has_query_fc && (A == 64 || A == 128 || A == 256 || A == 512) && U % DQ_CT == 0 &&
+                         a->ld_wq % 4 == 0 && ((uintptr_t)a->W_q) % 16 == 0 && ((uintptr_t)dqz) % 16 == 0 &&
+                         (!dv || ((uintptr_t)dv) % 16 == 0);
+    if (fused_q) {
+      const float* part = nullptr;
+      int nchq = 0;
+      DEC_TRY(energy_bwd_launch(h, denergy, a->keys, qz, a->v, T, B, A, a->att_mode, a->dkeys, dqz, dv, a->seq_len, fp, s,
+                                &part, &nchq));
+      CellBwdArgs ca = {dcs[cur], dhc[cur], dh2, a->gates_all + (size_t)k * B * 4 * U, a->craw_all + (size_t)k * B * U,
+                        a->c_all + (size_t)k * B * U, a->peep, a->live + (size_t)k * B, dmask,
+                        dpre, dcs[cur ^ 1], dhc[cur ^ 1], dpeep, Din};
+      hipLaunchKernelGGL(att_dq_cell_bwd_kernel, dim3(U / DQ_CT + 2, (B + 15) / 16), dim3(512), 0, st, part, nchq, B, A, U,
+                         a->W_q, a->ld_wq, dcell, dqz, dv, ca);
+      ASR_CHECK_LAUNCH(h, "asr_att_decoder_bwd");
+    } else {
+      if (!a->carry_alpha)
+        DEC_TRY(energy_bwd_launch(h, denergy, a->keys, qz, a->v, T, B, A, a->att_mode, a->dkeys, dqz, dv, a->seq_len, fp, s));
+      if (a->has_query_fc)
+        DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 1, B, U, A, dqz, A, a->W_q, a->ld_wq, dcell, U, nullptr, 1, 0, s));
+      else
+        DEC_TRY(asr_add_cols(h, dcell, U, dqz, A, dcell, U, B, U, s));
+      // the cell kernel applies the output dropout mask to dcell and adds the h-columns of step k+1's cell-input
+      // gradient to the carried dh itself
+      DEC_TRY(cell_bwd_launch(h, dcell, dcs[cur], dhc[cur], a->gates_all + (size_t)k * B * 4 * U,
+                              a->craw_all + (size_t)k * B * U, a->c_all + (size_t)k * B * U, a->peep,
+                              a->live + (size_t)k * B, B, U, dpre, dcs[cur ^ 1], dhc[cur ^ 1], dpeep, dh2, Din, dmask, s));
+    }
     float* d_in = a->d_in_all + (size_t)k * B * Din;
     DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 1, B, Din, 4 * U, dpre, 4 * U, a->W_cell, 4 * U, d_in, Din, nullptr, 0, 0, s));
     cur ^= 1;
