@@ -14,7 +14,7 @@ def _timed(name):
     setattr(_ops, name, w)
 _timed('att_decoder_fwd'); _timed('att_decoder_bwd')
 rng = np.random.RandomState(3)
-B, D, C = int(os.environ.get('PB', 32)), 240, 28
+B, D, C = int(os.environ.get('PB', 32)), 240, int(os.environ.get('PC', 28))
 tmax = int(os.environ.get('PT', 1600))
 sl = rng.randint(100, tmax + 1, size=B).astype(np.int32)
 T = int(sl.max())
