@@ -111,6 +111,14 @@ int asr_apply_mask(asr_handle* h, int dtype, const void* in, const float* mask, 
 /* Bernoulli(keep_prob)/keep_prob mask from a counter-based generator (seed, offset) */
 int asr_dropout_mask(asr_handle* h, float* mask, size_t n, float keep_prob,
                      uint64_t seed, uint64_t offset, asr_stream s);
+/* The same mask formed where it is used (no mask tensor): out = in * mask(seed, offset) in `dtype`, bit-identical to
+ * asr_dropout_mask + asr_apply_mask; and its backward through a ReLU, dpre = (out > 0 ? dout * mask : 0) =
+ * asr_relu_bwd with that mask.  tf.nn.dropout on the gigabyte-sized activations of the VGG front-end
+ * (vgg_blstm.py:121-157), where an fp32 mask would be three times the activation's own traffic. */
+int asr_dropout_apply(asr_handle* h, int dtype, const void* in, void* out, size_t n, float keep_prob, uint64_t seed,
+                      uint64_t offset, asr_stream s);
+int asr_relu_bwd_drop(asr_handle* h, int dtype, const float* dout, const void* out, size_t n, float keep_prob,
+                      uint64_t seed, uint64_t offset, void* dpre, asr_stream s);
 /* out[N] = sum over rows of a[M,N] (bias gradients); a in `dtype`, out fp32 */
 int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N, int lda,
                float* out, asr_stream s);
@@ -179,6 +187,13 @@ int asr_maxpool2x2_fwd(asr_handle* h, int dtype, const void* in, int N, int H, i
 int asr_maxpool2x2_bwd(asr_handle* h, const float* dout, const uint8_t* argmax, int N, int H, int W,
                        int C, float* din, asr_stream s);
 /* dpre = dout * (out > 0) (* mask if given), written in `dtype` (ReLU + dropout backward) */
+/* asr_dropout_apply (on the pooled gradient, when use_drop) -> asr_maxpool2x2_bwd -> asr_relu_bwd of the convolution
+ * under the pool, as one pass without the full-resolution fp32 gradient in between: dpre[n,h,w,c] (operand dtype) =
+ * (act[n,h,w,c] > 0 && argmax[o] == 2 (h & 1) + (w & 1)) ? dout[o] * mask(o) : 0, o = pooled cell (n, h/2, w/2, c).
+ * C % 4 == 0, 16-byte aligned arrays. */
+int asr_maxpool2x2_relu_bwd(asr_handle* h, int dtype, const float* dout, const uint8_t* argmax, const void* act, int N,
+                            int H, int W, int C, void* dpre, float keep_prob, uint64_t seed, uint64_t offset,
+                            int use_drop, asr_stream s);
 int asr_relu_bwd(asr_handle* h, int dtype, const float* dout, const void* out, const float* mask,
                  size_t n, void* dpre, asr_stream s);
 

@@ -34,6 +34,8 @@ SIGNATURES = {
     'asr_cast_to_f32': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     'asr_apply_mask': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp]),
     'asr_dropout_mask': (_i, [_vp, _vp, _sz, _f, _u64, _u64, _vp]),
+    'asr_dropout_apply': (_i, [_vp, _i, _vp, _vp, _sz, _f, _u64, _u64, _vp]),
+    'asr_relu_bwd_drop': (_i, [_vp, _i, _vp, _vp, _sz, _f, _u64, _u64, _vp, _vp]),
     'asr_colsum': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     'asr_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'asr_gemm_act': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
@@ -49,6 +51,7 @@ SIGNATURES = {
     'asr_maxpool2x2_fwd': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_maxpool2x2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'asr_relu_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
+    'asr_maxpool2x2_relu_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _u64, _u64, _i, _vp]),
     'asr_lstm_prep_weights': (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_lstm_prep_layer': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'asr_lstm_grad_finish': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),

@@ -155,6 +155,77 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float ke
   }
 }
 
+// The mask of dropout_mask_kernel formed where it is used instead of being stored: element e takes word e % 4 of
+// the Philox block at counter offset + e / 4 -- bit-identical to asr_dropout_mask followed by asr_apply_mask.  For the
+// VGG front-end, whose activation tensors are gigabytes (cfg C: 1.6 G elements after the first block): an fp32 mask
+// written once and read twice is 12 bytes per element against 2-4 for the activation itself.
+__device__ __forceinline__ void dropout_words(uint64_t ctr, uint64_t seed, float keep, float inv, float m[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m[j] = ((c[j] >> 8) * (1.0f / 16777216.0f) < keep) ? inv : 0.f;
+}
+// out = in * mask;  relu_out != NULL: out = (relu_out > 0 ? in * mask : 0)  (in fp32 gradient, out in TO).
+// Four elements per thread and trip as ONE vector load / store per array (8 bytes of bf16, 16 of fp32): with 2-byte
+// scalar accesses the kernel ran at 2.5 TB/s.
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  typedef f32x4_t raw_t;
+  static __device__ __forceinline__ void load(const float* p, float v[4]) {
+    const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p);
+    v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+  }
+  static __device__ __forceinline__ void store(float* p, const float v[4]) {
+    *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){v[0], v[1], v[2], v[3]};
+  }
+};
+template <> struct Vec4<bf16_t> {
+  typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+  static __device__ __forceinline__ void load(const bf16_t* p, float v[4]) {
+    const us4_t r = *reinterpret_cast<const us4_t*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = bf16_to_f32(r[j]);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float v[4]) {
+    us4_t r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = f32_to_bf16(v[j]);
+    *reinterpret_cast<us4_t*>(p) = r;
+  }
+};
+template <typename TI, typename TO>
+__global__ void dropout_apply_kernel(const TI* __restrict__ in, const TO* __restrict__ relu_out, TO* __restrict__ out,
+                                     size_t n, float keep, uint64_t seed, uint64_t offset, int vec_ok) {
+  const float inv = 1.f / keep;
+  const size_t n4 = (n + 3) / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float m[4];
+    dropout_words(offset + i, seed, keep, inv, m);
+    const size_t e0 = i * 4;
+    if (vec_ok && e0 + 4 <= n) {
+      float x[4], r[4];
+      Vec4<TI>::load(in + e0, x);
+      if (relu_out) Vec4<TO>::load(relu_out + e0, r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] *= m[j];
+        if (relu_out) x[j] = r[j] > 0.f ? x[j] : 0.f;
+      }
+      Vec4<TO>::store(out + e0, x);
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t e = e0 + j;
+      if (e < n) {
+        float g = Elem<TI>::to_f32(in[e]) * m[j];
+        if (relu_out) g = Elem<TO>::to_f32(relu_out[e]) > 0.f ? g : 0.f;
+        out[e] = Elem<TO>::from_f32(g);
+      }
+    }
+  }
+}
+
 // column sums, two deterministic stages: grid (col blocks, row blocks) -> partial[rb][N] -> out[N]
 constexpr int COLSUM_ROWS = 512;
 template <typename T>
@@ -524,6 +595,38 @@ extern "C" int asr_dropout_mask(asr_handle* h, float* mask, size_t n, float keep
   if (!n) return ASR_OK;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)s, mask, n, keep_prob, seed, offset);
   ASR_CHECK_LAUNCH(h, "asr_dropout_mask");
+  return ASR_OK;
+}
+extern "C" int asr_dropout_apply(asr_handle* h, int dtype, const void* in, void* out, size_t n, float keep_prob,
+                                 uint64_t seed, uint64_t offset, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(asr_dtype_ok(dtype) && in && out && keep_prob > 0.f && keep_prob <= 1.f, "asr_dropout_apply: bad args");
+  if (!n) return ASR_OK;
+  const dim3 grid(grid_for((n + 3) / 4));
+  const int vec_ok = (((uintptr_t)in | (uintptr_t)out) % 16) == 0;
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL((dropout_apply_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)in,
+                       (const float*)nullptr, (float*)out, n, keep_prob, seed, offset, vec_ok);
+  else
+    hipLaunchKernelGGL((dropout_apply_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)in,
+                       (const bf16_t*)nullptr, (bf16_t*)out, n, keep_prob, seed, offset, vec_ok);
+  ASR_CHECK_LAUNCH(h, "asr_dropout_apply");
+  return ASR_OK;
+}
+extern "C" int asr_relu_bwd_drop(asr_handle* h, int dtype, const float* dout, const void* out, size_t n, float keep_prob,
+                                 uint64_t seed, uint64_t offset, void* dpre, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  ASR_NEED(asr_dtype_ok(dtype) && dout && out && dpre && keep_prob > 0.f && keep_prob <= 1.f, "asr_relu_bwd_drop: bad args");
+  if (!n) return ASR_OK;
+  const dim3 grid(grid_for((n + 3) / 4));
+  const int vec_ok = (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)dpre) % 16) == 0;
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL((dropout_apply_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)s, dout, (const float*)out,
+                       (float*)dpre, n, keep_prob, seed, offset, vec_ok);
+  else
+    hipLaunchKernelGGL((dropout_apply_kernel<float, bf16_t>), grid, dim3(256), 0, (hipStream_t)s, dout,
+                       (const bf16_t*)out, (bf16_t*)dpre, n, keep_prob, seed, offset, vec_ok);
+  ASR_CHECK_LAUNCH(h, "asr_relu_bwd_drop");
   return ASR_OK;
 }
 extern "C" int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N, int lda, float* out, asr_stream s) {

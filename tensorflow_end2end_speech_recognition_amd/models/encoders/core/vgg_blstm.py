@@ -102,9 +102,10 @@ class _VGGFrontEnd(object):
                 return t
             seed, off = rng_state
             self._drop_i += 1
-            m = ops.dropout_mask(t.shape, keep_prob, seed + 7, off + (self._drop_i << 32), t.device)
-            self.ctx['masks'][key] = m
-            return ops.apply_mask(t, m)
+            # no mask tensor: the mask is formed from (seed, offset) where it is applied, forward and backward
+            d = (float(keep_prob), seed + 7, off + (self._drop_i << 32))
+            self.ctx['masks'][key] = d
+            return ops.dropout_apply(t, *d)
         a1 = self._layer(x0, CONVS[0], sh)
         a1d = dropout(a1, 'a1')
         a2 = self._layer(a1d, CONVS[1], sh)
@@ -151,14 +152,24 @@ class _VGGFrontEnd(object):
         return out
 
     # conv backward on the full batch, chunked: dout fp32 [N,H,W,Cout] -> din fp32 [N,H,W,Cin]; fills dW, db
-    def _conv_bwd(self, dout, out, mask, x_in, conv, sh, need_dx=True):
+    def _conv_bwd(self, dout, out, mask, x_in, conv, sh, need_dx=True, pooled=None):
+        """pooled = (argmax, drop or None): dout is the gradient of the POOLED output (before its dropout); un-pooling,
+        that dropout and this convolution's ReLU backward run as one kernel (implicit-GEMM layers)."""
         name, cin, cout = conv
         st = self.store
         N, H, W, _ = out.shape
         gw = st.g(self.prefix + name + '/weight').view(9 * cin, cout)
         gb = st.g(self.prefix + name + '/bias')
+        if pooled is not None and not (self._implicit(cin, cout) and mask is None and cout % 4 == 0):
+            d = dout.contiguous()
+            if pooled[1] is not None:
+                d = ops.dropout_apply(d, *pooled[1])
+            dout, pooled = ops.maxpool2x2_bwd(d, pooled[0], H, W), None
         if self._implicit(cin, cout):
-            dpre = ops.relu_bwd(dout.contiguous(), out, mask)                  # [N,H,W,cout] bf16
+            if pooled is not None:
+                dpre = ops.maxpool2x2_relu_bwd(dout.contiguous(), pooled[0], out, drop=pooled[1])
+            else:
+                dpre = ops.relu_bwd(dout.contiguous(), out, drop=mask)         # [N,H,W,cout] bf16
             ops.conv3x3_bwd_weight(x_in, dpre, gw)
             ops.colsum(dpre.view(N * H * W, cout), out=gb)
             return ops.conv3x3_bwd_data(dpre, self._conv_images(name)[1]) if need_dx else None
@@ -169,8 +180,9 @@ class _VGGFrontEnd(object):
         for ci, c0 in enumerate(range(0, N, CHUNK_FRAMES)):
             sl = slice(c0, c0 + CHUNK_FRAMES)
             n = out[sl].shape[0]
-            dpre = ops.relu_bwd(dout[sl].contiguous(), out[sl].contiguous(),
-                                mask[sl].contiguous() if mask is not None else None).view(n * H * W, cout)
+            # a chunk's elements start at element c0*H*W*cout of the layer's tensor = Philox block offset + that / 4
+            dchunk = None if mask is None else (mask[0], mask[1], mask[2] + (c0 * H * W * cout) // 4)
+            dpre = ops.relu_bwd(dout[sl].contiguous(), out[sl].contiguous(), drop=dchunk).view(n * H * W, cout)
             patches = ops.im2col3x3(x_in[sl].contiguous(), ldp)
             if self.dtype == ASR_BF16 and ldp % 8 == 0 and cout % 8 == 0:
                 # all ldp columns (the padding ones are zero): M = 32 instead of 27 keeps this K = frames*F*W ~ 2 M
@@ -198,22 +210,16 @@ class _VGGFrontEnd(object):
         d = dout_btd.reshape(c['B'] * c['T'], 256).contiguous()
         if c['pack'] is not None:
             d = ops.embedding_gather(d, c['pack'][0])
-        dpre = ops.relu_bwd(d, c['br'], m.get('br'))
+        dpre = ops.relu_bwd(d, c['br'], drop=m.get('br'))
         ops.gemm(c['flat'], dpre, transA=True, out=st.g(self.prefix + 'bridge/weights'))
         ops.colsum(dpre, out=st.g(self.prefix + 'bridge/biases'))
         dflat = ops.gemm(dpre, sh[self.prefix + 'bridge/weights'], transB=True, out_dtype=ASR_F32)
         H2, W2 = (self.F + 1) // 2, (self.W + 1) // 2
         H4, W4 = (H2 + 1) // 2, (W2 + 1) // 2
         dp2 = dflat.view(N, H4, W4, 128)
-        if 'p2' in m:
-            dp2 = ops.apply_mask(dp2.contiguous(), m['p2'])
-        da4 = ops.maxpool2x2_bwd(dp2.contiguous(), c['arg2'], H2, W2)
-        da3d = self._conv_bwd(da4, c['a4'], None, c['a3d'], CONVS[3], sh)
+        da3d = self._conv_bwd(dp2, c['a4'], None, c['a3d'], CONVS[3], sh, pooled=(c['arg2'], m.get('p2')))
         dp1d = self._conv_bwd(da3d, c['a3'], m.get('a3'), c['p1d'], CONVS[2], sh)
-        if 'p1' in m:
-            dp1d = ops.apply_mask(dp1d, m['p1'])
-        da2 = ops.maxpool2x2_bwd(dp1d, c['arg1'], self.F, self.W)
-        da1d = self._conv_bwd(da2, c['a2'], None, c['a1d'], CONVS[1], sh)
+        da1d = self._conv_bwd(dp1d, c['a2'], None, c['a1d'], CONVS[1], sh, pooled=(c['arg1'], m.get('p1')))
         self._conv_bwd(da1d, c['a1'], m.get('a1'), c['x0'], CONVS[0], sh, need_dx=False)
         self.ctx = None
 

@@ -235,6 +235,15 @@ def dropout_mask(shape, keep_prob, seed, offset, device):
     return mask
 
 
+def dropout_apply(x, keep_prob, seed, offset):
+    """x * dropout mask(seed, offset) without a mask tensor (== apply_mask(x, dropout_mask(x.shape, ...)) bit for bit)."""
+    h = _h(x)
+    out = torch.empty_like(x)
+    h.check(h.lib.asr_dropout_apply(h.h, dtype_id(x.dtype), _p(x), _p(out), x.numel(), float(keep_prob), int(seed),
+                                    int(offset), _s()), 'asr_dropout_apply')
+    return out
+
+
 def colsum(a, out=None):
     """sum over rows of a [M,N] (last-dim contiguous 2-D view) -> fp32 [N]."""
     h = _h(a)
@@ -401,11 +410,29 @@ def maxpool2x2_bwd(dout, arg, H, W):
     return din
 
 
-def relu_bwd(dout, out, mask=None):
-    """dout fp32, out in the operand dtype -> dpre (operand dtype) = dout * (out>0) (* mask)."""
+def maxpool2x2_relu_bwd(dout, arg, act, drop=None):
+    """relu_bwd(maxpool2x2_bwd(dropout_apply(dout, *drop)), act) in one pass: dout [N,Ho,Wo,C] fp32 pooled gradient,
+    arg the pool's argmax, act [N,H,W,C] the ReLU output under the pool (operand dtype) -> dpre like act."""
+    h = _h(dout)
+    N, H, W, Cc = act.shape
+    dpre = torch.empty_like(act)
+    k, sd, off = drop if drop is not None else (1.0, 0, 0)
+    h.check(h.lib.asr_maxpool2x2_relu_bwd(h.h, dtype_id(act.dtype), _p(dout), _p(arg), _p(act), N, H, W, Cc, _p(dpre),
+                                          float(k), int(sd), int(off), int(drop is not None), _s()),
+            'asr_maxpool2x2_relu_bwd')
+    return dpre
+
+
+def relu_bwd(dout, out, mask=None, drop=None):
+    """dout fp32, out in the operand dtype -> dpre (operand dtype) = dout * (out>0) (* mask).
+    drop = (keep_prob, seed, offset): the mask of dropout_apply with those arguments, formed in the kernel."""
     h = _h(dout)
     dt = dtype_id(out.dtype)
     dpre = torch.empty_like(out)
+    if drop is not None:
+        h.check(h.lib.asr_relu_bwd_drop(h.h, dt, _p(dout), _p(out), out.numel(), float(drop[0]), int(drop[1]),
+                                        int(drop[2]), _p(dpre), _s()), 'asr_relu_bwd_drop')
+        return dpre
     h.check(h.lib.asr_relu_bwd(h.h, dt, _p(dout), _p(out), _p(mask), out.numel(), _p(dpre), _s()), 'asr_relu_bwd')
     return dpre
 

@@ -68,9 +68,23 @@ def _apply_mask(x, mask, out=None):
     return y
 
 
-def _dropout_mask(shape, keep_prob, seed, offset, device):
-    g = torch.Generator().manual_seed((int(seed) * 1000003 + int(offset)) % (2 ** 63 - 1))
-    return (torch.rand(shape, generator=g) < keep_prob).float() / float(keep_prob)
+def _dropout_mask(shape, keep_prob, seed, offset, device=None):
+    """Counter-based like the device generator (element e of a tensor = word e % 4 of block offset + e / 4), so that a
+    mask formed chunk by chunk with shifted offsets equals the slice of the whole one; the bits are splitmix64's, not
+    Philox's -- the stand-ins only have to be self-consistent."""
+    n = int(np.prod(shape))
+    with np.errstate(over='ignore'):
+        z = np.uint64(int(offset) % (1 << 62)) * np.uint64(4) + np.arange(n, dtype=np.uint64)
+        z = z + np.uint64(int(seed) % (1 << 62)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+    return torch.from_numpy(((u < keep_prob) / float(keep_prob)).astype(np.float32)).view(*shape)
+
+
+def _dropout_apply(x, keep_prob, seed, offset):
+    return _apply_mask(x, _dropout_mask(tuple(x.shape), keep_prob, seed, offset))
 
 
 def _colsum(a, out=None):
@@ -106,8 +120,10 @@ def _gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None,
     return y.float()
 
 
-def _relu_bwd(dout, out, mask=None):
+def _relu_bwd(dout, out, mask=None, drop=None):
     y = dout * (out > 0).to(dout.dtype)
+    if drop is not None:
+        mask = _dropout_mask(tuple(y.shape), *drop)
     if mask is not None:
         y = y * mask.view(y.shape)
     return y
@@ -709,10 +725,17 @@ def _maxpool2x2_bwd(dout, arg, H, W):
     return g[:, :H, :W].contiguous()
 
 
+def _maxpool2x2_relu_bwd(dout, arg, act, drop=None):
+    d = dout if drop is None else _dropout_apply(dout, *drop)
+    N, H, W, _ = act.shape
+    return _relu_bwd(_maxpool2x2_bwd(d, arg, H, W), act).to(act.dtype)
+
+
 STAND_INS = dict(
     side_lane=_NullLane, join_side=lambda device: None, stream_event=lambda: None, set_side_gemm_workgroups=lambda device, n: None, wait_event=lambda ev: None,
     gru_fwd=_gru_fwd, gru_bwd=_gru_bwd, lstm_prep_layer=_lstm_prep_layer, lstm_grad_finish=_lstm_grad_finish, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
     cast_from_f32=_cast_from_f32, cast_to_f32=_cast_to_f32, apply_mask=_apply_mask, dropout_mask=_dropout_mask,
+    dropout_apply=_dropout_apply, maxpool2x2_relu_bwd=_maxpool2x2_relu_bwd,
     colsum=_colsum, gemm=_gemm, relu_bwd=_relu_bwd, lstm_prep_weights=_lstm_prep_weights,
     gate_deinterleave=_gate_deinterleave, lstm_fwd=_lstm_fwd, lstm_bwd=_lstm_bwd, ctc_loss=_ctc_loss,
     ctc_greedy_decode=_ctc_greedy_decode, softmax_rows=_softmax_rows, clip_by_norm_multi=_clip_by_norm_multi,

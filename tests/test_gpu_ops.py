@@ -873,6 +873,41 @@ def test_dropout_mask(cuda):
     assert torch.equal(m, m2) and not torch.equal(m, m3)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('N,H,W,C,drop', [(5, 40, 11, 64, True), (3, 20, 6, 128, False), (2, 5, 3, 8, True)])
+def test_pool_dropout_relu_backward_in_one_pass(cuda, dtype, N, H, W, C, drop):
+    """asr_maxpool2x2_relu_bwd == asr_dropout_apply -> asr_maxpool2x2_bwd -> asr_relu_bwd, bit for bit (the cfg C image
+    sizes 40 x 11 x 64 and 20 x 6 x 128, and a small one with odd edges in both directions)."""
+    ops = _ops()
+    rng = np.random.RandomState(N * H + C)
+    act = torch.tensor(rng.randn(N, H, W, C), dtype=torch.float32, device=cuda).clamp_min(0).to(dtype)
+    pooled, arg = ops.maxpool2x2_fwd(act)
+    dp = torch.tensor(rng.randn(*pooled.shape), dtype=torch.float32, device=cuda)
+    d = (0.8, 5, (3 << 32) + 9) if drop else None
+    ref = ops.relu_bwd(ops.maxpool2x2_bwd(ops.dropout_apply(dp, *d) if drop else dp, arg, H, W), act)
+    got = ops.maxpool2x2_relu_bwd(dp, arg, act, drop=d)
+    assert got.dtype == act.dtype and torch.equal(got, ref)
+    assert float(got.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dropout_formed_in_the_kernel_equals_the_stored_mask(cuda, dtype):
+    """asr_dropout_apply == asr_dropout_mask + asr_apply_mask and asr_relu_bwd_drop == asr_relu_bwd with that mask, bit
+    for bit -- whole tensors and chunks addressed by a shifted Philox block offset (how the VGG front-end's chunked
+    first-layer backward uses it), sizes that are not multiples of 4 included."""
+    ops = _ops()
+    rng = np.random.RandomState(3)
+    for n, seed, off in ((1000 * 257, 7, 0), (4099, 11, (5 << 32) + 17), (64 * 440 * 64, 3, 1 << 50)):
+        x = torch.tensor(rng.randn(n), dtype=torch.float32, device=cuda).to(dtype)
+        m = ops.dropout_mask((n,), 0.8, seed, off, cuda)
+        assert torch.equal(ops.dropout_apply(x, 0.8, seed, off), ops.apply_mask(x, m))
+        dout = torch.tensor(rng.randn(n), dtype=torch.float32, device=cuda)
+        assert torch.equal(ops.relu_bwd(dout, x, drop=(0.8, seed, off)), ops.relu_bwd(dout, x, m))
+        c0 = (n // 3) // 4 * 4                            # a chunk starting at a multiple of 4 elements
+        assert torch.equal(ops.relu_bwd(dout[c0:].contiguous(), x[c0:].contiguous(), drop=(0.8, seed, off + c0 // 4)),
+                           ops.relu_bwd(dout, x, m)[c0:])
+
+
 @pytest.mark.parametrize('T,F,num_stack,num_skip,splice', [
     (37, 2, 1, 1, 11),      # VGG recipe shape: splice only (F*3 = 6 values per frame)
     (41, 3, 3, 3, 1),       # stacking only
