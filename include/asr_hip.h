@@ -178,6 +178,11 @@ int asr_conv3x3_fwd(asr_handle* h, const void* x, int N, int H, int W, int Cin, 
                     const float* bias, int Cout, int relu, void* out, asr_stream s);
 int asr_conv3x3_bwd_data(asr_handle* h, const void* dy, int N, int H, int W, int Cout,
                          const void* wt_bwd, int Cin, float* dx, asr_stream s);
+/* asr_conv3x3_bwd_data followed by asr_relu_bwd(_drop) of the layer below, in the epilogue: dpre_below (bf16
+ * [N,H,W,Cin]) = (act_below > 0) ? dx * dropout mask(seed, offset) : 0 -- the fp32 dx is never written. */
+int asr_conv3x3_bwd_data_relu(asr_handle* h, const void* dy, int N, int H, int W, int Cout, const void* wt_bwd, int Cin,
+                              const void* act_below, float keep_prob, uint64_t seed, uint64_t offset, int use_drop,
+                              void* dpre_below, asr_stream s);
 int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* dy, int N, int H, int W,
                            int Cin, int Cout, float* dw, int accumulate, asr_stream s);
 /* tf.nn.max_pool 2x2 stride 2 SAME (cnn_util.py:13-28): out [N, ceil(H/2), ceil(W/2), C];

@@ -102,6 +102,26 @@ __device__ __forceinline__ float fast_tanhf(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
+// Philox4x32-10 block -> the four dropout multipliers of elements 4 ctr' .. 4 ctr' + 3 (ctr = offset + element / 4);
+// the generator of asr_dropout_mask (elementwise.hip), for the kernels that form the mask in their epilogue.
+__device__ __forceinline__ void asr_dropout_words(uint64_t ctr, uint64_t seed, float keep, float inv, float m[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m[j] = ((c[j] >> 8) * (1.0f / 16777216.0f) < keep) ? inv : 0.f;
+}
+
 // top ASR_XCH_BYTES of the scratch: granule exchange + error word of the multi-CU LSTM kernels
 static constexpr size_t ASR_XCH_BYTES = (size_t)16 << 20;
 bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* xproj,

@@ -655,6 +655,13 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int M, int N, int K, 
   }
 }
 
+struct ConvGate {               // epilogue operands of conv3x3_nt_bf16_kernel's act == 2
+  const bf16_t* act;            // ReLU output of the layer below, [pixels, Cout of this product]
+  float keep;
+  uint64_t seed, offset;        // dropout applied to that output (element e -> Philox block offset + e / 4)
+  int use_drop;
+};
+
 // ---------------------------------------------------------------- implicit-GEMM 3x3 convolution (bf16)
 // out[p, co] = act(sum_{tap, ci} x[p + s_tap, ci] * Wt[co][tap*Cin + ci] + bias[co]),  SAME padding,
 // x NHWC [Nimg, H, W, Cin], p = flat pixel index, s_tap = (tap/3 - 1, tap%3 - 1).
@@ -668,7 +675,10 @@ __global__ __launch_bounds__(256) void conv3x3_nt_bf16_kernel(int Mpix, int H, i
                                                               const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ Wt,
                                                               TO* __restrict__ Out, const float* __restrict__ bias,
-                                                              int act) {
+                                                              int act, ConvGate gate) {
+  // act == 2 (data gradient): the ReLU backward of the layer BELOW in the epilogue -- Out (operand dtype) =
+  // (gate.act[p, c] > 0) ? value * dropout mask(element) : 0, instead of an fp32 gradient that asr_relu_bwd(_drop)
+  // would read back
   constexpr int BM = 128, BK = 64, LD = BK + 8;
   constexpr int STAGE = (BM + BN) * LD;
   constexpr int WN = BN / 2, TN = WN / 16;
@@ -779,6 +789,15 @@ __global__ __launch_bounds__(256) void conv3x3_nt_bf16_kernel(int Mpix, int H, i
       if (act == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (act == 2) {
+        typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+        const size_t e = (size_t)m * Cout + nb;
+        const us4_t g = *reinterpret_cast<const us4_t*>(gate.act + e);
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (gate.use_drop) asr_dropout_words(gate.offset + e / 4, gate.seed, gate.keep, 1.f / gate.keep, mk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bf16_to_f32(g[r]) > 0.f ? v[r] * mk[r] : 0.f;
       }
       if constexpr (sizeof(TO) == 4) {
         *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
@@ -1147,7 +1166,8 @@ extern "C" int asr_conv3x3_prep_weights(asr_handle* h, const float* w_hwio, int 
 
 template <typename TO>
 static int conv3x3_launch(asr_handle* h, const void* x, int Nimg, int H, int W, int Cin, const void* wt,
-                          const float* bias, int Cout, int act, void* out, hipStream_t st) {
+                          const float* bias, int Cout, int act, void* out, hipStream_t st,
+                          ConvGate gate = ConvGate{nullptr, 1.f, 0, 0, 0}) {
   const long long mp = (long long)Nimg * H * W;
   if (mp <= 0 || mp >= (1ll << 31)) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3: %lld pixels", mp);
   const int Mpix = (int)mp;
@@ -1157,12 +1177,12 @@ static int conv3x3_launch(asr_handle* h, const void* x, int Nimg, int H, int W, 
     auto k = conv3x3_nt_bf16_kernel<TO, 128>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)tm * (Cout / 128)), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
-                       (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, bias, act);
+                       (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, bias, act, gate);
   } else {
     const size_t lds = (size_t)2 * (128 + 64) * 72 * sizeof(bf16_t);
     auto k = conv3x3_nt_bf16_kernel<TO, 64>;
     hipLaunchKernelGGL(k, dim3((unsigned)tm * (Cout / 64)), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
-                       (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, bias, act);
+                       (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, bias, act, gate);
   }
   ASR_CHECK_LAUNCH(h, "asr_conv3x3");
   return ASR_OK;
@@ -1187,6 +1207,19 @@ extern "C" int asr_conv3x3_bwd_data(asr_handle* h, const void* dy, int Nimg, int
     ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_bwd_data: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);
   // the data gradient is a convolution of dOut (Cout channels) with the flipped-tap image -> Cin channels
   return conv3x3_launch<float>(h, dy, Nimg, H, W, Cout, wt_bwd, nullptr, Cin, 0, dx, (hipStream_t)s);
+}
+
+extern "C" int asr_conv3x3_bwd_data_relu(asr_handle* h, const void* dy, int Nimg, int H, int W, int Cout,
+                                         const void* wt_bwd, int Cin, const void* act_below, float keep_prob,
+                                         uint64_t seed, uint64_t offset, int use_drop, void* dpre_below, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!dy || !wt_bwd || !act_below || !dpre_below || Nimg < 1 || H < 1 || W < 1 ||
+      (use_drop && !(keep_prob > 0.f && keep_prob <= 1.f)))
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_bwd_data_relu: bad args");
+  if (Cin % 64 != 0 || Cout % 64 != 0)
+    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_bwd_data_relu: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);
+  const ConvGate gate = {(const bf16_t*)act_below, keep_prob, seed, offset, use_drop};
+  return conv3x3_launch<bf16_t>(h, dy, Nimg, H, W, Cout, wt_bwd, nullptr, Cin, 2, dpre_below, (hipStream_t)s, gate);
 }
 
 extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* dy, int Nimg, int H, int W,

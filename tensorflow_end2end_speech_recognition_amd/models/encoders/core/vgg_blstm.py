@@ -152,9 +152,12 @@ class _VGGFrontEnd(object):
         return out
 
     # conv backward on the full batch, chunked: dout fp32 [N,H,W,Cout] -> din fp32 [N,H,W,Cin]; fills dW, db
-    def _conv_bwd(self, dout, out, mask, x_in, conv, sh, need_dx=True, pooled=None):
+    def _conv_bwd(self, dout, out, mask, x_in, conv, sh, need_dx=True, pooled=None, below=None, dout_is_dpre=False):
         """pooled = (argmax, drop or None): dout is the gradient of the POOLED output (before its dropout); un-pooling,
-        that dropout and this convolution's ReLU backward run as one kernel (implicit-GEMM layers)."""
+        that dropout and this convolution's ReLU backward run as one kernel (implicit-GEMM layers).
+        below = (act, drop or None) of the layer below (implicit-GEMM layers): the data gradient comes back as that
+        layer's pre-activation gradient in the operand dtype (its ReLU / dropout backward in the convolution's
+        epilogue) and is passed to its _conv_bwd with dout_is_dpre=True."""
         name, cin, cout = conv
         st = self.store
         N, H, W, _ = out.shape
@@ -166,13 +169,19 @@ class _VGGFrontEnd(object):
                 d = ops.dropout_apply(d, *pooled[1])
             dout, pooled = ops.maxpool2x2_bwd(d, pooled[0], H, W), None
         if self._implicit(cin, cout):
-            if pooled is not None:
+            if dout_is_dpre:
+                dpre = dout
+            elif pooled is not None:
                 dpre = ops.maxpool2x2_relu_bwd(dout.contiguous(), pooled[0], out, drop=pooled[1])
             else:
                 dpre = ops.relu_bwd(dout.contiguous(), out, drop=mask)         # [N,H,W,cout] bf16
             ops.conv3x3_bwd_weight(x_in, dpre, gw)
             ops.colsum(dpre.view(N * H * W, cout), out=gb)
-            return ops.conv3x3_bwd_data(dpre, self._conv_images(name)[1]) if need_dx else None
+            if not need_dx:
+                return None
+            if below is not None:
+                return ops.conv3x3_bwd_data_relu(dpre, self._conv_images(name)[1], below[0], drop=below[1])
+            return ops.conv3x3_bwd_data(dpre, self._conv_images(name)[1])
         w2d = sh[self.prefix + name + '/weight'].view(9 * cin, cout)
         ldp = (9 * cin + 7) // 8 * 8
         din = torch.empty((N, H, W, cin), dtype=torch.float32, device=dout.device) if need_dx else None
@@ -181,8 +190,11 @@ class _VGGFrontEnd(object):
             sl = slice(c0, c0 + CHUNK_FRAMES)
             n = out[sl].shape[0]
             # a chunk's elements start at element c0*H*W*cout of the layer's tensor = Philox block offset + that / 4
-            dchunk = None if mask is None else (mask[0], mask[1], mask[2] + (c0 * H * W * cout) // 4)
-            dpre = ops.relu_bwd(dout[sl].contiguous(), out[sl].contiguous(), drop=dchunk).view(n * H * W, cout)
+            if dout_is_dpre:
+                dpre = dout[sl].contiguous().view(n * H * W, cout)
+            else:
+                dchunk = None if mask is None else (mask[0], mask[1], mask[2] + (c0 * H * W * cout) // 4)
+                dpre = ops.relu_bwd(dout[sl].contiguous(), out[sl].contiguous(), drop=dchunk).view(n * H * W, cout)
             patches = ops.im2col3x3(x_in[sl].contiguous(), ldp)
             if self.dtype == ASR_BF16 and ldp % 8 == 0 and cout % 8 == 0:
                 # all ldp columns (the padding ones are zero): M = 32 instead of 27 keeps this K = frames*F*W ~ 2 M
@@ -217,10 +229,16 @@ class _VGGFrontEnd(object):
         H2, W2 = (self.F + 1) // 2, (self.W + 1) // 2
         H4, W4 = (H2 + 1) // 2, (W2 + 1) // 2
         dp2 = dflat.view(N, H4, W4, 128)
-        da3d = self._conv_bwd(dp2, c['a4'], None, c['a3d'], CONVS[3], sh, pooled=(c['arg2'], m.get('p2')))
-        dp1d = self._conv_bwd(da3d, c['a3'], m.get('a3'), c['p1d'], CONVS[2], sh)
-        da1d = self._conv_bwd(dp1d, c['a2'], None, c['a1d'], CONVS[1], sh, pooled=(c['arg1'], m.get('p1')))
-        self._conv_bwd(da1d, c['a1'], m.get('a1'), c['x0'], CONVS[0], sh, need_dx=False)
+        # where both neighbours are implicit-GEMM layers the ReLU / dropout backward of the lower one sits in the data
+        # gradient's epilogue (no fp32 activation gradient is written): conv4 -> a3, conv2 -> a1
+        fuse43 = self._implicit(*CONVS[3][1:]) and self._implicit(*CONVS[2][1:])
+        fuse21 = self._implicit(*CONVS[1][1:]) and self.dtype == ASR_BF16
+        da3d = self._conv_bwd(dp2, c['a4'], None, c['a3d'], CONVS[3], sh, pooled=(c['arg2'], m.get('p2')),
+                              below=(c['a3'], m.get('a3')) if fuse43 else None)
+        dp1d = self._conv_bwd(da3d, c['a3'], m.get('a3'), c['p1d'], CONVS[2], sh, dout_is_dpre=fuse43)
+        da1d = self._conv_bwd(dp1d, c['a2'], None, c['a1d'], CONVS[1], sh, pooled=(c['arg1'], m.get('p1')),
+                              below=(c['a1'], m.get('a1')) if fuse21 else None)
+        self._conv_bwd(da1d, c['a1'], m.get('a1'), c['x0'], CONVS[0], sh, need_dx=False, dout_is_dpre=fuse21)
         self.ctx = None
 
 

@@ -333,6 +333,21 @@ def conv3x3_bwd_data(dy_nhwc, wt_bwd):
     return dx
 
 
+def conv3x3_bwd_data_relu(dy_nhwc, wt_bwd, act_below, drop=None):
+    """relu_bwd(conv3x3_bwd_data(dy, wt_bwd), act_below, drop=drop) without the fp32 gradient in between -> bf16."""
+    h = _h(dy_nhwc)
+    _chk(dy_nhwc, torch.bfloat16, 'dy')
+    _chk(act_below, torch.bfloat16, 'act_below')
+    N, H, W, Cout = dy_nhwc.shape
+    Cin = wt_bwd.shape[0]
+    dpre = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=dy_nhwc.device)
+    k, sd, off = drop if drop is not None else (1.0, 0, 0)
+    h.check(h.lib.asr_conv3x3_bwd_data_relu(h.h, _p(dy_nhwc), N, H, W, Cout, _p(wt_bwd), Cin, _p(act_below), float(k),
+                                            int(sd), int(off), int(drop is not None), _p(dpre), _s()),
+            'asr_conv3x3_bwd_data_relu')
+    return dpre
+
+
 def conv3x3_bwd_weight(x_nhwc, dy_nhwc, dw, accumulate=False):
     """dw: fp32 [9*Cin, Cout] view of the HWIO gradient."""
     h = _h(x_nhwc)

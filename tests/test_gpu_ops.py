@@ -873,6 +873,21 @@ def test_dropout_mask(cuda):
     assert torch.equal(m, m2) and not torch.equal(m, m3)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,drop', [(3, 40, 11, 64, 64, True), (2, 20, 6, 64, 128, False), (2, 20, 6, 128, 128, True)])
+def test_conv_data_gradient_with_the_relu_backward_below_in_its_epilogue(cuda, N, H, W, Cin, Cout, drop):
+    """asr_conv3x3_bwd_data_relu == asr_relu_bwd(_drop)(asr_conv3x3_bwd_data(...), act_below), bit for bit."""
+    ops = _ops()
+    rng = np.random.RandomState(H + Cin + Cout)
+    w = torch.tensor(rng.randn(3, 3, Cin, Cout) * 0.05, dtype=torch.float32, device=cuda)
+    _, wb = ops.conv3x3_prep_weights(w)
+    dy = torch.tensor(rng.randn(N, H, W, Cout), dtype=torch.float32, device=cuda).to(torch.bfloat16)
+    act = torch.tensor(rng.randn(N, H, W, Cin), dtype=torch.float32, device=cuda).clamp_min(0).to(torch.bfloat16)
+    d = (0.8, 9, (2 << 32) + 5) if drop else None
+    ref = ops.relu_bwd(ops.conv3x3_bwd_data(dy, wb), act, drop=d)
+    got = ops.conv3x3_bwd_data_relu(dy, wb, act, drop=d)
+    assert torch.equal(got, ref) and float(got.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('N,H,W,C,drop', [(5, 40, 11, 64, True), (3, 20, 6, 128, False), (2, 5, 3, 8, True)])
 def test_pool_dropout_relu_backward_in_one_pass(cuda, dtype, N, H, W, C, drop):
