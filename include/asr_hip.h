@@ -192,6 +192,13 @@ int asr_maxpool2x2_fwd(asr_handle* h, int dtype, const void* in, int N, int H, i
 int asr_maxpool2x2_bwd(asr_handle* h, const float* dout, const uint8_t* argmax, int N, int H, int W,
                        int C, float* din, asr_stream s);
 /* dpre = dout * (out > 0) (* mask if given), written in `dtype` (ReLU + dropout backward) */
+/* 3x3 SAME convolution with few input channels (9 Cin <= 32, Cout == 64: the first VGG layer, vgg_blstm.py:113-121),
+ * direct -- no patch matrix: out (bf16 [N,H,W,64]) = act(conv(x bf16 [N,H,W,Cin], w2d bf16 [9 Cin, 64]) + bias), and
+ * its weight gradient dw fp32 [9 Cin, 64] = patches(x)^T dpre (dpre bf16 [N,H,W,64]; deterministic two-stage sum). */
+int asr_conv3x3_smallc_fwd(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* w2d,
+                           const float* bias, int Cout, int relu, void* out, asr_stream s);
+int asr_conv3x3_smallc_bwd_weight(asr_handle* h, const void* x, const void* dpre, int N, int H, int W, int Cin,
+                                  int Cout, float* dw, asr_stream s);
 /* asr_dropout_apply (on the pooled gradient, when use_drop) -> asr_maxpool2x2_bwd -> asr_relu_bwd of the convolution
  * under the pool, as one pass without the full-resolution fp32 gradient in between: dpre[n,h,w,c] (operand dtype) =
  * (act[n,h,w,c] > 0 && argmax[o] == 2 (h & 1) + (w & 1)) ? dout[o] * mask(o) : 0, o = pooled cell (n, h/2, w/2, c).

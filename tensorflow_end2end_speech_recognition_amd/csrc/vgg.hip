@@ -139,6 +139,117 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dout, const uint8_t
   }
 }
 
+// ---- 3x3 SAME convolution with FEW input channels (9 Cin <= 32: the first VGG layer, Cin = 3), direct.
+// Through im2col + GEMM the K = 27 layer writes and re-reads a [pixels x 32] patch matrix (1.6 GB at cfg C, twice:
+// forward and weight gradient) to feed 27 multiply-adds per output; the layer is bound by writing its OUTPUT, so the
+// patch is gathered in registers instead.  bf16 operands, fp32 accumulation (as the MFMA path).
+//   forward: 4 threads per pixel, 16 output channels each; weights [9 Cin][64] as fp32 in LDS (broadcast reads).
+constexpr int SC_K = 32, SC_CO = 64;
+__device__ __forceinline__ float sc_tap(const bf16_t* __restrict__ x, size_t n, int h, int w, int H, int W, int Cin, int k) {
+  const int tap = k / Cin, ci = k - tap * Cin;
+  const int hs = h + tap / 3 - 1, ws = w + tap % 3 - 1;
+  return (hs >= 0 && hs < H && ws >= 0 && ws < W) ? bf16_to_f32(x[((n * H + hs) * W + ws) * Cin + ci]) : 0.f;
+}
+__global__ __launch_bounds__(256) void conv3x3_smallc_fwd_kernel(const bf16_t* __restrict__ x, size_t Npix, int H, int W,
+                                                                 int Cin, const bf16_t* __restrict__ w2d,
+                                                                 const float* __restrict__ bias, int relu,
+                                                                 bf16_t* __restrict__ out) {
+  __shared__ float ws[SC_K][SC_CO];
+  const int K = 9 * Cin;
+  for (int i = threadIdx.x; i < SC_K * SC_CO; i += 256) ws[i / SC_CO][i % SC_CO] = (i / SC_CO < K) ? bf16_to_f32(w2d[i]) : 0.f;
+  __syncthreads();
+  const size_t p = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (p >= Npix) return;
+  const int cg = (threadIdx.x & 3) * 16;
+  const int w = p % W, h = (p / W) % H;
+  const size_t n = p / ((size_t)W * H);
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[cg + j] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float xv = sc_tap(x, n, h, w, H, W, Cin, k);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(&ws[k][cg + q * 4]);
+      acc[q * 4 + 0] += xv * wv[0]; acc[q * 4 + 1] += xv * wv[1]; acc[q * 4 + 2] += xv * wv[2]; acc[q * 4 + 3] += xv * wv[3];
+    }
+  }
+  typedef __attribute__((ext_vector_type(8))) unsigned short us8_t;
+  bf16_t* o = out + p * SC_CO + cg;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    us8_t y;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = relu ? fmaxf(acc[q * 8 + j], 0.f) : acc[q * 8 + j];
+      y[j] = f32_to_bf16(v);
+    }
+    *reinterpret_cast<us8_t*>(o + q * 8) = y;
+  }
+}
+//   weight gradient dW[k][co] = sum_p patch[p][k] dpre[p][co]: a workgroup walks its slice of the pixels in tiles of
+//   64, stages the tile's dpre rows and gathered patches in LDS and keeps its [32][64] sums in registers (thread: one
+//   output channel x 8 consecutive k); the per-workgroup sums are added in a fixed order by a second kernel.
+__global__ __launch_bounds__(256) void conv3x3_smallc_wgrad_kernel(const bf16_t* __restrict__ x,
+                                                                   const bf16_t* __restrict__ dpre, size_t Npix, int H,
+                                                                   int W, int Cin, size_t per_blk,
+                                                                   float* __restrict__ partial) {
+  __shared__ float dp[64][SC_CO + 1];
+  __shared__ float pt[64][SC_K + 4];
+  const int K = 9 * Cin;
+  const int co = threadIdx.x & 63, kg = (threadIdx.x >> 6) * 8;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const size_t p_beg = (size_t)blockIdx.x * per_blk, p_end = min(Npix, p_beg + per_blk);
+  for (size_t p0 = p_beg; p0 < p_end; p0 += 64) {
+    // stage: dpre rows (16 elements per thread), patches (8 per thread)
+    {
+      const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
+      const size_t p = p0 + r;
+      typedef __attribute__((ext_vector_type(8))) unsigned short us8_t;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        us8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p < p_end) v = *reinterpret_cast<const us8_t*>(dpre + p * SC_CO + c0 + q * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dp[r][c0 + q * 8 + j] = bf16_to_f32(v[j]);
+      }
+      const int k0 = (threadIdx.x & 3) * 8;
+      const int w = p % W, h = (p / W) % H;
+      const size_t n = p / ((size_t)W * H);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pt[r][k0 + j] = (p < p_end && k0 + j < K) ? sc_tap(x, n, h, w, H, W, Cin, k0 + j) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) {
+      const float d = dp[r][co];
+      const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(&pt[r][kg]), a1 = *reinterpret_cast<const f32x4_t*>(&pt[r][kg + 4]);
+      acc[0] += a0[0] * d; acc[1] += a0[1] * d; acc[2] += a0[2] * d; acc[3] += a0[3] * d;
+      acc[4] += a1[0] * d; acc[5] += a1[1] * d; acc[6] += a1[2] * d; acc[7] += a1[3] * d;
+    }
+    __syncthreads();
+  }
+  float* o = partial + (size_t)blockIdx.x * SC_K * SC_CO;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[(kg + i) * SC_CO + co] = acc[i];
+}
+__global__ void conv3x3_smallc_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int K,
+                                                   float* __restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * SC_CO) return;
+  float s = 0.f;
+  for (int b0 = 0; b0 < nblk; b0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = (b0 + q < nblk) ? partial[(size_t)(b0 + q) * SC_K * SC_CO + i] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += v[q];
+  }
+  dw[i] = s;
+}
+
 // Pooling backward, dropout on the pooled gradient and the ReLU backward of the convolution below the pool in ONE pass,
 // written in the operand dtype:  dpre[n,h,w,c] = (act > 0 && arg[o] == k) ? dout[o] * mask(o) : 0,  o = the pooled cell.
 // Separately (asr_dropout_apply -> asr_maxpool2x2_bwd -> asr_relu_bwd) the full-resolution fp32 gradient is written and
@@ -270,6 +381,41 @@ extern "C" int asr_maxpool2x2_bwd(asr_handle* h, const float* dout, const uint8_
   if (!total) return ASR_OK;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gridv(total)), dim3(256), 0, (hipStream_t)s, dout, argmax, N, H, W, C, din);
   ASR_CHECK_LAUNCH(h, "asr_maxpool2x2_bwd");
+  return ASR_OK;
+}
+extern "C" int asr_conv3x3_smallc_fwd(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* w2d,
+                                     const float* bias, int Cout, int relu, void* out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(x && w2d && out && N >= 0 && H > 0 && W > 0 && Cin > 0 && 9 * Cin <= SC_K && Cout == SC_CO &&
+               ((uintptr_t)out) % 16 == 0, "asr_conv3x3_smallc_fwd: needs 9 Cin <= 32, Cout == 64");
+  const size_t npix = (size_t)N * H * W;
+  if (!npix) return ASR_OK;
+  hipLaunchKernelGGL(conv3x3_smallc_fwd_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, (hipStream_t)s,
+                     (const bf16_t*)x, npix, H, W, Cin, (const bf16_t*)w2d, bias, relu, (bf16_t*)out);
+  ASR_CHECK_LAUNCH(h, "asr_conv3x3_smallc_fwd");
+  return ASR_OK;
+}
+extern "C" int asr_conv3x3_smallc_bwd_weight(asr_handle* h, const void* x, const void* dpre, int N, int H, int W, int Cin,
+                                            int Cout, float* dw, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(x && dpre && dw && N >= 0 && H > 0 && W > 0 && Cin > 0 && 9 * Cin <= SC_K && Cout == SC_CO &&
+               ((uintptr_t)dpre) % 16 == 0, "asr_conv3x3_smallc_bwd_weight: needs 9 Cin <= 32, Cout == 64");
+  const size_t npix = (size_t)N * H * W;
+  int nblk = (int)((npix + 2047) / 2048);
+  if (nblk > 2048) nblk = 2048;
+  if (nblk < 1) nblk = 1;
+  size_t per = (npix + nblk - 1) / nblk;
+  per = (per + 63) / 64 * 64;
+  nblk = (int)((npix + per - 1) / per);
+  if (nblk < 1) nblk = 1;
+  const size_t need = (size_t)nblk * SC_K * SC_CO * sizeof(float);
+  if (need > h->scratch_bytes - ASR_XCH_BYTES) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_conv3x3_smallc_bwd_weight: scratch too small");
+  float* partial = (float*)h->scratch;
+  hipLaunchKernelGGL(conv3x3_smallc_wgrad_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x,
+                     (const bf16_t*)dpre, npix, H, W, Cin, per, partial);
+  hipLaunchKernelGGL(conv3x3_smallc_wgrad_reduce_kernel, dim3((9 * Cin * SC_CO + 255) / 256), dim3(256), 0,
+                     (hipStream_t)s, partial, nblk, 9 * Cin, dw);
+  ASR_CHECK_LAUNCH(h, "asr_conv3x3_smallc_bwd_weight");
   return ASR_OK;
 }
 extern "C" int asr_maxpool2x2_relu_bwd(asr_handle* h, int dtype, const float* dout, const uint8_t* argmax,

@@ -140,10 +140,18 @@ class _VGGFrontEnd(object):
             cache[name] = ops.conv3x3_prep_weights(self.store[self.prefix + name + '/weight'])
         return cache[name]
 
+    def _direct(self, cin, cout):
+        """The few-channel first layer (K = 27) without a patch matrix (asr_conv3x3_smallc_*)."""
+        import os
+        return self.dtype == ASR_BF16 and 9 * cin <= 32 and cout == 64 and os.environ.get('ASR_VGG_IMPLICIT', '1') != '0'
+
     def _layer(self, x, conv, sh):
         name, cin, cout = conv
         if self._implicit(cin, cout):
             return ops.conv3x3_fwd(x, self._conv_images(name)[0], self.store[self.prefix + name + '/bias'], relu=True)
+        if self._direct(cin, cout):
+            return ops.conv3x3_smallc_fwd(x, sh[self.prefix + name + '/weight'].view(9 * cin, cout),
+                                          self.store[self.prefix + name + '/bias'], relu=True)
         N, H, W, _ = x.shape
         out = torch.empty((N, H, W, cout), dtype=x.dtype, device=x.device)
         for c0 in range(0, N, CHUNK_FRAMES):
@@ -182,6 +190,11 @@ class _VGGFrontEnd(object):
             if below is not None:
                 return ops.conv3x3_bwd_data_relu(dpre, self._conv_images(name)[1], below[0], drop=below[1])
             return ops.conv3x3_bwd_data(dpre, self._conv_images(name)[1])
+        if self._direct(cin, cout) and not need_dx:
+            dpre = dout if dout_is_dpre else ops.relu_bwd(dout.contiguous(), out, drop=mask)
+            ops.conv3x3_smallc_bwd_weight(x_in, dpre, gw)
+            ops.colsum(dpre.view(N * H * W, cout), out=gb)
+            return None
         w2d = sh[self.prefix + name + '/weight'].view(9 * cin, cout)
         ldp = (9 * cin + 7) // 8 * 8
         din = torch.empty((N, H, W, cin), dtype=torch.float32, device=dout.device) if need_dx else None

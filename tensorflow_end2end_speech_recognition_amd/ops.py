@@ -333,6 +333,29 @@ def conv3x3_bwd_data(dy_nhwc, wt_bwd):
     return dx
 
 
+def conv3x3_smallc_fwd(x_nhwc, w2d, bias, relu=True):
+    """Direct 3x3 SAME convolution for 9*Cin <= 32, Cout == 64 (bf16): x [N,H,W,Cin], w2d [9*Cin, 64] bf16 -> [N,H,W,64]."""
+    h = _h(x_nhwc)
+    _chk(x_nhwc, torch.bfloat16, 'x')
+    _chk(w2d, torch.bfloat16, 'w2d')
+    N, H, W, Cin = x_nhwc.shape
+    out = torch.empty((N, H, W, w2d.shape[1]), dtype=torch.bfloat16, device=x_nhwc.device)
+    h.check(h.lib.asr_conv3x3_smallc_fwd(h.h, _p(x_nhwc), N, H, W, Cin, _p(w2d), _p(bias), w2d.shape[1], int(relu),
+                                         _p(out), _s()), 'asr_conv3x3_smallc_fwd')
+    return out
+
+
+def conv3x3_smallc_bwd_weight(x_nhwc, dpre_nhwc, dw):
+    """dw fp32 [9*Cin, 64] = patches(x)^T dpre (both bf16), no patch matrix."""
+    h = _h(x_nhwc)
+    _chk(x_nhwc, torch.bfloat16, 'x')
+    _chk(dpre_nhwc, torch.bfloat16, 'dpre')
+    N, H, W, Cin = x_nhwc.shape
+    h.check(h.lib.asr_conv3x3_smallc_bwd_weight(h.h, _p(x_nhwc), _p(dpre_nhwc), N, H, W, Cin, dpre_nhwc.shape[-1],
+                                                _p(dw), _s()), 'asr_conv3x3_smallc_bwd_weight')
+    return dw
+
+
 def conv3x3_bwd_data_relu(dy_nhwc, wt_bwd, act_below, drop=None):
     """relu_bwd(conv3x3_bwd_data(dy, wt_bwd), act_below, drop=drop) without the fp32 gradient in between -> bf16."""
     h = _h(dy_nhwc)

@@ -301,12 +301,15 @@ def test_vgg_blstm_bf16_parity_at_the_cfgC_image_size(cuda):
         report.append('%-44s rel-to-max %.2e' % (name, e))
         worst = max(worst, e)
     print('\n' + '\n'.join(report))
-    # measured on MI355X: loss rel 6e-5, logits 1.9e-2 abs (|logit| <= 3.4), gradients 0.7e-2 .. 1.5e-2 of their max:
-    # a stored bf16 activation whose fp32-accumulated value lies near a rounding boundary lands one bf16 step (2^-8)
-    # away from the fp64-accumulated oracle's, the same bound as the cfg-B test below
+    # measured on MI355X: loss rel 2e-5 .. 6e-5, logits 1.9e-2 .. 2.1e-2 abs (|logit| <= 3.4), gradients 0.7e-2 .. 2.6e-2
+    # of their max over the three summation orders the first layer has had (im2col GEMM, lean TN GEMM, direct -- whose
+    # outputs agree with each other on 99.998 % of the elements and are all within one bf16 step of the fp64 value,
+    # scripts/check_smallc.py): a stored bf16 activation whose fp32-accumulated value lies near a rounding boundary lands
+    # one bf16 step (2^-8) away from the fp64-accumulated oracle's, and WHICH ones do moves the worst gradient entry
+    # between 1.5e-2 and 2.6e-2
     assert rel < 2e-3, report[0]
-    assert elog.max() < 2e-2 * max(1.0, np.abs(ref['logits']).max()), report[0]
-    assert worst < 2e-2, '\n'.join(report)
+    assert elog.max() < 3e-2 * max(1.0, np.abs(ref['logits']).max()), report[0]
+    assert worst < 3e-2, '\n'.join(report)
 
 
 @pytest.mark.parametrize('enc,B,T,D,H,L,C', [('bgru', 16, 37, 24, 64, 2, 12), ('gru', 5, 21, 12, 32, 2, 9),

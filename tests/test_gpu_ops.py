@@ -873,6 +873,31 @@ def test_dropout_mask(cuda):
     assert torch.equal(m, m2) and not torch.equal(m, m3)
 
 
+@pytest.mark.parametrize('N,H,W,Cin', [(3, 40, 11, 3), (70, 5, 3, 3), (2, 7, 6, 2), (1, 1, 1, 3)])
+def test_direct_convolution_of_the_few_channel_first_layer(cuda, N, H, W, Cin):
+    """asr_conv3x3_smallc_fwd / _bwd_weight (no patch matrix) against fp64 conv2d on the bf16-rounded operands: the
+    cfg C image 40 x 11 x 3, odd sizes, more pixels than one weight-gradient slice, a single pixel."""
+    ops = _ops()
+    rng = np.random.RandomState(N + H * W)
+    Cout = 64
+    x = torch.tensor(rng.randn(N, H, W, Cin), dtype=torch.float32).to(torch.bfloat16)
+    w = torch.tensor(rng.randn(3, 3, Cin, Cout) * 0.2, dtype=torch.float32).to(torch.bfloat16)
+    b = torch.tensor(rng.randn(Cout) * 0.1, dtype=torch.float32)
+    dpre = torch.tensor(rng.randn(N, H, W, Cout), dtype=torch.float32).to(torch.bfloat16)
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = w.double().permute(3, 2, 0, 1).clone().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, b.double(), padding=1)
+    (y64 * dpre.double().permute(0, 3, 1, 2)).sum().backward()
+    ref = torch.relu(y64).permute(0, 2, 3, 1)
+    got = ops.conv3x3_smallc_fwd(x.to(cuda), w.to(cuda).view(9 * Cin, Cout), b.to(cuda), relu=True)
+    assert got.dtype == torch.bfloat16
+    assert np.abs(got.float().cpu().numpy() - ref.detach().numpy()).max() < 1e-2 * max(1.0, float(ref.abs().max()))
+    dw = torch.empty(9 * Cin, Cout, device=cuda)
+    ops.conv3x3_smallc_bwd_weight(x.to(cuda), dpre.to(cuda), dw)
+    ref_dw = w64.grad.permute(2, 3, 1, 0).reshape(9 * Cin, Cout).numpy()
+    assert np.abs(dw.cpu().numpy() - ref_dw).max() < 2e-5 * max(1.0, np.abs(ref_dw).max())
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,drop', [(3, 40, 11, 64, 64, True), (2, 20, 6, 64, 128, False), (2, 20, 6, 128, 128, True)])
 def test_conv_data_gradient_with_the_relu_backward_below_in_its_epilogue(cuda, N, H, W, Cin, Cout, drop):
     """asr_conv3x3_bwd_data_relu == asr_relu_bwd(_drop)(asr_conv3x3_bwd_data(...), act_below), bit for bit."""
