@@ -314,7 +314,7 @@ def test_attention_model_parity_carried_alpha_and_long_inputs(cuda, att, sig, B,
 
 
 @pytest.mark.parametrize('case', ['location_zeros_bf16', 'bahdanau_sigmoid_f32', 'location_carry_bf16', 'hybrid_carry_f32',
-                                  'luong_dot_small'])
+                                  'luong_dot_small', 'bahdanau_sigmoid_f32/one_step', 'location_carry_bf16/one_step'])
 def test_native_decoder_loop_against_the_step_by_step_statement(cuda, case):
     """asr_att_decoder_fwd / _bwd (all To steps from one call, with the fused kernels the loop uses: dctx add inside the
     4-frame d-alpha kernel, softmax backward folded into the energy backward through partial alpha.dalpha sums, dropout
@@ -325,19 +325,21 @@ def test_native_decoder_loop_against_the_step_by_step_statement(cuda, case):
     case (A = U = 2H = 64, dot-product scoring without a query FC) takes the general fallbacks instead."""
     import _cpu_ops as cpu
     from tensorflow_end2end_speech_recognition_amd import ops
+    one_step = case.endswith('/one_step')                    # a single decoder step: no "next step" operands anywhere
+    case = case.split('/')[0]
     cfg = dict(location_zeros_bf16=dict(keys=False, carry=0, sig=False, bf16=True, A=128, E2=512, mode=0, hasq=1, taps=0),
                bahdanau_sigmoid_f32=dict(keys=True, carry=0, sig=True, bf16=False, A=128, E2=256, mode=0, hasq=1, taps=0),
                location_carry_bf16=dict(keys=False, carry=1, sig=False, bf16=True, A=128, E2=512, mode=0, hasq=1, taps=201),
                hybrid_carry_f32=dict(keys=True, carry=1, sig=True, bf16=False, A=32, E2=256, mode=0, hasq=1, taps=200),
                luong_dot_small=dict(keys=True, carry=0, sig=False, bf16=False, A=64, E2=64, mode=1, hasq=0, taps=0))[case]
     rng = np.random.RandomState(len(case))
-    B, T, To, Em = 3, 200, 5, 8
+    B, T, To, Em = 3, 200, (1 if one_step else 5), 8
     A, E2 = cfg['A'], cfg['E2']
     U = A if not cfg['hasq'] else 64
     Din = Em + E2 + U
     f = lambda *s, sc=1.0: torch.tensor(rng.randn(*s) * sc, dtype=torch.float32)
     seq_len = torch.tensor([T, 77, 130], dtype=torch.int32)
-    live = torch.tensor([[1, 1, 1], [1, 1, 1], [1, 0, 1], [1, 0, 1], [1, 0, 0]], dtype=torch.float32)   # [To,B]
+    live = torch.tensor([[1, 1, 1], [1, 1, 1], [1, 0, 1], [1, 0, 1], [1, 0, 0]], dtype=torch.float32)[:To].contiguous()   # [To,B]
     enc = f(T, B, E2, sc=0.5)
     enc = enc * (torch.arange(T).view(T, 1, 1) < seq_len.view(1, B, 1))
     if cfg['bf16']:
