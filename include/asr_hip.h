@@ -145,6 +145,12 @@ int asr_gemm_act(asr_handle* h, int dtype, int out_dtype, int transA, int transB
 int asr_gemm_mul(asr_handle* h, int dtype, int transA, int transB, int M, int N, int K,
                  const void* A, int lda, const void* B, int ldb, float* C, int ldc,
                  const float* bias, int accumulate, int act, const float* mul, int ldmul, asr_stream s);
+/* asr_gemm_mul whose multiplier is the dropout mask asr_dropout_mask(M*N, keep_prob, seed, offset) would produce, formed
+ * in the epilogue from its Philox counter instead of read from a mask tensor (C contiguous: ldc == N, N % 4 == 0):
+ * a recurrent layer's dx times the DropoutWrapper mask of the layer below (blstm.py:308-311), without that tensor. */
+int asr_gemm_drop(asr_handle* h, int dtype, int transA, int transB, int M, int N, int K, const void* A, int lda,
+                  const void* B, int ldb, float* C, int ldc, const float* bias, int accumulate, int act, float keep_prob,
+                  uint64_t seed, uint64_t offset, asr_stream s);
 
 /* ---- VGG front-end (models/encoders/core/vgg_blstm.py:107-177) --------------- *
  * Images are NHWC: [N = B*T frames, H = channels(40), W = splice*stack, C].

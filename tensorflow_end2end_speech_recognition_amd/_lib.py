@@ -39,6 +39,7 @@ SIGNATURES = {
     'asr_colsum': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     'asr_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'asr_gemm_act': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    'asr_gemm_drop': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _f, _u64, _u64, _vp]),
     'asr_gemm_mul': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     'asr_conv3x3_prep_weights': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     'asr_conv3x3_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),

@@ -241,6 +241,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
     }
 }
 
+struct GemmDrop {               // dropout multiplier of the OUTPUT formed in the epilogue (element m*N + n of a contiguous
+  float keep;                   // [M,N] tensor -> word (m*N + n) % 4 of Philox block offset + (m*N + n) / 4): asr_dropout_mask's
+  uint64_t seed, offset;        // values without the mask tensor
+  int use;
+};
+
 // ---------------------------------------------------------------- lean NT kernel (bf16)
 // C[M,N] = A[M,K] * Bt[N,K]^T (+bias)(+C)(relu): both operands reduction-contiguous, K % 64 == 0,
 // N % 128 == 0, 16-byte aligned rows.  This is the shape of every GEMM on the critical path of
@@ -255,7 +261,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
                                                            int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                            TO* __restrict__ C, int ldc,
                                                            const float* __restrict__ bias, int accumulate,
-                                                           int act, const float* __restrict__ mul, int ldm) {
+                                                           int act, const float* __restrict__ mul, int ldm,
+                                                           GemmDrop drop) {
   constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
   constexpr int STAGE = (BM + BN) * LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -361,6 +368,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] *= mv[r];
         }
+        if (drop.use) {                                    // the same mask from its Philox counter (N % 4 == 0)
+          float mk[4];
+          asr_dropout_words(drop.offset + ((size_t)m * N + nb) / 4, drop.seed, drop.keep, 1.f / drop.keep, mk);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= mk[r];
+        }
         *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
       } else {
         typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
@@ -382,8 +395,9 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
 template <typename TO>
 bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
                       int ldb, void* C, int ldc, const float* bias, int accumulate, hipStream_t st, int act,
-                      const float* mul, int ldm) {
+                      const float* mul, int ldm, GemmDrop drop = GemmDrop{1.f, 0, 0, 0}) {
   if (transA || !transB || K % 64 != 0 || N % 128 != 0 || M < 1024) return false;
+  if (drop.use && sizeof(TO) != 4) return false;
   if (mul && (sizeof(TO) != 4 || ldm % 4 != 0 || ((uintptr_t)mul) % 16 != 0)) return false;
   if (lda % 8 != 0 || ldb % 8 != 0 || ((uintptr_t)A) % 16 != 0 || ((uintptr_t)B) % 16 != 0) return false;
   if (ldc % 4 != 0 || ((uintptr_t)C) % (4 * sizeof(TO)) != 0 || (bias && ((uintptr_t)bias) % 16 != 0)) return false;
@@ -395,7 +409,7 @@ bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A
   }
   const int total = (N / 128) * ((M + 127) / 128);
   hipLaunchKernelGGL(gemm_nt_bf16_kernel<TO>, dim3(total), dim3(256), lds, st, M, N, K, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, (TO*)C, ldc, bias, accumulate, act, mul, ldm);
+                     (const bf16_t*)B, ldb, (TO*)C, ldc, bias, accumulate, act, mul, ldm, drop);
   return true;
 }
 
@@ -977,13 +991,14 @@ int launch_layout(int transA, int transB, dim3 grid, size_t lds, hipStream_t st,
 template <typename T, typename TO>
 int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, const void* A, int lda,
                 const void* B, int ldb, void* C, int ldc, const float* bias, int accumulate,
-                hipStream_t st, int act, const float* mul = nullptr, int ldm = 0, bool* mul_done = nullptr) {
+                hipStream_t st, int act, const float* mul = nullptr, int ldm = 0, bool* mul_done = nullptr,
+                GemmDrop drop = GemmDrop{1.f, 0, 0, 0}) {
   constexpr int VEC = GT<T>::VEC, BK = GT<T>::BK;
   if constexpr (sizeof(T) == 4 && sizeof(TO) == 4) {
     if (try_gemm_skinny_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act)) return 0;
   }
   if constexpr (sizeof(T) == 2) {
-    if (try_gemm_nt_bf16<TO>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act, mul, ldm)) {
+    if (try_gemm_nt_bf16<TO>(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act, mul, ldm, drop)) {
       if (mul_done) *mul_done = true;
       return 0;
     }
@@ -1146,6 +1161,31 @@ extern "C" int asr_gemm_mul(asr_handle* h, int dtype, int transA, int transB, in
     hipLaunchKernelGGL(mul_rows_kernel, dim3(blocks), dim3(256), 0, st, C, ldc, mul, ldmul, M, N);
     ASR_CHECK_LAUNCH(h, "asr_gemm_mul(multiply)");
   }
+  return ASR_OK;
+}
+
+// C (fp32, CONTIGUOUS rows: ldc == N) = (op(A) op(B) + bias [+ C]) [relu] * dropout mask(seed, offset) of a [M,N] tensor
+// -- asr_gemm_mul with the mask of asr_dropout_mask(M*N, keep, seed, offset) formed in the epilogue instead of read
+// from memory (the lean NT kernel); other shapes run the plain GEMM and asr_dropout_apply in place.
+extern "C" int asr_dropout_apply(asr_handle* h, int dtype, const void* in, void* out, size_t n, float keep_prob,
+                                 uint64_t seed, uint64_t offset, asr_stream s);
+extern "C" int asr_gemm_drop(asr_handle* h, int dtype, int transA, int transB, int M, int N, int K, const void* A,
+                             int lda, const void* B, int ldb, float* C, int ldc, const float* bias, int accumulate,
+                             int act, float keep_prob, uint64_t seed, uint64_t offset, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!asr_dtype_ok(dtype) || (act != 0 && act != 1) || M < 0 || N < 0 || K < 0 || !A || !B || !C ||
+      lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc != N || N % 4 != 0 || !(keep_prob > 0.f && keep_prob <= 1.f))
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_gemm_drop: bad args M=%d N=%d K=%d ldc=%d (ldc == N, N %% 4 == 0)", M, N, K, ldc);
+  if (M == 0 || N == 0) return ASR_OK;
+  hipStream_t st = (hipStream_t)s;
+  bool fused = false;
+  const GemmDrop drop = {keep_prob, seed, offset, 1};
+  if (dtype == ASR_F32)
+    launch_gemm<float, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act, nullptr, 0, &fused, drop);
+  else
+    launch_gemm<bf16_t, float>(h, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act, nullptr, 0, &fused, drop);
+  ASR_CHECK_LAUNCH(h, "asr_gemm_drop");
+  if (!fused) return asr_dropout_apply(h, ASR_F32, C, C, (size_t)M * N, keep_prob, seed, offset, s);
   return ASR_OK;
 }
 

@@ -78,13 +78,21 @@ class LSTMLayer(object):
         return w
 
     def make_mask(self, device, T, B, keep_prob=1.0, is_training=True, rng_state=None, drop_mask=None):
-        """Dropout mask of the layer's output ([T,B,ndir*H] fp32, 1/keep_prob or 0), or None."""
+        """Dropout mask of the layer's output, or None: a caller-supplied tensor ([T,B,ndir*H] fp32, 1/keep_prob or 0),
+        or -- the normal case -- the descriptor (keep_prob, seed, offset) of the mask ops.dropout_mask would generate
+        with those arguments.  The kernels that apply it (asr_dropout_apply, the dx GEMM's epilogue: asr_gemm_drop)
+        form it from the generator's counter, so no [T,B,ndir*H] fp32 tensor is written beside the first recurrence
+        (5 x 25 MB at cfg B: the first layer's forward kernel ran 85 us longer than the others) or read back."""
         if not (is_training and (drop_mask is not None or keep_prob < 1.0)):
             return None
         if drop_mask is not None:
             return drop_mask
         seed, offset = rng_state
-        return ops.dropout_mask((T, B, self.ndir * self.H), keep_prob, seed, offset, device)
+        return (float(keep_prob), int(seed), int(offset))
+
+    @staticmethod
+    def _masked(t, mask):
+        return ops.dropout_apply(t, *mask) if isinstance(mask, tuple) else ops.apply_mask(t, mask)
 
     def forward(self, x, seq_len, dtype, keep_prob=1.0, is_training=True, rng_state=None,
                 drop_mask=None, save=True, prep=None, mask_event=None):
@@ -103,8 +111,9 @@ class LSTMLayer(object):
         out = hout
         mask = prep['mask']
         if mask is not None:
-            ops.wait_event(mask_event)       # the mask was generated on the side stream (None: same stream)
-            out = ops.apply_mask(hout, mask)
+            if not isinstance(mask, tuple):
+                ops.wait_event(mask_event)   # a mask tensor may have been produced on the side stream
+            out = self._masked(hout, mask)
         if save:
             self.ctx = dict(x=x, gates=gates, cs=cs, hout=hout, whb=prep['whb'], peep=prep['peep'],
                             seq_len=seq_len, dtype=dtype, mask=mask, wx_cat=prep['wx_cat'])
@@ -125,7 +134,7 @@ class LSTMLayer(object):
         T, B, ldk = x.shape
         din, H, ndir = self.din, self.H, self.ndir
         if c['mask'] is not None and not dout_masked:
-            dout = ops.apply_mask(dout, c['mask'])
+            dout = self._masked(dout, c['mask'])
         dgates, dpeep = ops.lstm_bwd(dout, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H,
                                      ndir, dtype, d_c_final, d_h_final, want_dpeep=True)
         x2d = x.view(T * B, ldk)[:, :din]
@@ -133,8 +142,11 @@ class LSTMLayer(object):
         dg2d = dgates.view(T * B, ndir * 4 * H)
         dx = torch.empty((T, B, din), dtype=torch.float32, device=x.device) if need_dx else None
         if need_dx:   # the only result the layer below waits for: main stream, first
-            ops.gemm(dg2d, c['wx_cat'], transB=True, out=dx.view(T * B, din),
-                     mul=dx_mask.view(T * B, din) if dx_mask is not None else None)
+            if isinstance(dx_mask, tuple):
+                ops.gemm(dg2d, c['wx_cat'], transB=True, out=dx.view(T * B, din), drop=dx_mask)
+            else:
+                ops.gemm(dg2d, c['wx_cat'], transB=True, out=dx.view(T * B, din),
+                         mul=dx_mask.view(T * B, din) if dx_mask is not None else None)
         # weight gradients: side streams (one per direction), concurrent with the BPTT kernel of the layer
         # below (joined in the model's backward before clipping)
         dw_il = torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols

@@ -260,8 +260,10 @@ def colsum(a, out=None):
 
 # ---------------------------------------------------------------- GEMM
 def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, accumulate=False, relu=False,
-         mul=None):
-    """C = op(A) @ op(B) (+bias) (+C).  A, B 2-D, same dtype (f32 or bf16), row stride = ld."""
+         mul=None, drop=None):
+    """C = op(A) @ op(B) (+bias) (+C).  A, B 2-D, same dtype (f32 or bf16), row stride = ld.
+    mul: fp32 [M,N] multiplier of the result (a dropout mask); drop = (keep_prob, seed, offset): the same multiplier
+    formed from the dropout generator's counter in the epilogue -- dropout_mask((M, N), ...) without the tensor."""
     h = _h(A)
     dt = dtype_id(A.dtype)
     if B.dtype != A.dtype:
@@ -282,6 +284,14 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, 
             raise ValueError('gemm: bad out shape %s' % (tuple(out.shape),))
     if bias is not None:
         _chk(bias, torch.float32, 'bias')
+    if drop is not None:
+        if odt != ASR_F32 or not out.is_contiguous() or N % 4:
+            raise ValueError('gemm: drop needs a contiguous fp32 output with N % 4 == 0')
+        h.check(h.lib.asr_gemm_drop(h.h, dt, int(transA), int(transB), M, N, K,
+                                    C.c_void_p(A.data_ptr()), A.stride(0), C.c_void_p(B.data_ptr()), B.stride(0),
+                                    C.c_void_p(out.data_ptr()), out.stride(0), _p(bias), int(accumulate),
+                                    1 if relu else 0, float(drop[0]), int(drop[1]), int(drop[2]), _s()), 'asr_gemm_drop')
+        return out
     if mul is not None:   # fp32 output times an elementwise fp32 multiplier [M,N] (a dropout mask), in the epilogue
         _chk(mul, torch.float32, 'mul')
         if odt != ASR_F32 or mul.dim() != 2 or mul.shape != (M, N) or mul.stride(1) != 1:

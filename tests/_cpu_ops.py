@@ -96,7 +96,7 @@ def _colsum(a, out=None):
 
 
 def _gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None, accumulate=False, relu=False,
-          mul=None):
+          mul=None, drop=None):
     if A.dim() != 2 or B.dim() != 2 or A.stride(1) != 1 or B.stride(1) != 1:
         raise ValueError('gemm: operands must be 2-D with unit inner stride')
     a = A.double().t() if transA else A.double()
@@ -112,6 +112,8 @@ def _gemm(A, B, transA=False, transB=False, bias=None, out=None, out_dtype=None,
         y = torch.relu(y)
     if mul is not None:
         y = y * mul.double()
+    if drop is not None:
+        y = y * _dropout_mask(tuple(y.shape), *drop).double()
     if out is not None:
         if tuple(out.shape) != tuple(y.shape) or out.stride(1) != 1:
             raise ValueError('gemm: bad out shape %s' % (tuple(out.shape),))

@@ -873,6 +873,23 @@ def test_dropout_mask(cuda):
     assert torch.equal(m, m2) and not torch.equal(m, m3)
 
 
+@pytest.mark.parametrize('M,N,K,dt', [(12448, 512, 2048, torch.bfloat16), (1500, 256, 128, torch.bfloat16),
+                                      (100, 36, 24, torch.float32), (33, 8, 64, torch.bfloat16)])
+def test_gemm_with_the_dropout_mask_formed_in_its_epilogue(cuda, M, N, K, dt):
+    """asr_gemm_drop == asr_gemm_mul with the tensor asr_dropout_mask produces for the same (keep, seed, offset), bit for
+    bit: the headline dx shape (lean NT kernel, mask from the Philox counter in the epilogue) and shapes that take the
+    generic kernels followed by asr_dropout_apply in place."""
+    ops = _ops()
+    rng = np.random.RandomState(N)
+    A = torch.tensor(rng.randn(M, K), dtype=torch.float32, device=cuda).to(dt)
+    Bt = torch.tensor(rng.randn(N, K) * 0.1, dtype=torch.float32, device=cuda).to(dt)
+    d = (0.8, 11, (4 << 32) + 3)
+    mask = ops.dropout_mask((M, N), *d, cuda)
+    ref = ops.gemm(A, Bt, transB=True, out_dtype=torch.float32, mul=mask)
+    got = ops.gemm(A, Bt, transB=True, out_dtype=torch.float32, drop=d)
+    assert torch.equal(got, ref) and float(got.abs().sum()) > 0
+
+
 @pytest.mark.parametrize('N,H,W,Cin', [(3, 40, 11, 3), (70, 5, 3, 3), (2, 7, 6, 2), (1, 1, 1, 3)])
 def test_direct_convolution_of_the_few_channel_first_layer(cuda, N, H, W, Cin):
     """asr_conv3x3_smallc_fwd / _bwd_weight (no patch matrix) against fp64 conv2d on the bf16-rounded operands: the
