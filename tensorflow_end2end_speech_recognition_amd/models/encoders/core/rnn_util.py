@@ -25,6 +25,8 @@ DIRS = ('fw', 'bw')
 # side streams the weight-gradient GEMMs of a layer are spread over: one per direction (one lane for both measures the
 # same step time, 12.39 ms, but leaves a longer tail after the last BPTT kernel)
 DW_LANES = 2
+import os as _os
+BG_WGS = int(_os.environ.get('ASR_BG_WGS', '32'))   # workgroups of a weight-gradient GEMM that runs beside a BPTT kernel
 
 
 def declare_lstm_vars(store, scope, din, H, ndir, use_peephole, parameter_init, rng, cell_scope=None):
@@ -150,7 +152,7 @@ class LSTMLayer(object):
         # weight gradients: side streams (one per direction), concurrent with the BPTT kernel of the layer
         # below (joined in the model's backward before clipping)
         dw_il = torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols
-        ops.set_side_gemm_workgroups(x.device, 32 if background else 0)
+        ops.set_side_gemm_workgroups(x.device, BG_WGS if background else 0)
         done = []
         for d in range(ndir):
             with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il), lane=1 + (d % DW_LANES)):
