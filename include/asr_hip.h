@@ -109,6 +109,9 @@ int asr_cast_to_f32(asr_handle* h, int dtype, const void* in, float* out, size_t
 int asr_apply_mask(asr_handle* h, int dtype, const void* in, const float* mask, void* out,
                    size_t n, asr_stream s);
 /* Bernoulli(keep_prob)/keep_prob mask from a counter-based generator (seed, offset) */
+/* Read pass over a device buffer (nothing is written): brings it into the memory-side cache ahead of a kernel whose
+ * loads are latency-critical (the BPTT kernels' saved activations). */
+int asr_touch(asr_handle* h, const void* p, size_t bytes, asr_stream s);
 int asr_dropout_mask(asr_handle* h, float* mask, size_t n, float keep_prob,
                      uint64_t seed, uint64_t offset, asr_stream s);
 /* The same mask formed where it is used (no mask tensor): out = in * mask(seed, offset) in `dtype`, bit-identical to

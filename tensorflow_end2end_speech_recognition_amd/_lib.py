@@ -34,6 +34,7 @@ SIGNATURES = {
     'asr_cast_to_f32': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     'asr_apply_mask': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp]),
     'asr_dropout_mask': (_i, [_vp, _vp, _sz, _f, _u64, _u64, _vp]),
+    'asr_touch': (_i, [_vp, _vp, _sz, _vp]),
     'asr_dropout_apply': (_i, [_vp, _i, _vp, _vp, _sz, _f, _u64, _u64, _vp]),
     'asr_relu_bwd_drop': (_i, [_vp, _i, _vp, _vp, _sz, _f, _u64, _u64, _vp, _vp]),
     'asr_colsum': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),

@@ -19,6 +19,9 @@ from ...._lib import ASR_F32
 from ....utils.parameter import ParamStore
 from .rnn_util import LSTMLayer, declare_lstm_vars
 
+import os as _os
+WARM_BPTT = _os.environ.get('ASR_WARM_BPTT', '1') != '0'    # A-B switch of the read pass ahead of each BPTT kernel
+
 # tf.contrib.rnn.LSTMStateTuple: what the reference's encoders hand back as final state (.c, .h)
 LSTMStateTuple = collections.namedtuple('LSTMStateTuple', ('c', 'h'))
 
@@ -177,8 +180,16 @@ class _RecurrentEncoderBase(object):
             below = self.layers[li - 1].ctx['mask'] if li > 0 else None
             if d_outputs_sub is not None and li - 1 == self.num_layers_sub - 1:
                 below = None
+            # read pass over the saved activations of the layer below while this layer's dx product runs -- when they
+            # fit the 256 MB memory-side cache with room to spare (76 MB at cfg B; 306 MB at 5x512 / B = 32 do not)
+            cb = self.layers[li - 1].ctx if (li > 0 and WARM_BPTT) else None
+            if cb is not None and (cb['gates'].numel() * cb['gates'].element_size() +
+                                   cb['cs'].numel() * cb['cs'].element_size()) > (128 << 20):
+                cb = None
             dx = self.layers[li].backward(dx.contiguous(), dcf, dhf, need_dx=(li > 0 or need_input_grad),
-                                          dout_masked=masked, dx_mask=below, background=(li > 0))
+                                          dout_masked=masked, dx_mask=below, background=(li > 0),
+                                          warm=(cb['gates'], cb['cs']) if cb is not None else None)
+            ops.wait_event(getattr(self.layers[li], 'warm_event', None))
             masked = below is not None
             if self.grad_ready_hook is not None:      # data-parallel step: this layer's gradients are on their way
                 self.grad_ready_hook(li, self.layers[li])

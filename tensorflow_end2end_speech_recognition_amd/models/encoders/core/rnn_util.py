@@ -122,7 +122,7 @@ class LSTMLayer(object):
         return out, (cf, hf)
 
     def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True, dout_masked=False, dx_mask=None,
-                 background=False):
+                 background=False, warm=None):
         """dout [T,B,ndir*H] fp32 -> dx [T,B,din] fp32 (or None).  Fills store.grad.
         dout_masked: the caller has already multiplied dout with this layer's dropout mask.
         dx_mask: dropout mask [T,B,din] of the layer BELOW: dx comes back already multiplied with it (in the epilogue
@@ -139,6 +139,14 @@ class LSTMLayer(object):
             dout = self._masked(dout, c['mask'])
         dgates, dpeep = ops.lstm_bwd(dout, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H,
                                      ndir, dtype, d_c_final, d_h_final, want_dpeep=True)
+        self.warm_event = None
+        if warm:
+            # warm: the saved activations of the layer BELOW, read once on a side lane while this layer's dx product runs
+            # (after this BPTT kernel, before the next one): its BPTT kernel then finds them in the memory-side cache
+            with ops.side_lane(dout.device, keep=tuple(warm), lane=2):
+                for t in warm:
+                    ops.touch(t)
+                self.warm_event = ops.stream_event()
         x2d = x.view(T * B, ldk)[:, :din]
         h2d = hout.view(T * B, ndir * H)
         dg2d = dgates.view(T * B, ndir * 4 * H)

@@ -235,6 +235,12 @@ def dropout_mask(shape, keep_prob, seed, offset, device):
     return mask
 
 
+def touch(t):
+    """Read pass over a tensor (asr_touch): into the memory-side cache ahead of a latency-critical consumer."""
+    h = _h(t)
+    h.check(h.lib.asr_touch(h.h, _p(t), t.numel() * t.element_size(), _s()), 'asr_touch')
+
+
 def dropout_apply(x, keep_prob, seed, offset):
     """x * dropout mask(seed, offset) without a mask tensor (== apply_mask(x, dropout_mask(x.shape, ...)) bit for bit)."""
     h = _h(x)

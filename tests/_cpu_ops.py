@@ -737,7 +737,7 @@ STAND_INS = dict(
     side_lane=_NullLane, join_side=lambda device: None, stream_event=lambda: None, set_side_gemm_workgroups=lambda device, n: None, wait_event=lambda ev: None,
     gru_fwd=_gru_fwd, gru_bwd=_gru_bwd, lstm_prep_layer=_lstm_prep_layer, lstm_grad_finish=_lstm_grad_finish, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
     cast_from_f32=_cast_from_f32, cast_to_f32=_cast_to_f32, apply_mask=_apply_mask, dropout_mask=_dropout_mask,
-    dropout_apply=_dropout_apply, maxpool2x2_relu_bwd=_maxpool2x2_relu_bwd,
+    dropout_apply=_dropout_apply, maxpool2x2_relu_bwd=_maxpool2x2_relu_bwd, touch=lambda t: None,
     colsum=_colsum, gemm=_gemm, relu_bwd=_relu_bwd, lstm_prep_weights=_lstm_prep_weights,
     gate_deinterleave=_gate_deinterleave, lstm_fwd=_lstm_fwd, lstm_bwd=_lstm_bwd, ctc_loss=_ctc_loss,
     ctc_greedy_decode=_ctc_greedy_decode, softmax_rows=_softmax_rows, clip_by_norm_multi=_clip_by_norm_multi,
