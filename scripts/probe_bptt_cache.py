@@ -41,3 +41,20 @@ def bwd_time(flush):
 for it in range(3):
     a = bwd_time(False); b = bwd_time(True)
     print('H=%d  after forward: %.0f us, again %.0f us | after 1 GB of other traffic: %.0f us, again %.0f us' % (H, a[0], a[1], b[0], b[1]))
+
+# ---- the forward kernel: x-projection just written by the GEMM (never read) vs read once before the launch
+prep = layer.prepare(dev, ASR_BF16, T, B, 1.0, False, None, None, ldk=D)
+for it in range(3):
+    ts = []
+    for warm in (False, True):
+        xproj = torch.empty((T, B, 2 * 4 * H), dtype=torch.float32, device=dev)
+        junk.mul_(1.0001)
+        ops.gemm(x.view(T * B, D), prep['wxT'], transB=True, bias=prep['bias'], out=xproj.view(T * B, 8 * H))
+        if warm:
+            ops.touch(xproj)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.lstm_fwd(xproj, prep['whf'], prep['peep'], sl, H, 2, ASR_BF16, 1.0, 50.0)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    print('H=%d forward kernel: x-projection fresh from the GEMM %.0f us, after a read pass %.0f us' % (H, ts[0], ts[1]))
