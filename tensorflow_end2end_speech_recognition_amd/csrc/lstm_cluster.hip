@@ -277,6 +277,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
     const char* hcur = smem + P * 16 * LDH * 2;
     char* hnxt = smem + (1 - P) * 16 * LDH * 2;
     const f32x4_t x0 = xq[P % XD][0], x1 = xq[P % XD][1];
+    // (requested here, at the top of the step: behind the poll loop at its end -- where the BPTT kernel's fetch belongs,
+    // see there -- the forward kernel measured 1.21 ms per launch instead of 0.92)
     if (s + XD < tmax) {                                   // lands during the next step(s)
 #pragma unroll
       for (int r = 0; r < 2; ++r)
@@ -640,7 +642,10 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
     // next iteration's inputs (independent of everything below)
 #pragma unroll
     for (int r = 0; r < 2; ++r) { oa[r] += dstep; os[r] -= stride; }
-    if (s > 0) prefetch(s - 1);
+    // The fetch of the next iteration's saved activations used to go out here, ahead of the poll loop; kflags bit 2
+    // (ASR_LSTM_DFLAGS bit 7) puts it back for A-B runs.  It now goes out BEHIND the loop, see there.
+    const bool early_fetch = (kflags & 4) != 0;
+    if (s > 0 && early_fetch) prefetch(s - 1);
     // ---- 3. finish the polls: every word must carry the previous iteration's tag
     if (it > 0) {
       const unsigned want = (((unsigned)(it - 1) >> 1) + 1u) & 1u;
@@ -667,6 +672,13 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
       dhr[0] += add0;
       dhr[1] += add1;
     }
+    // The fetch of the next iteration's saved activations goes out BEHIND the poll loop.  Vector loads return in order: a
+    // re-poll issued after a fetch that has to come from HBM cannot land before that fetch does, so with the fetch in
+    // front of the loop the hand-off waited for DRAM on every step whose first poll came too early -- 1.22 ms per
+    // launch against 0.94 ms behind it (11.93 -> 10.52 ms per headline step); the fetch still has the rest of the
+    // step to arrive.  (Written as the second arm of a run-time switch on purpose: as an unconditional statement the
+    // compiler schedules these independent loads differently and the launch takes 1.06 ms.)
+    if (s > 0 && !early_fetch) prefetch(s - 1);
     const unsigned long long t1 = C8_T();
     // ---- 4. gate gradients of the own pairs
     const float pdhv[2] = {pdh0, pdh1}, pcpv[2] = {pcp0, pcp1}, curv[2] = {cur0, cur1};
@@ -813,7 +825,7 @@ static int dbg_flags() {
   if (g_dflags < 0) { const char* e = getenv("ASR_LSTM_DFLAGS"); g_dflags = e ? atoi(e) : 0; }
   return g_dflags;
 }
-static int kernel_flags() { return ((dbg_flags() & 16) ? 1 : 0) | ((dbg_flags() & 64) ? 2 : 0); }
+static int kernel_flags() { return ((dbg_flags() & 16) ? 1 : 0) | ((dbg_flags() & 64) ? 2 : 0) | ((dbg_flags() & 128) ? 4 : 0); }
 static bool cluster_enabled() {
   static const bool on = [] { const char* e = getenv("ASR_LSTM_CLUSTER"); return !(e && e[0] == '0'); }();
   return on;
