@@ -25,7 +25,9 @@ for n in ['lstm_fwd_cluster8', 'cell_fwd_kernel', 'cell_bwd_kernel', 'lstm_bwd_c
 print('between the loops %.2f ms, after the reverse loop %.2f ms, total %.2f ms' % (
     (marks[2][0] - marks[1][1]) / 1e3, (marks[3][0] - marks[2][1]) / 1e3, (rows[-1][2] + rows[-1][3]) / 1e3))
 for name in ('cell_fwd_kernel', 'cell_bwd_kernel'):
-    cf = [r for r in rows if r[1].startswith(name)]
+    cf = [r for r in rows if name in r[1]]
+    if len(cf) < 2:
+        continue
     d = [cf[i + 1][2] - cf[i][2] for i in range(len(cf) - 1)]
     print('%s period: median %.1f us, mean %.1f us' % (name, statistics.median(d), sum(d) / len(d)))
 if len(sys.argv) > 3:
