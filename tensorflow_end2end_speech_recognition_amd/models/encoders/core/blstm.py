@@ -10,6 +10,7 @@ num_proj is dropped exactly as the reference drops it unless lstm_impl ==
 'LSTMCell' (blstm.py:49-52); a projection layer is not implemented -> ValueError.
 """
 import collections
+import os as _os
 
 import numpy as np
 import torch
@@ -19,7 +20,6 @@ from ...._lib import ASR_F32
 from ....utils.parameter import ParamStore
 from .rnn_util import LSTMLayer, declare_lstm_vars
 
-import os as _os
 WARM_BPTT = _os.environ.get('ASR_WARM_BPTT', '1') != '0'    # A-B switch of the read pass ahead of each BPTT kernel
 
 # tf.contrib.rnn.LSTMStateTuple: what the reference's encoders hand back as final state (.c, .h)

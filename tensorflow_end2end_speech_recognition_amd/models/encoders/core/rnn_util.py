@@ -15,6 +15,8 @@ Dataflow per layer (all device-side, one stream):
 Variable names follow TF 1.3:
   <scope>/{fw,bw}/lstm_cell/{kernel,bias,w_i_diag,w_f_diag,w_o_diag}
 """
+import os as _os
+
 import numpy as np
 import torch
 
@@ -25,7 +27,6 @@ DIRS = ('fw', 'bw')
 # side streams the weight-gradient GEMMs of a layer are spread over: one per direction (one lane for both measures the
 # same step time, 12.39 ms, but leaves a longer tail after the last BPTT kernel)
 DW_LANES = 2
-import os as _os
 BG_WGS = int(_os.environ.get('ASR_BG_WGS', '32'))   # workgroups of a weight-gradient GEMM that runs beside a BPTT kernel
 
 
