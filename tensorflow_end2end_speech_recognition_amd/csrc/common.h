@@ -132,6 +132,15 @@ bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
                          const void* gates, const float* cs, const void* whpb, const float* peep,
                          const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
                          float* dpeep_part, hipStream_t st);
+// fp32 operands (H = 128 on two CUs per direction); same contract: false = not applicable, nothing launched
+bool asr_cluster_fwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const float* xproj,
+                             const void* whp, const float* peep, const int32_t* seq_len, float fb,
+                             float clip, void* gates, void* hout, float* cs, float* cf, float* hf,
+                             hipStream_t st);
+bool asr_cluster_bwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const float* dhout,
+                             const void* gates, const float* cs, const void* whpb, const float* peep,
+                             const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
+                             float* dpeep_part, hipStream_t st);
 
 static inline int asr_dtype_ok(int dt) { return dt == ASR_F32 || dt == ASR_BF16; }
 static inline size_t asr_dtype_size(int dt) { return dt == ASR_BF16 ? 2 : 4; }

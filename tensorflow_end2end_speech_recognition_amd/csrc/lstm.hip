@@ -891,6 +891,11 @@ extern "C" int asr_lstm_fwd(asr_handle* h, int dtype, int T, int B, int H, int n
     ASR_CHECK_LAUNCH(h, "asr_lstm_fwd(cluster)");
     return ASR_OK;
   }
+  if (dtype == ASR_F32 && asr_cluster_fwd_f32_try(h, T, B, H, ndir, xproj, wh_packed, peep, seq_len, forget_bias,
+                                                  cell_clip, gates, hout, cs, c_final, h_final, st)) {
+    ASR_CHECK_LAUNCH(h, "asr_lstm_fwd(cluster, fp32)");
+    return ASR_OK;
+  }
   if (dtype == ASR_F32) {
     ASR_H_DISPATCH(H, T, (launch_fwd<float, HH>(T, B, ndir, xproj, wh_packed, peep, seq_len, forget_bias,
                                                 cell_clip, gates, hout, cs, c_final, h_final, st)));
@@ -926,6 +931,10 @@ extern "C" int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int n
   bool launched = false;
   if (dtype == ASR_BF16 && asr_cluster_bwd_try(h, T, B, H, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len,
                                                d_c_final, d_h_final, dgates, part, st)) {
+    launched = true;
+  } else
+  if (dtype == ASR_F32 && asr_cluster_bwd_f32_try(h, T, B, H, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len,
+                                                  d_c_final, d_h_final, dgates, part, st)) {
     launched = true;
   } else
   if (dtype == ASR_F32) {

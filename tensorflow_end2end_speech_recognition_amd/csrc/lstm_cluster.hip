@@ -823,6 +823,486 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
   }
 }
 
+// ---------------------------------------------------------------- fp32 operands (exact fp32 MFMA path), H = 128
+// BASELINE configs[0] (2 x 128 BLSTM-CTC, fp32) ran on the single-CU kernels of lstm.hip at 5.1 / 6.7 us per
+// recurrence step: with fp32 operands the step is bound by the CU's fp32 matrix rate (v_mfma_f32_16x16x4_f32:
+// 256 flop/clk/CU; h W_h of one step = 2.1 Mflop = 8.2 k cycles), not by streaming W_h.  The same cluster scheme
+// halves that: G = H/64 = 2 CUs per (direction, tile), 64 units per CU, and the byte layouts of the bf16 H = 256
+// form carry over unchanged (a row of h is 128 fp32 = 512 B, a fragment 16 B per lane, 8 fragments per tile, W_h
+// slice in 64 VGPRs per wave).  What differs: four K = 4 MFMAs per fragment, one {tag, fp32} granule per (row,
+// unit) pair in the all-gather (two per lane) instead of one {tag, 2 x bf16}, saved activations in fp32.
+__device__ __forceinline__ void mma_f32x2(const f32x4_t& a, const f32x4_t& b0, const f32x4_t& b1, f32x4_t& c0,
+                                          f32x4_t& c1) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], c1, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ f32x4_t mma_f32(const f32x4_t& a, const f32x4_t& b, f32x4_t c) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
+  return c;
+}
+
+template <int H>
+__global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
+    int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const float* __restrict__ whp,
+    const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
+    float cell_clip, f32x4_t* __restrict__ gates, float* __restrict__ hout, float* __restrict__ cs,
+    float* __restrict__ c_final, float* __restrict__ h_final, u64* __restrict__ xch,
+    unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+  zero_next_area(znext, zwords);
+  constexpr int G = H / HS;
+  constexpr int KS = H / 16;                               // fragments of k = 16 (four K = 4 MFMAs each)
+  constexpr int LDH = H + 4;                               // floats: 33 x 16 B at H = 128, like the bf16 image
+  constexpr int SLICE = 16 * HS;                           // granules one CU publishes per step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* hs = reinterpret_cast<float*>(smem);              // [2][16][LDH]
+
+  const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
+  if (!cid.valid) return;
+  const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rg = lane >> 4;
+  const bool lo = col < 8;
+  const bool rev = (d == 1);
+  const float* wp = whp + (size_t)d * H * 4 * H;
+  const int ul = wave * 8 + (col & 7);                     // unit inside this CU's slice
+  const unsigned jw = g * HS + ul;                         // global unit of this lane
+  const int rbase = rg * 4 + (lo ? 0 : 2);                 // first of this lane's two batch rows
+
+  int len[2];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) len[r] = seq_len[b0 + rbase + r];
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  float c[2] = {0.f, 0.f}, hr[2] = {0.f, 0.f};
+  const float wci = peep ? peep[(d * 3 + 0) * H + jw] : 0.f;
+  const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
+  const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
+
+  for (int i = threadIdx.x; i < 2 * 16 * LDH; i += CT8) hs[i] = 0.f;
+  // B fragments out of the standard forward packing (lstm.hip prep: tile = (unit/16)*4 + gate, fragment ks, lane
+  // (n, rg) holds k = ks*16 + rg*4 + e): this lane's column of tile p is (gate p*2 + (col>>3), unit jw)
+  f32x4_t wreg[2][KS];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int tile = (jw >> 4) * 4 + p * 2 + (col >> 3);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wreg[p][ks] = *reinterpret_cast<const f32x4_t*>(wp + (((size_t)tile * KS + ks) * 64 + rg * 16 + (jw & 15)) * 4);
+  }
+
+  u64* xhdr = xch + (size_t)cid.c * (XHDR + 2 * G * SLICE);
+  u64* xbase = xhdr + XHDR;                                // [2 parity][G][8 waves][16 rows][8 units]
+  bool timed_out = false;
+  const bool colocated = same_xcd<G>(xhdr, g, timed_out);
+  const bool fast = colocated && !(kflags & 1);
+  unsigned spin_limit = (kflags & 2) ? 2000u : SPIN_LIMIT;
+  if ((kflags & 2) && g == G - 1) return;                  // TEST ONLY: a member goes missing
+  __syncthreads();
+
+  const unsigned stride = (unsigned)B_ * ndir * H;
+  const unsigned dstep = rev ? 0u - stride : stride;
+  unsigned oa[2], os[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    os[r] = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+    oa[r] = os[r] + (rev ? (unsigned)max(len[r] - 1, 0) * stride : 0u);
+  }
+  // granule i of a wave's 128: row i >> 3, unit i & 7.  A lane publishes its two (row, unit) pairs and polls
+  // granules lane and 64 + lane of wave `wave` of every peer.
+  const unsigned pofs = (unsigned)(wave * 128 + rbase * 8 + (col & 7));
+  const unsigned lofs = (unsigned)(wave * 128 + lane);
+  unsigned ldst[G - 1][2];                                 // byte offsets inside one h buffer
+  auto slice = [&](int P, int gg) -> u64* { return xbase + ((size_t)P * G + gg) * SLICE; };
+#pragma unroll
+  for (int k = 0; k < G - 1; ++k) {
+    const int gsrc = k + (k >= g ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 8 + (lane >> 3);
+      ldst[k][j] = ((unsigned)(row * LDH + gsrc * HS + wave * 8 + (lane & 7)) * 4u) ^ lds_swz(row);
+    }
+  }
+  unsigned lown[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) lown[r] = ((unsigned)((rbase + r) * LDH + g * HS + ul) * 4u) ^ lds_swz(rbase + r);
+  const unsigned lrd = ((unsigned)(col * LDH + rg * 4) * 4u) ^ lds_swz(col);
+
+  f32x4_t xq[2][2];                                        // x projection rows, requested two steps ahead
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    xq[0][r] = xg[(0 < len[r]) ? oa[r] : os[r]];
+    xq[1][r] = (tmax > 1) ? xg[(1 < len[r]) ? oa[r] + dstep : os[r] + stride] : xq[0][r];
+  }
+
+  auto step = [&](int s, auto PAR) {
+    constexpr int P = decltype(PAR)::value;
+    const char* hcur = smem + P * 16 * LDH * 4;
+    char* hnxt = smem + (1 - P) * 16 * LDH * 4;
+    const f32x4_t x0 = xq[P][0], x1 = xq[P][1];
+    if (s + 2 < tmax) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        xq[P][r] = xg[(s + 2 < len[r]) ? oa[r] + 2u * dstep : os[r] + 2u * stride];
+    }
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    {
+      f32x4_t afr[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) afr[ks] = *reinterpret_cast<const f32x4_t*>(hcur + lrd + ks * 64);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) mma_f32x2(afr[ks], wreg[0][ks], wreg[1][ks], acc0, acc1);
+    }
+    float pi[2], pq[2], pf[2], po[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      pi[r] = dpp_ror8_into<0xC>(acc0[r], acc0[2 + r]);
+      pq[r] = dpp_ror8_into<0x3>(acc0[2 + r], acc0[r]);
+      pf[r] = dpp_ror8_into<0xC>(acc1[r], acc1[2 + r]);
+      po[r] = dpp_ror8_into<0x3>(acc1[2 + r], acc1[r]);
+    }
+    const unsigned epoch = (unsigned)s + 1u;
+    bool act[2];
+    float ig[2], gg[2], fg[2], og[2], cn[2], hn[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) act[r] = s < len[r];
+    const f32x4_t xr[2] = {x0, x1};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) ig[r] = cfsig(pi[r] + xr[r][0] + wci * c[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) gg[r] = cftanh(pq[r] + xr[r][1]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) fg[r] = cfsig(pf[r] + xr[r][2] + forget_bias + wcf * c[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      cn[r] = gg[r] * ig[r] + c[r] * fg[r];
+      if (cell_clip > 0.f) cn[r] = fminf(fmaxf(cn[r], -cell_clip), cell_clip);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) og[r] = cfsig(po[r] + xr[r][3] + wco * cn[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) hn[r] = cftanh(cn[r]) * og[r];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      c[r] = act[r] ? cn[r] : c[r];
+      hr[r] = act[r] ? hn[r] : hr[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      gpublish(uoff(slice(P, g), pofs + 8u * r), epoch, __float_as_uint(hr[r]), fast);
+      *reinterpret_cast<float*>(hnxt + lown[r]) = hr[r];
+    }
+    unsigned offs[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      offs[r] = act[r] ? oa[r] : os[r];
+      oa[r] += dstep;
+      os[r] += stride;
+    }
+    {
+      u64 v[G - 1][2];
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) v[k][j] = gload(uoff(slice(P, k + (k >= g ? 1 : 0)), lofs + 64u * j));
+      unsigned spins = 0;
+#pragma unroll 1
+      for (;;) {                                           // wave-uniform loop: no exec masking
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ok = ok && ((unsigned)(v[k][j] >> 32) == epoch);
+        if (__all(ok)) break;
+        if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) v[k][j] = gload(uoff(slice(P, k + (k >= g ? 1 : 0)), lofs + 64u * j));
+      }
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<unsigned*>(hnxt + ldst[k][j]) = (unsigned)v[k][j];
+    }
+    // saved activations behind the poll loop (loads and stores share the wave's in-order counter); rows past their
+    // length write frame s of the padding (hout: zeros; gates / cs: never read there)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      hout[offs[r]] = act[r] ? hr[r] : 0.f;
+      gates[offs[r]] = (f32x4_t){ig[r], gg[r], fg[r], og[r]};
+      cs[offs[r]] = cn[r];
+    }
+    __syncthreads();
+  };
+  int s = 0;
+  for (; s + 1 < tmax; s += 2) {
+    step(s, std::integral_constant<int, 0>{});
+    step(s + 1, std::integral_constant<int, 1>{});
+  }
+  if (s < tmax) step(s, std::integral_constant<int, 0>{});
+
+  if (timed_out) atomicOr(err, 1u);
+  for (int t = tmax; t < T_; ++t)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { hout[os[r]] = 0.f; os[r] += stride; }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const size_t o = ((size_t)d * B_ + b0 + rbase + r) * H + jw;
+    if (c_final) c_final[o] = c[r];
+    if (h_final) h_final[o] = hr[r];
+  }
+}
+
+// BPTT, fp32 operands: the H = 512 arrangement of the bf16 kernel (each tile computed ONCE: the hh = 0 waves take the
+// four own-unit tiles and hand rows 2,3 to their hh = 1 partners through LDS, the hh = 1 waves take the four tiles of
+// the peer's units and publish them) -- 64 K = 4 MFMAs per wave and step instead of the 128 + 64 of the redundant form.
+template <int H>
+__global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_f32_kernel(
+    int T_, int B_, int ndir, const float* __restrict__ dhout, const f32x4_t* __restrict__ gates,
+    const float* __restrict__ cs, const float* __restrict__ whpb, const float* __restrict__ peep,
+    const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
+    const float* __restrict__ d_h_final, f32x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
+    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+  static_assert(H / HS == 2, "one foreign tile per hh = 1 wave: two CUs per direction");
+  zero_next_area(znext, zwords);
+  constexpr int G = H / HS;
+  constexpr int KC = 4 * HS / 16;            // fragments of this CU's slice of k' (16)
+  constexpr int KSF = 4 * H / 16;            // fragments of the full packing
+  constexpr int LDG = 4 * HS + 4;            // floats: 65 x 16 B per row
+  constexpr size_t CL_U64 = XHDR + (size_t)2 * G * G * 4 * 64 * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DGB = 16 * LDG * 4;                        // bytes per dG image
+
+  const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
+  if (!cid.valid) return;
+  const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, rg = lane >> 4;
+  const int hh = wave >> 2, wt = wave & 3;
+  const bool rev = (d == 1);
+  const float* wp = whpb + (size_t)d * H * 4 * H;
+  const int ul = wt * 16 + col;
+  const unsigned jw = g * HS + ul;
+  const int rbase = rg * 4 + hh * 2;
+
+  int len[2];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) len[r] = seq_len[b0 + rbase + r];
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  const float wci = peep ? peep[(d * 3 + 0) * H + jw] : 0.f;
+  const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
+  const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
+
+  const unsigned stride = (unsigned)B_ * ndir * H;
+  const unsigned dstep = rev ? stride : 0u - stride;
+  unsigned oa[2], os[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned base = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+    os[r] = base + (unsigned)(tmax - 1) * stride;
+    oa[r] = base + (unsigned)(rev ? len[r] - tmax : tmax - 1) * stride;
+  }
+  {
+    const f32x4_t gzero = {0.f, 0.f, 0.f, 0.f};
+    for (int t = tmax; t < T_; ++t)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) dgates[os[r] + (unsigned)(t - tmax + 1) * stride] = gzero;
+  }
+
+  float dhr[2], dcr[2], cc[2];
+  float sums[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const size_t o = ((size_t)d * B_ + b0 + rbase + r) * H + jw;
+    dhr[r] = d_h_final ? d_h_final[o] : 0.f;
+    dcr[r] = d_c_final ? d_c_final[o] : 0.f;
+    cc[r] = (tmax > 0 && tmax - 1 < len[r]) ? cs[oa[r]] : 0.f;
+  }
+  // this wave's tile of W_h^T (rows k' of the CU's slice): hh = 0 the own-unit tile 4g + wt, hh = 1 tile wt of the peer
+  const int peer = 1 - g;
+  const int nt = (hh == 0 ? g : peer) * 4 + wt;
+  f32x4_t wf[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc)
+    wf[kc] = *reinterpret_cast<const f32x4_t*>(wp + (((size_t)nt * KSF + g * KC + kc) * 64 + lane) * 4);
+  float* ownx = reinterpret_cast<float*>(smem + 2 * DGB);  // [2 parity][4 tiles][64 lanes] x (row 2, row 3)
+
+  u64* xhdr = xch + (size_t)cid.c * CL_U64;
+  bool timed_out = false;
+  const bool fast = same_xcd<G>(xhdr, g, timed_out) && !(kflags & 1);
+  unsigned spin_limit = (kflags & 2) ? 2000u : SPIN_LIMIT;
+  if ((kflags & 2) && g == G - 1) return;                  // TEST ONLY: a member goes missing
+  f32x4_t* xs = reinterpret_cast<f32x4_t*>(xhdr + XHDR);   // [2][G dst][G src][4][64] x 16 B
+  auto uslot = [&](int par, int dst, int src_, int tile) -> f32x4_t* {
+    return xs + ((((size_t)par * G + dst) * G + src_) * 4 + tile) * 64;
+  };
+  const unsigned voff16 = (unsigned)lane * 16u;
+  const unsigned pofs = (unsigned)lane * 2u + hh;          // u64 index of this lane's two rows in a slot
+  const unsigned lwr[2] = {((unsigned)(rbase * LDG + ul * 4) * 4u) ^ lds_swz(rbase),
+                           ((unsigned)((rbase + 1) * LDG + ul * 4) * 4u) ^ lds_swz(rbase + 1)};
+  const unsigned lrd = ((unsigned)(col * LDG + rg * 4) * 4u) ^ lds_swz(col);
+
+  f32x4_t pg[2];
+  float pcp[2], pdh[2];
+  auto prefetch = [&](int s_) {                            // oa/os already hold iteration s_
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const bool act = s_ < len[r];
+      const bool ldp = (s_ > 0) && (s_ - 1 < len[r]);
+      const unsigned offl = act ? oa[r] : os[r];
+      const unsigned offn = ldp ? oa[r] + dstep : os[r];
+      pg[r] = gates[offl];
+      pcp[r] = cs[offn];
+      pdh[r] = dhout[offl];
+    }
+  };
+  if (tmax > 0) prefetch(tmax - 1);
+  __syncthreads();
+
+  auto step = [&](int s, auto PAR) {
+    constexpr int P = decltype(PAR)::value;                // parity of THIS iteration's publish
+    const int it = tmax - 1 - s;
+    // ---- 1. poll for the partial the peer published at the previous iteration (parity 1-P)
+    u64 pv = 0;
+    if (it > 0) pv = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, peer, wt)), pofs));
+    // ---- 2. everything that does not need dh
+    bool act[2], ldp[2];
+    float gi[2], gq[2], gf[2], go[2], cprev[2], a_o[2], b_c[2], c_g[2], c_i[2], c_f[2];
+    unsigned off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      act[r] = s < len[r];
+      ldp[r] = (s > 0) && (s - 1 < len[r]);
+      off[r] = act[r] ? oa[r] : os[r];
+      gi[r] = pg[r][0]; gq[r] = pg[r][1]; gf[r] = pg[r][2]; go[r] = pg[r][3];
+      cprev[r] = (act[r] && s > 0) ? pcp[r] : 0.f;
+    }
+    float tc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) tc[r] = cftanh(cc[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      a_o[r] = tc[r] * go[r] * (1.f - go[r]);
+      b_c[r] = go[r] * (1.f - tc[r] * tc[r]);
+      c_g[r] = gi[r] * (1.f - gq[r] * gq[r]);
+      c_i[r] = gq[r] * gi[r] * (1.f - gi[r]);
+      c_f[r] = cprev[r] * gf[r] * (1.f - gf[r]);
+    }
+    const float pdhv[2] = {pdh[0], pdh[1]}, pcpv[2] = {pcp[0], pcp[1]}, curv[2] = {cc[0], cc[1]};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { oa[r] += dstep; os[r] -= stride; }
+    // ---- 3. finish the poll: both words must carry the previous iteration's tag
+    if (it > 0) {
+      const unsigned want = (((unsigned)(it - 1) >> 1) + 1u) & 1u;
+      const u64 wmask = 0x0000000100000001ull, wtag = want ? wmask : 0ull;
+      unsigned spins = 0;
+#pragma unroll 1
+      for (;;) {
+        if (__all((pv & wmask) == wtag)) break;
+        if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+        pv = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, peer, wt)), pofs));
+      }
+      dhr[0] += __uint_as_float((unsigned)pv & ~1u);
+      dhr[1] += __uint_as_float((unsigned)(pv >> 32) & ~1u);
+    }
+    // next iteration's saved activations: requested BEHIND the poll loop (see the bf16 kernel)
+    if (s > 0) prefetch(s - 1);
+    // ---- 4. gate gradients of the own pairs
+    float zi[2], zg[2], zf[2], zo[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float dh = pdhv[r] + dhr[r];
+      const float d_o = dh * a_o[r];
+      const float dc = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float d_g = dc * c_g[r], d_i = dc * c_i[r], d_f = dc * c_f[r];
+      dcr[r] = act[r] ? (dc * gf[r] + d_i * wci + d_f * wcf) : dcr[r];
+      dhr[r] = act[r] ? 0.f : dhr[r];
+      zi[r] = act[r] ? d_i : 0.f; zg[r] = act[r] ? d_g : 0.f;
+      zf[r] = act[r] ? d_f : 0.f; zo[r] = act[r] ? d_o : 0.f;
+      cc[r] = ldp[r] ? pcpv[r] : 0.f;
+      const f32x4_t pk = {zi[r], zg[r], zf[r], zo[r]};
+      *reinterpret_cast<f32x4_t*>(smem + P * DGB + lwr[r]) = pk;
+      dgates[off[r]] = pk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      sums[0] += zi[r] * cprev[r]; sums[1] += zf[r] * cprev[r]; sums[2] += zo[r] * curv[r];
+      sums[3] += zi[r]; sums[4] += zg[r]; sums[5] += zf[r]; sums[6] += zo[r];
+    }
+    // ---- 5. partial dh_prev of this wave's tile from the own dG slice
+    if (s > 0) {
+      f32x4_t ac = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KC; kb += 8) {
+        f32x4_t afr[8];
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) afr[kc] = *reinterpret_cast<const f32x4_t*>(smem + P * DGB + lrd + (kb + kc) * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) ac = mma_f32(afr[kc], wf[kb + kc], ac);
+      }
+      if (hh == 1) {                                       // the peer's units: publish, every word tagged
+        const unsigned tag = (((unsigned)it >> 1) + 1u) & 1u;
+        f32x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __uint_as_float((__float_as_uint(ac[i]) & ~1u) | tag);
+        xstore16(uslot(P, peer, g, wt), voff16, o, fast);
+      } else {                                             // own units: rows 0,1 stay, rows 2,3 -> partner wave
+        dhr[0] += ac[0];
+        dhr[1] += ac[1];
+        float* o = ownx + ((P * 4 + wt) * 64 + lane) * 2;
+        o[0] = ac[2];
+        o[1] = ac[3];
+      }
+    }
+    __syncthreads();                                       // hand-over visible before the partner's next step
+    if (s > 0 && hh == 1) {
+      const float* o = ownx + ((P * 4 + wt) * 64 + lane) * 2;
+      dhr[0] += o[0];
+      dhr[1] += o[1];
+    }
+  };
+  int s = tmax - 1;
+  for (; s >= 1; s -= 2) {
+    step(s, std::integral_constant<int, 0>{});
+    step(s - 1, std::integral_constant<int, 1>{});
+  }
+  if (s == 0) step(0, std::integral_constant<int, 0>{});
+
+  if (timed_out) atomicOr(err, 2u);
+  if (dpeep_part) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      sums[k] += __shfl_xor(sums[k], 16, 64);
+      sums[k] += __shfl_xor(sums[k], 32, 64);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);           // [7][HS]
+    if (hh == 1 && rg == 0) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) red[k * HS + ul] = sums[k];
+    }
+    __syncthreads();
+    if (hh == 0 && rg == 0) {
+      float* p = dpeep_part + ((size_t)cid.tile * ndir + d) * 7 * H;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) p[k * H + jw] = sums[k] + red[k * HS + ul];
+    }
+  }
+}
+
 static unsigned long long* g_cdbg_host = nullptr;
 static void cdbg_setup() {
   static bool done = false;
@@ -938,6 +1418,52 @@ bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
   cdbg_setup();
   return H == 512 ? cluster_bwd_launch<512>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st)
                   : cluster_bwd_launch<256>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st);
+}
+
+// fp32 operands: H = 128 on two CUs per (direction, tile).  ASR_LSTM_CLUSTER_F32=0 keeps the single-CU kernels (A/B).
+static bool cluster_f32_enabled() {
+  static const bool on = [] { const char* e = getenv("ASR_LSTM_CLUSTER_F32"); return !(e && e[0] == '0'); }();
+  return on && cluster_enabled();
+}
+
+bool asr_cluster_fwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const float* xproj,
+                             const void* whp, const float* peep, const int32_t* seq_len, float fb,
+                             float clip, void* gates, void* hout, float* cs, float* cf, float* hf,
+                             hipStream_t st) {
+  constexpr int HH = 128, G = HH / HS;
+  if (!cluster_f32_enabled() || H != HH) return false;
+  const int ncl = (B / 16) * ndir;
+  const size_t need = (size_t)ncl * (XHDR + 2 * G * 16 * HS) * sizeof(u64);
+  if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
+      (int)cluster_grid(G, ncl) > h->num_cu)
+    return false;
+  char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+  const XchAreas xa = xch_take(h, base, need, st);
+  hipLaunchKernelGGL(lstm_fwd_cluster8_f32_kernel<HH>, dim3(cluster_grid(G, ncl)), dim3(CT8),
+                     (size_t)2 * 16 * (HH + 4) * 4, st, T, B, ndir, (const f32x4_t*)xproj, (const float*)whp, peep,
+                     seq_len, fb, clip, (f32x4_t*)gates, (float*)hout, cs, cf, hf, xa.area, (unsigned*)base,
+                     kernel_flags(), xa.znext, xa.zwords);
+  return true;
+}
+
+bool asr_cluster_bwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const float* dhout,
+                             const void* gates, const float* cs, const void* whpb, const float* peep,
+                             const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
+                             float* dpeep_part, hipStream_t st) {
+  constexpr int HH = 128, G = HH / HS;
+  if (!cluster_f32_enabled() || H != HH) return false;
+  const int ncl = (B / 16) * ndir;
+  const size_t need = (size_t)ncl * (XHDR + (size_t)2 * G * G * 4 * 64 * 2) * sizeof(u64);
+  if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
+      (int)cluster_grid(G, ncl) > h->num_cu)
+    return false;
+  char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+  const XchAreas xa = xch_take(h, base, need, st);
+  const size_t lds = (size_t)2 * 16 * (4 * HS + 4) * 4 + 2 * 4 * 64 * 8;   // two dG images + the hand-over buffer
+  hipLaunchKernelGGL(lstm_bwd_cluster8_f32_kernel<HH>, dim3(cluster_grid(G, ncl)), dim3(CT8), lds, st, T, B, ndir,
+                     dhout, (const f32x4_t*)gates, cs, (const float*)whpb, peep, seq_len, dcf, dhf, (f32x4_t*)dgates,
+                     dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
+  return true;
 }
 
 extern "C" int asr_debug_set_lstm_flags(int flags) { g_dflags = flags; return 0; }

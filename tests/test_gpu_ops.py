@@ -340,6 +340,58 @@ def test_lstm_cluster_exchange_paths(cuda):
     assert np.abs(res[0]['hout'] - ref['hout']).max() < 3e-2
 
 
+@pytest.mark.parametrize('T,B,ndir,clip', [(301, 16, 2, 0.0), (150, 32, 1, 2.0), (778, 16, 2, 50.0)])
+def test_lstm_cluster_f32_long_sequences(cuda, T, B, ndir, clip):
+    """fp32 operands at H = 128 (BASELINE configs[0]) run on the two-CU cluster kernels: forward values, final states and
+    every gradient the BPTT kernel produces against the fp64 oracle over hundreds of hand-offs, ragged lengths, with and
+    without the cell clip; both exchange flavours bit-identical; no hand-off may time out."""
+    ops = _ops()
+    rng = np.random.RandomState(T + B)
+    D, H = 24, 128
+    lens = rng.randint(1, T + 1, size=B)
+    lens[0], lens[3] = T, 1
+    x, ps = _lstm_case(rng, T, B, D, H, ndir, lens, init=0.1)
+    dout = rng.randn(T, B, ndir * H)
+    dfinal = (rng.randn(ndir, B, H) * 0.5, rng.randn(ndir, B, H) * 0.5)
+    res = []
+    try:
+        for flags in (0, 16):
+            ops.debug_set_lstm_flags(flags)
+            res.append(_run_hip_layer(cuda, x, ps, lens, H, ndir, 'f32', clip, dout, dfinal))
+            assert ops.check_async_errors(0) == 0
+    finally:
+        ops.debug_set_lstm_flags(0)
+    for k in ('hout', 'cf', 'hf', 'dgates', 'dpeep'):
+        assert np.array_equal(res[0][k], res[1][k]), k
+    got = res[0]
+    ref = _oracle_layer(x, ps, lens, ndir, clip, dout, dfinal)
+    assert np.abs(got['hout'] - ref['hout']).max() < 5e-5
+    assert np.abs(got['cf'] - ref['cf']).max() < 2e-4
+    assert np.abs(got['hf'] - ref['hf']).max() < 5e-5
+    dg = got['dgates'].astype(np.float64)
+    xt = np.transpose(x, (1, 0, 2))
+    hout = got['hout'].astype(np.float64)
+    dx = np.zeros_like(xt)
+    for d, p in enumerate(ps):
+        dd = d if ndir == 2 else 0
+        g = dg[:, :, dd * 4 * H:(dd + 1) * 4 * H].reshape(T * B, 4 * H)
+        w = p['w'].detach().numpy()
+        hp = np.zeros((T, B, H))
+        if d == 0:
+            hp[1:] = hout[:-1, :, :H]
+        else:
+            hp[:-1] = hout[1:, :, H:2 * H]
+        assert _rel(np.concatenate([xt.reshape(T * B, D).T @ g, hp.reshape(T * B, H).T @ g], 0), ref['dw'][d]) < 2e-4
+        assert _rel(got['dpeep'][d, 3:7].reshape(-1), ref['db'][d]) < 2e-4
+        dx += (g @ w[:D].T).reshape(T, B, D)
+    assert _rel(dx, ref['dx']) < 2e-4
+    assert _rel(got['dpeep'][:, :3], ref['dpeep']) < 2e-4
+    for b in range(B):
+        if lens[b] < T:
+            assert np.abs(got['hout'][lens[b]:, b]).max() == 0
+            assert np.abs(got['dgates'][lens[b]:, b]).max() == 0
+
+
 def test_cluster_handoff_timeout_is_reported(cuda):
     """A hand-off that times out must not go unnoticed: with the test-only flag (one member of every cluster leaves
     early, spin limit 2000 polls) the sticky error word is raised, the blocking check raises at the next sync point,
