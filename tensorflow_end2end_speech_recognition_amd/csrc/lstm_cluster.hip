@@ -845,7 +845,9 @@ __device__ __forceinline__ f32x4_t mma_f32(const f32x4_t& a, const f32x4_t& b, f
   return c;
 }
 
-template <int H>
+// EARLY: as in the bf16 kernel, the fragments of the CU's OWN slice of h (half of K with two CUs) are multiplied for
+// step s+1 right after they are written, before the wave starts polling for the peer's half.
+template <int H, bool EARLY>
 __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
     int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const float* __restrict__ whp,
     const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
@@ -857,6 +859,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
   constexpr int KS = H / 16;                               // fragments of k = 16 (four K = 4 MFMAs each)
   constexpr int LDH = H + 4;                               // floats: 33 x 16 B at H = 128, like the bf16 image
   constexpr int SLICE = 16 * HS;                           // granules one CU publishes per step
+  constexpr int KO = HS / 16;                              // fragments of one CU's own slice
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* hs = reinterpret_cast<float*>(smem);              // [2][16][LDH]
 
@@ -892,8 +895,10 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
   for (int p = 0; p < 2; ++p) {
     const int tile = (jw >> 4) * 4 + p * 2 + (col >> 3);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      wreg[p][ks] = *reinterpret_cast<const f32x4_t*>(wp + (((size_t)tile * KS + ks) * 64 + rg * 16 + (jw & 15)) * 4);
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kk = EARLY ? ((ks + g * KO) & (KS - 1)) : ks;   // EARLY: register fragment ks holds k-fragment kk
+      wreg[p][ks] = *reinterpret_cast<const f32x4_t*>(wp + (((size_t)tile * KS + kk) * 64 + rg * 16 + (jw & 15)) * 4);
+    }
   }
 
   u64* xhdr = xch + (size_t)cid.c * (XHDR + 2 * G * SLICE);
@@ -939,6 +944,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
     xq[0][r] = xg[(0 < len[r]) ? oa[r] : os[r]];
     xq[1][r] = (tmax > 1) ? xg[(1 < len[r]) ? oa[r] + dstep : os[r] + stride] : xq[0][r];
   }
+  f32x4_t accn0 = {0.f, 0.f, 0.f, 0.f}, accn1 = {0.f, 0.f, 0.f, 0.f};   // EARLY: own-slice part of the next step
 
   auto step = [&](int s, auto PAR) {
     constexpr int P = decltype(PAR)::value;
@@ -951,13 +957,16 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
         xq[P][r] = xg[(s + 2 < len[r]) ? oa[r] + 2u * dstep : os[r] + 2u * stride];
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EARLY) { acc0 = accn0; acc1 = accn1; }    // own-slice fragments: done at the end of the last step
     {
+      constexpr int K0 = EARLY ? KO : 0;
       f32x4_t afr[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) afr[ks] = *reinterpret_cast<const f32x4_t*>(hcur + lrd + ks * 64);
+      for (int ks = K0; ks < KS; ++ks)
+        afr[ks] = *reinterpret_cast<const f32x4_t*>(hcur + lrd + (EARLY ? ((ks + g * KO) & (KS - 1)) : ks) * 64);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) mma_f32x2(afr[ks], wreg[0][ks], wreg[1][ks], acc0, acc1);
+      for (int ks = K0; ks < KS; ++ks) mma_f32x2(afr[ks], wreg[0][ks], wreg[1][ks], acc0, acc1);
     }
     float pi[2], pq[2], pf[2], po[2];
 #pragma unroll
@@ -1004,6 +1013,18 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
       offs[r] = act[r] ? oa[r] : os[r];
       oa[r] += dstep;
       os[r] += stride;
+    }
+    if constexpr (EARLY) {
+      if (s + 1 < tmax) {                                  // block-uniform
+        __syncthreads();                                   // the CU's own slice of h(s) is complete in hnxt
+        f32x4_t ao[KO];
+#pragma unroll
+        for (int k = 0; k < KO; ++k) ao[k] = *reinterpret_cast<const f32x4_t*>(hnxt + lrd + ((k + g * KO) & (KS - 1)) * 64);
+        accn0 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        accn1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KO; ++k) mma_f32x2(ao[k], wreg[0][k], wreg[1][k], accn0, accn1);
+      }
     }
     {
       u64 v[G - 1][2];
@@ -1244,6 +1265,9 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_f32_kernel(
     // ---- 5. partial dh_prev of this wave's tile from the own dG slice
     if (s > 0) {
       f32x4_t ac = {0.f, 0.f, 0.f, 0.f};
+      // the tile the peer waits for outranks its SIMD sibling's own-unit tile (nobody waits for that one before the
+      // next step's gate math): it is published after ~half of the SIMD's MFMA time instead of all of it
+      if (hh == 1 && !(kflags & 8)) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int kb = 0; kb < KC; kb += 8) {
         f32x4_t afr[8];
@@ -1259,6 +1283,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_f32_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = __uint_as_float((__float_as_uint(ac[i]) & ~1u) | tag);
         xstore16(uslot(P, peer, g, wt), voff16, o, fast);
+        __builtin_amdgcn_s_setprio(0);
       } else {                                             // own units: rows 0,1 stay, rows 2,3 -> partner wave
         dhr[0] += ac[0];
         dhr[1] += ac[1];
@@ -1317,6 +1342,8 @@ static void cdbg_setup() {
 static int g_dflags = -1;
 // bit 4 (16): force the placement-independent write-through exchange
 // bit 5 (32): invert the default choice of the EARLY forward variant (A/B measurements)
+// bit 7 (128): BPTT kernel requests the next iteration's saved activations ahead of the poll loop (the old place; A/B)
+// bit 8 (256): fp32 BPTT kernel without the priority of the published tile's MFMAs (A/B)
 // bit 6 (64): TEST ONLY -- the last member of every cluster leaves right after the placement handshake and the
 //             spin limit drops to 2000 polls, so every hand-off times out (tests/test_gpu_ops.py checks that the
 //             error word is raised and surfaces as an exception)
@@ -1324,7 +1351,10 @@ static int dbg_flags() {
   if (g_dflags < 0) { const char* e = getenv("ASR_LSTM_DFLAGS"); g_dflags = e ? atoi(e) : 0; }
   return g_dflags;
 }
-static int kernel_flags() { return ((dbg_flags() & 16) ? 1 : 0) | ((dbg_flags() & 64) ? 2 : 0) | ((dbg_flags() & 128) ? 4 : 0); }
+static int kernel_flags() {
+  return ((dbg_flags() & 16) ? 1 : 0) | ((dbg_flags() & 64) ? 2 : 0) | ((dbg_flags() & 128) ? 4 : 0) |
+         ((dbg_flags() & 256) ? 8 : 0);
+}
 static bool cluster_enabled() {
   static const bool on = [] { const char* e = getenv("ASR_LSTM_CLUSTER"); return !(e && e[0] == '0'); }();
   return on;
@@ -1439,7 +1469,9 @@ bool asr_cluster_fwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const
     return false;
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
   const XchAreas xa = xch_take(h, base, need, st);
-  hipLaunchKernelGGL(lstm_fwd_cluster8_f32_kernel<HH>, dim3(cluster_grid(G, ncl)), dim3(CT8),
+  const bool early = (dbg_flags() & 32) == 0;              // ASR_LSTM_DFLAGS bit 5 inverts the default (A/B)
+  auto k = early ? lstm_fwd_cluster8_f32_kernel<HH, true> : lstm_fwd_cluster8_f32_kernel<HH, false>;
+  hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8),
                      (size_t)2 * 16 * (HH + 4) * 4, st, T, B, ndir, (const f32x4_t*)xproj, (const float*)whp, peep,
                      seq_len, fb, clip, (f32x4_t*)gates, (float*)hout, cs, cf, hf, xa.area, (unsigned*)base,
                      kernel_flags(), xa.znext, xa.zwords);
