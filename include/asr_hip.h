@@ -301,7 +301,9 @@ int asr_peek_async_errors(asr_handle* h, unsigned* host_flags, asr_stream s);
 /* Resets the sticky error word (after it has been reported). */
 int asr_clear_async_errors(asr_handle* h, asr_stream s);
 /* Debug / test switches of the cluster kernels (process-wide, same bits as the environment variable ASR_LSTM_DFLAGS):
- * 16 = force the placement-independent write-through exchange, 64 = TEST ONLY, make every hand-off time out. */
+ * 16 = force the placement-independent write-through exchange, 64 = TEST ONLY, make every hand-off time out;
+ * 32 / 128 / 256 = A-B switches of kernel variants (own-slice products ahead of the poll, the BPTT kernel's fetch ahead of
+ * its poll loop, MFMA priority in the fp32 BPTT kernel), result-neutral. */
 int asr_debug_set_lstm_flags(int flags);
 
 /* Debug: records, per workgroup of a probe grid launched on `s`, {XCC id, HW_ID register} into out[2*nblocks]
