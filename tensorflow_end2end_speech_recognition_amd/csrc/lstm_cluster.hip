@@ -209,6 +209,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if constexpr (EARLY) {
+        static_assert((KS & (KS - 1)) == 0, "EARLY rotates the chunk order with a mask");
         const int kk = (ks + g * KO) & (KS - 1);           // register chunk ks holds k-chunk kk
         wreg[p][ks] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)tile * KS + kk) * 64 + rg * 16 + (jw & 15)) * 8);
       } else {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   // xproj rows of the running step, requested TWO steps ahead (slot = step parity): one step (~1.2 us) covers the
   // idle HBM latency but not always the latency beside the side streams' traffic (measured: 945 -> 931 us per launch)
   // (H = 512 keeps the one-step queue: the second slot costs 8 VGPRs the 8-CU form does not have -- 4 -> 12 spills)
-  constexpr int XD = (H == 256) ? 2 : 1;
+  constexpr int XD = (H <= 320) ? 2 : 1;
   f32x4_t xq[XD][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
       bf16x8_t afr[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
+        if (kb + ks >= KS) continue;                       // H = 320: 10 chunks = 8 + 2
         if constexpr (EARLY) {
           if (kb + ks >= KO) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + ((kb + ks + g * KO) & (KS - 1)) * 64);
         } else {
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         if (EARLY && kb + ks < KO) continue;
+        if (kb + ks >= KS) continue;
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[0][kb + ks], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[1][kb + ks], acc1, 0, 0, 0);
       }
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
     for (int r = 0; r < 2; ++r) off[r] = act[r] ? oa[r] : os[r];
     // H = 256: the saved activations are stored BEHIND the poll loop, see there.  H = 512 stores them here: keeping the
     // values alive across the loop costs registers that form has not got (4 -> 12 spills, 43.3 -> 47.7 ms at cfg D).
-    constexpr bool LATE_STORE = (H == 256);
+    constexpr bool LATE_STORE = (H <= 320);
     unsigned offs[2] = {off[0], off[1]};
     if constexpr (!LATE_STORE) {
       const bool pact = odd ? act[1] : act[0];
@@ -1359,6 +1362,12 @@ static bool cluster_enabled() {
   static const bool on = [] { const char* e = getenv("ASR_LSTM_CLUSTER"); return !(e && e[0] == '0'); }();
   return on;
 }
+// H = 320 (the width of most of the reference's recipes): five CUs per (direction, tile).  ASR_LSTM_CLUSTER_320=0
+// keeps the single-CU kernels for that width (A/B).
+static bool cluster_320_enabled() {
+  static const bool on = [] { const char* e = getenv("ASR_LSTM_CLUSTER_320"); return !(e && e[0] == '0'); }();
+  return on;
+}
 }  // namespace
 
 static constexpr size_t XCH_BYTES = ASR_XCH_BYTES;
@@ -1400,8 +1409,13 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   // EARLY (own-slice k-chunks multiplied under the L2 hop): measured at H = 256 (round 2, cfg B): 970 -> 938 us per
   // launch; default there.  ASR_LSTM_DFLAGS bit 5 (32) inverts the default for A/B measurements.
   const bool early = (H == 256) != ((dbg_flags() & 32) != 0);
-  auto k = g_cdbg_host ? lstm_fwd_cluster8_kernel<H, true>
-                       : (early ? lstm_fwd_cluster8_kernel<H, false, true> : lstm_fwd_cluster8_kernel<H, false, false>);
+  auto k = lstm_fwd_cluster8_kernel<H, false, false>;
+  if constexpr (H == 320) {                                // 10 k-chunks: no EARLY form (its chunk rotation is a mask)
+    if (g_cdbg_host) k = lstm_fwd_cluster8_kernel<H, true>;
+  } else {
+    k = g_cdbg_host ? lstm_fwd_cluster8_kernel<H, true>
+                    : (early ? lstm_fwd_cluster8_kernel<H, false, true> : lstm_fwd_cluster8_kernel<H, false, false>);
+  }
   hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8), (size_t)2 * 16 * (H + 8) * 2, st, T, B, ndir,
                      (const f32x4_t*)xproj, (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates,
                      (bf16_t*)hout, cs, cf, hf, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
@@ -1412,8 +1426,9 @@ bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
                          const void* whp, const float* peep, const int32_t* seq_len, float fb,
                          float clip, void* gates, void* hout, float* cs, float* cf, float* hf,
                          hipStream_t st) {
-  if (!cluster_enabled() || (H != 256 && H != 512)) return false;
+  if (!cluster_enabled() || (H != 256 && H != 512 && !(H == 320 && cluster_320_enabled()))) return false;
   cdbg_setup();
+  if (H == 320) return cluster_fwd_launch<320>(h, T, B, ndir, xproj, whp, peep, seq_len, fb, clip, gates, hout, cs, cf, hf, st);
   return H == 512 ? cluster_fwd_launch<512>(h, T, B, ndir, xproj, whp, peep, seq_len, fb, clip, gates, hout, cs, cf, hf, st)
                   : cluster_fwd_launch<256>(h, T, B, ndir, xproj, whp, peep, seq_len, fb, clip, gates, hout, cs, cf, hf, st);
 }
@@ -1444,8 +1459,10 @@ bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
                          const void* gates, const float* cs, const void* whpb, const float* peep,
                          const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
                          float* dpeep_part, hipStream_t st) {
-  if (!cluster_enabled() || (H != 256 && H != 512)) return false;
+  if (!cluster_enabled() || (H != 256 && H != 512 && !(H == 320 && cluster_320_enabled()))) return false;
   cdbg_setup();
+  if (H == 320)
+    return cluster_bwd_launch<320>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st);
   return H == 512 ? cluster_bwd_launch<512>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st)
                   : cluster_bwd_launch<256>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st);
 }

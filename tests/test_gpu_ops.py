@@ -435,8 +435,9 @@ def _err_stats(got, ref):
     return d.max() / max(np.abs(ref).max(), 1e-30), d.mean() / max(np.abs(ref).mean(), 1e-30)
 
 
-# (H, B, T, cell_clip): the shapes bench.py times (cfg B: H=256, B=16, T<=778) and the cfg C/D width
-HEADLINE_LSTM = [(256, 16, 778, 50.0), (256, 32, 300, 1.0), (512, 16, 300, 50.0), (512, 32, 778, 50.0)]
+# (H, B, T, cell_clip): the shapes bench.py times (cfg B: H=256, B=16, T<=778), the cfg C/D width and H = 320
+HEADLINE_LSTM = [(256, 16, 778, 50.0), (256, 32, 300, 1.0), (512, 16, 300, 50.0), (512, 32, 778, 50.0),
+                 (320, 16, 250, 50.0), (320, 32, 90, 1.0)]      # 320: the width of most of the reference's recipes (5 CUs)
 
 
 @pytest.mark.parametrize('H,B,T,clip', HEADLINE_LSTM)
