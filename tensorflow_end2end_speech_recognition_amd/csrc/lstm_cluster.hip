@@ -175,6 +175,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   // 1-D grid laid out so that the G workgroups of a cluster get block ids congruent mod 8: the
   // dispatcher is observed to put block b on XCD b % 8, so a cluster shares ONE L2 (speed only:
   // the placement is verified below and the exchange falls back to write-through stores)
+  // EARLY: k-chunk index modulo KS (a mask where KS is a power of two; H = 320 has 10 chunks: x < 2 KS there)
+  auto krot = [](int x) -> int { return ((KS & (KS - 1)) == 0) ? (x & (KS - 1)) : (x >= KS ? x - KS : x); };
   const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
   if (!cid.valid) return;
   const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
@@ -209,8 +211,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if constexpr (EARLY) {
-        static_assert((KS & (KS - 1)) == 0, "EARLY rotates the chunk order with a mask");
-        const int kk = (ks + g * KO) & (KS - 1);           // register chunk ks holds k-chunk kk
+        const int kk = krot(ks + g * KO);                  // register chunk ks holds k-chunk kk
         wreg[p][ks] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)tile * KS + kk) * 64 + rg * 16 + (jw & 15)) * 8);
       } else {
         wreg[p][ks] = *reinterpret_cast<const bf16x8_t*>(wp + (((size_t)tile * KS + ks) * 64 + rg * 16 + (jw & 15)) * 8);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
       for (int ks = 0; ks < 8; ++ks) {
         if (kb + ks >= KS) continue;                       // H = 320: 10 chunks = 8 + 2
         if constexpr (EARLY) {
-          if (kb + ks >= KO) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + ((kb + ks + g * KO) & (KS - 1)) * 64);
+          if (kb + ks >= KO) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + krot(kb + ks + g * KO) * 64);
         } else {
           afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + (kb + ks) * 64);
         }
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
         __syncthreads();                                   // the CU's own slice of h(s) is complete in hnxt
         bf16x8_t ao[KO];
 #pragma unroll
-        for (int k = 0; k < KO; ++k) ao[k] = *reinterpret_cast<const bf16x8_t*>(hnxt + lrd + ((k + g * KO) & (KS - 1)) * 64);
+        for (int k = 0; k < KO; ++k) ao[k] = *reinterpret_cast<const bf16x8_t*>(hnxt + lrd + krot(k + g * KO) * 64);
         accn0 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         accn1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1407,15 +1408,10 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
   const XchAreas xa = xch_take(h, base, need, st);
   // EARLY (own-slice k-chunks multiplied under the L2 hop): measured at H = 256 (round 2, cfg B): 970 -> 938 us per
-  // launch; default there.  ASR_LSTM_DFLAGS bit 5 (32) inverts the default for A/B measurements.
-  const bool early = (H == 256) != ((dbg_flags() & 32) != 0);
-  auto k = lstm_fwd_cluster8_kernel<H, false, false>;
-  if constexpr (H == 320) {                                // 10 k-chunks: no EARLY form (its chunk rotation is a mask)
-    if (g_cdbg_host) k = lstm_fwd_cluster8_kernel<H, true>;
-  } else {
-    k = g_cdbg_host ? lstm_fwd_cluster8_kernel<H, true>
-                    : (early ? lstm_fwd_cluster8_kernel<H, false, true> : lstm_fwd_cluster8_kernel<H, false, false>);
-  }
+  // launch, at H = 320: 1069 -> 969; default at both.  ASR_LSTM_DFLAGS bit 5 (32) inverts the default for A/B measurements.
+  const bool early = (H == 256 || H == 320) != ((dbg_flags() & 32) != 0);   // H = 320: 1069 -> 969 us per launch
+  auto k = g_cdbg_host ? lstm_fwd_cluster8_kernel<H, true>
+                       : (early ? lstm_fwd_cluster8_kernel<H, false, true> : lstm_fwd_cluster8_kernel<H, false, false>);
   hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8), (size_t)2 * 16 * (H + 8) * 2, st, T, B, ndir,
                      (const f32x4_t*)xproj, (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates,
                      (bf16_t*)hout, cs, cf, hf, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
