@@ -51,11 +51,7 @@ def _num_classes(params):
 
 def _bcast(value, src=0):
     """rank 0's decision (float) to every rank."""
-    if not multi_gpu.is_distributed():
-        return value
-    obj = [value]
-    torch.distributed.broadcast_object_list(obj, src=src)
-    return obj[0]
+    return multi_gpu.broadcast_decision(value, src=src)
 
 
 def _tower_eval(model, inputs, labels, seq_len, padded_value, beam_width):

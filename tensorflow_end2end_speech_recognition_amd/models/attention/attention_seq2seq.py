@@ -328,6 +328,10 @@ class AttentionSeq2Seq(ModelBase):
         ctc_tape = None
         if lam is not None:
             ops.wait_event(ctc_event)
+            if not is_training:
+                # no backward pass will join the side lane: release the encoder outputs it holds for the CTC head now
+                # (a dev-loss loop would otherwise pin one [T,B,2H] tensor per evaluated batch)
+                ops.join_side(dev)
             ctc_logits, ctc_mean, ctc_tape = self._ctc_head_finish(ctc_pending, B)
             total = (1.0 - lam) * seq_loss + lam * ctc_mean
         if self.weight_decay > 0:

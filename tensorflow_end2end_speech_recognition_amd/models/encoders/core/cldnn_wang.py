@@ -157,7 +157,13 @@ class CLDNNEncoder(BLSTMEncoder):
             self.build(store, inputs.shape[-1], np.random.RandomState(self.seed))
             store.finalize()
         st = self.store
-        rs = rng_state or (self.seed, 1 << 50)
+        rs = rng_state
+        if rs is None:
+            # an encoder used on its own (the models pass their state): fresh masks for the conv stack / fc1 every
+            # training call, as tf.nn.dropout draws them (own seed: the BLSTM stack below counts its calls itself)
+            if is_training and keep_prob is not None and float(keep_prob) < 1.0:
+                self._front_calls = getattr(self, '_front_calls', 0) + 1
+            rs = (self.seed + 7, getattr(self, '_front_calls', 0) << 40)
         x = self.front.forward(inputs.contiguous(), float(keep_prob), is_training, rs)
         want = self.want_f32_outputs
         self.want_f32_outputs = False

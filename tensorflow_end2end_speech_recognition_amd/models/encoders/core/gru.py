@@ -186,6 +186,9 @@ class _GRUEncoderBase(object):
             dx = self.layers[li].backward(dx.contiguous(), None, need_dx=(li > 0 or need_input_grad))
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(li, self.layers[li])
+        # the model's head gradients were issued on side lane 1 (CTC._backward): clip / all-reduce / update on the main
+        # stream must be ordered after them, and the lane's keep list is only released here (blstm.py does the same)
+        ops.join_side(d_outputs.device)
         return dx
 
 

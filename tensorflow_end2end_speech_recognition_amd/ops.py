@@ -6,6 +6,7 @@ there is no CPU fallback: non-CUDA tensors raise.
 """
 import ctypes as C
 import os
+import time as _time
 
 import numpy as np
 import torch
@@ -64,7 +65,7 @@ class side_lane(object):
         if st is None:
             st = _side[(self.dev, self.lane)] = dict(stream=torch.cuda.Stream(device=self.dev), keep=[])
         st['keep'].extend(self.keep)
-        st['stream'].wait_stream(torch.cuda.current_stream(self.dev))
+        st['stream'].wait_stream(_cur_stream(self.dev))
         self._ctx = torch.cuda.stream(st['stream'])
         self._ctx.__enter__()
         self._prev = _lane
@@ -108,7 +109,7 @@ def join_side(device):
     for (d, lane), st in _side.items():
         if d != dev:
             continue
-        torch.cuda.current_stream(dev).wait_stream(st['stream'])
+        _cur_stream(dev).wait_stream(st['stream'])
         st['keep'] = []
 
 
@@ -116,17 +117,36 @@ def stream_event():
     """Event recorded on the CURRENT stream (inside a side_lane block: on that lane).  wait_event(ev) makes the
     then-current stream wait for exactly this point instead of for everything on the other stream."""
     ev = torch.cuda.Event()
-    ev.record()
+    ev.record(_cur_stream())
     return ev
 
 
 def wait_event(ev):
     if ev is not None:
-        torch.cuda.current_stream().wait_event(ev)
+        _cur_stream().wait_event(ev)
+
+
+_stream_objs = {}
+
+
+def _raw_stream(dev=None):
+    """Raw hipStream_t of torch's current stream (torch.cuda.current_stream() resolves the device through four Python
+    layers every time: 1.1 ms of a 3.8 ms step issue at ~160 calls per step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice() if dev is None else dev)
+
+
+def _cur_stream(dev=None):
+    """torch.cuda.current_stream(dev) as a cached Stream object, looked up by its raw handle."""
+    raw = _raw_stream(dev)
+    key = (dev, raw)
+    so = _stream_objs.get(key)
+    if so is None:
+        so = _stream_objs[key] = torch.cuda.current_stream(dev)
+    return so
 
 
 def _s():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream())
 
 
 def _p(t):
@@ -614,7 +634,10 @@ def gru_fwd(xg, xc, wgh, wch, seq_len, tmax, H, ndir):
     if G != ndir * 2 * H or tuple(xc.shape) != (T, B, ndir * H):
         raise ValueError('gru_fwd: xg / xc shapes do not match ndir, H')
     dev = xg.device
-    out = {k: torch.empty((T, B, ndir * H), dtype=torch.float32, device=dev) for k in ('r', 'u', 'c', 'rh', 'hout')}
+    out = {k: torch.empty((T, B, ndir * H), dtype=torch.float32, device=dev) for k in ('r', 'u', 'c', 'hout')}
+    # rh is contracted over ALL T*B rows into the candidate kernel's recurrent gradient (with dcand = 0 at padded frames):
+    # the kernel skips inactive rows, so they must hold zeros, not allocator leftovers (0 * NaN = NaN)
+    out['rh'] = torch.zeros((T, B, ndir * H), dtype=torch.float32, device=dev)
     hs = torch.empty((2, ndir, B, H), dtype=torch.float32, device=dev)
     h.check(h.lib.asr_gru_fwd(h.h, T, B, H, ndir, _p(xg), _p(xc), _p(wgh), _p(wch), _p(seq_len), int(tmax),
                               _p(out['r']), _p(out['u']), _p(out['c']), _p(out['rh']), _p(out['hout']), _p(hs), _s()),
@@ -664,12 +687,17 @@ class ErrorWatch(object):
         self.host = torch.zeros(self.DEPTH, dtype=torch.int32).pin_memory()
         self.events = [None] * self.DEPTH
         self.i = 0
+        self.waited_s = 0.0   # host time spent blocked on a step armed DEPTH polls ago (bench.py subtracts it)
 
     def poll(self):
         slot = self.i % self.DEPTH
         ev = self.events[slot]
         if ev is not None:
-            ev.synchronize()
+            if not ev.query():
+                # the host is DEPTH steps ahead of the device: this wait is the throttle of the issue loop, not issue work
+                t0 = _time.perf_counter()
+                ev.synchronize()
+                self.waited_s += _time.perf_counter() - t0
             flags = int(self.host[slot])
             if flags:
                 h = _lib.handle(self.dev)
@@ -681,12 +709,18 @@ class ErrorWatch(object):
         h.check(h.lib.asr_peek_async_errors(h.h, C.c_void_p(self.host.data_ptr() + 4 * slot), _s()),
                 'asr_peek_async_errors')
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(_cur_stream())
         self.events[slot] = ev
         self.i += 1
 
 
 _watches = {}
+
+
+def watch_waited_seconds(device=0):
+    """Cumulative host time the device's ErrorWatch spent blocked behind the GPU (0 if none exists yet)."""
+    w = _watches.get(device.index or 0 if isinstance(device, torch.device) else int(device))
+    return w.waited_s if w is not None else 0.0
 
 
 def watch_async_errors(device):

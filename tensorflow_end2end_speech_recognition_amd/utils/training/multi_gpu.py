@@ -13,6 +13,8 @@ ONE bucket (average_gradients: 28 MB for the 5x256 BLSTM) where that does not ap
 then applies the identical optimizer step, so replicas stay bit-identical without a broadcast
 after step 0.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -127,9 +129,11 @@ class BucketedAverager(object):
         self.enc = enc if hasattr(enc, 'grad_ready_hook') else None
         layers = list(getattr(self.enc, 'layers', None) or [])
         self.layers = layers
-        self.buckets = []
+        self.buckets = []          # one per GROUP of consecutive layers, top group first
+        self.trigger = {}          # lowest layer index of a group -> index into self.buckets
         self.ok = bool(layers) and not float(getattr(model, 'weight_decay', 0.0) or 0.0) > 0.0
         covered = []
+        runs = []
         if self.ok:
             for layer in layers:
                 names = layer.var_names()
@@ -137,9 +141,29 @@ class BucketedAverager(object):
                 if idx != list(range(idx[0], idx[0] + len(idx))):
                     self.ok = False                       # not one contiguous run: keep the single bucket
                     break
-                b = st.bucket(names[0], names[-1])
+                runs.append((names[0], names[-1], idx[0], idx[-1]))
+            if self.ok and any(runs[i][3] + 1 != runs[i + 1][2] for i in range(len(runs) - 1)):
+                self.ok = False                           # layers not back to back in the flat buffer
+        if self.ok:
+            # small layers share a collective: an all-reduce below a few MB is latency-bound on xGMI (ring set-up + one
+            # launch per call, each also a few CUs beside the recurrence), so consecutive layers -- top down, the order
+            # the backward pass finishes them -- are coalesced until the group holds ASR_DP_BUCKET_MB (default 6 MB:
+            # three layers at 5x256, every layer alone at 5x512); the group goes out when its LOWEST layer is ready
+            self.bucket_min_bytes = int(float(os.environ.get('ASR_DP_BUCKET_MB', '6')) * (1 << 20))
+            hi = len(runs) - 1
+            while hi >= 0:
+                lo, nbytes = hi, 0
+                while True:
+                    nbytes += 4 * int(st.offsets_host[runs[lo][3] + 1] - st.offsets_host[runs[lo][2]])
+                    if nbytes >= self.bucket_min_bytes or lo == 0:
+                        break
+                    lo -= 1
+                self.trigger[lo] = len(self.buckets)
+                b = st.bucket(runs[lo][0], runs[hi][1])
+                b['layers'] = (lo, hi)
                 self.buckets.append(b)
-                covered.append((idx[0], idx[-1]))
+                covered.append((runs[lo][2], runs[hi][3]))
+                hi = lo - 1
         self.rest = []
         if self.ok:
             taken = set()
@@ -179,14 +203,18 @@ class BucketedAverager(object):
 
     def layer_ready(self, li, layer):
         """Hook of encoder.backward(): layer li's gradient GEMMs have been issued."""
-        self._seen.add(li)
+        bi = self.trigger.get(li)
+        if bi is None:
+            return                       # a higher layer of a coalesced group: goes out with the group's lowest layer
+        self._seen.add(bi)
         cs = self._comm()
         if cs is None:
-            self._reduce(self.buckets[li])
+            self._reduce(self.buckets[bi])
             return
         with torch.cuda.stream(cs):
+            # side lane 1 is in order: the lowest layer's event implies the gradients of the layers above it
             ops.wait_event(layer.grad_event)
-            self._reduce(self.buckets[li])
+            self._reduce(self.buckets[bi])
 
     def finish(self):
         """After the backward pass (or for a rank with an empty shard, whose gradients are zero): the layers the hook
@@ -201,9 +229,9 @@ class BucketedAverager(object):
         if ctx is not None:
             ctx.__enter__()
         try:
-            for li in reversed(range(len(self.buckets))):
-                if li not in self._seen:
-                    self._reduce(self.buckets[li])
+            for bi in range(len(self.buckets)):          # top group first, as the hook issues them
+                if bi not in self._seen:
+                    self._reduce(self.buckets[bi])
             for b in self.rest:
                 self._reduce(b)
         finally:
@@ -265,15 +293,55 @@ def init_process_group(device):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         device = torch.device(device)
-        # rank 0 alone evaluates dev / test sets at epoch ends while the others wait in a collective
-        # (examples/librispeech/training/train_ctc.py): far longer than the default 10-minute watchdog
+        # training collectives keep a short watchdog: a rank that dies (ErrorWatch / AsrError, any exception) must not
+        # leave the others blocked in the per-layer all-reduces for hours.  The one long wait of the recipes -- rank 0
+        # alone evaluates dev / test sets at epoch ends (examples/librispeech/training/train_ctc.py) -- goes through
+        # broadcast_decision(), which has its own long-timeout group
         import datetime
-        timeout = datetime.timedelta(hours=float(os.environ.get('ASR_DIST_TIMEOUT_HOURS', '6')))
+        timeout = datetime.timedelta(minutes=float(os.environ.get('ASR_DIST_TIMEOUT_MINUTES', '10')))
         if device.type == 'cuda':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device, timeout=timeout)
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world, timeout=timeout)
+        if device.type == 'cuda':
+            warm_up_collectives(device)
     return rank, world
+
+
+def warm_up_collectives(device):
+    """RCCL bootstrap (ring / tree setup over xGMI, the C ABI's own communicator) and one tiny all-reduce on each path
+    NOW, at start-up, instead of inside the first training step -- where its seconds would land in step 1 of every
+    rank and, with ranks bootstrapping at different speeds, in the watchdog."""
+    if not is_distributed():
+        return
+    device = torch.device(device)
+    t = torch.ones(256, dtype=torch.float32, device=device)
+    dist.all_reduce(t)
+    comm = native_comm(device)
+    if comm is not None:
+        comm.allreduce_mean(t)
+    if device.type == 'cuda':
+        torch.cuda.synchronize(device)
+
+
+_decision_group = None
+
+
+def broadcast_decision(value, src=0):
+    """rank `src`'s Python value (early-stop flag, new learning rate, run directory) to every rank.  The other ranks may
+    wait here for as long as rank 0 needs to evaluate the dev / test sets, so this uses its own gloo group with a long
+    timeout (ASR_DIST_EVAL_TIMEOUT_HOURS, default 6) and leaves the training collectives' watchdog short."""
+    global _decision_group
+    if not is_distributed():
+        return value
+    if _decision_group is None:
+        import datetime
+        import os
+        hours = float(os.environ.get('ASR_DIST_EVAL_TIMEOUT_HOURS', '6'))
+        _decision_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=hours))
+    box = [value]
+    dist.broadcast_object_list(box, src=src, group=_decision_group)
+    return box[0]
 
 
 def tower_step(model, optimizer, inputs, labels, inputs_seq_len, keep_prob, learning_rate=None):

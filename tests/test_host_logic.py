@@ -153,13 +153,17 @@ def test_cldnn_ctc_model_host_logic(monkeypatch):
     assert l.item() < l0
 
 
-@pytest.mark.parametrize('enc,L,bn', [('blstm', 3, None), ('lstm', 2, 12)])
-def test_bucketed_gradient_averaging_is_the_single_bucket_arithmetic(monkeypatch, enc, L, bn):
+@pytest.mark.parametrize('enc,L,bn,bucket_mb', [('blstm', 3, None, '0'), ('lstm', 2, 12, '0'), ('blstm', 3, None, '6'),
+                                                ('blstm', 4, None, '0.008')])
+def test_bucketed_gradient_averaging_is_the_single_bucket_arithmetic(monkeypatch, enc, L, bn, bucket_mb):
     """utils/training/multi_gpu.BucketedAverager (clip + tower mean per encoder layer as soon as the layer's gradients
     are issued, the rest after the backward pass): its buckets partition the flat gradient buffer, the hook fires for
     every layer top-down, and the clipped gradients equal those of the single-bucket path bit for bit (one rank: the
     mean is the identity; N ranks are covered by the gloo tests of the recipes, which run this path)."""
     _cpu_ops.install(monkeypatch)
+    # ASR_DP_BUCKET_MB: consecutive layers (top down) share a collective until the group holds that many MB;
+    # 0 = every layer alone, 6 (default) = one group at these toy widths, 0.008 = two groups of two ~6 KB layers
+    monkeypatch.setenv('ASR_DP_BUCKET_MB', bucket_mb)
     from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
     from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu
     rng = np.random.RandomState(8)
@@ -173,7 +177,9 @@ def test_bucketed_gradient_averaging_is_the_single_bucket_arithmetic(monkeypatch
     model._clip_gradients(gv)
     want = model.store.grad.clone()
     avg = multi_gpu.averager_for(model)
-    assert avg.ok and len(avg.buckets) == L
+    groups = [b['layers'] for b in avg.buckets]
+    assert avg.ok and len(avg.buckets) == {'0': L, '6': 1, '0.008': 2}[bucket_mb], groups
+    assert groups[0][1] == L - 1 and groups[-1][0] == 0 and all(a[0] == b[1] + 1 for a, b in zip(groups, groups[1:]))
     spans = sorted((b['start'], b['end']) for b in avg.buckets + avg.rest)
     assert spans[0][0] == 0 and spans[-1][1] == model.store.total
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
