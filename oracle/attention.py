@@ -110,12 +110,23 @@ def decoder_params(sd, dtype=torch.float64, requires_grad=True):
 def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_len, enc_layers,
                             att_type, clip_enc=0.0, clip_dec=0.0, sharpening=1.0, temperature=1.0,
                             drop_emb=None, drop_dec=None, ctc_labels=None, lambda_weight=None,
-                            dtype=torch.float64, sigmoid_smoothing=False, prev_alpha='zeros'):
+                            dtype=torch.float64, sigmoid_smoothing=False, prev_alpha='zeros', operand_round=None):
     """Teacher-forced forward + loss + all parameter gradients.
     prev_alpha: 'zeros' (reference's effective graph, Q1) | 'carry' (previous step's weights feed location / hybrid).
     labels [B, Lmax] int (<SOS> y <EOS>, padded with eos); returns dict(loss, logits [B,To,C],
-    alphas, grads, ...)."""
+    alphas, grads, ...).
+    operand_round (e.g. oracle.lstm.bf16_round_t): the rounding points of the bf16-operand device model in the forward
+    -- the inputs, the encoder's LSTM kernels and every h it emits / feeds back, and the CTC head's weight matrix
+    (straight-through); the decoder, the attention layer and the bridge multiply in fp32 on the device and stay in
+    `dtype` here."""
     from .model import params_from_state_dict
+    if operand_round is not None:
+        sd = dict(sd)
+        for k in list(sd):
+            if (k.startswith('encoder/') and k.endswith('/kernel')) or k == 'ctc_output/weights':
+                v = sd[k].detach().cpu() if torch.is_tensor(sd[k]) else torch.as_tensor(np.asarray(sd[k]))
+                sd[k] = operand_round(v.to(torch.float64)).numpy()
+        inputs_btd = operand_round(torch.as_tensor(np.asarray(inputs_btd), dtype=torch.float64)).numpy()
     layers = params_from_state_dict(sd, enc_layers, 2, dtype, prefix='encoder/')
     P = decoder_params(sd, dtype)
     D = 'attention_decoder/decoder/'
@@ -126,8 +137,9 @@ def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_l
     lsl = torch.as_tensor(np.asarray(labels_seq_len), dtype=torch.long)
     lab = torch.as_tensor(np.asarray(labels), dtype=torch.long)
     peep = layers[0][0]['_peep']
+    enc_kw = dict(h_round=operand_round) if operand_round is not None else {}
     enc_tm, final = olstm.blstm_encoder(x, sl, layers, None, forget_bias=1.0, cell_clip=clip_enc,
-                                        use_peephole=peep)
+                                        use_peephole=peep, **enc_kw)
     enc = enc_tm.transpose(0, 1)                                          # [B,T,2H]
     B, T, E2 = enc.shape
     # bridge: flatten (c_fw, h_fw, c_bw, h_bw) -> FC -> (c0, h0)

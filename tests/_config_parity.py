@@ -1,0 +1,175 @@
+"""TEST INFRASTRUCTURE: model-level parity runs of BASELINE configs[2], [3], [4] (SURVEY 8d cfg C / D / E) against the
+oracle -- shared by the `-m gpu` tests (tests/test_gpu_configs.py: the HIP path at the configurations' own widths) and
+by the CPU suite (tests/test_host_logic.py: the same code on the torch stand-ins at toy widths, which pins the host
+wiring these runs exercise and keeps this file from rotting where no GPU is present).
+
+Each run builds the model exactly as the recipe / bench.py does, evaluates loss + every gradient on one seeded ragged
+batch, evaluates the oracle on the same parameters (for bf16 operands: with the device path's rounding points,
+`operand_round`), and returns the error figures; the callers assert the bounds.
+"""
+import time
+
+import numpy as np
+import torch
+
+from oracle import attention as oatt
+from oracle import lstm as olstm
+from oracle import model as omodel
+
+
+def _rel_to_max(a, r):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - r).max() / max(np.abs(r).max(), 1e-12))
+
+
+def _grad_report(gv, ref_grads, report, floor=0.0):
+    """Per-variable max |device - oracle| relative to the oracle gradient's largest entry.  `floor`: gradients whose
+    largest entry is below it are compared against the floor instead (dead paths: zeros against rounding noise)."""
+    worst, worst_name = 0.0, None
+    for g, name in gv:
+        r = ref_grads[name]
+        e = float(np.abs(g.detach().cpu().double().numpy() - r).max() / max(np.abs(r).max(), floor, 1e-30))
+        report.append('%-64s |g|max %.3e  rel-to-max %.2e' % (name, np.abs(r).max(), e))
+        if e > worst:
+            worst, worst_name = e, name
+    return worst, worst_name
+
+
+def ctc_batch(rng, B, T, D, C, lo_frac=0.35, label_div=7):
+    """Ragged zero-padded batch [B,T,D], seq_len (one utterance spans T, one is short), labels ~U{0..C-1} of length
+    seq_len // label_div (L = len // 7 for the character corpora)."""
+    sl = rng.randint(max(4, int(T * lo_frac)), T + 1, size=B).astype(np.int32)
+    sl[0] = T
+    if B > 2:
+        sl[B - 1] = max(4, int(T * lo_frac))
+    x = rng.randn(B, T, D).astype(np.float32)
+    labs = []
+    for b in range(B):
+        x[b, sl[b]:] = 0
+        labs.append(rng.randint(0, C, size=max(1, int(sl[b]) // label_div)).tolist())
+    dense = np.full((B, max(len(l) for l in labs)), -1, dtype=np.int64)
+    for b, l in enumerate(labs):
+        dense[b, :len(l)] = l
+    return x, sl, labs, dense
+
+
+def att_batch(rng, B, T, D, C, To, lo_frac=0.4):
+    """As ctc_batch, plus the attention labels <SOS> y <EOS> padded with EOS (utils/dataset/attention.py) with
+    len(y) <= To - 1; the CTC labels are the same y (joint model: utils/dataset/joint_ctc_attention.py)."""
+    sl = rng.randint(max(8, int(T * lo_frac)), T + 1, size=B).astype(np.int32)
+    sl[0] = T
+    x = rng.randn(B, T, D).astype(np.float32)
+    lens = rng.randint(max(1, (To - 1) // 3), To, size=B)
+    lens[0] = To - 1
+    lens = np.minimum(lens, np.maximum(1, sl // 3))       # a CTC alignment must exist (repeats need a blank between)
+    sos, eos = C, C + 1
+    labels = np.full((B, int(lens.max()) + 2), eos, dtype=np.int64)
+    ctc_labels = np.full((B, int(lens.max())), -1, dtype=np.int64)
+    for b in range(B):
+        x[b, sl[b]:] = 0
+        y = rng.randint(0, C, size=lens[b])
+        labels[b, 0] = sos
+        labels[b, 1:1 + lens[b]] = y
+        ctc_labels[b, :lens[b]] = y
+    return x, sl, labels, (lens + 2).astype(np.int64), ctc_labels
+
+
+def _randomise_biases(model, rng, scale=0.05):
+    """Zero-initialised biases would leave the bias paths untested: small random ones, same on both sides."""
+    sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+    for k in sd:
+        if k.endswith('/bias') or k.endswith('/biases'):
+            sd[k] = (rng.randn(*sd[k].shape) * scale).astype(np.float32)
+    model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    return sd
+
+
+def run_cfgC(device, dtype, B, T, F, W, H, L, C, seed=21):
+    """BASELINE configs[2]: VGG front-end on [F, W, 3] frame images (splice W) -> bridge FC -> L x H BLSTM -> CTC
+    (models/encoders/core/vgg_blstm.py:77-220, models/ctc/ctc.py:175-323).  B >= 17 puts two 16-utterance tiles
+    through the recurrence and, with ragged lengths, the valid-frame gather in front of the convolutions."""
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    rng = np.random.RandomState(seed)
+    D = F * W * 3
+    x, sl, labs, dense = ctc_batch(rng, B, T, D, C)
+    model = CTC(encoder_type='vgg_blstm', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
+                parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype=dtype, seed=7, device=device)
+    sd = _randomise_biases(model, rng)
+    loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
+    opt = model._set_optimizer('sgd', 0.1)
+    gv = opt.compute_gradients(loss, model=model)
+    t0 = time.perf_counter()
+    ref = omodel.ctc_model_forward(sd, x, labs, sl, L, ndir=2, cell_clip=50.0, vgg=(F, W),
+                                   operand_round=olstm.bf16_round_t if dtype == 'bf16' else None)
+    t_oracle = time.perf_counter() - t0
+    lg = logits.detach().cpu().numpy()
+    valid = (np.arange(lg.shape[0])[:, None] < sl[None, :])
+    out = dict(loss_rel=abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']),
+               per_utt_rel=float(np.abs(model.ctc_losses.cpu().numpy() - ref['ctc_losses']).max() / ref['ctc_losses'].max()),
+               logits_abs=float(np.abs(lg - ref['logits'])[valid].max()), logits_max=float(np.abs(ref['logits']).max()))
+    report = ['cfg C  %s  B=%d T=%d F=%d W=%d %dx%d C=%d: loss %.6f vs oracle %.6f rel %.2e  per-utt %.2e  logits abs '
+              '%.2e (max |logit| %.2f)  oracle %.1f s' % (dtype, B, T, F, W, L, H, C, loss.item(), ref['total_loss'],
+                                                         out['loss_rel'], out['per_utt_rel'], out['logits_abs'],
+                                                         out['logits_max'], t_oracle)]
+    out['grad_worst'], out['grad_worst_name'] = _grad_report(gv, ref['grads'], report)
+    out['report'] = '\n'.join(report)
+    return out
+
+
+def run_attention(device, dtype, att, B, T, To, D, H, L, U, A, Em, C, lam, prev_alpha, seed=33, joint=True):
+    """BASELINE configs[3] / [4]: L x H BLSTM encoder -> bridge -> LSTM decoder (U) with `att` attention (A), teacher
+    forced over To steps, (1 - lam) * sequence loss + lam * mean CTC loss on a 'ctc_output' head over the encoder
+    outputs (models/attention/joint_ctc_attention.py:237-346, attention_layer.py:191-265, attention_decoder.py:142-295).
+    C = number of labels: the attention softmax has C + 2 classes (SOS, EOS), the CTC head C + 1 (blank)."""
+    from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
+    from tensorflow_end2end_speech_recognition_amd.models.attention.joint_ctc_attention import JointCTCAttention
+    rng = np.random.RandomState(seed)
+    x, sl, labels, lsl, ctc_labels = att_batch(rng, B, T, D, C, To)
+    kw = dict(input_size=D, encoder_type='blstm', encoder_num_units=H, encoder_num_layers=L, encoder_num_proj=None,
+              attention_type=att, attention_dim=A, decoder_type='lstm', decoder_num_units=U, decoder_num_layers=1,
+              embedding_dim=Em, num_classes=C, sos_index=C, eos_index=C + 1, max_decode_length=To + 5,
+              parameter_init=0.1, clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50,
+              dtype=dtype, seed=5, prev_alpha=prev_alpha, device=device)
+    if joint:
+        model = JointCTCAttention(lambda_weight=lam, **kw)
+    else:
+        model = AttentionSeq2Seq(**kw)
+    sd = _randomise_biases(model, rng)
+    ctc_list = [[int(v) for v in row if v >= 0] for row in ctc_labels]
+    if joint:
+        loss, logits, ctc_logits, otr, oinf = model.compute_loss(x, labels, ctc_labels, sl, lsl, 1.0, 1.0, 1.0)
+    else:
+        loss, logits, otr, oinf = model.compute_loss(x, labels, sl, lsl, 1.0, 1.0, 1.0)
+    opt = model._set_optimizer('sgd', 0.1)
+    gv = opt.compute_gradients(loss, model=model)
+    t0 = time.perf_counter()
+    ref = oatt.attention_model_forward(sd, x, labels, sl, lsl, L, att, clip_enc=50.0, clip_dec=50.0,
+                                       ctc_labels=ctc_list if joint else None, lambda_weight=lam if joint else None,
+                                       prev_alpha=prev_alpha,
+                                       operand_round=olstm.bf16_round_t if dtype == 'bf16' else None)
+    t_oracle = time.perf_counter() - t0
+    out = dict(loss_rel=abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']),
+               seq_loss_rel=abs(float(model.sequence_loss.item()) - ref['sequence_loss']) / abs(ref['sequence_loss']),
+               logits_abs=float(np.abs(logits.detach().cpu().numpy() - ref['logits']).max()),
+               logits_max=float(np.abs(ref['logits']).max()),
+               alpha_abs=float(np.abs(otr.attention_weights.detach().cpu().numpy() - ref['alphas']).max()),
+               ids_mismatch=int((otr.predicted_ids.detach().cpu().numpy() != ref['predicted_ids']).sum()),
+               ids_total=int(ref['predicted_ids'].size))
+    head = ('%s %s prev_alpha=%s  B=%d T=%d To=%d D=%d enc %dx%d U=%d A=%d Em=%d C=%d lambda=%s: loss %.6f vs oracle '
+            '%.6f rel %.2e  seq-loss rel %.2e  logits abs %.2e (max %.2f)  alpha abs %.2e  teacher-forced ids %d / %d '
+            'differ' % (dtype, att, prev_alpha, B, T, To, D, L, H, U, A, Em, C, lam if joint else None, loss.item(),
+                        ref['total_loss'], out['loss_rel'], out['seq_loss_rel'], out['logits_abs'], out['logits_max'],
+                        out['alpha_abs'], out['ids_mismatch'], out['ids_total']))
+    if joint:
+        cl = ctc_logits.detach().cpu().numpy()
+        valid = (np.arange(cl.shape[0])[:, None] < sl[None, :])
+        out['ctc_logits_abs'] = float(np.abs(cl - ref['ctc_logits'])[valid].max())
+        out['ctc_losses_rel'] = float(np.abs(model.ctc_losses.cpu().numpy() - ref['ctc_losses']).max() /
+                                      ref['ctc_losses'].max())
+        head += '  ctc logits abs %.2e  ctc per-utt rel %.2e' % (out['ctc_logits_abs'], out['ctc_losses_rel'])
+    report = [head + '  oracle %.1f s' % t_oracle]
+    # variables without a path to the loss (W_keys of 'location', filter / W_filter weights under prev_alpha='zeros')
+    # are exact zeros on both sides: compared against a floor instead of their own (zero) maximum
+    out['grad_worst'], out['grad_worst_name'] = _grad_report(gv, ref['grads'], report, floor=1e-6)
+    out['report'] = '\n'.join(report)
+    out['model'], out['batch'] = model, (x, sl, labels, lsl, ctc_labels)
+    return out

@@ -1,0 +1,85 @@
+"""GPU parity of BASELINE configs[2], [3], [4] AS MODELS, at their own widths (SURVEY 8d cfg C / D / E), against the
+oracle -- the HIP path through the C ABI on one side, oracle/model.py / oracle/attention.py on the other, same
+parameters, same seeded ragged batch.  bf16-operand models are compared with the oracle evaluated at the device path's
+rounding points (`operand_round`: inputs, MFMA weight operands, every stored activation / emitted h; straight-through,
+state and accumulation fp64), so the bounds state arithmetic, not the precision choice; the fp32 run of the decoder
+widths has the plain fp64 oracle and the 1e-4 bar of north_star.
+
+The runs themselves live in tests/_config_parity.py (also executed on CPU stand-ins at toy widths by the CPU suite).
+Sequence lengths are cut to what the fp64 oracle finishes in about a minute; the widths -- which select the kernels --
+are the configurations' own.
+"""
+import numpy as np
+import pytest
+
+import _config_parity as cp
+
+pytestmark = pytest.mark.gpu
+
+
+def _no_handoff_errors():
+    from tensorflow_end2end_speech_recognition_amd import ops
+    assert ops.check_async_errors(0) == 0
+
+
+def test_cfgC_vgg_blstm_4x512_bf16_ragged_two_tiles(cuda):
+    """configs[2]: VGG (40 mel x splice 11 x 3 images, 64 / 128-channel implicit-GEMM convolutions on MFMA) -> bridge ->
+    4 x 512 BLSTM (8-CU cluster kernels) -> 29-class CTC, bf16 operands, B = 20 ragged utterances: two 16-utterance
+    recurrence tiles (12 rows of the second are padding) and the valid-frame gather in front of the convolutions.
+    Reference: models/encoders/core/vgg_blstm.py:77-220, cnn_util.py:13-84, models/ctc/ctc.py:175-323."""
+    r = cp.run_cfgC('cuda:0', 'bf16', B=20, T=60, F=40, W=11, H=512, L=4, C=28)
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 2e-3 and r['per_utt_rel'] < 5e-3, r['report']
+    assert r['logits_abs'] < 3e-2 * max(1.0, r['logits_max']), r['report']
+    assert r['grad_worst'] < 4e-2, r['report']
+
+
+@pytest.mark.parametrize('prev_alpha', ['zeros', 'carry'])
+def test_cfgD_joint_location_5x512_bf16(cuda, prev_alpha):
+    """configs[3]: 5 x 512 BLSTM encoder (bf16 operands) on D = 240 (120 x stack 2) -> bridge -> LSTM decoder U = 512
+    with LOCATION attention A = 128, embedding 64, 30 output classes, + the 29-class CTC head on the encoder's bf16
+    operand copy, lambda = 0.5; B = 6, T = 200 (four 64-frame chunks of the scoring kernels), 40 decoder steps through
+    asr_att_decoder_fwd / _bwd.  prev_alpha='zeros' is the reference's effective graph (quirk Q1), 'carry' the
+    recurrence attention_layer.py:231-265 expresses (conv1d over the previous weights -> W_filter inside the energy
+    kernels).  Loss, sequence loss, logits, attention weights, CTC logits / per-utterance losses, EVERY gradient.
+    Reference: models/attention/joint_ctc_attention.py:237-346, attention_layer.py:191-265, attention_decoder.py:142-295."""
+    r = cp.run_attention('cuda:0', 'bf16', 'location', B=6, T=200, To=40, D=240, H=512, L=5, U=512, A=128, Em=64, C=28,
+                         lam=0.5, prev_alpha=prev_alpha)
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 2e-3 and r['seq_loss_rel'] < 2e-3 and r['ctc_losses_rel'] < 5e-3, r['report']
+    assert r['alpha_abs'] < 2e-3, r['report']
+    assert r['logits_abs'] < 3e-2 * max(1.0, r['logits_max']), r['report']
+    assert r['ctc_logits_abs'] < 3e-2 * max(1.0, r['logits_max']), r['report']
+    assert r['grad_worst'] < 4e-2, r['report']
+
+
+def test_cfgD_decoder_widths_fp32_directly_against_the_oracle(cuda):
+    """The decoder loop at the widths of configs[3] (A = 128 -> 32 lanes x float4 per frame, U = 512 -> the skinny MFMA
+    products, T = 200 -> multi-chunk scoring, carried location features) with fp32 operands end to end -- so nothing
+    but kernel arithmetic separates the HIP path from oracle/attention.py: the 1e-4 loss bar of north_star, attention
+    weights to 1e-5, teacher-forced ids identical, every gradient to 2e-3 of its maximum.  (The encoder is 2 x 128:
+    fp32 at H = 512 would only add minutes of single-CU recurrence to a test about the decoder.)"""
+    r = cp.run_attention('cuda:0', 'f32', 'location', B=6, T=200, To=40, D=240, H=128, L=2, U=512, A=128, Em=64, C=28,
+                         lam=0.5, prev_alpha='carry')
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 1e-4 and r['seq_loss_rel'] < 1e-4 and r['ctc_losses_rel'] < 1e-4, r['report']
+    assert r['alpha_abs'] < 1e-5 and r['ids_mismatch'] == 0, r['report']
+    assert r['grad_worst'] < 2e-3, r['report']
+
+
+def test_cfgE_hybrid_kanji_vocabulary_bf16(cuda):
+    """configs[4]: 5 x 512 encoder on D = 246 (123 x stack 2), HYBRID attention (projected keys + location term),
+    a 3 388-class attention softmax (3 386 kanji + SOS + EOS) and the 3 387-class CTC head whose three [T*B x 2H x C]
+    products run on bf16 operands; B = 4, T = 120, 20 decoder steps.
+    Reference: models/attention/attention_layer.py:191-229, joint_ctc_attention.py:182-346."""
+    r = cp.run_attention('cuda:0', 'bf16', 'hybrid', B=4, T=120, To=20, D=246, H=512, L=5, U=512, A=128, Em=64, C=3386,
+                         lam=0.5, prev_alpha='zeros')
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 2e-3 and r['seq_loss_rel'] < 2e-3 and r['ctc_losses_rel'] < 5e-3, r['report']
+    assert r['alpha_abs'] < 2e-3, r['report']
+    assert r['logits_abs'] < 3e-2 * max(1.0, r['logits_max']), r['report']
+    assert r['grad_worst'] < 4e-2, r['report']

@@ -773,3 +773,25 @@ def test_dropout_descriptors_give_the_gradient_of_the_loss_they_produce(monkeypa
         assert abs(fd - g[idx]) < 8e-2 * max(abs(g[idx]), 0.1), (name, idx, fd, g[idx])
         checked += 1
     assert checked >= 4
+
+
+@pytest.mark.parametrize('which', ['cfgC', 'cfgD_location_carry', 'cfgD_location_zeros', 'cfgE_hybrid'])
+def test_config_parity_runs_on_cpu_stand_ins(monkeypatch, which):
+    """tests/_config_parity.py -- the model-level parity runs the `-m gpu` suite does at the widths of BASELINE
+    configs[2..4] (tests/test_gpu_configs.py) -- at toy widths on the torch stand-ins: the same batch makers, model
+    construction, oracle calls (with and without the bf16 rounding points) and error reports, so the host wiring
+    they exercise (ragged two-tile VGG batch, joint location / hybrid attention with a wide CTC head) is pinned here."""
+    import _config_parity as cp
+    _cpu_ops.install(monkeypatch)
+    if which == 'cfgC':
+        r = cp.run_cfgC('cpu', 'f32', B=18, T=7, F=5, W=3, H=8, L=2, C=6)
+        assert r['loss_rel'] < 1e-5 and r['per_utt_rel'] < 1e-5 and r['logits_abs'] < 1e-4, r['report']
+    else:
+        att = 'hybrid' if which == 'cfgE_hybrid' else 'location'
+        prev = 'zeros' if which.endswith('zeros') else 'carry'
+        C = 37 if which == 'cfgE_hybrid' else 6
+        r = cp.run_attention('cpu', 'f32', att, B=3, T=12, To=5, D=6, H=8, L=2, U=12, A=10, Em=4, C=C, lam=0.5,
+                             prev_alpha=prev)
+        assert r['loss_rel'] < 1e-5 and r['alpha_abs'] < 1e-5 and r['ids_mismatch'] == 0, r['report']
+        assert r['ctc_logits_abs'] < 1e-4 and r['ctc_losses_rel'] < 1e-5, r['report']
+    assert r['grad_worst'] < 2e-4, r['report']
