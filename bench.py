@@ -12,15 +12,23 @@ A step = forward + CTC loss + backward + per-variable clip + (all-reduce) + opti
 
 The ONE JSON line rank 0 prints holds
   value / ms_per_step    K steps bracketed by barrier + synchronize, inputs resident in HBM (the contract's number);
-  step_ms                per-step durations from HIP events on the launch stream: median / min / max;
+  step_ms                per-step durations from HIP events on the launch stream: median / min / max; the host's time
+                         to ENQUEUE a step (host_issue_mean) and, apart from it, the time the host spent waiting for
+                         the device (it runs at most three steps ahead: ops.ErrorWatch);
   h2d_inclusive          the same K steps with the batch uploaded from pinned host memory every step
                          (double-buffered on a copy stream, SURVEY 8d's step definition) -- reported, never `value`;
   parity                 CTC-loss match and greedy-label match against the CPU oracle on the same batch cut to its
                          first --cpu-tmax frames (computed outside the timed region, before training starts);
   roofline               dominant kernel, HIP-event duration measured live in the timed region;
-  cpu_baseline           oracle/fast_cpu.py port of the TF1 CPU path on a bounded sample;
-  cfgA                   BASELINE configs[0] (TIMIT-39, 2x128, fp32) timed the same way: the configuration the
-                         1e-4 fp32 loss tolerance of north_star is a statement about (N = 1 only).
+  cpu_baseline           oracle/fast_cpu.py port of the TF1 CPU path on a bounded sample, thread sweep, best reported;
+and, at N = 1, the other BASELINE configurations timed with the same harness (a few steps each):
+  cfgA                   configs[0] (TIMIT-39, 2x128, fp32): the configuration the 1e-4 fp32 loss tolerance is about;
+  cfgC                   configs[2] VGG-BLSTM 4x512 CTC, B = 64;
+  cfgD                   configs[3] 5x512 BLSTM joint CTC-attention (location), the per-GPU shard B = 32;
+  cfgE                   configs[4] hybrid-attention encoder-decoder + CTC head at the kanji vocabulary, B = 32;
+  decode                 greedy and prefix-beam CTC decode (TIMIT-61 width 20, kanji width 100) in utterances/s, the
+                         oracle's restatement of the reference's numpy decoders timed beside them on one core;
+  input_width_D39, batch_scaling   the headline model at the other input width / at B = 32 .. 128 per GPU.
 """
 import argparse
 import json
@@ -39,7 +47,8 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
 MFMA_F32_PEAK_TF = 157.3
 
 
-def make_batch(seed, B, D, C, tmin, tmax):
+# ------------------------------------------------------------------------------------------------ synthetic batches
+def make_batch(seed, B, D, C, tmin, tmax, label_div=8, label_lo=5, label_hi=75):
     rng = np.random.RandomState(seed)
     seq_len = rng.randint(tmin, tmax + 1, size=B).astype(np.int32)
     T = int(seq_len.max())
@@ -47,28 +56,40 @@ def make_batch(seed, B, D, C, tmin, tmax):
     labels = []
     for b in range(B):
         x[b, seq_len[b]:] = 0
-        L = int(np.clip(seq_len[b] // 8, 5, 75))
+        L = int(np.clip(seq_len[b] // label_div, label_lo, label_hi))
         labels.append(rng.randint(0, C - 1, size=L).tolist())
-    Lmax = max(len(l) for l in labels)
-    dense = np.full((B, Lmax), -1, dtype=np.int64)
+    return x, seq_len, labels, dense_labels(labels)
+
+
+def dense_labels(labels):
+    dense = np.full((len(labels), max(len(l) for l in labels)), -1, dtype=np.int64)
     for b, l in enumerate(labels):
         dense[b, :len(l)] = l
-    return x, seq_len, labels, dense
+    return dense
 
 
-def truncate_batch(x, seq_len, labels, tcut):
+def device_features(seed, seq_len, D, dev, T=None):
+    """[B, T, D] ~ N(0,1) fp32, zero past seq_len, generated ON the device (the cfg C batch is 550 MB: numpy takes
+    seconds for it).  Only for workloads whose timed loop keeps the batch resident."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    T = int(seq_len.max()) if T is None else int(T)
+    x = torch.randn((len(seq_len), T, D), generator=g, device=dev, dtype=torch.float32)
+    keep = torch.arange(T, device=dev).view(1, T, 1) < torch.as_tensor(seq_len, device=dev).view(-1, 1, 1)
+    return x * keep
+
+
+def truncate_batch(x, seq_len, labels, tcut, label_div=8):
     """The same utterances cut to their first tcut frames, labels cut to stay feasible (bounded CPU sample)."""
     sl = np.minimum(seq_len, tcut).astype(np.int32)
     xc = x[:, :int(sl.max())].copy()
     for b in range(len(sl)):
         xc[b, sl[b]:] = 0
-    labs = [list(l[:max(1, int(n) // 8)]) for l, n in zip(labels, sl)]
-    dense = np.full((len(labs), max(len(l) for l in labs)), -1, dtype=np.int64)
-    for b, l in enumerate(labs):
-        dense[b, :len(l)] = l
-    return xc, sl, labs, dense
+    labs = [list(l[:max(1, int(n) // label_div)]) for l, n in zip(labels, sl)]
+    return xc, sl, labs, dense_labels(labs)
 
 
+# ------------------------------------------------------------------------------------------------ timing harness
 class KernelTimer(object):
     """HIP-event brackets (torch.cuda.Event on the current stream == the launch stream of ops.*)."""
 
@@ -108,7 +129,55 @@ class KernelTimer(object):
         return out
 
 
-def parity_vs_oracle(model, x, seq_len, labels, dense, L, dtype, tcut):
+def fence(world):
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def time_steps(step, steps, warmup, world, dev_index, timed_ops=('lstm_fwd', 'lstm_bwd', 'ctc_loss')):
+    """W untimed + K timed calls of step() between barrier + synchronize; per-step HIP events; host issue time with
+    the ErrorWatch's wait for the device (the host may run three steps ahead, no more) accounted separately."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    # only the serial kernels are bracketed: an event pair around each of the ~40 small GEMMs of a step costs
+    # milliseconds of queue serialisation and would distort the number being measured
+    timer = KernelTimer(ops, list(timed_ops))
+    timer.install()
+    try:
+        for _ in range(warmup):
+            loss = step()
+        fence(world)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        waited0 = ops.watch_waited_seconds(dev_index)
+        host = 0.0
+        timer.enabled = True
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            h0 = time.perf_counter()
+            loss = step()
+            marks[i + 1].record()
+            host += time.perf_counter() - h0
+        fence(world)
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+    finally:
+        timer.uninstall()
+    waited = ops.watch_waited_seconds(dev_index) - waited0
+    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)])
+    return dict(elapsed=elapsed, final_loss=float(loss.item()), kernels=timer.summary(),
+                handoff_flags=ops.check_async_errors(dev_index),   # sticky error word of the multi-CU recurrence kernels
+                step_ms=dict(median=float(np.median(per_step)), min=float(per_step.min()), max=float(per_step.max()),
+                             host_issue_mean=(host - waited) / steps * 1e3, host_wait_for_device_mean=waited / steps * 1e3,
+                             note='HIP events between steps on the launch stream; host_issue = Python + C time to enqueue '
+                                  'one step; host_wait_for_device = time the issue loop spent blocked because it was '
+                                  'three steps ahead of the GPU (the step is device-bound while this is > 0)'))
+
+
+# ------------------------------------------------------------------------------------------------ parity / CPU legs
+def parity_vs_oracle(model, x, seq_len, labels, L, dtype, tcut):
     """Device loss / greedy labels against the CPU oracle on the batch cut to its first tcut frames.  For the bf16
     operand path the oracle is evaluated on the bf16-rounded operands (inputs, kernels, emitted h), so what is compared
     is the arithmetic, not the precision choice; for fp32 it is the plain fp64 oracle (tolerance 1e-4, north_star)."""
@@ -138,73 +207,136 @@ def parity_vs_oracle(model, x, seq_len, labels, dense, L, dtype, tcut):
                        % (tcut, int(sl.sum())), seconds=time.perf_counter() - t0)
 
 
-def run_workload(args, wl, dev, world, rank, local_rank, want_parity, want_h2d):
-    """Times one workload description `wl`; returns the result dict of this rank (rank 0 aggregates)."""
+def cpu_baseline_blstm_ctc(args, wl, model, x, seq_len, labels):
+    """oracle/fast_cpu.py (torch-CPU fp32 restatement of the TF1 CPU step) on the timed batch cut to its first
+    --cpu-tmax frames, at several thread counts of the box's host; the best one is `value`."""
+    from oracle import fast_cpu
+    sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+    xc, sl, labs, _ = truncate_batch(x, seq_len, labels, args.cpu_tmax)
+    cframes = int(sl.sum())
+    ncpu = os.cpu_count() or 1
+    sweep = sorted(set(min(int(t), ncpu) for t in args.cpu_threads.split(',') if t) | ({ncpu} if args.cpu_all_cores else set()))
+    runs = []
+    for nt in sweep:
+        cm = fast_cpu.CpuBLSTMCTC(sd, wl['layers'], cell_clip=50.0, clip_grad_norm=5.0, threads=nt, optimizer='rmsprop')
+        t = fast_cpu.time_train_steps(cm, xc, labs, sl, steps=args.cpu_steps, warmup=1)
+        runs.append(dict(threads=nt, frames_per_s=cframes / t, seconds_per_step=t))
+    best = max(runs, key=lambda r: r['frames_per_s'])
+    return dict(value=best['frames_per_s'], unit='frames/s', cores=best['threads'], kind='port', host_cores=ncpu,
+                thread_sweep=runs, seconds_per_step=best['seconds_per_step'],
+                sample='%d timed training step(s) after 1 warm-up step of the same %d-utterance batch cut to its first '
+                       '%d frames (%d valid frames), rmsprop, torch-CPU fp32 restatement of the TF1 path '
+                       '(oracle/fast_cpu.py); torch.set_num_threads swept over %s of a %d-core host, best reported'
+                       % (args.cpu_steps, wl['batch'], args.cpu_tmax, cframes, [r['threads'] for r in runs], ncpu))
+
+
+def cpu_baseline_oracle_call(fn, frames, what, threads):
+    """One forward + backward of the oracle's model function (fp32, autograd) on a bounded sample."""
+    torch.set_num_threads(threads)
+    fn()                                   # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    fn()
+    t = time.perf_counter() - t0
+    return dict(value=frames / t, unit='frames/s', cores=threads, kind='port', host_cores=os.cpu_count() or 1,
+                seconds_per_step=t, sample=what)
+
+
+# ------------------------------------------------------------------------------------------------ rooflines
+def recurrence_roofline(H, frames_dirs, T, dtype, ks, traffic=None, traffic_source=None, tiles=1):
+    """Roofline entry of the dominant recurrence kernel.  Algorithmic HBM bytes per launch:
+      fwd: read x W_x + b 16H, write gates s*4H + c 4H + h s*H     per valid frame per direction
+      bwd: read gates s*4H + c 4H + dh 4H, write dgates s*4H       per valid frame per direction
+    + W_h once per direction; `frames_dirs` = valid frames x directions of one launch."""
+    dom = max(('lstm_fwd', 'lstm_bwd'), key=lambda n: ks.get(n, {}).get('total_ms', 0))
+    if dom not in ks:
+        return None
+    s_act = 2 if dtype == 'bf16' else 4
+    per_frame = {'lstm_fwd': 20 * H + 5 * s_act * H, 'lstm_bwd': 8 * H + 8 * s_act * H}[dom]
+    flops_frame = 2 * 4 * H * H   # recurrent h W_h (fwd) / dG W_h^T (bwd), per frame per direction
+    bytes_launch = frames_dirs * per_frame + 2 * 4 * H * H * s_act
+    dur = ks[dom]['avg_us'] * 1e-6
+    ach = bytes_launch / dur / 1e9
+    peak_tf = MFMA_BF16_PEAK_TF if dtype == 'bf16' else MFMA_F32_PEAK_TF
+    return dict(kernel=dom, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
+                traffic=traffic, traffic_source=traffic_source, avg_launch_us=ks[dom]['avg_us'],
+                us_per_recurrence_step=ks[dom]['avg_us'] / T, algorithmic_bytes_per_launch=bytes_launch,
+                mfma_tflops=frames_dirs * flops_frame / dur / 1e12,
+                mfma_frac=frames_dirs * flops_frame / dur / 1e12 / peak_tf, utterance_tiles_per_direction=tiles,
+                note='serial recurrence over T frames, one 16-utterance MFMA tile per cluster: bound by the per-step '
+                     'chain (LDS operand reads, gate math issue, one cross-CU L2 hop), not by HBM or MFMA throughput '
+                     '(DESIGN.md section 4); traffic = HBM bytes per launch from a separate rocprofv3 --pmc pass '
+                     '(profiles/pmc_hbm_traffic.json), null if no pass matches this workload')
+
+
+def load_traffic_table():
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
+    return json.load(open(tpath)) if os.path.exists(tpath) else None
+
+
+# ------------------------------------------------------------------------------------------------ BLSTM-CTC workloads
+def run_blstm_ctc(args, wl, dev, world, rank, dev_index, steps, warmup, want_parity, want_h2d, want_cpu):
+    """Times one BLSTM-CTC workload description `wl` on this rank; returns the result dict (rank 0 aggregates)."""
     import torch.distributed as dist
-    from tensorflow_end2end_speech_recognition_amd import ops
     from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
     from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu
 
     H, L, C = wl['units'], wl['layers'], wl['classes'] + 1
     # every rank gets its own shard of the global batch (weak scaling: B per GPU fixed)
     x, seq_len, labels, dense = make_batch(wl['seed'] + rank, wl['batch'], wl['input_size'], C, wl['tmin'], wl['tmax'])
+    if world > 1 and wl.get('global_tmax', True):
+        # the reference pads the GLOBAL batch to its longest utterance and then splits it (utils/dataset/ctc.py:137-139,
+        # :171-182): every tower runs Tmax(global) recurrence steps, so do the ranks here
+        tg = torch.tensor([x.shape[1]], device=dev, dtype=torch.int64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        if int(tg.item()) > x.shape[1]:
+            x = np.concatenate([x, np.zeros((x.shape[0], int(tg.item()) - x.shape[1], x.shape[2]), np.float32)], 1)
     model = CTC('blstm', wl['input_size'], H, L, wl['classes'], parameter_init=0.1, clip_grad_norm=5.0,
                 clip_activation=50, dtype=wl['dtype'], device=str(dev), seed=0)
     multi_gpu.broadcast_parameters(model.store)
     frames = int(seq_len.sum())
-    res = dict(frames=frames)
+    res = dict(frames=frames, T=int(x.shape[1]))
     if want_parity and rank == 0:
-        res['parity'] = parity_vs_oracle(model, x, seq_len, labels, dense, L, wl['dtype'], args.cpu_tmax)
+        res['parity'] = parity_vs_oracle(model, x, seq_len, labels, L, wl['dtype'], args.cpu_tmax)
     xd = torch.tensor(x, device=dev)
     sld = torch.tensor(seq_len, device=dev)
     opt = model._set_optimizer('rmsprop', 1e-3)
+    cur = [xd]
+    comm_events = []
+    if world > 1:     # duration of the collectives on the communication stream (HIP events on that stream)
+        orig_ar = multi_gpu._allreduce_mean_
 
-    # only the serial kernels are bracketed (11 launches/step): an event pair around each of the ~40
-    # small GEMMs costs ~3.5 ms/step of queue serialisation and would distort the number being measured
-    timer = KernelTimer(ops, ['lstm_fwd', 'lstm_bwd', 'ctc_loss'])
-    timer.install()
+        def timed_ar(t):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_ar(t)
+            e1.record()
+            comm_events.append((e0, e1, t.numel() * 4))
+            return r
+        multi_gpu._allreduce_mean_ = timed_ar
 
-    def step(xin):
-        loss, logits = model.compute_loss(xin, dense, sld, keep_prob=wl['keep_prob'])
-        # gradients -> per-variable clip on the tower (BEFORE averaging) -> mean over towers: per encoder layer on a
-        # communication stream under the BPTT of the layers below when N > 1 (multi_gpu.BucketedAverager)
+    def step():
+        loss, logits = model.compute_loss(cur[0], dense, sld, keep_prob=wl['keep_prob'])
+        # gradients -> per-variable clip on the tower (BEFORE averaging) -> mean over towers: per group of encoder
+        # layers on a communication stream under the BPTT of the layers below when N > 1 (multi_gpu.BucketedAverager)
         multi_gpu.clip_and_average(model, opt, loss)
         opt.apply_gradients(None)
         return loss
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        loss = step(xd)
-    fence()
-    K = args.steps
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
-    host_issue = 0.0
-    timer.enabled = True
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(K):
-        h0 = time.perf_counter()
-        loss = step(xd)
-        marks[i + 1].record()
-        host_issue += time.perf_counter() - h0
-    fence()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    res['elapsed'] = elapsed
-    res['final_loss'] = float(loss.item())
-    res['handoff_flags'] = ops.check_async_errors(local_rank)   # sticky error word of the multi-CU recurrence kernels
-    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(K)])
-    res['step_ms'] = dict(median=float(np.median(per_step)), min=float(per_step.min()), max=float(per_step.max()),
-                          host_issue_mean=host_issue / K * 1e3,
-                          note='HIP events between steps on the launch stream; host_issue = time the Python side needs '
-                               'to enqueue one step (must stay below the GPU time or the step becomes host-bound)')
-    res['kernels'] = timer.summary()
-
+    res.update(time_steps(step, steps, warmup, world, dev_index))
+    if world > 1:
+        multi_gpu._allreduce_mean_ = orig_ar
+        n_timed = len(comm_events) * steps // (steps + warmup)     # the warm-up steps' collectives come first
+        ev = comm_events[-n_timed:] if n_timed else []
+        ms = [a.elapsed_time(b) for a, b, _ in ev]
+        avg = multi_gpu.averager_for(model)
+        res['comm'] = dict(allreduce_calls_per_step=len(ev) / max(steps, 1), allreduce_ms_per_step=float(np.sum(ms)) / max(steps, 1),
+                           bytes_per_step=float(sum(n for _, _, n in ev)) / max(steps, 1),
+                           bucket_min_mb=getattr(avg, 'bucket_min_bytes', 0) / float(1 << 20),
+                           buckets=[dict(layers=list(b.get('layers', ())), mbytes=(b['end'] - b['start']) * 4 / 1e6)
+                                    for b in avg.buckets] + [dict(rest=True, mbytes=(b['end'] - b['start']) * 4 / 1e6)
+                                                             for b in avg.rest],
+                           note='HIP events on the communication stream around each clip + all-reduce(mean) of a '
+                                'gradient bucket; these run beside the BPTT kernels of the layers below')
     if want_h2d:
         # the same K steps with the batch coming from pinned host memory each step: upload of step i+1 on a copy
         # stream under the compute of step i (what a prefetching input pipeline does); all K uploads in the bracket
@@ -222,92 +354,232 @@ def run_workload(args, wl, dev, world, rank, local_rank, want_parity, want_h2d):
                 e = torch.cuda.Event()
                 e.record(copy_stream)
                 ready[i % 2] = e
-        fence()
+        fence(world)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
         upload(0)
-        for i in range(K):
-            if i + 1 < K:
+        marks[0].record()
+        for i in range(steps):
+            if i + 1 < steps:
                 upload(i + 1)
             torch.cuda.current_stream().wait_event(ready[i % 2])
-            loss = step(bufs[i % 2])
+            cur[0] = bufs[i % 2]
+            step()
             e = torch.cuda.Event()
             e.record()
             done[i % 2] = e
-        fence()
+            marks[i + 1].record()
+        fence(world)
         res['elapsed_h2d'] = time.perf_counter() - t0
-    timer.uninstall()
-    res['x'], res['seq_len'], res['labels'], res['model'] = x, seq_len, labels, model
+        res['h2d_median_ms'] = float(np.median([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]))
+        cur[0] = xd
+    if want_cpu and rank == 0:
+        res['cpu_baseline'] = cpu_baseline_blstm_ctc(args, wl, model, x, seq_len, labels)
+    del model, opt
     return res
 
 
-def aggregate(res, args, world, dev):
-    import torch.distributed as dist
-    out = {}
-    for key in ('elapsed', 'elapsed_h2d'):
-        if key not in res:
-            continue
-        t = torch.tensor([res[key]], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out[key] = float(t.item())
-    f = torch.tensor([float(res['frames'])], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(f, op=dist.ReduceOp.SUM)
-    out['total_frames'] = float(f.item())
+def blstm_ctc_entry(args, wl, res, steps, desc):
+    """The JSON object of an auxiliary BLSTM-CTC workload (N = 1)."""
+    ks = res['kernels']
+    tt = load_traffic_table()
+    key = '%dx%d_%s_B%d_T%d' % (wl['layers'], wl['units'], wl['dtype'], wl['batch'], wl['tmax'])
+    traffic = src = None
+    dom = max(('lstm_fwd', 'lstm_bwd'), key=lambda n: ks.get(n, {}).get('total_ms', 0))
+    if tt and key in tt.get('workloads', {}):
+        traffic, src = tt['workloads'][key].get(dom), tt.get('source')
+    return dict(workload=desc, value=res['frames'] * steps / res['elapsed'], unit='frames/s', dtype=wl['dtype'],
+                steps=steps, ms_per_step=res['elapsed'] / steps * 1e3, step_ms=res['step_ms'],
+                final_loss=res['final_loss'], cluster_handoff_flags=res['handoff_flags'], parity=res.get('parity'),
+                kernels=ks, roofline=recurrence_roofline(wl['units'], res['frames'] * 2, res['T'], wl['dtype'], ks,
+                                                         traffic, src, tiles=(wl['batch'] + 15) // 16),
+                cpu_baseline=res.get('cpu_baseline'))
+
+
+# ------------------------------------------------------------------------------------------------ cfg C
+def run_cfgC(args, dev, dev_index):
+    """BASELINE configs[2] (SURVEY 8d cfg C, seed 2): LibriSpeech-100h-character-shaped batch, B = 64, F = 40 mel x
+    {static, d, dd}, splice 11 -> D = 1320, seq_len ~ U{150..1650}, L = len // 7 over 28 characters, VGG front-end +
+    4x512 BLSTM + 29-class CTC, bf16 operands, dropout 0.2, rmsprop 1e-3."""
+    from oracle import lstm as olstm
+    from oracle import model as omodel
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    B, F, W, H, L, C = 64, 40, 11, 512, 4, 28
+    rng = np.random.RandomState(2)
+    seq_len = rng.randint(150, 1651, size=B).astype(np.int32)
+    labels = [rng.randint(0, C, size=max(1, int(n) // 7)).tolist() for n in seq_len]
+    dense = dense_labels(labels)
+    xd = device_features(2, seq_len, F * W * 3, dev)
+    sld = torch.tensor(seq_len, device=dev)
+    model = CTC('vgg_blstm', 3 * F, H, L, C, splice=W, parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50,
+                dtype='bf16', device=str(dev), seed=0)
+
+    def step():
+        loss, _ = model.compute_loss(xd, dense, sld, keep_prob=0.8)
+        model.train(loss, 'rmsprop', 1e-3)
+        return loss
+    steps = args.aux_steps
+    res = time_steps(step, steps, args.aux_warmup, 1, dev_index)
+    frames = int(seq_len.sum())
+    T = int(seq_len.max())
+    out = dict(workload='LibriSpeech-100h char shaped: VGG (40x11x3 frame images) + 4x512 BLSTM + CTC(29), B=64, '
+                        'D=1320, seq_len~U{150..1650}, bf16 operands, dropout 0.2, rmsprop, train step',
+               value=frames * steps / res['elapsed'], unit='frames/s', dtype='bf16', steps=steps,
+               frames_per_step=frames, ms_per_step=res['elapsed'] / steps * 1e3, step_ms=res['step_ms'],
+               final_loss=res['final_loss'], cluster_handoff_flags=res['handoff_flags'], kernels=res['kernels'],
+               algorithmic_flops_per_frame=399.3e6,
+               mfma_frac_whole_step=399.3e6 * frames * steps / res['elapsed'] / 1e12 / MFMA_BF16_PEAK_TF,
+               roofline=recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
+               parity='model-level parity at these widths: tests/test_gpu_configs.py::test_cfgC_vgg_blstm_4x512_bf16_ragged_two_tiles')
+    if not args.no_cpu_baseline:
+        # bounded CPU sample: the first 4 utterances cut to 48 frames through the oracle's VGG + BLSTM + CTC model
+        # (fp32 autograd forward + backward; no optimizer step -- favours the CPU)
+        nb, tc = 4, 48
+        sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+        xc = xd[:nb, :tc].cpu().numpy()
+        slc = np.minimum(seq_len[:nb], tc)
+        labs = [l[:max(1, tc // 7)] for l in labels[:nb]]
+        th = min(16, os.cpu_count() or 1)
+        out['cpu_baseline'] = cpu_baseline_oracle_call(
+            lambda: omodel.ctc_model_forward(sd, xc, labs, slc, L, ndir=2, cell_clip=50.0, vgg=(F, W), dtype=torch.float32),
+            int(slc.sum()), 'forward + backward (no update) of oracle.model.ctc_model_forward(vgg=(40, 11)) in fp32 on the '
+            'first %d utterances cut to %d frames (%d frames), %d threads' % (nb, tc, int(slc.sum()), th), th)
+    del model
     return out
 
 
-def roofline(wl, frames, ks, traffic_table):
-    H, L = wl['units'], wl['layers']
-    dom = max(('lstm_fwd', 'lstm_bwd', 'ctc_loss'), key=lambda n: ks.get(n, {}).get('total_ms', 0))
-    s_act = 2 if wl['dtype'] == 'bf16' else 4
-    # algorithmic HBM bytes per launch of the recurrence kernels (DESIGN.md "Kernels"):
-    #   fwd: read x W_x+b 16H, write gates s*4H + c 4H + h s*H             per valid frame per direction
-    #   bwd: read gates s*4H + c 4H + dh 4H, write dgates s*4H              per valid frame per direction
-    per_frame = {'lstm_fwd': 20 * H + 5 * s_act * H, 'lstm_bwd': 8 * H + 8 * s_act * H}
-    if dom not in per_frame:
-        return None
-    flops_frame = 2 * 4 * H * H   # recurrent h W_h (fwd) / dG W_h^T (bwd), per frame per direction
-    bytes_launch = frames * 2 * per_frame[dom] + 2 * 4 * H * H * s_act
-    dur = ks[dom]['avg_us'] * 1e-6
-    ach = bytes_launch / dur / 1e9
-    T = wl['tmax']
-    traffic = None
-    src = None
-    key = '%dx%d_%s_B%d_T%d' % (L, H, wl['dtype'], wl['batch'], T)
-    if traffic_table and key in traffic_table.get('workloads', {}):
-        traffic = traffic_table['workloads'][key].get(dom)
-        src = traffic_table.get('source')
-    peak_tf = MFMA_BF16_PEAK_TF if wl['dtype'] == 'bf16' else MFMA_F32_PEAK_TF
-    return dict(kernel=dom, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
-                traffic=traffic, traffic_source=src, avg_launch_us=ks[dom]['avg_us'],
-                us_per_recurrence_step=ks[dom]['avg_us'] / T, algorithmic_bytes_per_launch=bytes_launch,
-                mfma_tflops=frames * 2 * flops_frame / dur / 1e12,
-                mfma_frac=frames * 2 * flops_frame / dur / 1e12 / peak_tf,
-                note='serial recurrence over T frames on one 16-utterance MFMA tile per direction: bound by the '
-                     'per-step chain (LDS operand reads, gate math issue, one cross-CU L2 hop), not by HBM or MFMA '
-                     'throughput (DESIGN.md section 4); traffic = HBM bytes per launch from a separate rocprofv3 --pmc '
-                     'pass of this command (cannot be collected inside the timed run), null if no pass matches')
+# ------------------------------------------------------------------------------------------------ cfg D / E
+def run_attention_cfg(args, dev, dev_index, which):
+    """BASELINE configs[3] (cfg D, seed 3: 5x512 BLSTM encoder on D = 240, LOCATION attention A = 128, LSTM decoder
+    U = 512, embedding 64, 28 characters, lambda = 0.5, per-GPU shard B = 32, seq_len ~ U{100..1600}, L = len // 4 + 2)
+    and configs[4] (cfg E, seed 4: D = 246, HYBRID attention, 3 386 kanji -> 3 388-class softmax + 3 387-class CTC head,
+    seq_len ~ U{100..1000}, L = len // 6 + 2).  bf16 encoder operands, dropout 0.2 everywhere, adam 1e-3."""
+    from oracle import attention as oatt
+    from tensorflow_end2end_speech_recognition_amd import ops
+    from tensorflow_end2end_speech_recognition_amd.models.attention.joint_ctc_attention import JointCTCAttention
+    if which == 'D':
+        seed, D, C, att, tlo, thi, ldiv = 3, 240, 28, 'location', 100, 1600, 4
+    else:
+        seed, D, C, att, tlo, thi, ldiv = 4, 246, 3386, 'hybrid', 100, 1000, 6
+    B, H, L, U, A, Em = 32, 512, 5, 512, 128, 64
+    rng = np.random.RandomState(seed)
+    seq_len = rng.randint(tlo, thi + 1, size=B).astype(np.int32)
+    lens = np.maximum(1, seq_len // ldiv)
+    Lmax = int(lens.max()) + 2
+    labels = np.full((B, Lmax), C + 1, dtype=np.int64)
+    ctc = np.full((B, int(lens.max())), -1, dtype=np.int64)
+    for b in range(B):
+        y = rng.randint(0, C, size=lens[b])
+        labels[b, 0] = C
+        labels[b, 1:1 + lens[b]] = y
+        ctc[b, :lens[b]] = y
+    xd = device_features(seed, seq_len, D, dev)
+    model = JointCTCAttention(input_size=D, encoder_type='blstm', encoder_num_units=H, encoder_num_layers=L,
+                              encoder_num_proj=None, attention_type=att, attention_dim=A, decoder_type='lstm',
+                              decoder_num_units=U, decoder_num_layers=1, embedding_dim=Em, lambda_weight=0.5,
+                              num_classes=C, sos_index=C, eos_index=C + 1, max_decode_length=Lmax, parameter_init=0.1,
+                              clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50, dtype='bf16',
+                              seed=5, device=str(dev))
+
+    def step():
+        loss, *_ = model.compute_loss(xd, labels, ctc, seq_len, lens + 2, 0.8, 0.8, 0.8)
+        model.train(loss, 'adam', 1e-3)
+        return loss
+    steps = args.aux_steps
+    res = time_steps(step, steps, args.aux_warmup, 1, dev_index,
+                     timed_ops=('lstm_fwd', 'lstm_bwd', 'ctc_loss', 'att_decoder_fwd', 'att_decoder_bwd'))
+    frames = int(seq_len.sum())
+    T = int(seq_len.max())
+    desc = ('LibriSpeech-960h shaped per-GPU shard: 5x512 BLSTM + joint CTC-attention (location, A=128, U=512, E=64, '
+            'C=28, lambda 0.5), B=32, D=240, seq_len~U{100..1600}, %d decoder steps' % (Lmax - 1)) if which == 'D' else \
+           ('CSJ-kanji shaped per-GPU shard: 5x512 BLSTM + hybrid attention decoder (3388 classes) + CTC head (3387), '
+            'B=32, D=246, seq_len~U{100..1000}, %d decoder steps' % (Lmax - 1))
+    out = dict(workload=desc + ', bf16 encoder operands, dropout 0.2, adam, train step', value=frames * steps / res['elapsed'],
+               unit='frames/s', dtype='bf16', steps=steps, frames_per_step=frames, decoder_steps=Lmax - 1,
+               ms_per_step=res['elapsed'] / steps * 1e3, step_ms=res['step_ms'], final_loss=res['final_loss'],
+               cluster_handoff_flags=res['handoff_flags'], kernels=res['kernels'],
+               roofline=recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
+               parity='model-level parity at these widths: tests/test_gpu_configs.py::test_cfg%s_*' % which)
+    if not args.no_cpu_baseline:
+        nb, tc, lc = 4, 64, 10
+        sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+        xc = xd[:nb, :tc].cpu().numpy()
+        slc = np.minimum(seq_len[:nb], tc)
+        lab_c = np.full((nb, lc + 2), C + 1, dtype=np.int64)
+        lab_c[:, 0] = C
+        lab_c[:, 1:1 + lc] = labels[:nb, 1:1 + lc]
+        ctc_c = [[int(v) for v in lab_c[b, 1:1 + lc]] for b in range(nb)]
+        th = min(16, os.cpu_count() or 1)
+        out['cpu_baseline'] = cpu_baseline_oracle_call(
+            lambda: oatt.attention_model_forward(sd, xc, lab_c, slc, np.full(nb, lc + 2), L, att, clip_enc=50.0,
+                                                 clip_dec=50.0, ctc_labels=ctc_c, lambda_weight=0.5, dtype=torch.float32),
+            int(slc.sum()), 'forward + backward (no update) of oracle.attention.attention_model_forward in fp32 on the first '
+            '%d utterances cut to %d frames / %d labels (%d frames), %d threads' % (nb, tc, lc, int(slc.sum()), th), th)
+    del model
+    return out
 
 
-def cpu_baseline(args, wl, res):
-    from oracle import fast_cpu
-    model, x, seq_len, labels = res['model'], res['x'], res['seq_len'], res['labels']
-    sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
-    ncores = min(os.cpu_count() or 1, args.cpu_threads)
-    xc, sl, labs, _ = truncate_batch(x, seq_len, labels, args.cpu_tmax)
-    cm = fast_cpu.CpuBLSTMCTC(sd, wl['layers'], cell_clip=50.0, clip_grad_norm=5.0, threads=ncores,
-                              optimizer='rmsprop')
-    t_cpu = fast_cpu.time_train_steps(cm, xc, labs, sl, steps=args.cpu_steps, warmup=1)
-    cframes = int(sl.sum())
-    return dict(value=cframes / t_cpu, unit='frames/s', cores=ncores, kind='port',
-                sample='%d timed training step(s) after 1 warm-up step of the same %d-utterance batch cut to its first '
-                       '%d frames (%d valid frames), rmsprop, torch-CPU fp32 restatement of the TF1 path '
-                       '(oracle/fast_cpu.py) on %d threads (torch.set_num_threads) of a %d-core host'
-                       % (args.cpu_steps, wl['batch'], args.cpu_tmax, cframes, ncores, os.cpu_count() or 1),
-                seconds_per_step=t_cpu)
+# ------------------------------------------------------------------------------------------------ decode
+def run_decode(args, dev):
+    """CTC decode throughput (models/ctc/decoders/*.py, ctc.py:325-352): asr_ctc_greedy_decode and asr_ctc_beam_decode on
+    softmax-peaked random logits, next to the oracle's restatement of the reference's numpy GreedyDecoder /
+    BeamSearchDecoder (pure Python, one core; pinned bit-exact to the reference's own outputs by
+    tests/golden/decoders_*.{npz,json}) on a bounded cut of the same posteriors."""
+    from oracle import decoders as odec
+    from tensorflow_end2end_speech_recognition_amd import ops
+    out = {}
+    rng = np.random.RandomState(5)
+    for name, T, B, C, W, tcut_cpu, bcut_cpu in (('timit61_beam20', 778, 16, 62, 20, 60, 1),
+                                                  ('kanji3387_beam100', 1000, 8, 3387, 100, 6, 1)):
+        logits = torch.tensor(rng.randn(T, B, C).astype(np.float32) * 3, device=dev)
+        sl = torch.full((B,), T, dtype=torch.int32, device=dev)
+        ent = {}
+        for kind in ('greedy', 'beam'):
+            fn = (lambda: ops.ctc_greedy_decode(logits, sl)) if kind == 'greedy' else \
+                 (lambda: ops.ctc_beam_decode(logits, sl, beam_width=W))
+            fn()
+            torch.cuda.synchronize()
+            reps = 3 if kind == 'beam' else 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / reps
+            ent[kind] = dict(utterances_per_s=B / t, frames_per_s=B * T / t, ms_per_call=t * 1e3, batch=B, frames=T,
+                             classes=C, **({'beam_width': W} if kind == 'beam' else {}))
+            # CPU: the oracle decoder on log-softmax of the first tcut frames of the first utterance(s), one core
+            lp = torch.log_softmax(logits[:tcut_cpu, :bcut_cpu].transpose(0, 1).double().cpu(), 2).numpy()
+            slc = np.full(bcut_cpu, tcut_cpu)
+            t0 = time.perf_counter()
+            if kind == 'greedy':
+                for _ in range(50):
+                    ref = odec.greedy_decode(lp, slc, C - 1)
+                tc = (time.perf_counter() - t0) / 50
+            else:
+                ref, _ = odec.beam_search_decode(lp, slc, C - 1, beam_width=W)
+                tc = time.perf_counter() - t0
+            ent[kind]['cpu_baseline'] = dict(value=bcut_cpu * tcut_cpu / tc, unit='frames/s', cores=1, kind='port',
+                                             sample='oracle.decoders.%s on %d utterance(s) x %d frames, C=%d%s'
+                                                    % ('greedy_decode' if kind == 'greedy' else 'beam_search_decode',
+                                                       bcut_cpu, tcut_cpu, C, '' if kind == 'greedy' else ', width %d' % W))
+            # the device result on that cut must be the oracle's (bit-exact labels)
+            lg_cut = logits[:tcut_cpu, :bcut_cpu].contiguous()
+            slcut = torch.full((bcut_cpu,), tcut_cpu, dtype=torch.int32, device=dev)
+            if kind == 'greedy':
+                lab, n = ops.ctc_greedy_decode(lg_cut, slcut)
+            else:
+                lab, n, _ = ops.ctc_beam_decode(lg_cut, slcut, beam_width=W)
+            lab, n = lab.cpu().numpy(), n.cpu().numpy()
+            ent[kind]['labels_identical_to_oracle_on_cpu_sample'] = bool(
+                all(list(lab[b, :int(n[b])]) == list(ref[b]) for b in range(bcut_cpu)))
+        out[name] = ent
+    out['note'] = ('HIP decoders on whole batches resident in HBM (one wave per (frame, utterance) row for greedy, one '
+                   'workgroup per utterance for the prefix beam search); cpu_baseline = oracle/decoders.py, the pinned '
+                   'restatement of the reference numpy decoders (models/ctc/decoders/*.py), single core, bounded cut')
+    return out
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -322,12 +594,19 @@ def main():
     ap.add_argument('--tmin', type=int, default=100)
     ap.add_argument('--tmax', type=int, default=778)
     ap.add_argument('--keep-prob', type=float, default=0.8)
+    ap.add_argument('--no-global-tmax', action='store_true',
+                    help='N > 1: every rank pads to its own longest utterance instead of the global one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-cfgA', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=3)
-    ap.add_argument('--cpu-threads', type=int, default=16)
-    ap.add_argument('--cpu-tmax', type=int, default=256,
+    ap.add_argument('--no-aux', action='store_true', help='skip cfgC / cfgD / cfgE / decode / input width / batch scaling')
+    ap.add_argument('--aux', default='cfgC,cfgD,cfgE,decode,D39,batch', help='which auxiliary entries to run (N = 1)')
+    ap.add_argument('--aux-steps', type=int, default=5)
+    ap.add_argument('--aux-warmup', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-threads', default='16,64', help='thread counts of the CPU baseline sweep (plus all cores)')
+    ap.add_argument('--cpu-all-cores', action='store_true', default=True)
+    ap.add_argument('--cpu-tmax', type=int, default=512,
                     help='CPU legs (baseline, oracle parity): the same batch truncated to its first N frames')
     args = ap.parse_args()
 
@@ -350,62 +629,121 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     import torch.distributed as dist
+    from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            multi_gpu.warm_up_collectives(dev)      # RCCL rings + the C ABI's communicator: before step 1, not inside it
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = dict(units=args.units, layers=args.layers, classes=args.classes, dtype=args.dtype, batch=args.batch,
-              input_size=args.input_size, tmin=args.tmin, tmax=args.tmax, keep_prob=args.keep_prob, seed=1)
-    res = run_workload(args, wl, dev, world, rank, dev_index, want_parity=not args.no_parity, want_h2d=True)
-    agg = aggregate(res, args, world, dev)
-    value = agg['total_frames'] * args.steps / agg['elapsed']
+              input_size=args.input_size, tmin=args.tmin, tmax=args.tmax, keep_prob=args.keep_prob, seed=1,
+              global_tmax=not args.no_global_tmax)
+    res = run_blstm_ctc(args, wl, dev, world, rank, dev_index, args.steps, args.warmup,
+                        want_parity=not args.no_parity, want_h2d=True,
+                        want_cpu=(world == 1 and not args.no_cpu_baseline))
+    # aggregate: slowest rank's time, all ranks' frames; per-rank medians so a straggler is visible
+    stats = torch.tensor([res['elapsed'], res['elapsed_h2d'], float(res['frames']), res['step_ms']['median'],
+                          float(res['T']), res.get('comm', {}).get('allreduce_ms_per_step', 0.0)],
+                         device=dev, dtype=torch.float64)
+    if world > 1:
+        allst = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(allst, stats)
+        allst = torch.stack(allst).cpu().numpy()
+    else:
+        allst = stats.cpu().numpy()[None]
+    elapsed, elapsed_h2d, total_frames = float(allst[:, 0].max()), float(allst[:, 1].max()), float(allst[:, 2].sum())
+    value = total_frames * args.steps / elapsed
 
     if rank == 0:
-        traffic_table = None
-        tpath = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
-        if os.path.exists(tpath):
-            traffic_table = json.load(open(tpath))
         ks = res['kernels']
         H, L, C = wl['units'], wl['layers'], wl['classes'] + 1
+        tt = load_traffic_table()
+        key = '%dx%d_%s_B%d_T%d' % (L, H, wl['dtype'], wl['batch'], wl['tmax'])
+        dom = max(('lstm_fwd', 'lstm_bwd'), key=lambda n: ks.get(n, {}).get('total_ms', 0))
+        traffic = src = None
+        if tt and key in tt.get('workloads', {}):
+            traffic, src = tt['workloads'][key].get(dom), tt.get('source')
         out = dict(metric='acoustic frames/sec (train), TIMIT-shaped BLSTM-CTC', value=value, unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=agg['elapsed'] / args.steps * 1e3, higher_is_better=True, scaling='weak',
+                   ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype=args.dtype, data='synthetic',
                    config=dict(workload='TIMIT 61-phone %dx%d BLSTM-CTC, B=%d/GPU, D=%d, C=%d, '
                                         'seq_len~U{%d..%d}, dropout %.1f, rmsprop, train step'
                                         % (L, H, args.batch, args.input_size, C, args.tmin, args.tmax,
                                            1 - args.keep_prob),
-                               global_batch=args.batch * world, frames_per_step=agg['total_frames'],
-                               parallelism='dp%d' % world),
+                               global_batch=args.batch * world, frames_per_step=total_frames,
+                               parallelism='dp%d' % world,
+                               padded_to=('global Tmax %d on every rank' % int(allst[:, 4].max())) if (world > 1 and wl['global_tmax'])
+                               else 'own Tmax per rank'),
                    step_ms=res['step_ms'],
-                   h2d_inclusive=dict(value=agg['total_frames'] * args.steps / agg['elapsed_h2d'], unit='frames/s',
-                                      ms_per_step=agg['elapsed_h2d'] / args.steps * 1e3,
+                   h2d_inclusive=dict(value=total_frames * args.steps / elapsed_h2d, unit='frames/s',
+                                      ms_per_step=elapsed_h2d / args.steps * 1e3, median_ms=res['h2d_median_ms'],
                                       note='batch uploaded from pinned host memory every step, double-buffered on a '
-                                           'copy stream; reported next to `value`, which has the inputs resident'),
+                                           'copy stream (SURVEY 8d step definition); reported next to `value`, which '
+                                           'has the inputs resident as the bench contract asks'),
                    final_loss=res['final_loss'], cluster_handoff_flags=res['handoff_flags'],
-                   parity=res.get('parity'), kernels=ks, roofline=roofline(wl, res['frames'], ks, traffic_table),
-                   cpu_baseline=None, cfgA=None)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args, wl, res)
+                   parity=res.get('parity'), kernels=ks,
+                   roofline=recurrence_roofline(H, res['frames'] * 2, res['T'], wl['dtype'], ks, traffic, src,
+                                                tiles=(wl['batch'] + 15) // 16),
+                   cpu_baseline=res.get('cpu_baseline'), cfgA=None)
+        if world > 1:
+            out['per_rank'] = dict(step_median_ms=[float(v) for v in allst[:, 3]], frames=[float(v) for v in allst[:, 2]],
+                                   elapsed_s=[float(v) for v in allst[:, 0]],
+                                   comm_stream_allreduce_ms_per_step=[float(v) for v in allst[:, 5]])
+            out['comm'] = res.get('comm')
         del res
+        torch.cuda.empty_cache()
         if world == 1 and not args.no_cfgA:
             # BASELINE configs[0]: TIMIT-39, 2x128 BLSTM-CTC, fp32 (exact fp32 MFMA path), B=16, dropout 0.5
             wa = dict(units=128, layers=2, classes=39, dtype='f32', batch=16, input_size=120, tmin=100, tmax=778,
                       keep_prob=0.5, seed=0)
-            ra = run_workload(args, wa, dev, world, rank, dev_index, want_parity=not args.no_parity, want_h2d=False)
-            out['cfgA'] = dict(workload='TIMIT 39-phone 2x128 BLSTM-CTC fp32, B=16, D=120, C=40, seq_len~U{100..778}, '
-                                        'dropout 0.5, rmsprop, train step',
-                               value=ra['frames'] * args.steps / ra['elapsed'], unit='frames/s', dtype='f32',
-                               ms_per_step=ra['elapsed'] / args.steps * 1e3, step_ms=ra['step_ms'],
-                               final_loss=ra['final_loss'], parity=ra.get('parity'), kernels=ra['kernels'],
-                               cpu_baseline=None if args.no_cpu_baseline else cpu_baseline(args, wa, ra))
+            ra = run_blstm_ctc(args, wa, dev, 1, 0, dev_index, args.steps, args.warmup, want_parity=not args.no_parity,
+                               want_h2d=False, want_cpu=not args.no_cpu_baseline)
+            out['cfgA'] = blstm_ctc_entry(args, wa, ra, args.steps,
+                                          'TIMIT 39-phone 2x128 BLSTM-CTC fp32, B=16, D=120, C=40, seq_len~U{100..778}, '
+                                          'dropout 0.5, rmsprop, train step')
+            del ra
+        aux = set() if (world > 1 or args.no_aux) else set(a for a in args.aux.split(',') if a)
+        for name, fn in (('cfgC', lambda: run_cfgC(args, dev, dev_index)),
+                         ('cfgD', lambda: run_attention_cfg(args, dev, dev_index, 'D')),
+                         ('cfgE', lambda: run_attention_cfg(args, dev, dev_index, 'E')),
+                         ('decode', lambda: run_decode(args, dev))):
+            if name in aux:
+                try:
+                    out[name] = fn()
+                except Exception as e:      # an auxiliary entry must not cost the headline line
+                    out[name] = dict(error=repr(e)[:400])
+                torch.cuda.empty_cache()
+        if 'D39' in aux:
+            # SURVEY 8d names a "D = 40" variant; the class surface rejects it as the reference does (input_size % 3,
+            # models/ctc/ctc.py:79: features come as static + delta + delta-delta): 39 = 13 x 3 is the nearest valid width
+            wd = dict(wl, input_size=39)
+            rd = run_blstm_ctc(args, wd, dev, 1, 0, dev_index, 20, 5, want_parity=False, want_h2d=False, want_cpu=False)
+            out['input_width_D39'] = blstm_ctc_entry(args, wd, rd, 20, 'headline model on D=39 (13x3) features: input_size '
+                                                     '40 is rejected by the class surface as by the reference (ctc.py:79)')
+            del rd
+        if 'batch' in aux:
+            # what the design delivers per GPU at the recipes' own batch sizes: one 16-utterance tile per cluster,
+            # so B = 32 .. 128 puts 2 .. 8 clusters per direction side by side (16 .. 64 of the 256 CUs)
+            rows = []
+            for Bn in (32, 64, 128):
+                wb = dict(wl, batch=Bn)
+                rb = run_blstm_ctc(args, wb, dev, 1, 0, dev_index, 10, 3, want_parity=False, want_h2d=False, want_cpu=False)
+                rows.append(dict(batch=Bn, value=rb['frames'] * 10 / rb['elapsed'], unit='frames/s',
+                                 ms_per_step=rb['elapsed'] / 10 * 1e3, lstm_fwd_us=rb['kernels'].get('lstm_fwd', {}).get('avg_us'),
+                                 lstm_bwd_us=rb['kernels'].get('lstm_bwd', {}).get('avg_us'),
+                                 cluster_handoff_flags=rb['handoff_flags']))
+                del rb
+                torch.cuda.empty_cache()
+            out['batch_scaling'] = dict(workload='headline model (5x256 bf16, D=120, C=62, T<=778) at larger per-GPU batches', rows=rows)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     os.close(result_fd)
 

@@ -1,4 +1,6 @@
-"""Oracle (test infrastructure, PARITY UNPINNED -- TF1 absent): numpy restatement of
+"""Oracle (test infrastructure; update rules pinned to TensorFlow's own optimizer tests where those hold numbers --
+tests/golden/tf_known_answers.py: sgd, momentum, nesterov, adagrad, rmsprop, adam; adadelta PARITY UNPINNED):
+numpy restatement of
 tf.clip_by_norm and the seven tf.train optimizers the reference selects in
 models/model_base.py:12-20,68-95 with TF1 default hyper-parameters
 (SURVEY.md Appendix B), plus the tower mean of utils/training/multi_gpu.py:13-48."""
@@ -21,16 +23,18 @@ def init_slots(name, p):
     return s0, s1
 
 
-def step(name, p, g, s0, s1, lr, t):
-    """One update; returns (p, s0, s1).  t is the 1-based step count."""
+def step(name, p, g, s0, s1, lr, t, momentum=0.9, decay=0.9, rms_eps=1e-10):
+    """One update; returns (p, s0, s1).  t is the 1-based step count.  momentum / decay / rms_eps default to what the
+    reference passes or leaves at TensorFlow's defaults (model_base.py:82-95); TensorFlow's own optimizer tests, which
+    tests/test_oracle.py pins the rules to, use other values for some of them."""
     if name == 'sgd':
         p = p - lr * g
     elif name == 'momentum':
-        s0 = 0.9 * s0 + g
+        s0 = momentum * s0 + g
         p = p - lr * s0
     elif name == 'nestrov':
-        s0 = 0.9 * s0 + g
-        p = p - (lr * g + lr * 0.9 * s0)
+        s0 = momentum * s0 + g
+        p = p - (lr * g + lr * momentum * s0)
     elif name == 'adagrad':
         s0 = s0 + g * g
         p = p - lr * g / np.sqrt(s0)
@@ -41,9 +45,8 @@ def step(name, p, g, s0, s1, lr, t):
         s1 = rho * s1 + (1 - rho) * upd * upd
         p = p - lr * upd
     elif name == 'rmsprop':
-        decay, eps = 0.9, 1e-10
         s0 = decay * s0 + (1 - decay) * g * g
-        s1 = lr * g / np.sqrt(s0 + eps)
+        s1 = lr * g / np.sqrt(s0 + rms_eps)
         p = p - s1
     elif name == 'adam':
         b1, b2, eps = 0.9, 0.999, 1e-8

@@ -30,27 +30,14 @@ from ...utils.parameter import ParamStore
 from ..ctc.ctc import Placeholder, truncated_normal
 from ..encoders.load_encoder import load as load_encoder
 from ..model_base import ModelBase
+from .bridge import InitialStateBridge
 from .decoders import attention_layer as AL
+from .decoders.attention_decoder import (AttentionDecoder, AttentionDecoderOutput, GreedyEmbeddingHelper,  # noqa: F401
+                                         LSTMDecoderCell, TrainingHelper)
+from .decoders.attention_layer import AttentionLayer
 
 D = 'attention_decoder/decoder/'
 AT = D + 'attention_layer/'
-
-
-class AttentionDecoderOutput(object):
-    """namedtuple stand-in of attention_decoder.py:19-26."""
-
-    def __init__(self, logits=None, predicted_ids=None, decoder_output=None, attention_weights=None,
-                 context_vector=None, lazy=None):
-        self.logits, self._ids = logits, predicted_ids
-        self.decoder_output, self.attention_weights, self.context_vector = \
-            decoder_output, attention_weights, context_vector
-        self._lazy = lazy
-
-    @property
-    def predicted_ids(self):
-        if self._ids is None and self._lazy is not None:
-            self._ids = self._lazy()          # the INFER decoder only runs when its output is fetched
-        return self._ids
 
 
 class AttentionSeq2Seq(ModelBase):
@@ -220,12 +207,20 @@ class AttentionSeq2Seq(ModelBase):
         return s                                             # luong_*: the decoder state itself
 
     def _bridge(self, final_c, final_h, B):
-        """final_c/final_h [2,Bp,H] -> (bi [Bp,4H], c0, h0)."""
-        bi = torch.cat([final_c[0], final_h[0], final_c[1], final_h[1]], dim=1).contiguous()
-        st = self.store
-        init = ops.gemm(bi, st['bridge/fully_connected/weights'], bias=st['bridge/fully_connected/biases'])
+        """final_c/final_h [2,Bp,H] -> (bi [Bp,4H], c0, h0) through InitialStateBridge (bridge.py:128-151: the final
+        (c, h) of the forward then the backward direction, flattened and concatenated, one FC, split)."""
+        class _Enc(object):
+            final_state = ((final_c[0], final_h[0]), (final_c[1], final_h[1]))
         U = self.decoder_num_units
-        return bi, init[:, :U].contiguous(), init[:, U:].contiguous()
+        br = InitialStateBridge(_Enc, (U, U), self.parameter_init, store=self.store)
+        c0, h0 = br()
+        return br.bridge_input(), c0, h0
+
+    def attention_layer(self, time_major_inputs=True):
+        """The model's AttentionLayer (attention_seq2seq.py:413-430), bound to its variables."""
+        return AttentionLayer(self.attention_type, self.attention_dim, self.parameter_init, self.sharpening_factor,
+                              self.sigmoid_smoothing, mode='infer', store=self.store,
+                              prev_alpha='carry' if self.carry_alpha else 'zeros', time_major_inputs=time_major_inputs)
 
     # ------------------------------------------------------------------ forward
     def compute_loss(self, inputs, labels, inputs_seq_len, labels_seq_len, keep_prob_encoder,
@@ -491,48 +486,23 @@ class AttentionSeq2Seq(ModelBase):
 
     # ------------------------------------------------------------------ inference
     def _decode_infer(self, inputs, isl):
-        """GreedyEmbeddingHelper loop (attention_seq2seq.py:462-509), at most max_decode_length steps."""
+        """GreedyEmbeddingHelper decode (attention_seq2seq.py:462-509): AttentionDecoder.step under dynamic_decode, at
+        most max_decode_length steps, impute_finished.  Returns the predicted ids [B, <= max_decode_length]."""
         st, dev = self.store, self.device
         B = inputs.shape[0]
         enc, seq_p = self._encode(inputs, isl, 1.0, False)
         T, Bp, E2 = enc.shape
-        U, Em = self.decoder_num_units, self.embedding_dim
         cf, hf = self.encoder._final_ch
         _, c, h = self._bridge(cf, hf, B)
-        keys, peep = self._keys(enc), self._peep()
-        ctx = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
-        tok = torch.full((Bp,), self.sos_index, dtype=torch.int32, device=dev)
-        live = torch.ones((Bp,), dtype=torch.float32, device=dev)
-        live[B:] = 0
-        v = st[AT + 'v_a'] if self.att_mode == 0 else None
-        dec_in = torch.empty((Bp, self.dec_in_dim), dtype=torch.float32, device=dev)
-        av_in = torch.empty((Bp, U + E2), dtype=torch.float32, device=dev)
-        out = []
-        snorm = torch.empty((Bp,), dtype=torch.float32, device=dev) if self.sigmoid_smoothing else None
-        a_prev = torch.zeros((Bp, T), dtype=torch.float32, device=dev) if self.carry_alpha else None
-        for k in range(self.max_decode_length):
-            dec_in[:, :Em].copy_(ops.embedding_gather(st['output_embedding/W_embedding'], tok))
-            dec_in[:, Em:Em + E2].copy_(ctx)
-            dec_in[:, Em + E2:].copy_(h)
-            pre = ops.gemm(dec_in, st[D + 'lstm_cell/kernel'], bias=st[D + 'lstm_cell/bias'])
-            _, _, c, h, h_raw = ops.lstm_cell_fwd(pre, c, h, peep, live, 1.0, self.clip_activation_decoder or 0.0)
-            if self.carry_alpha:
-                energy = ops.att_loc_energy_fwd(a_prev, st[AT + 'filter'], st[AT + 'W_filter/weights'], keys,
-                                                self._query(h_raw), v, T)
-            else:
-                energy = ops.att_energy_fwd(keys, self._query(h_raw), v, T, self.att_mode)
-            a_prev, ctx = ops.att_softmax_ctx_fwd(energy, seq_p, self.sharpening_factor, enc, sigmoid_norm=snorm)
-            av_in[:, :U].copy_(h_raw)
-            av_in[:, U:].copy_(ctx)
-            av = ops.tanh_fwd(ops.gemm(av_in, st[D + 'attentional_vector/weights']))
-            lg = ops.gemm(av, st[D + 'output_layer/weights'], bias=st[D + 'output_layer/biases'])
-            sample = ops.argmax_rows(lg)
-            out.append((sample * live.int())[:B])
-            live = live * (sample != self.eos_index).float()
-            tok = sample
-            if float(live[:B].sum()) == 0:
-                break
-        return torch.stack(out, 1)
+        layer = self.attention_layer(time_major_inputs=True)
+        cell = LSTMDecoderCell(st, self.decoder_num_units, self.use_peephole, self.clip_activation_decoder)
+        decoder = AttentionDecoder(cell, self.parameter_init, self.max_decode_length, self.num_classes, enc, seq_p, layer,
+                                   time_major=False, mode='infer', store=st)
+        decoder.live_rows = torch.arange(Bp, device=dev) < B      # rows B.. are the zero-length padding of the batch tile
+        helper = GreedyEmbeddingHelper(st['output_embedding/W_embedding'],
+                                       torch.full((Bp,), self.sos_index, dtype=torch.int32, device=dev), self.eos_index)
+        outputs, _ = decoder((c, h), helper)
+        return outputs.predicted_ids[:B]
 
     def infer(self, inputs, inputs_seq_len):
         """Greedy inference ids [B, <= max_decode_length] (numpy) for a batch of features -- what running the

@@ -173,3 +173,103 @@ def run_attention(device, dtype, att, B, T, To, D, H, L, U, A, Em, C, lam, prev_
     out['report'] = '\n'.join(report)
     out['model'], out['batch'] = model, (x, sl, labels, lsl, ctc_labels)
     return out
+
+
+def run_class_surface(device, att, prev_alpha, sig, B=3, T=12, To=5, D=6, H=8, L=1, U=12, A=10, Em=4, C=6, seed=17):
+    """The step-at-a-time class surface of models/attention (AttentionLayer, LSTMDecoderCell, AttentionDecoder under
+    dynamic_decode with a TrainingHelper, InitialStateBridge) against (a) the oracle's attention_step / model and (b)
+    the model's own fused teacher-forced loop (asr_att_decoder_fwd): the same logits / weights / ids must come out of
+    both forms.  Returns the error figures."""
+    from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
+    from tensorflow_end2end_speech_recognition_amd.models.attention.decoders.attention_decoder import (
+        AttentionDecoder, LSTMDecoderCell, TrainingHelper)
+    rng = np.random.RandomState(seed)
+    x, sl, labels, lsl, _ = att_batch(rng, B, T, D, C, To)
+    if att == 'luong_dot':
+        U = 2 * H
+    model = AttentionSeq2Seq(input_size=D, encoder_type='blstm', encoder_num_units=H, encoder_num_layers=L,
+                             encoder_num_proj=None, attention_type=att, attention_dim=A, decoder_type='lstm',
+                             decoder_num_units=U, decoder_num_layers=1, embedding_dim=Em, num_classes=C, sos_index=C,
+                             eos_index=C + 1, max_decode_length=To + 3, parameter_init=0.1, clip_grad_norm=5.0,
+                             clip_activation_encoder=50, clip_activation_decoder=50, dtype='f32', seed=5,
+                             sharpening_factor=1.5, sigmoid_smoothing=sig, prev_alpha=prev_alpha, device=device)
+    sd = _randomise_biases(model, rng)
+    loss, logits, otr, oinf = model.compute_loss(x, labels, sl, lsl, 1.0, 1.0, 1.0, is_training=False)
+    ref = oatt.attention_model_forward(sd, x, labels, sl, lsl, L, att, clip_enc=50.0, clip_dec=50.0, sharpening=1.5,
+                                       sigmoid_smoothing=sig, prev_alpha=prev_alpha)
+    # the same teacher-forced pass through the step-at-a-time classes
+    dev = model.device
+    st = model.store
+    enc, seq_p = model._encode(torch.as_tensor(x, device=dev), torch.as_tensor(sl, dtype=torch.int32, device=dev), 1.0, False)
+    Bp = enc.shape[1]
+    cf, hf = model.encoder._final_ch
+    _, c0, h0 = model._bridge(cf, hf, B)
+    layer = model.attention_layer(time_major_inputs=True)
+    cell = LSTMDecoderCell(st, U, True, 50.0)
+    dec = AttentionDecoder(cell, 0.1, To + 3, C + 2, enc, seq_p, layer, time_major=False, mode='train', store=st)
+    dec.live_rows = torch.arange(Bp, device=dev) < B
+    lab = np.full((Bp, labels.shape[1]), C + 1, dtype=np.int64)
+    lab[:B] = labels
+    emb = st['output_embedding/W_embedding'][torch.as_tensor(lab, device=dev)]            # [Bp, Lmax, Em]
+    n_steps = int(lsl.max()) - 1
+    lens = np.zeros(Bp, dtype=np.int64)
+    lens[:B] = lsl - 1
+    helper = TrainingHelper(emb[:, :n_steps].contiguous(), lens)
+    outs, _ = dec((c0, h0), helper)
+    lg_cls = outs.logits[:B].detach().cpu().numpy()
+    al_cls = outs.attention_weights[:B].detach().cpu().numpy()
+    ids_cls = outs.predicted_ids[:B].detach().cpu().numpy()
+    out = dict(loss_rel=abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']),
+               class_logits_vs_oracle=float(np.abs(lg_cls - ref['logits']).max()),
+               class_alpha_vs_oracle=float(np.abs(al_cls - ref['alphas']).max()),
+               class_ids_vs_oracle=int((ids_cls != ref['predicted_ids']).sum()),
+               class_logits_vs_fused=float(np.abs(lg_cls - logits.detach().cpu().numpy()).max()),
+               class_alpha_vs_fused=float(np.abs(al_cls - otr.attention_weights.detach().cpu().numpy()).max()))
+    # a standalone layer (declares its own variables at the first call) against the oracle's attention_step
+    from tensorflow_end2end_speech_recognition_amd.models.attention.decoders.attention_layer import AT_SCOPE, AttentionLayer
+    lay = AttentionLayer(att, A, 0.1, 1.5, sig, mode='train', prev_alpha=prev_alpha, seed=3)
+    enc_bm = torch.tensor(rng.randn(B, T, 2 * H).astype(np.float32), device=dev)
+    s_dec = torch.tensor(rng.randn(B, U).astype(np.float32), device=dev)
+    a_prev = torch.softmax(torch.tensor(rng.randn(B, T).astype(np.float32), device=dev), 1)
+    a_prev = a_prev * (torch.arange(T, device=dev).unsqueeze(0) < torch.as_tensor(sl, device=dev).unsqueeze(1))
+    alpha, ctx = lay(enc_bm, s_dec, sl, a_prev)
+    p64 = {k[len(AT_SCOPE):]: v.detach().cpu().double() for k, v in lay.store.state_dict().items()}
+    keys64 = oatt.compute_keys(p64, att, enc_bm.cpu().double())
+    carry = prev_alpha == 'carry' and att in ('location', 'hybrid')
+    a64, c64 = oatt.attention_step(p64, att, enc_bm.cpu().double(), keys64, s_dec.cpu().double(),
+                                   torch.as_tensor(sl, dtype=torch.long), 1.5, sig, a_prev.cpu().double() if carry else None)
+    out['layer_alpha'] = float(np.abs(alpha.detach().cpu().numpy() - a64.numpy()).max())
+    out['layer_ctx'] = float(np.abs(ctx.detach().cpu().numpy() - c64.numpy()).max())
+    out['report'] = '%s prev_alpha=%s sigmoid=%s: %s' % (att, prev_alpha, sig, {k: v for k, v in out.items()})
+    return out
+
+
+def run_bridges(device):
+    """Bridge classes (models/attention/bridge.py:28-151) against their definitions."""
+    from tensorflow_end2end_speech_recognition_amd.models.attention import bridge as br
+    rng = np.random.RandomState(2)
+    B, H, U = 5, 6, 7
+    dev = torch.device(device)
+    t = lambda *s: torch.tensor(rng.randn(*s).astype(np.float32), device=dev)
+
+    class Enc(object):
+        final_state = ((t(B, H), t(B, H)), (t(B, H), t(B, H)))
+    b = br.InitialStateBridge(Enc, (U, U), 0.1, seed=4)
+    c0, h0 = b()
+    flat = torch.cat([Enc.final_state[0][0], Enc.final_state[0][1], Enc.final_state[1][0], Enc.final_state[1][1]], 1)
+    want = flat.double().cpu() @ b.store['bridge/fully_connected/weights'].double().cpu() + \
+        b.store['bridge/fully_connected/biases'].double().cpu()
+    err = float((torch.cat([c0, h0], 1).double().cpu() - want).abs().max())
+    z = br.ZeroBridge(Enc, (U, U))()
+    ok_zero = all(float(v.abs().sum()) == 0 and tuple(v.shape) == (B, U) for v in z)
+
+    class Enc2(object):
+        final_state = (t(B, U), t(B, U))
+    p = br.PassThroughBridge(Enc2, (U, U))()
+    ok_pass = all(torch.equal(a, b_) for a, b_ in zip(p, Enc2.final_state))
+    try:
+        br.PassThroughBridge(Enc, (U, U))()
+        raised = False
+    except ValueError:
+        raised = True
+    return dict(fc_err=err, ok_zero=ok_zero, ok_pass=ok_pass, raised=raised)

@@ -70,6 +70,58 @@ ADAGRAD_LR, ADAGRAD_STEPS = 3.0, 3
 ADAGRAD_VAR0, ADAGRAD_GRAD0, ADAGRAD_OUT0 = [1.0, 2.0], [0.1, 0.1], [-1.6026098728179932, -0.6026098728179932]
 ADAGRAD_VAR1, ADAGRAD_GRAD1, ADAGRAD_OUT1 = [3.0, 4.0], [0.01, 0.01], [2.715679168701172, 3.715679168701172]
 
+# The other tf.train optimizers, from the expectations TensorFlow's own tests of them spell out (TF r1.2 / r1.3,
+# tensorflow/python/training/*_test.py; two variables [1, 2] and [3, 4], constant gradients).  Restated from those
+# tests' arithmetic -- the expressions below are theirs, evaluated here -- not copied files.
+#  * gradient_descent_test.py testBasic: learning rate 3.0, gradients 0.1 / 0.01, one step.
+SGD_LR, SGD_VAR, SGD_GRAD = 3.0, [[1.0, 2.0], [3.0, 4.0]], [[0.1, 0.1], [0.01, 0.01]]
+SGD_OUT = [[1.0 - 3.0 * 0.1, 2.0 - 3.0 * 0.1], [3.0 - 3.0 * 0.01, 4.0 - 3.0 * 0.01]]
+#  * momentum_test.py testBasic: learning rate 2.0, momentum 0.9, gradients 0.1 / 0.01, two steps; the accumulator
+#    holds 0.1 then 0.9 * 0.1 + 0.1 (accum = momentum * accum + grad; var -= lr * accum).
+MOM_LR, MOM_MOMENTUM, MOM_VAR, MOM_GRAD = 2.0, 0.9, [[1.0, 2.0], [3.0, 4.0]], [[0.1, 0.1], [0.01, 0.01]]
+MOM_OUT_STEP1 = [[1.0 - (0.1 * 2.0), 2.0 - (0.1 * 2.0)], [3.0 - (0.01 * 2.0), 4.0 - (0.01 * 2.0)]]
+MOM_OUT_STEP2 = [[1.0 - (0.1 * 2.0) - ((0.9 * 0.1 + 0.1) * 2.0), 2.0 - (0.1 * 2.0) - ((0.9 * 0.1 + 0.1) * 2.0)],
+                 [2.98 - ((0.9 * 0.01 + 0.01) * 2.0), 3.98 - ((0.9 * 0.01 + 0.01) * 2.0)]]
+MOM_ACCUM_STEP2 = [[0.9 * 0.1 + 0.1] * 2, [0.9 * 0.01 + 0.01] * 2]
+#  * momentum_test.py testNesterovMomentum's numpy reference (_update_nesterov_momentum_numpy):
+#    var += accum * lr * momentum; accum = accum * momentum + g; var -= lr * accum; var -= accum * lr * momentum.
+
+
+def nesterov_reference(var, accum, g, lr, momentum):
+    var = var + accum * lr * momentum
+    accum = accum * momentum + g
+    var = var - lr * accum
+    var = var - accum * lr * momentum
+    return var, accum
+
+
+#  * rmsprop_test.py testWithoutMomentum: learning rate 2.0, decay 0.9, momentum 0, epsilon 1.0; gradients
+#    [0.1, 0.2] / [0.01, 0.2]; the rms slot STARTS AT ONE (0.901 = 0.9 * 1 + 0.1 * 0.1^2) and epsilon sits INSIDE
+#    the root (sqrt(0.901 + 1.0)); two steps.
+RMS_LR, RMS_DECAY, RMS_EPS = 2.0, 0.9, 1.0
+RMS_VAR, RMS_GRAD = [[1.0, 2.0], [3.0, 4.0]], [[0.1, 0.2], [0.01, 0.2]]
+RMS_SLOT_STEP1 = [[0.901, 0.904], [0.90001, 0.904]]
+RMS_OUT_STEP1 = [[1.0 - (0.1 * 2.0 / np.sqrt(0.901 + 1.0)), 2.0 - (0.2 * 2.0 / np.sqrt(0.904 + 1.0))],
+                 [3.0 - (0.01 * 2.0 / np.sqrt(0.90001 + 1.0)), 4.0 - (0.2 * 2.0 / np.sqrt(0.904 + 1.0))]]
+RMS_SLOT_STEP2 = [[0.901 * 0.9 + 0.001, 0.904 * 0.9 + 0.004], [0.90001 * 0.9 + 1e-5, 0.904 * 0.9 + 0.004]]
+RMS_OUT_STEP2 = [[RMS_OUT_STEP1[0][0] - (0.1 * 2.0 / np.sqrt(0.901 * 0.9 + 0.001 + 1.0)),
+                  RMS_OUT_STEP1[0][1] - (0.2 * 2.0 / np.sqrt(0.904 * 0.9 + 0.004 + 1.0))],
+                 [RMS_OUT_STEP1[1][0] - (0.01 * 2.0 / np.sqrt(0.90001 * 0.9 + 1e-5 + 1.0)),
+                  RMS_OUT_STEP1[1][1] - (0.2 * 2.0 / np.sqrt(0.904 * 0.9 + 0.004 + 1.0))]]
+#  * adam_test.py testBasic's numpy reference (adam_update_numpy), default hyper-parameters, gradients 0.1 / 0.01,
+#    three steps: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); m = beta1 m + (1 - beta1) g; v = beta2 v + (1 - beta2) g^2;
+#    param -= lr_t * m / (sqrt(v) + epsilon).
+
+
+def adam_reference(param, g, t, m, v, alpha=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
+    alpha_t = alpha * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    m_t = beta1 * m + (1 - beta1) * g
+    v_t = beta2 * v + (1 - beta2) * g * g
+    return param - alpha_t * m_t / (np.sqrt(v_t) + epsilon), m_t, v_t
+
+
+ADAM_VAR, ADAM_GRAD, ADAM_STEPS = [[1.0, 2.0], [3.0, 4.0]], [[0.1, 0.1], [0.01, 0.01]], 3
+
 # tf.clip_by_norm: tensorflow/python/kernel_tests/clip_ops_test.py, testClipByNormClipped / NotClipped
 CLIP_X = [[-3.0, 0.0, 0.0], [4.0, 0.0, 0.0]]
 CLIP_NORM_CLIPPED, CLIP_ANS_CLIPPED = 4.0, [[-2.4, 0.0, 0.0], [3.2, 0.0, 0.0]]

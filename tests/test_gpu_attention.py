@@ -393,3 +393,26 @@ def test_native_decoder_loop_against_the_step_by_step_statement(cuda, case):
         if shape is not None:
             assert rel(got[name], ref[name]) < 5e-5, (name, rel(got[name], ref[name]))
     assert ops.check_async_errors(0) == 0
+
+
+@pytest.mark.parametrize('att,prev,sig', [('bahdanau_content', 'zeros', False), ('location', 'carry', False),
+                                          ('hybrid', 'carry', True), ('luong_dot', 'zeros', False),
+                                          ('luong_concat', 'zeros', False)])
+def test_attention_class_surface(cuda, att, prev, sig):
+    """AttentionLayer / LSTMDecoderCell / AttentionDecoder under dynamic_decode with a TrainingHelper, and
+    InitialStateBridge (models/attention/decoders/*.py, bridge.py) on the HIP kernels: teacher-forced logits / weights /
+    ids equal the oracle's and the model's own fused loop (asr_att_decoder_fwd); a standalone AttentionLayer equals
+    oracle.attention.attention_step.  (Greedy inference -- the path these classes serve in the model -- is checked
+    bit-exact against the oracle by every test_attention_model_parity case.)"""
+    import _config_parity as cp
+    r = cp.run_class_surface('cuda:0', att, prev, sig, B=5, T=70, To=6, D=12, H=64, L=1, U=128, A=32, Em=8, C=9)
+    assert r['loss_rel'] < 1e-4, r['report']
+    assert r['class_logits_vs_oracle'] < 2e-4 and r['class_alpha_vs_oracle'] < 1e-5 and r['class_ids_vs_oracle'] == 0, r['report']
+    assert r['class_logits_vs_fused'] < 2e-4 and r['class_alpha_vs_fused'] < 1e-5, r['report']
+    assert r['layer_alpha'] < 1e-5 and r['layer_ctx'] < 2e-4, r['report']
+
+
+def test_bridge_classes(cuda):
+    import _config_parity as cp
+    r = cp.run_bridges('cuda:0')
+    assert r['fc_err'] < 1e-5 and r['ok_zero'] and r['ok_pass'] and r['raised'], r

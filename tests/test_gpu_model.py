@@ -632,6 +632,48 @@ def test_native_rccl_allreduce_mean_world2(cuda):
     assert res == [(0, True), (1, True)]
 
 
+def test_bench_line_of_a_two_rank_run(cuda, tmp_path):
+    """bench.py under the driver's launcher contract with TWO ranks (`python -m torch.distributed.run --nproc-per-node 2
+    bench.py --gpus 2 ...`).  On a 1-GPU box both ranks share cuda:0 and gloo stands in for RCCL (which refuses two
+    ranks on one device; ASR_BENCH_DEVICE / ASR_BENCH_BACKEND are dry-run knobs the driver never sets); with two GPUs it
+    is the real RCCL run.  Checked: the rank-0 JSON line is a 2-GPU line (n_gpus, parallelism, global batch, frames of
+    BOTH ranks), every rank padded to the global Tmax, per-rank medians and the communication stream's collectives are
+    reported, the coalesced buckets partition the gradient buffer, loss finite, hand-off error word 0."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if torch.cuda.device_count() < 2:
+        env.update(ASR_BENCH_DEVICE='0', ASR_BENCH_BACKEND='gloo', ASR_DP_COLLECTIVE='torch')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4',
+           '--warmup', '2', '--no-parity', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 32
+    assert d['scaling'] == 'weak' and d['steps'] == 4 and d['warmup'] == 2 and d['unit'] == 'frames/s'
+    pr = d['per_rank']
+    assert len(pr['frames']) == 2 and abs(sum(pr['frames']) - d['config']['frames_per_step']) < 0.5
+    assert pr['frames'][0] != pr['frames'][1]                     # every rank has its own shard of the global batch
+    assert abs(d['value'] - d['config']['frames_per_step'] * 4 / (d['ms_per_step'] * 4e-3)) < 1e-6 * d['value']
+    assert 'global Tmax' in d['config']['padded_to']
+    comm = d['comm']
+    assert comm['allreduce_calls_per_step'] == len(comm['buckets']) and comm['allreduce_ms_per_step'] > 0
+    assert abs(sum(b['mbytes'] for b in comm['buckets']) * 1e6 - comm['bytes_per_step']) < 1.0
+    assert np.isfinite(d['final_loss']) and d['cluster_handoff_flags'] == 0
+    assert d['cfgA'] is None and 'cfgC' not in d                  # auxiliary configurations are N = 1 entries
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_overfit_one_utterance_to_low_ler(cuda, dtype):
     """The reference's own model test (models/test/test_ctc.py:170-233): one utterance repeated B = 4 times, adam,

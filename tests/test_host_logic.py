@@ -795,3 +795,27 @@ def test_config_parity_runs_on_cpu_stand_ins(monkeypatch, which):
         assert r['loss_rel'] < 1e-5 and r['alpha_abs'] < 1e-5 and r['ids_mismatch'] == 0, r['report']
         assert r['ctc_logits_abs'] < 1e-4 and r['ctc_losses_rel'] < 1e-5, r['report']
     assert r['grad_worst'] < 2e-4, r['report']
+
+
+@pytest.mark.parametrize('att,prev,sig', [('bahdanau_content', 'zeros', False), ('location', 'zeros', False),
+                                          ('location', 'carry', False), ('hybrid', 'carry', True), ('dot_product', 'zeros', False),
+                                          ('luong_dot', 'zeros', False), ('luong_general', 'zeros', True),
+                                          ('luong_concat', 'zeros', False)])
+def test_attention_class_surface_on_cpu_stand_ins(monkeypatch, att, prev, sig):
+    """models/attention/decoders/{attention_layer,attention_decoder,dynamic_decoder}.py and bridge.py: AttentionDecoder
+    stepped by dynamic_decode under a TrainingHelper reproduces the oracle's teacher-forced logits / weights / ids and
+    the model's own fused loop; a standalone AttentionLayer reproduces oracle.attention.attention_step."""
+    import _config_parity as cp
+    _cpu_ops.install(monkeypatch)
+    r = cp.run_class_surface('cpu', att, prev, sig)
+    assert r['loss_rel'] < 1e-5, r['report']
+    assert r['class_logits_vs_oracle'] < 1e-4 and r['class_alpha_vs_oracle'] < 1e-5 and r['class_ids_vs_oracle'] == 0, r['report']
+    assert r['class_logits_vs_fused'] < 1e-4 and r['class_alpha_vs_fused'] < 1e-5, r['report']
+    assert r['layer_alpha'] < 1e-5 and r['layer_ctx'] < 1e-4, r['report']
+
+
+def test_bridge_classes_on_cpu_stand_ins(monkeypatch):
+    import _config_parity as cp
+    _cpu_ops.install(monkeypatch)
+    r = cp.run_bridges('cpu')
+    assert r['fc_err'] < 1e-5 and r['ok_zero'] and r['ok_pass'] and r['raised'], r

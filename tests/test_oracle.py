@@ -352,6 +352,58 @@ def test_adagrad_matches_tensorflow_known_answer():
         assert np.abs(p - want).max() < 5e-7          # TensorFlow's constants are float32 results
 
 
+def test_sgd_momentum_nesterov_rmsprop_adam_match_tensorflow_known_answers():
+    """oracle/optim.py update rules against what TensorFlow's own optimizer tests expect (gradient_descent_test.py,
+    momentum_test.py testBasic + the numpy reference of testNesterovMomentum, rmsprop_test.py testWithoutMomentum --
+    which is what fixes "rms slot starts at 1" and "epsilon inside the root" --, adam_test.py's adam_update_numpy)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import optim as oopt
+    A = lambda v: np.asarray(v, dtype=np.float64)
+    for i in range(2):
+        # sgd
+        p, s0, s1 = oopt.step('sgd', A(tfk.SGD_VAR[i]), A(tfk.SGD_GRAD[i]), None, None, tfk.SGD_LR, 1)
+        assert np.abs(p - A(tfk.SGD_OUT[i])).max() < 1e-15
+        # momentum: two steps, variables and accumulator
+        p, g = A(tfk.MOM_VAR[i]), A(tfk.MOM_GRAD[i])
+        s0, s1 = oopt.init_slots('momentum', p)
+        assert np.all(s0 == 0)
+        p, s0, s1 = oopt.step('momentum', p, g, s0, s1, tfk.MOM_LR, 1, momentum=tfk.MOM_MOMENTUM)
+        assert np.abs(p - A(tfk.MOM_OUT_STEP1[i])).max() < 1e-15
+        p, s0, s1 = oopt.step('momentum', p, g, s0, s1, tfk.MOM_LR, 2, momentum=tfk.MOM_MOMENTUM)
+        assert np.abs(p - A(tfk.MOM_OUT_STEP2[i])).max() < 1e-15 and np.abs(s0 - A(tfk.MOM_ACCUM_STEP2[i])).max() < 1e-15
+        # nesterov: TensorFlow's numpy reference, changing gradients, five steps
+        p = q = A(tfk.MOM_VAR[i])
+        s0, _ = oopt.init_slots('nestrov', p)
+        acc = np.zeros_like(q)
+        for t in range(1, 6):
+            g = A(tfk.MOM_GRAD[i]) * (1.0 + 0.3 * t) * (-1) ** t
+            p, s0, _ = oopt.step('nestrov', p, g, s0, None, 2.0, t, momentum=0.9)
+            q, acc = tfk.nesterov_reference(q, acc, g, 2.0, 0.9)
+            assert np.abs(p - q).max() < 1e-14 and np.abs(s0 - acc).max() < 1e-14
+        # rmsprop: slot initial value, epsilon placement, two steps
+        p, g = A(tfk.RMS_VAR[i]), A(tfk.RMS_GRAD[i])
+        s0, s1 = oopt.init_slots('rmsprop', p)
+        assert np.all(s0 == 1.0)
+        p, s0, s1 = oopt.step('rmsprop', p, g, s0, s1, tfk.RMS_LR, 1, decay=tfk.RMS_DECAY, rms_eps=tfk.RMS_EPS)
+        assert np.abs(s0 - A(tfk.RMS_SLOT_STEP1[i])).max() < 1e-15 and np.abs(p - A(tfk.RMS_OUT_STEP1[i])).max() < 1e-15
+        p, s0, s1 = oopt.step('rmsprop', p, g, s0, s1, tfk.RMS_LR, 2, decay=tfk.RMS_DECAY, rms_eps=tfk.RMS_EPS)
+        assert np.abs(s0 - A(tfk.RMS_SLOT_STEP2[i])).max() < 1e-15 and np.abs(p - A(tfk.RMS_OUT_STEP2[i])).max() < 1e-14
+        # adam: three steps against adam_update_numpy
+        p = q = A(tfk.ADAM_VAR[i])
+        g = A(tfk.ADAM_GRAD[i])
+        s0, s1 = oopt.init_slots('adam', p)
+        m = v = np.zeros_like(q)
+        for t in range(1, tfk.ADAM_STEPS + 1):
+            p, s0, s1 = oopt.step('adam', p, g, s0, s1, 0.001, t)
+            q, m, v = tfk.adam_reference(q, g, t, m, v)
+            assert np.abs(p - q).max() < 1e-15
+        # ... which for a constant gradient moves every entry by lr * g / (|g| + eps / sqrt(1 - beta2^t)) per step
+        want = A(tfk.ADAM_VAR[i]) - sum(0.001 * g / (np.abs(g) + 1e-8 / np.sqrt(1 - 0.999 ** t)) for t in (1, 2, 3))
+        assert np.abs(p - want).max() < 1e-12
+
+
 def test_clip_by_norm_matches_tensorflow_known_answer():
     """oracle/optim.py clip_by_norm against TensorFlow's clip_ops_test.py testClipByNormClipped / NotClipped."""
     import sys
