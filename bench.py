@@ -47,6 +47,15 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
 MFMA_F32_PEAK_TF = 157.3
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr with the seconds since start (stdout carries only the JSON line)."""
+    sys.stderr.write('[bench %7.1f s] %s\n' % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
 # ------------------------------------------------------------------------------------------------ synthetic batches
 def make_batch(seed, B, D, C, tmin, tmax, label_div=8, label_lo=5, label_hi=75):
     rng = np.random.RandomState(seed)
@@ -209,25 +218,32 @@ def parity_vs_oracle(model, x, seq_len, labels, L, dtype, tcut):
 
 def cpu_baseline_blstm_ctc(args, wl, model, x, seq_len, labels):
     """oracle/fast_cpu.py (torch-CPU fp32 restatement of the TF1 CPU step) on the timed batch cut to its first
-    --cpu-tmax frames, at several thread counts of the box's host; the best one is `value`."""
+    --cpu-tmax frames.  Thread sweep over the box's host cores on a short probe (the batch cut to 32 frames, one step
+    each: the per-step loop of small matrix products does not scale with threads, and 256 threads on a 256-core host
+    take minutes per step on the full sample), then the full sample at the probe's best thread count."""
     from oracle import fast_cpu
     sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
-    xc, sl, labs, _ = truncate_batch(x, seq_len, labels, args.cpu_tmax)
-    cframes = int(sl.sum())
     ncpu = os.cpu_count() or 1
-    sweep = sorted(set(min(int(t), ncpu) for t in args.cpu_threads.split(',') if t) | ({ncpu} if args.cpu_all_cores else set()))
-    runs = []
+    sweep = sorted(set(min(int(t), ncpu) for t in args.cpu_threads.split(',') if t) | {ncpu})
+    xp, slp, labp, _ = truncate_batch(x, seq_len, labels, 32)
+    probes = []
     for nt in sweep:
         cm = fast_cpu.CpuBLSTMCTC(sd, wl['layers'], cell_clip=50.0, clip_grad_norm=5.0, threads=nt, optimizer='rmsprop')
-        t = fast_cpu.time_train_steps(cm, xc, labs, sl, steps=args.cpu_steps, warmup=1)
-        runs.append(dict(threads=nt, frames_per_s=cframes / t, seconds_per_step=t))
-    best = max(runs, key=lambda r: r['frames_per_s'])
-    return dict(value=best['frames_per_s'], unit='frames/s', cores=best['threads'], kind='port', host_cores=ncpu,
-                thread_sweep=runs, seconds_per_step=best['seconds_per_step'],
+        t = fast_cpu.time_train_steps(cm, xp, labp, slp, steps=1, warmup=1)
+        probes.append(dict(threads=nt, frames_per_s=int(slp.sum()) / t, seconds_per_step=t))
+        log('cpu probe %d threads: %.2f s/step' % (nt, t))
+    best_nt = max(probes, key=lambda r: r['frames_per_s'])['threads']
+    xc, sl, labs, _ = truncate_batch(x, seq_len, labels, args.cpu_tmax)
+    cframes = int(sl.sum())
+    cm = fast_cpu.CpuBLSTMCTC(sd, wl['layers'], cell_clip=50.0, clip_grad_norm=5.0, threads=best_nt, optimizer='rmsprop')
+    t = fast_cpu.time_train_steps(cm, xc, labs, sl, steps=args.cpu_steps, warmup=1)
+    return dict(value=cframes / t, unit='frames/s', cores=best_nt, kind='port', host_cores=ncpu,
+                thread_sweep_probe=probes, seconds_per_step=t,
                 sample='%d timed training step(s) after 1 warm-up step of the same %d-utterance batch cut to its first '
                        '%d frames (%d valid frames), rmsprop, torch-CPU fp32 restatement of the TF1 path '
-                       '(oracle/fast_cpu.py); torch.set_num_threads swept over %s of a %d-core host, best reported'
-                       % (args.cpu_steps, wl['batch'], args.cpu_tmax, cframes, [r['threads'] for r in runs], ncpu))
+                       '(oracle/fast_cpu.py) at %d threads -- the best of a sweep over %s threads of the %d-core host '
+                       'on a 32-frame probe of the same batch'
+                       % (args.cpu_steps, wl['batch'], args.cpu_tmax, cframes, best_nt, [r['threads'] for r in probes], ncpu))
 
 
 def cpu_baseline_oracle_call(fn, frames, what, threads):
@@ -297,6 +313,7 @@ def run_blstm_ctc(args, wl, dev, world, rank, dev_index, steps, warmup, want_par
     res = dict(frames=frames, T=int(x.shape[1]))
     if want_parity and rank == 0:
         res['parity'] = parity_vs_oracle(model, x, seq_len, labels, L, wl['dtype'], args.cpu_tmax)
+        log('parity leg done in %.1f s' % res['parity']['seconds'])
     xd = torch.tensor(x, device=dev)
     sld = torch.tensor(seq_len, device=dev)
     opt = model._set_optimizer('rmsprop', 1e-3)
@@ -322,7 +339,9 @@ def run_blstm_ctc(args, wl, dev, world, rank, dev_index, steps, warmup, want_par
         opt.apply_gradients(None)
         return loss
 
+    log('%dx%d %s B=%d: timing %d steps' % (L, H, wl['dtype'], wl['batch'], steps))
     res.update(time_steps(step, steps, warmup, world, dev_index))
+    log('   %.3f ms/step' % (res['elapsed'] / steps * 1e3))
     if world > 1:
         multi_gpu._allreduce_mean_ = orig_ar
         n_timed = len(comm_events) * steps // (steps + warmup)     # the warm-up steps' collectives come first
@@ -375,6 +394,7 @@ def run_blstm_ctc(args, wl, dev, world, rank, dev_index, steps, warmup, want_par
         cur[0] = xd
     if want_cpu and rank == 0:
         res['cpu_baseline'] = cpu_baseline_blstm_ctc(args, wl, model, x, seq_len, labels)
+        log('cpu baseline done: %.0f frames/s at %d threads' % (res['cpu_baseline']['value'], res['cpu_baseline']['cores']))
     del model, opt
     return res
 
@@ -605,7 +625,8 @@ def main():
     ap.add_argument('--aux-warmup', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--cpu-threads', default='16,64', help='thread counts of the CPU baseline sweep (plus all cores)')
-    ap.add_argument('--cpu-all-cores', action='store_true', default=True)
+    ap.add_argument('--time-budget', type=float, default=420.0,
+                    help='seconds after which the remaining auxiliary entries are skipped (recorded as such)')
     ap.add_argument('--cpu-tmax', type=int, default=512,
                     help='CPU legs (baseline, oracle parity): the same batch truncated to its first N frames')
     args = ap.parse_args()
@@ -697,6 +718,7 @@ def main():
             out['comm'] = res.get('comm')
         del res
         torch.cuda.empty_cache()
+        log('headline done: %.0f frames/s' % value)
         if world == 1 and not args.no_cfgA:
             # BASELINE configs[0]: TIMIT-39, 2x128 BLSTM-CTC, fp32 (exact fp32 MFMA path), B=16, dropout 0.5
             wa = dict(units=128, layers=2, classes=39, dtype='f32', batch=16, input_size=120, tmin=100, tmax=778,
@@ -708,17 +730,25 @@ def main():
                                           'dropout 0.5, rmsprop, train step')
             del ra
         aux = set() if (world > 1 or args.no_aux) else set(a for a in args.aux.split(',') if a)
+        def over_budget(name):
+            if time.perf_counter() - _T0 > args.time_budget:
+                out[name] = dict(skipped='time budget of %.0f s used up' % args.time_budget)
+                log('%s skipped: time budget' % name)
+                return True
+            return False
         for name, fn in (('cfgC', lambda: run_cfgC(args, dev, dev_index)),
                          ('cfgD', lambda: run_attention_cfg(args, dev, dev_index, 'D')),
                          ('cfgE', lambda: run_attention_cfg(args, dev, dev_index, 'E')),
                          ('decode', lambda: run_decode(args, dev))):
-            if name in aux:
+            if name in aux and not over_budget(name):
+                log('%s ...' % name)
                 try:
                     out[name] = fn()
                 except Exception as e:      # an auxiliary entry must not cost the headline line
                     out[name] = dict(error=repr(e)[:400])
                 torch.cuda.empty_cache()
-        if 'D39' in aux:
+        if 'D39' in aux and not over_budget('input_width_D39'):
+            log('D39 ...')
             # SURVEY 8d names a "D = 40" variant; the class surface rejects it as the reference does (input_size % 3,
             # models/ctc/ctc.py:79: features come as static + delta + delta-delta): 39 = 13 x 3 is the nearest valid width
             wd = dict(wl, input_size=39)
@@ -726,7 +756,8 @@ def main():
             out['input_width_D39'] = blstm_ctc_entry(args, wd, rd, 20, 'headline model on D=39 (13x3) features: input_size '
                                                      '40 is rejected by the class surface as by the reference (ctc.py:79)')
             del rd
-        if 'batch' in aux:
+        if 'batch' in aux and not over_budget('batch_scaling'):
+            log('batch scaling ...')
             # what the design delivers per GPU at the recipes' own batch sizes: one 16-utterance tile per cluster,
             # so B = 32 .. 128 puts 2 .. 8 clusters per direction side by side (16 .. 64 of the 256 CUs)
             rows = []

@@ -25,12 +25,17 @@ def _grad_report(gv, ref_grads, report, floor=0.0):
     """Per-variable max |device - oracle| relative to the oracle gradient's largest entry.  `floor`: gradients whose
     largest entry is below it are compared against the floor instead (dead paths: zeros against rounding noise)."""
     worst, worst_name = 0.0, None
+    stats = {}
     for g, name in gv:
         r = ref_grads[name]
-        e = float(np.abs(g.detach().cpu().double().numpy() - r).max() / max(np.abs(r).max(), floor, 1e-30))
-        report.append('%-64s |g|max %.3e  rel-to-max %.2e' % (name, np.abs(r).max(), e))
+        gd = g.detach().cpu().double().numpy()
+        e = float(np.abs(gd - r).max() / max(np.abs(r).max(), floor, 1e-30))
+        l2 = float(np.sqrt(((gd - r) ** 2).sum()) / max(np.sqrt((r ** 2).sum()), floor, 1e-30))
+        stats[name] = (e, l2)
+        report.append('%-64s |g|max %.3e  rel-to-max %.2e  rel-L2 %.2e' % (name, np.abs(r).max(), e, l2))
         if e > worst:
             worst, worst_name = e, name
+    _grad_report.last = stats
     return worst, worst_name
 
 
@@ -111,8 +116,20 @@ def run_cfgC(device, dtype, B, T, F, W, H, L, C, seed=21):
                                                          out['loss_rel'], out['per_utt_rel'], out['logits_abs'],
                                                          out['logits_max'], t_oracle)]
     out['grad_worst'], out['grad_worst_name'] = _grad_report(gv, ref['grads'], report)
+    _split_grad_stats(out)
     out['report'] = '\n'.join(report)
     return out
+
+
+def _split_grad_stats(out):
+    """Worst max-entry error (relative to the gradient's largest entry) over the matrices / biases and, apart from them,
+    over the peephole vectors (H-element gradients summed over every frame: their largest entry is not much larger than
+    the bf16 noise floor of the sum), and the worst relative L2 error over all variables."""
+    st = _grad_report.last
+    peep = [v[0] for k, v in st.items() if k.endswith('_diag')]
+    out['grad_worst_matrices'] = max(v[0] for k, v in st.items() if not k.endswith('_diag'))
+    out['grad_worst_peepholes'] = max(peep) if peep else 0.0
+    out['grad_worst_l2'] = max(v[1] for v in st.values())
 
 
 def run_attention(device, dtype, att, B, T, To, D, H, L, U, A, Em, C, lam, prev_alpha, seed=33, joint=True):
@@ -170,6 +187,7 @@ def run_attention(device, dtype, att, B, T, To, D, H, L, U, A, Em, C, lam, prev_
     # variables without a path to the loss (W_keys of 'location', filter / W_filter weights under prev_alpha='zeros')
     # are exact zeros on both sides: compared against a floor instead of their own (zero) maximum
     out['grad_worst'], out['grad_worst_name'] = _grad_report(gv, ref['grads'], report, floor=1e-6)
+    _split_grad_stats(out)
     out['report'] = '\n'.join(report)
     out['model'], out['batch'] = model, (x, sl, labels, lsl, ctc_labels)
     return out

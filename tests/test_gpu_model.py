@@ -540,7 +540,7 @@ def test_rccl_collectives_on_the_parameter_store(cuda):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('bucket_mb', ['0', '1.5'])
+@pytest.mark.parametrize('bucket_mb', ['0', '1000'])
 def test_bucketed_gradient_averaging_on_the_communication_stream(cuda, monkeypatch, bucket_mb):
     """multi_gpu.BucketedAverager on the device: per-layer clip (+ collective) on a communication stream hung on the
     layers' gradient events while the BPTT kernels of the layers below run, the rest after the backward pass -- the
@@ -551,7 +551,7 @@ def test_bucketed_gradient_averaging_on_the_communication_stream(cuda, monkeypat
     from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
     from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu
     rng = np.random.RandomState(4)
-    monkeypatch.setenv('ASR_DP_BUCKET_MB', bucket_mb)   # 0: one collective per layer; 1.5: layers share one until 1.5 MB
+    monkeypatch.setenv('ASR_DP_BUCKET_MB', bucket_mb)   # 0: one collective per layer; 1000: all layers share one
     for dtype, H, L in (('f32', 64, 3), ('bf16', 256, 3)):
         B, T, D, C = 16, 60, 24, 9
         x, sl, labs, dense = _batch(rng, B, T, D, C)
@@ -563,7 +563,7 @@ def test_bucketed_gradient_averaging_on_the_communication_stream(cuda, monkeypat
         want = model.store.grad.clone()
         model._dropout_calls -= 1                       # replay the same dropout masks
         avg = multi_gpu.averager_for(model)
-        assert avg.ok and (len(avg.buckets) == L if bucket_mb == '0' else len(avg.buckets) < L)
+        assert avg.ok and len(avg.buckets) == (L if bucket_mb == '0' else 1)
         avg.force = True
         loss2, _ = model.compute_loss(x, dense, sl, keep_prob=0.9)
         multi_gpu.clip_and_average(model, opt, loss2)
