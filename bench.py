@@ -224,7 +224,9 @@ def cpu_baseline_blstm_ctc(args, wl, model, x, seq_len, labels):
     from oracle import fast_cpu
     sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
     ncpu = os.cpu_count() or 1
-    sweep = sorted(set(min(int(t), ncpu) for t in args.cpu_threads.split(',') if t) | {ncpu})
+    # (never all cores: on the 256-core GPU box a 256-thread run of even the 32-frame probe did not finish in 6 minutes,
+    # and 64 threads are already 5x slower than 16 -- the per-step loop is latency-bound on the CPU as well)
+    sweep = sorted(set(min(int(t), ncpu, 64) for t in args.cpu_threads.split(',') if t))
     xp, slp, labp, _ = truncate_batch(x, seq_len, labels, 32)
     probes = []
     for nt in sweep:
@@ -242,7 +244,7 @@ def cpu_baseline_blstm_ctc(args, wl, model, x, seq_len, labels):
                 sample='%d timed training step(s) after 1 warm-up step of the same %d-utterance batch cut to its first '
                        '%d frames (%d valid frames), rmsprop, torch-CPU fp32 restatement of the TF1 path '
                        '(oracle/fast_cpu.py) at %d threads -- the best of a sweep over %s threads of the %d-core host '
-                       'on a 32-frame probe of the same batch'
+                       'on a 32-frame probe of the same batch (more threads are slower: 64 threads 5x, all cores do not finish)'
                        % (args.cpu_steps, wl['batch'], args.cpu_tmax, cframes, best_nt, [r['threads'] for r in probes], ncpu))
 
 
@@ -624,7 +626,7 @@ def main():
     ap.add_argument('--aux-steps', type=int, default=5)
     ap.add_argument('--aux-warmup', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=2)
-    ap.add_argument('--cpu-threads', default='16,64', help='thread counts of the CPU baseline sweep (plus all cores)')
+    ap.add_argument('--cpu-threads', default='8,16,32', help='thread counts of the CPU baseline sweep (capped at 64)')
     ap.add_argument('--time-budget', type=float, default=420.0,
                     help='seconds after which the remaining auxiliary entries are skipped (recorded as such)')
     ap.add_argument('--cpu-tmax', type=int, default=512,

@@ -156,19 +156,22 @@ __device__ __forceinline__ float dpp_ror8_into(float old, float src) {
 // never leave the CU -- are multiplied for step s+1 right after they are written, i.e. before the wave starts polling
 // for the peers' slices, so that part of the LDS-read + MFMA phase runs under the L2 hop.  The chunk order in the
 // registers is rotated by the CU index so that the own chunks are always register chunks 0 .. KO-1.
-template <int H, bool DBG, bool EARLY = false>
-__global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
+// HSU = hidden units per CU (64: eight waves per CU, two per SIMD; 32: four waves per CU, ONE per SIMD -- twice the CUs
+// per cluster, each wave alone on its SIMD's VALU / MFMA pipes and with half the LDS fragment traffic per CU).
+template <int H, bool DBG, bool EARLY = false, int HSU = 64>
+__global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const bf16_t* __restrict__ whp,
     const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
     float cell_clip, cbf16x4_t* __restrict__ gates, bf16_t* __restrict__ hout, float* __restrict__ cs,
     float* __restrict__ c_final, float* __restrict__ h_final, u64* __restrict__ xch,
     unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
   zero_next_area(znext, zwords);
-  constexpr int G = H / HS;
+  constexpr int G = H / HSU;
+  constexpr int CTW = HSU * 8;                             // threads per workgroup: a wave owns 8 units
   constexpr int KS = H / 32;
   constexpr int LDH = H + 8;
-  constexpr int SLICE = 16 * (HS / 2);                     // granules one CU publishes per step
-  constexpr int KO = HS / 32;                              // k-chunks of one CU's own slice
+  constexpr int SLICE = 16 * (HSU / 2);                     // granules one CU publishes per step
+  constexpr int KO = HSU / 32;                              // k-chunks of one CU's own slice
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* hs = reinterpret_cast<bf16_t*>(smem);            // [2][16][LDH]
 
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   const bool rev = (d == 1);
   const bf16_t* wp = whp + (size_t)d * H * 4 * H;
   const int ul = wave * 8 + (col & 7);                     // unit inside this CU's slice
-  const unsigned jw = g * HS + ul;                         // global unit of this lane
+  const unsigned jw = g * HSU + ul;                         // global unit of this lane
   const int rbase = rg * 4 + (lo ? 0 : 2);                 // first of this lane's two batch rows
 
   int len[2];
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
   const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
   const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
 
-  for (int i = threadIdx.x; i < 2 * 16 * LDH; i += CT8) hs[i] = 0;
+  for (int i = threadIdx.x; i < 2 * 16 * LDH; i += CTW) hs[i] = 0;
   // B fragments straight out of the standard forward packing (tile = (unit/16)*4 + gate, column
   // unit%16): this lane's column of tile p is (gate p*2 + (col>>3), unit jw)
   bf16x8_t wreg[2][KS];
@@ -249,16 +252,16 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
 #pragma unroll
   for (int k = 0; k < G - 1; ++k) {
     const int gsrc = k + (k >= g ? 1 : 0);
-    ldst[k] = ((unsigned)(((lane >> 2) & 15) * LDH + gsrc * HS + (wave * 4 + (lane & 3)) * 2) * 2u) ^
+    ldst[k] = ((unsigned)(((lane >> 2) & 15) * LDH + gsrc * HSU + (wave * 4 + (lane & 3)) * 2) * 2u) ^
               lds_swz((lane >> 2) & 15);
   }
-  const unsigned lown = ((unsigned)(prow * LDH + g * HS + (ul & ~1)) * 2u) ^ lds_swz(prow);
+  const unsigned lown = ((unsigned)(prow * LDH + g * HSU + (ul & ~1)) * 2u) ^ lds_swz(prow);
   const unsigned lrd = ((unsigned)(col * LDH + rg * 8) * 2u) ^ lds_swz(col);
 
   // xproj rows of the running step, requested TWO steps ahead (slot = step parity): one step (~1.2 us) covers the
   // idle HBM latency but not always the latency beside the side streams' traffic (measured: 945 -> 931 us per launch)
   // (H = 512 keeps the one-step queue: the second slot costs 8 VGPRs the 8-CU form does not have -- 4 -> 12 spills)
-  constexpr int XD = (H <= 320) ? 2 : 1;
+  constexpr int XD = (H <= 320 || HSU == 32) ? 2 : 1;      // (one wave per SIMD may use the whole 512-register file)
   f32x4_t xq[XD][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
     for (int r = 0; r < 2; ++r) off[r] = act[r] ? oa[r] : os[r];
     // H = 256: the saved activations are stored BEHIND the poll loop, see there.  H = 512 stores them here: keeping the
     // values alive across the loop costs registers that form has not got (4 -> 12 spills, 43.3 -> 47.7 ms at cfg D).
-    constexpr bool LATE_STORE = (H <= 320);
+    constexpr bool LATE_STORE = (H <= 320 || HSU == 32);
     unsigned offs[2] = {off[0], off[1]};
     if constexpr (!LATE_STORE) {
       const bool pact = odd ? act[1] : act[0];
@@ -484,19 +487,23 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_kernel(
 //  * everything that does not depend on dh (tanh(c), the gate-derivative factors) is computed
 //    while the polls for the peers' partials are in flight.
 // xch per cluster: header + [2 parity][G dst][G src][4 tiles][64 lanes][4 words].
-template <int H, bool DBG>
-__global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
+// HSU = hidden units per CU: 64 (eight waves: 4 unit tiles x 2 row halves) or 32 (four waves, ONE per SIMD: 2 unit tiles x
+// 2 row halves, twice the CUs per cluster, the whole 512-entry register file per wave).
+template <int H, bool DBG, int HSU = 64>
+__global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
     const float* __restrict__ cs, const bf16_t* __restrict__ whpb, const float* __restrict__ peep,
     const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
     const float* __restrict__ d_h_final, cbf16x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
     u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
   zero_next_area(znext, zwords);
-  constexpr int G = H / HS;
-  constexpr int KC = 4 * HS / 32;            // k-chunks of this CU's slice (8)
+  constexpr int G = H / HSU;
+  constexpr int TPC = HSU / 16;              // 16-unit output tiles per CU (4 / 2)
+  constexpr int NWAVES = 2 * TPC;            // waves per workgroup
+  constexpr int KC = 4 * HSU / 32;           // k-chunks of this CU's slice (8 / 4)
   constexpr int KSF = 4 * H / 32;            // k-chunks of the full packing
-  constexpr int LDG = 4 * HS + 8;
-  constexpr size_t CL_U64 = XHDR + (size_t)2 * G * G * 4 * 64 * 2;   // u64 words per cluster
+  constexpr int LDG = 4 * HSU + 8;
+  constexpr size_t CL_U64 = XHDR + (size_t)2 * G * G * TPC * 64 * 2;   // u64 words per cluster
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // smem: [2][16][LDG] bf16 -- the own dG slice (MFMA A operand), double-buffered by iteration
   // parity so that ONE barrier per step orders writers and readers
@@ -508,11 +515,11 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 15, rg = lane >> 4;
-  const int hh = wave >> 2, wt = wave & 3;
+  const int hh = wave / TPC, wt = wave % TPC;
   const bool rev = (d == 1);
   const bf16_t* wp = whpb + (size_t)d * H * 4 * H;
   const int ul = wt * 16 + col;
-  const unsigned jw = g * HS + ul;
+  const unsigned jw = g * HSU + ul;
   const int rbase = rg * 4 + hh * 2;
 
   int len[2];
@@ -555,24 +562,25 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
   }
   // W_h^T fragments: own tile (4g + wt) and this wave's foreign tiles f = wave, 8 + wave, ...
   // foreign index f in [0, 4(G-1)): destination CU = (f >> 2) skipping g, tile inside it = f & 3
-  constexpr int NFT = 4 * (G - 1);                         // foreign tiles per CU (12 / 28)
+  constexpr int NFT = TPC * (G - 1);                       // foreign tiles per CU (12 / 28; HSU = 32: 14 / 30)
   // G = 4: every wave also computes its own-unit tile (both row-half waves redundantly: no hand-over, one
   //        barrier per step) next to NF = 2 / 1 foreign tiles.
   // G = 8: that would be 5 tiles x 32 fragment registers per wave and spills (measured: 8 k of the 10 k
   //        cycles per step); instead the 4 own + 28 foreign tiles are dealt 4 per wave, the own tile is
   //        computed once by the hh = 0 wave, which hands rows 2,3 to its hh = 1 partner through LDS (a
   //        second barrier per step, cheap next to 32 MFMAs per wave).
-  constexpr bool OWN_ONCE = (G == 8);
-  constexpr int NF = OWN_ONCE ? 4 : (NFT + 7) / 8;         // fragment sets per wave (last one: see below)
-  auto ftile = [&](int f) { const int q = f >> 2; return ((q + (q >= g ? 1 : 0)) << 2) | (f & 3); };
-  const int nt_own = g * 4 + wt;
+  // HSU = 32 (one wave per SIMD, 512 registers): the redundant own tile again, NF = 4 (H = 256) / 8 (H = 512) foreign sets.
+  constexpr bool OWN_ONCE = (G == 8 && HSU == 64);
+  constexpr int NF = OWN_ONCE ? 4 : (NFT + NWAVES - 1) / NWAVES;   // fragment sets per wave (last one: see below)
+  auto ftile = [&](int f) { const int q = f / TPC; return ((q + (q >= g ? 1 : 0)) * TPC) | (f % TPC); };
+  const int nt_own = g * TPC + wt;
   // OWN_ONCE: slot NF-1 is the own tile on hh = 0 waves and foreign tile 24 + wt on hh = 1 waves
-  const bool last_f = OWN_ONCE ? (hh == 1) : (wave < NFT - 8 * (NF - 1));
+  const bool last_f = OWN_ONCE ? (hh == 1) : (wave < NFT - NWAVES * (NF - 1));
   int nt_f[NF];
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
     if (OWN_ONCE) nt_f[i] = (i < NF - 1) ? ftile(wave + 8 * i) : (hh == 1 ? ftile(24 + wt) : nt_own);
-    else nt_f[i] = ftile((i < NF - 1 || last_f) ? wave + 8 * i : wave);
+    else nt_f[i] = ftile((i < NF - 1 || last_f) ? wave + NWAVES * i : wave);
   }
   bf16x8_t wo[OWN_ONCE ? 1 : KC], wf[NF][KC];
 #pragma unroll
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
   if ((kflags & 2) && g == G - 1) return;                  // TEST ONLY (ASR_LSTM_DFLAGS bit 6): a member goes missing
   f32x4_t* xs = reinterpret_cast<f32x4_t*>(xhdr + XHDR);   // [2][G dst][G src][4][64] x 16 B
   auto uslot = [&](int par, int dst, int src_, int tile) -> f32x4_t* {       // uniform part of a slot
-    return xs + ((((size_t)par * G + dst) * G + src_) * 4 + tile) * 64;
+    return xs + ((((size_t)par * G + dst) * G + src_) * TPC + tile) * 64;
   };
   const unsigned voff16 = (unsigned)lane * 16u;            // byte offset of this lane's 16-byte word group
   const unsigned pofs = (unsigned)lane * 2u + hh;          // u64 index of this lane's two rows in a slot
@@ -660,8 +668,17 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
       c_i[r] = gq[r] * gi[r] * (1.f - gi[r]);
       c_f[r] = cprev[r] * gf[r] * (1.f - gf[r]);
     }
-    const float pdh0 = pdh[0], pdh1 = pdh[1], pcp0 = pcp[0], pcp1 = pcp[1];
+    float pdh0 = pdh[0], pdh1 = pdh[1], pcp0 = pcp[0], pcp1 = pcp[1];
     const float cur0 = cc[0], cur1 = cc[1];
+    if constexpr (HSU == 32) {
+      // Everything that reads the values fetched one iteration ago is pinned HERE, ahead of the next fetch.  With 512
+      // registers the allocator alternates the fetch's destination registers between the two unrolled iterations and
+      // lets the last read of the old ones (cprev) sink below the new fetch; at the join behind the conditional fetch it
+      // then has to wait with vmcnt(0) -- for the NEW fetch, i.e. for HBM, on every step (1.25 instead of 0.95 ms/launch).
+      asm volatile("" : "+v"(pdh0), "+v"(pdh1), "+v"(pcp0), "+v"(pcp1), "+v"(cprev[0]), "+v"(cprev[1]));
+      asm volatile("" : "+v"(c_g[0]), "+v"(c_g[1]), "+v"(c_i[0]), "+v"(c_i[1]), "+v"(c_f[0]), "+v"(c_f[1]));
+      asm volatile("" : "+v"(a_o[0]), "+v"(a_o[1]), "+v"(b_c[0]), "+v"(b_c[1]), "+v"(gf[0]), "+v"(gf[1]));
+    }
     // next iteration's inputs (independent of everything below)
 #pragma unroll
     for (int r = 0; r < 2; ++r) { oa[r] += dstep; os[r] -= stride; }
@@ -701,7 +718,24 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
     // launch against 0.94 ms behind it (11.93 -> 10.52 ms per headline step); the fetch still has the rest of the
     // step to arrive.  (Written as the second arm of a run-time switch on purpose: as an unconditional statement the
     // compiler schedules these independent loads differently and the launch takes 1.06 ms.)
-    if (s > 0 && !early_fetch) prefetch(s - 1);
+    if constexpr (HSU == 32) {
+      // unconditional (the last iteration re-fetches its own rows: harmless) and pinned behind the loop by a compiler
+      // barrier: behind a branch the wait-count pass waits with vmcnt(0) -- for THIS fetch -- at the join
+      asm volatile("" ::: "memory");
+      const bool more = s > 0;                             // block-uniform
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bool actn = s - 1 < len[r];
+        const bool ldpn = (s - 1 > 0) && (s - 2 < len[r]);
+        const unsigned offl = more ? (actn ? oa[r] : os[r]) : off[r];      // (oa / os already hold iteration s - 1)
+        const unsigned offn = more ? (ldpn ? oa[r] + dstep : os[r]) : off[r];
+        pg[r] = gates[offl];
+        pcp[r] = cs[offn];
+        pdh[r] = dhout[offl];
+      }
+    } else {
+      if (s > 0 && !early_fetch) prefetch(s - 1);
+    }
     const unsigned long long t1 = C8_T();
     // ---- 4. gate gradients of the own pairs
     const float pdhv[2] = {pdh0, pdh1}, pcpv[2] = {pcp0, pcp1}, curv[2] = {cur0, cur1};
@@ -751,7 +785,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
           f32x4_t af = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kc = 0; kc < KC; ++kc) af = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[i][kc], af, 0, 0, 0);
-          xstore16(uslot(P, nt_f[i] >> 2, g, nt_f[i] & 3), voff16, tagged(af), fast);
+          xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(af), fast);
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -813,16 +847,16 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_kernel(
       sums[k] += __shfl_xor(sums[k], 32, 64);
     }
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);           // [7][HS]
+    float* red = reinterpret_cast<float*>(smem);           // [7][HSU]
     if (hh == 1 && rg == 0) {
 #pragma unroll
-      for (int k = 0; k < 7; ++k) red[k * HS + ul] = sums[k];
+      for (int k = 0; k < 7; ++k) red[k * HSU + ul] = sums[k];
     }
     __syncthreads();
     if (hh == 0 && rg == 0) {
       float* p = dpeep_part + ((size_t)cid.tile * ndir + d) * 7 * H;
 #pragma unroll
-      for (int k = 0; k < 7; ++k) p[k * H + jw] = sums[k] + red[k * HS + ul];
+      for (int k = 0; k < 7; ++k) p[k * H + jw] = sums[k] + red[k * HSU + ul];
     }
   }
 }
@@ -1348,6 +1382,7 @@ static int g_dflags = -1;
 // bit 5 (32): invert the default choice of the EARLY forward variant (A/B measurements)
 // bit 7 (128): BPTT kernel requests the next iteration's saved activations ahead of the poll loop (the old place; A/B)
 // bit 8 (256): fp32 BPTT kernel without the priority of the published tile's MFMAs (A/B)
+// bit 9 (512): H = 256 / 512 clusters of H/64 CUs x eight waves instead of H/32 CUs x four waves
 // bit 6 (64): TEST ONLY -- the last member of every cluster leaves right after the placement handshake and the
 //             spin limit drops to 2000 polls, so every hand-off times out (tests/test_gpu_ops.py checks that the
 //             error word is raised and surfaces as an exception)
@@ -1395,13 +1430,29 @@ static XchAreas xch_take(asr_handle* h, char* base, size_t need, hipStream_t st)
   return x;
 }
 
-template <int H>
+// ASR_LSTM_FWD_HS=32: forward recurrence on clusters of H/32 CUs with four waves each (one per SIMD) instead of H/64
+// CUs with eight (A/B switch)
+// Units per CU of the H = 256 / 512 clusters: 32 (default since round 3: H/32 CUs with four waves each, one per SIMD) or
+// 64 (H/64 CUs with eight waves; ASR_LSTM_HS=64, ASR_LSTM_FWD_HS / ASR_LSTM_BWD_HS for one pass only, or
+// ASR_LSTM_DFLAGS bit 9 at run time -- the tests run both).  Measured (profiles/r03_cluster_hs32.md): forward
+// 907 -> 866 us and BPTT 953 -> 929 us per launch at H = 256 (T = 778), 1791 -> 1374 and 2354 -> 1833 us at H = 512.
+static int units_per_cu(const char* specific) {
+  if (dbg_flags() & 512) return 64;
+  const char* e = getenv(specific);
+  if (!e) e = getenv("ASR_LSTM_HS");
+  return (e && atoi(e) == 64) ? 64 : 32;
+}
+static int fwd_units_per_cu() { return units_per_cu("ASR_LSTM_FWD_HS"); }
+static int bwd_units_per_cu() { return units_per_cu("ASR_LSTM_BWD_HS"); }
+
+template <int H, int HSU = 64>
 static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const float* xproj, const void* whp,
                                const float* peep, const int32_t* seq_len, float fb, float clip, void* gates,
                                void* hout, float* cs, float* cf, float* hf, hipStream_t st) {
-  constexpr int G = H / HS;
+  constexpr int G = H / HSU;
+  static_assert(G <= XHDR, "placement header too small");
   const int ncl = (B / 16) * ndir;
-  const size_t need = (size_t)ncl * (XHDR + 2 * G * 16 * (HS / 2)) * sizeof(u64);
+  const size_t need = (size_t)ncl * (XHDR + 2 * G * 16 * (HSU / 2)) * sizeof(u64);
   if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
       (int)cluster_grid(G, ncl) > h->num_cu)   // every member must be resident at once: 1 workgroup per CU
     return false;
@@ -1409,10 +1460,13 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   const XchAreas xa = xch_take(h, base, need, st);
   // EARLY (own-slice k-chunks multiplied under the L2 hop): measured at H = 256 (round 2, cfg B): 970 -> 938 us per
   // launch, at H = 320: 1069 -> 969; default at both.  ASR_LSTM_DFLAGS bit 5 (32) inverts the default for A/B measurements.
-  const bool early = (H == 256 || H == 320) != ((dbg_flags() & 32) != 0);   // H = 320: 1069 -> 969 us per launch
-  auto k = g_cdbg_host ? lstm_fwd_cluster8_kernel<H, true>
-                       : (early ? lstm_fwd_cluster8_kernel<H, false, true> : lstm_fwd_cluster8_kernel<H, false, false>);
-  hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8), (size_t)2 * 16 * (H + 8) * 2, st, T, B, ndir,
+  const bool early = (H == 256 || H == 320 || HSU == 32) != ((dbg_flags() & 32) != 0);   // H = 320: 1069 -> 969 us per launch
+  auto k = g_cdbg_host ? lstm_fwd_cluster8_kernel<H, true, false, HSU>
+                       : (early ? lstm_fwd_cluster8_kernel<H, false, true, HSU> : lstm_fwd_cluster8_kernel<H, false, false, HSU>);
+  // (padding the LDS request past half a CU so that two 4-wave members can never share one was measured: no
+  // difference, 866.7 vs 867.6 us -- the dispatcher spreads the members over the CUs by itself)
+  const size_t lds = (size_t)2 * 16 * (H + 8) * 2;
+  hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir,
                      (const f32x4_t*)xproj, (const bf16_t*)whp, peep, seq_len, fb, clip, (cbf16x4_t*)gates,
                      (bf16_t*)hout, cs, cf, hf, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
   return true;
@@ -1425,27 +1479,34 @@ bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
   if (!cluster_enabled() || (H != 256 && H != 512 && !(H == 320 && cluster_320_enabled()))) return false;
   cdbg_setup();
   if (H == 320) return cluster_fwd_launch<320>(h, T, B, ndir, xproj, whp, peep, seq_len, fb, clip, gates, hout, cs, cf, hf, st);
+  if (fwd_units_per_cu() == 32) {
+    const bool ok = H == 512
+        ? cluster_fwd_launch<512, 32>(h, T, B, ndir, xproj, whp, peep, seq_len, fb, clip, gates, hout, cs, cf, hf, st)
+        : cluster_fwd_launch<256, 32>(h, T, B, ndir, xproj, whp, peep, seq_len, fb, clip, gates, hout, cs, cf, hf, st);
+    if (ok) return true;
+  }
   return H == 512 ? cluster_fwd_launch<512>(h, T, B, ndir, xproj, whp, peep, seq_len, fb, clip, gates, hout, cs, cf, hf, st)
                   : cluster_fwd_launch<256>(h, T, B, ndir, xproj, whp, peep, seq_len, fb, clip, gates, hout, cs, cf, hf, st);
 }
 
-template <int H>
+template <int H, int HSU = 64>
 static bool cluster_bwd_launch(asr_handle* h, int T, int B, int ndir, const float* dhout, const void* gates,
                                const float* cs, const void* whpb, const float* peep, const int32_t* seq_len,
                                const float* dcf, const float* dhf, void* dgates, float* dpeep_part,
                                hipStream_t st) {
-  constexpr int G = H / HS;
+  constexpr int G = H / HSU;
+  static_assert(G <= XHDR, "placement header too small");
   const int ncl = (B / 16) * ndir;
-  const size_t need = (size_t)ncl * (XHDR + (size_t)2 * G * G * 4 * 64 * 2) * sizeof(u64);
+  const size_t need = (size_t)ncl * (XHDR + (size_t)2 * G * G * (HSU / 16) * 64 * 2) * sizeof(u64);
   if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
       (int)cluster_grid(G, ncl) > h->num_cu)   // every member must be resident at once: 1 workgroup per CU
     return false;
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
   const XchAreas xa = xch_take(h, base, need, st);
   // two dG images; the H = 512 form adds the own-tile hand-over buffer behind them
-  const size_t lds = (size_t)2 * 16 * (4 * HS + 8) * 2 + (G == 8 ? 2 * 4 * 64 * 8 : 0);
-  auto k = g_cdbg_host ? lstm_bwd_cluster8_kernel<H, true> : lstm_bwd_cluster8_kernel<H, false>;
-  hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8), lds, st, T, B, ndir, dhout,
+  const size_t lds = (size_t)2 * 16 * (4 * HSU + 8) * 2 + ((G == 8 && HSU == 64) ? 2 * 4 * 64 * 8 : 0);
+  auto k = g_cdbg_host ? lstm_bwd_cluster8_kernel<H, true, HSU> : lstm_bwd_cluster8_kernel<H, false, HSU>;
+  hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir, dhout,
                      (const cbf16x4_t*)gates, cs, (const bf16_t*)whpb, peep, seq_len, dcf, dhf,
                      (cbf16x4_t*)dgates, dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
   return true;
@@ -1459,6 +1520,13 @@ bool asr_cluster_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const flo
   cdbg_setup();
   if (H == 320)
     return cluster_bwd_launch<320>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st);
+  if (bwd_units_per_cu() == 32) {
+    // (falls through to the 64-unit form when the exchange area of the wider clusters does not fit)
+    const bool ok = H == 512
+        ? cluster_bwd_launch<512, 32>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st)
+        : cluster_bwd_launch<256, 32>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st);
+    if (ok) return true;
+  }
   return H == 512 ? cluster_bwd_launch<512>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st)
                   : cluster_bwd_launch<256>(h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st);
 }

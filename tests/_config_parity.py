@@ -129,7 +129,8 @@ def _split_grad_stats(out):
     peep = [v[0] for k, v in st.items() if k.endswith('_diag')]
     out['grad_worst_matrices'] = max(v[0] for k, v in st.items() if not k.endswith('_diag'))
     out['grad_worst_peepholes'] = max(peep) if peep else 0.0
-    out['grad_worst_l2'] = max(v[1] for v in st.values())
+    out['grad_worst_l2'] = max(v[1] for k, v in st.items() if not k.endswith('_diag'))
+    out['grad_worst_l2_peepholes'] = max([v[1] for k, v in st.items() if k.endswith('_diag')] or [0.0])
 
 
 def run_attention(device, dtype, att, B, T, To, D, H, L, U, A, Em, C, lam, prev_alpha, seed=33, joint=True):

@@ -36,7 +36,9 @@ def test_cfgC_vgg_blstm_4x512_bf16_ragged_two_tiles(cuda):
     # The exact two-tile / valid-frame logic is what the fp32 run below pins to 2e-3.
     assert r['loss_rel'] < 2e-3 and r['per_utt_rel'] < 5e-3, r['report']
     assert r['logits_abs'] < 3e-2 * max(1.0, r['logits_max']), r['report']
-    assert r['grad_worst_matrices'] < 7e-2 and r['grad_worst_peepholes'] < 1.5e-1 and r['grad_worst_l2'] < 6e-2, r['report']
+    # relative L2 error: matrices / biases <= 3.1e-2, peephole vectors <= 6.9e-2
+    assert r['grad_worst_matrices'] < 7e-2 and r['grad_worst_l2'] < 5e-2, r['report']
+    assert r['grad_worst_peepholes'] < 1.5e-1 and r['grad_worst_l2_peepholes'] < 1e-1, r['report']
 
 
 def test_cfgC_two_tiles_ragged_fp32(cuda):

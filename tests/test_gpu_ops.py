@@ -324,20 +324,23 @@ def test_lstm_cluster_exchange_paths(cuda):
     lens[0], lens[5] = T, 1
     x, ps = _lstm_case(rng, T, B, D, H, ndir, lens, init=0.1)
     dout = rng.randn(T, B, ndir * H)
-    res = []
-    try:
-        for flags in (0, 16):
-            ops.debug_set_lstm_flags(flags)
-            res.append(_run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', 50.0, dout))
-            assert ops.check_async_errors(0) == 0
-    finally:
-        ops.debug_set_lstm_flags(0)
-    for k in ('hout', 'cf', 'hf', 'dgates', 'dpeep'):
-        assert np.array_equal(res[0][k], res[1][k]), k
-    for b in range(B):   # saved cell states are only defined on valid frames
-        assert np.array_equal(res[0]['cs'][:lens[b], b], res[1]['cs'][:lens[b], b])
     ref = _oracle_layer(x, ps, lens, ndir, 50.0, dout)
-    assert np.abs(res[0]['hout'] - ref['hout']).max() < 3e-2
+    # both cluster shapes: H/32 CUs x four waves (default) and H/64 CUs x eight waves (flag bit 9 = 512); the two sum
+    # the k-chunks of h W_h in different orders, so bit-identity is asserted per shape, between the exchange flavours
+    for base in (0, 512):
+        res = []
+        try:
+            for flags in (base, base | 16):
+                ops.debug_set_lstm_flags(flags)
+                res.append(_run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', 50.0, dout))
+                assert ops.check_async_errors(0) == 0
+        finally:
+            ops.debug_set_lstm_flags(0)
+        for k in ('hout', 'cf', 'hf', 'dgates', 'dpeep'):
+            assert np.array_equal(res[0][k], res[1][k]), (base, k)
+        for b in range(B):   # saved cell states are only defined on valid frames
+            assert np.array_equal(res[0]['cs'][:lens[b], b], res[1]['cs'][:lens[b], b])
+        assert np.abs(res[0]['hout'] - ref['hout']).max() < 3e-2
 
 
 @pytest.mark.parametrize('T,B,ndir,clip', [(301, 16, 2, 0.0), (150, 32, 1, 2.0), (778, 16, 2, 50.0)])
@@ -436,12 +439,24 @@ def _err_stats(got, ref):
 
 
 # (H, B, T, cell_clip): the shapes bench.py times (cfg B: H=256, B=16, T<=778), the cfg C/D width and H = 320
-HEADLINE_LSTM = [(256, 16, 778, 50.0), (256, 32, 300, 1.0), (512, 16, 300, 50.0), (512, 32, 778, 50.0),
-                 (320, 16, 250, 50.0), (320, 32, 90, 1.0)]      # 320: the width of most of the reference's recipes (5 CUs)
+HEADLINE_LSTM = [(256, 16, 778, 50.0, 0), (256, 32, 300, 1.0, 0), (512, 16, 300, 50.0, 0), (512, 32, 778, 50.0, 0),
+                 (320, 16, 250, 50.0, 0), (320, 32, 90, 1.0, 0),    # 320: the width of most of the reference's recipes (5 CUs)
+                 # flag bit 9: clusters of H/64 CUs x eight waves (the round-2 form; default is H/32 CUs x four waves)
+                 (256, 16, 778, 50.0, 512), (512, 32, 300, 1.0, 512)]
 
 
-@pytest.mark.parametrize('H,B,T,clip', HEADLINE_LSTM)
-def test_lstm_cluster_bf16_gradient_parity_headline_shapes(cuda, H, B, T, clip):
+@pytest.fixture
+def lstm_flags():
+    from tensorflow_end2end_speech_recognition_amd import ops
+
+    def set_flags(f):
+        ops.debug_set_lstm_flags(f)
+    yield set_flags
+    ops.debug_set_lstm_flags(0)
+
+
+@pytest.mark.parametrize('H,B,T,clip,flags', HEADLINE_LSTM)
+def test_lstm_cluster_bf16_gradient_parity_headline_shapes(cuda, lstm_flags, H, B, T, clip, flags):
     """The multi-CU bf16 recurrence kernels (lstm_{fwd,bwd}_cluster8_kernel<256|512>, what bench.py times) against the
     oracle evaluated ON THE SAME bf16-rounded operands (oracle.lstm.layer_*_np with round_fn=bf16_round reproduces the
     kernels' rounding points: x, W, fed-back / emitted h, saved gates, dG entering dG.W_h^T), at the headline shapes:
@@ -456,6 +471,7 @@ def test_lstm_cluster_bf16_gradient_parity_headline_shapes(cuda, H, B, T, clip):
     mean 3e-4 .. 1e-3; dW_x 1.7e-3 .. 4.5e-3, dW_h 1.2e-3 .. 2.9e-3, dx 2.0e-3 .. 3.7e-3, dpeep / db 1e-3 .. 2.6e-3.
     Reference semantics: models/encoders/core/blstm.py:286-323."""
     ops = _ops()
+    lstm_flags(flags)
     ndir, D = 2, 48
     rng = np.random.RandomState(H + B + T)
     lens = rng.randint(T // 3, T + 1, size=B)
