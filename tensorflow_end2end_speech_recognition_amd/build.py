@@ -21,7 +21,9 @@ FLAGS = ['--offload-arch=%s' % ARCH, '-O3', '-std=c++17', '-fPIC', '-Wno-unused-
 # ctc.hip: the SLP vectoriser pairs the per-state multiplies of the single-wave recursion into v_pk_mul_f32 and then
 # re-packs freshly loaded emission registers right behind their global_load (s_waitcnt vmcnt(0) every frame: the whole
 # memory latency on the serial chain); without it the loads stay 8 frames ahead of their use
-FILE_FLAGS = {'ctc.hip': ['-fno-slp-vectorize']}
+# lstm_cluster.hip: MFMA results in VGPRs (the default picks AGPR accumulators for the 4-wave kernels, whose gate math then
+# starts with 12 v_accvgpr_read per step on the serial chain)
+FILE_FLAGS = {'ctc.hip': ['-fno-slp-vectorize'], 'lstm_cluster.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 
 def _hipcc():
