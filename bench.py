@@ -244,7 +244,8 @@ def cpu_baseline_blstm_ctc(args, wl, model, x, seq_len, labels):
                 sample='%d timed training step(s) after 1 warm-up step of the same %d-utterance batch cut to its first '
                        '%d frames (%d valid frames), rmsprop, torch-CPU fp32 restatement of the TF1 path '
                        '(oracle/fast_cpu.py) at %d threads -- the best of a sweep over %s threads of the %d-core host '
-                       'on a 32-frame probe of the same batch (more threads are slower: 64 threads 5x, all cores do not finish)'
+                       'on a 32-frame probe of the same batch (more threads are slower: 64 threads 5x, all cores do not finish; a 512-frame cut takes 33 s per step at '
+                       '16 threads -- 176 frames/s -- against 1.5 s for this 256-frame one, so the shorter cut favours the CPU)'
                        % (args.cpu_steps, wl['batch'], args.cpu_tmax, cframes, best_nt, [r['threads'] for r in probes], ncpu))
 
 
@@ -569,6 +570,10 @@ def run_decode(args, dev):
             t = (time.perf_counter() - t0) / reps
             ent[kind] = dict(utterances_per_s=B / t, frames_per_s=B * T / t, ms_per_call=t * 1e3, batch=B, frames=T,
                              classes=C, **({'beam_width': W} if kind == 'beam' else {}))
+            if kind == 'greedy':     # one pass over the logits: HBM roofline (wall time of the two launches incl. launch gaps)
+                gbs = B * T * C * 4 / t / 1e9
+                ent[kind]['roofline'] = dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS,
+                                             algorithmic_bytes=B * T * C * 4, traffic=None)
             # CPU: the oracle decoder on log-softmax of the first tcut frames of the first utterance(s), one core
             lp = torch.log_softmax(logits[:tcut_cpu, :bcut_cpu].transpose(0, 1).double().cpu(), 2).numpy()
             slc = np.full(bcut_cpu, tcut_cpu)
@@ -629,7 +634,7 @@ def main():
     ap.add_argument('--cpu-threads', default='8,16,32', help='thread counts of the CPU baseline sweep (capped at 64)')
     ap.add_argument('--time-budget', type=float, default=420.0,
                     help='seconds after which the remaining auxiliary entries are skipped (recorded as such)')
-    ap.add_argument('--cpu-tmax', type=int, default=512,
+    ap.add_argument('--cpu-tmax', type=int, default=256,
                     help='CPU legs (baseline, oracle parity): the same batch truncated to its first N frames')
     args = ap.parse_args()
 

@@ -13,7 +13,7 @@
  *   - the caller owns every tensor and every per-call workspace argument (asr_*_workspace_bytes);
  *     the handle owns ONE scratch arena, allocated once by asr_create / asr_create_ex and reported by
  *     asr_scratch_bytes: deterministic split-K slabs and chunk partials of the calls that say so, and
- *     (its top 16 MiB) the exchange slots + error word of the multi-CU recurrence kernels.  A call
+ *     (its top 64 MiB) the exchange slots + error word of the multi-CU recurrence kernels.  A call
  *     that needs more than the arena holds returns ASR_ERR_WORKSPACE -- create the handle larger.
  *     No allocation and no synchronisation inside any call; everything is enqueued on `stream`;
  *   - row-major, contiguous unless a leading dimension (ld*) is given;
@@ -56,8 +56,8 @@ typedef enum {
 
 /* ---- lifetime ------------------------------------------------------------ */
 int asr_abi_version(void);
-int asr_create(asr_handle** out, int device);                        /* 128 MiB scratch arena */
-int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes); /* >= 32 MiB */
+int asr_create(asr_handle** out, int device);                        /* 192 MiB scratch arena */
+int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes); /* >= 96 MiB (64 MiB of it: recurrence exchange areas) */
 size_t asr_scratch_bytes(asr_handle* h);
 int asr_destroy(asr_handle* h);
 const char* asr_last_error_string(asr_handle* h);

@@ -123,7 +123,8 @@ __device__ __forceinline__ void asr_dropout_words(uint64_t ctr, uint64_t seed, f
 }
 
 // top ASR_XCH_BYTES of the scratch: granule exchange + error word of the multi-CU LSTM kernels
-static constexpr size_t ASR_XCH_BYTES = (size_t)16 << 20;
+// (64 MB: two areas; the BPTT kernel's H = 512 clusters of 16 CUs take 1 MB of slots each, 16 clusters at B = 128)
+static constexpr size_t ASR_XCH_BYTES = (size_t)64 << 20;
 bool asr_cluster_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* xproj,
                          const void* whp, const float* peep, const int32_t* seq_len, float fb,
                          float clip, void* gates, void* hout, float* cs, float* cf, float* hf,

@@ -356,24 +356,26 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
 }
 
 // ---- greedy decode -------------------------------------------------------------
-__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ logits, int T,
-                                                         int B, int C,
+// tf.nn.ctc_greedy_decoder (ctc.py:341-342) / GreedyDecoder (greedy_decoder.py:19-50): per-frame argmax (first maximum
+// wins), collapse repeats, drop blanks.  Two launches:
+//  1. ctc_argmax_kernel -- one WAVE per valid (t, b) row over the whole grid: the only pass over the logits, HBM-bound
+//     (a 3 387-class row is 13.5 KB: with one workgroup per utterance -- the first version -- 8 utterances kept 8 CUs busy
+//     and the pass ran at 24 GB/s); writes the frame's argmax to out_labels[b, t], which serves as the scratch row;
+//  2. ctc_collapse_kernel -- one workgroup per utterance: its row of argmaxes -> LDS, ordered compaction back into
+//     out_labels[b, :n], -1 behind it.
+__global__ __launch_bounds__(256) void ctc_argmax_kernel(const float* __restrict__ logits, int T, int B, int C,
                                                          const int32_t* __restrict__ seq_len,
-                                                         int blank, int32_t* __restrict__ out_labels,
-                                                         int32_t* __restrict__ out_len) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int32_t* am = reinterpret_cast<int32_t*>(smem);  // [T] per-frame argmax
-  __shared__ int32_t wsum[4];
-  __shared__ int32_t carry;
-  const int b = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int Tb = min(max(seq_len[b], 0), T);
-  for (int t = wave; t < Tb; t += 4) {
-    const float* row = logits + ((size_t)t * B + b) * C;
+                                                         int32_t* __restrict__ out_labels) {
+  const int lane = threadIdx.x & 63;
+  const size_t nrows = (size_t)T * B;
+  for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += (size_t)gridDim.x * 4) {
+    const int t = (int)(row / B), b = (int)(row % B);
+    if (t >= min(max(seq_len[b], 0), T)) continue;       // wave-uniform
+    const float* p = logits + row * C;
     float best = NEG_INF;
     int bi = 0x7fffffff;
     for (int k = lane; k < C; k += 64) {
-      const float v = row[k];
+      const float v = p[k];
       if (v > best || (v == best && k < bi)) { best = v; bi = k; }
     }
 #pragma unroll
@@ -382,8 +384,21 @@ __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict
       const int oi = __shfl_xor(bi, o, 64);
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if (lane == 0) am[t] = (bi == 0x7fffffff) ? 0 : bi;
+    if (lane == 0) out_labels[(size_t)b * T + t] = (bi == 0x7fffffff) ? 0 : bi;
   }
+}
+
+__global__ __launch_bounds__(256) void ctc_collapse_kernel(int T, const int32_t* __restrict__ seq_len, int blank,
+                                                           int32_t* __restrict__ out_labels,
+                                                           int32_t* __restrict__ out_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* am = reinterpret_cast<int32_t*>(smem);  // [T] per-frame argmax
+  __shared__ int32_t wsum[4];
+  __shared__ int32_t carry;
+  const int b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Tb = min(max(seq_len[b], 0), T);
+  for (int t = threadIdx.x; t < Tb; t += 256) am[t] = out_labels[(size_t)b * T + t];
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   // ordered compaction, 256 frames per pass
@@ -511,9 +526,12 @@ extern "C" int asr_ctc_greedy_decode(asr_handle* h, const float* logits, int T, 
     ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_ctc_greedy_decode: bad args T=%d B=%d C=%d", T, B, C);
   const size_t lds = (size_t)T * sizeof(int32_t);
   if (lds > 150 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_greedy_decode: T=%d too long", T);
-  (void)hipFuncSetAttribute((const void*)ctc_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, logits, T, B, C, seq_len,
-                     blank, out_labels, out_len);
+  (void)hipFuncSetAttribute((const void*)ctc_collapse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t nrows = (size_t)T * B;
+  const unsigned ablocks = (unsigned)((nrows + 3) / 4 < 16384 ? (nrows + 3) / 4 : 16384);
+  hipLaunchKernelGGL(ctc_argmax_kernel, dim3(ablocks), dim3(256), 0, (hipStream_t)s, logits, T, B, C, seq_len, out_labels);
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(256), lds, (hipStream_t)s, T, seq_len, blank, out_labels,
+                     out_len);
   ASR_CHECK_LAUNCH(h, "asr_ctc_greedy_decode");
   return ASR_OK;
 }

@@ -7,11 +7,11 @@
 
 extern "C" int asr_abi_version(void) { return 1; }
 
-extern "C" int asr_create(asr_handle** out, int device) { return asr_create_ex(out, device, (size_t)128 << 20); }
+extern "C" int asr_create(asr_handle** out, int device) { return asr_create_ex(out, device, (size_t)192 << 20); }
 extern "C" size_t asr_scratch_bytes(asr_handle* h) { return h ? h->scratch_bytes : 0; }
 
 extern "C" int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes) {
-  if (!out || scratch_bytes < ((size_t)32 << 20)) return ASR_ERR_INVALID_ARG;
+  if (!out || scratch_bytes < ((size_t)96 << 20)) return ASR_ERR_INVALID_ARG;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return ASR_ERR_HIP;
   if (hipSetDevice(device) != hipSuccess) return ASR_ERR_HIP;
