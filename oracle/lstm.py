@@ -282,3 +282,52 @@ def layer_param_grads_np(x_tm, hout, dgates, lens, p, reverse=False, round_fn=No
     dw = np.concatenate([x_tm.reshape(T * B, Din).T @ dg, hp.reshape(T * B, H).T @ dg], 0)
     dx = (dg @ rnd(p['w'])[:Din].T).reshape(T, B, Din)
     return dw, dx
+
+
+# --------------------------------------------------------------------------------------------------
+# tf.contrib.rnn.LSTMCell with a projection layer (num_proj), the cell models/encoders/core/blstm.py:187-230 builds for
+# lstm_impl == 'LSTMCell' (Sak et al. 2014, "LSTMP"): same gates as above (split order i, j, f, o; peepholes
+# w_i_diag / w_f_diag on c_prev, w_o_diag on the new c; forget_bias added to f; cell clip before the output gate),
+# then m = (sigmoid(o) * tanh(c)) @ projection/kernel [H, P]; the RECURRENT input and the emitted output are the
+# projected m (kernel [(Din + P), 4H]), the state is (c [H], m [P]).  PARITY UNPINNED (TF1 absent).
+def lstmp_cell(x, c_prev, m_prev, w, b, wci, wcf, wco, w_proj, forget_bias=1.0, cell_clip=0.0, use_peephole=True):
+    c, h = lstm_block_cell(x, c_prev, m_prev, w, b, wci, wcf, wco, forget_bias, cell_clip, use_peephole)
+    return c, h @ w_proj
+
+
+def dynamic_rnn_p(x_tm, seq_len, p, reverse=False, drop_mask=None, forget_bias=1.0, cell_clip=0.0, use_peephole=True):
+    """dynamic_rnn over one direction of projected cells; returns out [T,B,P], (c_final [B,H], m_final [B,P])."""
+    T, B, _ = x_tm.shape
+    H = p['b'].shape[0] // 4
+    P = p['w_proj'].shape[1]
+    if reverse:
+        x_tm = reverse_sequence(x_tm, seq_len)
+    c = x_tm.new_zeros(B, H)
+    m = x_tm.new_zeros(B, P)
+    outs = []
+    for s in range(T):
+        active = (s < seq_len).to(x_tm.dtype).unsqueeze(1)
+        c_new, m_new = lstmp_cell(x_tm[s], c, m, p['w'], p['b'], p['wci'], p['wcf'], p['wco'], p['w_proj'],
+                                  forget_bias, cell_clip, use_peephole)
+        c = active * c_new + (1 - active) * c
+        m = active * m_new + (1 - active) * m
+        outs.append(m_new * active)
+    out = torch.stack(outs, dim=0)
+    if reverse:
+        out = reverse_sequence(out, seq_len)
+    if drop_mask is not None:
+        out = out * drop_mask
+    return out, (c, m)
+
+
+def blstmp_encoder(inputs_bm, seq_len, layers, drop_masks=None, **kw):
+    """BLSTMEncoder with lstm_impl='LSTMCell' and num_proj (blstm.py:187-230): layer outputs are [T,B,2P]."""
+    x = inputs_bm.transpose(0, 1)
+    final = None
+    for li, (p_fw, p_bw) in enumerate(layers):
+        m = drop_masks[li] if drop_masks is not None else (None, None)
+        o_fw, st_fw = dynamic_rnn_p(x, seq_len, p_fw, False, m[0], **kw)
+        o_bw, st_bw = dynamic_rnn_p(x, seq_len, p_bw, True, m[1], **kw)
+        x = torch.cat([o_fw, o_bw], dim=2)
+        final = (st_fw, st_bw)
+    return x, final

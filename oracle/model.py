@@ -275,3 +275,47 @@ def cldnn_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, F,
     return dict(total_loss=float(total.detach()), ctc_losses=losses.detach().numpy(), logits=logits.detach().numpy(),
                 grads=grads, enc=a2.detach().numpy().reshape(T, B, -1))
 
+
+
+def lstmp_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, cell_clip=0.0, want_grads=True,
+                            dtype=torch.float64):
+    """CTC(encoder_type='blstm', lstm_impl='LSTMCell', num_proj=P): stacked bidirectional projected LSTM cells
+    (models/encoders/core/blstm.py:187-230, tf.contrib.rnn.LSTMCell(num_proj)) -> output FC on the [T,B,2P] outputs ->
+    CTC.  Variables: blstm_hidden<i>/{fw,bw}/lstm_cell/{kernel [(Din+P),4H], bias, w_{i,f,o}_diag, projection/kernel
+    [H,P]}.  Returns dict(total_loss, ctc_losses, logits, grads, enc, final)."""
+    named = {}
+
+    def t(name):
+        v = sd[name]
+        v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        named[name] = torch.as_tensor(v, dtype=dtype).clone().requires_grad_(True)
+        return named[name]
+
+    layers = []
+    peep = 'blstm_hidden1/fw/lstm_cell/w_i_diag' in sd
+    for i in range(1, num_layers + 1):
+        dirs = []
+        for d in ('fw', 'bw'):
+            b = 'blstm_hidden%d/%s/lstm_cell' % (i, d)
+            p = dict(w=t(b + '/kernel'), b=t(b + '/bias'), w_proj=t(b + '/projection/kernel'))
+            if peep:
+                p.update(wci=t(b + '/w_i_diag'), wcf=t(b + '/w_f_diag'), wco=t(b + '/w_o_diag'))
+            else:
+                z = torch.zeros(p['b'].shape[0] // 4, dtype=dtype)
+                p.update(wci=z, wcf=z, wco=z)
+            dirs.append(p)
+        layers.append(tuple(dirs))
+    w_out, b_out = t('output/weights'), t('output/biases')
+    x = torch.as_tensor(np.asarray(inputs_btd), dtype=dtype)
+    sl = torch.as_tensor(np.asarray(seq_len), dtype=torch.long)
+    enc, final = olstm.blstmp_encoder(x, sl, layers, None, forget_bias=1.0, cell_clip=cell_clip, use_peephole=peep)
+    T, B, E = enc.shape
+    logits = (enc.reshape(T * B, E) @ w_out + b_out).reshape(T, B, -1)
+    losses = ctc_loss(logits, labels_list, seq_len)
+    total = losses.mean()
+    grads = None
+    if want_grads:
+        total.backward()
+        grads = {n: v.grad.detach().numpy().copy() for n, v in named.items()}
+    return dict(total_loss=float(total.detach()), ctc_losses=losses.detach().numpy(), logits=logits.detach().numpy(),
+                grads=grads, enc=enc.detach().numpy(), final=final)

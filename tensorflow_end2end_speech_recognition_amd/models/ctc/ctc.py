@@ -89,8 +89,8 @@ class CTC(ModelBase):
         self.time_major = time_major
         self.name = encoder_type + '_ctc'
         self.dtype = ops.dtype_id(dtype)
-        if encoder_type in ('gru', 'bgru'):
-            self.dtype = ASR_F32                         # the GRU recurrence kernels are fp32: the heads follow
+        if encoder_type in ('gru', 'bgru') or (lstm_impl == 'LSTMCell' and self.num_proj is not None):
+            self.dtype = ASR_F32                         # the GRU / projected-LSTM recurrences are fp32: the heads follow
         self.device = torch.device(device)
         self._dropout_calls = 0
         self.seed = seed

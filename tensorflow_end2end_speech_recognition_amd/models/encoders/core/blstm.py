@@ -7,7 +7,10 @@ is_training) -> (outputs, final_state)).  Every lstm_impl the reference offers
 'CudnnLSTM'; blstm.py:83-121) computes the same cell; here they all map onto
 the one fused kernel ('BasicLSTMCell' = no peephole / no clip, blstm.py:124-190).
 num_proj is dropped exactly as the reference drops it unless lstm_impl ==
-'LSTMCell' (blstm.py:49-52); a projection layer is not implemented -> ValueError.
+'LSTMCell' (blstm.py:49-52); with 'LSTMCell' it builds tf.contrib.rnn.LSTMCell's
+projected cells (blstm.py:187-230) on rnn_util.LSTMPLayer -- the step-by-step fp32
+form, for the plain 'blstm' / 'lstm' encoders (the VGG / CLDNN / multitask
+front-ends over projected cells raise ValueError: no reference recipe builds them).
 """
 import collections
 import os as _os
@@ -18,7 +21,7 @@ import torch
 from .... import ops
 from ...._lib import ASR_F32
 from ....utils.parameter import ParamStore
-from .rnn_util import LSTMLayer, declare_lstm_vars
+from .rnn_util import LSTMLayer, LSTMPLayer, declare_lstm_vars, declare_lstmp_vars
 
 WARM_BPTT = _os.environ.get('ASR_WARM_BPTT', '1') != '0'    # A-B switch of the read pass ahead of each BPTT kernel
 
@@ -40,8 +43,9 @@ class _RecurrentEncoderBase(object):
                              '"LSTMBlockFusedCell" or "CudnnLSTM".')
         self.num_units = num_units
         self.num_proj = num_proj if lstm_impl == 'LSTMCell' else None
-        if self.num_proj is not None:
-            raise ValueError('LSTMCell projection layers (num_proj) are not implemented on the HIP path')
+        if self.num_proj is not None and type(self).__name__ not in ('BLSTMEncoder', 'LSTMEncoder'):
+            raise ValueError('LSTMCell projection layers (num_proj) are implemented for the plain blstm / lstm '
+                             'encoders only, not for %s' % type(self).__name__)
         self.num_layers = num_layers
         self.lstm_impl = lstm_impl
         self.use_peephole = bool(use_peephole) and lstm_impl != 'BasicLSTMCell'
@@ -50,6 +54,8 @@ class _RecurrentEncoderBase(object):
         self.time_major = time_major
         self.name = name
         self.dtype = ops.dtype_id(dtype)
+        if self.num_proj is not None:
+            self.dtype = ASR_F32                     # the projected cells run on the step-by-step fp32 kernels
         self.seed = seed
         self.layers = None
         self.store = None
@@ -67,6 +73,14 @@ class _RecurrentEncoderBase(object):
         self.layers = []
         din = input_dim
         H = self.num_units
+        if self.num_proj is not None:
+            P = int(self.num_proj)
+            for i in range(1, self.num_layers + 1):
+                bases = self._declare_projected(store, i, din, P, rng)
+                self.layers.append(LSTMPLayer(store, bases, din, H, P, self.use_peephole, 1.0, self.clip_activation))
+                din = self.ndir * P
+            self.output_dim = self.ndir * P
+            return self.output_dim
         for i in range(1, self.num_layers + 1):
             bases = self._declare(store, i, din, rng)
             self.layers.append(LSTMLayer(store, bases, din, H, self.use_peephole, 1.0,
@@ -74,6 +88,11 @@ class _RecurrentEncoderBase(object):
             din = self.ndir * H
         self.output_dim = self.ndir * H
         return self.output_dim
+
+    def _declare_projected(self, store, i, din, P, rng):
+        scope = self.scope_prefix + (self.scope_fmt % i)
+        return declare_lstmp_vars(store, scope, din, self.num_units, P, self.ndir, self.use_peephole,
+                                  self.parameter_init, rng)
 
     def _declare(self, store, i, din, rng):
         scope = self.scope_prefix + (self.scope_fmt % i)
@@ -91,6 +110,8 @@ class _RecurrentEncoderBase(object):
         Returns outputs [T,B,ndir*H] if time_major else [B,T,ndir*H] (fp32) and final_state of
         the last layer: ((c_fw,h_fw),(c_bw,h_bw)) for the bidirectional encoder."""
         self._ensure_built(inputs)
+        if self.num_proj is not None:
+            return self._call_projected(inputs, inputs_seq_len, keep_prob, is_training, drop_masks, rng_state)
         B, T, _ = inputs.shape
         self.pad_b = (-B) % 16
         if self.pad_b:  # the kernel tiles 16 utterances; pad with zero-length rows
@@ -153,6 +174,39 @@ class _RecurrentEncoderBase(object):
             out_user = out_user.transpose(0, 1)
         return out_user, final_state
 
+    def _call_projected(self, inputs, inputs_seq_len, keep_prob, is_training, drop_masks, rng_state):
+        """lstm_impl='LSTMCell' with num_proj: the stack on LSTMPLayer.  Outputs [T,B,ndir*P]; final state
+        ((c_fw [B,H], m_fw [B,P]), (c_bw, m_bw)) of the last layer (one tuple per layer for the unidirectional stack)."""
+        B, T, _ = inputs.shape
+        self.pad_b, self.batch = 0, B
+        seq_len = inputs_seq_len.to(torch.int32).contiguous()
+        x = ops.bt_to_tb(inputs.contiguous(), ASR_F32)
+        if rng_state is None and drop_masks is None and is_training and keep_prob is not None and keep_prob < 1.0:
+            self._dropout_calls = getattr(self, '_dropout_calls', 0) + 1
+            rng_state = (self.seed, self._dropout_calls << 40)
+        finals = []
+        for li, layer in enumerate(self.layers):
+            mask = None
+            if is_training and drop_masks is not None:
+                mask = drop_masks[li]
+            elif is_training and rng_state is not None and keep_prob < 1.0:
+                mask = ops.dropout_mask((T, B, self.ndir * layer.P), keep_prob, rng_state[0],
+                                        rng_state[1] + li * (1 << 32), x.device)
+            x, fin = layer.forward(x, seq_len, mask)
+            finals.append(fin)
+            if self.num_layers_sub is not None and li + 1 == self.num_layers_sub:
+                self._out_sub_op, self._final_sub_ch = x, fin
+        self.seq_len_padded = seq_len
+        self._out_op = self._out_tm = x
+        self._finals = finals
+        self._final_ch = None
+        out_user = x if self.time_major else x.transpose(0, 1)
+        if self.ndir == 2:
+            final_state = tuple(LSTMStateTuple(c, m) for c, m in finals[-1])
+        else:
+            final_state = tuple(LSTMStateTuple(*f[0]) for f in finals)
+        return out_user, final_state
+
     def _state_tuple(self, finals, upto):
         """The reference's final_state: bidirectional_dynamic_rnn of the LAST layer -> (LSTMStateTuple fw,
         LSTMStateTuple bw) (blstm.py:313-323); MultiRNNCell under one dynamic_rnn -> one LSTMStateTuple per layer
@@ -167,6 +221,14 @@ class _RecurrentEncoderBase(object):
         """d_outputs: gradient w.r.t. the TIME-MAJOR padded-batch outputs [T,Bpad,ndir*H] fp32.
         d_outputs_sub (multitask encoders): gradient w.r.t. the sub-task outputs, joined where they branch off.
         Returns the gradient w.r.t. the (time-major) encoder input if need_input_grad."""
+        if self.num_proj is not None:
+            dx = d_outputs
+            for li in reversed(range(len(self.layers))):
+                dx = self.layers[li].backward(dx.contiguous(), None, need_dx=(li > 0 or need_input_grad))
+                if self.grad_ready_hook is not None:
+                    self.grad_ready_hook(li, self.layers[li])
+            ops.join_side(d_outputs.device)
+            return dx
         dx = d_outputs
         masked = False
         for li in reversed(range(len(self.layers))):

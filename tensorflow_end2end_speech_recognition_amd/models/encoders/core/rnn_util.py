@@ -196,3 +196,174 @@ class LSTMLayer(object):
             if self.use_peephole:
                 names += [b + '/w_i_diag', b + '/w_f_diag', b + '/w_o_diag']
         return names
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# tf.contrib.rnn.LSTMCell WITH A PROJECTION LAYER (num_proj) -- the cell the reference builds for lstm_impl == 'LSTMCell'
+# (models/encoders/core/blstm.py:187-230, lstm.py:117-180; Sak et al. 2014): the recurrent input and the emitted output
+# are m = (o * tanh(c)) @ projection/kernel [H, P], so the layer's recurrence is  pre = x W_x + b + m_prev W_h  with
+# W_h [P, 4H], and its outputs are [T, B, ndir * P].
+# No BASELINE configuration uses it, and the multi-CU recurrence kernels are built around an H x 4H recurrent matrix;
+# this layer runs the recurrence step by step on the generic kernels instead (per step: one skinny MFMA product for the
+# recurrent term, asr_lstm_cell_fwd, one for the projection; backwards the mirror image), fp32, with everything that does
+# not feed back (x W_x over all T, every weight gradient, dx) batched into single GEMMs as in LSTMLayer.  Correct and
+# complete (every reference configuration that names num_proj constructs and trains), not a fast path.
+def declare_lstmp_vars(store, scope, din, H, P, ndir, use_peephole, parameter_init, rng, cell_scope=None):
+    names = []
+    for d in range(ndir):
+        base = '%s/%s/lstm_cell' % (scope, DIRS[d]) if cell_scope is None else cell_scope
+        u = lambda *s: rng.uniform(-parameter_init, parameter_init, size=s)
+        store.declare(base + '/kernel', (din + P, 4 * H), u(din + P, 4 * H))
+        store.declare(base + '/bias', (4 * H,), np.zeros(4 * H))
+        if use_peephole:
+            store.declare(base + '/w_f_diag', (H,), u(H))
+            store.declare(base + '/w_i_diag', (H,), u(H))
+            store.declare(base + '/w_o_diag', (H,), u(H))
+        store.declare(base + '/projection/kernel', (H, P), u(H, P))
+        names.append(base)
+    return names
+
+
+class LSTMPLayer(object):
+    def __init__(self, store, bases, din, H, P, use_peephole, forget_bias=1.0, cell_clip=None):
+        self.store, self.bases = store, bases
+        self.ndir = len(bases)
+        self.din, self.H, self.P = din, H, P
+        self.use_peephole = use_peephole
+        self.forget_bias, self.cell_clip = forget_bias, cell_clip
+        self.ctx = None
+        self.grad_event = None
+
+    def var_names(self):
+        names = []
+        for b in self.bases:
+            names += [b + '/kernel', b + '/bias']
+            if self.use_peephole:
+                names += [b + '/w_f_diag', b + '/w_i_diag', b + '/w_o_diag']
+            names.append(b + '/projection/kernel')
+        return names
+
+    def _peep(self, b):
+        st = self.store
+        if not self.use_peephole:
+            return None
+        return torch.stack([st[b + '/w_i_diag'], st[b + '/w_f_diag'], st[b + '/w_o_diag']]).contiguous()
+
+    @staticmethod
+    def _frames(seq_len, T, reverse):
+        """[T,B] frame index each row works on at recurrence step s (tf.reverse_sequence on the valid prefix for the
+        backward direction; rows past their length stay on frame s) and the live mask [T,B] fp32."""
+        B = seq_len.shape[0]
+        s = torch.arange(T, device=seq_len.device).unsqueeze(1)
+        L = seq_len.to(torch.int64).unsqueeze(0)
+        live = s < L
+        src = torch.where(live, L - 1 - s, s) if reverse else s.expand(T, B)
+        return src.contiguous(), live.to(torch.float32).contiguous()
+
+    def forward(self, x, seq_len, mask=None, save=True):
+        """x [T,B,din] fp32 time-major -> (out [T,B,ndir*P], per direction final (c [B,H], m [B,P]))."""
+        st = self.store
+        T, B, din = x.shape
+        H, P, ndir = self.H, self.P, self.ndir
+        dev = x.device
+        out = torch.zeros((T, B, ndir * P), dtype=torch.float32, device=dev)
+        bidx = torch.arange(B, device=dev).unsqueeze(0)
+        saved, finals = [], []
+        for d, b in enumerate(self.bases):
+            w = st[b + '/kernel']
+            wx, wh, wp = w[:din], w[din:], st[b + '/projection/kernel']
+            peep = self._peep(b)
+            src, live = self._frames(seq_len, T, d == 1)
+            pre = ops.gemm(x.view(T * B, din), wx, bias=st[b + '/bias']).view(T, B, 4 * H)
+            pre = pre[src, bidx].contiguous()                 # step-major: row b of step s holds its own frame
+            c = torch.zeros((B, H), dtype=torch.float32, device=dev)
+            m = torch.zeros((B, P), dtype=torch.float32, device=dev)
+            hdummy = torch.zeros((B, H), dtype=torch.float32, device=dev)
+            gates_all = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+            craw_all = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+            cprev_all = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+            hraw_all = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+            mprev_all = torch.empty((T, B, P), dtype=torch.float32, device=dev)
+            mstep = torch.zeros((T, B, P), dtype=torch.float32, device=dev)
+            for s in range(T):
+                cprev_all[s].copy_(c)
+                mprev_all[s].copy_(m)
+                ops.gemm(m, wh, out=pre[s], accumulate=True)                           # + m_prev W_h
+                g, c_raw, c, _, h_raw = ops.lstm_cell_fwd(pre[s], c, hdummy, peep, live[s], self.forget_bias,
+                                                          self.cell_clip or 0.0)
+                gates_all[s].copy_(g)
+                craw_all[s].copy_(c_raw)
+                hraw_all[s].copy_(h_raw)
+                m_new = ops.gemm(h_raw, wp)                                            # projection
+                lv = live[s].unsqueeze(1)
+                m = m_new * lv + m * (1.0 - lv)               # dynamic_rnn: finished rows keep their state
+                mstep[s].copy_(m_new * lv)                    #              and emit zeros
+            # step-major -> frame-major (reverse_sequence back); padded frames are zero already
+            o = torch.zeros((T, B, P), dtype=torch.float32, device=dev)
+            o[src, bidx] = mstep
+            o = o * (torch.arange(T, device=dev).unsqueeze(1) < seq_len.to(torch.int64).unsqueeze(0)).unsqueeze(2)
+            out[:, :, d * P:(d + 1) * P] = o
+            finals.append((c, m))
+            saved.append(dict(src=src, live=live, gates=gates_all, craw=craw_all, cprev=cprev_all, hraw=hraw_all,
+                              mprev=mprev_all, peep=peep))
+        res = out if mask is None else ops.apply_mask(out, mask)
+        if save:
+            self.ctx = dict(x=x, saved=saved, mask=mask, seq_len=seq_len)
+        return res, finals
+
+    def backward(self, dout, d_final=None, need_dx=True):
+        """dout [T,B,ndir*P] fp32 -> dx [T,B,din] or None.  d_final: per direction (dc [B,H], dm [B,P]) or None."""
+        c, st = self.ctx, self.store
+        x = c['x']
+        T, B, din = x.shape
+        H, P, ndir = self.H, self.P, self.ndir
+        dev = x.device
+        if c['mask'] is not None:
+            dout = ops.apply_mask(dout.contiguous(), c['mask'])
+        bidx = torch.arange(B, device=dev).unsqueeze(0)
+        dx = torch.zeros((T, B, din), dtype=torch.float32, device=dev) if need_dx else None
+        for d, b in enumerate(self.bases):
+            sv = c['saved'][d]
+            w = st[b + '/kernel']
+            wx, wh, wp = w[:din], w[din:], st[b + '/projection/kernel']
+            src, live = sv['src'], sv['live']
+            dstep = dout[:, :, d * P:(d + 1) * P][src, bidx].contiguous()              # [T,B,P] step-major
+            dpre_all = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+            dpeep_all = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev) if self.use_peephole else None
+            dm_all = torch.empty((T, B, P), dtype=torch.float32, device=dev)
+            dc = torch.zeros((B, H), dtype=torch.float32, device=dev)
+            dm = torch.zeros((B, P), dtype=torch.float32, device=dev)
+            if d_final is not None and d_final[d] is not None:
+                dc, dm = d_final[d][0].contiguous().clone(), d_final[d][1].contiguous().clone()
+            zero_h = torch.zeros((B, H), dtype=torch.float32, device=dev)
+            for s in reversed(range(T)):
+                lv = live[s].unsqueeze(1)
+                dm_t = (dstep[s] + dm) * lv                   # gradient w.r.t. this step's projected output (live rows)
+                dm_carry = dm * (1.0 - lv)                    # finished rows: the state gradient passes through
+                dm_all[s].copy_(dm_t)
+                dh_raw = ops.gemm(dm_t, wp, transB=True)                               # [B,H]
+                _, dc, _, _ = ops.lstm_cell_bwd(dh_raw, dc, zero_h, sv['gates'][s], sv['craw'][s], sv['cprev'][s],
+                                                sv['peep'], live[s], want_dpeep=self.use_peephole,
+                                                dpre_out=dpre_all[s], dpeep_out=dpeep_all[s] if dpeep_all is not None else None)
+                dm = ops.gemm(dpre_all[s], wh, transB=True) + dm_carry                 # d m_prev
+            dp2d = dpre_all.view(T * B, 4 * H)
+            gk = st.g(b + '/kernel')
+            # x in step order for this direction: the same gather the forward applied to x W_x
+            xs = x[src, bidx].contiguous().view(T * B, din)
+            ops.gemm(xs, dp2d, transA=True, out=gk[:din])
+            ops.gemm(sv['mprev'].view(T * B, P), dp2d, transA=True, out=gk[din:])
+            ops.colsum(dp2d, out=st.g(b + '/bias'))
+            ops.gemm(sv['hraw'].view(T * B, H), dm_all.view(T * B, P), transA=True, out=st.g(b + '/projection/kernel'))
+            if self.use_peephole:
+                dp = ops.colsum(dpeep_all.view(T * B, 3 * H))
+                st.g(b + '/w_i_diag').copy_(dp[:H])
+                st.g(b + '/w_f_diag').copy_(dp[H:2 * H])
+                st.g(b + '/w_o_diag').copy_(dp[2 * H:])
+            if need_dx:
+                dxs = ops.gemm(dp2d, wx, transB=True).view(T, B, din)                  # step-major
+                dxf = torch.zeros_like(dxs)
+                dxf[src, bidx] = dxs                           # back to frame order (dpre of dead steps is zero)
+                dx += dxf
+        self.grad_event = ops.stream_event()
+        self.ctx = None
+        return dx

@@ -751,3 +751,16 @@ def test_cfgB_bf16_model_parity_at_the_benchmarked_shape(cuda):
     assert elog.max() < 5e-2 and elog.mean() < 2e-3, report[0]
     assert worst < 2e-2, '\n'.join(report)
     assert ler < 0.02, report[-1]
+
+
+@pytest.mark.parametrize('ndir,B,T,D,H,P,L', [(2, 6, 40, 24, 128, 48, 2), (1, 20, 25, 12, 64, 32, 2)])
+def test_lstmcell_projection_layers(cuda, ndir, B, T, D, H, P, L):
+    """lstm_impl='LSTMCell' with num_proj on the HIP path (rnn_util.LSTMPLayer: step-by-step fp32 on the generic
+    kernels -- skinny MFMA products, asr_lstm_cell_fwd / _bwd): loss 1e-4, logits, every gradient incl.
+    projection/kernel against the oracle's projected-cell model; trains.  Reference: blstm.py:187-230."""
+    import _config_parity as cp
+    r = cp.run_lstmp('cuda:0', B=B, T=T, D=D, H=H, P=P, L=L, C=9, ndir=ndir)
+    assert r['trained']
+    if ndir == 2:
+        print('\n' + r['report'])
+        assert r['loss_rel'] < 1e-4 and r['logits_abs'] < 2e-4 and r['grad_worst'] < 2e-3, r['report']
