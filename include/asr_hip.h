@@ -303,8 +303,12 @@ int asr_clear_async_errors(asr_handle* h, asr_stream s);
 /* Debug / test switches of the cluster kernels (process-wide, same bits as the environment variable ASR_LSTM_DFLAGS):
  * 16 = force the placement-independent write-through exchange, 64 = TEST ONLY, make every hand-off time out;
  * 32 / 128 / 256 = A-B switches of kernel variants (own-slice products ahead of the poll, the BPTT kernel's fetch ahead of
- * its poll loop, MFMA priority in the fp32 BPTT kernel), result-neutral. */
+ * its poll loop, MFMA priority in the fp32 BPTT kernel), result-neutral; 512 = clusters of H/64 CUs x eight waves instead
+ * of H/32 CUs x four (H = 256 / 512). */
 int asr_debug_set_lstm_flags(int flags);
+/* 1 (default; env ASR_GRU_PERSISTENT): asr_gru_fwd / asr_gru_bwd run ONE persistent launch per call (state in LDS, both
+ * products per step on exact-fp32 MFMA) where the LDS images fit; 0: the launch-per-step kernels. */
+int asr_debug_set_gru_persistent(int on);
 
 /* Debug: records, per workgroup of a probe grid launched on `s`, {XCC id, HW_ID register} into out[2*nblocks]
  * (device memory); every workgroup stays resident for spin_cycles so that the grid spreads over the CUs. */

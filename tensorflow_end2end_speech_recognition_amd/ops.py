@@ -738,6 +738,11 @@ def debug_set_lstm_flags(flags):
 
 
 # ---------------------------------------------------------------- CTC
+def debug_set_gru_persistent(on):
+    """asr_debug_set_gru_persistent: 1 = one persistent launch per GRU layer call (default), 0 = launch per step."""
+    _lib.load().asr_debug_set_gru_persistent(int(bool(on)))
+
+
 def ctc_loss(logits, labels_flat, label_offsets, seq_len, max_label_len, grad_scale=1.0,
              want_grad=True):
     """logits [T,B,C] fp32; returns (loss [B], grad [T,B,C] or None, num_infeasible [1] int32)."""

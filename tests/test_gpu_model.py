@@ -312,13 +312,25 @@ def test_vgg_blstm_bf16_parity_at_the_cfgC_image_size(cuda):
     assert worst < 3e-2, '\n'.join(report)
 
 
+@pytest.fixture
+def gru_mode():
+    from tensorflow_end2end_speech_recognition_amd import ops
+
+    def set_mode(persistent):
+        ops.debug_set_gru_persistent(persistent)
+    yield set_mode
+    ops.debug_set_gru_persistent(1)
+
+
+@pytest.mark.parametrize('persistent', [1, 0])
 @pytest.mark.parametrize('enc,B,T,D,H,L,C', [('bgru', 16, 37, 24, 64, 2, 12), ('gru', 5, 21, 12, 32, 2, 9),
                                             ('bgru', 20, 90, 42, 256, 1, 30)])
-def test_gru_ctc_model_loss_grads_and_step(cuda, enc, B, T, D, H, L, C):
+def test_gru_ctc_model_loss_grads_and_step(cuda, gru_mode, enc, B, T, D, H, L, C, persistent):
     """CTC(encoder_type='gru' | 'bgru') on the HIP GRU kernels (csrc/gru.hip) against the oracle's GRU model
     (oracle/gru.py, cell pinned to TensorFlow's testGRUCell): loss 1e-4, logits, EVERY gradient, final states, greedy
     labels bit-exact, ragged lengths incl. a zero-padded batch tile; then training lowers the loss.
     Reference: models/encoders/core/gru.py:9-152, models/ctc/ctc.py:150-155."""
+    gru_mode(persistent)     # 1: one persistent launch per layer call (state in LDS, exact-fp32 MFMA); 0: launch per step
     from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
     from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import sparsetensor2list
     rng = np.random.RandomState(B + T)
@@ -764,3 +776,36 @@ def test_lstmcell_projection_layers(cuda, ndir, B, T, D, H, P, L):
     if ndir == 2:
         print('\n' + r['report'])
         assert r['loss_rel'] < 1e-4 and r['logits_abs'] < 2e-4 and r['grad_worst'] < 2e-3, r['report']
+
+
+def test_gru_long_run_keeps_side_lane_bounded_and_survives_poisoned_allocator(cuda):
+    """Two regressions of the GRU encoders found in review: (1) the model's head gradients are issued on side lane 1 and
+    must be joined (ordered before clip / update, and the lane's keep list released) by the encoder's backward -- 60
+    bgru-CTC steps, the keep list stays empty after every step; (2) frames past an utterance's length are skipped by the
+    kernels, so whatever they leave there must not reach a weight gradient: the allocator is poisoned with NaNs, the
+    batch is ragged, every gradient stays finite and equal to the run on a clean allocator."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    rng = np.random.RandomState(5)
+    B, T, D, H, C = 6, 33, 12, 32, 7
+    x, sl, labs, dense = _batch(rng, B, T, D, C, lo=5)
+    sl[1], sl[4] = 7, 12
+
+    def grads(poison):
+        if poison:
+            junk = [torch.full((1 << 20,), float('nan'), device=cuda) for _ in range(24)]
+            del junk                                          # back to the caching allocator, NaN patterns intact
+        model = CTC('bgru', D, H, 2, C, parameter_init=0.1, clip_grad_norm=5.0, seed=3)
+        loss, _ = model.compute_loss(x, dense, sl, keep_prob=1.0)
+        opt = model._set_optimizer('sgd', 0.1)
+        return {n: g.cpu().numpy().copy() for g, n in opt.compute_gradients(loss, model=model)}, model
+    clean, _ = grads(False)
+    dirty, model = grads(True)
+    for n in clean:
+        assert np.isfinite(dirty[n]).all(), n
+        assert np.array_equal(clean[n], dirty[n]), n
+    for step in range(60):
+        loss, _ = model.compute_loss(x, dense, sl, keep_prob=0.9)
+        model.train(loss, 'adam', 1e-3)
+        assert all(len(st['keep']) == 0 for st in ops._side.values()), step
+    assert np.isfinite(loss.item())
