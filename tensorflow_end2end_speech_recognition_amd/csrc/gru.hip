@@ -246,14 +246,28 @@ __device__ __forceinline__ int gp_pos(int m, int k, int LD) {
   return m * LD + (k & ~15) + ((k & 3) << 2) + ((k >> 2) & 3);
 }
 
-// one 16 x 16 output tile: acc += A(LDS image, all K) * B(packed fragments of this column tile)
+// one 16 x 16 output tile: acc += A(LDS image, all K) * B(packed fragments of this column tile).  K is walked in chunks
+// of 8 groups (128 k): the chunk's eight B fragments (8 x 16 bytes per lane, from L2) are all requested before its 32
+// MFMAs -- with the loads issued one group ahead of their use a tile waited for one L2 round trip per four groups
+// (55 us per step and layer at H = 256; the matrix work is 20).  The second wave of the SIMD fills what remains.
 __device__ __forceinline__ f32x4_t gp_tile(const float* __restrict__ img, int LD, const float* __restrict__ wpk, int KG,
                                            int lane) {
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   const float* ap = img + (lane & 15) * LD + ((lane >> 4) << 2);
   const f32x4_t* bp = reinterpret_cast<const f32x4_t*>(wpk) + lane;
-#pragma unroll 4
-  for (int jj = 0; jj < KG; ++jj) {
+  int jj = 0;
+  for (; jj + 8 <= KG; jj += 8) {
+    f32x4_t b[8], a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[q] = bp[(size_t)(jj + q) * 64];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = *reinterpret_cast<const f32x4_t*>(ap + (jj + q) * 16);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][j], b[q][j], acc, 0, 0, 0);
+  }
+  for (; jj < KG; ++jj) {
     const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ap + jj * 16);
     const f32x4_t b = bp[(size_t)jj * 64];
 #pragma unroll
