@@ -257,6 +257,34 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, in
     partial[(size_t)blockIdx.y * N + col] =
         part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
+// bf16, contiguous rows of N = 8 * NV columns (the pre-activation gradients of the VGG stack: [26 M pixels x 64] ...
+// [7 M x 128], 2 - 3 GB each): a thread owns EIGHT columns (one 16-byte load per row) of every (256 / NV)-th row of the
+// block's row range, so a wave's load covers whole rows and 1 KB instead of 128 bytes.  Sums in a fixed order:
+// thread-serial over its rows, then over the block's row-threads through LDS.  partial[block][N].
+__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ a, long long M, int N,
+                                                              long long rows_per_block, float* __restrict__ partial) {
+  extern __shared__ float cred[];                          // [256 / NV][N]
+  const int NV = N / 8, RT = 256 / NV;                     // column groups, row-threads
+  const int cg = threadIdx.x % NV, rt = threadIdx.x / NV;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rt < RT) {
+    for (long long m = r0 + rt; m < r1; m += RT) {
+      const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(a + (size_t)m * N + cg * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += bf16_to_f32((bf16_t)v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cred[rt * N + cg * 8 + i] = s[i];
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < N; col += 256) {
+    float t = 0.f;
+    for (int r = 0; r < RT; ++r) t += cred[r * N + col];
+    partial[(size_t)blockIdx.x * N + col] = t;
+  }
+}
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int RB, int N, float* __restrict__ out) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= N) return;
@@ -658,6 +686,19 @@ extern "C" int asr_touch(asr_handle* h, const void* p, size_t bytes, asr_stream 
 extern "C" int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N, int lda, float* out, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ASR_NEED(asr_dtype_ok(dtype) && a && out && M >= 0 && N > 0 && lda >= N, "asr_colsum: bad args");
+  if (dtype == ASR_BF16 && lda == N && N % 8 == 0 && 256 % (N / 8) == 0 && N <= 512 && M >= 4096 &&
+      ((uintptr_t)a & 15) == 0) {
+    // tall bf16 inputs with whole-row vector loads: at most 2048 blocks, one partial row each, then the final pass
+    long long rpb = ((long long)M + 2047) / 2048;
+    if (rpb < 256) rpb = 256;
+    const int nb = (int)(((long long)M + rpb - 1) / rpb);
+    float* pv = (float*)h->scratch;
+    hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3(nb), dim3(256), (size_t)(256 / (N / 8)) * N * sizeof(float),
+                       (hipStream_t)s, (const bf16_t*)a, (long long)M, N, rpb, pv);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, pv, nb, N, out);
+    ASR_CHECK_LAUNCH(h, "asr_colsum");
+    return ASR_OK;
+  }
   int RB = (M + COLSUM_ROWS - 1) / COLSUM_ROWS > 0 ? (M + COLSUM_ROWS - 1) / COLSUM_ROWS : 1;
   // partial[RB][N], then (for tall inputs) the partials themselves are reduced 512 rows at a time, ping-pong
   // inside the scratch, until few enough remain for the one-thread-per-column final pass

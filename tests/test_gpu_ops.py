@@ -1078,3 +1078,21 @@ def test_device_batch_assembly(cuda, T, F, num_stack, num_skip, splice):
         assert not x[b, n:].any()
     with pytest.raises(ValueError):
         _ops().stack_frames(torch.zeros((1, 4, 3), device=cuda), torch.ones(1, dtype=torch.int32, device=cuda), 2, 3)
+
+
+@pytest.mark.parametrize('M,N,dtype', [(300007, 64, 'bf16'), (70001, 128, 'bf16'), (5000, 256, 'bf16'), (4100, 24, 'bf16'),
+                                       (1000, 64, 'bf16'), (33000, 62, 'f32')])
+def test_colsum_paths(cuda, M, N, dtype):
+    """asr_colsum (bias gradients: models/ctc/ctc.py output FC, the VGG stack's convolutions): the whole-row vector
+    kernel for tall bf16 inputs (N % 8 == 0) and the generic two-stage kernels, against an fp64 sum of the same
+    (rounded) values; deterministic (two runs bit-identical)."""
+    ops = _ops()
+    rng = np.random.RandomState(M % 1000 + N)
+    a = torch.tensor(rng.randn(M, N).astype(np.float32), device=cuda)
+    if dtype == 'bf16':
+        a = a.to(torch.bfloat16)
+    want = a.double().sum(0).cpu().numpy()
+    got = ops.colsum(a).cpu().numpy()
+    got2 = ops.colsum(a).cpu().numpy()
+    assert np.array_equal(got, got2)
+    assert np.abs(got - want).max() < 2e-5 * a.double().abs().sum(0).max().item()
