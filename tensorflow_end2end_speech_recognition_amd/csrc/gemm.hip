@@ -823,6 +823,159 @@ __global__ __launch_bounds__(256) void conv3x3_nt_bf16_kernel(int Mpix, int H, i
   }
 }
 
+// ---------------------------------------------------------------- 3x3 convolution, image-resident form (bf16)
+// The per-frame images of the VGG front-end are small (40 x 11 x 64 ch = 56 KB, 20 x 6 x 128 ch = 31 KB), so a whole
+// image WITH its zero border fits the LDS of one CU.  conv3x3_nt_bf16_kernel above re-gathers every shifted pixel row from
+// L2 for each of the nine taps and is bound by its CU's L2 port and by re-staging A through LDS (330 - 540 TFLOP/s on
+// these shapes); here an image is staged ONCE (coalesced 16-byte copies, the next image's loads in flight under this
+// image's products), the A fragments of all nine taps are 16-byte LDS reads at constant offsets from the centre pixel,
+// and the weights -- the B operand -- sit in REGISTERS for the whole launch: a wave owns NTW 16-channel output tiles x all
+// of K (288 VGPRs; one wave per SIMD, 512-entry register file), so nothing but A fragments moves per MFMA.
+//   CIN = 64:  NTW = 4 -> a wave covers 64 output channels; waves split the image's 16-pixel tiles
+//   CIN = 128: NTW = 2 -> waves split the output channels (and the pixel tiles when COUT = 64)
+// One workgroup walks images blockIdx.x, + gridDim.x, ...  Same operands / epilogues / results as the kernel above
+// (out[p, co] = act(sum_{tap, ci} x[p + s_tap, ci] Wt[co][tap * CIN + ci] + bias[co])).
+template <typename TO, int CIN, int COUT>
+__global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, int W, const bf16_t* __restrict__ X,
+                                                             const bf16_t* __restrict__ Wt, TO* __restrict__ Out,
+                                                             const float* __restrict__ bias, int act, ConvGate gate,
+                                                             int nbuf) {
+  constexpr int KS = 9 * CIN / 32;                         // k-steps of 32
+  constexpr int KPT = CIN / 32;                            // k-steps per tap
+  constexpr int NTW = CIN == 64 ? 4 : 2;                   // output tiles per wave
+  constexpr int NGROUPS = (COUT / 16) / NTW;               // wave groups over the output channels
+  constexpr int MPARTS = 4 / NGROUPS;                      // waves sharing the pixel tiles of one channel group
+  constexpr int PST = CIN * 2 + 16;                        // bytes per pixel in LDS (16-byte pad: conflict-free b128 reads)
+  static_assert(NGROUPS >= 1 && NGROUPS <= 4 && 4 % NGROUPS == 0, "wave split");
+  extern __shared__ __attribute__((aligned(16))) char csm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ng = wave % NGROUPS, mp = wave / NGROUPS;
+  const int HW = H * W, WP = W + 2;
+  const int img_bytes = (H + 2) * WP * PST;
+  const int nvec = HW * CIN / 8;                           // 16-byte vectors of one image
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // weights -> registers: B fragment (as first MFMA operand: rows = output channel) of tile nt, k-step ks:
+  // lane (channel fr, k-group fq) holds Wt[n0 + fr][ks * 32 + fq * 8 .. + 7]
+  bf16x8_t breg[NTW][KS];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const bf16_t* wp = Wt + (size_t)((ng * NTW + j) * 16 + fr) * (9 * CIN) + fq * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) breg[j][ks] = *reinterpret_cast<const bf16x8_t*>(wp + ks * 32);
+  }
+  // zero both images (borders stay zero for the whole launch)
+  for (int i = tid * 16; i < nbuf * img_bytes; i += 256 * 16) *reinterpret_cast<bf16x8_t*>(csm + i) = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  __syncthreads();
+
+  constexpr int MAXV = 16;                                 // staged vectors per thread (nvec <= 4096)
+  bf16x8_t stage[MAXV];
+  auto gfetch = [&](int img) {
+    const bf16x8_t* src = reinterpret_cast<const bf16x8_t*>(X + (size_t)img * HW * CIN);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = tid + i * 256;
+      if (v < nvec) stage[i] = src[v];
+    }
+  };
+  auto lstore = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = tid + i * 256;
+      if (v < nvec) {
+        const int p = v / (CIN / 8), cv = v % (CIN / 8);
+        const int y = p / W, x = p - y * W;
+        *reinterpret_cast<bf16x8_t*>(buf + ((y + 1) * WP + x + 1) * PST + cv * 16) = stage[i];
+      }
+    }
+  };
+  int tapoff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tapoff[t] = ((t / 3 - 1) * WP + (t % 3 - 1)) * PST;
+  const int ntm = (HW + 15) / 16;
+
+  int img = blockIdx.x;
+  if (img >= Nimg) return;
+  gfetch(img);
+  lstore(csm);
+  __syncthreads();
+  for (int it = 0; img < Nimg; img += gridDim.x, ++it) {
+    char* cur = csm + (nbuf == 2 ? (it & 1) * img_bytes : 0);
+    const int nxt = img + gridDim.x;
+    if (nxt < Nimg) gfetch(nxt);                           // lands under this image's products
+    for (int mt = mp; mt < ntm; mt += MPARTS) {
+      const int p = mt * 16 + fr;
+      const int pc = p < HW ? p : 0;
+      const int y = pc / W, x = pc - y * W;
+      const char* ap = cur + ((y + 1) * WP + x + 1) * PST + fq * 16;
+      f32x4_t acc[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      // A fragments in groups of TG taps, the next group's LDS reads issued ahead of this group's MFMAs (one wave per
+      // SIMD: nothing else hides the LDS latency -- read-wait-multiply per fragment ran the matrix cores at ~15 %)
+      constexpr int TG = CIN == 64 ? 3 : 1, NG = 9 / TG, GF = TG * KPT;
+      bf16x8_t a[2][GF];
+#pragma unroll
+      for (int q = 0; q < GF; ++q) a[0][q] = *reinterpret_cast<const bf16x8_t*>(ap + tapoff[q / KPT] + (q % KPT) * 64);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int q = 0; q < GF; ++q)
+            a[(g + 1) & 1][q] = *reinterpret_cast<const bf16x8_t*>(ap + tapoff[(g + 1) * TG + q / KPT] + (q % KPT) * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // (left alone the scheduler recycles ONE register quad)
+#pragma unroll
+        for (int q = 0; q < GF; ++q)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[j][g * GF + q], a[g & 1][q], acc[j], 0, 0, 0);
+      }
+      // epilogue: lane holds channels n0 + fq*4 .. +3 of pixel p (transposed product)
+      if (p < HW) {
+        const size_t m = (size_t)img * HW + p;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          const int nb = (ng * NTW + j) * 16 + fq * 4;
+          TO* cp = Out + m * COUT + nb;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[j][r];
+          if (bias) {
+            const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + nb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+          }
+          if (act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (act == 2) {
+            typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+            const size_t e = m * COUT + nb;
+            const us4_t g = *reinterpret_cast<const us4_t*>(gate.act + e);
+            float mk[4] = {1.f, 1.f, 1.f, 1.f};
+            if (gate.use_drop) asr_dropout_words(gate.offset + e / 4, gate.seed, gate.keep, 1.f / gate.keep, mk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = bf16_to_f32(g[r]) > 0.f ? v[r] * mk[r] : 0.f;
+          }
+          if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+          } else {
+            typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+            *reinterpret_cast<us4_t*>(cp) = (us4_t){f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+          }
+        }
+      }
+    }
+    if (nxt < Nimg) {
+      if (nbuf == 1) __syncthreads();                      // every wave is done with the only buffer
+      lstore(csm + (nbuf == 2 ? ((it + 1) & 1) * img_bytes : 0));
+    }
+    __syncthreads();
+  }
+}
+
 // weight images for the two implicit GEMMs from the HWIO fp32 master [9][Cin][Cout]:
 //   wf[co][tap*Cin + ci] = w[tap][ci][co]          (forward:   B^T of x * W)
 //   wb[ci][tap*Cout + co] = w[8 - tap][ci][co]     (data grad: B^T of dOut * flipped W)
@@ -1211,6 +1364,33 @@ static int conv3x3_launch(asr_handle* h, const void* x, int Nimg, int H, int W, 
   const long long mp = (long long)Nimg * H * W;
   if (mp <= 0 || mp >= (1ll << 31)) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3: %lld pixels", mp);
   const int Mpix = (int)mp;
+  {
+    // image-resident form: the image with its border fits one CU's LDS (twice: the next image is staged under the
+    // products of this one) and there are enough images to fill the chip; ASR_CONV_IMG=0 keeps the tiled kernel (A/B)
+    static const bool img_on = [] { const char* e = getenv("ASR_CONV_IMG"); return !(e && e[0] == '0'); }();
+    const size_t img_bytes = (size_t)(H + 2) * (W + 2) * (Cin * 2 + 16);
+    const int nvec = H * W * Cin / 8;
+    const bool shape = (Cin == 64 || Cin == 128) && (Cout == 64 || Cout == 128);
+    if (img_on && shape && nvec <= 16 * 256 && img_bytes <= (size_t)156 * 1024 && Nimg >= 64) {
+      const int nbuf = 2 * img_bytes <= (size_t)158 * 1024 ? 2 : 1;
+      const size_t lds = nbuf * img_bytes;
+      const unsigned grid = (unsigned)(Nimg < h->num_cu ? Nimg : h->num_cu);
+#define ASR_CONV_IMG(CI, CO)                                                                                         \
+  do {                                                                                                               \
+    auto k = conv3x3_img_kernel<TO, CI, CO>;                                                                         \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, Nimg, H, W, (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, \
+                       bias, act, gate, nbuf);                                                                       \
+  } while (0)
+      if (Cin == 64 && Cout == 64) ASR_CONV_IMG(64, 64);
+      else if (Cin == 64 && Cout == 128) ASR_CONV_IMG(64, 128);
+      else if (Cin == 128 && Cout == 128) ASR_CONV_IMG(128, 128);
+      else ASR_CONV_IMG(128, 64);
+#undef ASR_CONV_IMG
+      ASR_CHECK_LAUNCH(h, "asr_conv3x3(image-resident)");
+      return ASR_OK;
+    }
+  }
   const int tm = (Mpix + 127) / 128;
   if (Cout % 128 == 0) {
     const size_t lds = (size_t)2 * (128 + 128) * 72 * sizeof(bf16_t);

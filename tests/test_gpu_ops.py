@@ -35,7 +35,12 @@ def test_transpose2d(cuda, dtype, shape):
     assert torch.equal(y, x.t().contiguous())
 
 
-@pytest.mark.parametrize('N,H,W,Cin,Cout', [(5, 7, 5, 64, 64), (3, 40, 11, 64, 128), (70, 6, 3, 128, 128), (2, 1, 1, 64, 64)])
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(5, 7, 5, 64, 64), (3, 40, 11, 64, 128), (70, 6, 3, 128, 128), (2, 1, 1, 64, 64),
+                                            # N >= 64 images that fit the LDS: the image-resident kernels (conv3x3_img_kernel),
+                                            # all four channel shapes (the data gradient runs the mirrored one), the cfg C
+                                            # image sizes, more images than CUs (a workgroup walks several), 1 x 1 images
+                                            (70, 40, 11, 64, 64), (66, 20, 6, 64, 128), (65, 20, 6, 128, 128),
+                                            (300, 5, 4, 64, 64), (64, 1, 1, 128, 64)])
 def test_conv3x3_implicit_gemm(cuda, N, H, W, Cin, Cout):
     """Implicit-GEMM 3x3 SAME convolution (forward, data gradient, weight gradient) against
     torch.nn.functional.conv2d in fp64 on the same bf16-rounded operands."""
@@ -984,7 +989,8 @@ def test_direct_convolution_of_the_few_channel_first_layer(cuda, N, H, W, Cin):
     assert np.abs(dw.cpu().numpy() - ref_dw).max() < 2e-5 * max(1.0, np.abs(ref_dw).max())
 
 
-@pytest.mark.parametrize('N,H,W,Cin,Cout,drop', [(3, 40, 11, 64, 64, True), (2, 20, 6, 64, 128, False), (2, 20, 6, 128, 128, True)])
+@pytest.mark.parametrize('N,H,W,Cin,Cout,drop', [(3, 40, 11, 64, 64, True), (2, 20, 6, 64, 128, False), (2, 20, 6, 128, 128, True),
+                                                 (70, 40, 11, 64, 64, True), (70, 20, 6, 64, 128, False), (70, 20, 6, 128, 128, True)])
 def test_conv_data_gradient_with_the_relu_backward_below_in_its_epilogue(cuda, N, H, W, Cin, Cout, drop):
     """asr_conv3x3_bwd_data_relu == asr_relu_bwd(_drop)(asr_conv3x3_bwd_data(...), act_below), bit for bit."""
     ops = _ops()
