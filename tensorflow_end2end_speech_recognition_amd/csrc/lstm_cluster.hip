@@ -779,13 +779,37 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
       // the tiles other CUs wait for go first; while they issue, this wave outranks its SIMD sibling's
       // own-tile MFMAs (nobody waits for those before the next step's gate math)
       __builtin_amdgcn_s_setprio(2);
+      if constexpr (HSU == 32) {
+        // One wave per SIMD: nothing fills the gaps of a tile-by-tile schedule (four DEPENDENT MFMAs into one
+        // accumulator, drain, tag, a branch on the store flavour, store: ~170 cycles per tile, 9 tiles at H = 512), and
+        // every destination waits for the LAST of its partials anyway.  So: all NF chains advance together (k-chunk
+        // outer, tile inner: independent accumulators back to back), then the stores go out in one straight run per
+        // flavour.  (The last tile of a wave that has none is computed and not stored.)
+        f32x4_t af[NF];
 #pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        if (OWN_ONCE ? (i < NF - 1 || last_f) : (i < NF - 1 || last_f)) {      // wave-uniform: a foreign tile
-          f32x4_t af = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NF; ++i) af[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kc = 0; kc < KC; ++kc) af = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[i][kc], af, 0, 0, 0);
-          xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(af), fast);
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+          for (int i = 0; i < NF; ++i) af[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[i][kc], af[i], 0, 0, 0);
+        if (fast) {
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+            if (i < NF - 1 || last_f) xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(af[i]), true);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+            if (i < NF - 1 || last_f) xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(af[i]), false);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          if (OWN_ONCE ? (i < NF - 1 || last_f) : (i < NF - 1 || last_f)) {      // wave-uniform: a foreign tile
+            f32x4_t af = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) af = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[i][kc], af, 0, 0, 0);
+            xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(af), fast);
+          }
         }
       }
       __builtin_amdgcn_s_setprio(0);
