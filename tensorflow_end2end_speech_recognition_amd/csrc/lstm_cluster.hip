@@ -909,19 +909,24 @@ __device__ __forceinline__ f32x4_t mma_f32(const f32x4_t& a, const f32x4_t& b, f
 
 // EARLY: as in the bf16 kernel, the fragments of the CU's OWN slice of h (half of K with two CUs) are multiplied for
 // step s+1 right after they are written, before the wave starts polling for the peer's half.
-template <int H, bool EARLY>
-__global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
+// HSU = units per CU: 64 (eight waves) or 32 (four waves, one per SIMD: twice the CUs, each wave alone on its SIMD's fp32
+// matrix pipe -- the step is bound by that pipe: 2 waves x 64 K=4 MFMAs x 32 cycles per SIMD in the 8-wave form).
+template <int H, bool EARLY, int HSU = 64>
+__global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_f32_kernel(
     int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const float* __restrict__ whp,
     const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
     float cell_clip, f32x4_t* __restrict__ gates, float* __restrict__ hout, float* __restrict__ cs,
     float* __restrict__ c_final, float* __restrict__ h_final, u64* __restrict__ xch,
     unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
   zero_next_area(znext, zwords);
-  constexpr int G = H / HS;
+  constexpr int G = H / HSU;
+  constexpr int CTW = HSU * 8;
   constexpr int KS = H / 16;                               // fragments of k = 16 (four K = 4 MFMAs each)
   constexpr int LDH = H + 4;                               // floats: 33 x 16 B at H = 128, like the bf16 image
-  constexpr int SLICE = 16 * HS;                           // granules one CU publishes per step
-  constexpr int KO = HS / 16;                              // fragments of one CU's own slice
+  constexpr int SLICE = 16 * HSU;                           // granules one CU publishes per step
+  constexpr int KO = HSU / 16;                              // fragments of one CU's own slice
+  // fragment index modulo KS (a mask where KS is a power of two; H = 320 has 20 fragments: x < 2 KS there)
+  auto krotf = [](int x) -> int { return ((KS & (KS - 1)) == 0) ? (x & (KS - 1)) : (x >= KS ? x - KS : x); };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* hs = reinterpret_cast<float*>(smem);              // [2][16][LDH]
 
@@ -934,7 +939,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
   const bool rev = (d == 1);
   const float* wp = whp + (size_t)d * H * 4 * H;
   const int ul = wave * 8 + (col & 7);                     // unit inside this CU's slice
-  const unsigned jw = g * HS + ul;                         // global unit of this lane
+  const unsigned jw = g * HSU + ul;                         // global unit of this lane
   const int rbase = rg * 4 + (lo ? 0 : 2);                 // first of this lane's two batch rows
 
   int len[2];
@@ -949,7 +954,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
   const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
   const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
 
-  for (int i = threadIdx.x; i < 2 * 16 * LDH; i += CT8) hs[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * 16 * LDH; i += CTW) hs[i] = 0.f;
   // B fragments out of the standard forward packing (lstm.hip prep: tile = (unit/16)*4 + gate, fragment ks, lane
   // (n, rg) holds k = ks*16 + rg*4 + e): this lane's column of tile p is (gate p*2 + (col>>3), unit jw)
   f32x4_t wreg[2][KS];
@@ -958,7 +963,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
     const int tile = (jw >> 4) * 4 + p * 2 + (col >> 3);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const int kk = EARLY ? ((ks + g * KO) & (KS - 1)) : ks;   // EARLY: register fragment ks holds k-fragment kk
+      const int kk = EARLY ? krotf(ks + g * KO) : ks;            // EARLY: register fragment ks holds k-fragment kk
       wreg[p][ks] = *reinterpret_cast<const f32x4_t*>(wp + (((size_t)tile * KS + kk) * 64 + rg * 16 + (jw & 15)) * 4);
     }
   }
@@ -992,12 +997,12 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = j * 8 + (lane >> 3);
-      ldst[k][j] = ((unsigned)(row * LDH + gsrc * HS + wave * 8 + (lane & 7)) * 4u) ^ lds_swz(row);
+      ldst[k][j] = ((unsigned)(row * LDH + gsrc * HSU + wave * 8 + (lane & 7)) * 4u) ^ lds_swz(row);
     }
   }
   unsigned lown[2];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) lown[r] = ((unsigned)((rbase + r) * LDH + g * HS + ul) * 4u) ^ lds_swz(rbase + r);
+  for (int r = 0; r < 2; ++r) lown[r] = ((unsigned)((rbase + r) * LDH + g * HSU + ul) * 4u) ^ lds_swz(rbase + r);
   const unsigned lrd = ((unsigned)(col * LDH + rg * 4) * 4u) ^ lds_swz(col);
 
   f32x4_t xq[2][2];                                        // x projection rows, requested two steps ahead
@@ -1022,13 +1027,27 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
     if constexpr (EARLY) { acc0 = accn0; acc1 = accn1; }    // own-slice fragments: done at the end of the last step
     {
       constexpr int K0 = EARLY ? KO : 0;
-      f32x4_t afr[KS];
+      if constexpr (KS <= 16) {
+        f32x4_t afr[KS];
 #pragma unroll
-      for (int ks = K0; ks < KS; ++ks)
-        afr[ks] = *reinterpret_cast<const f32x4_t*>(hcur + lrd + (EARLY ? ((ks + g * KO) & (KS - 1)) : ks) * 64);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int ks = K0; ks < KS; ++ks)
+          afr[ks] = *reinterpret_cast<const f32x4_t*>(hcur + lrd + (EARLY ? krotf(ks + g * KO) : ks) * 64);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = K0; ks < KS; ++ks) mma_f32x2(afr[ks], wreg[0][ks], wreg[1][ks], acc0, acc1);
+        for (int ks = K0; ks < KS; ++ks) mma_f32x2(afr[ks], wreg[0][ks], wreg[1][ks], acc0, acc1);
+      } else {                                             // H >= 320: the weights hold 160+ registers; A in runs of 8
+#pragma unroll
+        for (int kb = K0; kb < KS; kb += 8) {
+          f32x4_t afr[8];
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+            if (kb + ks < KS)
+              afr[ks] = *reinterpret_cast<const f32x4_t*>(hcur + lrd + (EARLY ? krotf(kb + ks + g * KO) : kb + ks) * 64);
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+            if (kb + ks < KS) mma_f32x2(afr[ks], wreg[0][kb + ks], wreg[1][kb + ks], acc0, acc1);
+        }
+      }
     }
     float pi[2], pq[2], pf[2], po[2];
 #pragma unroll
@@ -1081,7 +1100,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_fwd_cluster8_f32_kernel(
         __syncthreads();                                   // the CU's own slice of h(s) is complete in hnxt
         f32x4_t ao[KO];
 #pragma unroll
-        for (int k = 0; k < KO; ++k) ao[k] = *reinterpret_cast<const f32x4_t*>(hnxt + lrd + ((k + g * KO) & (KS - 1)) * 64);
+        for (int k = 0; k < KO; ++k) ao[k] = *reinterpret_cast<const f32x4_t*>(hnxt + lrd + krotf(k + g * KO) * 64);
         accn0 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         accn1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1390,6 +1409,306 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_f32_kernel(
   }
 }
 
+// BPTT, fp32 operands, GENERAL form: clusters of G = H / HSU CUs (any even G), four waves per CU at HSU = 32 (one per SIMD:
+// the fp32 step is bound by the SIMD's matrix pipe -- 32 cycles per K = 4 MFMA -- so a wave alone on its SIMD is what pays).
+// Tile deal as in the bf16 kernel's each-tile-once arrangement: a CU owns TPC = HSU / 16 unit tiles and multiplies its dG
+// slice by W_h^T for ALL H / 16 tiles; the TPC own + TPC (G - 1) foreign tiles are dealt G / 2 per wave -- an hh = 0 wave
+// takes its own-unit tile (rows 2,3 handed to the hh = 1 partner through LDS) and G/2 - 1 foreign ones, an hh = 1 wave
+// G / 2 foreign ones; foreign partials go out as 16-byte stores of self-tagged fp32 words, the chains of a wave's
+// foreign tiles advance together and the stores follow in one run.  H = 128 runs on four CUs (the two-CU kernel above:
+// 2011 us per launch at T = 778), H = 256 / 320 / 512 -- which had no fp32 cluster kernel -- on 8 / 10 / 16.
+template <int H, int HSU>
+__global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32_kernel(
+    int T_, int B_, int ndir, const float* __restrict__ dhout, const f32x4_t* __restrict__ gates,
+    const float* __restrict__ cs, const float* __restrict__ whpb, const float* __restrict__ peep,
+    const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
+    const float* __restrict__ d_h_final, f32x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
+    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+  zero_next_area(znext, zwords);
+  constexpr int G = H / HSU;
+  static_assert(G % 2 == 0 && G >= 2 && G <= XHDR, "even number of CUs per cluster");
+  constexpr int TPC = HSU / 16, NWAVES = 2 * TPC;
+  constexpr int KC = 4 * HSU / 16;           // fragments (k = 16) of this CU's slice of k'
+  constexpr int KSF = 4 * H / 16;            // fragments of the full packing
+  constexpr int LDG = 4 * HSU + 4;           // floats per row of the dG image
+  constexpr int NF = G / 2;                  // tile slots per wave
+  constexpr size_t CL_U64 = XHDR + (size_t)2 * G * G * TPC * 64 * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DGB = 16 * LDG * 4;                        // bytes per dG image
+
+  const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
+  if (!cid.valid) return;
+  const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, rg = lane >> 4;
+  const int hh = wave / TPC, wt = wave % TPC;
+  const bool rev = (d == 1);
+  const float* wp = whpb + (size_t)d * H * 4 * H;
+  const int ul = wt * 16 + col;
+  const unsigned jw = g * HSU + ul;
+  const int rbase = rg * 4 + hh * 2;
+
+  int len[2];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) len[r] = seq_len[b0 + rbase + r];
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  const float wci = peep ? peep[(d * 3 + 0) * H + jw] : 0.f;
+  const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
+  const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
+
+  const unsigned stride = (unsigned)B_ * ndir * H;
+  const unsigned dstep = rev ? stride : 0u - stride;
+  unsigned oa[2], os[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned base = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+    os[r] = base + (unsigned)(tmax - 1) * stride;
+    oa[r] = base + (unsigned)(rev ? len[r] - tmax : tmax - 1) * stride;
+  }
+  {
+    const f32x4_t gzero = {0.f, 0.f, 0.f, 0.f};
+    for (int t = tmax; t < T_; ++t)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) dgates[os[r] + (unsigned)(t - tmax + 1) * stride] = gzero;
+  }
+
+  float dhr[2], dcr[2], cc[2];
+  float sums[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const size_t o = ((size_t)d * B_ + b0 + rbase + r) * H + jw;
+    dhr[r] = d_h_final ? d_h_final[o] : 0.f;
+    dcr[r] = d_c_final ? d_c_final[o] : 0.f;
+    cc[r] = (tmax > 0 && tmax - 1 < len[r]) ? cs[oa[r]] : 0.f;
+  }
+  // tile slots: i < NF - 1: foreign tile f = wave + NWAVES i;  slot NF - 1: hh = 0 the own tile, hh = 1 foreign tile
+  // f = NWAVES (NF - 1) + wt.  Foreign index f -> destination CU (f / TPC, skipping g), its tile f % TPC.
+  auto ftile = [&](int f) { const int q = f / TPC; return ((q + (q >= g ? 1 : 0)) * TPC) | (f % TPC); };
+  int nt_f[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+    nt_f[i] = (i < NF - 1) ? ftile(wave + NWAVES * i) : (hh == 1 ? ftile(NWAVES * (NF - 1) + wt) : g * TPC + wt);
+  f32x4_t wf[NF][KC];
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+      wf[i][kc] = *reinterpret_cast<const f32x4_t*>(wp + (((size_t)nt_f[i] * KSF + g * KC + kc) * 64 + lane) * 4);
+  float* ownx = reinterpret_cast<float*>(smem + 2 * DGB);  // [2 parity][TPC tiles][64 lanes] x (row 2, row 3)
+
+  u64* xhdr = xch + (size_t)cid.c * CL_U64;
+  bool timed_out = false;
+  const bool fast = same_xcd<G>(xhdr, g, timed_out) && !(kflags & 1);
+  unsigned spin_limit = (kflags & 2) ? 2000u : SPIN_LIMIT;
+  if ((kflags & 2) && g == G - 1) return;                  // TEST ONLY: a member goes missing
+  f32x4_t* xs = reinterpret_cast<f32x4_t*>(xhdr + XHDR);   // [2][G dst][G src][TPC][64] x 16 B
+  auto uslot = [&](int par, int dst, int src_, int tile) -> f32x4_t* {
+    return xs + ((((size_t)par * G + dst) * G + src_) * TPC + tile) * 64;
+  };
+  const unsigned voff16 = (unsigned)lane * 16u;
+  const unsigned pofs = (unsigned)lane * 2u + hh;          // u64 index of this lane's two rows in a slot
+  const unsigned lwr[2] = {((unsigned)(rbase * LDG + ul * 4) * 4u) ^ lds_swz(rbase),
+                           ((unsigned)((rbase + 1) * LDG + ul * 4) * 4u) ^ lds_swz(rbase + 1)};
+  const unsigned lrd = ((unsigned)(col * LDG + rg * 4) * 4u) ^ lds_swz(col);
+
+  f32x4_t pg[2];
+  float pcp[2], pdh[2];
+  if (tmax > 0) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int s_ = tmax - 1;
+      const bool act = s_ < len[r];
+      const bool ldp = (s_ > 0) && (s_ - 1 < len[r]);
+      pg[r] = gates[act ? oa[r] : os[r]];
+      pcp[r] = cs[ldp ? oa[r] + dstep : os[r]];
+      pdh[r] = dhout[act ? oa[r] : os[r]];
+    }
+  }
+  __syncthreads();
+
+  auto step = [&](int s, auto PAR) {
+    constexpr int P = decltype(PAR)::value;                // parity of THIS iteration's publish
+    const int it = tmax - 1 - s;
+    // ---- 1. polls for the partials the peers published at the previous iteration (parity 1-P)
+    u64 pv[G - 1];
+    if (it > 0) {
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+        pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
+    }
+    // ---- 2. everything that does not need dh
+    bool act[2], ldp[2];
+    float gi[2], gq[2], gf[2], go[2], cprev[2], a_o[2], b_c[2], c_g[2], c_i[2], c_f[2];
+    unsigned off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      act[r] = s < len[r];
+      ldp[r] = (s > 0) && (s - 1 < len[r]);
+      off[r] = act[r] ? oa[r] : os[r];
+      gi[r] = pg[r][0]; gq[r] = pg[r][1]; gf[r] = pg[r][2]; go[r] = pg[r][3];
+      cprev[r] = (act[r] && s > 0) ? pcp[r] : 0.f;
+    }
+    float tc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) tc[r] = cftanh(cc[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      a_o[r] = tc[r] * go[r] * (1.f - go[r]);
+      b_c[r] = go[r] * (1.f - tc[r] * tc[r]);
+      c_g[r] = gi[r] * (1.f - gq[r] * gq[r]);
+      c_i[r] = gq[r] * gi[r] * (1.f - gi[r]);
+      c_f[r] = cprev[r] * gf[r] * (1.f - gf[r]);
+    }
+    float pdh0 = pdh[0], pdh1 = pdh[1], pcp0 = pcp[0], pcp1 = pcp[1];
+    const float cur0 = cc[0], cur1 = cc[1];
+    // everything that reads the values fetched one iteration ago is pinned here, ahead of the next fetch (see the bf16 kernel)
+    asm volatile("" : "+v"(pdh0), "+v"(pdh1), "+v"(pcp0), "+v"(pcp1), "+v"(cprev[0]), "+v"(cprev[1]));
+    asm volatile("" : "+v"(c_g[0]), "+v"(c_g[1]), "+v"(c_i[0]), "+v"(c_i[1]), "+v"(c_f[0]), "+v"(c_f[1]));
+    asm volatile("" : "+v"(a_o[0]), "+v"(a_o[1]), "+v"(b_c[0]), "+v"(b_c[1]), "+v"(gf[0]), "+v"(gf[1]));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { oa[r] += dstep; os[r] -= stride; }
+    // ---- 3. finish the polls: every word must carry the previous iteration's tag
+    if (it > 0) {
+      const unsigned want = (((unsigned)(it - 1) >> 1) + 1u) & 1u;
+      const u64 wmask = 0x0000000100000001ull, wtag = want ? wmask : 0ull;
+      unsigned spins = 0;
+#pragma unroll 1
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) ok = ok && ((pv[k] & wmask) == wtag);
+        if (__all(ok)) break;
+        if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k)
+          pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
+      }
+      float add0 = 0.f, add1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k) {                     // fixed order
+        add0 += __uint_as_float((unsigned)pv[k] & ~1u);
+        add1 += __uint_as_float((unsigned)(pv[k] >> 32) & ~1u);
+      }
+      dhr[0] += add0;
+      dhr[1] += add1;
+    }
+    // next iteration's saved activations: unconditional (the last iteration re-fetches its own rows) and pinned BEHIND
+    // the poll loop by a compiler barrier
+    {
+      asm volatile("" ::: "memory");
+      const bool more = s > 0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bool actn = s - 1 < len[r];
+        const bool ldpn = (s - 1 > 0) && (s - 2 < len[r]);
+        const unsigned offl = more ? (actn ? oa[r] : os[r]) : off[r];
+        const unsigned offn = more ? (ldpn ? oa[r] + dstep : os[r]) : off[r];
+        pg[r] = gates[offl];
+        pcp[r] = cs[offn];
+        pdh[r] = dhout[offl];
+      }
+    }
+    // ---- 4. gate gradients of the own pairs
+    const float pdhv[2] = {pdh0, pdh1}, pcpv[2] = {pcp0, pcp1}, curv[2] = {cur0, cur1};
+    float zi[2], zg[2], zf[2], zo[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float dh = pdhv[r] + dhr[r];
+      const float d_o = dh * a_o[r];
+      const float dc = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float d_g = dc * c_g[r], d_i = dc * c_i[r], d_f = dc * c_f[r];
+      dcr[r] = act[r] ? (dc * gf[r] + d_i * wci + d_f * wcf) : dcr[r];
+      dhr[r] = act[r] ? 0.f : dhr[r];
+      zi[r] = act[r] ? d_i : 0.f; zg[r] = act[r] ? d_g : 0.f;
+      zf[r] = act[r] ? d_f : 0.f; zo[r] = act[r] ? d_o : 0.f;
+      cc[r] = ldp[r] ? pcpv[r] : 0.f;
+      const f32x4_t pk = {zi[r], zg[r], zf[r], zo[r]};
+      *reinterpret_cast<f32x4_t*>(smem + P * DGB + lwr[r]) = pk;
+      dgates[off[r]] = pk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      sums[0] += zi[r] * cprev[r]; sums[1] += zf[r] * cprev[r]; sums[2] += zo[r] * curv[r];
+      sums[3] += zi[r]; sums[4] += zg[r]; sums[5] += zf[r]; sums[6] += zo[r];
+    }
+    // ---- 5. partial dh_prev of this wave's tiles from the own dG slice
+    if (s > 0) {
+      f32x4_t afr[KC];
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) afr[kc] = *reinterpret_cast<const f32x4_t*>(smem + P * DGB + lrd + kc * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4_t ac[NF];
+#pragma unroll
+      for (int i = 0; i < NF; ++i) ac[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int i = 0; i < NF; ++i) ac[i] = mma_f32(afr[kc], wf[i][kc], ac[i]);
+      const unsigned tag = (((unsigned)it >> 1) + 1u) & 1u;
+      auto tagged = [&](const f32x4_t& a) {
+        f32x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __uint_as_float((__float_as_uint(a[i]) & ~1u) | tag);
+        return o;
+      };
+      if (fast) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          if (i < NF - 1 || hh == 1) xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(ac[i]), true);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          if (i < NF - 1 || hh == 1) xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(ac[i]), false);
+      }
+      if (hh == 0) {                                       // own units: rows 0,1 stay, rows 2,3 -> partner wave
+        dhr[0] += ac[NF - 1][0];
+        dhr[1] += ac[NF - 1][1];
+        float* o = ownx + ((P * TPC + wt) * 64 + lane) * 2;
+        o[0] = ac[NF - 1][2];
+        o[1] = ac[NF - 1][3];
+      }
+    }
+    __syncthreads();                                       // hand-over visible before the partner's next step
+    if (s > 0 && hh == 1) {
+      const float* o = ownx + ((P * TPC + wt) * 64 + lane) * 2;
+      dhr[0] += o[0];
+      dhr[1] += o[1];
+    }
+  };
+  int s = tmax - 1;
+  for (; s >= 1; s -= 2) {
+    step(s, std::integral_constant<int, 0>{});
+    step(s - 1, std::integral_constant<int, 1>{});
+  }
+  if (s == 0) step(0, std::integral_constant<int, 0>{});
+
+  if (timed_out) atomicOr(err, 2u);
+  if (dpeep_part) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      sums[k] += __shfl_xor(sums[k], 16, 64);
+      sums[k] += __shfl_xor(sums[k], 32, 64);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);           // [7][HSU]
+    if (hh == 1 && rg == 0) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) red[k * HSU + ul] = sums[k];
+    }
+    __syncthreads();
+    if (hh == 0 && rg == 0) {
+      float* p = dpeep_part + ((size_t)cid.tile * ndir + d) * 7 * H;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) p[k * H + jw] = sums[k] + red[k * HSU + ul];
+    }
+  }
+}
+
 static unsigned long long* g_cdbg_host = nullptr;
 static void cdbg_setup() {
   static bool done = false;
@@ -1561,34 +1880,92 @@ static bool cluster_f32_enabled() {
   return on && cluster_enabled();
 }
 
-bool asr_cluster_fwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const float* xproj,
-                             const void* whp, const float* peep, const int32_t* seq_len, float fb,
-                             float clip, void* gates, void* hout, float* cs, float* cf, float* hf,
-                             hipStream_t st) {
-  constexpr int HH = 128, G = HH / HS;
-  if (!cluster_f32_enabled() || H != HH) return false;
+template <int HH, int HSU>
+static bool cluster_fwd_f32_launch(asr_handle* h, int T, int B, int ndir, const float* xproj, const void* whp,
+                                   const float* peep, const int32_t* seq_len, float fb, float clip, void* gates,
+                                   void* hout, float* cs, float* cf, float* hf, hipStream_t st) {
+  constexpr int G = HH / HSU;
+  static_assert(G <= XHDR, "placement header too small");
   const int ncl = (B / 16) * ndir;
-  const size_t need = (size_t)ncl * (XHDR + 2 * G * 16 * HS) * sizeof(u64);
-  if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
+  const size_t need = (size_t)ncl * (XHDR + 2 * G * 16 * HSU) * sizeof(u64);
+  if ((size_t)T * B * ndir * HH >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
       (int)cluster_grid(G, ncl) > h->num_cu)
     return false;
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
   const XchAreas xa = xch_take(h, base, need, st);
-  const bool early = (dbg_flags() & 32) == 0;              // ASR_LSTM_DFLAGS bit 5 inverts the default (A/B)
-  auto k = early ? lstm_fwd_cluster8_f32_kernel<HH, true> : lstm_fwd_cluster8_f32_kernel<HH, false>;
-  hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(CT8),
-                     (size_t)2 * 16 * (HH + 4) * 4, st, T, B, ndir, (const f32x4_t*)xproj, (const float*)whp, peep,
-                     seq_len, fb, clip, (f32x4_t*)gates, (float*)hout, cs, cf, hf, xa.area, (unsigned*)base,
-                     kernel_flags(), xa.znext, xa.zwords);
+  // EARLY own-slice products by default, except H = 512 where their extra live accumulators push the 256 weight
+  // registers into scratch (measured 5.93 vs 5.36 ms per 778-step launch); ASR_LSTM_DFLAGS bit 5 inverts (A/B)
+  const bool early = ((dbg_flags() & 32) == 0) != (HH >= 512);
+  auto k = early ? lstm_fwd_cluster8_f32_kernel<HH, true, HSU> : lstm_fwd_cluster8_f32_kernel<HH, false, HSU>;
+  const size_t lds = (size_t)2 * 16 * (HH + 4) * 4;
+  if (lds > ((size_t)64 << 10))
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir, (const f32x4_t*)xproj,
+                     (const float*)whp, peep, seq_len, fb, clip, (f32x4_t*)gates, (float*)hout, cs, cf, hf, xa.area,
+                     (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
   return true;
 }
 
+// fp32 operands: H = 128 / 256 / 320 / 512 on clusters of H/32 CUs x four waves (default), H = 128 also on two CUs x eight
+// waves (ASR_LSTM_HS=64 / flag bit 9).  ASR_LSTM_CLUSTER_F32=0 keeps the single-CU kernels (A/B);
+// ASR_LSTM_CLUSTER_F32_WIDE=0 keeps them for H > 128 only.
+static bool cluster_f32_wide_enabled() {
+  static const bool on = [] { const char* e = getenv("ASR_LSTM_CLUSTER_F32_WIDE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+#define ASR_F32_ARGS_F h, T, B, ndir, xproj, whp, peep, seq_len, fb, clip, gates, hout, cs, cf, hf, st
+bool asr_cluster_fwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const float* xproj,
+                             const void* whp, const float* peep, const int32_t* seq_len, float fb,
+                             float clip, void* gates, void* hout, float* cs, float* cf, float* hf,
+                             hipStream_t st) {
+  if (!cluster_f32_enabled()) return false;
+  if (fwd_units_per_cu() == 32) {
+    if (H == 128) return cluster_fwd_f32_launch<128, 32>(ASR_F32_ARGS_F);
+    if (!cluster_f32_wide_enabled()) return false;
+    if (H == 256) return cluster_fwd_f32_launch<256, 32>(ASR_F32_ARGS_F);
+    if (H == 320) return cluster_fwd_f32_launch<320, 32>(ASR_F32_ARGS_F);
+    if (H == 512) return cluster_fwd_f32_launch<512, 32>(ASR_F32_ARGS_F);
+    return false;
+  }
+  return H == 128 ? cluster_fwd_f32_launch<128, 64>(ASR_F32_ARGS_F) : false;
+}
+#undef ASR_F32_ARGS_F
+
+template <int HH, int HSU>
+static bool cluster_bwd_f32_launch(asr_handle* h, int T, int B, int ndir, const float* dhout, const void* gates,
+                                   const float* cs, const void* whpb, const float* peep, const int32_t* seq_len,
+                                   const float* dcf, const float* dhf, void* dgates, float* dpeep_part, hipStream_t st) {
+  constexpr int G = HH / HSU, TPC = HSU / 16;
+  const int ncl = (B / 16) * ndir;
+  const size_t need = (size_t)ncl * (XHDR + (size_t)2 * G * G * TPC * 64 * 2) * sizeof(u64);
+  if ((size_t)T * B * ndir * HH >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
+      (int)cluster_grid(G, ncl) > h->num_cu)
+    return false;
+  char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+  const XchAreas xa = xch_take(h, base, need, st);
+  const size_t lds = (size_t)2 * 16 * (4 * HSU + 4) * 4 + (size_t)2 * TPC * 64 * 8;   // two dG images + the hand-over buffer
+  hipLaunchKernelGGL((lstm_bwd_cluster_f32_kernel<HH, HSU>), dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir,
+                     dhout, (const f32x4_t*)gates, cs, (const float*)whpb, peep, seq_len, dcf, dhf, (f32x4_t*)dgates,
+                     dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
+  return true;
+}
+
+#define ASR_F32_ARGS_B h, T, B, ndir, dhout, gates, cs, whpb, peep, seq_len, dcf, dhf, dgates, dpeep_part, st
 bool asr_cluster_bwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const float* dhout,
                              const void* gates, const float* cs, const void* whpb, const float* peep,
                              const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
                              float* dpeep_part, hipStream_t st) {
+  if (!cluster_f32_enabled()) return false;
+  if (bwd_units_per_cu() == 32) {
+    if (H == 128) return cluster_bwd_f32_launch<128, 32>(ASR_F32_ARGS_B);
+    if (!cluster_f32_wide_enabled()) return false;
+    if (H == 256) return cluster_bwd_f32_launch<256, 32>(ASR_F32_ARGS_B);
+    if (H == 320) return cluster_bwd_f32_launch<320, 32>(ASR_F32_ARGS_B);
+    if (H == 512) return cluster_bwd_f32_launch<512, 32>(ASR_F32_ARGS_B);
+    return false;
+  }
   constexpr int HH = 128, G = HH / HS;
-  if (!cluster_f32_enabled() || H != HH) return false;
+  if (H != HH) return false;
   const int ncl = (B / 16) * ndir;
   const size_t need = (size_t)ncl * (XHDR + (size_t)2 * G * G * 4 * 64 * 2) * sizeof(u64);
   if ((size_t)T * B * ndir * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
@@ -1602,6 +1979,7 @@ bool asr_cluster_bwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const
                      dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
   return true;
 }
+#undef ASR_F32_ARGS_B
 
 extern "C" int asr_debug_set_lstm_flags(int flags) { g_dflags = flags; return 0; }
 

@@ -348,14 +348,19 @@ def test_lstm_cluster_exchange_paths(cuda):
         assert np.abs(res[0]['hout'] - ref['hout']).max() < 3e-2
 
 
-@pytest.mark.parametrize('T,B,ndir,clip', [(301, 16, 2, 0.0), (150, 32, 1, 2.0), (778, 16, 2, 50.0)])
-def test_lstm_cluster_f32_long_sequences(cuda, T, B, ndir, clip):
-    """fp32 operands at H = 128 (BASELINE configs[0]) run on the two-CU cluster kernels: forward values, final states and
-    every gradient the BPTT kernel produces against the fp64 oracle over hundreds of hand-offs, ragged lengths, with and
-    without the cell clip; both exchange flavours bit-identical; no hand-off may time out."""
+@pytest.mark.parametrize('T,B,ndir,clip,H,base', [(301, 16, 2, 0.0, 128, 0), (150, 32, 1, 2.0, 128, 0),
+                                                  (778, 16, 2, 50.0, 128, 0), (301, 16, 2, 0.0, 128, 512),
+                                                  (150, 32, 2, 50.0, 256, 0), (97, 16, 2, 0.0, 320, 0),
+                                                  (120, 32, 1, 2.0, 320, 0), (131, 16, 2, 50.0, 512, 0),
+                                                  (64, 32, 1, 0.0, 512, 32)])
+def test_lstm_cluster_f32_long_sequences(cuda, T, B, ndir, clip, H, base):
+    """fp32 operands run on the cluster kernels at every registry width: H = 128 (BASELINE configs[0]) on four CUs x four
+    waves (and, flag bit 9, two CUs x eight waves), H = 256 / 320 / 512 on H/32 CUs x four waves.  Forward values, final
+    states and every gradient the BPTT kernel produces against the fp64 oracle over hundreds of hand-offs, ragged
+    lengths, with and without the cell clip; both exchange flavours bit-identical; no hand-off may time out."""
     ops = _ops()
     rng = np.random.RandomState(T + B)
-    D, H = 24, 128
+    D = 24
     lens = rng.randint(1, T + 1, size=B)
     lens[0], lens[3] = T, 1
     x, ps = _lstm_case(rng, T, B, D, H, ndir, lens, init=0.1)
@@ -363,7 +368,7 @@ def test_lstm_cluster_f32_long_sequences(cuda, T, B, ndir, clip):
     dfinal = (rng.randn(ndir, B, H) * 0.5, rng.randn(ndir, B, H) * 0.5)
     res = []
     try:
-        for flags in (0, 16):
+        for flags in (base, base | 16):
             ops.debug_set_lstm_flags(flags)
             res.append(_run_hip_layer(cuda, x, ps, lens, H, ndir, 'f32', clip, dout, dfinal))
             assert ops.check_async_errors(0) == 0
