@@ -21,6 +21,7 @@ import torch
 from .... import ops
 from ...._lib import ASR_F32
 from ....utils.parameter import ParamStore
+from . import rnn_util
 from .rnn_util import LSTMLayer, LSTMPLayer, declare_lstm_vars, declare_lstmp_vars
 
 WARM_BPTT = _os.environ.get('ASR_WARM_BPTT', '1') != '0'    # A-B switch of the read pass ahead of each BPTT kernel
@@ -153,7 +154,12 @@ class _RecurrentEncoderBase(object):
         final = None
         finals = []
         for li, layer in enumerate(self.layers):
-            ops.wait_event(ready_w[li])
+            # the first layer waits for its own weight image (~10 us of side work), the second for the last one's --
+            # the lane is in order, so that covers the rest: one marker between two recurrence kernels instead of L - 1
+            if not rnn_util.FORK_ONCE or li == 0:
+                ops.wait_event(ready_w[li])
+            elif li == 1:
+                ops.wait_event(ready_w[-1])
             x, final = layer.forward(x, seq_len, self.dtype, keep_prob, is_training, prep=preps[li],
                                      mask_event=ready_m[li])
             finals.append(final)

@@ -27,6 +27,9 @@ DIRS = ('fw', 'bw')
 # side streams the weight-gradient GEMMs of a layer are spread over: one per direction (one lane for both measures the
 # same step time, 12.39 ms, but leaves a longer tail after the last BPTT kernel)
 DW_LANES = 2
+# one main-stream marker per BPTT layer for all its side lanes, one wait for all weight images (A-B: ASR_FORK_ONCE=0
+# restores a marker per lane entry and a wait per layer)
+FORK_ONCE = _os.environ.get('ASR_FORK_ONCE', '1') != '0'
 BG_WGS = int(_os.environ.get('ASR_BG_WGS', '32'))   # workgroups of a weight-gradient GEMM that runs beside a BPTT kernel
 
 
@@ -141,13 +144,16 @@ class LSTMLayer(object):
         dgates, dpeep = ops.lstm_bwd(dout, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H,
                                      ndir, dtype, d_c_final, d_h_final, want_dpeep=True)
         self.warm_event = None
+        # ONE marker on the main stream behind the BPTT kernel: every side lane of this layer starts there
+        fork = ops.stream_event() if FORK_ONCE else None
         if warm:
             # warm: the saved activations of the layer BELOW, read once on a side lane while this layer's dx product runs
             # (after this BPTT kernel, before the next one): its BPTT kernel then finds them in the memory-side cache
-            with ops.side_lane(dout.device, keep=tuple(warm), lane=2):
+            with ops.side_lane(dout.device, keep=tuple(warm), lane=2, after=fork):
                 for t in warm:
                     ops.touch(t)
-                self.warm_event = ops.stream_event()
+                if not FORK_ONCE:
+                    self.warm_event = ops.stream_event()
         x2d = x.view(T * B, ldk)[:, :din]
         h2d = hout.view(T * B, ndir * H)
         dg2d = dgates.view(T * B, ndir * 4 * H)
@@ -164,7 +170,7 @@ class LSTMLayer(object):
         ops.set_side_gemm_workgroups(x.device, BG_WGS if background else 0)
         done = []
         for d in range(ndir):
-            with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il), lane=1 + (d % DW_LANES)):
+            with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il), lane=1 + (d % DW_LANES), after=fork):
                 dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
                 ops.gemm(x2d, dg, transA=True, out=dw_il[d, :din])
                 if T > 1:
@@ -176,7 +182,7 @@ class LSTMLayer(object):
                     dw_il[d, din:].zero_()
                 if d % DW_LANES > 0:
                     done.append(ops.stream_event())
-        with ops.side_lane(x.device, lane=1):
+        with ops.side_lane(x.device, lane=1, after=fork):
             for ev in done:
                 ops.wait_event(ev)
             # interleaved columns -> TF's gate-major kernel gradient; bias / peephole gradients (accumulated

@@ -20,7 +20,7 @@ F64 = torch.float64
 
 
 class _NullLane(object):
-    def __init__(self, device, keep=(), lane=1):
+    def __init__(self, device, keep=(), lane=1, after=None):
         pass
 
     def __enter__(self):
