@@ -37,9 +37,13 @@ for name, M, N, K, form in shapes:
         b = torch.randn(N, K, device=dev).bfloat16()
         out = torch.empty(M, N, device=dev)
         outb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        t_lib = timeit(lambda: torch.matmul(a, b.t(), out=outb))
+        t_lib = timeit(lambda: torch.matmul(a, b.t(), out=outb)) if not os.environ.get('SKIP_LIB') else float('nan')
         au, bu = a, b
         t_own = timeit(lambda: ops.gemm(au, bu, transB=True, out=out))
+        ref = torch.matmul(a[:4096].float(), b.float().t())
+        err = (out[:4096] - ref).abs().max().item() / ref.abs().max().item()
+        tail = (out[-300:] - torch.matmul(a[-300:].float(), b.float().t())).abs().max().item() / ref.abs().max().item()
+        name = name + ' err %.1e/%.1e' % (err, tail)
     else:
         a = torch.randn(K, M, device=dev).bfloat16()
         b = torch.randn(K, N, device=dev).bfloat16()
@@ -48,5 +52,5 @@ for name, M, N, K, form in shapes:
         t_lib = timeit(lambda: torch.matmul(a.t(), b, out=outb))
         au, bu = a, b
         t_own = timeit(lambda: ops.gemm(au, bu, transA=True, out=out))
-    print('%-26s M %6d N %5d K %6d  library (bf16 out) %8.1f us %6.0f TF/s | asr_gemm (fp32 out) %8.1f us %6.0f TF/s'
+    print('%-44s M %6d N %5d K %6d  library (bf16 out) %8.1f us %6.0f TF/s | asr_gemm (fp32 out) %8.1f us %6.0f TF/s'
           % (name, M, N, K, t_lib * 1e6, fl / t_lib / 1e12, t_own * 1e6, fl / t_own / 1e12), flush=True)

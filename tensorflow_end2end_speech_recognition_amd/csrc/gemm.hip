@@ -392,6 +392,180 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
   }
 }
 
+// ---------------------------------------------------------------- NT kernel, large tiles (bf16)
+// The 128 x 128 kernel above is bound by LDS traffic, not by the matrix pipes: a wave's 64 x 64 tile reads 8 KB of
+// fragments per 16 MFMAs, eight waves per CU -> 128 KB read + 64 KB written per k-tile round = 1 536 LDS clocks against
+// 1 024 MFMA clocks per SIMD (measured 0.62-0.64 PFLOP/s on the [105 600 x 1 024] x [1 024 x 4 096] projection of cfg C).
+// This one gives a wave a (BM / WM) x (BN / WN) tile of a BM x BN block: 128 x 64 wave tiles read 12 KB per 32 MFMAs,
+// 128 x 128 ones 16 KB per 64.  Measured on one MI355X (scripts/probe_matmul.py, fp32 output, TFLOP/s on the
+// [12 448 x 512] x [512 x 2 048] / [51 136 x 1 024] x [1 024 x 4 096] / [105 600 x 1 024] x [1 024 x 4 096] projections):
+//   128 x 128 block, four waves of 64 x 64, two blocks per CU (the kernel above)      509 / 578 / 643
+//   256 x 256 block, EIGHT waves of 128 x 64 (two per SIMD, 244 VGPRs)                496 / 721 / 842   <- used from 512 tiles on
+//   256 x 128 block, four waves of 128 x 64 (one per SIMD: nothing hides a stall)     321 / 491 / 512
+//   256 x 256 block, four waves of 128 x 128: the 256 accumulators ARE the AGPR file; the allocator keeps half of them
+//   in VGPRs and copies (433 v_accvgpr moves per k-tile, 94 spilled registers)        169 / 200 / 205
+// (torch.matmul -> hipBLASLt with a bf16 result reaches 420 / 1 029 / 1 237 on the same operands.)  Same staging scheme (next k-tile's global loads in flight during the MFMAs, one barrier
+// per k-tile), same transposed accumulators and epilogue; the staging loads are buffer loads (descriptor in SGPRs, a
+// per-lane 32-bit byte offset that never changes, the k-tile's offset in one SGPR).
+template <typename TO, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 1) void gemm_nt_bf16_big_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
+                                                                           int lda, const bf16_t* __restrict__ Bt, int ldb,
+                                                                           TO* __restrict__ C, int ldc,
+                                                                           const float* __restrict__ bias, int accumulate,
+                                                                           int act, const float* __restrict__ mul, int ldm,
+                                                                           GemmDrop drop) {
+  constexpr int BK = 64, LD = BK + 8, NT = WM * WN * 64;
+  constexpr int STAGE = (BM + BN) * LD;
+  constexpr int TM = BM / WM, TN = BN / WN, TI = TM / 16, TJ = TN / 16;
+  constexpr int VA = BM * 8 / NT, VB = BN * 8 / NT, RSTEP = NT / 8;   // staging vectors per thread, rows between them
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* S = reinterpret_cast<bf16_t*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = N / BN, ntm = (M + BM - 1) / BM, total = ntn * ntm;
+  int t = blockIdx.x;
+  if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);   // XCD x gets a contiguous run of tiles
+  const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+
+  // staging vector i of a thread: row (tid >> 3) + RSTEP i, k-offset (tid & 7) * 8; rows of A past M (last tile) are
+  // clamped to row M - 1 and masked at the store
+  const int r0 = tid >> 3, kv = (tid & 7) * 8;
+  unsigned oa[VA], ob[VB];
+#pragma unroll
+  for (int i = 0; i < VA; ++i) oa[i] = (unsigned)(((size_t)min(m0 + r0 + RSTEP * i, M - 1) * lda + kv) * sizeof(bf16_t));
+#pragma unroll
+  for (int i = 0; i < VB; ++i) ob[i] = (unsigned)(((size_t)(n0 + r0 + RSTEP * i) * ldb + kv) * sizeof(bf16_t));
+  const unsigned so0 = (unsigned)(r0 * LD + kv);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(A), 0, (int)min((size_t)0xFFFFFFFFu, ((size_t)(M - 1) * lda + K) * sizeof(bf16_t)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(Bt), 0, (int)min((size_t)0xFFFFFFFFu, ((size_t)(N - 1) * ldb + K) * sizeof(bf16_t)), 0x00020000);
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  u32x4_t ra[VA], rb[VB];
+  unsigned koff = 0;                                       // byte offset of the k-tile being fetched (uniform)
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < VA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa[i], koff, 0);
+#pragma unroll
+    for (int i = 0; i < VB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ob[i], koff, 0);
+    koff += BK * sizeof(bf16_t);
+  };
+  auto sstore = [&](bf16_t* st) {
+#pragma unroll
+    for (int i = 0; i < VA; ++i) *reinterpret_cast<u32x4_t*>(st + so0 + i * RSTEP * LD) = ra[i];
+#pragma unroll
+    for (int i = 0; i < VB; ++i) *reinterpret_cast<u32x4_t*>(st + BM * LD + so0 + i * RSTEP * LD) = rb[i];
+  };
+
+  f32x4_t acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / BK;
+  gload();
+  sstore(S);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  const unsigned aoff = (unsigned)((wm * TM + fr) * LD + fq * 8);
+  const unsigned boff = (unsigned)(BM * LD + (wn * TN + fr) * LD + fq * 8);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bf16_t* cur = S + (kt & 1) * STAGE;
+    if (kt + 1 < nkt) gload();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[TI];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(cur + aoff + i * 16 * LD + ks * 32);
+#pragma unroll
+      for (int jh = 0; jh < TJ; jh += 4) {                  // B fragments in runs of four (registers)
+        bf16x8_t b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(cur + boff + (jh + j) * 16 * LD + ks * 32);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][jh + j], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) sstore(S + ((kt + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+  // lane holds C[m = fr][n = fq*4 .. +3] of each 16x16 tile
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int m = m0 + wm * TM + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int nb = n0 + wn * TN + j * 16 + fq * 4;
+      TO* cp = C + (size_t)m * ldc + nb;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      if (bias) {
+        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+      }
+      if constexpr (sizeof(TO) == 4) {
+        if (accumulate) {
+          const f32x4_t o = *reinterpret_cast<const f32x4_t*>(cp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += o[r];
+        }
+        if (act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (mul) {
+          const f32x4_t mv = *reinterpret_cast<const f32x4_t*>(mul + (size_t)m * ldm + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= mv[r];
+        }
+        if (drop.use) {
+          float mk[4];
+          asr_dropout_words(drop.offset + ((size_t)m * N + nb) / 4, drop.seed, drop.keep, 1.f / drop.keep, mk);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= mk[r];
+        }
+        *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+      } else {
+        typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+        if (accumulate) {
+          const us4_t o = *reinterpret_cast<const us4_t*>(cp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bf16_to_f32(o[r]);
+        }
+        if (act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        *reinterpret_cast<us4_t*>(cp) = (us4_t){f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+      }
+    }
+  }
+}
+
+template <typename TO, int BM, int BN, int WM, int WN>
+static void launch_gemm_nt_big(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                               const float* bias, int accumulate, hipStream_t st, int act, const float* mul, int ldm,
+                               GemmDrop drop) {
+  const size_t lds = (size_t)2 * (BM + BN) * (64 + 8) * sizeof(bf16_t);
+  static bool attr_done = false;
+  auto k = gemm_nt_bf16_big_kernel<TO, BM, BN, WM, WN>;
+  if (!attr_done) {
+    attr_done = true;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  const long tiles = (long)(N / BN) * ((M + BM - 1) / BM);
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(WM * WN * 64), lds, st, M, N, K, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, (TO*)C, ldc, bias, accumulate, act, mul, ldm, drop);
+}
+
 template <typename TO>
 bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
                       int ldb, void* C, int ldc, const float* bias, int accumulate, hipStream_t st, int act,
@@ -401,6 +575,15 @@ bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A
   if (mul && (sizeof(TO) != 4 || ldm % 4 != 0 || ((uintptr_t)mul) % 16 != 0)) return false;
   if (lda % 8 != 0 || ldb % 8 != 0 || ((uintptr_t)A) % 16 != 0 || ((uintptr_t)B) % 16 != 0) return false;
   if (ldc % 4 != 0 || ((uintptr_t)C) % (4 * sizeof(TO)) != 0 || (bias && ((uintptr_t)bias) % 16 != 0)) return false;
+  // large products (>= 512 tiles of 256 x 256, i.e. two full rounds of the chip): 256 x 256 blocks of eight waves, see
+  // gemm_nt_bf16_big_kernel; ASR_GEMM_NT_BIG=0 keeps the 128 x 128 tiles (A/B), =2 takes the big ones from M >= 2048 on
+  static const int big = [] { const char* e = getenv("ASR_GEMM_NT_BIG"); return e ? atoi(e) : 1; }();
+  const bool fits32 = ((size_t)(M - 1) * lda + K) * sizeof(bf16_t) < 0xFFFFFFFFull && ((size_t)(N - 1) * ldb + K) * sizeof(bf16_t) < 0xFFFFFFFFull;
+  const long tiles256 = (long)(N / 256) * ((M + 255) / 256);
+  if (big && fits32 && N % 256 == 0 && (big == 2 ? M >= 2048 : tiles256 >= 512)) {
+    launch_gemm_nt_big<TO, 256, 256, 2, 4>(M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, st, act, mul, ldm, drop);
+    return true;
+  }
   const size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * sizeof(bf16_t);
   static bool attr_done = false;
   if (!attr_done) {

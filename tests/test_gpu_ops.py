@@ -128,6 +128,38 @@ def test_gemm_with_multiplier_epilogue(cuda, M, N, K, dt):
         ops.gemm(A, Bt, transB=True, out_dtype='f32', mul=mask[:, :N - 1])
 
 
+@pytest.mark.parametrize('M,N,K', [(66000, 512, 128), (33003, 1024, 192)])
+def test_gemm_nt_large_tiles(cuda, M, N, K):
+    """Products of >= 512 tiles of 256 x 256 take the eight-wave 256 x 256 NT kernel (buffer-load staging, the last M tile
+    ragged): plain, + bias, accumulate, fp32 multiplier, dropout formed in the epilogue, bf16 result -- each against the
+    exact product of the bf16 operands (fp64) / bit-identical to the unfused form."""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(cuda)
+    Bt = torch.randn(N, K, generator=g).to(torch.bfloat16).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    ref = A.double() @ Bt.double().t()
+    out = ops.gemm(A, Bt, transB=True, out_dtype='f32')
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) < 2e-6 * scale
+    outb = ops.gemm(A, Bt, transB=True, out_dtype='f32', bias=bias)
+    assert float((outb.double() - (ref + bias.double())).abs().max()) < 2e-6 * scale
+    acc = out.clone()
+    ops.gemm(A, Bt, transB=True, out=acc, accumulate=True)
+    assert float((acc.double() - 2 * ref).abs().max()) < 4e-6 * scale
+    mask = (torch.rand(M, N, generator=g) < 0.8).float().to(cuda) / 0.8
+    assert torch.equal(ops.gemm(A, Bt, transB=True, out_dtype='f32', mul=mask), ops.apply_mask(out, mask))
+    d = (0.8, 5, (2 << 32) + 7)
+    assert torch.equal(ops.gemm(A, Bt, transB=True, out_dtype='f32', drop=d),
+                       ops.apply_mask(out, ops.dropout_mask((M, N), *d, cuda)))
+    o16 = ops.gemm(A, Bt, transB=True, out_dtype='bf16')
+    assert float((o16.double() - ref).abs().max()) < 5e-3 * scale
+    # the last rows (ragged tile) and nothing beyond the tensor
+    guard = torch.full((M + 2, N), 7.0, device=cuda)
+    ops.gemm(A, Bt, transB=True, out=guard[:M])
+    assert torch.equal(guard[:M], out) and float(guard[M:].min()) == 7.0
+
+
 def test_gemm_tn_xcd_skip_is_result_neutral(cuda):
     """The side lanes' reduction-major GEMM with the first n XCDs left alone (asr_set_xcd_skip): bit-identical to n = 0
     for every n, including shapes whose tile count is not a multiple of the XCDs in use."""
