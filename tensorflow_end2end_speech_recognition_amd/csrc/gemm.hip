@@ -1287,6 +1287,107 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tn_kernel(int Mpix, int H, 
   }
 }
 
+// The same weight gradient on gemm_tn_bf16_kernel's LDS image: a thread's gathered 16 bytes (8 channels of one tap at one
+// pixel) are ONE ds_write_b128 into [subtile][k row][16 columns], and the MFMA fragments come out of it through the
+// transposing reads (ds_read_b64_tr_b16) -- the kernel above interleaves pixel pairs into a [column][k] image with 64
+// four-byte LDS writes per thread per k-tile (twice the instructions of its 32 MFMAs).  ASR_CONV_WGRAD_TR=0 keeps it (A/B).
+__global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(int Mpix, int H, int W, int Cin, int Cout,
+                                                               const bf16_t* __restrict__ X,
+                                                               const bf16_t* __restrict__ dY, int kchunk,
+                                                               float* __restrict__ partial) {
+  constexpr int BM = 128, BN = 128, BK = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int M = 9 * Cin, N = Cout, K = Mpix, HW = H * W;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+
+  // four (pixel, 8-column vector) items per operand per thread: vector mvec = tid & 15 of pixels (tid >> 4) + 16 q
+  const int mvec = tid & 15, kr0 = tid >> 4;
+  const int mcol = m0 + mvec * 8;                          // first of this thread's 8 virtual columns (tap, ci)
+  const bool a_ok = mcol + 8 <= M, b_ok = n0 + mvec * 8 + 8 <= N;
+  const int tap = a_ok ? mcol / Cin : 0, ci = a_ok ? mcol - tap * Cin : 0;
+  const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+  const ptrdiff_t sh = ((ptrdiff_t)dy * W + dx) * Cin + ci;
+  const float invW = 1.0f / (float)W;
+  const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8_t ra[4], rb[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = kbeg + kt * BK + kr0 + 16 * q;         // pixel = reduction index
+      const bool kin = p < kend;
+      const int pp = kin ? p : 0;
+      const int rem = pp % HW;
+      const int y = (int)(((float)rem + 0.5f) * invW), x = rem - y * W;      // exact for rem < 2^22
+      const bool ok = a_ok && kin && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+      ra[q] = ok ? *reinterpret_cast<const bf16x8_t*>(X + (ptrdiff_t)((size_t)pp * Cin) + sh) : zero;
+      rb[q] = (b_ok && kin) ? *reinterpret_cast<const bf16x8_t*>(dY + (size_t)pp * Cout + n0 + mvec * 8) : zero;
+    }
+  };
+  const unsigned wbase = (unsigned)(mvec >> 1) * TN_SUB + (unsigned)kr0 * 32u + (unsigned)(mvec & 1) * 16u;
+  auto sstore = [&](char* st) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<bf16x8_t*>(st + wbase + q * 16 * 32) = ra[q];
+      *reinterpret_cast<bf16x8_t*>(st + TN_OPER + wbase + q * 16 * 32) = rb[q];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  if (nkt > 0) {
+    gload(0);
+    sstore(smem);
+  }
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  const unsigned piece = (unsigned)(8 * fq + (fr >> 2)) * 32u + (unsigned)(fr & 3) * 8u;
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    aoff[i] = (unsigned)(wm * 4 + i) * TN_SUB + piece;
+    boff[i] = (unsigned)TN_OPER + (unsigned)(wn * 4 + i) * TN_SUB + piece;
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* cur = smem + (kt & 1) * TN_STAGE;
+    if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = tn_frag(cur + aoff[i] + ks * 32 * 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = tn_frag(cur + boff[j] + ks * 32 * 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) sstore(smem + ((kt + 1) & 1) * TN_STAGE);
+    __syncthreads();
+  }
+  float* slab = partial + (size_t)blockIdx.z * M * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + wn * 64 + j * 16 + fq * 4;
+      if (nb >= N) continue;
+      *reinterpret_cast<f32x4_t*>(slab + (size_t)m * N + nb) = acc[i][j];
+    }
+  }
+}
+
 // fixed-order sum of the split-K slabs -> deterministic
 template <typename TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
@@ -1646,12 +1747,20 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
   int kchunk = (Mpix + S - 1) / S;
   kchunk = (kchunk + 63) / 64 * 64;
   S = (Mpix + kchunk - 1) / kchunk;
-  const size_t lds = (size_t)2 * (128 + 128) * 72 * sizeof(bf16_t);
-  (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   float* partial = (float*)h->scratch;
   hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(conv3x3_wgrad_tn_kernel, dim3(tn, tm, S), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
-                     (const bf16_t*)x, (const bf16_t*)dy, kchunk, partial);
+  static const bool wgrad_tr = [] { const char* e = getenv("ASR_CONV_WGRAD_TR"); return !(e && e[0] == '0'); }();
+  if (wgrad_tr) {
+    const size_t lds = (size_t)2 * TN_STAGE;
+    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(conv3x3_wgrad_tr_kernel, dim3(tn, tm, S), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
+                       (const bf16_t*)x, (const bf16_t*)dy, kchunk, partial);
+  } else {
+    const size_t lds = (size_t)2 * (128 + 128) * 72 * sizeof(bf16_t);
+    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(conv3x3_wgrad_tn_kernel, dim3(tn, tm, S), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
+                       (const bf16_t*)x, (const bf16_t*)dy, kchunk, partial);
+  }
   const size_t total = (size_t)M * N;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
