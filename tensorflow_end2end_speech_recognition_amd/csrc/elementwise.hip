@@ -293,6 +293,28 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int RB, i
   out[col] = s;
 }
 
+// The same final pass for MANY partial rows (the vector kernel leaves up to 2048): one thread per column walks them with
+// a handful of loads in flight -- 335 us for 2048 rows of 64 columns (`profiles/r03_cfgC_kernel_trace.md`, six calls
+// per cfg C step).  Here 16 columns x 16 row groups per workgroup: a thread sums every 16th row in row order, the 16
+// group sums are added in group order (fixed order: deterministic).
+__global__ __launch_bounds__(256) void colsum_final_wide_kernel(const float* __restrict__ partial, int RB, int N,
+                                                                float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
+  float s = 0.f;
+  if (col < N)
+    for (int r = grp; r < RB; r += 16) s += partial[(size_t)r * N + col];
+  red[grp][c] = s;
+  __syncthreads();
+  if (grp == 0 && col < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][c];
+    out[col] = t;
+  }
+}
+
 // ---- per-tensor L2 norms (two-stage, deterministic) + clip ----
 constexpr int NORM_CHUNK = 4096;  // elements per partial
 __global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restrict__ g,
@@ -695,7 +717,10 @@ extern "C" int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N,
     float* pv = (float*)h->scratch;
     hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3(nb), dim3(256), (size_t)(256 / (N / 8)) * N * sizeof(float),
                        (hipStream_t)s, (const bf16_t*)a, (long long)M, N, rpb, pv);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, pv, nb, N, out);
+    if (nb > 64)
+      hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)s, pv, nb, N, out);
+    else
+      hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, pv, nb, N, out);
     ASR_CHECK_LAUNCH(h, "asr_colsum");
     return ASR_OK;
   }
