@@ -480,6 +480,140 @@ __global__ void att_ctx_reduce_kernel(const float* __restrict__ part, int nch, i
   if (ctx3) ctx3[(size_t)(i / E) * ld3 + i % E] = c;
 }
 
+// ---------------------------------------------------------------- energies + softmax + context in ONE pass (decoder loop)
+// A decoder step used to be energies -> softmax -> partial context -> reduction: four dependent launches of 4-12 us each
+// with ~4 us of queue latency between them (profiles/r03_cfgD_kernel_trace.md).  The softmax does not need a launch of
+// its own: a (chunk, utterance) workgroup computes its 64 energies, their maximum m_c, p_t = exp(e_t - m_c), s_c = sum p_t
+// and the UNNORMALISED partial context sum_t p_t enc_t in one go (the chunk's weights never leave LDS), and the
+// combine kernel that sums the chunk partials anyway rescales them: with M = max_c m_c and S = sum_c s_c exp(m_c - M),
+// ctx = sum_c part_c exp(m_c - M) / S and alpha_t = p_t exp(m_c(t) - M) / S (written for the backward pass).  Same
+// masking as att_softmax_kernel: frames past the length get weight 0, an all-masked row (batch padding) uniform weights.
+// Measured (cfg D / cfg E shards, ms per step): 83.84 / 48.91 against 83.85 / 49.57 for the four-launch form -- two launches
+// and their queue gaps fewer, but the same dependent round trips inside one kernel: device time is unchanged (the
+// round-2 finding again), host issue drops by 800 launches per step.
+// FCH = frames per workgroup: 32 for T <= 2048 (twice the workgroups, half the serial frames of the context phase each)
+template <int LPF, int NV, typename TE, int FCH>
+__global__ __launch_bounds__(256) void att_fused_fwd_kernel(const float* __restrict__ keys, const float* __restrict__ qz,
+                                                            const float* __restrict__ v, int T, int B, int A, int mode,
+                                                            float sharp, const int32_t* __restrict__ seq_len,
+                                                            const TE* __restrict__ enc, int E, float* __restrict__ alpha,
+                                                            float* __restrict__ part, float* __restrict__ stat) {
+  constexpr int FPW = 64 / LPF;
+  __shared__ float el[FCH];
+  __shared__ float s_m;
+  const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int sub = lane / LPF, l = lane % LPF, nvec = A >> 2;
+  const int len = min(max(seq_len[b], 0), T);
+  const int t0 = blockIdx.x * FCH;
+  const float lowest = -3.402823466e+38f;
+  const int n = max(0, min(FCH, (len == 0 ? T : len) - t0));      // frames of this chunk that carry weight
+  float* st = stat + ((size_t)blockIdx.x * B + b) * 2;
+  float* o = part + ((size_t)blockIdx.x * B + b) * E;
+  if (n == 0) {                                                       // block-uniform
+    if (tid == 0) { st[0] = lowest; st[1] = 0.f; }
+    return;                                                           // (the combine kernel skips the partial)
+  }
+  if (len == 0) {
+    if (tid < n) el[tid] = lowest;
+  } else {
+    const int t1 = t0 + n;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t qv[NV], vv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int a4 = l + i * LPF;
+      qv[i] = a4 < nvec ? *reinterpret_cast<const f32x4_t*>(qz + (size_t)b * A + a4 * 4) : zero;
+      vv[i] = (a4 < nvec && mode == 0) ? *reinterpret_cast<const f32x4_t*>(v + a4 * 4) : zero;
+    }
+    for (int tb = t0 + wave * FPW; tb < t1; tb += 4 * FPW) {
+      const int t = tb + sub;
+      const bool valid = t < t1;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int a4 = l + i * LPF;
+        f32x4_t kv = zero;
+        if (keys && valid && a4 < nvec) kv = *reinterpret_cast<const f32x4_t*>(keys + ((size_t)t * B + b) * A + a4 * 4);
+        if (mode == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum += vv[i][e] * fast_tanhf(kv[e] + qv[i][e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum += kv[e] * qv[i][e];
+        }
+      }
+      sum = group_reduce_sum<LPF>(sum);
+      if (l == 0 && valid) el[t - t0] = fmaxf(sum * sharp, lowest);
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float e = lane < n ? el[lane] : -INFINITY;
+    const float m = wave_reduce_max(e);
+    const float pe = lane < n ? expf(e - m) : 0.f;
+    const float sm = wave_reduce_sum(pe);
+    if (lane < n) {
+      el[lane] = pe;
+      alpha[(size_t)b * T + t0 + lane] = pe;                          // unnormalised; the combine kernel rescales it
+    }
+    if (lane == 0) { st[0] = m; st[1] = sm; s_m = m; }
+  }
+  __syncthreads();
+  const size_t rs = (size_t)B * E;
+  for (int e4 = tid; e4 < E / 4; e4 += 256) {
+    const TE* pe = enc + ((size_t)t0 * B + b) * E + e4 * 4;
+    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < n; ++i) {
+      const f32x4_t x = enc_ld4(pe + i * rs);
+      const float w = el[i];
+      c[0] += w * x[0]; c[1] += w * x[1]; c[2] += w * x[2]; c[3] += w * x[3];
+    }
+    *reinterpret_cast<f32x4_t*>(o + e4 * 4) = c;
+  }
+}
+// combine: a workgroup belongs to ONE utterance -- its first wave turns the <= 64 chunk statistics into the weights
+// w_c = exp(m_c - M) / S once (LDS), then blocks [0, B * E/256) sum 256 context elements each over the chunk partials and the
+// rest rescale 256 attention weights each
+__global__ __launch_bounds__(256) void att_fused_combine_kernel(const float* __restrict__ part, const float* __restrict__ stat,
+                                                                int nch, int fch, int B, int E, int T,
+                                                                const int32_t* __restrict__ seq_len,
+                                                                float* __restrict__ ctx, float* __restrict__ ctx2, int ld2,
+                                                                float* __restrict__ ctx3, int ld3, float* __restrict__ alpha) {
+  __shared__ float w[64];
+  const int epb = E / 256, nb_ctx = B * epb, tpb = (T + 255) / 256;
+  const bool is_ctx = (int)blockIdx.x < nb_ctx;
+  const int b = is_ctx ? blockIdx.x / epb : (blockIdx.x - nb_ctx) / tpb;
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const float m = tid < nch ? stat[((size_t)tid * B + b) * 2] : -3.402823466e+38f;
+    const float sk = tid < nch ? stat[((size_t)tid * B + b) * 2 + 1] : 0.f;
+    const float M = wave_reduce_max(m);
+    const float wk = sk > 0.f ? expf(m - M) : 0.f;
+    const float S = wave_reduce_sum(sk * wk);
+    w[tid] = wk / S;
+  }
+  __syncthreads();
+  if (is_ctx) {
+    const int e = (blockIdx.x % epb) * 256 + tid;
+    const size_t BE = (size_t)B * E, i = (size_t)b * E + e;
+    float c = 0.f;
+    for (int k = 0; k < nch; ++k) {                                    // fixed order
+      const float wk = w[k];
+      if (wk > 0.f) c += part[(size_t)k * BE + i] * wk;                // (chunks past the length were never written)
+    }
+    ctx[i] = c;
+    if (ctx2) ctx2[(size_t)b * ld2 + e] = c;
+    if (ctx3) ctx3[(size_t)b * ld3 + e] = c;
+  } else {
+    const int t = ((blockIdx.x - nb_ctx) % tpb) * 256 + tid;
+    if (t >= T) return;
+    int len = min(max(seq_len[b], 0), T);
+    if (len == 0) len = T;
+    const size_t i = (size_t)b * T + t;
+    alpha[i] = t < len ? alpha[i] * w[t / fch] : 0.f;
+  }
+}
+
 // dalpha[b,t] = enc[t,b,:] . dctx[b,:]  for t < len (one wave per frame, float4 lanes)
 template <typename TE>
 __global__ __launch_bounds__(256) void att_dalpha_kernel(const float* __restrict__ dctx,
@@ -1961,6 +2095,45 @@ static int dec_check(asr_handle* h, const asr_att_decoder* a, bool bwd) {
   return ASR_OK;
 }
 
+// energies + softmax + context of one decoder step as two launches (att_fused_fwd_kernel + combine); false = the shape is
+// not covered (the caller takes the four-launch path).  ASR_ATT_FUSED=0 switches it off (A/B).
+static bool att_fused_step(asr_handle* h, const asr_att_decoder* a, const float* qz, float* alpha, float* ctx, float* ctx2,
+                           int ld2, float* ctx3, int ld3, asr_stream s) {
+  static const bool on = [] { const char* e = getenv("ASR_ATT_FUSED"); return !(e && e[0] == '0'); }();
+  const int B = a->B, T = a->T, E = a->E2, A = a->A;
+  if (!on || a->carry_alpha || a->snorm_all || E % 256 != 0 || T > 64 * ATT_CH || ((uintptr_t)a->enc) % 16 != 0) return false;
+  const int shape = energy_vec_shape(A, a->keys, qz, a->v, nullptr);
+  if (!shape) return false;
+  // 64-frame chunks; 32 (twice the workgroups, half the serial frames of the context phase) measured 86.5 vs 83.6 ms
+  // per cfg D step (ASR_ATT_FUSED_CH=32 selects it)
+  static const int fch_env = [] { const char* e = getenv("ASR_ATT_FUSED_CH"); return e ? atoi(e) : 64; }();
+  const int fch = (fch_env == 32 && T <= 2048) ? 32 : 64;
+  const int nch = (T + fch - 1) / fch;
+  float* part = att_scratch(h, ((size_t)nch * B * E + (size_t)nch * B * 2) * sizeof(float));
+  if (!part) return false;
+  float* stat = part + (size_t)nch * B * E;
+  const dim3 grid(nch, B);
+  hipStream_t st = (hipStream_t)s;
+#define ASR_FUSED(L, NV_, TE_, F_) \
+  hipLaunchKernelGGL((att_fused_fwd_kernel<L, NV_, TE_, F_>), grid, dim3(256), 0, st, a->keys, qz, a->v, T, B, A, a->att_mode, \
+                     a->sharpening, a->seq_len, (const TE_*)a->enc, E, alpha, part, stat)
+#define ASR_FUSED_T(L, NV_) do { \
+    if (a->enc_dtype == ASR_F32) { if (fch == 32) ASR_FUSED(L, NV_, float, 32); else ASR_FUSED(L, NV_, float, 64); } \
+    else { if (fch == 32) ASR_FUSED(L, NV_, bf16_t, 32); else ASR_FUSED(L, NV_, bf16_t, 64); } } while (0)
+  switch (shape) {
+    case 16 * 4 + 1: ASR_FUSED_T(16, 1); break;
+    case 32 * 4 + 1: ASR_FUSED_T(32, 1); break;
+    case 64 * 4 + 1: ASR_FUSED_T(64, 1); break;
+    default: ASR_FUSED_T(64, 2); break;
+  }
+#undef ASR_FUSED_T
+#undef ASR_FUSED
+  const int nb_ctx = B * (E / 256), nb_al = B * ((T + 255) / 256);
+  hipLaunchKernelGGL(att_fused_combine_kernel, dim3(nb_ctx + nb_al), dim3(256), 0, st, part, stat, nch, fch, B, E, T, a->seq_len,
+                     ctx, ctx2, ld2, ctx3, ld3, alpha);
+  return true;
+}
+
 extern "C" int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   DEC_TRY(dec_check(h, a, false));
@@ -1985,6 +2158,10 @@ extern "C" int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_
                                  dnext ? dnext + Em + E2 : nullptr, Din, av, Dav, s));
     if (a->has_query_fc)
       DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, A, U, av, Dav, a->W_q, a->ld_wq, qz, A, a->b_q, 0, 0, s));
+    if (att_fused_step(h, a, qz, a->alpha_all + (size_t)k * B * T, ctx, av + U, Dav, dnext ? dnext + Em : nullptr, Din, s)) {
+      ASR_CHECK_LAUNCH(h, "asr_att_decoder_fwd(fused step)");
+      continue;
+    }
     if (a->carry_alpha)
       DEC_TRY(loc_energy_fwd_launch(h, k > 0 ? a->alpha_all + (size_t)(k - 1) * B * T : a->alpha_zero, a->filt, a->wfil,
                                     a->keys, qz, a->v, T, B, A, a->taps, energy, a->seq_len, s));
