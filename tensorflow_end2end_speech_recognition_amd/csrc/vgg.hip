@@ -243,6 +243,72 @@ __global__ __launch_bounds__(256) void conv3x3_smallc_fwd_kernel(const bf16_t* _
 //   weight gradient dW[k][co] = sum_p patch[p][k] dpre[p][co]: a workgroup walks its slice of the pixels in tiles of
 //   64, stages the tile's dpre rows and gathered patches in LDS and keeps its [32][64] sums in registers (thread: one
 //   output channel x 8 consecutive k); the per-workgroup sums are added in a fixed order by a second kernel.
+// The same layer on the matrix cores (round 3).  The VALU form above is bound by its 27 x 64 multiply-adds per pixel
+// (87 GFLOP at cfg C = a third of the chip's fp32 vector rate: 3.4 ms), not by the 3.2 GB it writes.  As a GEMM the layer
+// is [pixels x 32] x [32 x 64] with ONE k-step: a wave gathers the (zero-padded) 27-value patches of 16 pixels straight
+// into an MFMA operand (lane = (pixel, 8 consecutive k)), multiplies them with the four 16-channel weight fragments it
+// keeps in registers, and stages its 64 pixels x 64 channels through LDS so that the result leaves as 1 KB stores -- the
+// output rows of consecutive pixels are contiguous.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_smallc_fwd_mfma_kernel(const bf16_t* __restrict__ x, size_t Npix, int H, int W,
+                                                                      const bf16_t* __restrict__ w2d,
+                                                                      const float* __restrict__ bias, int relu,
+                                                                      bf16_t* __restrict__ out) {
+  constexpr int K = 9 * CIN, LDT = SC_CO + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t tile[4][64][LDT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16x8_t wb[4];
+  f32x4_t bv[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = fq * 8 + j;
+      wb[nt][j] = k < K ? (short)w2d[k * SC_CO + nt * 16 + fr] : (short)0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[nt][r] = bias ? bias[nt * 16 + fq * 4 + r] : 0.f;
+  }
+  const size_t pbase = (size_t)blockIdx.x * 256 + (size_t)wave * 64;
+  const int HW = H * W;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const size_t p = pbase + mt * 16 + fr;
+    const bool valid = p < Npix;
+    const size_t n = valid ? p / (size_t)HW : 0;
+    const int rem = valid ? (int)(p - n * HW) : 0;
+    const int h = rem / W, w = rem - h * W;
+    const bf16_t* xn = x + n * (size_t)HW * CIN;
+    bf16x8_t a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = fq * 8 + j;
+      const int tap = k / CIN, ci = k - tap * CIN;
+      const int hs = h + tap / 3 - 1, ws = w + tap % 3 - 1;
+      const bool ok = valid && k < K && hs >= 0 && hs < H && ws >= 0 && ws < W;
+      a[j] = ok ? (short)xn[(hs * W + ws) * CIN + ci] : (short)0;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nt], a, bv[nt], 0, 0, 0);   // lane: pixel fr, channels fq*4..+3
+      typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+      us4_t y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = f32_to_bf16(relu ? fmaxf(acc[r], 0.f) : acc[r]);
+      *reinterpret_cast<us4_t*>(&tile[wave][mt * 16 + fr][nt * 16 + fq * 4]) = y;
+    }
+  }
+  __syncthreads();
+  typedef __attribute__((ext_vector_type(8))) unsigned short us8_t;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+    const size_t p = pbase + row;
+    if (p < Npix) *reinterpret_cast<us8_t*>(out + p * SC_CO + c8) = *reinterpret_cast<const us8_t*>(&tile[wave][row][c8]);
+  }
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_smallc_wgrad_kernel(const bf16_t* __restrict__ x,
                                                                    const bf16_t* __restrict__ dpre, size_t Npix, int H,
@@ -288,6 +354,101 @@ __global__ __launch_bounds__(256) void conv3x3_smallc_wgrad_kernel(const bf16_t*
   float* o = partial + (size_t)blockIdx.x * SC_K * SC_CO;
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[(kg + i) * SC_CO + co] = acc[i];
+}
+// Weight gradient of the same layer on the matrix cores: dW[k][co] = sum_p patch[p][k] dpre[p][co] is a reduction-major
+// product with M = 32 (27 used), N = 64 and K = pixels.  A wave stages 32 pixels at a time: each lane gathers 16 patch
+// values of ONE pixel (one coordinate computation) and loads 64 bytes of that pixel's dpre row, both written as whole
+// 32-byte rows into [16-column subtile][pixel] images -- the layout gemm.hip's reduction-major GEMM uses -- from which
+// the transposing LDS reads (ds_read_b64_tr_b16) deliver the MFMA operands: 8 MFMAs per 32 pixels instead of 27 x 64
+// vector multiply-adds per pixel.  Partials per workgroup as before.
+constexpr int SCW_SUB = 32 * 32 + 32;                     // bytes from one [32 pixels][16 columns] subtile to the next
+__device__ __forceinline__ bf16x8_t scw_frag(const char* p) {
+  typedef __attribute__((ext_vector_type(4))) short s4_t;
+  typedef __attribute__((address_space(3))) s4_t lds4_t;
+  const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t*)(p));
+  const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t*)(p + 128));
+  return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_smallc_wgrad_mfma_kernel(const bf16_t* __restrict__ x,
+                                                                        const bf16_t* __restrict__ dpre, size_t Npix, int H,
+                                                                        int W, size_t per_blk,
+                                                                        float* __restrict__ partial) {
+  constexpr int K = 9 * CIN;
+  // per wave: 2 patch + 4 dpre subtiles; the same memory holds the four waves' accumulators for the final sum
+  constexpr int IMG_BYTES = 4 * 6 * SCW_SUB, RED_BYTES = 4 * SC_K * (SC_CO + 1) * 4;
+  __shared__ __attribute__((aligned(16))) char lds[IMG_BYTES > RED_BYTES ? IMG_BYTES : RED_BYTES];
+  char (*img)[6 * SCW_SUB] = reinterpret_cast<char (*)[6 * SCW_SUB]>(lds);
+  float (*red)[SC_K][SC_CO + 1] = reinterpret_cast<float (*)[SC_K][SC_CO + 1]>(lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int px = lane & 31, half = lane >> 5;              // staging: pixel of the group, which half of its row
+  const int HW = H * W;
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  char* my = img[wave];
+  const unsigned piece = (unsigned)(8 * fq + (fr >> 2)) * 32u + (unsigned)(fr & 3) * 8u;
+  const size_t p_beg = (size_t)blockIdx.x * per_blk, p_end = min(Npix, p_beg + per_blk);
+  typedef __attribute__((ext_vector_type(8))) unsigned short us8_t;
+  for (size_t g0 = p_beg; g0 < p_end; g0 += 128) {          // block-uniform trip count
+    const size_t p = g0 + (size_t)wave * 32 + px;
+    const bool valid = p < p_end;
+    // ---- stage: 16 patch values (k = 16 half .. + 15) and 32 channels (32 half .. + 31) of pixel p
+    {
+      const size_t n = valid ? p / (size_t)HW : 0;
+      const int rem = valid ? (int)(p - n * HW) : 0;
+      const int h = rem / W, w = rem - h * W;
+      const bf16_t* xn = x + n * (size_t)HW * CIN;
+      us8_t pv[2];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = half * 16 + j;
+        const int tap = k / CIN, ci = k - tap * CIN;
+        const int hs = h + tap / 3 - 1, ws = w + tap % 3 - 1;
+        const bool ok = valid && k < K && hs >= 0 && hs < H && ws >= 0 && ws < W;
+        pv[j >> 3][j & 7] = ok ? xn[(hs * W + ws) * CIN + ci] : (bf16_t)0;
+      }
+      char* prow = my + half * SCW_SUB + px * 32;
+      *reinterpret_cast<us8_t*>(prow) = pv[0];
+      *reinterpret_cast<us8_t*>(prow + 16) = pv[1];
+      const us8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const us8_t dv = valid ? *reinterpret_cast<const us8_t*>(dpre + p * SC_CO + half * 32 + q * 8) : zero;
+        // channels half*32 + q*8 .. +7 -> subtile 2 half + (q >> 1), half-row (q & 1)
+        *reinterpret_cast<us8_t*>(my + (2 + 2 * half + (q >> 1)) * SCW_SUB + px * 32 + (q & 1) * 16) = dv;
+      }
+    }
+    __syncthreads();
+    {
+      bf16x8_t a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = scw_frag(my + i * SCW_SUB + piece);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = scw_frag(my + (2 + j) * SCW_SUB + piece);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // C[k = 16 i + fr][co = 16 j + 4 fq ..]
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][i * 16 + fr][j * 16 + fq * 4 + r] = acc[i][j][r];
+  __syncthreads();
+  float* o = partial + (size_t)blockIdx.x * SC_K * SC_CO;
+  for (int e = threadIdx.x; e < SC_K * SC_CO; e += 256) {
+    const int k = e / SC_CO, co = e % SC_CO;
+    o[e] = red[0][k][co] + red[1][k][co] + red[2][k][co] + red[3][k][co];
+  }
 }
 __global__ void conv3x3_smallc_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int K,
                                                    float* __restrict__ dw) {
@@ -453,7 +614,14 @@ extern "C" int asr_conv3x3_smallc_fwd(asr_handle* h, const void* x, int N, int H
 #define ASR_SC_FWD(C_) \
   hipLaunchKernelGGL(conv3x3_smallc_fwd_kernel<C_>, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, (hipStream_t)s, \
                      (const bf16_t*)x, npix, H, W, (const bf16_t*)w2d, bias, relu, (bf16_t*)out)
-  if (Cin == 1) ASR_SC_FWD(1); else if (Cin == 2) ASR_SC_FWD(2); else ASR_SC_FWD(3);
+  // matrix-core form (see the kernel); ASR_SMALLC_MFMA=0 keeps the vector-ALU kernels (A/B)
+  static const bool mfma = [] { const char* e = getenv("ASR_SMALLC_MFMA"); return !(e && e[0] == '0'); }();
+#define ASR_SC_FWD_M(C_) \
+  hipLaunchKernelGGL(conv3x3_smallc_fwd_mfma_kernel<C_>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)s, \
+                     (const bf16_t*)x, npix, H, W, (const bf16_t*)w2d, bias, relu, (bf16_t*)out)
+  if (mfma) { if (Cin == 1) ASR_SC_FWD_M(1); else if (Cin == 2) ASR_SC_FWD_M(2); else ASR_SC_FWD_M(3); }
+  else if (Cin == 1) ASR_SC_FWD(1); else if (Cin == 2) ASR_SC_FWD(2); else ASR_SC_FWD(3);
+#undef ASR_SC_FWD_M
 #undef ASR_SC_FWD
   ASR_CHECK_LAUNCH(h, "asr_conv3x3_smallc_fwd");
   return ASR_OK;
@@ -477,7 +645,13 @@ extern "C" int asr_conv3x3_smallc_bwd_weight(asr_handle* h, const void* x, const
 #define ASR_SC_WG(C_) \
   hipLaunchKernelGGL(conv3x3_smallc_wgrad_kernel<C_>, dim3(nblk), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, \
                      (const bf16_t*)dpre, npix, H, W, per, partial)
-  if (Cin == 1) ASR_SC_WG(1); else if (Cin == 2) ASR_SC_WG(2); else ASR_SC_WG(3);
+  static const bool mfma = [] { const char* e = getenv("ASR_SMALLC_MFMA"); return !(e && e[0] == '0'); }();
+#define ASR_SC_WG_M(C_) \
+  hipLaunchKernelGGL(conv3x3_smallc_wgrad_mfma_kernel<C_>, dim3(nblk), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, \
+                     (const bf16_t*)dpre, npix, H, W, per, partial)
+  if (mfma) { if (Cin == 1) ASR_SC_WG_M(1); else if (Cin == 2) ASR_SC_WG_M(2); else ASR_SC_WG_M(3); }
+  else if (Cin == 1) ASR_SC_WG(1); else if (Cin == 2) ASR_SC_WG(2); else ASR_SC_WG(3);
+#undef ASR_SC_WG_M
 #undef ASR_SC_WG
   hipLaunchKernelGGL(conv3x3_smallc_wgrad_reduce_kernel, dim3((9 * Cin * SC_CO + 255) / 256), dim3(256), 0,
                      (hipStream_t)s, partial, nblk, 9 * Cin, dw);
