@@ -1291,16 +1291,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tn_kernel(int Mpix, int H, 
 // pixel) are ONE ds_write_b128 into [subtile][k row][16 columns], and the MFMA fragments come out of it through the
 // transposing reads (ds_read_b64_tr_b16) -- the kernel above interleaves pixel pairs into a [column][k] image with 64
 // four-byte LDS writes per thread per k-tile (twice the instructions of its 32 MFMAs).  ASR_CONV_WGRAD_TR=0 keeps it (A/B).
+template <int BN>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(int Mpix, int H, int W, int Cin, int Cout,
                                                                const bf16_t* __restrict__ X,
                                                                const bf16_t* __restrict__ dY, int kchunk,
                                                                float* __restrict__ partial) {
-  constexpr int BM = 128, BN = 128, BK = 64;
+  constexpr int BM = 128, BK = 64;
+  constexpr int WN = BN / 64, WM = 4 / WN, TI = BM / WM / 16;   // BN = 64: four waves of 32 x 64, BN = 128: 2 x 2 of 64 x 64
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = 9 * Cin, N = Cout, K = Mpix, HW = H * W;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
   const int nkt = (kend - kbeg + BK - 1) / BK;
@@ -1308,7 +1310,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(int Mpix, int H, 
   // four (pixel, 8-column vector) items per operand per thread: vector mvec = tid & 15 of pixels (tid >> 4) + 16 q
   const int mvec = tid & 15, kr0 = tid >> 4;
   const int mcol = m0 + mvec * 8;                          // first of this thread's 8 virtual columns (tap, ci)
-  const bool a_ok = mcol + 8 <= M, b_ok = n0 + mvec * 8 + 8 <= N;
+  const bool a_ok = mcol + 8 <= M, b_ok = mvec * 8 < BN && n0 + mvec * 8 + 8 <= N;
   const int tap = a_ok ? mcol / Cin : 0, ci = a_ok ? mcol - tap * Cin : 0;
   const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
   const ptrdiff_t sh = ((ptrdiff_t)dy * W + dx) * Cin + ci;
@@ -1333,13 +1335,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(int Mpix, int H, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       *reinterpret_cast<bf16x8_t*>(st + wbase + q * 16 * 32) = ra[q];
-      *reinterpret_cast<bf16x8_t*>(st + TN_OPER + wbase + q * 16 * 32) = rb[q];
+      if (mvec * 8 < BN) *reinterpret_cast<bf16x8_t*>(st + TN_OPER + wbase + q * 16 * 32) = rb[q];
     }
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[TI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   if (nkt > 0) {
@@ -1349,24 +1351,23 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(int Mpix, int H, 
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   const unsigned piece = (unsigned)(8 * fq + (fr >> 2)) * 32u + (unsigned)(fr & 3) * 8u;
-  unsigned aoff[4], boff[4];
+  unsigned aoff[TI], boff[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    aoff[i] = (unsigned)(wm * 4 + i) * TN_SUB + piece;
-    boff[i] = (unsigned)TN_OPER + (unsigned)(wn * 4 + i) * TN_SUB + piece;
-  }
+  for (int i = 0; i < TI; ++i) aoff[i] = (unsigned)(wm * TI + i) * TN_SUB + piece;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) boff[i] = (unsigned)TN_OPER + (unsigned)(wn * 4 + i) * TN_SUB + piece;
   for (int kt = 0; kt < nkt; ++kt) {
     const char* cur = smem + (kt & 1) * TN_STAGE;
     if (kt + 1 < nkt) gload(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t a[4], b[4];
+      bf16x8_t a[TI], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = tn_frag(cur + aoff[i] + ks * 32 * 32);
+      for (int i = 0; i < TI; ++i) a[i] = tn_frag(cur + aoff[i] + ks * 32 * 32);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = tn_frag(cur + boff[j] + ks * 32 * 32);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
@@ -1376,8 +1377,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(int Mpix, int H, 
   }
   float* slab = partial + (size_t)blockIdx.z * M * N;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
+  for (int i = 0; i < TI; ++i) {
+    const int m = m0 + wm * (16 * TI) + i * 16 + fr;
     if (m >= M) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1736,7 +1737,11 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
   const long long mp = (long long)Nimg * H * W;
   if (mp >= (1ll << 31)) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_bwd_weight: %lld pixels", mp);
   const int Mpix = (int)mp, M = 9 * Cin, N = Cout;
-  const int tm = (M + 127) / 128, tn = (N + 127) / 128;
+  static const bool wgrad_tr = [] { const char* e = getenv("ASR_CONV_WGRAD_TR"); return !(e && e[0] == '0'); }();
+  // COUT = 64 (or a last 64-column tile): 128 x 64 tiles -- with 128 x 128 half of the MFMAs would multiply zero columns
+  static const bool bn64_on = [] { const char* e = getenv("ASR_CONV_WGRAD_BN64"); return !(e && e[0] == '0'); }();
+  const bool bn64 = wgrad_tr && bn64_on && N % 128 == 64;
+  const int tm = (M + 127) / 128, tn = bn64 ? (N + 63) / 64 : (N + 127) / 128;
   int S = (2048 + tm * tn - 1) / (tm * tn);
   const int maxS = (Mpix + 511) / 512;
   if (S > maxS) S = maxS;
@@ -1749,11 +1754,11 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
   S = (Mpix + kchunk - 1) / kchunk;
   float* partial = (float*)h->scratch;
   hipStream_t st = (hipStream_t)s;
-  static const bool wgrad_tr = [] { const char* e = getenv("ASR_CONV_WGRAD_TR"); return !(e && e[0] == '0'); }();
   if (wgrad_tr) {
     const size_t lds = (size_t)2 * TN_STAGE;
-    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(conv3x3_wgrad_tr_kernel, dim3(tn, tm, S), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
+    auto kern = bn64 ? conv3x3_wgrad_tr_kernel<64> : conv3x3_wgrad_tr_kernel<128>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(tn, tm, S), dim3(256), lds, st, Mpix, H, W, Cin, Cout,
                        (const bf16_t*)x, (const bf16_t*)dy, kchunk, partial);
   } else {
     const size_t lds = (size_t)2 * (128 + 128) * 72 * sizeof(bf16_t);
