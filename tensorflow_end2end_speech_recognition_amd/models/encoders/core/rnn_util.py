@@ -30,7 +30,7 @@ DW_LANES = 2
 # one main-stream marker per BPTT layer for all its side lanes, one wait for all weight images (A-B: ASR_FORK_ONCE=0
 # restores a marker per lane entry and a wait per layer)
 FORK_ONCE = _os.environ.get('ASR_FORK_ONCE', '1') != '0'
-BG_WGS = int(_os.environ.get('ASR_BG_WGS', '32'))   # workgroups of a weight-gradient GEMM that runs beside a BPTT kernel
+BG_WGS = int(_os.environ.get('ASR_BG_WGS', '128'))   # workgroups of a weight-gradient GEMM that runs beside a BPTT kernel
 
 
 def declare_lstm_vars(store, scope, din, H, ndir, use_peephole, parameter_init, rng, cell_scope=None):
