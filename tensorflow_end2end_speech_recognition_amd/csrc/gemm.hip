@@ -1738,8 +1738,10 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
   if (mp >= (1ll << 31)) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_bwd_weight: %lld pixels", mp);
   const int Mpix = (int)mp, M = 9 * Cin, N = Cout;
   static const bool wgrad_tr = [] { const char* e = getenv("ASR_CONV_WGRAD_TR"); return !(e && e[0] == '0'); }();
-  // COUT = 64 (or a last 64-column tile): 128 x 64 tiles -- with 128 x 128 half of the MFMAs would multiply zero columns
-  static const bool bn64_on = [] { const char* e = getenv("ASR_CONV_WGRAD_BN64"); return !(e && e[0] == '0'); }();
+  // COUT = 64 (or a last 64-column tile): 128 x 64 tiles, so that no MFMA multiplies zero columns -- measured 6.4 ms per
+  // call against 6.0 for the 128 x 128 tiles at cfg C's second layer (the kernel is bound by gathering every pixel nine
+  // times from L2, not by its MFMAs): OFF unless ASR_CONV_WGRAD_BN64=1
+  static const bool bn64_on = [] { const char* e = getenv("ASR_CONV_WGRAD_BN64"); return e && e[0] == '1'; }();
   const bool bn64 = wgrad_tr && bn64_on && N % 128 == 64;
   const int tm = (M + 127) / 128, tn = bn64 ? (N + 63) / 64 : (N + 127) / 128;
   int S = (2048 + tm * tn - 1) / (tm * tn);
