@@ -241,6 +241,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const T*
     }
 }
 
+// LDS images [rows][64 + 8 bf16] read as MFMA fragments with ds_read_b128 (16 lanes = 16 rows of one 16-byte k-slot): the
+// hardware serves a wave in lane groups that pair rows 0-3, 12-15 of k-slot q with rows 4-11 of k-slot q ^ 1
+// (lstm_cluster.hip, lds_swz), so with plain padding those two sets collide on the 16 sixteen-byte bank groups --
+// SQ_LDS_BANK_CONFLICT on 11-13 % of the CU cycles of these kernels (profiles/r03_pmc_util.md).  Swapping the two halves of
+// every 32 bytes OF A ROW for rows 4-11 (mod 16), by writers and readers alike, makes every group hit 16 distinct slots
+// (row stride 9 slots: 9 r + q mod 16 is a permutation of the 16 rows).
+__device__ __forceinline__ unsigned nt_swz(int row) { return (((row + 4) >> 3) & 1) ? 8u : 0u; }   // in bf16 elements
+
 struct GemmDrop {               // dropout multiplier of the OUTPUT formed in the epilogue (element m*N + n of a contiguous
   float keep;                   // [M,N] tensor -> word (m*N + n) % 4 of Philox block offset + (m*N + n) / 4): asr_dropout_mask's
   uint64_t seed, offset;        // values without the mask tensor
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
     const int v = tid + i * 256, r = v >> 3, kv = (v & 7) * 8;
     pa[i] = A + (size_t)min(m0 + r, M - 1) * lda + kv;
     pb[i] = Bt + (size_t)(n0 + r) * ldb + kv;
-    so[i] = (unsigned)(r * LD + kv);
+    so[i] = (unsigned)(r * LD) + ((unsigned)kv ^ nt_swz(r));
   }
   bf16x8_t ra[4], rb[4];
   auto gload = [&]() {
@@ -315,8 +323,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
   sstore(S);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  const unsigned aoff = (unsigned)((wm * 64 + fr) * LD + fq * 8);
-  const unsigned boff = (unsigned)(BM * LD + (wn * 64 + fr) * LD + fq * 8);
+  const unsigned aoff = (unsigned)((wm * 64 + fr) * LD) + ((unsigned)(fq * 8) ^ nt_swz(fr));
+  const unsigned boff = (unsigned)(BM * LD + (wn * 64 + fr) * LD) + ((unsigned)(fq * 8) ^ nt_swz(fr));
   for (int kt = 0; kt < nkt; ++kt) {
     const bf16_t* cur = S + (kt & 1) * STAGE;
     if (kt + 1 < nkt) gload();
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_nt_bf16_big_kernel(int M
   for (int i = 0; i < VA; ++i) oa[i] = (unsigned)(((size_t)min(m0 + r0 + RSTEP * i, M - 1) * lda + kv) * sizeof(bf16_t));
 #pragma unroll
   for (int i = 0; i < VB; ++i) ob[i] = (unsigned)(((size_t)(n0 + r0 + RSTEP * i) * ldb + kv) * sizeof(bf16_t));
-  const unsigned so0 = (unsigned)(r0 * LD + kv);
+  const unsigned so0 = (unsigned)(r0 * LD) + ((unsigned)kv ^ nt_swz(r0));   // (a thread's rows are RSTEP = 32 k apart: same class)
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(A), 0, (int)min((size_t)0xFFFFFFFFu, ((size_t)(M - 1) * lda + K) * sizeof(bf16_t)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
@@ -469,8 +477,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_nt_bf16_big_kernel(int M
   sstore(S);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  const unsigned aoff = (unsigned)((wm * TM + fr) * LD + fq * 8);
-  const unsigned boff = (unsigned)(BM * LD + (wn * TN + fr) * LD + fq * 8);
+  const unsigned aoff = (unsigned)((wm * TM + fr) * LD) + ((unsigned)(fq * 8) ^ nt_swz(fr));
+  const unsigned boff = (unsigned)(BM * LD + (wn * TN + fr) * LD) + ((unsigned)(fq * 8) ^ nt_swz(fr));
   for (int kt = 0; kt < nkt; ++kt) {
     const bf16_t* cur = S + (kt & 1) * STAGE;
     if (kt + 1 < nkt) gload();
