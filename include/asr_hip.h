@@ -310,6 +310,14 @@ int asr_debug_set_lstm_flags(int flags);
  * products per step on exact-fp32 MFMA) where the LDS images fit; 0: the launch-per-step kernels. */
 int asr_debug_set_gru_persistent(int on);
 
+/* Debug / measurement: are 16-byte per-lane stores seen whole by 16-byte loads of another CU?  Workgroup 0 stores
+ * {i, i, i, i}, i = 1 .. iters, into buf[16 lane .. ] (64 lanes; plain stores, or write-through when write_through != 0);
+ * workgroup `peer` (8: the same XCD as workgroup 0, 1: another one) polls them with L1-bypassing loads.
+ * out[3 lane .. +2] = {loads, loads whose four dwords differed, distinct values seen}.  Evidence for DESIGN section 8
+ * item 1-i (the product path exchanges 8-byte granules and per-word tags only). */
+int asr_debug_tear_probe(asr_handle* h, unsigned* buf, unsigned iters, int peer, int write_through,
+                         unsigned long long* out, asr_stream s);
+
 /* Debug: records, per workgroup of a probe grid launched on `s`, {XCC id, HW_ID register} into out[2*nblocks]
  * (device memory); every workgroup stays resident for spin_cycles so that the grid spreads over the CUs. */
 int asr_debug_placement(asr_handle* h, unsigned* out, int nblocks, int spin_cycles, asr_stream s);

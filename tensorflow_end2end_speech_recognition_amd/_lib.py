@@ -72,6 +72,7 @@ SIGNATURES = {
     'asr_debug_set_lstm_flags': (_i, [_i]),
     'asr_debug_set_gru_persistent': (_i, [_i]),
     'asr_debug_placement': (_i, [_vp, _vp, _i, _i, _vp]),
+    'asr_debug_tear_probe': (_i, [_vp, _vp, C.c_uint, _i, _i, _vp, _vp]),
     'asr_ctc_workspace_bytes': (_sz, [_i, _i, _i]),
     'asr_ctc_loss': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'asr_ctc_greedy_decode': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),

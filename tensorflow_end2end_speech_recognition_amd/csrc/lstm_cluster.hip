@@ -1981,6 +1981,55 @@ bool asr_cluster_bwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const
 }
 #undef ASR_F32_ARGS_B
 
+// ---------------------------------------------------------------- debug: 16-byte exchange words, tear probe
+// Would a lane's 16-byte store be seen whole by a 16-byte load of another CU?  The clusters' exchange uses 8-byte granules
+// (one 64-bit store / load per lane: single-copy atomic by construction) or per-word tags; a 16-byte self-tagged word would
+// halve the poll instructions but is only correct if the four dwords of one
+// global_store_dwordx4 never appear torn.  Workgroup 0 writes {i, i, i, i} for i = 1 .. iters into one word per lane
+// (plain stores when `wt` is 0, as a co-located cluster does, write-through sc1 stores otherwise); workgroup `peer`
+// (8: same XCD as workgroup 0, 1: another XCD) polls the same words with L1-bypassing 16-byte loads and counts the loads
+// whose four dwords differ.  out[3 lane .. + 2] = {loads, torn loads, distinct values seen}.
+namespace {
+__global__ __launch_bounds__(64) void tear_probe_kernel(unsigned* __restrict__ buf, unsigned iters, int peer, int wt,
+                                                        unsigned long long* __restrict__ out) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  const int lane = threadIdx.x;
+  u32x4_t* word = reinterpret_cast<u32x4_t*>(buf) + lane;
+  if (blockIdx.x == 0) {
+    for (unsigned i = 1; i <= iters; ++i) {
+      const u32x4_t v = {i, i, i, i};
+      if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(word), "v"(v) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(word), "v"(v) : "memory");
+      if ((i & 63u) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bounded queue, stores in order
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  if ((int)blockIdx.x != peer) return;
+  unsigned long long loads = 0, torn = 0, seen = 0;
+  unsigned last = 0;
+  for (unsigned long long spin = 0; spin < (1ull << 24); ++spin) {          // bounded: ~15 s even if nothing ever arrives
+    u32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(word) : "memory");
+    ++loads;
+    if (!(v[0] == v[1] && v[1] == v[2] && v[2] == v[3])) ++torn;
+    if (v[0] != last) { ++seen; last = v[0]; }
+    if (__all(v[0] >= iters && v[1] >= iters && v[2] >= iters && v[3] >= iters)) break;
+  }
+  out[3 * lane + 0] = loads;
+  out[3 * lane + 1] = torn;
+  out[3 * lane + 2] = seen;
+}
+}  // namespace
+extern "C" int asr_debug_tear_probe(asr_handle* h, unsigned* buf, unsigned iters, int peer, int write_through,
+                                    unsigned long long* out, asr_stream s) {
+  if (!h || !buf || !out || iters < 1 || (peer != 1 && peer != 8) || ((uintptr_t)buf) % 16 != 0) return ASR_ERR_INVALID_ARG;
+  if (hipMemsetAsync(buf, 0, 64 * 16, (hipStream_t)s) != hipSuccess) return ASR_ERR_HIP;
+  hipLaunchKernelGGL(tear_probe_kernel, dim3(9), dim3(64), 0, (hipStream_t)s, buf, iters, peer, write_through, out);
+  ASR_CHECK_LAUNCH(h, "asr_debug_tear_probe");
+  return ASR_OK;
+}
+
 extern "C" int asr_debug_set_lstm_flags(int flags) { g_dflags = flags; return 0; }
 
 // Asynchronous read of the sticky error word: one 4-byte device->host copy on `st`, no synchronisation.
