@@ -403,6 +403,11 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       }
     }
     {
+      // The first poll round goes out BEHIND the own-slice MFMAs above, not in front of them (left alone the scheduler
+      // hoists the poll loads to right behind the barrier): ~150 cycles later, and the round comes back full more often --
+      // forward launch 840 -> 805 us at H = 256, 1400 -> 1358 at H = 512, 975 -> 967 at H = 320.  (Later still is worse again: + 128 cycles 818 us,
+      // + 256 860, + 384 882; the fp32 kernel, whose own-slice MFMAs take three times as long, gains nothing from it.)
+      __builtin_amdgcn_sched_barrier(0);
       u64 v[G - 1];
 #pragma unroll
       for (int k = 0; k < G - 1; ++k) v[k] = gload(uoff(slice(P, k + (k >= g ? 1 : 0)), lofs));
