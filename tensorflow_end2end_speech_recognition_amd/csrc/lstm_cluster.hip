@@ -404,7 +404,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     }
     {
       // The first poll round goes out BEHIND the own-slice MFMAs above, not in front of them (left alone the scheduler
-      // hoists the poll loads to right behind the barrier): ~150 cycles later, and the round comes back full more often --
+      // hoists the poll loads to right behind the barrier, in front of the LDS read and the MFMAs): ~150 cycles later --
       // forward launch 840 -> 805 us at H = 256, 1400 -> 1358 at H = 512, 975 -> 967 at H = 320.  (Later still is worse again: + 128 cycles 818 us,
       // + 256 860, + 384 882; the fp32 kernel, whose own-slice MFMAs take three times as long, gains nothing from it.)
       __builtin_amdgcn_sched_barrier(0);
