@@ -494,7 +494,13 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 // xch per cluster: header + [2 parity][G dst][G src][4 tiles][64 lanes][4 words].
 // HSU = hidden units per CU: 64 (eight waves: 4 unit tiles x 2 row halves) or 32 (four waves, ONE per SIMD: 2 unit tiles x
 // 2 row halves, twice the CUs per cluster, the whole 512-entry register file per wave).
-template <int H, bool DBG, int HSU = 64>
+// PIN: bit k set = a scheduling barrier at phase boundary k of the step (0: top, 1: behind the fetch, 2: in front of the
+// step's barrier, 3: end) -- the places where the timer build has its s_memtime reads.  -1: the default for the width.
+// Measured, BPTT launch at H = 256 (four waves): no pins 888 us; {1,2} 888; {0,3} 859; {0,1,2} 859; {1,2,3} 859; {0,1,3} 855; all
+// four 855 -- what matters is that nothing moves across the STEP boundary (the scheduler otherwise interleaves the next
+// iteration's polls and address arithmetic with this iteration's MFMAs and exchange stores).  H = 512: none 1537, {0} 1538,
+// {1} 1530, {2} 1529, {1,2} 1528, {3} 1605, {0,3} 1570, all four 1567 -- there the pins stay off.
+template <int H, bool DBG, int HSU = 64, int PIN = -1>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
     const float* __restrict__ cs, const bf16_t* __restrict__ whpb, const float* __restrict__ peep,
@@ -502,6 +508,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     const float* __restrict__ d_h_final, cbf16x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
     u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
   zero_next_area(znext, zwords);
+  constexpr int PINM = PIN >= 0 ? PIN : ((HSU == 32 && H <= 320) ? 15 : 0);
   constexpr int G = H / HSU;
   constexpr int TPC = HSU / 16;              // 16-unit output tiles per CU (4 / 2)
   constexpr int NWAVES = 2 * TPC;            // waves per workgroup
@@ -638,10 +645,12 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
   unsigned long long ph[4] = {0, 0, 0, 0};
   unsigned nspin = 0;
 #define C8_T() (DBG ? (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime()) : 0ull)
+#define C8_PIN(k) do { if constexpr (!DBG && ((PINM >> (k)) & 1)) __builtin_amdgcn_sched_barrier(0); } while (0)
 
   auto step = [&](int s, auto PAR) {
     constexpr int P = decltype(PAR)::value;                // parity of THIS iteration's publish
     const int it = tmax - 1 - s;                           // 0, 1, ...
+    C8_PIN(0);
     const unsigned long long t0 = C8_T();
     // ---- 1. polls for the partials the peers published at the previous iteration (parity 1-P)
     u64 pv[G - 1];
@@ -741,6 +750,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     } else {
       if (s > 0 && !early_fetch) prefetch(s - 1);
     }
+    C8_PIN(1);
     const unsigned long long t1 = C8_T();
     // ---- 4. gate gradients of the own pairs
     const float pdhv[2] = {pdh0, pdh1}, pcpv[2] = {pcp0, pcp1}, curv[2] = {cur0, cur1};
@@ -760,6 +770,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
       *reinterpret_cast<cbf16x4_t*>(smem + P * DGB + lwr[r]) = pk;
       dgates[off[r]] = pk;
     }
+    C8_PIN(2);
     const unsigned long long t2 = C8_T();
     __syncthreads();
     // peephole / bias gradient sums: off the critical path, behind the barrier
@@ -845,6 +856,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
         dhr[1] += o[1];
       }
     }
+    C8_PIN(3);
     const unsigned long long t3 = C8_T();
     if (DBG) { ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; }
   };
@@ -857,6 +869,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
   }
   if (s == 0) step(0, std::integral_constant<int, 0>{});
 #undef C8_T
+#undef C8_PIN
 
   if (DBG && dbg && lane == 0 && cid.tile == 0 && g < 4) {
     unsigned long long* o = dbg + 768 + ((size_t)(d * 4 + g) * 8 + wave) * 8;   // [768, 1280)
