@@ -508,7 +508,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     const float* __restrict__ d_h_final, cbf16x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
     u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
   zero_next_area(znext, zwords);
-  constexpr int PINM = PIN >= 0 ? PIN : ((HSU == 32 && H <= 320) ? 15 : 0);
+  constexpr int PINM = PIN >= 0 ? PIN : ((HSU == 32 && H <= 320) ? 15 : 0);   // (H = 320 on eight waves: 1089 -> 1216 us with pins)
   constexpr int G = H / HSU;
   constexpr int TPC = HSU / 16;              // 16-unit output tiles per CU (4 / 2)
   constexpr int NWAVES = 2 * TPC;            // waves per workgroup
@@ -1549,6 +1549,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32_kernel(
   __syncthreads();
 
   auto step = [&](int s, auto PAR) {
+    // step boundary pinned (see the bf16 BPTT kernel): neutral at H = 128 / 256, 7.6 -> 4.4 ms per launch at H = 512, B = 32
+    __builtin_amdgcn_sched_barrier(0);
     constexpr int P = decltype(PAR)::value;                // parity of THIS iteration's publish
     const int it = tmax - 1 - s;
     // ---- 1. polls for the partials the peers published at the previous iteration (parity 1-P)
