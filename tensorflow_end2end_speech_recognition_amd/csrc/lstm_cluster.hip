@@ -158,7 +158,7 @@ __device__ __forceinline__ float dpp_ror8_into(float old, float src) {
 // registers is rotated by the CU index so that the own chunks are always register chunks 0 .. KO-1.
 // HSU = hidden units per CU (64: eight waves per CU, two per SIMD; 32: four waves per CU, ONE per SIMD -- twice the CUs
 // per cluster, each wave alone on its SIMD's VALU / MFMA pipes and with half the LDS fragment traffic per CU).
-template <int H, bool DBG, bool EARLY = false, int HSU = 64>
+template <int H, bool DBG, bool EARLY = false, int HSU = 64, int FPIN = 0>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const bf16_t* __restrict__ whp,
     const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
@@ -275,9 +275,11 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
   unsigned long long ph4 = 0;
   unsigned nspin = 0;
 #define C8_T() (DBG ? (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime()) : 0ull)
+#define C8_FPIN(k) do { if constexpr (!DBG && ((FPIN >> (k)) & 1)) __builtin_amdgcn_sched_barrier(0); } while (0)
 
   auto step = [&](int s, auto PAR) {
     constexpr int P = decltype(PAR)::value;                // parity of step s
+    C8_FPIN(0);
     const unsigned long long t0 = C8_T();
     const char* hcur = smem + P * 16 * LDH * 2;
     char* hnxt = smem + (1 - P) * 16 * LDH * 2;
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       }
     }
     if (DBG) { asm volatile("" : "+v"(acc0)); asm volatile("" : "+v"(acc1)); }
+    C8_FPIN(1);
     const unsigned long long t1 = C8_T();
     // lanes n / n^8 swap halves: lo lanes (banks 0,1) keep rows 0,1 (own i,f + the partner's ci,o),
     // hi lanes (banks 2,3) rows 2,3 (own ci,o + the partner's i,f)
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       oa[r] += dstep;
       os[r] += stride;
     }
+    C8_FPIN(2);
     const unsigned long long t2 = C8_T();
     if constexpr (EARLY) {
       if (s + 1 < tmax) {                                  // block-uniform
@@ -438,6 +442,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
         cs[offs[r]] = cn[r];
       }
     }
+    C8_FPIN(3);
     const unsigned long long t3 = C8_T();
     __syncthreads();
     if (DBG) {
@@ -452,6 +457,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
   }
   if (s < tmax) step(s, std::integral_constant<int, 0>{});
 #undef C8_T
+#undef C8_FPIN
 
   if (DBG && dbg && lane == 0 && cid.tile == 0 && g < 4) {
     unsigned long long* o = dbg + 256 + ((size_t)(d * 4 + g) * 8 + wave) * 8;   // [256, 768): 8-wave kernels
@@ -1826,6 +1832,12 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   const bool early = (H == 256 || H == 320 || HSU == 32) != ((dbg_flags() & 32) != 0);   // H = 320: 1069 -> 969 us per launch
   auto k = g_cdbg_host ? lstm_fwd_cluster8_kernel<H, true, false, HSU>
                        : (early ? lstm_fwd_cluster8_kernel<H, false, true, HSU> : lstm_fwd_cluster8_kernel<H, false, false, HSU>);
+  // scheduling barrier between the MFMA phase and the gate math (FPIN bit 1) at H = 256 on four waves; masks measured
+  // there (us per launch): none 806, {0} 808, {1} 777, {2} 855, {3} 808, {0,1} 779, {1,2} 799, all 808; at H = 512 every mask
+  // is slower than none (1350: 1355 .. 1399), and so is this one at H = 320 on eight waves (968 -> 984)
+  if constexpr (HSU == 32 && H == 256) {
+    if (early && !g_cdbg_host) k = lstm_fwd_cluster8_kernel<H, false, true, HSU, 2>;
+  }
   // (padding the LDS request past half a CU so that two 4-wave members can never share one was measured: no
   // difference, 866.7 vs 867.6 us -- the dispatcher spreads the members over the CUs by itself)
   const size_t lds = (size_t)2 * 16 * (H + 8) * 2;
