@@ -1,13 +1,10 @@
 #!/bin/bash
 set -u
-OUT=${1:-gpurun_out/r03_fpin2}
+OUT=${1:-gpurun_out/r03_fpin3}
 mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -m gpu -k "cluster or lstm" > $OUT/tests.log 2>&1
-tail -2 $OUT/tests.log
 Q="--no-aux --no-cfgA --no-parity --no-cpu-baseline"
-timeout 120 python bench.py --steps 20 --warmup 5 $Q > $OUT/b256.json 2>> $OUT/err.log
-for F in 0 2048; do
-  ASR_LSTM_DFLAGS=$F timeout 120 python bench.py --steps 8 --warmup 3 --units 320 $Q > $OUT/b320_f$F.json 2>> $OUT/err.log
+for F in 0 2048 4096 6144 8192 10240 12288 14336; do
+  ASR_LSTM_DFLAGS=$F timeout 120 python bench.py --steps 12 --warmup 4 $Q > $OUT/b256_f$F.json 2>> $OUT/err.log
 done
 python - <<PY
 import json, glob

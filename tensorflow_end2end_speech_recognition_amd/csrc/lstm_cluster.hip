@@ -334,6 +334,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       pf[r] = dpp_ror8_into<0xC>(acc1[r], acc1[2 + r]);
       po[r] = dpp_ror8_into<0x3>(acc1[2 + r], acc1[r]);
     }
+    C8_FPIN(4);                                            // behind the DPP half swap
     const unsigned epoch = (unsigned)s + 1u;
     bool act[2];
     float ig[2], gg[2], fg[2], og[2], cn[2], hn[2];
@@ -360,10 +361,12 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       c[r] = act[r] ? cn[r] : c[r];
       hr[r] = act[r] ? hn[r] : hr[r];
     }
+    C8_FPIN(5);                                            // behind the gate math
     // publish: even lanes the (unit, unit+1) granule of row 0, odd lanes (unit-1, unit) of row 1
     const float nb = dpp_xor1(odd ? hr[0] : hr[1]);
     const unsigned pk = odd ? pack_bf16x2(nb, hr[1]) : pack_bf16x2(hr[0], nb);
     gpublish(uoff(slice(P, g), pofs), epoch, pk, fast);
+    C8_FPIN(6);                                            // behind the publish
     *reinterpret_cast<unsigned*>(hnxt + lown) = pk;
     // saved activations; rows past their length write frame s of the padding (hout: zeros,
     // gates / cs: never read there), so nothing is predicated
@@ -427,8 +430,10 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
         for (int k = 0; k < G - 1; ++k) v[k] = gload(uoff(slice(P, k + (k >= g ? 1 : 0)), lofs));
       }
       if (DBG) nspin += spins;
+      C8_FPIN(7);                                          // behind the poll loop
 #pragma unroll
       for (int k = 0; k < G - 1; ++k) *reinterpret_cast<unsigned*>(hnxt + ldst[k]) = (unsigned)v[k];
+      C8_FPIN(8);                                          // behind the LDS staging
     }
     // saved activations: stored behind the poll loop -- on gfx950 loads and stores share one in-order counter, so a poll
     // issued after these stores waits for their acknowledgements too (0.921 -> 0.908 ms per launch)
@@ -505,7 +510,9 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 // Measured, BPTT launch at H = 256 (four waves): no pins 888 us; {1,2} 888; {0,3} 859; {0,1,2} 859; {1,2,3} 859; {0,1,3} 855; all
 // four 855 -- what matters is that nothing moves across the STEP boundary (the scheduler otherwise interleaves the next
 // iteration's polls and address arithmetic with this iteration's MFMAs and exchange stores).  H = 512: none 1537, {0} 1538,
-// {1} 1530, {2} 1529, {1,2} 1528, {3} 1605, {0,3} 1570, all four 1567 -- there the pins stay off.
+// {1} 1530, {2} 1529, {1,2} 1528, {3} 1605, {0,3} 1570, all four 1567 -- there the pins stay off.  Further points on top of the
+// four at H = 256 (bits 4..8: behind the poll issue / the dh-independent math / the poll loop / the barrier / the gradient
+// sums): 858 / 858 / 849 / 856 / 857 against 855 -- bit 6 is kept.
 template <int H, bool DBG, int HSU = 64, int PIN = -1>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     const float* __restrict__ d_h_final, cbf16x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
     u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
   zero_next_area(znext, zwords);
-  constexpr int PINM = PIN >= 0 ? PIN : ((HSU == 32 && H <= 320) ? 15 : 0);   // (H = 320 on eight waves: 1089 -> 1216 us with pins)
+  constexpr int PINM = PIN >= 0 ? PIN : ((HSU == 32 && H <= 320) ? (15 | 64) : 0);   // (H = 320 on eight waves: 1089 -> 1216 us with pins)
   constexpr int G = H / HSU;
   constexpr int TPC = HSU / 16;              // 16-unit output tiles per CU (4 / 2)
   constexpr int NWAVES = 2 * TPC;            // waves per workgroup
@@ -665,6 +672,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
       for (int k = 0; k < G - 1; ++k)
         pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
     }
+    C8_PIN(4);                                             // behind the poll issue
     // ---- 2. everything that does not need dh
     bool act[2], ldp[2];
     float gi[2], gq[2], gf[2], go[2], cprev[2], a_o[2], b_c[2], c_g[2], c_i[2], c_f[2];
@@ -706,6 +714,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     // (ASR_LSTM_DFLAGS bit 7) puts it back for A-B runs.  It now goes out BEHIND the loop, see there.
     const bool early_fetch = (kflags & 4) != 0;
     if (s > 0 && early_fetch) prefetch(s - 1);
+    C8_PIN(5);                                             // behind the dh-independent math
     // ---- 3. finish the polls: every word must carry the previous iteration's tag
     if (it > 0) {
       const unsigned want = (((unsigned)(it - 1) >> 1) + 1u) & 1u;
@@ -738,6 +747,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     // launch against 0.94 ms behind it (11.93 -> 10.52 ms per headline step); the fetch still has the rest of the
     // step to arrive.  (Written as the second arm of a run-time switch on purpose: as an unconditional statement the
     // compiler schedules these independent loads differently and the launch takes 1.06 ms.)
+    C8_PIN(6);                                             // behind the poll loop, in front of the fetch
     if constexpr (HSU == 32) {
       // unconditional (the last iteration re-fetches its own rows: harmless) and pinned behind the loop by a compiler
       // barrier: behind a branch the wait-count pass waits with vmcnt(0) -- for THIS fetch -- at the join
@@ -779,12 +789,14 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     C8_PIN(2);
     const unsigned long long t2 = C8_T();
     __syncthreads();
+    C8_PIN(7);                                             // behind the step's barrier
     // peephole / bias gradient sums: off the critical path, behind the barrier
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       sums[0] += zi[r] * cprev[r]; sums[1] += zf[r] * cprev[r]; sums[2] += zo[r] * curv[r];
       sums[3] += zi[r]; sums[4] += zg[r]; sums[5] += zf[r]; sums[6] += zo[r];
     }
+    C8_PIN(8);                                             // behind the gradient sums
     // ---- 5. partial dh_prev from the own dG slice; own tile stays, foreign tiles are published
     if (s > 0) {
       bf16x8_t afr[KC];
@@ -1834,9 +1846,11 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
                        : (early ? lstm_fwd_cluster8_kernel<H, false, true, HSU> : lstm_fwd_cluster8_kernel<H, false, false, HSU>);
   // scheduling barrier between the MFMA phase and the gate math (FPIN bit 1) at H = 256 on four waves; masks measured
   // there (us per launch): none 806, {0} 808, {1} 777, {2} 855, {3} 808, {0,1} 779, {1,2} 799, all 808; at H = 512 every mask
-  // is slower than none (1350: 1355 .. 1399), and so is this one at H = 320 on eight waves (968 -> 984)
+  // is slower than none (1350: 1355 .. 1399), and so is this one at H = 320 on eight waves (968 -> 984).  On top of {1}:
+  // a second barrier behind the gate math (bit 5) 781 -> 776; behind the DPP half swap (bit 4) 850, behind the publish
+  // (bit 6) 799, behind the poll loop (bit 7) 797, behind the LDS staging (bit 8) 797
   if constexpr (HSU == 32 && H == 256) {
-    if (early && !g_cdbg_host) k = lstm_fwd_cluster8_kernel<H, false, true, HSU, 2>;
+    if (early && !g_cdbg_host) k = lstm_fwd_cluster8_kernel<H, false, true, HSU, 2 | 32>;
   }
   // (padding the LDS request past half a CU so that two 4-wave members can never share one was measured: no
   // difference, 866.7 vs 867.6 us -- the dispatcher spreads the members over the CUs by itself)
