@@ -1,10 +1,10 @@
 #!/bin/bash
 set -u
-OUT=${1:-gpurun_out/r03_fpin3}
+OUT=${1:-gpurun_out/r03_pin512}
 mkdir -p $OUT
 Q="--no-aux --no-cfgA --no-parity --no-cpu-baseline"
-for F in 0 2048 4096 6144 8192 10240 12288 14336; do
-  ASR_LSTM_DFLAGS=$F timeout 120 python bench.py --steps 12 --warmup 4 $Q > $OUT/b256_f$F.json 2>> $OUT/err.log
+for F in 0 10240 20480 30720; do
+  ASR_LSTM_DFLAGS=$F timeout 120 python bench.py --steps 8 --warmup 3 --units 512 --batch 32 $Q > $OUT/b512_f$F.json 2>> $OUT/err.log
 done
 python - <<PY
 import json, glob

@@ -512,7 +512,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 // iteration's polls and address arithmetic with this iteration's MFMAs and exchange stores).  H = 512: none 1537, {0} 1538,
 // {1} 1530, {2} 1529, {1,2} 1528, {3} 1605, {0,3} 1570, all four 1567 -- there the pins stay off.  Further points on top of the
 // four at H = 256 (bits 4..8: behind the poll issue / the dh-independent math / the poll loop / the barrier / the gradient
-// sums): 858 / 858 / 849 / 856 / 857 against 855 -- bit 6 is kept.
+// sums): 858 / 858 / 849 / 856 / 857 against 855 -- bit 6 is kept.  (H = 512 with bit 6 / {1,2,6} / bit 5: 1541 / 1535 / 1536
+// against 1530.)
 template <int H, bool DBG, int HSU = 64, int PIN = -1>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
@@ -1848,7 +1849,8 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   // there (us per launch): none 806, {0} 808, {1} 777, {2} 855, {3} 808, {0,1} 779, {1,2} 799, all 808; at H = 512 every mask
   // is slower than none (1350: 1355 .. 1399), and so is this one at H = 320 on eight waves (968 -> 984).  On top of {1}:
   // a second barrier behind the gate math (bit 5) 781 -> 776; behind the DPP half swap (bit 4) 850, behind the publish
-  // (bit 6) 799, behind the poll loop (bit 7) 797, behind the LDS staging (bit 8) 797
+  // (bit 6) 799, behind the poll loop (bit 7) 797, behind the LDS staging (bit 8) 797.  H = 512 with bit 5 / 6 / 7 alone:
+  // 1365 / 1369 / 1391 against 1356
   if constexpr (HSU == 32 && H == 256) {
     if (early && !g_cdbg_host) k = lstm_fwd_cluster8_kernel<H, false, true, HSU, 2 | 32>;
   }
