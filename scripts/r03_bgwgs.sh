@@ -1,11 +1,10 @@
 #!/bin/bash
 set -u
-OUT=${1:-gpurun_out/r03_bgwgs}
+OUT=${1:-gpurun_out/r03_bgwgs3}
 mkdir -p $OUT
 Q="--no-aux --no-cfgA --no-parity --no-cpu-baseline"
-for V in 128 256 512 1024; do
+for V in 64 96 128 192 256; do
   ASR_BG_WGS=$V timeout 120 python bench.py --steps 20 --warmup 5 $Q > $OUT/b256_w$V.json 2>> $OUT/err.log
-  ASR_BG_WGS=$V timeout 120 python bench.py --steps 8 --warmup 3 --units 512 --batch 32 $Q > $OUT/b512_w$V.json 2>> $OUT/err.log
 done
 python - <<PY
 import json, glob
