@@ -513,7 +513,9 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 // {1} 1530, {2} 1529, {1,2} 1528, {3} 1605, {0,3} 1570, all four 1567 -- there the pins stay off.  Further points on top of the
 // four at H = 256 (bits 4..8: behind the poll issue / the dh-independent math / the poll loop / the barrier / the gradient
 // sums): 858 / 858 / 849 / 856 / 857 against 855 -- bit 6 is kept.  (H = 512 with bit 6 / {1,2,6} / bit 5: 1541 / 1535 / 1536
-// against 1530.)
+// against 1530; finer points -- between the foreign-tile chains and their stores / between those stores and the own-tile
+// chain / in front of the A-fragment reads: 1575 / 1525 / 1523 against 1519; forward, between the two A-fragment batches:
+// 1364 against 1353.)
 template <int H, bool DBG, int HSU = 64, int PIN = -1>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
