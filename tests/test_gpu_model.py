@@ -671,19 +671,51 @@ def test_bench_line_of_a_two_rank_run(cuda, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert len(lines[0]) < 6000                                   # the driver keeps 8 000 bytes of stdout
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    full = json.load(open(os.path.join(root, d['full'])))         # prose, bucket tables: the file, not the line
+    assert full['n_gpus'] == 2 and abs(full['value'] - d['value']) < 1e-4 * d['value']
     assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 32
     assert d['scaling'] == 'weak' and d['steps'] == 4 and d['warmup'] == 2 and d['unit'] == 'frames/s'
     pr = d['per_rank']
     assert len(pr['frames']) == 2 and abs(sum(pr['frames']) - d['config']['frames_per_step']) < 0.5
     assert pr['frames'][0] != pr['frames'][1]                     # every rank has its own shard of the global batch
-    assert abs(d['value'] - d['config']['frames_per_step'] * 4 / (d['ms_per_step'] * 4e-3)) < 1e-6 * d['value']
+    assert abs(d['value'] - d['config']['frames_per_step'] * 4 / (d['ms_per_step'] * 4e-3)) < 1e-3 * d['value']
     assert 'global Tmax' in d['config']['padded_to']
-    comm = d['comm']
+    assert d['comm']['allreduce_ms_per_step'] > 0
+    comm = full['comm']
     assert comm['allreduce_calls_per_step'] == len(comm['buckets']) and comm['allreduce_ms_per_step'] > 0
     assert abs(sum(b['mbytes'] for b in comm['buckets']) * 1e6 - comm['bytes_per_step']) < 1.0
     assert np.isfinite(d['final_loss']) and d['cluster_handoff_flags'] == 0
-    assert d['cfgA'] is None and 'cfgC' not in d                  # auxiliary configurations are N = 1 entries
+    assert 'cfgA' not in d and 'cfgC' not in d                    # auxiliary configurations are N = 1 entries
+
+
+def test_bench_last_stdout_line_is_the_compact_record(cuda):
+    """`python bench.py --steps 2 --warmup 1` as the driver runs it at N = 1: the LAST stdout line parses, fits the
+    driver's 8 000-byte window with margin and carries the contract keys + roofline + cpu_baseline; the full object it
+    points to exists (a 20.7 KB line lost its head in the driver's record)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--aux', 'decode,D39',
+                        '--aux-steps', '1', '--aux-warmup', '1', '--cpu-tmax', '64', '--cpu-threads', '8'],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 6000, len(last)
+    d = json.loads(last)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['steps'] == 2 and d['warmup'] == 1 and d['n_gpus'] == 1 and d['dtype'] == 'bf16'
+    rf, cb = d['roofline'], d['cpu_baseline']
+    assert rf['bound'] in ('hbm', 'mfma') and rf['peak'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 * rf['frac']
+    assert cb['value'] > 0 and cb['cores'] >= 1 and cb['kind'] in ('port', 'reference') and cb['sample']
+    assert d['cfgA']['value'] > 0 and d['decode'] and d['input_width_D39']['value'] > 0
+    full = json.load(open(os.path.join(root, d['full'])))
+    assert abs(full['value'] - d['value']) < 1e-4 * d['value'] and 'note' in full['roofline']
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])

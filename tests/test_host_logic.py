@@ -842,3 +842,66 @@ def test_lstmcell_projection_host_logic(monkeypatch, ndir):
     # without lstm_impl='LSTMCell' num_proj is dropped, as in the reference (blstm.py:49-52)
     m = CTC(encoder_type='blstm', input_size=6, num_units=8, num_layers=1, num_classes=5, num_proj=4, device='cpu')
     assert m.encoder.num_proj is None and m.encoder.output_dim == 16
+
+
+def _load_bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(root, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, root
+
+
+def test_bench_compact_line_fits_the_drivers_window():
+    """bench.py's last stdout line is built by compact_line(): from a canned FULL result (round 3's 20.7 KB object, which
+    the driver's 8 000-byte stdout window cut the head off) it must stay under 6 000 bytes, keep every contract key and
+    the roofline / cpu_baseline objects, and hold no prose notes; an 8-rank line (per_rank + comm) obeys the same limit,
+    and an over-long object sheds auxiliary entries rather than overflow."""
+    import json
+    bench, root = _load_bench_module()
+    full = json.load(open(os.path.join(root, 'profiles', 'r03_bench_steps20_warmup5.json')))
+    assert len(json.dumps(full)) > 15000
+    line = bench.compact_line(dict(full, full='bench_full.json'))
+    assert len(line) < 6000 and '\n' not in line
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'step_ms', 'parity', 'kernels', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert abs(d['value'] - full['value']) < 1e-4 * full['value'] and d['config']['workload'] == full['config']['workload']
+    rf = d['roofline']
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(rf) and 'note' not in rf
+    assert rf['traffic_file'] == 'profiles/r03_pmc_hbm.md' and abs(rf['frac'] - full['roofline']['frac']) < 1e-6
+    cb = d['cpu_baseline']
+    assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(cb) and len(cb['sample']) <= 160
+    for k in ('cfgA', 'cfgC', 'cfgD', 'cfgE'):
+        e = d[k]
+        assert abs(e['value'] - full[k]['value']) < 1e-4 * e['value'] and e['roofline']['frac'] > 0
+        assert e['cpu_baseline']['value'] > 0 and e['cpu_baseline']['cores'] >= 1 and 'workload' not in e
+    assert d['decode']['kanji3387_beam100']['beam']['ms_per_call'] > 0 and d['full'] == 'bench_full.json'
+
+    def strings(o):
+        if isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, list):
+            for v in o:
+                yield from strings(v)
+        elif isinstance(o, str):
+            yield o
+    assert max(len(s) for s in strings(d)) <= 160
+    # N = 8: per-rank tables and the communication summary ride on the same line
+    multi = dict(full, n_gpus=8, per_rank=dict(step_median_ms=[9.31] * 8, frames=[6400.0 + i for i in range(8)],
+                                               elapsed_s=[0.1871234] * 8, comm_stream_allreduce_ms_per_step=[0.71] * 8),
+                 comm=dict(allreduce_calls_per_step=3.0, allreduce_ms_per_step=0.7, bytes_per_step=2.2e7, bucket_min_mb=4.0,
+                           buckets=[dict(layers=[4, 3], mbytes=8.0)] * 3, note='x' * 300))
+    l8 = bench.compact_line(multi)
+    d8 = json.loads(l8)
+    assert len(l8) < 6000 and len(d8['per_rank']['frames']) == 8 and 'buckets' not in d8['comm']
+    # pathological growth (many more kernels per auxiliary entry): entries are shed, the headline never is
+    fat = json.loads(json.dumps(full))
+    for k in ('cfgA', 'cfgC', 'cfgD', 'cfgE', 'input_width_D39'):
+        fat[k]['kernels'] = {'kernel_%03d' % i: dict(calls=5, total_ms=1.0, avg_us=200.0 + i) for i in range(60)}
+    lf = bench.compact_line(fat)
+    df = json.loads(lf)
+    assert len(lf) <= 6000 and df['roofline']['frac'] > 0 and df['cpu_baseline']['value'] > 0 and df['cfgC']['value'] > 0
