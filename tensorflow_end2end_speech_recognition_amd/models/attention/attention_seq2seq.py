@@ -226,10 +226,14 @@ class AttentionSeq2Seq(ModelBase):
     def compute_loss(self, inputs, labels, inputs_seq_len, labels_seq_len, keep_prob_encoder,
                      keep_prob_decoder, keep_prob_embedding, scope=None, is_training=True, **joint):
         dev, st = self.device, self.store
-        inputs = torch.as_tensor(inputs, dtype=torch.float32, device=dev)
-        isl = torch.as_tensor(inputs_seq_len, dtype=torch.int32, device=dev)
-        labels_np = np.asarray(labels.cpu() if torch.is_tensor(labels) else labels).astype(np.int64)
-        lsl_np = np.asarray(labels_seq_len.cpu() if torch.is_tensor(labels_seq_len) else labels_seq_len).astype(np.int64)
+        # nothing below may drain the stream (pageable uploads and device read-backs do): the host has to run ahead of the
+        # device for the step to be device-bound -- ops.to_device stages through pinned memory, ops.host_ints remembers
+        # the host copy of a device vector it has seen
+        self.encoder._lens_host = ops.host_ints(inputs_seq_len)
+        inputs = ops.to_device(inputs, torch.float32, dev)
+        isl = ops.to_device(inputs_seq_len, torch.int32, dev)
+        labels_np = (ops.host_ints(labels) if torch.is_tensor(labels) else np.asarray(labels)).astype(np.int64)
+        lsl_np = (ops.host_ints(labels_seq_len) if torch.is_tensor(labels_seq_len) else np.asarray(labels_seq_len)).astype(np.int64)
         B = inputs.shape[0]
         enc, seq_p = self._encode(inputs, isl, keep_prob_encoder, is_training)
         T, Bp, E2 = enc.shape
@@ -252,9 +256,9 @@ class AttentionSeq2Seq(ModelBase):
         ids_in[:, :B] = labels_np[:, :To].T
         tgt[:, :B] = labels_np[:, 1:To + 1].T
         live[:, :B] = (np.arange(To)[:, None] < (lsl_np - 1)[None, :]).astype(np.float32)
-        ids_d = torch.from_numpy(ids_in).to(dev)
-        tgt_d = torch.from_numpy(tgt).to(dev)
-        live_d = torch.from_numpy(live).to(dev)
+        ids_d = ops.to_device(ids_in, torch.int32, dev)
+        tgt_d = ops.to_device(tgt, torch.int32, dev)
+        live_d = ops.to_device(live, torch.float32, dev)
         emb = ops.embedding_gather(st['output_embedding/W_embedding'], ids_d.view(-1)).view(To, Bp, Em)
         emb_mask = None
         if is_training and float(keep_prob_embedding) < 1.0:
@@ -508,8 +512,9 @@ class AttentionSeq2Seq(ModelBase):
         """Greedy inference ids [B, <= max_decode_length] (numpy) for a batch of features -- what running the
         reference's `decode_op_infer` with a feed_dict of inputs / inputs_seq_len / keep_prob = 1 returns
         (examples/timit/metrics/attention.py:80-86)."""
-        inputs = torch.as_tensor(inputs, dtype=torch.float32, device=self.device)
-        isl = torch.as_tensor(inputs_seq_len, dtype=torch.int32, device=self.device)
+        self.encoder._lens_host = ops.host_ints(inputs_seq_len)
+        inputs = ops.to_device(inputs, torch.float32, self.device)
+        isl = ops.to_device(inputs_seq_len, torch.int32, self.device)
         return self._decode_infer(inputs, isl).cpu().numpy()
 
     def decode(self, decoder_outputs_train, decoder_outputs_infer):

@@ -17,6 +17,10 @@ from ..ctc.ctc import CTC, truncated_normal
 from .attention_seq2seq import AttentionSeq2Seq
 
 
+def _not_enough_time(n):
+    return ValueError('Not enough time for target transition sequence (%d utterance(s))' % n)
+
+
 class JointCTCAttention(AttentionSeq2Seq):
 
     def __init__(self, input_size, encoder_type, encoder_num_units, encoder_num_layers, encoder_num_proj,
@@ -73,16 +77,18 @@ class JointCTCAttention(AttentionSeq2Seq):
         flat, offsets, max_len = CTC._labels_to_flat(ctc_labels, B)
         if Bp > B:
             offsets = np.concatenate([offsets, np.full(Bp - B, offsets[-1], dtype=np.int32)])
-        flat_d = torch.from_numpy(np.ascontiguousarray(flat if len(flat) else np.zeros(1, np.int32))).to(dev)
-        off_d = torch.from_numpy(np.ascontiguousarray(offsets)).to(dev)
+        # pinned staging + asynchronous copies: a pageable upload would drain the stream (ops.to_device)
+        flat_d = ops.to_device(flat if len(flat) else np.zeros(1, np.int32), torch.int32, dev)
+        off_d = ops.to_device(offsets, torch.int32, dev)
         losses, grad, ninf = ops.ctc_loss(logits, flat_d, off_d, seq_p, max_len, grad_scale=lam / B,
                                           want_grad=is_training)
         return logits, losses, grad, ninf, flat_d, off_d
 
     def _ctc_head_finish(self, pending, B):
         logits, losses, grad, ninf = pending[:4]
-        if int(ninf.item()) > 0:      # ignore_longer_outputs_than_inputs=False
-            raise ValueError('Not enough time for target transition sequence (%d utterance(s))' % int(ninf.item()))
+        # ignore_longer_outputs_than_inputs=False: checked through the deferred counter watch while training (the host
+        # must not wait for the forward pass every step; the error surfaces <= 3 steps late), at once otherwise
+        ops.defer_zero_check(ninf, _not_enough_time, blocking=grad is None)
         self.ctc_losses = losses[:B]
         return logits[:, :B], losses[:B].mean(), dict(dlogits=grad)
 

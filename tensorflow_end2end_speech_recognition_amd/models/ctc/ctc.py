@@ -43,6 +43,10 @@ class Placeholder(object):
         return self
 
 
+def _not_enough_time(n):
+    return ValueError('Not enough time for target transition sequence (%d utterance(s))' % n)
+
+
 class CTC(ModelBase):
     """Connectionist Temporal Classification (CTC) network (models/ctc/ctc.py:15-57 docstring).
 
@@ -211,8 +215,11 @@ class CTC(ModelBase):
         list2sparsetensor or a dense [B,Lmax] array padded -1; inputs_seq_len [B].
         Returns (total_loss 0-dim cuda tensor, logits [T,B,num_classes])."""
         dev = self.device
-        inputs = torch.as_tensor(inputs, dtype=torch.float32, device=dev)
-        inputs_seq_len = torch.as_tensor(inputs_seq_len, dtype=torch.int32, device=dev)
+        # host-side view of the lengths for encoders that plan on the host (VGG valid-frame packing, GRU tmax): taken
+        # from what the caller handed over, never by reading a device copy back (that would drain the stream each step)
+        self.encoder._lens_host = ops.host_ints(inputs_seq_len)
+        inputs = ops.to_device(inputs, torch.float32, dev)
+        inputs_seq_len = ops.to_device(inputs_seq_len, torch.int32, dev)
         B = inputs.shape[0]
         flat, offsets, max_len = self._labels_to_flat(labels, B)
         Bp = B + (-B) % 16                               # the encoder pads the batch to whole 16-utterance tiles
@@ -240,6 +247,10 @@ class CTC(ModelBase):
             total_loss = ctc_loss + l2                                      # ctc.py:280-302
         self.ctc_losses = ctc_losses[:B]
         self.num_infeasible = ninf
+        # tf.nn.ctc_loss(ignore_longer_outputs_than_inputs=False) fails the step (ctc.py:289); here the counter is watched
+        # asynchronously while training (raises <= 3 steps late, the rows themselves contribute 0 loss / 0 gradient) and
+        # checked at once in evaluation
+        ops.defer_zero_check(ninf, _not_enough_time, blocking=not is_training)
         self._tape = dict(dlogits=grad, B=B) if is_training else None
         total_loss._asr_model = self
         return total_loss, logits[:, :B]

@@ -89,8 +89,9 @@ class MultitaskCTC(CTC):
                      is_training=True):
         """:227-312.  Returns (total_loss, logits_main [T,B,C_main], logits_sub [T,B,C_sub])."""
         dev = self.device
-        inputs = torch.as_tensor(inputs, dtype=torch.float32, device=dev)
-        inputs_seq_len = torch.as_tensor(inputs_seq_len, dtype=torch.int32, device=dev)
+        self.encoder._lens_host = ops.host_ints(inputs_seq_len)
+        inputs = ops.to_device(inputs, torch.float32, dev)
+        inputs_seq_len = ops.to_device(inputs_seq_len, torch.int32, dev)
         B = inputs.shape[0]
         logits_main, logits_sub = self._build(inputs, inputs_seq_len, keep_prob, is_training)
         Bp = logits_main.shape[1]
@@ -112,6 +113,9 @@ class MultitaskCTC(CTC):
             total_loss = total_loss + l2                                     # :240-247
         self.ctc_losses, self.ctc_losses_sub = losses_m[:B], losses_s[:B]
         self.num_infeasible, self.num_infeasible_sub = ninf_m, ninf_s
+        from .ctc import _not_enough_time
+        ops.defer_zero_check(ninf_m, _not_enough_time, blocking=not is_training)
+        ops.defer_zero_check(ninf_s, _not_enough_time, blocking=not is_training)
         self._tape = dict(dlogits=grad_m, dlogits_sub=grad_s, B=B) if is_training else None
         total_loss._asr_model = self
         return total_loss, logits_main[:, :B], logits_sub[:, :B]

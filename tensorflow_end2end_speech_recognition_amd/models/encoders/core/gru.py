@@ -144,13 +144,16 @@ class _GRUEncoderBase(object):
             self.build(store, inputs.shape[-1], np.random.RandomState(self.seed))
             store.finalize()
         B, T, _ = inputs.shape
+        lens_host = getattr(self, '_lens_host', None)    # the caller's host lengths (model classes), else one read-back
+        self._lens_host = None
+        if lens_host is None or len(lens_host) != B:
+            lens_host = ops.host_ints(inputs_seq_len)
         pad = (-B) % 16
         if pad:  # the kernels tile 16 utterances; pad with zero-length rows
             inputs = torch.cat([inputs, inputs.new_zeros(pad, T, inputs.shape[2])], 0)
             inputs_seq_len = torch.cat([inputs_seq_len, inputs_seq_len.new_zeros(pad)], 0)
         self.batch = B
         seq_len = inputs_seq_len.to(torch.int32).contiguous()
-        lens_host = seq_len.detach().cpu().numpy()
         tmax = int(min(max(int(lens_host.max()), 0), T)) if len(lens_host) else 0
         x = ops.bt_to_tb(inputs.contiguous(), ASR_F32)
         Bp = x.shape[1]

@@ -66,6 +66,25 @@ class _VGGFrontEnd(object):
         w2d = sh[self.prefix + name + '/weight'].view(9 * cin, cout)
         return ops.gemm(patches[:, :9 * cin], w2d, bias=self.store[self.prefix + name + '/bias'], relu=True)
 
+    def _pack_index(self, lens, T, dev):
+        """(valid-frame gather index, inverse index) on the device for the lengths `lens`: built once per distinct batch
+        geometry (an epoch on bucketed batches repeats them; bench loops reuse one) and uploaded through pinned memory,
+        so the step never waits on it."""
+        key = (lens.tobytes(), int(T), str(dev))
+        cache = self.__dict__.setdefault('_pack_cache', {})
+        hit = cache.get(key)
+        if hit is None:
+            B = len(lens)
+            t = np.arange(T, dtype=np.int64)[None, :]
+            mask = t < lens[:, None]
+            valid = np.flatnonzero(mask.reshape(-1)).astype(np.int32)      # b * T + t of every valid frame, row-major
+            inv = np.full(B * T, len(valid), dtype=np.int32)                # padded frames -> the extra zero row
+            inv[valid] = np.arange(len(valid), dtype=np.int32)
+            if len(cache) >= 16:
+                cache.clear()
+            hit = cache[key] = (ops.to_device(valid, torch.int32, dev), ops.to_device(inv, torch.int32, dev))
+        return hit
+
     def forward(self, x_btd, keep_prob, is_training, rng_state=None, seq_len=None):
         """x [B,T,F*W*3] fp32 cuda -> [B,T,256] fp32; keeps what backward needs.
         seq_len (host ints): only the valid frames go through the convolutions -- every frame is an
@@ -79,11 +98,7 @@ class _VGGFrontEnd(object):
         if seq_len is not None:
             lens = np.minimum(np.maximum(np.asarray(seq_len, dtype=np.int64), 0), T)
             if int(lens.sum()) < B * T:
-                valid = np.concatenate([b * T + np.arange(lens[b]) for b in range(B)]).astype(np.int32) \
-                    if lens.sum() else np.zeros(0, np.int32)
-                inv = np.full(B * T, len(valid), dtype=np.int32)           # padded frames -> the extra zero row
-                inv[valid] = np.arange(len(valid), dtype=np.int32)
-                pack = (torch.from_numpy(valid).to(x_btd.device), torch.from_numpy(inv).to(x_btd.device))
+                pack = self._pack_index(lens, T, x_btd.device)
         if pack is not None and pack[0].numel() > 0:
             x_rows = ops.embedding_gather(x_btd.reshape(B * T, Dd), pack[0])
         else:
@@ -272,7 +287,12 @@ class _VGGRecurrentMixin(object):
             store = ParamStore(inputs.device)
             self.build(store, inputs.shape[-1], np.random.RandomState(self.seed))
             store.finalize()
-        lens_host = inputs_seq_len.detach().cpu().numpy() if torch.is_tensor(inputs_seq_len) else inputs_seq_len
+        # the lengths as the caller gave them on the host (the model classes leave them in _lens_host); a device vector
+        # seen for the first time costs one read-back, remembered by ops.host_ints
+        lens_host = getattr(self, '_lens_host', None)
+        self._lens_host = None
+        if lens_host is None or len(lens_host) != inputs.shape[0]:
+            lens_host = ops.host_ints(inputs_seq_len)
         x = self.front.forward(inputs.contiguous(), float(keep_prob), is_training,
                                rng_state or (self.seed, 1 << 50), seq_len=lens_host)
         return super(_VGGRecurrentMixin, self).__call__(x, inputs_seq_len, keep_prob, is_training, drop_masks,

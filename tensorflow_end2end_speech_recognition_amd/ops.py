@@ -144,8 +144,13 @@ def _raw_stream(dev=None):
 
 def _cur_stream(dev=None):
     """torch.cuda.current_stream(dev) as a cached Stream object, looked up by its raw handle."""
-    raw = _raw_stream(dev)
-    key = (dev, raw)
+    # the default stream's raw handle is 0 on EVERY device: the key must carry the resolved device index, or a process
+    # that touches a second GPU would be handed the first one's stream object (ADVICE r03)
+    d = torch._C._cuda_getDevice() if dev is None else (dev.index if isinstance(dev, torch.device) else dev)
+    if d is None:
+        d = torch._C._cuda_getDevice()
+    raw = torch._C._cuda_getCurrentRawStream(d)
+    key = (d, raw)
     so = _stream_objs.get(key)
     if so is None:
         so = _stream_objs[key] = torch.cuda.current_stream(dev)
@@ -154,6 +159,49 @@ def _cur_stream(dev=None):
 
 def _s():
     return C.c_void_p(_raw_stream())
+
+
+def to_device(x, dtype, dev):
+    """Host array / list / CPU tensor -> device tensor WITHOUT draining the stream: staged in pinned memory and copied
+    with non_blocking=True (a pageable `torch.as_tensor(x, device=dev)` waits for everything enqueued before it -- one
+    such call per training step makes the whole step host-synchronous).  Device tensors pass through (dtype converted on
+    the device).  torch's caching host allocator keeps the pinned block alive until the copy has run."""
+    if torch.is_tensor(x) and x.is_cuda:
+        return x if x.dtype == dtype else x.to(dtype)
+    t = torch.as_tensor(x) if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x))
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    t = t.contiguous()
+    if torch.device(dev).type != 'cuda':
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
+_host_copies = {}
+
+
+def host_ints(x):
+    """Host numpy view of an integer vector the caller may hand over on the host (the reference feeds seq_len as numpy,
+    examples/timit/training/train_ctc.py:134-144) or on the device.  A device tensor costs ONE synchronising copy the
+    first time it is seen; the copy is remembered for that tensor OBJECT (weak reference + version counter: a new tensor
+    that merely reuses the address, or an in-place update, is read again), so a batch object reused across steps (bench
+    loops, an epoch cached on the device) never drains the stream a second time."""
+    if not torch.is_tensor(x):
+        return np.asarray(x)
+    if not x.is_cuda:
+        return x.detach().numpy()
+    import weakref
+    hit = _host_copies.get(id(x))
+    if hit is not None and hit[0]() is x and hit[1] == x._version:
+        return hit[2]
+    if len(_host_copies) > 64:
+        for k in [k for k, v in _host_copies.items() if v[0]() is None]:
+            del _host_copies[k]
+        if len(_host_copies) > 64:
+            _host_copies.clear()
+    host = x.detach().cpu().numpy()
+    _host_copies[id(x)] = (weakref.ref(x), x._version, host)
+    return host
 
 
 def _p(t):
@@ -677,6 +725,7 @@ def check_async_errors(device=0):
     if flags.value:
         h.lib.asr_clear_async_errors(h.h, _s())     # sticky until reported once
     h.check(rc, 'asr_check_async_errors')
+    _deferred.flush()                                # the device is idle: every armed counter has landed
     return flags.value
 
 
@@ -722,6 +771,65 @@ class ErrorWatch(object):
 
 
 _watches = {}
+
+
+class DeferredCheck(object):
+    """A device-side counter that must be zero (tf.nn.ctc_loss's "Not enough time for target transition sequence"
+    InvalidArgumentError, ctc.py:289 with ignore_longer_outputs_than_inputs=False), checked WITHOUT stalling the training
+    step: arm() copies the counter to pinned memory behind the step's kernels; the copy armed DEPTH arm()s earlier is
+    inspected then (long complete in steady state).  The error therefore surfaces at most DEPTH steps late -- before the
+    reference's would have let a second epoch start -- instead of costing one device drain per step.  flush() is the
+    blocking form for sync points (evaluation, checkpoints, tests)."""
+    DEPTH = 3
+
+    def __init__(self):
+        self.slots = []          # (pinned host tensor, event, exception factory)
+
+    def _inspect(self, host, ev, make_exc, block):
+        if not ev.query():
+            if not block:
+                return False
+            ev.synchronize()
+        n = int(host[0])
+        if n:
+            self.slots = []
+            raise make_exc(n)
+        return True
+
+    def arm(self, counter, make_exc):
+        host = torch.empty(1, dtype=counter.dtype).pin_memory()
+        host.copy_(counter.view(-1)[:1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(_cur_stream())
+        self.slots.append((host, ev, make_exc))
+        while self.slots:
+            block = len(self.slots) > self.DEPTH
+            if not self._inspect(*self.slots[0], block=block):
+                break
+            self.slots.pop(0)
+
+    def flush(self):
+        while self.slots:
+            slot = self.slots.pop(0)
+            self._inspect(*slot, block=True)
+
+
+_deferred = DeferredCheck()
+
+
+def defer_zero_check(counter, make_exc, blocking=False):
+    """counter: device int tensor that must be 0; make_exc(n) builds the exception.  blocking=True checks now."""
+    if not counter.is_cuda:
+        if int(counter.view(-1)[0]):
+            raise make_exc(int(counter.view(-1)[0]))
+        return
+    _deferred.arm(counter, make_exc)
+    if blocking:
+        _deferred.flush()
+
+
+def flush_deferred_checks():
+    _deferred.flush()
 
 
 def watch_waited_seconds(device=0):
