@@ -52,6 +52,38 @@ __device__ __forceinline__ void xstore16(f32x4_t* ubase, unsigned voff, f32x4_t 
   if (fast) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(ubase) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(ubase) : "memory");
 }
+// ---- forward exchange with 4-byte SELF-TAGGED words (XW) ----
+// h = o * tanh(c) lies in [-1, 1], so the top exponent bit of its bf16 form (bit 14) is always 0: the two free bits of a
+// packed {bf16, bf16} word (bits 14 and 30) carry a 2-bit step tag and the DATA IS THE FLAG at 4-byte granularity -- no
+// separate tag word (half of every polled byte in the 8-byte {tag, payload} granules), tear-proof for any load / store
+// width because every 4-byte word validates itself.  tag(s) = ((s >> 1) + 1) & 3 for the slot of parity s & 1: 1 on the
+// first write into the zeroed area, a different value on each of the next three writes to the same word (a consumer is
+// never more than one write behind, see the poll).  The publisher FORCES the two bits, so a NaN (exponent all ones)
+// cannot forge a tag and stall the cluster.
+constexpr unsigned XW_MASK = 0x40004000u;
+__device__ __forceinline__ unsigned xw_tag(int s) {
+  const unsigned t = (((unsigned)s >> 1) + 1u) & 3u;
+  return ((t & 1u) << 14) | ((t & 2u) << 29);
+}
+typedef __attribute__((ext_vector_type(4))) unsigned xw4_t;
+// NL L1-bypassing 16-byte poll loads from uniform base + per-lane byte offsets, then the wait: one asm block, because the
+// compiler does not count inline-asm loads on vmcnt and must not touch the destinations before they have landed.
+template <int NL>
+__device__ __forceinline__ void xw_poll(const unsigned* ubase, const unsigned (&voff)[NL], xw4_t (&v)[NL]) {
+  static_assert(NL == 1 || NL == 2 || NL == 4, "poll width");
+  if constexpr (NL == 1) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]) : "v"(voff[0]), "s"(ubase) : "memory");
+  } else if constexpr (NL == 2) {
+    asm volatile("global_load_dwordx4 %0, %2, %4 sc1\n\tglobal_load_dwordx4 %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(voff[0]), "v"(voff[1]), "s"(ubase) : "memory");
+  } else {
+    asm volatile("global_load_dwordx4 %0, %4, %8 sc1\n\tglobal_load_dwordx4 %1, %5, %8 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, %8 sc1\n\tglobal_load_dwordx4 %3, %7, %8 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(ubase) : "memory");
+  }
+}
 // uniform base + per-lane element offset (lets the backend use the SGPR-base addressing mode)
 template <typename T>
 __device__ __forceinline__ T* uoff(T* ubase, unsigned elem) {
@@ -158,7 +190,10 @@ __device__ __forceinline__ float dpp_ror8_into(float old, float src) {
 // registers is rotated by the CU index so that the own chunks are always register chunks 0 .. KO-1.
 // HSU = hidden units per CU (64: eight waves per CU, two per SIMD; 32: four waves per CU, ONE per SIMD -- twice the CUs
 // per cluster, each wave alone on its SIMD's VALU / MFMA pipes and with half the LDS fragment traffic per CU).
-template <int H, bool DBG, bool EARLY = false, int HSU = 64, int FPIN = 0>
+// XW: the all-gather uses 4-byte self-tagged words (see xw_tag) -- a lane polls with 16-byte loads, each holding one row of
+// the 8 units of a peer's wave (ceil((G-1)/4) loads per round instead of G-1 8-byte ones, half the bytes) and stages it
+// with one ds_write_b128.  XW = false: 8-byte {step, payload} granules (ASR_LSTM_XW=0 / ASR_LSTM_DFLAGS bit 10).
+template <int H, bool DBG, bool EARLY = false, int HSU = 64, int FPIN = 0, bool XW = true>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const bf16_t* __restrict__ whp,
     const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
@@ -254,6 +289,18 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     const int gsrc = k + (k >= g ? 1 : 0);
     ldst[k] = ((unsigned)(((lane >> 2) & 15) * LDH + gsrc * HSU + (wave * 4 + (lane & 3)) * 2) * 2u) ^
               lds_swz((lane >> 2) & 15);
+  }
+  // XW: load j of a lane covers peer k = 4 j + lane / 16 (clamped: the spare lanes of the last load repeat its last peer --
+  // same bytes, same LDS target, nothing exec-masked), row lane % 16 of that peer's wave `wave`: 16 bytes = 8 units
+  constexpr int NL = XW ? ((G - 1) * 16 + 63) / 64 : 1;
+  unsigned* xw = reinterpret_cast<unsigned*>(xbase);       // [2 parity][G][SLICE] words
+  unsigned xvoff[NL], xldst[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int k = min(j * 4 + (lane >> 4), G - 2);
+    const int gsrc = k + (k >= g ? 1 : 0);
+    xvoff[j] = (unsigned)(gsrc * SLICE + wave * 64 + (lane & 15) * 4) * 4u;
+    xldst[j] = ((unsigned)((lane & 15) * LDH + gsrc * HSU + wave * 8) * 2u) ^ lds_swz(lane & 15);
   }
   const unsigned lown = ((unsigned)(prow * LDH + g * HSU + (ul & ~1)) * 2u) ^ lds_swz(prow);
   const unsigned lrd = ((unsigned)(col * LDH + rg * 8) * 2u) ^ lds_swz(col);
@@ -365,7 +412,15 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     // publish: even lanes the (unit, unit+1) granule of row 0, odd lanes (unit-1, unit) of row 1
     const float nb = dpp_xor1(odd ? hr[0] : hr[1]);
     const unsigned pk = odd ? pack_bf16x2(nb, hr[1]) : pack_bf16x2(hr[0], nb);
-    gpublish(uoff(slice(P, g), pofs), epoch, pk, fast);
+    const unsigned etag = xw_tag(s);
+    if constexpr (XW) {
+      unsigned* pw = uoff(xw + (size_t)(P * G + g) * SLICE, pofs);
+      const unsigned tv = (pk & ~XW_MASK) | etag;
+      if (fast) __hip_atomic_store(pw, tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store, stays in the L2
+      else __hip_atomic_store(pw, tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      gpublish(uoff(slice(P, g), pofs), epoch, pk, fast);
+    }
     C8_FPIN(6);                                            // behind the publish
     *reinterpret_cast<unsigned*>(hnxt + lown) = pk;
     // saved activations; rows past their length write frame s of the padding (hout: zeros,
@@ -415,6 +470,29 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       // forward launch 840 -> 805 us at H = 256, 1400 -> 1358 at H = 512, 975 -> 967 at H = 320.  (Later still is worse again: + 128 cycles 818 us,
       // + 256 860, + 384 882; the fp32 kernel, whose own-slice MFMAs take three times as long, gains nothing from it.)
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (XW) {
+        const unsigned* pbase = xw + (size_t)P * G * SLICE;  // uniform: this parity's slices
+        xw4_t v[NL];
+        unsigned spins = 0;
+#pragma unroll 1
+        for (;;) {                                         // wave-uniform loop: no exec masking
+          xw_poll<NL>(pbase, xvoff, v);
+          // v ^ tag has the two tag bits clear exactly where the word is this step's -- and is then the clean payload
+          unsigned bad = 0;
+#pragma unroll
+          for (int j = 0; j < NL; ++j) {
+            v[j] ^= etag;
+            bad |= v[j][0] | v[j][1] | v[j][2] | v[j][3];
+          }
+          if (__all((bad & XW_MASK) == 0u)) break;
+          if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+        }
+        if (DBG) nspin += spins;
+        C8_FPIN(7);                                        // behind the poll loop
+#pragma unroll
+        for (int j = 0; j < NL; ++j) *reinterpret_cast<xw4_t*>(hnxt + xldst[j]) = v[j];
+        C8_FPIN(8);                                        // behind the LDS staging
+      } else {
       u64 v[G - 1];
 #pragma unroll
       for (int k = 0; k < G - 1; ++k) v[k] = gload(uoff(slice(P, k + (k >= g ? 1 : 0)), lofs));
@@ -434,6 +512,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 #pragma unroll
       for (int k = 0; k < G - 1; ++k) *reinterpret_cast<unsigned*>(hnxt + ldst[k]) = (unsigned)v[k];
       C8_FPIN(8);                                          // behind the LDS staging
+      }
     }
     // saved activations: stored behind the poll loop -- on gfx950 loads and stores share one in-order counter, so a poll
     // issued after these stores waits for their acknowledgements too (0.921 -> 0.908 ms per launch)
@@ -1767,6 +1846,7 @@ static int g_dflags = -1;
 // bit 7 (128): BPTT kernel requests the next iteration's saved activations ahead of the poll loop (the old place; A/B)
 // bit 8 (256): fp32 BPTT kernel without the priority of the published tile's MFMAs (A/B)
 // bit 9 (512): H = 256 / 512 clusters of H/64 CUs x eight waves instead of H/32 CUs x four waves
+// bit 10 (1024): forward all-gather with 8-byte {step, payload} granules instead of 4-byte self-tagged words (A/B, tests)
 // bit 6 (64): TEST ONLY -- the last member of every cluster leaves right after the placement handshake and the
 //             spin limit drops to 2000 polls, so every hand-off times out (tests/test_gpu_ops.py checks that the
 //             error word is raised and surfaces as an exception)
@@ -1827,6 +1907,11 @@ static int units_per_cu(const char* specific) {
   return (e && atoi(e) == 64) ? 64 : 32;
 }
 static int fwd_units_per_cu() { return units_per_cu("ASR_LSTM_FWD_HS"); }
+// forward all-gather word format: 4-byte self-tagged words unless ASR_LSTM_XW=0 or ASR_LSTM_DFLAGS bit 10 (run time, tests)
+static bool fwd_xw_enabled() {
+  static const bool on = [] { const char* e = getenv("ASR_LSTM_XW"); return !(e && e[0] == '0'); }();
+  return on && !(dbg_flags() & 1024);
+}
 static int bwd_units_per_cu() { return units_per_cu("ASR_LSTM_BWD_HS"); }
 
 template <int H, int HSU = 64>
@@ -1845,8 +1930,11 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   // EARLY (own-slice k-chunks multiplied under the L2 hop): measured at H = 256 (round 2, cfg B): 970 -> 938 us per
   // launch, at H = 320: 1069 -> 969; default at both.  ASR_LSTM_DFLAGS bit 5 (32) inverts the default for A/B measurements.
   const bool early = (H == 256 || H == 320 || HSU == 32) != ((dbg_flags() & 32) != 0);   // H = 320: 1069 -> 969 us per launch
-  auto k = g_cdbg_host ? lstm_fwd_cluster8_kernel<H, true, false, HSU>
-                       : (early ? lstm_fwd_cluster8_kernel<H, false, true, HSU> : lstm_fwd_cluster8_kernel<H, false, false, HSU>);
+  // forward all-gather in 4-byte self-tagged words (default) or 8-byte {step, payload} granules (ASR_LSTM_XW=0, flag bit 10)
+  const bool xw = fwd_xw_enabled();
+  auto k = g_cdbg_host ? (xw ? lstm_fwd_cluster8_kernel<H, true, false, HSU, 0, true> : lstm_fwd_cluster8_kernel<H, true, false, HSU, 0, false>)
+                       : (early ? (xw ? lstm_fwd_cluster8_kernel<H, false, true, HSU, 0, true> : lstm_fwd_cluster8_kernel<H, false, true, HSU, 0, false>)
+                                : (xw ? lstm_fwd_cluster8_kernel<H, false, false, HSU, 0, true> : lstm_fwd_cluster8_kernel<H, false, false, HSU, 0, false>));
   // scheduling barrier between the MFMA phase and the gate math (FPIN bit 1) at H = 256 on four waves; masks measured
   // there (us per launch): none 806, {0} 808, {1} 777, {2} 855, {3} 808, {0,1} 779, {1,2} 799, all 808; at H = 512 every mask
   // is slower than none (1350: 1355 .. 1399), and so is this one at H = 320 on eight waves (968 -> 984).  On top of {1}:
@@ -1854,7 +1942,8 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   // (bit 6) 799, behind the poll loop (bit 7) 797, behind the LDS staging (bit 8) 797.  H = 512 with bit 5 / 6 / 7 alone:
   // 1365 / 1369 / 1391 against 1356
   if constexpr (HSU == 32 && H == 256) {
-    if (early && !g_cdbg_host) k = lstm_fwd_cluster8_kernel<H, false, true, HSU, 2 | 32>;
+    if (early && !g_cdbg_host)
+      k = xw ? lstm_fwd_cluster8_kernel<H, false, true, HSU, 2 | 32, true> : lstm_fwd_cluster8_kernel<H, false, true, HSU, 2 | 32, false>;
   }
   // (padding the LDS request past half a CU so that two 4-wave members can never share one was measured: no
   // difference, 866.7 vs 867.6 us -- the dispatcher spreads the members over the CUs by itself)

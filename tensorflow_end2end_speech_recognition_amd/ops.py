@@ -777,19 +777,25 @@ class DeferredCheck(object):
     """A device-side counter that must be zero (tf.nn.ctc_loss's "Not enough time for target transition sequence"
     InvalidArgumentError, ctc.py:289 with ignore_longer_outputs_than_inputs=False), checked WITHOUT stalling the training
     step: arm() copies the counter to pinned memory behind the step's kernels; the copy armed DEPTH arm()s earlier is
-    inspected then (long complete in steady state).  The error therefore surfaces at most DEPTH steps late -- before the
-    reference's would have let a second epoch start -- instead of costing one device drain per step.  flush() is the
-    blocking form for sync points (evaluation, checkpoints, tests)."""
-    DEPTH = 3
+    inspected then (long complete in steady state).  The error therefore surfaces a few steps late (the issue loop is
+    throttled to ErrorWatch.DEPTH steps ahead of the device by the optimizer step's poll; arm() itself only blocks as a
+    backstop, at DEPTH pending copies) instead of costing one device drain per step.  flush() is the blocking form for
+    sync points (evaluation, checkpoints, tests)."""
+    DEPTH = 8
 
     def __init__(self):
         self.slots = []          # (pinned host tensor, event, exception factory)
+        self.waited_s = 0.0
+        self.ring = None
+        self.n = 0
 
     def _inspect(self, host, ev, make_exc, block):
         if not ev.query():
             if not block:
                 return False
+            t0 = _time.perf_counter()
             ev.synchronize()
+            self.waited_s += _time.perf_counter() - t0
         n = int(host[0])
         if n:
             self.slots = []
@@ -797,8 +803,11 @@ class DeferredCheck(object):
         return True
 
     def arm(self, counter, make_exc):
-        host = torch.empty(1, dtype=counter.dtype).pin_memory()
-        host.copy_(counter.view(-1)[:1], non_blocking=True)
+        if self.ring is None:        # one pinned block for the life of the process: no pinned allocation per step
+            self.ring = torch.zeros(4 * self.DEPTH, dtype=torch.int32).pin_memory()
+        self.n += 1
+        host = self.ring[self.n % (4 * self.DEPTH):][:1]
+        host.copy_(counter.view(-1)[:1].to(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(_cur_stream())
         self.slots.append((host, ev, make_exc))
@@ -835,7 +844,7 @@ def flush_deferred_checks():
 def watch_waited_seconds(device=0):
     """Cumulative host time the device's ErrorWatch spent blocked behind the GPU (0 if none exists yet)."""
     w = _watches.get(device.index or 0 if isinstance(device, torch.device) else int(device))
-    return w.waited_s if w is not None else 0.0
+    return (w.waited_s if w is not None else 0.0) + _deferred.waited_s
 
 
 def watch_async_errors(device):

@@ -857,7 +857,7 @@ def test_infeasible_labels_raise_without_a_per_step_sync(cuda):
     good[:, :2] = rng.randint(0, C, size=(B, 2))
     bad = good.copy()
     bad[2] = [1, 1, 1, 1]                        # 4 repeats need 7 frames, the utterance has 3
-    model = CTC('blstm', D, 32, 1, C, parameter_init=0.1, dtype='f32', seed=0)
+    model = CTC('blstm', D, 64, 1, C, parameter_init=0.1, dtype='f32', seed=0)
     ops.flush_deferred_checks()
     for _ in range(6):
         loss, _ = model.compute_loss(x, good, sl, 1.0)

@@ -350,13 +350,15 @@ def test_lstm_bf16_and_wide(cuda, T, B, D, H, ndir):
         assert _rel(got['dpeep'][:, :3], ref['dpeep']) < (1e-4 if dtype == 'f32' else 5e-2)
 
 
-def test_lstm_cluster_exchange_paths(cuda):
-    """The multi-CU recurrence (bf16, H=256) must give bit-identical results whether the cluster's
-    per-step exchange uses same-XCD plain stores or the placement-independent write-through form
-    (forced with the debug flag), and no hand-off may time out."""
+@pytest.mark.parametrize('H', [256, 512, 320])
+def test_lstm_cluster_exchange_paths(cuda, H):
+    """The multi-CU recurrence (bf16) must give bit-identical results whether the cluster's per-step exchange uses
+    same-XCD plain stores or the placement-independent write-through form (flag bit 4), and whether the forward
+    all-gather travels as 4-byte self-tagged words (default: the step tag rides in the always-zero top exponent bits of
+    the two bf16 halves) or as 8-byte {step, payload} granules (flag bit 10); no hand-off may time out."""
     ops = _ops()
     rng = np.random.RandomState(7)
-    T, B, D, H, ndir = 61, 32, 40, 256, 2
+    T, B, D, ndir = 61, 32, 40, 2
     lens = rng.randint(1, T + 1, size=B)
     lens[0], lens[5] = T, 1
     x, ps = _lstm_case(rng, T, B, D, H, ndir, lens, init=0.1)
@@ -364,19 +366,20 @@ def test_lstm_cluster_exchange_paths(cuda):
     ref = _oracle_layer(x, ps, lens, ndir, 50.0, dout)
     # both cluster shapes: H/32 CUs x four waves (default) and H/64 CUs x eight waves (flag bit 9 = 512); the two sum
     # the k-chunks of h W_h in different orders, so bit-identity is asserted per shape, between the exchange flavours
-    for base in (0, 512):
+    for base in ((0, 512) if H != 320 else (0,)):
         res = []
         try:
-            for flags in (base, base | 16):
+            for flags in (base, base | 16, base | 1024, base | 1024 | 16):
                 ops.debug_set_lstm_flags(flags)
                 res.append(_run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', 50.0, dout))
                 assert ops.check_async_errors(0) == 0
         finally:
             ops.debug_set_lstm_flags(0)
-        for k in ('hout', 'cf', 'hf', 'dgates', 'dpeep'):
-            assert np.array_equal(res[0][k], res[1][k]), (base, k)
-        for b in range(B):   # saved cell states are only defined on valid frames
-            assert np.array_equal(res[0]['cs'][:lens[b], b], res[1]['cs'][:lens[b], b])
+        for other in res[1:]:
+            for k in ('hout', 'cf', 'hf', 'dgates', 'dpeep'):
+                assert np.array_equal(res[0][k], other[k]), (base, k)
+            for b in range(B):   # saved cell states are only defined on valid frames
+                assert np.array_equal(res[0]['cs'][:lens[b], b], other['cs'][:lens[b], b])
         assert np.abs(res[0]['hout'] - ref['hout']).max() < 3e-2
 
 
