@@ -49,8 +49,10 @@ __device__ unsigned long long* g_cdbg = nullptr;   // debug phase timers (env AS
 // in program order (a plain C++ store could legally sink below the spin loop that follows).
 __device__ __forceinline__ void xstore16(f32x4_t* ubase, unsigned voff, f32x4_t v, bool fast) {
   // uniform base in SGPRs + 32-bit per-lane byte offset: no 64-bit pointer registers per slot
-  if (fast) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(ubase) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(ubase) : "memory");
+  // (s_nop 4 in front: a base restored from a spill lane by v_readlane is a VALU-written SGPR, which a VMEM address may
+  // only use 5 wait states later -- the compiler cannot see that hazard inside the block; see the XP publish)
+  if (fast) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(ubase) : "memory");
+  else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(ubase) : "memory");
 }
 // ---- forward exchange with 4-byte SELF-TAGGED words (XW) ----
 // h = o * tanh(c) lies in [-1, 1], so the top exponent bit of its bf16 form (bit 14) is always 0: the two free bits of a
@@ -68,17 +70,19 @@ __device__ __forceinline__ unsigned xw_tag(int s) {
 typedef __attribute__((ext_vector_type(4))) unsigned xw4_t;
 // NL L1-bypassing 16-byte poll loads from uniform base + per-lane byte offsets, then the wait: one asm block, because the
 // compiler does not count inline-asm loads on vmcnt and must not touch the destinations before they have landed.
+// The leading s_nop 4: if the allocator ever restores the base from a spill lane (v_readlane = a VALU write of an SGPR)
+// right in front of the block, a VMEM address needs 5 wait states after it, and the compiler cannot see into the block.
 template <int NL>
 __device__ __forceinline__ void xw_poll(const unsigned* ubase, const unsigned (&voff)[NL], xw4_t (&v)[NL]) {
   static_assert(NL == 1 || NL == 2 || NL == 4, "poll width");
   if constexpr (NL == 1) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)"
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v[0]) : "v"(voff[0]), "s"(ubase) : "memory");
   } else if constexpr (NL == 2) {
-    asm volatile("global_load_dwordx4 %0, %2, %4 sc1\n\tglobal_load_dwordx4 %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)"
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %4 sc1\n\tglobal_load_dwordx4 %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]) : "v"(voff[0]), "v"(voff[1]), "s"(ubase) : "memory");
   } else {
-    asm volatile("global_load_dwordx4 %0, %4, %8 sc1\n\tglobal_load_dwordx4 %1, %5, %8 sc1\n\t"
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %8 sc1\n\tglobal_load_dwordx4 %1, %5, %8 sc1\n\t"
                  "global_load_dwordx4 %2, %6, %8 sc1\n\tglobal_load_dwordx4 %3, %7, %8 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
                  : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(ubase) : "memory");
@@ -595,7 +599,14 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 // against 1530; finer points -- between the foreign-tile chains and their stores / between those stores and the own-tile
 // chain / in front of the A-fragment reads: 1575 / 1525 / 1523 against 1519; forward, between the two A-fragment batches:
 // 1364 against 1353.)
-template <int H, bool DBG, int HSU = 64, int PIN = -1>
+// XP (default): the reduce-scatter slots are laid out for the CONSUMER -- a destination wave (hh, wt) finds the two rows it
+// owns of TWO sources side by side in one 16-byte word per lane, [dst][tile][hh][source pair][lane]: ceil((G-1)/2)
+// full-line 16-byte polls per round instead of G-1 8-byte ones that each use half of the 16 bytes per lane they touch
+// (8-byte L2 accesses run at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).  The producers pay with two 8-byte
+// stores per lane and tile (rows 0,1 -> the hh = 0 word, rows 2,3 -> hh = 1) instead of one 16-byte store.  Same words,
+// same tags, same summation order: bit-identical to XP = false.  Which form runs: bwd_xp_enabled() (a win only on the
+// eight-wave clusters, measured there).
+template <int H, bool DBG, int HSU = 64, int PIN = -1, bool XP = true>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
     const float* __restrict__ cs, const bf16_t* __restrict__ whpb, const float* __restrict__ peep,
@@ -712,6 +723,13 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
   };
   const unsigned voff16 = (unsigned)lane * 16u;            // byte offset of this lane's 16-byte word group
   const unsigned pofs = (unsigned)lane * 2u + hh;          // u64 index of this lane's two rows in a slot
+  // XP: 16-byte units [2 par][G dst][TPC][2 hh][NPAIR][64 lanes]; source g sits in pair k/2, half k%2 of destination
+  // dst, k = g - (g > dst) its index among dst's peers
+  constexpr int NPAIR = G / 2;                             // = ceil((G - 1) / 2)
+  auto pslot = [&](int par, int dst, int tile, int h2, int pair) -> unsigned {   // uniform 16-byte index
+    return (unsigned)((((par * G + dst) * TPC + tile) * 2 + h2) * NPAIR + pair) * 64u;
+  };
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xs, 0, 0x7fffffff, 0x00020000);
   // own dG rows -> LDS (bytes); rows rbase, rbase+1 are in the same swizzle class (rbase is even)
   const unsigned lwr[2] = {((unsigned)(rbase * LDG + ul * 4) * 2u) ^ lds_swz(rbase),
                            ((unsigned)((rbase + 1) * LDG + ul * 4) * 2u) ^ lds_swz(rbase + 1)};
@@ -748,11 +766,18 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     C8_PIN(0);
     const unsigned long long t0 = C8_T();
     // ---- 1. polls for the partials the peers published at the previous iteration (parity 1-P)
-    u64 pv[G - 1];
+    u64 pv[XP ? 1 : G - 1];
+    xw4_t pq[XP ? NPAIR : 1];
     if (it > 0) {
+      if constexpr (XP) {
 #pragma unroll
-      for (int k = 0; k < G - 1; ++k)
-        pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
+        for (int p = 0; p < NPAIR; ++p)                     // L1-bypassing (sc1) 16-byte loads, counted on vmcnt by the compiler
+          pq[p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff16, pslot(1 - P, g, wt, hh, p) * 16u, 16);
+      } else {
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k)
+          pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
+      }
     }
     C8_PIN(4);                                             // behind the poll issue
     // ---- 2. everything that does not need dh
@@ -802,24 +827,47 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
       const unsigned want = (((unsigned)(it - 1) >> 1) + 1u) & 1u;
       const u64 wmask = 0x0000000100000001ull, wtag = want ? wmask : 0ull;
       unsigned spins = 0;
+      float add0 = 0.f, add1 = 0.f;
+      if constexpr (XP) {
 #pragma unroll 1
-      for (;;) {
-        bool ok = true;
+        for (;;) {
+          unsigned bad = 0;                                 // LSB of every live word must be the tag
 #pragma unroll
-        for (int k = 0; k < G - 1; ++k) ok = ok && ((pv[k] & wmask) == wtag);
-        if (__all(ok)) break;
-        if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+          for (int p = 0; p < NPAIR; ++p) {
+            bad |= (pq[p][0] ^ want) | (pq[p][1] ^ want);
+            if (2 * p + 1 <= G - 2) bad |= (pq[p][2] ^ want) | (pq[p][3] ^ want);   // (G even: the last pair has one source)
+          }
+          if (__all((bad & 1u) == 0u)) break;
+          if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+          asm volatile("" ::: "memory");                    // a fresh round of loads, not the old values
 #pragma unroll
-        for (int k = 0; k < G - 1; ++k)
-          pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
+          for (int p = 0; p < NPAIR; ++p)
+            pq[p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff16, pslot(1 - P, g, wt, hh, p) * 16u, 16);
+        }
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) {                   // fixed order: source index ascending, as XP = false
+          add0 += __uint_as_float(pq[k >> 1][(k & 1) * 2 + 0] & ~1u);
+          add1 += __uint_as_float(pq[k >> 1][(k & 1) * 2 + 1] & ~1u);
+        }
+      } else {
+#pragma unroll 1
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int k = 0; k < G - 1; ++k) ok = ok && ((pv[k] & wmask) == wtag);
+          if (__all(ok)) break;
+          if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+#pragma unroll
+          for (int k = 0; k < G - 1; ++k)
+            pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
+        }
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) {                   // fixed order
+          add0 += __uint_as_float((unsigned)pv[k] & ~1u);
+          add1 += __uint_as_float((unsigned)(pv[k] >> 32) & ~1u);
+        }
       }
       if (DBG) nspin += spins;
-      float add0 = 0.f, add1 = 0.f;
-#pragma unroll
-      for (int k = 0; k < G - 1; ++k) {                     // fixed order
-        add0 += __uint_as_float((unsigned)pv[k] & ~1u);
-        add1 += __uint_as_float((unsigned)(pv[k] >> 32) & ~1u);
-      }
       dhr[0] += add0;
       dhr[1] += add1;
     }
@@ -892,6 +940,27 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
         for (int i = 0; i < 4; ++i) o[i] = __uint_as_float((__float_as_uint(a[i]) & ~1u) | tag);
         return o;
       };
+      // one foreign tile's partial (4 rows of one unit per lane) to its destination
+      auto publish = [&](int nt, const f32x4_t& tv, auto FAST) {
+        constexpr bool F = decltype(FAST)::value;
+        const int dst = nt / TPC, tile = nt % TPC;
+        if constexpr (XP) {
+          // Compiler-issued buffer stores, NOT inline asm with an SGPR base: with 16 slot bases per step (H = 512) the
+          // bases are spilled to VGPR lanes and restored by v_readlane right in front of the store, and a VALU-written
+          // SGPR needs 5 wait states before a VMEM instruction may use it as its address -- a hazard the compiler
+          // handles for its own instructions but cannot see inside an asm block (measured: wild stores, memory fault).
+          typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+          const int k = g - (g > dst ? 1 : 0);
+          const unsigned so0 = pslot(P, dst, tile, 0, k >> 1) * 16u + (unsigned)(k & 1) * 8u;
+          const unsigned so1 = pslot(P, dst, tile, 1, k >> 1) * 16u + (unsigned)(k & 1) * 8u;
+          const u32x2_t lo2 = {__float_as_uint(tv[0]), __float_as_uint(tv[1])};
+          const u32x2_t hi2 = {__float_as_uint(tv[2]), __float_as_uint(tv[3])};
+          __builtin_amdgcn_raw_buffer_store_b64(lo2, xrs, voff16, so0, F ? 0 : 16);   // plain (stays in the L2) / sc1
+          __builtin_amdgcn_raw_buffer_store_b64(hi2, xrs, voff16, so1, F ? 0 : 16);
+        } else {
+          xstore16(uslot(P, dst, g, tile), voff16, tv, F);
+        }
+      };
       // the tiles other CUs wait for go first; while they issue, this wave outranks its SIMD sibling's
       // own-tile MFMAs (nobody waits for those before the next step's gate math)
       __builtin_amdgcn_s_setprio(2);
@@ -911,11 +980,11 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
         if (fast) {
 #pragma unroll
           for (int i = 0; i < NF; ++i)
-            if (i < NF - 1 || last_f) xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(af[i]), true);
+            if (i < NF - 1 || last_f) publish(nt_f[i], tagged(af[i]), std::integral_constant<bool, true>{});
         } else {
 #pragma unroll
           for (int i = 0; i < NF; ++i)
-            if (i < NF - 1 || last_f) xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(af[i]), false);
+            if (i < NF - 1 || last_f) publish(nt_f[i], tagged(af[i]), std::integral_constant<bool, false>{});
         }
       } else {
 #pragma unroll
@@ -924,7 +993,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
             f32x4_t af = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) af = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[i][kc], af, 0, 0, 0);
-            xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(af), fast);
+            if (fast) publish(nt_f[i], tagged(af), std::integral_constant<bool, true>{});
+            else publish(nt_f[i], tagged(af), std::integral_constant<bool, false>{});
           }
         }
       }
@@ -1847,6 +1917,7 @@ static int g_dflags = -1;
 // bit 8 (256): fp32 BPTT kernel without the priority of the published tile's MFMAs (A/B)
 // bit 9 (512): H = 256 / 512 clusters of H/64 CUs x eight waves instead of H/32 CUs x four waves
 // bit 10 (1024): forward all-gather with 8-byte {step, payload} granules instead of 4-byte self-tagged words (A/B, tests)
+// bit 11 (2048): inverts the default choice of the BPTT reduce-scatter slot layout (consumer-major source pairs, XP) (A/B, tests)
 // bit 6 (64): TEST ONLY -- the last member of every cluster leaves right after the placement handshake and the
 //             spin limit drops to 2000 polls, so every hand-off times out (tests/test_gpu_ops.py checks that the
 //             error word is raised and surfaces as an exception)
@@ -1913,6 +1984,17 @@ static bool fwd_xw_enabled() {
   return on && !(dbg_flags() & 1024);
 }
 static int bwd_units_per_cu() { return units_per_cu("ASR_LSTM_BWD_HS"); }
+// BPTT reduce-scatter slot layout: consumer-major source pairs (XP) or one 16-byte slot per (source, tile).  Measured
+// (round 4, us per BPTT launch, T = 778): H = 320 on five CUs x eight waves 1107 -> 1064 with XP, but H = 256 on eight CUs x
+// four waves 851 -> 940 and H = 512 on sixteen 1520 -> 1790: with one wave per SIMD the doubled store count of the
+// producers (two 8-byte stores per tile instead of one 16-byte store) sits on the chain between the MFMAs and the peers'
+// polls and costs more than the halved poll count saves.  Default: XP only on the eight-wave clusters (units per CU 64);
+// ASR_LSTM_XP=1 / 0 forces it on / off everywhere, ASR_LSTM_DFLAGS bit 11 inverts the choice at run time (tests, A/B).
+static bool bwd_xp_enabled(int hsu) {
+  static const int env = [] { const char* e = getenv("ASR_LSTM_XP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool def = env >= 0 ? env == 1 : hsu == 64;
+  return def != ((dbg_flags() & 2048) != 0);
+}
 
 template <int H, int HSU = 64>
 static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const float* xproj, const void* whp,
@@ -1987,7 +2069,10 @@ static bool cluster_bwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   const XchAreas xa = xch_take(h, base, need, st);
   // two dG images; the H = 512 form adds the own-tile hand-over buffer behind them
   const size_t lds = (size_t)2 * 16 * (4 * HSU + 8) * 2 + ((G == 8 && HSU == 64) ? 2 * 4 * 64 * 8 : 0);
-  auto k = g_cdbg_host ? lstm_bwd_cluster8_kernel<H, true, HSU> : lstm_bwd_cluster8_kernel<H, false, HSU>;
+  // reduce-scatter slots in the consumer-major paired layout (default) or one 16-byte slot per (source, tile) (ASR_LSTM_XP=0)
+  const bool xp = bwd_xp_enabled(HSU);
+  auto k = g_cdbg_host ? (xp ? lstm_bwd_cluster8_kernel<H, true, HSU, -1, true> : lstm_bwd_cluster8_kernel<H, true, HSU, -1, false>)
+                       : (xp ? lstm_bwd_cluster8_kernel<H, false, HSU, -1, true> : lstm_bwd_cluster8_kernel<H, false, HSU, -1, false>);
   hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir, dhout,
                      (const cbf16x4_t*)gates, cs, (const bf16_t*)whpb, peep, seq_len, dcf, dhf,
                      (cbf16x4_t*)dgates, dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);

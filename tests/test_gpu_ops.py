@@ -355,7 +355,9 @@ def test_lstm_cluster_exchange_paths(cuda, H):
     """The multi-CU recurrence (bf16) must give bit-identical results whether the cluster's per-step exchange uses
     same-XCD plain stores or the placement-independent write-through form (flag bit 4), and whether the forward
     all-gather travels as 4-byte self-tagged words (default: the step tag rides in the always-zero top exponent bits of
-    the two bf16 halves) or as 8-byte {step, payload} granules (flag bit 10); no hand-off may time out."""
+    the two bf16 halves) or as 8-byte {step, payload} granules (flag bit 10), and whether the BPTT reduce-scatter uses
+    the consumer-major paired slots (default) or one 16-byte slot per (source, tile) (flag bit 11 inverts the per-shape default); no hand-off may time
+    out."""
     ops = _ops()
     rng = np.random.RandomState(7)
     T, B, D, ndir = 61, 32, 40, 2
@@ -369,7 +371,7 @@ def test_lstm_cluster_exchange_paths(cuda, H):
     for base in ((0, 512) if H != 320 else (0,)):
         res = []
         try:
-            for flags in (base, base | 16, base | 1024, base | 1024 | 16):
+            for flags in (base, base | 16, base | 1024, base | 1024 | 16, base | 2048, base | 2048 | 16):
                 ops.debug_set_lstm_flags(flags)
                 res.append(_run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', 50.0, dout))
                 assert ops.check_async_errors(0) == 0
