@@ -68,26 +68,6 @@ __device__ __forceinline__ unsigned xw_tag(int s) {
   return ((t & 1u) << 14) | ((t & 2u) << 29);
 }
 typedef __attribute__((ext_vector_type(4))) unsigned xw4_t;
-// NL L1-bypassing 16-byte poll loads from uniform base + per-lane byte offsets, then the wait: one asm block, because the
-// compiler does not count inline-asm loads on vmcnt and must not touch the destinations before they have landed.
-// The leading s_nop 4: if the allocator ever restores the base from a spill lane (v_readlane = a VALU write of an SGPR)
-// right in front of the block, a VMEM address needs 5 wait states after it, and the compiler cannot see into the block.
-template <int NL>
-__device__ __forceinline__ void xw_poll(const unsigned* ubase, const unsigned (&voff)[NL], xw4_t (&v)[NL]) {
-  static_assert(NL == 1 || NL == 2 || NL == 4, "poll width");
-  if constexpr (NL == 1) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]) : "v"(voff[0]), "s"(ubase) : "memory");
-  } else if constexpr (NL == 2) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %4 sc1\n\tglobal_load_dwordx4 %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(voff[0]), "v"(voff[1]), "s"(ubase) : "memory");
-  } else {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %8 sc1\n\tglobal_load_dwordx4 %1, %5, %8 sc1\n\t"
-                 "global_load_dwordx4 %2, %6, %8 sc1\n\tglobal_load_dwordx4 %3, %7, %8 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                 : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(ubase) : "memory");
-  }
-}
 // uniform base + per-lane element offset (lets the backend use the SGPR-base addressing mode)
 template <typename T>
 __device__ __forceinline__ T* uoff(T* ubase, unsigned elem) {
@@ -298,6 +278,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
   // same bytes, same LDS target, nothing exec-masked), row lane % 16 of that peer's wave `wave`: 16 bytes = 8 units
   constexpr int NL = XW ? ((G - 1) * 16 + 63) / 64 : 1;
   unsigned* xw = reinterpret_cast<unsigned*>(xbase);       // [2 parity][G][SLICE] words
+  const __amdgpu_buffer_rsrc_t xwrs = __builtin_amdgcn_make_buffer_rsrc(xw, 0, 0x7fffffff, 0x00020000);
   unsigned xvoff[NL], xldst[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
@@ -475,12 +456,15 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       // + 256 860, + 384 882; the fp32 kernel, whose own-slice MFMAs take three times as long, gains nothing from it.)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (XW) {
-        const unsigned* pbase = xw + (size_t)P * G * SLICE;  // uniform: this parity's slices
+        constexpr unsigned pbytes = (unsigned)P * G * SLICE * 4u;   // this parity's slices
         xw4_t v[NL];
         unsigned spins = 0;
 #pragma unroll 1
         for (;;) {                                         // wave-uniform loop: no exec masking
-          xw_poll<NL>(pbase, xvoff, v);
+          asm volatile("" ::: "memory");                   // every round is a fresh set of loads
+#pragma unroll
+          for (int j = 0; j < NL; ++j)                      // L1-bypassing (sc1) 16-byte loads, counted on vmcnt by the compiler
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(xwrs, xvoff[j], pbytes, 16);
           // v ^ tag has the two tag bits clear exactly where the word is this step's -- and is then the clean payload
           unsigned bad = 0;
 #pragma unroll
