@@ -46,8 +46,10 @@ def _lse(*args):
     return m + math.log(sum(math.exp(a - m) for a in args))
 
 
-def beam_search_decode(log_probs_btc, seq_len, blank, beam_width=1):
-    """Returns (list of best prefixes, np.array of -log scores)."""
+def beam_search_decode(log_probs_btc, seq_len, blank, beam_width=1, top_paths=None):
+    """Returns (list of best prefixes, np.array of -log scores); with top_paths = k the first k beams of every
+    utterance instead: (list of lists of prefixes, [B, k] -log scores) -- tf.nn.ctc_beam_search_decoder(top_paths=k,
+    merge_repeated=False); pinned to TensorFlow's own test constants in tests/golden/tf_known_answers.py."""
     B, T, C = log_probs_btc.shape
     results, scores = [], []
     for b in range(B):
@@ -74,6 +76,16 @@ def beam_search_decode(log_probs_btc, seq_len, blank, beam_width=1):
                         nb, nnb = nxt.get(prefix, (NEG_INF, NEG_INF))
                         nxt[prefix] = (nb, _lse(nnb, p_nb + p_t))
             beam = sorted(nxt.items(), key=lambda kv: _lse(*kv[1]), reverse=True)[:beam_width]
-        results.append(list(beam[0][0]))
-        scores.append(-_lse(*beam[0][1]))
+        if top_paths is None:
+            results.append(list(beam[0][0]))
+            scores.append(-_lse(*beam[0][1]))
+        else:
+            results.append([list(e[0]) for e in beam[:top_paths]])
+            scores.append([-_lse(*e[1]) for e in beam[:top_paths]])
     return results, np.array(scores)
+
+
+def merge_repeated(path):
+    """tf.nn.ctc_beam_search_decoder(merge_repeated=True), the reference's call (models/ctc/ctc.py:344-346): consecutive
+    equal labels of an OUTPUT beam collapse to one."""
+    return [c for i, c in enumerate(path) if i == 0 or c != path[i - 1]]

@@ -64,6 +64,30 @@ GREEDY_PROBS = np.asarray(
 GREEDY_DECODED = [[0, 1], [1, 1, 0]]
 GREEDY_NEG_LOG_PROB = [float(np.sum(-np.log([1.0, 0.6, 0.6, 0.9]))), float(np.sum(-np.log([0.9] * 5)))]
 
+# tf.nn.ctc_beam_search_decoder: tensorflow/python/kernel_tests/ctc_decoder_ops_test.py, testCTCDecoderBeamSearch ("one
+# batch, two beams -- hibernating beam search") -- depth 6 (blank = 5), one utterance of 5 frames (a sixth, random frame
+# and two zero frames lie beyond seq_len), beam_width = 2, top_paths = 2, merge_repeated = False.  The test feeds
+# log(probabilities) + 2.0 ("arbitrary offset -- this is fine": the decoder works on frame-normalised scores) and expects
+# the two beams [1, 0] and [0, 1, 0] with log_probability 0.584855 / 0.389139.  Those numbers are POSITIVE because the
+# TF1 kernel normalises every frame by its MAXIMUM, not by its log-sum-exp: log_probability = log p(path | x) +
+# sum_t -log max_c softmax(x_t)_c  (here -3.582118 + 4.166973 and -3.777833 + 4.166973).  Restated, not a copied file.
+BEAM_PROBS = np.asarray(
+    [[0.30999, 0.309938, 0.0679938, 0.0673362, 0.0708352, 0.173908],
+     [0.215136, 0.439699, 0.0370931, 0.0393967, 0.0381581, 0.230517],
+     [0.199959, 0.489485, 0.0233221, 0.0251417, 0.0233289, 0.238763],
+     [0.279611, 0.452966, 0.0204795, 0.0209126, 0.0194803, 0.20655],
+     [0.51286, 0.288951, 0.0243026, 0.0220788, 0.0219297, 0.129878],
+     [0.155251, 0.164444, 0.173517, 0.176138, 0.169979, 0.160671]], dtype=np.float64)   # [T = 6, depth]; seq_len = 5
+BEAM_SEQ_LEN, BEAM_WIDTH, BEAM_BLANK, BEAM_LOGIT_OFFSET, BEAM_PADDED_FRAMES = 5, 2, 5, 2.0, 8
+BEAM_DECODED = [[1, 0], [0, 1, 0]]                    # beam 0, beam 1
+BEAM_LOG_PROB = [0.584855, 0.389139]                  # TF1's max-normalised log-probabilities of the two beams
+
+
+def beam_max_normaliser(probs, seq_len):
+    """sum_t -log max_c p[t, c]: what TF1's frame-max normalisation adds to log p(path | x)."""
+    return float(np.sum(-np.log(np.asarray(probs)[:seq_len].max(1))))
+
+
 # tf.train.AdagradOptimizer: tensorflow/python/training/adagrad_test.py, doTestBasic -- learning rate 3.0,
 # initial_accumulator_value 0.1, constant gradients, 3 steps.
 ADAGRAD_LR, ADAGRAD_STEPS = 3.0, 3

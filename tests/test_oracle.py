@@ -336,6 +336,28 @@ def test_greedy_decoder_matches_tensorflow_known_answer():
         assert abs(float(-logp[b, :n].max(1).sum()) - tfk.GREEDY_NEG_LOG_PROB[b]) < 1e-12
 
 
+def test_beam_search_decoder_matches_tensorflow_known_answer():
+    """oracle/decoders.py beam_search_decode against TensorFlow's own ctc_decoder_ops_test.py testCTCDecoderBeamSearch:
+    beam_width 2, top_paths 2 -> beams [1, 0] and [0, 1, 0]; TF1's log_probability is log p(path) plus the frame-max
+    normaliser (it divides every frame by its maximum, not by its sum), reproduced to the constants' six digits.  The
+    logit offset (+2.0) and the frames beyond seq_len must not matter."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import decoders as odec
+    logits = np.zeros((1, tfk.BEAM_PADDED_FRAMES, tfk.BEAM_PROBS.shape[1]))
+    logits[0, :tfk.BEAM_PROBS.shape[0]] = np.log(tfk.BEAM_PROBS) + tfk.BEAM_LOGIT_OFFSET
+    lp = logits - np.log(np.exp(logits).sum(2, keepdims=True))            # the decoders take log-softmax
+    paths, nll = odec.beam_search_decode(lp, [tfk.BEAM_SEQ_LEN], tfk.BEAM_BLANK, beam_width=tfk.BEAM_WIDTH, top_paths=2)
+    assert paths[0] == tfk.BEAM_DECODED
+    norm = tfk.beam_max_normaliser(tfk.BEAM_PROBS, tfk.BEAM_SEQ_LEN)
+    assert np.abs(-nll[0] + norm - np.asarray(tfk.BEAM_LOG_PROB)).max() < 2e-6
+    best, nll1 = odec.beam_search_decode(lp, [tfk.BEAM_SEQ_LEN], tfk.BEAM_BLANK, beam_width=tfk.BEAM_WIDTH)
+    assert best[0] == tfk.BEAM_DECODED[0] and abs(nll1[0] - nll[0][0]) < 1e-12
+    # merge_repeated=True (the reference's call) collapses repeats of an output beam; these two have none
+    assert [odec.merge_repeated(p) for p in paths[0]] == tfk.BEAM_DECODED and odec.merge_repeated([3, 3, 1, 1, 3]) == [3, 1, 3]
+
+
 def test_adagrad_matches_tensorflow_known_answer():
     """oracle/optim.py 'adagrad' (accumulator starts at 0.1, TF1 default) against the constants of TensorFlow's
     own adagrad_test.py doTestBasic: three steps at learning rate 3.0."""
