@@ -26,16 +26,21 @@ def _grad_report(gv, ref_grads, report, floor=0.0):
     largest entry is below it are compared against the floor instead (dead paths: zeros against rounding noise)."""
     worst, worst_name = 0.0, None
     stats = {}
+    num = den = 0.0
     for g, name in gv:
         r = ref_grads[name]
         gd = g.detach().cpu().double().numpy()
         e = float(np.abs(gd - r).max() / max(np.abs(r).max(), floor, 1e-30))
         l2 = float(np.sqrt(((gd - r) ** 2).sum()) / max(np.sqrt((r ** 2).sum()), floor, 1e-30))
+        num += float(((gd - r) ** 2).sum())
+        den += float((r ** 2).sum())
         stats[name] = (e, l2)
         report.append('%-64s |g|max %.3e  rel-to-max %.2e  rel-L2 %.2e' % (name, np.abs(r).max(), e, l2))
         if e > worst:
             worst, worst_name = e, name
     _grad_report.last = stats
+    _grad_report.global_l2 = float(np.sqrt(num / max(den, 1e-300)))       # the whole gradient as one vector
+    report.append('whole gradient, relative L2: %.2e' % _grad_report.global_l2)
     return worst, worst_name
 
 
@@ -88,7 +93,7 @@ def _randomise_biases(model, rng, scale=0.05):
     return sd
 
 
-def run_cfgC(device, dtype, B, T, F, W, H, L, C, seed=21):
+def run_cfgC(device, dtype, B, T, F, W, H, L, C, seed=21, perturb_eps=0.0):
     """BASELINE configs[2]: VGG front-end on [F, W, 3] frame images (splice W) -> bridge FC -> L x H BLSTM -> CTC
     (models/encoders/core/vgg_blstm.py:77-220, models/ctc/ctc.py:175-323).  B >= 17 puts two 16-utterance tiles
     through the recurrence and, with ragged lengths, the valid-frame gather in front of the convolutions."""
@@ -117,6 +122,29 @@ def run_cfgC(device, dtype, B, T, F, W, H, L, C, seed=21):
                                                          out['logits_max'], t_oracle)]
     out['grad_worst'], out['grad_worst_name'] = _grad_report(gv, ref['grads'], report)
     _split_grad_stats(out)
+    if perturb_eps and dtype == 'bf16':
+        # How much of a gap do a few flipped bf16 roundings open by themselves?  The SAME oracle, with every value nudged
+        # by a relative `perturb_eps` in front of each rounding point: only values within that distance of a rounding
+        # boundary change (by one bf16 ulp), i.e. a fraction ~ perturb_eps / 2^-8 of them -- the kind of difference two
+        # correct realisations of the arithmetic (different summation orders) have.  What this moves is amplification
+        # through the bf16 BPTT stack, by construction not an arithmetic error.
+        t0 = time.perf_counter()
+        nudged = lambda v: olstm.bf16_round_t(v * (1.0 + perturb_eps))       # noqa: E731
+        ref2 = omodel.ctc_model_forward(sd, x, labs, sl, L, ndir=2, cell_clip=50.0, vgg=(F, W), operand_round=nudged)
+        pm, pp, pl2 = 0.0, 0.0, 0.0
+        for name, r in ref['grads'].items():
+            e = float(np.abs(ref2['grads'][name] - r).max() / max(np.abs(r).max(), 1e-30))
+            l2 = float(np.sqrt(((ref2['grads'][name] - r) ** 2).sum()) / max(np.sqrt((r ** 2).sum()), 1e-30))
+            if name.endswith('_diag'):
+                pp = max(pp, e)
+            else:
+                pm, pl2 = max(pm, e), max(pl2, l2)
+        out.update(perturb_worst_matrices=pm, perturb_worst_peepholes=pp, perturb_worst_l2=pl2,
+                   perturb_loss_rel=abs(ref2['total_loss'] - ref['total_loss']) / abs(ref['total_loss']))
+        report.append('oracle vs the same oracle with roundings nudged by %.0e: loss %.2e  matrices %.2e (L2 %.2e)  peepholes '
+                      '%.2e   [device vs oracle: matrices %.2e (L2 %.2e) peepholes %.2e]  %.1f s'
+                      % (perturb_eps, out['perturb_loss_rel'], pm, pl2, pp, out['grad_worst_matrices'],
+                         out['grad_worst_l2'], out['grad_worst_peepholes'], time.perf_counter() - t0))
     out['report'] = '\n'.join(report)
     return out
 
@@ -131,6 +159,7 @@ def _split_grad_stats(out):
     out['grad_worst_peepholes'] = max(peep) if peep else 0.0
     out['grad_worst_l2'] = max(v[1] for k, v in st.items() if not k.endswith('_diag'))
     out['grad_worst_l2_peepholes'] = max([v[1] for k, v in st.items() if k.endswith('_diag')] or [0.0])
+    out['grad_global_l2'] = _grad_report.global_l2
 
 
 def run_attention(device, dtype, att, B, T, To, D, H, L, U, A, Em, C, lam, prev_alpha, seed=33, joint=True):

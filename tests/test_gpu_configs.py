@@ -27,7 +27,7 @@ def test_cfgC_vgg_blstm_4x512_bf16_ragged_two_tiles(cuda):
     4 x 512 BLSTM (8-CU cluster kernels) -> 29-class CTC, bf16 operands, B = 20 ragged utterances: two 16-utterance
     recurrence tiles (12 rows of the second are padding) and the valid-frame gather in front of the convolutions.
     Reference: models/encoders/core/vgg_blstm.py:77-220, cnn_util.py:13-84, models/ctc/ctc.py:175-323."""
-    r = cp.run_cfgC('cuda:0', 'bf16', B=20, T=60, F=40, W=11, H=512, L=4, C=28)
+    r = cp.run_cfgC('cuda:0', 'bf16', B=20, T=60, F=40, W=11, H=512, L=4, C=28, perturb_eps=2e-6)
     print('\n' + r['report'])
     _no_handoff_errors()
     # measured on MI355X, two realisations of the same arithmetic: with the first convolution on the vector ALUs loss 5e-5,
@@ -40,8 +40,16 @@ def test_cfgC_vgg_blstm_4x512_bf16_ragged_two_tiles(cuda):
     # valid-frame logic is what the fp32 run below pins to 2e-3.
     assert r['loss_rel'] < 2e-3 and r['per_utt_rel'] < 5e-3, r['report']
     assert r['logits_abs'] < 3e-2 * max(1.0, r['logits_max']), r['report']
-    assert r['grad_worst_matrices'] < 1.2e-1 and r['grad_worst_l2'] < 7e-2, r['report']
-    assert r['grad_worst_peepholes'] < 1.5e-1 and r['grad_worst_l2_peepholes'] < 1e-1, r['report']
+    # Round 4: the amplification is SHOWN, not asserted.  The same oracle with every rounding point nudged by a relative
+    # 2e-6 (a fraction ~5e-4 of the roundings flip by one bf16 ulp -- what two correct summation orders differ by) moves
+    # its own worst gradient entry by 12.5e-2 (matrices, L2 10.9e-2) / 12.8e-2 (peepholes) and the loss by 1.3e-3: more than
+    # the device-vs-oracle gap (7.5e-2 / 4.2e-2 / 7.6e-2, loss 1.8e-4).  With fp32 operands the same model at the same
+    # widths agrees to 2e-3 (test_cfgC_4x512_fp32_operands_two_tiles).  Bounds: 1.5 x measured, and never beyond what the
+    # nudged oracle shows rounding alone does.
+    assert r['grad_worst_matrices'] < 1.13e-1 and r['grad_worst_l2'] < 6.3e-2, r['report']
+    assert r['grad_worst_peepholes'] < 1.14e-1 and r['grad_worst_l2_peepholes'] < 8.7e-2, r['report']
+    assert r['grad_worst_matrices'] < r['perturb_worst_matrices'] and r['grad_worst_l2'] < r['perturb_worst_l2'], r['report']
+    assert r['grad_worst_peepholes'] < r['perturb_worst_peepholes'] and r['loss_rel'] < r['perturb_loss_rel'], r['report']
 
 
 def test_cfgC_two_tiles_ragged_fp32(cuda):
@@ -54,6 +62,54 @@ def test_cfgC_two_tiles_ragged_fp32(cuda):
     assert r['loss_rel'] < 1e-4 and r['per_utt_rel'] < 1e-4, r['report']
     assert r['logits_abs'] < 2e-4 * max(1.0, r['logits_max']), r['report']
     assert r['grad_worst'] < 2e-3, r['report']
+
+
+def test_cfgC_4x512_fp32_operands_two_tiles(cuda):
+    """configs[2] at its OWN widths (VGG on 40 x 11 x 3 images, 4 x 512 BLSTM on the fp32 cluster kernels, two ragged
+    recurrence tiles) with fp32 operands end to end against the plain fp64 oracle at the fp32 bars: with no bf16
+    rounding anywhere the whole model -- the same host wiring, gather, tile reduction and layer stack the bf16 test
+    runs -- agrees to 2e-3 of every gradient's largest entry.  What the bf16 run adds on top is rounding."""
+    r = cp.run_cfgC('cuda:0', 'f32', B=20, T=60, F=40, W=11, H=512, L=4, C=28)
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 1e-4 and r['per_utt_rel'] < 1e-4, r['report']
+    assert r['logits_abs'] < 2e-4 * max(1.0, r['logits_max']), r['report']
+    assert r['grad_worst'] < 2e-3, r['report']
+
+
+def test_cfgC_long_sequences_bf16(cuda):
+    """configs[2] at its widths on LONG utterances: T = 400 frames (the bench batch has 150 .. 1650; the fp64 oracle
+    takes about a minute here), B = 17 -> two recurrence tiles, ragged.  Forward quantities: loss, per-utterance losses,
+    logits.  Gradients: the whole gradient as one vector and every matrix / bias in relative L2 -- per-entry figures of a
+    400-step bf16 BPTT under four layers are dominated by single rounding flips (the nudged-oracle figures in
+    test_cfgC_vgg_blstm_4x512_bf16_ragged_two_tiles: 12 % at T = 60 from flipping 5e-4 of the roundings), and the
+    peephole vectors -- sums over 6 000 frames of products with cell states up to the clip, |g| an order below the
+    matrices' -- lose all significance per variable here; the recurrence kernels' own peephole gradients are held to 6e-3
+    at T = 778 by test_lstm_cluster_bf16_gradient_parity_headline_shapes.  Measured: loss 1.3e-4, per-utterance 8e-4,
+    logits 9e-2 abs of |logit| <= 4.2, whole gradient 1.2e-1, worst matrix 1.7e-1 (VGG1/conv1, under everything)."""
+    r = cp.run_cfgC('cuda:0', 'bf16', B=17, T=400, F=40, W=11, H=512, L=4, C=28, seed=22)
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 4e-4 and r['per_utt_rel'] < 2e-3, r['report']                  # bounds: 1.5 - 3 x measured
+    assert r['logits_abs'] < 3.3e-2 * max(1.0, r['logits_max']), r['report']
+    assert r['grad_global_l2'] < 1.7e-1 and r['grad_worst_l2'] < 2.5e-1, r['report']
+
+
+def test_cfgD_long_sequences_bf16(cuda):
+    """configs[3] at its widths on LONG utterances: T = 800 encoder frames (thirteen 64-frame chunks of the scoring
+    kernels), 150 decoder steps through asr_att_decoder_fwd / _bwd with carried location features, B = 6 ragged.
+    Measured: loss 1.4e-5, sequence loss 1.5e-4, CTC per-utterance 3.4e-4, attention weights 6e-9, logits 2.3e-2 abs of
+    |logit| <= 3.8, 4 of 900 teacher-forced argmax ids differ (bf16 ties), whole gradient 1.5e-2, worst variable 3.2e-2
+    in relative L2 (the attention layer's v_a)."""
+    r = cp.run_attention('cuda:0', 'bf16', 'location', B=6, T=800, To=150, D=240, H=512, L=5, U=512, A=128, Em=64, C=28,
+                         lam=0.5, prev_alpha='carry', seed=34)
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 2e-3 and r['seq_loss_rel'] < 2e-3 and r['ctc_losses_rel'] < 5e-3, r['report']
+    assert r['alpha_abs'] < 2e-3, r['report']
+    assert r['loss_rel'] < 1e-4 and r['seq_loss_rel'] < 5e-4 and r['ctc_losses_rel'] < 1e-3, r['report']
+    assert r['alpha_abs'] < 1e-6 and r['logits_abs'] < 1.2e-2 * max(1.0, r['logits_max']), r['report']
+    assert r['grad_global_l2'] < 2.3e-2 and r['grad_worst_l2'] < 5e-2, r['report']
 
 
 @pytest.mark.parametrize('prev_alpha', ['zeros', 'carry'])
