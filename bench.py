@@ -524,6 +524,22 @@ def run_attention_cfg(args, dev, dev_index, which):
                cluster_handoff_flags=res['handoff_flags'], kernels=res['kernels'],
                roofline=recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
                parity='model-level parity at these widths: tests/test_gpu_configs.py::test_cfg%s_*' % which)
+    # greedy attention inference (attention_seq2seq.py:462-509) through the native loop: encoder + up to
+    # max_decode_length decoder steps with the output head, argmax and embedding feedback on the device, one read-back
+    try:
+        model.infer(xd, seq_len)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            ids = model.infer(xd, seq_len)
+        tinf = (time.perf_counter() - t0) / reps
+        out['greedy_infer'] = dict(tokens_per_s=B * ids.shape[1] / tinf, ms_per_call=tinf * 1e3, decoded_steps=int(ids.shape[1]),
+                                   steps_issued=int(model._infer_raw['steps_issued']), batch=B,
+                                   note='encoder forward + native greedy decoder loop (asr_att_decoder_infer) on the training '
+                                        'batch, random-initialised weights (rows rarely emit EOS: max_decode_length steps)')
+    except Exception as e:
+        out['greedy_infer'] = dict(error=repr(e)[:300])
     if not args.no_cpu_baseline:
         nb, tc, lc = 4, 64, 10
         sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
@@ -679,6 +695,8 @@ def _compact_aux(e):
     for k in ('mfma_frac_whole_step', 'decoder_steps', 'cluster_handoff_flags'):
         if k in e:
             out[k] = e[k]
+    if isinstance(e.get('greedy_infer'), dict):
+        out['greedy_infer_tokens_per_s'] = e['greedy_infer'].get('tokens_per_s')
     if isinstance(e.get('parity'), dict):
         out['parity'] = _numbers_only(e['parity'], ('loss_rel_err_vs_oracle', 'per_utterance_loss_rel_err_max',
                                                     'greedy_label_mismatch', 'greedy_labels_compared'))

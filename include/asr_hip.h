@@ -501,6 +501,33 @@ typedef struct asr_att_decoder {
   float *dc0, *dh0;                             /* [B,U] out: gradient w.r.t. the initial state */
 } asr_att_decoder;
 int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_stream s);
+/* ---- greedy inference, native ------------------------------------------------------------------------------ *
+ * dynamic_decode over a GreedyEmbeddingHelper with impute_finished (attention_seq2seq.py:462-509,
+ * decoders/dynamic_decoder.py:148-197): the reference's in-graph while_loop, here ONE call that issues, per step, the
+ * forward step of asr_att_decoder_fwd, the attentional-vector FC + tanh, the output layer, and a selection kernel
+ * (argmax -> emitted id, per-row finished flag, embedding of the id into the next step's input row, imputed context).
+ * `a` as for asr_att_decoder_fwd with To = max_decode_length, dmask NULL, a->live == f->live ([To+1,B], row 0 set by the
+ * caller: 1 for rows that decode), gates_all / craw_all / qz_all ONE step long (reused), snorm_all [To,B] or NULL;
+ * dec_in row 0 = embedding(start token) | zero context | initial h.  Outputs: ids_all [To,B] (0 once a row has
+ * finished), logits_all [To,B,C2] and av_all [To,B,U] (NOT imputed: multiply by live[k] for the reference's emitted
+ * fields), a->alpha_all [To,B,T], live [To+1,B], live_count [To+1] (live rows at the START of step k; entry 0 is the
+ * caller's).  The number of decoded steps is the first k with live_count[k] == 0 (or To).
+ * Early exit: with host_live_count (pinned host int32 [To+1]) and check_every > 0 the call stops issuing steps once a
+ * check point's asynchronous copy shows no live row; it waits only for the copy of two check points ago (the issue loop
+ * stays 2-3 intervals ahead of the device, the pipeline is never drained); *steps_issued tells how many steps were
+ * enqueued (>= the number decoded). */
+typedef struct asr_att_infer {
+  const float *W_av, *W_out, *b_out;            /* [U+E2,U], [U,C2], [C2] or NULL */
+  const float *embedding;                       /* [vocabulary, Em] */
+  int C2, eos;
+  float *live;                                  /* [To+1,B] */
+  float *av_all, *logits_all;                   /* [To,B,U], [To,B,C2] */
+  int32_t *ids_all, *live_count;                /* [To,B], [To+1] */
+  int32_t *host_live_count;                     /* pinned host [To+1] or NULL */
+  int check_every;
+} asr_att_infer;
+int asr_att_decoder_infer(asr_handle* h, const asr_att_decoder* a, const asr_att_infer* f, int* steps_issued,
+                          asr_stream s);
 /* work: B*(5*U + 3*T + E2) floats.  dav_cell is consumed (its rows accumulate the query-path gradient in place). */
 int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_stream s);
 /* out[b, j] = x[b*ldx + j] + y[b*ldy + j], j < W (row blocks of wider arrays; out may alias x) */

@@ -93,6 +93,7 @@ SIGNATURES = {
     'asr_att_loc_energy_bwd': (_i, [_vp] * 8 + [_i, _i, _i, _i] + [_vp] * 6 + [_i, _vp]),
     'asr_att_decoder_fwd': (_i, [_vp, _vp, _vp]),
     'asr_att_decoder_bwd': (_i, [_vp, _vp, _vp]),
+    'asr_att_decoder_infer': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'asr_add_cols': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     'asr_tanh_fwd': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'asr_tanh_bwd': (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),

@@ -2134,44 +2134,168 @@ static bool att_fused_step(asr_handle* h, const asr_att_decoder* a, const float*
   return true;
 }
 
-extern "C" int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_stream s) {
-  if (!h) return ASR_ERR_INVALID_ARG;
-  DEC_TRY(dec_check(h, a, false));
+// One forward step of the decoder loop: cell-input GEMM -> cell -> query FC -> energies -> softmax + context.  k indexes
+// the step arrays that carry the recurrence (dec_in, av_in, c / h, alpha, live); ks the saved activations only the
+// backward reads (gates, raw cell, query: the inference loop reuses row 0).
+static int dec_fwd_step(asr_handle* h, const asr_att_decoder* a, int k, int ks, bool more, asr_stream s) {
   const int B = a->B, U = a->U, T = a->T, E2 = a->E2, Em = a->Em, A = a->A;
   const int Din = Em + E2 + U, Dav = U + E2;
   float* pre = a->work;                                    // [B,4U]
   float* hraw = pre + (size_t)B * 4 * U;                   // [B,U]
   float* energy = hraw + (size_t)B * U;                    // [B,T]
   float* ctx = energy + (size_t)B * T;                     // [B,E2]
-  for (int k = 0; k < a->To; ++k) {
-    float* din = a->dec_in + (size_t)k * B * Din;
-    float* dnext = (k + 1 < a->To) ? din + (size_t)B * Din : nullptr;
-    float* av = a->av_in + (size_t)k * B * Dav;
-    float* qz = a->qz_all + (size_t)k * B * A;
-    DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, 4 * U, Din, din, Din, a->W_cell, 4 * U, pre, 4 * U, a->b_cell, 0, 0, s));
-    // the cell output (times its dropout mask) lands in av[:, :U]; without a query FC it IS the query
-    DEC_TRY(asr_lstm_cell_fwd_ex(h, pre, a->c_all + (size_t)k * B * U, a->h_all + (size_t)k * B * U, a->peep,
-                                 a->live + (size_t)k * B, B, U, a->forget_bias, a->cell_clip,
-                                 a->gates_all + (size_t)k * B * 4 * U, a->craw_all + (size_t)k * B * U,
-                                 a->c_all + (size_t)(k + 1) * B * U, a->h_all + (size_t)(k + 1) * B * U, hraw,
-                                 a->dmask ? a->dmask + (size_t)k * B * U : nullptr, a->has_query_fc ? nullptr : qz,
-                                 dnext ? dnext + Em + E2 : nullptr, Din, av, Dav, s));
-    if (a->has_query_fc)
-      DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, A, U, av, Dav, a->W_q, a->ld_wq, qz, A, a->b_q, 0, 0, s));
-    if (att_fused_step(h, a, qz, a->alpha_all + (size_t)k * B * T, ctx, av + U, Dav, dnext ? dnext + Em : nullptr, Din, s)) {
-      ASR_CHECK_LAUNCH(h, "asr_att_decoder_fwd(fused step)");
-      continue;
-    }
-    if (a->carry_alpha)
-      DEC_TRY(loc_energy_fwd_launch(h, k > 0 ? a->alpha_all + (size_t)(k - 1) * B * T : a->alpha_zero, a->filt, a->wfil,
-                                    a->keys, qz, a->v, T, B, A, a->taps, energy, a->seq_len, s));
-    else
-      DEC_TRY(energy_fwd_launch(h, a->keys, qz, a->v, T, B, A, a->att_mode, energy, a->seq_len, s));
-    DEC_TRY(asr_att_softmax_ctx_fwd_ex(h, energy, a->seq_len, a->sharpening, a->enc, a->enc_dtype, T, B, E2,
-                                       a->alpha_all + (size_t)k * B * T, ctx,
-                                       a->snorm_all ? a->snorm_all + (size_t)k * B : nullptr, av + U, Dav,
-                                       dnext ? dnext + Em : nullptr, Din, s));
+  float* din = a->dec_in + (size_t)k * B * Din;
+  float* dnext = more ? din + (size_t)B * Din : nullptr;
+  float* av = a->av_in + (size_t)k * B * Dav;
+  float* qz = a->qz_all + (size_t)ks * B * A;
+  DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, 4 * U, Din, din, Din, a->W_cell, 4 * U, pre, 4 * U, a->b_cell, 0, 0, s));
+  // the cell output (times its dropout mask) lands in av[:, :U]; without a query FC it IS the query
+  DEC_TRY(asr_lstm_cell_fwd_ex(h, pre, a->c_all + (size_t)k * B * U, a->h_all + (size_t)k * B * U, a->peep,
+                               a->live + (size_t)k * B, B, U, a->forget_bias, a->cell_clip,
+                               a->gates_all + (size_t)ks * B * 4 * U, a->craw_all + (size_t)ks * B * U,
+                               a->c_all + (size_t)(k + 1) * B * U, a->h_all + (size_t)(k + 1) * B * U, hraw,
+                               a->dmask ? a->dmask + (size_t)k * B * U : nullptr, a->has_query_fc ? nullptr : qz,
+                               dnext ? dnext + Em + E2 : nullptr, Din, av, Dav, s));
+  if (a->has_query_fc)
+    DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, A, U, av, Dav, a->W_q, a->ld_wq, qz, A, a->b_q, 0, 0, s));
+  if (att_fused_step(h, a, qz, a->alpha_all + (size_t)k * B * T, ctx, av + U, Dav, dnext ? dnext + Em : nullptr, Din, s)) {
+    ASR_CHECK_LAUNCH(h, "asr_att_decoder_fwd(fused step)");
+    return ASR_OK;
   }
+  if (a->carry_alpha)
+    DEC_TRY(loc_energy_fwd_launch(h, k > 0 ? a->alpha_all + (size_t)(k - 1) * B * T : a->alpha_zero, a->filt, a->wfil,
+                                  a->keys, qz, a->v, T, B, A, a->taps, energy, a->seq_len, s));
+  else
+    DEC_TRY(energy_fwd_launch(h, a->keys, qz, a->v, T, B, A, a->att_mode, energy, a->seq_len, s));
+  DEC_TRY(asr_att_softmax_ctx_fwd_ex(h, energy, a->seq_len, a->sharpening, a->enc, a->enc_dtype, T, B, E2,
+                                     a->alpha_all + (size_t)k * B * T, ctx,
+                                     a->snorm_all ? a->snorm_all + (size_t)k * B : nullptr, av + U, Dav,
+                                     dnext ? dnext + Em : nullptr, Din, s));
+  return ASR_OK;
+}
+
+extern "C" int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  DEC_TRY(dec_check(h, a, false));
+  const int B = a->B, U = a->U, T = a->T, E2 = a->E2, Em = a->Em, A = a->A;
+  const int Din = Em + E2 + U, Dav = U + E2;
+  for (int k = 0; k < a->To; ++k) DEC_TRY(dec_fwd_step(h, a, k, k, k + 1 < a->To, s));
+  (void)B; (void)U; (void)T; (void)E2; (void)Em; (void)A; (void)Din; (void)Dav;
+  return ASR_OK;
+}
+
+// ---------------------------------------------------------------- greedy inference loop, native
+namespace {
+// One workgroup per batch row, behind the output layer of decoder step k: id = argmax(logits) (first maximum wins, as
+// asr_argmax_rows), emitted id = id for a row that was live at the start of the step and 0 otherwise (impute_finished),
+// live[k+1] = live[k] && id != eos, live_count[k+1] += live[k+1]; the NEXT step's input row gets the embedding of id
+// (whatever the row's state: GreedyEmbeddingHelper.next_inputs does not look at `finished`) and its context columns
+// are zeroed for rows that had finished before this step (dynamic_decode zeroes next_inputs' attention part with the
+// imputed outputs, dynamic_decoder.py:172-190).
+__global__ __launch_bounds__(256) void att_infer_select_kernel(const float* __restrict__ logits, int C2, int eos,
+                                                               const float* __restrict__ live_k, float* __restrict__ live_n,
+                                                               int32_t* __restrict__ count_n, int32_t* __restrict__ ids,
+                                                               const float* __restrict__ emb, int Em, float* __restrict__ dnext,
+                                                               int Din, int E2) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* p = logits + (size_t)b * C2;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int k = threadIdx.x; k < C2; k += 256) {
+    const float v = p[k];
+    if (v > best || (v == best && k < bi)) { best = v; bi = k; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { sv[w] = best; si[w] = bi; }
+  __syncthreads();
+  best = sv[0]; bi = si[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (sv[i] > best || (sv[i] == best && si[i] < bi)) { best = sv[i]; bi = si[i]; }
+  const int id = bi == 0x7fffffff ? 0 : bi;
+  const float lv = live_k[b];
+  if (threadIdx.x == 0) {
+    ids[b] = lv != 0.f ? id : 0;
+    const float ln = (lv != 0.f && id != eos) ? 1.f : 0.f;
+    live_n[b] = ln;
+    if (ln != 0.f) atomicAdd(count_n, 1);
+  }
+  if (dnext) {
+    float* d = dnext + (size_t)b * Din;
+    const float* e = emb + (size_t)id * Em;
+    for (int j = threadIdx.x; j < Em; j += 256) d[j] = e[j];
+    if (lv == 0.f)
+      for (int j = threadIdx.x; j < E2; j += 256) d[Em + j] = 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int asr_att_decoder_infer(asr_handle* h, const asr_att_decoder* a, const asr_att_infer* f, int* steps_issued,
+                                     asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  DEC_TRY(dec_check(h, a, false));
+  if (!f || !f->W_av || !f->W_out || !f->embedding || !f->live || !f->av_all || !f->logits_all || !f->ids_all ||
+      !f->live_count || f->C2 < 1 || f->eos < 0 || f->live != a->live || a->dmask)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_att_decoder_infer: bad arguments");
+  const int B = a->B, U = a->U, E2 = a->E2, Em = a->Em, To = a->To, C2 = f->C2;
+  const int Din = Em + E2 + U, Dav = U + E2;
+  hipStream_t st = (hipStream_t)s;
+  if (hipMemsetAsync(f->live_count + 1, 0, (size_t)To * sizeof(int32_t), st) != hipSuccess)
+    ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder_infer: memset");
+  // early exit without draining the pipeline: every `check_every` steps the count of live rows at that step is copied to
+  // the caller's pinned words behind the step's kernels.  A check point looks at the newest copy that has ALREADY landed
+  // and, so that the host cannot run arbitrarily far past the end of the decode (it enqueues a step in a fraction of the
+  // time the device takes to run one), waits for the copy of two check points ago: the issue loop stays 2 .. 3 intervals
+  // ahead of the device, never idle, and at most that many surplus steps are enqueued.  The result does not depend on how
+  // many were: a step with no live row changes nothing but its own (imputed: zero) outputs, and the caller trims at the
+  // first such step.
+  constexpr int NEV = 3;
+  hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr};
+  const int every = (f->host_live_count && f->check_every > 0) ? f->check_every : 0;
+  if (every) {
+    for (int i = 0; i < NEV; ++i)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
+        ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder_infer: event");
+  }
+  int rc = ASR_OK, k = 0;
+  for (; k < To; ++k) {
+    if (every && k % every == 0 && k > 0) {
+      const int c = k / every;                             // this check point; c - 1 was recorded one interval ago
+      bool done = false;
+      if (c >= 3) {
+        (void)hipEventSynchronize(ev[(c - 2) % NEV]);
+        done = f->host_live_count[(c - 2) * every] == 0;
+      }
+      if (!done && c >= 2 && hipEventQuery(ev[(c - 1) % NEV]) == hipSuccess) done = f->host_live_count[(c - 1) * every] == 0;
+      if (done) break;
+      if (hipMemcpyAsync(f->host_live_count + k, f->live_count + k, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipEventRecord(ev[c % NEV], st) != hipSuccess) { rc = ASR_ERR_HIP; break; }
+    }
+    const bool more = k + 1 < To;
+    // (saved-activation arrays the backward would need are reused every step: index 0)
+    if ((rc = dec_fwd_step(h, a, k, 0, more, s)) != ASR_OK) break;
+    float* av = f->av_all + (size_t)k * B * U;
+    float* lg = f->logits_all + (size_t)k * B * C2;
+    if ((rc = asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, U, Dav, a->av_in + (size_t)k * B * Dav, Dav, f->W_av, U, av, U, nullptr,
+                           0, 0, s)) != ASR_OK) break;
+    if ((rc = asr_tanh_fwd(h, av, av, (size_t)B * U, s)) != ASR_OK) break;
+    if ((rc = asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, C2, U, av, U, f->W_out, C2, lg, C2, f->b_out, 0, 0, s)) != ASR_OK) break;
+    hipLaunchKernelGGL(att_infer_select_kernel, dim3(B), dim3(256), 0, st, lg, C2, f->eos, f->live + (size_t)k * B,
+                       f->live + (size_t)(k + 1) * B, f->live_count + k + 1, f->ids_all + (size_t)k * B, f->embedding, Em,
+                       more ? a->dec_in + (size_t)(k + 1) * B * Din : nullptr, Din, E2);
+  }
+  if (every)
+    for (int i = 0; i < NEV; ++i) (void)hipEventDestroy(ev[i]);
+  if (rc != ASR_OK) ASR_FAIL(h, rc, "asr_att_decoder_infer: step %d failed", k);
+  ASR_CHECK_LAUNCH(h, "asr_att_decoder_infer");
+  if (steps_issued) *steps_issued = k;
   return ASR_OK;
 }
 

@@ -489,9 +489,64 @@ class AttentionSeq2Seq(ModelBase):
         raise NotImplementedError
 
     # ------------------------------------------------------------------ inference
-    def _decode_infer(self, inputs, isl):
-        """GreedyEmbeddingHelper decode (attention_seq2seq.py:462-509): AttentionDecoder.step under dynamic_decode, at
-        most max_decode_length steps, impute_finished.  Returns the predicted ids [B, <= max_decode_length]."""
+    def _decode_infer(self, inputs, isl, native=True):
+        """GreedyEmbeddingHelper decode (attention_seq2seq.py:462-509, the reference's in-graph while_loop): at most
+        max_decode_length steps, impute_finished.  Returns the predicted ids [B, <= max_decode_length].
+        native=True: ONE call (ops.att_decoder_infer -> asr_att_decoder_infer) issues every step -- decoder cell,
+        attention, attentional vector, output layer, argmax, embedding of the chosen id, finished flags -- without the
+        host looking at the device until the end (one read-back of the per-step live counts); native=False: the
+        class-surface loop below (AttentionDecoder.step under dynamic_decode: one device sync per token), kept as the
+        reference-shaped form and as the oracle of the native one (ids identical, tests/test_gpu_attention.py)."""
+        if not native:
+            return self._decode_infer_class_surface(inputs, isl)
+        st, dev = self.store, self.device
+        B = inputs.shape[0]
+        enc, seq_p = self._encode(inputs, isl, 1.0, False)
+        T, Bp, E2 = enc.shape
+        cf, hf = self.encoder._final_ch
+        _, c, h = self._bridge(cf, hf, B)
+        U, Em, A = self.decoder_num_units, self.embedding_dim, self.key_dim
+        To, Din = int(self.max_decode_length), self.dec_in_dim
+        keys = self._keys(enc)
+        enc_att = self.encoder._out_op.contiguous() if self.dtype == ASR_BF16 else enc
+        has_q = self.attention_type in AL.HAS_QUERY_FC
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)          # noqa: E731
+        dec_in = f32(To, Bp, Din)
+        emb0 = ops.embedding_gather(st['output_embedding/W_embedding'],
+                                    torch.full((Bp,), self.sos_index, dtype=torch.int32, device=dev))
+        dec_in[0, :, :Em].copy_(emb0)
+        dec_in[0, :, Em:Em + E2].zero_()
+        dec_in[0, :, Em + E2:].copy_(h)
+        c_all, h_all = f32(To + 1, Bp, U), f32(To + 1, Bp, U)
+        c_all[0].copy_(c)
+        h_all[0].copy_(h)
+        live = torch.zeros((To + 1, Bp), dtype=torch.float32, device=dev)
+        live[0, :B] = 1.0                                    # rows B.. are the zero-length padding of the batch tile
+        loop = dict(To=To, B=Bp, T=T, U=U, Em=Em, E2=E2, A=A, att_mode=self.att_mode, has_query_fc=int(has_q),
+                    carry_alpha=int(self.carry_alpha), taps=int(st[AT + 'filter'].shape[0]) if self.carry_alpha else 0,
+                    enc_dtype=ops.dtype_id(enc_att.dtype), forget_bias=1.0,
+                    cell_clip=float(self.clip_activation_decoder or 0.0), sharpening=float(self.sharpening_factor),
+                    W_cell=st[D + 'lstm_cell/kernel'], b_cell=st[D + 'lstm_cell/bias'], peep=self._peep(),
+                    W_q=self._wq() if has_q else None,
+                    b_q=st[AT + 'W_filter/biases'] if (has_q and self.attention_type in AL.HAS_FILTER) else None,
+                    v=st[AT + 'v_a'] if self.att_mode == 0 else None, keys=keys, enc=enc_att, seq_len=seq_p,
+                    filt=st[AT + 'filter'] if self.carry_alpha else None,
+                    wfil=st[AT + 'W_filter/weights'] if self.carry_alpha else None,
+                    alpha_zero=torch.zeros((Bp, T), dtype=torch.float32, device=dev) if self.carry_alpha else None,
+                    live=live, dmask=None, dec_in=dec_in, av_in=f32(To, Bp, U + E2), alpha_all=f32(To, Bp, T),
+                    snorm_all=f32(To, Bp) if self.sigmoid_smoothing else None,
+                    gates_all=f32(1, Bp, 4 * U), craw_all=f32(1, Bp, U), c_all=c_all, h_all=h_all, qz_all=f32(1, Bp, A))
+        out = ops.att_decoder_infer(loop, st[D + 'attentional_vector/weights'], st[D + 'output_layer/weights'],
+                                    st[D + 'output_layer/biases'], st['output_embedding/W_embedding'], self.eos_index,
+                                    n_live=B)
+        counts = out['live_count'].cpu().numpy()             # the ONE synchronisation of the decode
+        dead = np.flatnonzero(counts[:out['steps_issued'] + 1] == 0)
+        n = int(dead[0]) if len(dead) else min(To, out['steps_issued'])
+        self._infer_raw = dict(out, alpha=loop['alpha_all'], steps=n, B=B)     # un-imputed fields, for visualisation
+        return out['ids'][:n, :B].t().contiguous()
+
+    def _decode_infer_class_surface(self, inputs, isl):
+        """The reference-shaped inference path: AttentionDecoder.step under dynamic_decode (one device sync per token)."""
         st, dev = self.store, self.device
         B = inputs.shape[0]
         enc, seq_p = self._encode(inputs, isl, 1.0, False)
@@ -508,14 +563,14 @@ class AttentionSeq2Seq(ModelBase):
         outputs, _ = decoder((c, h), helper)
         return outputs.predicted_ids[:B]
 
-    def infer(self, inputs, inputs_seq_len):
+    def infer(self, inputs, inputs_seq_len, native=True):
         """Greedy inference ids [B, <= max_decode_length] (numpy) for a batch of features -- what running the
         reference's `decode_op_infer` with a feed_dict of inputs / inputs_seq_len / keep_prob = 1 returns
-        (examples/timit/metrics/attention.py:80-86)."""
+        (examples/timit/metrics/attention.py:80-86).  native: see _decode_infer."""
         self.encoder._lens_host = ops.host_ints(inputs_seq_len)
         inputs = ops.to_device(inputs, torch.float32, self.device)
         isl = ops.to_device(inputs_seq_len, torch.int32, self.device)
-        return self._decode_infer(inputs, isl).cpu().numpy()
+        return self._decode_infer(inputs, isl, native=native).cpu().numpy()
 
     def decode(self, decoder_outputs_train, decoder_outputs_infer):
         """attention_seq2seq.py:666-701."""

@@ -1119,6 +1119,44 @@ def att_decoder_bwd(a):
     h.check(h.lib.asr_att_decoder_bwd(h.h, C.byref(st), _s()), 'asr_att_decoder_bwd')
 
 
+class _AttInfer(C.Structure):
+    """struct asr_att_infer (include/asr_hip.h), field for field."""
+    _fields_ = [('W_av', C.c_void_p), ('W_out', C.c_void_p), ('b_out', C.c_void_p), ('embedding', C.c_void_p),
+                ('C2', C.c_int), ('eos', C.c_int), ('live', C.c_void_p), ('av_all', C.c_void_p), ('logits_all', C.c_void_p),
+                ('ids_all', C.c_void_p), ('live_count', C.c_void_p), ('host_live_count', C.c_void_p), ('check_every', C.c_int)]
+
+
+def att_decoder_infer(a, W_av, W_out, b_out, embedding, eos, n_live, check_every=8):
+    """Greedy inference loop (asr_att_decoder_infer): `a` as for att_decoder_fwd with To = max_decode_length and
+    a['live'] a [To+1,B] tensor whose row 0 marks the rows that decode.  Returns a dict: ids [To,B] int32 (imputed),
+    logits [To,B,C2], av [To,B,U], live [To+1,B], live_count [To+1] int32 (all on the device, nothing synchronised) and
+    steps_issued (host int)."""
+    h = _h(a['dec_in'])
+    dev = a['dec_in'].device
+    To, B, U = a['To'], a['B'], a['U']
+    C2 = W_out.shape[1]
+    if a.get('work') is None:
+        a['work'] = _f32((B * (5 * U + a['T'] + a['E2']),), dev)
+    out = dict(ids=torch.empty((To, B), dtype=torch.int32, device=dev), logits=_f32((To, B, C2), dev), av=_f32((To, B, U), dev),
+               live=a['live'], live_count=torch.empty((To + 1,), dtype=torch.int32, device=dev))
+    out['live_count'][:1].fill_(int(n_live))
+    host = torch.ones((To + 1,), dtype=torch.int32).pin_memory() if check_every else None
+    st = _att_decoder_struct(a)
+    f = _AttInfer()
+    for n, t in (('W_av', W_av), ('W_out', W_out), ('b_out', b_out), ('embedding', embedding), ('live', a['live']),
+                 ('av_all', out['av']), ('logits_all', out['logits']), ('ids_all', out['ids']), ('live_count', out['live_count'])):
+        if t is not None and (not t.is_cuda or not t.is_contiguous()):
+            raise ValueError('att_decoder_infer: %s must be a contiguous device tensor' % n)
+        setattr(f, n, t.data_ptr() if t is not None else None)
+    f.C2, f.eos, f.check_every = int(C2), int(eos), int(check_every or 0)
+    f.host_live_count = host.data_ptr() if host is not None else None
+    issued = C.c_int(0)
+    h.check(h.lib.asr_att_decoder_infer(h.h, C.byref(st), C.byref(f), C.byref(issued), _s()), 'asr_att_decoder_infer')
+    out['steps_issued'] = issued.value
+    out['_host'] = host                      # keeps the pinned words alive until the caller has synchronised
+    return out
+
+
 def tanh_fwd(x):
     h = _h(x)
     y = torch.empty_like(x)

@@ -583,6 +583,53 @@ def _att_decoder_fwd(a):
                              ctx_also=(av_in[k, :, U:], nxt[:, Em:Em + E2] if nxt is not None else None))
 
 
+def _att_decoder_infer(a, W_av, W_out, b_out, embedding, eos, n_live, check_every=8):
+    """asr_att_decoder_infer: every step = the forward step above (saved activations reused: row 0), attentional vector,
+    output layer, the selection (argmax, emitted id, finished flag, next input row)."""
+    To, B, U, Em, E2, T = a['To'], a['B'], a['U'], a['Em'], a['E2'], a['T']
+    dec_in, av_in, c_all, h_all, live = a['dec_in'], a['av_in'], a['c_all'], a['h_all'], a['live']
+    C2 = W_out.shape[1]
+    out = dict(ids=torch.zeros((To, B), dtype=torch.int32), logits=torch.zeros((To, B, C2)), av=torch.zeros((To, B, U)),
+               live=live, live_count=torch.zeros((To + 1,), dtype=torch.int32))
+    out['live_count'][0] = int(n_live)
+    issued = To
+    for k in range(To):
+        if check_every and k > 0 and k % check_every == 0 and int(out['live_count'][k]) == 0:
+            issued = k           # (the device form may issue a few steps more; the result is trimmed the same way)
+            break
+        pre = _gemm(dec_in[k], a['W_cell'], bias=a['b_cell'])
+        nxt = dec_in[k + 1] if k + 1 < To else None
+        gates, c_raw, c_new, h_new, _, cell_out = _lstm_cell_fwd(
+            pre, c_all[k], h_all[k], a.get('peep'), live[k], a['forget_bias'], a['cell_clip'], out_mask=None,
+            want_cell_out=True, h_also=nxt[:, Em + E2:] if nxt is not None else None, cell_out_also=av_in[k, :, :U])
+        c_all[k + 1].copy_(c_new)
+        h_all[k + 1].copy_(h_new)
+        qz = _gemm(cell_out, a['W_q'], bias=a.get('b_q')) if a['has_query_fc'] else cell_out
+        if a['carry_alpha']:
+            energy = _att_loc_energy_fwd(a['alpha_all'][k - 1] if k > 0 else a['alpha_zero'], a['filt'], a['wfil'],
+                                         a.get('keys'), qz, a['v'], T)
+        else:
+            energy = _att_energy_fwd(a.get('keys'), qz, a.get('v'), T, a['att_mode'])
+        sn = a.get('snorm_all')
+        _att_softmax_ctx_fwd(energy, a['seq_len'], a['sharpening'], a['enc'], alpha_out=a['alpha_all'][k],
+                             sigmoid_norm=sn[k] if sn is not None else None,
+                             ctx_also=(av_in[k, :, U:], nxt[:, Em:Em + E2] if nxt is not None else None))
+        av = _tanh_fwd(_gemm(av_in[k], W_av))
+        lg = _gemm(av, W_out, bias=b_out)
+        out['av'][k].copy_(av)
+        out['logits'][k].copy_(lg)
+        ids = _argmax_rows(lg)
+        lv = live[k]
+        out['ids'][k].copy_((ids.float() * lv).to(torch.int32))
+        live[k + 1].copy_(lv * (ids != int(eos)).float())
+        out['live_count'][k + 1] = int(live[k + 1].sum())
+        if nxt is not None:
+            nxt[:, :Em].copy_(_embedding_gather(embedding, ids))
+            nxt[:, Em:Em + E2].mul_(lv.unsqueeze(1))
+    out['steps_issued'] = issued
+    return out
+
+
 def _att_decoder_bwd(a):
     """asr_att_decoder_bwd, step for step."""
     To, B, U, Em, E2 = a['To'], a['B'], a['U'], a['Em'], a['E2']
@@ -749,7 +796,7 @@ STAND_INS = dict(
     embedding_gather=_embedding_gather, embedding_scatter=_embedding_scatter, seq_xent=_seq_xent,
     argmax_rows=_argmax_rows, im2col3x3=_im2col3x3, col2im3x3=_col2im3x3, maxpool2x2_fwd=_maxpool2x2_fwd,
     maxpool2x2_bwd=_maxpool2x2_bwd, im2col=_im2col, col2im=_col2im, att_decoder_fwd=_att_decoder_fwd,
-    att_decoder_bwd=_att_decoder_bwd,
+    att_decoder_bwd=_att_decoder_bwd, att_decoder_infer=_att_decoder_infer,
 )
 
 

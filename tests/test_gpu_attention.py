@@ -313,6 +313,47 @@ def test_attention_model_parity_carried_alpha_and_long_inputs(cuda, att, sig, B,
     assert np.array_equal(out_infer.predicted_ids.cpu().numpy(), ref_ids)
 
 
+@pytest.mark.parametrize('att,prev,sig,dtype', [('location', 'carry', False, 'f32'), ('hybrid', 'zeros', False, 'bf16'),
+                                               ('bahdanau_content', 'zeros', True, 'f32'), ('luong_dot', 'zeros', False, 'f32')])
+def test_native_greedy_inference_loop(cuda, att, prev, sig, dtype):
+    """asr_att_decoder_infer (every decoder step, the output head, argmax, the embedding of the chosen id and the
+    per-row finished flags issued from one call; one read-back at the end) against the class-surface path
+    (AttentionDecoder.step under dynamic_decode, a device sync per token) and against oracle.attention: ids identical,
+    same number of emitted steps.  The end-of-sequence bias is set so that (a) no row ever finishes (all 40 steps), (b) rows
+    finish at different steps (imputed zeros behind the first EOS, state copy-through, zeroed context input), (c) every
+    row finishes at once (one step; the early exit must not change the result).  Reference:
+    models/attention/attention_seq2seq.py:462-509, decoders/dynamic_decoder.py:148-197."""
+    from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
+    rng = np.random.RandomState(5)
+    B, T, D, H, L, U, A, Em, C = 5, 70, 12, 64, 1, 128, 32, 8, 9
+    if att == 'luong_dot':
+        U = 2 * H
+    x, sl, labels, lsl, _ = _batch(rng, B, T, D, C)
+    model = AttentionSeq2Seq(input_size=D, encoder_type='blstm', encoder_num_units=H, encoder_num_layers=L,
+                             encoder_num_proj=None, attention_type=att, attention_dim=A, decoder_type='lstm',
+                             decoder_num_units=U, decoder_num_layers=1, embedding_dim=Em, num_classes=C, sos_index=C,
+                             eos_index=C + 1, max_decode_length=40, parameter_init=0.1, clip_grad_norm=5.0,
+                             clip_activation_encoder=50, clip_activation_decoder=50, dtype=dtype, seed=5,
+                             sharpening_factor=1.5, sigmoid_smoothing=sig, prev_alpha=prev)
+    lens = []
+    for eos_bias in (-50.0, 0.35, 50.0):
+        sd = {k: v.clone() for k, v in model.store.state_dict().items()}
+        sd['attention_decoder/decoder/output_layer/biases'][C + 1] = eos_bias
+        model.store.load_state_dict(sd)
+        ids_native = model.infer(x, sl, native=True)
+        raw = model._infer_raw
+        ids_class = model.infer(x, sl, native=False)
+        assert ids_native.shape == ids_class.shape and np.array_equal(ids_native, ids_class), (eos_bias, ids_native, ids_class)
+        assert raw['steps'] == ids_native.shape[1] and raw['steps_issued'] >= raw['steps']
+        lens.append(ids_native.shape[1])
+        if dtype == 'f32':
+            sdn = {k: v.cpu().numpy() for k, v in sd.items()}
+            ref_ids = oatt.attention_model_infer(sdn, x, sl, L, att, C, C + 1, 40, clip_enc=50.0, clip_dec=50.0,
+                                                 sharpening=1.5, sigmoid_smoothing=sig, prev_alpha=prev)
+            assert np.array_equal(ids_native, ref_ids), eos_bias
+    assert lens[0] == 40 and lens[2] == 1 and 1 <= lens[1] <= 40
+
+
 @pytest.mark.parametrize('case', ['location_zeros_bf16', 'bahdanau_sigmoid_f32', 'location_carry_bf16', 'hybrid_carry_f32',
                                   'luong_dot_small', 'bahdanau_sigmoid_f32/one_step', 'location_carry_bf16/one_step'])
 def test_native_decoder_loop_against_the_step_by_step_statement(cuda, case):
