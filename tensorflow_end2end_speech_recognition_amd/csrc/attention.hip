@@ -480,6 +480,24 @@ __global__ void att_ctx_reduce_kernel(const float* __restrict__ part, int nch, i
   if (ctx3) ctx3[(size_t)(i / E) * ld3 + i % E] = c;
 }
 
+// 16-byte vectors of an encoder row in either storage type
+template <typename TE> struct EncVec;
+template <> struct EncVec<float> {
+  static constexpr int N = 4;
+  typedef f32x4_t raw_t;
+  static __device__ __forceinline__ void unpack(const raw_t& r, float* o) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = r[i];
+  }
+};
+template <> struct EncVec<bf16_t> {
+  static constexpr int N = 8;
+  typedef bf16x8_t raw_t;
+  static __device__ __forceinline__ void unpack(const raw_t& r, float* o) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32((bf16_t)r[i]);
+  }
+};
 // ---------------------------------------------------------------- energies + softmax + context in ONE pass (decoder loop)
 // A decoder step used to be energies -> softmax -> partial context -> reduction: four dependent launches of 4-12 us each
 // with ~4 us of queue latency between them (profiles/r03_cfgD_kernel_trace.md).  The softmax does not need a launch of
@@ -560,6 +578,9 @@ __global__ __launch_bounds__(256) void att_fused_fwd_kernel(const float* __restr
   }
   __syncthreads();
   const size_t rs = (size_t)B * E;
+  // (Measured, round 4: a form of this phase with one 16-byte vector per thread, the 256 threads split into frame groups
+  // and 16 rows requested per trip -- 32 KB in flight per wave instead of a few rows -- takes 16.7 us per launch at
+  // cfg D against 15.7 for this loop: the launch is not bound by the loads in flight per thread.)
   for (int e4 = tid; e4 < E / 4; e4 += 256) {
     const TE* pe = enc + ((size_t)t0 * B + b) * E + e4 * 4;
     f32x4_t c = {0.f, 0.f, 0.f, 0.f};
@@ -597,9 +618,14 @@ __global__ __launch_bounds__(256) void att_fused_combine_kernel(const float* __r
     const int e = (blockIdx.x % epb) * 256 + tid;
     const size_t BE = (size_t)B * E, i = (size_t)b * E + e;
     float c = 0.f;
+    // (every partial is REQUESTED -- a load behind `if (w > 0)` cannot leave before the one in front of it has been
+    // tested, and 25 dependent round trips were this kernel's 10 us -- but the partials of chunks past the length were
+    // never written and are not used: a select, not a multiplication by zero)
+#pragma unroll 8
     for (int k = 0; k < nch; ++k) {                                    // fixed order
       const float wk = w[k];
-      if (wk > 0.f) c += part[(size_t)k * BE + i] * wk;                // (chunks past the length were never written)
+      const float pv = part[(size_t)k * BE + i];
+      c += wk > 0.f ? pv * wk : 0.f;
     }
     ctx[i] = c;
     if (ctx2) ctx2[(size_t)b * ld2 + e] = c;
@@ -646,24 +672,9 @@ __global__ __launch_bounds__(256) void att_dalpha_kernel(const float* __restrict
 // rate of att_ctx_partial_kernel over the same bytes).  dctx = dctx_a (+ dctx_b, row stride ldb): inside the loop the
 // attentional-vector part plus the context columns of the next step's cell-input gradient; the sum is also written
 // to dctx_out (by the first workgroup of each utterance) for the d_enc contraction after the loop.
-template <typename TE> struct EncVec;
-template <> struct EncVec<float> {
-  static constexpr int N = 4;
-  typedef f32x4_t raw_t;
-  static __device__ __forceinline__ void unpack(const raw_t& r, float* o) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = r[i];
-  }
-};
-template <> struct EncVec<bf16_t> {
-  static constexpr int N = 8;
-  typedef bf16x8_t raw_t;
-  static __device__ __forceinline__ void unpack(const raw_t& r, float* o) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32((bf16_t)r[i]);
-  }
-};
-template <typename TE, int G>
+// FPT = frames per trip of a wave (their FPT * G sixteen-byte loads are all requested before the first multiply).  Four:
+// sixteen per trip (one trip per 64-frame chunk and wave) measured 16.6 us per launch at cfg D against 15.1 (round 4).
+template <typename TE, int G, int FPT = 4>
 __global__ __launch_bounds__(256) void att_dalpha_vec_kernel(const float* __restrict__ dctx_a,
                                                              const float* __restrict__ dctx_b, int ldb,
                                                              float* __restrict__ dctx_out,
@@ -695,18 +706,18 @@ __global__ __launch_bounds__(256) void att_dalpha_vec_kernel(const float* __rest
     }
   }
   float wdot = 0.f;
-  for (int tb = t0 + wave * 4; tb < t1; tb += 16) {
-    typename V::raw_t x[4][G];
+  for (int tb = t0 + wave * FPT; tb < t1; tb += 4 * FPT) {
+    typename V::raw_t x[FPT][G];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < FPT; ++f) {
       const int t = min(tb + f, t1 - 1);
 #pragma unroll
       for (int g = 0; g < G; ++g)
         x[f][g] = *reinterpret_cast<const typename V::raw_t*>(enc + ((size_t)t * B + b) * E + (g * 64 + lane) * N);
     }
-    float sum[4];
+    float sum[FPT];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < FPT; ++f) {
       float acc = 0.f;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -719,7 +730,7 @@ __global__ __launch_bounds__(256) void att_dalpha_vec_kernel(const float* __rest
     }
     if (lane == 0) {
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < FPT; ++f)
         if (tb + f < t1) {
           da[(size_t)b * T + tb + f] = sum[f];
           if (dotp) wdot += alpha[(size_t)b * T + tb + f] * sum[f];
