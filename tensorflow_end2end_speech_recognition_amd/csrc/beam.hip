@@ -32,8 +32,19 @@
 // Merged pairs are handled in the stay candidates and do not depend on the pruning; insertion
 // indices still use the real class id, so the reference's tie order is unchanged.
 // HBM/latency-bound integer+fp64 work; nothing here is GEMM-shaped.
+//
+// Round 4: the candidate keys of a frame live in LDS (orderable u64 of the fp64 total; 0 = excluded) whenever they fit --
+// with the class pruning they are W (W + 2) ~ 10 k keys = 80 KB -- instead of fp64 totals in global memory re-read by every
+// pass of the radix select; the digit of a radix pass is chosen by one wave with a suffix scan over the 256 bins instead of
+// thread 0 walking them; the ordered compaction of the kept classes is one pass with a block-wide prefix sum instead of
+// C / 256 rounds of two barriers each; and the two radix selects NARROW: a thread keeps its share of the keys in
+// registers, a key that falls out of (or is decided by) a pass is dropped from the later ones, and the select stops at
+// the first pass whose chosen bin holds exactly the number of keys still wanted (usually the third or fourth of twelve).
+// Same candidates, same composite keys, same winners: the result is bit-identical.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -66,6 +77,71 @@ __device__ __forceinline__ unsigned long long hmix(unsigned long long h, int c) 
   return x;
 }
 
+// One radix pass' decision, by ONE wave (lane = threadIdx.x < 64): the reference walk
+//     for (d = 255; d > 0; --d) { if (hist[d] >= rem) break; rem -= hist[d]; }
+// as a suffix scan -- lane l owns bins 4 l .. 4 l + 3 (bin 0 never counts: the walk stops at d = 1 and falls through to 0).
+// Also returns the population of the chosen bin.
+__device__ __forceinline__ void pick_digit(const unsigned* hist, unsigned rem0, int lane, unsigned& digit, unsigned& rem,
+                                           unsigned& pop) {
+  const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+  const unsigned own = h1 + h2 + h3 + (lane ? h0 : 0u);
+  unsigned suf = own;                                      // inclusive suffix sum over lanes (lane 63 = highest bins)
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_down(suf, o, 64);
+    if (lane + o < 64) suf += v;
+  }
+  const unsigned above = suf - own;
+  const bool here = above < rem0 && (lane == 0 || rem0 <= suf);
+  unsigned d = 0, r = 0, p = 0;
+  if (here) {
+    unsigned acc = above;
+    if (acc + h3 >= rem0) { d = 4 * lane + 3; r = rem0 - acc; p = h3; }
+    else {
+      acc += h3;
+      if (acc + h2 >= rem0) { d = 4 * lane + 2; r = rem0 - acc; p = h2; }
+      else {
+        acc += h2;
+        if (acc + h1 >= rem0) { d = 4 * lane + 1; r = rem0 - acc; p = h1; }
+        else { acc += h1; d = 4 * lane; r = rem0 - acc; p = h0; }   // lane 0: digit 0, the walk's fall-through
+      }
+    }
+  }
+  const int src = __ffsll((unsigned long long)__ballot(here)) - 1;
+  digit = __shfl(d, src, 64);
+  rem = __shfl(r, src, 64);
+  pop = __shfl(p, src, 64);
+}
+
+// The keys a thread holds in registers (0 = dead) towards the histogram of byte `byte` (7 .. 0 of the 64-bit key; all
+// arithmetic on the 32-bit half the byte lives in).  The high-order bytes are mostly the same for every key (sign and
+// exponent of values a few units apart): a thread whose keys agree adds its count with ONE LDS atomic.
+template <int NK>
+__device__ __forceinline__ void hist_regs(unsigned* hist, const unsigned long long (&rk)[NK], int byte) {
+  const bool upper = byte >= 4;
+  const int ds = (byte & 3) * 8;
+  unsigned d0 = 0;
+  int n = 0;
+  bool uni = true;
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    const unsigned long long k = rk[i];
+    const unsigned d = ((upper ? (unsigned)(k >> 32) : (unsigned)k) >> ds) & 0xffu;
+    if (k != 0ull) {
+      if (n == 0) d0 = d;
+      uni = uni && d == d0;
+      ++n;
+    }
+  }
+  if (n == 0) return;
+  if (uni) { atomicAdd(&hist[d0], (unsigned)n); return; }
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    const unsigned long long k = rk[i];
+    if (k != 0ull) atomicAdd(&hist[((upper ? (unsigned)(k >> 32) : (unsigned)k) >> ds) & 0xffu], 1u);
+  }
+}
+
 struct Entry {            // one beam entry
   double pb, pnb;
   unsigned long long hash, phash;   // hash of the prefix / of its parent prefix
@@ -80,11 +156,21 @@ __device__ __forceinline__ unsigned digit_of(unsigned long long key, unsigned ni
 __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
     const float* __restrict__ logits, int T, int B, int C, const int32_t* __restrict__ seq_len,
     int blank, int W, double* __restrict__ tot_ws, int2* __restrict__ node_ws,
-    int32_t* __restrict__ out_labels, int32_t* __restrict__ out_len, double* __restrict__ out_score) {
+    int32_t* __restrict__ out_labels, int32_t* __restrict__ out_len, double* __restrict__ out_score, int lds_keys,
+    unsigned long long* __restrict__ dbg) {
+  // phase timers (ASR_BEAM_DBG=1): cycles of utterance 0's workgroup per phase, summed over the frames
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#define BEAM_T(k) do { if (dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[k] += now_ - tprev; tprev = now_; } } while (0)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lp = reinterpret_cast<double*>(smem);      // [C]
   int* kc = reinterpret_cast<int*>(lp + C);          // [C] kept classes of the frame, ascending
   int* kpos = kc + C;                                // [C] position of a class in kc, -1 if pruned
+  unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(smem + (((size_t)C * 16 + 15) & ~(size_t)15));   // [lds_keys]
+  __shared__ unsigned tcnt[BEAM_THREADS / 64];
+  __shared__ unsigned s_digit, s_exact;
+  __shared__ unsigned long long s_min[BEAM_THREADS / 64];
+  __shared__ unsigned long long w_tie;
   __shared__ double s_L[BEAM_MAX];                   // logsumexp(p_b, p_nb) of each beam entry
   __shared__ unsigned wcnt[BEAM_THREADS / 64];
   __shared__ int s_K;
@@ -108,7 +194,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Tb = min(max(seq_len[b], 0), T);
-  double* tot = tot_ws + (size_t)b * W * C;
+  unsigned long long* gkeys = reinterpret_cast<unsigned long long*>(tot_ws) + (size_t)b * ((size_t)W * C + W);
   int2* nodes = node_ws + (size_t)b * ((size_t)T * W + 1);
 
   if (tid == 0) {
@@ -121,23 +207,29 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
 
   for (int t = 0; t < Tb; ++t) {
     const int nb = s_nb;
+    if (dbg) tprev = __builtin_amdgcn_s_memtime();
     // ---- 1. fp64 log-softmax of the frame
     const float* row = logits + ((size_t)t * B + b) * C;
     float m = -INFINITY;
-    for (int c = tid; c < C; c += BEAM_THREADS) m = fmaxf(m, row[c]);
+    for (int c = tid; c < C; c += BEAM_THREADS) {        // (the row is read from memory once; a thread revisits its own lp[c])
+      const float v = row[c];
+      lp[c] = (double)v;
+      m = fmaxf(m, v);
+    }
     m = wave_reduce_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     double mm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     __syncthreads();
     double ssum = 0.0;
-    for (int c = tid; c < C; c += BEAM_THREADS) ssum += exp((double)row[c] - mm);
+    for (int c = tid; c < C; c += BEAM_THREADS) ssum += exp(lp[c] - mm);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
     if (lane == 0) red[wave] = ssum;
     __syncthreads();
     const double z = mm + log(red[0] + red[1] + red[2] + red[3]);
-    for (int c = tid; c < C; c += BEAM_THREADS) lp[c] = (double)row[c] - z;
+    for (int c = tid; c < C; c += BEAM_THREADS) lp[c] = lp[c] - z;
+    BEAM_T(0);
     // ---- 2. parent lookup + stay candidates
     if (tid < nb) {
       int par = -1;
@@ -179,182 +271,337 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
       s_idx[tid] = ~first;
     }
     __syncthreads();
+    BEAM_T(1);
     // ---- 2b. classes that can still reach the top W (see the header): threshold = (W+1)-th largest
     //      non-blank log-probability, found with a byte-wise radix select over the frame's C values
     if (tid < nb) s_L[tid] = lse2d(beam[tid].pb, beam[tid].pnb);
     const int R = W + 1;
     if (C - 1 > 4 * R) {   // small vocabularies: the select + compaction passes cost more than they prune
-      if (tid == 0) { sel_key = 0; sel_remaining = (unsigned)R; }
-      __syncthreads();
-      for (int byte = 7; byte >= 0; --byte) {
-        hist[tid] = 0;
-        __syncthreads();
-        const unsigned long long pk = sel_key;
-        const int sh = (byte + 1) * 8;
-        for (int c = tid; c < C; c += BEAM_THREADS) {
-          if (c == blank) continue;
-          const unsigned long long k = okey(lp[c]);
-          if (sh >= 64 || (k >> sh) == (pk >> sh)) atomicAdd(&hist[(unsigned)((k >> (byte * 8)) & 0xff)], 1u);
+      // R-th largest non-blank log-probability by a NARROWING radix select: a thread holds its classes' keys in registers;
+      // after a pass the keys outside the chosen bin are dropped (the ones above it are simply counted off), and the first
+      // pass whose bin holds exactly the keys still wanted ends the search -- the answer is that bin's smallest key
+      auto class_select = [&](auto NKC) __attribute__((always_inline)) {
+        constexpr int NK = decltype(NKC)::value;
+        unsigned long long rc[NK];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+          const int c = i * BEAM_THREADS + tid;
+          rc[i] = (c < C && c != blank) ? okey(lp[c]) : 0ull;   // (okey of a log-probability is never 0)
         }
+        if (tid == 0) { sel_key = 0; sel_remaining = (unsigned)R; }
+        __syncthreads();
+        for (int byte = 7; byte >= 0; --byte) {
+          hist[tid] = 0;
+          __syncthreads();
+          hist_regs<NK>(hist, rc, byte);
+          __syncthreads();
+          if (tid < 64) {
+            unsigned dgt, rem, pop;
+            pick_digit(hist, sel_remaining, lane, dgt, rem, pop);
+            if (tid == 0) {
+              sel_remaining = rem;
+              sel_key |= ((unsigned long long)dgt) << (byte * 8);
+              s_digit = dgt;
+              s_exact = (pop == rem) ? 1u : 0u;
+            }
+          }
+          __syncthreads();
+          const unsigned dgt = s_digit;
+          const bool upper = byte >= 4;
+          const int ds = (byte & 3) * 8;
+#pragma unroll
+          for (int i = 0; i < NK; ++i) {
+            const unsigned long long k = rc[i];
+            const unsigned d = ((upper ? (unsigned)(k >> 32) : (unsigned)k) >> ds) & 0xffu;
+            if (d != dgt) rc[i] = 0ull;
+          }
+          if (s_exact) break;                               // block-uniform
+        }
+        // the R-th largest = the smallest key still alive (after all eight bytes: the one value sel_key spells)
+        unsigned long long mn = ~0ull;
+#pragma unroll
+        for (int i = 0; i < NK; ++i)
+          if (rc[i] != 0ull && rc[i] < mn) mn = rc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long v = __shfl_xor(mn, o, 64);
+          if (v < mn) mn = v;
+        }
+        if (lane == 0) s_min[wave] = mn;
         __syncthreads();
         if (tid == 0) {
-          unsigned rem = sel_remaining;
-          int dgt = 255;
-          for (; dgt > 0; --dgt) {
-            if (hist[dgt] >= rem) break;
-            rem -= hist[dgt];
-          }
-          sel_remaining = rem;
-          sel_key |= ((unsigned long long)dgt) << (byte * 8);
+          unsigned long long m4 = s_min[0];
+          for (int w = 1; w < BEAM_THREADS / 64; ++w) if (s_min[w] < m4) m4 = s_min[w];
+          const double th = unokey(m4);
+          s_thr = th - 1e-9 * (1.0 + fabs(th));
         }
-        __syncthreads();
-      }
-      if (tid == 0) {
-        const double th = unokey(sel_key);
-        s_thr = th - 1e-9 * (1.0 + fabs(th));
-      }
+      };
+      if (C <= 8 * BEAM_THREADS) class_select(std::integral_constant<int, 8>{});
+      else class_select(std::integral_constant<int, 24>{});   // C <= 6144: the LDS limit of the launcher
     } else if (tid == 0) {
       s_thr = DNEG;
     }
     __syncthreads();
-    {   // ordered compaction of the kept classes
+    BEAM_T(2);
+    {   // ordered compaction of the kept classes: thread t owns the contiguous classes [t cpt, (t + 1) cpt)
       const double thr = s_thr;
-      int base = 0;
-      for (int c0 = 0; c0 < C; c0 += BEAM_THREADS) {
-        const int c = c0 + tid;
-        const bool keep = c < C && c != blank && lp[c] >= thr;
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) wcnt[wave] = (unsigned)__popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += (int)wcnt[w];
-        const int pos = off + (int)__popcll(bal & ((1ull << lane) - 1ull));
-        if (c < C) kpos[c] = keep ? pos : -1;
-        if (keep) kc[pos] = c;
-        base += (int)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
-        __syncthreads();
+      const int cpt = (C + BEAM_THREADS - 1) / BEAM_THREADS;
+      const int c_lo = min(C, tid * cpt), c_hi = min(C, c_lo + cpt);
+      int mine = 0;
+      for (int c = c_lo; c < c_hi; ++c) mine += (c != blank && lp[c] >= thr) ? 1 : 0;
+      int incl = mine;                                      // inclusive prefix over the wave's lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
       }
-      if (tid == 0) s_K = base;
+      if (lane == 63) wcnt[wave] = (unsigned)incl;
+      __syncthreads();
+      int pos = incl - mine;
+      for (int w = 0; w < wave; ++w) pos += (int)wcnt[w];
+      for (int c = c_lo; c < c_hi; ++c) {
+        const bool keep = c != blank && lp[c] >= thr;
+        kpos[c] = keep ? pos : -1;
+        if (keep) kc[pos++] = c;
+      }
+      if (tid == 0) s_K = (int)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
     }
     __syncthreads();
     const int K = s_K;
-    // ---- 3. extension totals over the kept classes (p_b = -inf, so total = p_nb contribution)
-    for (int e = tid; e < nb * K; e += BEAM_THREADS) {
-      const int j = e / K, c = kc[e % K];
-      tot[e] = ((c == beam[j].last) ? beam[j].pb : s_L[j]) + lp[c];
-    }
-    __syncthreads();
-    if (tid < nb && s_parent[tid] >= 0 && beam[tid].last != blank) {   // merged pairs are not new prefixes
-      const int kp = kpos[beam[tid].last];
-      if (kp >= 0) tot[(size_t)s_parent[tid] * K + kp] = NAN;           // NaN = excluded marker
-    }
-    __syncthreads();
-    // ---- 4. exact top-W over nb stay + nb*K extension candidates (excluded ones skipped)
+    BEAM_T(3);
+    // ---- 3. candidate keys: [0, nb) the stay candidates, nb + j K + ci the extension of entry j by kept class ci
+    //      (p_b = -inf, so total = p_nb contribution); 0 = excluded.  In LDS when they fit, else in the workspace.
     const int M = nb + nb * K;
-    auto cand = [&](int id, unsigned long long& key, unsigned& nidx) -> bool {
-      if (id < nb) { key = s_key[id]; nidx = s_idx[id]; return true; }
-      const int e = id - nb;
-      const double v = tot[e];
-      if (v != v) return false;
-      const int j = e / K, c = kc[e % K];
-      key = okey(v);
-      nidx = ~((unsigned)c * (2u * W) + 2u * j);
-      return true;
+    // tie-break index of candidate id (needed for the winners, and where keys tie at the threshold)
+    auto nidx_of = [&](int id) -> unsigned {
+      if (id < nb) return s_idx[id];
+      const int e = id - nb, j = e / K;
+      return ~((unsigned)kc[e - j * K] * (2u * W) + 2u * j);
     };
-    // count valid candidates
-    if (tid == 0) { s_nw = 0; sel_key = 0; sel_nidx = 0; }
-    __syncthreads();
-    {
-      int cnt = 0;
-      for (int id = tid; id < M; id += BEAM_THREADS) { unsigned long long k; unsigned n; cnt += cand(id, k, n) ? 1 : 0; }
-      atomicAdd(&s_nw, cnt);
-    }
-    __syncthreads();
-    const int valid = s_nw;
-    const int want = min(W, valid);
-    __syncthreads();
-    if (tid == 0) { sel_remaining = want; s_nw = 0; }
-    __syncthreads();
-    if (valid > want) {
-      for (int byte = 11; byte >= 0; --byte) {
-        hist[tid] = 0;   // BEAM_THREADS == 256
+    auto push_winner = [&](unsigned long long k, unsigned n, int id) {
+      const int pos = atomicAdd(&s_nw, 1);
+      if (pos < BEAM_MAX) { w_key[pos] = k; w_nidx[pos] = n; w_src[pos] = id; }
+    };
+    auto frame_tail = [&](unsigned long long* ck) __attribute__((always_inline)) {
+      if (tid < nb) ck[tid] = s_key[tid];
+      {
+        int j = tid / K, ci = tid - j * K;
+        const int dj = BEAM_THREADS / K, dci = BEAM_THREADS - dj * K;
+        for (int e = tid; e < nb * K; e += BEAM_THREADS) {
+          const int c = kc[ci];
+          ck[nb + e] = okey(((c == beam[j].last) ? beam[j].pb : s_L[j]) + lp[c]);
+          j += dj; ci += dci;
+          if (ci >= K) { ci -= K; ++j; }
+        }
+      }
+      __syncthreads();
+      if (tid < nb && s_parent[tid] >= 0 && beam[tid].last != blank) {   // merged pairs are not new prefixes
+        const int kp = kpos[beam[tid].last];
+        if (kp >= 0) ck[nb + s_parent[tid] * K + kp] = 0ull;
+      }
+      if (tid == 0) { s_nw = 0; sel_key = 0; sel_nidx = 0; }
+      __syncthreads();
+      BEAM_T(4);
+      // ---- 4. exact top-W over the valid candidates, ordered by (key, tie index): a NARROWING radix select on the keys a
+      //      thread holds in registers.  After each pass a key above the chosen bin is a winner (pushed at once), one
+      //      below it is out, one inside it stays; when the bin holds exactly the keys still wanted they all win and
+      //      the select is over.  Keys that survive all eight bytes are equal: the tie index decides, four more bytes.
+      // frames with more candidates than a thread can hold (ties at the pruning threshold, flat posteriors): the plain
+      // twelve-pass select over the key array
+      auto select_mem = [&](const unsigned long long* ckm) -> int {
+        int cnt = 0;
+        for (int id = tid; id < M; id += BEAM_THREADS) cnt += ckm[id] != 0ull ? 1 : 0;
+        cnt = (int)wave_reduce_sum((float)cnt);              // <= 64 * ceil(M / 256): exact in fp32
+        if (lane == 0) tcnt[wave] = (unsigned)cnt;
         __syncthreads();
-        const unsigned long long pk = sel_key;
-        const unsigned pn = sel_nidx;
-        for (int id = tid; id < M; id += BEAM_THREADS) {
-          unsigned long long k; unsigned n;
-          if (!cand(id, k, n)) continue;
-          // matches the already fixed more-significant bytes?
-          bool ok;
-          if (byte >= 4) {
-            const int sh = (byte - 4 + 1) * 8;
-            ok = (sh >= 64) ? true : ((k >> sh) == (pk >> sh));
-          } else {
-            const int sh = (byte + 1) * 8;
-            ok = (k == pk) && ((sh >= 32) ? true : ((n >> sh) == (pn >> sh)));
+        const int valid = (int)(tcnt[0] + tcnt[1] + tcnt[2] + tcnt[3]);
+        const int want = min(W, valid);
+        if (tid == 0) sel_remaining = want;
+        __syncthreads();
+        if (valid > want) {
+          for (int byte = 11; byte >= 0; --byte) {
+            hist[tid] = 0;   // BEAM_THREADS == 256
+            __syncthreads();
+            const unsigned long long pk = sel_key;
+            const unsigned pn = sel_nidx;
+            if (byte >= 4) {
+              const int sh = (byte - 4 + 1) * 8, ds = (byte - 4) * 8;
+              for (int id = tid; id < M; id += BEAM_THREADS) {
+                const unsigned long long k = ckm[id];
+                if (k != 0ull && (sh >= 64 || (k >> sh) == (pk >> sh))) atomicAdd(&hist[(unsigned)((k >> ds) & 0xff)], 1u);
+              }
+            } else {
+              const int sh = (byte + 1) * 8;
+              for (int id = tid; id < M; id += BEAM_THREADS) {
+                if (ckm[id] != pk) continue;                 // (pk != 0: the threshold is a valid candidate's key)
+                const unsigned n = nidx_of(id);
+                if (sh >= 32 || (n >> sh) == (pn >> sh)) atomicAdd(&hist[(n >> (byte * 8)) & 0xff], 1u);
+              }
+            }
+            __syncthreads();
+            if (tid < 64) {
+              unsigned d, rem, pop;
+              pick_digit(hist, sel_remaining, lane, d, rem, pop);
+              if (tid == 0) {
+                sel_remaining = rem;
+                if (byte >= 4) sel_key |= ((unsigned long long)d) << ((byte - 4) * 8);
+                else sel_nidx |= d << (byte * 8);
+              }
+            }
+            __syncthreads();
           }
-          if (ok) atomicAdd(&hist[digit_of(k, n, byte)], 1u);
         }
+        const unsigned long long tk = sel_key;
+        const unsigned tn = sel_nidx;
+        for (int id = tid; id < M; id += BEAM_THREADS) {    // winners: composite >= threshold (all valid ones when valid <= W)
+          const unsigned long long k = ckm[id];
+          if (k == 0ull) continue;
+          bool win = (valid <= want) || (k > tk);
+          unsigned n = 0;
+          bool have_n = false;
+          if (!win && k == tk) { n = nidx_of(id); have_n = true; win = n >= tn; }
+          if (win) push_winner(k, have_n ? n : nidx_of(id), id);
+        }
+        return want;
+      };
+      auto select = [&](auto NKC) __attribute__((always_inline)) {
+        constexpr int NK = decltype(NKC)::value;
+        unsigned long long rk[NK];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+          const int id = i * BEAM_THREADS + tid;
+          rk[i] = id < M ? ck[id] : 0ull;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) cnt += rk[i] != 0ull ? 1 : 0;
+        cnt = (int)wave_reduce_sum((float)cnt);              // <= 64 NK: exact in fp32
+        if (lane == 0) tcnt[wave] = (unsigned)cnt;
         __syncthreads();
-        if (tid == 0) {
-          unsigned rem = sel_remaining;
-          int d = 255;
-          for (; d > 0; --d) {
-            if (hist[d] >= rem) break;
-            rem -= hist[d];
+        const int valid = (int)(tcnt[0] + tcnt[1] + tcnt[2] + tcnt[3]);
+        const int want = min(W, valid);
+        if (tid == 0) sel_remaining = want;
+        __syncthreads();
+        if (valid <= want) {                                  // everything wins
+#pragma unroll
+          for (int i = 0; i < NK; ++i)
+            if (rk[i] != 0ull) push_winner(rk[i], nidx_of(i * BEAM_THREADS + tid), i * BEAM_THREADS + tid);
+          return want;
+        }
+        bool exact = false;
+        for (int byte = 7; byte >= 0; --byte) {
+          hist[tid] = 0;   // BEAM_THREADS == 256
+          __syncthreads();
+          hist_regs<NK>(hist, rk, byte);
+          __syncthreads();
+          if (tid < 64) {
+            unsigned d, rem, pop;
+            pick_digit(hist, sel_remaining, lane, d, rem, pop);
+            if (tid == 0) { sel_remaining = rem; s_digit = d; s_exact = (pop == rem) ? 1u : 0u; }
           }
-          sel_remaining = rem;
-          if (byte >= 4) sel_key |= ((unsigned long long)d) << ((byte - 4) * 8);
-          else sel_nidx |= ((unsigned)d) << (byte * 8);
+          __syncthreads();
+          const unsigned dgt = s_digit;
+          exact = s_exact != 0u;
+          const bool upper = byte >= 4;
+          const int ds = (byte & 3) * 8;
+#pragma unroll
+          for (int i = 0; i < NK; ++i) {
+            const unsigned long long k = rk[i];
+            if (k == 0ull) continue;
+            const unsigned d = ((upper ? (unsigned)(k >> 32) : (unsigned)k) >> ds) & 0xffu;
+            if (d > dgt || (exact && d == dgt)) {
+              push_winner(k, nidx_of(i * BEAM_THREADS + tid), i * BEAM_THREADS + tid);
+              rk[i] = 0ull;
+            } else if (d < dgt) {
+              rk[i] = 0ull;
+            }
+          }
+          if (exact) break;                                   // block-uniform
         }
-        __syncthreads();
-      }
-    }
-    // collect winners: composite >= threshold (all valid ones when valid <= W)
-    {
-      const unsigned long long tk = sel_key;
-      const unsigned tn = sel_nidx;
-      for (int id = tid; id < M; id += BEAM_THREADS) {
-        unsigned long long k; unsigned n;
-        if (!cand(id, k, n)) continue;
-        const bool win = (valid <= want) || (k > tk) || (k == tk && n >= tn);
-        if (win) {
-          const int pos = atomicAdd(&s_nw, 1);
-          if (pos < BEAM_MAX) { w_key[pos] = k; w_nidx[pos] = n; w_src[pos] = id; }
+        if (!exact) {
+          // the survivors share one key; sel_remaining of them win, those with the largest tie index (= the earliest in
+          // the reference's insertion order).  The same select on the 32-bit index, kept in the register's low word
+          // (bit 32 marks the slot as alive: an index can be 0)
+#pragma unroll
+          for (int i = 0; i < NK; ++i)
+            if (rk[i] != 0ull) { w_tie = rk[i]; rk[i] = (1ull << 32) | nidx_of(i * BEAM_THREADS + tid); }
+          __syncthreads();
+          const unsigned long long tiekey = w_tie;            // (every survivor wrote the same value)
+          for (int byte = 3; byte >= 0; --byte) {
+            hist[tid] = 0;
+            __syncthreads();
+            hist_regs<NK>(hist, rk, byte);
+            __syncthreads();
+            if (tid < 64) {
+              unsigned d, rem, pop;
+              pick_digit(hist, sel_remaining, lane, d, rem, pop);
+              if (tid == 0) { sel_remaining = rem; s_digit = d; s_exact = (pop == rem) ? 1u : 0u; }
+            }
+            __syncthreads();
+            const unsigned dgt = s_digit;
+            exact = s_exact != 0u;
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+              const unsigned long long k = rk[i];
+              if (k == 0ull) continue;
+              const unsigned n = (unsigned)k, d = (n >> (byte * 8)) & 0xffu;
+              if (d > dgt || (exact && d == dgt)) {
+                push_winner(tiekey, n, i * BEAM_THREADS + tid);
+                rk[i] = 0ull;
+              } else if (d < dgt) {
+                rk[i] = 0ull;
+              }
+            }
+            if (exact) break;
+          }
+          // (tie indices are distinct, so the last byte's bin holds one key: the select always ends exactly)
         }
+        return want;
+      };
+      int want;
+      if (M <= 4 * BEAM_THREADS) want = select(std::integral_constant<int, 4>{});
+      else if (M <= 48 * BEAM_THREADS) want = select(std::integral_constant<int, 48>{});
+      else want = select_mem(ck);
+      __syncthreads();
+      BEAM_T(6);
+      const int nw = min(s_nw, want);
+      // ---- 5. rank winners (composite keys are distinct) and build the next beam
+      if (tid < nw) {
+        const unsigned long long k = w_key[tid];
+        const unsigned n = w_nidx[tid];
+        int rank = 0;
+#pragma unroll 8
+        for (int o = 0; o < nw; ++o) rank += (w_key[o] > k) || (w_key[o] == k && w_nidx[o] > n);
+        const int id = w_src[tid];
+        Entry ne;
+        if (id < nb) {
+          ne = beam[id];
+          ne.pb = s_pb[id]; ne.pnb = s_pnb[id];
+        } else {
+          const int e = id - nb, j = e / K, c = kc[e - j * K];
+          const Entry p = beam[j];
+          ne.pb = DNEG; ne.pnb = unokey(k);                  // the key IS the total (order-preserving bijection)
+          ne.phash = p.hash; ne.hash = hmix(p.hash, c);
+          ne.len = p.len + 1; ne.last = c;
+          const int node = atomicAdd(&s_nodes, 1);
+          nodes[node] = make_int2(p.node, c);
+          ne.node = node;
+        }
+        nbeam[rank] = ne;
       }
-    }
-    __syncthreads();
-    const int nw = min(s_nw, want);
-    // ---- 5. rank winners (composite keys are distinct) and build the next beam
-    if (tid < nw) {
-      const unsigned long long k = w_key[tid];
-      const unsigned n = w_nidx[tid];
-      int rank = 0;
-      for (int o = 0; o < nw; ++o) rank += (w_key[o] > k) || (w_key[o] == k && w_nidx[o] > n);
-      const int id = w_src[tid];
-      Entry ne;
-      if (id < nb) {
-        ne = beam[id];
-        ne.pb = s_pb[id]; ne.pnb = s_pnb[id];
-      } else {
-        const int e = id - nb, j = e / K, c = kc[e % K];
-        const Entry p = beam[j];
-        ne.pb = DNEG; ne.pnb = tot[e];
-        ne.phash = p.hash; ne.hash = hmix(p.hash, c);
-        ne.len = p.len + 1; ne.last = c;
-        const int node = atomicAdd(&s_nodes, 1);
-        nodes[node] = make_int2(p.node, c);
-        ne.node = node;
-      }
-      nbeam[rank] = ne;
-    }
+      BEAM_T(7);
+      return nw;
+    };
+    const int nw = (M <= lds_keys) ? frame_tail(lkeys) : frame_tail(gkeys);
     __syncthreads();
     if (tid < nw) beam[tid] = nbeam[tid];
     if (tid == 0) s_nb = nw;
     __syncthreads();
   }
 
+  if (dbg && b == 0 && tid == 0)
+    for (int k = 0; k < 8; ++k) dbg[k] = ph[k];
+#undef BEAM_T
   // best hypothesis = beam[0]; walk the trie back
   if (tid == 0) {
     const Entry e = beam[0];
@@ -376,7 +623,7 @@ inline BeamWs beam_ws_layout(int T, int B, int C, int W) {
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   BeamWs w;
   size_t o = 0;
-  w.tot = o;   o += al((size_t)B * W * C * sizeof(double));
+  w.tot = o;   o += al((size_t)B * ((size_t)W * C + W) * sizeof(double));   // candidate keys when they do not fit in LDS
   w.nodes = o; o += al((size_t)B * ((size_t)T * W + 1) * sizeof(int2));
   w.total = o;
   return w;
@@ -404,13 +651,32 @@ extern "C" int asr_ctc_beam_decode(asr_handle* h, const float* logits, int T, in
   const BeamWs w = beam_ws_layout(T, B, C, beam_width);
   if (!workspace || workspace_bytes < w.total)
     ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_ctc_beam_decode: workspace %zu < %zu bytes", workspace_bytes, w.total);
-  const size_t lds = (size_t)C * (sizeof(double) + 2 * sizeof(int));
-  if (lds > 96 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_beam_decode: C=%d too large for LDS", C);
+  const size_t lds_c = (((size_t)C * (sizeof(double) + 2 * sizeof(int))) + 15) & ~(size_t)15;
+  if (lds_c > 96 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_beam_decode: C=%d too large for LDS", C);
+  // candidate keys in LDS: all of W (C - 1) + W when that fits, else what the pruned search needs in the common case
+  // (W (W + 2) + slack) up to the room left beside ~24 KB of static arrays; a frame with more candidates (ties at the
+  // pruning threshold, flat posteriors) keeps that frame's keys in the workspace
+  const size_t room = (size_t)160 * 1024 - 26 * 1024 - lds_c;
+  size_t nkeys = (size_t)beam_width * (C - 1) + beam_width;
+  if (nkeys * 8 > room) nkeys = room / 8;
+  const size_t lds = lds_c + nkeys * 8;
   (void)hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   char* ws = (char*)workspace;
+  static unsigned long long* dbgbuf = [] {
+    const char* e = getenv("ASR_BEAM_DBG");
+    unsigned long long* p = nullptr;
+    if (e && e[0] == '1') (void)hipMalloc(&p, 8 * sizeof(unsigned long long));
+    return p;
+  }();
   hipLaunchKernelGGL(ctc_beam_kernel, dim3(B), dim3(BEAM_THREADS), lds, (hipStream_t)s, logits, T, B, C, seq_len,
                      blank, beam_width, (double*)(ws + w.tot), (int2*)(ws + w.nodes), out_labels, out_len,
-                     out_score);
+                     out_score, (int)nkeys, dbgbuf);
   ASR_CHECK_LAUNCH(h, "asr_ctc_beam_decode");
+  if (dbgbuf) {
+    unsigned long long v[8];
+    if (hipMemcpy(v, dbgbuf, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[beam dbg] T=%d C=%d W=%d cycles/frame: softmax %llu stay %llu class-select %llu compact %llu keys %llu "
+              "select %llu rank+build %llu\n", T, C, beam_width, v[0] / T, v[1] / T, v[2] / T, v[3] / T, v[4] / T, v[6] / T, v[7] / T);
+  }
   return ASR_OK;
 }
