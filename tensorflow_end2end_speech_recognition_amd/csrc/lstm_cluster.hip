@@ -263,6 +263,14 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
   }
   // per-lane exchange addresses (both parities): publish slot, the three foreign slices this
   // wave polls (wave w polls the granules wave w of the peers publishes), LDS staging targets
+  // Rows past their length: their saved activations are never read and their x-projection rows are not used, so both go
+  // to ONE parked position per row -- the row's own frame tmax - 1, padding for any row that is ever inactive -- that
+  // stays in the L2 instead of streaming the padded part of the batch through HBM (round 4: the "1.87x the algorithmic
+  // bytes" of profiles/r03_pmc_hbm.md was exactly this: the batch is 49 % padding).  Only hout keeps its own frames:
+  // the next layer reads zeros there.
+  unsigned opark[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) opark[r] = os[r] + (unsigned)max(tmax - 1, 0) * stride;
   const int prow = rbase + (odd ? 1 : 0);
   const unsigned pofs = (unsigned)(wave * 64 + prow * 4 + ((col & 7) >> 1));   // publish slot in the slice
   const unsigned lofs = threadIdx.x;                                           // polled granule in a slice
@@ -297,8 +305,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
   f32x4_t xq[XD][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    xq[0][r] = xg[(0 < len[r]) ? oa[r] : os[r]];
-    if constexpr (XD == 2) xq[1][r] = (tmax > 1) ? xg[(1 < len[r]) ? oa[r] + dstep : os[r] + stride] : xq[0][r];
+    xq[0][r] = xg[(0 < len[r]) ? oa[r] : opark[r]];
+    if constexpr (XD == 2) xq[1][r] = (tmax > 1) ? xg[(1 < len[r]) ? oa[r] + dstep : opark[r]] : xq[0][r];
   }
   f32x4_t accn0 = {0.f, 0.f, 0.f, 0.f}, accn1 = {0.f, 0.f, 0.f, 0.f};   // EARLY: own-slice part of the next step
 
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     if (s + XD < tmax) {                                   // lands during the next step(s)
 #pragma unroll
       for (int r = 0; r < 2; ++r)
-        xq[P % XD][r] = xg[(s + XD < len[r]) ? oa[r] + (unsigned)XD * dstep : os[r] + (unsigned)XD * stride];
+        xq[P % XD][r] = xg[(s + XD < len[r]) ? oa[r] + (unsigned)XD * dstep : opark[r]];
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (EARLY) { acc0 = accn0; acc1 = accn1; }    // own-slice chunks: done at the end of the last step
@@ -410,21 +418,24 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     *reinterpret_cast<unsigned*>(hnxt + lown) = pk;
     // saved activations; rows past their length write frame s of the padding (hout: zeros,
     // gates / cs: never read there), so nothing is predicated
-    unsigned off[2];
+    unsigned off[2], offg[2];                              // hout position / saved-activation position
 #pragma unroll
-    for (int r = 0; r < 2; ++r) off[r] = act[r] ? oa[r] : os[r];
+    for (int r = 0; r < 2; ++r) {
+      off[r] = act[r] ? oa[r] : os[r];
+      offg[r] = act[r] ? oa[r] : opark[r];
+    }
     // H = 256: the saved activations are stored BEHIND the poll loop, see there.  H = 512 stores them here: keeping the
     // values alive across the loop costs registers that form has not got (4 -> 12 spills, 43.3 -> 47.7 ms at cfg D).
     constexpr bool LATE_STORE = (H <= 320 || HSU == 32);
-    unsigned offs[2] = {off[0], off[1]};
+    unsigned offs[2] = {off[0], off[1]}, offgs[2] = {offg[0], offg[1]};
     if constexpr (!LATE_STORE) {
       const bool pact = odd ? act[1] : act[0];
       const unsigned poff = (odd ? off[1] : off[0]) - (odd ? 1u : 0u);
       *reinterpret_cast<unsigned*>(hout + poff) = pact ? pk : 0u;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        gates[off[r]] = (cbf16x4_t){(__bf16)ig[r], (__bf16)gg[r], (__bf16)fg[r], (__bf16)og[r]};
-        cs[off[r]] = cn[r];
+        gates[offg[r]] = (cbf16x4_t){(__bf16)ig[r], (__bf16)gg[r], (__bf16)fg[r], (__bf16)og[r]};
+        cs[offg[r]] = cn[r];
       }
     }
 #pragma unroll
@@ -510,8 +521,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       *reinterpret_cast<unsigned*>(hout + poff) = pact ? pk : 0u;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        gates[offs[r]] = (cbf16x4_t){(__bf16)ig[r], (__bf16)gg[r], (__bf16)fg[r], (__bf16)og[r]};
-        cs[offs[r]] = cn[r];
+        gates[offgs[r]] = (cbf16x4_t){(__bf16)ig[r], (__bf16)gg[r], (__bf16)fg[r], (__bf16)og[r]};
+        cs[offgs[r]] = cn[r];
       }
     }
     C8_FPIN(3);
@@ -645,6 +656,9 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     os[r] = base + (unsigned)(tmax - 1) * stride;
     oa[r] = base + (unsigned)(rev ? len[r] - tmax : tmax - 1) * stride;
   }
+  // inactive rows read nothing that is used: their fetches go to one parked position per row (frame tmax - 1, padding
+  // for any row that is ever inactive) that stays in the L2 -- see the forward kernel
+  unsigned opark[2] = {os[0], os[1]};
   // zero the gate gradients of the common padded tail [tmax, T)
   {
     const cbf16x4_t gzero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
@@ -728,8 +742,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     for (int r = 0; r < 2; ++r) {
       const bool act = s_ < len[r];
       const bool ldp = (s_ > 0) && (s_ - 1 < len[r]);
-      const unsigned offl = act ? oa[r] : os[r];
-      const unsigned offn = ldp ? oa[r] + dstep : os[r];
+      const unsigned offl = act ? oa[r] : opark[r];
+      const unsigned offn = ldp ? oa[r] + dstep : opark[r];
       pg[r] = gates[offl];
       pcp[r] = cs[offn];
       pdh[r] = dhout[offl];
@@ -871,8 +885,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
       for (int r = 0; r < 2; ++r) {
         const bool actn = s - 1 < len[r];
         const bool ldpn = (s - 1 > 0) && (s - 2 < len[r]);
-        const unsigned offl = more ? (actn ? oa[r] : os[r]) : off[r];      // (oa / os already hold iteration s - 1)
-        const unsigned offn = more ? (ldpn ? oa[r] + dstep : os[r]) : off[r];
+        const unsigned offl = more ? (actn ? oa[r] : opark[r]) : off[r];   // (oa / os already hold iteration s - 1)
+        const unsigned offn = more ? (ldpn ? oa[r] + dstep : opark[r]) : off[r];
         pg[r] = gates[offl];
         pcp[r] = cs[offn];
         pdh[r] = dhout[offl];

@@ -799,6 +799,9 @@ class DeferredCheck(object):
         n = int(host[0])
         if n:
             self.slots = []
+            # a timed-out cluster hand-off leaves NaN activations, which the CTC kernels count as infeasible rows: report the
+            # root cause (AsrError from the sticky error word) rather than its symptom
+            check_async_errors(torch.cuda.current_device())
             raise make_exc(n)
         return True
 
