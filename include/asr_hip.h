@@ -55,7 +55,7 @@ typedef enum {
 } asr_optimizer;
 
 /* ---- lifetime ------------------------------------------------------------ */
-int asr_abi_version(void);
+int asr_abi_version(void);                                         /* 2 since round 4 (additions + the two size changes noted at asr_create_ex / asr_ctc_beam_workspace_bytes) */
 int asr_create(asr_handle** out, int device);                        /* 192 MiB scratch arena */
 int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes); /* >= 96 MiB (64 MiB of it: recurrence exchange areas) */
 size_t asr_scratch_bytes(asr_handle* h);
@@ -411,6 +411,14 @@ int asr_lstm_cell_bwd(asr_handle* h, const float* dh_use, const float* dc_next, 
                       const float* gates, const float* c_raw, const float* c_prev, const float* peep,
                       const float* live, int B, int U, float* dpre, float* dc_prev,
                       float* dh_prev_carry, float* dpeep_rows, asr_stream s);
+/* The same with the forward's cell clip: a state the forward clamped (tf.clip_by_value inside LSTMCell,
+ * models/recurrent/layers/lstm.py:152-157) passes no gradient to the gates or to c_prev; c_raw holds the clamped value,
+ * |c_raw| >= cell_clip marks it.  cell_clip <= 0: identical to asr_lstm_cell_bwd.  (asr_att_decoder_bwd applies the
+ * decoder's cell_clip the same way.) */
+int asr_lstm_cell_bwd_ex(asr_handle* h, const float* dh_use, const float* dc_next, const float* dh_next,
+                         const float* gates, const float* c_raw, const float* c_prev, const float* peep,
+                         const float* live, int B, int U, float cell_clip, float* dpre, float* dc_prev,
+                         float* dh_prev_carry, float* dpeep_rows, asr_stream s);
 /* Attention energies (attention_layer.py:115-347).  mode 0 (bahdanau_content / location / hybrid):
  * energy[b,t] = sum_a v[a] * tanh(keys[t,b,a] + qz[b,a])   (keys NULL for 'location');
  * mode 1 (dot_product / luong_dot / luong_general): energy[b,t] = sum_a keys[t,b,a] * qz[b,a].

@@ -28,8 +28,11 @@ import torch
 
 
 def lstm_block_cell(x, cs_prev, h_prev, w, b, wci, wcf, wco,
-                    forget_bias=1.0, cell_clip=0.0, use_peephole=True):
-    """One LSTMBlockCell step. x [B,Din], cs_prev/h_prev [B,H], w [Din+H,4H]."""
+                    forget_bias=1.0, cell_clip=0.0, use_peephole=True, clip_blocks_gradient=False):
+    """One LSTMBlockCell step. x [B,Din], cs_prev/h_prev [B,H], w [Din+H,4H].
+    clip_blocks_gradient: the python LSTMCell (tf.contrib.rnn.LSTMCell, the projected cells of lstm_impl='LSTMCell',
+    models/encoders/core/blstm.py:215-230 / models/recurrent/layers/lstm.py:152-157) clamps with tf.clip_by_value, whose
+    gradient is zero where the state was clamped; the fused LSTMBlockCell's gradient op ignores the clip."""
     H = cs_prev.shape[1]
     icfo = torch.cat([x, h_prev], dim=1) @ w + b
     i, ci, f, o = icfo[:, :H], icfo[:, H:2 * H], icfo[:, 2 * H:3 * H], icfo[:, 3 * H:]
@@ -41,8 +44,11 @@ def lstm_block_cell(x, cs_prev, h_prev, w, b, wci, wcf, wco,
     f = torch.sigmoid(f + forget_bias)
     cs = ci * i + cs_prev * f
     if cell_clip is not None and cell_clip > 0:
-        # straight-through in backward (TF LSTMBlockCellGrad ignores the clip)
-        cs = cs + (torch.clamp(cs, -cell_clip, cell_clip) - cs).detach()
+        if clip_blocks_gradient:
+            cs = torch.clamp(cs, -cell_clip, cell_clip)
+        else:
+            # straight-through in backward (TF LSTMBlockCellGrad ignores the clip)
+            cs = cs + (torch.clamp(cs, -cell_clip, cell_clip) - cs).detach()
     if use_peephole:
         o = o + wco * cs
     o = torch.sigmoid(o)
@@ -291,7 +297,8 @@ def layer_param_grads_np(x_tm, hout, dgates, lens, p, reverse=False, round_fn=No
 # then m = (sigmoid(o) * tanh(c)) @ projection/kernel [H, P]; the RECURRENT input and the emitted output are the
 # projected m (kernel [(Din + P), 4H]), the state is (c [H], m [P]).  PARITY UNPINNED (TF1 absent).
 def lstmp_cell(x, c_prev, m_prev, w, b, wci, wcf, wco, w_proj, forget_bias=1.0, cell_clip=0.0, use_peephole=True):
-    c, h = lstm_block_cell(x, c_prev, m_prev, w, b, wci, wcf, wco, forget_bias, cell_clip, use_peephole)
+    c, h = lstm_block_cell(x, c_prev, m_prev, w, b, wci, wcf, wco, forget_bias, cell_clip, use_peephole,
+                           clip_blocks_gradient=True)
     return c, h @ w_proj
 
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     'asr_lstm_cell_fwd': (_i, [_vp] * 6 + [_i, _i, _f, _f] + [_vp] * 6),
     'asr_lstm_cell_fwd_ex': (_i, [_vp] * 6 + [_i, _i, _f, _f] + [_vp] * 5 + [_vp, _vp, _vp, _i, _vp, _i, _vp]),
     'asr_lstm_cell_bwd': (_i, [_vp] * 9 + [_i, _i] + [_vp] * 5),
+    'asr_lstm_cell_bwd_ex': (_i, [_vp] * 9 + [_i, _i, _f] + [_vp] * 5),
     'asr_stack_frames': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_splice': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_att_energy_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -65,7 +65,10 @@ __global__ void cell_bwd_kernel(const float* __restrict__ dh_out_use, const floa
                                 const float* __restrict__ peep, const float* __restrict__ live, int B, int U,
                                 float* __restrict__ dpre, float* __restrict__ dc_prev,
                                 float* __restrict__ dh_prev_carry, float* __restrict__ dpeep_rows,
-                                const float* __restrict__ dh_next2, int ld2, const float* __restrict__ use_mask) {
+                                const float* __restrict__ dh_next2, int ld2, const float* __restrict__ use_mask,
+                                float clip) {
+  // clip (> 0: the forward clamped the new cell state to [-clip, clip], tf.clip_by_value in LSTMCell): no gradient
+  // reaches the gates or c_prev through a state that was clamped (c_raw holds the CLAMPED value: |c| >= clip marks it).
   // dh_next2 (may be NULL, row stride ld2): a second addend of the carried-h gradient -- inside the decoder loop the
   // h-columns of the NEXT step's cell-input gradient; use_mask (may be NULL): the DropoutWrapper mask of the cell
   // output, applied to dh_out_use here instead of by a launch of its own
@@ -89,7 +92,8 @@ __global__ void cell_bwd_kernel(const float* __restrict__ dh_out_use, const floa
   const float dh = (use_mask ? dh_out_use[idx] * use_mask[idx] : dh_out_use[idx]) + dhn;
   const float tc = tanhf(c);
   const float d_o = dh * tc * o * (1.f - o);
-  const float dc = dc_next[idx] + dh * o * (1.f - tc * tc) + d_o * wco;
+  const float dct = dc_next[idx] + dh * o * (1.f - tc * tc) + d_o * wco;
+  const float dc = (clip > 0.f && fabsf(c) >= clip) ? 0.f : dct;
   const float d_g = dc * i * (1.f - g * g);
   const float d_i = dc * g * i * (1.f - i);
   const float d_f = dc * cp * f * (1.f - f);
@@ -1517,6 +1521,7 @@ struct CellBwdArgs {
   const float *dc_next, *dh_next, *dh_next2, *gates, *c_raw, *c_prev, *peep, *live, *use_mask;
   float *dpre, *dc_prev, *dh_prev_carry, *dpeep_rows;
   int ld2;
+  float clip;
 };
 // NTL MFMA column tiles (16 NTL units) per workgroup.  Measured on the cfg D shard (A = 128, U = 512, 25 chunks): NTL = 1
 // (34 workgroups x 2 row groups) 54.3 ms for the reverse pass, NTL = 4 (10 x 2) 55.4, the three separate launches 55.0.
@@ -1664,7 +1669,8 @@ __global__ __launch_bounds__(512) void att_dq_cell_bwd_kernel(const float* __res
     const float dh = dcell * e_mask[h2] + e_dhn[h2];
     const float tc = tanhf(e_cr[h2]);
     const float d_o = dh * tc * go * (1.f - go);
-    const float dc = e_dcn[h2] + dh * go * (1.f - tc * tc) + d_o * e_w[h2][2];
+    const float dct = e_dcn[h2] + dh * go * (1.f - tc * tc) + d_o * e_w[h2][2];
+    const float dc = (c.clip > 0.f && fabsf(e_cr[h2]) >= c.clip) ? 0.f : dct;     // a clamped state passes nothing back
     const float d_g = dc * gi * (1.f - gg * gg);
     const float d_i = dc * gg * gi * (1.f - gi);
     const float d_f = dc * e_cp[h2] * gf * (1.f - gf);
@@ -1707,13 +1713,14 @@ extern "C" int asr_lstm_cell_fwd(asr_handle* h, const float* pre, const float* c
 static int cell_bwd_launch(asr_handle* h, const float* dh_use, const float* dc_next, const float* dh_next,
                            const float* gates, const float* c_raw, const float* c_prev, const float* peep,
                            const float* live, int B, int U, float* dpre, float* dc_prev, float* dh_prev_carry,
-                           float* dpeep_rows, const float* dh_next2, int ld2, const float* use_mask, asr_stream s) {
+                           float* dpeep_rows, const float* dh_next2, int ld2, const float* use_mask, float clip,
+                           asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   ATT_NEED(dh_use && dc_next && dh_next && gates && c_raw && c_prev && live && dpre && dc_prev && dh_prev_carry &&
                B > 0 && U > 0 && (!dh_next2 || ld2 >= U), "asr_lstm_cell_bwd: bad args");
   hipLaunchKernelGGL(cell_bwd_kernel, dim3((B * U + 255) / 256), dim3(256), 0, (hipStream_t)s, dh_use, dc_next,
                      dh_next, gates, c_raw, c_prev, peep, live, B, U, dpre, dc_prev, dh_prev_carry, dpeep_rows,
-                     dh_next2, ld2, use_mask);
+                     dh_next2, ld2, use_mask, clip);
   ASR_CHECK_LAUNCH(h, "asr_lstm_cell_bwd");
   return ASR_OK;
 }
@@ -1722,7 +1729,14 @@ extern "C" int asr_lstm_cell_bwd(asr_handle* h, const float* dh_use, const float
                                  const float* live, int B, int U, float* dpre, float* dc_prev,
                                  float* dh_prev_carry, float* dpeep_rows, asr_stream s) {
   return cell_bwd_launch(h, dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, B, U, dpre, dc_prev,
-                         dh_prev_carry, dpeep_rows, nullptr, 0, nullptr, s);
+                         dh_prev_carry, dpeep_rows, nullptr, 0, nullptr, 0.f, s);
+}
+extern "C" int asr_lstm_cell_bwd_ex(asr_handle* h, const float* dh_use, const float* dc_next, const float* dh_next,
+                                    const float* gates, const float* c_raw, const float* c_prev, const float* peep,
+                                    const float* live, int B, int U, float cell_clip, float* dpre, float* dc_prev,
+                                    float* dh_prev_carry, float* dpeep_rows, asr_stream s) {
+  return cell_bwd_launch(h, dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, B, U, dpre, dc_prev,
+                         dh_prev_carry, dpeep_rows, nullptr, 0, nullptr, cell_clip, s);
 }
 
 static int energy_fwd_launch(asr_handle* h, const float* keys, const float* qz, const float* v, int T, int B, int A,
@@ -2373,7 +2387,7 @@ extern "C" int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_
                                 &part, &nchq));
       CellBwdArgs ca = {dcs[cur], dhc[cur], dh2, a->gates_all + (size_t)k * B * 4 * U, a->craw_all + (size_t)k * B * U,
                         a->c_all + (size_t)k * B * U, a->peep, a->live + (size_t)k * B, dmask,
-                        dpre, dcs[cur ^ 1], dhc[cur ^ 1], dpeep, Din};
+                        dpre, dcs[cur ^ 1], dhc[cur ^ 1], dpeep, Din, 0.f};   // (clip: see the unfused call below)
       hipLaunchKernelGGL(att_dq_cell_bwd_kernel, dim3(U / DQ_CT + 2, (B + 15) / 16), dim3(512), 0, st, part, nchq, B, A, U,
                          a->W_q, a->ld_wq, dcell, dqz, dv, ca);
       ASR_CHECK_LAUNCH(h, "asr_att_decoder_bwd");
@@ -2388,7 +2402,9 @@ extern "C" int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_
       // gradient to the carried dh itself
       DEC_TRY(cell_bwd_launch(h, dcell, dcs[cur], dhc[cur], a->gates_all + (size_t)k * B * 4 * U,
                               a->craw_all + (size_t)k * B * U, a->c_all + (size_t)k * B * U, a->peep,
-                              a->live + (size_t)k * B, B, U, dpre, dcs[cur ^ 1], dhc[cur ^ 1], dpeep, dh2, Din, dmask, s));
+                              a->live + (size_t)k * B, B, U, dpre, dcs[cur ^ 1], dhc[cur ^ 1], dpeep, dh2, Din, dmask,
+                              0.f, s));   // the decoder cell is tf.contrib.rnn.LSTMBlockCell (attention_seq2seq.py:354-365),
+                                          // whose gradient op ignores cell_clip: the clamp is straight-through here
     }
     float* d_in = a->d_in_all + (size_t)k * B * Din;
     DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 1, B, Din, 4 * U, dpre, 4 * U, a->W_cell, 4 * U, d_in, Din, nullptr, 0, 0, s));

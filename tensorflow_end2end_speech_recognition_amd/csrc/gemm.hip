@@ -15,6 +15,17 @@
 
 namespace {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: "set once per process" leaves a
+// second GPU of the same process without the LDS opt-in.  One bit per device ordinal.
+static inline bool first_on_device(unsigned long long& mask) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const unsigned long long bit = 1ull << (d & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 template <typename T> struct GT;
 template <> struct GT<float> {
   static constexpr int BK = 32;   // 128 B of K per row
@@ -563,10 +574,9 @@ static void launch_gemm_nt_big(int M, int N, int K, const void* A, int lda, cons
                                const float* bias, int accumulate, hipStream_t st, int act, const float* mul, int ldm,
                                GemmDrop drop) {
   const size_t lds = (size_t)2 * (BM + BN) * (64 + 8) * sizeof(bf16_t);
-  static bool attr_done = false;
+  static unsigned long long attr_done = 0;
   auto k = gemm_nt_bf16_big_kernel<TO, BM, BN, WM, WN>;
-  if (!attr_done) {
-    attr_done = true;
+  if (first_on_device(attr_done)) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   const long tiles = (long)(N / BN) * ((M + BM - 1) / BM);
@@ -593,9 +603,8 @@ bool try_gemm_nt_bf16(int transA, int transB, int M, int N, int K, const void* A
     return true;
   }
   const size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * sizeof(bf16_t);
-  static bool attr_done = false;
-  if (!attr_done) {
-    attr_done = true;
+  static unsigned long long attr_done = 0;
+  if (first_on_device(attr_done)) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   const int total = (N / 128) * ((M + 127) / 128);
@@ -1466,9 +1475,8 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
         kchunk = (kchunk + 63) / 64 * 64;
         S = (K + kchunk - 1) / kchunk;
         const size_t lds = (size_t)2 * TN_STAGE;
-        static bool attr_done = false;
-        if (!attr_done) {
-          attr_done = true;
+        static unsigned long long attr_done = 0;
+        if (first_on_device(attr_done)) {
           (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
         float* partial = (float*)h->scratch;
@@ -1491,9 +1499,8 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
   if (tiles128 >= 320) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     size_t lds = (size_t)2 * (128 + 128) * (BK + VEC) * sizeof(T);
-    static bool attr_done = false;   // 72 KB of dynamic LDS needs the opt-in
-    if (!attr_done) {
-      attr_done = true;
+    static unsigned long long attr_done = 0;   // 72 KB of dynamic LDS needs the opt-in
+    if (first_on_device(attr_done)) {
       (void)hipFuncSetAttribute((const void*)gemm_kernel<T, TO, 128, 128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void*)gemm_kernel<T, TO, 128, 128, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void*)gemm_kernel<T, TO, 128, 128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -350,7 +350,9 @@ class LSTMPLayer(object):
                 dh_raw = ops.gemm(dm_t, wp, transB=True)                               # [B,H]
                 _, dc, _, _ = ops.lstm_cell_bwd(dh_raw, dc, zero_h, sv['gates'][s], sv['craw'][s], sv['cprev'][s],
                                                 sv['peep'], live[s], want_dpeep=self.use_peephole,
-                                                dpre_out=dpre_all[s], dpeep_out=dpeep_all[s] if dpeep_all is not None else None)
+                                                dpre_out=dpre_all[s], dpeep_out=dpeep_all[s] if dpeep_all is not None else None,
+                                                cell_clip=self.cell_clip or 0.0)   # LSTMCell clips with tf.clip_by_value:
+                                                                                   # no gradient through a clamped state
                 dm = ops.gemm(dpre_all[s], wh, transB=True) + dm_carry                 # d m_prev
             dp2d = dpre_all.view(T * B, 4 * H)
             gk = st.g(b + '/kernel')

@@ -972,17 +972,18 @@ def lstm_cell_fwd(pre, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.
 
 
 def lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True, dpre_out=None,
-                  dpeep_out=None):
-    """dpre_out [B,4U] / dpeep_out [B,3U] (contiguous rows of the caller's per-step arrays): written in place."""
+                  dpeep_out=None, cell_clip=0.0):
+    """dpre_out [B,4U] / dpeep_out [B,3U] (contiguous rows of the caller's per-step arrays): written in place.
+    cell_clip: the clip the forward applied to the new cell state (0: none) -- a clamped state passes no gradient."""
     h = _h(dh_use)
     B, U = dh_use.shape
     dev = dh_use.device
     dpre = dpre_out if dpre_out is not None else _f32((B, 4 * U), dev)
     dc_prev, dh_carry = _f32((B, U), dev), _f32((B, U), dev)
     dpeep = (dpeep_out if dpeep_out is not None else _f32((B, 3, U), dev)) if want_dpeep else None
-    h.check(h.lib.asr_lstm_cell_bwd(h.h, _p(dh_use), _p(dc_next), _p(dh_next), _p(gates), _p(c_raw), _p(c_prev),
-                                    _p(peep), _p(live), B, U, _p(dpre), _p(dc_prev), _p(dh_carry), _p(dpeep), _s()),
-            'asr_lstm_cell_bwd')
+    h.check(h.lib.asr_lstm_cell_bwd_ex(h.h, _p(dh_use), _p(dc_next), _p(dh_next), _p(gates), _p(c_raw), _p(c_prev),
+                                       _p(peep), _p(live), B, U, float(cell_clip or 0.0), _p(dpre), _p(dc_prev),
+                                       _p(dh_carry), _p(dpeep), _s()), 'asr_lstm_cell_bwd')
     return dpre, dc_prev, dh_carry, dpeep
 
 

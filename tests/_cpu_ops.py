@@ -407,7 +407,7 @@ def _into(out, val):
 
 
 def _lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True, dpre_out=None,
-                   dpeep_out=None):
+                   dpeep_out=None, cell_clip=0.0):
     B, U = dh_use.shape
     gt = gates.double()
     i, g, f, o = gt[:, :U], gt[:, U:2 * U], gt[:, 2 * U:3 * U], gt[:, 3 * U:]
@@ -418,7 +418,9 @@ def _lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, w
     dh = dh_use.double() + dh_next.double()
     tc = torch.tanh(c)
     d_o = dh * tc * o * (1 - o)
-    dc = dc_next.double() + dh * o * (1 - tc * tc) + d_o * wco          # the clip is straight-through
+    dc = dc_next.double() + dh * o * (1 - tc * tc) + d_o * wco          # the clip is straight-through (LSTMBlockCell) ...
+    if cell_clip and cell_clip > 0:                                       # ... or blocks a clamped state (LSTMCell)
+        dc = torch.where(c.abs() >= cell_clip, torch.zeros_like(dc), dc)
     d_g = dc * i * (1 - g * g)
     d_i = dc * g * i * (1 - i)
     d_f = dc * cp * f * (1 - f)

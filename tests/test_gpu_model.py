@@ -808,6 +808,9 @@ def test_lstmcell_projection_layers(cuda, ndir, B, T, D, H, P, L):
     if ndir == 2:
         print('\n' + r['report'])
         assert r['loss_rel'] < 1e-4 and r['logits_abs'] < 2e-4 and r['grad_worst'] < 2e-3, r['report']
+        # an active cell clip (LSTMCell clamps with tf.clip_by_value: a clamped state passes no gradient back)
+        rc = cp.run_lstmp('cuda:0', B=B, T=T, D=D, H=H, P=P, L=L, C=9, ndir=2, clip=0.15)
+        assert rc['loss_rel'] < 1e-4 and rc['grad_worst'] < 2e-3, rc['report']
 
 
 def test_gru_long_run_keeps_side_lane_bounded_and_survives_poisoned_allocator(cuda):

@@ -832,6 +832,10 @@ def test_lstmcell_projection_host_logic(monkeypatch, ndir):
     assert r['trained']
     if ndir == 2:
         assert r['loss_rel'] < 1e-5 and r['logits_abs'] < 1e-4 and r['grad_worst'] < 2e-4, r['report']
+        # an ACTIVE cell clip: tf.contrib.rnn.LSTMCell clamps with tf.clip_by_value, so a clamped state passes no gradient
+        # to its gates or to c_prev (the fused LSTMBlockCell of the other paths is straight-through) -- ADVICE r03
+        rc = cp.run_lstmp('cpu', B=5, T=9, D=6, H=8, P=5, L=2, C=6, ndir=2, clip=0.15)
+        assert rc['loss_rel'] < 1e-5 and rc['grad_worst'] < 2e-4, rc['report']
         assert 'blstm_hidden2/bw/lstm_cell/projection/kernel' in r['names']
     else:
         assert 'multi_lstm/multi_rnn_cell/cell_1/lstm_cell/projection/kernel' in r['names']
