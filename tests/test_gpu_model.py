@@ -876,3 +876,30 @@ def test_infeasible_labels_raise_without_a_per_step_sync(cuda):
         model.compute_loss(x, bad, sl, 1.0, is_training=False)
     loss, _ = model.compute_loss(x, good, sl, 1.0, is_training=False)
     assert np.isfinite(float(loss.item()))
+
+
+def test_full_chip_clusters_beside_background_gemms_hand_off_cleanly(cuda):
+    """at H = 512 the four-wave clusters take 16 CUs each, so B = 128 bidirectional is 16 clusters = all 256 CUs
+    of the chip, and the weight-gradient GEMMs of the layer above run beside every BPTT kernel on 128 workgroups that
+    share those CUs.  Every cluster member must still become resident and no hand-off may time out (sticky error word 0
+    after several training steps of a 3-layer model; the loss stays finite and falls)."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    rng = np.random.RandomState(12)
+    B, T, D, C = 128, 48, 24, 12
+    x = rng.randn(B, T, D).astype(np.float32)
+    sl = rng.randint(T // 2, T + 1, size=B).astype(np.int32)
+    sl[0] = T
+    labels = np.full((B, 5), -1, dtype=np.int64)
+    for b in range(B):
+        x[b, sl[b]:] = 0
+        labels[b, :4] = rng.randint(0, C, size=4)
+    model = CTC('blstm', D, 512, 3, C, parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='bf16', seed=3)
+    assert ops.check_async_errors(0) == 0
+    losses = []
+    for _ in range(6):
+        loss, _ = model.compute_loss(x, labels, sl, keep_prob=0.9)
+        model.train(loss, 'adam', 2e-3)
+        losses.append(float(loss.item()))
+    assert ops.check_async_errors(0) == 0
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
