@@ -185,10 +185,19 @@ int asr_conv3x3_prep_weights(asr_handle* h, const float* w_hwio, int Cin, int Co
                              void* wt_bwd, asr_stream s);
 int asr_conv3x3_fwd(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* wt_fwd,
                     const float* bias, int Cout, int relu, void* out, asr_stream s);
+/* conv_layer + tf.nn.dropout (vgg_blstm.py:113-157) in one launch (round 4): out = dropout(round(relu(conv + bias))) with the
+ * mask of asr_dropout_apply(keep_prob, seed, offset) formed in the epilogue -- bit for bit asr_dropout_apply of
+ * asr_conv3x3_fwd's output; the undropped activation is never written (the backward needs only its sign where the mask
+ * kept it: use_drop == 2 below). */
+int asr_conv3x3_fwd_drop(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* wt_fwd,
+                         const float* bias, int Cout, float keep_prob, uint64_t seed, uint64_t offset, void* out,
+                         asr_stream s);
 int asr_conv3x3_bwd_data(asr_handle* h, const void* dy, int N, int H, int W, int Cout,
                          const void* wt_bwd, int Cin, float* dx, asr_stream s);
 /* asr_conv3x3_bwd_data followed by asr_relu_bwd(_drop) of the layer below, in the epilogue: dpre_below (bf16
- * [N,H,W,Cin]) = (act_below > 0) ? dx * dropout mask(seed, offset) : 0 -- the fp32 dx is never written. */
+ * [N,H,W,Cin]) = (act_below > 0) ? dx * dropout mask(seed, offset) : 0 -- the fp32 dx is never written.
+ * use_drop: 0 no dropout, 1 the mask is formed from (keep_prob, seed, offset), 2 act_below IS the dropped activation
+ * (asr_conv3x3_fwd_drop / asr_conv3x3_smallc_fwd_drop): it is > 0 exactly where active and kept, dx is scaled by 1 / keep. */
 int asr_conv3x3_bwd_data_relu(asr_handle* h, const void* dy, int N, int H, int W, int Cout, const void* wt_bwd, int Cin,
                               const void* act_below, float keep_prob, uint64_t seed, uint64_t offset, int use_drop,
                               void* dpre_below, asr_stream s);
@@ -198,6 +207,10 @@ int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* dy, int N, 
  * argmax (uint8, 0..3 = position in the window) drives the backward pass. */
 int asr_maxpool2x2_fwd(asr_handle* h, int dtype, const void* in, int N, int H, int W, int C,
                        void* out, uint8_t* argmax, asr_stream s);
+/* max_pool + tf.nn.dropout in one launch: out = dropout(round(max)) (== asr_dropout_apply of asr_maxpool2x2_fwd's output).
+ * C % 4 == 0, 16-byte aligned arrays. */
+int asr_maxpool2x2_fwd_drop(asr_handle* h, int dtype, const void* in, int N, int H, int W, int C, void* out,
+                            uint8_t* argmax, float keep_prob, uint64_t seed, uint64_t offset, asr_stream s);
 int asr_maxpool2x2_bwd(asr_handle* h, const float* dout, const uint8_t* argmax, int N, int H, int W,
                        int C, float* din, asr_stream s);
 /* dpre = dout * (out > 0) (* mask if given), written in `dtype` (ReLU + dropout backward) */
@@ -206,17 +219,27 @@ int asr_maxpool2x2_bwd(asr_handle* h, const float* dout, const uint8_t* argmax, 
  * its weight gradient dw fp32 [9 Cin, 64] = patches(x)^T dpre (dpre bf16 [N,H,W,64]; deterministic two-stage sum). */
 int asr_conv3x3_smallc_fwd(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* w2d,
                            const float* bias, int Cout, int relu, void* out, asr_stream s);
+int asr_conv3x3_smallc_fwd_drop(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* w2d,
+                                const float* bias, int Cout, float keep_prob, uint64_t seed, uint64_t offset, void* out,
+                                asr_stream s);      /* ReLU + dropout in the epilogue, as asr_conv3x3_fwd_drop */
 int asr_conv3x3_smallc_bwd_weight(asr_handle* h, const void* x, const void* dpre, int N, int H, int W, int Cin,
                                   int Cout, float* dw, asr_stream s);
 /* asr_dropout_apply (on the pooled gradient, when use_drop) -> asr_maxpool2x2_bwd -> asr_relu_bwd of the convolution
  * under the pool, as one pass without the full-resolution fp32 gradient in between: dpre[n,h,w,c] (operand dtype) =
  * (act[n,h,w,c] > 0 && argmax[o] == 2 (h & 1) + (w & 1)) ? dout[o] * mask(o) : 0, o = pooled cell (n, h/2, w/2, c).
- * C % 4 == 0, 16-byte aligned arrays. */
+ * C % 4 == 0, 16-byte aligned arrays.
+ * use_drop == 2: `act` is the POOLED activation after its dropout ([N, ceil(H/2), ceil(W/2), C], asr_maxpool2x2_fwd_drop, or
+ * the plain pooled output with keep_prob 1): dpre = (act[o] > 0 && argmax[o] == position) ? dout[o] / keep_prob : 0 -- the
+ * full-resolution ReLU output is not read. */
 int asr_maxpool2x2_relu_bwd(asr_handle* h, int dtype, const float* dout, const uint8_t* argmax, const void* act, int N,
                             int H, int W, int C, void* dpre, float keep_prob, uint64_t seed, uint64_t offset,
                             int use_drop, asr_stream s);
 int asr_relu_bwd(asr_handle* h, int dtype, const float* dout, const void* out, const float* mask,
                  size_t n, void* dpre, asr_stream s);
+/* dpre = (out > 0) ? dout * (1 / keep) : 0 with `out` a DROPPED ReLU output (asr_conv3x3_fwd_drop etc.): the same values as
+   asr_relu_bwd_drop over the undropped output, without forming the mask */
+int asr_relu_bwd_scaled(asr_handle* h, int dtype, const float* dout, const void* out, size_t n, float keep, void* dpre,
+                        asr_stream s);
 
 /* ---- LSTM recurrence ------------------------------------------------------ *
  * One layer, `ndir` directions (1 = LSTMEncoder, 2 = BLSTMEncoder), all T steps:

@@ -44,8 +44,10 @@ SIGNATURES = {
     'asr_gemm_mul': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     'asr_conv3x3_prep_weights': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     'asr_conv3x3_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    'asr_conv3x3_fwd_drop': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _u64, _u64, _vp, _vp]),
     'asr_conv3x3_bwd_data': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     'asr_conv3x3_smallc_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    'asr_conv3x3_smallc_fwd_drop': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _u64, _u64, _vp, _vp]),
     'asr_conv3x3_smallc_bwd_weight': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_conv3x3_bwd_data_relu': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _f, _u64, _u64, _i, _vp, _vp]),
     'asr_conv3x3_bwd_weight': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -54,6 +56,8 @@ SIGNATURES = {
     'asr_im2col': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_col2im': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_maxpool2x2_fwd': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'asr_maxpool2x2_fwd_drop': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _u64, _u64, _vp]),
+    'asr_relu_bwd_scaled': (_i, [_vp, _i, _vp, _vp, _sz, _f, _vp, _vp]),
     'asr_maxpool2x2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'asr_relu_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     'asr_maxpool2x2_relu_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _u64, _u64, _i, _vp]),

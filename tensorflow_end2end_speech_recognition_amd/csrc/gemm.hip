@@ -869,12 +869,31 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int M, int N, int K, 
   }
 }
 
-struct ConvGate {               // epilogue operands of conv3x3_nt_bf16_kernel's act == 2
-  const bf16_t* act;            // ReLU output of the layer below, [pixels, Cout of this product]
+struct ConvGate {               // epilogue operands of conv3x3_nt_bf16_kernel's act == 2 / act == 3
+  const bf16_t* act;            // act == 2: ReLU output of the layer below, [pixels, Cout of this product]
   float keep;
   uint64_t seed, offset;        // dropout applied to that output (element e -> Philox block offset + e / 4)
-  int use_drop;
-};
+  int use_drop;                 // act == 2: 1 = form the mask (Philox), 2 = `act` is the DROPPED output: it is > 0 exactly
+};                              //           where the unit was active AND kept, the gradient is scaled by 1 / keep there
+// act == 3 (forward): ReLU, round to the operand dtype, then tf.nn.dropout (mask from keep / seed / offset) -- the stored
+// activation is the dropped one, bit for bit what asr_dropout_apply makes of the stored ReLU output, and the undropped
+// one is never written (the backward needs only its sign where the mask kept it: gate mode 2)
+__device__ __forceinline__ void conv_gate_apply(int act, const ConvGate& gate, size_t e, float (&v)[4]) {
+  typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+  if (act == 2) {
+    const us4_t g = *reinterpret_cast<const us4_t*>(gate.act + e);
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if (gate.use_drop == 1) asr_dropout_words(gate.offset + e / 4, gate.seed, gate.keep, 1.f / gate.keep, mk);
+    else if (gate.use_drop == 2) { const float inv = 1.f / gate.keep; mk[0] = mk[1] = mk[2] = mk[3] = inv; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = bf16_to_f32(g[r]) > 0.f ? v[r] * mk[r] : 0.f;
+  } else if (act == 3) {
+    float mk[4];
+    asr_dropout_words(gate.offset + e / 4, gate.seed, gate.keep, 1.f / gate.keep, mk);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = bf16_to_f32(f32_to_bf16(fmaxf(v[r], 0.f))) * mk[r];
+  }
+}
 
 // ---------------------------------------------------------------- implicit-GEMM 3x3 convolution (bf16)
 // out[p, co] = act(sum_{tap, ci} x[p + s_tap, ci] * Wt[co][tap*Cin + ci] + bias[co]),  SAME padding,
@@ -1004,15 +1023,7 @@ __global__ __launch_bounds__(256) void conv3x3_nt_bf16_kernel(int Mpix, int H, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
-      if (act == 2) {
-        typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
-        const size_t e = (size_t)m * Cout + nb;
-        const us4_t g = *reinterpret_cast<const us4_t*>(gate.act + e);
-        float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (gate.use_drop) asr_dropout_words(gate.offset + e / 4, gate.seed, gate.keep, 1.f / gate.keep, mk);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = bf16_to_f32(g[r]) > 0.f ? v[r] * mk[r] : 0.f;
-      }
+      if (act >= 2) conv_gate_apply(act, gate, (size_t)m * Cout + nb, v);
       if constexpr (sizeof(TO) == 4) {
         *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
       } else {
@@ -1150,15 +1161,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
           }
-          if (act == 2) {
-            typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
-            const size_t e = m * COUT + nb;
-            const us4_t g = *reinterpret_cast<const us4_t*>(gate.act + e);
-            float mk[4] = {1.f, 1.f, 1.f, 1.f};
-            if (gate.use_drop) asr_dropout_words(gate.offset + e / 4, gate.seed, gate.keep, 1.f / gate.keep, mk);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = bf16_to_f32(g[r]) > 0.f ? v[r] * mk[r] : 0.f;
-          }
+          if (act >= 2) conv_gate_apply(act, gate, m * COUT + nb, v);
           if constexpr (sizeof(TO) == 4) {
             *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
           } else {
@@ -1718,6 +1721,18 @@ extern "C" int asr_conv3x3_fwd(asr_handle* h, const void* x, int Nimg, int H, in
   return conv3x3_launch<bf16_t>(h, x, Nimg, H, W, Cin, wt_fwd, bias, Cout, relu ? 1 : 0, out, (hipStream_t)s);
 }
 
+extern "C" int asr_conv3x3_fwd_drop(asr_handle* h, const void* x, int Nimg, int H, int W, int Cin, const void* wt_fwd,
+                                    const float* bias, int Cout, float keep_prob, uint64_t seed, uint64_t offset,
+                                    void* out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!x || !wt_fwd || !out || Nimg < 1 || H < 1 || W < 1 || !(keep_prob > 0.f && keep_prob <= 1.f))
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_fwd_drop: bad args");
+  if (Cin % 64 != 0 || Cout % 64 != 0)
+    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_fwd_drop: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);
+  const ConvGate gate = {nullptr, keep_prob, seed, offset, 1};
+  return conv3x3_launch<bf16_t>(h, x, Nimg, H, W, Cin, wt_fwd, bias, Cout, 3, out, (hipStream_t)s, gate);
+}
+
 extern "C" int asr_conv3x3_bwd_data(asr_handle* h, const void* dy, int Nimg, int H, int W, int Cout,
                                     const void* wt_bwd, int Cin, float* dx, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
@@ -1734,7 +1749,7 @@ extern "C" int asr_conv3x3_bwd_data_relu(asr_handle* h, const void* dy, int Nimg
                                          uint64_t seed, uint64_t offset, int use_drop, void* dpre_below, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   if (!dy || !wt_bwd || !act_below || !dpre_below || Nimg < 1 || H < 1 || W < 1 ||
-      (use_drop && !(keep_prob > 0.f && keep_prob <= 1.f)))
+      (use_drop && !(keep_prob > 0.f && keep_prob <= 1.f)) || use_drop < 0 || use_drop > 2)
     ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_bwd_data_relu: bad args");
   if (Cin % 64 != 0 || Cout % 64 != 0)
     ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_bwd_data_relu: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);

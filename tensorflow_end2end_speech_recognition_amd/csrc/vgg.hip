@@ -125,9 +125,11 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ in, int N, int H, int W
   }
 }
 // four channels per thread (C % 4 == 0): one 8 / 16-byte load per window cell instead of four scalar ones
+// use_drop: tf.nn.dropout on the (rounded) pooled output -- the stored pooled activation is the dropped one
 template <typename T>
 __global__ void maxpool_fwd_vec_kernel(const T* __restrict__ in, int N, int H, int W, int C, T* __restrict__ out,
-                                       uint8_t* __restrict__ arg) {
+                                       uint8_t* __restrict__ arg, float keep = 1.f, uint64_t seed = 0, uint64_t offset = 0,
+                                       int use_drop = 0) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C / 4;
   const size_t total = (size_t)N * Ho * Wo * C4;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
@@ -159,6 +161,12 @@ __global__ void maxpool_fwd_vec_kernel(const T* __restrict__ in, int N, int H, i
       }
     }
     const size_t e = idx * 4;
+    if (use_drop) {                                         // e % 4 == 0: exactly one Philox block
+      float mk[4];
+      asr_dropout_words(offset + e / 4, seed, keep, 1.f / keep, mk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) best[j] = Elem<T>::to_f32(Elem<T>::from_f32(best[j])) * mk[j];
+    }
     if (sizeof(T) == 2) {
       typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
       *reinterpret_cast<us4_t*>(out + e) = (us4_t){f32_to_bf16(best[0]), f32_to_bf16(best[1]), f32_to_bf16(best[2]), f32_to_bf16(best[3])};
@@ -253,7 +261,9 @@ template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_smallc_fwd_mfma_kernel(const bf16_t* __restrict__ x, size_t Npix, int H, int W,
                                                                       const bf16_t* __restrict__ w2d,
                                                                       const float* __restrict__ bias, int relu,
-                                                                      bf16_t* __restrict__ out) {
+                                                                      bf16_t* __restrict__ out, float keep, uint64_t seed,
+                                                                      uint64_t offset, int use_drop) {
+  // use_drop: tf.nn.dropout on the (rounded) ReLU output in the epilogue -- the stored activation is the dropped one
   constexpr int K = 9 * CIN, LDT = SC_CO + 8;
   __shared__ __attribute__((aligned(16))) bf16_t tile[4][64][LDT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -296,6 +306,12 @@ __global__ __launch_bounds__(256) void conv3x3_smallc_fwd_mfma_kernel(const bf16
       us4_t y;
 #pragma unroll
       for (int r = 0; r < 4; ++r) y[r] = f32_to_bf16(relu ? fmaxf(acc[r], 0.f) : acc[r]);
+      if (use_drop) {                                       // element p * 64 + nt * 16 + fq * 4: one Philox block of four
+        float mk[4];
+        asr_dropout_words(offset + (p * SC_CO + nt * 16 + fq * 4) / 4, seed, keep, 1.f / keep, mk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = f32_to_bf16(bf16_to_f32(y[r]) * mk[r]);
+      }
       *reinterpret_cast<us4_t*>(&tile[wave][mt * 16 + fr][nt * 16 + fq * 4]) = y;
     }
   }
@@ -487,6 +503,10 @@ template <typename T>
 __global__ void maxpool_relu_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ arg,
                                         const T* __restrict__ act, int N, int H, int W, int C, T* __restrict__ dpre,
                                         float keep, uint64_t seed, uint64_t offset, int use_drop) {
+  // use_drop == 2: `act` is the POOLED activation AFTER its dropout, [N,Ho,Wo,C] -- it is > 0 exactly where the window's
+  // maximum was active and the mask kept it, so the ReLU test, the mask and its 1 / keep come from one 8-byte read per
+  // pooled cell (shared by the window's four positions) instead of an 8-byte read of the full-resolution ReLU output per
+  // position plus a Philox block; keep == 1: no dropout was applied, the same test still holds
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C / 4;
   const size_t total = (size_t)N * H * W * C4;
   const float inv = use_drop ? 1.f / keep : 1.f;
@@ -500,6 +520,30 @@ __global__ void maxpool_relu_bwd_kernel(const float* __restrict__ dout, const ui
     const f32x4_t g = *reinterpret_cast<const f32x4_t*>(dout + o);
     const uint32_t a4 = *reinterpret_cast<const uint32_t*>(arg + o);
     float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (use_drop == 2) {
+      float pv[4];
+      if (sizeof(T) == 2) {
+        typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+        const us4_t x = *reinterpret_cast<const us4_t*>(act + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = bf16_to_f32(x[j]);
+      } else {
+        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(act + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = x[j];
+      }
+      float r2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r2[j] = (pv[j] > 0.f && (int)((a4 >> (8 * j)) & 0xFFu) == k) ? g[j] * inv : 0.f;
+      const size_t e2 = idx * 4;
+      if (sizeof(T) == 2) {
+        typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+        *reinterpret_cast<us4_t*>(dpre + e2) = (us4_t){f32_to_bf16(r2[0]), f32_to_bf16(r2[1]), f32_to_bf16(r2[2]), f32_to_bf16(r2[3])};
+      } else {
+        *reinterpret_cast<f32x4_t*>(dpre + e2) = (f32x4_t){r2[0], r2[1], r2[2], r2[3]};
+      }
+      continue;
+    }
     if (use_drop) {                                       // o % 4 == 0: exactly the Philox block of the pooled cell
       const uint64_t ctr = offset + o / 4;
       uint32_t cw[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
@@ -542,6 +586,16 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dout, const T* __restr
     if (mask) g *= mask[i];
     dpre[i] = Elem<T>::from_f32(Elem<T>::to_f32(out[i]) > 0.f ? g : 0.f);
   }
+}
+
+// dpre = (out > 0) ? dout * (1 / keep) : 0 -- `out` is a DROPPED ReLU output (> 0 exactly where active and kept); the scale is
+// formed here as 1.f / keep like in every kernel that applies the mask, so the product is the same float
+template <typename T>
+__global__ void relu_bwd_scaled_kernel(const float* __restrict__ dout, const T* __restrict__ out, float keep, size_t n,
+                                       T* __restrict__ dpre) {
+  const float scale = 1.f / keep;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dpre[i] = Elem<T>::from_f32(Elem<T>::to_f32(out[i]) > 0.f ? dout[i] * scale : 0.f);
 }
 
 inline int gridv(size_t n) {
@@ -594,6 +648,34 @@ extern "C" int asr_maxpool2x2_fwd(asr_handle* h, int dtype, const void* in, int 
   ASR_CHECK_LAUNCH(h, "asr_maxpool2x2_fwd");
   return ASR_OK;
 }
+extern "C" int asr_maxpool2x2_fwd_drop(asr_handle* h, int dtype, const void* in, int N, int H, int W, int C, void* out,
+                                       uint8_t* argmax, float keep_prob, uint64_t seed, uint64_t offset, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(asr_dtype_ok(dtype) && in && out && argmax && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 &&
+               keep_prob > 0.f && keep_prob <= 1.f && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)argmax) % 16) == 0,
+           "asr_maxpool2x2_fwd_drop: bad args (C %% 4 == 0, 16-byte aligned arrays)");
+  const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
+  if (!total) return ASR_OK;
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL(maxpool_fwd_vec_kernel<float>, dim3(gridv(total / 4)), dim3(256), 0, (hipStream_t)s, (const float*)in, N, H,
+                       W, C, (float*)out, argmax, keep_prob, seed, offset, 1);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_vec_kernel<bf16_t>, dim3(gridv(total / 4)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, N,
+                       H, W, C, (bf16_t*)out, argmax, keep_prob, seed, offset, 1);
+  ASR_CHECK_LAUNCH(h, "asr_maxpool2x2_fwd_drop");
+  return ASR_OK;
+}
+extern "C" int asr_relu_bwd_scaled(asr_handle* h, int dtype, const float* dout, const void* out, size_t n, float keep,
+                                   void* dpre, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(asr_dtype_ok(dtype) && dout && out && dpre && keep > 0.f && keep <= 1.f, "asr_relu_bwd_scaled: bad args");
+  if (!n) return ASR_OK;
+  if (dtype == ASR_F32) hipLaunchKernelGGL(relu_bwd_scaled_kernel<float>, dim3(gridv(n)), dim3(256), 0, (hipStream_t)s, dout, (const float*)out, keep, n, (float*)dpre);
+  else hipLaunchKernelGGL(relu_bwd_scaled_kernel<bf16_t>, dim3(gridv(n)), dim3(256), 0, (hipStream_t)s, dout, (const bf16_t*)out, keep, n, (bf16_t*)dpre);
+  ASR_CHECK_LAUNCH(h, "asr_relu_bwd_scaled");
+  return ASR_OK;
+}
+
 extern "C" int asr_maxpool2x2_bwd(asr_handle* h, const float* dout, const uint8_t* argmax, int N, int H, int W,
                                   int C, float* din, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
@@ -604,8 +686,23 @@ extern "C" int asr_maxpool2x2_bwd(asr_handle* h, const float* dout, const uint8_
   ASR_CHECK_LAUNCH(h, "asr_maxpool2x2_bwd");
   return ASR_OK;
 }
+static int smallc_fwd_launch(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* w2d, const float* bias,
+                             int Cout, int relu, void* out, float keep, uint64_t seed, uint64_t offset, int use_drop,
+                             asr_stream s);
 extern "C" int asr_conv3x3_smallc_fwd(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* w2d,
                                      const float* bias, int Cout, int relu, void* out, asr_stream s) {
+  return smallc_fwd_launch(h, x, N, H, W, Cin, w2d, bias, Cout, relu, out, 1.f, 0, 0, 0, s);
+}
+extern "C" int asr_conv3x3_smallc_fwd_drop(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* w2d,
+                                          const float* bias, int Cout, float keep_prob, uint64_t seed, uint64_t offset,
+                                          void* out, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  VGG_NEED(keep_prob > 0.f && keep_prob <= 1.f, "asr_conv3x3_smallc_fwd_drop: keep_prob");
+  return smallc_fwd_launch(h, x, N, H, W, Cin, w2d, bias, Cout, 1, out, keep_prob, seed, offset, 1, s);
+}
+static int smallc_fwd_launch(asr_handle* h, const void* x, int N, int H, int W, int Cin, const void* w2d, const float* bias,
+                             int Cout, int relu, void* out, float keep, uint64_t seed, uint64_t offset, int use_drop,
+                             asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   VGG_NEED(x && w2d && out && N >= 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 3 && Cout == SC_CO &&
                ((uintptr_t)out) % 16 == 0, "asr_conv3x3_smallc_fwd: needs Cin <= 3, Cout == 64");
@@ -618,7 +715,8 @@ extern "C" int asr_conv3x3_smallc_fwd(asr_handle* h, const void* x, int N, int H
   static const bool mfma = [] { const char* e = getenv("ASR_SMALLC_MFMA"); return !(e && e[0] == '0'); }();
 #define ASR_SC_FWD_M(C_) \
   hipLaunchKernelGGL(conv3x3_smallc_fwd_mfma_kernel<C_>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)s, \
-                     (const bf16_t*)x, npix, H, W, (const bf16_t*)w2d, bias, relu, (bf16_t*)out)
+                     (const bf16_t*)x, npix, H, W, (const bf16_t*)w2d, bias, relu, (bf16_t*)out, keep, seed, offset, use_drop)
+  if (use_drop && !mfma) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_conv3x3_smallc_fwd_drop needs the matrix-core kernel (ASR_SMALLC_MFMA)");
   if (mfma) { if (Cin == 1) ASR_SC_FWD_M(1); else if (Cin == 2) ASR_SC_FWD_M(2); else ASR_SC_FWD_M(3); }
   else if (Cin == 1) ASR_SC_FWD(1); else if (Cin == 2) ASR_SC_FWD(2); else ASR_SC_FWD(3);
 #undef ASR_SC_FWD_M
@@ -663,7 +761,7 @@ extern "C" int asr_maxpool2x2_relu_bwd(asr_handle* h, int dtype, const float* do
                                       uint64_t seed, uint64_t offset, int use_drop, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   VGG_NEED(asr_dtype_ok(dtype) && dout && argmax && act && dpre && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 &&
-               (!use_drop || (keep_prob > 0.f && keep_prob <= 1.f)) &&
+               (!use_drop || (keep_prob > 0.f && keep_prob <= 1.f)) && use_drop >= 0 && use_drop <= 2 &&
                (((uintptr_t)dout | (uintptr_t)argmax | (uintptr_t)act | (uintptr_t)dpre) % 16) == 0,
            "asr_maxpool2x2_relu_bwd: bad args (C %% 4 == 0, 16-byte aligned arrays)");
   const size_t total = (size_t)N * H * W * (C / 4);

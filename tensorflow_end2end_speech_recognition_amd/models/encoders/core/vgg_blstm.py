@@ -13,6 +13,8 @@ implicit GEMMs (asr_conv3x3_fwd / _bwd_data / _bwd_weight: no patch matrix); the
 layer and the fp32 parity path use asr_im2col3x3 + MFMA GEMM with fused bias+ReLU, chunked over
 frames (CHUNK_FRAMES) so the patch matrix is a bounded scratch; backward recomputes the patches.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -46,6 +48,9 @@ class _VGGFrontEnd(object):
         self.dtype = dtype
         self.out_dim = 256
         self.prefix = ''
+        # dropout in the epilogue of the producing kernels (forward()); ASR_VGG_FUSED_DROP=0 / .fused_drop = False: every
+        # dropout as its own pass over the stored activation (A/B and the equality test)
+        self.fused_drop = os.environ.get('ASR_VGG_FUSED_DROP', '1') != '0'
 
     def build(self, store, rng, prefix=''):
         self.store, self.prefix = store, prefix
@@ -121,16 +126,42 @@ class _VGGFrontEnd(object):
             d = (float(keep_prob), seed + 7, off + (self._drop_i << 32))
             self.ctx['masks'][key] = d
             return ops.dropout_apply(t, *d)
-        a1 = self._layer(x0, CONVS[0], sh)
-        a1d = dropout(a1, 'a1')
-        a2 = self._layer(a1d, CONVS[1], sh)
-        p1, arg1 = ops.maxpool2x2_fwd(a2)
-        p1d = dropout(p1, 'p1')
-        a3 = self._layer(p1d, CONVS[2], sh)
-        a3d = dropout(a3, 'a3')
-        a4 = self._layer(a3d, CONVS[3], sh)
-        p2, arg2 = ops.maxpool2x2_fwd(a4)
-        p2d = dropout(p2, 'p2')
+        def descriptor(key):
+            """The dropout of tensor `key` as (keep, seed, offset) -- same numbering as dropout() -- for the kernels that
+            apply it in their epilogue."""
+            seed, off = rng_state
+            self._drop_i += 1
+            d = (float(keep_prob), seed + 7, off + (self._drop_i << 32))
+            self.ctx['masks'][key] = d
+            return d
+        # Round 4: on the bf16 MFMA path tf.nn.dropout is applied in the epilogue of the kernel that produces the tensor
+        # (first-layer and implicit-GEMM convolutions, max-pool): the undropped ReLU output is never written and there is no
+        # pass over the gigabyte activations just to mask them (3.6 ms of an 83 ms cfg C step).  Same masks, same values:
+        # the dropped tensors are bit-identical to dropout_apply of the separate outputs; the backward takes "active and
+        # kept" from the sign of the dropped tensor.
+        fused = (drop and self.dtype == ASR_BF16 and self.fused_drop and self._direct(*CONVS[0][1:]) and
+                 all(self._implicit(*c[1:]) for c in CONVS[1:]))      # (.fused_drop = False: the separate passes, A/B + tests)
+        self.ctx['fused_drop'] = fused
+        if fused:
+            w1 = sh[self.prefix + CONVS[0][0] + '/weight'].view(9 * CONVS[0][1], CONVS[0][2])
+            a1 = a1d = ops.conv3x3_smallc_fwd_drop(x0, w1, st[self.prefix + CONVS[0][0] + '/bias'], descriptor('a1'))
+            a2 = self._layer(a1d, CONVS[1], sh)
+            p1d, arg1 = ops.maxpool2x2_fwd_drop(a2, descriptor('p1'))
+            a3 = a3d = ops.conv3x3_fwd_drop(p1d, self._conv_images(CONVS[2][0])[0], st[self.prefix + CONVS[2][0] + '/bias'],
+                                            descriptor('a3'))
+            a4 = self._layer(a3d, CONVS[3], sh)
+            p2d, arg2 = ops.maxpool2x2_fwd_drop(a4, descriptor('p2'))
+        else:
+            a1 = self._layer(x0, CONVS[0], sh)
+            a1d = dropout(a1, 'a1')
+            a2 = self._layer(a1d, CONVS[1], sh)
+            p1, arg1 = ops.maxpool2x2_fwd(a2)
+            p1d = dropout(p1, 'p1')
+            a3 = self._layer(p1d, CONVS[2], sh)
+            a3d = dropout(a3, 'a3')
+            a4 = self._layer(a3d, CONVS[3], sh)
+            p2, arg2 = ops.maxpool2x2_fwd(a4)
+            p2d = dropout(p2, 'p2')
         flat = p2d.reshape(N, self.flat)
         br = ops.gemm(flat, sh[self.prefix + 'bridge/weights'], bias=st[self.prefix + 'bridge/biases'], relu=True)
         brd = dropout(br, 'br')
@@ -175,12 +206,16 @@ class _VGGFrontEnd(object):
         return out
 
     # conv backward on the full batch, chunked: dout fp32 [N,H,W,Cout] -> din fp32 [N,H,W,Cin]; fills dW, db
-    def _conv_bwd(self, dout, out, mask, x_in, conv, sh, need_dx=True, pooled=None, below=None, dout_is_dpre=False):
+    def _conv_bwd(self, dout, out, mask, x_in, conv, sh, need_dx=True, pooled=None, below=None, dout_is_dpre=False,
+                  out_dropped=False):
         """pooled = (argmax, drop or None): dout is the gradient of the POOLED output (before its dropout); un-pooling,
         that dropout and this convolution's ReLU backward run as one kernel (implicit-GEMM layers).
         below = (act, drop or None) of the layer below (implicit-GEMM layers): the data gradient comes back as that
         layer's pre-activation gradient in the operand dtype (its ReLU / dropout backward in the convolution's
-        epilogue) and is passed to its _conv_bwd with dout_is_dpre=True."""
+        epilogue) and is passed to its _conv_bwd with dout_is_dpre=True.
+        Fused-dropout forward (ctx['fused_drop']): pooled = (argmax, drop, pooled activation AFTER its dropout) -- that
+        tensor replaces `out` and the mask in the un-pooling pass; below = (DROPPED act, drop, True); out_dropped: `out`
+        is the dropped ReLU output, the mask is its sign and the scale 1 / keep."""
         name, cin, cout = conv
         st = self.store
         N, H, W, _ = out.shape
@@ -194,8 +229,12 @@ class _VGGFrontEnd(object):
         if self._implicit(cin, cout):
             if dout_is_dpre:
                 dpre = dout
+            elif pooled is not None and len(pooled) > 2:
+                dpre = ops.maxpool2x2_relu_bwd(dout.contiguous(), pooled[0], None, drop=pooled[1], pooled=pooled[2], hw=(H, W))
             elif pooled is not None:
                 dpre = ops.maxpool2x2_relu_bwd(dout.contiguous(), pooled[0], out, drop=pooled[1])
+            elif out_dropped and mask is not None:
+                dpre = ops.relu_bwd_scaled(dout.contiguous(), out, mask[0])
             else:
                 dpre = ops.relu_bwd(dout.contiguous(), out, drop=mask)         # [N,H,W,cout] bf16
             ops.conv3x3_bwd_weight(x_in, dpre, gw)
@@ -203,10 +242,16 @@ class _VGGFrontEnd(object):
             if not need_dx:
                 return None
             if below is not None:
-                return ops.conv3x3_bwd_data_relu(dpre, self._conv_images(name)[1], below[0], drop=below[1])
+                return ops.conv3x3_bwd_data_relu(dpre, self._conv_images(name)[1], below[0], drop=below[1],
+                                                 dropped=len(below) > 2 and below[2] and below[1] is not None)
             return ops.conv3x3_bwd_data(dpre, self._conv_images(name)[1])
         if self._direct(cin, cout) and not need_dx:
-            dpre = dout if dout_is_dpre else ops.relu_bwd(dout.contiguous(), out, drop=mask)
+            if dout_is_dpre:
+                dpre = dout
+            elif out_dropped and mask is not None:
+                dpre = ops.relu_bwd_scaled(dout.contiguous(), out, mask[0])
+            else:
+                dpre = ops.relu_bwd(dout.contiguous(), out, drop=mask)
             ops.conv3x3_smallc_bwd_weight(x_in, dpre, gw)
             ops.colsum(dpre.view(N * H * W, cout), out=gb)
             return None
@@ -261,12 +306,19 @@ class _VGGFrontEnd(object):
         # gradient's epilogue (no fp32 activation gradient is written): conv4 -> a3, conv2 -> a1
         fuse43 = self._implicit(*CONVS[3][1:]) and self._implicit(*CONVS[2][1:])
         fuse21 = self._implicit(*CONVS[1][1:]) and self.dtype == ASR_BF16
-        da3d = self._conv_bwd(dp2, c['a4'], None, c['a3d'], CONVS[3], sh, pooled=(c['arg2'], m.get('p2')),
-                              below=(c['a3'], m.get('a3')) if fuse43 else None)
-        dp1d = self._conv_bwd(da3d, c['a3'], m.get('a3'), c['p1d'], CONVS[2], sh, dout_is_dpre=fuse43)
-        da1d = self._conv_bwd(dp1d, c['a2'], None, c['a1d'], CONVS[1], sh, pooled=(c['arg1'], m.get('p1')),
-                              below=(c['a1'], m.get('a1')) if fuse21 else None)
-        self._conv_bwd(da1d, c['a1'], m.get('a1'), c['x0'], CONVS[0], sh, need_dx=False, dout_is_dpre=fuse21)
+        fd = bool(c.get('fused_drop'))      # a1 / a3 are the DROPPED outputs, the pooled tensors carry their masks
+        # (the pooled tensor as the mask source of the un-pooling pass works with or without dropout on the implicit path)
+        pool_src = (self._implicit(*CONVS[3][1:]) and self._implicit(*CONVS[1][1:]) and
+                    (fd or self.fused_drop))
+        da3d = self._conv_bwd(dp2, c['a4'], None, c['a3d'], CONVS[3], sh,
+                              pooled=(c['arg2'], m.get('p2'), c['p2d']) if pool_src else (c['arg2'], m.get('p2')),
+                              below=(c['a3'], m.get('a3'), fd) if fuse43 else None)
+        dp1d = self._conv_bwd(da3d, c['a3'], m.get('a3'), c['p1d'], CONVS[2], sh, dout_is_dpre=fuse43, out_dropped=fd)
+        da1d = self._conv_bwd(dp1d, c['a2'], None, c['a1d'], CONVS[1], sh,
+                              pooled=(c['arg1'], m.get('p1'), c['p1d']) if pool_src else (c['arg1'], m.get('p1')),
+                              below=(c['a1'], m.get('a1'), fd) if fuse21 else None)
+        self._conv_bwd(da1d, c['a1'], m.get('a1'), c['x0'], CONVS[0], sh, need_dx=False, dout_is_dpre=fuse21,
+                       out_dropped=fd)
         self.ctx = None
 
 

@@ -413,6 +413,18 @@ def conv3x3_fwd(x_nhwc, wt_fwd, bias, relu=True):
     return out
 
 
+def conv3x3_fwd_drop(x_nhwc, wt_fwd, bias, drop):
+    """dropout_apply(conv3x3_fwd(x, ..., relu=True), *drop) in one launch (the undropped activation is never written)."""
+    h = _h(x_nhwc)
+    _chk(x_nhwc, torch.bfloat16, 'x')
+    N, H, W, Cin = x_nhwc.shape
+    Cout = wt_fwd.shape[0]
+    out = torch.empty((N, H, W, Cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    h.check(h.lib.asr_conv3x3_fwd_drop(h.h, _p(x_nhwc), N, H, W, Cin, _p(wt_fwd), _p(bias), Cout, float(drop[0]),
+                                       int(drop[1]), int(drop[2]), _p(out), _s()), 'asr_conv3x3_fwd_drop')
+    return out
+
+
 def conv3x3_bwd_data(dy_nhwc, wt_bwd):
     h = _h(dy_nhwc)
     _chk(dy_nhwc, torch.bfloat16, 'dy')
@@ -436,6 +448,19 @@ def conv3x3_smallc_fwd(x_nhwc, w2d, bias, relu=True):
     return out
 
 
+def conv3x3_smallc_fwd_drop(x_nhwc, w2d, bias, drop):
+    """dropout_apply(conv3x3_smallc_fwd(x, ..., relu=True), *drop) in one launch."""
+    h = _h(x_nhwc)
+    _chk(x_nhwc, torch.bfloat16, 'x')
+    _chk(w2d, torch.bfloat16, 'w2d')
+    N, H, W, Cin = x_nhwc.shape
+    out = torch.empty((N, H, W, w2d.shape[1]), dtype=torch.bfloat16, device=x_nhwc.device)
+    h.check(h.lib.asr_conv3x3_smallc_fwd_drop(h.h, _p(x_nhwc), N, H, W, Cin, _p(w2d), _p(bias), w2d.shape[1],
+                                              float(drop[0]), int(drop[1]), int(drop[2]), _p(out), _s()),
+            'asr_conv3x3_smallc_fwd_drop')
+    return out
+
+
 def conv3x3_smallc_bwd_weight(x_nhwc, dpre_nhwc, dw):
     """dw fp32 [9*Cin, 64] = patches(x)^T dpre (both bf16), no patch matrix."""
     h = _h(x_nhwc)
@@ -447,7 +472,7 @@ def conv3x3_smallc_bwd_weight(x_nhwc, dpre_nhwc, dw):
     return dw
 
 
-def conv3x3_bwd_data_relu(dy_nhwc, wt_bwd, act_below, drop=None):
+def conv3x3_bwd_data_relu(dy_nhwc, wt_bwd, act_below, drop=None, dropped=False):
     """relu_bwd(conv3x3_bwd_data(dy, wt_bwd), act_below, drop=drop) without the fp32 gradient in between -> bf16."""
     h = _h(dy_nhwc)
     _chk(dy_nhwc, torch.bfloat16, 'dy')
@@ -456,8 +481,10 @@ def conv3x3_bwd_data_relu(dy_nhwc, wt_bwd, act_below, drop=None):
     Cin = wt_bwd.shape[0]
     dpre = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=dy_nhwc.device)
     k, sd, off = drop if drop is not None else (1.0, 0, 0)
+    # dropped=True: act_below is the DROPPED activation (conv3x3_fwd_drop): no mask is formed, dx * (1 / keep) where it is > 0
+    mode = 0 if drop is None else (2 if dropped else 1)
     h.check(h.lib.asr_conv3x3_bwd_data_relu(h.h, _p(dy_nhwc), N, H, W, Cout, _p(wt_bwd), Cin, _p(act_below), float(k),
-                                            int(sd), int(off), int(drop is not None), _p(dpre), _s()),
+                                            int(sd), int(off), mode, _p(dpre), _s()),
             'asr_conv3x3_bwd_data_relu')
     return dpre
 
@@ -531,6 +558,18 @@ def maxpool2x2_fwd(x_nhwc):
     return out, arg
 
 
+def maxpool2x2_fwd_drop(x_nhwc, drop):
+    """dropout_apply(maxpool2x2_fwd(x)[0], *drop) and the argmax in one launch."""
+    h = _h(x_nhwc)
+    dt = dtype_id(x_nhwc.dtype)
+    N, H, W, Cc = x_nhwc.shape
+    out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, Cc), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    arg = torch.empty(out.shape, dtype=torch.uint8, device=x_nhwc.device)
+    h.check(h.lib.asr_maxpool2x2_fwd_drop(h.h, dt, _p(x_nhwc), N, H, W, Cc, _p(out), _p(arg), float(drop[0]), int(drop[1]),
+                                          int(drop[2]), _s()), 'asr_maxpool2x2_fwd_drop')
+    return out, arg
+
+
 def maxpool2x2_bwd(dout, arg, H, W):
     h = _h(dout)
     N, _, _, Cc = dout.shape
@@ -539,16 +578,35 @@ def maxpool2x2_bwd(dout, arg, H, W):
     return din
 
 
-def maxpool2x2_relu_bwd(dout, arg, act, drop=None):
+def maxpool2x2_relu_bwd(dout, arg, act, drop=None, pooled=None, hw=None):
     """relu_bwd(maxpool2x2_bwd(dropout_apply(dout, *drop)), act) in one pass: dout [N,Ho,Wo,C] fp32 pooled gradient,
-    arg the pool's argmax, act [N,H,W,C] the ReLU output under the pool (operand dtype) -> dpre like act."""
+    arg the pool's argmax, act [N,H,W,C] the ReLU output under the pool (operand dtype) -> dpre like act.
+    pooled (with hw = (H, W)): the POOLED activation after its dropout (maxpool2x2_fwd_drop; or the plain pooled output when
+    drop is None) instead of act -- it is > 0 exactly where the window's maximum was active and kept, so neither the
+    full-resolution activation is read nor a mask formed."""
     h = _h(dout)
+    k, sd, off = drop if drop is not None else (1.0, 0, 0)
+    if pooled is not None:
+        N, _, _, Cc = pooled.shape
+        H, W = hw
+        dpre = torch.empty((N, H, W, Cc), dtype=pooled.dtype, device=pooled.device)
+        h.check(h.lib.asr_maxpool2x2_relu_bwd(h.h, dtype_id(pooled.dtype), _p(dout), _p(arg), _p(pooled), N, H, W, Cc, _p(dpre),
+                                              float(k), 0, 0, 2, _s()), 'asr_maxpool2x2_relu_bwd')
+        return dpre
     N, H, W, Cc = act.shape
     dpre = torch.empty_like(act)
-    k, sd, off = drop if drop is not None else (1.0, 0, 0)
     h.check(h.lib.asr_maxpool2x2_relu_bwd(h.h, dtype_id(act.dtype), _p(dout), _p(arg), _p(act), N, H, W, Cc, _p(dpre),
                                           float(k), int(sd), int(off), int(drop is not None), _s()),
             'asr_maxpool2x2_relu_bwd')
+    return dpre
+
+
+def relu_bwd_scaled(dout, out_dropped, keep):
+    """dpre = (out_dropped > 0) ? dout * (1 / keep) : 0 (out_dropped: a ReLU output after its dropout with keep_prob keep)."""
+    h = _h(dout)
+    dpre = torch.empty_like(out_dropped)
+    h.check(h.lib.asr_relu_bwd_scaled(h.h, dtype_id(out_dropped.dtype), _p(dout), _p(out_dropped), out_dropped.numel(),
+                                      float(keep), _p(dpre), _s()), 'asr_relu_bwd_scaled')
     return dpre
 
 

@@ -776,7 +776,11 @@ def _maxpool2x2_bwd(dout, arg, H, W):
     return g[:, :H, :W].contiguous()
 
 
-def _maxpool2x2_relu_bwd(dout, arg, act, drop=None):
+def _maxpool2x2_relu_bwd(dout, arg, act, drop=None, pooled=None, hw=None):
+    if pooled is not None:      # the pooled activation after its dropout is the mask source: > 0 where active and kept
+        H, W = hw
+        d = dout * (pooled > 0).to(dout.dtype) * (1.0 / drop[0] if drop is not None else 1.0)
+        return _maxpool2x2_bwd(d, arg, H, W).to(pooled.dtype)
     d = dout if drop is None else _dropout_apply(dout, *drop)
     N, H, W, _ = act.shape
     return _relu_bwd(_maxpool2x2_bwd(d, arg, H, W), act).to(act.dtype)

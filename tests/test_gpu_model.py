@@ -261,6 +261,42 @@ def test_vgg_blstm_ctc_parity(cuda):
     assert l.item() < 0.8 * l0
 
 
+@pytest.mark.parametrize('B', [3, 6])
+def test_vgg_dropout_in_the_producing_kernels_equals_the_separate_passes(cuda, B):
+    """The bf16 VGG front-end with tf.nn.dropout applied in the convolution / max-pool epilogues (default) against the
+    same step with every dropout as its own pass over the stored activation (front.fused_drop = False), same Philox
+    counters: identical loss, logits and -- up to the summation order of the atomically accumulated weight gradients --
+    every gradient.  B = 3: 42 images (tiled convolution kernels); B = 6: 84 images (image-resident kernels)."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    rng = np.random.RandomState(31 + B)
+    T, F, W, H, L, C = 14, 40, 11, 256, 1, 28
+    x, sl, labs, dense = _batch(rng, B, T, F * W * 3, C, lo=6)
+    model = CTC(encoder_type='vgg_blstm', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
+                parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='bf16', seed=7)
+    opt = model._set_optimizer('sgd', 0.1)
+    runs = {}
+    for fused in (True, False, False):
+        model.encoder.front.fused_drop = fused
+        calls = model._dropout_calls
+        loss, logits = model.compute_loss(x, dense, sl, keep_prob=0.8)
+        assert model.encoder.front.ctx['fused_drop'] == fused
+        gv = opt.compute_gradients(loss, model=model)
+        torch.cuda.synchronize()
+        runs.setdefault(fused, []).append((loss.item(), logits.clone(), model.store.grad.clone()))
+        model._dropout_calls = calls                      # replay the same masks
+    assert ops.check_async_errors(0) == 0
+    (lf, zf, gf), = runs[True]
+    (l0, z0, g0), (l1, z1, g1) = runs[False]
+    assert lf == l0 == l1 and torch.equal(zf, z0)
+    scale = float(g0.abs().max())
+    noise = float((g1 - g0).abs().max())                  # run-to-run spread of the separate-pass step itself
+    diff = float((gf - g0).abs().max())
+    print('\nfused vs separate dropout: loss %.6f  grad max |diff| %.3e  (run-to-run %.3e, max |g| %.3e)'
+          % (lf, diff, noise, scale))
+    assert scale > 0 and diff <= max(4 * noise, 2e-6 * scale)
+
+
 def test_vgg_blstm_bf16_parity_at_the_cfgC_image_size(cuda):
     """BASELINE configs[2] front-end at its own image size (40 mel bins x splice 11 x {static, delta, delta-delta}, the
     implicit-GEMM convolutions with 64 / 128 channels on MFMA) + one 512-unit BLSTM layer (the 8-CU cluster kernels)

@@ -1091,6 +1091,76 @@ def test_pool_dropout_relu_backward_in_one_pass(cuda, dtype, N, H, W, C, drop):
     assert float(got.float().abs().sum()) > 0
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(5, 7, 5, 64, 64), (3, 40, 11, 64, 128), (70, 6, 3, 128, 128), (2, 1, 1, 64, 64),
+                                            (70, 40, 11, 64, 64), (66, 20, 6, 64, 128), (65, 20, 6, 128, 128),
+                                            (300, 5, 4, 64, 64)])
+def test_conv_relu_dropout_in_the_epilogue(cuda, N, H, W, Cin, Cout):
+    """asr_conv3x3_fwd_drop == asr_dropout_apply(asr_conv3x3_fwd(relu)) bit for bit (tiled and image-resident kernels),
+    and the backward forms that read the DROPPED activation -- asr_conv3x3_bwd_data_relu mode 2, asr_relu_bwd_scaled --
+    equal the ones that re-form the Philox mask over the undropped activation."""
+    ops = _ops()
+    rng = np.random.RandomState(N + H + Cin + 1)
+    x = torch.tensor(rng.randn(N, H, W, Cin), dtype=torch.float32, device=cuda).to(torch.bfloat16)
+    w = torch.tensor(rng.randn(3, 3, Cin, Cout) * 0.05, dtype=torch.float32, device=cuda)
+    b = torch.tensor(rng.randn(Cout) * 0.1, dtype=torch.float32, device=cuda)
+    wf, _ = ops.conv3x3_prep_weights(w)
+    d = (0.9, 21, (4 << 32) + 3)                                        # 1 / 0.9 is not exact: the scale must be formed alike
+    act = ops.conv3x3_fwd(x, wf, b, relu=True)
+    want = ops.dropout_apply(act, *d)
+    got = ops.conv3x3_fwd_drop(x, wf, b, d)
+    assert torch.equal(got, want)
+    frac = float((got > 0).float().mean()) / max(float((act > 0).float().mean()), 1e-9)
+    assert 0.8 < frac < 0.97                                         # ~ keep_prob of the active units survive
+    # backward through this ReLU + dropout from the dropped tensor
+    dout = torch.tensor(rng.randn(N, H, W, Cout), dtype=torch.float32, device=cuda)
+    assert torch.equal(ops.relu_bwd_scaled(dout, got, d[0]), ops.relu_bwd(dout, act, drop=d))
+    # ... and in the epilogue of the data gradient of the layer above (Cout2 -> Cout channels)
+    w2 = torch.tensor(rng.randn(3, 3, Cout, 128) * 0.05, dtype=torch.float32, device=cuda)
+    _, wb2 = ops.conv3x3_prep_weights(w2)
+    dy = torch.tensor(rng.randn(N, H, W, 128), dtype=torch.float32, device=cuda).to(torch.bfloat16)
+    ref = ops.conv3x3_bwd_data_relu(dy, wb2, act, drop=d)
+    assert torch.equal(ops.conv3x3_bwd_data_relu(dy, wb2, got, drop=d, dropped=True), ref)
+    assert float(ref.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize('N,H,W,Cin', [(5, 40, 11, 3), (70, 40, 11, 3), (3, 7, 5, 1), (2, 1, 1, 3)])
+def test_first_layer_conv_relu_dropout_in_the_epilogue(cuda, N, H, W, Cin):
+    """asr_conv3x3_smallc_fwd_drop == asr_dropout_apply(asr_conv3x3_smallc_fwd(relu)), bit for bit."""
+    ops = _ops()
+    rng = np.random.RandomState(N + H + Cin + 2)
+    x = torch.tensor(rng.randn(N, H, W, Cin), dtype=torch.float32, device=cuda).to(torch.bfloat16)
+    w2d = torch.tensor(rng.randn(9 * Cin, 64) * 0.2, dtype=torch.float32, device=cuda).to(torch.bfloat16)
+    b = torch.tensor(rng.randn(64) * 0.1, dtype=torch.float32, device=cuda)
+    d = (0.8, 13, (1 << 32) + 6)
+    want = ops.dropout_apply(ops.conv3x3_smallc_fwd(x, w2d, b, relu=True), *d)
+    got = ops.conv3x3_smallc_fwd_drop(x, w2d, b, d)
+    assert torch.equal(got, want) and float(got.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('N,H,W,C,drop', [(5, 40, 11, 64, True), (3, 20, 6, 128, True), (3, 20, 6, 128, False),
+                                          (2, 5, 3, 8, True), (70, 40, 11, 64, True)])
+def test_pool_dropout_in_one_pass_and_its_backward_from_the_pooled_tensor(cuda, dtype, N, H, W, C, drop):
+    """asr_maxpool2x2_fwd_drop == asr_maxpool2x2_fwd + asr_dropout_apply (values and argmax), and
+    asr_maxpool2x2_relu_bwd in mode 2 (mask = sign of the pooled, dropped activation; no Philox, no full-resolution
+    activation read) == the mode that re-forms the mask over the activation, bit for bit."""
+    ops = _ops()
+    rng = np.random.RandomState(N * H + C + 3)
+    act = torch.tensor(rng.randn(N, H, W, C), dtype=torch.float32, device=cuda).clamp_min(0).to(dtype)
+    pooled, arg = ops.maxpool2x2_fwd(act)
+    d = (0.8, 5, (3 << 32) + 9) if drop else None
+    if drop:
+        pd, arg2 = ops.maxpool2x2_fwd_drop(act, d)
+        assert torch.equal(arg2, arg) and torch.equal(pd, ops.dropout_apply(pooled, *d))
+    else:
+        pd = pooled
+    dp = torch.tensor(rng.randn(*pooled.shape), dtype=torch.float32, device=cuda)
+    ref = ops.maxpool2x2_relu_bwd(dp, arg, act, drop=d)
+    got = ops.maxpool2x2_relu_bwd(dp, arg, None, drop=d, pooled=pd, hw=(H, W))
+    assert got.dtype == act.dtype and torch.equal(got, ref)
+    assert float(got.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_dropout_formed_in_the_kernel_equals_the_stored_mask(cuda, dtype):
     """asr_dropout_apply == asr_dropout_mask + asr_apply_mask and asr_relu_bwd_drop == asr_relu_bwd with that mask, bit
