@@ -55,7 +55,7 @@ typedef enum {
 } asr_optimizer;
 
 /* ---- lifetime ------------------------------------------------------------ */
-int asr_abi_version(void);                                         /* 2 since round 4 (additions + the two size changes noted at asr_create_ex / asr_ctc_beam_workspace_bytes) */
+int asr_abi_version(void);                                         /* 3: round 4 (2: additions + the two size changes noted at asr_create_ex / asr_ctc_beam_workspace_bytes; 3: asr_att_decoder grew a trailing field) */
 int asr_create(asr_handle** out, int device);                        /* 192 MiB scratch arena */
 int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes); /* >= 96 MiB (64 MiB of it: recurrence exchange areas) */
 size_t asr_scratch_bytes(asr_handle* h);
@@ -427,6 +427,18 @@ int asr_lstm_cell_fwd_ex(asr_handle* h, const float* pre, const float* c_prev, c
                          float cell_clip, float* gates, float* c_raw, float* c_out, float* h_out,
                          float* h_raw, const float* out_mask, float* cell_out, float* h_out2, int ld_h2,
                          float* cell_out2, int ld_c2, asr_stream s);
+/* asr_gemm_act(x [B,K] (row stride ldx) x W [K,4U] + b) -> asr_lstm_cell_fwd_ex as ONE launch (a decoder step's first two
+ * kernels): the product runs on the gate-INTERLEAVED weight image W_il [(K + 1), 4U] (column 4 u + g = gate g of unit u, the
+ * last row the bias; written by asr_lstm_cell_gemm_prep once per weight update), so a workgroup holds all four gates of its
+ * units and applies the cell in its epilogue; the pre-activations are never written.  Same arithmetic in the same order
+ * as the two separate calls: bit-identical outputs.  asr_lstm_cell_gemm_ok: B <= 32, K % 64 == 0, U % 8 == 0, ldx % 4 == 0. */
+int asr_lstm_cell_gemm_ok(int B, int K, int U, int ldx);
+int asr_lstm_cell_gemm_prep(asr_handle* h, const float* W, const float* bias, int K, int U, float* W_il, asr_stream s);
+int asr_lstm_cell_gemm_fwd(asr_handle* h, const float* x, int ldx, int K, const float* W_il, int has_bias,
+                           const float* c_prev, const float* h_prev, const float* peep, const float* live,
+                           int B, int U, float forget_bias, float cell_clip, float* gates, float* c_raw,
+                           float* c_out, float* h_out, float* h_raw, const float* out_mask, float* cell_out,
+                           float* h_out2, int ld_h2, float* cell_out2, int ld_c2, asr_stream s);
 /* dh_use: gradient on the cell output of live rows; dc_next/dh_next: gradient on the carried state.
  * dpre[B,4U]; dc_prev; dh_prev_carry (pass-through part, add (dpre W^T)[h] for live rows);
  * dpeep_rows[B][3][U] per-row peephole gradient terms (sum over rows/steps on the caller side). */
@@ -530,6 +542,10 @@ typedef struct asr_att_decoder {
   float *dctx_all, *dpre_all, *dqz_all, *dv_all, *dpeep_all, *d_in_all;   /* [To,B,E2|4U|A|A or NULL|3U or NULL|Em+E2+U] */
   float *dkeys, *dwfil_rows, *dfilt_rows;       /* [T,B,A] += or NULL; carry_alpha: [B,10,A], [B,taps,10] */
   float *dc0, *dh0;                             /* [B,U] out: gradient w.r.t. the initial state */
+  /* forward / inference, optional (abi 3): (Em+E2+U+1) x 4U floats of work space.  When given (and asr_lstm_cell_gemm_ok)
+   * the loop writes the gate-interleaved image of W_cell | b_cell there once (asr_lstm_cell_gemm_prep) and every step runs
+   * the cell-input product and the LSTM cell as ONE launch (asr_lstm_cell_gemm_fwd) -- same values, bit for bit. */
+  float *W_cell_il;
 } asr_att_decoder;
 int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_stream s);
 /* ---- greedy inference, native ------------------------------------------------------------------------------ *

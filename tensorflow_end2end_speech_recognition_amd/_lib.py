@@ -85,6 +85,10 @@ SIGNATURES = {
     'asr_softmax_rows': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'asr_lstm_cell_fwd': (_i, [_vp] * 6 + [_i, _i, _f, _f] + [_vp] * 6),
     'asr_lstm_cell_fwd_ex': (_i, [_vp] * 6 + [_i, _i, _f, _f] + [_vp] * 5 + [_vp, _vp, _vp, _i, _vp, _i, _vp]),
+    'asr_lstm_cell_gemm_ok': (_i, [_i, _i, _i, _i]),
+    'asr_lstm_cell_gemm_prep': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    'asr_lstm_cell_gemm_fwd': (_i, [_vp, _vp, _i, _i, _vp, _i] + [_vp] * 4 + [_i, _i, _f, _f] + [_vp] * 5 +
+                               [_vp, _vp, _vp, _i, _vp, _i, _vp]),
     'asr_lstm_cell_bwd': (_i, [_vp] * 9 + [_i, _i] + [_vp] * 5),
     'asr_lstm_cell_bwd_ex': (_i, [_vp] * 9 + [_i, _i, _f] + [_vp] * 5),
     'asr_stack_frames': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

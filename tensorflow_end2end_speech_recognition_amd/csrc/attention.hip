@@ -2159,6 +2159,17 @@ static bool att_fused_step(asr_handle* h, const asr_att_decoder* a, const float*
   return true;
 }
 
+// The fused cell launch of a step (asr_lstm_cell_gemm_fwd) needs the caller's work space for the interleaved weight image
+static inline bool dec_cell_gemm(const asr_att_decoder* a) {
+  const int Din = a->Em + a->E2 + a->U;
+  return a->W_cell_il && asr_lstm_cell_gemm_ok(a->B, Din, a->U, Din) && ((uintptr_t)a->dec_in) % 16 == 0 &&
+         ((uintptr_t)a->W_cell_il) % 16 == 0;
+}
+static int dec_cell_image(asr_handle* h, const asr_att_decoder* a, asr_stream s) {
+  if (!dec_cell_gemm(a)) return ASR_OK;
+  return asr_lstm_cell_gemm_prep(h, a->W_cell, a->b_cell, a->Em + a->E2 + a->U, a->U, a->W_cell_il, s);
+}
+
 // One forward step of the decoder loop: cell-input GEMM -> cell -> query FC -> energies -> softmax + context.  k indexes
 // the step arrays that carry the recurrence (dec_in, av_in, c / h, alpha, live); ks the saved activations only the
 // backward reads (gates, raw cell, query: the inference loop reuses row 0).
@@ -2173,14 +2184,23 @@ static int dec_fwd_step(asr_handle* h, const asr_att_decoder* a, int k, int ks, 
   float* dnext = more ? din + (size_t)B * Din : nullptr;
   float* av = a->av_in + (size_t)k * B * Dav;
   float* qz = a->qz_all + (size_t)ks * B * A;
-  DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, 4 * U, Din, din, Din, a->W_cell, 4 * U, pre, 4 * U, a->b_cell, 0, 0, s));
   // the cell output (times its dropout mask) lands in av[:, :U]; without a query FC it IS the query
-  DEC_TRY(asr_lstm_cell_fwd_ex(h, pre, a->c_all + (size_t)k * B * U, a->h_all + (size_t)k * B * U, a->peep,
-                               a->live + (size_t)k * B, B, U, a->forget_bias, a->cell_clip,
-                               a->gates_all + (size_t)ks * B * 4 * U, a->craw_all + (size_t)ks * B * U,
-                               a->c_all + (size_t)(k + 1) * B * U, a->h_all + (size_t)(k + 1) * B * U, hraw,
-                               a->dmask ? a->dmask + (size_t)k * B * U : nullptr, a->has_query_fc ? nullptr : qz,
-                               dnext ? dnext + Em + E2 : nullptr, Din, av, Dav, s));
+  if (dec_cell_gemm(a)) {    // product + cell as one launch on the interleaved weight image (dec_cell_image)
+    DEC_TRY(asr_lstm_cell_gemm_fwd(h, din, Din, Din, a->W_cell_il, a->b_cell ? 1 : 0, a->c_all + (size_t)k * B * U,
+                                   a->h_all + (size_t)k * B * U, a->peep, a->live + (size_t)k * B, B, U, a->forget_bias,
+                                   a->cell_clip, a->gates_all + (size_t)ks * B * 4 * U, a->craw_all + (size_t)ks * B * U,
+                                   a->c_all + (size_t)(k + 1) * B * U, a->h_all + (size_t)(k + 1) * B * U, hraw,
+                                   a->dmask ? a->dmask + (size_t)k * B * U : nullptr, a->has_query_fc ? nullptr : qz,
+                                   dnext ? dnext + Em + E2 : nullptr, Din, av, Dav, s));
+  } else {
+    DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, 4 * U, Din, din, Din, a->W_cell, 4 * U, pre, 4 * U, a->b_cell, 0, 0, s));
+    DEC_TRY(asr_lstm_cell_fwd_ex(h, pre, a->c_all + (size_t)k * B * U, a->h_all + (size_t)k * B * U, a->peep,
+                                 a->live + (size_t)k * B, B, U, a->forget_bias, a->cell_clip,
+                                 a->gates_all + (size_t)ks * B * 4 * U, a->craw_all + (size_t)ks * B * U,
+                                 a->c_all + (size_t)(k + 1) * B * U, a->h_all + (size_t)(k + 1) * B * U, hraw,
+                                 a->dmask ? a->dmask + (size_t)k * B * U : nullptr, a->has_query_fc ? nullptr : qz,
+                                 dnext ? dnext + Em + E2 : nullptr, Din, av, Dav, s));
+  }
   if (a->has_query_fc)
     DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 0, B, A, U, av, Dav, a->W_q, a->ld_wq, qz, A, a->b_q, 0, 0, s));
   if (att_fused_step(h, a, qz, a->alpha_all + (size_t)k * B * T, ctx, av + U, Dav, dnext ? dnext + Em : nullptr, Din, s)) {
@@ -2204,6 +2224,7 @@ extern "C" int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_
   DEC_TRY(dec_check(h, a, false));
   const int B = a->B, U = a->U, T = a->T, E2 = a->E2, Em = a->Em, A = a->A;
   const int Din = Em + E2 + U, Dav = U + E2;
+  DEC_TRY(dec_cell_image(h, a, s));
   for (int k = 0; k < a->To; ++k) DEC_TRY(dec_fwd_step(h, a, k, k, k + 1 < a->To, s));
   (void)B; (void)U; (void)T; (void)E2; (void)Em; (void)A; (void)Din; (void)Dav;
   return ASR_OK;
@@ -2289,8 +2310,8 @@ extern "C" int asr_att_decoder_infer(asr_handle* h, const asr_att_decoder* a, co
       if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
         ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder_infer: event");
   }
-  int rc = ASR_OK, k = 0;
-  for (; k < To; ++k) {
+  int rc = dec_cell_image(h, a, s), k = 0;
+  for (; rc == ASR_OK && k < To; ++k) {
     if (every && k % every == 0 && k > 0) {
       const int c = k / every;                             // this check point; c - 1 was recorded one interval ago
       bool done = false;

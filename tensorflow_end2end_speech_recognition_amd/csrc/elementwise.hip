@@ -7,7 +7,7 @@
 
 // 2 (round 4): asr_create_ex's minimum scratch is 96 MiB (was 32), asr_ctc_beam_workspace_bytes asks for W more doubles per
 // utterance, new entry points asr_att_decoder_infer / asr_lstm_cell_bwd_ex; nothing was removed or re-typed.
-extern "C" int asr_abi_version(void) { return 2; }
+extern "C" int asr_abi_version(void) { return 3; }
 
 extern "C" int asr_create(asr_handle** out, int device) { return asr_create_ex(out, device, (size_t)192 << 20); }
 extern "C" size_t asr_scratch_bytes(asr_handle* h) { return h ? h->scratch_bytes : 0; }

@@ -639,17 +639,41 @@ static inline unsigned xcd_grid(long work, int skip) {     // workgroups to laun
 // partial tiles meet in LDS in a fixed order (deterministic).
 // Requires K % 64 == 0, N % (16 NT) == 0, 16-byte aligned rows.
 constexpr int SK_WAVES = 8;
-template <bool TRANSB, int NT>
+// CELL: the product is the decoder cell's pre-activation with the gate columns INTERLEAVED (column 4 u + g = gate g of unit
+// u, asr_lstm_cell_gemm_prep) so that a workgroup's 32 columns are all four gates of 8 units, and the LSTM cell
+// (cell_fwd_kernel of attention.hip, same arithmetic in the same order) runs in the epilogue on the reduced tile: one launch
+// and one dependent round trip fewer per decoder step, the pre-activations never written.  The cell's own inputs are
+// requested before the product's first load.
+struct SkinnyCell {
+  const float *c_prev, *h_prev, *peep, *live, *out_mask;
+  float *gates, *c_raw, *c_out, *h_out, *h_raw, *cell_out, *h_out2, *cell_out2;
+  int U, ld_h2, ld_c2;
+  float fb, clip;
+};
+__device__ __forceinline__ float sk_sigf(float x) { return 1.0f / (1.0f + expf(-x)); }
+template <bool TRANSB, int NT, bool CELL = false>
 __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_f32_kernel(int M, int N, int K, const float* __restrict__ A,
                                                                         int lda, const float* __restrict__ Bm, int ldb,
                                                                         float* __restrict__ C, int ldc,
                                                                         const float* __restrict__ bias, int accumulate,
-                                                                        int act) {
+                                                                        int act, SkinnyCell cell) {
   constexpr int TN = 16 * NT;
   __shared__ float red[SK_WAVES][16][TN + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, rg = lane >> 4;
   const int n0 = blockIdx.x * TN, m0 = blockIdx.y * 16;
+  // CELL: thread idx < 16 * TN / 4 owns (row m0 + idx / (TN/4), unit n0/4 + idx % (TN/4))
+  float cl_cp = 0.f, cl_hp = 0.f, cl_lv = 0.f, cl_wci = 0.f, cl_wcf = 0.f, cl_wco = 0.f, cl_om = 1.f;
+  const int cl_m = m0 + (int)threadIdx.x / (TN / 4), cl_u = n0 / 4 + (int)threadIdx.x % (TN / 4);
+  const bool cl_on = CELL && (int)threadIdx.x < 16 * (TN / 4) && cl_m < M;
+  if (CELL && cl_on) {
+    const size_t ci = (size_t)cl_m * cell.U + cl_u;
+    cl_cp = cell.c_prev[ci];
+    cl_hp = cell.h_prev[ci];
+    cl_lv = cell.live[cl_m];
+    if (cell.peep) { cl_wci = cell.peep[cl_u]; cl_wcf = cell.peep[cell.U + cl_u]; cl_wco = cell.peep[2 * cell.U + cl_u]; }
+    if (cell.out_mask) cl_om = cell.out_mask[ci];
+  }
   struct Frag {
     f32x4_t a[4], b[NT][4];
     float keep;                 // 1 for a real unit, 0 for a round past the end (A is zeroed at the multiply)
@@ -714,6 +738,41 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_f32_kernel(int M, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][rg * 4 + r][n * 16 + col] = acc[n][r];
   __syncthreads();
+  if constexpr (CELL) {
+    if (!cl_on) return;
+    const int m = (int)threadIdx.x / (TN / 4), ul = (int)threadIdx.x % (TN / 4), U = cell.U;
+    float p[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                          // the plain epilogue's sum, in its order
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) v += red[w][m][ul * 4 + g];
+      if (bias) v += bias[n0 + ul * 4 + g];
+      p[g] = v;
+    }
+    // cell_fwd_kernel (attention.hip), expression for expression
+    const float cp = cl_cp;
+    const float i = sk_sigf(p[0] + cl_wci * cp);
+    const float g = tanhf(p[1]);
+    const float f = sk_sigf(p[2] + cell.fb + cl_wcf * cp);
+    float cn = g * i + cp * f;
+    if (cell.clip > 0.f) cn = fminf(fmaxf(cn, -cell.clip), cell.clip);
+    const float o = sk_sigf(p[3] + cl_wco * cn);
+    const float hn = tanhf(cn) * o;
+    const size_t ci = (size_t)cl_m * U + cl_u;
+    float* gp = cell.gates + (size_t)cl_m * 4 * U;
+    gp[cl_u] = i; gp[U + cl_u] = g; gp[2 * U + cl_u] = f; gp[3 * U + cl_u] = o;
+    cell.c_raw[ci] = cn;
+    cell.h_raw[ci] = hn;
+    cell.c_out[ci] = cl_lv > 0.f ? cn : cp;
+    const float ho = cl_lv > 0.f ? hn : cl_hp;
+    cell.h_out[ci] = ho;
+    if (cell.h_out2) cell.h_out2[(size_t)cl_m * cell.ld_h2 + cl_u] = ho;
+    const float co = cell.out_mask ? hn * cl_om : hn;
+    if (cell.cell_out) cell.cell_out[ci] = co;
+    if (cell.cell_out2) cell.cell_out2[(size_t)cl_m * cell.ld_c2 + cl_u] = co;
+    return;
+  }
   for (int idx = threadIdx.x; idx < 16 * TN; idx += 64 * SK_WAVES) {
     const int m = idx / TN, n = idx % TN;
     if (m0 + m >= M) continue;
@@ -739,7 +798,7 @@ static bool try_gemm_skinny_f32(int transA, int transB, int M, int N, int K, con
   const unsigned gy = (unsigned)((M + 15) / 16);
 #define ASR_SKINNY(TB, NT_)                                                                                             \
   hipLaunchKernelGGL((gemm_skinny_f32_kernel<TB, NT_>), dim3(N / (16 * NT_), gy), dim3(64 * SK_WAVES), 0, st, M, N, K, \
-                     (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, bias, accumulate, act)
+                     (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, bias, accumulate, act, SkinnyCell{})
   if (transB) {
     if (wide) ASR_SKINNY(true, 2); else ASR_SKINNY(true, 1);
   } else {
@@ -1545,6 +1604,19 @@ int launch_gemm(asr_handle* h, int transA, int transB, int M, int N, int K, cons
   return 0;
 }
 
+// rows x [4, U] gate-major -> rows x [U, 4] (column 4 u + g <- column g U + u): the weight image of the CELL form of the
+// skinny kernel; the bias is row `rows - 1` of the image when one is given
+__global__ void interleave_gates_kernel(const float* __restrict__ W, const float* __restrict__ bias, int K, int U,
+                                        float* __restrict__ out) {
+  const size_t n = (size_t)(K + (bias ? 1 : 0)) * U;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t k = i / U;
+    const int u = (int)(i % U);
+    const float* src = k < (size_t)K ? W + k * 4 * U : bias;
+    *reinterpret_cast<f32x4_t*>(out + k * 4 * U + (size_t)u * 4) = (f32x4_t){src[u], src[U + u], src[2 * U + u], src[3 * U + u]};
+  }
+}
+
 }  // namespace
 
 extern "C" int asr_gemm_act(asr_handle* h, int dtype, int out_dtype, int transA, int transB, int M,
@@ -1804,5 +1876,44 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
   hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, partial, S, M, N, dw, N, nullptr,
                      accumulate, 0, 0);
   ASR_CHECK_LAUNCH(h, "asr_conv3x3_bwd_weight");
+  return ASR_OK;
+}
+
+// ---------------------------------------------------------------- decoder cell: product + LSTM cell in one launch
+extern "C" int asr_lstm_cell_gemm_prep(asr_handle* h, const float* W, const float* bias, int K, int U, float* W_il,
+                                       asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!W || !W_il || K < 1 || U < 1 || ((uintptr_t)W_il) % 16 != 0)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_cell_gemm_prep: bad args");
+  const size_t n = (size_t)(K + (bias ? 1 : 0)) * U;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(interleave_gates_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, W, bias, K, U, W_il);
+  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_gemm_prep");
+  return ASR_OK;
+}
+extern "C" int asr_lstm_cell_gemm_ok(int B, int K, int U, int ldx) {
+  return B >= 1 && B <= 32 && K >= 64 && K % 64 == 0 && U >= 8 && U % 8 == 0 && ldx % 4 == 0 && ldx >= K;
+}
+extern "C" int asr_lstm_cell_gemm_fwd(asr_handle* h, const float* x, int ldx, int K, const float* W_il, int has_bias,
+                                      const float* c_prev, const float* h_prev, const float* peep, const float* live,
+                                      int B, int U, float forget_bias, float cell_clip, float* gates, float* c_raw,
+                                      float* c_out, float* h_out, float* h_raw, const float* out_mask, float* cell_out,
+                                      float* h_out2, int ld_h2, float* cell_out2, int ld_c2, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!x || !W_il || !c_prev || !h_prev || !live || !gates || !c_raw || !c_out || !h_out || !h_raw ||
+      !asr_lstm_cell_gemm_ok(B, K, U, ldx) || ((uintptr_t)x) % 16 != 0 || ((uintptr_t)W_il) % 16 != 0 ||
+      (h_out2 && ld_h2 < U) || (cell_out2 && ld_c2 < U))
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_cell_gemm_fwd: bad args (B <= 32, K %% 64 == 0, U %% 8 == 0, 16-byte aligned rows)");
+  SkinnyCell c;
+  c.c_prev = c_prev; c.h_prev = h_prev; c.peep = peep; c.live = live; c.out_mask = out_mask;
+  c.gates = gates; c.c_raw = c_raw; c.c_out = c_out; c.h_out = h_out; c.h_raw = h_raw;
+  c.cell_out = cell_out; c.h_out2 = h_out2; c.cell_out2 = cell_out2;
+  c.U = U; c.ld_h2 = ld_h2; c.ld_c2 = ld_c2; c.fb = forget_bias; c.clip = cell_clip;
+  const int N = 4 * U;
+  hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, 2, true>), dim3(N / 32, (unsigned)((B + 15) / 16)), dim3(64 * SK_WAVES), 0,
+                     (hipStream_t)s, B, N, K, x, ldx, W_il, N, (float*)nullptr, N, has_bias ? W_il + (size_t)K * N : nullptr,
+                     0, 0, c);
+  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_gemm_fwd");
   return ASR_OK;
 }

@@ -1029,6 +1029,34 @@ def lstm_cell_fwd(pre, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.
     return gates, c_raw, c_out, h_out, h_raw
 
 
+def lstm_cell_gemm_prep(W, bias):
+    """Gate-interleaved image [(K + 1), 4U] of a decoder cell's kernel [K,4U] and bias [4U] (asr_lstm_cell_gemm_prep)."""
+    h = _h(W)
+    K, U4 = W.shape
+    out = _f32(((K + (1 if bias is not None else 0)), U4), W.device)
+    h.check(h.lib.asr_lstm_cell_gemm_prep(h.h, _p(W), _p(bias), K, U4 // 4, _p(out), _s()), 'asr_lstm_cell_gemm_prep')
+    return out
+
+
+def lstm_cell_gemm_fwd(x, W_il, has_bias, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.0, out_mask=None,
+                       h_also=None, cell_out_also=None):
+    """lstm_cell_fwd(gemm(x, W) + b, ...) as one launch on the interleaved image; x [B,K] (a row block of a wider array is
+    fine).  Returns (gates, c_raw, c_out, h_out, h_raw, cell_out)."""
+    h = _h(x)
+    B, K = x.shape
+    U = W_il.shape[1] // 4
+    dev = x.device
+    gates, c_raw, c_out, h_out, h_raw, cell_out = _f32((B, 4 * U), dev), _f32((B, U), dev), _f32((B, U), dev), \
+        _f32((B, U), dev), _f32((B, U), dev), _f32((B, U), dev)
+    hp, hld = _col_block(h_also, B, U, 'h_also')
+    cp, cld = _col_block(cell_out_also, B, U, 'cell_out_also')
+    h.check(h.lib.asr_lstm_cell_gemm_fwd(h.h, _p(x), int(x.stride(0)), K, _p(W_il), int(bool(has_bias)), _p(c_prev), _p(h_prev),
+                                         _p(peep), _p(live), B, U, float(forget_bias), float(cell_clip or 0.0), _p(gates),
+                                         _p(c_raw), _p(c_out), _p(h_out), _p(h_raw), _p(out_mask), _p(cell_out), hp, hld, cp,
+                                         cld, _s()), 'asr_lstm_cell_gemm_fwd')
+    return gates, c_raw, c_out, h_out, h_raw, cell_out
+
+
 def lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True, dpre_out=None,
                   dpeep_out=None, cell_clip=0.0):
     """dpre_out [B,4U] / dpeep_out [B,3U] (contiguous rows of the caller's per-step arrays): written in place.
@@ -1139,7 +1167,8 @@ class _AttDecoder(C.Structure):
     _PTRS1 = ['W_cell', 'b_cell', 'peep', 'W_q', 'b_q', 'v']
     _PTRS2 = ['keys', 'enc', 'seq_len', 'filt', 'wfil', 'alpha_zero', 'live', 'dmask', 'dec_in', 'av_in', 'alpha_all',
               'snorm_all', 'gates_all', 'craw_all', 'c_all', 'h_all', 'qz_all', 'work', 'dav_cell', 'dav_ctx', 'dctx_all',
-              'dpre_all', 'dqz_all', 'dv_all', 'dpeep_all', 'd_in_all', 'dkeys', 'dwfil_rows', 'dfilt_rows', 'dc0', 'dh0']
+              'dpre_all', 'dqz_all', 'dv_all', 'dpeep_all', 'd_in_all', 'dkeys', 'dwfil_rows', 'dfilt_rows', 'dc0', 'dh0',
+              'W_cell_il']
     _fields_ = ([(n, C.c_int) for n in _INTS] + [(n, C.c_float) for n in _FLOATS] +
                 [(n, C.c_void_p) for n in _PTRS1] + [('ld_wq', C.c_int)] + [(n, C.c_void_p) for n in _PTRS2])
 
@@ -1162,12 +1191,24 @@ def _att_decoder_struct(a):
     return st
 
 
+FUSED_CELL_GEMM = os.environ.get('ASR_DEC_CELL_GEMM', '1') != '0'   # A/B: 0 keeps product and cell as two launches
+
+
+def _cell_gemm_image(h, a):
+    """Work space for the gate-interleaved image of W_cell | b_cell (the loops fill it): with it a decoder step's cell-input
+    product and LSTM cell are one launch (asr_lstm_cell_gemm_fwd)."""
+    Din = a['Em'] + a['E2'] + a['U']
+    if FUSED_CELL_GEMM and a.get('W_cell_il') is None and h.lib.asr_lstm_cell_gemm_ok(int(a['B']), Din, int(a['U']), Din):
+        a['W_cell_il'] = _f32(((Din + 1) * 4 * a['U'],), a['dec_in'].device)
+
+
 def att_decoder_fwd(a):
     """All To steps of the attention decoder's forward pass from one call (asr_att_decoder_fwd).  `a`: dict of the
     struct's fields (ints / floats / cuda tensors or None); the per-step arrays are filled in place."""
     h = _h(a['dec_in'])
     if a.get('work') is None:
         a['work'] = _f32((a['B'] * (5 * a['U'] + a['T'] + a['E2']),), a['dec_in'].device)
+    _cell_gemm_image(h, a)
     st = _att_decoder_struct(a)
     h.check(h.lib.asr_att_decoder_fwd(h.h, C.byref(st), _s()), 'asr_att_decoder_fwd')
 
@@ -1199,6 +1240,7 @@ def att_decoder_infer(a, W_av, W_out, b_out, embedding, eos, n_live, check_every
     C2 = W_out.shape[1]
     if a.get('work') is None:
         a['work'] = _f32((B * (5 * U + a['T'] + a['E2']),), dev)
+    _cell_gemm_image(h, a)
     out = dict(ids=torch.empty((To, B), dtype=torch.int32, device=dev), logits=_f32((To, B, C2), dev), av=_f32((To, B, U), dev),
                live=a['live'], live_count=torch.empty((To + 1,), dtype=torch.int32, device=dev))
     out['live_count'][:1].fill_(int(n_live))

@@ -313,6 +313,39 @@ def test_attention_model_parity_carried_alpha_and_long_inputs(cuda, att, sig, B,
     assert np.array_equal(out_infer.predicted_ids.cpu().numpy(), ref_ids)
 
 
+@pytest.mark.parametrize('B,K,U,peep,bias,mask', [(32, 1600, 512, True, True, True), (5, 192, 64, False, True, False),
+                                                  (17, 640, 128, True, False, True), (1, 64, 8, False, False, False)])
+def test_cell_product_and_cell_in_one_launch(cuda, B, K, U, peep, bias, mask):
+    """asr_lstm_cell_gemm_fwd on the gate-interleaved image (asr_lstm_cell_gemm_prep) == asr_gemm_act -> asr_lstm_cell_fwd_ex,
+    bit for bit: every output, the copies into column blocks of wider arrays included; finished rows (live = 0) copy their
+    state through; the cfg D decoder's own shape (B = 32, 1600 -> 4 x 512) and ragged ones.  Reference:
+    attention_decoder.py:142-229 (LSTMBlockCell of the decoder)."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    rng = np.random.RandomState(B + K + U)
+    f = lambda *s, sc=1.0: torch.tensor(rng.randn(*s) * sc, dtype=torch.float32, device=cuda)
+    wide = f(B, K + 8, sc=0.5)                               # x as a row block of a wider array
+    x = wide[:, :K]
+    W, b = f(K, 4 * U, sc=0.06), (f(4 * U, sc=0.2) if bias else None)
+    pp = f(3, U, sc=0.3) if peep else None
+    cp, hp = f(B, U, sc=2.0), f(B, U, sc=0.5)
+    live = torch.tensor((rng.rand(B) < 0.7).astype(np.float32), device=cuda)
+    om = torch.tensor((rng.rand(B, U) < 0.8) / 0.8, dtype=torch.float32, device=cuda) if mask else None
+    next_in, av = torch.zeros(B, K, device=cuda), torch.zeros(B, U + 24, device=cuda)
+    next_in2, av2 = torch.zeros_like(next_in), torch.zeros_like(av)
+    pre = ops.gemm(x, W, bias=b)
+    want = ops.lstm_cell_fwd(pre, cp, hp, pp, live, 1.0, 3.0, out_mask=om, want_cell_out=True,
+                             h_also=next_in[:, K - U:], cell_out_also=av[:, :U])
+    W_il = ops.lstm_cell_gemm_prep(W, b)
+    assert torch.equal(W_il[:K].view(K, U, 4), W.view(K, 4, U).transpose(1, 2))
+    got = ops.lstm_cell_gemm_fwd(x, W_il, bias, cp, hp, pp, live, 1.0, 3.0, out_mask=om, h_also=next_in2[:, K - U:],
+                                 cell_out_also=av2[:, :U])
+    for name, g, w in zip(('gates', 'c_raw', 'c_out', 'h_out', 'h_raw', 'cell_out'), got, want):
+        assert torch.equal(g, w), (name, float((g - w).abs().max()))
+    assert torch.equal(next_in2, next_in) and torch.equal(av2, av)
+    assert float(want[0].abs().sum()) > 0 and float((want[2] - cp).abs().max()) > 0     # the clip (3.0) and live rows are exercised
+    assert float(want[1].abs().max()) <= 3.0
+
+
 @pytest.mark.parametrize('att,prev,sig,dtype', [('location', 'carry', False, 'f32'), ('hybrid', 'zeros', False, 'bf16'),
                                                ('bahdanau_content', 'zeros', True, 'f32'), ('luong_dot', 'zeros', False, 'f32')])
 def test_native_greedy_inference_loop(cuda, att, prev, sig, dtype):
@@ -355,8 +388,9 @@ def test_native_greedy_inference_loop(cuda, att, prev, sig, dtype):
 
 
 @pytest.mark.parametrize('case', ['location_zeros_bf16', 'bahdanau_sigmoid_f32', 'location_carry_bf16', 'hybrid_carry_f32',
-                                  'luong_dot_small', 'bahdanau_sigmoid_f32/one_step', 'location_carry_bf16/one_step'])
-def test_native_decoder_loop_against_the_step_by_step_statement(cuda, case):
+                                  'luong_dot_small', 'bahdanau_sigmoid_f32/one_step', 'location_carry_bf16/one_step',
+                                  'location_zeros_bf16/em64', 'hybrid_carry_f32/em64'])
+def test_native_decoder_loop_against_the_step_by_step_statement(cuda, monkeypatch, case):
     """asr_att_decoder_fwd / _bwd (all To steps from one call, with the fused kernels the loop uses: dctx add inside the
     4-frame d-alpha kernel, softmax backward folded into the energy backward through partial alpha.dalpha sums, dropout
     mask and carried-dh add inside the cell backward, length-limited vectorised energy / location kernels with exp2-rcp
@@ -367,6 +401,7 @@ def test_native_decoder_loop_against_the_step_by_step_statement(cuda, case):
     import _cpu_ops as cpu
     from tensorflow_end2end_speech_recognition_amd import ops
     one_step = case.endswith('/one_step')                    # a single decoder step: no "next step" operands anywhere
+    em64 = case.endswith('/em64')      # cell input width % 64 == 0: product + cell as ONE launch (asr_lstm_cell_gemm_fwd)
     case = case.split('/')[0]
     cfg = dict(location_zeros_bf16=dict(keys=False, carry=0, sig=False, bf16=True, A=128, E2=512, mode=0, hasq=1, taps=0),
                bahdanau_sigmoid_f32=dict(keys=True, carry=0, sig=True, bf16=False, A=128, E2=256, mode=0, hasq=1, taps=0),
@@ -374,7 +409,7 @@ def test_native_decoder_loop_against_the_step_by_step_statement(cuda, case):
                hybrid_carry_f32=dict(keys=True, carry=1, sig=True, bf16=False, A=32, E2=256, mode=0, hasq=1, taps=200),
                luong_dot_small=dict(keys=True, carry=0, sig=False, bf16=False, A=64, E2=64, mode=1, hasq=0, taps=0))[case]
     rng = np.random.RandomState(len(case))
-    B, T, To, Em = 3, 200, (1 if one_step else 5), 8
+    B, T, To, Em = 3, 200, (1 if one_step else 5), (64 if em64 else 8)
     A, E2 = cfg['A'], cfg['E2']
     U = A if not cfg['hasq'] else 64
     Din = Em + E2 + U
@@ -419,6 +454,14 @@ def test_native_decoder_loop_against_the_step_by_step_statement(cuda, case):
     ref, got = clone_to('cpu'), clone_to(cuda)
     cpu._att_decoder_fwd(ref)
     ops.att_decoder_fwd(got)
+    assert (got.get('W_cell_il') is not None) == em64
+    if em64:       # the one-launch product + cell against the two launches it replaces: the whole loop bit for bit
+        two = clone_to(cuda)
+        monkeypatch.setattr(ops, 'FUSED_CELL_GEMM', False)
+        ops.att_decoder_fwd(two)
+        assert two.get('W_cell_il') is None
+        for name in ('alpha_all', 'av_in', 'dec_in', 'c_all', 'h_all', 'qz_all', 'gates_all', 'craw_all'):
+            assert torch.equal(got[name], two[name]), name
     # relative to the array's largest entry, with a floor: without keys and without carried location features every frame
     # has the same energy, so dqz / dv are (sum_t denergy) x const = rounding noise around zero (1e-7) on both sides
     rel = lambda x, y: float(np.abs(x.cpu().double().numpy() - y.double().numpy()).max() / max(np.abs(y.double().numpy()).max(), 1e-2))
