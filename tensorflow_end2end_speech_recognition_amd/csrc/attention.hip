@@ -513,40 +513,20 @@ template <> struct EncVec<bf16_t> {
 // Measured (cfg D / cfg E shards, ms per step): 83.84 / 48.91 against 83.85 / 49.57 for the four-launch form -- two launches
 // and their queue gaps fewer, but the same dependent round trips inside one kernel: device time is unchanged (the
 // round-2 finding again), host issue drops by 800 launches per step.
+// (Round 4, measured: dropping the combine launch as well -- every workgroup publishes its partials with write-through
+// stores and takes a ticket, the last arrival of an utterance combines after reading them back past its L2 -- is bit-identical
+// and NOT faster: cfg D 77.7 ms with it against 77.4 ms with the combine launch, cfg E 44.95 / 44.92.  A 5 us launch and
+// its gap buy the same as a device-scope ticket plus ~30 dependent sc1 round trips in one workgroup; left out.)
 // FCH = frames per workgroup: 32 for T <= 2048 (twice the workgroups, half the serial frames of the context phase each)
-// TAIL (round 4): no combine launch.  Every workgroup publishes its partial context, statistics and unnormalised weights
-// with write-through (sc1) stores, waits for their acknowledgement and takes a ticket from the utterance's counter; the
-// workgroup that draws the last ticket of the step reads all of them back with L2-bypassing (sc1) loads -- they were
-// written from other XCDs, whose L2s are not coherent with this one -- and does the combine kernel's work for the
-// utterance, expression for expression (bit-identical context and weights).  The counter only ever grows (nact tickets per
-// step, nact fixed for the loop), so nothing is reset between steps; the caller zeroes it once per loop.
-struct FusedTail {
-  int* cnt;                     // [B] tickets
-  float *ctx, *ctx2, *ctx3;     // combine outputs (ctx2 / ctx3: column blocks of wider arrays, may be NULL)
-  int ld2, ld3, nch;
-};
-__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_wt4(float* p, f32x4_t v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ float ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ f32x4_t ld_wt4(const float* p) {
-  f32x4_t v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-template <int LPF, int NV, typename TE, int FCH, bool TAIL = false>
+template <int LPF, int NV, typename TE, int FCH>
 __global__ __launch_bounds__(256) void att_fused_fwd_kernel(const float* __restrict__ keys, const float* __restrict__ qz,
                                                             const float* __restrict__ v, int T, int B, int A, int mode,
                                                             float sharp, const int32_t* __restrict__ seq_len,
                                                             const TE* __restrict__ enc, int E, float* __restrict__ alpha,
-                                                            float* __restrict__ part, float* __restrict__ stat,
-                                                            FusedTail tail) {
+                                                            float* __restrict__ part, float* __restrict__ stat) {
   constexpr int FPW = 64 / LPF;
   __shared__ float el[FCH];
   __shared__ float s_m;
-  __shared__ float tw[64];
-  __shared__ int s_last;
   const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sub = lane / LPF, l = lane % LPF, nvec = A >> 2;
   const int len = min(max(seq_len[b], 0), T);
@@ -600,14 +580,9 @@ __global__ __launch_bounds__(256) void att_fused_fwd_kernel(const float* __restr
     const float sm = wave_reduce_sum(pe);
     if (lane < n) {
       el[lane] = pe;
-      if constexpr (TAIL) st_wt(alpha + (size_t)b * T + t0 + lane, pe);
-      else alpha[(size_t)b * T + t0 + lane] = pe;                     // unnormalised; the combine kernel rescales it
+      alpha[(size_t)b * T + t0 + lane] = pe;                          // unnormalised; the combine kernel rescales it
     }
-    if (lane == 0) {
-      if constexpr (TAIL) { st_wt(st, m); st_wt(st + 1, sm); }
-      else { st[0] = m; st[1] = sm; }
-      s_m = m;
-    }
+    if (lane == 0) { st[0] = m; st[1] = sm; s_m = m; }
   }
   __syncthreads();
   const size_t rs = (size_t)B * E;
@@ -622,60 +597,7 @@ __global__ __launch_bounds__(256) void att_fused_fwd_kernel(const float* __restr
       const float w = el[i];
       c[0] += w * x[0]; c[1] += w * x[1]; c[2] += w * x[2]; c[3] += w * x[3];
     }
-    if constexpr (TAIL) st_wt4(o + e4 * 4, c);
-    else *reinterpret_cast<f32x4_t*>(o + e4 * 4) = c;
-  }
-  if constexpr (TAIL) {
-    const int Lb = len == 0 ? T : len;
-    const int nact = (Lb + FCH - 1) / FCH;                            // workgroups of this utterance that got here
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this thread's write-through stores have landed
-    __syncthreads();
-    if (tid == 0) {
-      const int prev = __hip_atomic_fetch_add(tail.cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (prev % nact) == nact - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // ---- att_fused_combine_kernel for utterance b, same expressions in the same order
-    const int nch = tail.nch;
-    if (tid < 64) {
-      const float m = tid < nact ? ld_wt(stat + ((size_t)tid * B + b) * 2) : -3.402823466e+38f;
-      const float sk = tid < nact ? ld_wt(stat + ((size_t)tid * B + b) * 2 + 1) : 0.f;
-      const float M = wave_reduce_max(m);
-      const float wk = sk > 0.f ? expf(m - M) : 0.f;
-      const float S = wave_reduce_sum(sk * wk);
-      tw[tid] = wk / S;
-    }
-    __syncthreads();
-    const size_t BE = (size_t)B * E;
-    for (int e4 = tid; e4 < E / 4; e4 += 256) {
-      const size_t i = (size_t)b * E + e4 * 4;
-      f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-      for (int k0 = 0; k0 < nact; k0 += 8) {                           // eight partials requested per round trip
-        f32x4_t pv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pv[j] = ld_wt4(part + (size_t)min(k0 + j, nact - 1) * BE + i);
-        // the loads are asm: the wait names their registers so that no use can be scheduled in front of it
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]),
-                     "+v"(pv[6]), "+v"(pv[7]) :: "memory");
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (k0 + j < nact) {                                        // fixed order; chunks past nact have weight 0
-            const float wk = tw[k0 + j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] += wk > 0.f ? pv[j][r] * wk : 0.f;
-          }
-        }
-      }
-      *reinterpret_cast<f32x4_t*>(tail.ctx + i) = c;
-      if (tail.ctx2) *reinterpret_cast<f32x4_t*>(tail.ctx2 + (size_t)b * tail.ld2 + e4 * 4) = c;
-      if (tail.ctx3) *reinterpret_cast<f32x4_t*>(tail.ctx3 + (size_t)b * tail.ld3 + e4 * 4) = c;
-    }
-    for (int t = tid; t < T; t += 256) {
-      const size_t i = (size_t)b * T + t;
-      alpha[i] = t < Lb ? ld_wt(alpha + i) * tw[t / FCH] : 0.f;
-    }
-    (void)nch;
+    *reinterpret_cast<f32x4_t*>(o + e4 * 4) = c;
   }
 }
 // combine: a workgroup belongs to ONE utterance -- its first wave turns the <= 64 chunk statistics into the weights
@@ -2204,23 +2126,11 @@ static int dec_check(asr_handle* h, const asr_att_decoder* a, bool bwd) {
 
 // energies + softmax + context of one decoder step as two launches (att_fused_fwd_kernel + combine); false = the shape is
 // not covered (the caller takes the four-launch path).  ASR_ATT_FUSED=0 switches it off (A/B).
-static inline bool att_fused_ok(const asr_att_decoder* a) {
-  static const bool on = [] { const char* e = getenv("ASR_ATT_FUSED"); return !(e && e[0] == '0'); }();
-  return on && !a->carry_alpha && !a->snorm_all && a->E2 % 256 == 0 && a->T <= 64 * ATT_CH && ((uintptr_t)a->enc) % 16 == 0;
-}
-static inline bool att_tail_on() {       // ASR_ATT_TAIL=0: the separate combine launch (A/B)
-  static const bool on = [] { const char* e = getenv("ASR_ATT_TAIL"); return !(e && e[0] == '0'); }();
-  return on;
-}
-// the ticket counters of the fused step's last-arriver combine: the first B words of the `energy` block of a->work, which
-// the fused step does not use otherwise (zeroed once per loop by dec_loop_begin)
-static inline int* att_tail_counters(const asr_att_decoder* a) {
-  return reinterpret_cast<int*>(a->work + (size_t)a->B * 4 * a->U + (size_t)a->B * a->U);
-}
 static bool att_fused_step(asr_handle* h, const asr_att_decoder* a, const float* qz, float* alpha, float* ctx, float* ctx2,
                            int ld2, float* ctx3, int ld3, asr_stream s) {
+  static const bool on = [] { const char* e = getenv("ASR_ATT_FUSED"); return !(e && e[0] == '0'); }();
   const int B = a->B, T = a->T, E = a->E2, A = a->A;
-  if (!att_fused_ok(a)) return false;
+  if (!on || a->carry_alpha || a->snorm_all || E % 256 != 0 || T > 64 * ATT_CH || ((uintptr_t)a->enc) % 16 != 0) return false;
   const int shape = energy_vec_shape(A, a->keys, qz, a->v, nullptr);
   if (!shape) return false;
   // 64-frame chunks; 32 (twice the workgroups, half the serial frames of the context phase) measured 86.5 vs 83.6 ms
@@ -2233,13 +2143,9 @@ static bool att_fused_step(asr_handle* h, const asr_att_decoder* a, const float*
   float* stat = part + (size_t)nch * B * E;
   const dim3 grid(nch, B);
   hipStream_t st = (hipStream_t)s;
-  const bool tail_on = att_tail_on();                    // (its counters live in the energy block [B,T] of a->work)
-  const FusedTail tl = {att_tail_counters(a), ctx, ctx2, ctx3, ld2, ld3, nch};
-#define ASR_FUSED(L, NV_, TE_, F_) do { \
-    if (tail_on) hipLaunchKernelGGL((att_fused_fwd_kernel<L, NV_, TE_, F_, true>), grid, dim3(256), 0, st, a->keys, qz, a->v, T, B, A, \
-                                    a->att_mode, a->sharpening, a->seq_len, (const TE_*)a->enc, E, alpha, part, stat, tl); \
-    else hipLaunchKernelGGL((att_fused_fwd_kernel<L, NV_, TE_, F_, false>), grid, dim3(256), 0, st, a->keys, qz, a->v, T, B, A, \
-                            a->att_mode, a->sharpening, a->seq_len, (const TE_*)a->enc, E, alpha, part, stat, tl); } while (0)
+#define ASR_FUSED(L, NV_, TE_, F_) \
+  hipLaunchKernelGGL((att_fused_fwd_kernel<L, NV_, TE_, F_>), grid, dim3(256), 0, st, a->keys, qz, a->v, T, B, A, a->att_mode, \
+                     a->sharpening, a->seq_len, (const TE_*)a->enc, E, alpha, part, stat)
 #define ASR_FUSED_T(L, NV_) do { \
     if (a->enc_dtype == ASR_F32) { if (fch == 32) ASR_FUSED(L, NV_, float, 32); else ASR_FUSED(L, NV_, float, 64); } \
     else { if (fch == 32) ASR_FUSED(L, NV_, bf16_t, 32); else ASR_FUSED(L, NV_, bf16_t, 64); } } while (0)
@@ -2251,7 +2157,6 @@ static bool att_fused_step(asr_handle* h, const asr_att_decoder* a, const float*
   }
 #undef ASR_FUSED_T
 #undef ASR_FUSED
-  if (tail_on) return true;
   const int nb_ctx = B * (E / 256), nb_al = B * ((T + 255) / 256);
   hipLaunchKernelGGL(att_fused_combine_kernel, dim3(nb_ctx + nb_al), dim3(256), 0, st, part, stat, nch, fch, B, E, T, a->seq_len,
                      ctx, ctx2, ld2, ctx3, ld3, alpha);
@@ -2265,11 +2170,6 @@ static inline bool dec_cell_gemm(const asr_att_decoder* a) {
          ((uintptr_t)a->W_cell_il) % 16 == 0;
 }
 static int dec_cell_image(asr_handle* h, const asr_att_decoder* a, asr_stream s) {
-  // once per loop: the ticket counters of the fused attention step start at zero ...
-  if (att_fused_ok(a) && att_tail_on() &&
-      hipMemsetAsync(att_tail_counters(a), 0, (size_t)a->B * sizeof(int), (hipStream_t)s) != hipSuccess)
-    ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder: memset");
-  // ... and the interleaved image of the cell's weights is written
   if (!dec_cell_gemm(a)) return ASR_OK;
   return asr_lstm_cell_gemm_prep(h, a->W_cell, a->b_cell, a->Em + a->E2 + a->U, a->U, a->W_cell_il, s);
 }

@@ -34,6 +34,11 @@ extern "C" int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes)
     delete h;
     return ASR_ERR_HIP;
   }
+  // ASR_POISON_SCRATCH=1 (debug / test aid): the work part of the arena starts as NaN bit patterns (0xFF bytes) instead of
+  // whatever the device memory held -- on a fresh box that is usually zeros, which hides a kernel that reads a partial
+  // nobody wrote (a 1e-3 error once in a few cold starts instead of a NaN every time)
+  if (const char* e = getenv("ASR_POISON_SCRATCH"))
+    if (e[0] == '1') (void)hipMemset(h->scratch, 0xFF, h->scratch_bytes - ASR_XCH_BYTES);
   (void)hipMemset((char*)h->scratch + h->scratch_bytes - ASR_XCH_BYTES, 0, ASR_XCH_BYTES);
   *out = h;
   return ASR_OK;

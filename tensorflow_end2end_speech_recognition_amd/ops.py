@@ -1050,7 +1050,9 @@ def lstm_cell_gemm_fwd(x, W_il, has_bias, c_prev, h_prev, peep, live, forget_bia
         _f32((B, U), dev), _f32((B, U), dev), _f32((B, U), dev)
     hp, hld = _col_block(h_also, B, U, 'h_also')
     cp, cld = _col_block(cell_out_also, B, U, 'cell_out_also')
-    h.check(h.lib.asr_lstm_cell_gemm_fwd(h.h, _p(x), int(x.stride(0)), K, _p(W_il), int(bool(has_bias)), _p(c_prev), _p(h_prev),
+    if x.dtype != torch.float32 or x.stride(1) != 1:
+        raise ValueError('lstm_cell_gemm_fwd: x must be fp32 with unit inner stride')
+    h.check(h.lib.asr_lstm_cell_gemm_fwd(h.h, C.c_void_p(x.data_ptr()), int(x.stride(0)), K, _p(W_il), int(bool(has_bias)), _p(c_prev), _p(h_prev),
                                          _p(peep), _p(live), B, U, float(forget_bias), float(cell_clip or 0.0), _p(gates),
                                          _p(c_raw), _p(c_out), _p(h_out), _p(h_raw), _p(out_mask), _p(cell_out), hp, hld, cp,
                                          cld, _s()), 'asr_lstm_cell_gemm_fwd')

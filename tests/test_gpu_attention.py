@@ -329,6 +329,7 @@ def test_cell_product_and_cell_in_one_launch(cuda, B, K, U, peep, bias, mask):
     pp = f(3, U, sc=0.3) if peep else None
     cp, hp = f(B, U, sc=2.0), f(B, U, sc=0.5)
     live = torch.tensor((rng.rand(B) < 0.7).astype(np.float32), device=cuda)
+    live[0] = 1.0
     om = torch.tensor((rng.rand(B, U) < 0.8) / 0.8, dtype=torch.float32, device=cuda) if mask else None
     next_in, av = torch.zeros(B, K, device=cuda), torch.zeros(B, U + 24, device=cuda)
     next_in2, av2 = torch.zeros_like(next_in), torch.zeros_like(av)
