@@ -344,6 +344,9 @@ int asr_debug_tear_probe(asr_handle* h, unsigned* buf, unsigned iters, int peer,
 /* Debug: records, per workgroup of a probe grid launched on `s`, {XCC id, HW_ID register} into out[2*nblocks]
  * (device memory); every workgroup stays resident for spin_cycles so that the grid spreads over the CUs. */
 int asr_debug_placement(asr_handle* h, unsigned* out, int nblocks, int spin_cycles, asr_stream s);
+/* test aid: fills every CU's LDS with NaN bit patterns (a kernel that reads LDS words nobody wrote then fails every time
+ * instead of once in a few cold starts); tests/conftest.py runs it in front of every test under ASR_POISON_LDS=1 */
+int asr_debug_poison_lds(asr_handle* h, asr_stream s);
 
 /* ---- GRU recurrence ------------------------------------------------------- *
  * tf.contrib.rnn.GRUCell under tf.nn.(bidirectional_)dynamic_rnn(sequence_length) -- the reference's GRUEncoder /
@@ -439,6 +442,19 @@ int asr_lstm_cell_gemm_fwd(asr_handle* h, const float* x, int ldx, int K, const 
                            int B, int U, float forget_bias, float cell_clip, float* gates, float* c_raw,
                            float* c_out, float* h_out, float* h_raw, const float* out_mask, float* cell_out,
                            float* h_out2, int ld_h2, float* cell_out2, int ld_c2, asr_stream s);
+/* The same pair with bf16 WEIGHTS (fp32 activations, exact fp32 products of an fp32 value and a bf16-valued one): `img`
+ * (asr_lstm_cell_gemm_h_bytes) holds, written by asr_lstm_cell_gemm_prep_h, the gate-interleaved kernel in the order the
+ * multiplies consume it (four 16-byte loads per lane and 64-row unit), the interleaved fp32 bias, and a plain bf16 copy of
+ * W whose rows asr_lstm_cell_gemm_bwd_h (dx [B,K] = dpre [B,4U] W^T, the backward product of a decoder step) streams. */
+size_t asr_lstm_cell_gemm_h_bytes(int K, int U);
+int asr_lstm_cell_gemm_prep_h(asr_handle* h, const float* W, const float* bias, int K, int U, void* img, asr_stream s);
+int asr_lstm_cell_gemm_fwd_h(asr_handle* h, const float* x, int ldx, int K, const void* img,
+                             const float* c_prev, const float* h_prev, const float* peep, const float* live,
+                             int B, int U, float forget_bias, float cell_clip, float* gates, float* c_raw,
+                             float* c_out, float* h_out, float* h_raw, const float* out_mask, float* cell_out,
+                             float* h_out2, int ld_h2, float* cell_out2, int ld_c2, asr_stream s);
+int asr_lstm_cell_gemm_bwd_h(asr_handle* h, const float* dpre, int B, int K, int U, const void* img, float* dx, int lddx,
+                             asr_stream s);
 /* dh_use: gradient on the cell output of live rows; dc_next/dh_next: gradient on the carried state.
  * dpre[B,4U]; dc_prev; dh_prev_carry (pass-through part, add (dpre W^T)[h] for live rows);
  * dpeep_rows[B][3][U] per-row peephole gradient terms (sum over rows/steps on the caller side). */
@@ -546,6 +562,12 @@ typedef struct asr_att_decoder {
    * the loop writes the gate-interleaved image of W_cell | b_cell there once (asr_lstm_cell_gemm_prep) and every step runs
    * the cell-input product and the LSTM cell as ONE launch (asr_lstm_cell_gemm_fwd) -- same values, bit for bit. */
   float *W_cell_il;
+  /* forward / inference / backward, optional: asr_lstm_cell_gemm_h_bytes(Em+E2+U, U) bytes of work space.  When given (and
+   * asr_lstm_cell_gemm_ok, U % 16 == 0) the loops write the bf16 images of W_cell there (asr_lstm_cell_gemm_prep_h) and the
+   * cell-input product (+ cell) of every forward step and the dpre W_cell^T product of every backward step stream bf16
+   * weights: the rounding point of a bf16-operand model's decoder kernel (oracle: operand_round on lstm_cell/kernel).
+   * Takes precedence over W_cell_il. */
+  void *W_cell_h;
 } asr_att_decoder;
 int asr_att_decoder_fwd(asr_handle* h, const asr_att_decoder* a, asr_stream s);
 /* ---- greedy inference, native ------------------------------------------------------------------------------ *

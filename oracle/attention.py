@@ -117,13 +117,15 @@ def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_l
     alphas, grads, ...).
     operand_round (e.g. oracle.lstm.bf16_round_t): the rounding points of the bf16-operand device model in the forward
     -- the inputs, the encoder's LSTM kernels and every h it emits / feeds back, and the CTC head's weight matrix
-    (straight-through); the decoder, the attention layer and the bridge multiply in fp32 on the device and stay in
-    `dtype` here."""
+    (straight-through), and since round 4 the decoder cell's kernel (its per-step products stream bf16 weights against
+    fp32 activations); the attention layer, the bridge and the decoder's other products multiply in fp32 on the device
+    and stay in `dtype` here."""
     from .model import params_from_state_dict
     if operand_round is not None:
         sd = dict(sd)
         for k in list(sd):
-            if (k.startswith('encoder/') and k.endswith('/kernel')) or k == 'ctc_output/weights':
+            if ((k.startswith('encoder/') and k.endswith('/kernel')) or k == 'ctc_output/weights' or
+                    k == 'attention_decoder/decoder/lstm_cell/kernel'):
                 v = sd[k].detach().cpu() if torch.is_tensor(sd[k]) else torch.as_tensor(np.asarray(sd[k]))
                 sd[k] = operand_round(v.to(torch.float64)).numpy()
         inputs_btd = operand_round(torch.as_tensor(np.asarray(inputs_btd), dtype=torch.float64)).numpy()

@@ -76,6 +76,7 @@ SIGNATURES = {
     'asr_debug_set_lstm_flags': (_i, [_i]),
     'asr_debug_set_gru_persistent': (_i, [_i]),
     'asr_debug_placement': (_i, [_vp, _vp, _i, _i, _vp]),
+    'asr_debug_poison_lds': (_i, [_vp, _vp]),
     'asr_debug_tear_probe': (_i, [_vp, _vp, C.c_uint, _i, _i, _vp, _vp]),
     'asr_ctc_workspace_bytes': (_sz, [_i, _i, _i]),
     'asr_ctc_loss': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -89,6 +90,11 @@ SIGNATURES = {
     'asr_lstm_cell_gemm_prep': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     'asr_lstm_cell_gemm_fwd': (_i, [_vp, _vp, _i, _i, _vp, _i] + [_vp] * 4 + [_i, _i, _f, _f] + [_vp] * 5 +
                                [_vp, _vp, _vp, _i, _vp, _i, _vp]),
+    'asr_lstm_cell_gemm_h_bytes': (_sz, [_i, _i]),
+    'asr_lstm_cell_gemm_prep_h': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    'asr_lstm_cell_gemm_fwd_h': (_i, [_vp, _vp, _i, _i, _vp] + [_vp] * 4 + [_i, _i, _f, _f] + [_vp] * 5 +
+                                 [_vp, _vp, _vp, _i, _vp, _i, _vp]),
+    'asr_lstm_cell_gemm_bwd_h': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     'asr_lstm_cell_bwd': (_i, [_vp] * 9 + [_i, _i] + [_vp] * 5),
     'asr_lstm_cell_bwd_ex': (_i, [_vp] * 9 + [_i, _i, _f] + [_vp] * 5),
     'asr_stack_frames': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

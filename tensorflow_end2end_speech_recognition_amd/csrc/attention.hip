@@ -2169,7 +2169,14 @@ static inline bool dec_cell_gemm(const asr_att_decoder* a) {
   return a->W_cell_il && asr_lstm_cell_gemm_ok(a->B, Din, a->U, Din) && ((uintptr_t)a->dec_in) % 16 == 0 &&
          ((uintptr_t)a->W_cell_il) % 16 == 0;
 }
+// ... or for the bf16 weight images (both loops)
+static inline bool dec_cell_gemm_h(const asr_att_decoder* a) {
+  const int Din = a->Em + a->E2 + a->U;
+  return a->W_cell_h && asr_lstm_cell_gemm_ok(a->B, Din, a->U, Din) && a->U % 16 == 0 && ((uintptr_t)a->dec_in) % 16 == 0 &&
+         ((uintptr_t)a->W_cell_h) % 16 == 0;
+}
 static int dec_cell_image(asr_handle* h, const asr_att_decoder* a, asr_stream s) {
+  if (dec_cell_gemm_h(a)) return asr_lstm_cell_gemm_prep_h(h, a->W_cell, a->b_cell, a->Em + a->E2 + a->U, a->U, a->W_cell_h, s);
   if (!dec_cell_gemm(a)) return ASR_OK;
   return asr_lstm_cell_gemm_prep(h, a->W_cell, a->b_cell, a->Em + a->E2 + a->U, a->U, a->W_cell_il, s);
 }
@@ -2189,7 +2196,14 @@ static int dec_fwd_step(asr_handle* h, const asr_att_decoder* a, int k, int ks, 
   float* av = a->av_in + (size_t)k * B * Dav;
   float* qz = a->qz_all + (size_t)ks * B * A;
   // the cell output (times its dropout mask) lands in av[:, :U]; without a query FC it IS the query
-  if (dec_cell_gemm(a)) {    // product + cell as one launch on the interleaved weight image (dec_cell_image)
+  if (dec_cell_gemm_h(a)) {  // product + cell as one launch on the bf16 fragment image (dec_cell_image)
+    DEC_TRY(asr_lstm_cell_gemm_fwd_h(h, din, Din, Din, a->W_cell_h, a->c_all + (size_t)k * B * U,
+                                     a->h_all + (size_t)k * B * U, a->peep, a->live + (size_t)k * B, B, U, a->forget_bias,
+                                     a->cell_clip, a->gates_all + (size_t)ks * B * 4 * U, a->craw_all + (size_t)ks * B * U,
+                                     a->c_all + (size_t)(k + 1) * B * U, a->h_all + (size_t)(k + 1) * B * U, hraw,
+                                     a->dmask ? a->dmask + (size_t)k * B * U : nullptr, a->has_query_fc ? nullptr : qz,
+                                     dnext ? dnext + Em + E2 : nullptr, Din, av, Dav, s));
+  } else if (dec_cell_gemm(a)) {    // ... on the fp32 interleaved weight image
     DEC_TRY(asr_lstm_cell_gemm_fwd(h, din, Din, Din, a->W_cell_il, a->b_cell ? 1 : 0, a->c_all + (size_t)k * B * U,
                                    a->h_all + (size_t)k * B * U, a->peep, a->live + (size_t)k * B, B, U, a->forget_bias,
                                    a->cell_clip, a->gates_all + (size_t)ks * B * 4 * U, a->craw_all + (size_t)ks * B * U,
@@ -2363,6 +2377,10 @@ extern "C" int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_
   if (hipMemsetAsync(dcs[0], 0, (size_t)B * U * sizeof(float), st) != hipSuccess ||
       hipMemsetAsync(dhc[0], 0, (size_t)B * U * sizeof(float), st) != hipSuccess)
     ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder_bwd: memset");
+  // the bf16 images of W_cell are written again here (one launch per loop): the call does not depend on the forward
+  // loop having run with the same work space
+  const bool cell_h = dec_cell_gemm_h(a);
+  if (cell_h) DEC_TRY(asr_lstm_cell_gemm_prep_h(h, a->W_cell, a->b_cell, Din, U, a->W_cell_h, s));
   int cur = 0;
   const float* dalpha_next = nullptr;
   for (int k = To - 1; k >= 0; --k) {
@@ -2432,7 +2450,8 @@ extern "C" int asr_att_decoder_bwd(asr_handle* h, const asr_att_decoder* a, asr_
                                           // whose gradient op ignores cell_clip: the clamp is straight-through here
     }
     float* d_in = a->d_in_all + (size_t)k * B * Din;
-    DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 1, B, Din, 4 * U, dpre, 4 * U, a->W_cell, 4 * U, d_in, Din, nullptr, 0, 0, s));
+    if (cell_h) DEC_TRY(asr_lstm_cell_gemm_bwd_h(h, dpre, B, Din, U, a->W_cell_h, d_in, Din, s));   // bf16 weight rows
+    else DEC_TRY(asr_gemm_act(h, ASR_F32, ASR_F32, 0, 1, B, Din, 4 * U, dpre, 4 * U, a->W_cell, 4 * U, d_in, Din, nullptr, 0, 0, s));
     cur ^= 1;
   }
   DEC_TRY(asr_add_cols(h, dhc[cur], U, a->d_in_all + Em + E2, Din, a->dh0, U, B, U, s));

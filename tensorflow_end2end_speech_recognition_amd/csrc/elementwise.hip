@@ -839,3 +839,27 @@ extern "C" int asr_scale(asr_handle* h, float* x, size_t n, float scale, asr_str
   ASR_CHECK_LAUNCH(h, "asr_scale");
   return ASR_OK;
 }
+
+// ---------------------------------------------------------------- debug: LDS poisoning
+// Every CU's LDS filled with NaN bit patterns (twice as many workgroups as CUs, each claiming the whole 160 KB, so that
+// the dispatcher has to walk over every CU).  A kernel that reads LDS words nobody wrote -- the tail of a tile, the unused
+// lanes of a reduction array -- normally sees what the previous kernel left there, i.e. the same thing on every run; on a
+// freshly booted box it sees something else.  tests/conftest.py runs this in front of every test under ASR_POISON_LDS=1.
+namespace {
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, unsigned words, unsigned* sink) {
+  extern __shared__ unsigned lds_words[];
+  for (unsigned i = threadIdx.x; i < words; i += 256) lds_words[i] = pattern;
+  __syncthreads();
+  if (sink && lds_words[(threadIdx.x * 97u) % words] != pattern) *sink = 1u;   // keeps the stores alive
+  __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace
+extern "C" int asr_debug_poison_lds(asr_handle* h, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  const size_t bytes = (size_t)160 << 10;
+  (void)hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  hipLaunchKernelGGL(poison_lds_kernel, dim3((unsigned)(2 * h->num_cu)), dim3(256), bytes, (hipStream_t)s, 0xFFFFFFFFu,
+                     (unsigned)(bytes / 4), (unsigned*)nullptr);
+  ASR_CHECK_LAUNCH(h, "asr_debug_poison_lds");
+  return ASR_OK;
+}

@@ -651,7 +651,14 @@ struct SkinnyCell {
   float fb, clip;
 };
 __device__ __forceinline__ float sk_sigf(float x) { return 1.0f / (1.0f + expf(-x)); }
-template <bool TRANSB, int NT, bool CELL = false>
+// BH: the weights are bf16 (the activations stay fp32, the products are exact fp32 MFMAs of an fp32 value and a
+// bf16-valued one): half the bytes of a launch that is weight streaming.  !TRANSB: Bm is the FRAGMENT image of
+// asr_lstm_cell_gemm_prep_h -- per (32-column block, 64-row unit) the 64 lanes' 32 values each, contiguous, in the order
+// the multiplies consume them: four 16-byte loads per lane and unit instead of 32 strided dword loads.  TRANSB: Bm is a
+// bf16 [N, ldb] matrix of B^T rows; a lane takes 16 consecutive k of its row (two 16-byte loads) and the matching 16
+// consecutive k of its A row -- MFMA slot rg carries k = kb + 16 rg + t at multiply t (any k-to-slot map is a valid dot
+// product as long as both operands use it).
+template <bool TRANSB, int NT, bool CELL = false, bool BH = false>
 __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_f32_kernel(int M, int N, int K, const float* __restrict__ A,
                                                                         int lda, const float* __restrict__ Bm, int ldb,
                                                                         float* __restrict__ C, int ldc,
@@ -674,15 +681,20 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_f32_kernel(int M, i
     if (cell.peep) { cl_wci = cell.peep[cl_u]; cl_wcf = cell.peep[cell.U + cl_u]; cl_wco = cell.peep[2 * cell.U + cl_u]; }
     if (cell.out_mask) cl_om = cell.out_mask[ci];
   }
+  typedef __attribute__((ext_vector_type(4))) unsigned skw4_t;
+  static_assert(!BH || (TRANSB ? NT == 1 : NT == 2), "bf16 weights: NT = 2 fragment image / NT = 1 transposed rows");
   struct Frag {
-    f32x4_t a[4], b[NT][4];
+    f32x4_t a[4], b[BH ? 1 : NT][BH ? 1 : 4];
+    skw4_t w[BH ? (TRANSB ? 2 : 4) : 1];
     float keep;                 // 1 for a real unit, 0 for a round past the end (A is zeroed at the multiply)
   };
   f32x4_t acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const float* ap = A + (size_t)min(m0 + col, M - 1) * lda + rg * 4;   // rows past M read a valid row, masked at the store
+  // rows past M read a valid row, masked at the store
+  const float* ap = A + (size_t)min(m0 + col, M - 1) * lda + ((BH && TRANSB) ? rg * 16 : rg * 4);
   const int units = K / 64;
+  const bf16_t* Bh = reinterpret_cast<const bf16_t*>(Bm);
   // round r of a wave is the 64-element unit wave + 8r; rounds past the end re-read the last unit with A zeroed, so
   // every wave runs the same (even) number of rounds and every prefetch below is consumed -- a prefetch whose use sits
   // behind a branch gets sunk below the multiplies by the compiler, which serialises load and multiply again
@@ -691,6 +703,22 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_f32_kernel(int M, i
     const bool valid = unit < units;
     const int kb = (valid ? unit : units - 1) * 64;
     f.keep = valid ? 1.f : 0.f;
+    if constexpr (BH) {
+      if constexpr (TRANSB) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.a[j] = *reinterpret_cast<const f32x4_t*>(ap + kb + j * 4);   // A[row][kb + 16rg + 4j + e]
+        const bf16_t* bp = Bh + (size_t)(n0 + col) * ldb + kb + rg * 16;                           // Bt[n][kb + 16rg + 0..15]
+        f.w[0] = *reinterpret_cast<const skw4_t*>(bp);
+        f.w[1] = *reinterpret_cast<const skw4_t*>(bp + 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.a[j] = *reinterpret_cast<const f32x4_t*>(ap + kb + j * 16);
+        const skw4_t* bp = reinterpret_cast<const skw4_t*>(Bh + (((size_t)blockIdx.x * units + (kb >> 6)) * 64 + lane) * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.w[j] = bp[j];       // word e of w[j]: {column n0 + col, column n0 + 16 + col} at k = kb + 16j + 4rg + e
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f.a[j] = *reinterpret_cast<const f32x4_t*>(ap + kb + j * 16);     // A[row][kb + 16j + 4rg + e]
@@ -707,6 +735,24 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_f32_kernel(int M, i
     }
   };
   auto mma = [&](const Frag& f) {
+    if constexpr (BH) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (TRANSB) {                           // multiply t = 4j + e: k = kb + 16rg + t
+            const int t = 4 * j + e;
+            const unsigned wd = f.w[t >> 3][(t & 7) >> 1];
+            const float bv = __uint_as_float((t & 1) ? (wd & 0xffff0000u) : (wd << 16));
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[j][e] * f.keep, bv, acc[0], 0, 0, 0);
+          } else {
+            const unsigned wd = f.w[j][e];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[j][e] * f.keep, __uint_as_float(wd << 16), acc[0], 0, 0, 0);
+            acc[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[j][e] * f.keep, __uint_as_float(wd & 0xffff0000u), acc[NT - 1], 0, 0, 0);
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1617,6 +1663,27 @@ __global__ void interleave_gates_kernel(const float* __restrict__ W, const float
   }
 }
 
+// The bf16 images of a decoder cell's kernel W [K, 4U] (gate-major columns) for the BH forms of the skinny kernel:
+//   frag [4U/32][K/64][64 lanes][32] bf16 -- gate-interleaved columns (4 u + g), fragment order (see the kernel): value
+//        idx = (4j + e) * 2 + n of lane rg * 16 + col is W[unit * 64 + 16j + 4rg + e][column 32 nb + 16 n + col];
+//   bias fp32 [4U], interleaved;   plain [K, 4U] bf16, W as it is (the backward product's B^T rows).
+__global__ void cell_images_h_kernel(const float* __restrict__ W, const float* __restrict__ bias, int K, int U,
+                                     bf16_t* __restrict__ frag, float* __restrict__ bias_il, bf16_t* __restrict__ plain) {
+  const size_t n = (size_t)K * 4 * U;
+  const int units = K / 64;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    plain[i] = f32_to_bf16(W[i]);
+    // frag element i: decode (nb, unit, lane, idx)
+    const int idx = (int)(i & 31), lane = (int)((i >> 5) & 63);
+    const size_t bu = i >> 11;
+    const int unit = (int)(bu % units), nb = (int)(bu / units);
+    const int nn = idx & 1, je = idx >> 1, j = je >> 2, e = je & 3, rg = lane >> 4, col = lane & 15;
+    const int k = unit * 64 + 16 * j + 4 * rg + e, c = nb * 32 + 16 * nn + col;      // interleaved column c = 4 u + g
+    frag[i] = f32_to_bf16(W[(size_t)k * 4 * U + (size_t)(c & 3) * U + (c >> 2)]);
+    if (i < (size_t)4 * U) bias_il[i] = bias ? bias[(i & 3) * U + (i >> 2)] : 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" int asr_gemm_act(asr_handle* h, int dtype, int out_dtype, int transA, int transB, int M,
@@ -1915,5 +1982,63 @@ extern "C" int asr_lstm_cell_gemm_fwd(asr_handle* h, const float* x, int ldx, in
                      (hipStream_t)s, B, N, K, x, ldx, W_il, N, (float*)nullptr, N, has_bias ? W_il + (size_t)K * N : nullptr,
                      0, 0, c);
   ASR_CHECK_LAUNCH(h, "asr_lstm_cell_gemm_fwd");
+  return ASR_OK;
+}
+
+// ---- the same with bf16 weight images (bf16-operand models)
+extern "C" size_t asr_lstm_cell_gemm_h_bytes(int K, int U) {
+  return (size_t)K * 4 * U * 2 * 2 + (size_t)4 * U * 4;     // fragment image | interleaved fp32 bias | plain bf16 copy
+}
+static inline float* cell_h_bias(void* img, int K, int U) { return reinterpret_cast<float*>((char*)img + (size_t)K * 4 * U * 2); }
+static inline bf16_t* cell_h_plain(void* img, int K, int U) {
+  return reinterpret_cast<bf16_t*>((char*)img + (size_t)K * 4 * U * 2 + (size_t)4 * U * 4);
+}
+extern "C" int asr_lstm_cell_gemm_prep_h(asr_handle* h, const float* W, const float* bias, int K, int U, void* img,
+                                         asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!W || !img || K < 64 || K % 64 != 0 || U < 8 || U % 8 != 0 || ((uintptr_t)img) % 16 != 0)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_cell_gemm_prep_h: bad args");
+  const size_t n = (size_t)K * 4 * U;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cell_images_h_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, W, bias, K, U,
+                     (bf16_t*)img, cell_h_bias(img, K, U), cell_h_plain(img, K, U));
+  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_gemm_prep_h");
+  return ASR_OK;
+}
+extern "C" int asr_lstm_cell_gemm_fwd_h(asr_handle* h, const float* x, int ldx, int K, const void* img,
+                                        const float* c_prev, const float* h_prev, const float* peep, const float* live,
+                                        int B, int U, float forget_bias, float cell_clip, float* gates, float* c_raw,
+                                        float* c_out, float* h_out, float* h_raw, const float* out_mask, float* cell_out,
+                                        float* h_out2, int ld_h2, float* cell_out2, int ld_c2, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!x || !img || !c_prev || !h_prev || !live || !gates || !c_raw || !c_out || !h_out || !h_raw ||
+      !asr_lstm_cell_gemm_ok(B, K, U, ldx) || ((uintptr_t)x) % 16 != 0 || ((uintptr_t)img) % 16 != 0 ||
+      (h_out2 && ld_h2 < U) || (cell_out2 && ld_c2 < U))
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_cell_gemm_fwd_h: bad args (B <= 32, K %% 64 == 0, U %% 8 == 0, 16-byte aligned rows)");
+  SkinnyCell c;
+  c.c_prev = c_prev; c.h_prev = h_prev; c.peep = peep; c.live = live; c.out_mask = out_mask;
+  c.gates = gates; c.c_raw = c_raw; c.c_out = c_out; c.h_out = h_out; c.h_raw = h_raw;
+  c.cell_out = cell_out; c.h_out2 = h_out2; c.cell_out2 = cell_out2;
+  c.U = U; c.ld_h2 = ld_h2; c.ld_c2 = ld_c2; c.fb = forget_bias; c.clip = cell_clip;
+  const int N = 4 * U;
+  hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, 2, true, true>), dim3(N / 32, (unsigned)((B + 15) / 16)),
+                     dim3(64 * SK_WAVES), 0, (hipStream_t)s, B, N, K, x, ldx, (const float*)img, N, (float*)nullptr, N,
+                     cell_h_bias(const_cast<void*>(img), K, U), 0, 0, c);
+  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_gemm_fwd_h");
+  return ASR_OK;
+}
+// dx [B, K] = dpre [B, 4U] W^T on the plain bf16 copy inside the image (the decoder step's backward product)
+extern "C" int asr_lstm_cell_gemm_bwd_h(asr_handle* h, const float* dpre, int B, int K, int U, const void* img, float* dx,
+                                        int lddx, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!dpre || !img || !dx || B < 1 || B > 32 || K < 16 || K % 16 != 0 || U < 16 || U % 16 != 0 || lddx < K ||
+      ((uintptr_t)dpre) % 16 != 0 || ((uintptr_t)img) % 16 != 0)
+    ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_cell_gemm_bwd_h: bad args (B <= 32, K %% 16 == 0, U %% 16 == 0)");
+  hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, 1, false, true>), dim3(K / 16, (unsigned)((B + 15) / 16)),
+                     dim3(64 * SK_WAVES), 0, (hipStream_t)s, B, K, 4 * U, dpre, 4 * U,
+                     (const float*)cell_h_plain(const_cast<void*>(img), K, U), 4 * U, dx, lddx, (const float*)nullptr, 0, 0,
+                     SkinnyCell{});
+  ASR_CHECK_LAUNCH(h, "asr_lstm_cell_gemm_bwd_h");
   return ASR_OK;
 }

@@ -157,6 +157,14 @@ class AttentionSeq2Seq(ModelBase):
                         (self.keep_prob_embedding_pl_list, 'keep_prob_embedding')):
             lst.append(Placeholder(nm))
 
+    def _w_cell(self):
+        """The decoder cell's kernel as the products see it: itself in an fp32 model; rounded to bf16 (straight-through:
+        the gradient lands on the fp32 variable) in a bf16-operand model -- the per-step products stream 13 MB of it at
+        cfg D widths, half of that as bf16 (asr_lstm_cell_gemm_*_h); the copy made here keeps every other path that
+        multiplies with it (class surface, shapes the skinny kernels do not take) on the same values."""
+        W = self.store[D + 'lstm_cell/kernel']
+        return W.to(torch.bfloat16).to(torch.float32) if self.dtype == ASR_BF16 else W
+
     def _peep(self):
         st = self.store
         if not self.use_peephole:
@@ -276,7 +284,7 @@ class AttentionSeq2Seq(ModelBase):
         dec_in = torch.empty((To, Bp, Din), dtype=torch.float32, device=dev)
         av_in = torch.empty((To, Bp, U + E2), dtype=torch.float32, device=dev)
         ctx = torch.zeros((Bp, E2), dtype=torch.float32, device=dev)
-        W_cell, b_cell = st[D + 'lstm_cell/kernel'], st[D + 'lstm_cell/bias']
+        W_cell, b_cell = self._w_cell(), st[D + 'lstm_cell/bias']
         v = st[AT + 'v_a'] if self.att_mode == 0 else None
         alpha_all = torch.empty((To, Bp, T), dtype=torch.float32, device=dev)   # one slab: d_enc GEMMs read it strided
         use_ddrop = is_training and float(keep_prob_decoder) < 1.0
@@ -302,7 +310,8 @@ class AttentionSeq2Seq(ModelBase):
                     carry_alpha=int(self.carry_alpha), taps=int(st[AT + 'filter'].shape[0]) if self.carry_alpha else 0,
                     enc_dtype=ops.dtype_id(enc_att.dtype), forget_bias=1.0,
                     cell_clip=float(self.clip_activation_decoder or 0.0), sharpening=float(self.sharpening_factor),
-                    W_cell=W_cell, b_cell=b_cell, peep=peep, W_q=self._wq() if has_q else None,
+                    W_cell=W_cell, b_cell=b_cell, cell_bf16=(self.dtype == ASR_BF16), peep=peep,
+                    W_q=self._wq() if has_q else None,
                     b_q=st[AT + 'W_filter/biases'] if (has_q and self.attention_type in AL.HAS_FILTER) else None,
                     v=v, keys=keys, enc=enc_att, seq_len=seq_p,
                     filt=st[AT + 'filter'] if self.carry_alpha else None,
@@ -526,7 +535,8 @@ class AttentionSeq2Seq(ModelBase):
                     carry_alpha=int(self.carry_alpha), taps=int(st[AT + 'filter'].shape[0]) if self.carry_alpha else 0,
                     enc_dtype=ops.dtype_id(enc_att.dtype), forget_bias=1.0,
                     cell_clip=float(self.clip_activation_decoder or 0.0), sharpening=float(self.sharpening_factor),
-                    W_cell=st[D + 'lstm_cell/kernel'], b_cell=st[D + 'lstm_cell/bias'], peep=self._peep(),
+                    W_cell=self._w_cell(), b_cell=st[D + 'lstm_cell/bias'], cell_bf16=(self.dtype == ASR_BF16),
+                    peep=self._peep(),
                     W_q=self._wq() if has_q else None,
                     b_q=st[AT + 'W_filter/biases'] if (has_q and self.attention_type in AL.HAS_FILTER) else None,
                     v=st[AT + 'v_a'] if self.att_mode == 0 else None, keys=keys, enc=enc_att, seq_len=seq_p,
@@ -554,7 +564,8 @@ class AttentionSeq2Seq(ModelBase):
         cf, hf = self.encoder._final_ch
         _, c, h = self._bridge(cf, hf, B)
         layer = self.attention_layer(time_major_inputs=True)
-        cell = LSTMDecoderCell(st, self.decoder_num_units, self.use_peephole, self.clip_activation_decoder)
+        cell = LSTMDecoderCell(st, self.decoder_num_units, self.use_peephole, self.clip_activation_decoder,
+                               kernel=self._w_cell())
         decoder = AttentionDecoder(cell, self.parameter_init, self.max_decode_length, self.num_classes, enc, seq_p, layer,
                                    time_major=False, mode='infer', store=st)
         decoder.live_rows = torch.arange(Bp, device=dev) < B      # rows B.. are the zero-length padding of the batch tile

@@ -36,8 +36,11 @@ class LSTMDecoderCell(object):
     """tf.contrib.rnn.LSTMBlockCell of the decoder (attention_seq2seq.py:353-363): (c, h) state, peepholes, cell clip,
     forget_bias 1; variables attention_decoder/decoder/lstm_cell/{kernel,bias,w_*_diag} of `store`."""
 
-    def __init__(self, store, num_units, use_peephole=True, cell_clip=None, forget_bias=1.0):
+    def __init__(self, store, num_units, use_peephole=True, cell_clip=None, forget_bias=1.0, kernel=None):
+        """kernel: the tensor to multiply with instead of the stored variable (a bf16-operand model hands in the kernel
+        rounded to bf16, AttentionSeq2Seq._w_cell)."""
         self.store, self.num_units = store, num_units
+        self.kernel = kernel
         self.output_size = num_units
         self.cell_clip, self.forget_bias = float(cell_clip or 0.0), forget_bias
         self.peep = None
@@ -53,7 +56,8 @@ class LSTMDecoderCell(object):
         c, h = state
         if live is None:
             live = torch.ones((inputs.shape[0],), dtype=torch.float32, device=inputs.device)
-        pre = ops.gemm(inputs, st[D_SCOPE + 'lstm_cell/kernel'], bias=st[D_SCOPE + 'lstm_cell/bias'])
+        W = self.kernel if self.kernel is not None else st[D_SCOPE + 'lstm_cell/kernel']
+        pre = ops.gemm(inputs, W, bias=st[D_SCOPE + 'lstm_cell/bias'])
         _, _, c_new, h_new, h_raw = ops.lstm_cell_fwd(pre, c, h, self.peep, live, self.forget_bias, self.cell_clip)
         return h_raw, (c_new, h_new)
 

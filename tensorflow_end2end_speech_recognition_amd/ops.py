@@ -1059,6 +1059,44 @@ def lstm_cell_gemm_fwd(x, W_il, has_bias, c_prev, h_prev, peep, live, forget_bia
     return gates, c_raw, c_out, h_out, h_raw, cell_out
 
 
+def lstm_cell_gemm_prep_h(W, bias):
+    """The bf16 images of a decoder cell's kernel [K,4U] (+ bias) for lstm_cell_gemm_fwd_h / _bwd_h: one opaque buffer."""
+    h = _h(W)
+    K, U4 = W.shape
+    nbytes = int(h.lib.asr_lstm_cell_gemm_h_bytes(K, U4 // 4))
+    img = torch.empty((nbytes // 4,), dtype=torch.float32, device=W.device)
+    h.check(h.lib.asr_lstm_cell_gemm_prep_h(h.h, _p(W), _p(bias), K, U4 // 4, _p(img), _s()), 'asr_lstm_cell_gemm_prep_h')
+    return img
+
+
+def lstm_cell_gemm_fwd_h(x, img, U, c_prev, h_prev, peep, live, forget_bias=1.0, cell_clip=0.0, out_mask=None,
+                         h_also=None, cell_out_also=None):
+    """lstm_cell_gemm_fwd with bf16 weights (the image of lstm_cell_gemm_prep_h)."""
+    h = _h(x)
+    B, K = x.shape
+    dev = x.device
+    if x.dtype != torch.float32 or x.stride(1) != 1:
+        raise ValueError('lstm_cell_gemm_fwd_h: x must be fp32 with unit inner stride')
+    gates, c_raw, c_out, h_out, h_raw, cell_out = _f32((B, 4 * U), dev), _f32((B, U), dev), _f32((B, U), dev), \
+        _f32((B, U), dev), _f32((B, U), dev), _f32((B, U), dev)
+    hp, hld = _col_block(h_also, B, U, 'h_also')
+    cp, cld = _col_block(cell_out_also, B, U, 'cell_out_also')
+    h.check(h.lib.asr_lstm_cell_gemm_fwd_h(h.h, C.c_void_p(x.data_ptr()), int(x.stride(0)), K, _p(img), _p(c_prev), _p(h_prev),
+                                           _p(peep), _p(live), B, U, float(forget_bias), float(cell_clip or 0.0), _p(gates),
+                                           _p(c_raw), _p(c_out), _p(h_out), _p(h_raw), _p(out_mask), _p(cell_out), hp, hld,
+                                           cp, cld, _s()), 'asr_lstm_cell_gemm_fwd_h')
+    return gates, c_raw, c_out, h_out, h_raw, cell_out
+
+
+def lstm_cell_gemm_bwd_h(dpre, img, K):
+    """dx [B,K] = dpre [B,4U] W^T on the bf16 copy of W inside the image."""
+    h = _h(dpre)
+    B, U4 = dpre.shape
+    dx = _f32((B, K), dpre.device)
+    h.check(h.lib.asr_lstm_cell_gemm_bwd_h(h.h, _p(dpre), B, K, U4 // 4, _p(img), _p(dx), K, _s()), 'asr_lstm_cell_gemm_bwd_h')
+    return dx
+
+
 def lstm_cell_bwd(dh_use, dc_next, dh_next, gates, c_raw, c_prev, peep, live, want_dpeep=True, dpre_out=None,
                   dpeep_out=None, cell_clip=0.0):
     """dpre_out [B,4U] / dpeep_out [B,3U] (contiguous rows of the caller's per-step arrays): written in place.
@@ -1170,7 +1208,7 @@ class _AttDecoder(C.Structure):
     _PTRS2 = ['keys', 'enc', 'seq_len', 'filt', 'wfil', 'alpha_zero', 'live', 'dmask', 'dec_in', 'av_in', 'alpha_all',
               'snorm_all', 'gates_all', 'craw_all', 'c_all', 'h_all', 'qz_all', 'work', 'dav_cell', 'dav_ctx', 'dctx_all',
               'dpre_all', 'dqz_all', 'dv_all', 'dpeep_all', 'd_in_all', 'dkeys', 'dwfil_rows', 'dfilt_rows', 'dc0', 'dh0',
-              'W_cell_il']
+              'W_cell_il', 'W_cell_h']
     _fields_ = ([(n, C.c_int) for n in _INTS] + [(n, C.c_float) for n in _FLOATS] +
                 [(n, C.c_void_p) for n in _PTRS1] + [('ld_wq', C.c_int)] + [(n, C.c_void_p) for n in _PTRS2])
 
@@ -1196,11 +1234,21 @@ def _att_decoder_struct(a):
 FUSED_CELL_GEMM = os.environ.get('ASR_DEC_CELL_GEMM', '1') != '0'   # A/B: 0 keeps product and cell as two launches
 
 
+BF16_CELL_WEIGHTS = os.environ.get('ASR_DEC_CELL_BF16', '1') != '0'   # A/B: 0 keeps fp32 decoder weights in bf16 models
+
+
 def _cell_gemm_image(h, a):
     """Work space for the gate-interleaved image of W_cell | b_cell (the loops fill it): with it a decoder step's cell-input
-    product and LSTM cell are one launch (asr_lstm_cell_gemm_fwd)."""
+    product and LSTM cell are one launch (asr_lstm_cell_gemm_fwd).  a['cell_bf16'] (bf16-operand models): the bf16 images
+    instead (asr_lstm_cell_gemm_*_h: forward product + cell, backward product)."""
     Din = a['Em'] + a['E2'] + a['U']
-    if FUSED_CELL_GEMM and a.get('W_cell_il') is None and h.lib.asr_lstm_cell_gemm_ok(int(a['B']), Din, int(a['U']), Din):
+    if not (FUSED_CELL_GEMM and h.lib.asr_lstm_cell_gemm_ok(int(a['B']), Din, int(a['U']), Din)):
+        return
+    if a.get('cell_bf16') and BF16_CELL_WEIGHTS and a['U'] % 16 == 0:
+        if a.get('W_cell_h') is None:
+            nbytes = int(h.lib.asr_lstm_cell_gemm_h_bytes(Din, int(a['U'])))
+            a['W_cell_h'] = torch.empty((nbytes // 4,), dtype=torch.float32, device=a['dec_in'].device)
+    elif a.get('W_cell_il') is None:
         a['W_cell_il'] = _f32(((Din + 1) * 4 * a['U'],), a['dec_in'].device)
 
 
@@ -1220,6 +1268,7 @@ def att_decoder_bwd(a):
     (and adds into dkeys / the filter gradients)."""
     h = _h(a['dec_in'])
     a['work'] = _f32((a['B'] * (5 * a['U'] + 3 * a['T'] + a['E2']),), a['dec_in'].device)
+    _cell_gemm_image(h, a)
     st = _att_decoder_struct(a)
     h.check(h.lib.asr_att_decoder_bwd(h.h, C.byref(st), _s()), 'asr_att_decoder_bwd')
 

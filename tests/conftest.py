@@ -34,3 +34,17 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_lds(request):
+    """ASR_POISON_LDS=1 (GPU box): every CU's LDS holds NaN patterns when a GPU test starts (asr_debug_poison_lds), so a
+    kernel that reads LDS words nobody wrote fails every time instead of once in a few cold starts.  Together with
+    ASR_POISON_SCRATCH=1 (the handle's work arena) and scripts/poison_pytest.py (torch's caching allocator)."""
+    if os.environ.get('ASR_POISON_LDS') == '1' and request.node.get_closest_marker('gpu') is not None:
+        import torch
+        if torch.cuda.is_available():
+            from tensorflow_end2end_speech_recognition_amd import _lib, ops
+            h = _lib.handle(0, 0)
+            h.check(h.lib.asr_debug_poison_lds(h.h, ops._s()), 'asr_debug_poison_lds')
+    yield

@@ -347,6 +347,35 @@ def test_cell_product_and_cell_in_one_launch(cuda, B, K, U, peep, bias, mask):
     assert float(want[1].abs().max()) <= 3.0
 
 
+@pytest.mark.parametrize('B,K,U', [(32, 1600, 512), (5, 192, 64), (17, 640, 128), (1, 64, 16)])
+def test_cell_products_with_bf16_weight_images(cuda, B, K, U):
+    """asr_lstm_cell_gemm_fwd_h / _bwd_h (bf16 weight images: fragment-ordered, gate-interleaved for the forward product +
+    cell; plain rows for dpre W^T) against the fp32 kernels on the same weights rounded to bf16 -- the activations stay
+    fp32 and the products are exact, so only the summation order differs: 1e-5 of the largest entry."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    rng = np.random.RandomState(B + K + U + 1)
+    f = lambda *s, sc=1.0: torch.tensor(rng.randn(*s) * sc, dtype=torch.float32, device=cuda)
+    x, W, b, pp = f(B, K, sc=0.5), f(K, 4 * U, sc=0.06), f(4 * U, sc=0.2), f(3, U, sc=0.3)
+    cp, hp = f(B, U, sc=2.0), f(B, U, sc=0.5)
+    live = torch.ones(B, device=cuda)
+    live[B // 2:] = torch.tensor((rng.rand(B - B // 2) < 0.6).astype(np.float32), device=cuda)
+    om = torch.tensor((rng.rand(B, U) < 0.8) / 0.8, dtype=torch.float32, device=cuda)
+    Wr = W.to(torch.bfloat16).float()
+    img = ops.lstm_cell_gemm_prep_h(W, b)
+    nxt, av = torch.zeros(B, K, device=cuda), torch.zeros(B, U + 8, device=cuda)
+    nxt2, av2 = torch.zeros_like(nxt), torch.zeros_like(av)
+    want = ops.lstm_cell_fwd(ops.gemm(x, Wr, bias=b), cp, hp, pp, live, 1.0, 3.0, out_mask=om, want_cell_out=True,
+                             h_also=nxt[:, K - U:], cell_out_also=av[:, :U])
+    got = ops.lstm_cell_gemm_fwd_h(x, img, U, cp, hp, pp, live, 1.0, 3.0, out_mask=om, h_also=nxt2[:, K - U:],
+                                   cell_out_also=av2[:, :U])
+    rel = lambda g, w: float((g - w).abs().max() / w.abs().max().clamp_min(1e-6))
+    for name, g, w in zip(('gates', 'c_raw', 'c_out', 'h_out', 'h_raw', 'cell_out'), got, want):
+        assert rel(g, w) < 1e-5, (name, rel(g, w))
+    assert rel(nxt2, nxt) < 1e-5 and rel(av2, av) < 1e-5
+    dpre = f(B, 4 * U, sc=0.3)
+    assert rel(ops.lstm_cell_gemm_bwd_h(dpre, img, K), ops.gemm(dpre, Wr, transB=True)) < 1e-5
+
+
 @pytest.mark.parametrize('att,prev,sig,dtype', [('location', 'carry', False, 'f32'), ('hybrid', 'zeros', False, 'bf16'),
                                                ('bahdanau_content', 'zeros', True, 'f32'), ('luong_dot', 'zeros', False, 'f32')])
 def test_native_greedy_inference_loop(cuda, att, prev, sig, dtype):
