@@ -1,0 +1,15 @@
+#!/bin/bash
+# image-resident convolution with the epilogue's operands requested ahead: tests, cfg C timing, kernel stats
+set -u
+OUT=gpurun_out/r04_conv
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -x -q -k "epilogue or pool or vgg or cfgC or dropout or conv3x3" > $OUT/tests.txt 2>&1
+grep -E "^FAILED|passed|failed" $OUT/tests.txt | cut -c1-220 | tail -6
+timeout 300 python bench.py --steps 2 --warmup 1 --no-cfgA --no-parity --no-cpu-baseline --aux cfgC > $OUT/b.out 2> $OUT/b.err
+tail -1 $OUT/b.out | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['cfgC'])" || tail -5 $OUT/b.err
+ONLY_C=1 rocprofv3 --kernel-trace --stats -d $OUT/trace -o cfgC -- python scripts/probe_cfgCE.py > $OUT/probe.log 2>&1
+DB=$(find $OUT/trace -name '*.db' | head -1)
+python scripts/rocpd_stats.py "$DB" $OUT/stats.md > /dev/null
+head -22 $OUT/stats.md | cut -c1-70,110-200
+rm -rf $OUT/trace

@@ -987,10 +987,18 @@ struct ConvGate {               // epilogue operands of conv3x3_nt_bf16_kernel's
 // act == 3 (forward): ReLU, round to the operand dtype, then tf.nn.dropout (mask from keep / seed / offset) -- the stored
 // activation is the dropped one, bit for bit what asr_dropout_apply makes of the stored ReLU output, and the undropped
 // one is never written (the backward needs only its sign where the mask kept it: gate mode 2)
-__device__ __forceinline__ void conv_gate_apply(int act, const ConvGate& gate, size_t e, float (&v)[4]) {
+typedef __attribute__((ext_vector_type(4))) unsigned short cg_us4_t;
+// (the gate operand of act == 2 as a separate load: the image-resident kernel requests it at the top of a pixel tile, a
+// thousand matrix cycles ahead of the epilogue that consumes it)
+__device__ __forceinline__ cg_us4_t conv_gate_load(const ConvGate& gate, size_t e) {
+  return *reinterpret_cast<const cg_us4_t*>(gate.act + e);
+}
+template <bool PRE = false>
+__device__ __forceinline__ void conv_gate_apply(int act, const ConvGate& gate, size_t e, float (&v)[4],
+                                                cg_us4_t pre = cg_us4_t{0, 0, 0, 0}) {
   typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
   if (act == 2) {
-    const us4_t g = *reinterpret_cast<const us4_t*>(gate.act + e);
+    const us4_t g = PRE ? pre : *reinterpret_cast<const us4_t*>(gate.act + e);
     float mk[4] = {1.f, 1.f, 1.f, 1.f};
     if (gate.use_drop == 1) asr_dropout_words(gate.offset + e / 4, gate.seed, gate.keep, 1.f / gate.keep, mk);
     else if (gate.use_drop == 2) { const float inv = 1.f / gate.keep; mk[0] = mk[1] = mk[2] = mk[3] = inv; }
@@ -1219,30 +1227,68 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
   gfetch(img);
   lstore(csm);
   __syncthreads();
+  // Round 4: one wave per SIMD means every dependent trip of the epilogue was exposed -- the bias vector and (act == 2)
+  // the gate operand were requested inside the epilogue, 4 + 4 global round trips per 16-pixel tile against 1 152 matrix
+  // cycles (MfmaUtil 18 % at 64 -> 64, profiles/r03_pmc_util.md).  The bias now lives in registers for the launch, the gate
+  // operand of a tile is requested at its top, and the first fragment group of the NEXT tile is read from LDS under the
+  // last multiplies of this one.  Same arithmetic in the same order.
+  f32x4_t bvr[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+    bvr[j] = bias ? *reinterpret_cast<const f32x4_t*>(bias + (ng * NTW + j) * 16 + fq * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  constexpr int TG = CIN == 64 ? 3 : 1, NG = 9 / TG, GF = TG * KPT;
+  auto tile_ptr = [&](const char* base, int mt) -> const char* {
+    const int p = mt * 16 + fr;
+    const int pc = p < HW ? p : 0;
+    const int y = pc / W, x = pc - y * W;
+    return base + ((y + 1) * WP + x + 1) * PST + fq * 16;
+  };
   for (int it = 0; img < Nimg; img += gridDim.x, ++it) {
     char* cur = csm + (nbuf == 2 ? (it & 1) * img_bytes : 0);
     const int nxt = img + gridDim.x;
     if (nxt < Nimg) gfetch(nxt);                           // lands under this image's products
+    // (CIN = 64 keeps 288 weight registers + 64 staging registers: the 24 of the look-ahead group would spill)
+    constexpr bool NEXTPF = CIN == 128;
+    bf16x8_t anx[NEXTPF ? GF : 1];                         // group 0 of the tile about to start
+    if (NEXTPF && mp < ntm) {
+      const char* ap0 = tile_ptr(cur, mp);
+#pragma unroll
+      for (int q = 0; q < GF; ++q) anx[q] = *reinterpret_cast<const bf16x8_t*>(ap0 + tapoff[q / KPT] + (q % KPT) * 64);
+    }
     for (int mt = mp; mt < ntm; mt += MPARTS) {
       const int p = mt * 16 + fr;
-      const int pc = p < HW ? p : 0;
-      const int y = pc / W, x = pc - y * W;
-      const char* ap = cur + ((y + 1) * WP + x + 1) * PST + fq * 16;
+      const char* ap = tile_ptr(cur, mt);
+      const bool more = mt + MPARTS < ntm;                 // wave-uniform
+      const char* apn = tile_ptr(cur, more ? mt + MPARTS : mt);
+      const size_t m = (size_t)img * HW + (p < HW ? p : 0);
+      cg_us4_t gpre[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) gpre[j] = cg_us4_t{0, 0, 0, 0};
+      if (act == 2) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) gpre[j] = conv_gate_load(gate, m * COUT + (ng * NTW + j) * 16 + fq * 4);
+      }
       f32x4_t acc[NTW];
 #pragma unroll
       for (int j = 0; j < NTW; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       // A fragments in groups of TG taps, the next group's LDS reads issued ahead of this group's MFMAs (one wave per
       // SIMD: nothing else hides the LDS latency -- read-wait-multiply per fragment ran the matrix cores at ~15 %)
-      constexpr int TG = CIN == 64 ? 3 : 1, NG = 9 / TG, GF = TG * KPT;
       bf16x8_t a[2][GF];
 #pragma unroll
-      for (int q = 0; q < GF; ++q) a[0][q] = *reinterpret_cast<const bf16x8_t*>(ap + tapoff[q / KPT] + (q % KPT) * 64);
+      for (int q = 0; q < GF; ++q) {
+        if constexpr (NEXTPF) a[0][q] = anx[q];
+        else a[0][q] = *reinterpret_cast<const bf16x8_t*>(ap + tapoff[q / KPT] + (q % KPT) * 64);
+      }
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         if (g + 1 < NG) {
 #pragma unroll
           for (int q = 0; q < GF; ++q)
             a[(g + 1) & 1][q] = *reinterpret_cast<const bf16x8_t*>(ap + tapoff[(g + 1) * TG + q / KPT] + (q % KPT) * 64);
+        } else if constexpr (NEXTPF) {
+#pragma unroll
+          for (int q = 0; q < GF; ++q)                      // the next tile's first group (this tile's again if it is the last)
+            anx[q] = *reinterpret_cast<const bf16x8_t*>(apn + tapoff[q / KPT] + (q % KPT) * 64);
         }
         __builtin_amdgcn_sched_barrier(0);                 // (left alone the scheduler recycles ONE register quad)
 #pragma unroll
@@ -1253,7 +1299,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
       }
       // epilogue: lane holds channels n0 + fq*4 .. +3 of pixel p (transposed product)
       if (p < HW) {
-        const size_t m = (size_t)img * HW + p;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           const int nb = (ng * NTW + j) * 16 + fq * 4;
@@ -1262,15 +1307,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[j][r];
           if (bias) {
-            const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + nb);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            for (int r = 0; r < 4; ++r) v[r] += bvr[j][r];
           }
           if (act == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
           }
-          if (act >= 2) conv_gate_apply(act, gate, m * COUT + nb, v);
+          if (act >= 2) conv_gate_apply<true>(act, gate, m * COUT + nb, v, gpre[j]);
           if constexpr (sizeof(TO) == 4) {
             *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
           } else {
