@@ -2264,13 +2264,18 @@ extern "C" int asr_peek_async_errors(asr_handle* h, unsigned* host_flags, asr_st
     ASR_FAIL(h, ASR_ERR_HIP, "asr_peek_async_errors: copy failed");
   return ASR_OK;
 }
-// Clears the sticky error word (after it has been reported).
+// Clears the sticky error word (after it has been reported) -- and, since a launch whose hand-off timed out leaves its
+// exchange area in a state no later launch was written for (members that gave up at different steps, a header of a cluster
+// that never completed its placement handshake), puts BOTH exchange areas and their bookkeeping back to what a fresh handle
+// has: everything zero, nothing owed.  64 MiB of memset on the error path only.
 extern "C" int asr_clear_async_errors(asr_handle* h, asr_stream s) {
   hipStream_t st = (hipStream_t)s;
   if (!h) return ASR_ERR_INVALID_ARG;
   if (h->scratch_bytes < XCH_BYTES) return ASR_OK;
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
-  if (hipMemsetAsync(base, 0, sizeof(unsigned), st) != hipSuccess) ASR_FAIL(h, ASR_ERR_HIP, "asr_clear_async_errors");
+  if (hipMemsetAsync(base, 0, XCH_BYTES, st) != hipSuccess) ASR_FAIL(h, ASR_ERR_HIP, "asr_clear_async_errors");
+  h->xch_dirty[0] = h->xch_dirty[1] = 0;
+  h->xch_next = 0;
   return ASR_OK;
 }
 extern "C" int asr_debug_cluster_cycles(unsigned long long* out, int n) {

@@ -782,6 +782,12 @@ def check_async_errors(device=0):
     rc = h.lib.asr_check_async_errors(h.h, C.byref(flags))
     if flags.value:
         h.lib.asr_clear_async_errors(h.h, _s())     # sticky until reported once
+        # ... and once only: the non-blocking watch may still hold copies of the same word armed before this point (the
+        # device has been drained, they have all landed); left in its ring they would raise the error a second time up to
+        # DEPTH optimizer steps later -- after the caller has restored its checkpoint
+        w = _watches.get(device.index or 0 if isinstance(device, torch.device) else int(device))
+        if w is not None:
+            w.events = [None] * w.DEPTH
     h.check(rc, 'asr_check_async_errors')
     _deferred.flush()                                # the device is idle: every armed counter has landed
     return flags.value

@@ -466,6 +466,27 @@ def test_cluster_handoff_timeout_is_reported(cuda):
             for _ in range(ops.ErrorWatch.DEPTH + 1):
                 loss, _ = model.compute_loss(x.astype(np.float32), labels, lens.astype(np.int32), keep_prob=1.0)
                 model.train(loss, 'sgd', 0.0)
+        # reported ONCE: two more faulty steps arm the non-blocking watch with copies of the word, then the blocking check
+        # reports it -- the armed copies must not raise the same error again during the clean steps that follow (they did:
+        # a spurious second AsrError up to DEPTH steps after the caller had restored its checkpoint)
+        for _ in range(2):
+            loss, _ = model.compute_loss(x.astype(np.float32), labels, lens.astype(np.int32), keep_prob=1.0)
+            try:
+                model.train(loss, 'sgd', 0.0)
+            except _lib.AsrError:
+                pass
+        ops.debug_set_lstm_flags(0)
+        try:
+            ops.check_async_errors(0)
+        except _lib.AsrError:
+            pass
+        try:
+            ops.flush_deferred_checks()                 # (the faulty steps' "labels fit the frames" counters saw NaN logits)
+        except (ValueError, _lib.AsrError):
+            pass
+        for _ in range(ops.ErrorWatch.DEPTH + 2):
+            loss, _ = model.compute_loss(x.astype(np.float32), labels, lens.astype(np.int32), keep_prob=1.0)
+            model.train(loss, 'sgd', 0.0)
     finally:
         ops.debug_set_lstm_flags(0)
     torch.cuda.synchronize()
