@@ -1490,13 +1490,21 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(int Mpix, int H, 
   const float invW = 1.0f / (float)W;
   const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8_t ra[4], rb[4];
+  // position of this thread's four pixels inside their images, carried from k-tile to k-tile (gload runs once per k-tile, in
+  // order): the modulo by a run-time H W per pixel and k-tile -- ~60 instructions, four times -- was more VALU work than the
+  // 32 MFMAs of the k-tile it feeds (MfmaUtil 27 %, profiles/r03_pmc_util.md)
+  int remq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) remq[q] = (kbeg + kr0 + 16 * q) % HW;
   auto gload = [&](int kt) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int p = kbeg + kt * BK + kr0 + 16 * q;         // pixel = reduction index
       const bool kin = p < kend;
       const int pp = kin ? p : 0;
-      const int rem = pp % HW;
+      const int rem = remq[q];
+      remq[q] += BK;
+      while (remq[q] >= HW) remq[q] -= HW;
       const int y = (int)(((float)rem + 0.5f) * invW), x = rem - y * W;      // exact for rem < 2^22
       const bool ok = a_ok && kin && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
       ra[q] = ok ? *reinterpret_cast<const bf16x8_t*>(X + (ptrdiff_t)((size_t)pp * Cin) + sh) : zero;
