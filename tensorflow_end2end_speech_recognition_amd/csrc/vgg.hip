@@ -126,6 +126,24 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ in, int N, int H, int W
 }
 // four channels per thread (C % 4 == 0): one 8 / 16-byte load per window cell instead of four scalar ones
 // use_drop: tf.nn.dropout on the (rounded) pooled output -- the stored pooled activation is the dropped one
+// (n, h, w, c4) of a flat index over [N][H][W][C4]: 32-bit divisions when the whole range fits (three udiv of ~20
+// instructions each); the size_t form -- five 64-bit divisions by run-time values, ~150 instructions each -- was what these
+// "memory-bound" pooling passes actually spent their time on (round 4: un-pool pass 1.61 ms at 2.2 TB/s)
+__device__ __forceinline__ void nhwc4_split(size_t idx, bool i32, int C4, int W, int H, int& c4, int& w, int& h, size_t& n) {
+  if (i32) {
+    unsigned t = (unsigned)idx;
+    c4 = (int)(t % (unsigned)C4); t /= (unsigned)C4;
+    w = (int)(t % (unsigned)W); t /= (unsigned)W;
+    h = (int)(t % (unsigned)H);
+    n = t / (unsigned)H;
+  } else {
+    c4 = (int)(idx % C4);
+    w = (int)((idx / C4) % W);
+    h = (int)((idx / ((size_t)C4 * W)) % H);
+    n = idx / ((size_t)C4 * W * H);
+  }
+}
+
 template <typename T>
 __global__ void maxpool_fwd_vec_kernel(const T* __restrict__ in, int N, int H, int W, int C, T* __restrict__ out,
                                        uint8_t* __restrict__ arg, float keep = 1.f, uint64_t seed = 0, uint64_t offset = 0,
@@ -134,9 +152,9 @@ __global__ void maxpool_fwd_vec_kernel(const T* __restrict__ in, int N, int H, i
   const size_t total = (size_t)N * Ho * Wo * C4;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
-    const int c4 = idx % C4;
-    const int wo = (idx / C4) % Wo, ho = (idx / ((size_t)C4 * Wo)) % Ho;
-    const size_t n = idx / ((size_t)C4 * Wo * Ho);
+    int c4, wo, ho;
+    size_t n;
+    nhwc4_split(idx, total <= 0xFFFFFFFFull, C4, Wo, Ho, c4, wo, ho, n);
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int bi[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -286,7 +304,8 @@ __global__ __launch_bounds__(256) void conv3x3_smallc_fwd_mfma_kernel(const bf16
   for (int mt = 0; mt < 4; ++mt) {
     const size_t p = pbase + mt * 16 + fr;
     const bool valid = p < Npix;
-    const size_t n = valid ? p / (size_t)HW : 0;
+    // (a 32-bit division when the pixel count allows: the size_t form is ~150 instructions per pixel)
+    const size_t n = !valid ? 0 : (Npix <= 0xFFFFFFFFull ? (size_t)((unsigned)p / (unsigned)HW) : p / (size_t)HW);
     const int rem = valid ? (int)(p - n * HW) : 0;
     const int h = rem / W, w = rem - h * W;
     const bf16_t* xn = x + n * (size_t)HW * CIN;
@@ -512,9 +531,9 @@ __global__ void maxpool_relu_bwd_kernel(const float* __restrict__ dout, const ui
   const float inv = use_drop ? 1.f / keep : 1.f;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
-    const int c4 = idx % C4;
-    const int w = (idx / C4) % W, h = (idx / ((size_t)C4 * W)) % H;
-    const size_t n = idx / ((size_t)C4 * W * H);
+    int c4, w, h;
+    size_t n;
+    nhwc4_split(idx, total <= 0xFFFFFFFFull, C4, W, H, c4, w, h, n);
     const size_t o = ((n * Ho + h / 2) * Wo + w / 2) * C + (size_t)c4 * 4;
     const int k = ((h & 1) << 1) | (w & 1);
     const f32x4_t g = *reinterpret_cast<const f32x4_t*>(dout + o);
