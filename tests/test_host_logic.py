@@ -315,6 +315,44 @@ def test_attention_model_host_logic(monkeypatch, att, sig, prev):
     assert np.array_equal(out_infer.predicted_ids.numpy(), ref_ids)
 
 
+def test_bf16_model_multiplies_with_the_rounded_decoder_kernel_everywhere(monkeypatch):
+    """A bf16-operand attention model streams its decoder cell's kernel as bf16 (asr_lstm_cell_gemm_*_h) -- one more
+    rounding point, straight-through (AttentionSeq2Seq._w_cell, oracle.attention's operand_round set).  On the CPU
+    stand-ins nothing else rounds, so the point can be isolated: loss, logits and EVERY gradient equal the oracle's for the
+    same weights with ONLY that kernel rounded to bf16 (1e-6), and differ measurably from the oracle on the stored kernel."""
+    _cpu_ops.install(monkeypatch)
+    from oracle import attention as oatt
+    from oracle import lstm as olstm
+    from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
+    rng = np.random.RandomState(11)
+    B, T, D, H, L, A, Em, C, U = 3, 9, 6, 8, 1, 10, 4, 6, 12
+    x, sl, labels, lsl, _ = _att_batch(rng, B, T, D, C)
+    model = AttentionSeq2Seq(input_size=D, encoder_type='blstm', encoder_num_units=H, encoder_num_layers=L,
+                             encoder_num_proj=None, attention_type='location', attention_dim=A, decoder_type='lstm',
+                             decoder_num_units=U, decoder_num_layers=1, embedding_dim=Em, num_classes=C, sos_index=C,
+                             eos_index=C + 1, max_decode_length=8, parameter_init=0.5, clip_grad_norm=5.0,
+                             clip_activation_encoder=50, clip_activation_decoder=50, dtype='bf16', seed=5, device='cpu',
+                             sharpening_factor=1.5, logits_temperature=2.0)
+    key = 'attention_decoder/decoder/lstm_cell/kernel'
+    sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    rounded = dict(sd)
+    rounded[key] = olstm.bf16_round_t(torch.tensor(sd[key], dtype=torch.float64)).numpy()
+    assert np.abs(rounded[key] - sd[key]).max() > 1e-4                    # the rounding is not a no-op on these weights
+    assert torch.equal(model._w_cell(), torch.tensor(rounded[key], dtype=torch.float32))
+    loss, logits, _, _ = model.compute_loss(x, labels, sl, lsl, 1.0, 1.0, 1.0)
+    opt = model._set_optimizer('adam', 1e-3)
+    grads = {name: g.numpy() for g, name in opt.compute_gradients(loss, model=model)}
+    gap = {}
+    for tag, weights in (('rounded', rounded), ('stored', sd)):
+        ref = oatt.attention_model_forward(weights, x, labels, sl, lsl, L, 'location', clip_enc=50.0, clip_dec=50.0,
+                                           sharpening=1.5, temperature=2.0)
+        gap[tag] = (abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']),
+                    np.abs(logits.numpy() - ref['logits'] * 2.0).max(),
+                    max(np.abs(grads[n] - ref['grads'][n]).max() / max(np.abs(ref['grads'][n]).max(), 1e-3) for n in grads))
+    assert gap['rounded'][0] < 1e-6 and gap['rounded'][1] < 1e-6 and gap['rounded'][2] < 1e-5, gap
+    assert gap['stored'][1] > 1e-4 and gap['stored'][2] > 1e-4, gap       # ... and the test can tell the two apart
+
+
 def test_joint_ctc_attention_host_logic(monkeypatch):
     _cpu_ops.install(monkeypatch)
     from oracle import attention as oatt
