@@ -40,7 +40,7 @@ _PEEK = {}
 
 
 @pytest.fixture(autouse=True)
-def _poisoned_lds(request):
+def _gpu_test_aids(request):
     """ASR_POISON_LDS=1 (GPU box): every CU's LDS holds NaN patterns when a GPU test starts (asr_debug_poison_lds), so a
     kernel that reads LDS words nobody wrote fails every time instead of once in a few cold starts.  Together with
     ASR_POISON_SCRATCH=1 (the handle's work arena) and scripts/poison_pytest.py (torch's caching allocator)."""
