@@ -786,6 +786,94 @@ def _maxpool2x2_relu_bwd(dout, arg, act, drop=None, pooled=None, hw=None):
     return _relu_bwd(_maxpool2x2_bwd(d, arg, H, W), act).to(act.dtype)
 
 
+# ---- the bf16 MFMA path of the VGG front-end (models/encoders/core/vgg_blstm.py: implicit-GEMM 3x3 convolutions, the
+# few-channel first layer, dropout in the producing kernels' epilogues).  Values are rounded where the device rounds
+# (stored activations / pre-activation gradients are bf16, data gradients fp32); products accumulate in fp64.
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _conv3x3_prep_weights(w_hwio):
+    """(wf [Cout, 9 Cin], wb [Cin, 9 Cout]) bf16: forward image and flipped-tap image (asr_conv3x3_prep_weights)."""
+    _, _, Cin, Cout = w_hwio.shape
+    wq = _bf(w_hwio)
+    wf = wq.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    wb = wq.flip(0, 1).permute(2, 0, 1, 3).reshape(Cin, 9 * Cout).contiguous()
+    return wf, wb
+
+
+def _conv_nhwc(x, w_oihw, bias=None):
+    y = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w_oihw.double(), None if bias is None else bias.double(),
+                                   padding=1)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def _conv3x3_fwd(x, wt_fwd, bias, relu=True):
+    Cout, Cin = wt_fwd.shape[0], x.shape[3]
+    y = _conv_nhwc(x, wt_fwd.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), bias)
+    return _bf(torch.relu(y) if relu else y)
+
+
+def _conv3x3_fwd_drop(x, wt_fwd, bias, drop):
+    return _bf(_dropout_apply(_conv3x3_fwd(x, wt_fwd, bias, True).float(), *drop))
+
+
+def _conv3x3_bwd_data(dy, wt_bwd):
+    Cin, Cout = wt_bwd.shape[0], dy.shape[3]
+    return _conv_nhwc(dy, wt_bwd.view(Cin, 3, 3, Cout).permute(0, 3, 1, 2)).float()      # the image holds the flipped taps
+
+
+def _conv3x3_bwd_data_relu(dy, wt_bwd, act_below, drop=None, dropped=False):
+    dx = _conv3x3_bwd_data(dy, wt_bwd)
+    if drop is None:
+        return _bf(dx * (act_below > 0))
+    if dropped:                 # act_below is the DROPPED activation: > 0 where active and kept
+        return _bf(dx * (act_below > 0) * (1.0 / drop[0]))
+    return _bf(_relu_bwd(dx, act_below, drop=drop))
+
+
+def _conv_wgrad(x, dy):
+    """[9 Cin, Cout] fp64: dW[tap Cin + ci, co] = sum_p x[p + s_tap, ci] dy[p, co]."""
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    xp = torch.nn.functional.pad(x.double(), (0, 0, 1, 1, 1, 1))
+    rows = []
+    for ty in range(3):
+        for tx in range(3):
+            rows.append(torch.einsum('nhwc,nhwo->co', xp[:, ty:ty + H, tx:tx + W], dy.double()))
+    return torch.cat(rows, 0)
+
+
+def _conv3x3_bwd_weight(x, dy, dw, accumulate=False):
+    g = _conv_wgrad(x, dy).float()
+    dw.copy_(dw + g if accumulate else g)
+    return dw
+
+
+def _conv3x3_smallc_fwd(x, w2d, bias, relu=True):
+    Cin, Cout = x.shape[3], w2d.shape[1]
+    y = _conv_nhwc(x, w2d.view(3, 3, Cin, Cout).permute(3, 2, 0, 1), bias)
+    return _bf(torch.relu(y) if relu else y)
+
+
+def _conv3x3_smallc_fwd_drop(x, w2d, bias, drop):
+    return _bf(_dropout_apply(_conv3x3_smallc_fwd(x, w2d, bias, True).float(), *drop))
+
+
+def _conv3x3_smallc_bwd_weight(x, dpre, dw):
+    dw.copy_(_conv_wgrad(x, dpre).float())
+    return dw
+
+
+def _maxpool2x2_fwd_drop(x, drop):
+    out, arg = _maxpool2x2_fwd(x)
+    return _dropout_apply(out.float(), *drop).to(x.dtype), arg
+
+
+def _relu_bwd_scaled(dout, out_dropped, keep):
+    return (dout * (out_dropped > 0) * (1.0 / keep)).to(out_dropped.dtype)
+
+
 STAND_INS = dict(
     side_lane=_NullLane, join_side=lambda device: None, stream_event=lambda: None, set_side_gemm_workgroups=lambda device, n: None, wait_event=lambda ev: None,
     gru_fwd=_gru_fwd, gru_bwd=_gru_bwd, lstm_prep_layer=_lstm_prep_layer, lstm_grad_finish=_lstm_grad_finish, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
@@ -803,6 +891,11 @@ STAND_INS = dict(
     argmax_rows=_argmax_rows, im2col3x3=_im2col3x3, col2im3x3=_col2im3x3, maxpool2x2_fwd=_maxpool2x2_fwd,
     maxpool2x2_bwd=_maxpool2x2_bwd, im2col=_im2col, col2im=_col2im, att_decoder_fwd=_att_decoder_fwd,
     att_decoder_bwd=_att_decoder_bwd, att_decoder_infer=_att_decoder_infer,
+    conv3x3_prep_weights=_conv3x3_prep_weights, conv3x3_fwd=_conv3x3_fwd, conv3x3_fwd_drop=_conv3x3_fwd_drop,
+    conv3x3_bwd_data=_conv3x3_bwd_data, conv3x3_bwd_data_relu=_conv3x3_bwd_data_relu, conv3x3_bwd_weight=_conv3x3_bwd_weight,
+    conv3x3_smallc_fwd=_conv3x3_smallc_fwd, conv3x3_smallc_fwd_drop=_conv3x3_smallc_fwd_drop,
+    conv3x3_smallc_bwd_weight=_conv3x3_smallc_bwd_weight, maxpool2x2_fwd_drop=_maxpool2x2_fwd_drop,
+    relu_bwd_scaled=_relu_bwd_scaled,
 )
 
 
