@@ -1324,6 +1324,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
         }
       }
     }
+    // (Measured, round 4: barriers that wait for the LDS counter only -- s_waitcnt lgkmcnt(0) + s_barrier instead of
+    // __syncthreads(), whose release fence also waits for the epilogue's global stores -- change nothing: 2.80 vs 2.76 ms.)
     if (nxt < Nimg) {
       if (nbuf == 1) __syncthreads();                      // every wave is done with the only buffer
       lstore(csm + (nbuf == 2 ? ((it + 1) & 1) * img_bytes : 0));
