@@ -22,12 +22,21 @@ Pinning status (see DESIGN.md "Oracle"):
   conv_ops / pooling_ops / adagrad / clip_ops tests.
 * The label maps, the dataset iterators, the LR controller and the sparse-label helpers of the host side are
   PINNED to outputs recorded from the reference's own classes (``tests/golden/*.json``, ``datasets_v1.npz``).
-* The rest of what lives in TensorFlow 1.x (peepholes and cell clip of LSTMBlockCell,
-  dynamic_rnn masking, conv2d SAME, the attention decoder, optimizers ...) is
-  "PARITY UNPINNED": TensorFlow 1.2/1.3 (requirements.txt:11) is not
-  installable here and the reference's tests hold no golden numbers
-  (models/test/test_ctc.py:225-233 only loops until LER < 0.1).  Those parts
-  restate the published op semantics and are
-  cross-checked against an independent second implementation
-  (torch.nn.LSTM, torch.nn.functional.ctc_loss, finite differences).
+* Round 5: ``oracle.attention`` (attention layer, decoder step, dynamic_decode, bridge, sequence loss, joint loss),
+  the peephole / clip / projection cell and the encoders of ``oracle.lstm``, ``oracle.model`` (CTC model over blstm /
+  lstm / bottleneck / vgg_blstm / LSTMCell + num_proj / gru / bgru), ``oracle.vgg`` and the per-variable clip are
+  PINNED to the REFERENCE'S OWN CODE AS EXECUTED: ``tests/golden/make_golden_tfshim.py`` imports the unchanged files
+  (models/attention/decoders/attention_layer.py, attention_decoder.py, dynamic_decoder.py, models/attention/bridge.py,
+  attention_seq2seq.py, joint_ctc_attention.py, models/ctc/ctc.py, models/encoders/core/*.py,
+  models/recurrent/layers/lstm.py, models/model_base.py) over an eager float64 stand-in for the TensorFlow ops they call
+  (``tests/golden/tf_shim``; autograd gives the gradients of the reference's own forward graph), and
+  ``tests/test_oracle_tfshim.py`` (65 cases) holds the oracle to the recorded numbers at 1e-11 (values) / 1e-9
+  (gradients).  Adadelta is pinned to the recurrence of TensorFlow's adadelta_test.py, merge_repeated on a path with
+  repeats to the worked example of TensorFlow's documentation of the op.
+* What remains a restatement of TensorFlow-internal semantics INSIDE that stand-in (TF 1.2/1.3 is
+  not installable here): dynamic_rnn's zero-output / state-copy rule and reverse_sequence, SAME padding,
+  TrainingHelper / GreedyEmbeddingHelper, sequence_loss, LSTMBlockCell's straight-through clip in the gradient.  Each is
+  a few lines, checked where TensorFlow publishes constants (lstm_ops_test, core_rnn_cell_test, conv / pooling tests,
+  ctc tests) and against the reference's Python LSTMCell; tf.nn.ctc_loss inside the stand-in is
+  torch.nn.functional.ctc_loss -- a third implementation beside oracle.ctc and the HIP kernel.
 """

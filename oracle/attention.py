@@ -1,5 +1,10 @@
-"""Oracle (test infrastructure, PARITY UNPINNED -- TF1 absent, see oracle/__init__.py): CPU
+"""Oracle (test infrastructure; PINNED to the reference's own code since round 5, see oracle/__init__.py): CPU
 restatement of the attention encoder-decoder and the joint CTC-attention model.
+
+Pin: tests/golden/tfshim_v1.npz holds what the UNCHANGED reference files listed below computed when executed on an eager
+float64 TensorFlow stand-in (tests/golden/make_golden_tfshim.py); tests/test_oracle_tfshim.py holds attention_step (all
+seven types, sharpening, sigmoid smoothing, ragged masks, carried weights) and attention_model_forward / _infer (logits,
+ids, attention weights, loss, every gradient; joint loss) to those numbers at 1e-11 / 1e-9.
 
 Follows
   * models/attention/attention_seq2seq.py:193-277 (_build), :413-509 (_decode_train /

@@ -9,8 +9,9 @@ equations (TF 1.x):
     c      = tanh([x, r * h] W_c + b_c)     the reset gate is applied BEFORE the candidate's matrix product
     h'     = u * h + (1 - u) * c
 The sequence_length handling (state carried, output zero past the length, reverse_sequence for the backward
-direction) is the one oracle.lstm.dynamic_rnn restates; "parity unpinned" for that part (TF1 absent), cross-checked
-by finite differences in tests/test_oracle.py."""
+direction) is the one oracle.lstm.dynamic_rnn restates; the stacked encoders (scopes, MultiRNNCell, bidirectional concat)
+are PINNED to the reference's own GRUEncoder / BGRUEncoder as executed (tests/test_oracle_tfshim.py::test_tfshim_ctc_models
+[ctc_gru, ctc_bgru]) and cross-checked by finite differences in tests/test_oracle.py."""
 import torch
 
 from .lstm import reverse_sequence

@@ -1,5 +1,9 @@
-"""Oracle (test infrastructure; the peephole-free cell is PINNED to TensorFlow's lstm_ops_test.py constants, the
-peephole / clip / sequence-masking parts are PARITY UNPINNED -- see oracle/__init__.py):
+"""Oracle (test infrastructure; PINNED -- the peephole-free cell to TensorFlow's lstm_ops_test.py constants; peepholes,
+cell clip (both gradient conventions) and the projection to the reference's own Python LSTMCell
+(models/recurrent/layers/lstm.py:104-170) as EXECUTED, and the stacked / bidirectional / masked encoders to the
+reference's own encoder + model code as executed (tests/golden/tfshim_v1.npz, tests/test_oracle_tfshim.py; inside
+those runs dynamic_rnn's zero-output / state-copy rule is the TensorFlow stand-in's statement of rnn.py) -- see
+oracle/__init__.py):
 CPU restatement of the recurrent encoder of the reference.
 
 Follows
@@ -295,7 +299,8 @@ def layer_param_grads_np(x_tm, hout, dgates, lens, p, reverse=False, round_fn=No
 # lstm_impl == 'LSTMCell' (Sak et al. 2014, "LSTMP"): same gates as above (split order i, j, f, o; peepholes
 # w_i_diag / w_f_diag on c_prev, w_o_diag on the new c; forget_bias added to f; cell clip before the output gate),
 # then m = (sigmoid(o) * tanh(c)) @ projection/kernel [H, P]; the RECURRENT input and the emitted output are the
-# projected m (kernel [(Din + P), 4H]), the state is (c [H], m [P]).  PARITY UNPINNED (TF1 absent).
+# projected m (kernel [(Din + P), 4H]), the state is (c [H], m [P]).  PINNED to the reference's Python LSTMCell as
+# executed (tests/test_oracle_tfshim.py::test_tfshim_python_lstm_cell, ::test_tfshim_ctc_models[ctc_blstm_lstmcell_proj]).
 def lstmp_cell(x, c_prev, m_prev, w, b, wci, wcf, wco, w_proj, forget_bias=1.0, cell_clip=0.0, use_peephole=True):
     c, h = lstm_block_cell(x, c_prev, m_prev, w, b, wci, wcf, wco, forget_bias, cell_clip, use_peephole,
                            clip_blocks_gradient=True)

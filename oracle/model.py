@@ -1,4 +1,6 @@
-"""Oracle (test infrastructure, PARITY UNPINNED -- see oracle/__init__.py): the CTC
+"""Oracle (test infrastructure; PINNED to the reference's own CTC.compute_loss as executed on the eager TensorFlow
+stand-in -- blstm, lstm, bottleneck, vgg_blstm, LSTMCell + num_proj, gru, bgru: encoder outputs, logits, loss, every
+gradient, per-variable clip; tests/test_oracle_tfshim.py::test_tfshim_ctc_models -- see oracle/__init__.py): the CTC
 model of the reference end to end on the CPU.
 
 Follows models/ctc/ctc.py:175-323: encoder (oracle.lstm) -> reshape [T*B, 2H] ->

@@ -1,5 +1,6 @@
 """Oracle (test infrastructure; update rules pinned to TensorFlow's own optimizer tests where those hold numbers --
-tests/golden/tf_known_answers.py: sgd, momentum, nesterov, adagrad, rmsprop, adam; adadelta PARITY UNPINNED):
+tests/golden/tf_known_answers.py: sgd, momentum, nesterov, adagrad, adadelta, rmsprop, adam; clip_by_norm per variable
+also to the reference's ModelBase._clip_gradients as executed, tests/test_oracle_tfshim.py):
 numpy restatement of
 tf.clip_by_norm and the seven tf.train optimizers the reference selects in
 models/model_base.py:12-20,68-95 with TF1 default hyper-parameters

@@ -1,4 +1,6 @@
-"""Oracle (test infrastructure, PARITY UNPINNED -- TF1 absent): CPU restatement of the VGG
+"""Oracle (test infrastructure; layout / padding conventions PINNED to TensorFlow's conv_ops / pooling_ops test constants,
+the front-end as a whole to the reference's own VGGBLSTMEncoder + cnn_util.py as executed,
+tests/test_oracle_tfshim.py::test_tfshim_ctc_models[ctc_vgg_blstm]): CPU restatement of the VGG
 front-end of models/encoders/core/vgg_blstm.py:107-177 (conv_layer / max_pool of
 models/encoders/core/cnn_util.py:13-84) with TF 'SAME' semantics:
 conv 3x3 stride 1 pads 1/1; max_pool 2x2 stride 2 pads the EXTRA cell AFTER with -inf.

@@ -6,7 +6,14 @@ ctc num_classes = num_classes + 1 (blank = last).  ignore_longer_outputs_than_in
 reference (:315): an utterance without a valid alignment raises ValueError here too.
 Quirk Q2 (the [B*T,C] -> [T,B,C] reshape of batch-major logits, :190-226) is NOT reproduced: the
 encoder outputs are kept time-major, which is the intended computation.
+Quirk Q15 (found by EXECUTING the reference's class, tests/golden/make_golden_tfshim.py): its constructor hands
+clip_activation_decoder=50, weight_decay=0.0, time_major=True, sharpening_factor=1.0, logits_temperature=1.0 to the base
+class as literals (:133-137) -- whatever the recipe passed (examples/timit/training/train_joint_ctc_attention.py:382-386
+passes all of them from the config) is ignored.  REPRODUCED by default, with a warning when a passed value differs from
+the literal; `honour_ctor_args=True` (extension keyword) uses the caller's values instead.
 """
+import warnings
+
 import numpy as np
 import torch
 
@@ -29,8 +36,21 @@ class JointCTCAttention(AttentionSeq2Seq):
                  lstm_impl='LSTMBlockCell', use_peephole=True, splice=1, parameter_init=0.1,
                  clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50,
                  weight_decay=0.0, time_major=True, sharpening_factor=1.0, logits_temperature=1.0,
-                 name='joint_ctc_attention', **kw):
+                 name='joint_ctc_attention', honour_ctor_args=False, **kw):
         assert 0 <= lambda_weight <= 1, 'lambda_weight must be in [0, 1]'
+        if not honour_ctor_args:                      # Q15: joint_ctc_attention.py:133-137
+            passed = dict(clip_activation_decoder=clip_activation_decoder, weight_decay=weight_decay,
+                          time_major=time_major, sharpening_factor=sharpening_factor,
+                          logits_temperature=logits_temperature)
+            fixed = dict(clip_activation_decoder=50, weight_decay=0.0, time_major=True, sharpening_factor=1.0,
+                         logits_temperature=1.0)
+            dropped = {k: v for k, v in passed.items() if v != fixed[k]}
+            if dropped:
+                warnings.warn('JointCTCAttention ignores %s as the reference does (joint_ctc_attention.py:133-137 '
+                              'passes literals to its base class); honour_ctor_args=True uses them'
+                              % ', '.join('%s=%r' % kv for kv in sorted(dropped.items())))
+            clip_activation_decoder, weight_decay, time_major = 50, 0.0, True
+            sharpening_factor, logits_temperature = 1.0, 1.0
         self.lambda_weight = float(lambda_weight)
         self.ctc_num_classes = num_classes + 1
         init = parameter_init

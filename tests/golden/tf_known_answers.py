@@ -83,6 +83,22 @@ BEAM_DECODED = [[1, 0], [0, 1, 0]]                    # beam 0, beam 1
 BEAM_LOG_PROB = [0.584855, 0.389139]                  # TF1's max-normalised log-probabilities of the two beams
 
 
+# merge_repeated on a path WITH repeats: the worked example in the documentation of tf.nn.ctc_beam_search_decoder /
+# tf.nn.ctc_greedy_decoder (tensorflow/python/ops/ctc_ops.py): "if consecutive entries in a beam are the same, only the
+# first of these is emitted.  That is, when the sequence is `A B B * B * B` (where '*' is the blank label), the return
+# value is: `A B` if merge_repeated = True; `A B B B` if merge_repeated = False."  A = 0, B = 1, blank = 2; the frame
+# posteriors put 0.9 on the documented sequence, so it is the best alignment and A B B B the best labelling.
+MERGE_DOC_FRAMES = [0, 1, 1, 2, 1, 2, 1]              # A B B * B * B
+MERGE_DOC_DEPTH, MERGE_DOC_BLANK, MERGE_DOC_PEAK = 3, 2, 0.9
+MERGE_DOC_MERGED, MERGE_DOC_UNMERGED = [0, 1], [0, 1, 1, 1]
+
+
+def merge_doc_probs():
+    p = np.full((len(MERGE_DOC_FRAMES), MERGE_DOC_DEPTH), (1.0 - MERGE_DOC_PEAK) / (MERGE_DOC_DEPTH - 1))
+    p[np.arange(len(MERGE_DOC_FRAMES)), MERGE_DOC_FRAMES] = MERGE_DOC_PEAK
+    return p
+
+
 def beam_max_normaliser(probs, seq_len):
     """sum_t -log max_c p[t, c]: what TF1's frame-max normalisation adds to log p(path | x)."""
     return float(np.sum(-np.log(np.asarray(probs)[:seq_len].max(1))))
@@ -145,6 +161,29 @@ def adam_reference(param, g, t, m, v, alpha=0.001, beta1=0.9, beta2=0.999, epsil
 
 
 ADAM_VAR, ADAM_GRAD, ADAM_STEPS = [[1.0, 2.0], [3.0, 4.0]], [[0.1, 0.1], [0.01, 0.01]], 3
+
+#  * adadelta_test.py doTestBasic: variables [1, 2] / [3, 4], the SAME constant gradient for both, for grad in
+#    {0.2, 0.1, 0.01} x lr in {1.0, 0.5, 0.1}; rho 0.95, epsilon 1e-8, four updates.  The test carries its own scalar
+#    recurrence and asserts after every step that both slots and both variables follow it:
+#        accum        = accum * rho + grad^2 * (1 - rho)
+#        update       = sqrt(accum_update + epsilon) * (1 / sqrt(accum + epsilon)) * grad
+#        accum_update = accum_update * rho + update^2 * (1 - rho)
+#        tot_update  += update * lr ;  var == var_init - tot_update
+ADADELTA_GRADS, ADADELTA_LRS, ADADELTA_RHO, ADADELTA_EPS, ADADELTA_STEPS = [0.2, 0.1, 0.01], [1.0, 0.5, 0.1], 0.95, 1e-8, 4
+ADADELTA_VAR = [[1.0, 2.0], [3.0, 4.0]]
+
+
+def adadelta_reference(grad, lr, steps, rho=0.95, epsilon=1e-8):
+    """-> per step (accum, accum_update, tot_update), the test's scalars."""
+    accum = accum_update = tot_update = 0.0
+    out = []
+    for _ in range(steps):
+        accum = accum * rho + (grad ** 2) * (1 - rho)
+        update = ((accum_update + epsilon) ** 0.5 * (accum + epsilon) ** (-0.5) * grad)
+        accum_update = accum_update * rho + (update ** 2) * (1.0 - rho)
+        tot_update += update * lr
+        out.append((accum, accum_update, tot_update))
+    return out
 
 # tf.clip_by_norm: tensorflow/python/kernel_tests/clip_ops_test.py, testClipByNormClipped / NotClipped
 CLIP_X = [[-3.0, 0.0, 0.0], [4.0, 0.0, 0.0]]

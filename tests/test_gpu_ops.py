@@ -895,6 +895,14 @@ def test_beam_search_matches_tensorflow_known_answer(cuda):
     for merge in (True, False):
         hyp = sparsetensor2list(model.decoder(lg, [tfk.BEAM_SEQ_LEN], beam_width=tfk.BEAM_WIDTH, merge_repeated=merge), 1)
         assert [int(v) for v in hyp[0]] == tfk.BEAM_DECODED[0]
+    # a best path WITH repeats: the worked example of TensorFlow's documentation of the op, `A B B * B * B` ->
+    # `A B` under merge_repeated=True (the reference's call, ctc.py:344-346), `A B B B` under False
+    doc = torch.tensor(np.log(tfk.merge_doc_probs())[:, None].astype(np.float32), device=cuda)
+    model3 = CTC('blstm', 12, 64, 1, tfk.MERGE_DOC_DEPTH - 1, dtype='f32', seed=0)
+    for width in (2, 4, 8):
+        for merge, want in ((True, tfk.MERGE_DOC_MERGED), (False, tfk.MERGE_DOC_UNMERGED)):
+            hyp = sparsetensor2list(model3.decoder(doc, [doc.shape[0]], beam_width=width, merge_repeated=merge), 1)
+            assert [int(v) for v in hyp[0]] == want, (width, merge, hyp)
 
 
 def test_beam_search_cfgE_scale_matches_reference_golden(cuda):

@@ -769,11 +769,21 @@ def test_attention_host_logic_edge_shapes(monkeypatch, B, T, D, C, L, att, sig, 
               embedding_dim=3, num_classes=C, sos_index=C, eos_index=C + 1, max_decode_length=6, parameter_init=0.2,
               clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50, dtype='f32', device='cpu',
               seed=B, sharpening_factor=1.3, sigmoid_smoothing=sig)
-    model = AttentionSeq2Seq(**kw) if lam is None else JointCTCAttention(lambda_weight=lam, **kw)
+    if lam is None:
+        model, sharp = AttentionSeq2Seq(**kw), 1.3
+    elif B % 2:
+        # the reference's JointCTCAttention hands sharpening_factor=1.0 (and four more literals) to its base class
+        # whatever the caller passed (joint_ctc_attention.py:133-137, quirk Q15): reproduced, with a warning
+        with pytest.warns(UserWarning, match='sharpening_factor=1.3'):
+            model = JointCTCAttention(lambda_weight=lam, **kw)
+        sharp = 1.0
+    else:
+        model, sharp = JointCTCAttention(lambda_weight=lam, honour_ctor_args=True, **kw), 1.3
+    assert model.sharpening_factor == sharp
     sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
     ctc_list = [[int(v) for v in row if v >= 0] for row in ctc] if lam is not None else None
     ref = oatt.attention_model_forward(sd, x, labels, sl, lens + 2, L, att, clip_enc=50.0, clip_dec=50.0,
-                                       sharpening=1.3, sigmoid_smoothing=sig, ctc_labels=ctc_list, lambda_weight=lam)
+                                       sharpening=sharp, sigmoid_smoothing=sig, ctc_labels=ctc_list, lambda_weight=lam)
     if lam is None:
         loss = model.compute_loss(x, labels, sl, lens + 2, 1.0, 1.0, 1.0)[0]
     else:
@@ -782,7 +792,7 @@ def test_attention_host_logic_edge_shapes(monkeypatch, B, T, D, C, L, att, sig, 
     for g, name in model._set_optimizer('sgd', 0.1).compute_gradients(loss, model=model):
         r = ref['grads'][name]
         assert np.abs(g.numpy() - r).max() < 3e-4 * max(np.abs(r).max(), 1e-3) + 1e-7, name
-    ref_ids = oatt.attention_model_infer(sd, x, sl, L, att, C, C + 1, 6, clip_enc=50.0, clip_dec=50.0, sharpening=1.3,
+    ref_ids = oatt.attention_model_infer(sd, x, sl, L, att, C, C + 1, 6, clip_enc=50.0, clip_dec=50.0, sharpening=sharp,
                                          sigmoid_smoothing=sig)
     assert np.array_equal(np.asarray(model.infer(x, sl)), ref_ids)
 

@@ -356,6 +356,11 @@ def test_beam_search_decoder_matches_tensorflow_known_answer():
     assert best[0] == tfk.BEAM_DECODED[0] and abs(nll1[0] - nll[0][0]) < 1e-12
     # merge_repeated=True (the reference's call) collapses repeats of an output beam; these two have none
     assert [odec.merge_repeated(p) for p in paths[0]] == tfk.BEAM_DECODED and odec.merge_repeated([3, 3, 1, 1, 3]) == [3, 1, 3]
+    # ... and a path WITH repeats: the worked example of TensorFlow's own documentation of the op (A B B * B * B)
+    lp = np.log(tfk.merge_doc_probs())[None]
+    for width in (2, 4, 8):
+        best, _ = odec.beam_search_decode(lp, [lp.shape[1]], tfk.MERGE_DOC_BLANK, beam_width=width)
+        assert best[0] == tfk.MERGE_DOC_UNMERGED and odec.merge_repeated(best[0]) == tfk.MERGE_DOC_MERGED
 
 
 def test_adagrad_matches_tensorflow_known_answer():
@@ -424,6 +429,29 @@ def test_sgd_momentum_nesterov_rmsprop_adam_match_tensorflow_known_answers():
         # ... which for a constant gradient moves every entry by lr * g / (|g| + eps / sqrt(1 - beta2^t)) per step
         want = A(tfk.ADAM_VAR[i]) - sum(0.001 * g / (np.abs(g) + 1e-8 / np.sqrt(1 - 0.999 ** t)) for t in (1, 2, 3))
         assert np.abs(p - want).max() < 1e-12
+
+
+def test_adadelta_matches_tensorflow_known_answer():
+    """oracle/optim.py's Adadelta against the scalar recurrence TensorFlow's adadelta_test.py::doTestBasic carries and
+    asserts step by step (both slots and both variables, 3 gradients x 3 learning rates, 4 updates; slots start at 0,
+    epsilon inside both roots, the learning rate scales the update only)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf_known_answers as tfk
+    from oracle import optim as oopt
+    for grad in tfk.ADADELTA_GRADS:
+        for lr in tfk.ADADELTA_LRS:
+            want = tfk.adadelta_reference(grad, lr, tfk.ADADELTA_STEPS, tfk.ADADELTA_RHO, tfk.ADADELTA_EPS)
+            for var in tfk.ADADELTA_VAR:
+                p0 = np.asarray(var, dtype=np.float64)
+                p, g = p0.copy(), np.full(2, grad)
+                s0, s1 = oopt.init_slots('adadelta', p)
+                assert np.all(s0 == 0) and np.all(s1 == 0)
+                for t in range(1, tfk.ADADELTA_STEPS + 1):
+                    p, s0, s1 = oopt.step('adadelta', p, g, s0, s1, lr, t)
+                    accum, accum_update, tot = want[t - 1]
+                    assert np.abs(s0 - accum).max() < 1e-15 and np.abs(s1 - accum_update).max() < 1e-15
+                    assert np.abs(p - (p0 - tot)).max() < 1e-14
 
 
 def test_clip_by_norm_matches_tensorflow_known_answer():
