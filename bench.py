@@ -288,6 +288,27 @@ def recurrence_roofline(H, frames_dirs, T, dtype, ks, traffic=None, traffic_sour
                      '(profiles/pmc_hbm_traffic.json), null if no pass matches this workload')
 
 
+def conv_roofline(F, W, frames, ks):
+    """MFMA roofline of cfg C's dominant matrix kernel group: the three image-resident 3x3 convolutions of the forward
+    pass (conv3x3_img_kernel<64,64>, <64,128>, <128,128>; one ops.conv3x3_fwd_drop call each per step).  Algorithmic
+    flops per valid frame: 2 * pixels * 9 * Cin * Cout with F x W pixels before and ceil(F/2) x ceil(W/2) after the
+    first pool (models/encoders/core/vgg_blstm.py:113-151); duration = HIP events around the calls in the timed region."""
+    k = ks.get('conv3x3_fwd_drop')
+    if not k:
+        return None
+    p1, p2 = F * W, ((F + 1) // 2) * ((W + 1) // 2)
+    flops_frame = 2.0 * 9 * (p1 * 64 * 64 + p2 * 64 * 128 + p2 * 128 * 128)
+    calls_per_step = 3
+    steps = k['calls'] / calls_per_step
+    ach = flops_frame * frames * steps / (k['total_ms'] * 1e-3) / 1e12
+    return dict(kernel='conv3x3_img_fwd', bound='mfma', achieved=ach,
+                peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s', frac=ach / MFMA_BF16_PEAK_TF, traffic=None,
+                avg_launch_us=k['avg_us'], algorithmic_flops_per_frame=flops_frame,
+                note='2 * pixels * 9 * Cin * Cout over the valid frames of the batch / HIP-event time of the three '
+                     'ops.conv3x3_fwd_drop calls per step (dropout + ReLU + bias in the epilogue); the recurrence entry '
+                     'of this configuration is roofline_recurrence')
+
+
 def load_traffic_table():
     tpath = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
     return json.load(open(tpath)) if os.path.exists(tpath) else None
@@ -443,7 +464,9 @@ def run_cfgC(args, dev, dev_index):
         model.train(loss, 'rmsprop', 1e-3)
         return loss
     steps = args.aux_steps
-    res = time_steps(step, steps, args.aux_warmup, 1, dev_index)
+    res = time_steps(step, steps, args.aux_warmup, 1, dev_index,
+                     timed_ops=('lstm_fwd', 'lstm_bwd', 'ctc_loss', 'conv3x3_fwd_drop', 'conv3x3_bwd_data_relu',
+                                'conv3x3_bwd_weight'))
     frames = int(seq_len.sum())
     T = int(seq_len.max())
     out = dict(workload='LibriSpeech-100h char shaped: VGG (40x11x3 frame images) + 4x512 BLSTM + CTC(29), B=64, '
@@ -453,8 +476,29 @@ def run_cfgC(args, dev, dev_index):
                final_loss=res['final_loss'], cluster_handoff_flags=res['handoff_flags'], kernels=res['kernels'],
                algorithmic_flops_per_frame=399.3e6,
                mfma_frac_whole_step=399.3e6 * frames * steps / res['elapsed'] / 1e12 / MFMA_BF16_PEAK_TF,
-               roofline=recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
-               parity='model-level parity at these widths: tests/test_gpu_configs.py::test_cfgC_vgg_blstm_4x512_bf16_ragged_two_tiles')
+               roofline=conv_roofline(F, W, frames, res['kernels']) or
+               recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
+               roofline_recurrence=recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
+               parity_tests='model-level parity at these widths: tests/test_gpu_configs.py::test_cfgC_vgg_blstm_4x512_bf16_ragged_two_tiles')
+    if not args.no_parity:
+        # bounded parity leg: the first 4 utterances cut to 48 frames, dropout off, against the fp64 oracle evaluated at
+        # the device path's rounding points
+        nb, tc = 4, 48
+        t0 = time.perf_counter()
+        sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+        xc = xd[:nb, :tc].cpu().numpy()
+        slc = np.minimum(seq_len[:nb], tc).astype(np.int32)
+        labs = [l[:max(1, tc // 7)] for l in labels[:nb]]
+        ref = omodel.ctc_model_forward(sd, xc, labs, slc, L, ndir=2, cell_clip=50.0, vgg=(F, W), want_grads=False,
+                                       operand_round=olstm.bf16_round_t)
+        loss_c, _ = model.compute_loss(xc, dense_labels(labs), slc, keep_prob=1.0, is_training=False)
+        per = np.abs(model.ctc_losses.cpu().numpy()[:nb] - ref['ctc_losses']) / np.abs(ref['ctc_losses'])
+        out['parity'] = dict(loss_device=float(loss_c.item()), loss_oracle=float(ref['total_loss']),
+                             loss_rel_err_vs_oracle=abs(float(loss_c.item()) - ref['total_loss']) / abs(ref['total_loss']),
+                             per_utterance_loss_rel_err_max=float(per.max()), utterances=nb,
+                             oracle='oracle.model fp64 on bf16-rounded operands',
+                             sample='first %d utterances cut to %d frames, dropout off' % (nb, tc),
+                             seconds=time.perf_counter() - t0)
     if not args.no_cpu_baseline:
         # bounded CPU sample: the first 4 utterances cut to 48 frames through the oracle's VGG + BLSTM + CTC model
         # (fp32 autograd forward + backward; no optimizer step -- favours the CPU)
@@ -523,7 +567,29 @@ def run_attention_cfg(args, dev, dev_index, which):
                ms_per_step=res['elapsed'] / steps * 1e3, step_ms=res['step_ms'], final_loss=res['final_loss'],
                cluster_handoff_flags=res['handoff_flags'], kernels=res['kernels'],
                roofline=recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
-               parity='model-level parity at these widths: tests/test_gpu_configs.py::test_cfg%s_*' % which)
+               parity_tests='model-level parity at these widths: tests/test_gpu_configs.py::test_cfg%s_*' % which)
+    if not args.no_parity:
+        # bounded parity leg: 4 utterances cut to 64 frames / 10 labels, dropout off, against the fp64 oracle evaluated at
+        # the device path's rounding points (teacher-forced joint loss)
+        from oracle import lstm as olstm
+        nb, tc, lc = 4, 64, 10
+        t0 = time.perf_counter()
+        sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
+        xc = xd[:nb, :tc].cpu().numpy()
+        slc = np.minimum(seq_len[:nb], tc).astype(np.int32)
+        lab_c = np.full((nb, lc + 2), C + 1, dtype=np.int64)
+        lab_c[:, 0] = C
+        lab_c[:, 1:1 + lc] = labels[:nb, 1:1 + lc]
+        ctc_d = np.asarray(lab_c[:, 1:1 + lc])
+        ref = oatt.attention_model_forward(sd, xc, lab_c, slc, np.full(nb, lc + 2), L, att, clip_enc=50.0, clip_dec=50.0,
+                                           ctc_labels=[[int(v) for v in r] for r in ctc_d], lambda_weight=0.5,
+                                           operand_round=olstm.bf16_round_t)
+        loss_c, *_ = model.compute_loss(xc, lab_c, ctc_d, slc, np.full(nb, lc + 2), 1.0, 1.0, 1.0, is_training=False)
+        out['parity'] = dict(loss_device=float(loss_c.item()), loss_oracle=float(ref['total_loss']),
+                             loss_rel_err_vs_oracle=abs(float(loss_c.item()) - ref['total_loss']) / abs(ref['total_loss']),
+                             utterances=nb, oracle='oracle.attention fp64 at the device path\'s rounding points',
+                             sample='first %d utterances cut to %d frames / %d labels, dropout off' % (nb, tc, lc),
+                             seconds=time.perf_counter() - t0)
     # greedy attention inference (attention_seq2seq.py:462-509) through the native loop: encoder + up to
     # max_decode_length decoder steps with the output head, argmax and embedding feedback on the device, one read-back
     try:
@@ -663,7 +729,8 @@ def _compact_roofline(r, full=True):
     if not r:
         return None
     if not full:
-        return dict(kernel=r.get('kernel'), frac=r.get('frac'), bound=r.get('bound'))
+        return dict(kernel=r.get('kernel'), frac=r.get('frac'), bound=r.get('bound'), achieved=r.get('achieved'),
+                    unit=r.get('unit'))
     out = {k: r.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
     src = r.get('traffic_source') or ''
     out['traffic_file'] = src.split(':')[0] if src else None          # a path, no prose

@@ -312,9 +312,14 @@ int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
                  const float* d_c_final, const float* d_h_final,
                  void* dgates, float* dpeep_dbias, float* dpeep_workspace, asr_stream s);
 
-/* The bf16 H=256 recurrence runs as a cluster of 4 workgroups per direction that hand their
- * slices of h / dh to each other inside the launch (bounded spins).  This synchronises the device
- * and reports a hand-off timeout (never expected; ASR_ERR_HIP) -- call at a sync point. */
+/* The recurrences run as clusters of H/32 (or H/64) workgroups per (direction, 16-utterance tile) that hand their
+ * slices of h / dh to each other inside the launch (bounded spins).  This synchronises the device and reports the
+ * sticky error word (ASR_ERR_HIP when non-zero) -- call at a sync point.  Bits: 1 = a forward hand-off timed out,
+ * 2 = a backward hand-off timed out (never expected), 4 = a bf16 forward recurrence published a NON-FINITE hidden state
+ * (the model diverged: its 4-byte self-tagged exchange words would otherwise hand the peers a finite value).
+ * Saved activations (gates, cs) of frames past an utterance's length are UNSPECIFIED (rows past their length park
+ * their accesses): only asr_lstm_bwd consumes them and it never reads those positions; hout and dgates ARE
+ * zero there. */
 int asr_check_async_errors(asr_handle* h, unsigned* flags_out);
 /* Non-blocking form for training loops: enqueues ONE 4-byte device->host copy of the sticky error word on `s` into
  * host_flags (pinned host memory owned by the caller; valid once work on `s` up to here has completed) -- the Python
@@ -464,8 +469,9 @@ int asr_lstm_cell_bwd(asr_handle* h, const float* dh_use, const float* dc_next, 
                       float* dh_prev_carry, float* dpeep_rows, asr_stream s);
 /* The same with the forward's cell clip: a state the forward clamped (tf.clip_by_value inside LSTMCell,
  * models/recurrent/layers/lstm.py:152-157) passes no gradient to the gates or to c_prev; c_raw holds the clamped value,
- * |c_raw| >= cell_clip marks it.  cell_clip <= 0: identical to asr_lstm_cell_bwd.  (asr_att_decoder_bwd applies the
- * decoder's cell_clip the same way.) */
+ * |c_raw| >= cell_clip marks it.  cell_clip <= 0: identical to asr_lstm_cell_bwd.  (asr_att_decoder_bwd does NOT do
+ * this: the attention decoder's cell is tf.contrib.rnn.LSTMBlockCell, attention_seq2seq.py:354-363, whose gradient op has
+ * no clip attribute -- the clamp is transparent to the gradient there, as in the encoders' fused cells.) */
 int asr_lstm_cell_bwd_ex(asr_handle* h, const float* dh_use, const float* dc_next, const float* dh_next,
                          const float* gates, const float* c_raw, const float* c_prev, const float* peep,
                          const float* live, int B, int U, float cell_clip, float* dpre, float* dc_prev,

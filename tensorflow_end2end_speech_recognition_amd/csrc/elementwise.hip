@@ -7,6 +7,7 @@
 
 // 2 (round 4): asr_create_ex's minimum scratch is 96 MiB (was 32), asr_ctc_beam_workspace_bytes asks for W more doubles per
 // utterance, new entry points asr_att_decoder_infer / asr_lstm_cell_bwd_ex; nothing was removed or re-typed.
+// 3 (round 4): asr_lstm_cell_gemm_prep / _fwd and their _h forms (decoder cell product + cell in one launch).
 extern "C" int asr_abi_version(void) { return 3; }
 
 extern "C" int asr_create(asr_handle** out, int device) { return asr_create_ex(out, device, (size_t)192 << 20); }

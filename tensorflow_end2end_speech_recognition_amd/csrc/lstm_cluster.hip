@@ -314,6 +314,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
   unsigned long long ph[4] = {0, 0, 0, 0};
   unsigned long long ph4 = 0;
   unsigned nspin = 0;
+  unsigned nonfin = 0;                                     // XW: OR of every published pair (one v_or per step)
 #define C8_T() (DBG ? (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime()) : 0ull)
 #define C8_FPIN(k) do { if constexpr (!DBG && ((FPIN >> (k)) & 1)) __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     const unsigned etag = xw_tag(s);
     if constexpr (XW) {
       unsigned* pw = uoff(xw + (size_t)(P * G + g) * SLICE, pofs);
+      nonfin |= pk;                                        // bit 14 / 30 of a FINITE |h| <= 1 is clear (see the tail)
       const unsigned tv = (pk & ~XW_MASK) | etag;
       if (fast) __hip_atomic_store(pw, tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store, stays in the L2
       else __hip_atomic_store(pw, tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -552,6 +554,10 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     o[7] = ph4;
   }
   if (timed_out) atomicOr(err, 1u);
+  // XW forces bits 14 / 30 of a published word (the step tag), so a NaN / Inf h (exponent all ones) would reach the
+  // peers as a finite value while its owner keeps the NaN: report it instead of laundering it.  h =
+  // o * tanh(c) is in [-1, 1], whose bf16 forms all have bit 14 clear; any set bit 14 is a non-finite (or > 1) value.
+  if (XW && (nonfin & XW_MASK)) atomicOr(err, 4u);
   // zero-fill the common padded tail [tmax, T): os already points at frame tmax
   for (int t = tmax; t < T_; ++t)
 #pragma unroll
@@ -2293,6 +2299,7 @@ extern "C" int asr_check_async_errors(asr_handle* h, unsigned* flags_out) {
       hipMemcpy(&v, base, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
     ASR_FAIL(h, ASR_ERR_HIP, "asr_check_async_errors: device error");
   if (flags_out) *flags_out = v;
-  if (v) ASR_FAIL(h, ASR_ERR_HIP, "LSTM cluster hand-off timed out (flags 0x%x)", v);
+  if (v & 3u) ASR_FAIL(h, ASR_ERR_HIP, "LSTM cluster hand-off timed out (flags 0x%x)", v);
+  if (v) ASR_FAIL(h, ASR_ERR_HIP, "LSTM recurrence produced a non-finite hidden state (flags 0x%x)", v);
   return ASR_OK;
 }

@@ -107,7 +107,7 @@ class JointCTCAttention(AttentionSeq2Seq):
     def _ctc_head_finish(self, pending, B):
         logits, losses, grad, ninf = pending[:4]
         # ignore_longer_outputs_than_inputs=False: checked through the deferred counter watch while training (the host
-        # must not wait for the forward pass every step; the error surfaces <= 3 steps late), at once otherwise
+        # must not wait for the forward pass every step; the error surfaces at most ops.DeferredCheck.DEPTH (4) arm() calls late, in steady state <= 3 steps), at once otherwise
         ops.defer_zero_check(ninf, _not_enough_time, blocking=grad is None)
         self.ctc_losses = losses[:B]
         return logits[:, :B], losses[:B].mean(), dict(dlogits=grad)

@@ -248,7 +248,7 @@ class CTC(ModelBase):
         self.ctc_losses = ctc_losses[:B]
         self.num_infeasible = ninf
         # tf.nn.ctc_loss(ignore_longer_outputs_than_inputs=False) fails the step (ctc.py:289); here the counter is watched
-        # asynchronously while training (raises <= 3 steps late, the rows themselves contribute 0 loss / 0 gradient) and
+        # asynchronously while training (raises at most ops.DeferredCheck.DEPTH = 4 steps late, the rows themselves contribute 0 loss / 0 gradient) and
         # checked at once in evaluation
         ops.defer_zero_check(ninf, _not_enough_time, blocking=not is_training)
         self._tape = dict(dlogits=grad, B=B) if is_training else None

@@ -789,7 +789,7 @@ def check_async_errors(device=0):
         if w is not None:
             w.events = [None] * w.DEPTH
     h.check(rc, 'asr_check_async_errors')
-    _deferred.flush()                                # the device is idle: every armed counter has landed
+    _deferred_for(device).flush()                    # the device is idle: every counter armed on it has landed
     return flags.value
 
 
@@ -823,8 +823,10 @@ class ErrorWatch(object):
                 h = _lib.handle(self.dev)
                 h.lib.asr_clear_async_errors(h.h, _s())
                 self.events = [None] * self.DEPTH
-                raise _lib.AsrError('LSTM cluster hand-off timed out (flags 0x%x): the recurrent state of a recent '
-                                    'step is garbage -- restore the last checkpoint' % flags)
+                what = 'LSTM cluster hand-off timed out' if flags & 3 else \
+                    'LSTM recurrence produced a non-finite hidden state (the model diverged)'
+                raise _lib.AsrError('%s (flags 0x%x): the recurrent state of a recent '
+                                    'step is garbage -- restore the last checkpoint' % (what, flags))
         h = _lib.handle(self.dev)
         h.check(h.lib.asr_peek_async_errors(h.h, C.c_void_p(self.host.data_ptr() + 4 * slot), _s()),
                 'asr_peek_async_errors')
@@ -840,14 +842,18 @@ _watches = {}
 class DeferredCheck(object):
     """A device-side counter that must be zero (tf.nn.ctc_loss's "Not enough time for target transition sequence"
     InvalidArgumentError, ctc.py:289 with ignore_longer_outputs_than_inputs=False), checked WITHOUT stalling the training
-    step: arm() copies the counter to pinned memory behind the step's kernels; the copy armed DEPTH arm()s earlier is
-    inspected then (long complete in steady state).  The error therefore surfaces a few steps late (the issue loop is
-    throttled to ErrorWatch.DEPTH steps ahead of the device by the optimizer step's poll; arm() itself only blocks as a
-    backstop, at DEPTH pending copies) instead of costing one device drain per step.  flush() is the blocking form for
-    sync points (evaluation, checkpoints, tests)."""
-    DEPTH = 8
+    step: arm() copies the counter to pinned memory behind the step's kernels -- on the counter's OWN device and that
+    device's current stream (one DeferredCheck per device) -- and every earlier copy that has landed is inspected then.
+    Lateness: the reference raises inside the sess.run of the offending step; here the error surfaces at a later arm() --
+    in steady state within ErrorWatch.DEPTH (3) optimizer steps, because that is how far the issue loop may run ahead of
+    the device, and NEVER more than DEPTH (4) arm() calls late (one arm() per CTC head and step): at DEPTH pending copies
+    arm() blocks on the oldest.  The optimizer has applied the updates of the steps in between.  flush() is the blocking
+    form; it runs at every sync point: evaluation (is_training=False), Saver.save / check_async_errors (checkpoints), the
+    end of the recipes' epochs, and at interpreter exit (a pending error is printed, it cannot be raised any more)."""
+    DEPTH = 4
 
-    def __init__(self):
+    def __init__(self, device=None):
+        self.device = device
         self.slots = []          # (pinned host tensor, event, exception factory)
         self.waited_s = 0.0
         self.ring = None
@@ -865,7 +871,7 @@ class DeferredCheck(object):
             self.slots = []
             # a timed-out cluster hand-off leaves NaN activations, which the CTC kernels count as infeasible rows: report the
             # root cause (AsrError from the sticky error word) rather than its symptom
-            check_async_errors(torch.cuda.current_device())
+            check_async_errors(self.device if self.device is not None else torch.cuda.current_device())
             raise make_exc(n)
         return True
 
@@ -876,10 +882,10 @@ class DeferredCheck(object):
         host = self.ring[self.n % (4 * self.DEPTH):][:1]
         host.copy_(counter.view(-1)[:1].to(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record(_cur_stream())
+        ev.record(_cur_stream(counter.device))       # the stream the copy was enqueued on: the counter's device
         self.slots.append((host, ev, make_exc))
         while self.slots:
-            block = len(self.slots) > self.DEPTH
+            block = len(self.slots) >= self.DEPTH
             if not self._inspect(*self.slots[0], block=block):
                 break
             self.slots.pop(0)
@@ -890,7 +896,16 @@ class DeferredCheck(object):
             self._inspect(*slot, block=True)
 
 
-_deferred = DeferredCheck()
+_deferred_by_dev = {}
+
+
+def _deferred_for(device):
+    d = device.index if isinstance(device, torch.device) else device
+    d = torch.cuda.current_device() if d is None else int(d)
+    w = _deferred_by_dev.get(d)
+    if w is None:
+        w = _deferred_by_dev[d] = DeferredCheck(d)
+    return w
 
 
 def defer_zero_check(counter, make_exc, blocking=False):
@@ -899,19 +914,36 @@ def defer_zero_check(counter, make_exc, blocking=False):
         if int(counter.view(-1)[0]):
             raise make_exc(int(counter.view(-1)[0]))
         return
-    _deferred.arm(counter, make_exc)
-    if blocking:
-        _deferred.flush()
+    w = _deferred_for(counter.device)
+    with torch.cuda.device(counter.device):
+        w.arm(counter, make_exc)
+        if blocking:
+            w.flush()
 
 
 def flush_deferred_checks():
-    _deferred.flush()
+    """Blocking inspection of every armed counter on every device (end of an epoch / of training)."""
+    for w in list(_deferred_by_dev.values()):
+        w.flush()
+
+
+def _flush_deferred_at_exit():
+    try:
+        flush_deferred_checks()
+    except Exception as e:       # too late to raise into the training loop: say so
+        import sys
+        sys.stderr.write('tensorflow_end2end_speech_recognition_amd: an error of one of the LAST training steps was still '
+                         'pending at exit: %r\n' % (e,))
+
+
+import atexit as _atexit      # noqa: E402
+_atexit.register(_flush_deferred_at_exit)
 
 
 def watch_waited_seconds(device=0):
     """Cumulative host time the device's ErrorWatch spent blocked behind the GPU (0 if none exists yet)."""
     w = _watches.get(device.index or 0 if isinstance(device, torch.device) else int(device))
-    return (w.waited_s if w is not None else 0.0) + _deferred.waited_s
+    return (w.waited_s if w is not None else 0.0) + sum(d.waited_s for d in _deferred_by_dev.values())
 
 
 def watch_async_errors(device):

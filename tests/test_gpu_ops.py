@@ -199,7 +199,7 @@ def _lstm_case(rng, T, B, D, H, ndir, lens, init=0.3):
     return x, ps
 
 
-def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfinal=None):
+def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfinal=None, saved_fill=None):
     ops = _ops()
     from tensorflow_end2end_speech_recognition_amd._lib import ASR_BF16, ASR_F32
     dt = ASR_BF16 if dtype == 'bf16' else ASR_F32
@@ -224,6 +224,10 @@ def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfin
     res = dict(hout=hout.float().cpu().numpy(), cs=cs.cpu().numpy(), cf=cf.cpu().numpy(), hf=hf.cpu().numpy())
     # saved activations, device layout [T,B,ndir,H,4] -> [ndir][T,B,4,H]
     res['gates'] = gates.float().view(T, B, ndir, H, 4).permute(2, 0, 1, 4, 3).contiguous().cpu().numpy()
+    if saved_fill is not None:     # overwrite the saved activations of frames past each utterance's length
+        pad = torch.arange(T, device=cuda).view(T, 1, 1) >= sl.view(1, B, 1)
+        gates.masked_fill_(pad, saved_fill)
+        cs.masked_fill_(pad, saved_fill)
     if dout is not None:
         dcf = dhf = None
         if dfinal is not None:
@@ -442,6 +446,54 @@ def test_lstm_cluster_f32_long_sequences(cuda, T, B, ndir, clip, H, base):
             assert np.abs(got['dgates'][lens[b]:, b]).max() == 0
 
 
+@pytest.mark.parametrize('H,dtype,B', [(256, 'bf16', 16), (512, 'bf16', 32), (128, 'f32', 16), (64, 'f32', 16)])
+def test_bptt_never_reads_saved_activations_of_padded_frames(cuda, H, dtype, B):
+    """The forward kernels park the accesses of rows past their length, so the saved gates / cell states of padded frames
+    are whatever the allocator handed out.  The only consumer is asr_lstm_bwd: with those positions
+    set to NaN or to zero it must produce the same BITS (dgates, zero at padded frames, and the peephole / bias sums)."""
+    ops = _ops()
+    rng = np.random.RandomState(H + B)
+    T, D, ndir = 21, 24, 2
+    lens = rng.randint(1, T + 1, size=B)
+    lens[0], lens[1] = T, 1
+    if B > 16:
+        lens[-1] = 0
+    x, ps = _lstm_case(rng, T, B, D, H, ndir, lens, init=0.1)
+    dout = rng.randn(T, B, ndir * H)
+    a = _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, 50.0, dout, saved_fill=float('nan'))
+    b = _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, 50.0, dout, saved_fill=0.0)
+    assert np.isfinite(a['dgates']).all() and np.isfinite(a['dpeep']).all()
+    assert np.array_equal(a['dgates'], b['dgates']) and np.array_equal(a['dpeep'], b['dpeep'])
+    valid = np.arange(T)[:, None] < lens[None, :]
+    assert np.abs(a['dgates'][~valid]).max() == 0
+    assert ops.check_async_errors(0) == 0
+
+
+def test_nonfinite_hidden_state_is_reported_not_laundered(cuda):
+    """The forward all-gather's 4-byte self-tagged words force two bits of every published pair (the step tag), so a NaN
+    h would reach the peer CUs as a finite value while its owner keeps the NaN: the kernel ORs the published
+    pairs and raises bit 2 of the sticky error word at the end of the launch; the blocking check reports it as a
+    non-finite state, not as a hand-off timeout, and clears it."""
+    from tensorflow_end2end_speech_recognition_amd import _lib
+    ops = _ops()
+    rng = np.random.RandomState(5)
+    T, B, D, H, ndir = 10, 16, 24, 256, 2
+    lens = rng.randint(4, T + 1, size=B)
+    lens[3] = T
+    x, ps = _lstm_case(rng, T, B, D, H, ndir, lens, init=0.1)
+    assert ops.check_async_errors(0) == 0
+    _run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', 0.0)
+    assert ops.check_async_errors(0) == 0                    # finite inputs: nothing raised
+    xn = x.copy()
+    xn[2, 3, 5] = np.nan                                     # one NaN feature of a valid frame
+    _run_hip_layer(cuda, xn, ps, lens, H, ndir, 'bf16', 0.0)
+    with pytest.raises(_lib.AsrError, match='non-finite'):
+        ops.check_async_errors(0)
+    assert ops.check_async_errors(0) == 0                    # reported once, then cleared
+    _run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', 0.0)
+    assert ops.check_async_errors(0) == 0
+
+
 def test_cluster_handoff_timeout_is_reported(cuda):
     """A hand-off that times out must not go unnoticed: with the test-only flag (one member of every cluster leaves
     early, spin limit 2000 polls) the sticky error word is raised, the blocking check raises at the next sync point,
@@ -588,7 +640,10 @@ def test_lstm_cluster_bf16_gradient_parity_headline_shapes(cuda, lstm_flags, H, 
         chk(tag + 'h_final max abs', np.abs(got['hf'][d] - f['h_final']).max(), 5e-3)
         # ---- backward kernel in isolation: explicit BPTT fed with the DEVICE's saved activations
         dg_dev = got['dgates'][:, :, d * 4 * H:(d + 1) * 4 * H].reshape(T, B, 4, H)
-        bwd = olstm.layer_backward_np(dout[:, :, sl], got['gates'][d], got['cs'][:, :, sl], lens, pn, rev, True,
+        # (saved activations past an utterance's length are unspecified memory: mask them before the oracle multiplies)
+        g_dev = np.where(valid[:, :, None, None], got['gates'][d], 0.0)
+        c_dev = np.where(valid[:, :, None], got['cs'][:, :, sl], 0.0)
+        bwd = olstm.layer_backward_np(dout[:, :, sl], g_dev, c_dev, lens, pn, rev, True,
                                       dfinal[0][d], dfinal[1][d], round_fn=R)
         mx, mean = _err_stats(dg_dev, bwd['dgates'])
         chk(tag + 'dgates|device activations max rel', mx, 1.5e-2)
