@@ -290,23 +290,27 @@ def recurrence_roofline(H, frames_dirs, T, dtype, ks, traffic=None, traffic_sour
 
 def conv_roofline(F, W, frames, ks):
     """MFMA roofline of cfg C's dominant matrix kernel group: the three image-resident 3x3 convolutions of the forward
-    pass (conv3x3_img_kernel<64,64>, <64,128>, <128,128>; one ops.conv3x3_fwd_drop call each per step).  Algorithmic
+    pass (conv3x3_img_kernel<64,64>, <64,128>, <128,128>; ops.conv3x3_fwd / conv3x3_fwd_drop).  Algorithmic
     flops per valid frame: 2 * pixels * 9 * Cin * Cout with F x W pixels before and ceil(F/2) x ceil(W/2) after the
     first pool (models/encoders/core/vgg_blstm.py:113-151); duration = HIP events around the calls in the timed region."""
-    k = ks.get('conv3x3_fwd_drop')
-    if not k:
+    ka, kb = ks.get('conv3x3_fwd'), ks.get('conv3x3_fwd_drop')
+    if not ka or not kb:
         return None
     p1, p2 = F * W, ((F + 1) // 2) * ((W + 1) // 2)
     flops_frame = 2.0 * 9 * (p1 * 64 * 64 + p2 * 64 * 128 + p2 * 128 * 128)
-    calls_per_step = 3
-    steps = k['calls'] / calls_per_step
-    ach = flops_frame * frames * steps / (k['total_ms'] * 1e-3) / 1e12
+    # per step: VGG1/conv2 and VGG2/conv2 through ops.conv3x3_fwd, VGG2/conv1 through ops.conv3x3_fwd_drop (dropout in
+    # its epilogue; models/encoders/core/vgg_blstm.py _forward_frontend)
+    steps = kb['calls']
+    assert ka['calls'] == 2 * steps, (ka['calls'], kb['calls'])
+    total_ms = ka['total_ms'] + kb['total_ms']
+    ach = flops_frame * frames * steps / (total_ms * 1e-3) / 1e12
+    k = dict(avg_us=total_ms * 1e3 / (3 * steps))
     return dict(kernel='conv3x3_img_fwd', bound='mfma', achieved=ach,
                 peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s', frac=ach / MFMA_BF16_PEAK_TF, traffic=None,
                 avg_launch_us=k['avg_us'], algorithmic_flops_per_frame=flops_frame,
                 note='2 * pixels * 9 * Cin * Cout over the valid frames of the batch / HIP-event time of the three '
-                     'ops.conv3x3_fwd_drop calls per step (dropout + ReLU + bias in the epilogue); the recurrence entry '
-                     'of this configuration is roofline_recurrence')
+                     'image-resident forward convolutions of a step (ReLU + bias, one of them + dropout, in the '
+                     'epilogue); the recurrence entry of this configuration is roofline_recurrence')
 
 
 def load_traffic_table():
@@ -465,8 +469,8 @@ def run_cfgC(args, dev, dev_index):
         return loss
     steps = args.aux_steps
     res = time_steps(step, steps, args.aux_warmup, 1, dev_index,
-                     timed_ops=('lstm_fwd', 'lstm_bwd', 'ctc_loss', 'conv3x3_fwd_drop', 'conv3x3_bwd_data_relu',
-                                'conv3x3_bwd_weight'))
+                     timed_ops=('lstm_fwd', 'lstm_bwd', 'ctc_loss', 'conv3x3_fwd', 'conv3x3_fwd_drop',
+                                'conv3x3_bwd_data_relu', 'conv3x3_bwd_weight'))
     frames = int(seq_len.sum())
     T = int(seq_len.max())
     out = dict(workload='LibriSpeech-100h char shaped: VGG (40x11x3 frame images) + 4x512 BLSTM + CTC(29), B=64, '
