@@ -1354,6 +1354,314 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_f32_kernel(
   }
 }
 
+// ---------------------------------------------------------------- fp32 operands on the bf16 matrix pipe (round 5)
+// The fp32 cluster kernels above are bound by v_mfma_f32_16x16x4_f32: 32 cycles per SIMD for K = 4, i.e. 256 cycles per
+// K = 32 against 17 for one v_mfma_f32_16x16x32_bf16 (MI355X_MICROARCH.md) -- 2 048 of the ~4 000 cycles of a step at
+// H = 128.  An fp32 value IS the sum of three bf16 values (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8
+// significand bits; both subtractions are exact in fp32), so x.w = sum of the nine term products, of which the six with
+// weight >= 2^-16 are kept: lo.hi + hi.lo + mid.mid + mid.hi + hi.mid + hi.hi -- every product of two bf16 values is exact
+// in the MFMA's fp32 accumulator; the dropped terms (mid.lo, lo.mid, lo.lo) are below 2^-24 of the result.  6 bf16 MFMAs x 17
+// cycles = 102 per K = 32: the matrix phase of a step drops from 2 048 to ~820 cycles.  W_h is split once per launch into
+// registers; h (forward) / the gate gradients (BPTT) are split by the lane that writes them into three bf16 LDS images.
+// Same exchange, same saved activations, same lane <-> (row, unit) mapping as the fp32 kernels above; results differ from
+// theirs by accumulation rounding only (fp32 parity bounds unchanged, tests/test_gpu_ops.py).  ASR_LSTM_F32_SPLIT=0 keeps
+// the exact-fp32 MFMA kernels.
+__device__ __forceinline__ void split3(float x, unsigned short (&t)[3]) {
+  const __bf16 h = (__bf16)x;
+  const float r1 = x - (float)h;
+  const __bf16 m = (__bf16)r1;
+  const float r2 = r1 - (float)m;
+  t[0] = __builtin_bit_cast(unsigned short, h);
+  t[1] = __builtin_bit_cast(unsigned short, m);
+  t[2] = __builtin_bit_cast(unsigned short, (__bf16)r2);
+}
+// one K = 32 chunk of a 16 x 16 tile: a[term], b[term] bf16 fragments; smallest terms first
+__device__ __forceinline__ f32x4_t mma_s3(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x4_t c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+// B fragment of chunk c (k = 32 c + 8 rg + j, j < 8) of one 16-column tile out of an fp32 fragment packing
+// [frag16][64 lanes][4] (lane (n, rg') holds k = 16 frag16 + 4 rg' + e): two 16-byte loads, split into three bf16 terms
+__device__ __forceinline__ void load_split_frag(const float* tile_base, int c, int rg, int n, bf16x8_t (&out)[3]) {
+  const float* p = tile_base + (((size_t)(2 * c + (rg >> 1)) * 64 + ((rg & 1) * 2) * 16 + n) * 4);
+  const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(p);
+  const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(p + 16 * 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    unsigned short t[3];
+    split3(j < 4 ? v0[j] : v1[j - 4], t);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k][j] = (short)t[k];
+  }
+}
+
+template <int H, bool EARLY, int HSU = 32>
+__global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster_f32s_kernel(
+    int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const float* __restrict__ whp,
+    const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
+    float cell_clip, f32x4_t* __restrict__ gates, float* __restrict__ hout, float* __restrict__ cs,
+    float* __restrict__ c_final, float* __restrict__ h_final, u64* __restrict__ xch,
+    unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+  zero_next_area(znext, zwords);
+  constexpr int G = H / HSU;
+  constexpr int CTW = HSU * 8;
+  static_assert(HSU == 32 && (H & (H - 1)) == 0, "four waves per CU, power-of-two width");
+  constexpr int KS = H / 32;                               // chunks of k = 32 (six bf16 MFMAs each per tile)
+  constexpr int KS16 = H / 16;                             // fragments of the fp32 weight packing
+  constexpr int LDH = H + 8;                               // bf16 elements per image row: 17 / 33 x 16 B
+  constexpr int PLB = 16 * LDH * 2;                        // bytes of one term image
+  constexpr int SLICE = 16 * HSU;                           // granules one CU publishes per step
+  constexpr int KO = HSU / 32;                              // chunks of one CU's own slice
+  auto krotf = [](int x) -> int { return x & (KS - 1); };
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* hs = reinterpret_cast<unsigned short*>(smem);   // [2 parity][3 terms][16][LDH]
+
+  const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
+  if (!cid.valid) return;
+  const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rg = lane >> 4;
+  const bool lo = col < 8;
+  const bool rev = (d == 1);
+  const float* wp = whp + (size_t)d * H * 4 * H;
+  const int ul = wave * 8 + (col & 7);                     // unit inside this CU's slice
+  const unsigned jw = g * HSU + ul;                         // global unit of this lane
+  const int rbase = rg * 4 + (lo ? 0 : 2);                 // first of this lane's two batch rows
+
+  int len[2];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) len[r] = seq_len[b0 + rbase + r];
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  float c[2] = {0.f, 0.f}, hr[2] = {0.f, 0.f};
+  const float wci = peep ? peep[(d * 3 + 0) * H + jw] : 0.f;
+  const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
+  const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
+
+  for (int i = threadIdx.x; i < 2 * 3 * 16 * LDH; i += CTW) hs[i] = 0;
+  // B fragments out of the standard fp32 forward packing (lstm.hip prep: tile = (unit/16)*4 + gate, fragment of k = 16, lane
+  // (n, rg) holds k = 16 frag + 4 rg + e), re-cut into k = 32 chunks and split: this lane's column of tile p is
+  // (gate p*2 + (col>>3), unit jw)
+  bf16x8_t wreg[2][KS][3];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int tile = (jw >> 4) * 4 + p * 2 + (col >> 3);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kk = EARLY ? krotf(ks + g * KO) : ks;            // EARLY: register chunk ks holds k-chunk kk
+      load_split_frag(wp + (size_t)tile * KS16 * 256, kk, rg, (int)(jw & 15), wreg[p][ks]);
+    }
+  }
+
+  u64* xhdr = xch + (size_t)cid.c * (XHDR + 2 * G * SLICE);
+  u64* xbase = xhdr + XHDR;                                // [2 parity][G][8 waves][16 rows][8 units]
+  bool timed_out = false;
+  const bool colocated = same_xcd<G>(xhdr, g, timed_out);
+  const bool fast = colocated && !(kflags & 1);
+  unsigned spin_limit = (kflags & 2) ? 2000u : SPIN_LIMIT;
+  if ((kflags & 2) && g == G - 1) return;                  // TEST ONLY: a member goes missing
+  __syncthreads();
+
+  const unsigned stride = (unsigned)B_ * ndir * H;
+  const unsigned dstep = rev ? 0u - stride : stride;
+  unsigned oa[2], os[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    os[r] = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+    oa[r] = os[r] + (rev ? (unsigned)max(len[r] - 1, 0) * stride : 0u);
+  }
+  // granule i of a wave's 128: row i >> 3, unit i & 7.  A lane publishes its two (row, unit) pairs and polls
+  // granules lane and 64 + lane of wave `wave` of every peer.
+  const unsigned pofs = (unsigned)(wave * 128 + rbase * 8 + (col & 7));
+  const unsigned lofs = (unsigned)(wave * 128 + lane);
+  unsigned ldst[G - 1][2];                                 // byte offsets inside one h buffer
+  auto slice = [&](int P, int gg) -> u64* { return xbase + ((size_t)P * G + gg) * SLICE; };
+#pragma unroll
+  for (int k = 0; k < G - 1; ++k) {
+    const int gsrc = k + (k >= g ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 8 + (lane >> 3);
+      ldst[k][j] = ((unsigned)(row * LDH + gsrc * HSU + wave * 8 + (lane & 7)) * 2u) ^ lds_swz(row);
+    }
+  }
+  unsigned lown[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) lown[r] = ((unsigned)((rbase + r) * LDH + g * HSU + ul) * 2u) ^ lds_swz(rbase + r);
+  const unsigned lrd = ((unsigned)(col * LDH + rg * 8) * 2u) ^ lds_swz(col);
+  // The all-gather carries the TERMS: granule = {hi | mid << 16, lo | tag16 << 16} (one 8-byte store / load per (row, unit)
+  // pair as in the fp32 kernels, tag = (step + 1) & 0xffff: T_ < 65536, checked by the launcher) -- a value is split once, by
+  // the lane that produced it, and a consumer stages what it polled with three 2-byte LDS stores and no arithmetic.
+  auto put3w = [&](char* img, unsigned off, unsigned w0, unsigned w1) {
+    *reinterpret_cast<unsigned short*>(img + off) = (unsigned short)w0;
+    *reinterpret_cast<unsigned short*>(img + PLB + off) = (unsigned short)(w0 >> 16);
+    *reinterpret_cast<unsigned short*>(img + 2 * PLB + off) = (unsigned short)w1;
+  };
+
+  f32x4_t xq[2][2];                                        // x projection rows, requested two steps ahead
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    xq[0][r] = xg[(0 < len[r]) ? oa[r] : os[r]];
+    xq[1][r] = (tmax > 1) ? xg[(1 < len[r]) ? oa[r] + dstep : os[r] + stride] : xq[0][r];
+  }
+  f32x4_t accn0 = {0.f, 0.f, 0.f, 0.f}, accn1 = {0.f, 0.f, 0.f, 0.f};   // EARLY: own-slice part of the next step
+
+  auto step = [&](int s, auto PAR) {
+    constexpr int P = decltype(PAR)::value;
+    const char* hcur = smem + P * 3 * PLB;
+    char* hnxt = smem + (1 - P) * 3 * PLB;
+    const f32x4_t x0 = xq[P][0], x1 = xq[P][1];
+    if (s + 2 < tmax) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        xq[P][r] = xg[(s + 2 < len[r]) ? oa[r] + 2u * dstep : os[r] + 2u * stride];
+    }
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EARLY) { acc0 = accn0; acc1 = accn1; }    // own-slice fragments: done at the end of the last step
+    {
+      constexpr int K0 = EARLY ? KO : 0;
+      bf16x8_t afr[KS][3];
+#pragma unroll
+      for (int ks = K0; ks < KS; ++ks)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          afr[ks][k] = *reinterpret_cast<const bf16x8_t*>(hcur + k * PLB + lrd + (EARLY ? krotf(ks + g * KO) : ks) * 64);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = K0; ks < KS; ++ks) {
+        acc0 = mma_s3(afr[ks], wreg[0][ks], acc0);
+        acc1 = mma_s3(afr[ks], wreg[1][ks], acc1);
+      }
+    }
+    float pi[2], pq[2], pf[2], po[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      pi[r] = dpp_ror8_into<0xC>(acc0[r], acc0[2 + r]);
+      pq[r] = dpp_ror8_into<0x3>(acc0[2 + r], acc0[r]);
+      pf[r] = dpp_ror8_into<0xC>(acc1[r], acc1[2 + r]);
+      po[r] = dpp_ror8_into<0x3>(acc1[2 + r], acc1[r]);
+    }
+    const unsigned epoch = (unsigned)s + 1u;
+    bool act[2];
+    float ig[2], gg[2], fg[2], og[2], cn[2], hn[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) act[r] = s < len[r];
+    const f32x4_t xr[2] = {x0, x1};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) ig[r] = cfsig(pi[r] + xr[r][0] + wci * c[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) gg[r] = cftanh(pq[r] + xr[r][1]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) fg[r] = cfsig(pf[r] + xr[r][2] + forget_bias + wcf * c[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      cn[r] = gg[r] * ig[r] + c[r] * fg[r];
+      if (cell_clip > 0.f) cn[r] = fminf(fmaxf(cn[r], -cell_clip), cell_clip);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) og[r] = cfsig(po[r] + xr[r][3] + wco * cn[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) hn[r] = cftanh(cn[r]) * og[r];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      c[r] = act[r] ? cn[r] : c[r];
+      hr[r] = act[r] ? hn[r] : hr[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned short t3[3];
+      split3(hr[r], t3);
+      const unsigned w0 = (unsigned)t3[0] | ((unsigned)t3[1] << 16);
+      gpublish(uoff(slice(P, g), pofs + 8u * r), ((unsigned)t3[2]) | (epoch << 16), w0, fast);
+      put3w(hnxt, lown[r], w0, (unsigned)t3[2]);
+    }
+    unsigned offs[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      offs[r] = act[r] ? oa[r] : os[r];
+      oa[r] += dstep;
+      os[r] += stride;
+    }
+    if constexpr (EARLY) {
+      if (s + 1 < tmax) {                                  // block-uniform
+        __syncthreads();                                   // the CU's own slice of h(s) is complete in hnxt
+        bf16x8_t ao[KO][3];
+#pragma unroll
+        for (int k = 0; k < KO; ++k)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            ao[k][q] = *reinterpret_cast<const bf16x8_t*>(hnxt + q * PLB + lrd + krotf(k + g * KO) * 64);
+        accn0 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        accn1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KO; ++k) {
+          accn0 = mma_s3(ao[k], wreg[0][k], accn0);
+          accn1 = mma_s3(ao[k], wreg[1][k], accn1);
+        }
+      }
+    }
+    {
+      u64 v[G - 1][2];
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) v[k][j] = gload(uoff(slice(P, k + (k >= g ? 1 : 0)), lofs + 64u * j));
+      unsigned spins = 0;
+#pragma unroll 1
+      for (;;) {                                           // wave-uniform loop: no exec masking
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ok = ok && ((unsigned)(v[k][j] >> 48) == (epoch & 0xffffu));
+        if (__all(ok)) break;
+        if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) v[k][j] = gload(uoff(slice(P, k + (k >= g ? 1 : 0)), lofs + 64u * j));
+      }
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) put3w(hnxt, ldst[k][j], (unsigned)v[k][j], (unsigned)(v[k][j] >> 32));
+    }
+    // saved activations behind the poll loop (loads and stores share the wave's in-order counter); rows past their
+    // length write frame s of the padding (hout: zeros; gates / cs: never read there)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      hout[offs[r]] = act[r] ? hr[r] : 0.f;
+      gates[offs[r]] = (f32x4_t){ig[r], gg[r], fg[r], og[r]};
+      cs[offs[r]] = cn[r];
+    }
+    __syncthreads();
+  };
+  int s = 0;
+  for (; s + 1 < tmax; s += 2) {
+    step(s, std::integral_constant<int, 0>{});
+    step(s + 1, std::integral_constant<int, 1>{});
+  }
+  if (s < tmax) step(s, std::integral_constant<int, 0>{});
+
+  if (timed_out) atomicOr(err, 1u);
+  for (int t = tmax; t < T_; ++t)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { hout[os[r]] = 0.f; os[r] += stride; }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const size_t o = ((size_t)d * B_ + b0 + rbase + r) * H + jw;
+    if (c_final) c_final[o] = c[r];
+    if (h_final) h_final[o] = hr[r];
+  }
+}
+
 // BPTT, fp32 operands: the H = 512 arrangement of the bf16 kernel (each tile computed ONCE: the hh = 0 waves take the
 // four own-unit tiles and hand rows 2,3 to their hh = 1 partners through LDS, the hh = 1 waves take the four tiles of
 // the peer's units and publish them) -- 64 K = 4 MFMAs per wave and step instead of the 128 + 64 of the redundant form.
@@ -1903,6 +2211,316 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32_kernel(
   }
 }
 
+// BPTT of the fp32-operand clusters on the bf16 matrix pipe (three-term split, see lstm_fwd_cluster_f32s_kernel)
+template <int H, int HSU>
+__global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32s_kernel(
+    int T_, int B_, int ndir, const float* __restrict__ dhout, const f32x4_t* __restrict__ gates,
+    const float* __restrict__ cs, const float* __restrict__ whpb, const float* __restrict__ peep,
+    const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
+    const float* __restrict__ d_h_final, f32x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
+    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+  zero_next_area(znext, zwords);
+  constexpr int G = H / HSU;
+  static_assert(G % 2 == 0 && G >= 2 && G <= XHDR, "even number of CUs per cluster");
+  constexpr int TPC = HSU / 16, NWAVES = 2 * TPC;
+  constexpr int KC = 4 * HSU / 32;           // chunks (k = 32) of this CU's slice of k'
+  constexpr int KC16 = 4 * HSU / 16;         // ... in fragments of the fp32 weight packing
+  constexpr int KSF = 4 * H / 16;            // fragments of the full packing
+  constexpr int LDG = 4 * HSU + 8;           // bf16 elements per row of a dG term image (17 x 16 B)
+  constexpr int NF = G / 2;                  // tile slots per wave
+  constexpr size_t CL_U64 = XHDR + (size_t)2 * G * G * TPC * 64 * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PLB = 16 * LDG * 2;                        // bytes of one term image
+  constexpr int DGB = 3 * PLB;                             // bytes per dG image (three bf16 terms)
+
+  const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
+  if (!cid.valid) return;
+  const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, rg = lane >> 4;
+  const int hh = wave / TPC, wt = wave % TPC;
+  const bool rev = (d == 1);
+  const float* wp = whpb + (size_t)d * H * 4 * H;
+  const int ul = wt * 16 + col;
+  const unsigned jw = g * HSU + ul;
+  const int rbase = rg * 4 + hh * 2;
+
+  int len[2];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) len[r] = seq_len[b0 + rbase + r];
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  const float wci = peep ? peep[(d * 3 + 0) * H + jw] : 0.f;
+  const float wcf = peep ? peep[(d * 3 + 1) * H + jw] : 0.f;
+  const float wco = peep ? peep[(d * 3 + 2) * H + jw] : 0.f;
+
+  const unsigned stride = (unsigned)B_ * ndir * H;
+  const unsigned dstep = rev ? stride : 0u - stride;
+  unsigned oa[2], os[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned base = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+    os[r] = base + (unsigned)(tmax - 1) * stride;
+    oa[r] = base + (unsigned)(rev ? len[r] - tmax : tmax - 1) * stride;
+  }
+  {
+    const f32x4_t gzero = {0.f, 0.f, 0.f, 0.f};
+    for (int t = tmax; t < T_; ++t)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) dgates[os[r] + (unsigned)(t - tmax + 1) * stride] = gzero;
+  }
+
+  float dhr[2], dcr[2], cc[2];
+  float sums[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const size_t o = ((size_t)d * B_ + b0 + rbase + r) * H + jw;
+    dhr[r] = d_h_final ? d_h_final[o] : 0.f;
+    dcr[r] = d_c_final ? d_c_final[o] : 0.f;
+    cc[r] = (tmax > 0 && tmax - 1 < len[r]) ? cs[oa[r]] : 0.f;
+  }
+  // tile slots: i < NF - 1: foreign tile f = wave + NWAVES i;  slot NF - 1: hh = 0 the own tile, hh = 1 foreign tile
+  // f = NWAVES (NF - 1) + wt.  Foreign index f -> destination CU (f / TPC, skipping g), its tile f % TPC.
+  auto ftile = [&](int f) { const int q = f / TPC; return ((q + (q >= g ? 1 : 0)) * TPC) | (f % TPC); };
+  int nt_f[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+    nt_f[i] = (i < NF - 1) ? ftile(wave + NWAVES * i) : (hh == 1 ? ftile(NWAVES * (NF - 1) + wt) : g * TPC + wt);
+  bf16x8_t wf[NF][KC][3];                  // W_h^T fragments, re-cut into k = 32 chunks and split into three bf16 terms
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+      load_split_frag(wp + ((size_t)nt_f[i] * KSF + g * KC16) * 256, kc, rg, col, wf[i][kc]);
+  float* ownx = reinterpret_cast<float*>(smem + 2 * DGB);  // [2 parity][TPC tiles][64 lanes] x (row 2, row 3)
+
+  u64* xhdr = xch + (size_t)cid.c * CL_U64;
+  bool timed_out = false;
+  const bool fast = same_xcd<G>(xhdr, g, timed_out) && !(kflags & 1);
+  unsigned spin_limit = (kflags & 2) ? 2000u : SPIN_LIMIT;
+  if ((kflags & 2) && g == G - 1) return;                  // TEST ONLY: a member goes missing
+  f32x4_t* xs = reinterpret_cast<f32x4_t*>(xhdr + XHDR);   // [2][G dst][G src][TPC][64] x 16 B
+  auto uslot = [&](int par, int dst, int src_, int tile) -> f32x4_t* {
+    return xs + ((((size_t)par * G + dst) * G + src_) * TPC + tile) * 64;
+  };
+  const unsigned voff16 = (unsigned)lane * 16u;
+  const unsigned pofs = (unsigned)lane * 2u + hh;          // u64 index of this lane's two rows in a slot
+  const unsigned lwr[2] = {((unsigned)(rbase * LDG + ul * 4) * 2u) ^ lds_swz(rbase),
+                           ((unsigned)((rbase + 1) * LDG + ul * 4) * 2u) ^ lds_swz(rbase + 1)};
+  const unsigned lrd = ((unsigned)(col * LDG + rg * 8) * 2u) ^ lds_swz(col);
+
+  f32x4_t pg[2];
+  float pcp[2], pdh[2];
+  if (tmax > 0) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int s_ = tmax - 1;
+      const bool act = s_ < len[r];
+      const bool ldp = (s_ > 0) && (s_ - 1 < len[r]);
+      pg[r] = gates[act ? oa[r] : os[r]];
+      pcp[r] = cs[ldp ? oa[r] + dstep : os[r]];
+      pdh[r] = dhout[act ? oa[r] : os[r]];
+    }
+  }
+  __syncthreads();
+
+  auto step = [&](int s, auto PAR) {
+    // step boundary pinned (see the bf16 BPTT kernel): neutral at H = 128 / 256, 7.6 -> 4.4 ms per launch at H = 512, B = 32
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int P = decltype(PAR)::value;                // parity of THIS iteration's publish
+    const int it = tmax - 1 - s;
+    // ---- 1. polls for the partials the peers published at the previous iteration (parity 1-P)
+    u64 pv[G - 1];
+    if (it > 0) {
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+        pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
+    }
+    // ---- 2. everything that does not need dh
+    bool act[2], ldp[2];
+    float gi[2], gq[2], gf[2], go[2], cprev[2], a_o[2], b_c[2], c_g[2], c_i[2], c_f[2];
+    unsigned off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      act[r] = s < len[r];
+      ldp[r] = (s > 0) && (s - 1 < len[r]);
+      off[r] = act[r] ? oa[r] : os[r];
+      gi[r] = pg[r][0]; gq[r] = pg[r][1]; gf[r] = pg[r][2]; go[r] = pg[r][3];
+      cprev[r] = (act[r] && s > 0) ? pcp[r] : 0.f;
+    }
+    float tc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) tc[r] = cftanh(cc[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      a_o[r] = tc[r] * go[r] * (1.f - go[r]);
+      b_c[r] = go[r] * (1.f - tc[r] * tc[r]);
+      c_g[r] = gi[r] * (1.f - gq[r] * gq[r]);
+      c_i[r] = gq[r] * gi[r] * (1.f - gi[r]);
+      c_f[r] = cprev[r] * gf[r] * (1.f - gf[r]);
+    }
+    float pdh0 = pdh[0], pdh1 = pdh[1], pcp0 = pcp[0], pcp1 = pcp[1];
+    const float cur0 = cc[0], cur1 = cc[1];
+    // everything that reads the values fetched one iteration ago is pinned here, ahead of the next fetch (see the bf16 kernel)
+    asm volatile("" : "+v"(pdh0), "+v"(pdh1), "+v"(pcp0), "+v"(pcp1), "+v"(cprev[0]), "+v"(cprev[1]));
+    asm volatile("" : "+v"(c_g[0]), "+v"(c_g[1]), "+v"(c_i[0]), "+v"(c_i[1]), "+v"(c_f[0]), "+v"(c_f[1]));
+    asm volatile("" : "+v"(a_o[0]), "+v"(a_o[1]), "+v"(b_c[0]), "+v"(b_c[1]), "+v"(gf[0]), "+v"(gf[1]));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { oa[r] += dstep; os[r] -= stride; }
+    // ---- 3. finish the polls: every word must carry the previous iteration's tag
+    if (it > 0) {
+      const unsigned want = (((unsigned)(it - 1) >> 1) + 1u) & 1u;
+      const u64 wmask = 0x0000000100000001ull, wtag = want ? wmask : 0ull;
+      unsigned spins = 0;
+#pragma unroll 1
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) ok = ok && ((pv[k] & wmask) == wtag);
+        if (__all(ok)) break;
+        if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k)
+          pv[k] = gload(uoff(reinterpret_cast<const u64*>(uslot(1 - P, g, k + (k >= g ? 1 : 0), wt)), pofs));
+      }
+      float add0 = 0.f, add1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k) {                     // fixed order
+        add0 += __uint_as_float((unsigned)pv[k] & ~1u);
+        add1 += __uint_as_float((unsigned)(pv[k] >> 32) & ~1u);
+      }
+      dhr[0] += add0;
+      dhr[1] += add1;
+    }
+    // next iteration's saved activations: unconditional (the last iteration re-fetches its own rows) and pinned BEHIND
+    // the poll loop by a compiler barrier
+    {
+      asm volatile("" ::: "memory");
+      const bool more = s > 0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bool actn = s - 1 < len[r];
+        const bool ldpn = (s - 1 > 0) && (s - 2 < len[r]);
+        const unsigned offl = more ? (actn ? oa[r] : os[r]) : off[r];
+        const unsigned offn = more ? (ldpn ? oa[r] + dstep : os[r]) : off[r];
+        pg[r] = gates[offl];
+        pcp[r] = cs[offn];
+        pdh[r] = dhout[offl];
+      }
+    }
+    // ---- 4. gate gradients of the own pairs
+    const float pdhv[2] = {pdh0, pdh1}, pcpv[2] = {pcp0, pcp1}, curv[2] = {cur0, cur1};
+    float zi[2], zg[2], zf[2], zo[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float dh = pdhv[r] + dhr[r];
+      const float d_o = dh * a_o[r];
+      const float dc = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float d_g = dc * c_g[r], d_i = dc * c_i[r], d_f = dc * c_f[r];
+      dcr[r] = act[r] ? (dc * gf[r] + d_i * wci + d_f * wcf) : dcr[r];
+      dhr[r] = act[r] ? 0.f : dhr[r];
+      zi[r] = act[r] ? d_i : 0.f; zg[r] = act[r] ? d_g : 0.f;
+      zf[r] = act[r] ? d_f : 0.f; zo[r] = act[r] ? d_o : 0.f;
+      cc[r] = ldp[r] ? pcpv[r] : 0.f;
+      const f32x4_t pk = {zi[r], zg[r], zf[r], zo[r]};
+      typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+      us4_t tq[3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned short t[3];
+        split3(pk[q], t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tq[k][q] = t[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<us4_t*>(smem + P * DGB + k * PLB + lwr[r]) = tq[k];
+      dgates[off[r]] = pk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      sums[0] += zi[r] * cprev[r]; sums[1] += zf[r] * cprev[r]; sums[2] += zo[r] * curv[r];
+      sums[3] += zi[r]; sums[4] += zg[r]; sums[5] += zf[r]; sums[6] += zo[r];
+    }
+    // ---- 5. partial dh_prev of this wave's tiles from the own dG slice
+    if (s > 0) {
+      bf16x8_t afr[KC][3];
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          afr[kc][k] = *reinterpret_cast<const bf16x8_t*>(smem + P * DGB + k * PLB + lrd + kc * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4_t ac[NF];
+#pragma unroll
+      for (int i = 0; i < NF; ++i) ac[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int i = 0; i < NF; ++i) ac[i] = mma_s3(afr[kc], wf[i][kc], ac[i]);
+      const unsigned tag = (((unsigned)it >> 1) + 1u) & 1u;
+      auto tagged = [&](const f32x4_t& a) {
+        f32x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __uint_as_float((__float_as_uint(a[i]) & ~1u) | tag);
+        return o;
+      };
+      if (fast) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          if (i < NF - 1 || hh == 1) xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(ac[i]), true);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          if (i < NF - 1 || hh == 1) xstore16(uslot(P, nt_f[i] / TPC, g, nt_f[i] % TPC), voff16, tagged(ac[i]), false);
+      }
+      if (hh == 0) {                                       // own units: rows 0,1 stay, rows 2,3 -> partner wave
+        dhr[0] += ac[NF - 1][0];
+        dhr[1] += ac[NF - 1][1];
+        float* o = ownx + ((P * TPC + wt) * 64 + lane) * 2;
+        o[0] = ac[NF - 1][2];
+        o[1] = ac[NF - 1][3];
+      }
+    }
+    __syncthreads();                                       // hand-over visible before the partner's next step
+    if (s > 0 && hh == 1) {
+      const float* o = ownx + ((P * TPC + wt) * 64 + lane) * 2;
+      dhr[0] += o[0];
+      dhr[1] += o[1];
+    }
+  };
+  int s = tmax - 1;
+  for (; s >= 1; s -= 2) {
+    step(s, std::integral_constant<int, 0>{});
+    step(s - 1, std::integral_constant<int, 1>{});
+  }
+  if (s == 0) step(0, std::integral_constant<int, 0>{});
+
+  if (timed_out) atomicOr(err, 2u);
+  if (dpeep_part) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      sums[k] += __shfl_xor(sums[k], 16, 64);
+      sums[k] += __shfl_xor(sums[k], 32, 64);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);           // [7][HSU]
+    if (hh == 1 && rg == 0) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) red[k * HSU + ul] = sums[k];
+    }
+    __syncthreads();
+    if (hh == 0 && rg == 0) {
+      float* p = dpeep_part + ((size_t)cid.tile * ndir + d) * 7 * H;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) p[k * H + jw] = sums[k] + red[k * HSU + ul];
+    }
+  }
+}
+
 static unsigned long long* g_cdbg_host = nullptr;
 static void cdbg_setup() {
   static bool done = false;
@@ -1922,6 +2540,7 @@ static int g_dflags = -1;
 // bit 9 (512): H = 256 / 512 clusters of H/64 CUs x eight waves instead of H/32 CUs x four waves
 // bit 10 (1024): forward all-gather with 8-byte {step, payload} granules instead of 4-byte self-tagged words (A/B, tests)
 // bit 11 (2048): inverts the default choice of the BPTT reduce-scatter slot layout (consumer-major source pairs, XP) (A/B, tests)
+// bit 12 (4096): fp32 operands on the exact-fp32 MFMA kernels instead of the three-term bf16 split (A/B, tests)
 // bit 6 (64): TEST ONLY -- the last member of every cluster leaves right after the placement handshake and the
 //             spin limit drops to 2000 polls, so every hand-off times out (tests/test_gpu_ops.py checks that the
 //             error word is raised and surfaces as an exception)
@@ -2108,6 +2727,13 @@ static bool cluster_f32_enabled() {
   return on && cluster_enabled();
 }
 
+// fp32 operands as three bf16 terms on the bf16 matrix pipe (H = 128 / 256, four waves per CU); ASR_LSTM_F32_SPLIT=0 or
+// ASR_LSTM_DFLAGS bit 12 (run time, tests) keeps the exact-fp32 MFMA kernels
+static bool cluster_f32_split_enabled() {
+  static const bool on = [] { const char* e = getenv("ASR_LSTM_F32_SPLIT"); return !(e && e[0] == '0'); }();
+  return on && !(dbg_flags() & 4096);
+}
+
 template <int HH, int HSU>
 static bool cluster_fwd_f32_launch(asr_handle* h, int T, int B, int ndir, const float* xproj, const void* whp,
                                    const float* peep, const int32_t* seq_len, float fb, float clip, void* gates,
@@ -2124,6 +2750,16 @@ static bool cluster_fwd_f32_launch(asr_handle* h, int T, int B, int ndir, const 
   // EARLY own-slice products by default, except H = 512 where their extra live accumulators push the 256 weight
   // registers into scratch (measured 5.93 vs 5.36 ms per 778-step launch); ASR_LSTM_DFLAGS bit 5 inverts (A/B)
   const bool early = ((dbg_flags() & 32) == 0) != (HH >= 512);
+  if constexpr (HSU == 32 && (HH == 128 || HH == 256)) {
+    if (cluster_f32_split_enabled() && T < 65536) {   // round 5: the same recurrence on the bf16 matrix pipe (three-term split; 16-bit step tags)
+      auto ks = early ? lstm_fwd_cluster_f32s_kernel<HH, true, HSU> : lstm_fwd_cluster_f32s_kernel<HH, false, HSU>;
+      const size_t lds_s = (size_t)2 * 3 * 16 * (HH + 8) * 2;
+      hipLaunchKernelGGL(ks, dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds_s, st, T, B, ndir, (const f32x4_t*)xproj,
+                         (const float*)whp, peep, seq_len, fb, clip, (f32x4_t*)gates, (float*)hout, cs, cf, hf, xa.area,
+                         (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
+      return true;
+    }
+  }
   auto k = early ? lstm_fwd_cluster8_f32_kernel<HH, true, HSU> : lstm_fwd_cluster8_f32_kernel<HH, false, HSU>;
   const size_t lds = (size_t)2 * 16 * (HH + 4) * 4;
   if (lds > ((size_t)64 << 10))
@@ -2171,6 +2807,15 @@ static bool cluster_bwd_f32_launch(asr_handle* h, int T, int B, int ndir, const 
     return false;
   char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
   const XchAreas xa = xch_take(h, base, need, st);
+  if constexpr (HSU == 32 && (HH == 128 || HH == 256)) {
+    if (cluster_f32_split_enabled()) {
+      const size_t lds_s = (size_t)2 * 3 * 16 * (4 * HSU + 8) * 2 + (size_t)2 * TPC * 64 * 8;   // two x three term images + hand-over
+      hipLaunchKernelGGL((lstm_bwd_cluster_f32s_kernel<HH, HSU>), dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds_s, st, T,
+                         B, ndir, dhout, (const f32x4_t*)gates, cs, (const float*)whpb, peep, seq_len, dcf, dhf,
+                         (f32x4_t*)dgates, dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
+      return true;
+    }
+  }
   const size_t lds = (size_t)2 * 16 * (4 * HSU + 4) * 4 + (size_t)2 * TPC * 64 * 8;   // two dG images + the hand-over buffer
   hipLaunchKernelGGL((lstm_bwd_cluster_f32_kernel<HH, HSU>), dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir,
                      dhout, (const f32x4_t*)gates, cs, (const float*)whpb, peep, seq_len, dcf, dhf, (f32x4_t*)dgates,

@@ -393,12 +393,18 @@ def test_lstm_cluster_exchange_paths(cuda, H):
                                                   (778, 16, 2, 50.0, 128, 0), (301, 16, 2, 0.0, 128, 512),
                                                   (150, 32, 2, 50.0, 256, 0), (97, 16, 2, 0.0, 320, 0),
                                                   (120, 32, 1, 2.0, 320, 0), (131, 16, 2, 50.0, 512, 0),
-                                                  (64, 32, 1, 0.0, 512, 32)])
+                                                  (64, 32, 1, 0.0, 512, 32),
+                                                  # flag bit 12: the exact-fp32 MFMA kernels instead of the three-term split
+                                                  (301, 16, 2, 0.0, 128, 4096), (778, 16, 2, 50.0, 128, 4096),
+                                                  (150, 32, 2, 50.0, 256, 4096), (150, 32, 1, 2.0, 128, 4096 | 32)])
 def test_lstm_cluster_f32_long_sequences(cuda, T, B, ndir, clip, H, base):
     """fp32 operands run on the cluster kernels at every registry width: H = 128 (BASELINE configs[0]) on four CUs x four
     waves (and, flag bit 9, two CUs x eight waves), H = 256 / 320 / 512 on H/32 CUs x four waves.  Forward values, final
     states and every gradient the BPTT kernel produces against the fp64 oracle over hundreds of hand-offs, ragged
-    lengths, with and without the cell clip; both exchange flavours bit-identical; no hand-off may time out."""
+    lengths, with and without the cell clip; both exchange flavours bit-identical; no hand-off may time out.
+    Round 5: at H = 128 / 256 (four waves) the default kernels multiply on the bf16 matrix pipe with every fp32 operand
+    split into three bf16 terms (lstm_*_cluster_f32s_kernel); flag bit 12 selects the exact-fp32 MFMA kernels -- both
+    are held to the SAME bounds here."""
     ops = _ops()
     rng = np.random.RandomState(T + B)
     D = 24
