@@ -1505,11 +1505,16 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster_f32s_kernel(
     *reinterpret_cast<unsigned short*>(img + 2 * PLB + off) = (unsigned short)w1;
   };
 
+  // rows past their length: saved activations never read, x-projection rows not used -> ONE parked position per row (its
+  // frame tmax - 1) that stays in the L2 instead of streaming the padded part of the batch through HBM (see the bf16 kernel)
+  unsigned opark[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) opark[r] = os[r] + (unsigned)max(tmax - 1, 0) * stride;
   f32x4_t xq[2][2];                                        // x projection rows, requested two steps ahead
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    xq[0][r] = xg[(0 < len[r]) ? oa[r] : os[r]];
-    xq[1][r] = (tmax > 1) ? xg[(1 < len[r]) ? oa[r] + dstep : os[r] + stride] : xq[0][r];
+    xq[0][r] = xg[(0 < len[r]) ? oa[r] : opark[r]];
+    xq[1][r] = (tmax > 1) ? xg[(1 < len[r]) ? oa[r] + dstep : opark[r]] : xq[0][r];
   }
   f32x4_t accn0 = {0.f, 0.f, 0.f, 0.f}, accn1 = {0.f, 0.f, 0.f, 0.f};   // EARLY: own-slice part of the next step
 
@@ -1521,7 +1526,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster_f32s_kernel(
     if (s + 2 < tmax) {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
-        xq[P][r] = xg[(s + 2 < len[r]) ? oa[r] + 2u * dstep : os[r] + 2u * stride];
+        xq[P][r] = xg[(s + 2 < len[r]) ? oa[r] + 2u * dstep : opark[r]];
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (EARLY) { acc0 = accn0; acc1 = accn1; }    // own-slice fragments: done at the end of the last step
@@ -1582,10 +1587,11 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster_f32s_kernel(
       gpublish(uoff(slice(P, g), pofs + 8u * r), ((unsigned)t3[2]) | (epoch << 16), w0, fast);
       put3w(hnxt, lown[r], w0, (unsigned)t3[2]);
     }
-    unsigned offs[2];
+    unsigned offs[2], offgs[2];                            // hout position / saved-activation position
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       offs[r] = act[r] ? oa[r] : os[r];
+      offgs[r] = act[r] ? oa[r] : opark[r];
       oa[r] += dstep;
       os[r] += stride;
     }
@@ -1638,8 +1644,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster_f32s_kernel(
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       hout[offs[r]] = act[r] ? hr[r] : 0.f;
-      gates[offs[r]] = (f32x4_t){ig[r], gg[r], fg[r], og[r]};
-      cs[offs[r]] = cn[r];
+      gates[offgs[r]] = (f32x4_t){ig[r], gg[r], fg[r], og[r]};
+      cs[offgs[r]] = cn[r];
     }
     __syncthreads();
   };
@@ -2266,6 +2272,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32s_kernel(
     os[r] = base + (unsigned)(tmax - 1) * stride;
     oa[r] = base + (unsigned)(rev ? len[r] - tmax : tmax - 1) * stride;
   }
+  // inactive rows read nothing that is used: their fetches go to one parked position per row (frame tmax - 1)
+  const unsigned opark[2] = {os[0], os[1]};
   {
     const f32x4_t gzero = {0.f, 0.f, 0.f, 0.f};
     for (int t = tmax; t < T_; ++t)
@@ -2320,9 +2328,9 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32s_kernel(
       const int s_ = tmax - 1;
       const bool act = s_ < len[r];
       const bool ldp = (s_ > 0) && (s_ - 1 < len[r]);
-      pg[r] = gates[act ? oa[r] : os[r]];
-      pcp[r] = cs[ldp ? oa[r] + dstep : os[r]];
-      pdh[r] = dhout[act ? oa[r] : os[r]];
+      pg[r] = gates[act ? oa[r] : opark[r]];
+      pcp[r] = cs[ldp ? oa[r] + dstep : opark[r]];
+      pdh[r] = dhout[act ? oa[r] : opark[r]];
     }
   }
   __syncthreads();
@@ -2404,8 +2412,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32s_kernel(
       for (int r = 0; r < 2; ++r) {
         const bool actn = s - 1 < len[r];
         const bool ldpn = (s - 1 > 0) && (s - 2 < len[r]);
-        const unsigned offl = more ? (actn ? oa[r] : os[r]) : off[r];
-        const unsigned offn = more ? (ldpn ? oa[r] + dstep : os[r]) : off[r];
+        const unsigned offl = more ? (actn ? oa[r] : opark[r]) : off[r];
+        const unsigned offn = more ? (ldpn ? oa[r] + dstep : opark[r]) : off[r];
         pg[r] = gates[offl];
         pcp[r] = cs[offn];
         pdh[r] = dhout[offl];
