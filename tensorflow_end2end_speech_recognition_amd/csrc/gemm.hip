@@ -1163,10 +1163,19 @@ __global__ __launch_bounds__(256) void conv3x3_nt_bf16_kernel(int Mpix, int H, i
 //   CIN = 128: NTW = 2 -> waves split the output channels (and the pixel tiles when COUT = 64)
 // One workgroup walks images blockIdx.x, + gridDim.x, ...  Same operands / epilogues / results as the kernel above
 // (out[p, co] = act(sum_{tap, ci} x[p + s_tap, ci] Wt[co][tap * CIN + ci] + bias[co])).
-template <typename TO, int CIN, int COUT>
+// phase timers of the image loop (ASR_CONV_DBG=1; scripts/probe_conv_phases.py): per workgroup and wave, cycles summed over
+// its images: [0] tile loop (of which [1] multiplies incl. their LDS reads, [2] epilogues), [3] wait for + LDS store of the
+// next image, [4] the image's closing barrier, [5] images, [6] prefetch issue
+__device__ unsigned long long* g_convdbg = nullptr;
+// MAXV = staged 16-byte vectors per thread: ceil(H W CIN / 8 / 256) rounded up to an instantiated value (4 / 8 / 14 / 16) --
+// the staging registers are what the CIN = 64 forms are short of (288 weight registers)
+// ACT (compile time since round 5: a run-time `act` put branches into every epilogue piece, and a piece has to be straight-line
+// code to be scheduled between the multiplies): 0 none, 1 ReLU, 2 data gradient gated by the sign of gate.act with a uniform
+// scale (use_drop 0: 1, use_drop 2: 1 / keep), 4 the same with the Philox mask (use_drop 1), 3 forward ReLU + dropout.
+template <typename TO, int CIN, int COUT, int MAXV = 16, int ACT = 1, bool DBG = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, int W, const bf16_t* __restrict__ X,
                                                              const bf16_t* __restrict__ Wt, TO* __restrict__ Out,
-                                                             const float* __restrict__ bias, int act, ConvGate gate,
+                                                             const float* __restrict__ bias, ConvGate gate,
                                                              int nbuf) {
   constexpr int KS = 9 * CIN / 32;                         // k-steps of 32
   constexpr int KPT = CIN / 32;                            // k-steps per tap
@@ -1174,6 +1183,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
   constexpr int NGROUPS = (COUT / 16) / NTW;               // wave groups over the output channels
   constexpr int MPARTS = 4 / NGROUPS;                      // waves sharing the pixel tiles of one channel group
   constexpr int PST = CIN * 2 + 16;                        // bytes per pixel in LDS (16-byte pad: conflict-free b128 reads)
+  // the deferred epilogue keeps a second set of accumulators + gate operands alive: CIN = 64 with 14+ staged vectors (the
+  // 40 x 11 images) has no registers for it (measured with it: spills in the tile loop, 2.87 -> 4.13 ms) and keeps the
+  // epilogue behind its own tile; every other form defers (20 x 6 x 64 -> 128: 1.59 -> 1.23 ms, 128 -> 128: 2.44 -> 1.90 ms)
+  constexpr bool DEFER = true;
   static_assert(NGROUPS >= 1 && NGROUPS <= 4 && 4 % NGROUPS == 0, "wave split");
   extern __shared__ __attribute__((aligned(16))) char csm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1196,8 +1209,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
   for (int i = tid * 16; i < nbuf * img_bytes; i += 256 * 16) *reinterpret_cast<bf16x8_t*>(csm + i) = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
   __syncthreads();
 
-  constexpr int MAXV = 16;                                 // staged vectors per thread (nvec <= 4096)
-  bf16x8_t stage[MAXV];
+  bf16x8_t stage[MAXV];                                    // staged vectors per thread (nvec <= 256 MAXV)
   auto gfetch = [&](int img) {
     const bf16x8_t* src = reinterpret_cast<const bf16x8_t*>(X + (size_t)img * HW * CIN);
 #pragma unroll
@@ -1206,13 +1218,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
       if (v < nvec) stage[i] = src[v];
     }
   };
+  const float invW = 1.0f / (float)W;
   auto lstore = [&](char* buf) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int v = tid + i * 256;
       if (v < nvec) {
         const int p = v / (CIN / 8), cv = v % (CIN / 8);
-        const int y = p / W, x = p - y * W;
+        // (round 5: the quotient by the run-time W through the reciprocal -- exact for p < 2^22 -- instead of an integer
+        // division per staged vector: the 14 divisions were most of the 1.3 k cycles of this phase per image)
+        const int y = (int)(((float)p + 0.5f) * invW), x = p - y * W;
         *reinterpret_cast<bf16x8_t*>(buf + ((y + 1) * WP + x + 1) * PST + cv * 16) = stage[i];
       }
     }
@@ -1232,21 +1247,89 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
   // cycles (MfmaUtil 18 % at 64 -> 64, profiles/r03_pmc_util.md).  The bias now lives in registers for the launch, the gate
   // operand of a tile is requested at its top, and the first fragment group of the NEXT tile is read from LDS under the
   // last multiplies of this one.  Same arithmetic in the same order.
-  f32x4_t bvr[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j)
-    bvr[j] = bias ? *reinterpret_cast<const f32x4_t*>(bias + (ng * NTW + j) * 16 + fq * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  constexpr int TG = CIN == 64 ? 3 : 1, NG = 9 / TG, GF = TG * KPT;
+  // (round 5: the bias sits in LDS behind the images -- 16 registers the deferred epilogue needs; its read is one more
+  // ds_read_b128 per piece beside the multiplies)
+  float* bsm = reinterpret_cast<float*>(csm + nbuf * img_bytes);
+  if (tid < COUT) bsm[tid] = bias ? bias[tid] : 0.f;
+  __syncthreads();
+  // taps per fragment group: CIN = 64 with the big staging set reads ONE tap (two fragments, 8 multiplies) ahead instead of
+  // three -- 32 fragment registers that pay for the pending tile's accumulators
+  constexpr int TG = (CIN == 64 && MAXV <= 8) ? 3 : 1, NG = 9 / TG, GF = TG * KPT;
   auto tile_ptr = [&](const char* base, int mt) -> const char* {
     const int p = mt * 16 + fr;
     const int pc = p < HW ? p : 0;
-    const int y = pc / W, x = pc - y * W;
+    const int y = (int)(((float)pc + 0.5f) * invW), x = pc - y * W;
     return base + ((y + 1) * WP + x + 1) * PST + fq * 16;
   };
+  // Round 5 (phase timers, scripts/probe_conv_phases.py: of 24.6 k cycles per image and wave at 64 -> 64 the epilogues took
+  // 5.5 k with nothing beside them -- one wave per SIMD, and the compiler does not pipeline across loop iterations): the
+  // epilogue of a pixel tile is DEFERRED by one tile and issued in pieces (one 16-channel output tile each) between the
+  // fragment groups of the NEXT tile's multiplies, across image boundaries too; the last tile of a workgroup is flushed
+  // behind the image loop.  The pending tile's stores are raw buffer stores on a per-image descriptor: a lane whose pixel
+  // lies past the image (the ragged last tile) or the very first "pending tile" of the workgroup (a zero-length
+  // descriptor) is dropped by the bounds check -- no exec masking, no branch in the multiply stream.  Same arithmetic,
+  // same values.
+  const unsigned img_out_bytes = (unsigned)HW * COUT * (unsigned)sizeof(TO);
+  f32x4_t accp[NTW];                                       // the pending tile: accumulators, gate operand, where it goes
+  cg_us4_t gprep[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) { accp[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; gprep[j] = cg_us4_t{0, 0, 0, 0}; }
+  __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(Out, 0, 0, 0x00020000);   // nothing pending: zero length
+  unsigned offp = 0;                                       // byte offset of the pending pixel's channel 0 in its image
+  size_t mp_elem = 0;                                      // element index of that pixel's channel 0 (gate / dropout counters)
+  const float gscale = (ACT == 2 && gate.use_drop == 2) ? 1.f / gate.keep : 1.f;
+  auto epilogue_piece = [&](int j) {
+    const int nb = (ng * NTW + j) * 16 + fq * 4;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = accp[j][r];
+    if constexpr (ACT == 0 || ACT == 1 || ACT == 3) {       // the forward products carry a bias (zeros in LDS without one)
+      const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bsm + nb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += bv[r];
+    }
+    if constexpr (ACT == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    // conv_gate_apply, branch-free (same expressions in the same order)
+    if constexpr (ACT == 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = bf16_to_f32(gprep[j][r]) > 0.f ? v[r] * gscale : 0.f;
+    }
+    if constexpr (ACT == 4) {
+      float mk[4];
+      asr_dropout_words(gate.offset + (mp_elem + nb) / 4, gate.seed, gate.keep, 1.f / gate.keep, mk);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = bf16_to_f32(gprep[j][r]) > 0.f ? v[r] * mk[r] : 0.f;
+    }
+    if constexpr (ACT == 3) {
+      float mk[4];
+      asr_dropout_words(gate.offset + (mp_elem + nb) / 4, gate.seed, gate.keep, 1.f / gate.keep, mk);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = bf16_to_f32(f32_to_bf16(fmaxf(v[r], 0.f))) * mk[r];
+    }
+    typedef __attribute__((ext_vector_type(2))) unsigned cv_u2_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned cv_u4_t;
+    if constexpr (sizeof(TO) == 4) {
+      const cv_u4_t w = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+      __builtin_amdgcn_raw_buffer_store_b128(w, rsp, offp + (unsigned)nb * 4u, 0, 0);
+    } else {
+      const cv_u2_t w = {(unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
+                         (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16)};
+      __builtin_amdgcn_raw_buffer_store_b64(w, rsp, offp + (unsigned)nb * 2u, 0, 0);
+    }
+  };
+  unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
+#define CV_T() (DBG ? (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime()) : 0ull)
   for (int it = 0; img < Nimg; img += gridDim.x, ++it) {
     char* cur = csm + (nbuf == 2 ? (it & 1) * img_bytes : 0);
     const int nxt = img + gridDim.x;
+    const unsigned long long tq0 = CV_T();
     if (nxt < Nimg) gfetch(nxt);                           // lands under this image's products
+    const unsigned long long tq1 = CV_T();
+    const __amdgpu_buffer_rsrc_t rsc =
+        __builtin_amdgcn_make_buffer_rsrc(Out + (size_t)img * HW * COUT, 0, img_out_bytes, 0x00020000);
     // (CIN = 64 keeps 288 weight registers + 64 staging registers: the 24 of the look-ahead group would spill)
     constexpr bool NEXTPF = CIN == 128;
     bf16x8_t anx[NEXTPF ? GF : 1];                         // group 0 of the tile about to start
@@ -1255,6 +1338,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
 #pragma unroll
       for (int q = 0; q < GF; ++q) anx[q] = *reinterpret_cast<const bf16x8_t*>(ap0 + tapoff[q / KPT] + (q % KPT) * 64);
     }
+    // Two tiles per loop trip where the registers allow it (the pending / current accumulator sets then swap roles without
+    // copies and the scheduler sees both tiles: 20 x 6 x 64 -> 128 ReLU 1.48 -> 1.21 ms, 128 -> 128 2.30 -> 2.04 ms); the gated
+    // data gradient (ACT 2: two sets of gate operands) and the 40 x 11 x 64 form spill 13 - 31 registers that way and stay at one
+    constexpr int UNR = (ACT >= 2 || MAXV > 8) ? 1 : 2;        // (the Philox epilogues measured slower unrolled: 1.96 -> 2.03 ms)
+#pragma unroll UNR
     for (int mt = mp; mt < ntm; mt += MPARTS) {
       const int p = mt * 16 + fr;
       const char* ap = tile_ptr(cur, mt);
@@ -1264,10 +1352,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
       cg_us4_t gpre[NTW];
 #pragma unroll
       for (int j = 0; j < NTW; ++j) gpre[j] = cg_us4_t{0, 0, 0, 0};
-      if (act == 2) {
+      if constexpr (ACT == 2 || ACT == 4) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) gpre[j] = conv_gate_load(gate, m * COUT + (ng * NTW + j) * 16 + fq * 4);
       }
+      const unsigned long long tt0 = CV_T();
       f32x4_t acc[NTW];
 #pragma unroll
       for (int j = 0; j < NTW; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -1296,42 +1385,53 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
 #pragma unroll
           for (int j = 0; j < NTW; ++j)
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[j][g * GF + q], a[g & 1][q], acc[j], 0, 0, 0);
-      }
-      // epilogue: lane holds channels n0 + fq*4 .. +3 of pixel p (transposed product)
-      if (p < HW) {
+        // the PENDING tile's epilogue, one output tile per piece, beside this group's multiplies
+        if constexpr (DEFER) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-          const int nb = (ng * NTW + j) * 16 + fq * 4;
-          TO* cp = Out + m * COUT + nb;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[j][r];
-          if (bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bvr[j][r];
-          }
-          if (act == 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-          }
-          if (act >= 2) conv_gate_apply<true>(act, gate, m * COUT + nb, v, gpre[j]);
-          if constexpr (sizeof(TO) == 4) {
-            *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
-          } else {
-            typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
-            *reinterpret_cast<us4_t*>(cp) = (us4_t){f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
-          }
+          for (int j = 0; j < NTW; ++j)
+            if ((j * NG) / NTW == g) epilogue_piece(j);
         }
+      }
+      // this tile becomes the pending one
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) { accp[j] = acc[j]; gprep[j] = gpre[j]; }
+      rsp = rsc;
+      offp = (unsigned)p * COUT * (unsigned)sizeof(TO);    // p >= HW: past the descriptor's length, the stores are dropped
+      mp_elem = m * COUT;
+      if constexpr (!DEFER) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) epilogue_piece(j);
+      }
+      if (DBG) {
+        const unsigned long long tt2 = CV_T();
+        ph[1] += tt2 - tt0;
       }
     }
     // (Measured, round 4: barriers that wait for the LDS counter only -- s_waitcnt lgkmcnt(0) + s_barrier instead of
     // __syncthreads(), whose release fence also waits for the epilogue's global stores -- change nothing: 2.80 vs 2.76 ms.)
+    const unsigned long long tq2 = CV_T();
     if (nxt < Nimg) {
       if (nbuf == 1) __syncthreads();                      // every wave is done with the only buffer
       lstore(csm + (nbuf == 2 ? ((it + 1) & 1) * img_bytes : 0));
     }
+    const unsigned long long tq3 = CV_T();
     __syncthreads();
+    if (DBG) {
+      const unsigned long long tq4 = CV_T();
+      ph[0] += tq2 - tq1; ph[3] += tq3 - tq2; ph[4] += tq4 - tq3; ph[5] += 1; ph[6] += tq1 - tq0;
+    }
   }
+  // flush: the last tile of this workgroup
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) epilogue_piece(j);
+  }
+  if (DBG && g_convdbg && lane == 0 && blockIdx.x < 64) {
+    unsigned long long* o = g_convdbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) o[k] = ph[k];
+  }
+#undef CV_T
 }
 
 // weight images for the two implicit GEMMs from the HWIO fp32 master [9][Cin][Cout]:
@@ -1857,6 +1957,11 @@ extern "C" int asr_conv3x3_prep_weights(asr_handle* h, const float* w_hwio, int 
   return ASR_OK;
 }
 
+static unsigned long long* g_convdbg_host = nullptr;
+extern "C" int asr_debug_conv_cycles(unsigned long long* out, int n) {
+  if (!g_convdbg_host || n > 64 * 4 * 8) return -1;
+  return hipMemcpy(out, g_convdbg_host, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
 template <typename TO>
 static int conv3x3_launch(asr_handle* h, const void* x, int Nimg, int H, int W, int Cin, const void* wt,
                           const float* bias, int Cout, int act, void* out, hipStream_t st,
@@ -1873,20 +1978,44 @@ static int conv3x3_launch(asr_handle* h, const void* x, int Nimg, int H, int W, 
     const bool shape = (Cin == 64 || Cin == 128) && (Cout == 64 || Cout == 128);
     if (img_on && shape && nvec <= 16 * 256 && img_bytes <= (size_t)156 * 1024 && Nimg >= 64) {
       const int nbuf = 2 * img_bytes <= (size_t)158 * 1024 ? 2 : 1;
-      const size_t lds = nbuf * img_bytes;
+      const size_t lds = nbuf * img_bytes + 128 * sizeof(float);             // images + the bias vector
+      const int mv = (nvec + 255) / 256;
       const unsigned grid = (unsigned)(Nimg < h->num_cu ? Nimg : h->num_cu);
-#define ASR_CONV_IMG(CI, CO)                                                                                         \
+      static unsigned long long* dbg_host = nullptr;
+      static const bool dbg_on = [] { const char* e = getenv("ASR_CONV_DBG"); return e && e[0] == '1'; }();
+      if (dbg_on && !dbg_host) {
+        (void)hipMalloc(&dbg_host, 64 * 4 * 8 * sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_convdbg), &dbg_host, sizeof(dbg_host));
+        g_convdbg_host = dbg_host;
+      }
+      // compile-time epilogue: 0 none, 1 ReLU, 2 gated data gradient with a uniform scale, 4 with the Philox mask, 3 ReLU + dropout
+      const int actc = act == 2 ? (gate.use_drop == 1 ? 4 : 2) : act;
+#define ASR_CONV_IMG_A(CI, CO, MV, AC)                                                                               \
   do {                                                                                                               \
-    auto k = conv3x3_img_kernel<TO, CI, CO>;                                                                         \
+    auto k = conv3x3_img_kernel<TO, CI, CO, MV, AC, false>;                                                          \
+    if constexpr (AC == 1) { if (dbg_on) k = conv3x3_img_kernel<TO, CI, CO, MV, AC, true>; }                         \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, Nimg, H, W, (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, \
-                       bias, act, gate, nbuf);                                                                       \
+                       bias, gate, nbuf);                                                                            \
   } while (0)
-      if (Cin == 64 && Cout == 64) ASR_CONV_IMG(64, 64);
-      else if (Cin == 64 && Cout == 128) ASR_CONV_IMG(64, 128);
-      else if (Cin == 128 && Cout == 128) ASR_CONV_IMG(128, 128);
-      else ASR_CONV_IMG(128, 64);
+#define ASR_CONV_IMG(CI, CO, MV)                                                                                     \
+  do {                                                                                                               \
+    if constexpr (sizeof(TO) == 4) { ASR_CONV_IMG_A(CI, CO, MV, 0); }                                                \
+    else {                                                                                                           \
+      if (actc == 1) ASR_CONV_IMG_A(CI, CO, MV, 1);                                                                  \
+      else if (actc == 2) ASR_CONV_IMG_A(CI, CO, MV, 2);                                                             \
+      else if (actc == 3) ASR_CONV_IMG_A(CI, CO, MV, 3);                                                             \
+      else if (actc == 4) ASR_CONV_IMG_A(CI, CO, MV, 4);                                                             \
+      else ASR_CONV_IMG_A(CI, CO, MV, 0);                                                                            \
+    }                                                                                                                \
+  } while (0)
+      // (the VGG front-end's images: 40 x 11 x 64 -> 14 staged vectors per thread, 20 x 6 x 64 -> 4, 20 x 6 x 128 -> 8)
+      if (Cin == 64 && Cout == 64) { if (mv <= 14) ASR_CONV_IMG(64, 64, 14); else ASR_CONV_IMG(64, 64, 16); }
+      else if (Cin == 64 && Cout == 128) { if (mv <= 4) ASR_CONV_IMG(64, 128, 4); else ASR_CONV_IMG(64, 128, 16); }
+      else if (Cin == 128 && Cout == 128) { if (mv <= 8) ASR_CONV_IMG(128, 128, 8); else ASR_CONV_IMG(128, 128, 16); }
+      else { if (mv <= 8) ASR_CONV_IMG(128, 64, 8); else ASR_CONV_IMG(128, 64, 16); }
 #undef ASR_CONV_IMG
+#undef ASR_CONV_IMG_A
       ASR_CHECK_LAUNCH(h, "asr_conv3x3(image-resident)");
       return ASR_OK;
     }
