@@ -33,7 +33,7 @@ from examples.timit.training.train_attention import attention_ler, model_kwargs,
 from tensorflow_end2end_speech_recognition_amd.models.attention.joint_ctc_attention import JointCTCAttention  # noqa: E402
 from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import list2sparsetensor         # noqa: E402
 from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu                               # noqa: E402
-from tensorflow_end2end_speech_recognition_amd.utils.training.checkpoint import Saver                        # noqa: E402
+from tensorflow_end2end_speech_recognition_amd.utils.training.checkpoint import Saver, sync_point                        # noqa: E402
 from tensorflow_end2end_speech_recognition_amd.utils.training.learning_rate_controller import Controller     # noqa: E402
 
 
@@ -101,6 +101,7 @@ def do_train(model, params, rank, world):
             start_step = time.time()
 
         if is_new_epoch:
+            sync_point()          # pending asynchronous error checks of this epoch's steps are raised here
             stop = False
             if rank == 0:
                 print('-----EPOCH:%d-----' % train_data.epoch)
@@ -133,6 +134,7 @@ def do_train(model, params, rank, world):
             if stop:
                 break
     if rank == 0:
+        sync_point()
         with open(join(model.save_path, 'complete.txt'), 'w') as f:
             f.write('')
     return result

@@ -29,7 +29,7 @@ from examples.timit.training._common import new_run_directory                   
 from tensorflow_end2end_speech_recognition_amd.models.ctc.multitask_ctc import MultitaskCTC                  # noqa: E402
 from tensorflow_end2end_speech_recognition_amd.utils.io.labels.sparsetensor import list2sparsetensor         # noqa: E402
 from tensorflow_end2end_speech_recognition_amd.utils.training import multi_gpu                               # noqa: E402
-from tensorflow_end2end_speech_recognition_amd.utils.training.checkpoint import Saver                        # noqa: E402
+from tensorflow_end2end_speech_recognition_amd.utils.training.checkpoint import Saver, sync_point                        # noqa: E402
 from tensorflow_end2end_speech_recognition_amd.utils.training.learning_rate_controller import Controller     # noqa: E402
 
 NUM_WORDS = {'train100h': 7213, 'train460h': 18641, 'train960h': 26642}          # word_freq10 (:443-449)
@@ -83,6 +83,7 @@ def do_train(model, params, rank, world):
             sys.stdout.flush()
             start_step = time.time()
         if is_new_epoch:
+            sync_point()          # pending asynchronous error checks of this epoch's steps are raised here
             stop = False
             if rank == 0:
                 print('-----EPOCH:%d-----' % train_data.epoch)
@@ -113,6 +114,7 @@ def do_train(model, params, rank, world):
             if stop:
                 break
     if rank == 0:
+        sync_point()
         with open(join(model.save_path, 'complete.txt'), 'w') as f:
             f.write('')
     return result

@@ -661,7 +661,8 @@ int asr_comm_unique_id(void* id128_host);
 int asr_comm_init(asr_comm** out, asr_handle* h, int rank, int world, const void* id128_host);
 int asr_comm_destroy(asr_comm* c);
 int asr_comm_info(asr_comm* c, int* rank, int* world);
-/* buf[0..n) <- mean over ranks, in place, asynchronous on `s`; every rank calls it with the same n. */
+/* buf[0..n) <- mean over ranks, in place, asynchronous on `s`; every rank calls it with the same n.  buf: any 4-byte
+ * aligned device pointer. */
 int asr_allreduce_mean(asr_comm* c, float* buf, size_t n, asr_stream s);
 
 #ifdef __cplusplus

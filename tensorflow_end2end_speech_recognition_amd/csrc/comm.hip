@@ -63,15 +63,23 @@ bool rccl_load() {
   return false;
 }
 
+// x[0..n) *= s.  Any 4-byte aligned buffer (an external C-ABI caller need not align to 16 bytes; ADVICE / VERDICT r04): a
+// scalar head up to the first 16-byte boundary, 16-byte vectors, a scalar tail.
 __global__ void comm_scale_kernel(float* __restrict__ x, size_t n, float s) {
-  const size_t n4 = n / 4;
-  f32x4_t* x4 = reinterpret_cast<f32x4_t*>(x);
+  size_t head = ((16u - (unsigned)((uintptr_t)x & 15u)) & 15u) / 4u;
+  if (head > n) head = n;
+  const size_t n4 = (n - head) / 4;
+  f32x4_t* x4 = reinterpret_cast<f32x4_t*>(x + head);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4_t v = x4[i];
     v[0] *= s; v[1] *= s; v[2] *= s; v[3] *= s;
     x4[i] = v;
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[n4 * 4 + threadIdx.x] *= s;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < head) x[threadIdx.x] *= s;
+    const size_t tail0 = head + n4 * 4;
+    if (threadIdx.x >= 32 && threadIdx.x - 32 < n - tail0) x[tail0 + threadIdx.x - 32] *= s;
+  }
 }
 
 }  // namespace
@@ -132,11 +140,22 @@ extern "C" int asr_comm_info(asr_comm* c, int* rank, int* world) {
   return ASR_OK;
 }
 
+// test hook: the scaling pass of asr_allreduce_mean on its own (it only runs with world > 1, which a 1-GPU box cannot reach)
+extern "C" int asr_debug_comm_scale(float* buf, size_t n, float s, asr_stream st) {
+  if (!buf || !n) return ASR_ERR_INVALID_ARG;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(comm_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, buf, n, s);
+  return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ERR_HIP;
+}
+
 // buf[i] <- (sum over ranks of buf[i]) / world, in place, enqueued on `s` (every rank, same n).
 extern "C" int asr_allreduce_mean(asr_comm* c, float* buf, size_t n, asr_stream s) {
   if (!c || !c->h) return ASR_ERR_INVALID_ARG;
   asr_handle* h = c->h;
   if (!buf && n) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_allreduce_mean: null buffer");
+  if (((uintptr_t)buf) & 3u) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_allreduce_mean: buffer not 4-byte aligned");
   if (!n) return ASR_OK;
   hipStream_t st = (hipStream_t)s;
   const nccl_result_t r = g_rccl.AllReduce(buf, buf, n, kNcclFloat32, kNcclSum, c->comm, st);

@@ -132,3 +132,15 @@ class Saver(object):
                     warnings.warn('checkpoint %s holds %s optimizer state but the model uses %s: slots and '
                                   'global_step restart from their initial values' % (path, saved, opt.name))
         return model
+
+
+def sync_point():
+    """End of an epoch / of training: every asynchronously watched condition of the steps issued so far is inspected NOW
+    (ops.flush_deferred_checks: the "labels do not fit the frames" error of tf.nn.ctc_loss, which the reference raises
+    inside the offending sess.run and this backend otherwise reports up to ops.DeferredCheck.DEPTH steps late).  Saver.save
+    does the same through ops.check_async_errors.  A no-op without pending checks."""
+    from ... import ops
+    flush = getattr(ops, 'flush_deferred_checks', None)
+    if flush is not None:
+        flush()
+

@@ -658,6 +658,26 @@ def _rccl_world2_worker(rank, port, out):
     dist.destroy_process_group()
 
 
+def test_allreduce_scaling_pass_takes_any_float_aligned_buffer(cuda):
+    """The x 1/N pass of asr_allreduce_mean (csrc/comm.hip: 16-byte vectors between a scalar head and tail) on buffers that
+    start 0..3 floats past a 16-byte boundary, lengths 0 mod 4 and not, down to shorter than the head -- an external C-ABI
+    caller need not align.  It only runs with world > 1, hence the test hook."""
+    import ctypes
+    from tensorflow_end2end_speech_recognition_amd import _lib, ops
+    lib = _lib.handle(0).lib
+    lib.asr_debug_comm_scale.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_float, ctypes.c_void_p]
+    base = torch.arange(1, 5001, dtype=torch.float32, device=cuda)
+    for off in range(4):
+        for n in (1, 2, 3, 4, 5, 7, 8, 1023, 1024, 4093):
+            buf = base.clone()
+            view = buf[off:off + n]
+            assert lib.asr_debug_comm_scale(ctypes.c_void_p(view.data_ptr()), n, 0.5, ops._s()) == 0
+            torch.cuda.synchronize()
+            want = base.clone()
+            want[off:off + n] *= 0.5
+            assert torch.equal(buf, want), (off, n)
+
+
 def test_native_rccl_allreduce_mean_world2(cuda):
     """Two ranks on two GPUs over xGMI through the C ABI communicator (skipped on a 1-GPU box: the driver's
     multi-GPU node is where this runs)."""
