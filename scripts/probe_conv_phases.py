@@ -61,4 +61,7 @@ for (H, W, Ci, Co) in ((40, 11, 64, 64), (20, 6, 64, 128), (20, 6, 128, 128)):
     fl2 = 2.0 * N * H * W * 9 * Ci * Co
     print('   fwd + dropout (ACT 3): %.1f us  %.0f TFLOP/s;  data gradient + gate (ACT 2, %d->%d): %.1f us  %.0f TFLOP/s'
           % (t3, flops / t3 / 1e6, Co, Ci, t2, fl2 / t2 / 1e6))
+    dw = torch.zeros(9 * Ci, Co, device=dev)
+    tw = timed(lambda: ops.conv3x3_bwd_weight(x, dy, dw))
+    print('   weight gradient: %.1f us  %.0f TFLOP/s' % (tw, flops / tw / 1e6))
     del x, y, dy, below

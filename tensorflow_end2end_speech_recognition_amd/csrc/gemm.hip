@@ -2083,6 +2083,154 @@ extern "C" int asr_conv3x3_bwd_data_relu(asr_handle* h, const void* dy, int Nimg
   return conv3x3_launch<bf16_t>(h, dy, Nimg, H, W, Cout, wt_bwd, nullptr, Cin, 2, dpre_below, (hipStream_t)s, gate);
 }
 
+// ---------------------------------------------------------------- 3x3 weight gradient, image-resident form (round 5)
+// dW[tap * CIN + ci][co] = sum over images and pixels p of x[p + s_tap, ci] * dY[p, co].  The tiled kernel above gathers every
+// shifted pixel row from L2 once per tap (nine times) and, at COUT = 64, multiplies half-empty 128-column tiles: 6.4 ms for
+// the 40 x 11 x 64 -> 64 layer of cfg C (299 TFLOP/s).  Here a workgroup stages a whole frame image of x (with its zero
+// border) and 64 output channels of dY into LDS ONCE per image, in the pixel-major layout they have in memory, and takes both
+// MFMA operands out of them with the transposing LDS read (ds_read_b64_tr_b16: each lane passes the address of 4 channels of
+// ONE pixel and receives ONE channel at 4 consecutive pixels -- the row stride is free, so the padded image works as it lies
+// and a tap is a constant byte offset).  Wave w owns the 16 input channels 16 w .. of all nine taps x the 64 output channels of
+// the workgroup's column block (blockIdx.y): 36 accumulator tiles in registers for the whole launch; CIN / 16 waves.  The
+// reduction runs over the pixels of an image in chunks of 32 and over the images blockIdx.x, + gridDim.x, ...; the next
+// image's vectors are requested a few per chunk under the multiplies.  Each workgroup row writes ONE slab [9 CIN][COUT] (its
+// 64 columns); splitk_reduce_kernel sums the slabs in a fixed order (deterministic).  HBM traffic: dY once, x once per
+// 64-column block.  40 x 11 x 64 -> 64: 6.40 -> 2.59 ms (738 TFLOP/s) on the first build.
+// NSPLIT: the workgroup's 64 output columns dealt over NSPLIT waves per input-channel group (CIN = 64: 2 -> eight waves, two per
+// SIMD, each 9 x 2 accumulator tiles: the second wave of a SIMD fills the LDS latency of the first; 2.66 -> see the launcher)
+template <int CIN, int MAXVX, int MAXVY, int NSPLIT>
+__global__ __launch_bounds__(CIN * 4 * NSPLIT, 1) void conv3x3_wgrad_img_kernel(int Nimg, int H, int W, int Cout,
+                                                                       const bf16_t* __restrict__ X,
+                                                                       const bf16_t* __restrict__ dY,
+                                                                       float* __restrict__ partial) {
+  static_assert(CIN == 64 || CIN == 128, "one 16-channel group of x per wave, 4 or 8 waves");
+  constexpr int NTH = CIN * 4 * NSPLIT;
+  constexpr int CB = 64, NT = 4 / NSPLIT;                    // columns of one workgroup / output tiles of one wave
+  constexpr int PSX = CIN * 2 + 16, PSY = CB * 2 + 16;       // bytes per pixel in LDS (16-byte pad: distinct banks per block row)
+  constexpr int MAXV = MAXVX > MAXVY ? MAXVX : MAXVY;
+  extern __shared__ __attribute__((aligned(16))) char wsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) % (CIN / 16), nh = (tid >> 6) / (CIN / 16);   // input-channel group / column part of this wave
+  const int HW = H * W, WP = W + 2;
+  const int n0 = blockIdx.y * CB;
+  const int nchunk = (HW + 31) / 32;
+  const int ximg_bytes = (H + 2) * WP * PSX;
+  char* xs = wsm;                                            // x image with its border
+  char* ys = wsm + ximg_bytes;                               // dY image (64 channels), nchunk * 32 pixel rows (tail rows stay zero)
+  const int yimg_bytes = nchunk * 32 * PSY;
+  const int nvx = HW * CIN / 8, nvy = HW * CB / 8;           // 16-byte vectors of one image
+  const float invW = 1.0f / (float)W;
+
+  for (int i = tid * 16; i < ximg_bytes + yimg_bytes; i += NTH * 16)
+    *reinterpret_cast<bf16x8_t*>(wsm + i) = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  __syncthreads();
+
+  bf16x8_t stx[MAXVX], sty[MAXVY];
+  auto fetch1 = [&](int img, int i) {                        // vector i of this thread, both operands
+    const int v = tid + i * NTH;
+    if (i < MAXVX && v < nvx) stx[i < MAXVX ? i : 0] = reinterpret_cast<const bf16x8_t*>(X + (size_t)img * HW * CIN)[v];
+    if (i < MAXVY && v < nvy) {
+      const int p = v / (CB / 8), cv = v % (CB / 8);
+      sty[i < MAXVY ? i : 0] = *reinterpret_cast<const bf16x8_t*>(dY + ((size_t)img * HW + p) * Cout + n0 + cv * 8);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < MAXVX; ++i) {
+      const int v = tid + i * NTH;
+      if (v < nvx) {
+        const int p = v / (CIN / 8), cv = v % (CIN / 8);
+        const int y = (int)(((float)p + 0.5f) * invW), x = p - y * W;
+        *reinterpret_cast<bf16x8_t*>(xs + ((y + 1) * WP + x + 1) * PSX + cv * 16) = stx[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXVY; ++i) {
+      const int v = tid + i * NTH;
+      if (v < nvy) {
+        const int p = v / (CB / 8), cv = v % (CB / 8);
+        *reinterpret_cast<bf16x8_t*>(ys + p * PSY + cv * 16) = sty[i];
+      }
+    }
+  };
+  // lane -> its piece of a 4-pixel x 16-channel block: pixel row (lane & 15) >> 2 of k-group lane >> 4, channels 4 (lane & 3)..
+  const int kg = lane >> 4, prow = (lane & 15) >> 2, c4 = lane & 3;
+  const int xch = (wave * 16 + c4 * 4) * 2;                  // byte offset of this lane's 4 input channels
+  const int ych = (nh * NT * 16 + c4 * 4) * 2;
+  int tapoff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tapoff[t] = ((t / 3 - 1) * WP + (t % 3 - 1)) * PSX;
+  // LDS byte offset of a pixel's centre tap in the x image.  A pixel past the image reads the LAST pixel of x (finite)
+  // against a zero row of dY.
+  auto xofs = [&](int p) -> int {
+    const int pc = p < HW ? p : HW - 1;
+    const int y = (int)(((float)pc + 0.5f) * invW), x = pc - y * W;
+    return ((y + 1) * WP + x + 1) * PSX + xch;
+  };
+  typedef __attribute__((address_space(3))) bf16x4_t wl4_t;
+  auto trfrag = [&](const char* lo, const char* hi) -> bf16x8_t {
+    const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wl4_t*)(lo));
+    const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wl4_t*)(hi));
+    return (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  };
+
+  f32x4_t acc[9][NT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[t][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  int img = blockIdx.x;
+  if (img < Nimg) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) fetch1(img, i);
+    lstore();
+  }
+  __syncthreads();
+  for (; img < Nimg; img += gridDim.x) {
+    const int nxt = img + gridDim.x;
+    const bool more = nxt < Nimg;                            // block-uniform
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+      // the next image: vector pairs i = 2c, 2c + 1 in chunk c (2 nchunk >= MAXV for every supported image: the launcher checks)
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+          if (i / 2 == c) fetch1(nxt, i);
+      }
+      const int p0 = c * 32 + kg * 8 + prow;
+      const int xlo = xofs(p0), xhi = xofs(p0 + 4);
+      const int ylo = p0 * PSY + ych, yhi = (p0 + 4) * PSY + ych;
+      bf16x8_t b[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = trfrag(ys + ylo + j * 32, ys + yhi + j * 32);
+      bf16x8_t a[3];
+      a[0] = trfrag(xs + xlo + tapoff[0], xs + xhi + tapoff[0]);
+      a[1] = trfrag(xs + xlo + tapoff[1], xs + xhi + tapoff[1]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 2 < 9) a[(t + 2) % 3] = trfrag(xs + xlo + tapoff[t + 2], xs + xhi + tapoff[t + 2]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t % 3], b[j], acc[t][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                         // every wave is done with this image
+    if (more) lstore();
+    __syncthreads();
+  }
+  // slab of this workgroup row: lane holds rows rg*4 + r (input channel within the wave's group), column lane & 15 of tile j
+  float* slab = partial + (size_t)blockIdx.x * (9 * CIN) * Cout;
+  const int col = lane & 15, rg = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        slab[(size_t)(t * CIN + wave * 16 + rg * 4 + r) * Cout + n0 + (nh * NT + j) * 16 + col] = acc[t][j][r];
+}
+
 extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* dy, int Nimg, int H, int W,
                                       int Cin, int Cout, float* dw, int accumulate, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
@@ -2112,6 +2260,45 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
   S = (Mpix + kchunk - 1) / kchunk;
   float* partial = (float*)h->scratch;
   hipStream_t st = (hipStream_t)s;
+  {
+    // image-resident form (round 5): x and dY images in LDS, 9 taps from one staging; ASR_CONV_WGRAD_IMG=0 keeps the tiled kernel
+    static const bool wimg_on = [] { const char* e = getenv("ASR_CONV_WGRAD_IMG"); return !(e && e[0] == '0'); }();
+    const int HWp = H * W, nchunk = (HWp + 31) / 32;
+    const size_t lds = (size_t)(H + 2) * (W + 2) * (Cin * 2 + 16) + (size_t)nchunk * 32 * (64 * 2 + 16);
+    const int nth = Cin * 4;
+    const int mvx = (HWp * Cin / 8 + nth - 1) / nth, mvy = (HWp * 8 + nth - 1) / nth;   // staged vectors per thread
+    const int mv = mvx > mvy ? mvx : mvy;
+    const size_t slab = (size_t)M * N * sizeof(float);
+    size_t wgs = (h->scratch_bytes - ASR_XCH_BYTES) / slab;
+    const size_t cols = (size_t)(Cout / 64);
+    if (wgs * cols > (size_t)h->num_cu) wgs = (size_t)h->num_cu / cols;
+    if (wgs > (size_t)Nimg) wgs = (size_t)Nimg;
+    // (Cin = 128 runs eight waves, two per SIMD: 256 registers, of which 144 are accumulators -- small images only)
+    if (wimg_on && (Cin == 64 || (Cin == 128 && mvx <= 4 && mvy <= 2)) && Cout % 64 == 0 && Nimg >= 64 &&
+        lds <= (size_t)158 * 1024 && mv <= 14 && nchunk * 2 >= mv && wgs >= 32) {
+#define ASR_WGRAD_IMG(CI, VX, VY, NS)                                                                                  \
+  do {                                                                                                                 \
+    auto kern = conv3x3_wgrad_img_kernel<CI, VX, VY, NS>;                                                              \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs, (unsigned)cols), dim3(CI * 4 * NS), lds, st, Nimg, H, W, Cout,        \
+                       (const bf16_t*)x, (const bf16_t*)dy, partial);                                                  \
+  } while (0)
+      // (the VGG front-end's images: 40 x 11 x 64 -> 7 + 7 staged vectors per thread of eight waves, 20 x 6 x 64 -> 2 + 2,
+      // 20 x 6 x 128 -> 4 + 2)
+      static const bool split_on = [] { const char* e = getenv("ASR_CONV_WGRAD_SPLIT"); return !(e && e[0] == '0'); }();
+      if (Cin == 64 && split_on) { if (mv <= 4) ASR_WGRAD_IMG(64, 2, 2, 2); else ASR_WGRAD_IMG(64, 7, 7, 2); }
+      else if (Cin == 64) { if (mv <= 4) ASR_WGRAD_IMG(64, 4, 4, 1); else ASR_WGRAD_IMG(64, 14, 14, 1); }
+      else ASR_WGRAD_IMG(128, 4, 2, 1);
+#undef ASR_WGRAD_IMG
+      const size_t total = (size_t)M * N;
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, partial, (int)wgs, M, N, dw, N, nullptr,
+                         accumulate, 0, 0);
+      ASR_CHECK_LAUNCH(h, "asr_conv3x3_bwd_weight(image-resident)");
+      return ASR_OK;
+    }
+  }
   if (wgrad_tr) {
     const size_t lds = (size_t)2 * TN_STAGE;
     auto kern = bn64 ? conv3x3_wgrad_tr_kernel<64> : conv3x3_wgrad_tr_kernel<128>;
