@@ -419,7 +419,7 @@ def main():
     for c in META:
         META[c]['vars'] = META_VARS[c]
     OUT['meta_json'] = np.frombuffer(json.dumps(META, sort_keys=True).encode(), dtype=np.uint8)
-    path = os.path.join(HERE, 'tfshim_v1.npz')
+    path = sys.argv[sys.argv.index('--out') + 1] if '--out' in sys.argv else os.path.join(HERE, 'tfshim_v1.npz')
     np.savez_compressed(path, **OUT)
     print('%d arrays, %d cases -> %s (%.1f KB)' % (len(OUT), len(META), path, os.path.getsize(path) / 1024))
     for c in sorted(META):

@@ -7,6 +7,8 @@ tests/golden/tf_shim; run where /root/reference exists).  These tests hold oracl
 oracle/model.py, oracle/gru.py, oracle/vgg.py and oracle/optim.py to those numbers in float64: values 1e-11, gradients
 1e-9 relative to the largest entry.  CPU only; nothing here touches the HIP path -- the `-m gpu` suite compares THAT
 with the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -197,3 +199,24 @@ def test_tfshim_ctc_models(name):
     c.check_grads(clipped, GRAD, group='clipped')
     norms = [np.sqrt((g ** 2).sum()) for g in out['grads'].values()]
     assert any(v > m['clip_grad_norm'] for v in norms)          # the clip is active
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference tree is only present in the build container')
+def test_tfshim_fixture_is_what_the_generator_produces(tmp_path):
+    """Where /root/reference exists: re-run tests/golden/make_golden_tfshim.py (the reference's model code on the eager
+    TensorFlow stand-in) and compare every array with the committed fixture -- the fixture is a pure function of the
+    reference's files, the stand-in and the generator's seeds."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'regen.npz')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'golden', 'make_golden_tfshim.py'), '--out', out],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    new, old = np.load(out), np.load(_tfshim.PATH)
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        if k == 'meta_json':
+            assert bytes(new[k]) == bytes(old[k])
+        else:
+            assert new[k].shape == old[k].shape and np.allclose(new[k], old[k], rtol=1e-13, atol=1e-300), k
