@@ -1172,22 +1172,25 @@ __device__ unsigned long long* g_convdbg = nullptr;
 // ACT (compile time since round 5: a run-time `act` put branches into every epilogue piece, and a piece has to be straight-line
 // code to be scheduled between the multiplies): 0 none, 1 ReLU, 2 data gradient gated by the sign of gate.act with a uniform
 // scale (use_drop 0: 1, use_drop 2: 1 / keep), 4 the same with the Philox mask (use_drop 1), 3 forward ReLU + dropout.
-template <typename TO, int CIN, int COUT, int MAXV = 16, int ACT = 1, bool DBG = false>
-__global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, int W, const bf16_t* __restrict__ X,
+// NW = waves per workgroup: 4 (one per SIMD) or, CIN = 64 only, 8 (two per SIMD, each wave two 16-channel output tiles = 144
+// weight registers: the sibling wave fills the LDS latency and the epilogue's VALU work; round 5)
+template <typename TO, int CIN, int COUT, int MAXV = 16, int ACT = 1, bool DBG = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 1) void conv3x3_img_kernel(int Nimg, int H, int W, const bf16_t* __restrict__ X,
                                                              const bf16_t* __restrict__ Wt, TO* __restrict__ Out,
                                                              const float* __restrict__ bias, ConvGate gate,
                                                              int nbuf) {
   constexpr int KS = 9 * CIN / 32;                         // k-steps of 32
   constexpr int KPT = CIN / 32;                            // k-steps per tap
-  constexpr int NTW = CIN == 64 ? 4 : 2;                   // output tiles per wave
+  constexpr int NTW = (CIN == 64 && NW == 4) ? 4 : 2;      // output tiles per wave
+  constexpr int NTHR = NW * 64;
   constexpr int NGROUPS = (COUT / 16) / NTW;               // wave groups over the output channels
-  constexpr int MPARTS = 4 / NGROUPS;                      // waves sharing the pixel tiles of one channel group
+  constexpr int MPARTS = NW / NGROUPS;                     // waves sharing the pixel tiles of one channel group
   constexpr int PST = CIN * 2 + 16;                        // bytes per pixel in LDS (16-byte pad: conflict-free b128 reads)
   // the deferred epilogue keeps a second set of accumulators + gate operands alive: CIN = 64 with 14+ staged vectors (the
   // 40 x 11 images) has no registers for it (measured with it: spills in the tile loop, 2.87 -> 4.13 ms) and keeps the
   // epilogue behind its own tile; every other form defers (20 x 6 x 64 -> 128: 1.59 -> 1.23 ms, 128 -> 128: 2.44 -> 1.90 ms)
   constexpr bool DEFER = true;
-  static_assert(NGROUPS >= 1 && NGROUPS <= 4 && 4 % NGROUPS == 0, "wave split");
+  static_assert(NGROUPS >= 1 && NGROUPS <= NW && NW % NGROUPS == 0, "wave split");
   extern __shared__ __attribute__((aligned(16))) char csm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ng = wave % NGROUPS, mp = wave / NGROUPS;
@@ -1206,7 +1209,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
     for (int ks = 0; ks < KS; ++ks) breg[j][ks] = *reinterpret_cast<const bf16x8_t*>(wp + ks * 32);
   }
   // zero both images (borders stay zero for the whole launch)
-  for (int i = tid * 16; i < nbuf * img_bytes; i += 256 * 16) *reinterpret_cast<bf16x8_t*>(csm + i) = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid * 16; i < nbuf * img_bytes; i += NTHR * 16) *reinterpret_cast<bf16x8_t*>(csm + i) = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
   __syncthreads();
 
   bf16x8_t stage[MAXV];                                    // staged vectors per thread (nvec <= 256 MAXV)
@@ -1214,7 +1217,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
     const bf16x8_t* src = reinterpret_cast<const bf16x8_t*>(X + (size_t)img * HW * CIN);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int v = tid + i * 256;
+      const int v = tid + i * NTHR;
       if (v < nvec) stage[i] = src[v];
     }
   };
@@ -1222,7 +1225,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_img_kernel(int Nimg, int H, in
   auto lstore = [&](char* buf) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int v = tid + i * 256;
+      const int v = tid + i * NTHR;
       if (v < nvec) {
         const int p = v / (CIN / 8), cv = v % (CIN / 8);
         // (round 5: the quotient by the run-time W through the reciprocal -- exact for p < 2^22 -- instead of an integer
@@ -1998,6 +2001,13 @@ static int conv3x3_launch(asr_handle* h, const void* x, int Nimg, int H, int W, 
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, Nimg, H, W, (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, \
                        bias, gate, nbuf);                                                                            \
   } while (0)
+#define ASR_CONV_IMG8_A(CI, CO, MV, AC)                                                                              \
+  do {                                                                                                               \
+    auto k = conv3x3_img_kernel<TO, CI, CO, MV, AC, false, 8>;                                                       \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, Nimg, H, W, (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, \
+                       bias, gate, nbuf);                                                                            \
+  } while (0)
 #define ASR_CONV_IMG(CI, CO, MV)                                                                                     \
   do {                                                                                                               \
     if constexpr (sizeof(TO) == 4) { ASR_CONV_IMG_A(CI, CO, MV, 0); }                                                \
@@ -2010,12 +2020,25 @@ static int conv3x3_launch(asr_handle* h, const void* x, int Nimg, int H, int W, 
     }                                                                                                                \
   } while (0)
       // (the VGG front-end's images: 40 x 11 x 64 -> 14 staged vectors per thread, 20 x 6 x 64 -> 4, 20 x 6 x 128 -> 8)
-      if (Cin == 64 && Cout == 64) { if (mv <= 14) ASR_CONV_IMG(64, 64, 14); else ASR_CONV_IMG(64, 64, 16); }
+      // eight waves (two per SIMD, two output tiles each) for the forward ReLU + dropout of small images: the sibling wave
+      // hides the Philox rounds of the epilogue (20 x 6 x 64 -> 128: 1.96 -> 1.70 ms).  Measured, not used elsewhere: the
+      // 40 x 11 forms spill 16 - 46 registers at 256 per wave (ACT 3: 3.54 -> 4.15 ms), the ReLU forms are unchanged (1.17 ms).
+      static const bool w8_on = [] { const char* e = getenv("ASR_CONV_IMG_W8"); return !(e && e[0] == '0'); }();
+      bool done8 = false;
+      if constexpr (sizeof(TO) == 2) {
+        if (Cin == 64 && w8_on && mv <= 4 && actc == 3) {
+          if (Cout == 64) ASR_CONV_IMG8_A(64, 64, 2, 3); else ASR_CONV_IMG8_A(64, 128, 2, 3);
+          done8 = true;
+        }
+      }
+      if (done8) {}
+      else if (Cin == 64 && Cout == 64) { if (mv <= 14) ASR_CONV_IMG(64, 64, 14); else ASR_CONV_IMG(64, 64, 16); }
       else if (Cin == 64 && Cout == 128) { if (mv <= 4) ASR_CONV_IMG(64, 128, 4); else ASR_CONV_IMG(64, 128, 16); }
       else if (Cin == 128 && Cout == 128) { if (mv <= 8) ASR_CONV_IMG(128, 128, 8); else ASR_CONV_IMG(128, 128, 16); }
       else { if (mv <= 8) ASR_CONV_IMG(128, 64, 8); else ASR_CONV_IMG(128, 64, 16); }
 #undef ASR_CONV_IMG
 #undef ASR_CONV_IMG_A
+#undef ASR_CONV_IMG8_A
       ASR_CHECK_LAUNCH(h, "asr_conv3x3(image-resident)");
       return ASR_OK;
     }
