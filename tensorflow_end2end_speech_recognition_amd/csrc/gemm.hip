@@ -1174,7 +1174,11 @@ __device__ unsigned long long* g_convdbg = nullptr;
 // scale (use_drop 0: 1, use_drop 2: 1 / keep), 4 the same with the Philox mask (use_drop 1), 3 forward ReLU + dropout.
 // NW = waves per workgroup: 4 (one per SIMD) or, CIN = 64 only, 8 (two per SIMD, each wave two 16-channel output tiles = 144
 // weight registers: the sibling wave fills the LDS latency and the epilogue's VALU work; round 5)
-template <typename TO, int CIN, int COUT, int MAXV = 16, int ACT = 1, bool DBG = false, int NW = 4>
+// STREAM (round 5, two LDS images): the next image is not held in MAXV staging registers for the whole image and written to LDS in
+// one phase at its end (14 loads issued at once: 1.7 k cycles of issue stall, then 0.9 k cycles of LDS stores with nothing
+// beside them, per 22.5 k-cycle image at 40 x 11 x 64) but STREAMED: every pixel tile requests two vectors at its top and stores
+// the two of the tile before into the other image buffer -- eight staging registers instead of 16 - 64.
+template <typename TO, int CIN, int COUT, int MAXV = 16, int ACT = 1, bool DBG = false, int NW = 4, bool STREAM = false>
 __global__ __launch_bounds__(NW * 64, 1) void conv3x3_img_kernel(int Nimg, int H, int W, const bf16_t* __restrict__ X,
                                                              const bf16_t* __restrict__ Wt, TO* __restrict__ Out,
                                                              const float* __restrict__ bias, ConvGate gate,
@@ -1212,27 +1216,49 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_img_kernel(int Nimg, int H
   for (int i = tid * 16; i < nbuf * img_bytes; i += NTHR * 16) *reinterpret_cast<bf16x8_t*>(csm + i) = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
   __syncthreads();
 
-  bf16x8_t stage[MAXV];                                    // staged vectors per thread (nvec <= 256 MAXV)
+  constexpr int SPT = 2;                                   // STREAM: vectors requested per pixel tile
+  bf16x8_t stage[STREAM ? SPT : MAXV];                     // staged vectors per thread (nvec <= 256 MAXV)
+  const int nvt = (nvec + NTHR - 1) / NTHR;                // vectors per thread and image
   auto gfetch = [&](int img) {
     const bf16x8_t* src = reinterpret_cast<const bf16x8_t*>(X + (size_t)img * HW * CIN);
+    if constexpr (!STREAM) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = tid + i * NTHR;
-      if (v < nvec) stage[i] = src[v];
+      for (int i = 0; i < MAXV; ++i) {
+        const int v = tid + i * NTHR;
+        if (v < nvec) stage[i] = src[v];
+      }
     }
   };
   const float invW = 1.0f / (float)W;
+  // LDS position of vector v of an image (round 5: the quotient by the run-time W through the reciprocal -- exact for p < 2^22
+  // -- instead of an integer division per staged vector: the 14 divisions were most of the 1.3 k cycles of this phase per image)
+  auto vofs = [&](int v) -> int {
+    const int p = v / (CIN / 8), cv = v % (CIN / 8);
+    const int y = (int)(((float)p + 0.5f) * invW), x = p - y * W;
+    return ((y + 1) * WP + x + 1) * PST + cv * 16;
+  };
   auto lstore = [&](char* buf) {
+    if constexpr (!STREAM) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = tid + i * NTHR;
-      if (v < nvec) {
-        const int p = v / (CIN / 8), cv = v % (CIN / 8);
-        // (round 5: the quotient by the run-time W through the reciprocal -- exact for p < 2^22 -- instead of an integer
-        // division per staged vector: the 14 divisions were most of the 1.3 k cycles of this phase per image)
-        const int y = (int)(((float)p + 0.5f) * invW), x = p - y * W;
-        *reinterpret_cast<bf16x8_t*>(buf + ((y + 1) * WP + x + 1) * PST + cv * 16) = stage[i];
+      for (int i = 0; i < MAXV; ++i) {
+        const int v = tid + i * NTHR;
+        if (v < nvec) *reinterpret_cast<bf16x8_t*>(buf + vofs(v)) = stage[i];
       }
+    }
+  };
+  // STREAM: vectors [i0, i0 + SPT) of this thread: request / store
+  auto sfetch = [&](const bf16x8_t* src, int i0) {
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+      const int v = tid + (i0 + q) * NTHR;
+      if (i0 + q < nvt && v < nvec) stage[q] = src[v];
+    }
+  };
+  auto sstore = [&](char* buf, int i0) {
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+      const int v = tid + (i0 + q) * NTHR;
+      if (i0 + q < nvt && v < nvec) *reinterpret_cast<bf16x8_t*>(buf + vofs(v)) = stage[q];
     }
   };
   int tapoff[9];
@@ -1242,8 +1268,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_img_kernel(int Nimg, int H
 
   int img = blockIdx.x;
   if (img >= Nimg) return;
-  gfetch(img);
-  lstore(csm);
+  if constexpr (STREAM) {                                  // the first image: straight through, once per launch
+    const bf16x8_t* src0 = reinterpret_cast<const bf16x8_t*>(X + (size_t)img * HW * CIN);
+    for (int i0 = 0; i0 < nvt; i0 += SPT) { sfetch(src0, i0); sstore(csm, i0); }
+  } else {
+    gfetch(img);
+    lstore(csm);
+  }
   __syncthreads();
   // Round 4: one wave per SIMD means every dependent trip of the epilogue was exposed -- the bias vector and (act == 2)
   // the gate operand were requested inside the epilogue, 4 + 4 global round trips per 16-pixel tile against 1 152 matrix
@@ -1331,6 +1362,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_img_kernel(int Nimg, int H
     const unsigned long long tq0 = CV_T();
     if (nxt < Nimg) gfetch(nxt);                           // lands under this image's products
     const unsigned long long tq1 = CV_T();
+    const bool morei = nxt < Nimg;                         // block-uniform
+    const bf16x8_t* srcn = reinterpret_cast<const bf16x8_t*>(X + (size_t)(morei ? nxt : img) * HW * CIN);
+    char* bufn = csm + ((it + 1) & 1) * img_bytes;         // STREAM implies two buffers
+    int sq = 0;                                            // STREAM: this thread's next vector index
     const __amdgpu_buffer_rsrc_t rsc =
         __builtin_amdgcn_make_buffer_rsrc(Out + (size_t)img * HW * COUT, 0, img_out_bytes, 0x00020000);
     // (CIN = 64 keeps 288 weight registers + 64 staging registers: the 24 of the look-ahead group would spill)
@@ -1347,6 +1382,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_img_kernel(int Nimg, int H
     constexpr int UNR = (ACT >= 2 || MAXV > 8) ? 1 : 2;        // (the Philox epilogues measured slower unrolled: 1.96 -> 2.03 ms)
 #pragma unroll UNR
     for (int mt = mp; mt < ntm; mt += MPARTS) {
+      if constexpr (STREAM) {
+        if (morei) {
+          if (sq > 0) sstore(bufn, sq - SPT);              // what the tile before requested has landed (a tile of multiplies ago)
+          sfetch(srcn, sq);
+          sq += SPT;
+        }
+      }
       const int p = mt * 16 + fr;
       const char* ap = tile_ptr(cur, mt);
       const bool more = mt + MPARTS < ntm;                 // wave-uniform
@@ -1413,7 +1455,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_img_kernel(int Nimg, int H
     // (Measured, round 4: barriers that wait for the LDS counter only -- s_waitcnt lgkmcnt(0) + s_barrier instead of
     // __syncthreads(), whose release fence also waits for the epilogue's global stores -- change nothing: 2.80 vs 2.76 ms.)
     const unsigned long long tq2 = CV_T();
-    if (nxt < Nimg) {
+    if constexpr (STREAM) {
+      if (morei) {
+        if (sq > 0) sstore(bufn, sq - SPT);
+        for (; sq < nvt; sq += SPT) { sfetch(srcn, sq); sstore(bufn, sq); }   // more vectors than tiles x SPT: the rest, exposed
+      }
+    } else if (nxt < Nimg) {
       if (nbuf == 1) __syncthreads();                      // every wave is done with the only buffer
       lstore(csm + (nbuf == 2 ? ((it + 1) & 1) * img_bytes : 0));
     }
@@ -1993,9 +2040,14 @@ static int conv3x3_launch(asr_handle* h, const void* x, int Nimg, int H, int W, 
       }
       // compile-time epilogue: 0 none, 1 ReLU, 2 gated data gradient with a uniform scale, 4 with the Philox mask, 3 ReLU + dropout
       const int actc = act == 2 ? (gate.use_drop == 1 ? 4 : 2) : act;
+      static const bool stream_on = [] { const char* e = getenv("ASR_CONV_STREAM"); return !(e && e[0] == '0'); }();
+      const bool strm = stream_on && nbuf == 2;
 #define ASR_CONV_IMG_A(CI, CO, MV, AC)                                                                               \
   do {                                                                                                               \
+    /* measured (profiles/r05_conv_stream.md): streaming wins 5 % for 64 -> 64 without the gate loads, loses 3 - 12 % elsewhere */ \
+    constexpr bool SOK = CI == 64 && CO == 64 && (AC == 1 || AC == 3);                                               \
     auto k = conv3x3_img_kernel<TO, CI, CO, MV, AC, false>;                                                          \
+    if constexpr (SOK) { if (strm) k = conv3x3_img_kernel<TO, CI, CO, MV, AC, false, 4, true>; }                     \
     if constexpr (AC == 1) { if (dbg_on) k = conv3x3_img_kernel<TO, CI, CO, MV, AC, true>; }                         \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, Nimg, H, W, (const bf16_t*)x, (const bf16_t*)wt, (TO*)out, \
