@@ -31,6 +31,12 @@ DW_LANES = 2
 # restores a marker per lane entry and a wait per layer)
 FORK_ONCE = _os.environ.get('ASR_FORK_ONCE', '1') != '0'
 BG_WGS = int(_os.environ.get('ASR_BG_WGS', '128'))   # workgroups of a weight-gradient GEMM that runs beside a BPTT kernel
+# a dx product of at least this many flops keeps the chip to itself: the layer's weight-gradient lanes start BEHIND it (one
+# more main-stream marker) instead of behind the BPTT kernel.  Timeline of the cfg-C-shaped step (4 x 512, 104 k frames,
+# profiles/r05_cfgC_timeline.md): the 874 GFLOP dx product took 2.1 - 2.4 ms beside the two W_x gradient GEMMs (1.04 alone)
+# and the layer below cannot start before it, while its BPTT kernel then left half the chip idle for 2 ms.
+# ASR_DW_AFTER_DX=0: never, =1: always.
+DW_AFTER_DX_FLOPS = {'0': float('inf'), '1': 0.0}.get(_os.environ.get('ASR_DW_AFTER_DX', ''), 2e11)
 
 
 def declare_lstm_vars(store, scope, din, H, ndir, use_peephole, parameter_init, rng, cell_scope=None):
@@ -164,6 +170,8 @@ class LSTMLayer(object):
             else:
                 ops.gemm(dg2d, c['wx_cat'], transB=True, out=dx.view(T * B, din),
                          mul=dx_mask.view(T * B, din) if dx_mask is not None else None)
+            if FORK_ONCE and background and 2.0 * T * B * din * ndir * 4 * H >= DW_AFTER_DX_FLOPS:
+                fork = ops.stream_event()
         # weight gradients: side streams (one per direction), concurrent with the BPTT kernel of the layer
         # below (joined in the model's backward before clipping)
         dw_il = torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols
