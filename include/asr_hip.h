@@ -203,6 +203,12 @@ int asr_conv3x3_bwd_data_relu(asr_handle* h, const void* dy, int N, int H, int W
                               void* dpre_below, asr_stream s);
 int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* dy, int N, int H, int W,
                            int Cin, int Cout, float* dw, int accumulate, asr_stream s);
+/* the weight AND the bias gradient of a convolution layer (tf.nn.bias_add's gradient, cnn_util.py:49-84: dbias[Cout] =
+ * column sums of dy over all N H W pixels) in one call: where the image-resident weight-gradient kernel applies, the bias
+ * sums come from the dy images it has staged in LDS anyway (fixed summation order); otherwise this is
+ * asr_conv3x3_bwd_weight followed by asr_colsum.  Both outputs are overwritten. */
+int asr_conv3x3_bwd_weight_bias(asr_handle* h, const void* x, const void* dy, int N, int H, int W,
+                                int Cin, int Cout, float* dw, float* dbias, asr_stream s);
 /* tf.nn.max_pool 2x2 stride 2 SAME (cnn_util.py:13-28): out [N, ceil(H/2), ceil(W/2), C];
  * argmax (uint8, 0..3 = position in the window) drives the backward pass. */
 int asr_maxpool2x2_fwd(asr_handle* h, int dtype, const void* in, int N, int H, int W, int C,
@@ -224,6 +230,10 @@ int asr_conv3x3_smallc_fwd_drop(asr_handle* h, const void* x, int N, int H, int 
                                 asr_stream s);      /* ReLU + dropout in the epilogue, as asr_conv3x3_fwd_drop */
 int asr_conv3x3_smallc_bwd_weight(asr_handle* h, const void* x, const void* dpre, int N, int H, int W, int Cin,
                                   int Cout, float* dw, asr_stream s);
+/* + the bias gradient dbias[64] = column sums of dpre, from a column of ones in the patch operand (as
+ * asr_conv3x3_bwd_weight_bias) */
+int asr_conv3x3_smallc_bwd_weight_bias(asr_handle* h, const void* x, const void* dpre, int N, int H, int W, int Cin,
+                                       int Cout, float* dw, float* dbias, asr_stream s);
 /* asr_dropout_apply (on the pooled gradient, when use_drop) -> asr_maxpool2x2_bwd -> asr_relu_bwd of the convolution
  * under the pool, as one pass without the full-resolution fp32 gradient in between: dpre[n,h,w,c] (operand dtype) =
  * (act[n,h,w,c] > 0 && argmax[o] == 2 (h & 1) + (w & 1)) ? dout[o] * mask(o) : 0, o = pooled cell (n, h/2, w/2, c).

@@ -49,8 +49,10 @@ SIGNATURES = {
     'asr_conv3x3_smallc_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     'asr_conv3x3_smallc_fwd_drop': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _u64, _u64, _vp, _vp]),
     'asr_conv3x3_smallc_bwd_weight': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'asr_conv3x3_smallc_bwd_weight_bias': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_conv3x3_bwd_data_relu': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _f, _u64, _u64, _i, _vp, _vp]),
     'asr_conv3x3_bwd_weight': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    'asr_conv3x3_bwd_weight_bias': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_im2col3x3': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_col2im3x3': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'asr_im2col': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -2173,7 +2173,11 @@ extern "C" int asr_conv3x3_bwd_data_relu(asr_handle* h, const void* dy, int Nimg
 // 64-column block.  40 x 11 x 64 -> 64: 6.40 -> 2.59 ms (738 TFLOP/s) on the first build.
 // NSPLIT: the workgroup's 64 output columns dealt over NSPLIT waves per input-channel group (CIN = 64: 2 -> eight waves, two per
 // SIMD, each 9 x 2 accumulator tiles: the second wave of a SIMD fills the LDS latency of the first; 2.66 -> see the launcher)
-template <int CIN, int MAXVX, int MAXVY, int NSPLIT>
+// BIAS: the bias gradient (column sums of dY over all pixels) from the staged dY as well: the wave of input-channel group g
+// multiplies a fragment of ONES with its dY fragments in the chunks c % (CIN / 16) == g (one more MFMA per NT tiles in a
+// quarter / an eighth of the chunks, instead of a second pass over dY: 0.30 - 0.54 ms per layer of the cfg C step), and
+// writes its partial sums as row 9 CIN + g of the slab; wgrad_img_reduce_kernel adds those rows over slabs and groups.
+template <int CIN, int MAXVX, int MAXVY, int NSPLIT, bool BIAS = false>
 __global__ __launch_bounds__(CIN * 4 * NSPLIT, 1) void conv3x3_wgrad_img_kernel(int Nimg, int H, int W, int Cout,
                                                                        const bf16_t* __restrict__ X,
                                                                        const bf16_t* __restrict__ dY,
@@ -2254,6 +2258,10 @@ __global__ __launch_bounds__(CIN * 4 * NSPLIT, 1) void conv3x3_wgrad_img_kernel(
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[t][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  f32x4_t accb[BIAS ? NT : 1];
+#pragma unroll
+  for (int j = 0; j < (BIAS ? NT : 1); ++j) accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bf16x8_t ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   int img = blockIdx.x;
   if (img < Nimg) {
@@ -2279,6 +2287,12 @@ __global__ __launch_bounds__(CIN * 4 * NSPLIT, 1) void conv3x3_wgrad_img_kernel(
       bf16x8_t b[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) b[j] = trfrag(ys + ylo + j * 32, ys + yhi + j * 32);
+      if constexpr (BIAS) {
+        if (c % (CIN / 16) == wave) {                        // wave-uniform
+#pragma unroll
+          for (int j = 0; j < NT; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[j], accb[j], 0, 0, 0);
+        }
+      }
       bf16x8_t a[3];
       a[0] = trfrag(xs + xlo + tapoff[0], xs + xhi + tapoff[0]);
       a[1] = trfrag(xs + xlo + tapoff[1], xs + xhi + tapoff[1]);
@@ -2295,7 +2309,7 @@ __global__ __launch_bounds__(CIN * 4 * NSPLIT, 1) void conv3x3_wgrad_img_kernel(
     __syncthreads();
   }
   // slab of this workgroup row: lane holds rows rg*4 + r (input channel within the wave's group), column lane & 15 of tile j
-  float* slab = partial + (size_t)blockIdx.x * (9 * CIN) * Cout;
+  float* slab = partial + (size_t)blockIdx.x * (9 * CIN + (BIAS ? CIN / 16 : 0)) * Cout;
   const int col = lane & 15, rg = lane >> 4;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -2304,10 +2318,46 @@ __global__ __launch_bounds__(CIN * 4 * NSPLIT, 1) void conv3x3_wgrad_img_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         slab[(size_t)(t * CIN + wave * 16 + rg * 4 + r) * Cout + n0 + (nh * NT + j) * 16 + col] = acc[t][j][r];
+  if constexpr (BIAS) {                                      // all 16 rows of accb are the same column sums: row 0
+    if (rg == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) slab[(size_t)(9 * CIN + wave) * Cout + n0 + (nh * NT + j) * 16 + col] = accb[j][0];
+    }
+  }
+}
+// fixed-order sum of the slabs of conv3x3_wgrad_img_kernel<..., BIAS = true>: rows [0, Mw) -> dw, rows Mw .. Mw + G - 1 -> dbias
+__global__ void wgrad_img_reduce_kernel(const float* __restrict__ partial, int S, int Mw, int G, int N, float* __restrict__ dw,
+                                        float* __restrict__ dbias, int accumulate) {
+  const size_t slab = (size_t)(Mw + G) * N, total = (size_t)(Mw + 1) * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t wn = (size_t)Mw * N;
+    float v = 0.f;
+    if (i < wn) {
+      for (int z = 0; z < S; ++z) v += partial[(size_t)z * slab + i];
+      dw[i] = accumulate ? dw[i] + v : v;
+    } else {
+      const size_t n = i - wn;
+      for (int z = 0; z < S; ++z)
+        for (int g = 0; g < G; ++g) v += partial[(size_t)z * slab + wn + (size_t)g * N + n];
+      dbias[n] = accumulate ? dbias[n] + v : v;
+    }
+  }
 }
 
+extern "C" int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N, int lda, float* out, asr_stream s);
+static int conv3x3_bwd_weight_impl(asr_handle* h, const void* x, const void* dy, int Nimg, int H, int W,
+                                   int Cin, int Cout, float* dw, float* dbias, int accumulate, asr_stream s);
 extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* dy, int Nimg, int H, int W,
                                       int Cin, int Cout, float* dw, int accumulate, asr_stream s) {
+  return conv3x3_bwd_weight_impl(h, x, dy, Nimg, H, W, Cin, Cout, dw, nullptr, accumulate, s);
+}
+extern "C" int asr_conv3x3_bwd_weight_bias(asr_handle* h, const void* x, const void* dy, int Nimg, int H, int W,
+                                           int Cin, int Cout, float* dw, float* dbias, asr_stream s) {
+  if (h && !dbias) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_bwd_weight_bias: dbias is NULL");
+  return conv3x3_bwd_weight_impl(h, x, dy, Nimg, H, W, Cin, Cout, dw, dbias, 0, s);
+}
+static int conv3x3_bwd_weight_impl(asr_handle* h, const void* x, const void* dy, int Nimg, int H, int W,
+                                   int Cin, int Cout, float* dw, float* dbias, int accumulate, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   if (!x || !dy || !dw || Nimg < 1 || H < 1 || W < 1)
     ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_bwd_weight: bad args");
@@ -2343,7 +2393,10 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
     const int nth = Cin * 4;
     const int mvx = (HWp * Cin / 8 + nth - 1) / nth, mvy = (HWp * 8 + nth - 1) / nth;   // staged vectors per thread
     const int mv = mvx > mvy ? mvx : mvy;
-    const size_t slab = (size_t)M * N * sizeof(float);
+    static const bool wbias_on = [] { const char* e = getenv("ASR_CONV_WGRAD_BIAS"); return !(e && e[0] == '0'); }();
+    const bool inb = dbias && wbias_on;                      // bias gradient inside the weight-gradient kernel
+    const int G = inb ? Cin / 16 : 0;
+    const size_t slab = (size_t)(M + G) * N * sizeof(float);
     size_t wgs = (h->scratch_bytes - ASR_XCH_BYTES) / slab;
     const size_t cols = (size_t)(Cout / 64);
     if (wgs * cols > (size_t)h->num_cu) wgs = (size_t)h->num_cu / cols;
@@ -2353,7 +2406,7 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
         lds <= (size_t)158 * 1024 && mv <= 14 && nchunk * 2 >= mv && wgs >= 32) {
 #define ASR_WGRAD_IMG(CI, VX, VY, NS)                                                                                  \
   do {                                                                                                                 \
-    auto kern = conv3x3_wgrad_img_kernel<CI, VX, VY, NS>;                                                              \
+    auto kern = inb ? conv3x3_wgrad_img_kernel<CI, VX, VY, NS, true> : conv3x3_wgrad_img_kernel<CI, VX, VY, NS, false>; \
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs, (unsigned)cols), dim3(CI * 4 * NS), lds, st, Nimg, H, W, Cout,        \
                        (const bf16_t*)x, (const bf16_t*)dy, partial);                                                  \
@@ -2368,9 +2421,14 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
       const size_t total = (size_t)M * N;
       int blocks = (int)((total + 255) / 256);
       if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, partial, (int)wgs, M, N, dw, N, nullptr,
-                         accumulate, 0, 0);
+      if (inb)
+        hipLaunchKernelGGL(wgrad_img_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, (int)wgs, M, G, N, dw, dbias,
+                           accumulate);
+      else
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, partial, (int)wgs, M, N, dw, N,
+                           nullptr, accumulate, 0, 0);
       ASR_CHECK_LAUNCH(h, "asr_conv3x3_bwd_weight(image-resident)");
+      if (dbias && !inb) return asr_colsum(h, ASR_BF16, dy, Mpix, Cout, Cout, dbias, s);
       return ASR_OK;
     }
   }
@@ -2392,6 +2450,7 @@ extern "C" int asr_conv3x3_bwd_weight(asr_handle* h, const void* x, const void* 
   hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, partial, S, M, N, dw, N, nullptr,
                      accumulate, 0, 0);
   ASR_CHECK_LAUNCH(h, "asr_conv3x3_bwd_weight");
+  if (dbias) return asr_colsum(h, ASR_BF16, dy, Mpix, Cout, Cout, dbias, s);
   return ASR_OK;
 }
 

@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void conv3x3_smallc_wgrad_mfma_kernel(const bf
         const int tap = k / CIN, ci = k - tap * CIN;
         const int hs = h + tap / 3 - 1, ws = w + tap % 3 - 1;
         const bool ok = valid && k < K && hs >= 0 && hs < H && ws >= 0 && ws < W;
-        pv[j >> 3][j & 7] = ok ? xn[(hs * W + ws) * CIN + ci] : (bf16_t)0;
+        // (k == K < 32: a column of ONES -- row K of the product is the column sum of dpre, the layer's bias gradient)
+        pv[j >> 3][j & 7] = ok ? xn[(hs * W + ws) * CIN + ci] : (bf16_t)((valid && k == K) ? 0x3F80 : 0);
       }
       char* prow = my + half * SCW_SUB + px * 32;
       *reinterpret_cast<us8_t*>(prow) = pv[0];
@@ -486,9 +487,9 @@ __global__ __launch_bounds__(256) void conv3x3_smallc_wgrad_mfma_kernel(const bf
   }
 }
 __global__ void conv3x3_smallc_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int K,
-                                                   float* __restrict__ dw) {
+                                                   float* __restrict__ dw, float* __restrict__ dbias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= K * SC_CO) return;
+  if (i >= (K + (dbias ? 1 : 0)) * SC_CO) return;
   float s = 0.f;
   for (int b0 = 0; b0 < nblk; b0 += 16) {
     float v[16];
@@ -497,7 +498,8 @@ __global__ void conv3x3_smallc_wgrad_reduce_kernel(const float* __restrict__ par
 #pragma unroll
     for (int q = 0; q < 16; ++q) s += v[q];
   }
-  dw[i] = s;
+  if (i < K * SC_CO) dw[i] = s;
+  else dbias[i - K * SC_CO] = s;                            // row K: the ones column of the matrix-core kernel
 }
 
 // Pooling backward, dropout on the pooled gradient and the ReLU backward of the convolution below the pool in ONE pass,
@@ -743,8 +745,20 @@ static int smallc_fwd_launch(asr_handle* h, const void* x, int N, int H, int W, 
   ASR_CHECK_LAUNCH(h, "asr_conv3x3_smallc_fwd");
   return ASR_OK;
 }
+extern "C" int asr_colsum(asr_handle* h, int dtype, const void* a, int M, int N, int lda, float* out, asr_stream s);
+static int smallc_bwd_weight_impl(asr_handle* h, const void* x, const void* dpre, int N, int H, int W, int Cin, int Cout,
+                                  float* dw, float* dbias, asr_stream s);
 extern "C" int asr_conv3x3_smallc_bwd_weight(asr_handle* h, const void* x, const void* dpre, int N, int H, int W, int Cin,
                                             int Cout, float* dw, asr_stream s) {
+  return smallc_bwd_weight_impl(h, x, dpre, N, H, W, Cin, Cout, dw, nullptr, s);
+}
+extern "C" int asr_conv3x3_smallc_bwd_weight_bias(asr_handle* h, const void* x, const void* dpre, int N, int H, int W,
+                                                 int Cin, int Cout, float* dw, float* dbias, asr_stream s) {
+  if (h && !dbias) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_conv3x3_smallc_bwd_weight_bias: dbias is NULL");
+  return smallc_bwd_weight_impl(h, x, dpre, N, H, W, Cin, Cout, dw, dbias, s);
+}
+static int smallc_bwd_weight_impl(asr_handle* h, const void* x, const void* dpre, int N, int H, int W, int Cin, int Cout,
+                                  float* dw, float* dbias, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   VGG_NEED(x && dpre && dw && N >= 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 3 && Cout == SC_CO &&
                ((uintptr_t)dpre) % 16 == 0, "asr_conv3x3_smallc_bwd_weight: needs Cin <= 3, Cout == 64");
@@ -770,9 +784,12 @@ extern "C" int asr_conv3x3_smallc_bwd_weight(asr_handle* h, const void* x, const
   else if (Cin == 1) ASR_SC_WG(1); else if (Cin == 2) ASR_SC_WG(2); else ASR_SC_WG(3);
 #undef ASR_SC_WG_M
 #undef ASR_SC_WG
-  hipLaunchKernelGGL(conv3x3_smallc_wgrad_reduce_kernel, dim3((9 * Cin * SC_CO + 255) / 256), dim3(256), 0,
-                     (hipStream_t)s, partial, nblk, 9 * Cin, dw);
+  static const bool wbias_on = [] { const char* e = getenv("ASR_CONV_WGRAD_BIAS"); return !(e && e[0] == '0'); }();
+  float* inb = (dbias && mfma && wbias_on) ? dbias : nullptr;      // bias gradient = row 9 Cin of the matrix-core kernel's product
+  hipLaunchKernelGGL(conv3x3_smallc_wgrad_reduce_kernel, dim3(((9 * Cin + 1) * SC_CO + 255) / 256), dim3(256), 0,
+                     (hipStream_t)s, partial, nblk, 9 * Cin, dw, inb);
   ASR_CHECK_LAUNCH(h, "asr_conv3x3_smallc_bwd_weight");
+  if (dbias && !inb) return asr_colsum(h, ASR_BF16, dpre, (int)npix, Cout, Cout, dbias, s);
   return ASR_OK;
 }
 extern "C" int asr_maxpool2x2_relu_bwd(asr_handle* h, int dtype, const float* dout, const uint8_t* argmax,

@@ -237,8 +237,7 @@ class _VGGFrontEnd(object):
                 dpre = ops.relu_bwd_scaled(dout.contiguous(), out, mask[0])
             else:
                 dpre = ops.relu_bwd(dout.contiguous(), out, drop=mask)         # [N,H,W,cout] bf16
-            ops.conv3x3_bwd_weight(x_in, dpre, gw)
-            ops.colsum(dpre.view(N * H * W, cout), out=gb)
+            ops.conv3x3_bwd_weight_bias(x_in, dpre, gw, gb)
             if not need_dx:
                 return None
             if below is not None:
@@ -252,8 +251,7 @@ class _VGGFrontEnd(object):
                 dpre = ops.relu_bwd_scaled(dout.contiguous(), out, mask[0])
             else:
                 dpre = ops.relu_bwd(dout.contiguous(), out, drop=mask)
-            ops.conv3x3_smallc_bwd_weight(x_in, dpre, gw)
-            ops.colsum(dpre.view(N * H * W, cout), out=gb)
+            ops.conv3x3_smallc_bwd_weight_bias(x_in, dpre, gw, gb)
             return None
         w2d = sh[self.prefix + name + '/weight'].view(9 * cin, cout)
         ldp = (9 * cin + 7) // 8 * 8

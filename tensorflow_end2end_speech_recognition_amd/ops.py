@@ -472,6 +472,20 @@ def conv3x3_smallc_bwd_weight(x_nhwc, dpre_nhwc, dw):
     return dw
 
 
+def conv3x3_smallc_bwd_weight_bias(x_nhwc, dpre_nhwc, dw, dbias):
+    """conv3x3_smallc_bwd_weight + dbias fp32 [64] = column sums of dpre, in the same two launches."""
+    h = _h(x_nhwc)
+    _chk(x_nhwc, torch.bfloat16, 'x')
+    _chk(dpre_nhwc, torch.bfloat16, 'dpre')
+    _chk(dbias, torch.float32, 'dbias')
+    N, H, W, Cin = x_nhwc.shape
+    if dbias.numel() != dpre_nhwc.shape[-1]:
+        raise ValueError('conv3x3_smallc_bwd_weight_bias: dbias has %d elements' % dbias.numel())
+    h.check(h.lib.asr_conv3x3_smallc_bwd_weight_bias(h.h, _p(x_nhwc), _p(dpre_nhwc), N, H, W, Cin, dpre_nhwc.shape[-1],
+                                                     _p(dw), _p(dbias), _s()), 'asr_conv3x3_smallc_bwd_weight_bias')
+    return dw, dbias
+
+
 def conv3x3_bwd_data_relu(dy_nhwc, wt_bwd, act_below, drop=None, dropped=False):
     """relu_bwd(conv3x3_bwd_data(dy, wt_bwd), act_below, drop=drop) without the fp32 gradient in between -> bf16."""
     h = _h(dy_nhwc)
@@ -499,6 +513,22 @@ def conv3x3_bwd_weight(x_nhwc, dy_nhwc, dw, accumulate=False):
     h.check(h.lib.asr_conv3x3_bwd_weight(h.h, _p(x_nhwc), _p(dy_nhwc), N, H, W, Cin, Cout, _p(dw),
                                          int(accumulate), _s()), 'asr_conv3x3_bwd_weight')
     return dw
+
+
+def conv3x3_bwd_weight_bias(x_nhwc, dy_nhwc, dw, dbias):
+    """dw: fp32 [9*Cin, Cout] view of the HWIO gradient, dbias: fp32 [Cout] = column sums of dy -- one call, the bias sums
+    from the dy images the weight-gradient kernel stages anyway (asr_conv3x3_bwd_weight_bias)."""
+    h = _h(x_nhwc)
+    _chk(x_nhwc, torch.bfloat16, 'x')
+    _chk(dy_nhwc, torch.bfloat16, 'dy')
+    _chk(dbias, torch.float32, 'dbias')
+    N, H, W, Cin = x_nhwc.shape
+    Cout = dy_nhwc.shape[3]
+    if dbias.numel() != Cout:
+        raise ValueError('conv3x3_bwd_weight_bias: dbias has %d elements, Cout = %d' % (dbias.numel(), Cout))
+    h.check(h.lib.asr_conv3x3_bwd_weight_bias(h.h, _p(x_nhwc), _p(dy_nhwc), N, H, W, Cin, Cout, _p(dw), _p(dbias), _s()),
+            'asr_conv3x3_bwd_weight_bias')
+    return dw, dbias
 
 
 def im2col3x3(x_nhwc, ldp=None, out=None):

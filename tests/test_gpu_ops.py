@@ -68,6 +68,16 @@ def test_conv3x3_implicit_gemm(cuda, N, H, W, Cin, Cout):
     assert _rel(dw.cpu().numpy(), refw) < 1e-5
     ops.conv3x3_bwd_weight(x.to(cuda), dy.to(cuda), dw, accumulate=True)
     assert _rel(dw.cpu().numpy(), 2 * refw) < 1e-5
+    # weight and bias gradient in one call (the bias sums from the dY images the weight-gradient kernel has staged):
+    # bit-identical weights, bias = column sums of dY
+    dw2 = torch.full((9 * Cin, Cout), 7.0, device=cuda)
+    db = torch.full((Cout,), 7.0, device=cuda)
+    ops.conv3x3_bwd_weight_bias(x.to(cuda), dy.to(cuda), dw2, db)
+    dw1 = torch.zeros(9 * Cin, Cout, device=cuda)
+    ops.conv3x3_bwd_weight(x.to(cuda), dy.to(cuda), dw1)
+    assert torch.equal(dw1, dw2)
+    refb = dy.double().sum(dim=(0, 1, 2)).numpy()
+    assert np.abs(db.cpu().numpy() - refb).max() < 1e-5 * max(1.0, float(dy.double().abs().sum(dim=(0, 1, 2)).max()))
 
 
 # --------------------------------------------------------------------------- GEMM
@@ -1147,6 +1157,13 @@ def test_direct_convolution_of_the_few_channel_first_layer(cuda, N, H, W, Cin):
     ops.conv3x3_smallc_bwd_weight(x.to(cuda), dpre.to(cuda), dw)
     ref_dw = w64.grad.permute(2, 3, 1, 0).reshape(9 * Cin, Cout).numpy()
     assert np.abs(dw.cpu().numpy() - ref_dw).max() < 2e-5 * max(1.0, np.abs(ref_dw).max())
+    # + the bias gradient from a column of ones in the patch operand: the same weights bit for bit, bias = column sums
+    dw2 = torch.full((9 * Cin, Cout), 5.0, device=cuda)
+    db = torch.full((Cout,), 5.0, device=cuda)
+    ops.conv3x3_smallc_bwd_weight_bias(x.to(cuda), dpre.to(cuda), dw2, db)
+    assert torch.equal(dw, dw2)
+    refb = dpre.double().sum(dim=(0, 1, 2)).numpy()
+    assert np.abs(db.cpu().numpy() - refb).max() < 1e-5 * max(1.0, float(dpre.double().abs().sum(dim=(0, 1, 2)).max()))
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,drop', [(3, 40, 11, 64, 64, True), (2, 20, 6, 64, 128, False), (2, 20, 6, 128, 128, True),
