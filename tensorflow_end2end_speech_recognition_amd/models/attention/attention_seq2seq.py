@@ -20,6 +20,8 @@ written to express: the previous step's weights go through conv1d([201|200,1,10]
 energy kernel (csrc/attention.hip asr_att_loc_energy_*), with gradients into `filter`, W_filter and, through the
 previous step's softmax, everything upstream.
 """
+import os as _os
+
 import numpy as np
 import torch
 
@@ -38,6 +40,9 @@ from .decoders.attention_layer import AttentionLayer
 
 D = 'attention_decoder/decoder/'
 AT = D + 'attention_layer/'
+
+
+ATT_BWD_BF16 = _os.environ.get('ASR_ATT_BWD_BF16', '1') != '0'
 
 
 class AttentionSeq2Seq(ModelBase):
@@ -390,16 +395,32 @@ class AttentionSeq2Seq(ModelBase):
         dlogits = tp['dlogits']
         W_out, W_av = st[D + 'output_layer/weights'], st[D + 'attentional_vector/weights']
         dav_pre = ops.tanh_bwd(ops.gemm(dlogits, W_out, transB=True), av)
+        # bf16-operand model: the batched products of the BACKWARD pass outside the loop (everything below that multiplies
+        # two [steps x utterances]- or [frames x utterances]-long arrays) round their operands to bf16 like the encoder's
+        # dx / weight-gradient products do, and run on the bf16 matrix pipe instead of the 1/16-rate fp32 one: 2 ms of
+        # the cfg-D-shaped step (profiles/r05_cfgD_timeline.md).  The forward keeps its fp32 products (the oracle's
+        # rounding points, oracle/attention.py).  ASR_ATT_BWD_BF16=0: fp32 as in an fp32 model.
+        b16 = self.dtype == ASR_BF16 and ATT_BWD_BF16
+        dav16 = dav_pre.to(torch.bfloat16) if b16 else None
         # weight gradients are nobody's input until the optimizer: they go to the side lane (joined by encoder.backward
         # / the end of this function) and run beside the reverse loop and the encoder's BPTT
-        with ops.side_lane(dev, keep=(av, dlogits, av_in, dav_pre), lane=1):
+        with ops.side_lane(dev, keep=(av, dlogits, av_in, dav_pre, dav16), lane=1):
             ops.gemm(av, dlogits, transA=True, out=st.g(D + 'output_layer/weights'))
             ops.colsum(dlogits, out=st.g(D + 'output_layer/biases'))
-            ops.gemm(av_in.view(To * Bp, U + E2), dav_pre, transA=True, out=st.g(D + 'attentional_vector/weights'))
+            if b16:
+                ops.gemm(av_in.view(To * Bp, U + E2).to(torch.bfloat16), dav16, transA=True,
+                         out=st.g(D + 'attentional_vector/weights'))
+            else:
+                ops.gemm(av_in.view(To * Bp, U + E2), dav_pre, transA=True, out=st.g(D + 'attentional_vector/weights'))
         # gradient of the attentional vector's inputs, as two contiguous arrays (cell output | context): a step's rows
         # are then the buffers the loop works in, not slices that have to be copied out first
-        dav_cell = ops.gemm(dav_pre, W_av[:U], transB=True).view(To, Bp, U)
-        dav_ctx = ops.gemm(dav_pre, W_av[U:], transB=True).view(To, Bp, E2)
+        if b16:
+            W16 = W_av.to(torch.bfloat16)
+            dav_cell = ops.gemm(dav16, W16[:U], transB=True, out_dtype=torch.float32).view(To, Bp, U)
+            dav_ctx = ops.gemm(dav16, W16[U:], transB=True, out_dtype=torch.float32).view(To, Bp, E2)
+        else:
+            dav_cell = ops.gemm(dav_pre, W_av[:U], transB=True).view(To, Bp, U)
+            dav_ctx = ops.gemm(dav_pre, W_av[U:], transB=True).view(To, Bp, E2)
         # ---- the recurrence, backwards
         # d_enc starts as the CTC head's part (joint model) -- one GEMM that needs nothing from the decoder, issued on
         # side lane 2 so that it runs beside the reverse loop; the first accumulation into d_enc waits for it
@@ -441,11 +462,23 @@ class AttentionSeq2Seq(ModelBase):
         # ---- d_enc[:, b, :] += alpha_b^T [T, To] . dctx_b [To, 2H]   (context path of all steps at once)
         alpha_all = tp['alpha_all']
         ops.wait_event(ctc_denc_event)
-        for b in range(tp['B']):
-            ops.gemm(alpha_all[:, b, :], dctx_all[:, b, :], transA=True, out=denc[:, b, :], accumulate=True)
+        if b16:
+            # (rows of 8-element vectors: the frame axis padded to a multiple of 8 so that every utterance's block is aligned)
+            Tp8 = (T + 7) // 8 * 8
+            a16 = torch.zeros((To, Bp, Tp8), dtype=torch.bfloat16, device=dev)
+            a16[:, :, :T].copy_(alpha_all)
+            c16 = dctx_all.to(torch.bfloat16)
+            for b in range(tp['B']):
+                ops.gemm(a16[:, b, :T], c16[:, b, :], transA=True, out=denc[:, b, :], accumulate=True)
+        else:
+            for b in range(tp['B']):
+                ops.gemm(alpha_all[:, b, :], dctx_all[:, b, :], transA=True, out=denc[:, b, :], accumulate=True)
         dq2d = dqz_all.view(To * Bp, -1)
         dk2d = dkeys.view(T * Bp, -1) if at in AL.USES_KEYS else None
-        if dk2d is not None:
+        dk16 = dk2d.to(torch.bfloat16) if (b16 and dk2d is not None) else None
+        if dk16 is not None:
+            ops.gemm(dk16, self._wk().to(torch.bfloat16), transB=True, out=denc.view(T * Bp, E2), accumulate=True)
+        elif dk2d is not None:
             ops.gemm(dk2d, self._wk(), transB=True, out=denc.view(T * Bp, E2), accumulate=True)
         # bridge
         dinit = torch.cat([dc_next, dh_next], dim=1).contiguous()
@@ -455,10 +488,15 @@ class AttentionSeq2Seq(ModelBase):
         dhf = torch.stack([dbi[:, H:2 * H], dbi[:, 3 * H:]]).contiguous()
         # ---- weight gradients of everything inside the loop, batched over the steps -- on the side lane
         side_keep = [t for t in (dec_in, dpre_all, dpeep_all, dqz_all, dv_all, dwfil_rows, dfilt_rows, dkeys, enc,
-                                 d_in_all, av_in, dinit, tp['bi'], tp['ids'], tp['emb_mask']) if t is not None]
+                                 d_in_all, av_in, dinit, tp['bi'], tp['ids'], tp['emb_mask'], dk16, tp['enc_att'])
+                     if t is not None]
         with ops.side_lane(dev, keep=side_keep, lane=1):
-            ops.gemm(dec_in.view(To * Bp, -1), dpre_all.view(To * Bp, 4 * U), transA=True,
-                     out=st.g(D + 'lstm_cell/kernel'))
+            if b16:     # 84 GFLOP at cfg D: 1.38 ms on the fp32 pipe beside the top encoder layer's BPTT
+                ops.gemm(dec_in.view(To * Bp, -1).to(torch.bfloat16), dpre_all.view(To * Bp, 4 * U).to(torch.bfloat16),
+                         transA=True, out=st.g(D + 'lstm_cell/kernel'))
+            else:
+                ops.gemm(dec_in.view(To * Bp, -1), dpre_all.view(To * Bp, 4 * U), transA=True,
+                         out=st.g(D + 'lstm_cell/kernel'))
             ops.colsum(dpre_all.view(To * Bp, 4 * U), out=st.g(D + 'lstm_cell/bias'))
             if self.use_peephole:
                 dp = ops.colsum(dpeep_all.view(To * Bp, 3 * U))
@@ -475,7 +513,10 @@ class AttentionSeq2Seq(ModelBase):
             if self.att_mode == 0:
                 ops.colsum(dv_all.view(To * Bp, -1), out=st.g(AT + 'v_a'))
             if dk2d is not None:
-                ops.gemm(enc.view(T * Bp, E2), dk2d, transA=True, out=self._wk(grad=True))
+                if dk16 is not None:
+                    ops.gemm(tp['enc_att'].view(T * Bp, E2), dk16, transA=True, out=self._wk(grad=True))
+                else:
+                    ops.gemm(enc.view(T * Bp, E2), dk2d, transA=True, out=self._wk(grad=True))
                 if (AT + 'W_keys/biases') in st.views:
                     ops.colsum(dk2d, out=st.g(AT + 'W_keys/biases'))
             # embedding
