@@ -765,6 +765,12 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_f32_kernel(int M, i
   // Frags, 154 / 108 registers -- the cell launch takes 12.7 us against 11.4 and the 8-unit query product 5.9 against 4.9:
   // the launch is not a chain of weight trips, it is the fp32 matrix rate (128 16x16x4 multiplies of 32 cycles per wave,
   // two waves per SIMD: 3.4 us) plus launch and epilogue; bf16 weights alone therefore buy only ~1 %.)
+  // (Round 5, measured: the activations split by the loading lane into hi + lo bf16 terms and multiplied as two
+  // v_mfma_f32_16x16x32_bf16 per 32-wide chunk -- 8 x fewer matrix cycles, VERDICT r04 item 4(i) -- leaves both launches where
+  // they were: cell product 11.3 -> 11.1 us, backward product 8.6 -> 8.6, cfg D step 69.0 -> 68.9 ms.  The fp32 multiplies
+  // were already hidden under the weight trips: the attention kernels stream 69 MB between two steps, so the 6.5 MB of
+  // W_cell come from the memory side every step and a launch is launch + two to four dependent ~2 us trips + the
+  // eight-wave reduction.  Not kept: the exact products cost nothing.)
   Frag f0, f1;
   load(0, f0);
   if (units <= SK_WAVES) {                  // one round: nothing to overlap
