@@ -427,6 +427,9 @@ __global__ __launch_bounds__(256) void att_softmax_kernel(const float* __restric
 
 // encoder rows are read either as fp32 or from the bf16 operand copy the encoder already keeps (half the bytes
 // of the two per-step streams over [T,B,2H])
+// (Round 5, measured: the non-temporal hint on these streams -- to keep the decoder cell's 6.5 MB weight image in the L2s
+// between two steps -- makes them SLOWER, att_fused_fwd 15.9 -> 19.8 us, att_dalpha_vec 15.1 -> 19.0, and the cell product
+// no faster (11.4 us): the 69 MB of a step live in the 256 MB memory-side cache from one step to the next, which nt bypasses.)
 __device__ __forceinline__ f32x4_t enc_ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
 __device__ __forceinline__ f32x4_t enc_ld4(const bf16_t* p) {
   typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
