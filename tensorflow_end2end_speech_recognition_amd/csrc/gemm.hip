@@ -426,6 +426,9 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(int M, int N, int K, 
 // (torch.matmul -> hipBLASLt with a bf16 result reaches 420 / 1 029 / 1 237 on the same operands.)  Same staging scheme (next k-tile's global loads in flight during the MFMAs, one barrier
 // per k-tile), same transposed accumulators and epilogue; the staging loads are buffer loads (descriptor in SGPRs, a
 // per-lane 32-bit byte offset that never changes, the k-tile's offset in one SGPR).
+// (Round 5, measured: a PERSISTENT form -- 256 / 512 workgroups walking the tiles, the next tile's first k-tile requested
+// before the epilogue's stores -- is 2 % SLOWER on every cfg C / D projection (1178 -> 1206 us, 493 -> 516 us): the
+// dispatcher already replaces a finished workgroup faster than the epilogue drains.  scripts/bench_nt.py.)
 template <typename TO, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_nt_bf16_big_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
                                                                            int lda, const bf16_t* __restrict__ Bt, int ldb,
