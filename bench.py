@@ -180,6 +180,7 @@ def time_steps(step, steps, warmup, world, dev_index, timed_ops=('lstm_fwd', 'ls
     return dict(elapsed=elapsed, final_loss=float(loss.item()), kernels=timer.summary(),
                 handoff_flags=ops.check_async_errors(dev_index),   # sticky error word of the multi-CU recurrence kernels
                 step_ms=dict(median=float(np.median(per_step)), min=float(per_step.min()), max=float(per_step.max()),
+                             slow_steps=[[int(i), round(float(per_step[i]), 3)] for i in np.flatnonzero(per_step > 1.15 * np.median(per_step))[:10]],
                              host_issue_mean=(host - waited) / steps * 1e3, host_wait_for_device_mean=waited / steps * 1e3,
                              note='HIP events between steps on the launch stream; host_issue = Python + C time to enqueue '
                                   'one step; host_wait_for_device = time the issue loop spent blocked because it was '

@@ -24,6 +24,8 @@ cp('statsA.md', 'r05_cfgA_kernel_trace.md')
 cp('gpu_tests.txt', 'r05_gpu_tests.txt')
 cp('cfgC/stats.md', 'r05_cfgC_kernel_trace.md')
 cp('cfgD/stats.md', 'r05_cfgD_kernel_trace.md')
+cp('cfgC/timeline.md', 'r05_cfgC_timeline.md')
+cp('cfgD/timeline.md', 'r05_cfgD_timeline.md')
 
 
 def pmc(dirname):

@@ -31,6 +31,15 @@ rm -rf $OUT/traceA
 bash scripts/r04_pmc.sh $OUT/pmc > $OUT/pmc.log 2>&1
 bash scripts/r04_pmc.sh $OUT/pmcA "$A" > $OUT/pmcA.log 2>&1
 grep "lstm_fwd\|lstm_bwd\|optimizer" $OUT/pmc/*.txt $OUT/pmcA/*.txt | cut -c1-220
-bash scripts/r02_trace_cfgC.sh $OUT/cfgC > $OUT/cfgC.log 2>&1
-bash scripts/r02_trace_cfgD.sh $OUT/cfgD > $OUT/cfgD.log 2>&1
+# cfg C / cfg D shaped steps: kernel statistics + timeline of one step
+mkdir -p $OUT/cfgC $OUT/cfgD
+ONLY_C=1 rocprofv3 --kernel-trace --stats -d $OUT/cfgC/trace -o cfgC -- python scripts/probe_cfgCE.py > $OUT/cfgC/probe.log 2>&1
+DB=$(find $OUT/cfgC/trace -name '*.db' | head -1)
+python scripts/rocpd_stats.py "$DB" $OUT/cfgC/stats.md > /dev/null; python scripts/rocpd_timeline.py "$DB" $OUT/cfgC/timeline.md > /dev/null
+rm -rf $OUT/cfgC/trace
+rocprofv3 --kernel-trace --stats -d $OUT/cfgD/trace -o cfgD -- python scripts/probe_cfgD.py > $OUT/cfgD/probe.log 2>&1
+DB=$(find $OUT/cfgD/trace -name '*.db' | head -1)
+python scripts/rocpd_stats.py "$DB" $OUT/cfgD/stats.md > /dev/null; python scripts/rocpd_timeline.py "$DB" $OUT/cfgD/timeline.md > /dev/null
+rm -rf $OUT/cfgD/trace
+grep cfgC $OUT/cfgC/probe.log | tail -1; grep "^it" $OUT/cfgD/probe.log | tail -1 | cut -c1-120
 ls $OUT
