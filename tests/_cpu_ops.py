@@ -865,6 +865,18 @@ def _conv3x3_smallc_bwd_weight(x, dpre, dw):
     return dw
 
 
+def _conv3x3_bwd_weight_bias(x, dy, dw, dbias):
+    _conv3x3_bwd_weight(x, dy, dw)
+    dbias.copy_(dy.double().sum(dim=(0, 1, 2)).float())
+    return dw, dbias
+
+
+def _conv3x3_smallc_bwd_weight_bias(x, dpre, dw, dbias):
+    _conv3x3_smallc_bwd_weight(x, dpre, dw)
+    dbias.copy_(dpre.double().sum(dim=(0, 1, 2)).float())
+    return dw, dbias
+
+
 def _maxpool2x2_fwd_drop(x, drop):
     out, arg = _maxpool2x2_fwd(x)
     return _dropout_apply(out.float(), *drop).to(x.dtype), arg
@@ -895,6 +907,7 @@ STAND_INS = dict(
     conv3x3_bwd_data=_conv3x3_bwd_data, conv3x3_bwd_data_relu=_conv3x3_bwd_data_relu, conv3x3_bwd_weight=_conv3x3_bwd_weight,
     conv3x3_smallc_fwd=_conv3x3_smallc_fwd, conv3x3_smallc_fwd_drop=_conv3x3_smallc_fwd_drop,
     conv3x3_smallc_bwd_weight=_conv3x3_smallc_bwd_weight, maxpool2x2_fwd_drop=_maxpool2x2_fwd_drop,
+    conv3x3_bwd_weight_bias=_conv3x3_bwd_weight_bias, conv3x3_smallc_bwd_weight_bias=_conv3x3_smallc_bwd_weight_bias,
     relu_bwd_scaled=_relu_bwd_scaled,
 )
 

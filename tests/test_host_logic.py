@@ -359,7 +359,12 @@ def test_bf16_model_multiplies_with_the_rounded_decoder_kernel_everywhere(monkey
     _cpu_ops.install(monkeypatch)
     from oracle import attention as oatt
     from oracle import lstm as olstm
+    from tensorflow_end2end_speech_recognition_amd.models.attention import attention_seq2seq as S
     from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
+    # (ASR_ATT_BWD_BF16 off for this check: with the backward's batched products on bf16 operands -- the device default
+    # for a bf16 model since round 5 -- the gradients differ from the oracle by bf16 rounding, 7e-3, like the encoder's; the
+    # statement below isolates the FORWARD rounding point)
+    monkeypatch.setattr(S, 'ATT_BWD_BF16', False)
     rng = np.random.RandomState(11)
     B, T, D, H, L, A, Em, C, U = 3, 9, 6, 8, 1, 10, 4, 6, 12
     x, sl, labels, lsl, _ = _att_batch(rng, B, T, D, C)
