@@ -15,6 +15,8 @@ frames (CHUNK_FRAMES) so the patch matrix is a bounded scratch; backward recompu
 """
 import os
 
+import os as _os
+
 import numpy as np
 import torch
 
@@ -26,6 +28,7 @@ from .lstm import LSTMEncoder
 
 CONVS = [('VGG1/conv1', 3, 64), ('VGG1/conv2', 64, 64), ('VGG2/conv1', 64, 128), ('VGG2/conv2', 128, 128)]
 CHUNK_FRAMES = 4096
+VGG_WGRAD_SIDE = _os.environ.get('ASR_VGG_WGRAD_SIDE', '1') != '0'   # weight gradients of the implicit-GEMM layers on side lane 1
 
 
 def _trunc_normal(rng, std, shape):
@@ -237,7 +240,14 @@ class _VGGFrontEnd(object):
                 dpre = ops.relu_bwd_scaled(dout.contiguous(), out, mask[0])
             else:
                 dpre = ops.relu_bwd(dout.contiguous(), out, drop=mask)         # [N,H,W,cout] bf16
-            ops.conv3x3_bwd_weight_bias(x_in, dpre, gw, gb)
+            if VGG_WGRAD_SIDE and need_dx:
+                # nobody waits for the weight gradient: side lane, beside the data gradient and the (HBM-bound) un-pooling
+                # pass that follow on the main stream; joined at the end of backward()
+                with ops.side_lane(dpre.device, keep=(x_in, dpre), lane=1):
+                    ops.conv3x3_bwd_weight_bias(x_in, dpre, gw, gb)
+                self._side_used = True
+            else:
+                ops.conv3x3_bwd_weight_bias(x_in, dpre, gw, gb)
             if not need_dx:
                 return None
             if below is not None:
@@ -317,6 +327,9 @@ class _VGGFrontEnd(object):
                               below=(c['a1'], m.get('a1'), fd) if fuse21 else None)
         self._conv_bwd(da1d, c['a1'], m.get('a1'), c['x0'], CONVS[0], sh, need_dx=False, dout_is_dpre=fuse21,
                        out_dropped=fd)
+        if getattr(self, '_side_used', False):
+            ops.join_side(dout_btd.device)
+            self._side_used = False
         self.ctx = None
 
 
