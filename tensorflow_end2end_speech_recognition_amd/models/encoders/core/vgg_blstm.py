@@ -28,6 +28,8 @@ from .lstm import LSTMEncoder
 
 CONVS = [('VGG1/conv1', 3, 64), ('VGG1/conv2', 64, 64), ('VGG2/conv1', 64, 128), ('VGG2/conv2', 128, 128)]
 CHUNK_FRAMES = 4096
+VGG_FWD_CHUNK_MIN = 2048     # images per run below which the single pass is kept
+VGG_FWD_CHUNKS = int(_os.environ.get('ASR_VGG_FWD_CHUNKS', '2'))        # runs of images the fused bf16 forward goes through on separate lanes
 VGG_WGRAD_SIDE = _os.environ.get('ASR_VGG_WGRAD_SIDE', '1') != '0'   # weight gradients of the implicit-GEMM layers on side lane 1
 
 
@@ -145,7 +147,51 @@ class _VGGFrontEnd(object):
         fused = (drop and self.dtype == ASR_BF16 and self.fused_drop and self._direct(*CONVS[0][1:]) and
                  all(self._implicit(*c[1:]) for c in CONVS[1:]))      # (.fused_drop = False: the separate passes, A/B + tests)
         self.ctx['fused_drop'] = fused
-        if fused:
+        if fused and VGG_FWD_CHUNKS > 1 and N >= VGG_FWD_CHUNK_MIN * VGG_FWD_CHUNKS:
+            # Round 5: the frames are independent images, and the chain alternates kernels bound by different things (the
+            # first layer by its Philox rounds, the 64 / 128-channel convolutions by the matrix pipe and the LDS, the pools
+            # by HBM).  The images go through in VGG_FWD_CHUNKS contiguous runs, run k on its own lane: two kernels of the
+            # SAME stage cannot share a CU (157 KB of LDS each), so the lanes fall one stage apart by themselves and a
+            # pool of one run streams under the multiplies of the other.  Same kernels on sub-ranges of the same buffers,
+            # the dropout counters shifted by the run's first element: bit-identical to the single pass.
+            F_, W_ = self.F, self.W
+            H2, W2 = (F_ + 1) // 2, (W_ + 1) // 2
+            H4, W4 = (H2 + 1) // 2, (W2 + 1) // 2
+            dev = x0.device
+            bf = torch.bfloat16
+            a1d = torch.empty((N, F_, W_, 64), dtype=bf, device=dev)
+            a2 = torch.empty((N, F_, W_, 64), dtype=bf, device=dev)
+            p1d = torch.empty((N, H2, W2, 64), dtype=bf, device=dev)
+            arg1 = torch.empty((N, H2, W2, 64), dtype=torch.uint8, device=dev)
+            a3d = torch.empty((N, H2, W2, 128), dtype=bf, device=dev)
+            a4 = torch.empty((N, H2, W2, 128), dtype=bf, device=dev)
+            p2d = torch.empty((N, H4, W4, 128), dtype=bf, device=dev)
+            arg2 = torch.empty((N, H4, W4, 128), dtype=torch.uint8, device=dev)
+            w1 = sh[self.prefix + CONVS[0][0] + '/weight'].view(9 * CONVS[0][1], CONVS[0][2])
+            b = [st[self.prefix + c[0] + '/bias'] for c in CONVS]
+            wi = [None, self._conv_images(CONVS[1][0])[0], self._conv_images(CONVS[2][0])[0],
+                  self._conv_images(CONVS[3][0])[0]]
+            d_a1, d_p1, d_a3, d_p2 = descriptor('a1'), descriptor('p1'), descriptor('a3'), descriptor('p2')
+
+            def at(d, first_elem):          # the same dropout stream, entered at element first_elem (a multiple of 4)
+                return (d[0], d[1], d[2] + first_elem // 4)
+
+            def chain(c0, c1):
+                ops.conv3x3_smallc_fwd_drop(x0[c0:c1], w1, b[0], at(d_a1, c0 * F_ * W_ * 64), out=a1d[c0:c1])
+                ops.conv3x3_fwd(a1d[c0:c1], wi[1], b[1], relu=True, out=a2[c0:c1])
+                ops.maxpool2x2_fwd_drop(a2[c0:c1], at(d_p1, c0 * H2 * W2 * 64), out=p1d[c0:c1], arg=arg1[c0:c1])
+                ops.conv3x3_fwd_drop(p1d[c0:c1], wi[2], b[2], at(d_a3, c0 * H2 * W2 * 128), out=a3d[c0:c1])
+                ops.conv3x3_fwd(a3d[c0:c1], wi[3], b[3], relu=True, out=a4[c0:c1])
+                ops.maxpool2x2_fwd_drop(a4[c0:c1], at(d_p2, c0 * H4 * W4 * 128), out=p2d[c0:c1], arg=arg2[c0:c1])
+            bounds = [N * k // VGG_FWD_CHUNKS for k in range(VGG_FWD_CHUNKS + 1)]
+            keep = (x0, a1d, a2, p1d, arg1, a3d, a4, p2d, arg2)
+            for k in range(1, VGG_FWD_CHUNKS):
+                with ops.side_lane(dev, keep=keep, lane=2 + k):
+                    chain(bounds[k], bounds[k + 1])
+            chain(bounds[0], bounds[1])
+            ops.join_side(dev)
+            a1, a3 = a1d, a3d
+        elif fused:
             w1 = sh[self.prefix + CONVS[0][0] + '/weight'].view(9 * CONVS[0][1], CONVS[0][2])
             a1 = a1d = ops.conv3x3_smallc_fwd_drop(x0, w1, st[self.prefix + CONVS[0][0] + '/bias'], descriptor('a1'))
             a2 = self._layer(a1d, CONVS[1], sh)

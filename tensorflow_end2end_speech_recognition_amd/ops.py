@@ -402,24 +402,33 @@ def conv3x3_prep_weights(w_hwio):
     return wf, wb
 
 
-def conv3x3_fwd(x_nhwc, wt_fwd, bias, relu=True):
+def _out_like(out, shape, dtype, device, what):
+    """`out` (a contiguous tensor of exactly this shape / dtype, e.g. a slice of a larger one along the first axis) or a fresh one."""
+    if out is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != dtype or not out.is_contiguous():
+        raise ValueError('%s: out must be a contiguous %s tensor of shape %s' % (what, dtype, tuple(shape)))
+    return out
+
+
+def conv3x3_fwd(x_nhwc, wt_fwd, bias, relu=True, out=None):
     h = _h(x_nhwc)
     _chk(x_nhwc, torch.bfloat16, 'x')
     N, H, W, Cin = x_nhwc.shape
     Cout = wt_fwd.shape[0]
-    out = torch.empty((N, H, W, Cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    out = _out_like(out, (N, H, W, Cout), torch.bfloat16, x_nhwc.device, 'conv3x3_fwd')
     h.check(h.lib.asr_conv3x3_fwd(h.h, _p(x_nhwc), N, H, W, Cin, _p(wt_fwd), _p(bias), Cout, 1 if relu else 0,
                                   _p(out), _s()), 'asr_conv3x3_fwd')
     return out
 
 
-def conv3x3_fwd_drop(x_nhwc, wt_fwd, bias, drop):
+def conv3x3_fwd_drop(x_nhwc, wt_fwd, bias, drop, out=None):
     """dropout_apply(conv3x3_fwd(x, ..., relu=True), *drop) in one launch (the undropped activation is never written)."""
     h = _h(x_nhwc)
     _chk(x_nhwc, torch.bfloat16, 'x')
     N, H, W, Cin = x_nhwc.shape
     Cout = wt_fwd.shape[0]
-    out = torch.empty((N, H, W, Cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    out = _out_like(out, (N, H, W, Cout), torch.bfloat16, x_nhwc.device, 'conv3x3_fwd_drop')
     h.check(h.lib.asr_conv3x3_fwd_drop(h.h, _p(x_nhwc), N, H, W, Cin, _p(wt_fwd), _p(bias), Cout, float(drop[0]),
                                        int(drop[1]), int(drop[2]), _p(out), _s()), 'asr_conv3x3_fwd_drop')
     return out
@@ -448,13 +457,13 @@ def conv3x3_smallc_fwd(x_nhwc, w2d, bias, relu=True):
     return out
 
 
-def conv3x3_smallc_fwd_drop(x_nhwc, w2d, bias, drop):
+def conv3x3_smallc_fwd_drop(x_nhwc, w2d, bias, drop, out=None):
     """dropout_apply(conv3x3_smallc_fwd(x, ..., relu=True), *drop) in one launch."""
     h = _h(x_nhwc)
     _chk(x_nhwc, torch.bfloat16, 'x')
     _chk(w2d, torch.bfloat16, 'w2d')
     N, H, W, Cin = x_nhwc.shape
-    out = torch.empty((N, H, W, w2d.shape[1]), dtype=torch.bfloat16, device=x_nhwc.device)
+    out = _out_like(out, (N, H, W, w2d.shape[1]), torch.bfloat16, x_nhwc.device, 'conv3x3_smallc_fwd_drop')
     h.check(h.lib.asr_conv3x3_smallc_fwd_drop(h.h, _p(x_nhwc), N, H, W, Cin, _p(w2d), _p(bias), w2d.shape[1],
                                               float(drop[0]), int(drop[1]), int(drop[2]), _p(out), _s()),
             'asr_conv3x3_smallc_fwd_drop')
@@ -588,13 +597,13 @@ def maxpool2x2_fwd(x_nhwc):
     return out, arg
 
 
-def maxpool2x2_fwd_drop(x_nhwc, drop):
+def maxpool2x2_fwd_drop(x_nhwc, drop, out=None, arg=None):
     """dropout_apply(maxpool2x2_fwd(x)[0], *drop) and the argmax in one launch."""
     h = _h(x_nhwc)
     dt = dtype_id(x_nhwc.dtype)
     N, H, W, Cc = x_nhwc.shape
-    out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, Cc), dtype=x_nhwc.dtype, device=x_nhwc.device)
-    arg = torch.empty(out.shape, dtype=torch.uint8, device=x_nhwc.device)
+    out = _out_like(out, (N, (H + 1) // 2, (W + 1) // 2, Cc), x_nhwc.dtype, x_nhwc.device, 'maxpool2x2_fwd_drop')
+    arg = _out_like(arg, tuple(out.shape), torch.uint8, x_nhwc.device, 'maxpool2x2_fwd_drop(arg)')
     h.check(h.lib.asr_maxpool2x2_fwd_drop(h.h, dt, _p(x_nhwc), N, H, W, Cc, _p(out), _p(arg), float(drop[0]), int(drop[1]),
                                           int(drop[2]), _s()), 'asr_maxpool2x2_fwd_drop')
     return out, arg

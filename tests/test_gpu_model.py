@@ -971,9 +971,10 @@ def _grad_digest(model_fn, x, dense, sl, keep_prob=0.8):
 
 
 def test_scheduling_switches_of_round5_do_not_change_a_bit(cuda, monkeypatch):
-    """Where the weight-gradient work is ISSUED must not show in the result: the LSTM layers' weight-gradient lanes behind
-    the dx product (rnn_util.DW_AFTER_DX_FLOPS: never / always) and the VGG front-end's weight-gradient kernels on a side
-    lane (vgg_blstm.VGG_WGRAD_SIDE) give the same loss and the same gradient bits as the forms they replace."""
+    """Where work is ISSUED must not show in the result: the LSTM layers' weight-gradient lanes behind the dx product
+    (rnn_util.DW_AFTER_DX_FLOPS: never / always), the VGG front-end's weight-gradient kernels on a side lane
+    (vgg_blstm.VGG_WGRAD_SIDE) and its forward in 2 / 3 runs of images on separate lanes (VGG_FWD_CHUNKS; dropout on, so
+    the shifted dropout counters are covered) give the same loss and the same gradient bits as the forms they replace."""
     from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
     from tensorflow_end2end_speech_recognition_amd.models.encoders.core import rnn_util, vgg_blstm
     rng = np.random.RandomState(17)
@@ -984,13 +985,16 @@ def test_scheduling_switches_of_round5_do_not_change_a_bit(cuda, monkeypatch):
         return CTC('vgg_blstm', F * 3, 64, 3, C, splice=splice, clip_grad_norm=5.0, clip_activation=50, dtype='bf16', seed=2,
                    device='cuda:0')
     runs = {}
-    for tag, flops, side in (('old', float('inf'), False), ('after_dx', 0.0, False), ('side', float('inf'), True),
-                             ('both', 0.0, True)):
+    monkeypatch.setattr(vgg_blstm, 'VGG_FWD_CHUNK_MIN', 1)       # the runs of images of the pipelined forward at this size
+    for tag, flops, side, chunks in (('old', float('inf'), False, 1), ('after_dx', 0.0, False, 1),
+                                     ('side', float('inf'), True, 1), ('both', 0.0, True, 1),
+                                     ('two_runs', float('inf'), False, 2), ('all_three_runs', 0.0, True, 3)):
         monkeypatch.setattr(rnn_util, 'DW_AFTER_DX_FLOPS', flops)
         monkeypatch.setattr(vgg_blstm, 'VGG_WGRAD_SIDE', side)
+        monkeypatch.setattr(vgg_blstm, 'VGG_FWD_CHUNKS', chunks)
         runs[tag] = _grad_digest(build, x, dense, sl)
     l0, g0 = runs['old']
-    for tag in ('after_dx', 'side', 'both'):
+    for tag in ('after_dx', 'side', 'both', 'two_runs', 'all_three_runs'):
         l, g = runs[tag]
         assert l == l0, (tag, l, l0)
         for n in g0:
