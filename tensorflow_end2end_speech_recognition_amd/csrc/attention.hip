@@ -2328,8 +2328,10 @@ extern "C" int asr_att_decoder_infer(asr_handle* h, const asr_att_decoder* a, co
   const int every = (f->host_live_count && f->check_every > 0) ? f->check_every : 0;
   if (every) {
     for (int i = 0; i < NEV; ++i)
-      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+        for (int j = 0; j < i; ++j) (void)hipEventDestroy(ev[j]);          // the ones already made
         ASR_FAIL(h, ASR_ERR_HIP, "asr_att_decoder_infer: event");
+      }
   }
   int rc = dec_cell_image(h, a, s), k = 0;
   for (; rc == ASR_OK && k < To; ++k) {

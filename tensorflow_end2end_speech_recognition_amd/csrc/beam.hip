@@ -391,8 +391,9 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
     auto frame_tail = [&](unsigned long long* ck) __attribute__((always_inline)) {
       if (tid < nb) ck[tid] = s_key[tid];
       {
-        int j = tid / K, ci = tid - j * K;
-        const int dj = BEAM_THREADS / K, dci = BEAM_THREADS - dj * K;
+        const int Kd = K > 0 ? K : 1;                        // (K == 0: one class, or every non-blank probability NaN -- the loop below is empty)
+        int j = tid / Kd, ci = tid - j * Kd;
+        const int dj = BEAM_THREADS / Kd, dci = BEAM_THREADS - dj * Kd;
         for (int e = tid; e < nb * K; e += BEAM_THREADS) {
           const int c = kc[ci];
           ck[nb + e] = okey(((c == beam[j].last) ? beam[j].pb : s_L[j]) + lp[c]);

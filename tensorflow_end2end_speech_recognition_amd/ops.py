@@ -204,6 +204,17 @@ def host_ints(x):
     return host
 
 
+def invalidate_host_ints(x=None):
+    """Forget the remembered host copy of device vector `x` (all of them when None).  The version counter host_ints keys
+    on does not move for writes torch does not see -- `x.data.copy_()`, a kernel launched on `x.data_ptr()` through ctypes
+    (this library's own calls), DLPack consumers: a caller that rewrites a length vector that way, in place, says so here
+    (or, simpler, hands the lengths over on the host, as the reference's feed_dict does)."""
+    if x is None:
+        _host_copies.clear()
+    else:
+        _host_copies.pop(id(x), None)
+
+
 def _p(t):
     if t is None:
         return None
