@@ -467,6 +467,10 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       // hoists the poll loads to right behind the barrier, in front of the LDS read and the MFMAs): ~150 cycles later --
       // forward launch 840 -> 805 us at H = 256, 1400 -> 1358 at H = 512, 975 -> 967 at H = 320.  (Later still is worse again: + 128 cycles 818 us,
       // + 256 860, + 384 882; the fp32 kernel, whose own-slice MFMAs take three times as long, gains nothing from it.)
+      // (Round 5, measured: TWO poll rounds in flight -- the second issued s_sleep(2 / 4 / 6) behind the first, before it
+      // returns -- is slower by exactly the sleep: 693 -> 722 / 765 / 838 us per launch, same bits.  The L2 round trip of a
+      // poll is ~200 cycles, so the one-round loop already samples every ~200 cycles; the 0.7 - 1.0 repolls per step of the
+      // phase probe cost what they look like, not a fabric trip each.)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (XW) {
         constexpr unsigned pbytes = (unsigned)P * G * SLICE * 4u;   // this parity's slices
