@@ -574,6 +574,12 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
   }
 }
 
+// (Round 5, built and measured: a forward kernel WITHOUT the LDS image -- the slice layout [wave][row][8 units] is already the
+// A operand of v_mfma_f32_16x16x32_bf16, so every wave polled the 16 bytes per lane of ALL G slices and multiplied them as
+// they came: no staging, no barrier, no LDS read on the chain.  Correct (same parity figures) and SLOWER: 695 -> 805 - 813 us
+// per launch at H = 256.  A poll round is then 4 waves x 8 KB = 32 KB per CU through a 64 B/clk L2 port (~500 cycles)
+// instead of 8 KB shared through the LDS (128 B/clk): the staging is what keeps the hop short.  Removed again.)
+
 // ---------------------------------------------------------------- backward
 // K-partition: CU g owns the gate gradients of its 64 units (k' = unit*4+q in its slice) and the
 // rows k' of W_h^T; each step it multiplies its dG slice by W_h^T[k' slice, all H] -> a partial
