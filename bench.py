@@ -100,12 +100,41 @@ def truncate_batch(x, seq_len, labels, tcut, label_div=8):
 
 
 # ------------------------------------------------------------------------------------------------ timing harness
+def _conv_work(a, k):
+    """flops of one 3x3 convolution call: x [n, H, W, Cin] against a weight image [Cout, 9 Cin] (ops.conv3x3_fwd*)."""
+    n, H, W, Cin = a[0].shape
+    return 2.0 * n * H * W * 9 * Cin * a[1].shape[0]
+
+
+def _conv_bwd_weight_work(a, k):
+    n, H, W, Cin = a[0].shape            # x [n, H, W, Cin], dY [n, H, W, Cout]
+    return 2.0 * n * H * W * 9 * Cin * a[1].shape[3]
+
+
+def _gemm_work(a, k):
+    """(group, flops) of one ops.gemm call; the group names the operand layout (reduction-major = weight gradients)."""
+    A, B = a[0], a[1]
+    tA = bool(a[2]) if len(a) > 2 else bool(k.get('transA', False))
+    tB = bool(a[3]) if len(a) > 3 else bool(k.get('transB', False))
+    M, K = (A.shape[1], A.shape[0]) if tA else (A.shape[0], A.shape[1])
+    N = B.shape[0] if tB else B.shape[1]
+    return ('gemm_tn' if tA else ('gemm_nt' if tB else 'gemm_nn')), 2.0 * M * N * K
+
+
+# per timed op: callable(args, kwargs) -> work units of THAT call (flops), or (record name, work units)
+CALL_WORK = {'conv3x3_fwd': _conv_work, 'conv3x3_fwd_drop': _conv_work, 'conv3x3_bwd_data_relu': _conv_work,
+             'conv3x3_bwd_weight': _conv_bwd_weight_work, 'conv3x3_bwd_weight_bias': _conv_bwd_weight_work,
+             'gemm': _gemm_work}
+
+
 class KernelTimer(object):
-    """HIP-event brackets (torch.cuda.Event on the current stream == the launch stream of ops.*)."""
+    """HIP-event brackets (torch.cuda.Event on the current stream == the launch stream of ops.*, inside ops.side_lane
+    that lane's stream).  Every record keeps the work of ITS call (CALL_WORK), so a step that runs a kernel several times
+    on parts of the batch (the VGG forward in runs of images) is credited call by call."""
 
     def __init__(self, ops, names):
         self.ops, self.names = ops, names
-        self.records = {n: [] for n in names}
+        self.records = {}
         self.enabled = False
         self._orig = {}
 
@@ -113,16 +142,21 @@ class KernelTimer(object):
         for n in self.names:
             orig = getattr(self.ops, n)
             self._orig[n] = orig
+            work = CALL_WORK.get(n)
 
-            def wrapped(*a, _n=n, _o=orig, **k):
+            def wrapped(*a, _n=n, _o=orig, _w=work, **k):
                 if not self.enabled:
                     return _o(*a, **k)
+                key, units = _n, 0.0
+                if _w is not None:
+                    w = _w(a, k)
+                    key, units = w if isinstance(w, tuple) else (_n, w)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 r = _o(*a, **k)
                 e1.record()
-                self.records[_n].append((e0, e1))
+                self.records.setdefault(key, []).append((e0, e1, units))
                 return r
             setattr(self.ops, n, wrapped)
 
@@ -134,8 +168,11 @@ class KernelTimer(object):
         out = {}
         for n, evs in self.records.items():
             if evs:
-                ms = [a.elapsed_time(b) for a, b in evs]
+                ms = [a.elapsed_time(b) for a, b, _ in evs]
                 out[n] = dict(calls=len(ms), total_ms=float(np.sum(ms)), avg_us=float(np.mean(ms) * 1e3))
+                work = float(sum(u for _, _, u in evs))
+                if work:
+                    out[n]['work'] = work
         return out
 
 
@@ -263,7 +300,7 @@ def cpu_baseline_oracle_call(fn, frames, what, threads):
 
 
 # ------------------------------------------------------------------------------------------------ rooflines
-def recurrence_roofline(H, frames_dirs, T, dtype, ks, traffic=None, traffic_source=None, tiles=1):
+def recurrence_roofline(H, frames_dirs, T, dtype, ks, traffic=None, traffic_source=None, tiles=1, steps=None):
     """Roofline entry of the dominant recurrence kernel.  Algorithmic HBM bytes per launch:
       fwd: read x W_x + b 16H, write gates s*4H + c 4H + h s*H     per valid frame per direction
       bwd: read gates s*4H + c 4H + dh 4H, write dgates s*4H       per valid frame per direction
@@ -281,6 +318,7 @@ def recurrence_roofline(H, frames_dirs, T, dtype, ks, traffic=None, traffic_sour
     return dict(kernel=dom, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
                 traffic=traffic, traffic_source=traffic_source, avg_launch_us=ks[dom]['avg_us'],
                 us_per_recurrence_step=ks[dom]['avg_us'] / T, algorithmic_bytes_per_launch=bytes_launch,
+                ms_per_step=(ks[dom]['total_ms'] / steps) if steps else None,
                 mfma_tflops=frames_dirs * flops_frame / dur / 1e12,
                 mfma_frac=frames_dirs * flops_frame / dur / 1e12 / peak_tf, utterance_tiles_per_direction=tiles,
                 note='serial recurrence over T frames, one 16-utterance MFMA tile per cluster: bound by the per-step '
@@ -289,29 +327,49 @@ def recurrence_roofline(H, frames_dirs, T, dtype, ks, traffic=None, traffic_sour
                      '(profiles/pmc_hbm_traffic.json), null if no pass matches this workload')
 
 
-def conv_roofline(F, W, frames, ks):
-    """MFMA roofline of cfg C's dominant matrix kernel group: the three image-resident 3x3 convolutions of the forward
-    pass (conv3x3_img_kernel<64,64>, <64,128>, <128,128>; ops.conv3x3_fwd / conv3x3_fwd_drop).  Algorithmic
-    flops per valid frame: 2 * pixels * 9 * Cin * Cout with F x W pixels before and ceil(F/2) x ceil(W/2) after the
-    first pool (models/encoders/core/vgg_blstm.py:113-151); duration = HIP events around the calls in the timed region."""
+def conv_roofline(F, W, frames, steps, ks):
+    """MFMA entry of cfg C's image-resident forward convolutions (conv3x3_img_kernel<64,64>, <64,128>, <128,128>;
+    ops.conv3x3_fwd / conv3x3_fwd_drop).  achieved = the flops of the timed calls / their HIP-event time, CALL BY CALL
+    (`work` of KernelTimer: 2 * images * pixels * 9 * Cin * Cout of the images that call processed): the VGG forward goes
+    through in ASR_VGG_FWD_CHUNKS runs of images (vgg_blstm.py), so a step makes several calls per kernel on part of the
+    batch each -- counting calls as steps doubled this figure in round 5.  `steps` = the timed steps of the loop; the
+    summed work must equal steps x valid frames x the per-frame figure (2 * pixels * 9 * Cin * Cout with F x W pixels
+    before and ceil(F/2) x ceil(W/2) after the first pool, models/encoders/core/vgg_blstm.py:113-151).  Calls of two runs
+    overlap on two lanes: summing their event times can only UNDERSTATE the rate."""
     ka, kb = ks.get('conv3x3_fwd'), ks.get('conv3x3_fwd_drop')
-    if not ka or not kb:
+    if not ka or not kb or not steps:
         return None
     p1, p2 = F * W, ((F + 1) // 2) * ((W + 1) // 2)
     flops_frame = 2.0 * 9 * (p1 * 64 * 64 + p2 * 64 * 128 + p2 * 128 * 128)
-    # per step: VGG1/conv2 and VGG2/conv2 through ops.conv3x3_fwd, VGG2/conv1 through ops.conv3x3_fwd_drop (dropout in
-    # its epilogue; models/encoders/core/vgg_blstm.py _forward_frontend)
-    steps = kb['calls']
-    assert ka['calls'] == 2 * steps, (ka['calls'], kb['calls'])
+    assert ka['calls'] % steps == 0 and kb['calls'] % steps == 0 and ka['calls'] == 2 * kb['calls'], \
+        (ka['calls'], kb['calls'], steps)
+    work = ka.get('work', 0.0) + kb.get('work', 0.0)
+    expect = flops_frame * frames * steps
+    assert abs(work - expect) <= 1e-6 * expect, ('timed convolution calls do not add up to the batch', work, expect)
     total_ms = ka['total_ms'] + kb['total_ms']
-    ach = flops_frame * frames * steps / (total_ms * 1e-3) / 1e12
-    k = dict(avg_us=total_ms * 1e3 / (3 * steps))
+    ach = work / (total_ms * 1e-3) / 1e12
     return dict(kernel='conv3x3_img_fwd', bound='mfma', achieved=ach,
                 peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s', frac=ach / MFMA_BF16_PEAK_TF, traffic=None,
-                avg_launch_us=k['avg_us'], algorithmic_flops_per_frame=flops_frame,
-                note='2 * pixels * 9 * Cin * Cout over the valid frames of the batch / HIP-event time of the three '
-                     'image-resident forward convolutions of a step (ReLU + bias, one of them + dropout, in the '
-                     'epilogue); the recurrence entry of this configuration is roofline_recurrence')
+                avg_launch_us=total_ms * 1e3 / (ka['calls'] + kb['calls']), calls_per_step=(ka['calls'] + kb['calls']) // steps,
+                ms_per_step=total_ms / steps, algorithmic_flops_per_frame=flops_frame,
+                note='flops of the timed calls (2 * images * pixels * 9 * Cin * Cout each) / their summed HIP-event time: '
+                     'the three image-resident forward convolutions (ReLU + bias, one of them + dropout, in the epilogue)')
+
+
+def mfma_group_roofline(name, k, steps):
+    """MFMA entry of one group of timed matrix calls (ops.gemm by operand layout, convolution gradients): the flops of
+    the calls / their summed HIP-event time on the lanes they ran on."""
+    if not k or not k.get('work'):
+        return None
+    ach = k['work'] / (k['total_ms'] * 1e-3) / 1e12
+    return dict(kernel=name, bound='mfma', achieved=ach, peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s', frac=ach / MFMA_BF16_PEAK_TF,
+                traffic=None, avg_launch_us=k['avg_us'], calls_per_step=k['calls'] / float(steps), ms_per_step=k['total_ms'] / steps)
+
+
+def dominant_roofline(entries):
+    """Of {name: roofline entry with ms_per_step}, the one whose calls took the most event time per step."""
+    live = {n: e for n, e in entries.items() if e and e.get('ms_per_step')}
+    return max(live.values(), key=lambda e: e['ms_per_step']) if live else None
 
 
 def load_traffic_table():
@@ -471,19 +529,28 @@ def run_cfgC(args, dev, dev_index):
     steps = args.aux_steps
     res = time_steps(step, steps, args.aux_warmup, 1, dev_index,
                      timed_ops=('lstm_fwd', 'lstm_bwd', 'ctc_loss', 'conv3x3_fwd', 'conv3x3_fwd_drop',
-                                'conv3x3_bwd_data_relu', 'conv3x3_bwd_weight'))
+                                'conv3x3_bwd_data_relu', 'conv3x3_bwd_weight_bias', 'gemm'))
     frames = int(seq_len.sum())
     T = int(seq_len.max())
+    ks = res['kernels']
+    # one roofline entry per group of timed calls; `roofline` is the group that took the most event time per step
+    # (the entry named the best matrix kernel, not the dominant one), the others sit beside it
+    groups = dict(recurrence=recurrence_roofline(H, frames * 2, T, 'bf16', ks, tiles=B // 16, steps=steps),
+                  conv_fwd=conv_roofline(F, W, frames, steps, ks),
+                  conv_bwd_data=mfma_group_roofline('conv3x3_bwd_data_relu', ks.get('conv3x3_bwd_data_relu'), steps),
+                  conv_bwd_weight=mfma_group_roofline('conv3x3_bwd_weight_bias', ks.get('conv3x3_bwd_weight_bias'), steps),
+                  gemm_tn=mfma_group_roofline('gemm_tn_bf16 (weight gradients, side lanes)', ks.get('gemm_tn'), steps),
+                  gemm_nt=mfma_group_roofline('gemm_nt_bf16 (projections, dx)', ks.get('gemm_nt'), steps),
+                  gemm_nn=mfma_group_roofline('gemm_nn', ks.get('gemm_nn'), steps))
     out = dict(workload='LibriSpeech-100h char shaped: VGG (40x11x3 frame images) + 4x512 BLSTM + CTC(29), B=64, '
                         'D=1320, seq_len~U{150..1650}, bf16 operands, dropout 0.2, rmsprop, train step',
                value=frames * steps / res['elapsed'], unit='frames/s', dtype='bf16', steps=steps,
                frames_per_step=frames, ms_per_step=res['elapsed'] / steps * 1e3, step_ms=res['step_ms'],
-               final_loss=res['final_loss'], cluster_handoff_flags=res['handoff_flags'], kernels=res['kernels'],
+               final_loss=res['final_loss'], cluster_handoff_flags=res['handoff_flags'], kernels=ks,
                algorithmic_flops_per_frame=399.3e6,
                mfma_frac_whole_step=399.3e6 * frames * steps / res['elapsed'] / 1e12 / MFMA_BF16_PEAK_TF,
-               roofline=conv_roofline(F, W, frames, res['kernels']) or
-               recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
-               roofline_recurrence=recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
+               roofline=dominant_roofline(groups), roofline_groups=groups,
+               roofline_conv=groups['conv_fwd'], roofline_recurrence=groups['recurrence'],
                parity_tests='model-level parity at these widths: tests/test_gpu_configs.py::test_cfgC_vgg_blstm_4x512_bf16_ragged_two_tiles')
     if not args.no_parity:
         # bounded parity leg: the first 4 utterances cut to 48 frames, dropout off, against the fp64 oracle evaluated at
@@ -767,6 +834,8 @@ def _compact_aux(e):
     for k in ('mfma_frac_whole_step', 'decoder_steps', 'cluster_handoff_flags'):
         if k in e:
             out[k] = e[k]
+    if isinstance(e.get('roofline_groups'), dict):       # [fraction of the bound's peak, ms of event time per step] per group
+        out['groups'] = {n: [g.get('frac'), g.get('ms_per_step')] for n, g in e['roofline_groups'].items() if g}
     if isinstance(e.get('greedy_infer'), dict):
         out['greedy_infer_tokens_per_s'] = e['greedy_infer'].get('tokens_per_s')
     if isinstance(e.get('parity'), dict):
@@ -833,14 +902,20 @@ def compact_line(out, limit=COMPACT_LIMIT):
         c['per_rank'] = dict(step_median_ms=pr.get('step_median_ms'), elapsed_s=pr.get('elapsed_s'), frames=pr.get('frames'),
                              comm_ms=pr.get('comm_stream_allreduce_ms_per_step'))
         cm = out.get('comm') or {}
-        c['comm'] = _numbers_only(cm, ('allreduce_calls_per_step', 'allreduce_ms_per_step', 'bytes_per_step', 'bucket_min_mb'))
+        c['comm'] = _numbers_only(cm, ('allreduce_calls_per_step', 'allreduce_ms_per_step', 'bytes_per_step', 'bucket_min_mb',
+                                       'ranks', 'rccl_ranks'))
+        c['comm']['backend'] = cm.get('backend')
+        op = out.get('other_padding')
+        if op:
+            c['other_padding'] = dict(padded_to=op.get('padded_to'), value=op.get('value'), ms_per_step=op.get('ms_per_step'),
+                                      per_rank_step_median_ms=op.get('per_rank_step_median_ms'))
     c['full'] = out.get('full')
     c = _sig(c)
     line = json.dumps(c, separators=(',', ':'))
     # shed optional detail, least important first, until the line fits
     for drop in (('decode',), ('batch_scaling',), ('input_width_D39',), ('per_rank',), ('h2d_inclusive',),
-                 ('cfgA', 'kernel_us'), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('cfgE', 'kernel_us'),
-                 ('cfgE',), ('cfgD',), ('cfgC',), ('cfgA',), ('comm',)):
+                 ('other_padding',), ('cfgA', 'kernel_us'), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('cfgE', 'kernel_us'),
+                 ('cfgC', 'groups'), ('cfgE',), ('cfgD',), ('cfgC',), ('cfgA',), ('comm',)):
         if len(line) <= limit:
             break
         if len(drop) == 1:
@@ -866,6 +941,73 @@ def write_full(out):
             except OSError:
                 pass
     return written[0] if written else None
+
+
+# ------------------------------------------------------------------------------------------------ launching N ranks
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N ...` outside a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` (the driver's own
+    command for N > 1), pass the ranks' stderr through, and print the LAST stdout line that parses as a JSON object --
+    rank 0's result -- as this process's single stdout line.  Returns the job's exit status (1 if no line came)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    log('self-launch: ' + ' '.join(cmd))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    out = p.communicate()[0].decode('utf-8', 'replace')
+    line = None
+    for ln in out.splitlines():
+        ln = ln.strip()
+        if ln.startswith('{') and ln.endswith('}'):
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    if line is not None:
+        sys.stdout.write(line + '\n')
+        sys.stdout.flush()
+    else:
+        sys.stderr.write('bench.py: the %d-rank job printed no result line (exit status %d)\n' % (n, p.returncode))
+    return p.returncode if (p.returncode or line is not None) else 1
+
+
+def dry_run_launch(args, world, rank, result_fd):
+    """The launch path without a GPU: process group on gloo, one all-gather of a per-rank record, the contract's line
+    from rank 0 with value null and dry_run true.  Nothing is measured and nothing is claimed."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        mine = torch.tensor([float(rank), float(os.getpid())], dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks = sorted(int(t[0].item()) for t in allr)
+        dist.barrier()
+    else:
+        ranks = [0]
+    if rank == 0:
+        assert ranks == list(range(world)), ranks
+        out = dict(metric='acoustic frames/sec (train), TIMIT-shaped BLSTM-CTC', value=None, unit='frames/s', n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=None, higher_is_better=True, scaling='weak',
+                   vs_baseline=None, dtype=args.dtype, data='synthetic', dry_run=True, ranks_seen=ranks,
+                   config=dict(workload='launch check only: no kernels ran', global_batch=args.batch * world,
+                               parallelism='dp%d' % world))
+        os.write(result_fd, (json.dumps(out, separators=(',', ':')) + '\n').encode())
+    if world > 1:
+        dist.destroy_process_group()
+    os.close(result_fd)
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -896,22 +1038,36 @@ def main():
     ap.add_argument('--cpu-threads', default='8,16,32', help='thread counts of the CPU baseline sweep (capped at 64)')
     ap.add_argument('--time-budget', type=float, default=420.0,
                     help='seconds after which the remaining auxiliary entries are skipped (recorded as such)')
+    ap.add_argument('--dry-run-launch', action='store_true',
+                    help='rendezvous + one gloo all-gather per rank and a line marked dry_run, NO kernels: checks the '
+                         'launch path of --gpus N on a box without GPUs (tests/test_distributed_cpu.py)')
+    ap.add_argument('--own-tmax-steps', type=int, default=10,
+                    help='N > 1: timed steps of the second leg with every rank padded to its OWN longest utterance '
+                         '(0 = skip); the headline pads to the global Tmax as the reference does')
     ap.add_argument('--cpu-tmax', type=int, default=256,
                     help='CPU legs (baseline, oracle parity): the same batch truncated to its first N frames')
     args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1) and hand on rank 0's line and the job's exit status
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if world != args.gpus:
+        sys.exit('bench.py --gpus %d inside a job of WORLD_SIZE %d: the two must agree' % (args.gpus, world))
 
     # stdout carries exactly ONE line, the JSON result: libraries that print banners to file descriptor 1 (RCCL's
     # version block, gloo's rank messages) are sent to stderr for the duration of the run
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d' % (args.gpus, args.gpus))
+    if not args.dry_run_launch and os.environ.get('ASR_BENCH_BACKEND') == 'gloo' and not torch.cuda.is_available():
+        log('no GPU visible and ASR_BENCH_BACKEND=gloo: launch check only (the line says dry_run, value null)')
+        args.dry_run_launch = True
+    if args.dry_run_launch:
+        return dry_run_launch(args, world, rank, result_fd)
     # dry-run knobs for a box with fewer GPUs than ranks (scripts/r02_dp_dryrun.sh): ASR_BENCH_DEVICE pins every rank to
     # one device, ASR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU).  Never set by the driver.
     dev_index = int(os.environ.get('ASR_BENCH_DEVICE', local_rank))
@@ -947,6 +1103,25 @@ def main():
         allst = stats.cpu().numpy()[None]
     elapsed, elapsed_h2d, total_frames = float(allst[:, 0].max()), float(allst[:, 1].max()), float(allst[:, 2].sum())
     value = total_frames * args.steps / elapsed
+    other_padding = None
+    if world > 1 and args.own_tmax_steps > 0:
+        # the same shards under the OTHER padding rule (default leg: the reference's global Tmax; this leg: every rank
+        # padded to its own longest utterance -- ranks then finish their recurrences at different times and the slowest
+        # one sets the step), a short run, reported beside the headline
+        wo = dict(wl, global_tmax=not wl['global_tmax'])
+        ro = run_blstm_ctc(args, wo, dev, world, rank, dev_index, args.own_tmax_steps, min(args.warmup, 3),
+                           want_parity=False, want_h2d=False, want_cpu=False)
+        so = torch.tensor([ro['elapsed'], float(ro['frames']), ro['step_ms']['median'], float(ro['T'])], device=dev,
+                          dtype=torch.float64)
+        allo = [torch.zeros_like(so) for _ in range(world)]
+        dist.all_gather(allo, so)
+        allo = torch.stack(allo).cpu().numpy()
+        other_padding = dict(padded_to='global Tmax %d on every rank' % int(allo[:, 3].max()) if wo['global_tmax']
+                             else 'own Tmax per rank', steps=args.own_tmax_steps,
+                             value=float(allo[:, 1].sum()) * args.own_tmax_steps / float(allo[:, 0].max()),
+                             ms_per_step=float(allo[:, 0].max()) / args.own_tmax_steps * 1e3,
+                             per_rank_step_median_ms=[float(v) for v in allo[:, 2]], per_rank_T=[int(v) for v in allo[:, 3]])
+        del ro
 
     if rank == 0:
         ks = res['kernels']
@@ -985,6 +1160,12 @@ def main():
                                    elapsed_s=[float(v) for v in allst[:, 0]],
                                    comm_stream_allreduce_ms_per_step=[float(v) for v in allst[:, 5]])
             out['comm'] = res.get('comm')
+            if out['comm'] is not None:
+                native = multi_gpu.native_comm(dev) is not None
+                out['comm'].update(ranks=dist.get_world_size(), backend=dist.get_backend(),
+                                   collective='asr_allreduce_mean: RCCL through the C ABI' if native else
+                                   'torch.distributed all_reduce (%s)' % dist.get_backend(), rccl_ranks=world if native else 0)
+            out['other_padding'] = other_padding
         del res
         torch.cuda.empty_cache()
         log('headline done: %.0f frames/s' % value)

@@ -55,7 +55,7 @@ typedef enum {
 } asr_optimizer;
 
 /* ---- lifetime ------------------------------------------------------------ */
-int asr_abi_version(void);                                         /* 3: round 4 (2: additions + the two size changes noted at asr_create_ex / asr_ctc_beam_workspace_bytes; 3: asr_att_decoder grew a trailing field) */
+int asr_abi_version(void);                                         /* 4: rounds 5-6, additive (asr_conv3x3_bwd_weight_bias, asr_conv3x3_smallc_bwd_weight_bias, asr_debug_* hooks).  3: round 4 (2: additions + the two size changes noted at asr_create_ex / asr_ctc_beam_workspace_bytes; 3: asr_att_decoder grew a trailing field) */
 int asr_create(asr_handle** out, int device);                        /* 192 MiB scratch arena */
 int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes); /* >= 96 MiB (64 MiB of it: recurrence exchange areas) */
 size_t asr_scratch_bytes(asr_handle* h);

@@ -134,6 +134,9 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 4          # include/asr_hip.h: asr_abi_version()
+
+
 def load():
     """dlopen libasr_hip.so and type every entry point.  Raises if absent."""
     global _lib
@@ -145,8 +148,17 @@ def load():
             '`python -m tensorflow_end2end_speech_recognition_amd.build` '
             '(there is no CPU fallback for the HIP path)' % LIB_PATH)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    ver = getattr(lib, 'asr_abi_version', None)
+    got = int(ver()) if ver is not None else 0
+    if got < ABI_VERSION:
+        raise RuntimeError('%s reports asr_abi_version() = %d but this package binds version %d entry points: the '
+                           'library is stale -- rebuild it with `python -m tensorflow_end2end_speech_recognition_amd.build`'
+                           % (LIB_PATH, got, ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError('%s (abi %d) does not export %s: rebuild it with '
+                               '`python -m tensorflow_end2end_speech_recognition_amd.build`' % (LIB_PATH, got, name))
         fn.restype = res
         fn.argtypes = args
     _lib = lib

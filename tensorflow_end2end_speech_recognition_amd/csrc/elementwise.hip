@@ -8,7 +8,9 @@
 // 2 (round 4): asr_create_ex's minimum scratch is 96 MiB (was 32), asr_ctc_beam_workspace_bytes asks for W more doubles per
 // utterance, new entry points asr_att_decoder_infer / asr_lstm_cell_bwd_ex; nothing was removed or re-typed.
 // 3 (round 4): asr_lstm_cell_gemm_prep / _fwd and their _h forms (decoder cell product + cell in one launch).
-extern "C" int asr_abi_version(void) { return 3; }
+// 4 (rounds 5-6, additive): asr_conv3x3_bwd_weight_bias, asr_conv3x3_smallc_bwd_weight_bias (bias gradient out of the
+// weight-gradient kernels), the asr_debug_* hooks; nothing removed or re-typed.
+extern "C" int asr_abi_version(void) { return 4; }
 
 extern "C" int asr_create(asr_handle** out, int device) { return asr_create_ex(out, device, (size_t)192 << 20); }
 extern "C" size_t asr_scratch_bytes(asr_handle* h) { return h ? h->scratch_bytes : 0; }

@@ -824,7 +824,7 @@ def gru_bwd(dout, d_h_final, saved, wghT, wchT, seq_len, tmax, H, ndir):
     return dgate, dcand
 
 
-def check_async_errors(device=0):
+def check_async_errors(device=0, flush_deferred=True):
     """Device sync + sticky error word of the multi-CU LSTM kernels (raises on a hand-off timeout).
     The blocking form: call at sync points (evaluation, checkpoint, end of an epoch)."""
     h = _lib.handle(device)
@@ -839,7 +839,8 @@ def check_async_errors(device=0):
         if w is not None:
             w.events = [None] * w.DEPTH
     h.check(rc, 'asr_check_async_errors')
-    _deferred_for(device).flush()                    # the device is idle: every counter armed on it has landed
+    if flush_deferred:
+        _deferred_for(device).flush()                # the device is idle: every counter armed on it has landed
     return flags.value
 
 
@@ -873,10 +874,16 @@ class ErrorWatch(object):
                 h = _lib.handle(self.dev)
                 h.lib.asr_clear_async_errors(h.h, _s())
                 self.events = [None] * self.DEPTH
-                what = 'LSTM cluster hand-off timed out' if flags & 3 else \
-                    'LSTM recurrence produced a non-finite hidden state (the model diverged)'
-                raise _lib.AsrError('%s (flags 0x%x): the recurrent state of a recent '
-                                    'step is garbage -- restore the last checkpoint' % (what, flags))
+                if flags & 3:
+                    raise _lib.AsrError('LSTM cluster hand-off timed out (flags 0x%x): the recurrent state of a recent '
+                                        'step is garbage -- restore the last checkpoint' % flags)
+                # not a hand-off fault: the MODEL diverged.  The reference would carry a NaN loss on (and its learning-rate
+                # controller / early stop would react); the bf16 cluster exchange cannot represent a non-finite h (its tag
+                # bits would launder it into a finite value for the peers), so this path stops instead (INTEGRATION.md,
+                # "Deviations"; bf16 self-tagged exchange only -- the fp32 paths propagate NaN like the reference)
+                raise _lib.AsrError('LSTM recurrence produced a non-finite hidden state (flags 0x%x): the model diverged '
+                                    '(learning rate / clipping); weights of the last %d steps are NaN-contaminated'
+                                    % (flags, self.DEPTH))
         h = _lib.handle(self.dev)
         h.check(h.lib.asr_peek_async_errors(h.h, C.c_void_p(self.host.data_ptr() + 4 * slot), _s()),
                 'asr_peek_async_errors')
@@ -896,20 +903,29 @@ class DeferredCheck(object):
     device's current stream (one DeferredCheck per device) -- and every earlier copy that has landed is inspected then.
     Lateness: the reference raises inside the sess.run of the offending step; here the error surfaces at a later arm() --
     in steady state within ErrorWatch.DEPTH (3) optimizer steps, because that is how far the issue loop may run ahead of
-    the device, and NEVER more than DEPTH (4) arm() calls late (one arm() per CTC head and step): at DEPTH pending copies
-    arm() blocks on the oldest.  The optimizer has applied the updates of the steps in between.  flush() is the blocking
+    the device, and NEVER more than DEPTH (4) optimizer STEPS late, however many CTC heads arm a counter per step
+    (MultitaskCTC arms two): a copy armed DEPTH steps ago is waited for (the device's ErrorWatch counts the steps:
+    note_step()); without optimizer steps in between (a loop of compute_loss calls) at most RING - 1 copies are pending.
+    The optimizer has applied the updates of the steps in between.  An error removes only ITS copy: the other pending
+    ones (another head's, a later step's) are still inspected at the following arm() / flush().  flush() is the blocking
     form; it runs at every sync point: evaluation (is_training=False), Saver.save / check_async_errors (checkpoints), the
     end of the recipes' epochs, and at interpreter exit (a pending error is printed, it cannot be raised any more)."""
-    DEPTH = 4
+    DEPTH = 4          # optimizer steps
+    RING = 16          # pinned slots: >= DEPTH x the heads of any model here, and the cap when no optimizer steps run
 
     def __init__(self, device=None):
         self.device = device
-        self.slots = []          # (pinned host tensor, event, exception factory)
+        self.slots = []          # (pinned host tensor, event, exception factory, step it was armed in)
         self.waited_s = 0.0
         self.ring = None
         self.n = 0
+        self.step = 0
 
-    def _inspect(self, host, ev, make_exc, block):
+    def note_step(self):
+        """One optimizer step has been issued on this device (watch_async_errors)."""
+        self.step += 1
+
+    def _inspect(self, host, ev, make_exc, step, block):
         if not ev.query():
             if not block:
                 return False
@@ -918,24 +934,25 @@ class DeferredCheck(object):
             self.waited_s += _time.perf_counter() - t0
         n = int(host[0])
         if n:
-            self.slots = []
+            if self.slots and self.slots[0][0] is host:
+                self.slots.pop(0)
             # a timed-out cluster hand-off leaves NaN activations, which the CTC kernels count as infeasible rows: report the
             # root cause (AsrError from the sticky error word) rather than its symptom
-            check_async_errors(self.device if self.device is not None else torch.cuda.current_device())
+            check_async_errors(self.device if self.device is not None else torch.cuda.current_device(), flush_deferred=False)
             raise make_exc(n)
         return True
 
     def arm(self, counter, make_exc):
         if self.ring is None:        # one pinned block for the life of the process: no pinned allocation per step
-            self.ring = torch.zeros(4 * self.DEPTH, dtype=torch.int32).pin_memory()
+            self.ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
         self.n += 1
-        host = self.ring[self.n % (4 * self.DEPTH):][:1]
+        host = self.ring[self.n % self.RING:][:1]
         host.copy_(counter.view(-1)[:1].to(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(_cur_stream(counter.device))       # the stream the copy was enqueued on: the counter's device
-        self.slots.append((host, ev, make_exc))
+        self.slots.append((host, ev, make_exc, self.step))
         while self.slots:
-            block = len(self.slots) >= self.DEPTH
+            block = self.step - self.slots[0][3] >= self.DEPTH or len(self.slots) >= self.RING - 1
             if not self._inspect(*self.slots[0], block=block):
                 break
             self.slots.pop(0)
@@ -1002,6 +1019,9 @@ def watch_async_errors(device):
     w = _watches.get(dev)
     if w is None:
         w = _watches[dev] = ErrorWatch(dev)
+    d = _deferred_by_dev.get(dev)
+    if d is not None:
+        d.note_step()
     w.poll()
 
 

@@ -389,3 +389,30 @@ def test_multitask_ctc_recipe_data_parallel_world2(tmp_path):
     model.store.flat.copy_(torch.from_numpy(flat0))
     for n in model.store.names:
         assert np.abs(model.store[n].numpy() - sd[n]).max() < 5e-5, n
+
+
+def test_bench_bare_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher environment must start its two ranks itself
+    (torch.distributed.run on 127.0.0.1) and print rank 0's single JSON line -- the driver may run exactly that command
+    for its scaling record.  On a box without a GPU only the launch path can be exercised: --dry-run-launch (also
+    implied by ASR_BENCH_BACKEND=gloo when no GPU is visible) joins the ranks on gloo, gathers one record per rank and
+    prints a line whose value is null and which says dry_run; the measured form of this test is the -m gpu test
+    test_bench_bare_gpus_2_on_the_device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    for extra, envx in ((['--dry-run-launch'], {}), ([], dict(ASR_BENCH_BACKEND='gloo', CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES=''))):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'] + extra,
+                           cwd=root, env=dict(env, **envx), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout[-1000:]
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['dry_run'] is True and d['value'] is None and d['ranks_seen'] == [0, 1]
+        assert d['steps'] == 3 and d['warmup'] == 1 and d['config']['parallelism'] == 'dp2'
+    # inside a launcher's job the rank count must agree with --gpus
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run-launch'], cwd=root,
+                       env=dict(env, RANK='0', WORLD_SIZE='1'), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'must agree' in r.stderr

@@ -746,6 +746,34 @@ def test_bench_line_of_a_two_rank_run(cuda, tmp_path):
     assert 'cfgA' not in d and 'cfgC' not in d                    # auxiliary configurations are N = 1 entries
 
 
+def test_bench_bare_gpus_2_on_the_device(cuda):
+    """`python bench.py --gpus 2 --steps 3 --warmup 1` with no launcher environment (what a scaling driver may run
+    verbatim): bench.py starts the two ranks itself and the single stdout line is a measured 2-rank line with per-rank
+    medians, the collectives' time, the rank count of the collective and the same shards under the OTHER padding rule
+    beside the headline (global Tmax, utils/dataset/ctc.py:171-182).  One GPU: both ranks on cuda:0 over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    if torch.cuda.device_count() < 2:
+        env.update(ASR_BENCH_DEVICE='0', ASR_BENCH_BACKEND='gloo', ASR_DP_COLLECTIVE='torch')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--no-parity', '--own-tmax-steps', '2'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 6000, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['steps'] == 3 and d['config']['parallelism'] == 'dp2'
+    assert 'dry_run' not in d and len(d['per_rank']['step_median_ms']) == 2
+    assert d['comm']['ranks'] == 2 and d['comm']['allreduce_ms_per_step'] > 0 and d['comm']['backend'] in ('gloo', 'nccl')
+    assert 'global Tmax' in d['config']['padded_to'] and d['other_padding']['padded_to'] == 'own Tmax per rank'
+    assert d['other_padding']['value'] > 0 and len(d['other_padding']['per_rank_step_median_ms']) == 2
+    assert d['cluster_handoff_flags'] == 0
+
+
 def test_bench_last_stdout_line_is_the_compact_record(cuda):
     """`python bench.py --steps 2 --warmup 1` as the driver runs it at N = 1: the LAST stdout line parses, fits the
     driver's 8 000-byte window with margin and carries the contract keys + roofline + cpu_baseline; the full object it
@@ -932,6 +960,46 @@ def test_infeasible_labels_raise_without_a_per_step_sync(cuda):
         model.compute_loss(x, bad, sl, 1.0, is_training=False)
     loss, _ = model.compute_loss(x, good, sl, 1.0, is_training=False)
     assert np.isfinite(float(loss.item()))
+
+
+def test_deferred_check_depth_is_in_steps_and_an_error_keeps_the_other_pending_checks(cuda):
+    """a model with two CTC heads arms two counters per step; the watch's depth is counted in optimizer STEPS
+    (note_step), so two heads do not halve the distance the issue loop may run ahead, and an error drops only ITS copy:
+    the other head's error of the same step is still reported by the next inspection."""
+    from tensorflow_end2end_speech_recognition_amd import ops
+    ops.flush_deferred_checks()
+    w = ops.DeferredCheck(0)
+    zero = torch.zeros(1, dtype=torch.int32, device='cuda:0')
+    three = torch.full((1,), 3, dtype=torch.int32, device='cuda:0')
+    five = torch.full((1,), 5, dtype=torch.int32, device='cuda:0')
+
+    def mk(tag):
+        return lambda n: ValueError('%s %d' % (tag, n))
+    # steps 0 .. 2, two heads each, all clean: nothing raises, and nothing older than DEPTH steps stays pending
+    for step in range(ops.DeferredCheck.DEPTH + 3):
+        w.arm(zero, mk('main'))
+        w.arm(zero, mk('sub'))
+        w.note_step()
+        assert all(w.step - s[3] <= ops.DeferredCheck.DEPTH for s in w.slots)
+    w.flush()
+    assert not w.slots
+    # both heads fail in one step: the first error surfaces, the second one is kept and surfaces next
+    w.arm(three, mk('main'))
+    w.arm(five, mk('sub'))
+    w.note_step()
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match='main 3'):
+        w.arm(zero, mk('main'))
+    assert len(w.slots) == 2                      # the sub head's failing copy and the clean one just armed
+    with pytest.raises(ValueError, match='sub 5'):
+        w.flush()
+    w.flush()
+    assert not w.slots
+    # no optimizer steps at all (a loop of compute_loss calls): pending copies are capped by the ring
+    for _ in range(3 * ops.DeferredCheck.RING):
+        w.arm(zero, mk('x'))
+        assert len(w.slots) < ops.DeferredCheck.RING
+    w.flush()
 
 
 def test_full_chip_clusters_beside_background_gemms_hand_off_cleanly(cuda):
