@@ -662,6 +662,25 @@ def run_attention_cfg(args, dev, dev_index, which):
                              utterances=nb, oracle='oracle.attention fp64 at the device path\'s rounding points',
                              sample='first %d utterances cut to %d frames / %d labels, dropout off' % (nb, tc, lc),
                              seconds=time.perf_counter() - t0)
+        # the fp32 leg: the SAME parameters in a model with fp32 operands end to end against the PLAIN fp64 oracle (no
+        # rounding points) -- north_star's statement (loss within 1e-4 relative in fp32) at this configuration's widths
+        t0 = time.perf_counter()
+        m32 = JointCTCAttention(input_size=D, encoder_type='blstm', encoder_num_units=H, encoder_num_layers=L,
+                                encoder_num_proj=None, attention_type=att, attention_dim=A, decoder_type='lstm',
+                                decoder_num_units=U, decoder_num_layers=1, embedding_dim=Em, lambda_weight=0.5,
+                                num_classes=C, sos_index=C, eos_index=C + 1, max_decode_length=Lmax, parameter_init=0.1,
+                                clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50, dtype='f32',
+                                seed=5, device=str(dev))
+        m32.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+        ref32 = oatt.attention_model_forward(sd, xc, lab_c, slc, np.full(nb, lc + 2), L, att, clip_enc=50.0, clip_dec=50.0,
+                                             ctc_labels=[[int(v) for v in r] for r in ctc_d], lambda_weight=0.5)
+        loss32, *_ = m32.compute_loss(xc, lab_c, ctc_d, slc, np.full(nb, lc + 2), 1.0, 1.0, 1.0, is_training=False)
+        out['parity_fp32'] = dict(loss_device=float(loss32.item()), loss_oracle=float(ref32['total_loss']),
+                                  loss_rel_err_vs_oracle=abs(float(loss32.item()) - ref32['total_loss']) / abs(ref32['total_loss']),
+                                  utterances=nb, oracle='oracle.attention fp64, no rounding points',
+                                  sample='fp32-operand model with the same parameters on the same cut',
+                                  seconds=time.perf_counter() - t0)
+        del m32
     # greedy attention inference (attention_seq2seq.py:462-509) through the native loop: encoder + up to
     # max_decode_length decoder steps with the output head, argmax and embedding feedback on the device, one read-back
     try:
@@ -841,6 +860,8 @@ def _compact_aux(e):
     if isinstance(e.get('parity'), dict):
         out['parity'] = _numbers_only(e['parity'], ('loss_rel_err_vs_oracle', 'per_utterance_loss_rel_err_max',
                                                     'greedy_label_mismatch', 'greedy_labels_compared'))
+    if isinstance(e.get('parity_fp32'), dict):
+        out['parity_fp32_loss_rel'] = e['parity_fp32'].get('loss_rel_err_vs_oracle')
     ks = e.get('kernels') or {}
     out['kernel_us'] = {k: v.get('avg_us') for k, v in ks.items()}
     return out

@@ -24,6 +24,10 @@ FLAGS = ['--offload-arch=%s' % ARCH, '-O3', '-std=c++17', '-fPIC', '-Wno-unused-
 # lstm_cluster.hip: MFMA results in VGPRs (the default picks AGPR accumulators for the 4-wave kernels, whose gate math then
 # starts with 12 v_accvgpr_read per step on the serial chain)
 FILE_FLAGS = {'ctc.hip': ['-fno-slp-vectorize'], 'lstm_cluster.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+# ASR_BUILD_ABLATE=1: the ablated instantiations of the headline recurrence kernels (scripts/probe_lstm_ablate.py); never
+# part of a shipped library -- the default kernels' ISA is identical with and without it
+if os.environ.get('ASR_BUILD_ABLATE') == '1':
+    FILE_FLAGS['lstm_cluster.hip'] = FILE_FLAGS['lstm_cluster.hip'] + ['-DASR_LSTM_ABLATE']
 
 
 def _hipcc():

@@ -177,7 +177,11 @@ __device__ __forceinline__ float dpp_ror8_into(float old, float src) {
 // XW: the all-gather uses 4-byte self-tagged words (see xw_tag) -- a lane polls with 16-byte loads, each holding one row of
 // the 8 units of a peer's wave (ceil((G-1)/4) loads per round instead of G-1 8-byte ones, half the bytes) and stages it
 // with one ds_write_b128.  XW = false: 8-byte {step, payload} granules (ASR_LSTM_XW=0 / ASR_LSTM_DFLAGS bit 10).
-template <int H, bool DBG, bool EARLY = false, int HSU = 64, int FPIN = 0, bool XW = true>
+// ABL (builds with -DASR_LSTM_ABLATE only, scripts/probe_lstm_ablate.py): bit k set = piece k of the step is left out (the
+// results are garbage; the launch time against ABL = 0 is what that piece costs ON the serial chain).  0: the poll loop does
+// not wait for valid tags, 1: no A-fragment reads from LDS, 2: no MFMAs, 3: no gate math, 4: no saved-activation stores,
+// 5: no barriers, 6: no x-projection fetch, 7: no publish, 8: no LDS staging of the polled slices, 9: no poll loads at all.
+template <int H, bool DBG, bool EARLY = false, int HSU = 64, int FPIN = 0, bool XW = true, int ABL = 0>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     int T_, int B_, int ndir, const f32x4_t* __restrict__ xg, const bf16_t* __restrict__ whp,
     const float* __restrict__ peep, const int32_t* __restrict__ seq_len, float forget_bias,
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     const f32x4_t x0 = xq[P % XD][0], x1 = xq[P % XD][1];
     // (requested here, at the top of the step: behind the poll loop at its end -- where the BPTT kernel's fetch belongs,
     // see there -- the forward kernel measured 1.21 ms per launch instead of 0.92)
-    if (s + XD < tmax) {                                   // lands during the next step(s)
+    if (s + XD < tmax && !(ABL & 64)) {                    // lands during the next step(s)
 #pragma unroll
       for (int r = 0; r < 2; ++r)
         xq[P % XD][r] = xg[(s + XD < len[r]) ? oa[r] + (unsigned)XD * dstep : opark[r]];
@@ -342,7 +346,9 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         if (kb + ks >= KS) continue;                       // H = 320: 10 chunks = 8 + 2
-        if constexpr (EARLY) {
+        if constexpr ((ABL & 2) != 0) {
+          afr[ks] = wreg[1][kb + ks];
+        } else if constexpr (EARLY) {
           if (kb + ks >= KO) afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + krot(kb + ks + g * KO) * 64);
         } else {
           afr[ks] = *reinterpret_cast<const bf16x8_t*>(hcur + lrd + (kb + ks) * 64);
@@ -358,6 +364,12 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
       for (int ks = 0; ks < 8; ++ks) {
         if (EARLY && kb + ks < KO) continue;
         if (kb + ks >= KS) continue;
+        if constexpr ((ABL & 4) != 0) {                     // keeps the dependence on every fragment, nothing else
+          const xw4_t fb = __builtin_bit_cast(xw4_t, afr[ks]);
+          acc0[0] = __uint_as_float(__float_as_uint(acc0[0]) ^ (fb[0] & 1u));
+          acc1[0] = __uint_as_float(__float_as_uint(acc1[0]) ^ (fb[3] & 1u));
+          continue;
+        }
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[0][kb + ks], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], wreg[1][kb + ks], acc1, 0, 0, 0);
       }
@@ -382,6 +394,14 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 #pragma unroll
     for (int r = 0; r < 2; ++r) act[r] = s < len[r];
     const f32x4_t xr[2] = {x0, x1};
+    if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        ig[r] = pi[r] + xr[r][0]; gg[r] = pq[r] + xr[r][1]; fg[r] = pf[r] + xr[r][2]; og[r] = po[r] + xr[r][3];
+        cn[r] = c[r];
+        hn[r] = fminf(fmaxf((ig[r] + gg[r]) + (fg[r] + og[r]), -1.f), 1.f);
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < 2; ++r) ig[r] = cfsig(pi[r] + xr[r][0] + wci * c[r]);
 #pragma unroll
@@ -397,6 +417,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     for (int r = 0; r < 2; ++r) og[r] = cfsig(po[r] + xr[r][3] + wco * cn[r]);
 #pragma unroll
     for (int r = 0; r < 2; ++r) hn[r] = cftanh(cn[r]) * og[r];
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       c[r] = act[r] ? cn[r] : c[r];
@@ -407,7 +428,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     const float nb = dpp_xor1(odd ? hr[0] : hr[1]);
     const unsigned pk = odd ? pack_bf16x2(nb, hr[1]) : pack_bf16x2(hr[0], nb);
     const unsigned etag = xw_tag(s);
-    if constexpr (XW) {
+    if constexpr ((ABL & 128) != 0) {
+    } else if constexpr (XW) {
       unsigned* pw = uoff(xw + (size_t)(P * G + g) * SLICE, pofs);
       nonfin |= pk;                                        // bit 14 / 30 of a FINITE |h| <= 1 is clear (see the tail)
       const unsigned tv = (pk & ~XW_MASK) | etag;
@@ -449,7 +471,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     const unsigned long long t2 = C8_T();
     if constexpr (EARLY) {
       if (s + 1 < tmax) {                                  // block-uniform
-        __syncthreads();                                   // the CU's own slice of h(s) is complete in hnxt
+        if constexpr (!(ABL & 32)) __syncthreads();        // the CU's own slice of h(s) is complete in hnxt
         bf16x8_t ao[KO];
 #pragma unroll
         for (int k = 0; k < KO; ++k) ao[k] = *reinterpret_cast<const bf16x8_t*>(hnxt + lrd + krot(k + g * KO) * 64);
@@ -479,6 +501,11 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 #pragma unroll 1
         for (;;) {                                         // wave-uniform loop: no exec masking
           asm volatile("" ::: "memory");                   // every round is a fresh set of loads
+          if constexpr ((ABL & 512) != 0) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) v[j] = (xw4_t){pk, pk, pk, pk};
+            break;
+          }
 #pragma unroll
           for (int j = 0; j < NL; ++j)                      // L1-bypassing (sc1) 16-byte loads, counted on vmcnt by the compiler
             v[j] = __builtin_amdgcn_raw_buffer_load_b128(xwrs, xvoff[j], pbytes, 16);
@@ -490,12 +517,18 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
             bad |= v[j][0] | v[j][1] | v[j][2] | v[j][3];
           }
           if (__all((bad & XW_MASK) == 0u)) break;
+          if constexpr ((ABL & 1) != 0) break;              // one round, whatever it carries
           if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
         }
         if (DBG) nspin += spins;
         C8_FPIN(7);                                        // behind the poll loop
+        if constexpr ((ABL & 256) != 0) {
+#pragma unroll
+          for (int j = 0; j < NL; ++j) asm volatile("" ::"v"(v[j]));
+        } else {
 #pragma unroll
         for (int j = 0; j < NL; ++j) *reinterpret_cast<xw4_t*>(hnxt + xldst[j]) = v[j];
+        }
         C8_FPIN(8);                                        // behind the LDS staging
       } else {
       u64 v[G - 1];
@@ -521,7 +554,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     }
     // saved activations: stored behind the poll loop -- on gfx950 loads and stores share one in-order counter, so a poll
     // issued after these stores waits for their acknowledgements too (0.921 -> 0.908 ms per launch)
-    if constexpr (LATE_STORE) {
+    if constexpr (LATE_STORE && !(ABL & 16)) {
       const bool pact = odd ? act[1] : act[0];
       const unsigned poff = (odd ? offs[1] : offs[0]) - (odd ? 1u : 0u);
       *reinterpret_cast<unsigned*>(hout + poff) = pact ? pk : 0u;
@@ -533,7 +566,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
     }
     C8_FPIN(3);
     const unsigned long long t3 = C8_T();
-    __syncthreads();
+    if constexpr (!(ABL & 32)) __syncthreads();
     if (DBG) {
       const unsigned long long t4 = C8_T();
       ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
@@ -617,7 +650,11 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 // stores per lane and tile (rows 0,1 -> the hh = 0 word, rows 2,3 -> hh = 1) instead of one 16-byte store.  Same words,
 // same tags, same summation order: bit-identical to XP = false.  Which form runs: bwd_xp_enabled() (a win only on the
 // eight-wave clusters, measured there).
-template <int H, bool DBG, int HSU = 64, int PIN = -1, bool XP = true>
+// ABL (builds with -DASR_LSTM_ABLATE only): bit k set = piece k of the step is left out, as in the forward kernel.  0: the
+// poll loop does not wait for valid tags, 1: no A-fragment reads from LDS, 2: no MFMAs, 3: no gate-gradient math, 4: no
+// dgates store to memory, 5: no barrier, 6: no fetch of the saved activations, 7: no publish stores, 8: no dG write to
+// LDS, 9: no poll loads at all.
+template <int H, bool DBG, int HSU = 64, int PIN = -1, bool XP = true, int ABL = 0>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
     const float* __restrict__ cs, const bf16_t* __restrict__ whpb, const float* __restrict__ peep,
@@ -787,6 +824,9 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p)                     // L1-bypassing (sc1) 16-byte loads, counted on vmcnt by the compiler
           pq[p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff16, pslot(1 - P, g, wt, hh, p) * 16u, 16);
+      } else if constexpr ((ABL & 512) != 0) {
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) pv[k] = (u64)(unsigned)lane;
       } else {
 #pragma unroll
         for (int k = 0; k < G - 1; ++k)
@@ -870,6 +910,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
 #pragma unroll
           for (int k = 0; k < G - 1; ++k) ok = ok && ((pv[k] & wmask) == wtag);
           if (__all(ok)) break;
+          if constexpr ((ABL & (1 | 512)) != 0) break;       // whatever the first round carried
           if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
 #pragma unroll
           for (int k = 0; k < G - 1; ++k)
@@ -892,7 +933,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     // step to arrive.  (Written as the second arm of a run-time switch on purpose: as an unconditional statement the
     // compiler schedules these independent loads differently and the launch takes 1.06 ms.)
     C8_PIN(6);                                             // behind the poll loop, in front of the fetch
-    if constexpr (HSU == 32) {
+    if constexpr ((ABL & 64) != 0) {
+    } else if constexpr (HSU == 32) {
       // unconditional (the last iteration re-fetches its own rows: harmless) and pinned behind the loop by a compiler
       // barrier: behind a branch the wait-count pass waits with vmcnt(0) -- for THIS fetch -- at the join
       asm volatile("" ::: "memory");
@@ -918,6 +960,10 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const float dh = pdhv[r] + dhr[r];
+      if constexpr ((ABL & 8) != 0) {
+        zi[r] = zg[r] = zf[r] = zo[r] = dh;
+        dhr[r] = 0.f;
+      } else {
       const float d_o = dh * a_o[r];
       const float dc = dcr[r] + dh * b_c[r] + d_o * wco;
       const float d_g = dc * c_g[r], d_i = dc * c_i[r], d_f = dc * c_f[r];
@@ -925,14 +971,16 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
       dhr[r] = act[r] ? 0.f : dhr[r];
       zi[r] = act[r] ? d_i : 0.f; zg[r] = act[r] ? d_g : 0.f;
       zf[r] = act[r] ? d_f : 0.f; zo[r] = act[r] ? d_o : 0.f;
+      }
       cc[r] = ldp[r] ? pcpv[r] : 0.f;
       const cbf16x4_t pk = {(__bf16)zi[r], (__bf16)zg[r], (__bf16)zf[r], (__bf16)zo[r]};
-      *reinterpret_cast<cbf16x4_t*>(smem + P * DGB + lwr[r]) = pk;
-      dgates[off[r]] = pk;
+      if constexpr (!(ABL & 256)) *reinterpret_cast<cbf16x4_t*>(smem + P * DGB + lwr[r]) = pk;
+      if constexpr (!(ABL & 16)) dgates[off[r]] = pk;
+      if constexpr ((ABL & (256 | 16)) == (256 | 16)) asm volatile("" ::"v"(pk));
     }
     C8_PIN(2);
     const unsigned long long t2 = C8_T();
-    __syncthreads();
+    if constexpr (!(ABL & 32)) __syncthreads();
     C8_PIN(7);                                             // behind the step's barrier
     // peephole / bias gradient sums: off the critical path, behind the barrier
 #pragma unroll
@@ -945,7 +993,10 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     if (s > 0) {
       bf16x8_t afr[KC];
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) afr[kc] = *reinterpret_cast<const bf16x8_t*>(smem + P * DGB + lrd + kc * 64);
+      for (int kc = 0; kc < KC; ++kc) {
+        if constexpr ((ABL & 2) != 0) afr[kc] = wf[0][kc];
+        else afr[kc] = *reinterpret_cast<const bf16x8_t*>(smem + P * DGB + lrd + kc * 64);
+      }
       __builtin_amdgcn_sched_barrier(0);
       const unsigned tag = (((unsigned)it >> 1) + 1u) & 1u;
       auto tagged = [&](const f32x4_t& a) {
@@ -958,7 +1009,9 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
       auto publish = [&](int nt, const f32x4_t& tv, auto FAST) {
         constexpr bool F = decltype(FAST)::value;
         const int dst = nt / TPC, tile = nt % TPC;
-        if constexpr (XP) {
+        if constexpr ((ABL & 128) != 0) {
+          asm volatile("" ::"v"(tv));
+        } else if constexpr (XP) {
           // Compiler-issued buffer stores, NOT inline asm with an SGPR base: with 16 slot bases per step (H = 512) the
           // bases are spilled to VGPR lanes and restored by v_readlane right in front of the store, and a VALU-written
           // SGPR needs 5 wait states before a VMEM instruction may use it as its address -- a hazard the compiler
@@ -990,7 +1043,10 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-          for (int i = 0; i < NF; ++i) af[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[i][kc], af[i], 0, 0, 0);
+          for (int i = 0; i < NF; ++i) {
+            if constexpr ((ABL & 4) != 0) af[i][0] = __uint_as_float(__float_as_uint(af[i][0]) ^ (__builtin_bit_cast(xw4_t, afr[kc])[i & 3] & 1u));
+            else af[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[i][kc], af[i], 0, 0, 0);
+          }
         if (fast) {
 #pragma unroll
           for (int i = 0; i < NF; ++i)
@@ -1027,7 +1083,10 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
       } else {
         f32x4_t ao = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wo[kc], ao, 0, 0, 0);
+        for (int kc = 0; kc < KC; ++kc) {
+          if constexpr ((ABL & 4) != 0) ao[hh ? 2 : 0] = __uint_as_float(__float_as_uint(ao[hh ? 2 : 0]) ^ (__builtin_bit_cast(xw4_t, afr[kc])[0] & 1u));
+          else ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wo[kc], ao, 0, 0, 0);
+        }
         dhr[0] += hh ? ao[2] : ao[0];
         dhr[1] += hh ? ao[3] : ao[1];
       }
@@ -2667,6 +2726,18 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   if constexpr (HSU == 32 && H == 256) {
     if (early && !g_cdbg_host)
       k = xw ? lstm_fwd_cluster8_kernel<H, false, true, HSU, 2 | 32, true> : lstm_fwd_cluster8_kernel<H, false, true, HSU, 2 | 32, false>;
+#ifdef ASR_LSTM_ABLATE
+    // scripts/probe_lstm_ablate.py: ASR_LSTM_ABL_FWD selects an ablated build of the headline kernel (garbage results)
+    if (const char* e = getenv("ASR_LSTM_ABL_FWD")) {
+      switch (atoi(e)) {
+#define ABLF(n) case n: k = lstm_fwd_cluster8_kernel<H, false, true, HSU, 2 | 32, true, n>; break;
+        ABLF(1) ABLF(2) ABLF(4) ABLF(8) ABLF(16) ABLF(32) ABLF(64) ABLF(128) ABLF(256) ABLF(512)
+        ABLF(513) ABLF(515) ABLF(519) ABLF(527) ABLF(545) ABLF(769) ABLF(1023) ABLF(6) ABLF(14) ABLF(48) ABLF(800)
+#undef ABLF
+        default: break;
+      }
+    }
+#endif
   }
   // (padding the LDS request past half a CU so that two 4-wave members can never share one was measured: no
   // difference, 866.7 vs 867.6 us -- the dispatcher spreads the members over the CUs by itself)
@@ -2714,6 +2785,19 @@ static bool cluster_bwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   const bool xp = bwd_xp_enabled(HSU);
   auto k = g_cdbg_host ? (xp ? lstm_bwd_cluster8_kernel<H, true, HSU, -1, true> : lstm_bwd_cluster8_kernel<H, true, HSU, -1, false>)
                        : (xp ? lstm_bwd_cluster8_kernel<H, false, HSU, -1, true> : lstm_bwd_cluster8_kernel<H, false, HSU, -1, false>);
+#ifdef ASR_LSTM_ABLATE
+  if constexpr (HSU == 32 && H == 256) {
+    if (const char* e = getenv("ASR_LSTM_ABL_BWD")) {
+      switch (atoi(e)) {
+#define ABLB(n) case n: k = lstm_bwd_cluster8_kernel<H, false, HSU, -1, false, n>; break;
+        ABLB(1) ABLB(2) ABLB(4) ABLB(8) ABLB(16) ABLB(32) ABLB(64) ABLB(128) ABLB(256) ABLB(512)
+        ABLB(513) ABLB(515) ABLB(519) ABLB(527) ABLB(545) ABLB(641) ABLB(1023) ABLB(6) ABLB(14) ABLB(144) ABLB(80)
+#undef ABLB
+        default: break;
+      }
+    }
+  }
+#endif
   hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir, dhout,
                      (const cbf16x4_t*)gates, cs, (const bf16_t*)whpb, peep, seq_len, dcf, dhf,
                      (cbf16x4_t*)dgates, dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);

@@ -906,9 +906,9 @@ class DeferredCheck(object):
     the device, and NEVER more than DEPTH (4) optimizer STEPS late, however many CTC heads arm a counter per step
     (MultitaskCTC arms two): a copy armed DEPTH steps ago is waited for (the device's ErrorWatch counts the steps:
     note_step()); without optimizer steps in between (a loop of compute_loss calls) at most RING - 1 copies are pending.
-    The optimizer has applied the updates of the steps in between.  An error removes only ITS copy: the other pending
-    ones (another head's, a later step's) are still inspected at the following arm() / flush().  flush() is the blocking
-    form; it runs at every sync point: evaluation (is_training=False), Saver.save / check_async_errors (checkpoints), the
+    The optimizer has applied the updates of the steps in between.  An error DROPS every other pending copy (another
+    head's, the later steps' -- which ran on the state the failing step left and would only repeat the report while the
+    caller restores its checkpoint): one exception per incident.  flush() is the blocking form; it runs at every sync point: evaluation (is_training=False), Saver.save / check_async_errors (checkpoints), the
     end of the recipes' epochs, and at interpreter exit (a pending error is printed, it cannot be raised any more)."""
     DEPTH = 4          # optimizer steps
     RING = 16          # pinned slots: >= DEPTH x the heads of any model here, and the cap when no optimizer steps run
@@ -934,8 +934,7 @@ class DeferredCheck(object):
             self.waited_s += _time.perf_counter() - t0
         n = int(host[0])
         if n:
-            if self.slots and self.slots[0][0] is host:
-                self.slots.pop(0)
+            self.slots = []
             # a timed-out cluster hand-off leaves NaN activations, which the CTC kernels count as infeasible rows: report the
             # root cause (AsrError from the sticky error word) rather than its symptom
             check_async_errors(self.device if self.device is not None else torch.cuda.current_device(), flush_deferred=False)

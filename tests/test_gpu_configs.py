@@ -105,8 +105,6 @@ def test_cfgD_long_sequences_bf16(cuda):
                          lam=0.5, prev_alpha='carry', seed=34)
     print('\n' + r['report'])
     _no_handoff_errors()
-    assert r['loss_rel'] < 2e-3 and r['seq_loss_rel'] < 2e-3 and r['ctc_losses_rel'] < 5e-3, r['report']
-    assert r['alpha_abs'] < 2e-3, r['report']
     assert r['loss_rel'] < 1e-4 and r['seq_loss_rel'] < 5e-4 and r['ctc_losses_rel'] < 1e-3, r['report']
     assert r['alpha_abs'] < 1e-6 and r['logits_abs'] < 1.2e-2 * max(1.0, r['logits_max']), r['report']
     assert r['grad_global_l2'] < 2.3e-2 and r['grad_worst_l2'] < 5e-2, r['report']
@@ -142,6 +140,39 @@ def test_cfgD_decoder_widths_fp32_directly_against_the_oracle(cuda):
     fp32 at H = 512 would only add minutes of single-CU recurrence to a test about the decoder.)"""
     r = cp.run_attention('cuda:0', 'f32', 'location', B=6, T=200, To=40, D=240, H=128, L=2, U=512, A=128, Em=64, C=28,
                          lam=0.5, prev_alpha='carry')
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 1e-4 and r['seq_loss_rel'] < 1e-4 and r['ctc_losses_rel'] < 1e-4, r['report']
+    assert r['alpha_abs'] < 1e-5 and r['ids_mismatch'] == 0, r['report']
+    assert r['grad_worst'] < 2e-3, r['report']
+
+
+def test_cfgD_5x512_fp32_at_its_own_widths_against_the_plain_oracle(cuda):
+    """configs[3] at its OWN widths -- 5 x 512 BLSTM encoder (fp32 cluster recurrences: exact-fp32 MFMA), LOCATION
+    attention A = 128, decoder U = 512, embedding 64, 30 classes + the 29-class CTC head, lambda 0.5, carried previous
+    weights -- with fp32 operands end to end against the PLAIN fp64 oracle (no rounding points): the parity statement of
+    north_star (loss within 1e-4 relative in fp32) at the configuration's widths rather than on a narrower encoder
+    (VERDICT r05 missing 3); T is what is cut (160 frames, three scoring chunks; 30 decoder steps), not the widths.
+    Bars: joint loss / sequence loss / per-utterance CTC <= 1e-4, attention weights <= 1e-5, teacher-forced ids
+    identical, every gradient <= 2e-3 of its largest entry.
+    Reference: models/attention/joint_ctc_attention.py:237-346, attention_layer.py:191-265, attention_decoder.py:142-295."""
+    r = cp.run_attention('cuda:0', 'f32', 'location', B=6, T=160, To=30, D=240, H=512, L=5, U=512, A=128, Em=64, C=28,
+                         lam=0.5, prev_alpha='carry', seed=36)
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 1e-4 and r['seq_loss_rel'] < 1e-4 and r['ctc_losses_rel'] < 1e-4, r['report']
+    assert r['alpha_abs'] < 1e-5 and r['ids_mismatch'] == 0, r['report']
+    assert r['grad_worst'] < 2e-3, r['report']
+
+
+def test_cfgE_hybrid_kanji_5x512_fp32_at_its_own_widths_against_the_plain_oracle(cuda):
+    """configs[4] at its OWN widths with fp32 operands end to end: 5 x 512 encoder on D = 246, HYBRID attention, the
+    3 388-class attention softmax and the 3 387-class CTC head, against the plain fp64 oracle at the fp32 bars (the
+    bf16 run of this configuration is held to the oracle at bf16 rounding points; this is the run that carries the
+    1e-4 statement).  B = 4, T = 120, 20 decoder steps.
+    Reference: models/attention/attention_layer.py:191-229, joint_ctc_attention.py:182-346."""
+    r = cp.run_attention('cuda:0', 'f32', 'hybrid', B=4, T=120, To=20, D=246, H=512, L=5, U=512, A=128, Em=64, C=3386,
+                         lam=0.5, prev_alpha='zeros', seed=37)
     print('\n' + r['report'])
     _no_handoff_errors()
     assert r['loss_rel'] < 1e-4 and r['seq_loss_rel'] < 1e-4 and r['ctc_losses_rel'] < 1e-4, r['report']
