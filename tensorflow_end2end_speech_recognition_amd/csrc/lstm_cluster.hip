@@ -607,6 +607,11 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
   }
 }
 
+// (Round 6, profiles/r06_lstm_ablation.md -- the step with one piece compiled out at a time, ABL above: free-running (no
+// poll at all) the forward step is 0.753 of its 0.929 us, i.e. the cross-CU exchange is 19 % of the step; the A-fragment
+// reads cost 0.016 - 0.05 us (the "800 exposed LDS cycles" of the round-5 s_memtime table were the timers: s_memtime returns
+// on the counter the LDS reads use), the MFMAs 0.10, gate math 0.11 - 0.13, the two barriers 0.11, staging 0.03 - 0.06,
+// stores 0.044, x fetch 0.033, and 0.23 is publish / own-slice hop / DPP / addresses.  No piece is above 14 %.)
 // (Round 5, built and measured: a forward kernel WITHOUT the LDS image -- the slice layout [wave][row][8 units] is already the
 // A operand of v_mfma_f32_16x16x32_bf16, so every wave polled the 16 bytes per lane of ALL G slices and multiplied them as
 // they came: no staging, no barrier, no LDS read on the chain.  Correct (same parity figures) and SLOWER: 695 -> 805 - 813 us

@@ -25,6 +25,21 @@ from . import rnn_util
 from .rnn_util import LSTMLayer, LSTMPLayer, declare_lstm_vars, declare_lstmp_vars
 
 WARM_BPTT = _os.environ.get('ASR_WARM_BPTT', '1') != '0'    # A-B switch of the read pass ahead of each BPTT kernel
+# Two half-batch pipelines (round 6; built, measured, OFF by default).  A recurrence kernel occupies 16 CUs per
+# (16-utterance tile, direction) -- 64 - 128 of the 256 at B = 32 / 64 -- and the chip-wide products between two recurrences
+# (the next layer's x W_x: 0.5 - 1.1 ms at 4 - 5 x 512, the dx product of the backward pass: 0.4 - 0.9 ms) run strictly
+# between them.  With ASR_ENC_HALVES=1 (or encoder.halves = True) a batch of at least two tiles is cut at a tile boundary
+# and the two parts go through the layer stack as independent pipelines on two streams (main and lane PIPE_LANE, each with
+# its own handle, i.e. its own exchange areas), so that the products of one part run under the recurrences of the other; the
+# parts meet again in the outputs (one concatenation) and in the weight gradients (the second part's GEMMs accumulate onto
+# the first's: same lanes, fixed order).  Correct (CPU + GPU parity tests run it) and SLOWER (profiles/r06_halves_ab.md): a
+# recurrence launch takes as long for half the tiles as for all of them (the chain is T, not B), so a pipeline saves only
+# HALF of each product, and two recurrences + a GEMM side by side cost each other more than that: cfg C 58.1 -> 63.8 ms,
+# cfg D 71.9 -> 74.6, cfg E 42.2 -> 44.5 with 8 hardware queues; with the runtime's default 4 the fifth stream shares a
+# queue and the pipelines serialise (70.6 / 81.1 / 47.8).  (The dropout masks of the two forms differ: a mask is indexed
+# by the element's position in ITS part's tensor.)
+ENC_HALVES = _os.environ.get('ASR_ENC_HALVES', '0') == '1'
+PIPE_LANE = 6
 
 # tf.contrib.rnn.LSTMStateTuple: what the reference's encoders hand back as final state (.c, .h)
 LSTMStateTuple = collections.namedtuple('LSTMStateTuple', ('c', 'h'))
@@ -66,6 +81,9 @@ class _RecurrentEncoderBase(object):
         self.side_extra = None         # callable run on the side stream after the weight images (once per call)
         self.side_extra_event = None
         self.want_f32_outputs = True   # False: __call__ returns the operand-dtype outputs (no fp32 copy is made)
+        self.halves = ENC_HALVES       # two half-batch pipelines where the batch has at least two tiles (see ENC_HALVES)
+        self.layers_b = None           # twin layer objects (same variables, own tape) of the second pipeline
+        self._split = 0                # rows of the first part in the last __call__ (0: one pipeline)
 
     # variables are created at graph-build time in the reference; here when the input size is known
     def build(self, store, input_dim, rng, scope_prefix=''):
@@ -150,6 +168,10 @@ class _RecurrentEncoderBase(object):
                 dm = drop_masks[li] if drop_masks is not None else None
                 preps[li]['mask'] = layer.make_mask(inputs.device, Tt, Bp, keep_prob, is_training, rs_of(li), dm)
                 ready_m.append(ops.stream_event())
+        self._split = self._split_rows(Bp) if drop_masks is None else 0
+        if self._split:
+            x, finals = self._forward_halves(inputs, seq_len, preps, ready_w, ready_m, keep_prob, is_training, ldk0)
+            return self._finish_call(x, finals, seq_len, B)
         x = ops.bt_to_tb(inputs.contiguous(), self.dtype, ld=ldk0)       # blstm.py:277-279
         final = None
         finals = []
@@ -166,12 +188,15 @@ class _RecurrentEncoderBase(object):
             if self.num_layers_sub is not None and li + 1 == self.num_layers_sub:
                 # blstm.py:326-328: outputs_sub IS the tensor the next layer consumes (after the dropout wrapper)
                 self._out_sub_op, self._final_sub_ch = x, final
+        return self._finish_call(x, finals, seq_len, B)
+
+    def _finish_call(self, x, finals, seq_len, B):
         self.seq_len_padded = seq_len
         self._out_op = x   # time-major padded-batch outputs in the MFMA operand dtype
         # the fp32 copy the reference's callers receive; models that only consume the operand copy switch it off
         out = ops.cast_to_f32(x) if (x.dtype != torch.float32 and self.want_f32_outputs) else x
         self._out_tm = out
-        cf, hf = final
+        cf, hf = finals[-1]
         self._final_ch = (cf, hf)          # [ndir,Bp,H] each (the attention bridge consumes these)
         self._finals = finals
         final_state = self._state_tuple(finals, len(finals))
@@ -179,6 +204,63 @@ class _RecurrentEncoderBase(object):
         if not self.time_major:
             out_user = out_user.transpose(0, 1)
         return out_user, final_state
+
+    # ---- two half-batch pipelines (ENC_HALVES)
+    def _split_rows(self, Bp):
+        """Rows of the first part (a multiple of 16), or 0 for one pipeline."""
+        tiles = Bp // 16
+        if not self.halves or tiles < 2 or self.num_proj is not None or self.num_layers_sub is not None:
+            return 0
+        return ((tiles + 1) // 2) * 16
+
+    def _twins(self):
+        if self.layers_b is None:
+            self.layers_b = [LSTMLayer(l.store, l.bases, l.din, l.H, l.use_peephole, l.forget_bias, l.cell_clip)
+                             for l in self.layers]
+        return self.layers_b
+
+    @staticmethod
+    def _second_mask(mask):
+        """The dropout descriptor of the second part: the same stream, entered 2^30 counters further on (a part's own
+        counters stay below 2^29: T B W / 4 with T B W < 2^31, asserted by the recurrence kernels)."""
+        return (mask[0], mask[1], mask[2] + (1 << 30)) if isinstance(mask, tuple) else mask
+
+    def _forward_halves(self, inputs, seq_len, preps, ready_w, ready_m, keep_prob, is_training, ldk0):
+        dev = inputs.device
+        B0, Bp = self._split, inputs.shape[0]
+        parts = ((0, B0, self.layers), (B0, Bp, self._twins()))
+        start = ops.stream_event()                  # the inputs exist on the main stream here
+        xs, fins = [None, None], [[], []]
+        sl = [seq_len[lo:hi].contiguous() for lo, hi, _ in parts]
+        for li in range(len(self.layers)):
+            for h, (lo, hi, layers) in enumerate(parts):
+                ctx = ops.side_lane(dev, keep=(inputs, seq_len, sl[1]), lane=PIPE_LANE, after=start) if h else _NoLane()
+                with ctx:
+                    if li == 0:
+                        xs[h] = ops.bt_to_tb(inputs[lo:hi].contiguous(), self.dtype, ld=ldk0)
+                        # the second pipeline waits once, for the weight images of every layer (the side lane that builds
+                        # them is in order); the first one as the single pipeline does
+                        ops.wait_event(ready_w[-1] if h else ready_w[0])
+                    elif not h:
+                        if not rnn_util.FORK_ONCE:
+                            ops.wait_event(ready_w[li])
+                        elif li == 1:
+                            ops.wait_event(ready_w[-1])
+                    prep = preps[li] if not h else dict(preps[li], mask=self._second_mask(preps[li]['mask']))
+                    xs[h], fin = layers[li].forward(xs[h], sl[h], self.dtype, keep_prob, is_training, prep=prep,
+                                                    mask_event=ready_m[li])
+                    fins[h].append(fin)
+                    if h and li + 1 == len(self.layers):
+                        done = ops.stream_event()
+        ops.wait_event(done)
+        ops.keep_on_lane(dev, PIPE_LANE, (xs[1],) + tuple(t for f in fins[1] for t in f))
+        x = torch.cat([xs[0], xs[1]], 1)
+        # final states: the last layer's for the bidirectional stack, every layer's for the unidirectional one
+        finals = []
+        for li, (a, b) in enumerate(zip(fins[0], fins[1])):
+            need = self.ndir == 1 or li + 1 == len(self.layers)
+            finals.append((torch.cat([a[0], b[0]], 1), torch.cat([a[1], b[1]], 1)) if need else (None, None))
+        return x, finals
 
     def _call_projected(self, inputs, inputs_seq_len, keep_prob, is_training, drop_masks, rng_state):
         """lstm_impl='LSTMCell' with num_proj: the stack on LSTMPLayer.  Outputs [T,B,ndir*P]; final state
@@ -235,6 +317,8 @@ class _RecurrentEncoderBase(object):
                     self.grad_ready_hook(li, self.layers[li])
             ops.join_side(d_outputs.device)
             return dx
+        if self._split:
+            return self._backward_halves(d_outputs, d_final, need_input_grad)
         dx = d_outputs
         masked = False
         for li in reversed(range(len(self.layers))):
@@ -263,6 +347,61 @@ class _RecurrentEncoderBase(object):
                 self.grad_ready_hook(li, self.layers[li])
         ops.join_side(d_outputs.device)      # weight-gradient GEMMs issued on the side stream
         return dx
+
+
+    def _backward_halves(self, d_outputs, d_final, need_input_grad):
+        """backward() of a call that went through _forward_halves: the same two pipelines, top layer first; per layer the
+        first part leaves its weight-gradient products to the second, whose twin layer writes the variables."""
+        dev = d_outputs.device
+        B0 = self._split
+        dxs = [d_outputs[:, :B0].contiguous(), d_outputs[:, B0:].contiguous()]
+        dfin = [(None, None), (None, None)]
+        if d_final is not None:
+            dcf, dhf = d_final
+            dfin = [(dcf[:, :B0].contiguous(), dhf[:, :B0].contiguous()), (dcf[:, B0:].contiguous(), dhf[:, B0:].contiguous())]
+        start = ops.stream_event()
+        stacks = (self.layers, self.layers_b)
+        masked = [False, False]
+        top = len(self.layers) - 1
+        for li in reversed(range(len(self.layers))):
+            acc = None
+            for h, layers in enumerate(stacks):
+                ctx = ops.side_lane(dev, keep=(dxs[1],) + dfin[1], lane=PIPE_LANE, after=start) if h else _NoLane()
+                with ctx:
+                    below = layers[li - 1].ctx['mask'] if li > 0 else None
+                    cb = layers[li - 1].ctx if (li > 0 and WARM_BPTT) else None
+                    if cb is not None and (cb['gates'].numel() * cb['gates'].element_size() +
+                                           cb['cs'].numel() * cb['cs'].element_size()) > (64 << 20):
+                        cb = None
+                    dcf, dhf = dfin[h] if li == top else (None, None)
+                    dxs[h] = layers[li].backward(dxs[h].contiguous(), dcf, dhf, need_dx=(li > 0 or need_input_grad),
+                                                 dout_masked=masked[h], dx_mask=below, background=(li > 0),
+                                                 warm=(cb['gates'], cb['cs']) if cb is not None else None,
+                                                 acc=acc, finish=bool(h))
+                    ops.wait_event(getattr(layers[li], 'warm_event', None))
+                    masked[h] = below is not None
+                    if not h:
+                        acc = layers[li].acc
+                        layers[li].acc = None
+                    elif li == 0:
+                        done = ops.stream_event()
+            if self.grad_ready_hook is not None:      # the twin finished the layer: its event covers both parts
+                self.grad_ready_hook(li, self.layers_b[li])
+        ops.wait_event(done)
+        ops.join_side(dev)
+        if not need_input_grad:
+            return None
+        return torch.cat([dxs[0], dxs[1]], 1)
+
+
+class _NoLane(object):
+    """The main stream as a context (the first pipeline runs where the caller stands)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 class BLSTMEncoder(_RecurrentEncoderBase):

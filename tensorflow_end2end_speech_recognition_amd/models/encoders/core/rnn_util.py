@@ -132,8 +132,12 @@ class LSTMLayer(object):
         return out, (cf, hf)
 
     def backward(self, dout, d_c_final=None, d_h_final=None, need_dx=True, dout_masked=False, dx_mask=None,
-                 background=False, warm=None):
+                 background=False, warm=None, acc=None, finish=True):
         """dout [T,B,ndir*H] fp32 -> dx [T,B,din] fp32 (or None).  Fills store.grad.
+        acc / finish (the encoder's two half-batch pipelines, blstm.py): finish=False leaves the weight gradients of THIS
+        part of the batch in self.acc = dict(dw_il, dpeep) instead of the variables; the twin layer that handles the other
+        part takes that dict as `acc`, adds its own products to it (GEMMs with accumulate on the same side lanes, i.e.
+        behind the first part's in lane order: a fixed summation order) and writes the variables.
         dout_masked: the caller has already multiplied dout with this layer's dropout mask.
         dx_mask: dropout mask [T,B,din] of the layer BELOW: dx comes back already multiplied with it (in the epilogue
         of the dx GEMM), i.e. ready to be passed to that layer's backward with dout_masked=True.
@@ -174,25 +178,37 @@ class LSTMLayer(object):
                 fork = ops.stream_event()
         # weight gradients: side streams (one per direction), concurrent with the BPTT kernel of the layer
         # below (joined in the model's backward before clipping)
-        dw_il = torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols
+        add = acc is not None
+        dw_il = acc['dw_il'] if add else \
+            torch.empty((ndir, din + H, 4 * H), dtype=torch.float32, device=x.device)   # interleaved cols
         ops.set_side_gemm_workgroups(x.device, BG_WGS if background else 0)
         done = []
         for d in range(ndir):
             with ops.side_lane(x.device, keep=(x, hout, dgates, dpeep, dw_il), lane=1 + (d % DW_LANES), after=fork):
                 dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
-                ops.gemm(x2d, dg, transA=True, out=dw_il[d, :din])
+                ops.gemm(x2d, dg, transA=True, out=dw_il[d, :din], accumulate=add)
                 if T > 1:
                     if d == 0:   # forward direction: h_prev(t) = h(t-1)
-                        ops.gemm(h2d[:(T - 1) * B, d * H:(d + 1) * H], dg[B:], transA=True, out=dw_il[d, din:])
+                        ops.gemm(h2d[:(T - 1) * B, d * H:(d + 1) * H], dg[B:], transA=True, out=dw_il[d, din:],
+                                 accumulate=add)
                     else:        # backward direction: h_prev(t) = h(t+1) (zero beyond len-1)
-                        ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=dw_il[d, din:])
-                else:
+                        ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=dw_il[d, din:],
+                                 accumulate=add)
+                elif not add:
                     dw_il[d, din:].zero_()
                 if d % DW_LANES > 0:
                     done.append(ops.stream_event())
-        with ops.side_lane(x.device, lane=1, after=fork):
+        if not finish:
+            # the other part of the batch finishes the layer (its GEMMs follow these in the lanes' order)
+            self.acc = dict(dw_il=dw_il, dpeep=dpeep)
+            self.ctx = None
+            return dx
+        with ops.side_lane(x.device, keep=(dpeep,), lane=1, after=fork):
             for ev in done:
                 ops.wait_event(ev)
+            if add:      # bias / peephole sums of the two parts (lane 1 already stands behind the first part's BPTT)
+                dpeep = acc['dpeep'] + dpeep
+                ops.keep_on_lane(x.device, 1, (dpeep,))
             # interleaved columns -> TF's gate-major kernel gradient; bias / peephole gradients (accumulated
             # inside the BPTT kernel) to their variables: one launch for the layer
             ops.lstm_grad_finish(self._vars(st.g), dw_il, dpeep, H)

@@ -110,6 +110,13 @@ def set_side_gemm_workgroups(device, n):
             h._tn_wgs = n
 
 
+def keep_on_lane(device, lane, tensors):
+    """Hold `tensors` until join_side(): work already issued on side lane `lane` reads or writes them."""
+    st = _side.get((device.index or 0, int(lane)))
+    if st is not None:
+        st['keep'].extend(tensors)
+
+
 def join_side(device):
     """Main stream waits for all side-lane work; releases the tensors held for it."""
     dev = device.index or 0
@@ -830,8 +837,21 @@ def check_async_errors(device=0, flush_deferred=True):
     h = _lib.handle(device)
     flags = C.c_uint(0)
     rc = h.lib.asr_check_async_errors(h.h, C.byref(flags))
+    dkey = device.index or 0 if isinstance(device, torch.device) else int(device)
+    for (d, lane), h2 in list(_lib._handles.items()):
+        # recurrences also run on the second pipeline's lane (models/encoders/core/blstm.py PIPE_LANE): its handle has
+        # its own exchange areas and its own error word
+        if d == dkey and lane == WATCHED_SIDE_LANE:
+            f2 = C.c_uint(0)
+            rc2 = h2.lib.asr_check_async_errors(h2.h, C.byref(f2))
+            if f2.value:
+                h2.lib.asr_clear_async_errors(h2.h, _s())
+                flags.value |= f2.value
+                rc = rc or rc2
+                h = h2 if rc2 else h
     if flags.value:
-        h.lib.asr_clear_async_errors(h.h, _s())     # sticky until reported once
+        h0 = _lib.handle(device)
+        h0.lib.asr_clear_async_errors(h0.h, _s())     # sticky until reported once
         # ... and once only: the non-blocking watch may still hold copies of the same word armed before this point (the
         # device has been drained, they have all landed); left in its ring they would raise the error a second time up to
         # DEPTH optimizer steps later -- after the caller has restored its checkpoint
@@ -842,6 +862,9 @@ def check_async_errors(device=0, flush_deferred=True):
     if flush_deferred:
         _deferred_for(device).flush()                # the device is idle: every counter armed on it has landed
     return flags.value
+
+
+WATCHED_SIDE_LANE = 6     # == blstm.PIPE_LANE: the one side lane recurrence kernels are issued on
 
 
 class ErrorWatch(object):
@@ -855,7 +878,7 @@ class ErrorWatch(object):
 
     def __init__(self, device):
         self.dev = device
-        self.host = torch.zeros(self.DEPTH, dtype=torch.int32).pin_memory()
+        self.host = torch.zeros(2 * self.DEPTH, dtype=torch.int32).pin_memory()   # [slot] main handle, [DEPTH + slot] side lane's
         self.events = [None] * self.DEPTH
         self.i = 0
         self.waited_s = 0.0   # host time spent blocked on a step armed DEPTH polls ago (bench.py subtracts it)
@@ -869,10 +892,13 @@ class ErrorWatch(object):
                 t0 = _time.perf_counter()
                 ev.synchronize()
                 self.waited_s += _time.perf_counter() - t0
-            flags = int(self.host[slot])
+            flags = int(self.host[slot]) | int(self.host[self.DEPTH + slot])
             if flags:
                 h = _lib.handle(self.dev)
                 h.lib.asr_clear_async_errors(h.h, _s())
+                h2 = _lib._handles.get((self.dev, WATCHED_SIDE_LANE))
+                if h2 is not None:
+                    h2.lib.asr_clear_async_errors(h2.h, _s())
                 self.events = [None] * self.DEPTH
                 if flags & 3:
                     raise _lib.AsrError('LSTM cluster hand-off timed out (flags 0x%x): the recurrent state of a recent '
@@ -887,6 +913,11 @@ class ErrorWatch(object):
         h = _lib.handle(self.dev)
         h.check(h.lib.asr_peek_async_errors(h.h, C.c_void_p(self.host.data_ptr() + 4 * slot), _s()),
                 'asr_peek_async_errors')
+        self.host[self.DEPTH + slot] = 0
+        h2 = _lib._handles.get((self.dev, WATCHED_SIDE_LANE))
+        if h2 is not None:       # the second pipeline's handle (its work has been joined into this stream by now)
+            h2.check(h2.lib.asr_peek_async_errors(h2.h, C.c_void_p(self.host.data_ptr() + 4 * (self.DEPTH + slot)), _s()),
+                     'asr_peek_async_errors')
         ev = torch.cuda.Event()
         ev.record(_cur_stream())
         self.events[slot] = ev

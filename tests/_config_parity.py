@@ -93,7 +93,7 @@ def _randomise_biases(model, rng, scale=0.05):
     return sd
 
 
-def run_cfgC(device, dtype, B, T, F, W, H, L, C, seed=21, perturb_eps=0.0):
+def run_cfgC(device, dtype, B, T, F, W, H, L, C, seed=21, perturb_eps=0.0, halves=False):
     """BASELINE configs[2]: VGG front-end on [F, W, 3] frame images (splice W) -> bridge FC -> L x H BLSTM -> CTC
     (models/encoders/core/vgg_blstm.py:77-220, models/ctc/ctc.py:175-323).  B >= 17 puts two 16-utterance tiles
     through the recurrence and, with ragged lengths, the valid-frame gather in front of the convolutions."""
@@ -104,6 +104,7 @@ def run_cfgC(device, dtype, B, T, F, W, H, L, C, seed=21, perturb_eps=0.0):
     model = CTC(encoder_type='vgg_blstm', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
                 parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype=dtype, seed=7, device=device)
     sd = _randomise_biases(model, rng)
+    model.encoder.halves = bool(halves)
     loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
     opt = model._set_optimizer('sgd', 0.1)
     gv = opt.compute_gradients(loss, model=model)
@@ -162,7 +163,7 @@ def _split_grad_stats(out):
     out['grad_global_l2'] = _grad_report.global_l2
 
 
-def run_attention(device, dtype, att, B, T, To, D, H, L, U, A, Em, C, lam, prev_alpha, seed=33, joint=True):
+def run_attention(device, dtype, att, B, T, To, D, H, L, U, A, Em, C, lam, prev_alpha, seed=33, joint=True, halves=False):
     """BASELINE configs[3] / [4]: L x H BLSTM encoder -> bridge -> LSTM decoder (U) with `att` attention (A), teacher
     forced over To steps, (1 - lam) * sequence loss + lam * mean CTC loss on a 'ctc_output' head over the encoder
     outputs (models/attention/joint_ctc_attention.py:237-346, attention_layer.py:191-265, attention_decoder.py:142-295).
@@ -181,6 +182,7 @@ def run_attention(device, dtype, att, B, T, To, D, H, L, U, A, Em, C, lam, prev_
     else:
         model = AttentionSeq2Seq(**kw)
     sd = _randomise_biases(model, rng)
+    model.encoder.halves = bool(halves)      # the encoder's two half-batch pipelines (blstm.ENC_HALVES; off by default)
     ctc_list = [[int(v) for v in row if v >= 0] for row in ctc_labels]
     if joint:
         loss, logits, ctc_logits, otr, oinf = model.compute_loss(x, labels, ctc_labels, sl, lsl, 1.0, 1.0, 1.0)

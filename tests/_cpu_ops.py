@@ -887,7 +887,7 @@ def _relu_bwd_scaled(dout, out_dropped, keep):
 
 
 STAND_INS = dict(
-    side_lane=_NullLane, join_side=lambda device: None, stream_event=lambda: None, set_side_gemm_workgroups=lambda device, n: None, wait_event=lambda ev: None,
+    side_lane=_NullLane, join_side=lambda device: None, keep_on_lane=lambda device, lane, tensors: None, stream_event=lambda: None, set_side_gemm_workgroups=lambda device, n: None, wait_event=lambda ev: None,
     gru_fwd=_gru_fwd, gru_bwd=_gru_bwd, lstm_prep_layer=_lstm_prep_layer, lstm_grad_finish=_lstm_grad_finish, bt_to_tb=_bt_to_tb, transpose2d=_transpose2d,
     cast_from_f32=_cast_from_f32, cast_to_f32=_cast_to_f32, apply_mask=_apply_mask, dropout_mask=_dropout_mask,
     dropout_apply=_dropout_apply, maxpool2x2_relu_bwd=_maxpool2x2_relu_bwd, touch=lambda t: None,

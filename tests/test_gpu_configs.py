@@ -180,6 +180,40 @@ def test_cfgE_hybrid_kanji_5x512_fp32_at_its_own_widths_against_the_plain_oracle
     assert r['grad_worst'] < 2e-3, r['report']
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_cfgD_two_pipelines_joint_location_two_tiles(cuda, dtype):
+    """configs[3] with TWO 16-utterance tiles (B = 20 -> 32 padded rows): the encoder runs its two half-batch pipelines
+    (models/encoders/core/blstm.py ENC_HALVES; measured slower than one pipeline and off by default, kept correct) -- two
+    recurrence launches per layer side by side on two streams / two
+    handles, final states of both parts into the bridge, the decoder's and the CTC head's gradients back into both
+    parts, weight gradients accumulated across them -- under the joint location model at the configuration's widths.
+    fp32: the plain oracle at the fp32 bars; bf16: the oracle at the device path's rounding points, bounds of
+    test_cfgD_joint_location_5x512_bf16."""
+    r = cp.run_attention('cuda:0', dtype, 'location', B=20, T=120, To=24, D=240, H=512, L=5, U=512, A=128, Em=64, C=28,
+                         lam=0.5, prev_alpha='carry', seed=38, halves=True)
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['model'].encoder._split == 16 and r['model'].encoder.layers_b is not None
+    if dtype == 'f32':
+        assert r['loss_rel'] < 1e-4 and r['seq_loss_rel'] < 1e-4 and r['ctc_losses_rel'] < 1e-4, r['report']
+        assert r['alpha_abs'] < 1e-5 and r['ids_mismatch'] == 0, r['report']
+        assert r['grad_worst'] < 2e-3, r['report']
+    else:
+        assert r['loss_rel'] < 2e-3 and r['seq_loss_rel'] < 2e-3 and r['ctc_losses_rel'] < 5e-3, r['report']
+        assert r['alpha_abs'] < 2e-3 and r['logits_abs'] < 3e-2 * max(1.0, r['logits_max']), r['report']
+        # (measured at B = 20: worst matrix entry 4.0e-2 of its maximum, relative L2 <= 2.4e-2 -- 2.0e-2 / 3.5e-2 at B = 6)
+        assert r['grad_worst_matrices'] < 6e-2 and r['grad_worst_peepholes'] < 8e-2 and r['grad_worst_l2'] < 4e-2, r['report']
+
+
+def test_cfgC_two_pipelines_vgg_two_tiles_fp32(cuda):
+    """The two half-batch pipelines under the VGG front-end (the input gradient of both parts back into the convolutions),
+    fp32 operands against the plain oracle at the fp32 bars."""
+    r = cp.run_cfgC('cuda:0', 'f32', B=20, T=40, F=40, W=11, H=256, L=2, C=28, halves=True)
+    print('\n' + r['report'])
+    _no_handoff_errors()
+    assert r['loss_rel'] < 1e-4 and r['per_utt_rel'] < 1e-4 and r['grad_worst'] < 2e-3, r['report']
+
+
 def test_cfgE_hybrid_kanji_vocabulary_bf16(cuda):
     """configs[4]: 5 x 512 encoder on D = 246 (123 x stack 2), HYBRID attention (projected keys + location term),
     a 3 388-class attention softmax (3 386 kanji + SOS + EOS) and the 3 387-class CTC head whose three [T*B x 2H x C]
