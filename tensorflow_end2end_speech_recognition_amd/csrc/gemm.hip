@@ -1743,7 +1743,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, i
   for (size_t i = widx * (size_t)blockDim.x + threadIdx.x; i < total; i += nwork * blockDim.x) {
     const int m = i / N, n = i % N;
     float v = bias ? bias[n] : 0.f;
-    for (int z = 0; z < S; ++z) v += partial[(size_t)z * total + i];
+    // the slabs' values are requested eight at a time and added in slab order (round 6: one dependent load per addition
+    // left this pass at the memory LATENCY per slab -- ~1 ms for 128 slabs where the bytes take 25 us; same sums, same order)
+    int z = 0;
+    for (; z + 8 <= S; z += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(z + u) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; z < S; ++z) v += partial[(size_t)z * total + i];
     TO* cp = C + (size_t)m * ldc + n;
     if (accumulate) v += load_out<TO>(cp);
     if (act == 1) v = fmaxf(v, 0.f);
@@ -2335,17 +2345,39 @@ __global__ __launch_bounds__(CIN * 4 * NSPLIT, 1) void conv3x3_wgrad_img_kernel(
   }
 }
 // fixed-order sum of the slabs of conv3x3_wgrad_img_kernel<..., BIAS = true>: rows [0, Mw) -> dw, rows Mw .. Mw + G - 1 -> dbias
+// Round 6: four columns per thread and eight slabs requested at a time, added in slab order -- the same sums in the same order
+// as the one-load-per-addition loop this replaces, which ran at the memory latency per slab (0.98 ms for the 128 slabs of
+// the 128 -> 128 layer at cfg C, three such passes on the lane that ends the step; the bytes take ~25 us).  N % 4 == 0 (the
+// image-resident kernel wants Cout % 64 == 0); VEC = 0: dw is not 16-byte aligned, scalar stores.
+template <int VEC>
 __global__ void wgrad_img_reduce_kernel(const float* __restrict__ partial, int S, int Mw, int G, int N, float* __restrict__ dw,
                                         float* __restrict__ dbias, int accumulate) {
-  const size_t slab = (size_t)(Mw + G) * N, total = (size_t)(Mw + 1) * N;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t wn = (size_t)Mw * N;
-    float v = 0.f;
-    if (i < wn) {
-      for (int z = 0; z < S; ++z) v += partial[(size_t)z * slab + i];
-      dw[i] = accumulate ? dw[i] + v : v;
+  const size_t slab = (size_t)(Mw + G) * N, wn = (size_t)Mw * N;
+  const size_t nv = wn / 4, slab4 = slab / 4;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x, tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const f32x4_t* p4 = reinterpret_cast<const f32x4_t*>(partial);
+  for (size_t q = tid; q < nv; q += nthreads) {
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 8 <= S; z += 8) {
+      f32x4_t t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = p4[(size_t)(z + u) * slab4 + q];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; z < S; ++z) v += p4[(size_t)z * slab4 + q];
+    if (VEC) {
+      f32x4_t* d = reinterpret_cast<f32x4_t*>(dw) + q;
+      *d = accumulate ? *d + v : v;
     } else {
-      const size_t n = i - wn;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dw[4 * q + k] = accumulate ? dw[4 * q + k] + v[k] : v[k];
+    }
+  }
+  if (dbias) {
+    for (size_t n = tid; n < (size_t)N; n += nthreads) {
+      float v = 0.f;
       for (int z = 0; z < S; ++z)
         for (int g = 0; g < G; ++g) v += partial[(size_t)z * slab + wn + (size_t)g * N + n];
       dbias[n] = accumulate ? dbias[n] + v : v;
@@ -2430,10 +2462,13 @@ static int conv3x3_bwd_weight_impl(asr_handle* h, const void* x, const void* dy,
       const size_t total = (size_t)M * N;
       int blocks = (int)((total + 255) / 256);
       if (blocks > 2048) blocks = 2048;
-      if (inb)
-        hipLaunchKernelGGL(wgrad_img_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, (int)wgs, M, G, N, dw, dbias,
-                           accumulate);
-      else
+      if (inb) {
+        const int rb = (int)((total / 4 + 255) / 256);
+        if (((uintptr_t)dw) % 16 == 0)
+          hipLaunchKernelGGL(wgrad_img_reduce_kernel<1>, dim3(rb), dim3(256), 0, st, partial, (int)wgs, M, G, N, dw, dbias, accumulate);
+        else
+          hipLaunchKernelGGL(wgrad_img_reduce_kernel<0>, dim3(rb), dim3(256), 0, st, partial, (int)wgs, M, G, N, dw, dbias, accumulate);
+      } else
         hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, partial, (int)wgs, M, N, dw, N,
                            nullptr, accumulate, 0, 0);
       ASR_CHECK_LAUNCH(h, "asr_conv3x3_bwd_weight(image-resident)");
