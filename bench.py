@@ -621,6 +621,24 @@ def run_attention_cfg(args, dev, dev_index, which):
                               clip_grad_norm=5.0, clip_activation_encoder=50, clip_activation_decoder=50, dtype='bf16',
                               seed=5, device=str(dev))
 
+    # greedy attention inference (attention_seq2seq.py:462-509) through the native loop: encoder + up to
+    # max_decode_length decoder steps with the output head, argmax and embedding feedback on the device, one read-back
+    try:
+        model.infer(xd, seq_len)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            ids = model.infer(xd, seq_len)
+        tinf = (time.perf_counter() - t0) / reps
+        infer_rec = dict(tokens_per_s=B * ids.shape[1] / tinf, ms_per_call=tinf * 1e3, decoded_steps=int(ids.shape[1]),
+                         steps_issued=int(model._infer_raw['steps_issued']), batch=B,
+                         note='encoder forward + native greedy decoder loop (asr_att_decoder_infer) on the training batch with '
+                              'the FRESHLY INITIALISED weights, i.e. before the timed training steps (rows then rarely emit EOS: '
+                              'max_decode_length steps; round 5 ran this leg after training, where the cfg E model had learnt to '
+                              'stop after 9 tokens and the figure was the encoder time over 288 tokens)')
+    except Exception as e:
+        infer_rec = dict(error=repr(e)[:300])
     def step():
         loss, *_ = model.compute_loss(xd, labels, ctc, seq_len, lens + 2, 0.8, 0.8, 0.8)
         model.train(loss, 'adam', 1e-3)
@@ -639,6 +657,7 @@ def run_attention_cfg(args, dev, dev_index, which):
                ms_per_step=res['elapsed'] / steps * 1e3, step_ms=res['step_ms'], final_loss=res['final_loss'],
                cluster_handoff_flags=res['handoff_flags'], kernels=res['kernels'],
                roofline=recurrence_roofline(H, frames * 2, T, 'bf16', res['kernels'], tiles=B // 16),
+               greedy_infer=infer_rec,
                parity_tests='model-level parity at these widths: tests/test_gpu_configs.py::test_cfg%s_*' % which)
     if not args.no_parity:
         # bounded parity leg: 4 utterances cut to 64 frames / 10 labels, dropout off, against the fp64 oracle evaluated at
@@ -681,22 +700,6 @@ def run_attention_cfg(args, dev, dev_index, which):
                                   sample='fp32-operand model with the same parameters on the same cut',
                                   seconds=time.perf_counter() - t0)
         del m32
-    # greedy attention inference (attention_seq2seq.py:462-509) through the native loop: encoder + up to
-    # max_decode_length decoder steps with the output head, argmax and embedding feedback on the device, one read-back
-    try:
-        model.infer(xd, seq_len)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 2
-        for _ in range(reps):
-            ids = model.infer(xd, seq_len)
-        tinf = (time.perf_counter() - t0) / reps
-        out['greedy_infer'] = dict(tokens_per_s=B * ids.shape[1] / tinf, ms_per_call=tinf * 1e3, decoded_steps=int(ids.shape[1]),
-                                   steps_issued=int(model._infer_raw['steps_issued']), batch=B,
-                                   note='encoder forward + native greedy decoder loop (asr_att_decoder_infer) on the training '
-                                        'batch, random-initialised weights (rows rarely emit EOS: max_decode_length steps)')
-    except Exception as e:
-        out['greedy_infer'] = dict(error=repr(e)[:300])
     if not args.no_cpu_baseline:
         nb, tc, lc = 4, 64, 10
         sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
