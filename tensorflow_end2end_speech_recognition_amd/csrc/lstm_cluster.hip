@@ -612,6 +612,11 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 // reads cost 0.016 - 0.05 us (the "800 exposed LDS cycles" of the round-5 s_memtime table were the timers: s_memtime returns
 // on the counter the LDS reads use), the MFMAs 0.10, gate math 0.11 - 0.13, the two barriers 0.11, staging 0.03 - 0.06,
 // stores 0.044, x fetch 0.033, and 0.23 is publish / own-slice hop / DPP / addresses.  No piece is above 14 %.)
+// (Round 6, built and measured, profiles/r06_helper_wave.md: a FIFTH wave per workgroup that owns the step's big arrays -- it
+// fetched the x rows ahead into an LDS image and copied the saved activations from an LDS image to memory, so that the chain
+// waves issued no global load / store at all.  Bit-identical.  An idle fifth wave costs nothing (690 vs 694 us per launch);
+// the stores through it gain 1.2 % at H = 256 (686 us) and LOSE 18 % at H = 512 (2 004 -> 2 380 us); x through LDS loses
+// 12 % whatever the prefetch depth (2 or 4 steps) and wherever the helper writes it (775 - 809 us).  Removed again.)
 // (Round 5, built and measured: a forward kernel WITHOUT the LDS image -- the slice layout [wave][row][8 units] is already the
 // A operand of v_mfma_f32_16x16x32_bf16, so every wave polled the 16 bytes per lane of ALL G slices and multiplied them as
 // they came: no staging, no barrier, no LDS read on the chain.  Correct (same parity figures) and SLOWER: 695 -> 805 - 813 us
