@@ -18,6 +18,7 @@
 //                    is deterministic; writes softmax - occupation   (1 read + 1 write)
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -123,12 +124,20 @@ __device__ __forceinline__ int dpp_shift_e(int v, bool right) {   // the lane wi
                : __builtin_amdgcn_update_dpp(ME_ZERO, v, 0x130, 0xF, 0xF, false);
 }
 
+// Round 6: NW waves per recursion.  With long label sequences (S = 2 L + 1 up to 801 states at cfg D: K = 16 states per lane) a
+// frame is K x ~16 dependent-ish instructions of ONE wave: 0.7 us at K = 8 (cfg C), 1.2 ms of a 58 ms step on the critical
+// path between the forward and the backward pass.  The states are dealt over NW x 64 lanes instead (K / NW per lane, lane
+// index = wave * 64 + lane); the two states that cross a WAVE boundary go through LDS (double-buffered by frame parity) behind
+// ONE workgroup barrier per frame.  Same operands, same operations per state: the values are bit-identical to NW = 1.
+struct CtcEdge { float m1, m2; int e1, e2; };
 // ybase / ws: rows in RECURSION order (step 0, 1, ...): for beta that is reversed time (row i = frame Tb-1-i).
-template <int K, int D, bool BETA>
+// `lane` is the lane index over all NW waves (0 .. 64 NW - 1); SPW = states per frame in memory (64 NW K).
+template <int K, int D, bool BETA, int NW>
 __device__ __forceinline__ void ctc_recursion(const MantExp* __restrict__ ybase, MantExp* __restrict__ ws, int Tb,
                                               int S, int lane, const int32_t* __restrict__ lab, float (&am)[K],
-                                              int (&ae)[K]) {
-  constexpr int SP = 64 * K;
+                                              int (&ae)[K], CtcEdge (*edge)[NW]) {
+  constexpr int SP = 64 * K * NW;
+  const int wave = lane >> 6, wl = lane & 63;
   // exponent offset of the skip term: 0 where the transition s-2 -> s (beta: s+2 -> s) exists, else "times 0"
   int skoff[K];
 #pragma unroll
@@ -159,8 +168,25 @@ __device__ __forceinline__ void ctc_recursion(const MantExp* __restrict__ ybase,
   auto frame = [&](int slot, int step) {
     float nm[K];
     int ne[K];
-    const float p1m = dpp_shift_f(BETA ? am[0] : am[K - 1], !BETA), p2m = dpp_shift_f(BETA ? am[1] : am[K - 2], !BETA);
-    const int p1e = dpp_shift_e(BETA ? ae[0] : ae[K - 1], !BETA), p2e = dpp_shift_e(BETA ? ae[1] : ae[K - 2], !BETA);
+    // (K = 1: the second neighbour state is the first state of the lane TWO away; not instantiated, K >= 2 here)
+    float p1m = dpp_shift_f(BETA ? am[0] : am[K - 1], !BETA), p2m = dpp_shift_f(BETA ? am[1] : am[K - 2], !BETA);
+    int p1e = dpp_shift_e(BETA ? ae[0] : ae[K - 1], !BETA), p2e = dpp_shift_e(BETA ? ae[1] : ae[K - 2], !BETA);
+    if constexpr (NW > 1) {
+      // the lane at the wave's edge publishes what its neighbour WAVE needs, the lane at the other edge picks it up.
+      // (Measured: computing the frame's states under the barrier and redoing the two edge states behind it is slower --
+      // 1 219 against 1 177 us per call at cfg C: the frame is the LDS -> barrier -> LDS chain, not the state arithmetic.)
+      CtcEdge* row = edge[step & 1];
+      if (wl == (BETA ? 0 : 63)) row[wave] = (CtcEdge){BETA ? am[0] : am[K - 1], BETA ? am[1] : am[K - 2],
+                                                        BETA ? ae[0] : ae[K - 1], BETA ? ae[1] : ae[K - 2]};
+      __syncthreads();
+      const int nbw = BETA ? wave + 1 : wave - 1;
+      if (nbw >= 0 && nbw < NW) {                         // wave-uniform
+        const CtcEdge nb = row[nbw];
+        const bool at = wl == (BETA ? 63 : 0);
+        p1m = at ? nb.m1 : p1m;  p2m = at ? nb.m2 : p2m;
+        p1e = at ? nb.e1 : p1e;  p2e = at ? nb.e2 : p2e;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       float m1, m2;
@@ -202,16 +228,19 @@ __device__ __forceinline__ void ctc_recursion(const MantExp* __restrict__ ybase,
     if (base + j < Tb) frame(j, base + j);                 // wave-uniform; slot j holds frame base + j
 }
 
-template <int K, int D>
-__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(
+template <int K, int D, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void ctc_alpha_beta_kernel(
     const MantExp* __restrict__ yext, const MantExp* __restrict__ yrev, int T, int B, int C,
     const int32_t* __restrict__ labels_flat, const int32_t* __restrict__ label_offsets,
     const int32_t* __restrict__ seq_len, int Lcap, MantExp* __restrict__ alpha_ws, MantExp* __restrict__ beta_ws, int32_t* __restrict__ rank_ws,
     double* __restrict__ ll_ws, float* __restrict__ loss, int32_t* __restrict__ num_infeasible) {
-  constexpr int SP = 64 * K;
+  constexpr int SP = 64 * K * NW;
+  static_assert(K >= 2, "two states cross a lane boundary");
+  __shared__ CtcEdge edge[2][NW];
+  __shared__ CtcEdge fin[NW];
   const int b = blockIdx.x >> 1;
   const bool is_beta = blockIdx.x & 1;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x;                            // over all NW waves
   const int lo = label_offsets[b];
   const int L = label_offsets[b + 1] - lo;
   const int S = 2 * L + 1;
@@ -221,7 +250,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(
   if (!is_beta) {
     // rank of each label among equal earlier labels (fixed summation order in the grad kernel) and the position of
     // the first label of its class (where the grad kernel accumulates that class), packed rank | first << 16
-    for (int i = lane; i < L && i < Lcap; i += 64) {
+    for (int i = lane; i < L && i < Lcap; i += 64 * NW) {
       const int li = lab[i];
       int r = 0, first = i;
       for (int k = i - 1; k >= 0; --k)
@@ -241,10 +270,10 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(
   float am[K];
   int ae[K];
   if (is_beta) {
-    ctc_recursion<K, D, true>(ybase, beta_ws + (size_t)b * T * SP + K * lane, Tb, S, lane, lab, am, ae);
+    ctc_recursion<K, D, true, NW>(ybase, beta_ws + (size_t)b * T * SP + K * lane, Tb, S, lane, lab, am, ae, edge);
     return;
   }
-  ctc_recursion<K, D, false>(ybase, alpha_ws + (size_t)b * T * SP + K * lane, Tb, S, lane, lab, am, ae);
+  ctc_recursion<K, D, false, NW>(ybase, alpha_ws + (size_t)b * T * SP + K * lane, Tb, S, lane, lab, am, ae, edge);
   // p = alpha_T(S-1) + alpha_T(S-2): the two states live in lanes (S-1)/K and (S-2)/K
   float m1 = 0.f, m2 = 0.f;
   int e1 = ME_ZERO, e2 = ME_ZERO;
@@ -260,6 +289,17 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(
     const int oe1 = __shfl_xor(e1, o, 64), oe2 = __shfl_xor(e2, o, 64);
     if (oe1 > e1) { m1 = om1; e1 = oe1; }
     if (oe2 > e2) { m2 = om2; e2 = oe2; }
+  }
+  if constexpr (NW > 1) {                                  // the owners of the two final states may sit in different waves
+    if ((lane & 63) == 0) fin[lane >> 6] = (CtcEdge){m1, m2, e1, e2};
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        if (fin[w].e1 > e1) { m1 = fin[w].m1; e1 = fin[w].e1; }
+        if (fin[w].e2 > e2) { m2 = fin[w].m2; e2 = fin[w].e2; }
+      }
+    }
   }
   if (lane == 0) {
     const int E = max(e1, e2);
@@ -491,17 +531,31 @@ extern "C" int asr_ctc_loss(asr_handle* h, const float* logits, int T, int B, in
                      label_offsets, seq_len, SP, yext, yrev);
   ASR_CHECK_LAUNCH(h, "asr_ctc_loss(row_lse)");
   {
-#define ASR_AB(KV, DV)                                                                                   \
-  hipLaunchKernelGGL((ctc_alpha_beta_kernel<KV, DV>), dim3(2 * B), dim3(64), 0, st, yext, yrev, T, B, C, labels_flat, \
+#define ASR_AB(KV, DV, NWV)                                                                              \
+  hipLaunchKernelGGL((ctc_alpha_beta_kernel<KV, DV, NWV>), dim3(2 * B), dim3(64 * NWV), 0, st, yext, yrev, T, B, C, labels_flat, \
                      label_offsets, seq_len, max_label_len, alpha, beta, rank, ll, loss, num_infeasible)
-    switch (w.K) {
-      case 3: ASR_AB(3, 8); break;          // D frames of emissions in flight: D * K * 2 ring registers
-      case 6: ASR_AB(6, 4); break;
-      case 8: ASR_AB(8, 4); break;
-      case 12: ASR_AB(12, 4); break;
-      case 16: ASR_AB(16, 3); break;
-      case 24: ASR_AB(24, 2); break;
-      default: ASR_AB(32, 2); break;
+    // ASR_CTC_WAVES=1: one wave per recursion whatever the label length (round 5; A/B and the bit-identity test)
+    const char* env_w = getenv("ASR_CTC_WAVES");            // (read per call: the bit-identity test flips it inside one process)
+    const bool multi = !(env_w && env_w[0] == '1');
+    if (multi && w.K >= 6) {
+      switch (w.K) {                          // K states per lane of ONE wave = K / NW per lane of NW waves
+        case 6: ASR_AB(3, 8, 2); break;
+        case 8: ASR_AB(2, 8, 4); break;
+        case 12: ASR_AB(3, 8, 4); break;
+        case 16: ASR_AB(4, 8, 4); break;
+        case 24: ASR_AB(6, 4, 4); break;
+        default: ASR_AB(8, 4, 4); break;
+      }
+    } else {
+      switch (w.K) {
+        case 3: ASR_AB(3, 8, 1); break;       // D frames of emissions in flight: D * K * 2 ring registers
+        case 6: ASR_AB(6, 4, 1); break;
+        case 8: ASR_AB(8, 4, 1); break;
+        case 12: ASR_AB(12, 4, 1); break;
+        case 16: ASR_AB(16, 3, 1); break;
+        case 24: ASR_AB(24, 2, 1); break;
+        default: ASR_AB(32, 2, 1); break;
+      }
     }
 #undef ASR_AB
   }

@@ -822,6 +822,42 @@ def test_ctc_loss_and_grad(cuda, T, B, C, lmax):
     assert int(ninf.item()) == 0
 
 
+@pytest.mark.parametrize('T,C,lmax', [(300, 62, 100), (700, 29, 200), (800, 29, 300), (1100, 29, 450), (1300, 29, 550),
+                                      (2000, 12, 950)])
+def test_ctc_multi_wave_recursion_is_bit_identical_to_one_wave(cuda, T, C, lmax):
+    """Round 6: with 6 or more states per lane the alpha / beta recursions run on 2 or 4 waves (K / NW states per lane, the
+    two states that cross a wave boundary through LDS behind one barrier per frame).  Same operands and operations per
+    state: losses and gradients must be the SAME BITS as the one-wave recursion (ASR_CTC_WAVES=1), for every class of
+    states per lane (6, 8, 12, 16, 24, 32), with ragged utterances (the short ones leave whole waves without a state)."""
+    import os
+    ops = _ops()
+    rng = np.random.RandomState(T + lmax)
+    B = 3
+    logits = (rng.randn(T, B, C) * 2.0).astype(np.float32)
+    sl = np.array([T, max(8, T // 3), max(8, (2 * T) // 3)], dtype=np.int32)
+    labs = [[int(v) for v in rng.randint(0, C - 1, size=n)] for n in (lmax, 3, max(1, lmax // 2))]
+    flat, off = _flat(labs)
+    args = (torch.tensor(logits, device=cuda), torch.tensor(flat, device=cuda), torch.tensor(off, device=cuda),
+            torch.tensor(sl, device=cuda), lmax)
+    old = os.environ.get('ASR_CTC_WAVES')
+    try:
+        os.environ['ASR_CTC_WAVES'] = '1'
+        l1, g1, n1 = ops.ctc_loss(*args, grad_scale=1.0)
+        l1, g1 = l1.cpu().numpy().copy(), g1.cpu().numpy().copy()
+        os.environ.pop('ASR_CTC_WAVES')
+        l4, g4, n4 = ops.ctc_loss(*args, grad_scale=1.0)
+    finally:
+        if old is None:
+            os.environ.pop('ASR_CTC_WAVES', None)
+        else:
+            os.environ['ASR_CTC_WAVES'] = old
+    assert int(n1.item()) == 0 and int(n4.item()) == 0
+    assert np.array_equal(l1.view(np.uint32), l4.cpu().numpy().view(np.uint32))
+    assert np.array_equal(g1.view(np.uint32), g4.cpu().numpy().view(np.uint32))
+    ref_loss, _ = octc.ctc_loss_batch(logits.astype(np.float64), labs, sl)
+    assert np.abs(l1 - ref_loss).max() / ref_loss.max() < 1e-5
+
+
 def test_ctc_peaked_posteriors_and_long_utterances(cuda):
     """The scaled linear-domain recursion over inputs where log-domain and linear-domain arithmetic differ most:
     near one-hot posteriors (logit gaps of 60: most emission probabilities sit at the 2^-126 floor), a long utterance
