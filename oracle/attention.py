@@ -49,8 +49,47 @@ def location_features(p, prev_alpha):
     return f.transpose(1, 2) @ p['W_filter/weights'] + p['W_filter/biases']
 
 
+class _MMBwdRound(torch.autograd.Function):
+    """y = a @ w, exact in the forward; in the BACKWARD the products take operands rounded by `rnd` the way the device's
+    bf16-operand model rounds them outside the decoder loop (models/attention/attention_seq2seq.py, ASR_ATT_BWD_BF16):
+    da = R(g) @ R(w)^T (round_g_da) or g @ R(w)^T, dw = R(a)^T @ R(g) (round_a_dw) or a^T @ R(g) (the key projection: its
+    input is the encoder's operand-dtype output as it lies in memory, bf16-valued already on the device)."""
+
+    @staticmethod
+    def forward(ctx, a, w, rnd, round_g_da, round_a_dw=True):
+        ctx.save_for_backward(a, w)
+        ctx.rnd, ctx.round_g_da, ctx.round_a_dw = rnd, round_g_da, round_a_dw
+        return a @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w = ctx.saved_tensors
+        R = ctx.rnd
+        gr = R(g)
+        da = (gr if ctx.round_g_da else g) @ R(w).transpose(-1, -2)
+        dw = (R(a) if ctx.round_a_dw else a).reshape(-1, a.shape[-1]).t() @ gr.reshape(-1, g.shape[-1])
+        return da, dw, None, None, None
+
+
+class _CtxBwdRound(torch.autograd.Function):
+    """ctx[b] = sum_t alpha[b, t] enc[b, t]; backward: d alpha = enc . g (inside the decoder loop: unrounded), d enc =
+    R(alpha) (x) R(g) (the per-utterance alpha^T . dctx products after the loop, on bf16 operands)."""
+
+    @staticmethod
+    def forward(ctx, alpha, enc, rnd):
+        ctx.save_for_backward(alpha, enc)
+        ctx.rnd = rnd
+        return (alpha.unsqueeze(2) * enc).sum(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, enc = ctx.saved_tensors
+        R = ctx.rnd
+        return (enc * g.unsqueeze(1)).sum(2), R(alpha).unsqueeze(2) * R(g).unsqueeze(1), None
+
+
 def attention_step(p, att_type, enc_bt, keys, s, seq_len, sharpening=1.0, sigmoid_smoothing=False,
-                   prev_alpha=None):
+                   prev_alpha=None, bwd_round=None):
     """enc_bt [B,T,2H]; keys [B,T,A] or None; s [B,U] -> (alpha [B,T], ctx [B,2H]).
     sigmoid_smoothing: attention_layer.py:92-96, sigmoid(e) / sum_t sigmoid(e) instead of the softmax.
     prev_alpha: None = the reference's EFFECTIVE graph (quirk Q1: the location features see the zeros of
@@ -88,15 +127,16 @@ def attention_step(p, att_type, enc_bt, keys, s, seq_len, sharpening=1.0, sigmoi
         alpha = sg / sg.sum(dim=1, keepdim=True)
     else:
         alpha = torch.softmax(energy, dim=1)
-    ctx = (alpha.unsqueeze(2) * enc_bt).sum(1)
+    ctx = (alpha.unsqueeze(2) * enc_bt).sum(1) if bwd_round is None else _CtxBwdRound.apply(alpha, enc_bt, bwd_round)
     return alpha, ctx
 
 
-def compute_keys(p, att_type, enc_bt):
+def compute_keys(p, att_type, enc_bt, bwd_round=None):
+    mm = (lambda a, w: a @ w) if bwd_round is None else (lambda a, w: _MMBwdRound.apply(a, w, bwd_round, True, False))
     if att_type in ('bahdanau_content', 'hybrid'):
-        return enc_bt @ p['W_keys/weights'] + p['W_keys/biases']
+        return mm(enc_bt, p['W_keys/weights']) + p['W_keys/biases']
     if att_type in ('dot_product', 'luong_general'):
-        return enc_bt @ p['W_keys/weights']
+        return mm(enc_bt, p['W_keys/weights'])
     return None
 
 
@@ -115,8 +155,13 @@ def decoder_params(sd, dtype=torch.float64, requires_grad=True):
 def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_len, enc_layers,
                             att_type, clip_enc=0.0, clip_dec=0.0, sharpening=1.0, temperature=1.0,
                             drop_emb=None, drop_dec=None, ctc_labels=None, lambda_weight=None,
-                            dtype=torch.float64, sigmoid_smoothing=False, prev_alpha='zeros', operand_round=None):
+                            dtype=torch.float64, sigmoid_smoothing=False, prev_alpha='zeros', operand_round=None,
+                            bwd_round='same'):
     """Teacher-forced forward + loss + all parameter gradients.
+    bwd_round: the rounding of the BACKWARD pass's batched products outside the decoder loop (round 6; the device's
+    ASR_ATT_BWD_BF16 default of a bf16-operand model): the attentional vector's weight / input gradients, alpha^T . dctx
+    into d enc, the key projection's two gradients, the decoder cell's weight gradient -- 'same' = operand_round (none for
+    the plain oracle), None = exact products, or a rounding function.
     prev_alpha: 'zeros' (reference's effective graph, Q1) | 'carry' (previous step's weights feed location / hybrid).
     labels [B, Lmax] int (<SOS> y <EOS>, padded with eos); returns dict(loss, logits [B,To,C],
     alphas, grads, ...).
@@ -126,6 +171,8 @@ def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_l
     fp32 activations); the attention layer, the bridge and the decoder's other products multiply in fp32 on the device
     and stay in `dtype` here."""
     from .model import params_from_state_dict
+    if bwd_round == 'same':
+        bwd_round = operand_round
     if operand_round is not None:
         sd = dict(sd)
         for k in list(sd):
@@ -160,8 +207,10 @@ def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_l
     if drop_emb is not None:
         emb = emb * torch.as_tensor(drop_emb, dtype=dtype)
     To = int(lsl.max()) - 1
-    keys = compute_keys(ap, att_type, enc)
+    keys = compute_keys(ap, att_type, enc, bwd_round)
     cell = dict(w=P[D + 'lstm_cell/kernel'], b=P[D + 'lstm_cell/bias'])
+    cell_mm = None if bwd_round is None else (lambda a, w: _MMBwdRound.apply(a, w, bwd_round, False))
+    av_mm = (lambda a, w: a @ w) if bwd_round is None else (lambda a, w: _MMBwdRound.apply(a, w, bwd_round, True))
     has_peep = (D + 'lstm_cell/w_i_diag') in P
     z = torch.zeros(U, dtype=dtype)
     wci, wcf, wco = (P[D + 'lstm_cell/w_i_diag'], P[D + 'lstm_cell/w_f_diag'], P[D + 'lstm_cell/w_o_diag']) \
@@ -174,12 +223,13 @@ def attention_model_forward(sd, inputs_btd, labels, inputs_seq_len, labels_seq_l
         fin_prev = (k >= (lsl - 1)).to(dtype).unsqueeze(1)               # finished BEFORE this step
         inp_emb = emb[:, k] if k == 0 else emb[:, k] * (1.0 - fin_prev_in)
         inp = torch.cat([inp_emb, ctx], dim=1)
-        cn, hn = olstm.lstm_block_cell(inp, c, h, cell['w'], cell['b'], wci, wcf, wco, 1.0, clip_dec, has_peep)
+        cn, hn = olstm.lstm_block_cell(inp, c, h, cell['w'], cell['b'], wci, wcf, wco, 1.0, clip_dec, has_peep, mm=cell_mm)
         cell_out = hn if drop_dec is None else hn * torch.as_tensor(drop_dec[k], dtype=dtype)
-        alpha, ctx_k = attention_step(ap, att_type, enc, keys, cell_out, sl, sharpening, sigmoid_smoothing, a_prev)
+        alpha, ctx_k = attention_step(ap, att_type, enc, keys, cell_out, sl, sharpening, sigmoid_smoothing, a_prev,
+                                      bwd_round=bwd_round)
         if carry:
             a_prev = alpha
-        av = torch.tanh(torch.cat([cell_out, ctx_k], dim=1) @ P[D + 'attentional_vector/weights'])
+        av = torch.tanh(av_mm(torch.cat([cell_out, ctx_k], dim=1), P[D + 'attentional_vector/weights']))
         lg = av @ P[D + 'output_layer/weights'] + P[D + 'output_layer/biases']
         live = 1.0 - fin_prev                                             # impute_finished
         logits_steps.append(lg * live)

@@ -32,13 +32,14 @@ import torch
 
 
 def lstm_block_cell(x, cs_prev, h_prev, w, b, wci, wcf, wco,
-                    forget_bias=1.0, cell_clip=0.0, use_peephole=True, clip_blocks_gradient=False):
+                    forget_bias=1.0, cell_clip=0.0, use_peephole=True, clip_blocks_gradient=False, mm=None):
     """One LSTMBlockCell step. x [B,Din], cs_prev/h_prev [B,H], w [Din+H,4H].
     clip_blocks_gradient: the python LSTMCell (tf.contrib.rnn.LSTMCell, the projected cells of lstm_impl='LSTMCell',
     models/encoders/core/blstm.py:215-230 / models/recurrent/layers/lstm.py:152-157) clamps with tf.clip_by_value, whose
     gradient is zero where the state was clamped; the fused LSTMBlockCell's gradient op ignores the clip."""
     H = cs_prev.shape[1]
-    icfo = torch.cat([x, h_prev], dim=1) @ w + b
+    xh = torch.cat([x, h_prev], dim=1)
+    icfo = (xh @ w if mm is None else mm(xh, w)) + b           # mm: a product with its own backward (oracle.attention)
     i, ci, f, o = icfo[:, :H], icfo[:, H:2 * H], icfo[:, 2 * H:3 * H], icfo[:, 3 * H:]
     if use_peephole:
         i = i + wci * cs_prev

@@ -394,6 +394,49 @@ def test_bf16_model_multiplies_with_the_rounded_decoder_kernel_everywhere(monkey
     assert gap['stored'][1] > 1e-4 and gap['stored'][2] > 1e-4, gap       # ... and the test can tell the two apart
 
 
+@pytest.mark.parametrize('att', ['location', 'hybrid', 'bahdanau_content', 'luong_general'])
+def test_bf16_attention_backward_rounding_points_are_the_oracles(monkeypatch, att):
+    """a bf16-operand attention model rounds the operands of its backward pass's batched products to bf16
+    (ASR_ATT_BWD_BF16, the device default).  oracle.attention models those points (bwd_round: d W_av and d av_in, alpha^T .
+    dctx into d enc, both gradients of the key projection, d W_cell).  On the CPU stand-ins the only FORWARD rounding point
+    of a bf16 model is the decoder cell's kernel (the test above), so the oracle gets that kernel rounded, no operand_round,
+    and the backward points: with the flag ON the model agrees with it to 1e-5 of every gradient's maximum -- and does NOT
+    agree with the oracle without the backward points (the test sees them)."""
+    _cpu_ops.install(monkeypatch)
+    from oracle import attention as oatt
+    from oracle import lstm as olstm
+    from tensorflow_end2end_speech_recognition_amd.models.attention import attention_seq2seq as S
+    from tensorflow_end2end_speech_recognition_amd.models.attention.attention_seq2seq import AttentionSeq2Seq
+    monkeypatch.setattr(S, 'ATT_BWD_BF16', True)
+    rng = np.random.RandomState(13)
+    B, T, D, H, L, A, Em, C, U = 3, 9, 6, 8, 1, 10, 4, 6, 12
+    if att == 'luong_general':
+        A = U
+    x, sl, labels, lsl, _ = _att_batch(rng, B, T, D, C)
+    prev = 'carry' if att in ('location', 'hybrid') else 'zeros'
+    model = AttentionSeq2Seq(input_size=D, encoder_type='blstm', encoder_num_units=H, encoder_num_layers=L,
+                             encoder_num_proj=None, attention_type=att, attention_dim=A, decoder_type='lstm',
+                             decoder_num_units=U, decoder_num_layers=1, embedding_dim=Em, num_classes=C, sos_index=C,
+                             eos_index=C + 1, max_decode_length=8, parameter_init=0.5, clip_grad_norm=5.0,
+                             clip_activation_encoder=50, clip_activation_decoder=50, dtype='bf16', seed=5, device='cpu',
+                             prev_alpha=prev)
+    sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
+    key = 'attention_decoder/decoder/lstm_cell/kernel'
+    sd[key] = olstm.bf16_round_t(torch.tensor(sd[key], dtype=torch.float64)).numpy()
+    loss, logits, *_ = model.compute_loss(x, labels, sl, lsl, 1.0, 1.0, 1.0)
+    opt = model._set_optimizer('adam', 1e-3)
+    grads = {name: g.numpy() for g, name in opt.compute_gradients(loss, model=model)}
+    gap = {}
+    for tag, br in (('with', olstm.bf16_round_t), ('without', None)):
+        ref = oatt.attention_model_forward(sd, x, labels, sl, lsl, L, att, clip_enc=50.0, clip_dec=50.0, prev_alpha=prev,
+                                           bwd_round=br)
+        gap[tag] = (abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']),
+                    {n: np.abs(grads[n] - ref['grads'][n]).max() / max(np.abs(ref['grads'][n]).max(), 1e-3) for n in grads})
+    worst = max(gap['with'][1].values())
+    assert gap['with'][0] < 1e-6 and worst < 1e-5, (gap['with'][0], sorted(gap['with'][1].items(), key=lambda kv: -kv[1])[:4])
+    assert max(gap['without'][1].values()) > 1e-3            # without the backward points the difference is bf16-sized
+
+
 def test_joint_ctc_attention_host_logic(monkeypatch):
     _cpu_ops.install(monkeypatch)
     from oracle import attention as oatt
