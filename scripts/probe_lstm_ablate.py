@@ -18,9 +18,9 @@ from bench import make_batch
 from tensorflow_end2end_speech_recognition_amd import ops
 from tensorflow_end2end_speech_recognition_amd._lib import ASR_BF16
 
-H, B, D, ndir = 256, 16, 120, 2
+H, B, D, ndir = int(os.environ.get('ABL_H', '256')), int(os.environ.get('ABL_B', '16')), 120, 2
 dev = torch.device('cuda:0')
-x, sl, labels, dense = make_batch(1, B, D, 62, 100, 778)       # the bench's batch: T = 778, 49 % padding
+x, sl, labels, dense = make_batch(1, B, D, 62, 100, int(os.environ.get('ABL_T', '778')))     # the bench's batch: T = 778, 49 % padding
 T = x.shape[1]
 g = torch.Generator(device='cpu').manual_seed(0)
 xd = ops.bt_to_tb(torch.tensor(x, device=dev), ASR_BF16)
@@ -68,9 +68,11 @@ def name(bits, names):
 
 print('T = %d, B = %d, H = %d, ndir = %d; us per launch (median of 12, min), us per recurrence step' % (T, B, H, ndir))
 for label, env, names, variants, fn in (
-        ('forward', 'ASR_LSTM_ABL_FWD', FW, (0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 6, 14, 48, 513, 515, 519, 527, 545, 769, 800, 1023),
+        ('forward', 'ASR_LSTM_ABL_FWD', FW, (0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 6, 14, 48, 513, 515, 519, 527, 545, 769, 800, 1023) if H == 256
+         else (0, 1, 8, 16, 64, 512, 6, 513, 519, 527, 545, 1023),
          lambda: ops.lstm_fwd(xproj, whf, peep, sld, H, ndir, ASR_BF16, 1.0, 50.0)),
-        ('BPTT', 'ASR_LSTM_ABL_BWD', BW, (0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 6, 14, 80, 144, 513, 515, 519, 527, 545, 641, 1023),
+        ('BPTT', 'ASR_LSTM_ABL_BWD', BW, (0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 6, 14, 80, 144, 513, 515, 519, 527, 545, 641, 1023) if H == 256
+         else (0, 1, 8, 64, 512, 6, 513, 519, 527, 545, 641, 1023),
          lambda: ops.lstm_bwd(dout, gates, cs, whb, peep, sld, H, ndir, ASR_BF16))):
     base = None
     print('\n| %s ABL | left out | us / launch (median) | min | us / step | delta vs full (us / step) |' % label)

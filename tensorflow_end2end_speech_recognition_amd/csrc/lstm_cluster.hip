@@ -2749,6 +2749,20 @@ static bool cluster_fwd_launch(asr_handle* h, int T, int B, int ndir, const floa
     }
 #endif
   }
+#ifdef ASR_LSTM_ABLATE
+  if constexpr (HSU == 32 && H == 512) {                   // the width of cfg C / D / E: a shorter list
+    if (const char* e = getenv("ASR_LSTM_ABL_FWD")) {
+      if (early && xw && !g_cdbg_host) {
+        switch (atoi(e)) {
+#define ABLF(n) case n: k = lstm_fwd_cluster8_kernel<H, false, true, HSU, 0, true, n>; break;
+          ABLF(1) ABLF(8) ABLF(16) ABLF(64) ABLF(512) ABLF(6) ABLF(513) ABLF(519) ABLF(527) ABLF(545) ABLF(1023)
+#undef ABLF
+          default: break;
+        }
+      }
+    }
+  }
+#endif
   // (padding the LDS request past half a CU so that two 4-wave members can never share one was measured: no
   // difference, 866.7 vs 867.6 us -- the dispatcher spreads the members over the CUs by itself)
   const size_t lds = (size_t)2 * 16 * (H + 8) * 2;
@@ -2796,6 +2810,16 @@ static bool cluster_bwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   auto k = g_cdbg_host ? (xp ? lstm_bwd_cluster8_kernel<H, true, HSU, -1, true> : lstm_bwd_cluster8_kernel<H, true, HSU, -1, false>)
                        : (xp ? lstm_bwd_cluster8_kernel<H, false, HSU, -1, true> : lstm_bwd_cluster8_kernel<H, false, HSU, -1, false>);
 #ifdef ASR_LSTM_ABLATE
+  if constexpr (HSU == 32 && H == 512) {
+    if (const char* e = getenv("ASR_LSTM_ABL_BWD")) {
+      switch (atoi(e)) {
+#define ABLB(n) case n: k = lstm_bwd_cluster8_kernel<H, false, HSU, -1, false, n>; break;
+        ABLB(1) ABLB(8) ABLB(64) ABLB(128) ABLB(512) ABLB(6) ABLB(513) ABLB(519) ABLB(527) ABLB(545) ABLB(641) ABLB(1023)
+#undef ABLB
+        default: break;
+      }
+    }
+  }
   if constexpr (HSU == 32 && H == 256) {
     if (const char* e = getenv("ASR_LSTM_ABL_BWD")) {
       switch (atoi(e)) {
