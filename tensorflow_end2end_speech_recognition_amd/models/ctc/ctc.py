@@ -219,17 +219,16 @@ class CTC(ModelBase):
         # from what the caller handed over, never by reading a device copy back (that would drain the stream each step)
         self.encoder._lens_host = ops.host_ints(inputs_seq_len)
         inputs = ops.to_device(inputs, torch.float32, dev)
-        inputs_seq_len = ops.to_device(inputs_seq_len, torch.int32, dev)
         B = inputs.shape[0]
         flat, offsets, max_len = self._labels_to_flat(labels, B)
         Bp = B + (-B) % 16                               # the encoder pads the batch to whole 16-utterance tiles
         if Bp > B:
             offsets = np.concatenate([offsets, np.full(Bp - B, offsets[-1], dtype=np.int32)])
-        # labels go up FIRST (pinned staging + async copy), i.e. before the forward is enqueued: behind it they
-        # would sit on the critical path between the output FC and the CTC kernels
-        flat_d = torch.from_numpy(np.ascontiguousarray(flat if len(flat) else np.zeros(1, np.int32))) \
-            .pin_memory().to(dev, non_blocking=True)
-        off_d = torch.from_numpy(np.ascontiguousarray(offsets)).pin_memory().to(dev, non_blocking=True)
+        # frame counts and labels go up FIRST and together (one pinned staging buffer, one async copy on the upload
+        # stream), i.e. before the forward is enqueued: behind it the labels would sit on the critical path between the
+        # output FC and the CTC kernels
+        inputs_seq_len, off_d, flat_d = ops.upload_ints(
+            dev, [inputs_seq_len, offsets, flat if len(flat) else np.zeros(1, np.int32)])
         logits = self._build(inputs, inputs_seq_len, keep_prob, is_training)
         T, Bp, C = logits.shape
         ctc_in = logits

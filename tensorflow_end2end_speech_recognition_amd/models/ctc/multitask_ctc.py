@@ -79,10 +79,7 @@ class MultitaskCTC(CTC):
         flat, offsets, max_len = self._labels_to_flat(labels, B)
         if Bp > B:
             offsets = np.concatenate([offsets, np.full(Bp - B, offsets[-1], dtype=np.int32)])
-        dev = self.device
-        flat_d = torch.from_numpy(np.ascontiguousarray(flat if len(flat) else np.zeros(1, np.int32))) \
-            .pin_memory().to(dev, non_blocking=True)
-        off_d = torch.from_numpy(np.ascontiguousarray(offsets)).pin_memory().to(dev, non_blocking=True)
+        flat_d, off_d = ops.upload_ints(self.device, [flat if len(flat) else np.zeros(1, np.int32), offsets])
         return flat_d, off_d, max_len
 
     def compute_loss(self, inputs, labels_main, labels_sub, inputs_seq_len, keep_prob, scope=None,

@@ -27,6 +27,9 @@ DIRS = ('fw', 'bw')
 # side streams the weight-gradient GEMMs of a layer are spread over: one per direction (one lane for both measures the
 # same step time, 12.39 ms, but leaves a longer tail after the last BPTT kernel)
 DW_LANES = 2
+# (round 6: the bottom layer's two recurrent products moved off these lanes -- a third lane and the main stream, all four
+# products side by side behind the last BPTT kernel -- measured: last BPTT end -> grad_finish 127 us against 114 us as it is,
+# step 8.911 against 8.899 ms; the four split-K GEMMs already fill the chip two at a time.  Not kept.)
 # one main-stream marker per BPTT layer for all its side lanes, one wait for all weight images (A-B: ASR_FORK_ONCE=0
 # restores a marker per lane entry and a wait per layer)
 FORK_ONCE = _os.environ.get('ASR_FORK_ONCE', '1') != '0'

@@ -184,6 +184,56 @@ def to_device(x, dtype, dev):
     return t.pin_memory().to(dev, non_blocking=True)
 
 
+_upload_streams = {}
+
+
+def upload_ints(dev, vectors):
+    """Host int vectors -> int32 device vectors through ONE pinned staging buffer and ONE asynchronous copy, issued on
+    an upload stream of its own and joined to the current stream by an event.  A CTC step hands over three such vectors
+    (frame counts, label offsets, labels); as three copies on the main stream they and the queue gaps between them held
+    the first kernel of the step back by 50 us behind the previous step's optimizer (profiles/r06_step_timeline.md); on
+    the upload stream the copy runs as soon as the host has issued it, beside whatever the main stream is still doing.
+    (Step time of the headline bench is unchanged by it, 8.90 ms: without the profiler the host runs steps ahead and the
+    copies' gaps were the profiler's; what remains is two packets fewer on the main stream.)
+    Device vectors pass through (converted to int32 on the device).  Each result starts on a 16-byte boundary."""
+    d = torch.device(dev)
+    out, host = [None] * len(vectors), []
+    for i, v in enumerate(vectors):
+        if torch.is_tensor(v) and v.is_cuda:
+            out[i] = v if v.dtype == torch.int32 else v.to(torch.int32)
+        else:
+            a = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+            host.append((i, np.ascontiguousarray(a, dtype=np.int32).ravel()))
+    if not host:
+        return out
+    if d.type != 'cuda':
+        for i, a in host:
+            out[i] = torch.from_numpy(a.copy()).to(d)
+        return out
+    starts, n = [], 0
+    for _, a in host:
+        starts.append(n)
+        n += max(4, a.size + (-a.size) % 4)
+    stage = torch.zeros(n, dtype=torch.int32).pin_memory()
+    sv = stage.numpy()
+    for (_, a), s0 in zip(host, starts):
+        sv[s0:s0 + a.size] = a
+    idx = d.index if d.index is not None else torch._C._cuda_getDevice()
+    up = _upload_streams.get(idx)
+    if up is None:
+        up = _upload_streams[idx] = torch.cuda.Stream(device=idx)
+    with torch.cuda.stream(up):
+        buf = stage.to(d, non_blocking=True)      # allocated in the upload stream's pool: no wait for the main stream
+    ev = torch.cuda.Event()
+    ev.record(up)
+    cur = _cur_stream(idx)
+    cur.wait_event(ev)
+    buf.record_stream(cur)                        # side lanes fork from / join into this stream within the step
+    for (i, a), s0 in zip(host, starts):
+        out[i] = buf[s0:s0 + a.size]
+    return out
+
+
 _host_copies = {}
 
 

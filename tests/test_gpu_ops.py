@@ -1385,3 +1385,26 @@ def test_colsum_paths(cuda, M, N, dtype):
     got2 = ops.colsum(a).cpu().numpy()
     assert np.array_equal(got, got2)
     assert np.abs(got - want).max() < 2e-5 * a.double().abs().sum(0).max().item()
+
+
+def test_upload_ints_is_one_copy_off_the_main_stream(cuda):
+    """ops.upload_ints: several host vectors arrive through one staging buffer (each on a 16-byte boundary), device
+    vectors pass through, and the current stream -- and a side lane forked from it -- sees the values."""
+    ops = _ops()
+    rng = np.random.RandomState(5)
+    busy = torch.randn(4096, 4096, device=cuda)
+    for rep in range(6):                                     # the staging block / device block get reused across calls
+        (busy @ busy).sum()                                  # main stream busy: the upload must not wait behind it
+        lens = rng.randint(1, 900, size=64).astype(np.int64)
+        offs = np.cumsum(rng.randint(0, 50, size=65)).astype(np.int32)
+        flat = rng.randint(0, 28, size=int(offs[-1]) + rep).astype(np.int32)
+        on_dev = torch.arange(7, device=cuda, dtype=torch.int64)
+        a, b, c, d, e = ops.upload_ints(cuda, [lens, offs, flat, on_dev, np.zeros(0, np.int32)])
+        assert all(t.dtype == torch.int32 and t.is_cuda for t in (a, b, c, d, e)) and e.numel() == 0
+        assert a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and c.data_ptr() % 16 == 0
+        with ops.side_lane(cuda, lane=1):
+            on_lane = (a.long().sum() + c.long().sum()).clone()
+        ops.join_side(cuda)
+        assert int(on_lane) == int(lens.sum() + flat.sum())
+        assert np.array_equal(a.cpu().numpy(), lens) and np.array_equal(b.cpu().numpy(), offs)
+        assert np.array_equal(c.cpu().numpy(), flat) and np.array_equal(d.cpu().numpy(), np.arange(7))

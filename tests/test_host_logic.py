@@ -1133,3 +1133,16 @@ def test_encoder_half_batch_pipelines_against_the_oracle(monkeypatch, enc, L, B)
     l2, _ = model.compute_loss(x, dense, sl, keep_prob=0.7)
     model.train(l2, 'adam', 1e-3)
     assert np.isfinite(l2.item()) and all(np.isfinite(v.numpy()).all() for v in model.store.state_dict().values())
+
+
+def test_upload_ints_host_path_keeps_values_and_dtypes():
+    """ops.upload_ints without a GPU device: plain int32 tensors, one per vector, input arrays left alone."""
+    import torch
+    from tensorflow_end2end_speech_recognition_amd import ops
+    lens = np.array([5, 7, 9], np.int64)
+    flat = [1, 2, 3, 4, 5]
+    a, b, c = ops.upload_ints('cpu', [lens, flat, torch.tensor([3, 1], dtype=torch.int64)])
+    assert a.dtype == b.dtype == c.dtype == torch.int32
+    assert a.tolist() == [5, 7, 9] and b.tolist() == flat and c.tolist() == [3, 1]
+    a[0] = 99
+    assert lens[0] == 5
