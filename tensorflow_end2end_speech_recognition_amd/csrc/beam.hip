@@ -45,6 +45,18 @@
 // utterance's workgroup): C = 3387, W = 100: 366 -> 69; C = 62, W = 20: 90 -> 17.  What a frame costs now, in cycles
 // (ASR_BEAM_DBG=1): fp64 log-softmax 16 k, stay candidates 27 k, class select 22 k, compaction 8 k, keys 14 k, top-W
 // select 52 k, ranking + trie 22 k.
+//
+// Round 6: 512 threads per utterance instead of 256 (template parameter NT; the phases that stride over classes or
+// candidates scale, the register budget still holds 24 keys per thread); the parent lookup and the ranking of the
+// winners run NT / 128 threads per entry, branch-free (as loops that break / short-circuit they waited for one LDS read
+// per iteration: 13 k + 15 k cycles of a W = 100 frame); trie node ids are base + rank instead of one atomic per new
+// prefix; the frame's logits are requested one frame ahead; both radix selects skip the leading bytes all keys share
+// (one AND / OR reduction), and the top-W select only narrows during the passes -- the winners are collected by one
+// pass against the threshold the passes spell.  Same candidates, same composite keys, same winners (goldens, and
+// ASR_BEAM_THREADS=256 against 512 in tests/test_gpu_ops.py).  us per frame, C = 3387 / W = 100: 69 -> 33 (flat
+// posteriors) / 36 (peaked); C = 62 / W = 20: 16.7 -> 11.9.  Cycles of a C = 3387 / W = 100 frame now: log-softmax 8 k,
+// stay candidates 8 k, class select 15 k, compaction 5 k, keys 7.5 k, top-W select 6 k + 24 k, ranking + trie 4 k; a radix
+// pass costs ~2 k cycles whatever it counts (three barriers + the one-wave digit choice), which is what is left.
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -53,7 +65,6 @@
 namespace {
 
 constexpr int BEAM_MAX = 128;
-constexpr int BEAM_THREADS = 256;
 constexpr double DNEG = -INFINITY;
 
 __device__ __forceinline__ double lse2d(double a, double b) {
@@ -157,7 +168,8 @@ __device__ __forceinline__ unsigned digit_of(unsigned long long key, unsigned ni
   return byte >= 4 ? (unsigned)((key >> ((byte - 4) * 8)) & 0xff) : ((nidx >> (byte * 8)) & 0xff);
 }
 
-__global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
+template <int NT>
+__global__ __launch_bounds__(NT) void ctc_beam_kernel(
     const float* __restrict__ logits, int T, int B, int C, const int32_t* __restrict__ seq_len,
     int blank, int W, double* __restrict__ tot_ws, int2* __restrict__ node_ws,
     int32_t* __restrict__ out_labels, int32_t* __restrict__ out_len, double* __restrict__ out_score, int lds_keys,
@@ -171,12 +183,11 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
   int* kc = reinterpret_cast<int*>(lp + C);          // [C] kept classes of the frame, ascending
   int* kpos = kc + C;                                // [C] position of a class in kc, -1 if pruned
   unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(smem + (((size_t)C * 16 + 15) & ~(size_t)15));   // [lds_keys]
-  __shared__ unsigned tcnt[BEAM_THREADS / 64];
+  __shared__ unsigned tcnt[NT / 64];
   __shared__ unsigned s_digit, s_exact;
-  __shared__ unsigned long long s_min[BEAM_THREADS / 64];
-  __shared__ unsigned long long w_tie;
+  __shared__ unsigned long long s_min[NT / 64], s_or[NT / 64];
   __shared__ double s_L[BEAM_MAX];                   // logsumexp(p_b, p_nb) of each beam entry
-  __shared__ unsigned wcnt[BEAM_THREADS / 64];
+  __shared__ unsigned wcnt[NT / 64];
   __shared__ int s_K;
   __shared__ double s_thr;
   __shared__ Entry beam[BEAM_MAX];
@@ -189,11 +200,12 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
   __shared__ unsigned long long w_key[BEAM_MAX];
   __shared__ unsigned w_nidx[BEAM_MAX];
   __shared__ int w_src[BEAM_MAX];                    // candidate id of each winner
-  __shared__ double red[BEAM_THREADS / 64];
+  __shared__ double red[NT / 64];
   __shared__ unsigned long long sel_key;              // threshold prefix being built
   __shared__ unsigned sel_nidx;
   __shared__ unsigned sel_remaining;
   __shared__ int s_nw, s_nb, s_nodes;
+  __shared__ int s_rank[BEAM_MAX];
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -209,41 +221,75 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
   }
   __syncthreads();
 
+  // a thread's share of a frame's logits (classes tid, tid + NT, ...; C <= 6144: the launcher's LDS limit), requested one
+  // frame ahead: the row of frame t + 1 travels while frame t is searched
+  constexpr int RP = (6144 + NT - 1) / NT;
+  float pre[RP];
+  auto fetch_row = [&](int t) {
+    const float* row = logits + ((size_t)t * B + b) * C;
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const int c = i * NT + tid;
+      pre[i] = c < C ? row[c] : -INFINITY;
+    }
+  };
+  if (Tb > 0) fetch_row(0);
+
   for (int t = 0; t < Tb; ++t) {
     const int nb = s_nb;
     if (dbg) tprev = __builtin_amdgcn_s_memtime();
     // ---- 1. fp64 log-softmax of the frame
-    const float* row = logits + ((size_t)t * B + b) * C;
     float m = -INFINITY;
-    for (int c = tid; c < C; c += BEAM_THREADS) {        // (the row is read from memory once; a thread revisits its own lp[c])
-      const float v = row[c];
-      lp[c] = (double)v;
-      m = fmaxf(m, v);
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {                         // (a thread revisits its own lp[c])
+      const int c = i * NT + tid;
+      if (c < C) {
+        lp[c] = (double)pre[i];
+        m = fmaxf(m, pre[i]);
+      }
     }
+    if (t + 1 < Tb) fetch_row(t + 1);
     m = wave_reduce_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
-    double mm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    double mm = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) mm = fmax(mm, red[w]);
     __syncthreads();
     double ssum = 0.0;
-    for (int c = tid; c < C; c += BEAM_THREADS) ssum += exp(lp[c] - mm);
+    for (int c = tid; c < C; c += NT) ssum += exp(lp[c] - mm);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
     if (lane == 0) red[wave] = ssum;
     __syncthreads();
-    const double z = mm + log(red[0] + red[1] + red[2] + red[3]);
-    for (int c = tid; c < C; c += BEAM_THREADS) lp[c] = lp[c] - z;
+    double zs = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) zs += red[w];
+    const double z = mm + log(zs);
+    for (int c = tid; c < C; c += NT) lp[c] = lp[c] - z;
     BEAM_T(0);
     // ---- 2. parent lookup + stay candidates
-    if (tid < nb) {
-      int par = -1;
-      const Entry e = beam[tid];
-      if (e.len > 0)
-        for (int j = 0; j < nb; ++j)
-          if (beam[j].hash == e.phash && beam[j].len + 1 == e.len) { par = j; break; }
-      s_parent[tid] = par;
+    // the first (lowest) entry that spells this entry's parent prefix: NT / 128 threads per entry walk the beam in strides,
+    // branch-free (a loop that breaks at the hit waits for one LDS read per iteration: 13 k cycles of a W = 100 frame)
+    if (tid < BEAM_MAX) s_parent[tid] = 0x7fffffff;
+    __syncthreads();
+    {
+      constexpr int PARTS = NT / BEAM_MAX;
+      const int e = tid & (BEAM_MAX - 1), part = tid / BEAM_MAX;
+      if (e < nb) {
+        const unsigned long long eph = beam[e].phash;
+        const int elen = beam[e].len;                        // (len 0, the empty prefix: no entry has len + 1 == 0)
+        int cand = 0x7fffffff;
+#pragma unroll 4
+        for (int j = part; j < nb; j += PARTS) {
+          const bool hit = (beam[j].hash == eph) & (beam[j].len + 1 == elen);
+          cand = hit ? min(cand, j) : cand;
+        }
+        if (cand != 0x7fffffff) atomicMin(&s_parent[e], cand);
+      }
     }
     __syncthreads();
+    if (tid < nb && s_parent[tid] == 0x7fffffff) s_parent[tid] = -1;   // (every later reader of s_parent[i] is thread i)
     if (tid < nb) {
       const Entry e = beam[tid];
       const double lpb = lp[blank];
@@ -279,6 +325,29 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
     // ---- 2b. classes that can still reach the top W (see the header): threshold = (W+1)-th largest
     //      non-blank log-probability, found with a byte-wise radix select over the frame's C values
     if (tid < nb) s_L[tid] = lse2d(beam[tid].pb, beam[tid].pnb);
+    // Bytes 7 .. first + 1 are the same in every live key a thread holds in rk (first = -1: all keys are equal); `common`
+    // = those bytes.  Log-probabilities a few units apart share sign, exponent and often the top of the significand: two
+    // or three of the eight radix passes would find every key in one bin.  One barrier.
+    auto lead_byte = [&](const auto& rk, unsigned long long& common) __attribute__((always_inline)) -> int {
+      unsigned long long ka = ~0ull, ko = 0ull;
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(rk) / sizeof(rk[0])); ++i)
+        if (rk[i] != 0ull) { ka &= rk[i]; ko |= rk[i]; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ka &= __shfl_xor(ka, o, 64);
+        ko |= __shfl_xor(ko, o, 64);
+      }
+      if (lane == 0) { s_min[wave] = ka; s_or[wave] = ko; }
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) { ka &= s_min[w]; ko |= s_or[w]; }
+      const unsigned long long diff = ka ^ ko;
+      if (ko == 0ull) { common = 0ull; return -1; }          // no live key at all
+      const int first = diff ? 7 - (__clzll((long long)diff) >> 3) : -1;
+      common = first >= 7 ? 0ull : (first < 0 ? ka : (ka & ~((1ull << ((first + 1) * 8)) - 1ull)));
+      return first;
+    };
     const int R = W + 1;
     if (C - 1 > 4 * R) {   // small vocabularies: the select + compaction passes cost more than they prune
       // R-th largest non-blank log-probability by a NARROWING radix select: a thread holds its classes' keys in registers;
@@ -289,13 +358,15 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
         unsigned long long rc[NK];
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
-          const int c = i * BEAM_THREADS + tid;
+          const int c = i * NT + tid;
           rc[i] = (c < C && c != blank) ? okey(lp[c]) : 0ull;   // (okey of a log-probability is never 0)
         }
+        unsigned long long common_c = 0;
+        const int first_c = lead_byte(rc, common_c);         // the passes start at the first byte the keys differ in
         if (tid == 0) { sel_key = 0; sel_remaining = (unsigned)R; }
         __syncthreads();
-        for (int byte = 7; byte >= 0; --byte) {
-          hist[tid] = 0;
+        for (int byte = first_c; byte >= 0; --byte) {
+          if (tid < 256) hist[tid] = 0;
           __syncthreads();
           hist_regs<NK>(hist, rc, byte);
           __syncthreads();
@@ -335,13 +406,15 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
         __syncthreads();
         if (tid == 0) {
           unsigned long long m4 = s_min[0];
-          for (int w = 1; w < BEAM_THREADS / 64; ++w) if (s_min[w] < m4) m4 = s_min[w];
+          for (int w = 1; w < NT / 64; ++w) if (s_min[w] < m4) m4 = s_min[w];
           const double th = unokey(m4);
           s_thr = th - 1e-9 * (1.0 + fabs(th));
         }
       };
-      if (C <= 8 * BEAM_THREADS) class_select(std::integral_constant<int, 8>{});
-      else class_select(std::integral_constant<int, 24>{});   // C <= 6144: the LDS limit of the launcher
+      if (NT > 256 && C <= 2 * NT) class_select(std::integral_constant<int, 2>{});
+      else if (NT > 256 && C <= 4 * NT) class_select(std::integral_constant<int, 4>{});
+      else if (C <= 8 * NT) class_select(std::integral_constant<int, 8>{});
+      else class_select(std::integral_constant<int, NT == 256 ? 24 : 8>{});   // (NT = 256) C <= 6144: the LDS limit of the launcher
     } else if (tid == 0) {
       s_thr = DNEG;
     }
@@ -349,7 +422,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
     BEAM_T(2);
     {   // ordered compaction of the kept classes: thread t owns the contiguous classes [t cpt, (t + 1) cpt)
       const double thr = s_thr;
-      const int cpt = (C + BEAM_THREADS - 1) / BEAM_THREADS;
+      const int cpt = (C + NT - 1) / NT;
       const int c_lo = min(C, tid * cpt), c_hi = min(C, c_lo + cpt);
       int mine = 0;
       for (int c = c_lo; c < c_hi; ++c) mine += (c != blank && lp[c] >= thr) ? 1 : 0;
@@ -368,7 +441,11 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
         kpos[c] = keep ? pos : -1;
         if (keep) kc[pos++] = c;
       }
-      if (tid == 0) s_K = (int)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+      if (tid == 0) {
+        unsigned kk = 0;
+        for (int w = 0; w < NT / 64; ++w) kk += wcnt[w];
+        s_K = (int)kk;
+      }
     }
     __syncthreads();
     const int K = s_K;
@@ -393,8 +470,8 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
       {
         const int Kd = K > 0 ? K : 1;                        // (K == 0: one class, or every non-blank probability NaN -- the loop below is empty)
         int j = tid / Kd, ci = tid - j * Kd;
-        const int dj = BEAM_THREADS / Kd, dci = BEAM_THREADS - dj * Kd;
-        for (int e = tid; e < nb * K; e += BEAM_THREADS) {
+        const int dj = NT / Kd, dci = NT - dj * Kd;
+        for (int e = tid; e < nb * K; e += NT) {
           const int c = kc[ci];
           ck[nb + e] = okey(((c == beam[j].last) ? beam[j].pb : s_L[j]) + lp[c]);
           j += dj; ci += dci;
@@ -417,29 +494,31 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
       // twelve-pass select over the key array
       auto select_mem = [&](const unsigned long long* ckm) -> int {
         int cnt = 0;
-        for (int id = tid; id < M; id += BEAM_THREADS) cnt += ckm[id] != 0ull ? 1 : 0;
-        cnt = (int)wave_reduce_sum((float)cnt);              // <= 64 * ceil(M / 256): exact in fp32
+        for (int id = tid; id < M; id += NT) cnt += ckm[id] != 0ull ? 1 : 0;
+        cnt = (int)wave_reduce_sum((float)cnt);              // <= 64 * ceil(M / NT): exact in fp32
         if (lane == 0) tcnt[wave] = (unsigned)cnt;
         __syncthreads();
-        const int valid = (int)(tcnt[0] + tcnt[1] + tcnt[2] + tcnt[3]);
+        int valid = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) valid += (int)tcnt[w];
         const int want = min(W, valid);
         if (tid == 0) sel_remaining = want;
         __syncthreads();
         if (valid > want) {
           for (int byte = 11; byte >= 0; --byte) {
-            hist[tid] = 0;   // BEAM_THREADS == 256
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const unsigned long long pk = sel_key;
             const unsigned pn = sel_nidx;
             if (byte >= 4) {
               const int sh = (byte - 4 + 1) * 8, ds = (byte - 4) * 8;
-              for (int id = tid; id < M; id += BEAM_THREADS) {
+              for (int id = tid; id < M; id += NT) {
                 const unsigned long long k = ckm[id];
                 if (k != 0ull && (sh >= 64 || (k >> sh) == (pk >> sh))) atomicAdd(&hist[(unsigned)((k >> ds) & 0xff)], 1u);
               }
             } else {
               const int sh = (byte + 1) * 8;
-              for (int id = tid; id < M; id += BEAM_THREADS) {
+              for (int id = tid; id < M; id += NT) {
                 if (ckm[id] != pk) continue;                 // (pk != 0: the threshold is a valid candidate's key)
                 const unsigned n = nidx_of(id);
                 if (sh >= 32 || (n >> sh) == (pn >> sh)) atomicAdd(&hist[(n >> (byte * 8)) & 0xff], 1u);
@@ -460,7 +539,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
         }
         const unsigned long long tk = sel_key;
         const unsigned tn = sel_nidx;
-        for (int id = tid; id < M; id += BEAM_THREADS) {    // winners: composite >= threshold (all valid ones when valid <= W)
+        for (int id = tid; id < M; id += NT) {    // winners: composite >= threshold (all valid ones when valid <= W)
           const unsigned long long k = ckm[id];
           if (k == 0ull) continue;
           bool win = (valid <= want) || (k > tk);
@@ -474,7 +553,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
         unsigned long long rk[NK];
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
-          const int id = i * BEAM_THREADS + tid;
+          const int id = i * NT + tid;
           rk[i] = id < M ? ck[id] : 0ull;
         }
         int cnt = 0;
@@ -482,20 +561,29 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
         for (int i = 0; i < NK; ++i) cnt += rk[i] != 0ull ? 1 : 0;
         cnt = (int)wave_reduce_sum((float)cnt);              // <= 64 NK: exact in fp32
         if (lane == 0) tcnt[wave] = (unsigned)cnt;
-        __syncthreads();
-        const int valid = (int)(tcnt[0] + tcnt[1] + tcnt[2] + tcnt[3]);
+        unsigned long long common = 0;
+        const int first = lead_byte(rk, common);             // (its barrier also publishes tcnt)
+        int valid = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) valid += (int)tcnt[w];
         const int want = min(W, valid);
         if (tid == 0) sel_remaining = want;
         __syncthreads();
         if (valid <= want) {                                  // everything wins
 #pragma unroll
           for (int i = 0; i < NK; ++i)
-            if (rk[i] != 0ull) push_winner(rk[i], i * BEAM_THREADS + tid);
+            if (rk[i] != 0ull) push_winner(rk[i], i * NT + tid);
           return want;
         }
-        bool exact = false;
-        for (int byte = 7; byte >= 0; --byte) {
-          hist[tid] = 0;   // BEAM_THREADS == 256
+        // The passes only NARROW (branch-free: a key outside the chosen bin leaves the registers, the ones above the bin
+        // are counted off by pick_digit); `thr` collects the chosen digits under the bytes every key shares.  When a bin
+        // holds exactly the keys still wanted the search is over: the winners are the keys >= thr.  Keys that survive all
+        // eight bytes are equal (= thr): everything above wins, and the tie index decides among them, four more bytes.
+        unsigned long long thr = common;
+        bool key_exact = false;
+        BEAM_T(5);
+        for (int byte = first; byte >= 0; --byte) {
+          if (tid < 256) hist[tid] = 0;
           __syncthreads();
           hist_regs<NK>(hist, rk, byte);
           __syncthreads();
@@ -506,34 +594,28 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
           }
           __syncthreads();
           const unsigned dgt = s_digit;
-          exact = s_exact != 0u;
+          key_exact = s_exact != 0u;
+          thr |= (unsigned long long)dgt << (byte * 8);
           const bool upper = byte >= 4;
           const int ds = (byte & 3) * 8;
 #pragma unroll
           for (int i = 0; i < NK; ++i) {
             const unsigned long long k = rk[i];
-            if (k == 0ull) continue;
             const unsigned d = ((upper ? (unsigned)(k >> 32) : (unsigned)k) >> ds) & 0xffu;
-            if (d > dgt || (exact && d == dgt)) {
-              push_winner(k, i * BEAM_THREADS + tid);
-              rk[i] = 0ull;
-            } else if (d < dgt) {
-              rk[i] = 0ull;
-            }
+            rk[i] = (d == dgt) ? k : 0ull;                    // (a dead slot stays dead)
           }
-          if (exact) break;                                   // block-uniform
+          if (key_exact) break;                               // block-uniform
         }
-        if (!exact) {
+        if (!key_exact) {
           // the survivors share one key; sel_remaining of them win, those with the largest tie index (= the earliest in
           // the reference's insertion order).  The same select on the 32-bit index, kept in the register's low word
           // (bit 32 marks the slot as alive: an index can be 0)
 #pragma unroll
           for (int i = 0; i < NK; ++i)
-            if (rk[i] != 0ull) { w_tie = rk[i]; rk[i] = (1ull << 32) | nidx_of(i * BEAM_THREADS + tid); }
-          __syncthreads();
-          const unsigned long long tiekey = w_tie;            // (every survivor wrote the same value)
+            if (rk[i] != 0ull) rk[i] = (1ull << 32) | nidx_of(i * NT + tid);
+          bool exact = false;
           for (int byte = 3; byte >= 0; --byte) {
-            hist[tid] = 0;
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
             hist_regs<NK>(hist, rk, byte);
             __syncthreads();
@@ -551,7 +633,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
               if (k == 0ull) continue;
               const unsigned n = (unsigned)k, d = (n >> (byte * 8)) & 0xffu;
               if (d > dgt || (exact && d == dgt)) {
-                push_winner(tiekey, i * BEAM_THREADS + tid);
+                push_winner(thr, i * NT + tid);
                 rk[i] = 0ull;
               } else if (d < dgt) {
                 rk[i] = 0ull;
@@ -561,27 +643,52 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
           }
           // (tie indices are distinct, so the last byte's bin holds one key: the select always ends exactly)
         }
+        // the winners decided by their keys alone: one pass over the frame's keys
+        #pragma unroll
+        for (int i = 0; i < NK; ++i) {
+          const int id = i * NT + tid;
+          const unsigned long long k = id < M ? ck[id] : 0ull;
+          if (k != 0ull && (key_exact ? k >= thr : k > thr)) push_winner(k, id);
+        }
         return want;
       };
       int want;
-      if (M <= 4 * BEAM_THREADS) want = select(std::integral_constant<int, 4>{});
-      else if (M <= 8 * BEAM_THREADS) want = select(std::integral_constant<int, 8>{});
-      else if (M <= 16 * BEAM_THREADS) want = select(std::integral_constant<int, 16>{});
-      else if (M <= 40 * BEAM_THREADS) want = select(std::integral_constant<int, 40>{});
-      else if (M <= 48 * BEAM_THREADS) want = select(std::integral_constant<int, 48>{});
+      // keys per thread: what M needs, from a ladder that fits the register budget of NT / 64 waves (512 / 256 VGPRs)
+      if (NT > 256 && M <= 2 * NT) want = select(std::integral_constant<int, 2>{});
+      else if (M <= 4 * NT) want = select(std::integral_constant<int, 4>{});
+      else if (M <= 8 * NT) want = select(std::integral_constant<int, 8>{});
+      else if (M <= 16 * NT) want = select(std::integral_constant<int, 16>{});
+      else if (NT == 512 && M <= 24 * NT) want = select(std::integral_constant<int, NT == 512 ? 24 : 16>{});
+      else if (NT == 256 && M <= 40 * NT) want = select(std::integral_constant<int, NT == 256 ? 40 : 16>{});
+      else if (NT == 256 && M <= 48 * NT) want = select(std::integral_constant<int, NT == 256 ? 48 : 16>{});
       else want = select_mem(ck);
       __syncthreads();
       BEAM_T(6);
       const int nw = min(s_nw, want);
       // ---- 5. rank winners (composite keys are distinct) and build the next beam
       if (tid < nw) w_nidx[tid] = nidx_of(w_src[tid]);
+      if (tid < BEAM_MAX) s_rank[tid] = 0;
+      __syncthreads();
+      {   // rank of winner i = winners above it: NT / 128 threads per winner, branch-free partial counts
+        constexpr int PARTS = NT / BEAM_MAX;
+        const int i = tid & (BEAM_MAX - 1), part = tid / BEAM_MAX;
+        if (i < nw) {
+          const unsigned long long k = w_key[i];
+          const unsigned n = w_nidx[i];
+          int r = 0;
+#pragma unroll 4
+          for (int o = part; o < nw; o += PARTS) {
+            const unsigned long long ko = w_key[o];
+            const unsigned no = w_nidx[o];
+            r += (int)((ko > k) | ((ko == k) & (no > n)));
+          }
+          if (r) atomicAdd(&s_rank[i], r);
+        }
+      }
       __syncthreads();
       if (tid < nw) {
         const unsigned long long k = w_key[tid];
-        const unsigned n = w_nidx[tid];
-        int rank = 0;
-#pragma unroll 8
-        for (int o = 0; o < nw; ++o) rank += (w_key[o] > k) || (w_key[o] == k && w_nidx[o] > n);
+        const int rank = s_rank[tid];
         const int id = w_src[tid];
         Entry ne;
         if (id < nb) {
@@ -593,7 +700,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
           ne.pb = DNEG; ne.pnb = unokey(k);                  // the key IS the total (order-preserving bijection)
           ne.phash = p.hash; ne.hash = hmix(p.hash, c);
           ne.len = p.len + 1; ne.last = c;
-          const int node = atomicAdd(&s_nodes, 1);
+          const int node = s_nodes + rank;                   // ids of a frame: s_nodes .. s_nodes + nw - 1 (stay winners leave gaps)
           nodes[node] = make_int2(p.node, c);
           ne.node = node;
         }
@@ -605,7 +712,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void ctc_beam_kernel(
     const int nw = (M <= lds_keys) ? frame_tail(lkeys) : frame_tail(gkeys);
     __syncthreads();
     if (tid < nw) beam[tid] = nbeam[tid];
-    if (tid == 0) s_nb = nw;
+    if (tid == 0) { s_nb = nw; s_nodes += nw; }
     __syncthreads();
   }
 
@@ -670,7 +777,13 @@ extern "C" int asr_ctc_beam_decode(asr_handle* h, const float* logits, int T, in
   size_t nkeys = (size_t)beam_width * (C - 1) + beam_width;
   if (nkeys * 8 > room) nkeys = room / 8;
   const size_t lds = lds_c + nkeys * 8;
-  (void)hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // 512 threads per utterance (round 6; 256 before): every phase that strides over a frame's classes / candidates gets
+  // twice the lanes and the kernel still has 256 registers per thread (1024 threads: 128 registers, ~100 spilled, no faster
+  // at any shape measured).  ASR_BEAM_THREADS=256 selects the four-wave form (A/B, the bit-identity test).
+  const char* env_t = getenv("ASR_BEAM_THREADS");          // (read per call: the test flips it inside one process)
+  const int nt = (env_t && atoi(env_t) == 256) ? 256 : 512;
+  const void* kfn = nt == 512 ? (const void*)ctc_beam_kernel<512> : (const void*)ctc_beam_kernel<256>;
+  (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   char* ws = (char*)workspace;
   static unsigned long long* dbgbuf = [] {
     const char* e = getenv("ASR_BEAM_DBG");
@@ -678,15 +791,19 @@ extern "C" int asr_ctc_beam_decode(asr_handle* h, const float* logits, int T, in
     if (e && e[0] == '1') (void)hipMalloc(&p, 8 * sizeof(unsigned long long));
     return p;
   }();
-  hipLaunchKernelGGL(ctc_beam_kernel, dim3(B), dim3(BEAM_THREADS), lds, (hipStream_t)s, logits, T, B, C, seq_len,
-                     blank, beam_width, (double*)(ws + w.tot), (int2*)(ws + w.nodes), out_labels, out_len,
-                     out_score, (int)nkeys, dbgbuf);
+#define ASR_BEAM_LAUNCH(NT_)                                                                                              \
+  hipLaunchKernelGGL(ctc_beam_kernel<NT_>, dim3(B), dim3(NT_), lds, (hipStream_t)s, logits, T, B, C, seq_len, blank,         \
+                     beam_width, (double*)(ws + w.tot), (int2*)(ws + w.nodes), out_labels, out_len, out_score, (int)nkeys, \
+                     dbgbuf)
+  if (nt == 512) ASR_BEAM_LAUNCH(512);
+  else ASR_BEAM_LAUNCH(256);
+#undef ASR_BEAM_LAUNCH
   ASR_CHECK_LAUNCH(h, "asr_ctc_beam_decode");
   if (dbgbuf) {
     unsigned long long v[8];
     if (hipMemcpy(v, dbgbuf, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
       fprintf(stderr, "[beam dbg] T=%d C=%d W=%d cycles/frame: softmax %llu stay %llu class-select %llu compact %llu keys %llu "
-              "select %llu rank+build %llu\n", T, C, beam_width, v[0] / T, v[1] / T, v[2] / T, v[3] / T, v[4] / T, v[6] / T, v[7] / T);
+              "select-setup %llu select %llu rank+build %llu\n", T, C, beam_width, v[0] / T, v[1] / T, v[2] / T, v[3] / T, v[4] / T, v[5] / T, v[6] / T, v[7] / T);
   }
   return ASR_OK;
 }

@@ -1408,3 +1408,34 @@ def test_upload_ints_is_one_copy_off_the_main_stream(cuda):
         assert int(on_lane) == int(lens.sum() + flat.sum())
         assert np.array_equal(a.cpu().numpy(), lens) and np.array_equal(b.cpu().numpy(), offs)
         assert np.array_equal(c.cpu().numpy(), flat) and np.array_equal(d.cpu().numpy(), np.arange(7))
+
+
+def test_beam_search_thread_counts_agree(cuda, monkeypatch):
+    """asr_ctc_beam_decode with 512 threads per utterance (default) against the four-wave form (ASR_BEAM_THREADS=256):
+    same labels and lengths on flat, peaked and tie-heavy posteriors (quantised logits: many equal candidate totals, so
+    the tie-index passes run), small and large vocabularies, ragged lengths; scores to 1e-9 (the fp64 log-softmax sums
+    in a different order)."""
+    ops = _ops()
+    rng = np.random.RandomState(11)
+    for T, B, C, W, kind in ((60, 5, 62, 20, 'flat'), (60, 5, 62, 20, 'ties'), (40, 3, 3387, 100, 'peaked'),
+                             (40, 3, 3387, 100, 'ties'), (50, 4, 1000, 40, 'flat'), (30, 2, 30, 128, 'flat'),
+                             (25, 2, 5000, 64, 'peaked')):
+        if kind == 'flat':
+            lg = rng.randn(T, B, C).astype(np.float32) * 3
+        elif kind == 'ties':
+            lg = np.round(rng.randn(T, B, C).astype(np.float32) * 2) / 2          # steps of 0.5: equal totals abound
+        else:
+            lg = rng.randn(T, B, C).astype(np.float32)
+            win = np.where(rng.rand(T, B) < 0.6, C - 1, rng.randint(0, C - 1, size=(T, B)))
+            np.put_along_axis(lg, win[:, :, None], 12.0 + rng.rand(T, B, 1).astype(np.float32), axis=2)
+        logits = torch.tensor(lg, device=cuda)
+        sl = torch.tensor(rng.randint(T // 2, T + 1, size=B).astype(np.int32), device=cuda)
+        out = {}
+        for nt in ('256', '512'):
+            monkeypatch.setenv('ASR_BEAM_THREADS', nt)
+            lab, n, score = ops.ctc_beam_decode(logits, sl, beam_width=W)
+            out[nt] = (lab.cpu().numpy(), n.cpu().numpy(), score.cpu().numpy())
+        monkeypatch.delenv('ASR_BEAM_THREADS')
+        assert np.array_equal(out['256'][1], out['512'][1]), (T, B, C, W, kind)
+        assert np.array_equal(out['256'][0], out['512'][0]), (T, B, C, W, kind)
+        assert np.abs(out['256'][2] - out['512'][2]).max() < 1e-9 * max(1.0, np.abs(out['256'][2]).max())
