@@ -51,12 +51,15 @@
 // winners run NT / 128 threads per entry, branch-free (as loops that break / short-circuit they waited for one LDS read
 // per iteration: 13 k + 15 k cycles of a W = 100 frame); trie node ids are base + rank instead of one atomic per new
 // prefix; the frame's logits are requested one frame ahead; both radix selects skip the leading bytes all keys share
-// (one AND / OR reduction), and the top-W select only narrows during the passes -- the winners are collected by one
-// pass against the threshold the passes spell.  Same candidates, same composite keys, same winners (goldens, and
-// ASR_BEAM_THREADS=256 against 512 in tests/test_gpu_ops.py).  us per frame, C = 3387 / W = 100: 69 -> 33 (flat
-// posteriors) / 36 (peaked); C = 62 / W = 20: 16.7 -> 11.9.  Cycles of a C = 3387 / W = 100 frame now: log-softmax 8 k,
-// stay candidates 8 k, class select 15 k, compaction 5 k, keys 7.5 k, top-W select 6 k + 24 k, ranking + trie 4 k; a radix
-// pass costs ~2 k cycles whatever it counts (three barriers + the one-wave digit choice), which is what is left.
+// (one AND / OR reduction); a radix pass is ONE barrier (three rotating histograms, every wave walks the bins itself,
+// on a DPP scan); the class select stops at a bin that holds a few keys more than wanted (any threshold at or below the
+// exact one prunes correctly); the top-W select only narrows during the passes -- the winners are collected by one pass
+// against the threshold the passes spell.  Same candidates up to classes kept in vain, same composite keys, same winners
+// (goldens, and ASR_BEAM_THREADS=256 against 512 in tests/test_gpu_ops.py).  us per frame (scripts/probe_beam.py),
+// C = 3387 / W = 100: 69 -> 31 (flat posteriors) / 34.5 (peaked); C = 62 / W = 20: 16.7 -> 11.6 / 10.9.  Cycles of a
+// C = 3387 / W = 100 frame now: log-softmax 8 k, stay candidates 8 k, class select 12.5 k, compaction 5 k, keys 7.5 k,
+// top-W select 6 k + 23-30 k, ranking + trie 4 k.  What is left in the select is the first counting pass: 10 k keys that
+// fall into a handful of bins are LDS atomics on a handful of addresses (privatised copies do not fit beside the keys).
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -92,40 +95,49 @@ __device__ __forceinline__ unsigned long long hmix(unsigned long long h, int c) 
   return x;
 }
 
-// One radix pass' decision, by ONE wave (lane = threadIdx.x < 64): the reference walk
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP path (row shifts by 1 / 2 / 4 / 8 with zero fill, then lane 15
+// of a row added to the next row, then lane 31 to the upper half): eight VALU operations instead of six LDS permutes.
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// One radix pass' decision, by one wave (all 64 lanes active): the reference walk
 //     for (d = 255; d > 0; --d) { if (hist[d] >= rem) break; rem -= hist[d]; }
-// as a suffix scan -- lane l owns bins 4 l .. 4 l + 3 (bin 0 never counts: the walk stops at d = 1 and falls through to 0).
+// as a scan -- lane l owns bins 4 q .. 4 q + 3 of q = 63 - l (the HIGHEST bins in lane 0, so that the inclusive prefix over
+// the lanes is the suffix sum over the bins; bin 0 never counts: the walk stops at d = 1 and falls through to 0).
 // Also returns the population of the chosen bin.
 __device__ __forceinline__ void pick_digit(const unsigned* hist, unsigned rem0, int lane, unsigned& digit, unsigned& rem,
                                            unsigned& pop) {
-  const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-  const unsigned own = h1 + h2 + h3 + (lane ? h0 : 0u);
-  unsigned suf = own;                                      // inclusive suffix sum over lanes (lane 63 = highest bins)
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned v = __shfl_down(suf, o, 64);
-    if (lane + o < 64) suf += v;
-  }
+  const int q = 63 - lane;
+  const unsigned h0 = hist[4 * q], h1 = hist[4 * q + 1], h2 = hist[4 * q + 2], h3 = hist[4 * q + 3];
+  const unsigned own = h1 + h2 + h3 + (q ? h0 : 0u);
+  const unsigned suf = wave_incl_scan_u32(own);            // bins 4 q and above
   const unsigned above = suf - own;
-  const bool here = above < rem0 && (lane == 0 || rem0 <= suf);
+  const bool here = above < rem0 && (q == 0 || rem0 <= suf);
   unsigned d = 0, r = 0, p = 0;
   if (here) {
     unsigned acc = above;
-    if (acc + h3 >= rem0) { d = 4 * lane + 3; r = rem0 - acc; p = h3; }
+    if (acc + h3 >= rem0) { d = 4 * q + 3; r = rem0 - acc; p = h3; }
     else {
       acc += h3;
-      if (acc + h2 >= rem0) { d = 4 * lane + 2; r = rem0 - acc; p = h2; }
+      if (acc + h2 >= rem0) { d = 4 * q + 2; r = rem0 - acc; p = h2; }
       else {
         acc += h2;
-        if (acc + h1 >= rem0) { d = 4 * lane + 1; r = rem0 - acc; p = h1; }
-        else { acc += h1; d = 4 * lane; r = rem0 - acc; p = h0; }   // lane 0: digit 0, the walk's fall-through
+        if (acc + h1 >= rem0) { d = 4 * q + 1; r = rem0 - acc; p = h1; }
+        else { acc += h1; d = 4 * q; r = rem0 - acc; p = h0; }   // q = 0: digit 0, the walk's fall-through
       }
     }
   }
-  const int src = __ffsll((unsigned long long)__ballot(here)) - 1;
-  digit = __shfl(d, src, 64);
-  rem = __shfl(r, src, 64);
-  pop = __shfl(p, src, 64);
+  const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)__ballot(here)) - 1);
+  digit = (unsigned)__builtin_amdgcn_readlane((int)d, src);
+  rem = (unsigned)__builtin_amdgcn_readlane((int)r, src);
+  pop = (unsigned)__builtin_amdgcn_readlane((int)p, src);
 }
 
 // The keys a thread holds in registers (0 = dead) towards the histogram of byte `byte` (7 .. 0 of the 64-bit key; all
@@ -184,7 +196,6 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
   int* kpos = kc + C;                                // [C] position of a class in kc, -1 if pruned
   unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(smem + (((size_t)C * 16 + 15) & ~(size_t)15));   // [lds_keys]
   __shared__ unsigned tcnt[NT / 64];
-  __shared__ unsigned s_digit, s_exact;
   __shared__ unsigned long long s_min[NT / 64], s_or[NT / 64];
   __shared__ double s_L[BEAM_MAX];                   // logsumexp(p_b, p_nb) of each beam entry
   __shared__ unsigned wcnt[NT / 64];
@@ -196,7 +207,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
   __shared__ unsigned long long s_key[BEAM_MAX];
   __shared__ unsigned s_idx[BEAM_MAX];
   __shared__ int s_parent[BEAM_MAX];
-  __shared__ unsigned hist[256];
+  __shared__ unsigned hist[256];                     // select_mem only
+  __shared__ unsigned hist3[3][256];                 // the register selects' histograms, rotating (radix_pass)
+  __shared__ unsigned long long s_mn2[NT / 64];
   __shared__ unsigned long long w_key[BEAM_MAX];
   __shared__ unsigned w_nidx[BEAM_MAX];
   __shared__ int w_src[BEAM_MAX];                    // candidate id of each winner
@@ -213,6 +226,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
   unsigned long long* gkeys = reinterpret_cast<unsigned long long*>(tot_ws) + (size_t)b * ((size_t)W * C + W);
   int2* nodes = node_ws + (size_t)b * ((size_t)T * W + 1);
 
+  for (int i = tid; i < 3 * 256; i += NT) hist3[0][i] = 0;
+  int hrot = 0;                                            // the histogram the next radix pass counts into (block-uniform)
   if (tid == 0) {
     beam[0].pb = 0.0; beam[0].pnb = DNEG; beam[0].hash = 0x1234567ull; beam[0].phash = 0;
     beam[0].node = 0; beam[0].len = 0; beam[0].last = -1;
@@ -348,6 +363,24 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
       common = first >= 7 ? 0ull : (first < 0 ? ka : (ka & ~((1ull << ((first + 1) * 8)) - 1ull)));
       return first;
     };
+    // One pass of a register-resident radix select, ONE barrier: count byte `byte` of the live keys into the current
+    // histogram (zero since the pass before last) while the next one is cleared, then every wave walks the bins itself
+    // (the same arithmetic on the same counts: block-uniform results in registers, nothing to publish).  rem: keys still
+    // wanted, counted down by the bins above the chosen one; exact: the chosen bin holds exactly rem keys.
+    // Why three histograms: the readers of the one cleared here finished before the barrier of the previous pass.
+    auto radix_pass = [&](const auto& rk, int byte, unsigned& rem, unsigned& dgt, bool& exact, unsigned* pop_out = nullptr)
+        __attribute__((always_inline)) {
+      unsigned* hc = hist3[hrot];
+      hrot = hrot == 2 ? 0 : hrot + 1;
+      if (tid < 256) hist3[hrot][tid] = 0;
+      hist_regs(hc, rk, byte);
+      __syncthreads();
+      unsigned r2, pop;
+      pick_digit(hc, rem, lane, dgt, r2, pop);
+      exact = pop == r2;
+      rem = r2;
+      if (pop_out) *pop_out = pop;
+    };
     const int R = W + 1;
     if (C - 1 > 4 * R) {   // small vocabularies: the select + compaction passes cost more than they prune
       // R-th largest non-blank log-probability by a NARROWING radix select: a thread holds its classes' keys in registers;
@@ -363,25 +396,17 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
         }
         unsigned long long common_c = 0;
         const int first_c = lead_byte(rc, common_c);         // the passes start at the first byte the keys differ in
-        if (tid == 0) { sel_key = 0; sel_remaining = (unsigned)R; }
-        __syncthreads();
+        // The threshold only has to be AT OR BELOW the R-th largest value (a class kept in vain costs W more candidates, a
+        // class dropped in error would cost the result): the passes stop as soon as the bin the R-th largest falls into
+        // holds at most W / 8 keys more than are still wanted -- the smallest key of that bin is the threshold
+        // (... as long as the frame's candidate keys still fit the LDS: nb (K + 1) <= lds_keys)
+        const int fit = lds_keys / nb - 1 - R;
+        const unsigned slack = (unsigned)max(0, min(W >> 3, fit));
+        unsigned rem = (unsigned)R;
         for (int byte = first_c; byte >= 0; --byte) {
-          if (tid < 256) hist[tid] = 0;
-          __syncthreads();
-          hist_regs<NK>(hist, rc, byte);
-          __syncthreads();
-          if (tid < 64) {
-            unsigned dgt, rem, pop;
-            pick_digit(hist, sel_remaining, lane, dgt, rem, pop);
-            if (tid == 0) {
-              sel_remaining = rem;
-              sel_key |= ((unsigned long long)dgt) << (byte * 8);
-              s_digit = dgt;
-              s_exact = (pop == rem) ? 1u : 0u;
-            }
-          }
-          __syncthreads();
-          const unsigned dgt = s_digit;
+          unsigned dgt, pop;
+          bool ex;
+          radix_pass(rc, byte, rem, dgt, ex, &pop);
           const bool upper = byte >= 4;
           const int ds = (byte & 3) * 8;
 #pragma unroll
@@ -390,9 +415,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
             const unsigned d = ((upper ? (unsigned)(k >> 32) : (unsigned)k) >> ds) & 0xffu;
             if (d != dgt) rc[i] = 0ull;
           }
-          if (s_exact) break;                               // block-uniform
+          if (pop - rem <= slack) break;                      // block-uniform (pop >= rem; equal: the pass ended exactly)
         }
-        // the R-th largest = the smallest key still alive (after all eight bytes: the one value sel_key spells)
+        // the threshold = the smallest key still alive (the R-th largest itself when a pass ended exactly)
         unsigned long long mn = ~0ull;
 #pragma unroll
         for (int i = 0; i < NK; ++i)
@@ -402,11 +427,11 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
           const unsigned long long v = __shfl_xor(mn, o, 64);
           if (v < mn) mn = v;
         }
-        if (lane == 0) s_min[wave] = mn;
+        if (lane == 0) s_mn2[wave] = mn;
         __syncthreads();
         if (tid == 0) {
-          unsigned long long m4 = s_min[0];
-          for (int w = 1; w < NT / 64; ++w) if (s_min[w] < m4) m4 = s_min[w];
+          unsigned long long m4 = s_mn2[0];
+          for (int w = 1; w < NT / 64; ++w) if (s_mn2[w] < m4) m4 = s_mn2[w];
           const double th = unokey(m4);
           s_thr = th - 1e-9 * (1.0 + fabs(th));
         }
@@ -567,14 +592,13 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
 #pragma unroll
         for (int w = 0; w < NT / 64; ++w) valid += (int)tcnt[w];
         const int want = min(W, valid);
-        if (tid == 0) sel_remaining = want;
-        __syncthreads();
         if (valid <= want) {                                  // everything wins
 #pragma unroll
           for (int i = 0; i < NK; ++i)
             if (rk[i] != 0ull) push_winner(rk[i], i * NT + tid);
           return want;
         }
+        unsigned rem = (unsigned)want;
         // The passes only NARROW (branch-free: a key outside the chosen bin leaves the registers, the ones above the bin
         // are counted off by pick_digit); `thr` collects the chosen digits under the bytes every key shares.  When a bin
         // holds exactly the keys still wanted the search is over: the winners are the keys >= thr.  Keys that survive all
@@ -583,18 +607,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
         bool key_exact = false;
         BEAM_T(5);
         for (int byte = first; byte >= 0; --byte) {
-          if (tid < 256) hist[tid] = 0;
-          __syncthreads();
-          hist_regs<NK>(hist, rk, byte);
-          __syncthreads();
-          if (tid < 64) {
-            unsigned d, rem, pop;
-            pick_digit(hist, sel_remaining, lane, d, rem, pop);
-            if (tid == 0) { sel_remaining = rem; s_digit = d; s_exact = (pop == rem) ? 1u : 0u; }
-          }
-          __syncthreads();
-          const unsigned dgt = s_digit;
-          key_exact = s_exact != 0u;
+          unsigned dgt;
+          radix_pass(rk, byte, rem, dgt, key_exact);
           thr |= (unsigned long long)dgt << (byte * 8);
           const bool upper = byte >= 4;
           const int ds = (byte & 3) * 8;
@@ -615,18 +629,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
             if (rk[i] != 0ull) rk[i] = (1ull << 32) | nidx_of(i * NT + tid);
           bool exact = false;
           for (int byte = 3; byte >= 0; --byte) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            hist_regs<NK>(hist, rk, byte);
-            __syncthreads();
-            if (tid < 64) {
-              unsigned d, rem, pop;
-              pick_digit(hist, sel_remaining, lane, d, rem, pop);
-              if (tid == 0) { sel_remaining = rem; s_digit = d; s_exact = (pop == rem) ? 1u : 0u; }
-            }
-            __syncthreads();
-            const unsigned dgt = s_digit;
-            exact = s_exact != 0u;
+            unsigned dgt;
+            radix_pass(rk, byte, rem, dgt, exact);
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
               const unsigned long long k = rk[i];
