@@ -55,11 +55,13 @@
 // on a DPP scan); the class select stops at a bin that holds a few keys more than wanted (any threshold at or below the
 // exact one prunes correctly); the top-W select only narrows during the passes -- the winners are collected by one pass
 // against the threshold the passes spell.  Same candidates up to classes kept in vain, same composite keys, same winners
-// (goldens, and ASR_BEAM_THREADS=256 against 512 in tests/test_gpu_ops.py).  us per frame (scripts/probe_beam.py),
-// C = 3387 / W = 100: 69 -> 31 (flat posteriors) / 34.5 (peaked); C = 62 / W = 20: 16.7 -> 11.6 / 10.9.  Cycles of a
-// C = 3387 / W = 100 frame now: log-softmax 8 k, stay candidates 8 k, class select 12.5 k, compaction 5 k, keys 7.5 k,
-// top-W select 6 k + 23-30 k, ranking + trie 4 k.  What is left in the select is the first counting pass: 10 k keys that
-// fall into a handful of bins are LDS atomics on a handful of addresses (privatised copies do not fit beside the keys).
+// (goldens, and ASR_BEAM_THREADS=256 against 512 in tests/test_gpu_ops.py).  And the candidates themselves are pruned by
+// (entry, class) PAIR, not only by class (step 2c in the kernel: entry j x class of rank r has (j + 1)(r - 1) candidates
+// strictly above it): ~W (ln W + 2) keys per frame instead of W (W + 1), 0.7 k instead of 10 k at W = 100 -- the select's
+// first counting pass had been 10 k LDS atomics on a handful of bins.  us per frame (scripts/probe_beam.py),
+// C = 3387 / W = 100: 69 -> 26 (flat and peaked posteriors); C = 62 / W = 20: 16.7 -> 12.0 / 11.3.  Cycles of a
+// C = 3387 / W = 100 frame now: log-softmax 8 k, stay candidates 8 k, class select 12 k, compaction 5 k, class ranks +
+// keys 15 k, top-W select 7 k, ranking + trie 5 k.
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -219,6 +221,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
   __shared__ unsigned sel_remaining;
   __shared__ int s_nw, s_nb, s_nodes;
   __shared__ int s_rank[BEAM_MAX];
+  __shared__ int cJ[NT], coff[NT + 1];               // entries enumerated per kept class / their first candidate (pruned frames)
+  __shared__ int s_mext;
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -399,9 +403,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
         // The threshold only has to be AT OR BELOW the R-th largest value (a class kept in vain costs W more candidates, a
         // class dropped in error would cost the result): the passes stop as soon as the bin the R-th largest falls into
         // holds at most W / 8 keys more than are still wanted -- the smallest key of that bin is the threshold
-        // (... as long as the frame's candidate keys still fit the LDS: nb (K + 1) <= lds_keys)
+        // (... as long as the kept classes still fit the pruned enumeration below, K <= NT, or else the dense one the LDS)
         const int fit = lds_keys / nb - 1 - R;
-        const unsigned slack = (unsigned)max(0, min(W >> 3, fit));
+        const unsigned slack = (unsigned)((R + (W >> 3) <= NT) ? (W >> 3) : max(0, min(W >> 3, fit)));
         unsigned rem = (unsigned)R;
         for (int byte = first_c; byte >= 0; --byte) {
           unsigned dgt, pop;
@@ -475,14 +479,62 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
     __syncthreads();
     const int K = s_K;
     BEAM_T(3);
-    // ---- 3. candidate keys: [0, nb) the stay candidates, nb + j K + ci the extension of entry j by kept class ci
-    //      (p_b = -inf, so total = p_nb contribution); 0 = excluded.  In LDS when they fit, else in the workspace.
-    const int M = nb + nb * K;
+    // ---- 2c. which (entry, class) pairs can still reach the top W.  The beam is sorted by L = logsumexp(p_b, p_nb)
+    //      (the rank order of the previous frame's select), so the extension of entry j by class c has at least
+    //      (j + 1) (r_c - 1) candidates STRICTLY above it, r_c = the kept classes whose log-probability exceeds lp_c by a
+    //      margin far above fp64 rounding: entries j' <= j (L_j' >= L_j) x those classes, less the one class per entry that
+    //      repeats its last label (its total uses p_b alone); a pair that merged into a beam prefix counts through that
+    //      prefix's stay candidate, whose total is at least the pair's.  With W or more above it a candidate cannot be among
+    //      the top W whatever the tie order, so class c is enumerated for the entries j < J_c only, J_c = nb for r_c <= 1 and
+    //      min(nb, (W - 1) / (r_c - 1)) otherwise: ~W (ln W + 2) candidates instead of W (W + 1) -- 0.7 k instead of 10 k at
+    //      W = 100.  (j = 0 gives back the class pruning above: r_c <= W.)  Frames that keep more classes than the
+    //      workgroup has threads (ties at the threshold) enumerate every pair: J_c = nb.
+    // (frames with at most four candidates per thread are not worth the three barriers of the bookkeeping)
+    const bool pruned = K > 0 && K <= NT && K <= lds_keys && nb * K > 4 * NT;
+    if (pruned) {
+      double* klp = reinterpret_cast<double*>(lkeys);      // (the key area is free until the keys are written)
+      if (tid < K) klp[tid] = lp[kc[tid]];
+      __syncthreads();
+      int mine = 0;
+      if (tid < K) {
+        const double x = klp[tid];
+        const double xm = x + 1e-9 * (1.0 + fabs(x));
+        int r = 0;
+#pragma unroll 8
+        for (int o = 0; o < K; ++o) r += klp[o] > xm ? 1 : 0;
+        mine = r <= 1 ? nb : min(nb, (W - 1) / (r - 1));
+        cJ[tid] = mine;
+      }
+      const int incl = (int)wave_incl_scan_u32((unsigned)mine);
+      if (lane == 63) wcnt[wave] = (unsigned)incl;
+      __syncthreads();                                      // (also: every klp read is done before the keys land there)
+      int pos = incl - mine;
+      for (int w = 0; w < wave; ++w) pos += (int)wcnt[w];
+      if (tid < K) coff[tid] = pos;
+      if (tid == K - 1) { coff[K] = pos + mine; s_mext = pos + mine; }
+      __syncthreads();
+    }
+    // ---- 3. candidate keys: [0, nb) the stay candidates, then class-major the extensions: nb + base(ci) + j = entry j
+    //      extended by kept class ci (p_b = -inf, so total = p_nb contribution); 0 = excluded.  In LDS when they fit, else
+    //      in the workspace.
+    const int M = nb + (pruned ? s_mext : nb * K);
+    auto cand_base = [&](int ci) -> int { return pruned ? coff[ci] : ci * nb; };
+    auto cand_cnt = [&](int ci) -> int { return pruned ? cJ[ci] : nb; };
+    auto cand_decode = [&](int e, int& ci, int& j) {
+      if (!pruned) { ci = e / nb; j = e - ci * nb; return; }
+      int lo = 0, hi = K;                                    // the last class whose first candidate is at or before e
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (coff[mid] <= e) lo = mid; else hi = mid;
+      }
+      ci = lo; j = e - coff[lo];
+    };
     // tie-break index of candidate id (needed for the winners, and where keys tie at the threshold)
     auto nidx_of = [&](int id) -> unsigned {
       if (id < nb) return s_idx[id];
-      const int e = id - nb, j = e / K;
-      return ~((unsigned)kc[e - j * K] * (2u * W) + 2u * j);
+      int ci, j;
+      cand_decode(id - nb, ci, j);
+      return ~((unsigned)kc[ci] * (2u * W) + 2u * j);
     };
     // (the tie index of a winner is computed by its own thread in the ranking step -- one division per winner in
     // parallel instead of one inside every divergent push)
@@ -492,21 +544,31 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
     };
     auto frame_tail = [&](unsigned long long* ck) __attribute__((always_inline)) {
       if (tid < nb) ck[tid] = s_key[tid];
-      {
-        const int Kd = K > 0 ? K : 1;                        // (K == 0: one class, or every non-blank probability NaN -- the loop below is empty)
-        int j = tid / Kd, ci = tid - j * Kd;
-        const int dj = NT / Kd, dci = NT - dj * Kd;
+      if (!pruned) {   // every pair: candidate e = ci nb + j, walked in strides of NT (K == 0: one class, or every
+                       // non-blank probability NaN -- the loop is empty)
+        int ci = tid / nb, j = tid - ci * nb;
+        const int dci = NT / nb, dj = NT - dci * nb;
         for (int e = tid; e < nb * K; e += NT) {
           const int c = kc[ci];
           ck[nb + e] = okey(((c == beam[j].last) ? beam[j].pb : s_L[j]) + lp[c]);
-          j += dj; ci += dci;
-          if (ci >= K) { ci -= K; ++j; }
+          ci += dci; j += dj;
+          if (j >= nb) { j -= nb; ++ci; }
+        }
+      } else {   // NT / 128 classes at a time, one thread per entry
+        const int j = tid & (BEAM_MAX - 1);
+        const int jlast = j < nb ? beam[j].last : -2;
+        const double jpb = j < nb ? beam[j].pb : 0.0, jL = j < nb ? s_L[j] : 0.0;
+#pragma unroll 2
+        for (int ci = tid / BEAM_MAX; ci < K; ci += NT / BEAM_MAX) {
+          const int c = kc[ci], cnt = cand_cnt(ci), base = cand_base(ci);
+          const double lpc = lp[c];
+          if (j < cnt) ck[nb + base + j] = okey((c == jlast ? jpb : jL) + lpc);
         }
       }
       __syncthreads();
       if (tid < nb && s_parent[tid] >= 0 && beam[tid].last != blank) {   // merged pairs are not new prefixes
         const int kp = kpos[beam[tid].last];
-        if (kp >= 0) ck[nb + s_parent[tid] * K + kp] = 0ull;
+        if (kp >= 0 && s_parent[tid] < cand_cnt(kp)) ck[nb + cand_base(kp) + s_parent[tid]] = 0ull;
       }
       if (tid == 0) { s_nw = 0; sel_key = 0; sel_nidx = 0; }
       __syncthreads();
@@ -699,7 +761,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(
           ne = beam[id];
           ne.pb = s_pb[id]; ne.pnb = s_pnb[id];
         } else {
-          const int e = id - nb, j = e / K, c = kc[e - j * K];
+          int ci, j;
+          cand_decode(id - nb, ci, j);
+          const int c = kc[ci];
           const Entry p = beam[j];
           ne.pb = DNEG; ne.pnb = unokey(k);                  // the key IS the total (order-preserving bijection)
           ne.phash = p.hash; ne.hash = hmix(p.hash, c);
@@ -775,9 +839,9 @@ extern "C" int asr_ctc_beam_decode(asr_handle* h, const float* logits, int T, in
   const size_t lds_c = (((size_t)C * (sizeof(double) + 2 * sizeof(int))) + 15) & ~(size_t)15;
   if (lds_c > 96 * 1024) ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_ctc_beam_decode: C=%d too large for LDS", C);
   // candidate keys in LDS: all of W (C - 1) + W when that fits, else what the pruned search needs in the common case
-  // (W (W + 2) + slack) up to the room left beside ~24 KB of static arrays; a frame with more candidates (ties at the
+  // (W (W + 2) + slack) up to the room left beside ~29 KB of static arrays; a frame with more candidates (ties at the
   // pruning threshold, flat posteriors) keeps that frame's keys in the workspace
-  const size_t room = (size_t)160 * 1024 - 26 * 1024 - lds_c;
+  const size_t room = (size_t)160 * 1024 - 30 * 1024 - lds_c;
   size_t nkeys = (size_t)beam_width * (C - 1) + beam_width;
   if (nkeys * 8 > room) nkeys = room / 8;
   const size_t lds = lds_c + nkeys * 8;

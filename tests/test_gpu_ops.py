@@ -1054,10 +1054,13 @@ def test_beam_search_batch_vs_oracle(cuda):
     """A ragged batch at TIMIT shape (C=62, beam 20) and a wide-vocabulary case against the oracle."""
     ops = _ops()
     rng = np.random.RandomState(3)
+    # (the last four: beams wide enough for the (entry, class) pruning of round 6 to bite -- W^2 candidates cut to
+    # ~W ln W -- on smooth, peaked-with-repeats, quantised (ties inside the pruning rule's margins) and near-flat posteriors)
     for (T, B, C, W, sharp) in [(60, 6, 62, 20, 3.0), (30, 3, 300, 10, 4.0), (25, 2, 29, 100, 2.0),
-                                (20, 2, 400, 8, 2.0)]:
+                                (20, 2, 400, 8, 2.0), (24, 2, 200, 50, 2.0), (24, 2, 201, 48, 1.0), (16, 2, 600, 64, 1.5),
+                                (20, 2, 150, 100, 0.05)]:
         logits = (rng.randn(T, B, C) * sharp).astype(np.float32)
-        if C == 400:   # coarse grid of values: many exact ties at the class-pruning threshold
+        if C in (400, 201):   # coarse grid of values: many exact ties at the class-pruning threshold
             logits = np.round(logits * 2) / 2
         logits[:, :, C - 1] += sharp
         for t in range(1, T):
