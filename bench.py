@@ -23,6 +23,8 @@ its compact form (compact_line: numbers only, <= 6 000 bytes, the driver keeps 8
   roofline               dominant kernel, HIP-event duration measured live in the timed region;
   cpu_baseline           oracle/fast_cpu.py port of the TF1 CPU path on a bounded sample, thread sweep, best reported;
 and, at N = 1, the other BASELINE configurations timed with the same harness (a few steps each):
+  headline_f32           the headline shard itself with fp32 operands (20 steps): throughput and oracle parity at the
+                         precision the north_star's 1e-4 / identical-labels statement is made at;
   cfgA                   configs[0] (TIMIT-39, 2x128, fp32): the configuration the 1e-4 fp32 loss tolerance is about;
   cfgC                   configs[2] VGG-BLSTM 4x512 CTC, B = 64;
   cfgD                   configs[3] 5x512 BLSTM joint CTC-attention (location), the per-GPU shard B = 32;
@@ -911,7 +913,7 @@ def compact_line(out, limit=COMPACT_LIMIT):
     c['kernels'] = {k: dict(calls=v.get('calls'), avg_us=v.get('avg_us')) for k, v in (out.get('kernels') or {}).items()}
     c['roofline'] = _compact_roofline(out.get('roofline'))
     c['cpu_baseline'] = _compact_cpu(out.get('cpu_baseline'))
-    for k in ('cfgA', 'cfgC', 'cfgD', 'cfgE', 'input_width_D39'):
+    for k in ('headline_f32', 'cfgA', 'cfgC', 'cfgD', 'cfgE', 'input_width_D39'):
         if out.get(k) is not None:
             c[k] = _compact_aux(out[k])
     if out.get('decode') is not None:
@@ -937,9 +939,10 @@ def compact_line(out, limit=COMPACT_LIMIT):
     c = _sig(c)
     line = json.dumps(c, separators=(',', ':'))
     # shed optional detail, least important first, until the line fits
-    for drop in (('decode',), ('batch_scaling',), ('input_width_D39',), ('per_rank',), ('h2d_inclusive',),
-                 ('other_padding',), ('cfgA', 'kernel_us'), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('cfgE', 'kernel_us'),
-                 ('cfgC', 'groups'), ('cfgE',), ('cfgD',), ('cfgC',), ('cfgA',), ('comm',)):
+    for drop in (('batch_scaling',), ('input_width_D39',), ('headline_f32', 'kernel_us'), ('headline_f32', 'cpu_baseline'),
+                 ('cfgA', 'kernel_us'), ('decode',), ('per_rank',), ('h2d_inclusive',),
+                 ('other_padding',), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('cfgE', 'kernel_us'),
+                 ('cfgC', 'groups'), ('headline_f32',), ('cfgE',), ('cfgD',), ('cfgC',), ('cfgA',), ('comm',)):
         if len(line) <= limit:
             break
         if len(drop) == 1:
@@ -1055,7 +1058,7 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-cfgA', action='store_true')
     ap.add_argument('--no-aux', action='store_true', help='skip cfgC / cfgD / cfgE / decode / input width / batch scaling')
-    ap.add_argument('--aux', default='cfgC,cfgD,cfgE,decode,D39,batch', help='which auxiliary entries to run (N = 1)')
+    ap.add_argument('--aux', default='f32,cfgC,cfgD,cfgE,decode,D39,batch', help='which auxiliary entries to run (N = 1)')
     ap.add_argument('--aux-steps', type=int, default=5)
     ap.add_argument('--aux-warmup', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=2)
@@ -1210,6 +1213,21 @@ def main():
                 log('%s skipped: time budget' % name)
                 return True
             return False
+        if 'f32' in aux and wl['dtype'] != 'f32' and not over_budget('headline_f32'):
+            # the headline workload itself in fp32 operands (the three-term recurrence kernels at H = 256): the north_star's
+            # parity statement -- loss <= 1e-4 of the oracle, label indices identical -- is an fp32 statement, the headline
+            # `value` is bf16; this is what the same shard costs at the precision the statement is made at
+            log('headline workload in fp32 ...')
+            wf = dict(wl, dtype='f32')
+            try:
+                rf = run_blstm_ctc(args, wf, dev, 1, 0, dev_index, 20, 5, want_parity=not args.no_parity, want_h2d=False,
+                                   want_cpu=False)
+                out['headline_f32'] = blstm_ctc_entry(args, wf, rf, 20, 'the headline shard (5x%d BLSTM-CTC, B=%d) with fp32 '
+                                                      'operands' % (wl['units'], wl['batch']))
+                del rf
+            except Exception as e:
+                out['headline_f32'] = dict(error=repr(e)[:400])
+            torch.cuda.empty_cache()
         for name, fn in (('cfgC', lambda: run_cfgC(args, dev, dev_index)),
                          ('cfgD', lambda: run_attention_cfg(args, dev, dev_index, 'D')),
                          ('cfgE', lambda: run_attention_cfg(args, dev, dev_index, 'E')),

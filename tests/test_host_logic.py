@@ -1028,6 +1028,15 @@ def test_bench_compact_line_fits_the_drivers_window():
         elif isinstance(o, str):
             yield o
     assert max(len(s) for s in strings(d)) <= 160
+    # round 6's object with the fp32 run of the headline shard added: the new entry keeps its value and parity numbers, the
+    # decode figures stay on the line (the input-width / batch-size extras are what gives way first)
+    r6 = json.load(open(os.path.join(root, 'profiles', 'r06_bench_default.json')))
+    r6['headline_f32'] = dict(r6['cfgA'], workload='the headline shard with fp32 operands', value=5.1e5, ms_per_step=12.5)
+    l6 = bench.compact_line(dict(r6, full='bench_full.json'))
+    d6 = json.loads(l6)
+    assert len(l6) < 6000 and d6['headline_f32']['value'] == 5.1e5
+    assert d6['headline_f32']['parity']['greedy_label_mismatch'] == r6['cfgA']['parity']['greedy_label_mismatch']
+    assert d6['decode']['kanji3387_beam100']['beam']['ms_per_call'] > 0 and d6['cfgE']['value'] > 0
     # N = 8: per-rank tables and the communication summary ride on the same line
     multi = dict(full, n_gpus=8, per_rank=dict(step_median_ms=[9.31] * 8, frames=[6400.0 + i for i in range(8)],
                                                elapsed_s=[0.1871234] * 8, comm_stream_allreduce_ms_per_step=[0.71] * 8),
