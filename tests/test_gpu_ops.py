@@ -1442,3 +1442,32 @@ def test_beam_search_thread_counts_agree(cuda, monkeypatch):
         assert np.array_equal(out['256'][1], out['512'][1]), (T, B, C, W, kind)
         assert np.array_equal(out['256'][0], out['512'][0]), (T, B, C, W, kind)
         assert np.abs(out['256'][2] - out['512'][2]).max() < 1e-9 * max(1.0, np.abs(out['256'][2]).max())
+
+
+def test_beam_search_edge_inputs_against_the_oracle(cuda):
+    """Prefix beam search on inputs at the edges of its bookkeeping: width 1 and the maximum width 128, two classes,
+    constant logits (every candidate of a frame ties: the insertion order alone decides), classes masked with -inf, an empty
+    and a one-frame utterance in the batch -- labels identical to oracle.decoders.beam_search_decode."""
+    ops = _ops()
+    rng = np.random.RandomState(21)
+    cases = []
+    for T, B, C, W in ((12, 3, 2, 1), (10, 2, 5, 128), (9, 2, 40, 128), (14, 3, 30, 7), (8, 2, 700, 100)):
+        cases.append((rng.randn(T, B, C).astype(np.float32) * 2, W, 'random'))
+    cases.append((np.zeros((10, 2, 12), np.float32), 16, 'constant'))
+    cases.append((np.zeros((6, 2, 300), np.float32), 64, 'constant wide'))
+    masked = rng.randn(12, 3, 50).astype(np.float32)
+    masked[:, :, 5:30] = -np.inf
+    cases.append((masked, 20, 'masked'))
+    for logits, W, kind in cases:
+        T, B, C = logits.shape
+        sl = np.full(B, T, np.int32)
+        sl[-1] = 1
+        if B > 2:
+            sl[1] = 0
+        lab, n, score = ops.ctc_beam_decode(torch.tensor(logits, device=cuda), torch.tensor(sl, device=cuda), W)
+        lp = octc.log_softmax(logits.astype(np.float64).transpose(1, 0, 2))
+        ref, rs = odec.beam_search_decode(lp, sl, C - 1, W)
+        for b in range(B):
+            assert lab[b, :int(n[b])].cpu().tolist() == ref[b], (kind, T, C, W, b)
+            if sl[b] > 0:
+                assert abs(score[b].item() - rs[b]) < 1e-7 * max(1, abs(rs[b])), (kind, b)
