@@ -259,8 +259,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, in
   const int rgp = threadIdx.x >> 6;
   const int r0 = blockIdx.y * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
   float s = 0.f;
-  if (col < N)
+  if (col < N) {
+#pragma unroll 8                                           // eight rows requested ahead of the (ordered) additions
     for (int m = r0 + rgp; m < r1; m += 4) s += Elem<T>::to_f32(a[(size_t)m * lda + col]);
+  }
   part[rgp][threadIdx.x & 63] = s;
   __syncthreads();
   if (rgp == 0 && col < N)
@@ -299,6 +301,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int RB, i
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= N) return;
   float s = 0.f;
+#pragma unroll 8
   for (int r = 0; r < RB; ++r) s += partial[(size_t)r * N + col];
   out[col] = s;
 }
