@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restr
   const int64_t beg = offsets[lo] + (cid - chunk_start[lo]) * NORM_CHUNK;
   const int64_t end = min(beg + (int64_t)NORM_CHUNK, offsets[lo + 1]);
   float s = 0.f;
+#pragma unroll 8                                           // (NORM_CHUNK / 256 = 16 elements per thread: the loads ahead of the ordered sum)
   for (int64_t i = beg + threadIdx.x; i < end; i += 256) { const float v = g[i]; s += v * v; }
   s = wave_reduce_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
