@@ -502,6 +502,27 @@ __global__ void conv3x3_smallc_wgrad_reduce_kernel(const float* __restrict__ par
   else dbias[i - K * SC_CO] = s;                            // row K: the ones column of the matrix-core kernel
 }
 
+// First of two passes for many partials (round 6: 2048 workgroups leave 16.8 MB, and seven blocks walking all of them row by
+// row took 0.11 ms alone and 2 ms beside the other weight-gradient kernels at the end of a cfg C step): block (x, seg) sums
+// rows [seg SEGR, (seg + 1) SEGR) of 256 columns in row order -> stage[seg][2048]; the pass above then adds the segment sums
+// in segment order.  Fixed order, deterministic (the grouping differs from one sequential sum).
+constexpr int SC_SEGR = 64;
+__global__ __launch_bounds__(256) void conv3x3_smallc_wgrad_stage_kernel(const float* __restrict__ partial, int nblk,
+                                                                         int ncols, float* __restrict__ stage) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * SC_SEGR, r1 = min(nblk, r0 + SC_SEGR);
+  if (i >= ncols) return;
+  float s = 0.f;
+  for (int b0 = r0; b0 < r1; b0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = (b0 + q < r1) ? partial[(size_t)(b0 + q) * SC_K * SC_CO + i] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += v[q];
+  }
+  stage[(size_t)blockIdx.y * SC_K * SC_CO + i] = s;
+}
+
 // Pooling backward, dropout on the pooled gradient and the ReLU backward of the convolution below the pool in ONE pass,
 // written in the operand dtype:  dpre[n,h,w,c] = (act > 0 && arg[o] == k) ? dout[o] * mask(o) : 0,  o = the pooled cell.
 // Separately (asr_dropout_apply -> asr_maxpool2x2_bwd -> asr_relu_bwd) the full-resolution fp32 gradient is written and
@@ -770,9 +791,11 @@ static int smallc_bwd_weight_impl(asr_handle* h, const void* x, const void* dpre
   per = (per + 63) / 64 * 64;
   nblk = (int)((npix + per - 1) / per);
   if (nblk < 1) nblk = 1;
-  const size_t need = (size_t)nblk * SC_K * SC_CO * sizeof(float);
+  const int nseg = (nblk + SC_SEGR - 1) / SC_SEGR;
+  const size_t need = ((size_t)nblk + nseg) * SC_K * SC_CO * sizeof(float);
   if (need > h->scratch_bytes - ASR_XCH_BYTES) ASR_FAIL(h, ASR_ERR_WORKSPACE, "asr_conv3x3_smallc_bwd_weight: scratch too small");
   float* partial = (float*)h->scratch;
+  float* stage = partial + (size_t)nblk * SC_K * SC_CO;
 #define ASR_SC_WG(C_) \
   hipLaunchKernelGGL(conv3x3_smallc_wgrad_kernel<C_>, dim3(nblk), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, \
                      (const bf16_t*)dpre, npix, H, W, per, partial)
@@ -786,8 +809,16 @@ static int smallc_bwd_weight_impl(asr_handle* h, const void* x, const void* dpre
 #undef ASR_SC_WG
   static const bool wbias_on = [] { const char* e = getenv("ASR_CONV_WGRAD_BIAS"); return !(e && e[0] == '0'); }();
   float* inb = (dbias && mfma && wbias_on) ? dbias : nullptr;      // bias gradient = row 9 Cin of the matrix-core kernel's product
-  hipLaunchKernelGGL(conv3x3_smallc_wgrad_reduce_kernel, dim3(((9 * Cin + 1) * SC_CO + 255) / 256), dim3(256), 0,
-                     (hipStream_t)s, partial, nblk, 9 * Cin, dw, inb);
+  const int ncols = (9 * Cin + 1) * SC_CO;
+  if (nblk > 2 * SC_SEGR) {                                 // many partials: segment sums first
+    hipLaunchKernelGGL(conv3x3_smallc_wgrad_stage_kernel, dim3((ncols + 255) / 256, nseg), dim3(256), 0, (hipStream_t)s,
+                       partial, nblk, ncols, stage);
+    hipLaunchKernelGGL(conv3x3_smallc_wgrad_reduce_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)s, stage,
+                       nseg, 9 * Cin, dw, inb);
+  } else {
+    hipLaunchKernelGGL(conv3x3_smallc_wgrad_reduce_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)s, partial,
+                       nblk, 9 * Cin, dw, inb);
+  }
   ASR_CHECK_LAUNCH(h, "asr_conv3x3_smallc_bwd_weight");
   if (dbias && !inb) return asr_colsum(h, ASR_BF16, dpre, (int)npix, Cout, Cout, dbias, s);
   return ASR_OK;

@@ -1173,10 +1173,11 @@ def test_gemm_with_the_dropout_mask_formed_in_its_epilogue(cuda, M, N, K, dt):
     assert torch.equal(got, ref) and float(got.abs().sum()) > 0
 
 
-@pytest.mark.parametrize('N,H,W,Cin', [(3, 40, 11, 3), (70, 5, 3, 3), (2, 7, 6, 2), (1, 1, 1, 3)])
+@pytest.mark.parametrize('N,H,W,Cin', [(3, 40, 11, 3), (70, 5, 3, 3), (2, 7, 6, 2), (1, 1, 1, 3), (700, 40, 11, 3)])
 def test_direct_convolution_of_the_few_channel_first_layer(cuda, N, H, W, Cin):
     """asr_conv3x3_smallc_fwd / _bwd_weight (no patch matrix) against fp64 conv2d on the bf16-rounded operands: the
-    cfg C image 40 x 11 x 3, odd sizes, more pixels than one weight-gradient slice, a single pixel."""
+    cfg C image 40 x 11 x 3, odd sizes, more pixels than one weight-gradient slice, a single pixel, and enough pixels
+    (308 k: 151 workgroup partials) for the two-pass sum of the partials."""
     ops = _ops()
     rng = np.random.RandomState(N + H * W)
     Cout = 64
