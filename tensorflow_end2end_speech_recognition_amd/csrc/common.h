@@ -142,5 +142,10 @@ bool asr_cluster_bwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const
                              const int32_t* seq_len, const float* dcf, const float* dhf, void* dgates,
                              float* dpeep_part, hipStream_t st);
 
+// GRU forward on clusters (lstm_cluster.hip: the exchange machinery lives there); false = not applicable
+bool asr_cluster_gru_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* xg, const float* xc,
+                             const float* wgh, const float* wch, const int32_t* seq_len, float* r, float* u, float* c,
+                             float* rh, float* hout, float* h_final, hipStream_t st);
+
 static inline int asr_dtype_ok(int dt) { return dt == ASR_F32 || dt == ASR_BF16; }
 static inline size_t asr_dtype_size(int dt) { return dt == ASR_BF16 ? 2 : 4; }

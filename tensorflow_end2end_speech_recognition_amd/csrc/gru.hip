@@ -500,6 +500,11 @@ extern "C" int asr_gru_fwd(asr_handle* h, int T, int B, int H, int ndir, const f
   (void)hipFuncSetAttribute((const void*)gru_cand_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const size_t sn = (size_t)ndir * B * H;
   float* hs[2] = {hstate2, hstate2 + sn};
+  // H = 128 / 256: clusters of H / 32 CUs with the recurrent blocks in registers (lstm_cluster.hip), final state in hs[0]
+  if (asr_cluster_gru_fwd_try(h, T, B, H, ndir, xg, xc, wgh, wch, seq_len, r, u, c, rh, hout, hs[0], st)) {
+    ASR_CHECK_LAUNCH(h, "asr_gru_fwd(cluster)");
+    return ASR_OK;
+  }
   if (gru_persistent_ok(h, H, ndir, (size_t)3 * 16 * (H + 4) * sizeof(float))) {
     // frames [tmax, T) of the output are beyond every utterance: zero
     if (T > tmax && hipMemsetAsync(hout + (size_t)tmax * B * ndir * H, 0, (size_t)(T - tmax) * B * ndir * H * sizeof(float), st) != hipSuccess)

@@ -1747,6 +1747,227 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster_f32s_kernel(
   }
 }
 
+// ---------------------------------------------------------------- GRU forward on a cluster (round 6)
+// tf.contrib.rnn.GRUCell (models/encoders/core/gru.py:58-76):  [r | u] = sigmoid(xg + h W_gh),  c = tanh(xc + (r * h) W_ch),
+// h' = u h + (1 - u) c -- TWO dependent products per step, so two all-gathers: r * h between them, h' behind the second.
+// The single-CU persistent kernel (gru.hip) streams both recurrent blocks from L2 every step and multiplies on the fp32 MFMA:
+// 11.7 us of matrix work + the weight trips per step at H = 256.  Here the cluster machinery of lstm_fwd_cluster_f32s_kernel:
+// H / 32 CUs per (direction, 16-utterance tile), four waves x 8 units, the CU's slices of W_gh ([H] x [r | u of its units])
+// and W_ch as three-bf16-term fragments in registers for the whole launch, h and r * h as three-term LDS images, both
+// exchanges in 8-byte self-tagged granules {hi | mid << 16, lo | tag << 16}.  Phase 1 is one 16-column tile per wave
+// ([r x 8 | u x 8], halves swapped over DPP as in the LSTM kernels), phase 2 one tile whose upper eight columns repeat the
+// lower ones (a 16-column MFMA for 8 units: the lanes col >= 8 read rows 2, 3 of the same unit from their own copy).
+// Saved activations r, u, c, r * h at the frame a row worked on; rows past their length store nothing but hout's zero
+// and keep h (their x loads are parked on a valid frame).  Same fp32-level arithmetic as the f32s LSTM kernels (six exact bf16 products per k = 32 chunk).
+__device__ __forceinline__ float gru_sig(float x) { return 1.0f / (1.0f + expf(-x)); }
+template <int H>
+__global__ __launch_bounds__(256, 1) void gru_fwd_cluster_kernel(
+    int T_, int B_, int ndir, const float* __restrict__ xg, const float* __restrict__ xc, const float* __restrict__ wgh,
+    const float* __restrict__ wch, const int32_t* __restrict__ seq_len, float* __restrict__ r_out, float* __restrict__ u_out,
+    float* __restrict__ c_out, float* __restrict__ rh_out, float* __restrict__ hout, float* __restrict__ h_final,
+    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+  zero_next_area(znext, zwords);
+  constexpr int HSU = 32, G = H / HSU;
+  constexpr int KS = H / 32;
+  constexpr int LDH = H + 8;                               // bf16 elements per image row
+  constexpr int PLB = 16 * LDH * 2;                        // bytes of one term image
+  constexpr int SLICE = 16 * HSU;                           // granules one CU publishes per exchange and step
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [h parity 0][h parity 1][r * h], three term images each
+
+  const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
+  if (!cid.valid) return;
+  const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rg = lane >> 4;
+  const bool lo = col < 8;
+  const bool rev = (d == 1);
+  const int ul = wave * 8 + (col & 7);                     // unit inside this CU's slice
+  const unsigned jw = g * HSU + ul;                         // global unit of this lane
+  const int rbase = rg * 4 + (lo ? 0 : 2);                 // first of this lane's two batch rows
+
+  int len[2];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) len[r] = min(max(seq_len[b0 + rbase + r], 0), T_);
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  for (int i = threadIdx.x; i < 3 * 3 * 16 * LDH; i += 256) reinterpret_cast<unsigned short*>(smem)[i] = 0;
+  // B fragments straight from the row-major recurrent blocks: lane (column col, k-group rg) of chunk ks holds
+  // W[32 ks + 8 rg + j][column], j < 8, split into three bf16 terms.  Phase 1: column = gate (col >> 3) of unit jw;
+  // phase 2: unit jw (both halves of the tile).
+  bf16x8_t w1[KS][3], w2[KS][3];
+  {
+    const float* wg = wgh + (size_t)d * H * 2 * H + (size_t)(col >> 3) * H + jw;
+    const float* wc = wch + (size_t)d * H * H + jw;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * ks + 8 * rg + j;
+        unsigned short t1[3], t2[3];
+        split3(wg[(size_t)k * 2 * H], t1);
+        split3(wc[(size_t)k * H], t2);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { w1[ks][q][j] = (short)t1[q]; w2[ks][q][j] = (short)t2[q]; }
+      }
+  }
+
+  u64* xhdr = xch + (size_t)cid.c * (XHDR + 4 * G * SLICE);
+  u64* xa = xhdr + XHDR;                                   // r * h: [2 parity][G][SLICE]
+  u64* xb = xa + 2 * G * SLICE;                            // h':    [2 parity][G][SLICE]
+  bool timed_out = false;
+  const bool colocated = same_xcd<G>(xhdr, g, timed_out);
+  const bool fast = colocated && !(kflags & 1);
+  unsigned spin_limit = (kflags & 2) ? 2000u : SPIN_LIMIT;
+  if ((kflags & 2) && g == G - 1) return;                  // TEST ONLY: a member goes missing
+  __syncthreads();
+
+  const unsigned stride = (unsigned)B_ * ndir * H;
+  const unsigned dstep = rev ? 0u - stride : stride;
+  unsigned oa[2], os[2], opark[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    os[r] = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+    oa[r] = os[r] + (rev ? (unsigned)max(len[r] - 1, 0) * stride : 0u);
+    opark[r] = os[r] + (unsigned)max(tmax - 1, 0) * stride;
+  }
+  const unsigned pofs = (unsigned)(wave * 128 + rbase * 8 + (col & 7));
+  const unsigned lofs = (unsigned)(wave * 128 + lane);
+  unsigned ldst[G - 1][2];
+#pragma unroll
+  for (int k = 0; k < G - 1; ++k) {
+    const int gsrc = k + (k >= g ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 8 + (lane >> 3);
+      ldst[k][j] = ((unsigned)(row * LDH + gsrc * HSU + wave * 8 + (lane & 7)) * 2u) ^ lds_swz(row);
+    }
+  }
+  unsigned lown[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) lown[r] = ((unsigned)((rbase + r) * LDH + g * HSU + ul) * 2u) ^ lds_swz(rbase + r);
+  const unsigned lrd = ((unsigned)(col * LDH + rg * 8) * 2u) ^ lds_swz(col);
+  auto put3w = [&](char* img, unsigned off, unsigned w0, unsigned w1v) {
+    *reinterpret_cast<unsigned short*>(img + off) = (unsigned short)w0;
+    *reinterpret_cast<unsigned short*>(img + PLB + off) = (unsigned short)(w0 >> 16);
+    *reinterpret_cast<unsigned short*>(img + 2 * PLB + off) = (unsigned short)w1v;
+  };
+  auto product = [&](const char* img, const bf16x8_t (&w)[KS][3]) -> f32x4_t {
+    bf16x8_t afr[KS][3];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) afr[ks][q] = *reinterpret_cast<const bf16x8_t*>(img + q * PLB + lrd + ks * 64);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = mma_s3(afr[ks], w[ks], acc);
+    return acc;
+  };
+  // publish this lane's two (row, unit) values into slice g of `area`, stage them into `img`; then collect the peers' slices
+  auto exchange = [&](u64* area, int P, unsigned epoch, const float (&val)[2], char* img) {
+    u64* mine = area + ((size_t)P * G + g) * SLICE;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned short t3[3];
+      split3(val[r], t3);
+      const unsigned w0 = (unsigned)t3[0] | ((unsigned)t3[1] << 16);
+      gpublish(uoff(mine, pofs + 8u * r), ((unsigned)t3[2]) | (epoch << 16), w0, fast);
+      put3w(img, lown[r], w0, (unsigned)t3[2]);
+    }
+    u64 v[G - 1][2];
+#pragma unroll
+    for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) v[k][j] = gload(uoff(area + ((size_t)P * G + k + (k >= g ? 1 : 0)) * SLICE, lofs + 64u * j));
+    unsigned spins = 0;
+#pragma unroll 1
+    for (;;) {                                             // wave-uniform loop: no exec masking
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ok = ok && ((unsigned)(v[k][j] >> 48) == (epoch & 0xffffu));
+      if (__all(ok)) break;
+      if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) v[k][j] = gload(uoff(area + ((size_t)P * G + k + (k >= g ? 1 : 0)) * SLICE, lofs + 64u * j));
+    }
+#pragma unroll
+    for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) put3w(img, ldst[k][j], (unsigned)v[k][j], (unsigned)(v[k][j] >> 32));
+  };
+
+  float hr[2] = {0.f, 0.f};
+  char* rhimg = smem + 2 * 3 * PLB;
+  for (int s = 0; s < tmax; ++s) {
+    const int P = s & 1;
+    const char* hcur = smem + P * 3 * PLB;
+    char* hnxt = smem + (1 - P) * 3 * PLB;
+    const unsigned epoch = (unsigned)s + 1u;
+    bool act[2];
+    float xr[2], xu[2], xcv[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                          // requested ahead of the first product
+      act[r] = s < len[r];
+      const unsigned o = act[r] ? oa[r] : opark[r];
+      const unsigned og = (o - jw) * 2u + jw;              // the same (frame, row, direction) in the [.., 2H] gate tensor
+      xr[r] = xg[og];
+      xu[r] = xg[og + H];
+      xcv[r] = xc[o];
+    }
+    // ---- phase 1: [r | u] = sigmoid(xg + h W_gh)
+    const f32x4_t a1 = product(hcur, w1);
+    float rv[2], uv[2], rhv[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float pr = dpp_ror8_into<0xC>(a1[r], a1[2 + r]);
+      const float pu = dpp_ror8_into<0x3>(a1[2 + r], a1[r]);
+      rv[r] = gru_sig(pr + xr[r]);
+      uv[r] = gru_sig(pu + xu[r]);
+      rhv[r] = rv[r] * hr[r];
+    }
+    exchange(xa, P, epoch, rhv, rhimg);
+    __syncthreads();                                       // r * h complete in LDS
+    // ---- phase 2: c = tanh(xc + (r h) W_ch), h' = u h + (1 - u) c
+    const f32x4_t a2 = product(rhimg, w2);
+    float cv[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float pc = lo ? a2[r] : a2[2 + r];
+      cv[r] = tanhf(pc + xcv[r]);
+      const float hn = uv[r] * hr[r] + (1.f - uv[r]) * cv[r];
+      hr[r] = act[r] ? hn : hr[r];
+    }
+    exchange(xb, P, epoch, hr, hnxt);
+    // saved activations behind the poll loop; a row past its length writes a zero into frame s of hout's padding and
+    // nothing else (r * h is contracted over ALL T * B rows by the weight-gradient GEMM: the caller's zeros must stay)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      hout[act[r] ? oa[r] : os[r]] = act[r] ? hr[r] : 0.f;
+      if (act[r]) {
+        const unsigned o = oa[r];
+        r_out[o] = rv[r];
+        u_out[o] = uv[r];
+        c_out[o] = cv[r];
+        rh_out[o] = rhv[r];
+      }
+      oa[r] += dstep;
+      os[r] += stride;
+    }
+    __syncthreads();                                       // h' complete in LDS; r * h free again
+  }
+  if (timed_out) atomicOr(err, 1u);
+  for (int t = tmax; t < T_; ++t)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { hout[os[r]] = 0.f; os[r] += stride; }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) h_final[((size_t)d * B_ + b0 + rbase + r) * H + jw] = hr[r];
+}
+
 // BPTT, fp32 operands: the H = 512 arrangement of the bf16 kernel (each tile computed ONCE: the hh = 0 waves take the
 // four own-unit tiles and hand rows 2,3 to their hh = 1 partners through LDS, the hh = 1 waves take the four tiles of
 // the peer's units and publish them) -- 64 K = 4 MFMAs per wave and step instead of the 128 + 64 of the redundant form.
@@ -2956,6 +3177,33 @@ static bool cluster_bwd_f32_launch(asr_handle* h, int T, int B, int ndir, const 
   hipLaunchKernelGGL((lstm_bwd_cluster_f32_kernel<HH, HSU>), dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir,
                      dhout, (const f32x4_t*)gates, cs, (const float*)whpb, peep, seq_len, dcf, dhf, (f32x4_t*)dgates,
                      dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
+  return true;
+}
+
+// GRU forward on clusters of H / 32 CUs (H = 128 / 256; B a multiple of 16).  ASR_GRU_CLUSTER=0 keeps the single-CU
+// persistent kernel (A/B, and the tests run both).  false = not applicable, nothing launched.
+bool asr_cluster_gru_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* xg, const float* xc,
+                             const float* wgh, const float* wch, const int32_t* seq_len, float* r, float* u, float* c,
+                             float* rh, float* hout, float* h_final, hipStream_t st) {
+  const char* env_c = getenv("ASR_GRU_CLUSTER");          // (read per call: the A-B test flips it inside one process)
+  if ((env_c && env_c[0] == '0') || !cluster_f32_enabled() || (H != 128 && H != 256) || T < 1 || T >= 65536) return false;
+  const int G = H / 32, ncl = (B / 16) * ndir;
+  const size_t need = (size_t)ncl * (XHDR + (size_t)4 * G * 16 * 32) * sizeof(u64);
+  if ((size_t)T * B * ndir * 2 * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
+      (int)cluster_grid(G, ncl) > h->num_cu)
+    return false;
+  char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+  const XchAreas xa = xch_take(h, base, need, st);
+  const size_t lds = (size_t)3 * 3 * 16 * (H + 8) * 2;
+#define ASR_GRU_CL(HH)                                                                                              \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(gru_fwd_cluster_kernel<HH>, dim3(cluster_grid(HH / 32, ncl)), dim3(256), lds, st, T, B, ndir, xg, xc, \
+                       wgh, wch, seq_len, r, u, c, rh, hout, h_final, xa.area, (unsigned*)base, kernel_flags(), xa.znext, \
+                       xa.zwords);                                                                                   \
+  } while (0)
+  if (H == 128) ASR_GRU_CL(128); else ASR_GRU_CL(256);
+#undef ASR_GRU_CL
   return true;
 }
 

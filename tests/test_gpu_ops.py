@@ -1472,3 +1472,35 @@ def test_beam_search_edge_inputs_against_the_oracle(cuda):
             assert lab[b, :int(n[b])].cpu().tolist() == ref[b], (kind, T, C, W, b)
             if sl[b] > 0:
                 assert abs(score[b].item() - rs[b]) < 1e-7 * max(1, abs(rs[b])), (kind, b)
+
+
+@pytest.mark.parametrize('H,B,T,ndir', [(128, 16, 40, 2), (256, 16, 40, 2), (256, 32, 33, 1), (128, 48, 21, 2)])
+def test_gru_cluster_forward_matches_the_single_cu_kernel(cuda, monkeypatch, H, B, T, ndir):
+    """asr_gru_fwd on clusters of H / 32 CUs (three-bf16-term products, two exchanges per step) against the single-CU
+    persistent kernel (exact-fp32 MFMA; ASR_GRU_CLUSTER=0): r, u, c, r * h at every frame a row worked on, hout everywhere
+    (zero past a row's length), the final state; ragged lengths incl. an empty row; no hand-off flag raised."""
+    ops = _ops()
+    rng = np.random.RandomState(H + B + T)
+    xg = torch.tensor(rng.randn(T, B, ndir * 2 * H) * 0.5, dtype=torch.float32, device=cuda)
+    xc = torch.tensor(rng.randn(T, B, ndir * H) * 0.5, dtype=torch.float32, device=cuda)
+    wgh = torch.tensor(rng.randn(ndir, H, 2 * H) * 0.08, dtype=torch.float32, device=cuda)
+    wch = torch.tensor(rng.randn(ndir, H, H) * 0.08, dtype=torch.float32, device=cuda)
+    sl_np = rng.randint(1, T + 1, size=B).astype(np.int32)
+    sl_np[0] = T
+    if B > 16:
+        sl_np[17] = 0
+    sl = torch.tensor(sl_np, device=cuda)
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('ASR_GRU_CLUSTER', mode)
+        out[mode] = {k: v.cpu().numpy() for k, v in ops.gru_fwd(xg, xc, wgh, wch, sl, T, H, ndir).items()}
+    monkeypatch.delenv('ASR_GRU_CLUSTER')
+    assert ops.check_async_errors(0) == 0
+    valid = (np.arange(T)[:, None] < sl_np[None, :])[:, :, None]                  # [T,B,1]
+    for k in ('r', 'u', 'c', 'rh', 'hout'):                                       # (r, u, c past a row's length: unspecified)
+        a, b = out['0'][k], out['1'][k]
+        assert np.abs(np.where(valid, a - b, 0.0)).max() < 3e-6, k
+        assert np.isfinite(np.where(valid, b, 0.0)).all(), k
+    assert np.abs(np.where(valid, 0.0, out['1']['hout'])).max() == 0.0
+    assert np.abs(np.where(valid, 0.0, out['1']['rh'])).max() == 0.0             # the caller's zeros are left alone
+    assert np.abs(out['0']['h_final'] - out['1']['h_final']).max() < 3e-6
