@@ -147,5 +147,9 @@ bool asr_cluster_gru_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const
                              const float* wgh, const float* wch, const int32_t* seq_len, float* r, float* u, float* c,
                              float* rh, float* hout, float* h_final, hipStream_t st);
 
+bool asr_cluster_gru_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* dout, const float* d_h_final,
+                             const float* hout, const float* r, const float* u, const float* c, const float* wghT,
+                             const float* wchT, const int32_t* seq_len, float* dgate, float* dcand, hipStream_t st);
+
 static inline int asr_dtype_ok(int dt) { return dt == ASR_F32 || dt == ASR_BF16; }
 static inline size_t asr_dtype_size(int dt) { return dt == ASR_BF16 ? 2 : 4; }

@@ -558,6 +558,11 @@ extern "C" int asr_gru_bwd(asr_handle* h, int T, int B, int H, int ndir, const f
   if (hipMemsetAsync(dgate, 0, (size_t)T * B * ndir * 2 * H * sizeof(float), st) != hipSuccess ||
       hipMemsetAsync(dcand, 0, (size_t)T * B * ndir * H * sizeof(float), st) != hipSuccess)
     ASR_FAIL(h, ASR_ERR_HIP, "asr_gru_bwd: memset");
+  // H = 128 / 256: clusters of H / 32 CUs (lstm_cluster.hip)
+  if (asr_cluster_gru_bwd_try(h, T, B, H, ndir, dout, d_h_final, hout, r, u, c, wghT, wchT, seq_len, dgate, dcand, st)) {
+    ASR_CHECK_LAUNCH(h, "asr_gru_bwd(cluster)");
+    return ASR_OK;
+  }
   if (d_h_final) {
     if (hipMemcpyAsync(dh_rec, d_h_final, sn * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
       ASR_FAIL(h, ASR_ERR_HIP, "asr_gru_bwd: copy");

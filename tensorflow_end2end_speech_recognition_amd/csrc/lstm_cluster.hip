@@ -1968,6 +1968,235 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_cluster_kernel(
   for (int r = 0; r < 2; ++r) h_final[((size_t)d * B_ + b0 + rbase + r) * H + jw] = hr[r];
 }
 
+// GRU backward through time on the same clusters, as two ALL-GATHERS per step (not the LSTM BPTT's reduce-scatter of fp32
+// partials): a CU owns the dh of its 32 units, so it needs every unit's pre-activation gradients and the rows of W^T that
+// lead to its units --
+//     dh = dout[frame] + dh_rec;  du_pre = dh (hp - c) u (1 - u);  dc_pre = dh (1 - u)(1 - c^2);  acc = dh u      (own units)
+//     gather dc_pre, du_pre;      d(rh) = dc_pre W_c^T [own units];  dr_pre = d(rh) hp r (1 - r);  acc += d(rh) r
+//     gather dr_pre;              dh_rec' = acc + [dr_pre | du_pre] W_g^T [own units]
+// with W_c^T / W_g^T columns of the CU's units as three-term fragments in registers (three sets), the gathered gradients
+// as three-term LDS images (dc_pre and du_pre double-buffered by step parity: two barriers per step), saved activations and
+// dout requested one step ahead.  dgate / dcand are written for active rows only (the caller zeroes them).
+template <int H>
+__global__ __launch_bounds__(256, 1) void gru_bwd_cluster_kernel(
+    int T_, int B_, int ndir, const float* __restrict__ dout, const float* __restrict__ d_h_final,
+    const float* __restrict__ hout, const float* __restrict__ r_in, const float* __restrict__ u_in,
+    const float* __restrict__ c_in, const float* __restrict__ wghT, const float* __restrict__ wchT,
+    const int32_t* __restrict__ seq_len, float* __restrict__ dgate, float* __restrict__ dcand, u64* __restrict__ xch,
+    unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+  zero_next_area(znext, zwords);
+  constexpr int HSU = 32, G = H / HSU;
+  constexpr int KS = H / 32;
+  constexpr int LDH = H + 8;
+  constexpr int PLB = 16 * LDH * 2;
+  constexpr int IMG = 3 * PLB;                             // one gathered vector: three term images
+  constexpr int SLICE = 16 * HSU;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [dc_pre P0][dc_pre P1][du_pre P0][du_pre P1][dr_pre]
+
+  const ClusterId cid = cluster_id<G>(ndir, B_ / 16);
+  if (!cid.valid) return;
+  const int g = cid.g, d = cid.d, b0 = cid.tile * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rg = lane >> 4;
+  const bool lo = col < 8;
+  const bool rev = (d == 1);
+  const int ul = wave * 8 + (col & 7);
+  const unsigned jw = g * HSU + ul;
+  const int rbase = rg * 4 + (lo ? 0 : 2);
+
+  int len[2];
+  int tmax = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) len[r] = min(max(seq_len[b0 + rbase + r], 0), T_);
+  for (int i = 0; i < 16; ++i) tmax = max(tmax, seq_len[b0 + i]);
+  tmax = min(tmax, T_);
+
+  for (int i = threadIdx.x; i < 5 * 3 * 16 * LDH; i += 256) reinterpret_cast<unsigned short*>(smem)[i] = 0;
+  // B fragments: lane (column = unit jw, both halves of the tile; k-group rg) of chunk ks holds W^T[32 ks + 8 rg + j][jw]
+  bf16x8_t wc[KS][3], wr[KS][3], wu[KS][3];
+  {
+    const float* pc = wchT + (size_t)d * H * H + jw;
+    const float* pg = wghT + (size_t)d * 2 * H * H + jw;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * ks + 8 * rg + j;
+        unsigned short t1[3], t2[3], t3[3];
+        split3(pc[(size_t)k * H], t1);
+        split3(pg[(size_t)k * H], t2);
+        split3(pg[(size_t)(H + k) * H], t3);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { wc[ks][q][j] = (short)t1[q]; wr[ks][q][j] = (short)t2[q]; wu[ks][q][j] = (short)t3[q]; }
+      }
+  }
+
+  u64* xhdr = xch + (size_t)cid.c * (XHDR + 6 * G * SLICE);
+  u64* xc_ = xhdr + XHDR;                                  // dc_pre: [2 parity][G][SLICE]
+  u64* xu_ = xc_ + 2 * G * SLICE;                          // du_pre
+  u64* xr_ = xu_ + 2 * G * SLICE;                          // dr_pre
+  bool timed_out = false;
+  const bool colocated = same_xcd<G>(xhdr, g, timed_out);
+  const bool fast = colocated && !(kflags & 1);
+  unsigned spin_limit = (kflags & 2) ? 2000u : SPIN_LIMIT;
+  if ((kflags & 2) && g == G - 1) return;                  // TEST ONLY: a member goes missing
+  __syncthreads();
+
+  const unsigned stride = (unsigned)B_ * ndir * H;
+  unsigned ob[2];                                          // frame 0 of this lane's (row, direction, unit)
+#pragma unroll
+  for (int r = 0; r < 2; ++r) ob[r] = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+  const unsigned pofs = (unsigned)(wave * 128 + rbase * 8 + (col & 7));
+  const unsigned lofs = (unsigned)(wave * 128 + lane);
+  unsigned ldst[G - 1][2];
+#pragma unroll
+  for (int k = 0; k < G - 1; ++k) {
+    const int gsrc = k + (k >= g ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 8 + (lane >> 3);
+      ldst[k][j] = ((unsigned)(row * LDH + gsrc * HSU + wave * 8 + (lane & 7)) * 2u) ^ lds_swz(row);
+    }
+  }
+  unsigned lown[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) lown[r] = ((unsigned)((rbase + r) * LDH + g * HSU + ul) * 2u) ^ lds_swz(rbase + r);
+  const unsigned lrd = ((unsigned)(col * LDH + rg * 8) * 2u) ^ lds_swz(col);
+  auto put3w = [&](char* img, unsigned off, unsigned w0, unsigned w1v) {
+    *reinterpret_cast<unsigned short*>(img + off) = (unsigned short)w0;
+    *reinterpret_cast<unsigned short*>(img + PLB + off) = (unsigned short)(w0 >> 16);
+    *reinterpret_cast<unsigned short*>(img + 2 * PLB + off) = (unsigned short)w1v;
+  };
+  auto product = [&](const char* img, const bf16x8_t (&w)[KS][3], f32x4_t acc) -> f32x4_t {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8_t afr[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) afr[q] = *reinterpret_cast<const bf16x8_t*>(img + q * PLB + lrd + ks * 64);
+      acc = mma_s3(afr, w[ks], acc);
+    }
+    return acc;
+  };
+  auto publish = [&](u64* area, int P, unsigned epoch, const float (&val)[2], char* img) {
+    u64* mine = area + ((size_t)P * G + g) * SLICE;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned short t3[3];
+      split3(val[r], t3);
+      const unsigned w0 = (unsigned)t3[0] | ((unsigned)t3[1] << 16);
+      gpublish(uoff(mine, pofs + 8u * r), ((unsigned)t3[2]) | (epoch << 16), w0, fast);
+      put3w(img, lown[r], w0, (unsigned)t3[2]);
+    }
+  };
+  auto collect = [&](u64* area, int P, unsigned epoch, char* img) {
+    u64 v[G - 1][2];
+#pragma unroll
+    for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) v[k][j] = gload(uoff(area + ((size_t)P * G + k + (k >= g ? 1 : 0)) * SLICE, lofs + 64u * j));
+    unsigned spins = 0;
+#pragma unroll 1
+    for (;;) {                                             // wave-uniform loop: no exec masking
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ok = ok && ((unsigned)(v[k][j] >> 48) == (epoch & 0xffffu));
+      if (__all(ok)) break;
+      if (++spins > spin_limit) { timed_out = true; spin_limit = 0; break; }
+#pragma unroll
+      for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) v[k][j] = gload(uoff(area + ((size_t)P * G + k + (k >= g ? 1 : 0)) * SLICE, lofs + 64u * j));
+    }
+#pragma unroll
+    for (int k = 0; k < G - 1; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) put3w(img, ldst[k][j], (unsigned)v[k][j], (unsigned)(v[k][j] >> 32));
+  };
+
+  // saved activations + dout of step s, requested one step ahead (rows past their length: a valid position, unused)
+  struct Saved { float dout, u, c, r, hp; };
+  auto fetch = [&](int s, Saved (&sv)[2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const bool act = s >= 0 && s < len[r];
+      const int fr = act ? (rev ? len[r] - 1 - s : s) : 0;
+      const int fp = act ? (rev ? len[r] - s : s - 1) : 0;   // the frame of the previous step's h (s > 0)
+      const unsigned o = ob[r] + (unsigned)fr * stride;
+      sv[r].dout = dout[o];
+      sv[r].u = u_in[o];
+      sv[r].c = c_in[o];
+      sv[r].r = r_in[o];
+      sv[r].hp = (act && s > 0) ? hout[ob[r] + (unsigned)fp * stride] : 0.f;
+    }
+  };
+
+  float dhc[2];                                            // dh_rec of this lane's two (row, unit) pairs
+#pragma unroll
+  for (int r = 0; r < 2; ++r) dhc[r] = d_h_final ? d_h_final[((size_t)d * B_ + b0 + rbase + r) * H + jw] : 0.f;
+  char* drimg = smem + 4 * IMG;
+  Saved cur[2], nxt[2];
+  fetch(tmax - 1, cur);
+  unsigned epoch = 0;
+  for (int s = tmax - 1; s >= 0; --s) {
+    ++epoch;
+    const int P = (int)(epoch & 1u);
+    char* dcimg = smem + P * IMG;
+    char* duimg = smem + (2 + P) * IMG;
+    fetch(s - 1, nxt);
+    bool act[2];
+    float dcp[2], dup[2], da[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      act[r] = s < len[r];
+      const float dh = cur[r].dout + dhc[r];
+      const float u = cur[r].u, c = cur[r].c;
+      dup[r] = act[r] ? dh * (cur[r].hp - c) * u * (1.f - u) : 0.f;
+      dcp[r] = act[r] ? dh * (1.f - u) * (1.f - c * c) : 0.f;
+      da[r] = act[r] ? dh * u : dhc[r];
+    }
+    publish(xc_, P, epoch, dcp, dcimg);
+    publish(xu_, P, epoch, dup, duimg);
+    collect(xc_, P, epoch, dcimg);
+    collect(xu_, P, epoch, duimg);
+    __syncthreads();                                       // dc_pre, du_pre complete in LDS
+    // ---- d(rh) = dc_pre W_c^T for the own units
+    const f32x4_t a1 = product(dcimg, wc, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+    float drp[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float drh = lo ? a1[r] : a1[2 + r];
+      const float rr = cur[r].r;
+      drp[r] = act[r] ? drh * cur[r].hp * rr * (1.f - rr) : 0.f;
+      da[r] += act[r] ? drh * rr : 0.f;
+    }
+    publish(xr_, P, epoch, drp, drimg);
+    collect(xr_, P, epoch, drimg);
+    // gradients of the pre-activations, behind the poll loop (active rows only: the caller zeroed the tensors)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (act[r]) {
+        const int fr = rev ? len[r] - 1 - s : s;
+        const unsigned o = ob[r] + (unsigned)fr * stride;
+        dcand[o] = dcp[r];
+        const unsigned og = (o - jw) * 2u + jw;
+        dgate[og] = drp[r];
+        dgate[og + H] = dup[r];
+      }
+    __syncthreads();                                       // dr_pre complete in LDS
+    // ---- dh_rec' = acc + [dr_pre | du_pre] W_g^T for the own units
+    f32x4_t a2 = product(drimg, wr, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+    a2 = product(duimg, wu, a2);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      dhc[r] = da[r] + (lo ? a2[r] : a2[2 + r]);
+      cur[r] = nxt[r];
+    }
+  }
+  if (timed_out) atomicOr(err, 2u);
+}
+
 // BPTT, fp32 operands: the H = 512 arrangement of the bf16 kernel (each tile computed ONCE: the hh = 0 waves take the
 // four own-unit tiles and hand rows 2,3 to their hh = 1 partners through LDS, the hh = 1 waves take the four tiles of
 // the peer's units and publish them) -- 64 K = 4 MFMAs per wave and step instead of the 128 + 64 of the redundant form.
@@ -3204,6 +3433,31 @@ bool asr_cluster_gru_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const
   } while (0)
   if (H == 128) ASR_GRU_CL(128); else ASR_GRU_CL(256);
 #undef ASR_GRU_CL
+  return true;
+}
+
+bool asr_cluster_gru_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* dout, const float* d_h_final,
+                             const float* hout, const float* r, const float* u, const float* c, const float* wghT,
+                             const float* wchT, const int32_t* seq_len, float* dgate, float* dcand, hipStream_t st) {
+  const char* env_c = getenv("ASR_GRU_CLUSTER");          // (read per call: the A-B test flips it inside one process)
+  if ((env_c && env_c[0] == '0') || !cluster_f32_enabled() || (H != 128 && H != 256) || T < 1 || T >= 65536) return false;
+  const int G = H / 32, ncl = (B / 16) * ndir;
+  const size_t need = (size_t)ncl * (XHDR + (size_t)6 * G * 16 * 32) * sizeof(u64);
+  if ((size_t)T * B * ndir * 2 * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
+      (int)cluster_grid(G, ncl) > h->num_cu)
+    return false;
+  char* base = (char*)h->scratch + (h->scratch_bytes - XCH_BYTES);
+  const XchAreas xa = xch_take(h, base, need, st);
+  const size_t lds = (size_t)5 * 3 * 16 * (H + 8) * 2;
+#define ASR_GRU_CLB(HH)                                                                                             \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(gru_bwd_cluster_kernel<HH>, dim3(cluster_grid(HH / 32, ncl)), dim3(256), lds, st, T, B, ndir, dout,   \
+                       d_h_final, hout, r, u, c, wghT, wchT, seq_len, dgate, dcand, xa.area, (unsigned*)base,         \
+                       kernel_flags(), xa.znext, xa.zwords);                                                         \
+  } while (0)
+  if (H == 128) ASR_GRU_CLB(128); else ASR_GRU_CLB(256);
+#undef ASR_GRU_CLB
   return true;
 }
 

@@ -1504,3 +1504,37 @@ def test_gru_cluster_forward_matches_the_single_cu_kernel(cuda, monkeypatch, H, 
     assert np.abs(np.where(valid, 0.0, out['1']['hout'])).max() == 0.0
     assert np.abs(np.where(valid, 0.0, out['1']['rh'])).max() == 0.0             # the caller's zeros are left alone
     assert np.abs(out['0']['h_final'] - out['1']['h_final']).max() < 3e-6
+
+
+@pytest.mark.parametrize('H,B,T,ndir', [(128, 16, 40, 2), (256, 16, 40, 2), (256, 32, 33, 1), (128, 48, 21, 2)])
+def test_gru_cluster_backward_matches_the_single_cu_kernel(cuda, monkeypatch, H, B, T, ndir):
+    """asr_gru_bwd on clusters (two all-gathers per step: dc_pre + du_pre, then dr_pre; W^T columns of the CU's units in
+    registers) against the single-CU persistent kernel on the same saved activations: dgate / dcand within 2e-6 (of values up
+    to ~1), exact zeros wherever no row is active, a final-state gradient fed in, ragged lengths incl. an empty row."""
+    ops = _ops()
+    rng = np.random.RandomState(2 * H + B + T)
+    xg = torch.tensor(rng.randn(T, B, ndir * 2 * H) * 0.5, dtype=torch.float32, device=cuda)
+    xc = torch.tensor(rng.randn(T, B, ndir * H) * 0.5, dtype=torch.float32, device=cuda)
+    wgh = torch.tensor(rng.randn(ndir, H, 2 * H) * 0.08, dtype=torch.float32, device=cuda)
+    wch = torch.tensor(rng.randn(ndir, H, H) * 0.08, dtype=torch.float32, device=cuda)
+    sl_np = rng.randint(1, T + 1, size=B).astype(np.int32)
+    sl_np[0] = T
+    if B > 16:
+        sl_np[17] = 0
+    sl = torch.tensor(sl_np, device=cuda)
+    monkeypatch.setenv('ASR_GRU_CLUSTER', '0')
+    saved = ops.gru_fwd(xg, xc, wgh, wch, sl, T, H, ndir)
+    dout = torch.tensor(rng.randn(T, B, ndir * H) * 0.3, dtype=torch.float32, device=cuda)
+    dhf = torch.tensor(rng.randn(ndir, B, H) * 0.3, dtype=torch.float32, device=cuda)
+    wghT, wchT = wgh.transpose(1, 2).contiguous(), wch.transpose(1, 2).contiguous()
+    got = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('ASR_GRU_CLUSTER', mode)
+        dg, dc = ops.gru_bwd(dout, dhf, saved, wghT, wchT, sl, T, H, ndir)
+        got[mode] = (dg.cpu().numpy(), dc.cpu().numpy())
+    monkeypatch.delenv('ASR_GRU_CLUSTER')
+    assert ops.check_async_errors(0) == 0
+    for a, b in zip(got['0'], got['1']):
+        assert np.isfinite(b).all() and np.abs(a - b).max() < 2e-6 and np.abs(a).max() > 0.1
+    valid = (np.arange(T)[:, None] < sl_np[None, :])[:, :, None]
+    assert np.abs(np.where(valid, 0.0, got['1'][0])).max() == 0.0 and np.abs(np.where(valid, 0.0, got['1'][1])).max() == 0.0
