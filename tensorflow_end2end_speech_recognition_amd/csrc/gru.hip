@@ -486,6 +486,13 @@ static bool gru_persistent_ok(asr_handle* h, int H, int ndir, size_t lds) {
          h->scratch_bytes > ASR_XCH_BYTES && pk <= h->scratch_bytes - ASR_XCH_BYTES;
 }
 
+// the clusters stand in for the persistent single-CU kernels: asr_debug_set_gru_persistent(0) / ASR_GRU_PERSISTENT=0 (the
+// launch-per-step form, A/B and tests) switches them off as well
+static bool gru_cluster_allowed() {
+  if (g_gru_persistent < 0) { const char* e = getenv("ASR_GRU_PERSISTENT"); g_gru_persistent = (e && e[0] == '0') ? 0 : 1; }
+  return g_gru_persistent == 1;
+}
+
 extern "C" int asr_gru_fwd(asr_handle* h, int T, int B, int H, int ndir, const float* xg, const float* xc,
                            const float* wgh, const float* wch, const int32_t* seq_len, int tmax, float* r, float* u,
                            float* c, float* rh, float* hout, float* hstate2, asr_stream s) {
@@ -501,7 +508,8 @@ extern "C" int asr_gru_fwd(asr_handle* h, int T, int B, int H, int ndir, const f
   const size_t sn = (size_t)ndir * B * H;
   float* hs[2] = {hstate2, hstate2 + sn};
   // H = 128 / 256: clusters of H / 32 CUs with the recurrent blocks in registers (lstm_cluster.hip), final state in hs[0]
-  if (asr_cluster_gru_fwd_try(h, T, B, H, ndir, xg, xc, wgh, wch, seq_len, r, u, c, rh, hout, hs[0], st)) {
+  if (gru_cluster_allowed() &&
+      asr_cluster_gru_fwd_try(h, T, B, H, ndir, xg, xc, wgh, wch, seq_len, r, u, c, rh, hout, hs[0], st)) {
     ASR_CHECK_LAUNCH(h, "asr_gru_fwd(cluster)");
     return ASR_OK;
   }
@@ -559,7 +567,8 @@ extern "C" int asr_gru_bwd(asr_handle* h, int T, int B, int H, int ndir, const f
       hipMemsetAsync(dcand, 0, (size_t)T * B * ndir * H * sizeof(float), st) != hipSuccess)
     ASR_FAIL(h, ASR_ERR_HIP, "asr_gru_bwd: memset");
   // H = 128 / 256: clusters of H / 32 CUs (lstm_cluster.hip)
-  if (asr_cluster_gru_bwd_try(h, T, B, H, ndir, dout, d_h_final, hout, r, u, c, wghT, wchT, seq_len, dgate, dcand, st)) {
+  if (gru_cluster_allowed() &&
+      asr_cluster_gru_bwd_try(h, T, B, H, ndir, dout, d_h_final, hout, r, u, c, wghT, wchT, seq_len, dgate, dcand, st)) {
     ASR_CHECK_LAUNCH(h, "asr_gru_bwd(cluster)");
     return ASR_OK;
   }

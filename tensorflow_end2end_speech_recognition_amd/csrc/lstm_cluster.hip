@@ -1759,7 +1759,6 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster_f32s_kernel(
 // lower ones (a 16-column MFMA for 8 units: the lanes col >= 8 read rows 2, 3 of the same unit from their own copy).
 // Saved activations r, u, c, r * h at the frame a row worked on; rows past their length store nothing but hout's zero
 // and keep h (their x loads are parked on a valid frame).  Same fp32-level arithmetic as the f32s LSTM kernels (six exact bf16 products per k = 32 chunk).
-__device__ __forceinline__ float gru_sig(float x) { return 1.0f / (1.0f + expf(-x)); }
 template <int H>
 __global__ __launch_bounds__(256, 1) void gru_fwd_cluster_kernel(
     int T_, int B_, int ndir, const float* __restrict__ xg, const float* __restrict__ xc, const float* __restrict__ wgh,
@@ -1825,12 +1824,12 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_cluster_kernel(
 
   const unsigned stride = (unsigned)B_ * ndir * H;
   const unsigned dstep = rev ? 0u - stride : stride;
-  unsigned oa[2], os[2], opark[2];
+  unsigned oa[2], os[2], os0[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     os[r] = ((unsigned)(b0 + rbase + r) * ndir + d) * H + jw;
+    os0[r] = os[r];
     oa[r] = os[r] + (rev ? (unsigned)max(len[r] - 1, 0) * stride : 0u);
-    opark[r] = os[r] + (unsigned)max(tmax - 1, 0) * stride;
   }
   const unsigned pofs = (unsigned)(wave * 128 + rbase * 8 + (col & 7));
   const unsigned lofs = (unsigned)(wave * 128 + lane);
@@ -1903,6 +1902,21 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_cluster_kernel(
 
   float hr[2] = {0.f, 0.f};
   char* rhimg = smem + 2 * 3 * PLB;
+  // x-projections of a step, requested one step ahead (a row past its length: the parked frame, unused)
+  float nxr[2], nxu[2], nxc[2];
+  auto xfetch = [&](int s) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const bool a = s < len[r];
+      const int fr = a ? (rev ? len[r] - 1 - s : s) : max(tmax - 1, 0);
+      const unsigned o = os0[r] + (unsigned)fr * stride;
+      const unsigned og = (o - jw) * 2u + jw;              // the same (frame, row, direction) in the [.., 2H] gate tensor
+      nxr[r] = xg[og];
+      nxu[r] = xg[og + H];
+      nxc[r] = xc[o];
+    }
+  };
+  xfetch(0);
   for (int s = 0; s < tmax; ++s) {
     const int P = s & 1;
     const char* hcur = smem + P * 3 * PLB;
@@ -1911,14 +1925,11 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_cluster_kernel(
     bool act[2];
     float xr[2], xu[2], xcv[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {                          // requested ahead of the first product
+    for (int r = 0; r < 2; ++r) {
       act[r] = s < len[r];
-      const unsigned o = act[r] ? oa[r] : opark[r];
-      const unsigned og = (o - jw) * 2u + jw;              // the same (frame, row, direction) in the [.., 2H] gate tensor
-      xr[r] = xg[og];
-      xu[r] = xg[og + H];
-      xcv[r] = xc[o];
+      xr[r] = nxr[r]; xu[r] = nxu[r]; xcv[r] = nxc[r];
     }
+    if (s + 1 < tmax) xfetch(s + 1);                       // block-uniform
     // ---- phase 1: [r | u] = sigmoid(xg + h W_gh)
     const f32x4_t a1 = product(hcur, w1);
     float rv[2], uv[2], rhv[2];
@@ -1926,8 +1937,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_cluster_kernel(
     for (int r = 0; r < 2; ++r) {
       const float pr = dpp_ror8_into<0xC>(a1[r], a1[2 + r]);
       const float pu = dpp_ror8_into<0x3>(a1[2 + r], a1[r]);
-      rv[r] = gru_sig(pr + xr[r]);
-      uv[r] = gru_sig(pu + xu[r]);
+      rv[r] = cfsig(pr + xr[r]);
+      uv[r] = cfsig(pu + xu[r]);
       rhv[r] = rv[r] * hr[r];
     }
     exchange(xa, P, epoch, rhv, rhimg);
@@ -1938,7 +1949,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_cluster_kernel(
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const float pc = lo ? a2[r] : a2[2 + r];
-      cv[r] = tanhf(pc + xcv[r]);
+      cv[r] = cftanh(pc + xcv[r]);
       const float hn = uv[r] * hr[r] + (1.f - uv[r]) * cv[r];
       hr[r] = act[r] ? hn : hr[r];
     }
@@ -2172,6 +2183,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_cluster_kernel(
       da[r] += act[r] ? drh * rr : 0.f;
     }
     publish(xr_, P, epoch, drp, drimg);
+    // the du_pre half of the second product does not wait for dr_pre: its multiplies run under the poll
+    f32x4_t a2 = product(duimg, wu, (f32x4_t){0.f, 0.f, 0.f, 0.f});
     collect(xr_, P, epoch, drimg);
     // gradients of the pre-activations, behind the poll loop (active rows only: the caller zeroed the tensors)
 #pragma unroll
@@ -2186,8 +2199,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_cluster_kernel(
       }
     __syncthreads();                                       // dr_pre complete in LDS
     // ---- dh_rec' = acc + [dr_pre | du_pre] W_g^T for the own units
-    f32x4_t a2 = product(drimg, wr, (f32x4_t){0.f, 0.f, 0.f, 0.f});
-    a2 = product(duimg, wu, a2);
+    a2 = product(drimg, wr, a2);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       dhc[r] = da[r] + (lo ? a2[r] : a2[2 + r]);

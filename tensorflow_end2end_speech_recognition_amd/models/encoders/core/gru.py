@@ -74,26 +74,42 @@ class GRULayer(object):
         dg2d = dgate.view(T * B, ndir * 2 * H)
         dc2d = dcand.view(T * B, ndir * H)
         dx = torch.zeros((T, B, din), dtype=torch.float32, device=x.device) if need_dx else None
-        for d, b in enumerate(self.bases):
-            dg = dg2d[:, d * 2 * H:(d + 1) * 2 * H]
-            dc = dc2d[:, d * H:(d + 1) * H]
-            gk, ck = st.g(b + '/gates/kernel'), st.g(b + '/candidate/kernel')
-            ops.gemm(x2d, dg, transA=True, out=gk[:din])
-            ops.gemm(x2d, dc, transA=True, out=ck[:din])
-            if T > 1:
-                if d == 0:   # forward direction: h_prev(t) = h(t-1)
-                    ops.gemm(h2d[:(T - 1) * B, d * H:(d + 1) * H], dg[B:], transA=True, out=gk[din:])
-                else:        # backward direction: h_prev(t) = h(t+1) (zero beyond len-1)
-                    ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=gk[din:])
-            else:
-                gk[din:].zero_()
-            ops.gemm(rh2d[:, d * H:(d + 1) * H], dc, transA=True, out=ck[din:])          # r * h_prev, same frame
-            ops.colsum(dg, out=st.g(b + '/gates/bias'))
-            ops.colsum(dc, out=st.g(b + '/candidate/bias'))
-            if need_dx:
+        # ONE marker behind the recurrence kernel: the weight gradients start there on side lanes (one per direction) and run
+        # beside the dx products and the BPTT of the layer below -- nobody waits for them before the clip (the encoder's
+        # backward joins the lanes); the main stream carries only what the layer below needs (as LSTMLayer.backward)
+        fork = ops.stream_event()
+        if need_dx:
+            for d, b in enumerate(self.bases):
+                dg = dg2d[:, d * 2 * H:(d + 1) * 2 * H]
+                dc = dc2d[:, d * H:(d + 1) * H]
                 ops.gemm(dg, st[b + '/gates/kernel'][:din], transB=True, out=dx.view(T * B, din), accumulate=True)
                 ops.gemm(dc, st[b + '/candidate/kernel'][:din], transB=True, out=dx.view(T * B, din), accumulate=True)
-        self.grad_event = ops.stream_event()
+        done = []
+        for d, b in enumerate(self.bases):
+            with ops.side_lane(x.device, keep=(x, sv['hout'], sv['rh'], dgate, dcand), lane=1 + (d % 2), after=fork):
+                dg = dg2d[:, d * 2 * H:(d + 1) * 2 * H]
+                dc = dc2d[:, d * H:(d + 1) * H]
+                gk, ck = st.g(b + '/gates/kernel'), st.g(b + '/candidate/kernel')
+                ops.gemm(x2d, dg, transA=True, out=gk[:din])
+                ops.gemm(x2d, dc, transA=True, out=ck[:din])
+                if T > 1:
+                    if d == 0:   # forward direction: h_prev(t) = h(t-1)
+                        ops.gemm(h2d[:(T - 1) * B, d * H:(d + 1) * H], dg[B:], transA=True, out=gk[din:])
+                    else:        # backward direction: h_prev(t) = h(t+1) (zero beyond len-1)
+                        ops.gemm(h2d[B:, d * H:(d + 1) * H], dg[:(T - 1) * B], transA=True, out=gk[din:])
+                else:
+                    gk[din:].zero_()
+                ops.gemm(rh2d[:, d * H:(d + 1) * H], dc, transA=True, out=ck[din:])          # r * h_prev, same frame
+                ops.colsum(dg, out=st.g(b + '/gates/bias'))
+                ops.colsum(dc, out=st.g(b + '/candidate/bias'))
+                if d % 2 > 0:
+                    done.append(ops.stream_event())
+        with ops.side_lane(x.device, lane=1, after=fork):
+            for ev in done:
+                ops.wait_event(ev)
+            # every gradient of this layer is complete at this point of side lane 1 (the data-parallel step hangs the
+            # layer's clip + all-reduce on it)
+            self.grad_event = ops.stream_event()
         self.ctx = None
         return dx
 
