@@ -344,8 +344,10 @@ int asr_clear_async_errors(asr_handle* h, asr_stream s);
  * its poll loop, MFMA priority in the fp32 BPTT kernel), result-neutral; 512 = clusters of H/64 CUs x eight waves instead
  * of H/32 CUs x four (H = 256 / 512). */
 int asr_debug_set_lstm_flags(int flags);
-/* 1 (default; env ASR_GRU_PERSISTENT): asr_gru_fwd / asr_gru_bwd run ONE persistent launch per call (state in LDS, both
- * products per step on exact-fp32 MFMA) where the LDS images fit; 0: the launch-per-step kernels. */
+/* 1 (default; env ASR_GRU_PERSISTENT): asr_gru_fwd / asr_gru_bwd run ONE launch per call -- for 64 / 128 / 256 units on
+ * clusters of H/32 CUs (round 6: the recurrent blocks as three-bf16-term fragments in registers, two all-gathers per step;
+ * env ASR_GRU_CLUSTER=0 keeps the single-CU form), else on one CU per (direction, tile) with the state in LDS and both
+ * products on exact-fp32 MFMA where the LDS images fit; 0: the launch-per-step kernels. */
 int asr_debug_set_gru_persistent(int on);
 
 /* Debug / measurement: are 16-byte per-lane stores seen whole by 16-byte loads of another CU?  Workgroup 0 stores
@@ -372,7 +374,9 @@ int asr_debug_poison_lds(asr_handle* h, asr_stream s);
  * transposes ([ndir][2H][H] / [ndir][H][H]).  tmax = max(seq_len) (host value: the step loop is issued by the host).
  * Saved for the backward pass, all [T,B,ndir,H] at the frame a row worked on: r, u, c, rh = r * h_prev.
  * hout [T,B,ndir*H] (zero past seq_len); hstate2: 2*ndir*B*H floats of work space, the final state [ndir,B,H] is
- * left in its first half.
+ * left in its first half.  r, u, c past a row's length are unspecified, rh there is left as the caller set it (zeros:
+ * the candidate kernel's weight gradient contracts it over all T*B rows); a timed-out cluster hand-off sets the sticky
+ * error word of asr_check_async_errors (bit 1 forward, bit 2 backward) as the LSTM clusters do.
  * asr_gru_bwd: dout [T,B,ndir*H] (+ d_h_final [ndir,B,H] or NULL) -> dgate [T,B,ndir,2H] (d r_pre | d u_pre) and
  * dcand [T,B,ndir,H] (d c_pre), zero where no row is active; the weight / input gradients are GEMMs over them
  * (dW_g = [x; h_prev]^T dgate, dW_c = [x; rh]^T dcand, dx = dgate W_gx^T + dcand W_cx^T).  work2: 2*ndir*B*H floats. */
