@@ -1538,3 +1538,35 @@ def test_gru_cluster_backward_matches_the_single_cu_kernel(cuda, monkeypatch, H,
         assert np.isfinite(b).all() and np.abs(a - b).max() < 2e-6 and np.abs(a).max() > 0.1
     valid = (np.arange(T)[:, None] < sl_np[None, :])[:, :, None]
     assert np.abs(np.where(valid, 0.0, got['1'][0])).max() == 0.0 and np.abs(np.where(valid, 0.0, got['1'][1])).max() == 0.0
+
+
+def test_gru_cluster_handoff_timeout_is_reported(cuda):
+    """The GRU clusters use the LSTM clusters' bounded polls and sticky error word: with the test-only flag (one member of
+    every cluster leaves early, spin limit 2000 polls) a forward and a backward launch finish, and the blocking check
+    raises; the word is reported once and cleared."""
+    from tensorflow_end2end_speech_recognition_amd import _lib
+    ops = _ops()
+    rng = np.random.RandomState(4)
+    H, B, T, ndir = 128, 16, 9, 2
+    xg = torch.tensor(rng.randn(T, B, ndir * 2 * H) * 0.5, dtype=torch.float32, device=cuda)
+    xc = torch.tensor(rng.randn(T, B, ndir * H) * 0.5, dtype=torch.float32, device=cuda)
+    wgh = torch.tensor(rng.randn(ndir, H, 2 * H) * 0.08, dtype=torch.float32, device=cuda)
+    wch = torch.tensor(rng.randn(ndir, H, H) * 0.08, dtype=torch.float32, device=cuda)
+    sl = torch.full((B,), T, dtype=torch.int32, device=cuda)
+    assert ops.check_async_errors(0) == 0
+    saved = ops.gru_fwd(xg, xc, wgh, wch, sl, T, H, ndir)
+    try:
+        ops.debug_set_lstm_flags(64)
+        ops.gru_fwd(xg, xc, wgh, wch, sl, T, H, ndir)
+        with pytest.raises(_lib.AsrError):
+            ops.check_async_errors(0)
+        assert ops.check_async_errors(0) == 0
+        dout = torch.zeros((T, B, ndir * H), dtype=torch.float32, device=cuda)
+        ops.gru_bwd(dout, None, saved, wgh.transpose(1, 2).contiguous(), wch.transpose(1, 2).contiguous(), sl, T, H, ndir)
+        with pytest.raises(_lib.AsrError):
+            ops.check_async_errors(0)
+    finally:
+        ops.debug_set_lstm_flags(0)
+    assert ops.check_async_errors(0) == 0
+    out = ops.gru_fwd(xg, xc, wgh, wch, sl, T, H, ndir)             # and the clusters work again
+    assert float((out['hout'] - saved['hout']).abs().max()) == 0.0 and ops.check_async_errors(0) == 0
