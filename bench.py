@@ -31,6 +31,7 @@ and, at N = 1, the other BASELINE configurations timed with the same harness (a 
   cfgE                   configs[4] hybrid-attention encoder-decoder + CTC head at the kanji vocabulary, B = 32;
   decode                 greedy and prefix-beam CTC decode (TIMIT-61 width 20, kanji width 100) in utterances/s, the
                          oracle's restatement of the reference's numpy decoders timed beside them on one core;
+  bgru                   the reference's GRU encoder family: bgru 2x256 CTC (fp32) on the headline batch;
   input_width_D39, batch_scaling   the headline model at the other input width / at B = 32 .. 128 per GPU.
 """
 import argparse
@@ -372,6 +373,11 @@ def dominant_roofline(entries):
     """Of {name: roofline entry with ms_per_step}, the one whose calls took the most event time per step."""
     live = {n: e for n, e in entries.items() if e and e.get('ms_per_step')}
     return max(live.values(), key=lambda e: e['ms_per_step']) if live else None
+
+
+def ops_flags(dev_index):
+    from tensorflow_end2end_speech_recognition_amd import ops
+    return ops.check_async_errors(dev_index)
 
 
 def load_traffic_table():
@@ -919,6 +925,9 @@ def compact_line(out, limit=COMPACT_LIMIT):
     if out.get('decode') is not None:
         c['decode'] = _compact_decode(out['decode']) if 'error' not in out['decode'] and 'skipped' not in out['decode'] \
             else _compact_aux(out['decode'])
+    if isinstance(out.get('bgru'), dict):
+        g = out['bgru']
+        c['bgru'] = {k: g.get(k) for k in ('value', 'ms_per_step', 'cluster_handoff_flags')} if 'value' in g else _compact_aux(g)
     bs = out.get('batch_scaling')
     if isinstance(bs, dict):
         c['batch_scaling'] = [[r.get('batch'), r.get('value'), r.get('ms_per_step')] for r in bs.get('rows', [])] \
@@ -940,8 +949,8 @@ def compact_line(out, limit=COMPACT_LIMIT):
     line = json.dumps(c, separators=(',', ':'))
     # shed optional detail, least important first, until the line fits
     for drop in (('batch_scaling',), ('input_width_D39',), ('headline_f32', 'kernel_us'), ('headline_f32', 'cpu_baseline'),
-                 ('cfgA', 'kernel_us'), ('decode',), ('per_rank',), ('h2d_inclusive',),
-                 ('other_padding',), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('cfgE', 'kernel_us'),
+                 ('cfgA', 'kernel_us'), ('cfgE', 'kernel_us'), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('bgru',),
+                 ('decode',), ('per_rank',), ('h2d_inclusive',), ('other_padding',),
                  ('cfgC', 'groups'), ('headline_f32',), ('cfgE',), ('cfgD',), ('cfgC',), ('cfgA',), ('comm',)):
         if len(line) <= limit:
             break
@@ -1058,7 +1067,7 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-cfgA', action='store_true')
     ap.add_argument('--no-aux', action='store_true', help='skip cfgC / cfgD / cfgE / decode / input width / batch scaling')
-    ap.add_argument('--aux', default='f32,cfgC,cfgD,cfgE,decode,D39,batch', help='which auxiliary entries to run (N = 1)')
+    ap.add_argument('--aux', default='f32,cfgC,cfgD,cfgE,decode,gru,D39,batch', help='which auxiliary entries to run (N = 1)')
     ap.add_argument('--aux-steps', type=int, default=5)
     ap.add_argument('--aux-warmup', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=2)
@@ -1248,6 +1257,32 @@ def main():
             out['input_width_D39'] = blstm_ctc_entry(args, wd, rd, 20, 'headline model on D=39 (13x3) features: input_size '
                                                      '40 is rejected by the class surface as by the reference (ctc.py:79)')
             del rd
+        if 'gru' in aux and not over_budget('bgru'):
+            # the reference's other recurrent encoder family (models/encoders/core/gru.py) on the headline shard: bgru 2 x 256
+            # CTC, fp32 (the GRU kernels are fp32), the same batch -- on the GRU clusters of round 6
+            log('bgru ...')
+            try:
+                from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+                xb, slb, _, denseb = make_batch(wl['seed'], wl['batch'], wl['input_size'], wl['classes'] + 1, wl['tmin'], wl['tmax'])
+                xg_, sg_ = torch.tensor(xb, device=dev), torch.tensor(slb, device=dev)
+                mg = CTC('bgru', wl['input_size'], 256, 2, wl['classes'], clip_grad_norm=5.0, seed=0, device=str(dev))
+                for _ in range(3):
+                    lg_, _ = mg.compute_loss(xg_, denseb, sg_, keep_prob=wl['keep_prob'])
+                    mg.train(lg_, 'rmsprop', 1e-3)
+                torch.cuda.synchronize()
+                tg0 = time.perf_counter()
+                for _ in range(10):
+                    lg_, _ = mg.compute_loss(xg_, denseb, sg_, keep_prob=wl['keep_prob'])
+                    mg.train(lg_, 'rmsprop', 1e-3)
+                torch.cuda.synchronize()
+                tg = (time.perf_counter() - tg0) / 10
+                out['bgru'] = dict(workload='bgru 2x256 CTC fp32 on the headline batch (B=%d, T<=%d), train step' % (wl['batch'], wl['tmax']),
+                                   value=float(slb.sum()) / tg, unit='frames/s', ms_per_step=tg * 1e3, dtype='f32', steps=10,
+                                   final_loss=float(lg_.item()), cluster_handoff_flags=ops_flags(dev_index))
+                del mg, xg_, sg_
+            except Exception as e:
+                out['bgru'] = dict(error=repr(e)[:400])
+            torch.cuda.empty_cache()
         if 'batch' in aux and not over_budget('batch_scaling'):
             log('batch scaling ...')
             # what the design delivers per GPU at the recipes' own batch sizes: one 16-utterance tile per cluster,
