@@ -344,7 +344,7 @@ int asr_clear_async_errors(asr_handle* h, asr_stream s);
  * its poll loop, MFMA priority in the fp32 BPTT kernel), result-neutral; 512 = clusters of H/64 CUs x eight waves instead
  * of H/32 CUs x four (H = 256 / 512). */
 int asr_debug_set_lstm_flags(int flags);
-/* 1 (default; env ASR_GRU_PERSISTENT): asr_gru_fwd / asr_gru_bwd run ONE launch per call -- for 64 / 128 / 256 units on
+/* 1 (default; env ASR_GRU_PERSISTENT): asr_gru_fwd / asr_gru_bwd run ONE launch per call -- for 64 / 128 / 256 / 320 units on
  * clusters of H/32 CUs (round 6: the recurrent blocks as three-bf16-term fragments in registers, two all-gathers per step;
  * env ASR_GRU_CLUSTER=0 keeps the single-CU form), else on one CU per (direction, tile) with the state in LDS and both
  * products on exact-fp32 MFMA where the LDS images fit; 0: the launch-per-step kernels. */

@@ -11,7 +11,7 @@ from tensorflow_end2end_speech_recognition_amd import ops  # noqa: E402
 
 dev = torch.device('cuda:0')
 rng = np.random.RandomState(0)
-for H, B, T, ndir in ((128, 16, 60, 2), (256, 16, 60, 2), (256, 32, 45, 1), (128, 48, 33, 2), (256, 16, 381, 2)):
+for H, B, T, ndir in ((128, 16, 60, 2), (256, 16, 60, 2), (256, 32, 45, 1), (128, 48, 33, 2), (256, 16, 381, 2), (320, 16, 381, 2), (64, 16, 381, 2)):
     xg = torch.tensor(rng.randn(T, B, ndir * 2 * H) * 0.5, dtype=torch.float32, device=dev)
     xc = torch.tensor(rng.randn(T, B, ndir * H) * 0.5, dtype=torch.float32, device=dev)
     wgh = torch.tensor(rng.randn(ndir, H, 2 * H) * 0.08, dtype=torch.float32, device=dev)

@@ -3421,13 +3421,13 @@ static bool cluster_bwd_f32_launch(asr_handle* h, int T, int B, int ndir, const 
   return true;
 }
 
-// GRU forward on clusters of H / 32 CUs (H = 64 / 128 / 256; B a multiple of 16).  ASR_GRU_CLUSTER=0 keeps the single-CU
+// GRU forward on clusters of H / 32 CUs (H = 64 / 128 / 256 / 320; B a multiple of 16).  ASR_GRU_CLUSTER=0 keeps the single-CU
 // persistent kernel (A/B, and the tests run both).  false = not applicable, nothing launched.
 bool asr_cluster_gru_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const float* xg, const float* xc,
                              const float* wgh, const float* wch, const int32_t* seq_len, float* r, float* u, float* c,
                              float* rh, float* hout, float* h_final, hipStream_t st) {
   const char* env_c = getenv("ASR_GRU_CLUSTER");          // (read per call: the A-B test flips it inside one process)
-  if ((env_c && env_c[0] == '0') || !cluster_f32_enabled() || (H != 64 && H != 128 && H != 256) || T < 1 || T >= 65536) return false;
+  if ((env_c && env_c[0] == '0') || !cluster_f32_enabled() || (H != 64 && H != 128 && H != 256 && H != 320) || T < 1 || T >= 65536) return false;
   const int G = H / 32, ncl = (B / 16) * ndir;
   const size_t need = (size_t)ncl * (XHDR + (size_t)4 * G * 16 * 32) * sizeof(u64);
   if ((size_t)T * B * ndir * 2 * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
@@ -3443,7 +3443,7 @@ bool asr_cluster_gru_fwd_try(asr_handle* h, int T, int B, int H, int ndir, const
                        wgh, wch, seq_len, r, u, c, rh, hout, h_final, xa.area, (unsigned*)base, kernel_flags(), xa.znext, \
                        xa.zwords);                                                                                   \
   } while (0)
-  if (H == 64) ASR_GRU_CL(64); else if (H == 128) ASR_GRU_CL(128); else ASR_GRU_CL(256);
+  if (H == 64) ASR_GRU_CL(64); else if (H == 128) ASR_GRU_CL(128); else if (H == 256) ASR_GRU_CL(256); else ASR_GRU_CL(320);
 #undef ASR_GRU_CL
   return true;
 }
@@ -3452,7 +3452,7 @@ bool asr_cluster_gru_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const
                              const float* hout, const float* r, const float* u, const float* c, const float* wghT,
                              const float* wchT, const int32_t* seq_len, float* dgate, float* dcand, hipStream_t st) {
   const char* env_c = getenv("ASR_GRU_CLUSTER");          // (read per call: the A-B test flips it inside one process)
-  if ((env_c && env_c[0] == '0') || !cluster_f32_enabled() || (H != 64 && H != 128 && H != 256) || T < 1 || T >= 65536) return false;
+  if ((env_c && env_c[0] == '0') || !cluster_f32_enabled() || (H != 64 && H != 128 && H != 256 && H != 320) || T < 1 || T >= 65536) return false;
   const int G = H / 32, ncl = (B / 16) * ndir;
   const size_t need = (size_t)ncl * (XHDR + (size_t)6 * G * 16 * 32) * sizeof(u64);
   if ((size_t)T * B * ndir * 2 * H >= (1ull << 31) || h->scratch_bytes < XCH_BYTES || need > XCH_HALF ||
@@ -3468,7 +3468,7 @@ bool asr_cluster_gru_bwd_try(asr_handle* h, int T, int B, int H, int ndir, const
                        d_h_final, hout, r, u, c, wghT, wchT, seq_len, dgate, dcand, xa.area, (unsigned*)base,         \
                        kernel_flags(), xa.znext, xa.zwords);                                                         \
   } while (0)
-  if (H == 64) ASR_GRU_CLB(64); else if (H == 128) ASR_GRU_CLB(128); else ASR_GRU_CLB(256);
+  if (H == 64) ASR_GRU_CLB(64); else if (H == 128) ASR_GRU_CLB(128); else if (H == 256) ASR_GRU_CLB(256); else ASR_GRU_CLB(320);
 #undef ASR_GRU_CLB
   return true;
 }

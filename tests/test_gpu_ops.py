@@ -1474,7 +1474,7 @@ def test_beam_search_edge_inputs_against_the_oracle(cuda):
                 assert abs(score[b].item() - rs[b]) < 1e-7 * max(1, abs(rs[b])), (kind, b)
 
 
-@pytest.mark.parametrize('H,B,T,ndir', [(128, 16, 40, 2), (256, 16, 40, 2), (256, 32, 33, 1), (128, 48, 21, 2), (64, 32, 27, 2)])
+@pytest.mark.parametrize('H,B,T,ndir', [(128, 16, 40, 2), (256, 16, 40, 2), (256, 32, 33, 1), (128, 48, 21, 2), (64, 32, 27, 2), (320, 16, 23, 2)])
 def test_gru_cluster_forward_matches_the_single_cu_kernel(cuda, monkeypatch, H, B, T, ndir):
     """asr_gru_fwd on clusters of H / 32 CUs (three-bf16-term products, two exchanges per step) against the single-CU
     persistent kernel (exact-fp32 MFMA; ASR_GRU_CLUSTER=0): r, u, c, r * h at every frame a row worked on, hout everywhere
@@ -1506,7 +1506,7 @@ def test_gru_cluster_forward_matches_the_single_cu_kernel(cuda, monkeypatch, H, 
     assert np.abs(out['0']['h_final'] - out['1']['h_final']).max() < 3e-6
 
 
-@pytest.mark.parametrize('H,B,T,ndir', [(128, 16, 40, 2), (256, 16, 40, 2), (256, 32, 33, 1), (128, 48, 21, 2), (64, 32, 27, 2)])
+@pytest.mark.parametrize('H,B,T,ndir', [(128, 16, 40, 2), (256, 16, 40, 2), (256, 32, 33, 1), (128, 48, 21, 2), (64, 32, 27, 2), (320, 16, 23, 2)])
 def test_gru_cluster_backward_matches_the_single_cu_kernel(cuda, monkeypatch, H, B, T, ndir):
     """asr_gru_bwd on clusters (two all-gathers per step: dc_pre + du_pre, then dr_pre; W^T columns of the CU's units in
     registers) against the single-CU persistent kernel on the same saved activations: dgate / dcand within 2e-6 (of values up
