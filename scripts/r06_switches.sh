@@ -10,3 +10,5 @@ run ctc_one_wave ASR_CTC_WAVES=1
 run enc_halves ASR_ENC_HALVES=1
 run no_early ASR_LSTM_DFLAGS=32
 run eight_wave_clusters ASR_LSTM_DFLAGS=512
+( ASR_GRU_CLUSTER=0 timeout 900 python -m pytest tests -m gpu -q -x -k "gru" > $OUT/gru_single_cu.txt 2>&1 ); echo "gru_single_cu: $(grep -E 'passed|failed|error' $OUT/gru_single_cu.txt | tail -1)"
+( timeout 900 python -m pytest tests -m gpu -q -x -k "gru" > $OUT/gru_clusters.txt 2>&1 ); echo "gru_clusters: $(grep -E 'passed|failed|error' $OUT/gru_clusters.txt | tail -1)"

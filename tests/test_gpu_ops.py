@@ -1545,6 +1545,8 @@ def test_gru_cluster_handoff_timeout_is_reported(cuda):
     every cluster leaves early, spin limit 2000 polls) a forward and a backward launch finish, and the blocking check
     raises; the word is reported once and cleared."""
     from tensorflow_end2end_speech_recognition_amd import _lib
+    if os.environ.get('ASR_GRU_CLUSTER') == '0' or os.environ.get('ASR_GRU_PERSISTENT') == '0':
+        pytest.skip('the GRU clusters are switched off in this run')
     ops = _ops()
     rng = np.random.RandomState(4)
     H, B, T, ndir = 128, 16, 9, 2
