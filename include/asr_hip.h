@@ -55,7 +55,7 @@ typedef enum {
 } asr_optimizer;
 
 /* ---- lifetime ------------------------------------------------------------ */
-int asr_abi_version(void);                                         /* 4: rounds 5-6, additive (asr_conv3x3_bwd_weight_bias, asr_conv3x3_smallc_bwd_weight_bias, asr_debug_* hooks).  3: round 4 (2: additions + the two size changes noted at asr_create_ex / asr_ctc_beam_workspace_bytes; 3: asr_att_decoder grew a trailing field) */
+int asr_abi_version(void);                                         /* 5: round 6, additive (asr_lstm_bwd_ex).  4: round 5, additive (asr_conv3x3_bwd_weight_bias, asr_conv3x3_smallc_bwd_weight_bias, asr_debug_* hooks).  3: round 4 (2: additions + the two size changes noted at asr_create_ex / asr_ctc_beam_workspace_bytes; 3: asr_att_decoder grew a trailing field) */
 int asr_create(asr_handle** out, int device);                        /* 192 MiB scratch arena */
 int asr_create_ex(asr_handle** out, int device, size_t scratch_bytes); /* >= 96 MiB (64 MiB of it: recurrence exchange areas) */
 size_t asr_scratch_bytes(asr_handle* h);
@@ -321,6 +321,16 @@ int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
                  const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,
                  const float* d_c_final, const float* d_h_final,
                  void* dgates, float* dpeep_dbias, float* dpeep_workspace, asr_stream s);
+/* The same with clip_no_grad: 0 = asr_lstm_bwd (LSTMBlockCell: the fused gradient op does not know cell_clip, the clip is
+ * straight-through).  > 0 = the forward ran with cell_clip = clip_no_grad and the cell is tf.contrib.rnn.LSTMCell
+ * (models/encoders/core/blstm.py:187-230 of the reference, the num_proj cell), whose tf.clip_by_value passes NO gradient
+ * through a clamped state: a frame whose saved cs has |c| >= clip_no_grad sends nothing to its gates or to c_prev
+ * (its output gate still receives its gradient).  fp32 operands only (ASR_ERR_UNSUPPORTED otherwise). */
+int asr_lstm_bwd_ex(asr_handle* h, int dtype, int T, int B, int H, int ndir,
+                    const float* dhout, const void* gates, const float* cs,
+                    const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,
+                    const float* d_c_final, const float* d_h_final, float clip_no_grad,
+                    void* dgates, float* dpeep_dbias, float* dpeep_workspace, asr_stream s);
 
 /* The recurrences run as clusters of H/32 (or H/64) workgroups per (direction, 16-utterance tile) that hand their
  * slices of h / dh to each other inside the launch (bounded spins).  This synchronises the device and reports the

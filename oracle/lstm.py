@@ -81,8 +81,9 @@ def bf16_round_t(x):
 
 
 def dynamic_rnn(x_tm, seq_len, p, reverse=False, drop_mask=None,
-                forget_bias=1.0, cell_clip=0.0, use_peephole=True, h_round=None):
+                forget_bias=1.0, cell_clip=0.0, use_peephole=True, h_round=None, clip_blocks_gradient=False):
     """tf.nn.dynamic_rnn(time_major=True, sequence_length) over one direction.
+    clip_blocks_gradient: see lstm_block_cell (the python LSTMCell's tf.clip_by_value).
 
     x_tm [T,B,Din]; seq_len LongTensor [B]; p = dict(w,b,wci,wcf,wco).
     reverse=True gives the backward half of bidirectional_dynamic_rnn
@@ -103,7 +104,8 @@ def dynamic_rnn(x_tm, seq_len, p, reverse=False, drop_mask=None,
     for s in range(T):
         active = (s < seq_len).to(x_tm.dtype).unsqueeze(1)
         c_new, h_new = lstm_block_cell(x_tm[s], c, h_fb, p['w'], p['b'], p['wci'], p['wcf'],
-                                       p['wco'], forget_bias, cell_clip, use_peephole)
+                                       p['wco'], forget_bias, cell_clip, use_peephole,
+                                       clip_blocks_gradient=clip_blocks_gradient)
         c = active * c_new + (1 - active) * c
         h = active * h_new + (1 - active) * h
         h_emit = h_new if h_round is None else ste_round(h_new, h_round)

@@ -70,6 +70,8 @@ SIGNATURES = {
     'asr_lstm_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'asr_lstm_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp]),
+    'asr_lstm_bwd_ex': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,
+                             _vp, _vp]),
     'asr_gru_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'asr_gru_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'asr_check_async_errors': (_i, [_vp, C.POINTER(C.c_uint)]),
@@ -134,7 +136,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 4          # include/asr_hip.h: asr_abi_version()
+ABI_VERSION = 5          # include/asr_hip.h: asr_abi_version()
 
 
 def load():

@@ -23,6 +23,9 @@ struct asr_handle {
   int xcd_skip;
   // workgroups the lean reduction-major GEMM aims at (0 = default 512); see asr_set_gemm_tn_workgroups
   int tn_wgs;
+  // asr_lstm_bwd_ex: the clip the forward applied to the cell state when a clamped state must pass no gradient
+  // (tf.clip_by_value of LSTMCell); 0 = the straight-through clip of LSTMBlockCell.  Set around the kernel dispatch only.
+  float bptt_clip;
 };
 
 #define ASR_FAIL(h, code, ...)                                  \

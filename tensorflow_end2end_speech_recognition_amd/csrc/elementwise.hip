@@ -10,7 +10,7 @@
 // 3 (round 4): asr_lstm_cell_gemm_prep / _fwd and their _h forms (decoder cell product + cell in one launch).
 // 4 (rounds 5-6, additive): asr_conv3x3_bwd_weight_bias, asr_conv3x3_smallc_bwd_weight_bias (bias gradient out of the
 // weight-gradient kernels), the asr_debug_* hooks; nothing removed or re-typed.
-extern "C" int asr_abi_version(void) { return 4; }
+extern "C" int asr_abi_version(void) { return 5; }
 
 extern "C" int asr_create(asr_handle** out, int device) { return asr_create_ex(out, device, (size_t)192 << 20); }
 extern "C" size_t asr_scratch_bytes(asr_handle* h) { return h ? h->scratch_bytes : 0; }

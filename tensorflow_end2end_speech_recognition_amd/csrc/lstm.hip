@@ -525,7 +525,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(
     const typename LT<T>::g4_t* __restrict__ gates, const float* __restrict__ cs,
     const T* __restrict__ whpb, const float* __restrict__ peep, const int32_t* __restrict__ seq_len,
     const float* __restrict__ d_c_final, const float* __restrict__ d_h_final,
-    typename LT<T>::g4_t* __restrict__ dgates, float* __restrict__ dpeep_part) {
+    typename LT<T>::g4_t* __restrict__ dgates, float* __restrict__ dpeep_part, float clipz) {
   constexpr int NUB = H / (16 * NW);
   constexpr int KV = LT<T>::KV, KS = 4 * H / KV;
   constexpr int LDG = 4 * H + LT<T>::PAD;
@@ -655,7 +655,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(
         const float dh = dho + dhr[u][r];
         const float tc = ftanh(cur);
         const float d_o = dh * tc * oo * (1.f - oo);
-        const float dc = dcr[u][r] + dh * oo * (1.f - tc * tc) + d_o * wco[u];
+        const float dct = dcr[u][r] + dh * oo * (1.f - tc * tc) + d_o * wco[u];
+        // clipz > 0 (asr_lstm_bwd_ex): cs holds the CLAMPED state, |c| >= clip marks a state that passes nothing back
+        const float dc = (clipz > 0.f && fabsf(cur) >= clipz) ? 0.f : dct;
         const float d_g = dc * i * (1.f - g * g);
         const float d_i = dc * g * i * (1.f - i);
         const float d_f = dc * cprev * f * (1.f - f);
@@ -756,7 +758,7 @@ int launch_fwd(int T_, int B, int ndir, const float* xg, const void* whp, const 
 template <typename T, int H>
 int launch_bwd(int T_, int B, int ndir, const float* dhout, const void* gates, const float* cs,
                const void* whpb, const float* peep, const int32_t* seq_len, const float* dcf,
-               const float* dhf, void* dgates, float* dpeep_part, hipStream_t st) {
+               const float* dhf, void* dgates, float* dpeep_part, float clipz, hipStream_t st) {
   constexpr size_t one = (size_t)16 * (4 * H + LT<T>::PAD) * sizeof(T);
   constexpr bool DB = (2 * one <= 72 * 1024);
   constexpr int NW = pick_nw(H);
@@ -766,7 +768,7 @@ int launch_bwd(int T_, int B, int ndir, const float* dhout, const void* gates, c
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(B / 16, ndir), dim3(NW * 64), lds, st, T_, B, ndir, dhout,
                      (const typename LT<T>::g4_t*)gates, cs, (const T*)whpb, peep, seq_len, dcf, dhf,
-                     (typename LT<T>::g4_t*)dgates, dpeep_part);
+                     (typename LT<T>::g4_t*)dgates, dpeep_part, clipz);
   return 0;
 }
 
@@ -907,12 +909,11 @@ extern "C" int asr_lstm_fwd(asr_handle* h, int dtype, int T, int B, int H, int n
   return ASR_OK;
 }
 
-extern "C" int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
-                            const float* dhout, const void* gates, const float* cs,
-                            const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,
-                            const float* d_c_final, const float* d_h_final, void* dgates,
-                            float* dpeep, float* dpeep_workspace, asr_stream s) {
-  if (!h) return ASR_ERR_INVALID_ARG;
+static int lstm_bwd_impl(asr_handle* h, int dtype, int T, int B, int H, int ndir,
+                         const float* dhout, const void* gates, const float* cs,
+                         const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,
+                         const float* d_c_final, const float* d_h_final, float clipz, void* dgates,
+                         float* dpeep, float* dpeep_workspace, asr_stream s) {
   if (!asr_dtype_ok(dtype) || T < 0 || B <= 0 || B % 16 || (ndir != 1 && ndir != 2) || !dhout ||
       !gates || !cs || !wh_packed_bwd || !seq_len || !dgates)
     ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_bwd: bad args (B=%d must be a multiple of 16, ndir=%d)", B, ndir);
@@ -939,10 +940,10 @@ extern "C" int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int n
   } else
   if (dtype == ASR_F32) {
     ASR_H_DISPATCH(H, T, (launch_bwd<float, HH>(T, B, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len,
-                                                d_c_final, d_h_final, dgates, part, st)));
+                                                d_c_final, d_h_final, dgates, part, clipz, st)));
   } else {
     ASR_H_DISPATCH(H, T, (launch_bwd<bf16_t, HH>(T, B, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len,
-                                                 d_c_final, d_h_final, dgates, part, st)));
+                                                 d_c_final, d_h_final, dgates, part, clipz, st)));
   }
   ASR_CHECK_LAUNCH(h, "asr_lstm_bwd");
   if (dpeep && !single_tile) {
@@ -951,4 +952,32 @@ extern "C" int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int n
     ASR_CHECK_LAUNCH(h, "asr_lstm_bwd(reduce)");
   }
   return ASR_OK;
+}
+
+// clip_no_grad > 0: the forward ran with cell_clip = clip_no_grad and the cell is tf.contrib.rnn.LSTMCell, whose
+// tf.clip_by_value passes no gradient through a clamped state (LSTMBlockCell's fused gradient op does not know the
+// clip: asr_lstm_bwd, clip_no_grad = 0).  fp32 operands only.
+extern "C" int asr_lstm_bwd_ex(asr_handle* h, int dtype, int T, int B, int H, int ndir,
+                               const float* dhout, const void* gates, const float* cs,
+                               const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,
+                               const float* d_c_final, const float* d_h_final, float clip_no_grad, void* dgates,
+                               float* dpeep, float* dpeep_workspace, asr_stream s) {
+  if (!h) return ASR_ERR_INVALID_ARG;
+  if (!(clip_no_grad >= 0.f)) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_bwd_ex: clip_no_grad must be >= 0");
+  if (clip_no_grad > 0.f && dtype != ASR_F32)
+    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_lstm_bwd_ex: a gradient-blocking clip is implemented for fp32 operands");
+  h->bptt_clip = clip_no_grad;   // the cluster launchers (lstm_cluster.hip) read it
+  const int rc = lstm_bwd_impl(h, dtype, T, B, H, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len, d_c_final,
+                               d_h_final, clip_no_grad, dgates, dpeep, dpeep_workspace, s);
+  h->bptt_clip = 0.f;
+  return rc;
+}
+
+extern "C" int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
+                            const float* dhout, const void* gates, const float* cs,
+                            const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,
+                            const float* d_c_final, const float* d_h_final, void* dgates,
+                            float* dpeep, float* dpeep_workspace, asr_stream s) {
+  return asr_lstm_bwd_ex(h, dtype, T, B, H, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len, d_c_final, d_h_final,
+                         0.f, dgates, dpeep, dpeep_workspace, s);
 }

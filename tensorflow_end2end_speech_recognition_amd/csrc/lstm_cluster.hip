@@ -2218,7 +2218,7 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_f32_kernel(
     const float* __restrict__ cs, const float* __restrict__ whpb, const float* __restrict__ peep,
     const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
     const float* __restrict__ d_h_final, f32x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
-    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords, float clipz) {
   static_assert(H / HS == 2, "one foreign tile per hh = 1 wave: two CUs per direction");
   zero_next_area(znext, zwords);
   constexpr int G = H / HS;
@@ -2373,7 +2373,8 @@ __global__ __launch_bounds__(CT8, 1) void lstm_bwd_cluster8_f32_kernel(
     for (int r = 0; r < 2; ++r) {
       const float dh = pdhv[r] + dhr[r];
       const float d_o = dh * a_o[r];
-      const float dc = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float dct = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float dc = (clipz > 0.f && fabsf(curv[r]) >= clipz) ? 0.f : dct;   // asr_lstm_bwd_ex
       const float d_g = dc * c_g[r], d_i = dc * c_i[r], d_f = dc * c_f[r];
       dcr[r] = act[r] ? (dc * gf[r] + d_i * wci + d_f * wcf) : dcr[r];
       dhr[r] = act[r] ? 0.f : dhr[r];
@@ -2470,7 +2471,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32_kernel(
     const float* __restrict__ cs, const float* __restrict__ whpb, const float* __restrict__ peep,
     const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
     const float* __restrict__ d_h_final, f32x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
-    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords, float clipz) {
   zero_next_area(znext, zwords);
   constexpr int G = H / HSU;
   static_assert(G % 2 == 0 && G >= 2 && G <= XHDR, "even number of CUs per cluster");
@@ -2668,7 +2669,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32_kernel(
     for (int r = 0; r < 2; ++r) {
       const float dh = pdhv[r] + dhr[r];
       const float d_o = dh * a_o[r];
-      const float dc = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float dct = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float dc = (clipz > 0.f && fabsf(curv[r]) >= clipz) ? 0.f : dct;   // asr_lstm_bwd_ex
       const float d_g = dc * c_g[r], d_i = dc * c_i[r], d_f = dc * c_f[r];
       dcr[r] = act[r] ? (dc * gf[r] + d_i * wci + d_f * wcf) : dcr[r];
       dhr[r] = act[r] ? 0.f : dhr[r];
@@ -2765,7 +2767,7 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32s_kernel(
     const float* __restrict__ cs, const float* __restrict__ whpb, const float* __restrict__ peep,
     const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
     const float* __restrict__ d_h_final, f32x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
-    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords, float clipz) {
   zero_next_area(znext, zwords);
   constexpr int G = H / HSU;
   static_assert(G % 2 == 0 && G >= 2 && G <= XHDR, "even number of CUs per cluster");
@@ -2967,7 +2969,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster_f32s_kernel(
     for (int r = 0; r < 2; ++r) {
       const float dh = pdhv[r] + dhr[r];
       const float d_o = dh * a_o[r];
-      const float dc = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float dct = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float dc = (clipz > 0.f && fabsf(curv[r]) >= clipz) ? 0.f : dct;   // asr_lstm_bwd_ex
       const float d_g = dc * c_g[r], d_i = dc * c_i[r], d_f = dc * c_f[r];
       dcr[r] = act[r] ? (dc * gf[r] + d_i * wci + d_f * wcf) : dcr[r];
       dhr[r] = act[r] ? 0.f : dhr[r];
@@ -3410,14 +3413,14 @@ static bool cluster_bwd_f32_launch(asr_handle* h, int T, int B, int ndir, const 
       const size_t lds_s = (size_t)2 * 3 * 16 * (4 * HSU + 8) * 2 + (size_t)2 * TPC * 64 * 8;   // two x three term images + hand-over
       hipLaunchKernelGGL((lstm_bwd_cluster_f32s_kernel<HH, HSU>), dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds_s, st, T,
                          B, ndir, dhout, (const f32x4_t*)gates, cs, (const float*)whpb, peep, seq_len, dcf, dhf,
-                         (f32x4_t*)dgates, dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
+                         (f32x4_t*)dgates, dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords, h->bptt_clip);
       return true;
     }
   }
   const size_t lds = (size_t)2 * 16 * (4 * HSU + 4) * 4 + (size_t)2 * TPC * 64 * 8;   // two dG images + the hand-over buffer
   hipLaunchKernelGGL((lstm_bwd_cluster_f32_kernel<HH, HSU>), dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir,
                      dhout, (const f32x4_t*)gates, cs, (const float*)whpb, peep, seq_len, dcf, dhf, (f32x4_t*)dgates,
-                     dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
+                     dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords, h->bptt_clip);
   return true;
 }
 
@@ -3499,7 +3502,7 @@ bool asr_cluster_bwd_f32_try(asr_handle* h, int T, int B, int H, int ndir, const
   const size_t lds = (size_t)2 * 16 * (4 * HS + 4) * 4 + 2 * 4 * 64 * 8;   // two dG images + the hand-over buffer
   hipLaunchKernelGGL(lstm_bwd_cluster8_f32_kernel<HH>, dim3(cluster_grid(G, ncl)), dim3(CT8), lds, st, T, B, ndir,
                      dhout, (const f32x4_t*)gates, cs, (const float*)whpb, peep, seq_len, dcf, dhf, (f32x4_t*)dgates,
-                     dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
+                     dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords, h->bptt_clip);
   return true;
 }
 #undef ASR_F32_ARGS_B

@@ -236,11 +236,21 @@ class LSTMLayer(object):
 # (models/encoders/core/blstm.py:187-230, lstm.py:117-180; Sak et al. 2014): the recurrent input and the emitted output
 # are m = (o * tanh(c)) @ projection/kernel [H, P], so the layer's recurrence is  pre = x W_x + b + m_prev W_h  with
 # W_h [P, 4H], and its outputs are [T, B, ndir * P].
-# No BASELINE configuration uses it, and the multi-CU recurrence kernels are built around an H x 4H recurrent matrix;
-# this layer runs the recurrence step by step on the generic kernels instead (per step: one skinny MFMA product for the
-# recurrent term, asr_lstm_cell_fwd, one for the projection; backwards the mirror image), fp32, with everything that does
-# not feed back (x W_x over all T, every weight gradient, dx) batched into single GEMMs as in LSTMLayer.  Correct and
-# complete (every reference configuration that names num_proj constructs and trains), not a fast path.
+# The multi-CU recurrence kernels are built around an H x 4H recurrent matrix -- and the projected cell HAS one: the state
+# that feeds back is m = h W_p, so  m_prev W_h = h_prev (W_p W_h)  and the recurrence over the UNPROJECTED h = o * tanh(c)
+# is the plain cell's with W' = W_p W_h [H, 4H] (one small GEMM per step of training).  The fused path (round 6, the
+# default wherever asr_lstm_fwd takes the width: H in 64/128/192/256/320/512) therefore runs asr_lstm_fwd / asr_lstm_bwd_ex
+# -- the cluster kernels at 128/256/320/512 -- on W', fp32, and everything else is batched over all T:
+#   forward : x W_x + b,  the recurrence,  m = h W_p (the layer's output; padded frames are zero because h is)
+#   backward: dh = dout W_p^T,  BPTT on W'^T (clip_no_grad: LSTMCell clamps with tf.clip_by_value, a clamped state passes
+#             nothing back -- asr_lstm_bwd_ex),  Z = dG W_h^T (the part of dm that came back through the recurrence),
+#             dW_x = x^T dG,  dW_h = m_prev^T dG,  dW_p = h^T dout + h^T Z_next,  dx = dG W_x^T,  bias / peepholes from the
+#             BPTT kernel's column sums.
+# (h W_p) W_h and h (W_p W_h) differ by fp32 rounding only (the parity test holds the same 1e-4 / 2e-3 bars as before).
+# Other widths -- and ASR_LSTMP_FUSED=0, the A/B switch the tests use to hold the two paths against each other -- run the
+# recurrence step by step on the generic kernels (per step: one skinny MFMA product for the recurrent term,
+# asr_lstm_cell_fwd, one for the projection; backwards the mirror image), with everything that does not feed back batched
+# into single GEMMs as well.
 def declare_lstmp_vars(store, scope, din, H, P, ndir, use_peephole, parameter_init, rng, cell_scope=None):
     names = []
     for d in range(ndir):
@@ -293,8 +303,117 @@ class LSTMPLayer(object):
         src = torch.where(live, L - 1 - s, s) if reverse else s.expand(T, B)
         return src.contiguous(), live.to(torch.float32).contiguous()
 
+    def _vars(self, view):
+        rows = []
+        for b in self.bases:
+            row = [view(b + '/kernel'), view(b + '/bias')]
+            row += [view(b + '/w_i_diag'), view(b + '/w_f_diag'), view(b + '/w_o_diag')] if self.use_peephole \
+                else [None, None, None]
+            rows.append(tuple(row))
+        return rows
+
+    def fused(self):
+        """The recurrence on W' = W_p W_h through asr_lstm_fwd / asr_lstm_bwd_ex (see the comment above the class)."""
+        return _os.environ.get('ASR_LSTMP_FUSED', '1') != '0' and ops.lstm_units_supported(self.H)
+
+    def _forward_fused(self, x, seq_len, mask, save):
+        st = self.store
+        T, B, din = x.shape
+        H, P, ndir = self.H, self.P, self.ndir
+        dev = x.device
+        Bp = (B + 15) // 16 * 16
+        if Bp != B:   # the recurrence kernels work on 16-utterance tiles: rows of length 0 fill the last one
+            x = torch.cat([x, x.new_zeros((T, Bp - B, din))], 1)
+            seq_len = torch.cat([seq_len, seq_len.new_zeros((Bp - B,))])
+        x = x.contiguous()
+        # the layer as a plain cell over the input [x, m_prev-as-input-columns]: kernel rows [W_x; W_h; W'] -- the prep
+        # launch then also yields W_h in the interleaved gate layout the BPTT kernel's dG has (columns din.. of wx_cat)
+        rows = []
+        for b, v in zip(self.bases, self._vars(st.__getitem__)):
+            kf = torch.empty((din + P + H, 4 * H), dtype=torch.float32, device=dev)
+            kf[:din + P].copy_(v[0])
+            ops.gemm(st[b + '/projection/kernel'], v[0][din:], out=kf[din + P:])                 # W' = W_p W_h
+            rows.append((kf,) + v[1:])
+        prep = ops.lstm_prep_layer(rows, din + P, H, ASR_F32)
+        xproj = torch.empty((T, Bp, ndir * 4 * H), dtype=torch.float32, device=dev)
+        ops.gemm(x.view(T * Bp, din), prep['wxT'][:, :din], transB=True, bias=prep['bias'],
+                 out=xproj.view(T * Bp, ndir * 4 * H))
+        gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, prep['whf'], prep['peep'], seq_len, H, ndir, ASR_F32,
+                                               self.forget_bias, self.cell_clip or 0.0)
+        m = torch.empty((T, Bp, ndir * P), dtype=torch.float32, device=dev)
+        finals = []
+        for d, b in enumerate(self.bases):
+            wp = st[b + '/projection/kernel']
+            ops.gemm(hout.view(T * Bp, ndir * H)[:, d * H:(d + 1) * H], wp, out=m.view(T * Bp, ndir * P)[:, d * P:(d + 1) * P])
+            finals.append((cf[d, :B], ops.gemm(hf[d], wp)[:B]))
+        out = m[:, :B].contiguous() if Bp != B else m
+        res = out if mask is None else ops.apply_mask(out, mask)
+        if save:
+            self.ctx = dict(fused=True, x=x, m=m, hout=hout, hf=hf, gates=gates, cs=cs, whb=prep['whb'], peep=prep['peep'],
+                            wx_cat=prep['wx_cat'], seq_len=seq_len, mask=mask, batch=B)
+        return res, finals
+
+    def _backward_fused(self, dout, d_final, need_dx):
+        c, st = self.ctx, self.store
+        x, m, hout = c['x'], c['m'], c['hout']
+        T, Bp, din = x.shape
+        H, P, ndir, B = self.H, self.P, self.ndir, c['batch']
+        dev = x.device
+        if c['mask'] is not None:
+            dout = ops.apply_mask(dout.contiguous(), c['mask'])
+        if Bp != B:
+            dout = torch.cat([dout, dout.new_zeros((T, Bp - B, ndir * P))], 1)
+        dout = dout.contiguous()
+        do2d, h2d, m2d = dout.view(T * Bp, ndir * P), hout.view(T * Bp, ndir * H), m.view(T * Bp, ndir * P)
+        dh = torch.empty((T, Bp, ndir * H), dtype=torch.float32, device=dev)
+        dcf = dhf = None
+        if d_final is not None and any(f is not None for f in d_final):
+            dcf = torch.zeros((ndir, Bp, H), dtype=torch.float32, device=dev)
+            dhf = torch.zeros((ndir, Bp, H), dtype=torch.float32, device=dev)
+        for d, b in enumerate(self.bases):
+            wp = st[b + '/projection/kernel']
+            ops.gemm(do2d[:, d * P:(d + 1) * P], wp, transB=True, out=dh.view(T * Bp, ndir * H)[:, d * H:(d + 1) * H])
+            if dcf is not None and d_final[d] is not None:
+                dcf[d, :B].copy_(d_final[d][0])
+                ops.gemm(d_final[d][1].contiguous(), wp, transB=True, out=dhf[d, :B])
+        dgates, dpeep = ops.lstm_bwd(dh, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H, ndir, ASR_F32,
+                                     dcf, dhf, want_dpeep=True, clip_no_grad=self.cell_clip or 0.0)
+        dg2d = dgates.view(T * Bp, ndir * 4 * H)
+        wx_cat = c['wx_cat']                                       # [din + P, ndir * 4H], dG's column order
+        dw_il = torch.empty((ndir, din + P, 4 * H), dtype=torch.float32, device=dev)
+        x2d = x.view(T * Bp, din)
+        lo, hi = slice(0, (T - 1) * Bp), slice(Bp, T * Bp)
+        for d, b in enumerate(self.bases):
+            dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
+            hd, md = h2d[:, d * H:(d + 1) * H], m2d[:, d * P:(d + 1) * P]
+            gp = st.g(b + '/projection/kernel')
+            ops.gemm(x2d, dg, transA=True, out=dw_il[d, :din])
+            ops.gemm(hd, do2d[:, d * P:(d + 1) * P], transA=True, out=gp)        # dW_p: the part through the emitted output
+            if dcf is not None and d_final[d] is not None:                       # ... and through the final m
+                ops.gemm(c['hf'][d, :B], d_final[d][1].contiguous(), transA=True, out=gp, accumulate=True)
+            if T > 1:
+                # the step after frame t is frame t+1 (forward direction) / t-1 (backward); dG and h are zero at padded
+                # frames, so the shifted products need no mask
+                prev, nxt = (lo, hi) if d == 0 else (hi, lo)
+                z = ops.gemm(dg, wx_cat[din:, d * 4 * H:(d + 1) * 4 * H], transB=True)   # Z = dG W_h^T  [T*Bp, P]
+                ops.gemm(md[prev], dg[nxt], transA=True, out=dw_il[d, din:])             # dW_h = m_prev^T dG
+                ops.gemm(hd[prev], z[nxt], transA=True, out=gp, accumulate=True)         # dW_p += h^T Z_next
+            else:
+                dw_il[d, din:].zero_()
+        ops.lstm_grad_finish(self._vars(st.g), dw_il, dpeep, H)
+        dx = None
+        if need_dx:
+            dx = ops.gemm(dg2d, wx_cat[:din], transB=True).view(T, Bp, din)
+            if Bp != B:
+                dx = dx[:, :B].contiguous()
+        self.grad_event = ops.stream_event()
+        self.ctx = None
+        return dx
+
     def forward(self, x, seq_len, mask=None, save=True):
         """x [T,B,din] fp32 time-major -> (out [T,B,ndir*P], per direction final (c [B,H], m [B,P]))."""
+        if self.fused():
+            return self._forward_fused(x, seq_len, mask, save)
         st = self.store
         T, B, din = x.shape
         H, P, ndir = self.H, self.P, self.ndir
@@ -346,6 +465,8 @@ class LSTMPLayer(object):
 
     def backward(self, dout, d_final=None, need_dx=True):
         """dout [T,B,ndir*P] fp32 -> dx [T,B,din] or None.  d_final: per direction (dc [B,H], dm [B,P]) or None."""
+        if self.ctx.get('fused'):
+            return self._backward_fused(dout, d_final, need_dx)
         c, st = self.ctx, self.store
         x = c['x']
         T, B, din = x.shape

@@ -805,6 +805,14 @@ def lstm_grad_finish(grads, dw_il, dpeep, H):
                                        1 if has_peep else 0, _s()), 'asr_lstm_grad_finish')
 
 
+LSTM_UNITS = (64, 128, 192, 256, 320, 512)   # include/asr_hip.h asr_lstm_fwd
+
+
+def lstm_units_supported(H):
+    """Whether asr_lstm_fwd / asr_lstm_bwd take num_units = H (callers with a step-by-step alternative ask first)."""
+    return int(H) in LSTM_UNITS
+
+
 def lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, cell_clip=0.0,
              want_final=True):
     """xproj [T,B,ndir*4H] fp32 (interleaved gate layout [T,B,ndir,H,4]).
@@ -828,7 +836,9 @@ def lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, c
 
 
 def lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c_final=None,
-             d_h_final=None, want_dpeep=True):
+             d_h_final=None, want_dpeep=True, clip_no_grad=0.0):
+    """clip_no_grad > 0 (fp32 only): the forward's cell_clip, for a cell whose clamp passes no gradient (LSTMCell's
+    tf.clip_by_value; LSTMBlockCell's clip is straight-through: 0)."""
     h = _h(dhout)
     _chk(dhout, torch.float32, 'dhout')
     T, B, _ = dhout.shape
@@ -838,9 +848,9 @@ def lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c
     if want_dpeep:
         dpeep = torch.empty((ndir, 7, H), dtype=torch.float32, device=dev)   # 3 peephole + 4 bias rows
         ws = torch.empty(((B // 16) * ndir * 7 * H,), dtype=torch.float32, device=dev)
-    h.check(h.lib.asr_lstm_bwd(h.h, dtype, T, B, H, ndir, _p(dhout), _p(gates), _p(cs),
-                               _p(wh_packed_bwd), _p(peep), _p(seq_len), _p(d_c_final), _p(d_h_final),
-                               _p(dgates), _p(dpeep), _p(ws), _s()), 'asr_lstm_bwd')
+    h.check(h.lib.asr_lstm_bwd_ex(h.h, dtype, T, B, H, ndir, _p(dhout), _p(gates), _p(cs),
+                                  _p(wh_packed_bwd), _p(peep), _p(seq_len), _p(d_c_final), _p(d_h_final),
+                                  float(clip_no_grad or 0.0), _p(dgates), _p(dpeep), _p(ws), _s()), 'asr_lstm_bwd')
     return dgates, dpeep
 
 

@@ -173,13 +173,9 @@ def _gate_deinterleave(src, dst, H):
     return dst
 
 
-def _lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, cell_clip=0.0, want_final=True):
-    T, B, G = xproj.shape
-    if G != ndir * 4 * H:
-        raise ValueError('xproj last dim %d != ndir*4H' % G)
-    sl = seq_len.long()
+def _lstm_graph(xproj, wh_packed, peep, sl, H, ndir, forget_bias, cell_clip, clip_blocks_gradient=False):
     eye = torch.eye(4 * H, dtype=F64)
-    runs, outs, cfs, hfs = [], [], [], []
+    runs = []
     for d in range(ndir):
         xp = xproj[:, :, d * 4 * H:(d + 1) * 4 * H].double().clone().requires_grad_(True)
         wh = wh_packed[d].view(H, 4 * H).double()
@@ -191,24 +187,38 @@ def _lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, 
             wci = wcf = wco = torch.zeros(H, dtype=F64)
         p = dict(w=torch.cat([eye, wh], 0), b=torch.zeros(4 * H, dtype=F64), wci=wci, wcf=wcf, wco=wco)
         out, (cf, hf) = olstm.dynamic_rnn(xp, sl, p, reverse=(d == 1), forget_bias=forget_bias,
-                                          cell_clip=cell_clip, use_peephole=peep is not None)
+                                          cell_clip=cell_clip, use_peephole=peep is not None,
+                                          clip_blocks_gradient=clip_blocks_gradient)
         runs.append(dict(xp=xp, pp=pp, out=out, cf=cf, hf=hf))
-        outs.append(out.detach())
-        cfs.append(cf.detach())
-        hfs.append(hf.detach())
+    return runs
+
+
+def _lstm_fwd(xproj, wh_packed, peep, seq_len, H, ndir, dtype, forget_bias=1.0, cell_clip=0.0, want_final=True):
+    T, B, G = xproj.shape
+    if G != ndir * 4 * H:
+        raise ValueError('xproj last dim %d != ndir*4H' % G)
+    sl = seq_len.long()
+    runs = _lstm_graph(xproj, wh_packed, peep, sl, H, ndir, forget_bias, cell_clip)
+    outs, cfs, hfs = ([r[k].detach() for r in runs] for k in ('out', 'cf', 'hf'))
     gates = torch.zeros((T, B, ndir * 4 * H))
     gates._runs = runs                       # the graph lstm_bwd differentiates (stand-in for the saved gates)
+    # what a gradient-blocking clip needs to build its own graph (asr_lstm_bwd_ex)
+    gates._again = (xproj, wh_packed, peep, sl, H, ndir, forget_bias, cell_clip)
     hout = torch.cat(outs, 2).float().contiguous()
     cs = torch.zeros((T, B, ndir * H))
     return gates, hout, cs, torch.stack(cfs).float(), torch.stack(hfs).float()
 
 
 def _lstm_bwd(dhout, gates, cs, wh_packed_bwd, peep, seq_len, H, ndir, dtype, d_c_final=None, d_h_final=None,
-              want_dpeep=True):
+              want_dpeep=True, clip_no_grad=0.0):
     T, B, _ = dhout.shape
     dgates = torch.zeros((T, B, ndir * 4 * H))
     dpeep = torch.zeros((ndir, 7, H)) if want_dpeep else None
-    for d, r in enumerate(gates._runs):
+    runs = gates._runs
+    if clip_no_grad and clip_no_grad > 0:    # LSTMCell's tf.clip_by_value: the same forward, a clamp that passes nothing back
+        assert abs(gates._again[-1] - clip_no_grad) < 1e-12, 'clip_no_grad must be the clip the forward applied'
+        runs = _lstm_graph(*gates._again, clip_blocks_gradient=True)
+    for d, r in enumerate(runs):
         outs = [r['out'], r['cf'], r['hf']]
         gos = [dhout[:, :, d * H:(d + 1) * H].double(),
                d_c_final[d].double() if d_c_final is not None else torch.zeros_like(r['cf']),
@@ -892,7 +902,7 @@ STAND_INS = dict(
     cast_from_f32=_cast_from_f32, cast_to_f32=_cast_to_f32, apply_mask=_apply_mask, dropout_mask=_dropout_mask,
     dropout_apply=_dropout_apply, maxpool2x2_relu_bwd=_maxpool2x2_relu_bwd, touch=lambda t: None,
     colsum=_colsum, gemm=_gemm, relu_bwd=_relu_bwd, lstm_prep_weights=_lstm_prep_weights,
-    gate_deinterleave=_gate_deinterleave, lstm_fwd=_lstm_fwd, lstm_bwd=_lstm_bwd, ctc_loss=_ctc_loss,
+    gate_deinterleave=_gate_deinterleave, lstm_fwd=_lstm_fwd, lstm_bwd=_lstm_bwd, lstm_units_supported=lambda H: True, ctc_loss=_ctc_loss,
     ctc_greedy_decode=_ctc_greedy_decode, softmax_rows=_softmax_rows, clip_by_norm_multi=_clip_by_norm_multi,
     weight_decay=_weight_decay, optimizer_step=_optimizer_step, scale_=_scale_,
     lstm_cell_fwd=_lstm_cell_fwd, lstm_cell_bwd=_lstm_cell_bwd, att_energy_fwd=_att_energy_fwd,

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_typed():
         assert hasattr(lib, n), 'libasr_hip.so does not export %s' % n
         assert n in _lib.SIGNATURES, 'ctypes binding misses %s' % n
     assert set(_lib.SIGNATURES) <= set(names), set(_lib.SIGNATURES) - set(names)
-    assert lib.asr_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.asr_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_no_cpu_fallback():

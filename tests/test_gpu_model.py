@@ -881,12 +881,19 @@ def test_cfgB_bf16_model_parity_at_the_benchmarked_shape(cuda):
     assert ler < 0.02, report[-1]
 
 
-@pytest.mark.parametrize('ndir,B,T,D,H,P,L', [(2, 6, 40, 24, 128, 48, 2), (1, 20, 25, 12, 64, 32, 2)])
-def test_lstmcell_projection_layers(cuda, ndir, B, T, D, H, P, L):
-    """lstm_impl='LSTMCell' with num_proj on the HIP path (rnn_util.LSTMPLayer: step-by-step fp32 on the generic
-    kernels -- skinny MFMA products, asr_lstm_cell_fwd / _bwd): loss 1e-4, logits, every gradient incl.
-    projection/kernel against the oracle's projected-cell model; trains.  Reference: blstm.py:187-230."""
+@pytest.mark.parametrize('ndir,B,T,D,H,P,L,fused', [
+    (2, 6, 40, 24, 128, 48, 2, '1'), (1, 20, 25, 12, 64, 32, 2, '1'), (2, 6, 40, 24, 128, 48, 2, '0'),
+    (1, 20, 25, 12, 64, 32, 2, '0'), (2, 19, 33, 24, 256, 50, 2, '1'), (2, 16, 21, 21, 320, 128, 1, '1'),
+    (2, 7, 17, 12, 192, 21, 2, '1')])
+def test_lstmcell_projection_layers(cuda, monkeypatch, ndir, B, T, D, H, P, L, fused):
+    """lstm_impl='LSTMCell' with num_proj on the HIP path, both forms of rnn_util.LSTMPLayer -- fused '1': the
+    whole-sequence recurrence kernels (clusters at 128 / 256 / 320) on W_p W_h with asr_lstm_bwd_ex's gradient-blocking
+    clip and every other product batched over T (batches that do not fill a 16-utterance tile, projection widths that
+    are not a multiple of 4); '0': step by step on the generic kernels (skinny MFMA products, asr_lstm_cell_fwd / _bwd).
+    Loss 1e-4, logits, every gradient incl. projection/kernel against the oracle's projected-cell model; trains.
+    Reference: blstm.py:187-230."""
     import _config_parity as cp
+    monkeypatch.setenv('ASR_LSTMP_FUSED', fused)
     r = cp.run_lstmp('cuda:0', B=B, T=T, D=D, H=H, P=P, L=L, C=9, ndir=ndir)
     assert r['trained']
     if ndir == 2:

@@ -209,7 +209,8 @@ def _lstm_case(rng, T, B, D, H, ndir, lens, init=0.3):
     return x, ps
 
 
-def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfinal=None, saved_fill=None):
+def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfinal=None, saved_fill=None,
+                   clip_no_grad=0.0):
     ops = _ops()
     from tensorflow_end2end_speech_recognition_amd._lib import ASR_BF16, ASR_F32
     dt = ASR_BF16 if dtype == 'bf16' else ASR_F32
@@ -244,20 +245,20 @@ def _run_hip_layer(cuda, x, ps, lens, H, ndir, dtype, cell_clip, dout=None, dfin
             dcf = torch.tensor(dfinal[0], dtype=torch.float32, device=cuda)
             dhf = torch.tensor(dfinal[1], dtype=torch.float32, device=cuda)
         dg, dpeep = ops.lstm_bwd(torch.tensor(dout, dtype=torch.float32, device=cuda), gates, cs, whb, peep, sl,
-                                 H, ndir, dt, dcf, dhf)
+                                 H, ndir, dt, dcf, dhf, clip_no_grad=clip_no_grad)
         # device layout [T,B,ndir,H,4] (gates interleaved) -> gate-major [T,B,ndir*4H] for the checks
         res['dgates'] = dg.float().view(T, B, ndir, H, 4).permute(0, 1, 2, 4, 3).reshape(T, B, ndir * 4 * H).cpu().numpy()
         res['dpeep'] = dpeep.cpu().numpy()
     return res
 
 
-def _oracle_layer(x, ps, lens, ndir, cell_clip, dout=None, dfinal=None):
+def _oracle_layer(x, ps, lens, ndir, cell_clip, dout=None, dfinal=None, clip_blocks_gradient=False):
     xt = torch.tensor(x).transpose(0, 1).contiguous().requires_grad_(True)
     sl = torch.tensor(lens, dtype=torch.long)
     for p in ps:
         for k in ('w', 'b', 'wci', 'wcf', 'wco'):
             p[k] = p[k].detach().clone().requires_grad_(True)
-    kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=True)
+    kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=True, clip_blocks_gradient=clip_blocks_gradient)
     outs, fins = [], []
     for d, p in enumerate(ps):
         o, f = olstm.dynamic_rnn(xt, sl, p, reverse=(d == 1), **kw)
@@ -310,6 +311,46 @@ def test_lstm_fwd_cell_clip(cuda):
     cmax = max(np.abs(got['cs'][:lens[b], b]).max() for b in range(B))
     assert cmax <= 0.5 + 1e-6 and cmax > 0.49   # clip active
     assert np.abs(got['hout'] - ref['hout']).max() < 5e-5
+
+
+@pytest.mark.parametrize('T,B,D,H,ndir', [(14, 16, 20, 64, 2), (14, 32, 20, 128, 2), (12, 32, 20, 256, 2), (10, 16, 20, 320, 1),
+                                          (10, 16, 16, 512, 2), (11, 16, 20, 192, 2)])
+def test_lstm_bwd_gradient_blocking_clip(cuda, T, B, D, H, ndir):
+    """asr_lstm_bwd_ex, clip_no_grad: tf.contrib.rnn.LSTMCell (the num_proj cell, reference blstm.py:187-230) clamps the
+    cell state with tf.clip_by_value -- a clamped state passes nothing to its gates or to c_prev, while the fused
+    LSTMBlockCell gradient is straight-through.  Every fp32 BPTT kernel (single-CU at 64 / 192, the clusters at 128 / 256 /
+    320 / 512) against the oracle's autograd through torch.clamp, an ACTIVE clip; the straight-through gradient of the same
+    case is measurably different, so the comparison means something."""
+    rng = np.random.RandomState(T * 13 + H)
+    lens = rng.randint(2, T + 1, size=B)
+    lens[0] = T
+    x, ps = _lstm_case(rng, T, B, D, H, ndir, lens, init=0.3 if H > 128 else 1.0)
+    x = x * 3
+    clip = 0.5
+    dout = rng.randn(T, B, ndir * H)
+    dfinal = (rng.randn(ndir, B, H) * 0.5, rng.randn(ndir, B, H) * 0.5)
+    got = _run_hip_layer(cuda, x, ps, lens, H, ndir, 'f32', clip, dout, dfinal, clip_no_grad=clip)
+    thru = _run_hip_layer(cuda, x, ps, lens, H, ndir, 'f32', clip, dout, dfinal)
+    ref = _oracle_layer(x, ps, lens, ndir, clip, dout, dfinal, clip_blocks_gradient=True)
+    clamped = np.mean([np.mean(np.abs(got['cs'][:lens[b], b]) >= clip) for b in range(B)])
+    assert 0.02 < clamped < 0.9, clamped
+    dg = got['dgates'].astype(np.float64)
+    xt = np.transpose(x, (1, 0, 2))
+    dx = np.zeros_like(xt)
+    for d, p in enumerate(ps):
+        g = dg[:, :, d * 4 * H:(d + 1) * 4 * H].reshape(T * B, 4 * H)
+        dx += (g @ p['w'].detach().numpy()[:D].T).reshape(T, B, D)
+        assert _rel(xt.reshape(T * B, D).T @ g, ref['dw'][d][:D]) < 1e-4
+        assert _rel(got['dpeep'][d, 3:7].reshape(-1), ref['db'][d]) < 1e-4
+    assert _rel(dx, ref['dx']) < 1e-4
+    assert _rel(got['dpeep'][:, :3], ref['dpeep']) < 1e-4
+    assert _rel(thru['dgates'], got['dgates']) > 1e-2      # the straight-through gradient is another one
+    for b in range(B):
+        if lens[b] < T:
+            assert np.abs(got['dgates'][lens[b]:, b]).max() == 0
+    # bf16 operands: refused, not silently straight-through
+    with pytest.raises(RuntimeError):
+        _run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', clip, dout, dfinal, clip_no_grad=clip)
 
 
 @pytest.mark.parametrize('T,B,D,H,ndir', LSTM_SHAPES)

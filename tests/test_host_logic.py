@@ -955,13 +955,16 @@ def test_bridge_classes_on_cpu_stand_ins(monkeypatch):
     assert r['fc_err'] < 1e-5 and r['ok_zero'] and r['ok_pass'] and r['raised'], r
 
 
-@pytest.mark.parametrize('ndir', [2, 1])
-def test_lstmcell_projection_host_logic(monkeypatch, ndir):
+@pytest.mark.parametrize('ndir,fused', [(2, '1'), (1, '1'), (2, '0'), (1, '0')])
+def test_lstmcell_projection_host_logic(monkeypatch, ndir, fused):
     """lstm_impl='LSTMCell' with num_proj (models/encoders/core/blstm.py:187-230, lstm.py): the projected cells of
     rnn_util.LSTMPLayer (recurrent input and output = m W_proj) against the oracle's LSTMP model -- loss, logits, every
-    gradient incl. projection/kernel -- with TF's variable names; the VGG front-end over projected cells raises."""
+    gradient incl. projection/kernel -- with TF's variable names; the VGG front-end over projected cells raises.
+    fused: the layer's two forms (the whole-sequence recurrence on W_p W_h with its batched products and the padded
+    16-utterance tile; the step-by-step loop), the host logic of both."""
     import _config_parity as cp
     _cpu_ops.install(monkeypatch)
+    monkeypatch.setenv('ASR_LSTMP_FUSED', fused)
     r = cp.run_lstmp('cpu', B=5, T=9, D=6, H=8, P=5, L=2, C=6, ndir=ndir)
     assert r['trained']
     if ndir == 2:
