@@ -32,6 +32,8 @@ and, at N = 1, the other BASELINE configurations timed with the same harness (a 
   decode                 greedy and prefix-beam CTC decode (TIMIT-61 width 20, kanji width 100) in utterances/s, the
                          oracle's restatement of the reference's numpy decoders timed beside them on one core;
   bgru                   the reference's GRU encoder family: bgru 2x256 CTC (fp32) on the headline batch;
+  blstmp                 the reference's projected cells (lstm_impl='LSTMCell', num_proj): blstm 5x256 proj 128 CTC (fp32)
+                         on the headline batch;
   input_width_D39, batch_scaling   the headline model at the other input width / at B = 32 .. 128 per GPU.
 """
 import argparse
@@ -925,9 +927,10 @@ def compact_line(out, limit=COMPACT_LIMIT):
     if out.get('decode') is not None:
         c['decode'] = _compact_decode(out['decode']) if 'error' not in out['decode'] and 'skipped' not in out['decode'] \
             else _compact_aux(out['decode'])
-    if isinstance(out.get('bgru'), dict):
-        g = out['bgru']
-        c['bgru'] = {k: g.get(k) for k in ('value', 'ms_per_step', 'cluster_handoff_flags')} if 'value' in g else _compact_aux(g)
+    for key in ('bgru', 'blstmp'):
+        if isinstance(out.get(key), dict):
+            g = out[key]
+            c[key] = {k: g.get(k) for k in ('value', 'ms_per_step', 'cluster_handoff_flags')} if 'value' in g else _compact_aux(g)
     bs = out.get('batch_scaling')
     if isinstance(bs, dict):
         c['batch_scaling'] = [[r.get('batch'), r.get('value'), r.get('ms_per_step')] for r in bs.get('rows', [])] \
@@ -949,7 +952,7 @@ def compact_line(out, limit=COMPACT_LIMIT):
     line = json.dumps(c, separators=(',', ':'))
     # shed optional detail, least important first, until the line fits
     for drop in (('batch_scaling',), ('input_width_D39',), ('headline_f32', 'kernel_us'), ('headline_f32', 'cpu_baseline'),
-                 ('cfgA', 'kernel_us'), ('cfgE', 'kernel_us'), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('bgru',),
+                 ('blstmp',), ('cfgA', 'kernel_us'), ('cfgE', 'kernel_us'), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('bgru',),
                  ('decode',), ('per_rank',), ('h2d_inclusive',), ('other_padding',),
                  ('cfgC', 'groups'), ('headline_f32',), ('cfgE',), ('cfgD',), ('cfgC',), ('cfgA',), ('comm',)):
         if len(line) <= limit:
@@ -1067,7 +1070,7 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-cfgA', action='store_true')
     ap.add_argument('--no-aux', action='store_true', help='skip cfgC / cfgD / cfgE / decode / input width / batch scaling')
-    ap.add_argument('--aux', default='f32,cfgC,cfgD,cfgE,decode,gru,D39,batch', help='which auxiliary entries to run (N = 1)')
+    ap.add_argument('--aux', default='f32,cfgC,cfgD,cfgE,decode,gru,lstmp,D39,batch', help='which auxiliary entries to run (N = 1)')
     ap.add_argument('--aux-steps', type=int, default=5)
     ap.add_argument('--aux-warmup', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=2)
@@ -1282,6 +1285,33 @@ def main():
                 del mg, xg_, sg_
             except Exception as e:
                 out['bgru'] = dict(error=repr(e)[:400])
+            torch.cuda.empty_cache()
+        if 'lstmp' in aux and not over_budget('blstmp'):
+            # lstm_impl='LSTMCell' with num_proj (the reference's projected cells, blstm.py:187-230) on the headline shard:
+            # blstm 5 x 256, projection 128, fp32 -- the whole-sequence recurrence kernels on W_p W_h (round 6)
+            log('blstmp ...')
+            try:
+                from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+                xb, slb, _, denseb = make_batch(wl['seed'], wl['batch'], wl['input_size'], wl['classes'] + 1, wl['tmin'], wl['tmax'])
+                xp_, sp_ = torch.tensor(xb, device=dev), torch.tensor(slb, device=dev)
+                mp_ = CTC('blstm', wl['input_size'], 256, 5, wl['classes'], lstm_impl='LSTMCell', num_proj=128, clip_grad_norm=5.0,
+                          clip_activation=50.0, seed=0, device=str(dev))
+                for _ in range(3):
+                    lp_, _ = mp_.compute_loss(xp_, denseb, sp_, keep_prob=wl['keep_prob'])
+                    mp_.train(lp_, 'rmsprop', 1e-3)
+                torch.cuda.synchronize()
+                tp0 = time.perf_counter()
+                for _ in range(10):
+                    lp_, _ = mp_.compute_loss(xp_, denseb, sp_, keep_prob=wl['keep_prob'])
+                    mp_.train(lp_, 'rmsprop', 1e-3)
+                torch.cuda.synchronize()
+                tp = (time.perf_counter() - tp0) / 10
+                out['blstmp'] = dict(workload='blstm 5x256 LSTMCell num_proj 128 CTC fp32 on the headline batch (B=%d, T<=%d), train step'
+                                     % (wl['batch'], wl['tmax']), value=float(slb.sum()) / tp, unit='frames/s', ms_per_step=tp * 1e3,
+                                     dtype='f32', steps=10, final_loss=float(lp_.item()), cluster_handoff_flags=ops_flags(dev_index))
+                del mp_, xp_, sp_
+            except Exception as e:
+                out['blstmp'] = dict(error=repr(e)[:400])
             torch.cuda.empty_cache()
         if 'batch' in aux and not over_budget('batch_scaling'):
             log('batch scaling ...')

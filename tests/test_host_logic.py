@@ -1035,9 +1035,12 @@ def test_bench_compact_line_fits_the_drivers_window():
     # decode figures stay on the line (the input-width / batch-size extras are what gives way first)
     r6 = json.load(open(os.path.join(root, 'profiles', 'r06_bench_default.json')))
     r6['headline_f32'] = dict(r6['cfgA'], workload='the headline shard with fp32 operands', value=5.1e5, ms_per_step=12.5)
+    r6['blstmp'] = dict(workload='blstm 5x256 LSTMCell num_proj 128', value=3.02e5, ms_per_step=21.2, unit='frames/s',
+                        cluster_handoff_flags=0, final_loss=1000.0)
     l6 = bench.compact_line(dict(r6, full='bench_full.json'))
     d6 = json.loads(l6)
     assert len(l6) < 6000 and d6['headline_f32']['value'] == 5.1e5
+    assert d6['blstmp'] in ('see full', dict(value=3.02e5, ms_per_step=21.2, cluster_handoff_flags=0))
     assert d6['headline_f32']['parity']['greedy_label_mismatch'] == r6['cfgA']['parity']['greedy_label_mismatch']
     assert d6['decode']['kanji3387_beam100']['beam']['ms_per_call'] > 0 and d6['cfgE']['value'] > 0
     # N = 8: per-rank tables and the communication summary ride on the same line
