@@ -952,7 +952,7 @@ def compact_line(out, limit=COMPACT_LIMIT):
     line = json.dumps(c, separators=(',', ':'))
     # shed optional detail, least important first, until the line fits
     for drop in (('batch_scaling',), ('input_width_D39',), ('headline_f32', 'kernel_us'), ('headline_f32', 'cpu_baseline'),
-                 ('blstmp',), ('cfgA', 'kernel_us'), ('cfgE', 'kernel_us'), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('bgru',),
+                 ('cfgA', 'kernel_us'), ('cfgE', 'kernel_us'), ('cfgC', 'kernel_us'), ('cfgD', 'kernel_us'), ('blstmp',), ('bgru',),
                  ('decode',), ('per_rank',), ('h2d_inclusive',), ('other_padding',),
                  ('cfgC', 'groups'), ('headline_f32',), ('cfgE',), ('cfgD',), ('cfgC',), ('cfgA',), ('comm',)):
         if len(line) <= limit:

@@ -904,6 +904,58 @@ def test_lstmcell_projection_layers(cuda, monkeypatch, ndir, B, T, D, H, P, L, f
         assert rc['loss_rel'] < 1e-4 and rc['grad_worst'] < 2e-3, rc['report']
 
 
+@pytest.mark.parametrize('ndir,B,T,D,H,P,clip', [(2, 21, 30, 18, 128, 40, 0.4), (1, 16, 19, 12, 256, 64, None)])
+def test_projected_layer_fused_against_step_by_step_with_final_state_gradients(cuda, monkeypatch, ndir, B, T, D, H, P, clip):
+    """One rnn_util.LSTMPLayer, its two forms side by side on the same variables: outputs, final (c, m) states, dx and every
+    weight gradient -- with gradients arriving through the FINAL states as well (d_final; the CTC models never send one,
+    an attention bridge over projected cells would), an active gradient-blocking clip, a batch that does not fill its
+    last 16-utterance tile, a dropout mask on the output.  (Weights of +-0.2: at +-0.5 and 256 units the recurrence is
+    chaotic -- the two forms, which differ by fp32 rounding only, drift apart by a factor of ten every five steps, measured
+    5e-7 at step 1 and 5e-2 at step 30 -- and the comparison would say nothing.)"""
+    from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
+    from tensorflow_end2end_speech_recognition_amd import ops
+    m = CTC(encoder_type='blstm' if ndir == 2 else 'lstm', input_size=D, num_units=H, num_layers=1, num_classes=7,
+            lstm_impl='LSTMCell', num_proj=P, parameter_init=0.2, clip_activation=clip, seed=3, device='cuda:0')
+    layer = m.encoder.layers[0]
+    st = layer.store
+    rng = np.random.RandomState(B + H)
+    sl_np = rng.randint(1, T + 1, size=B).astype(np.int32)
+    sl_np[0], sl_np[-1] = T, 0
+    x = torch.tensor(rng.randn(T, B, D) * 1.5, dtype=torch.float32, device=cuda)
+    sl = torch.tensor(sl_np, device=cuda)
+    mask = torch.tensor((rng.rand(T, B, ndir * P) < 0.8) / 0.8, dtype=torch.float32, device=cuda)
+    dout = torch.tensor(rng.randn(T, B, ndir * P), dtype=torch.float32, device=cuda)
+    dfin = [(torch.tensor(rng.randn(B, H) * 0.5, dtype=torch.float32, device=cuda),
+             torch.tensor(rng.randn(B, P) * 0.5, dtype=torch.float32, device=cuda)) for _ in range(ndir)]
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('ASR_LSTMP_FUSED', mode)
+        assert layer.fused() == (mode == '1')
+        out, fin = layer.forward(x, sl, mask)
+        dx = layer.backward(dout, dfin, need_dx=True)
+        ops.join_side(cuda)
+        torch.cuda.synchronize()
+        res[mode] = dict(out=out.clone(), dx=dx.clone(), fin=[(c.clone(), mm.clone()) for c, mm in fin],
+                         g={n: st.g(n).clone() for n in layer.var_names()})
+    def rel(a, b):
+        return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+    f, s_ = res['1'], res['0']
+    assert rel(f['out'], s_['out']) < 2e-5 and rel(f['dx'], s_['dx']) < 2e-4
+    for d in range(ndir):
+        assert rel(f['fin'][d][0], s_['fin'][d][0]) < 2e-5 and rel(f['fin'][d][1], s_['fin'][d][1]) < 2e-5
+    worst = max((rel(f['g'][n], s_['g'][n]), n) for n in f['g'])
+    assert worst[0] < 2e-4, worst
+    if clip:     # the clip was active
+        monkeypatch.setenv('ASR_LSTMP_FUSED', '1')
+        layer.forward(x, sl, None)
+        cs = layer.ctx['cs'][:, :B]
+        live = (torch.arange(T, device=cuda).unsqueeze(1) < sl.unsqueeze(0)).unsqueeze(2)
+        frac = float(((cs.abs() >= clip) & live).float().sum() / (live.float().sum() * cs.shape[2]))
+        assert 0.02 < frac < 0.9, frac
+        layer.ctx = None
+    assert float(f['out'][:, -1].abs().max()) == 0 and float(f['dx'][:, -1].abs().max()) == 0   # the empty utterance
+
+
 def test_gru_long_run_keeps_side_lane_bounded_and_survives_poisoned_allocator(cuda):
     """Two regressions of the GRU encoders found in review: (1) the model's head gradients are issued on side lane 1 and
     must be joined (ordered before clip / update, and the lane's keep list released) by the encoder's backward -- 60
