@@ -15,7 +15,7 @@ for line in r.stderr.split('\n'):
         print(line)
     m = re.search(r'Function Name: (\S+)', line)
     if m:
-        cur = {'name': subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip()[:90]}
+        cur = {'name': subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip()[:150]}
         rows.append(cur)
         continue
     for key in ('VGPRs', 'AGPRs', 'VGPRs Spill', 'ScratchSize [bytes/lane]', 'Occupancy [waves/SIMD]', 'SGPRs'):
