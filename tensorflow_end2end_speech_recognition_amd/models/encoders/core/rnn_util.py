@@ -380,33 +380,46 @@ class LSTMPLayer(object):
                                      dcf, dhf, want_dpeep=True, clip_no_grad=self.cell_clip or 0.0)
         dg2d = dgates.view(T * Bp, ndir * 4 * H)
         wx_cat = c['wx_cat']                                       # [din + P, ndir * 4H], dG's column order
-        dw_il = torch.empty((ndir, din + P, 4 * H), dtype=torch.float32, device=dev)
-        x2d = x.view(T * Bp, din)
-        lo, hi = slice(0, (T - 1) * Bp), slice(Bp, T * Bp)
-        for d, b in enumerate(self.bases):
-            dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
-            hd, md = h2d[:, d * H:(d + 1) * H], m2d[:, d * P:(d + 1) * P]
-            gp = st.g(b + '/projection/kernel')
-            ops.gemm(x2d, dg, transA=True, out=dw_il[d, :din])
-            ops.gemm(hd, do2d[:, d * P:(d + 1) * P], transA=True, out=gp)        # dW_p: the part through the emitted output
-            if dcf is not None and d_final[d] is not None:                       # ... and through the final m
-                ops.gemm(c['hf'][d, :B], d_final[d][1].contiguous(), transA=True, out=gp, accumulate=True)
-            if T > 1:
-                # the step after frame t is frame t+1 (forward direction) / t-1 (backward); dG and h are zero at padded
-                # frames, so the shifted products need no mask
-                prev, nxt = (lo, hi) if d == 0 else (hi, lo)
-                z = ops.gemm(dg, wx_cat[din:, d * 4 * H:(d + 1) * 4 * H], transB=True)   # Z = dG W_h^T  [T*Bp, P]
-                ops.gemm(md[prev], dg[nxt], transA=True, out=dw_il[d, din:])             # dW_h = m_prev^T dG
-                ops.gemm(hd[prev], z[nxt], transA=True, out=gp, accumulate=True)         # dW_p += h^T Z_next
-            else:
-                dw_il[d, din:].zero_()
-        ops.lstm_grad_finish(self._vars(st.g), dw_il, dpeep, H)
+        # ONE marker behind the BPTT kernel; the main stream carries only what the layer below waits for (dx), the weight
+        # gradients run on side lanes (one per direction) beside it and beside the layer below's recurrence -- the encoder's
+        # backward joins the lanes before the clip (as LSTMLayer / GRULayer)
+        fork = ops.stream_event()
         dx = None
         if need_dx:
             dx = ops.gemm(dg2d, wx_cat[:din], transB=True).view(T, Bp, din)
             if Bp != B:
                 dx = dx[:, :B].contiguous()
-        self.grad_event = ops.stream_event()
+        dw_il = torch.empty((ndir, din + P, 4 * H), dtype=torch.float32, device=dev)
+        x2d = x.view(T * Bp, din)
+        lo, hi = slice(0, (T - 1) * Bp), slice(Bp, T * Bp)
+        held = (x, m, hout, dout, dgates, dpeep, dw_il, wx_cat, c['hf']) + \
+            tuple(t for f in (d_final or ()) if f is not None for t in f)
+        done = []
+        for d, b in enumerate(self.bases):
+            with ops.side_lane(dev, keep=held, lane=1 + (d % 2), after=fork):
+                dg = dg2d[:, d * 4 * H:(d + 1) * 4 * H]
+                hd, md = h2d[:, d * H:(d + 1) * H], m2d[:, d * P:(d + 1) * P]
+                gp = st.g(b + '/projection/kernel')
+                ops.gemm(x2d, dg, transA=True, out=dw_il[d, :din])
+                ops.gemm(hd, do2d[:, d * P:(d + 1) * P], transA=True, out=gp)    # dW_p: the part through the emitted output
+                if dcf is not None and d_final[d] is not None:                   # ... and through the final m
+                    ops.gemm(c['hf'][d, :B], d_final[d][1].contiguous(), transA=True, out=gp, accumulate=True)
+                if T > 1:
+                    # the step after frame t is frame t+1 (forward direction) / t-1 (backward); dG and h are zero at padded
+                    # frames, so the shifted products need no mask
+                    prev, nxt = (lo, hi) if d == 0 else (hi, lo)
+                    z = ops.gemm(dg, wx_cat[din:, d * 4 * H:(d + 1) * 4 * H], transB=True)   # Z = dG W_h^T  [T*Bp, P]
+                    ops.gemm(md[prev], dg[nxt], transA=True, out=dw_il[d, din:])             # dW_h = m_prev^T dG
+                    ops.gemm(hd[prev], z[nxt], transA=True, out=gp, accumulate=True)         # dW_p += h^T Z_next
+                else:
+                    dw_il[d, din:].zero_()
+                if d % 2 > 0:
+                    done.append(ops.stream_event())
+        with ops.side_lane(dev, lane=1, after=fork):
+            for ev in done:
+                ops.wait_event(ev)
+            ops.lstm_grad_finish(self._vars(st.g), dw_il, dpeep, H)
+            self.grad_event = ops.stream_event()
         self.ctx = None
         return dx
 
