@@ -325,7 +325,7 @@ int asr_lstm_bwd(asr_handle* h, int dtype, int T, int B, int H, int ndir,
  * straight-through).  > 0 = the forward ran with cell_clip = clip_no_grad and the cell is tf.contrib.rnn.LSTMCell
  * (models/encoders/core/blstm.py:187-230 of the reference, the num_proj cell), whose tf.clip_by_value passes NO gradient
  * through a clamped state: a frame whose saved cs has |c| >= clip_no_grad sends nothing to its gates or to c_prev
- * (its output gate still receives its gradient).  fp32 operands only (ASR_ERR_UNSUPPORTED otherwise). */
+ * (its output gate still receives its gradient).  Either operand dtype. */
 int asr_lstm_bwd_ex(asr_handle* h, int dtype, int T, int B, int H, int ndir,
                     const float* dhout, const void* gates, const float* cs,
                     const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,

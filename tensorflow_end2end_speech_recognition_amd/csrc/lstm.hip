@@ -956,7 +956,7 @@ static int lstm_bwd_impl(asr_handle* h, int dtype, int T, int B, int H, int ndir
 
 // clip_no_grad > 0: the forward ran with cell_clip = clip_no_grad and the cell is tf.contrib.rnn.LSTMCell, whose
 // tf.clip_by_value passes no gradient through a clamped state (LSTMBlockCell's fused gradient op does not know the
-// clip: asr_lstm_bwd, clip_no_grad = 0).  fp32 operands only.
+// clip: asr_lstm_bwd, clip_no_grad = 0).
 extern "C" int asr_lstm_bwd_ex(asr_handle* h, int dtype, int T, int B, int H, int ndir,
                                const float* dhout, const void* gates, const float* cs,
                                const void* wh_packed_bwd, const float* peep, const int32_t* seq_len,
@@ -964,8 +964,6 @@ extern "C" int asr_lstm_bwd_ex(asr_handle* h, int dtype, int T, int B, int H, in
                                float* dpeep, float* dpeep_workspace, asr_stream s) {
   if (!h) return ASR_ERR_INVALID_ARG;
   if (!(clip_no_grad >= 0.f)) ASR_FAIL(h, ASR_ERR_INVALID_ARG, "asr_lstm_bwd_ex: clip_no_grad must be >= 0");
-  if (clip_no_grad > 0.f && dtype != ASR_F32)
-    ASR_FAIL(h, ASR_ERR_UNSUPPORTED, "asr_lstm_bwd_ex: a gradient-blocking clip is implemented for fp32 operands");
   h->bptt_clip = clip_no_grad;   // the cluster launchers (lstm_cluster.hip) read it
   const int rc = lstm_bwd_impl(h, dtype, T, B, H, ndir, dhout, gates, cs, wh_packed_bwd, peep, seq_len, d_c_final,
                                d_h_final, clip_no_grad, dgates, dpeep, dpeep_workspace, s);

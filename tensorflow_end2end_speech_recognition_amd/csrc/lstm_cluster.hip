@@ -664,13 +664,15 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_fwd_cluster8_kernel(
 // poll loop does not wait for valid tags, 1: no A-fragment reads from LDS, 2: no MFMAs, 3: no gate-gradient math, 4: no
 // dgates store to memory, 5: no barrier, 6: no fetch of the saved activations, 7: no publish stores, 8: no dG write to
 // LDS, 9: no poll loads at all.
-template <int H, bool DBG, int HSU = 64, int PIN = -1, bool XP = true, int ABL = 0>
+// CLIPZ (asr_lstm_bwd_ex with bf16 operands, the projected LSTMCell layers): a state whose saved cs has |c| >= clipz passes no
+// gradient to its gates or to c_prev (tf.clip_by_value); its own instantiations -- the default kernels' code does not change.
+template <int H, bool DBG, int HSU = 64, int PIN = -1, bool XP = true, int ABL = 0, bool CLIPZ = false>
 __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
     int T_, int B_, int ndir, const float* __restrict__ dhout, const cbf16x4_t* __restrict__ gates,
     const float* __restrict__ cs, const bf16_t* __restrict__ whpb, const float* __restrict__ peep,
     const int32_t* __restrict__ seq_len, const float* __restrict__ d_c_final,
     const float* __restrict__ d_h_final, cbf16x4_t* __restrict__ dgates, float* __restrict__ dpeep_part,
-    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords) {
+    u64* __restrict__ xch, unsigned* __restrict__ err, int kflags, u64* __restrict__ znext, unsigned zwords, float clipz) {
   zero_next_area(znext, zwords);
   constexpr int PINM = PIN >= 0 ? PIN : ((HSU == 32 && H <= 320) ? (15 | 64) : 0);   // (H = 320 on eight waves: 1089 -> 1216 us with pins)
   constexpr int G = H / HSU;
@@ -975,7 +977,8 @@ __global__ __launch_bounds__(HSU * 8, 1) void lstm_bwd_cluster8_kernel(
         dhr[r] = 0.f;
       } else {
       const float d_o = dh * a_o[r];
-      const float dc = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float dct = dcr[r] + dh * b_c[r] + d_o * wco;
+      const float dc = (CLIPZ && fabsf(curv[r]) >= clipz) ? 0.f : dct;
       const float d_g = dc * c_g[r], d_i = dc * c_i[r], d_f = dc * c_f[r];
       dcr[r] = act[r] ? (dc * gf[r] + d_i * wci + d_f * wcf) : dcr[r];
       dhr[r] = act[r] ? 0.f : dhr[r];
@@ -3274,6 +3277,8 @@ static bool cluster_bwd_launch(asr_handle* h, int T, int B, int ndir, const floa
   const bool xp = bwd_xp_enabled(HSU);
   auto k = g_cdbg_host ? (xp ? lstm_bwd_cluster8_kernel<H, true, HSU, -1, true> : lstm_bwd_cluster8_kernel<H, true, HSU, -1, false>)
                        : (xp ? lstm_bwd_cluster8_kernel<H, false, HSU, -1, true> : lstm_bwd_cluster8_kernel<H, false, HSU, -1, false>);
+  if (h->bptt_clip > 0.f)   // asr_lstm_bwd_ex: the gradient-blocking clip of the projected LSTMCell layers
+    k = xp ? lstm_bwd_cluster8_kernel<H, false, HSU, -1, true, 0, true> : lstm_bwd_cluster8_kernel<H, false, HSU, -1, false, 0, true>;
 #ifdef ASR_LSTM_ABLATE
   if constexpr (HSU == 32 && H == 512) {
     if (const char* e = getenv("ASR_LSTM_ABL_BWD")) {
@@ -3299,7 +3304,8 @@ static bool cluster_bwd_launch(asr_handle* h, int T, int B, int ndir, const floa
 #endif
   hipLaunchKernelGGL(k, dim3(cluster_grid(G, ncl)), dim3(HSU * 8), lds, st, T, B, ndir, dhout,
                      (const cbf16x4_t*)gates, cs, (const bf16_t*)whpb, peep, seq_len, dcf, dhf,
-                     (cbf16x4_t*)dgates, dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords);
+                     (cbf16x4_t*)dgates, dpeep_part, xa.area, (unsigned*)base, kernel_flags(), xa.znext, xa.zwords,
+                     h->bptt_clip);
   return true;
 }
 

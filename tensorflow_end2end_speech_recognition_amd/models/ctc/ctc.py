@@ -93,8 +93,10 @@ class CTC(ModelBase):
         self.time_major = time_major
         self.name = encoder_type + '_ctc'
         self.dtype = ops.dtype_id(dtype)
+        self._requested_dtype = self.dtype               # the projected layers' operand dtype (rnn_util.LSTMPLayer)
         if encoder_type in ('gru', 'bgru') or (lstm_impl == 'LSTMCell' and self.num_proj is not None):
-            self.dtype = ASR_F32                         # the GRU / projected-LSTM recurrences are fp32: the heads follow
+            # the GRU recurrences are fp32 and the projected-LSTM layers take and return fp32: the heads follow
+            self.dtype = ASR_F32
         self.device = torch.device(device)
         self._dropout_calls = 0
         self.seed = seed
@@ -119,7 +121,7 @@ class CTC(ModelBase):
             return load(encoder_type)(
                 num_units=num_units, num_proj=self.num_proj, num_layers=num_layers,
                 lstm_impl=lstm_impl, use_peephole=use_peephole, parameter_init=parameter_init,
-                clip_activation=clip_activation, time_major=True, dtype=self.dtype)
+                clip_activation=clip_activation, time_major=True, dtype=self._requested_dtype)
         if encoder_type in ['vgg_blstm', 'vgg_lstm', 'cldnn_wang']:
             return load(encoder_type)(
                 input_size=input_size, splice=splice, num_stack=num_stack, num_units=num_units,

@@ -70,8 +70,9 @@ class _RecurrentEncoderBase(object):
         self.time_major = time_major
         self.name = name
         self.dtype = ops.dtype_id(dtype)
+        self.layer_dtype = self.dtype                # what the caller asked for: the projected layers' operand dtype
         if self.num_proj is not None:
-            self.dtype = ASR_F32                     # the projected cells run on the step-by-step fp32 kernels
+            self.dtype = ASR_F32                     # the projected layers take and return fp32 (rnn_util.LSTMPLayer)
         self.seed = seed
         self.layers = None
         self.store = None
@@ -96,7 +97,8 @@ class _RecurrentEncoderBase(object):
             P = int(self.num_proj)
             for i in range(1, self.num_layers + 1):
                 bases = self._declare_projected(store, i, din, P, rng)
-                self.layers.append(LSTMPLayer(store, bases, din, H, P, self.use_peephole, 1.0, self.clip_activation))
+                self.layers.append(LSTMPLayer(store, bases, din, H, P, self.use_peephole, 1.0, self.clip_activation,
+                                              dtype=self.layer_dtype))
                 din = self.ndir * P
             self.output_dim = self.ndir * P
             return self.output_dim

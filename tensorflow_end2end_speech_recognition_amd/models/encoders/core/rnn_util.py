@@ -268,10 +268,13 @@ def declare_lstmp_vars(store, scope, din, H, P, ndir, use_peephole, parameter_in
 
 
 class LSTMPLayer(object):
-    def __init__(self, store, bases, din, H, P, use_peephole, forget_bias=1.0, cell_clip=None):
+    def __init__(self, store, bases, din, H, P, use_peephole, forget_bias=1.0, cell_clip=None, dtype=ASR_F32):
         self.store, self.bases = store, bases
         self.ndir = len(bases)
         self.din, self.H, self.P = din, H, P
+        # operand dtype of the fused path's GEMMs and recurrences (the layer's inputs, outputs and gradients stay fp32 at its
+        # boundary; the step-by-step path is fp32 throughout)
+        self.dtype = dtype
         self.use_peephole = use_peephole
         self.forget_bias, self.cell_clip = forget_bias, cell_clip
         self.ctx = None
@@ -316,6 +319,15 @@ class LSTMPLayer(object):
         """The recurrence on W' = W_p W_h through asr_lstm_fwd / asr_lstm_bwd_ex (see the comment above the class)."""
         return _os.environ.get('ASR_LSTMP_FUSED', '1') != '0' and ops.lstm_units_supported(self.H)
 
+    def operand_dtype(self):
+        """bf16 operands (a bf16 model: the headline's recurrence kernels, W' = W_p W_h rounded once like every other weight
+        image) when the slices the batched products address are 16-byte aligned in bf16; fp32 otherwise and under
+        ASR_LSTMP_BF16=0 (A/B)."""
+        if self.dtype == ASR_BF16 and self.din % 8 == 0 and self.P % 8 == 0 and \
+                _os.environ.get('ASR_LSTMP_BF16', '1') != '0':
+            return ASR_BF16
+        return ASR_F32
+
     def _forward_fused(self, x, seq_len, mask, save):
         st = self.store
         T, B, din = x.shape
@@ -325,7 +337,9 @@ class LSTMPLayer(object):
         if Bp != B:   # the recurrence kernels work on 16-utterance tiles: rows of length 0 fill the last one
             x = torch.cat([x, x.new_zeros((T, Bp - B, din))], 1)
             seq_len = torch.cat([seq_len, seq_len.new_zeros((Bp - B,))])
-        x = x.contiguous()
+        dt = self.operand_dtype()
+        lo = dt != ASR_F32
+        x = ops.cast_from_f32(x.contiguous(), dt) if lo else x.contiguous()
         # the layer as a plain cell over the input [x, m_prev-as-input-columns]: kernel rows [W_x; W_h; W'] -- the prep
         # launch then also yields W_h in the interleaved gate layout the BPTT kernel's dG has (columns din.. of wx_cat)
         rows = []
@@ -334,23 +348,25 @@ class LSTMPLayer(object):
             kf[:din + P].copy_(v[0])
             ops.gemm(st[b + '/projection/kernel'], v[0][din:], out=kf[din + P:])                 # W' = W_p W_h
             rows.append((kf,) + v[1:])
-        prep = ops.lstm_prep_layer(rows, din + P, H, ASR_F32)
+        prep = ops.lstm_prep_layer(rows, din + P, H, dt)
         xproj = torch.empty((T, Bp, ndir * 4 * H), dtype=torch.float32, device=dev)
         ops.gemm(x.view(T * Bp, din), prep['wxT'][:, :din], transB=True, bias=prep['bias'],
                  out=xproj.view(T * Bp, ndir * 4 * H))
-        gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, prep['whf'], prep['peep'], seq_len, H, ndir, ASR_F32,
+        gates, hout, cs, cf, hf = ops.lstm_fwd(xproj, prep['whf'], prep['peep'], seq_len, H, ndir, dt,
                                                self.forget_bias, self.cell_clip or 0.0)
-        m = torch.empty((T, Bp, ndir * P), dtype=torch.float32, device=dev)
-        finals = []
+        m = torch.empty((T, Bp, ndir * P), dtype=hout.dtype, device=dev)      # (bf16 operands: rounded as LSTMLayer's h is)
+        finals, wps = [], []
         for d, b in enumerate(self.bases):
             wp = st[b + '/projection/kernel']
-            ops.gemm(hout.view(T * Bp, ndir * H)[:, d * H:(d + 1) * H], wp, out=m.view(T * Bp, ndir * P)[:, d * P:(d + 1) * P])
+            wps.append(ops.cast_from_f32(wp, dt) if lo else wp)
+            ops.gemm(hout.view(T * Bp, ndir * H)[:, d * H:(d + 1) * H], wps[d], out=m.view(T * Bp, ndir * P)[:, d * P:(d + 1) * P])
             finals.append((cf[d, :B], ops.gemm(hf[d], wp)[:B]))
-        out = m[:, :B].contiguous() if Bp != B else m
+        mo = ops.cast_to_f32(m) if lo else m
+        out = mo[:, :B].contiguous() if Bp != B else mo
         res = out if mask is None else ops.apply_mask(out, mask)
         if save:
             self.ctx = dict(fused=True, x=x, m=m, hout=hout, hf=hf, gates=gates, cs=cs, whb=prep['whb'], peep=prep['peep'],
-                            wx_cat=prep['wx_cat'], seq_len=seq_len, mask=mask, batch=B)
+                            wx_cat=prep['wx_cat'], seq_len=seq_len, mask=mask, batch=B, dt=dt, wps=wps)
         return res, finals
 
     def _backward_fused(self, dout, d_final, need_dx):
@@ -363,7 +379,9 @@ class LSTMPLayer(object):
             dout = ops.apply_mask(dout.contiguous(), c['mask'])
         if Bp != B:
             dout = torch.cat([dout, dout.new_zeros((T, Bp - B, ndir * P))], 1)
-        dout = dout.contiguous()
+        dt, wps = c['dt'], c['wps']
+        lo = dt != ASR_F32
+        dout = ops.cast_from_f32(dout.contiguous(), dt) if lo else dout.contiguous()
         do2d, h2d, m2d = dout.view(T * Bp, ndir * P), hout.view(T * Bp, ndir * H), m.view(T * Bp, ndir * P)
         dh = torch.empty((T, Bp, ndir * H), dtype=torch.float32, device=dev)
         dcf = dhf = None
@@ -372,11 +390,11 @@ class LSTMPLayer(object):
             dhf = torch.zeros((ndir, Bp, H), dtype=torch.float32, device=dev)
         for d, b in enumerate(self.bases):
             wp = st[b + '/projection/kernel']
-            ops.gemm(do2d[:, d * P:(d + 1) * P], wp, transB=True, out=dh.view(T * Bp, ndir * H)[:, d * H:(d + 1) * H])
+            ops.gemm(do2d[:, d * P:(d + 1) * P], wps[d], transB=True, out=dh.view(T * Bp, ndir * H)[:, d * H:(d + 1) * H])
             if dcf is not None and d_final[d] is not None:
                 dcf[d, :B].copy_(d_final[d][0])
                 ops.gemm(d_final[d][1].contiguous(), wp, transB=True, out=dhf[d, :B])
-        dgates, dpeep = ops.lstm_bwd(dh, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H, ndir, ASR_F32,
+        dgates, dpeep = ops.lstm_bwd(dh, c['gates'], c['cs'], c['whb'], c['peep'], c['seq_len'], H, ndir, dt,
                                      dcf, dhf, want_dpeep=True, clip_no_grad=self.cell_clip or 0.0)
         dg2d = dgates.view(T * Bp, ndir * 4 * H)
         wx_cat = c['wx_cat']                                       # [din + P, ndir * 4H], dG's column order
@@ -386,13 +404,13 @@ class LSTMPLayer(object):
         fork = ops.stream_event()
         dx = None
         if need_dx:
-            dx = ops.gemm(dg2d, wx_cat[:din], transB=True).view(T, Bp, din)
+            dx = ops.gemm(dg2d, wx_cat[:din], transB=True, out_dtype=torch.float32).view(T, Bp, din)
             if Bp != B:
                 dx = dx[:, :B].contiguous()
         dw_il = torch.empty((ndir, din + P, 4 * H), dtype=torch.float32, device=dev)
         x2d = x.view(T * Bp, din)
         lo, hi = slice(0, (T - 1) * Bp), slice(Bp, T * Bp)
-        held = (x, m, hout, dout, dgates, dpeep, dw_il, wx_cat, c['hf']) + \
+        held = (x, m, hout, dout, dgates, dpeep, dw_il, wx_cat, c['hf']) + tuple(wps) + \
             tuple(t for f in (d_final or ()) if f is not None for t in f)
         done = []
         for d, b in enumerate(self.bases):
@@ -408,7 +426,7 @@ class LSTMPLayer(object):
                     # the step after frame t is frame t+1 (forward direction) / t-1 (backward); dG and h are zero at padded
                     # frames, so the shifted products need no mask
                     prev, nxt = (lo, hi) if d == 0 else (hi, lo)
-                    z = ops.gemm(dg, wx_cat[din:, d * 4 * H:(d + 1) * 4 * H], transB=True)   # Z = dG W_h^T  [T*Bp, P]
+                    z = ops.gemm(dg, wx_cat[din:, d * 4 * H:(d + 1) * 4 * H], transB=True)   # Z = dG W_h^T  [T*Bp, P] (operand dtype)
                     ops.gemm(md[prev], dg[nxt], transA=True, out=dw_il[d, din:])             # dW_h = m_prev^T dG
                     ops.gemm(hd[prev], z[nxt], transA=True, out=gp, accumulate=True)         # dW_p += h^T Z_next
                 else:

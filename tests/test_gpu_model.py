@@ -915,7 +915,7 @@ def test_projected_layer_fused_against_step_by_step_with_final_state_gradients(c
     from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
     from tensorflow_end2end_speech_recognition_amd import ops
     m = CTC(encoder_type='blstm' if ndir == 2 else 'lstm', input_size=D, num_units=H, num_layers=1, num_classes=7,
-            lstm_impl='LSTMCell', num_proj=P, parameter_init=0.2, clip_activation=clip, seed=3, device='cuda:0')
+            lstm_impl='LSTMCell', num_proj=P, parameter_init=0.2, clip_activation=clip, seed=3, dtype='f32', device='cuda:0')
     layer = m.encoder.layers[0]
     st = layer.store
     rng = np.random.RandomState(B + H)
@@ -954,6 +954,35 @@ def test_projected_layer_fused_against_step_by_step_with_final_state_gradients(c
         assert 0.02 < frac < 0.9, frac
         layer.ctx = None
     assert float(f['out'][:, -1].abs().max()) == 0 and float(f['dx'][:, -1].abs().max()) == 0   # the empty utterance
+
+
+@pytest.mark.parametrize('ndir,B,T,D,H,P,L', [(2, 16, 60, 24, 256, 128, 2), (2, 9, 41, 24, 128, 48, 2), (1, 16, 33, 24, 512, 256, 1),
+                                              (2, 16, 27, 24, 320, 160, 1)])
+def test_lstmcell_projection_layers_bf16_operands(cuda, monkeypatch, ndir, B, T, D, H, P, L):
+    """A bf16 model's projected layers: the bf16 recurrence kernels (the headline's clusters at 256 / 512 / 320, with the
+    gradient-blocking clip as their own instantiation) on W_p W_h rounded once, bf16 operands in every batched product, fp32 at
+    the layer boundaries.  Against the fp32 oracle at the bars the bf16 BLSTM models are held to (loss 2e-3, gradients a few
+    per cent of the largest entry), with an inactive and an ACTIVE clip; and it is the bf16 path that ran."""
+    import _config_parity as cp
+    from tensorflow_end2end_speech_recognition_amd.models.encoders.core import rnn_util
+    from tensorflow_end2end_speech_recognition_amd._lib import ASR_BF16
+    seen = []
+    orig = rnn_util.LSTMPLayer.operand_dtype
+    monkeypatch.setattr(rnn_util.LSTMPLayer, 'operand_dtype', lambda self: seen.append(orig(self)) or seen[-1])
+    r = cp.run_lstmp('cuda:0', B=B, T=T, D=D, H=H, P=P, L=L, C=9, ndir=ndir, dtype='bf16')
+    assert r['trained'] and seen and all(d == ASR_BF16 for d in seen)
+    if ndir == 2:
+        print('\n' + r['report'])
+        assert r['loss_rel'] < 2e-3 and r['logits_abs'] < 5e-2 and r['grad_worst'] < 6e-2, r['report']
+        rc = cp.run_lstmp('cuda:0', B=B, T=T, D=D, H=H, P=P, L=L, C=9, ndir=2, clip=0.15, dtype='bf16')
+        assert rc['loss_rel'] < 2e-3 and rc['grad_worst'] < 8e-2, rc['report']
+    # the A/B switch keeps fp32 operands
+    monkeypatch.setenv('ASR_LSTMP_BF16', '0')
+    del seen[:]
+    r32 = cp.run_lstmp('cuda:0', B=B, T=T, D=D, H=H, P=P, L=L, C=9, ndir=ndir, dtype='bf16')
+    assert seen and all(d != ASR_BF16 for d in seen)
+    if ndir == 2:
+        assert r32['loss_rel'] < 1e-4 and r32['grad_worst'] < 2e-3, r32['report']
 
 
 def test_gru_long_run_keeps_side_lane_bounded_and_survives_poisoned_allocator(cuda):

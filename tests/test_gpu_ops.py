@@ -348,9 +348,21 @@ def test_lstm_bwd_gradient_blocking_clip(cuda, T, B, D, H, ndir):
     for b in range(B):
         if lens[b] < T:
             assert np.abs(got['dgates'][lens[b]:, b]).max() == 0
-    # bf16 operands: refused, not silently straight-through
-    with pytest.raises(RuntimeError):
-        _run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', clip, dout, dfinal, clip_no_grad=clip)
+    # bf16 operands (the cluster kernels' CLIPZ instantiations at 256 / 320 / 512, the single-CU kernel elsewhere): the same
+    # mask -- the blocked gradient, not the straight-through one.  A state within bf16 rounding of the clip may fall on the other
+    # side in the bf16 forward, so the comparison is over the input gradient as a whole, at bf16's bar
+    lo = _run_hip_layer(cuda, x, ps, lens, H, ndir, 'bf16', clip, dout, dfinal, clip_no_grad=clip)
+    dxl = thru_dx(lo, ps, xt, T, B, D, H)
+    err_lo, err_thru = _rel(dxl, ref['dx']), _rel(thru_dx(thru, ps, xt, T, B, D, H), ref['dx'])
+    assert err_lo < 0.5 * err_thru and err_lo < 0.15, (err_lo, err_thru)
+
+
+def thru_dx(res, ps, xt, T, B, D, H):
+    dg = res['dgates'].astype(np.float64)
+    dx = np.zeros_like(xt)
+    for d, p in enumerate(ps):
+        dx += (dg[:, :, d * 4 * H:(d + 1) * 4 * H].reshape(T * B, 4 * H) @ p['w'].detach().numpy()[:D].T).reshape(T, B, D)
+    return dx
 
 
 @pytest.mark.parametrize('T,B,D,H,ndir', LSTM_SHAPES)
