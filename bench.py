@@ -32,7 +32,7 @@ and, at N = 1, the other BASELINE configurations timed with the same harness (a 
   decode                 greedy and prefix-beam CTC decode (TIMIT-61 width 20, kanji width 100) in utterances/s, the
                          oracle's restatement of the reference's numpy decoders timed beside them on one core;
   bgru                   the reference's GRU encoder family: bgru 2x256 CTC (fp32) on the headline batch;
-  blstmp                 the reference's projected cells (lstm_impl='LSTMCell', num_proj): blstm 5x256 proj 128 CTC (fp32)
+  blstmp                 the reference's projected cells (lstm_impl='LSTMCell', num_proj): blstm 5x256 proj 128 CTC (operand dtype of the headline)
                          on the headline batch;
   input_width_D39, batch_scaling   the headline model at the other input width / at B = 32 .. 128 per GPU.
 """
@@ -1295,7 +1295,7 @@ def main():
                 xb, slb, _, denseb = make_batch(wl['seed'], wl['batch'], wl['input_size'], wl['classes'] + 1, wl['tmin'], wl['tmax'])
                 xp_, sp_ = torch.tensor(xb, device=dev), torch.tensor(slb, device=dev)
                 mp_ = CTC('blstm', wl['input_size'], 256, 5, wl['classes'], lstm_impl='LSTMCell', num_proj=128, clip_grad_norm=5.0,
-                          clip_activation=50.0, seed=0, device=str(dev))
+                          clip_activation=50.0, seed=0, dtype=wl['dtype'], device=str(dev))
                 for _ in range(3):
                     lp_, _ = mp_.compute_loss(xp_, denseb, sp_, keep_prob=wl['keep_prob'])
                     mp_.train(lp_, 'rmsprop', 1e-3)
@@ -1306,9 +1306,9 @@ def main():
                     mp_.train(lp_, 'rmsprop', 1e-3)
                 torch.cuda.synchronize()
                 tp = (time.perf_counter() - tp0) / 10
-                out['blstmp'] = dict(workload='blstm 5x256 LSTMCell num_proj 128 CTC fp32 on the headline batch (B=%d, T<=%d), train step'
-                                     % (wl['batch'], wl['tmax']), value=float(slb.sum()) / tp, unit='frames/s', ms_per_step=tp * 1e3,
-                                     dtype='f32', steps=10, final_loss=float(lp_.item()), cluster_handoff_flags=ops_flags(dev_index))
+                out['blstmp'] = dict(workload='blstm 5x256 LSTMCell num_proj 128 CTC (%s operands) on the headline batch (B=%d, T<=%d), train step'
+                                     % (wl['dtype'], wl['batch'], wl['tmax']), value=float(slb.sum()) / tp, unit='frames/s', ms_per_step=tp * 1e3,
+                                     dtype=wl['dtype'], steps=10, final_loss=float(lp_.item()), cluster_handoff_flags=ops_flags(dev_index))
                 del mp_, xp_, sp_
             except Exception as e:
                 out['blstmp'] = dict(error=repr(e)[:400])

@@ -17,10 +17,10 @@ for enc, H, P, L, B in (('blstm', 256, 128, 5, 16), ('blstm', 320, 160, 3, 16), 
     x, sl, _, dense = bench.make_batch(1, B, 120, 62, 100, 778)
     xd, sd = torch.tensor(x, device=dev), torch.tensor(sl, device=dev)
     res = {}
-    for mode, steps in (('1', 10), ('0', 2)):
-        os.environ['ASR_LSTMP_FUSED'] = mode
+    for mode, steps in (('1', 10), ('0', 2), ('bf16', 10)):
+        os.environ['ASR_LSTMP_FUSED'] = '0' if mode == '0' else '1'
         m = CTC(enc, 120, H, L, 61, lstm_impl='LSTMCell', num_proj=P, clip_grad_norm=5.0, clip_activation=50.0, seed=0,
-                device=str(dev))
+                dtype='bf16' if mode == 'bf16' else 'f32', device=str(dev))
         loss, _ = m.compute_loss(xd, dense, sd, keep_prob=1.0)
         gv = m._set_optimizer('sgd', 0.1).compute_gradients(loss, model=m)
         grads = {v: g.detach().clone() for g, v in gv}
@@ -38,8 +38,12 @@ for enc, H, P, L, B in (('blstm', 256, 128, 5, 16), ('blstm', 320, 160, 3, 16), 
         del m
     worst = max(float((res['1'][2][k] - res['0'][2][k]).abs().max() / max(float(res['0'][2][k].abs().max()), 1e-30))
                 for k in res['0'][2])
+    worst16 = max(float((res['bf16'][2][k] - res['0'][2][k]).abs().max() / max(float(res['0'][2][k].abs().max()), 1e-30))
+                  for k in res['0'][2])
     print('%s %dx%d proj %d B=%d T=%d: fused %.2f ms/step (%.0f frames/s)  step-by-step %.1f ms/step  x%.1f   '
-          'loss %.6f / %.6f   worst gradient difference (relative to the largest entry) %.1e'
+          'loss %.6f / %.6f   worst gradient difference (relative to the largest entry) %.1e   |   bf16 operands: %.2f ms/step '
+          '(%.0f frames/s)  loss %.6f  worst gradient difference %.1e'
           % (enc, L, H, P, B, x.shape[1], res['1'][0] * 1e3, float(sl.sum()) / res['1'][0], res['0'][0] * 1e3,
-             res['0'][0] / res['1'][0], res['1'][1], res['0'][1], worst), flush=True)
+             res['0'][0] / res['1'][0], res['1'][1], res['0'][1], worst, res['bf16'][0] * 1e3, float(sl.sum()) / res['bf16'][0],
+             res['bf16'][1], worst16), flush=True)
 os.environ.pop('ASR_LSTMP_FUSED')

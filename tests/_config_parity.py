@@ -325,7 +325,7 @@ def run_bridges(device):
     return dict(fc_err=err, ok_zero=ok_zero, ok_pass=ok_pass, raised=raised)
 
 
-def run_lstmp(device, B, T, D, H, P, L, C, seed=41, ndir=2, clip=50.0, dtype='f32'):
+def run_lstmp(device, B, T, D, H, P, L, C, seed=41, ndir=2, clip=50.0, dtype='f32', init=0.2):
     """CTC(lstm_impl='LSTMCell', num_proj=P) -- tf.contrib.rnn.LSTMCell's projected cells (models/encoders/core/blstm.py:
     187-230) -- against oracle.model.lstmp_ctc_model_forward: loss, logits, every gradient (incl. projection/kernel),
     final states; then a few training steps."""
@@ -333,7 +333,7 @@ def run_lstmp(device, B, T, D, H, P, L, C, seed=41, ndir=2, clip=50.0, dtype='f3
     rng = np.random.RandomState(seed)
     x, sl, labs, dense = ctc_batch(rng, B, T, D, C, label_div=4)
     model = CTC(encoder_type='blstm' if ndir == 2 else 'lstm', input_size=D, num_units=H, num_layers=L, num_classes=C,
-                lstm_impl='LSTMCell', num_proj=P, parameter_init=0.2, clip_grad_norm=5.0, clip_activation=clip, dtype=dtype,
+                lstm_impl='LSTMCell', num_proj=P, parameter_init=init, clip_grad_norm=5.0, clip_activation=clip, dtype=dtype,
                 seed=9, device=device)
     sd = _randomise_biases(model, rng)
     assert any(k.endswith('/projection/kernel') for k in sd) and model.encoder.output_dim == ndir * P
