@@ -280,11 +280,13 @@ def cldnn_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, F,
 
 
 def lstmp_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, cell_clip=0.0, want_grads=True,
-                            dtype=torch.float64):
+                            dtype=torch.float64, vgg=None):
     """CTC(encoder_type='blstm', lstm_impl='LSTMCell', num_proj=P): stacked bidirectional projected LSTM cells
     (models/encoders/core/blstm.py:187-230, tf.contrib.rnn.LSTMCell(num_proj)) -> output FC on the [T,B,2P] outputs ->
     CTC.  Variables: blstm_hidden<i>/{fw,bw}/lstm_cell/{kernel [(Din+P),4H], bias, w_{i,f,o}_diag, projection/kernel
-    [H,P]}.  Returns dict(total_loss, ctc_losses, logits, grads, enc, final)."""
+    [H,P]}.  Returns dict(total_loss, ctc_losses, logits, grads, enc, final).
+    vgg = (F, W): the VGG front-end of ctc_model_forward in front of the projected stack (CTC(encoder_type='vgg_blstm',
+    lstm_impl='LSTMCell', num_proj=P): models/encoders/core/vgg_blstm.py:107-190 hands num_proj to the same cell builder)."""
     named = {}
 
     def t(name):
@@ -310,6 +312,10 @@ def lstmp_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ce
     w_out, b_out = t('output/weights'), t('output/biases')
     x = torch.as_tensor(np.asarray(inputs_btd), dtype=dtype)
     sl = torch.as_tensor(np.asarray(seq_len), dtype=torch.long)
+    if vgg is not None:
+        from . import vgg as ovgg
+        vgg_params = {k: t(k) for k in sd if k.startswith('VGG') or k.startswith('bridge/')}
+        x = ovgg.vgg_frontend(x, vgg_params, vgg[0], vgg[1])
     enc, final = olstm.blstmp_encoder(x, sl, layers, None, forget_bias=1.0, cell_clip=cell_clip, use_peephole=peep)
     T, B, E = enc.shape
     logits = (enc.reshape(T * B, E) @ w_out + b_out).reshape(T, B, -1)

@@ -127,7 +127,7 @@ class CTC(ModelBase):
                 input_size=input_size, splice=splice, num_stack=num_stack, num_units=num_units,
                 num_proj=self.num_proj, num_layers=num_layers, lstm_impl=lstm_impl,
                 use_peephole=use_peephole, parameter_init=parameter_init,
-                clip_activation=clip_activation, time_major=True, dtype=self.dtype)
+                clip_activation=clip_activation, time_major=True, dtype=self._requested_dtype)
         if encoder_type in ['bgru', 'gru']:              # ctc.py:150-155
             return load(encoder_type)(num_units=num_units, num_layers=num_layers, parameter_init=parameter_init,
                                       time_major=True)

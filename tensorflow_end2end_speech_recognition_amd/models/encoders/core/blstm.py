@@ -59,9 +59,10 @@ class _RecurrentEncoderBase(object):
                              '"LSTMBlockFusedCell" or "CudnnLSTM".')
         self.num_units = num_units
         self.num_proj = num_proj if lstm_impl == 'LSTMCell' else None
-        if self.num_proj is not None and type(self).__name__ not in ('BLSTMEncoder', 'LSTMEncoder'):
-            raise ValueError('LSTMCell projection layers (num_proj) are implemented for the plain blstm / lstm '
-                             'encoders only, not for %s' % type(self).__name__)
+        if self.num_proj is not None and type(self).__name__ not in ('BLSTMEncoder', 'LSTMEncoder', 'VGGBLSTMEncoder',
+                                                                     'VGGLSTMEncoder'):
+            raise ValueError('LSTMCell projection layers (num_proj) are implemented for the blstm / lstm / vgg_blstm / '
+                             'vgg_lstm encoders, not for %s' % type(self).__name__)
         self.num_layers = num_layers
         self.lstm_impl = lstm_impl
         self.use_peephole = bool(use_peephole) and lstm_impl != 'BasicLSTMCell'

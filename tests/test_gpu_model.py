@@ -990,6 +990,22 @@ def test_lstmcell_projection_layers_bf16_operands(cuda, monkeypatch, ndir, B, T,
         assert r32['loss_rel'] < 1e-4 and r32['grad_worst'] < 2e-3, r32['report']
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_vgg_front_end_over_projected_cells(cuda, dtype):
+    """CTC(encoder_type='vgg_blstm', lstm_impl='LSTMCell', num_proj): the reference hands num_proj of the VGG encoders to the
+    same cell builder (models/encoders/core/vgg_blstm.py:107-190 -> blstm.py:187-230).  The front-end in the model's operand
+    dtype, the projected stack behind it on the whole-sequence kernels: loss, logits and every gradient (filters, bridge,
+    kernels, projection/kernel) against the oracle's composition of the two; fp32 at the fp32 bars, bf16 at the bf16 models'."""
+    import _config_parity as cp
+    r = cp.run_vgg_lstmp('cuda:0', B=6, T=24, F=16, W=5, H=128, P=48, L=2, C=9, dtype=dtype, init=0.1 if dtype == 'f32' else 0.06)
+    print('\n' + r['report'])
+    assert r['finite']
+    if dtype == 'f32':
+        assert r['loss_rel'] < 1e-4 and r['logits_abs'] < 5e-4 and r['grad_worst'] < 5e-3, r['report']
+    else:
+        assert r['loss_rel'] < 2e-3 and r['logits_abs'] < 5e-2 and r['grad_worst'] < 0.12, r['report']
+
+
 def test_gru_long_run_keeps_side_lane_bounded_and_survives_poisoned_allocator(cuda):
     """Two regressions of the GRU encoders found in review: (1) the model's head gradients are issued on side lane 1 and
     must be joined (ordered before clip / update, and the lane's keep list released) by the encoder's backward -- 60
