@@ -138,7 +138,7 @@ def ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir=2, 
 
 def multitask_ctc_model_forward(sd, inputs_btd, labels_main, labels_sub, seq_len, num_layers_main, num_layers_sub,
                                 main_task_weight, ndir=2, cell_clip=0.0, weight_decay=0.0, bottleneck=False,
-                                dtype=torch.float64):
+                                dtype=torch.float64, proj=False):
     """models/ctc/multitask_ctc.py:100-312: one encoder, the sub head ('output_sub') on the outputs of layer
     num_layers_sub (models/encoders/core/blstm.py:326-328), the main head ('output_main', behind 'bottleneck' if
     present) on the top layer; total = w * mean CTC(main) + (1 - w) * mean CTC(sub) (+ weight decay).
@@ -154,6 +154,12 @@ def multitask_ctc_model_forward(sd, inputs_btd, labels_main, labels_sub, seq_len
     peep = layers[0][0]['_peep'] if ndir == 2 else layers[0]['_peep']
     kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=peep)
     run = olstm.blstm_encoder if ndir == 2 else olstm.lstm_encoder
+    if proj:   # lstm_impl='LSTMCell' + num_proj (multitask_blstm.py:95 hands it to the cell builder; bidirectional here)
+        assert ndir == 2
+        for layer in layers:
+            for p in layer:
+                p['w_proj'] = t(p['_base'] + '/projection/kernel')
+        run = olstm.blstmp_encoder
     enc, _ = run(x, sl, layers, None, **kw)
     # the lower layers evaluated again with the SAME parameter tensors: identical values, and autograd adds the
     # two paths' gradients exactly as the shared graph of the reference does
@@ -179,6 +185,8 @@ def multitask_ctc_model_forward(sd, inputs_btd, labels_main, labels_sub, seq_len
             if p['_peep']:
                 named[base + '/w_i_diag'], named[base + '/w_f_diag'], named[base + '/w_o_diag'] = \
                     p['wci'], p['wcf'], p['wco']
+            if proj:
+                named[base + '/projection/kernel'] = p['w_proj']
     named.update(heads)
     if weight_decay > 0:
         total = total + weight_decay * sum(0.5 * (v ** 2).sum() for n, v in named.items() if 'bias' not in n.lower())

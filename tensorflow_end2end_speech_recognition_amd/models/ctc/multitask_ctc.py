@@ -48,7 +48,8 @@ class MultitaskCTC(CTC):
         return load(encoder_type)(                                          # multitask_ctc.py:87-96
             num_units=num_units, num_proj=self.num_proj, num_layers_main=num_layers,
             num_layers_sub=self.num_layers_sub, lstm_impl=lstm_impl, use_peephole=use_peephole,
-            parameter_init=parameter_init, clip_activation=clip_activation, time_major=True, dtype=self.dtype)
+            parameter_init=parameter_init, clip_activation=clip_activation, time_major=True,
+            dtype=self._requested_dtype)
 
     def _declare_heads(self, rng, enc_dim, parameter_init):
         # creation order of the reference graph: output_sub (:150-158), bottleneck (:173-181), output_main (:186-194)

@@ -60,9 +60,10 @@ class _RecurrentEncoderBase(object):
         self.num_units = num_units
         self.num_proj = num_proj if lstm_impl == 'LSTMCell' else None
         if self.num_proj is not None and type(self).__name__ not in ('BLSTMEncoder', 'LSTMEncoder', 'VGGBLSTMEncoder',
-                                                                     'VGGLSTMEncoder'):
-            raise ValueError('LSTMCell projection layers (num_proj) are implemented for the blstm / lstm / vgg_blstm / '
-                             'vgg_lstm encoders, not for %s' % type(self).__name__)
+                                                                     'VGGLSTMEncoder', 'MultitaskBLSTMEncoder',
+                                                                     'MultitaskLSTMEncoder'):
+            raise ValueError('LSTMCell projection layers (num_proj) are implemented for the blstm / lstm / vgg_* / '
+                             'multitask_* encoders, not for %s' % type(self).__name__)
         self.num_layers = num_layers
         self.lstm_impl = lstm_impl
         self.use_peephole = bool(use_peephole) and lstm_impl != 'BasicLSTMCell'
@@ -292,11 +293,13 @@ class _RecurrentEncoderBase(object):
         self._finals = finals
         self._final_ch = None
         out_user = x if self.time_major else x.transpose(0, 1)
+        return out_user, self._state_tuple_projected(finals, len(finals))
+
+    def _state_tuple_projected(self, finals, upto):
+        """_state_tuple for the projected stack: finals[li] = per direction (c [B,H], m [B,P])."""
         if self.ndir == 2:
-            final_state = tuple(LSTMStateTuple(c, m) for c, m in finals[-1])
-        else:
-            final_state = tuple(LSTMStateTuple(*f[0]) for f in finals)
-        return out_user, final_state
+            return tuple(LSTMStateTuple(c, m) for c, m in finals[upto - 1])
+        return tuple(LSTMStateTuple(*f[0]) for f in finals[:upto])
 
     def _state_tuple(self, finals, upto):
         """The reference's final_state: bidirectional_dynamic_rnn of the LAST layer -> (LSTMStateTuple fw,
@@ -315,6 +318,8 @@ class _RecurrentEncoderBase(object):
         if self.num_proj is not None:
             dx = d_outputs
             for li in reversed(range(len(self.layers))):
+                if d_outputs_sub is not None and li == self.num_layers_sub - 1:
+                    dx = torch.add(dx, d_outputs_sub)            # the sub-task head's gradient joins where it branched off
                 dx = self.layers[li].backward(dx.contiguous(), None, need_dx=(li > 0 or need_input_grad))
                 if self.grad_ready_hook is not None:
                     self.grad_ready_hook(li, self.layers[li])

@@ -27,7 +27,8 @@ class _MultitaskMixin(object):
         B = self.batch
         sub = self._out_sub_op
         self._out_sub_tm = ops.cast_to_f32(sub) if sub.dtype != torch.float32 else sub
-        final_sub = self._state_tuple(self._finals, self.num_layers_sub)
+        final_sub = self._state_tuple_projected(self._finals, self.num_layers_sub) if self.num_proj is not None \
+            else self._state_tuple(self._finals, self.num_layers_sub)
         out_sub = self._out_sub_tm[:, :B]
         if not self.time_major:
             out_sub = out_sub.transpose(0, 1)
