@@ -235,7 +235,7 @@ def gru_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ndir
 
 
 def cldnn_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, F, W, cell_clip=0.0, want_grads=True,
-                            dtype=torch.float64, operand_round=None):
+                            dtype=torch.float64, operand_round=None, proj=False):
     """CTC(encoder_type='cldnn_wang'): conv stack -> BLSTM stack -> fc1 relu -> fc2 relu -> output FC -> CTC
     (models/encoders/core/cldnn_wang.py:134-249, models/ctc/ctc.py:135-147).  No dropout.
     operand_round: the rounding points of the bf16-operand device path (inputs, every matrix operand, every stored
@@ -265,7 +265,14 @@ def cldnn_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, F,
     kw = dict(forget_bias=1.0, cell_clip=cell_clip, use_peephole=layers[0][0]['_peep'])
     if operand_round is not None:
         kw['h_round'] = operand_round
-    enc, final = olstm.blstm_encoder(feat, sl, layers, None, **kw)
+    if proj:   # lstm_impl='LSTMCell' + num_proj (cldnn_wang.py:202 hands it to the cell builder of blstm.py:187-230)
+        assert operand_round is None
+        for layer in layers:
+            for p in layer:
+                p['w_proj'] = t(p['_base'] + '/projection/kernel')
+        enc, final = olstm.blstmp_encoder(feat, sl, layers, None, **kw)
+    else:
+        enc, final = olstm.blstm_encoder(feat, sl, layers, None, **kw)
     T, B, E = enc.shape
     a1 = rnd(torch.relu(enc.reshape(T * B, E) @ t('fc1/weights') + t('fc1/biases')))
     a2 = rnd(torch.relu(a1 @ t('fc2/weights') + t('fc2/biases')))

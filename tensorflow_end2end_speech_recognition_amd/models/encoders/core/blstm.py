@@ -61,9 +61,9 @@ class _RecurrentEncoderBase(object):
         self.num_proj = num_proj if lstm_impl == 'LSTMCell' else None
         if self.num_proj is not None and type(self).__name__ not in ('BLSTMEncoder', 'LSTMEncoder', 'VGGBLSTMEncoder',
                                                                      'VGGLSTMEncoder', 'MultitaskBLSTMEncoder',
-                                                                     'MultitaskLSTMEncoder'):
+                                                                     'MultitaskLSTMEncoder', 'CLDNNEncoder'):
             raise ValueError('LSTMCell projection layers (num_proj) are implemented for the blstm / lstm / vgg_* / '
-                             'multitask_* encoders, not for %s' % type(self).__name__)
+                             'multitask_* / cldnn_wang encoders, not for %s' % type(self).__name__)
         self.num_layers = num_layers
         self.lstm_impl = lstm_impl
         self.use_peephole = bool(use_peephole) and lstm_impl != 'BasicLSTMCell'

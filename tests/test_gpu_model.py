@@ -408,8 +408,8 @@ def test_gru_ctc_model_loss_grads_and_step(cuda, gru_mode, enc, B, T, D, H, L, C
     assert l.item() < 0.9 * l0
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-def test_cldnn_ctc_model_parity(cuda, dtype):
+@pytest.mark.parametrize('dtype,proj', [('f32', None), ('bf16', None), ('f32', 40)])
+def test_cldnn_ctc_model_parity(cuda, dtype, proj):
     """CTC(encoder_type='cldnn_wang') on the device: the three strided SAME convolutions (asr_im2col + MFMA GEMM with
     fused bias + ReLU, gradients through asr_col2im), the BLSTM stack, fc1 / fc2 -- against the oracle
     (oracle/cldnn.py): loss, logits and every gradient in fp32; the bf16 operand path against the oracle evaluated with
@@ -425,14 +425,15 @@ def test_cldnn_ctc_model_parity(cuda, dtype):
     cldnn_wang.CHUNK_FRAMES = 24                              # several chunks of frames, the last one partial
     try:
         model = CTC(encoder_type='cldnn_wang', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
-                    parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype=dtype, seed=4)
+                    parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype=dtype, seed=4,
+                    **(dict(lstm_impl='LSTMCell', num_proj=proj) if proj else {}))    # (cldnn_wang.py:202 passes num_proj on)
         sd = {k: v.cpu().numpy() for k, v in model.store.state_dict().items()}
         for k in sd:
             if k.endswith('/bias') or k.endswith('/biases'):
                 sd[k] = (rng.randn(*sd[k].shape) * 0.05 + 0.02).astype(np.float32)
         model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
         from oracle import lstm as olstm
-        ref = omodel.cldnn_ctc_model_forward(sd, x, labs, sl, L, F, W, cell_clip=50.0,
+        ref = omodel.cldnn_ctc_model_forward(sd, x, labs, sl, L, F, W, cell_clip=50.0, proj=bool(proj),
                                              operand_round=olstm.bf16_round_t if dtype == 'bf16' else None)
         loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
         tol_l, tol_g = (1e-4, 2e-3) if dtype == 'f32' else (2e-3, 5e-2)   # bf16: measured up to 3.2e-2 (one-step bf16 flips of stored activations)

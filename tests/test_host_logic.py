@@ -115,10 +115,11 @@ def test_gru_ctc_model_host_logic(monkeypatch, enc, L):
     assert loss2.item() < loss.item()
 
 
-def test_cldnn_ctc_model_host_logic(monkeypatch):
+@pytest.mark.parametrize('proj', [None, 5])
+def test_cldnn_ctc_model_host_logic(monkeypatch, proj):
     """CTC(encoder_type='cldnn_wang') (models/encoders/core/cldnn_wang.py) on the CPU stand-ins against the oracle:
     the three strided SAME convolutions as im2col + GEMM (chunked over frames), the BLSTM stack on their flattened
-    output, fc1 / fc2, and every gradient back through col2im."""
+    output, fc1 / fc2, and every gradient back through col2im.  proj: lstm_impl='LSTMCell' with num_proj (cldnn_wang.py:202)."""
     _cpu_ops.install(monkeypatch)
     from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
     from tensorflow_end2end_speech_recognition_amd.models.encoders.core import cldnn_wang
@@ -128,16 +129,17 @@ def test_cldnn_ctc_model_host_logic(monkeypatch):
     D = F * W * 3
     x, sl, labs, dense = _batch(rng, B, T, D, C, div=3)
     model = CTC(encoder_type='cldnn_wang', input_size=3 * F, splice=W, num_units=H, num_layers=L, num_classes=C,
-                parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='f32', seed=4, device='cpu')
+                parameter_init=0.1, clip_grad_norm=5.0, clip_activation=50, dtype='f32', seed=4, device='cpu',
+                **(dict(lstm_impl='LSTMCell', num_proj=proj) if proj else {}))
     sd = {k: v.numpy().copy() for k, v in model.store.state_dict().items()}
     assert sd['CNN1/conv/weight'].shape == (11, 21, 3, 32) and sd['CNN2/conv/weight'].shape == (11, 11, 32, 32)
-    assert sd['CNN3/conv/weight'].shape == (3, 3, 32, 96) and sd['fc1/weights'].shape == (2 * H, 896)
+    assert sd['CNN3/conv/weight'].shape == (3, 3, 32, 96) and sd['fc1/weights'].shape == (2 * (proj or H), 896)
     assert sd['fc2/weights'].shape == (896, 74) and sd['output/weights'].shape == (74, C + 1)
     for k in sd:
         if k.endswith('/bias') or k.endswith('/biases'):
             sd[k] = (rng.randn(*sd[k].shape) * 0.05 + 0.02).astype(np.float32)
     model.store.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
-    ref = omodel.cldnn_ctc_model_forward(sd, x, labs, sl, L, F, W, cell_clip=50.0)
+    ref = omodel.cldnn_ctc_model_forward(sd, x, labs, sl, L, F, W, cell_clip=50.0, proj=bool(proj))
     loss, logits = model.compute_loss(x, dense, sl, keep_prob=1.0)
     assert abs(loss.item() - ref['total_loss']) / abs(ref['total_loss']) < 1e-5
     assert np.abs(logits.numpy() - ref['logits']).max() < 1e-5
@@ -983,9 +985,6 @@ def test_lstmcell_projection_host_logic(monkeypatch, ndir, fused):
     else:
         assert 'multi_lstm/multi_rnn_cell/cell_1/lstm_cell/projection/kernel' in r['names']
     from tensorflow_end2end_speech_recognition_amd.models.ctc.ctc import CTC
-    with pytest.raises(ValueError):    # (the CLDNN encoder: not built)
-        CTC(encoder_type='cldnn_wang', input_size=24, splice=5, num_units=8, num_layers=1, num_classes=5,
-            lstm_impl='LSTMCell', num_proj=4, device='cpu')
     if ndir == 2:   # the VGG front-end in front of the projected cells (vgg_blstm.py:107-190 passes num_proj on)
         rv = cp.run_vgg_lstmp('cpu', B=3, T=7, F=4, W=3, H=8, P=5, L=1, C=6)
         assert rv['loss_rel'] < 1e-5 and rv['grad_worst'] < 2e-4 and rv['finite'], rv['report']
