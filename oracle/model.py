@@ -295,7 +295,7 @@ def cldnn_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, F,
 
 
 def lstmp_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, cell_clip=0.0, want_grads=True,
-                            dtype=torch.float64, vgg=None):
+                            dtype=torch.float64, vgg=None, weight_decay=0.0):
     """CTC(encoder_type='blstm', lstm_impl='LSTMCell', num_proj=P): stacked bidirectional projected LSTM cells
     (models/encoders/core/blstm.py:187-230, tf.contrib.rnn.LSTMCell(num_proj)) -> output FC on the [T,B,2P] outputs ->
     CTC.  Variables: blstm_hidden<i>/{fw,bw}/lstm_cell/{kernel [(Din+P),4H], bias, w_{i,f,o}_diag, projection/kernel
@@ -336,6 +336,8 @@ def lstmp_ctc_model_forward(sd, inputs_btd, labels_list, seq_len, num_layers, ce
     logits = (enc.reshape(T * B, E) @ w_out + b_out).reshape(T, B, -1)
     losses = ctc_loss(logits, labels_list, seq_len)
     total = losses.mean()
+    if weight_decay > 0:   # models/ctc/ctc.py:280-286: every variable without 'bias' in its name
+        total = total + weight_decay * sum(0.5 * (v ** 2).sum() for n, v in named.items() if 'bias' not in n.lower())
     grads = None
     if want_grads:
         total.backward()

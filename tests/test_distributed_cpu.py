@@ -4,6 +4,7 @@ np.array_split shard rule of utils/dataset/ctc.py:171-182."""
 import os
 import socket
 
+import pytest
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -105,7 +106,8 @@ def _recipe_worker(rank, world, port, cfg_path, save_path, q):
     dist.destroy_process_group()
 
 
-def test_librispeech_recipe_data_parallel_world2(tmp_path):
+@pytest.mark.parametrize('proj', [0, 4])
+def test_librispeech_recipe_data_parallel_world2(tmp_path, proj):
     """examples/librispeech/training/train_ctc.py under two gloo ranks (kernel front end = CPU stand-ins):
     replicas stay bit-identical, rank 0 owns the run directory, and the parameters after the run equal the
     reference's tower loop (train_ctc.py:82-147) replayed with the oracle on the same global batches: per-tower
@@ -128,6 +130,8 @@ def test_librispeech_recipe_data_parallel_world2(tmp_path):
     P.update(input_size=6, num_stack=1, num_skip=1, num_units=8, num_layers=1, batch_size=3, num_epoch=2,
              eval_start_epoch=1, print_step=4, learning_rate=0.02, dropout=0.0, weight_decay=1e-3, clip_grad_norm=0.5,
              dtype='f32', device='cpu', dataset_root=corpus, sort_stop_epoch=1, seed=4)
+    if proj:   # the projected cells (lstm_impl 'LSTMCell' + num_proj): per-layer gradient events and names of another layer class
+        P.update(lstm_impl='LSTMCell', num_proj=proj)
     cfg_path = str(tmp_path / 'cfg.yml')
     with open(cfg_path, 'w') as f:
         yaml.safe_dump(cfg, f)
@@ -180,8 +184,11 @@ def test_librispeech_recipe_data_parallel_world2(tmp_path):
                 towers.append([np.zeros_like(sd[n]) for n in sd])       # multi_gpu.tower_step; TF would fail here)
                 continue
             labs = [[int(v) for v in row if v >= 0] for row in labels[g]]
-            ref = omodel.ctc_model_forward(sd, inputs[g], labs, seq_len[g], 1, ndir=2, cell_clip=50.0,
-                                           weight_decay=1e-3)
+            if proj:
+                ref = omodel.lstmp_ctc_model_forward(sd, inputs[g], labs, seq_len[g], 1, cell_clip=50.0, weight_decay=1e-3)
+            else:
+                ref = omodel.ctc_model_forward(sd, inputs[g], labs, seq_len[g], 1, ndir=2, cell_clip=50.0,
+                                               weight_decay=1e-3)
             towers.append([oopt.clip_by_norm(ref['grads'][n], 0.5) for n in sd])
         avg = oopt.average_gradients(towers)
         for n, g in zip(list(sd), avg):
