@@ -19,3 +19,5 @@ for it in range(int(os.environ.get('STEPS', '8'))):
     m.train(loss, 'rmsprop', 1e-3)
 torch.cuda.synchronize()
 print('loss %.4f' % loss.item())
+from tensorflow_end2end_speech_recognition_amd import ops  # noqa: E402
+print('cluster hand-off flags', ops.check_async_errors(0))
